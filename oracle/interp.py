@@ -1,0 +1,201 @@
+"""Oracle: control-path construction and evaluation (CPU, torch eager).  TEST INFRASTRUCTURE.
+
+Restates, operation-for-operation (so that float results are bit-identical to
+the reference on CPU), the interpolation half of the hot path:
+
+  check_path                 <- torchcde/misc.py:70-100            (validate_input_path)
+  linear_coeffs              <- torchcde/interpolation_linear.py:131-171 (no-NaN, non-rectilinear path)
+  hermite_bdiff_coeffs       <- torchcde/interpolation_hermite_cubic_bdiff.py:5-44
+  locate                     <- torchcde/interpolation_cubic.py:315-322  (== interpolation_linear.py:203-210)
+  cubic_value / cubic_slope  <- torchcde/interpolation_cubic.py:324-336
+  linear_value / linear_slope<- torchcde/interpolation_linear.py:212-225
+  CubicPath / LinearPath     <- the nn.Module shells (:282-313 / :177-201) so that
+                                oracle.cde can drive them exactly as the reference does.
+
+PINNED against the imported reference by oracle/make_golden.py (bitwise) and by
+tests/test_oracle.py (golden fixtures + the closed-form unit-time Hermite of the
+reference's test/test_hermite_cubic.py:6-21).
+"""
+import math
+
+import torch
+
+
+# ----------------------------------------------------------------------------- validation
+def check_path(x, t):
+    """misc.py:70-100.  Returns the (possibly defaulted) knot vector."""
+    if not x.is_floating_point():
+        raise ValueError("X must both be floating point.")
+    if x.ndimension() < 2:
+        raise ValueError("X must have at least two dimensions, corresponding to time and channels. It instead has "
+                         "shape {}.".format(tuple(x.shape)))
+    length = x.size(-2)
+    if t is None:
+        t = torch.linspace(0, length - 1, length, dtype=x.dtype, device=x.device)
+    if not t.is_floating_point():
+        raise ValueError("t must both be floating point.")
+    if t.dim() != 1:
+        raise ValueError("t must be one dimensional. It instead has shape {}.".format(tuple(t.shape)))
+    last = -math.inf
+    for value in t.tolist():
+        if value <= last:
+            raise ValueError("t must be monotonically increasing.")
+        last = value
+    if length != t.size(0):
+        raise ValueError("The time dimension of X must equal the length of t. X has shape {} and t has shape {}, "
+                         "corresponding to time dimensions of {} and {} respectively."
+                         .format(tuple(x.shape), tuple(t.shape), length, t.size(0)))
+    if t.size(0) < 2:
+        raise ValueError("Must have a time dimension of size at least 2. It instead has shape {}, corresponding to a "
+                         "time dimension of size {}.".format(tuple(t.shape), t.size(0)))
+    return t
+
+
+def linear_coeffs(x, t=None):
+    """interpolation_linear.py:131-171, restricted to the path the north star names:
+    no rectilinear preparation, no missing values (the reference then returns ``x`` itself)."""
+    check_path(x, t)
+    if torch.isnan(x).any():
+        raise NotImplementedError("oracle: NaN-fill path is outside the hot-path scope (SURVEY 8(f) rank 2)")
+    return x
+
+
+# ----------------------------------------------------------------------------- Hermite fit
+def hermite_bdiff_coeffs(x, t=None):
+    """interpolation_hermite_cubic_bdiff.py:23-44 + :5-20.
+
+    Output (..., L-1, 4C) = [a | b | 2c | 3d] per interval.  The arithmetic below keeps
+    the reference's association order: every intermediate is the same float.
+    """
+    knots_in = linear_coeffs(x, t)
+    if t is None:
+        t = torch.linspace(0, knots_in.size(-2) - 1, knots_in.size(-2), dtype=knots_in.dtype, device=knots_in.device)
+    left = knots_in[..., :-1, :]
+    right = knots_in[..., 1:, :]
+    h = (t[1:] - t[:-1]).unsqueeze(-1)
+    # secant slope on each interval (:39)
+    secant = (right - left) / h
+    # knot derivative entering each interval = slope of the interval before it; the
+    # first interval re-uses its own slope (:10)
+    enter = torch.cat((secant[..., [0], :], secant[..., :-1, :]), dim=-2)
+    rise = right - left
+    a = left
+    b = enter
+    two_c = 2 * (3 * (rise / h - b) - secant + enter) / h          # :17
+    three_d = (1 / h ** 2) * (secant - b) - (two_c) / h            # :18
+    return torch.cat([a, b, two_c, three_d], dim=-1)
+
+
+# ----------------------------------------------------------------------------- lookup
+def locate(t, knots, n_intervals, dtype, device):
+    """interpolation_cubic.py:315-322.  Returns (frac, index[int64]).
+
+    ``bucketize`` with right=False: a query exactly on knot k lands in interval k-1
+    with frac == knot spacing; clamped to [0, n_intervals-1], extrapolating outside."""
+    t = torch.as_tensor(t, dtype=dtype, device=device)
+    index = torch.bucketize(t.detach(), knots.detach()).sub(1).clamp(0, n_intervals - 1)
+    frac = t - knots[index]
+    return frac, index
+
+
+def cubic_value(coeffs, knots, t):
+    """interpolation_cubic.py:324-329 on the packed coefficient tensor."""
+    C = coeffs.size(-1) // 4
+    a, b, two_c, three_d = (coeffs[..., :C], coeffs[..., C:2 * C], coeffs[..., 2 * C:3 * C], coeffs[..., 3 * C:])
+    frac, index = locate(t, knots, coeffs.size(-2), coeffs.dtype, coeffs.device)
+    frac = frac.unsqueeze(-1)
+    inner = 0.5 * two_c[..., index, :] + three_d[..., index, :] * frac / 3
+    inner = b[..., index, :] + inner * frac
+    return a[..., index, :] + inner * frac
+
+
+def cubic_slope(coeffs, knots, t):
+    """interpolation_cubic.py:331-336."""
+    C = coeffs.size(-1) // 4
+    b, two_c, three_d = (coeffs[..., C:2 * C], coeffs[..., 2 * C:3 * C], coeffs[..., 3 * C:])
+    frac, index = locate(t, knots, coeffs.size(-2), coeffs.dtype, coeffs.device)
+    frac = frac.unsqueeze(-1)
+    inner = two_c[..., index, :] + three_d[..., index, :] * frac
+    return b[..., index, :] + inner * frac
+
+
+def linear_slopes(coeffs, knots):
+    """interpolation_linear.py:189 (constructor pre-computation)."""
+    return (coeffs[..., 1:, :] - coeffs[..., :-1, :]) / (knots[1:] - knots[:-1]).unsqueeze(-1)
+
+
+def linear_value(coeffs, knots, t):
+    """interpolation_linear.py:212-220."""
+    frac, index = locate(t, knots, coeffs.size(-2) - 1, coeffs.dtype, coeffs.device)
+    frac = frac.unsqueeze(-1)
+    lo = coeffs[..., index, :]
+    hi = coeffs[..., index + 1, :]
+    width = knots[index + 1] - knots[index]
+    return lo + frac * (hi - lo) / width.unsqueeze(-1)
+
+
+def linear_slope(coeffs, knots, t):
+    """interpolation_linear.py:222-225."""
+    _, index = locate(t, knots, coeffs.size(-2) - 1, coeffs.dtype, coeffs.device)
+    return linear_slopes(coeffs, knots)[..., index, :]
+
+
+# ----------------------------------------------------------------------------- module shells
+class CubicPath(torch.nn.Module):
+    """interpolation_cubic.py:282-336 as a thin nn.Module over the functions above."""
+
+    def __init__(self, coeffs, t=None):
+        super().__init__()
+        if t is None:
+            t = torch.linspace(0, coeffs.size(-2), coeffs.size(-2) + 1, dtype=coeffs.dtype, device=coeffs.device)
+        if (coeffs.size(-1) // 4) * 4 != coeffs.size(-1):
+            raise ValueError("Passed invalid coeffs.")
+        self.register_buffer("_t", t)
+        self.register_buffer("_coeffs", coeffs)
+
+    @property
+    def grid_points(self):
+        return self._t
+
+    @property
+    def interval(self):
+        return torch.stack([self._t[0], self._t[-1]])
+
+    def _interpret_t(self, t):
+        return locate(t, self._t, self._coeffs.size(-2), self._coeffs.dtype, self._coeffs.device)
+
+    def evaluate(self, t):
+        return cubic_value(self._coeffs, self._t, t)
+
+    def derivative(self, t):
+        return cubic_slope(self._coeffs, self._t, t)
+
+
+class LinearPath(torch.nn.Module):
+    """interpolation_linear.py:177-225."""
+
+    def __init__(self, coeffs, t=None):
+        super().__init__()
+        if t is None:
+            t = torch.linspace(0, coeffs.size(-2) - 1, coeffs.size(-2), dtype=coeffs.dtype, device=coeffs.device)
+        self.register_buffer("_t", t)
+        self.register_buffer("_coeffs", coeffs)
+        self.register_buffer("_derivs", linear_slopes(coeffs, t))
+
+    @property
+    def grid_points(self):
+        return self._t
+
+    @property
+    def interval(self):
+        return torch.stack([self._t[0], self._t[-1]])
+
+    def _interpret_t(self, t):
+        return locate(t, self._t, self._derivs.size(-2), self._derivs.dtype, self._derivs.device)
+
+    def evaluate(self, t):
+        return linear_value(self._coeffs, self._t, t)
+
+    def derivative(self, t):
+        _, index = self._interpret_t(t)
+        return self._derivs[..., index, :]

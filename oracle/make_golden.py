@@ -1,0 +1,215 @@
+"""Generate tests/golden/*.pt from the REAL reference (run in the build container only).
+
+    python oracle/make_golden.py                        # (re)write the fixtures + bitwise self-check
+    python oracle/make_golden.py --run-reference-tests  # additionally run the reference's own pytest files
+
+/root/reference is imported read-only.  Its ``torchcde/__init__.py:7`` imports
+``solver.py``, which imports ``torchdiffeq`` and ``torchsde`` (solver.py:2-3); neither is
+installed, so before importing we register ``oracle.odeint`` as ``torchdiffeq`` and an
+empty module as ``torchsde``.  Consequences, stated once:
+
+  * interpolation fixtures (hermite / spline / linear) are produced by reference code only
+    -> they PIN ``oracle.interp`` (this script also asserts bitwise equality oracle vs reference);
+  * ``cdeint`` fixtures are produced by the reference's real ``solver.py`` (vector field,
+    defaults, permute) driving ``oracle.odeint`` -> they pin ``oracle.cde`` and the plumbing, but
+    the integrator arithmetic itself stays PARITY UNPINNED (see oracle/odeint.py).
+
+Nothing here runs on the GPU box (no /root/reference there); tests read only the .pt files.
+"""
+import argparse
+import os
+import sys
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REFERENCE = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def import_reference():
+    from oracle import odeint as oracle_ode
+    shim = types.ModuleType("torchdiffeq")
+    shim.odeint = oracle_ode.odeint
+    shim.odeint_adjoint = oracle_ode.odeint_adjoint
+    sys.modules["torchdiffeq"] = shim
+    sys.modules["torchsde"] = types.ModuleType("torchsde")
+    sys.path.insert(0, REFERENCE)
+    import torchcde
+    assert os.path.realpath(torchcde.__file__).startswith(REFERENCE)
+    return torchcde
+
+
+def _irregular_t(L, dtype, gen):
+    gaps = torch.rand(L, generator=gen, dtype=torch.float64) * 1.5 + 0.1
+    return gaps.cumsum(0).to(dtype)
+
+
+def _query_times(knots, gen):
+    lo, hi = knots[0].item(), knots[-1].item()
+    inside = torch.rand(9, generator=gen, dtype=torch.float64) * (hi - lo) + lo
+    extra = torch.tensor([lo - 0.7, lo, hi, hi + 1.3], dtype=torch.float64)
+    on_knots = knots[: min(4, len(knots))].to(torch.float64)
+    return torch.cat([inside, extra, on_knots]).to(knots.dtype)
+
+
+def interpolation_cases(ref):
+    from oracle import interp
+    gen = torch.Generator().manual_seed(20240925)
+    cases = []
+    shapes = [((1,), 2, 1), ((3,), 5, 3), ((2, 3), 10, 6), ((4,), 16, 8), ((), 7, 2), ((5,), 128, 8)]
+    for dtype in (torch.float32, torch.float64):
+        for batch, L, C in shapes:
+            for explicit_t in (False, True):
+                x = torch.randn(*batch, L, C, generator=gen, dtype=dtype)
+                t = _irregular_t(L, dtype, gen) if explicit_t else None
+                coeffs = ref.hermite_cubic_coefficients_with_backward_differences(x, t)
+                assert torch.equal(coeffs, interp.hermite_bdiff_coeffs(x, t)), "oracle hermite != reference"
+                spline = ref.CubicSpline(coeffs, t)
+                knots = spline.grid_points
+                tq = _query_times(knots, gen)
+                frac, index = spline._interpret_t(tq)
+                value = spline.evaluate(tq)
+                slope = spline.derivative(tq)
+                ofrac, oindex = interp.locate(tq, knots, coeffs.size(-2), dtype, "cpu")
+                assert torch.equal(index, oindex) and torch.equal(frac, ofrac), "oracle locate != reference"
+                assert torch.equal(value, interp.cubic_value(coeffs, knots, tq)), "oracle evaluate != reference"
+                assert torch.equal(slope, interp.cubic_slope(coeffs, knots, tq)), "oracle derivative != reference"
+                # scalar-time call path (what the solver uses)
+                s_val = torch.stack([spline.evaluate(q) for q in tq], dim=-2)
+                s_der = torch.stack([spline.derivative(q) for q in tq], dim=-2)
+                assert torch.equal(s_val, value) and torch.equal(s_der, slope)
+                # piecewise-linear control on the same data
+                lin_coeffs = ref.linear_interpolation_coeffs(x, t)
+                assert lin_coeffs is x
+                lin = ref.LinearInterpolation(lin_coeffs, t)
+                lfrac, lindex = lin._interpret_t(tq)
+                lvalue = lin.evaluate(tq)
+                lslope = lin.derivative(tq)
+                opath = interp.LinearPath(lin_coeffs, t)
+                assert torch.equal(lvalue, opath.evaluate(tq)) and torch.equal(lslope, opath.derivative(tq))
+                cases.append(dict(x=x, t=t, knots=knots.clone(), coeffs=coeffs, tq=tq, index=index, frac=frac,
+                                  value=value, slope=slope, lin_index=lindex, lin_frac=lfrac, lin_value=lvalue,
+                                  lin_slope=lslope))
+    return cases
+
+
+class LinearField(torch.nn.Module):
+    """The README vector field (reference README.md:42-49): Linear(H, H*C) viewed (..., H, C)."""
+
+    def __init__(self, H, C, dtype, scale, gen):
+        super().__init__()
+        self.H, self.C = H, C
+        self.linear = torch.nn.Linear(H, H * C).to(dtype)
+        with torch.no_grad():
+            bound = 1 / H ** 0.5
+            self.linear.weight.copy_((torch.rand(H * C, H, generator=gen, dtype=torch.float64) * 2 - 1) * bound * scale)
+            self.linear.bias.copy_((torch.rand(H * C, generator=gen, dtype=torch.float64) * 2 - 1) * bound * scale)
+
+    def forward(self, t, z):
+        return self.linear(z).view(*z.shape[:-1], self.H, self.C)
+
+
+def cdeint_cases(ref):
+    from oracle import cde as oracle_cde, interp
+    gen = torch.Generator().manual_seed(777)
+    cases = []
+    specs = [
+        # name, B, L, C, H, dtype, scale, explicit_t, method, options, t_out kind
+        ("readme_toy_rk4", 1, 10, 2, 3, torch.float32, 1.0, "linspace01", "rk4", dict(step_size=1.0), "interval"),
+        ("readme_toy_dopri5", 1, 10, 2, 3, torch.float32, 1.0, "linspace01", None, None, "interval"),
+        ("mid_rk4_f32", 8, 16, 8, 32, torch.float32, 0.25, None, "rk4", dict(step_size=1.0), "interval"),
+        ("mid_rk4_f64", 8, 16, 8, 32, torch.float64, 0.25, None, "rk4", dict(step_size=1.0), "interval"),
+        ("mid_rk4_halfstep_multi_out", 5, 12, 8, 32, torch.float32, 0.25, None, "rk4", dict(step_size=0.5), "multi"),
+        ("odd_dims_irregular_t", 3, 9, 3, 5, torch.float64, 0.5, "irregular", "rk4", dict(step_size=0.7), "multi"),
+        ("mid_dopri5_f32", 6, 12, 4, 8, torch.float32, 0.25, None, "dopri5", None, "interval"),
+    ]
+    for name, B, L, C, H, dtype, scale, tkind, method, options, outkind in specs:
+        if tkind == "linspace01":
+            t = torch.linspace(0, 1, L, dtype=dtype)
+            x = torch.cat([t.unsqueeze(0).unsqueeze(-1).expand(B, L, 1),
+                           torch.rand(B, L, C - 1, generator=gen, dtype=dtype)], dim=2)
+            coeffs = ref.hermite_cubic_coefficients_with_backward_differences(x)   # README passes no t
+            knots_arg = None
+        elif tkind == "irregular":
+            t = _irregular_t(L, dtype, gen)
+            x = torch.randn(B, L, C, generator=gen, dtype=dtype)
+            coeffs = ref.hermite_cubic_coefficients_with_backward_differences(x, t)
+            knots_arg = t
+        else:
+            x = 0.5 * torch.randn(B, L, C, generator=gen, dtype=dtype)
+            x[..., 0] = torch.linspace(0, 1, L, dtype=dtype)
+            coeffs = ref.hermite_cubic_coefficients_with_backward_differences(x)
+            knots_arg = None
+        func = LinearField(H, C, dtype, scale, gen)
+        z0 = torch.randn(B, H, generator=gen, dtype=dtype)
+        X = ref.CubicSpline(coeffs, knots_arg)
+        if outkind == "interval":
+            t_out = X.interval
+        else:
+            lo, hi = X.interval
+            mids = torch.rand(4, generator=gen, dtype=torch.float64).sort().values.to(dtype) * (hi - lo) + lo
+            t_out = torch.cat([lo.unsqueeze(0), mids, hi.unsqueeze(0)])
+        kwargs = {}
+        if method is not None:
+            kwargs["method"] = method
+        if options is not None:
+            kwargs["options"] = options
+        record = dict(name=name, coeffs=coeffs, knots=knots_arg, W=func.linear.weight.detach().clone(),
+                      b=func.linear.bias.detach().clone(), z0=z0, t_out=t_out, method=method, options=options,
+                      H=H, C=C)
+        for adjoint in (False, True):
+            z0g = z0.clone().requires_grad_(True)
+            func.zero_grad()
+            out = ref.cdeint(X=X, func=func, z0=z0g, t=t_out, adjoint=adjoint, **kwargs)
+            assert out.shape == (B, len(t_out), H)
+            weight = torch.linspace(0.5, 1.5, out.numel(), dtype=dtype).view_as(out)
+            (out * weight).sum().backward()
+            tag = "adjoint" if adjoint else "direct"
+            record["out_" + tag] = out.detach().clone()
+            record["gz0_" + tag] = z0g.grad.clone()
+            record["gW_" + tag] = func.linear.weight.grad.clone()
+            record["gb_" + tag] = func.linear.bias.grad.clone()
+            # oracle.cde must reproduce the reference's solver.py plumbing bit-for-bit
+            z0o = z0.clone().requires_grad_(True)
+            func.zero_grad()
+            out_o = oracle_cde.cdeint(interp.CubicPath(coeffs, knots_arg), func, z0o, t_out, adjoint=adjoint, **kwargs)
+            (out_o * weight).sum().backward()
+            assert torch.equal(out_o, out), name
+            assert torch.equal(z0o.grad, record["gz0_" + tag]), name
+            assert torch.equal(func.linear.weight.grad, record["gW_" + tag]), name
+        record["loss_weight"] = "linspace(0.5, 1.5, numel)"
+        cases.append(record)
+    return cases
+
+
+def run_reference_tests():
+    import pytest
+    files = ["test_hermite_cubic.py", "test_natural_cubic_spline.py", "test_linear_interpolation.py", "test_misc.py",
+             "test_cdeint.py", "test_tricks.py"]
+    args = [os.path.join(REFERENCE, "test", f) for f in files]
+    # torchsde-backed parametrisations cannot run (package absent): deselect them by keyword
+    return pytest.main(args + ["-q", "-p", "no:cacheprovider", "-k", "not torchsde and not test_backend",
+                               "--rootdir", "/tmp", "-c", "/dev/null"])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--run-reference-tests", action="store_true")
+    opts = ap.parse_args()
+    ref = import_reference()
+    os.makedirs(OUT, exist_ok=True)
+    interp_cases = interpolation_cases(ref)
+    torch.save(interp_cases, os.path.join(OUT, "interpolation.pt"))
+    print("interpolation.pt: %d cases (oracle bit-identical to reference on all)" % len(interp_cases))
+    cde_cases = cdeint_cases(ref)
+    torch.save(cde_cases, os.path.join(OUT, "cdeint.pt"))
+    print("cdeint.pt: %d cases (oracle.cde bit-identical to reference solver.py over oracle.odeint)" % len(cde_cases))
+    if opts.run_reference_tests:
+        sys.exit(run_reference_tests())
+
+
+if __name__ == "__main__":
+    main()
