@@ -1,0 +1,156 @@
+/*
+ * cde_mi355x.h -- C ABI of libcde_mi355x.so: the MI355X (gfx950) Neural-CDE hot path.
+ *
+ * The reference (patrick-kidger/torchcde 0.2.5) is pure Python and has no FFI of its own; this
+ * header is the boundary a maintainer would bind with ctypes.  Every entry
+ * point names the reference code it replaces.  Conventions:
+ *
+ *   - all pointers are DEVICE pointers into caller-owned, contiguous, row-major buffers
+ *     (the Python host passes torch.Tensor.data_ptr()); nothing is allocated or freed here;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call is
+ *     asynchronous on that stream, keeps no global state and is safe to capture in a hipGraph;
+ *   - `dtype` / `time_dtype` are CDE_F32 or CDE_F64.  `dtype` is the arithmetic type of the
+ *     state z, the control coefficients and the knots; `time_dtype` is the type the solver's
+ *     time grid is stepped in (torchdiffeq keeps the grid in `t.dtype` and casts each stage
+ *     time to the state dtype before evaluating the vector field);
+ *   - return value: CDE_OK (0) or a negative CDE_ERR_* code; cde_error_string() explains it.
+ *     The Python host raises on any non-zero code -- there is no CPU fallback.
+ */
+#ifndef CDE_MI355X_H
+#define CDE_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CDE_ABI_VERSION 1
+
+enum { CDE_F32 = 0, CDE_F64 = 1 };
+
+enum {
+  CDE_OK = 0,
+  CDE_ERR_NULL = -1,        /* a required pointer is NULL                            */
+  CDE_ERR_DTYPE = -2,       /* unknown dtype enum                                    */
+  CDE_ERR_SHAPE = -3,       /* a size is out of range (e.g. L < 2, H*C*H too large)  */
+  CDE_ERR_UNSUPPORTED = -4, /* combination not implemented by the requested variant  */
+  CDE_ERR_WORKSPACE = -5,   /* workspace_bytes smaller than *_workspace_bytes() asks */
+  CDE_ERR_LAUNCH = -6       /* hipLaunchKernel reported an error                     */
+};
+
+/* control path kinds (piecewise polynomial degree) */
+enum { CDE_PATH_LINEAR = 1, CDE_PATH_CUBIC = 3 };
+
+/* what to evaluate on a path */
+enum { CDE_EVAL_VALUE = 0, CDE_EVAL_DERIVATIVE = 1 };
+
+/* vector-field families the fused solvers understand:
+ *   f(t, z) = act( reshape_{H x C}( W z + bias ) ),  W is (H*C, H) row-major, bias is (H*C)
+ * CDE_ACT_NONE is the README field (reference README.md:42-49), CDE_ACT_TANH the one of
+ * example/irregular_data.py:36-46.                                                       */
+enum { CDE_ACT_NONE = 0, CDE_ACT_TANH = 1 };
+
+/* kernel selection for the fused solvers */
+enum {
+  CDE_VARIANT_AUTO = 0,    /* MFMA kernel when (f32, H == 32, C == 8, ACT_NONE), else generic */
+  CDE_VARIANT_GENERIC = 1, /* VALU kernel: any H, C, f32 or f64                             */
+  CDE_VARIANT_MFMA = 2     /* fail with CDE_ERR_UNSUPPORTED unless the MFMA kernel applies   */
+};
+
+int cde_abi_version(void);
+const char* cde_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1  Hermite cubic coefficients with backward differences.
+ * Replaces torchcde/interpolation_hermite_cubic_bdiff.py:23-44 (and the helper at :5-20) on the
+ * no-missing-value path of linear_interpolation_coeffs (interpolation_linear.py:169-171).
+ *   x      (B, L, C)        observations
+ *   t      (L)              strictly increasing knot times (the host materialises the default
+ *                           linspace(0, L-1, L) exactly as the reference does at :35-36)
+ *   coeffs (B, L-1, 4C)     out: [a | b | 2c | 3d] per interval, same floats as the reference
+ * ------------------------------------------------------------------------------------------- */
+int cde_hermite_bdiff_coeffs(const void* x, const void* t, void* coeffs, int64_t B, int64_t L, int64_t C, int dtype,
+                             void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1b  Interval lookup and path evaluation for a vector of query times.
+ * cde_interpret_t replaces CubicSpline._interpret_t (interpolation_cubic.py:315-322) and
+ * LinearInterpolation._interpret_t (interpolation_linear.py:203-210):
+ *   index = clamp(bucketize(t, knots) - 1, 0, n_intervals - 1)   (int64, bit-exact)
+ *   frac  = t - knots[index]
+ * cde_path_eval replaces CubicSpline.evaluate/.derivative (interpolation_cubic.py:324-336) and
+ * LinearInterpolation.evaluate/.derivative (interpolation_linear.py:212-225):
+ *   coeffs  cubic: (B, n_intervals, 4C); linear: (B, n_intervals + 1, C) (the raw knots' values)
+ *   knots   (n_intervals + 1)
+ *   tq      (nq) query times, already in `dtype`
+ *   out     (B, nq, C)
+ * ------------------------------------------------------------------------------------------- */
+int cde_interpret_t(const void* knots, int64_t n_intervals, const void* tq, int64_t nq, int64_t* index_out,
+                    void* frac_out, int dtype, void* stream);
+int cde_path_eval(const void* coeffs, const void* knots, const void* tq, int64_t nq, void* out, int64_t B,
+                  int64_t n_intervals, int64_t C, int degree, int what, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Contraction of a materialised vector field with the control derivative,
+ *   out[b, h] = sum_c F[b, h, c] * dX[b, c]
+ * Replaces the batched mat-vec of _VectorField.forward (solver.py:130) on the step-wise path
+ * used for vector fields the fused solvers do not recognise.
+ * ------------------------------------------------------------------------------------------- */
+int cde_contract(const void* F, const void* dX, void* out, int64_t B, int64_t H, int64_t C, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2  Fused fixed-grid RK4 (3/8 rule) solve of  dz/dt = f(t, z) dX/dt  for the affine family.
+ * Replaces, for one cdeint call: _VectorField.forward (solver.py:117-135) x 4 per step,
+ * CubicSpline.derivative / LinearInterpolation.derivative inside it, and the whole of
+ * torchdiffeq.odeint(method='rk4') behind solver.py:226-227 (grid stepping, 3/8-rule stages,
+ * linear interpolation onto the output times).
+ *   coeffs, knots, n_intervals, degree   the control, as for cde_path_eval
+ *   W (H*C, H), bias (H*C), act           the vector field
+ *   z0     (B, H)
+ *   grid   (n_grid)  solver grid in `time_dtype`, built by the host exactly as torchdiffeq does
+ *                    (arange(n)*step + t[0], last point = t[-1]); grid[0] == t_out[0]
+ *   t_out  (n_out)   output times in `time_dtype`
+ *   z_out  (B, n_out, H)  out: z at the output times, already in cdeint's (..., T, H) layout
+ *   stage_index (4*(n_grid-1)) int64, stage_frac (4*(n_grid-1)) `dtype`: REQUIRED device scratch.
+ *                    The call first fills them with the interval index / fractional part of
+ *                    every stage time (what CubicSpline._interpret_t returns for it), then the
+ *                    solve kernel reads them; callers may inspect them afterwards as the trace
+ *                    for bit-exact index parity checks.
+ * ------------------------------------------------------------------------------------------- */
+int cde_rk4_forward_linear(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
+                           const void* bias, int act, const void* z0, const void* grid, int64_t n_grid,
+                           const void* t_out, int64_t n_out, void* z_out, int64_t B, int64_t C, int64_t H, int dtype,
+                           int time_dtype, int variant, int64_t* stage_index, void* stage_frac, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3  Fused continuous-adjoint reverse sweep for K2.
+ * Replaces torchdiffeq.odeint_adjoint's backward (behind solver.py:226): for every output
+ * interval, RK4 (3/8) integration in reversed time of the augmented state (z, a_z, a_W, a_b),
+ * re-seeding z from the stored forward solution and adding the incoming gradient at every
+ * output time.
+ *   z_saved  (B, n_out, H)   forward solution at the output times (K2's z_out)
+ *   grad_out (B, n_out, H)   dL/dz_out
+ *   sgrid    (n_sgrid) concatenated reversed-time grids in `time_dtype`, one segment per output
+ *            interval, processed in the order i = n_out-1 .. 1.  Segment p = n_out-1-i covers
+ *            s in [-t_out[i], -t_out[i-1]], built exactly as torchdiffeq builds the grid of
+ *            odeint(..., t[i-1:i+1].flip(0)).
+ *   seg_off  (n_out) DEVICE array of int64: segment p is sgrid[seg_off[p] .. seg_off[p+1])
+ *            (so seg_off[0] == 0 and seg_off[n_out-1] == n_sgrid)
+ *   grad_z0 (B, H), grad_W (H*C, H), grad_b (H*C)   out
+ *   workspace / workspace_bytes : device scratch of at least cde_rk4_adjoint_workspace_bytes()
+ *            bytes: the reverse-sweep stage table plus per-workgroup partial parameter
+ *            gradients, which are reduced in a fixed order (run-to-run deterministic, no atomics).
+ * ------------------------------------------------------------------------------------------- */
+size_t cde_rk4_adjoint_workspace_bytes(int64_t B, int64_t C, int64_t H, int64_t n_sgrid, int dtype, int variant);
+int cde_rk4_adjoint_linear(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
+                           const void* bias, int act, const void* z_saved, const void* grad_out, const void* sgrid,
+                           int64_t n_sgrid, const int64_t* seg_off, int64_t n_out, void* grad_z0, void* grad_W,
+                           void* grad_b, int64_t B, int64_t C, int64_t H, int dtype, int time_dtype, int variant,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CDE_MI355X_H */

@@ -1,0 +1,172 @@
+// api.hip -- C-ABI entry points of the fused solvers: argument checks, stage table, kernel dispatch.
+#include "cde_common.h"
+
+namespace cde {
+
+// from rk4_generic.hip
+size_t generic_adjoint_workspace_bytes(int64_t B, int64_t C, int64_t H, size_t elem);
+template <typename T, typename TT>
+int launch_forward_generic(const void*, const void*, int64_t, int, const void*, const void*, int, const void*,
+                           const void*, int64_t, const void*, int64_t, void*, int64_t, int64_t, int64_t,
+                           const int64_t*, const void*, hipStream_t);
+template <typename T, typename TT>
+int launch_adjoint_generic(const void*, const void*, int64_t, int, const void*, const void*, int, const void*,
+                           const void*, const void*, const int64_t*, int64_t, void*, void*, void*, int64_t, int64_t,
+                           int64_t, const int64_t*, const void*, void*, hipStream_t);
+// from rk4_mfma.hip
+bool mfma_applicable(int64_t C, int64_t H, int dtype, int act);
+size_t mfma_adjoint_partial_bytes(int64_t B);
+template <typename TT>
+int launch_forward_mfma(const void*, const void*, int64_t, int, const void*, const void*, const void*, const void*,
+                        int64_t, const void*, int64_t, void*, int64_t, const int64_t*, const void*, hipStream_t);
+template <typename TT>
+int launch_adjoint_mfma(const void*, const void*, int64_t, int, const void*, const void*, const void*, const void*,
+                        const void*, const int64_t*, int64_t, void*, void*, void*, int64_t, const int64_t*,
+                        const void*, float*, hipStream_t);
+
+// Stage table: for solver step k over [grid[k], grid[k+1]] and RK stage j, the control interval
+// and fractional part at the stage time -- what CubicSpline._interpret_t (interpolation_cubic.py:
+// 315-322) returns when torchdiffeq's rk4 evaluates the vector field there.  One lane per entry.
+// `negate`: the reverse sweep integrates in s = -t and evaluates the field at t = -s.
+template <typename T, typename TT>
+__global__ void stage_table_kernel(const T* __restrict__ knots, int64_t n_intervals, const TT* __restrict__ grid,
+                                   int64_t n_steps, int negate, int64_t* __restrict__ index_out,
+                                   T* __restrict__ frac_out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 4 * n_steps) return;
+  const int64_t k = e >> 2;
+  const StageClock<TT> clk(grid[k], grid[k + 1]);
+  T ts = (T)clk.time((int)(e & 3));
+  if (negate) ts = -ts;
+  T frac;
+  index_out[e] = locate(knots, n_intervals, ts, frac);
+  frac_out[e] = frac;
+}
+
+template <typename T, typename TT>
+static int fill_stage_table(const void* knots, int64_t n_intervals, const void* grid, int64_t n_steps, int negate,
+                            int64_t* index_out, void* frac_out, hipStream_t s) {
+  if (n_steps <= 0) return CDE_OK;
+  stage_table_kernel<T, TT><<<(unsigned)((4 * n_steps + 255) / 256), 256, 0, s>>>(
+      (const T*)knots, n_intervals, (const TT*)grid, n_steps, negate, index_out, (T*)frac_out);
+  return check_launch();
+}
+
+static inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+static bool pick_mfma(int variant, int64_t C, int64_t H, int dtype, int act, int* rc) {
+  const bool ok = mfma_applicable(C, H, dtype, act);
+  *rc = CDE_OK;
+  if (variant == CDE_VARIANT_MFMA) { if (!ok) *rc = CDE_ERR_UNSUPPORTED; return ok; }
+  if (variant == CDE_VARIANT_GENERIC) return false;
+  if (variant != CDE_VARIANT_AUTO) { *rc = CDE_ERR_UNSUPPORTED; return false; }
+  return ok;
+}
+
+template <typename T, typename TT>
+static int forward_typed(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
+                         const void* bias, int act, const void* z0, const void* grid, int64_t n_grid,
+                         const void* t_out, int64_t n_out, void* z_out, int64_t B, int64_t C, int64_t H, int dtype,
+                         int variant, int64_t* stage_index, void* stage_frac, hipStream_t s) {
+  int rc = fill_stage_table<T, TT>(knots, n_intervals, grid, n_grid - 1, 0, stage_index, stage_frac, s);
+  if (rc != CDE_OK) return rc;
+  const bool use_mfma = pick_mfma(variant, C, H, dtype, act, &rc);
+  if (rc != CDE_OK) return rc;
+  if (use_mfma)
+    return launch_forward_mfma<TT>(coeffs, knots, n_intervals, degree, W, bias, z0, grid, n_grid, t_out, n_out, z_out,
+                                   B, stage_index, stage_frac, s);
+  return launch_forward_generic<T, TT>(coeffs, knots, n_intervals, degree, W, bias, act, z0, grid, n_grid, t_out, n_out,
+                                       z_out, B, C, H, stage_index, stage_frac, s);
+}
+
+template <typename T, typename TT>
+static int adjoint_typed(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
+                         const void* bias, int act, const void* z_saved, const void* grad_out, const void* sgrid,
+                         int64_t n_sgrid, const int64_t* seg_off, int64_t n_out, void* grad_z0, void* grad_W,
+                         void* grad_b, int64_t B, int64_t C, int64_t H, int dtype, int variant, void* workspace,
+                         size_t workspace_bytes, hipStream_t s) {
+  int rc;
+  const bool use_mfma = pick_mfma(variant, C, H, dtype, act, &rc);
+  if (rc != CDE_OK) return rc;
+  // workspace: [stage_index: 4*(n_sgrid-1) int64][stage_frac: 4*(n_sgrid-1) T][partials]
+  const int64_t n_steps = n_sgrid - 1;
+  const size_t off_frac = align256((size_t)(4 * n_steps) * sizeof(int64_t));
+  const size_t off_part = off_frac + align256((size_t)(4 * n_steps) * sizeof(T));
+  const size_t part_bytes = use_mfma ? mfma_adjoint_partial_bytes(B) : generic_adjoint_workspace_bytes(B, C, H, sizeof(T));
+  if (workspace_bytes < off_part + part_bytes) return CDE_ERR_WORKSPACE;
+  int64_t* stage_index = (int64_t*)workspace;
+  void* stage_frac = (unsigned char*)workspace + off_frac;
+  void* partial = (unsigned char*)workspace + off_part;
+  rc = fill_stage_table<T, TT>(knots, n_intervals, sgrid, n_steps, 1, stage_index, stage_frac, s);
+  if (rc != CDE_OK) return rc;
+  if (use_mfma)
+    return launch_adjoint_mfma<TT>(coeffs, knots, n_intervals, degree, W, bias, z_saved, grad_out, sgrid, seg_off, n_out,
+                                   grad_z0, grad_W, grad_b, B, stage_index, stage_frac, (float*)partial, s);
+  return launch_adjoint_generic<T, TT>(coeffs, knots, n_intervals, degree, W, bias, act, z_saved, grad_out, sgrid,
+                                       seg_off, n_out, grad_z0, grad_W, grad_b, B, C, H, stage_index, stage_frac,
+                                       partial, s);
+}
+
+}  // namespace cde
+
+extern "C" int cde_rk4_forward_linear(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
+                                      const void* W, const void* bias, int act, const void* z0, const void* grid,
+                                      int64_t n_grid, const void* t_out, int64_t n_out, void* z_out, int64_t B,
+                                      int64_t C, int64_t H, int dtype, int time_dtype, int variant,
+                                      int64_t* stage_index, void* stage_frac, void* stream) {
+  if (B < 0 || C < 1 || H < 1 || n_intervals < 1 || n_grid < 1 || n_out < 1) return CDE_ERR_SHAPE;
+  if (act != CDE_ACT_NONE && act != CDE_ACT_TANH) return CDE_ERR_UNSUPPORTED;
+  if (B == 0) return CDE_OK;
+  if (!coeffs || !knots || !W || !bias || !z0 || !grid || !t_out || !z_out) return CDE_ERR_NULL;
+  if (n_grid > 1 && (!stage_index || !stage_frac)) return CDE_ERR_NULL;
+  hipStream_t s = (hipStream_t)stream;
+#define CDE_CALL(T, TT)                                                                                              \
+  return cde::forward_typed<T, TT>(coeffs, knots, n_intervals, degree, W, bias, act, z0, grid, n_grid, t_out, n_out, \
+                                   z_out, B, C, H, dtype, variant, stage_index, stage_frac, s)
+  if (dtype == CDE_F32 && time_dtype == CDE_F32) CDE_CALL(float, float);
+  if (dtype == CDE_F32 && time_dtype == CDE_F64) CDE_CALL(float, double);
+  if (dtype == CDE_F64 && time_dtype == CDE_F64) CDE_CALL(double, double);
+  if (dtype == CDE_F64 && time_dtype == CDE_F32) CDE_CALL(double, float);
+#undef CDE_CALL
+  return CDE_ERR_DTYPE;
+}
+
+extern "C" size_t cde_rk4_adjoint_workspace_bytes(int64_t B, int64_t C, int64_t H, int64_t n_sgrid, int dtype,
+                                                  int variant) {
+  const size_t elem = dtype == CDE_F64 ? 8 : 4;
+  const int64_t n_steps = n_sgrid > 1 ? n_sgrid - 1 : 0;
+  size_t bytes = cde::align256((size_t)(4 * n_steps) * sizeof(int64_t)) + cde::align256((size_t)(4 * n_steps) * elem);
+  int rc;
+  const bool use_mfma = cde::pick_mfma(variant, C, H, dtype, CDE_ACT_NONE, &rc);
+  // AUTO may resolve to either kernel depending on the activation: reserve the larger need
+  const size_t a = cde::mfma_adjoint_partial_bytes(B);
+  const size_t b = cde::generic_adjoint_workspace_bytes(B, C, H, elem);
+  if (variant == CDE_VARIANT_MFMA) bytes += a;
+  else if (variant == CDE_VARIANT_GENERIC || !use_mfma) bytes += b;
+  else bytes += (a > b ? a : b);
+  return bytes;
+}
+
+extern "C" int cde_rk4_adjoint_linear(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
+                                      const void* W, const void* bias, int act, const void* z_saved,
+                                      const void* grad_out, const void* sgrid, int64_t n_sgrid, const int64_t* seg_off,
+                                      int64_t n_out, void* grad_z0, void* grad_W, void* grad_b, int64_t B, int64_t C,
+                                      int64_t H, int dtype, int time_dtype, int variant, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+  if (B < 1 || C < 1 || H < 1 || n_intervals < 1 || n_out < 1 || n_sgrid < 0) return CDE_ERR_SHAPE;
+  if (act != CDE_ACT_NONE && act != CDE_ACT_TANH) return CDE_ERR_UNSUPPORTED;
+  if (!coeffs || !knots || !W || !bias || !z_saved || !grad_out || !grad_z0 || !grad_W || !grad_b || !workspace)
+    return CDE_ERR_NULL;
+  if (n_out > 1 && (!sgrid || !seg_off)) return CDE_ERR_NULL;
+  hipStream_t s = (hipStream_t)stream;
+#define CDE_CALL(T, TT)                                                                                               \
+  return cde::adjoint_typed<T, TT>(coeffs, knots, n_intervals, degree, W, bias, act, z_saved, grad_out, sgrid,        \
+                                   n_sgrid, seg_off, n_out, grad_z0, grad_W, grad_b, B, C, H, dtype, variant,         \
+                                   workspace, workspace_bytes, s)
+  if (dtype == CDE_F32 && time_dtype == CDE_F32) CDE_CALL(float, float);
+  if (dtype == CDE_F32 && time_dtype == CDE_F64) CDE_CALL(float, double);
+  if (dtype == CDE_F64 && time_dtype == CDE_F64) CDE_CALL(double, double);
+  if (dtype == CDE_F64 && time_dtype == CDE_F32) CDE_CALL(double, float);
+#undef CDE_CALL
+  return CDE_ERR_DTYPE;
+}

@@ -1,0 +1,75 @@
+// cde_common.h -- device helpers shared by every kernel of libcde_mi355x.so (gfx950 only).
+//
+// The library is compiled with -ffp-contract=off: wherever the reference's float result is
+// defined by a sequence of separately rounded torch ops (knot lookup, spline Horner steps, RK
+// stage combinations, output interpolation) the kernels reproduce that sequence literally;
+// fused multiply-adds appear only where written explicitly (dot products, MFMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cde_mi355x.h"
+
+namespace cde {
+
+// ---------------------------------------------------------------- interval lookup
+// index = clamp(bucketize(t, knots, right=False) - 1, 0, n_intervals - 1);  frac = t - knots[index]
+// (reference interpolation_cubic.py:315-322).  bucketize(right=False) is lower_bound with the
+// comparison torch uses, `!(knots[mid] >= t)`, so a query exactly on knot k resolves to interval
+// k-1 and NaN queries behave identically.
+template <typename T>
+__device__ __forceinline__ int64_t locate(const T* __restrict__ knots, int64_t n_intervals, T t, T& frac) {
+  int64_t lo = 0, hi = n_intervals + 1;  // n_intervals + 1 knots
+  while (lo < hi) {
+    const int64_t mid = lo + ((hi - lo) >> 1);
+    if (!(knots[mid] >= t)) lo = mid + 1; else hi = mid;
+  }
+  int64_t idx = lo - 1;
+  idx = idx < 0 ? 0 : idx;
+  idx = idx > n_intervals - 1 ? n_intervals - 1 : idx;
+  frac = t - knots[idx];
+  return idx;
+}
+
+// ---------------------------------------------------------------- RK4 3/8-rule stage clock
+// torchdiffeq rk4_alt_step_func: stage times t0, t0 + dt*(1/3), t0 + dt*(2/3), t1 formed in the
+// grid's dtype (python floats 1/3, 2/3 rounded to that dtype), then cast to the state dtype.
+template <typename TT>
+struct StageClock {
+  TT t0, t1, dt;
+  __device__ __forceinline__ StageClock(TT a, TT b) : t0(a), t1(b), dt(b - a) {}
+  __device__ __forceinline__ TT time(int stage) const {
+    const TT third = (TT)(1.0 / 3.0), two_thirds = (TT)(2.0 / 3.0);
+    switch (stage) {
+      case 0: return t0;
+      case 1: return t0 + dt * third;
+      case 2: return t0 + dt * two_thirds;
+      default: return t1;
+    }
+  }
+};
+
+// ---------------------------------------------------------------- control derivative of one channel
+// cubic row layout (one interval of one series): [a(C) | b(C) | two_c(C) | three_d(C)]
+//   derivative = b + (two_c + three_d*frac)*frac          (interpolation_cubic.py:334-335)
+//   value      = a + (b + (0.5*two_c + three_d*frac/3)*frac)*frac   (:327-329)
+template <typename T>
+__device__ __forceinline__ T cubic_derivative(T b, T two_c, T three_d, T frac) {
+  const T inner = two_c + three_d * frac;
+  return b + inner * frac;
+}
+template <typename T>
+__device__ __forceinline__ T cubic_value(T a, T b, T two_c, T three_d, T frac) {
+  T inner = (T)0.5 * two_c + three_d * frac / (T)3;
+  inner = b + inner * frac;
+  return a + inner * frac;
+}
+
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float tanh_t(float x) { return tanhf(x); }
+__device__ __forceinline__ double tanh_t(double x) { return tanh(x); }
+
+inline int check_launch() { return hipGetLastError() == hipSuccess ? CDE_OK : CDE_ERR_LAUNCH; }
+
+}  // namespace cde
