@@ -1,0 +1,197 @@
+#!/usr/bin/env python
+"""bench.py -- series/sec (fwd+adjoint) for cdeint RK4, batch=32768, L=128, C=8, H=32 (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic series already resident in HBM:
+``cdeint(X, func, z0, X.interval, method='rk4', options={'step_size': 1.0})`` (K2: 127 RK4 steps) followed
+by ``z_T.sum().backward()`` (K3: continuous-adjoint reverse sweep, gradients for z0, W, b).  This is
+BASELINE.json configs[2] ("same as [1] with adjoint=True backprop through solver, 1 MI355X"), the
+configuration the metric is quoted on.  Coefficients are fitted once outside the timed region (K1; the
+reference treats it as dataset pre-processing) and its rate is reported separately under "extra".
+
+Multi-GPU: series are independent, so the batch shards across ranks with NO data-path collective; every
+rank solves its own 32768 series (weak scaling) and the only communication is the all-reduce of the
+8,448 parameter gradients, included in the timed step when N > 1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+B, L, C, H = 32768, 128, 8, 32
+N_EVAL = 4 * (L - 1)
+# algorithmic work per series (restated in DESIGN.md)
+FLOP_FWD = N_EVAL * (2 * H * (H * C) + 2 * H * C)                                     # 8.58 MFLOP
+FLOP_ADJ = N_EVAL * ((2 * H * H * C + 2 * H * C) + 2 * H * C + 2 * H * C * H + 2 * H * C * H + H * C)   # 25.6 MFLOP
+PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def make_workload(device, seed):
+    from helpers import LinearField, make_series
+    x = make_series(B, L, C, seed=seed).to(device)
+    func = LinearField(H, C, scale=0.25, seed=0).to(device)
+    z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(seed)).to(device)
+    return x, func, z0
+
+
+def cpu_baseline(sample):
+    """The oracle (torch CPU restatement of the reference path) on a bounded sample of the same workload."""
+    from oracle import cde as oracle_cde, interp as oracle_interp
+    from helpers import LinearField, make_series
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    x = make_series(sample, L, C, seed=0)
+    func = LinearField(H, C, scale=0.25, seed=0)
+    z0 = torch.randn(sample, H, generator=torch.Generator().manual_seed(0))
+    X = oracle_interp.CubicPath(oracle_interp.hermite_bdiff_coeffs(x))
+
+    def one():
+        z = z0.clone().requires_grad_(True)
+        func.zero_grad()
+        out = oracle_cde.cdeint(X, func, z, X.interval, adjoint=True, method="rk4", options=dict(step_size=1.0))
+        out[:, -1].sum().backward()
+
+    one()                                   # warm-up (thread pool, allocator)
+    t0 = time.perf_counter()
+    one()
+    dt = time.perf_counter() - t0
+    return {"value": sample / dt, "unit": "series/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle (torch-CPU restatement of reference CubicSpline + _VectorField + torchdiffeq rk4/"
+                      "adjoint) on the first %d of the %d series, L=%d, 1 warm-up + 1 timed fwd+adjoint (%.1f s)"
+                      % (sample, B, L, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cpu-sample", type=int, default=8192, help="series in the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")           # "nccl" is RCCL on ROCm
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    import torchcde_amd as cde
+    from torchcde_amd.cdeint import _Plan
+    from torchcde_amd.distributed import allreduce_gradients
+    cde.load()
+
+    x, func, z0 = make_workload(device, seed=rank)
+
+    # K1 outside the timed region, timed on its own
+    torch.cuda.synchronize()
+    for _ in range(2):
+        coeffs = cde.hermite_cubic_coefficients_with_backward_differences(x)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(10):
+        coeffs = cde.hermite_cubic_coefficients_with_backward_differences(x)
+    ev[1].record()
+    torch.cuda.synchronize()
+    fit_ms = ev[0].elapsed_time(ev[1]) / 10
+    X = cde.CubicSpline(coeffs)
+    t = X.interval
+    params = list(func.parameters())
+
+    def step():
+        z = z0.detach().requires_grad_(True)
+        for p in params:
+            p.grad = None
+        out = cde.cdeint(X, func, z, t, method="rk4", options={"step_size": 1.0})
+        out[:, -1].sum().backward()
+        if distributed:
+            allreduce_gradients(params)
+        return out
+
+    for _ in range(args.warmup):
+        step()
+
+    _Plan.event_log = []                                   # HIP events around the K2 / K3 C-ABI calls
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    log, _Plan.event_log = _Plan.event_log, None
+
+    if distributed:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+
+    fwd_ms = [a.elapsed_time(b) for kind, a, b in log if kind == "forward"]
+    adj_ms = [a.elapsed_time(b) for kind, a, b in log if kind == "adjoint"]
+    fwd_avg = sum(fwd_ms) / max(len(fwd_ms), 1)
+    adj_avg = sum(adj_ms) / max(len(adj_ms), 1)
+
+    if rank == 0:
+        total_series = B * world * args.steps
+        value = total_series / elapsed
+        achieved = B * FLOP_ADJ / (adj_avg * 1e-3) / 1e12 if adj_avg > 0 else 0.0
+        result = {
+            "metric": "series/sec (fwd+adjoint) for cdeint RK4, batch=32k L=128 C=8 H=32",
+            "value": value,
+            "unit": "series/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: Hermite-cubic control, linear func Linear(32,256), RK4 "
+                                   "step 1.0 (127 steps), cdeint forward + adjoint=True backward, per GPU",
+                       "batch_per_gpu": B, "length": L, "input_channels": C, "hidden_channels": H,
+                       "global_batch": B * world, "parallelism": "batch-sharded x%d, no data-path collective" % world},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "rk4_adjoint_mfma (K3)", "kernel_ms": adj_avg,
+                         "algorithmic_flop_per_launch": B * FLOP_ADJ},
+            "extra": {
+                "forward_kernel_ms": fwd_avg,
+                "forward_tflops": B * FLOP_FWD / (fwd_avg * 1e-3) / 1e12 if fwd_avg > 0 else None,
+                "forward_only_series_per_s": B / (fwd_avg * 1e-3) if fwd_avg > 0 else None,
+                "hermite_fit_ms": fit_ms,
+                "hermite_fit_series_per_s": B / (fit_ms * 1e-3),
+                "hermite_fit_hbm_gbs": B * 20352 / (fit_ms * 1e-3) / 1e9,
+                "hermite_fit_hbm_frac_of_8TBs": B * 20352 / (fit_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+            },
+        }
+        if world == 1 and args.cpu_sample > 0:
+            result["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, B))
+        print(json.dumps(result))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

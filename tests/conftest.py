@@ -1,0 +1,34 @@
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_interp():
+    return torch.load(os.path.join(GOLDEN, "interpolation.pt"))
+
+
+@pytest.fixture(scope="session")
+def golden_cde():
+    return torch.load(os.path.join(GOLDEN, "cdeint.pt"))
+
+
+@pytest.fixture(scope="session")
+def native():
+    """The built extension; GPU tests must fail loudly (not skip) if it is missing."""
+    import torchcde_amd
+    torchcde_amd.load()
+    assert torch.cuda.is_available(), "gpu-marked test running without a GPU"
+    return torchcde_amd

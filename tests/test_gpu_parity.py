@@ -1,0 +1,364 @@
+"""GPU parity tests: the HIP path (through the ctypes C ABI) against the CPU oracle, the committed
+golden fixtures generated from the reference, and size-independent properties at full benchmark size.
+
+Tolerances (stated once, used below):
+  * interval indices: bit-exact (int64 equality)
+  * coefficients / frac / spline value & slope: bit-exact against the reference's floats
+  * trajectories: rtol 1e-4, atol 1e-6 (the north star's bar) in float32; 1e-9 / 1e-11 in float64
+  * gradients: rtol 1e-3 (float32 kernels vs float64 oracle), 1e-8 in float64
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import cde as oracle_cde, interp as oracle_interp
+from helpers import LinearField, golden_field, make_series
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _close(a, b, rtol, atol):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    ok = torch.allclose(a, b, rtol=rtol, atol=atol)
+    if not ok:
+        err = ((a - b).abs() / (atol + rtol * b.abs())).max().item()
+        raise AssertionError("mismatch: worst error = %.3g x tolerance, max abs diff %.3g" % (err, (a - b).abs().max()))
+
+
+# =========================================================================================== K1 / K1b
+def test_hermite_coefficients_bit_exact_vs_reference_golden(native, golden_interp):
+    for case in golden_interp:
+        x = case["x"].to(DEV)
+        t = None if case["t"] is None else case["t"].to(DEV)
+        got = native.hermite_cubic_coefficients_with_backward_differences(x, t)
+        assert got.shape == case["coeffs"].shape and got.dtype == case["coeffs"].dtype
+        assert torch.equal(got.cpu(), case["coeffs"]), "coeffs differ from the reference's floats"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("C", [1, 3, 8])
+def test_hermite_coefficients_vs_oracle_seeded(native, dtype, C):
+    gen = torch.Generator().manual_seed(100 + C)
+    for batch, L in (((7,), 2), ((2, 3), 33), ((257,), 128)):
+        x = torch.randn(*batch, L, C, generator=gen, dtype=dtype)
+        t = (torch.rand(L, generator=gen, dtype=torch.float64) + 0.05).cumsum(0).to(dtype)
+        for tt in (None, t):
+            got = native.hermite_cubic_coefficients_with_backward_differences(
+                x.to(DEV), None if tt is None else tt.to(DEV))
+            assert torch.equal(got.cpu(), oracle_interp.hermite_bdiff_coeffs(x, tt))
+
+
+def test_linear_coeffs_returns_same_tensor(native):
+    x = torch.randn(3, 6, 2, device=DEV)
+    assert native.linear_interpolation_coeffs(x) is x
+    with pytest.raises(NotImplementedError, match="missing values"):
+        y = x.clone()
+        y[0, 2, 1] = float("nan")
+        native.linear_interpolation_coeffs(y)
+
+
+def test_interpret_t_evaluate_derivative_bit_exact_vs_reference_golden(native, golden_interp):
+    for case in golden_interp:
+        knots = case["knots"].to(DEV)
+        explicit = case["t"] is not None
+        X = native.CubicSpline(case["coeffs"].to(DEV), knots if explicit else None)
+        assert torch.equal(X.grid_points.cpu(), case["knots"])
+        tq = case["tq"].to(DEV)
+        frac, index = X._interpret_t(tq)
+        assert index.dtype == torch.int64 and torch.equal(index.cpu(), case["index"])      # bit-exact indices
+        assert torch.equal(frac.cpu(), case["frac"])
+        value, slope = X.evaluate(tq), X.derivative(tq)
+        assert value.shape == case["value"].shape
+        assert torch.equal(value.cpu(), case["value"]) and torch.equal(slope.cpu(), case["slope"])
+        # scalar-time call (what cdeint's callers use: X.evaluate(X.interval[0]))
+        assert torch.equal(X.evaluate(tq[3]).cpu(), case["value"][..., 3, :])
+        L = native.LinearInterpolation(case["x"].to(DEV), knots if explicit else None)
+        lfrac, lindex = L._interpret_t(tq)
+        assert torch.equal(lindex.cpu(), case["lin_index"]) and torch.equal(lfrac.cpu(), case["lin_frac"])
+        assert torch.equal(L.evaluate(tq).cpu(), case["lin_value"])
+        assert torch.equal(L.derivative(tq).cpu(), case["lin_slope"])
+
+
+def test_path_output_shapes_follow_reference_contract(native):
+    """batch_dims + t.shape + (channels,)  (reference test_natural_cubic_spline.py:151-167)"""
+    coeffs = torch.randn(2, 3, 7, 12, device=DEV)
+    X = native.CubicSpline(coeffs)
+    for tshape in ((), (5,), (2, 4)):
+        t = torch.rand(*tshape, device=DEV) * 7
+        assert X.evaluate(t).shape == (2, 3) + tshape + (3,)
+        assert X.derivative(t).shape == (2, 3) + tshape + (3,)
+
+
+# =========================================================================================== cdeint
+def _run_native(native, case, variant, adjoint):
+    func = golden_field(case).to(DEV)
+    X = native.CubicSpline(case["coeffs"].to(DEV), None if case["knots"] is None else case["knots"].to(DEV))
+    z0 = case["z0"].to(DEV).requires_grad_(True)
+    out = native.cdeint(X, func, z0, case["t_out"].to(DEV), adjoint=adjoint, method=case["method"],
+                        options=case["options"], variant=variant)
+    return func, z0, out
+
+
+@pytest.mark.parametrize("variant", ["generic", "auto"])
+def test_cdeint_rk4_vs_reference_golden(native, golden_cde, variant):
+    """Trajectories and adjoint gradients against the fixtures produced by the reference's solver.py
+    (driven by the oracle integrator).  README toy (config 1) included."""
+    ran = 0
+    for case in golden_cde:
+        if case["method"] != "rk4":
+            continue
+        f64 = case["z0"].dtype == torch.float64
+        rt, at = (1e-9, 1e-11) if f64 else (1e-4, 1e-6)
+        func, z0, out = _run_native(native, case, variant, adjoint=True)
+        assert out.shape == case["out_adjoint"].shape
+        _close(out, case["out_adjoint"], rt, at)
+        w = torch.linspace(0.5, 1.5, out.numel(), dtype=out.dtype, device=DEV).view_as(out)
+        (out * w).sum().backward()
+        grt, gat = (1e-8, 1e-10) if f64 else (1e-3, 1e-4)     # atol relative to the largest gradient entry
+        for got, ref in ((z0.grad, case["gz0_adjoint"]), (func.linear.weight.grad, case["gW_adjoint"]),
+                         (func.linear.bias.grad, case["gb_adjoint"])):
+            _close(got, ref, grt, gat * ref.abs().max().item())
+        ran += 1
+    assert ran >= 5
+
+
+def test_stage_table_is_bit_exact_with_reference_interpret_t(native):
+    """Every stage time of every RK4 step must resolve to the interval index (int64, bit-exact) and
+    fractional part that CubicSpline._interpret_t gives for torchdiffeq's stage times."""
+    from torchcde_amd.cdeint import _Plan, _fixed_grid
+    from torchcde_amd.fields import probe
+    for dtype, L, step, explicit in ((torch.float32, 128, 1.0, False), (torch.float32, 40, 0.3, True),
+                                     (torch.float64, 17, 0.7, True)):
+        x = make_series(4, L, 8, dtype, seed=3)
+        knots = None
+        if explicit:
+            knots = (torch.rand(L, dtype=torch.float64).cumsum(0) + 0.2).to(dtype)
+        coeffs = oracle_interp.hermite_bdiff_coeffs(x, knots)
+        X = native.CubicSpline(coeffs.to(DEV), None if knots is None else knots.to(DEV))
+        func = LinearField(32, 8, dtype, scale=0.25).to(DEV)
+        z0 = torch.randn(4, 32, dtype=dtype, device=DEV)
+        field, _ = probe(func, X.interval[0], z0)
+        plan = _Plan(X, field, (4,), 32, 8, X.interval, step, step, True, 1)
+        plan.run_forward(z0, field.weight, field.bias)
+        grid = _fixed_grid(X.interval.cpu(), step)
+        cpu_knots = X.grid_points.cpu()
+        exp_idx, exp_frac = [], []
+        third, two_thirds = 1 / 3, 2 / 3
+        for t0, t1 in zip(grid[:-1], grid[1:]):
+            dt = t1 - t0
+            for ts in (t0, t0 + dt * third, t0 + dt * two_thirds, t1):
+                frac, idx = oracle_interp.locate(ts.to(dtype), cpu_knots, coeffs.size(-2), dtype, "cpu")
+                exp_idx.append(idx)
+                exp_frac.append(frac)
+        assert torch.equal(plan.stage_index.cpu(), torch.stack(exp_idx))
+        assert torch.equal(plan.stage_frac.cpu(), torch.stack(exp_frac))
+
+
+def _oracle_solution(coeffs, knots, func, z0, t_out, step, loss_weight=None):
+    """float64 oracle: trajectories and adjoint gradients."""
+    f64 = LinearField(func.H, func.C, torch.float64, tanh=func.tanh)
+    with torch.no_grad():
+        f64.linear.weight.copy_(func.linear.weight.double().cpu())
+        f64.linear.bias.copy_(func.linear.bias.double().cpu())
+    X = oracle_interp.CubicPath(coeffs.double().cpu(), None if knots is None else knots.double().cpu())
+    z = z0.double().cpu().clone().requires_grad_(True)
+    out = oracle_cde.cdeint(X, f64, z, t_out.double().cpu(), adjoint=True, method="rk4", options=dict(step_size=step))
+    w = torch.ones_like(out) if loss_weight is None else loss_weight.double().cpu()
+    (out * w).sum().backward()
+    return out.detach(), z.grad, f64.linear.weight.grad, f64.linear.bias.grad
+
+
+@pytest.mark.parametrize("variant,act", [("mfma", False), ("generic", False), ("generic", True)])
+def test_cdeint_vs_float64_oracle_ragged_batch(native, variant, act):
+    """B = 203 (not a multiple of the 32-series wave tile), 3 output times, fp32 kernels vs fp64 oracle."""
+    B, L, C, H = 203, 24, 8, 32
+    x = make_series(B, L, C, torch.float32, seed=21)
+    coeffs = oracle_interp.hermite_bdiff_coeffs(x)
+    func = LinearField(H, C, torch.float32, scale=0.25, tanh=act, seed=5)
+    gen = torch.Generator().manual_seed(6)
+    z0 = torch.randn(B, H, generator=gen)
+    t_out = torch.tensor([0., 7.5, 23.])
+    lw = torch.rand(B, 3, H, generator=gen) + 0.5
+    ref_out, ref_gz, ref_gw, ref_gb = _oracle_solution(coeffs, None, func, z0, t_out, 1.0, lw)
+
+    dfunc = LinearField(H, C, torch.float32, scale=0.25, tanh=act, seed=5).to(DEV)
+    X = native.CubicSpline(coeffs.to(DEV))
+    z = z0.to(DEV).requires_grad_(True)
+    out = native.cdeint(X, dfunc, z, t_out.to(DEV), method="rk4", options=dict(step_size=1.0), variant=variant)
+    _close(out, ref_out, 1e-4, 1e-6)
+    (out * lw.to(DEV)).sum().backward()
+    _close(z.grad, ref_gz, 1e-3, 1e-5)
+    _close(dfunc.linear.weight.grad, ref_gw, 1e-3, 1e-3 * ref_gw.abs().max().item())
+    _close(dfunc.linear.bias.grad, ref_gb, 1e-3, 1e-3 * ref_gb.abs().max().item())
+
+
+def test_linear_control_path(native):
+    """LinearInterpolation control (config 4's control type) through the same fused kernels."""
+    B, L, C, H = 70, 20, 8, 32
+    x = make_series(B, L, C, torch.float32, seed=2)
+    func = LinearField(H, C, torch.float32, scale=0.25, seed=1)
+    z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(1))
+    f64 = LinearField(H, C, torch.float64, scale=0.25, seed=1)
+    Xo = oracle_interp.LinearPath(x.double())
+    z = z0.double().requires_grad_(True)
+    ref = oracle_cde.cdeint(Xo, f64, z, Xo.interval, adjoint=True, method="rk4", options=dict(step_size=0.5))
+    ref.sum().backward()
+    for variant in ("mfma", "generic"):
+        dfunc = LinearField(H, C, torch.float32, scale=0.25, seed=1).to(DEV)
+        X = native.LinearInterpolation(native.linear_interpolation_coeffs(x.to(DEV)))
+        zd = z0.to(DEV).requires_grad_(True)
+        out = native.cdeint(X, dfunc, zd, X.interval, method="rk4", options=dict(step_size=0.5), variant=variant)
+        _close(out, ref, 1e-4, 1e-6)
+        out.sum().backward()
+        _close(zd.grad, z.grad, 1e-3, 1e-5)
+        _close(dfunc.linear.weight.grad, f64.linear.weight.grad, 1e-3, 1e-3 * f64.linear.weight.grad.abs().max().item())
+
+
+def test_float64_generic_kernel_vs_oracle_tight(native):
+    B, L, C, H = 9, 11, 3, 5
+    x = make_series(B, L, C, torch.float64, seed=8)
+    knots = (torch.rand(L, dtype=torch.float64).cumsum(0) + 0.3)
+    coeffs = oracle_interp.hermite_bdiff_coeffs(x, knots)
+    func = LinearField(H, C, torch.float64, scale=0.5, tanh=True, seed=4)
+    z0 = torch.randn(B, H, dtype=torch.float64, generator=torch.Generator().manual_seed(4))
+    t_out = torch.stack([knots[0], (knots[0] + knots[-1]) / 2, knots[-1]])
+    ref_out, ref_gz, ref_gw, ref_gb = _oracle_solution(coeffs, knots, func, z0, t_out, 0.4)
+    dfunc = LinearField(H, C, torch.float64, scale=0.5, tanh=True, seed=4).to(DEV)
+    X = native.CubicSpline(coeffs.to(DEV), knots.to(DEV))
+    z = z0.to(DEV).requires_grad_(True)
+    out = native.cdeint(X, dfunc, z, t_out.to(DEV), method="rk4", options=dict(step_size=0.4))
+    _close(out, ref_out, 1e-10, 1e-12)
+    out.sum().backward()
+    _close(z.grad, ref_gz, 1e-9, 1e-11)
+    _close(dfunc.linear.weight.grad, ref_gw, 1e-9, 1e-10)
+    _close(dfunc.linear.bias.grad, ref_gb, 1e-9, 1e-10)
+
+
+def test_batch_dims_time_dtype_and_adjoint_params(native):
+    """(2,3) batch dims, float64 output times with float32 state (reference test_cdeint.py:43), adjoint_params subset."""
+    x = make_series(6, 10, 2, torch.float32, seed=12).view(2, 3, 10, 2)
+    coeffs = native.hermite_cubic_coefficients_with_backward_differences(x.to(DEV))
+    X = native.CubicSpline(coeffs)
+    func = LinearField(3, 2, scale=0.5, seed=2).to(DEV)
+    z0 = torch.rand(2, 3, 3, device=DEV, requires_grad=True)
+    t = torch.tensor([0.4, 3.3, 8.1], dtype=torch.float64, device=DEV)
+    out = native.cdeint(X, func, z0, t, method="rk4", options=dict(step_size=1.0),
+                        adjoint_params=(func.linear.weight,))
+    assert out.shape == (2, 3, 3, 3)
+    out.sum().backward()
+    assert func.linear.weight.grad is not None and func.linear.bias.grad is None and z0.grad.shape == z0.shape
+    fo = LinearField(3, 2, scale=0.5, seed=2)
+    Xo = oracle_interp.CubicPath(oracle_interp.hermite_bdiff_coeffs(x))
+    ref = oracle_cde.cdeint(Xo, fo, z0.detach().cpu(), t.cpu(), adjoint=False, method="rk4", options=dict(step_size=1.0))
+    _close(out, ref, 1e-4, 1e-6)
+
+
+def test_gradients_are_run_to_run_deterministic(native):
+    """Parameter gradients are reduced in a fixed order (no atomics): two runs are bit-identical, which is
+    what the reference's detach-trick test relies on (test/test_tricks.py:111-131)."""
+    B, L = 1000, 32
+    coeffs = native.hermite_cubic_coefficients_with_backward_differences(make_series(B, L, 8, seed=9).to(DEV))
+    X = native.CubicSpline(coeffs)
+    func = LinearField(32, 8, scale=0.25).to(DEV)
+    z0 = torch.randn(B, 32, device=DEV)
+    grads = []
+    for _ in range(2):
+        func.zero_grad()
+        z = z0.clone().requires_grad_(True)
+        native.cdeint(X, func, z, X.interval, method="rk4", options=dict(step_size=1.0))[:, -1].sum().backward()
+        grads.append((z.grad.clone(), func.linear.weight.grad.clone(), func.linear.bias.grad.clone()))
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
+
+
+def test_unsupported_requests_fail_loudly(native):
+    coeffs = torch.randn(4, 5, 8, device=DEV)
+    X = native.CubicSpline(coeffs)
+    func = LinearField(3, 2).to(DEV)
+    z0 = torch.randn(4, 3, device=DEV)
+    with pytest.raises(NotImplementedError, match="dopri5"):
+        native.cdeint(X, func, z0, X.interval)
+    with pytest.raises(ValueError, match="same number of batch dimensions as z0"):
+        native.cdeint(X, func, torch.randn(5, 3, device=DEV), X.interval, method="rk4")
+    with pytest.raises(ValueError, match="same number of input channels"):
+        native.cdeint(X, LinearField(3, 4).to(DEV), z0, X.interval, method="rk4")
+
+    class Mlp(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b = torch.nn.Linear(3, 7), torch.nn.Linear(7, 6)
+
+        def forward(self, t, z):
+            return self.b(self.a(z).relu()).view(4, 3, 2)
+
+    with pytest.raises(NotImplementedError, match="affine family"):
+        native.cdeint(X, Mlp().to(DEV), z0, X.interval, method="rk4")
+    z = z0.clone().requires_grad_(True)
+    out = native.cdeint(X, func, z, X.interval, adjoint=False, method="rk4", options=dict(step_size=1.0))
+    with pytest.raises(NotImplementedError, match="adjoint=False"):
+        out.sum().backward()
+
+
+# =========================================================================================== full size
+def test_full_size_properties_config2_config3(native):
+    """BASELINE configs 2/3 (B=32768, L=128, C=8, H=32, fp32, RK4 step 1): size-independent properties.
+      * series independence: reversing the batch reverses the result bit-for-bit
+      * affine structure: z_T is an affine map of z0 for the affine field, RK4 preserves that
+      * MFMA kernel == generic kernel == float64 oracle on a sample of series (trajectory + grad_z0)
+      * parameter gradients of the two kernels agree"""
+    B, L, C, H = 32768, 128, 8, 32
+    x = make_series(B, L, C, seed=0).to(DEV)
+    coeffs = native.hermite_cubic_coefficients_with_backward_differences(x)
+    X = native.CubicSpline(coeffs)
+    func = LinearField(H, C, scale=0.25, seed=0).to(DEV)
+    z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(0)).to(DEV)
+    kw = dict(method="rk4", options=dict(step_size=1.0))
+
+    z = z0.clone().requires_grad_(True)
+    out = native.cdeint(X, func, z, X.interval, **kw)
+    assert out.shape == (B, 2, H) and torch.isfinite(out).all()
+    assert torch.equal(out[:, 0], z0)
+    out[:, -1].sum().backward()
+    gW, gb, gz = func.linear.weight.grad.clone(), func.linear.bias.grad.clone(), z.grad.clone()
+
+    # series independence (bit-exact)
+    Xr = native.CubicSpline(coeffs.flip(0).contiguous())
+    out_r = native.cdeint(Xr, func, z0.flip(0).contiguous(), X.interval, **kw)
+    assert torch.equal(out_r.flip(0), out.detach())
+
+    # affine in z0: z(a) + z(b) - 2 z((a+b)/2) = 0
+    zb = torch.randn(B, H, generator=torch.Generator().manual_seed(1)).to(DEV)
+    mid = native.cdeint(X, func, 0.5 * (z0 + zb), X.interval, **kw)[:, -1]
+    other = native.cdeint(X, func, zb, X.interval, **kw)[:, -1]
+    resid = (out.detach()[:, -1] + other - 2 * mid).abs().max().item()
+    assert resid < 1e-4 * max(1.0, out.detach().abs().max().item()), resid
+
+    # sample vs float64 oracle and vs the generic kernel
+    sample = torch.arange(0, B, 2048, device=DEV)
+    Xs = native.CubicSpline(coeffs[sample].contiguous())
+    zs = z0[sample].clone().requires_grad_(True)
+    func_g = LinearField(H, C, scale=0.25, seed=0).to(DEV)
+    out_g = native.cdeint(Xs, func_g, zs, X.interval, variant="generic", **kw)
+    _close(out.detach()[sample], out_g, 1e-4, 1e-6)
+    out_g[:, -1].sum().backward()
+    _close(gz[sample], zs.grad, 1e-3, 1e-5)
+    ref_out, ref_gz, _, _ = _oracle_solution(coeffs[sample].cpu(), None, LinearField(H, C, scale=0.25, seed=0),
+                                             z0[sample].cpu(), X.interval.cpu(), 1.0,
+                                             torch.cat([torch.zeros(len(sample), 1, H), torch.ones(len(sample), 1, H)], 1))
+    _close(out.detach()[sample], ref_out, 1e-4, 1e-6)
+    _close(gz[sample], ref_gz, 1e-3, 1e-5)
+
+    # parameter gradients: MFMA kernel vs generic kernel on a 4096-series slab
+    slab = slice(0, 4096)
+    res = []
+    for variant in ("mfma", "generic"):
+        f = LinearField(H, C, scale=0.25, seed=0).to(DEV)
+        zz = z0[slab].clone().requires_grad_(True)
+        o = native.cdeint(native.CubicSpline(coeffs[slab].contiguous()), f, zz, X.interval, variant=variant, **kw)
+        o[:, -1].sum().backward()
+        res.append((f.linear.weight.grad.clone(), f.linear.bias.grad.clone()))
+    _close(res[0][0], res[1][0], 1e-3, 1e-4 * res[1][0].abs().max().item())
+    _close(res[0][1], res[1][1], 1e-3, 1e-4 * res[1][1].abs().max().item())
+    assert torch.isfinite(gW).all() and torch.isfinite(gb).all()

@@ -1,0 +1,242 @@
+"""CPU tests of the host logic: C-ABI library loads and exports what the header declares, error
+behaviour mirrors the reference, solver grids equal the oracle's, field recognition, and a lane-level
+emulation of the MFMA operand layouts used by csrc/rk4_mfma.hip (index math only -- no GPU compute)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import torchcde_amd
+from torchcde_amd import _lib
+from torchcde_amd.cdeint import _fixed_grid, _parse_fixed_options
+from torchcde_amd.fields import probe
+from oracle import odeint as oracle_ode
+from helpers import LinearField
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------ the boundary
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    torchcde_amd.build()
+    lib = torchcde_amd.load()
+    header = open(os.path.join(ROOT, "include", "cde_mi355x.h")).read()
+    declared = set(re.findall(r"\b(cde_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    raw = ctypes.CDLL(_lib.SO_PATH)
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert lib.cde_abi_version() == 1
+    assert lib.cde_error_string(0) == b"ok"
+    assert b"workspace" in lib.cde_error_string(-5)
+
+
+def test_argument_errors_come_back_as_codes_without_a_gpu():
+    lib = torchcde_amd.load()
+    null = ctypes.c_void_p(0)
+    assert lib.cde_hermite_bdiff_coeffs(null, null, null, 4, 1, 3, 0, null) == -3      # L < 2
+    assert lib.cde_hermite_bdiff_coeffs(null, null, null, 4, 5, 3, 0, null) == -1      # NULL pointers
+    assert lib.cde_hermite_bdiff_coeffs(null, null, null, 0, 5, 3, 0, null) == 0       # empty batch is a no-op
+    assert lib.cde_path_eval(null, null, null, 3, null, 2, 0, 3, 3, 1, 0, null) == -3
+    assert lib.cde_rk4_adjoint_workspace_bytes(32768, 8, 32, 128, 0, 2) > 1024 * 8448 * 4
+
+
+def test_no_cpu_fallback():
+    x = torch.randn(2, 5, 3)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        torchcde_amd.hermite_cubic_coefficients_with_backward_differences(x)
+    X = torchcde_amd.CubicSpline(torch.randn(2, 4, 12))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        X.derivative(torch.tensor(0.5))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        torchcde_amd.cdeint(X, LinearField(4, 3), torch.randn(2, 4), X.interval, method="rk4")
+
+
+def test_reference_error_messages():
+    hermite = torchcde_amd.hermite_cubic_coefficients_with_backward_differences
+    with pytest.raises(ValueError, match="floating point"):
+        hermite(torch.zeros(3, 4, 2, dtype=torch.int64))
+    with pytest.raises(ValueError, match="at least two dimensions"):
+        hermite(torch.zeros(3))
+    with pytest.raises(ValueError, match="monotonically increasing"):
+        hermite(torch.zeros(2, 3, 1), torch.tensor([0., 2., 1.]))
+    with pytest.raises(ValueError, match="time dimension of X must equal"):
+        hermite(torch.zeros(2, 3, 1), torch.tensor([0., 1.]))
+    with pytest.raises(ValueError, match="Passed invalid coeffs"):
+        torchcde_amd.CubicSpline(torch.zeros(2, 3, 7))
+    X = torchcde_amd.CubicSpline(torch.zeros(2, 3, 8))
+    assert torch.equal(X.interval, torch.tensor([0., 3.]))
+    assert torch.equal(X.grid_points, torch.linspace(0, 3, 4))
+    assert set(dict(X.named_buffers())) == {"_t", "_a", "_b", "_two_c", "_three_d"}
+    with pytest.raises(ValueError, match="X must have a 'derivative' method"):
+        torchcde_amd.cdeint(object(), LinearField(4, 2), torch.zeros(2, 4), torch.tensor([0., 1.]))
+    with pytest.raises(ValueError, match="Unrecognised backend=foo"):
+        torchcde_amd.cdeint(X, LinearField(4, 2), torch.zeros(2, 4), torch.tensor([0., 1.]), backend="foo")
+    with pytest.raises(ValueError, match="z0 must either a tensor"):
+        torchcde_amd.cdeint(X, LinearField(4, 2), 3.0, torch.tensor([0., 1.]))
+
+
+def test_packed_view_is_recovered_without_copy():
+    coeffs = torch.randn(3, 5, 16)
+    X = torchcde_amd.CubicSpline(coeffs)
+    packed = X._packed()
+    assert packed.data_ptr() == coeffs.data_ptr() and torch.equal(packed, coeffs)
+    Y = torchcde_amd.CubicSpline(coeffs).double()          # buffers re-materialised separately
+    assert torch.equal(Y._packed(), coeffs.double())
+
+
+# ------------------------------------------------------------------ solver grids
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_fixed_grid_equals_oracle(dtype):
+    for lo, hi, h in ((0., 127., 1.0), (0., 9., 0.7), (0.3, 4.1, 0.25), (-2., 3., 10.)):
+        t = torch.tensor([lo, (lo + hi) / 2, hi], dtype=dtype)
+        assert torch.equal(_fixed_grid(t, h), oracle_ode._grid_from_step(t, h))
+    t = torch.tensor([0., 1., 4.], dtype=dtype)
+    assert torch.equal(_fixed_grid(t, None), t)            # torchdiffeq: no step_size => grid = t
+
+
+def test_option_parsing():
+    assert _parse_fixed_options(dict(step_size=0.5), "solver") == 0.5
+    assert _parse_fixed_options(None, "solver") is None
+    with pytest.raises(NotImplementedError):
+        _parse_fixed_options(dict(grid_constructor=lambda *a: None), "solver")
+    with pytest.raises(NotImplementedError):
+        _parse_fixed_options(dict(step_size=1.0, bogus=1), "solver")
+
+
+# ------------------------------------------------------------------ vector-field recognition
+def test_probe_accepts_exactly_the_affine_family():
+    z, t = torch.randn(4, 3), torch.tensor(0.25)
+
+    class Readme(torch.nn.Module):                       # reference README.md:42-49
+        def __init__(self):
+            super().__init__()
+            self.linear = torch.nn.Linear(3, 6)
+
+        def forward(self, t, z):
+            return self.linear(z).view(4, 3, 2)
+
+    class Irregular(Readme):                             # reference example/irregular_data.py:36-46
+        def forward(self, t, z):
+            return self.linear(z).tanh().view(*z.shape[:-1], 3, 2)
+
+    class TimeDependent(Readme):
+        def forward(self, t, z):
+            return (self.linear(z) * (1 + t)).view(4, 3, 2)
+
+    class Scaled(Readme):
+        def forward(self, t, z):
+            return (self.linear(z) * 1.0001).view(4, 3, 2)
+
+    class TwoLayer(torch.nn.Module):                     # example/time_series_classification.py:37-51
+        def __init__(self):
+            super().__init__()
+            self.l1, self.l2 = torch.nn.Linear(3, 5), torch.nn.Linear(5, 6)
+
+        def forward(self, t, z):
+            return self.l2(self.l1(z).relu()).tanh().view(4, 3, 2)
+
+    field, system = probe(Readme(), t, z)
+    assert field is not None and field.act == _lib.ACT_NONE and system.shape == (4, 3, 2)
+    field, _ = probe(Irregular(), t, z)
+    assert field is not None and field.act == _lib.ACT_TANH
+    field, _ = probe(torchcde_amd.LinearCDEFunc(2, 3, tanh=True), t, z)
+    assert field is not None and field.act == _lib.ACT_TANH
+    for bad in (TimeDependent(), Scaled(), TwoLayer()):
+        field, system = probe(bad, t, z)
+        assert field is None and system.shape == (4, 3, 2)
+
+
+# ------------------------------------------------------------------ MFMA operand layouts (emulated)
+def _mfma_32x32x2(a_lane, b_lane, acc):
+    """v_mfma_f32_32x32x2_f32 lane semantics (cdna_hip_programming.md section 3): lane l supplies
+    A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31]; register r of lane l holds D[(r&3)+8(r>>2)+4(l>>5)][l&31]."""
+    A = np.zeros((32, 2)); Bm = np.zeros((2, 32))
+    for l in range(64):
+        A[l & 31, l >> 5] = a_lane[l]
+        Bm[l >> 5, l & 31] = b_lane[l]
+    P = A @ Bm
+    for l in range(64):
+        for r in range(16):
+            acc[l, r] += P[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5), l & 31]
+
+
+def _rho(i):
+    return 2 * ((i & 3) + 4 * (i >> 3)) + ((i >> 2) & 1)
+
+
+def _w1_image(W, bias, s, l, H=32, C=8):
+    h_out, hk = _rho(l & 31), l >> 5
+    if s < 128:
+        j, c = s >> 3, s & 7
+        return W[(h_out * C + c), 2 * j + hk]
+    return bias[h_out * C + 2 * (s - 128) + hk]
+
+
+def _w2_image(W, s, l, H=32, C=8):
+    k_out, hk = _rho(l & 31), l >> 5
+    j, c = s >> 3, s & 7
+    return W[(2 * j + hk) * C + c, k_out]
+
+
+def test_mfma_operand_layouts_reproduce_the_vector_field_and_its_vjps():
+    rng = np.random.default_rng(0)
+    H, C = 32, 8
+    W = rng.standard_normal((H * C, H)); bias = rng.standard_normal(H * C)
+    z = rng.standard_normal((32, H)); a = rng.standard_normal((32, H)); dX = rng.standard_normal((32, C))
+    Y = z @ W.T + bias                                            # (32, H*C)
+    f_ref = np.einsum("nhc,nc->nh", Y.reshape(32, H, C), dX)
+    gY = (a[:, :, None] * dX[:, None, :]).reshape(32, H * C)      # a_h dX_c
+    vjp_ref = gY @ W                                              # (a^T df/dz)
+    gW_ref = gY.T @ z                                             # dL/dW
+    gb_ref = gY.sum(0)
+
+    lanes = np.arange(64)
+    n, half = lanes & 31, lanes >> 5
+    own = lambda v: np.stack([v[n, 2 * r + half] for r in range(16)], axis=1)   # lane register r <-> unit 2r+half
+    z_own, a_own = own(z), own(a)
+
+    # f chain (chain_field): 128 product steps + 4 bias steps
+    acc = np.zeros((64, 16))
+    for j in range(16):
+        for c in range(8):
+            s = 8 * j + c
+            _mfma_32x32x2([_w1_image(W, bias, s, l) for l in lanes], z_own[:, j] * dX[n, c], acc)
+    for sp in range(4):
+        _mfma_32x32x2([_w1_image(W, bias, 128 + sp, l) for l in lanes], dX[n, 2 * sp + half], acc)
+    assert np.allclose(acc, own(f_ref))
+
+    # vjp chain (chain_vjp)
+    acc = np.zeros((64, 16))
+    for j in range(16):
+        for c in range(8):
+            _mfma_32x32x2([_w2_image(W, 8 * j + c, l) for l in lanes], a_own[:, j] * dX[n, c], acc)
+    assert np.allclose(acc, own(vjp_ref))
+
+    # dL/dW through the (series -> K) LDS transpose: scratch rows have stride 33
+    scr_y = np.zeros(32 * 33); scr_a = np.zeros(32 * 33); scr_dx = np.zeros(32 * 8)
+    for l in lanes:
+        for r in range(16):
+            scr_y[n[l] * 33 + 2 * r + half[l]] = z_own[l, r]
+            scr_a[n[l] * 33 + 2 * r + half[l]] = a_own[l, r]
+        scr_dx[n[l] * 8 + 4 * half[l]: n[l] * 8 + 4 * half[l] + 4] = dX[n[l], 4 * half[l]: 4 * half[l] + 4]
+    accW = np.zeros((8, 64, 16)); gb = np.zeros((64, 8))
+    for s2 in range(16):
+        zb = scr_y[half * 33 + n + s2 * 66]
+        aa = scr_a[half * 33 + n + s2 * 66]
+        for c in range(8):
+            d = scr_dx[half * 8 + s2 * 16 + c]
+            gb[:, c] += aa * d
+            _mfma_32x32x2(aa * d, zb, accW[c])
+    gW = np.zeros((H * C, H)); gbv = np.zeros(H * C)
+    for l in lanes:
+        for c in range(8):
+            for r in range(16):
+                h = (r & 3) + 8 * (r >> 2) + 4 * half[l]
+                gW[h * C + c, n[l]] = accW[c, l, r]
+            if half[l] == 0:
+                gbv[n[l] * C + c] = gb[l, c] + gb[l + 32, c]
+    assert np.allclose(gW, gW_ref) and np.allclose(gbv, gb_ref)

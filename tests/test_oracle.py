@@ -1,0 +1,191 @@
+"""CPU tests of the oracle itself: pinned against the reference's golden vectors and known answers
+(interpolation half) and anchored by mathematics (solver half, PARITY UNPINNED -- see oracle/odeint.py)."""
+import math
+
+import pytest
+import torch
+
+from oracle import cde, interp, odeint
+from helpers import LinearField, golden_field, make_series
+
+
+# ------------------------------------------------------------------ interpolation: golden vectors
+def test_hermite_matches_reference_golden(golden_interp):
+    for case in golden_interp:
+        got = interp.hermite_bdiff_coeffs(case["x"], case["t"])
+        assert torch.equal(got, case["coeffs"])
+
+
+def test_locate_evaluate_derivative_match_reference_golden(golden_interp):
+    for case in golden_interp:
+        coeffs, knots, tq = case["coeffs"], case["knots"], case["tq"]
+        frac, index = interp.locate(tq, knots, coeffs.size(-2), coeffs.dtype, "cpu")
+        assert index.dtype == torch.int64 and torch.equal(index, case["index"])
+        assert torch.equal(frac, case["frac"])
+        assert torch.equal(interp.cubic_value(coeffs, knots, tq), case["value"])
+        assert torch.equal(interp.cubic_slope(coeffs, knots, tq), case["slope"])
+        lin = interp.LinearPath(case["x"], case["t"])
+        lfrac, lindex = lin._interpret_t(tq)
+        assert torch.equal(lindex, case["lin_index"]) and torch.equal(lfrac, case["lin_frac"])
+        assert torch.equal(lin.evaluate(tq), case["lin_value"])
+        assert torch.equal(lin.derivative(tq), case["lin_slope"])
+
+
+def test_hermite_unit_time_known_answer():
+    """The reference's closed-form KAT (test/test_hermite_cubic.py:6-38): with unit knot spacing
+    two_c = 4(d_next - d_prev), three_d = -3(d_next - d_prev)."""
+    gen = torch.Generator().manual_seed(3)
+    for C in (1, 3, 6):
+        for batch in ((1,), (2, 3)):
+            for L in (2, 5, 10):
+                data = torch.randn(*batch, L, C, generator=gen, dtype=torch.float64)
+                coeffs = interp.hermite_bdiff_coeffs(data)
+                nxt = data[..., 1:, :] - data[..., :-1, :]
+                prv = torch.cat([nxt[..., [0], :], nxt[..., :-1, :]], dim=-2)
+                a, b, two_c, three_d = data[..., :-1, :], prv, 4 * (nxt - prv), -3 * (nxt - prv)
+                knots = torch.linspace(0, L - 1, L, dtype=torch.float64)
+                for time in torch.linspace(0, L, 10):
+                    frac, index = interp.locate(time, knots, L - 1, torch.float64, "cpu")
+                    f = frac.unsqueeze(-1)
+                    inner = 0.5 * two_c[..., index, :] + three_d[..., index, :] * f / 3
+                    expect = a[..., index, :] + (b[..., index, :] + inner * f) * f
+                    assert torch.allclose(interp.cubic_value(coeffs, knots, time), expect)
+
+
+def test_knots_are_interpolated_and_derivative_is_consistent():
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 9, 4, generator=gen, dtype=torch.float64)
+    t = torch.rand(9, generator=gen, dtype=torch.float64).cumsum(0) + 0.1
+    coeffs = interp.hermite_bdiff_coeffs(x, t)
+    assert torch.allclose(interp.cubic_value(coeffs, t, t), x, atol=1e-12)
+    tq = (torch.rand(17, generator=gen, dtype=torch.float64) * (t[-1] - t[0]) + t[0]).requires_grad_(True)
+    val = interp.cubic_value(coeffs, t, tq)
+    for c in range(4):
+        (g,) = torch.autograd.grad(val[0, :, c].sum(), tq, retain_graph=True)
+        assert torch.allclose(g, interp.cubic_slope(coeffs, t, tq)[0, :, c].detach(), atol=1e-10)
+
+
+def test_validation_errors():
+    with pytest.raises(ValueError, match="floating point"):
+        interp.check_path(torch.zeros(3, 4, dtype=torch.int64), None)
+    with pytest.raises(ValueError, match="at least two dimensions"):
+        interp.check_path(torch.zeros(3), None)
+    with pytest.raises(ValueError, match="monotonically increasing"):
+        interp.check_path(torch.zeros(2, 3, 1), torch.tensor([0., 2., 1.]))
+    with pytest.raises(ValueError, match="time dimension of X must equal"):
+        interp.check_path(torch.zeros(2, 3, 1), torch.tensor([0., 1.]))
+    with pytest.raises(ValueError, match="size at least 2"):
+        interp.check_path(torch.zeros(2, 1, 1), torch.tensor([0.]))
+    with pytest.raises(ValueError, match="invalid coeffs"):
+        interp.CubicPath(torch.zeros(2, 3, 7))
+
+
+# ------------------------------------------------------------------ solver plumbing: golden vectors
+def test_cdeint_matches_reference_solver_golden(golden_cde):
+    for case in golden_cde:
+        func = golden_field(case)
+        X = interp.CubicPath(case["coeffs"], case["knots"])
+        kwargs = {}
+        if case["method"] is not None:
+            kwargs["method"] = case["method"]
+        if case["options"] is not None:
+            kwargs["options"] = case["options"]
+        for adjoint, tag in ((False, "direct"), (True, "adjoint")):
+            z0 = case["z0"].clone().requires_grad_(True)
+            func.zero_grad()
+            out = cde.cdeint(X, func, z0, case["t_out"], adjoint=adjoint, **kwargs)
+            w = torch.linspace(0.5, 1.5, out.numel(), dtype=out.dtype).view_as(out)
+            (out * w).sum().backward()
+            assert torch.equal(out, case["out_" + tag]), case["name"]
+            assert torch.equal(z0.grad, case["gz0_" + tag]), case["name"]
+            assert torch.equal(func.linear.weight.grad, case["gW_" + tag]), case["name"]
+            assert torch.equal(func.linear.bias.grad, case["gb_" + tag]), case["name"]
+
+
+# ------------------------------------------------------------------ solver mathematics (unpinned half)
+def _scalar_control_problem(dtype=torch.float64):
+    """dz = (A z) dX with a one-channel control: exact solution z(T) = expm(A (X(T)-X(0))) z0."""
+    gen = torch.Generator().manual_seed(11)
+    L, H = 9, 4
+    x = torch.randn(2, L, 1, generator=gen, dtype=dtype).cumsum(1) * 0.3
+    A = torch.randn(H, H, generator=gen, dtype=dtype) * 0.4
+    z0 = torch.randn(2, H, generator=gen, dtype=dtype)
+
+    class F(torch.nn.Module):
+        def forward(self, t, z):
+            return (z @ A.T).unsqueeze(-1)
+
+    coeffs = interp.hermite_bdiff_coeffs(x)
+    X = interp.CubicPath(coeffs)
+    dX = (x[:, -1, 0] - x[:, 0, 0])
+    exact = torch.stack([torch.linalg.matrix_exp(A * dX[i]) @ z0[i] for i in range(2)])
+    return X, F(), z0, exact
+
+
+def test_rk4_is_fourth_order():
+    X, f, z0, exact = _scalar_control_problem()
+    errs = []
+    for h in (0.5, 0.25, 0.125):
+        out = cde.cdeint(X, f, z0, X.interval, adjoint=False, method="rk4", options=dict(step_size=h))
+        errs.append((out[:, -1] - exact).abs().max().item())
+    assert errs[0] / errs[1] > 10 and errs[1] / errs[2] > 10, errs      # ~16 for a 4th-order method
+    assert errs[2] < 1e-5
+
+
+def test_dopri5_converges_with_tolerance():
+    X, f, z0, exact = _scalar_control_problem()
+    errs = []
+    for tol in (1e-4, 1e-7, 1e-10):
+        out = cde.cdeint(X, f, z0, X.interval, adjoint=False, method="dopri5", rtol=tol, atol=tol * 1e-2,
+                         options=dict(jump_t=X.grid_points))
+        errs.append((out[:, -1] - exact).abs().max().item())
+    assert errs[0] > errs[2] and errs[2] < 1e-8, errs
+
+
+def test_rk4_grid_and_output_interpolation():
+    t = torch.tensor([0., 0.3, 2.5, 3.0])
+    grid = odeint._grid_from_step(t, 1.0)
+    assert torch.equal(grid, torch.tensor([0., 1., 2., 3.]))
+    # outputs between grid points are linear interpolants of the step end points
+    sol = odeint.odeint(lambda tt, y: torch.ones_like(y) * 2.0, torch.zeros(1), t, method="rk4",
+                        options=dict(step_size=1.0))
+    assert torch.allclose(sol[:, 0], 2 * t)
+
+
+def test_adjoint_matches_backprop_through_solver():
+    gen = torch.Generator().manual_seed(2)
+    B, L, C, H = 5, 12, 3, 6
+    x = make_series(B, L, C, torch.float64, seed=4)
+    X = interp.CubicPath(interp.hermite_bdiff_coeffs(x))
+    z0 = torch.randn(B, H, generator=gen, dtype=torch.float64)
+    t_out = torch.tensor([0., 2.5, 7.25, 11.], dtype=torch.float64)
+    for tanh in (False, True):
+        func = LinearField(H, C, torch.float64, scale=0.25, tanh=tanh, seed=9)
+        gaps = []
+        for step in (0.25, 0.125):
+            grads = []
+            for adjoint in (False, True):
+                z = z0.clone().requires_grad_(True)
+                func.zero_grad()
+                out = cde.cdeint(X, func, z, t_out, adjoint=adjoint, method="rk4", options=dict(step_size=step))
+                (out ** 2).sum().backward()
+                grads.append((out.detach(), z.grad.clone(), func.linear.weight.grad.clone(),
+                              func.linear.bias.grad.clone()))
+            assert torch.equal(grads[0][0], grads[1][0])     # same forward pass
+            gaps.append(max(((d - a).abs().max() / d.abs().max()).item() for d, a in zip(grads[0][1:], grads[1][1:])))
+        # continuous adjoint vs discretise-then-optimise differ only by the RK4 truncation error: small, and
+        # shrinking fast with the step
+        assert gaps[1] < 1e-4 and gaps[1] < gaps[0] / 6, gaps
+
+
+def test_gradcheck_direct_float64():
+    gen = torch.Generator().manual_seed(8)
+    x = make_series(2, 6, 2, torch.float64, seed=1)
+    X = interp.CubicPath(interp.hermite_bdiff_coeffs(x))
+    func = LinearField(3, 2, torch.float64, scale=0.5, seed=3)
+    z0 = torch.randn(2, 3, generator=gen, dtype=torch.float64, requires_grad=True)
+
+    def run(z):
+        return cde.cdeint(X, func, z, X.interval, adjoint=False, method="rk4", options=dict(step_size=1.0))
+
+    assert torch.autograd.gradcheck(run, (z0,), atol=1e-7)

@@ -1,0 +1,14 @@
+"""torchcde_amd -- the MI355X-native Neural-CDE hot path behind torchcde's API.
+
+Drop-in names (reference ``torchcde/__init__.py:1-7``): ``hermite_cubic_coefficients_with_backward_differences``,
+``linear_interpolation_coeffs``, ``CubicSpline`` (+ ``NaturalCubicSpline`` alias), ``LinearInterpolation``,
+``InterpolationBase``, ``cdeint``.  Everything numerical runs in hand-written HIP kernels (gfx950) loaded from
+``libcde_mi355x.so`` through the C ABI of ``include/cde_mi355x.h``; there is no eager or CPU fallback.
+"""
+from ._lib import build, load, SO_PATH
+from .paths import (InterpolationBase, CubicSpline, NaturalCubicSpline, LinearInterpolation,
+                    hermite_cubic_coefficients_with_backward_differences, linear_interpolation_coeffs)
+from .fields import LinearCDEFunc
+from .cdeint import cdeint
+
+__version__ = "0.1.0"

@@ -1,0 +1,117 @@
+"""Build + ctypes binding of libcde_mi355x.so (the C ABI declared in include/cde_mi355x.h).
+
+The shared object is built in-tree by ``build()`` (hipcc, gfx950 only) and loaded lazily.
+There is NO fallback: if the library is missing or a call returns a non-zero code, a
+RuntimeError is raised.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(_HERE, "libcde_mi355x.so")
+SOURCES = ["interp_kernels.hip", "rk4_generic.hip", "rk4_mfma.hip", "api.hip"]
+HEADERS = [os.path.join(_CSRC, "cde_common.h"), os.path.join(_HERE, "..", "include", "cde_mi355x.h")]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC"]
+
+F32, F64 = 0, 1
+PATH_LINEAR, PATH_CUBIC = 1, 3
+EVAL_VALUE, EVAL_DERIVATIVE = 0, 1
+ACT_NONE, ACT_TANH = 0, 1
+VARIANT_AUTO, VARIANT_GENERIC, VARIANT_MFMA = 0, 1, 2
+
+_lib = None
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def _stale():
+    if not os.path.exists(SO_PATH):
+        return True
+    built = os.path.getmtime(SO_PATH)
+    deps = [os.path.join(_CSRC, s) for s in SOURCES] + HEADERS
+    return any(os.path.exists(d) and os.path.getmtime(d) > built for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into torchcde_amd/libcde_mi355x.so (cross-compiles without a GPU)."""
+    if not force and not _stale():
+        return SO_PATH
+    cmd = [_hipcc()] + HIPCC_FLAGS + [os.path.join(_CSRC, s) for s in SOURCES] + ["-o", SO_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + proc.stdout)
+    return SO_PATH
+
+
+_p, _i, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
+_SIGNATURES = {
+    "cde_abi_version": (_i, []),
+    "cde_error_string": (ctypes.c_char_p, [_i]),
+    "cde_hermite_bdiff_coeffs": (_i, [_p, _p, _p, _i64, _i64, _i64, _i, _p]),
+    "cde_interpret_t": (_i, [_p, _i64, _p, _i64, _p, _p, _i, _p]),
+    "cde_path_eval": (_i, [_p, _p, _p, _i64, _p, _i64, _i64, _i64, _i, _i, _i, _p]),
+    "cde_contract": (_i, [_p, _p, _p, _i64, _i64, _i64, _i, _p]),
+    "cde_rk4_forward_linear": (_i, [_p, _p, _i64, _i, _p, _p, _i, _p, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i, _i,
+                                    _i, _p, _p, _p]),
+    "cde_rk4_adjoint_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i, _i]),
+    "cde_rk4_adjoint_linear": (_i, [_p, _p, _i64, _i, _p, _p, _i, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _i64, _i64,
+                                    _i64, _i, _i, _i, _p, _sz, _p]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def load():
+    """Return the ctypes handle; raises (never falls back) if the extension is unavailable."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                "torchcde_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU/eager fallback." % SO_PATH)
+        lib = ctypes.CDLL(SO_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        if lib.cde_abi_version() != 1:
+            raise RuntimeError("torchcde_amd: ABI version mismatch in %s" % SO_PATH)
+        _lib = lib
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().cde_error_string(code).decode()
+        raise RuntimeError("torchcde_amd: %s failed: %s (code %d)" % (what, msg, code))
+
+
+def dtype_enum(dtype):
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.float64:
+        return F64
+    raise NotImplementedError("torchcde_amd: only float32 and float64 are supported on the native path, got %s" % dtype)
+
+
+def require_gpu(tensor, what):
+    if not tensor.is_cuda:
+        raise RuntimeError("torchcde_amd: %s must live on a ROCm device (got device %s). This package is the MI355X "
+                           "native path and has no CPU fallback." % (what, tensor.device))
+
+
+def stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(tensor):
+    return ctypes.c_void_p(tensor.data_ptr()) if tensor is not None else ctypes.c_void_p(0)

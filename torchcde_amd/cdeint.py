@@ -1,0 +1,318 @@
+"""``cdeint``: the drop-in solver front-end (host side of K2 / K3).
+
+Mirrors reference ``torchcde/solver.py:144-245`` -- same signature, defaults, ValueError messages
+and output layout ``(..., len(t), hidden)`` -- and replaces what lies behind it
+(``_VectorField.forward`` solver.py:117-135 and ``torchdiffeq.odeint[_adjoint]`` solver.py:226-227)
+by ONE fused HIP kernel per direction.  What the native path covers is stated explicitly; anything
+else raises ``NotImplementedError`` -- it never falls back to an eager/CPU computation.
+
+Native scope (round 1):
+  * X: ``torchcde_amd.CubicSpline`` or ``torchcde_amd.LinearInterpolation``
+  * func: the affine family recognised by ``torchcde_amd.fields`` (Linear(H, H*C) [+ tanh] viewed (..., H, C))
+  * backend "torchdiffeq", ``method='rk4'`` (torchdiffeq's 3/8-rule), ``options={'step_size': h}`` or no options
+    (grid = t, torchdiffeq's behaviour), increasing ``t``, tensor state
+  * gradients: continuous adjoint (``adjoint=True``) for z0 and the field's weight / bias
+"""
+import math
+import warnings
+
+import torch
+
+from . import _lib
+from .fields import probe
+from .paths import _NativePath
+
+_GRAD_WARNING = ("One of the inputs to the control path X requires gradients but "
+                 "`kwargs['adjoint_params']` has not been passed. This is probably a mistake: these "
+                 "inputs will not receive a gradient when using the adjoint method. Either have the input "
+                 "not require gradients (if that was unintended), or include it (and every other "
+                 "parameter needing gradients) in `adjoint_params`. For example:\n"
+                 "```\n"
+                 "coeffs = ...\n"
+                 "func = ...\n"
+                 "X = CubicSpline(coeffs)\n"
+                 "adjoint_params = tuple(func.parameters()) + (coeffs,)\n"
+                 "cdeint(X=X, func=func, ..., adjoint_params=adjoint_params)\n"
+                 "```")
+
+
+# ------------------------------------------------------------------------------------------ time grids
+def _fixed_grid(t, step_size):
+    """torchdiffeq's fixed-grid constructor, evaluated with the same torch ops on
+    the host: ``n = ceil((t[-1]-t[0])/h + 1)``; ``grid = arange(n)*h + t[0]``; ``grid[-1] = t[-1]``."""
+    if step_size is None:
+        grid = t.clone()
+    else:
+        n = torch.ceil((t[-1] - t[0]) / step_size + 1).item()
+        grid = torch.arange(0, n, dtype=t.dtype, device=t.device) * step_size + t[0]
+        grid[-1] = t[-1]
+    if not (grid[0] == t[0] and grid[-1] == t[-1]):
+        raise AssertionError("time grid does not span [t[0], t[-1]]")
+    return grid
+
+
+def _parse_fixed_options(options, what):
+    options = {} if options is None else dict(options)
+    step_size = options.pop("step_size", None)
+    if options.pop("grid_constructor", None) is not None:
+        raise NotImplementedError("torchcde_amd: %s option 'grid_constructor' is not supported natively" % what)
+    if options.pop("perturb", False):
+        raise NotImplementedError("torchcde_amd: %s option 'perturb' is not supported natively" % what)
+    if options.pop("interp", "linear") != "linear":
+        raise NotImplementedError("torchcde_amd: only interp='linear' is supported natively")
+    options.pop("norm", None)  # only used by adaptive solvers
+    if options:
+        raise NotImplementedError("torchcde_amd: unsupported %s options %s" % (what, sorted(options)))
+    return step_size
+
+
+class _Plan:
+    """Everything one cdeint call needs besides the differentiable tensors."""
+
+    # bench.py sets this to a list to receive ("forward" | "adjoint", start_event, end_event) around the
+    # C-ABI calls, recorded on the stream the kernels are launched on.
+    event_log = None
+
+    @staticmethod
+    def _mark():
+        if _Plan.event_log is None:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def __init__(self, path, field, batch, H, C, t, step_size, adjoint_step_size, adjoint, variant):
+        coeffs, knots, _ = path._native_inputs()
+        self.coeffs, self.knots = coeffs, knots
+        self.n_intervals = path._n_intervals()
+        self.degree = path._degree
+        self.act = field.act
+        self.batch, self.B, self.H, self.C = batch, coeffs.size(0), H, C
+        self.dtype = coeffs.dtype
+        self.device = coeffs.device
+        self.adjoint = adjoint
+        self.variant = variant
+        t_host = t.detach().cpu()
+        self.time_dtype = t_host.dtype
+        self.n_out = t_host.numel()
+        self.t_out = t_host.to(self.device)
+        self.grid = _fixed_grid(t_host, step_size).to(self.device)
+        self.adjoint_step_size = adjoint_step_size
+        self._t_host = t_host
+        self.stage_index = None
+        self.stage_frac = None
+
+    # forward: K2
+    def run_forward(self, z0, weight, bias):
+        lib = _lib.load()
+        out = torch.empty(self.B, self.n_out, self.H, dtype=self.dtype, device=self.device)
+        n_stage = 4 * max(self.grid.numel() - 1, 0)
+        self.stage_index = torch.empty(max(n_stage, 1), dtype=torch.int64, device=self.device)
+        self.stage_frac = torch.empty(max(n_stage, 1), dtype=self.dtype, device=self.device)
+        z0c = z0.detach().reshape(self.B, self.H).contiguous()
+        w = weight.detach().contiguous()
+        b = bias.detach().contiguous()
+        begin = self._mark()
+        _lib.check(lib.cde_rk4_forward_linear(
+            _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w), _lib.ptr(b),
+            self.act, _lib.ptr(z0c), _lib.ptr(self.grid), self.grid.numel(), _lib.ptr(self.t_out), self.n_out,
+            _lib.ptr(out), self.B, self.C, self.H, _lib.dtype_enum(self.dtype), _lib.dtype_enum(self.time_dtype),
+            self.variant, _lib.ptr(self.stage_index), _lib.ptr(self.stage_frac), _lib.stream_ptr(self.device)),
+            "cde_rk4_forward_linear")
+        if begin is not None:
+            _Plan.event_log.append(("forward", begin, self._mark()))
+        return out
+
+    # backward: K3
+    def reverse_grids(self):
+        """Concatenated reversed-time grids, one per output interval, in processing order i = T-1 .. 1."""
+        t = self._t_host
+        pieces, offsets = [], [0]
+        for i in range(self.n_out - 1, 0, -1):
+            seg_t = -(t[i - 1:i + 1].flip(0))          # torchdiffeq: t[i-1:i+1].flip(0) is decreasing -> solved on -t
+            pieces.append(_fixed_grid(seg_t, self.adjoint_step_size))
+            offsets.append(offsets[-1] + pieces[-1].numel())
+        if pieces:
+            sgrid = torch.cat(pieces)
+        else:
+            sgrid = torch.zeros(0, dtype=t.dtype)
+        return sgrid.to(self.device), torch.tensor(offsets, dtype=torch.int64).to(self.device), sgrid.numel()
+
+    def run_adjoint(self, z_saved, grad_out, weight, bias):
+        lib = _lib.load()
+        sgrid, seg_off, n_sgrid = self.reverse_grids()
+        dt = _lib.dtype_enum(self.dtype)
+        nbytes = lib.cde_rk4_adjoint_workspace_bytes(self.B, self.C, self.H, n_sgrid, dt, self.variant)
+        workspace = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+        grad_z0 = torch.empty(self.B, self.H, dtype=self.dtype, device=self.device)
+        grad_w = torch.empty(self.H * self.C, self.H, dtype=self.dtype, device=self.device)
+        grad_b = torch.empty(self.H * self.C, dtype=self.dtype, device=self.device)
+        zs = z_saved.detach().contiguous()
+        go = grad_out.detach().reshape(self.B, self.n_out, self.H).contiguous()
+        w = weight.detach().contiguous()
+        b = bias.detach().contiguous()
+        begin = self._mark()
+        _lib.check(lib.cde_rk4_adjoint_linear(
+            _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w), _lib.ptr(b),
+            self.act, _lib.ptr(zs), _lib.ptr(go), _lib.ptr(sgrid), n_sgrid, _lib.ptr(seg_off), self.n_out,
+            _lib.ptr(grad_z0), _lib.ptr(grad_w), _lib.ptr(grad_b), self.B, self.C, self.H, dt,
+            _lib.dtype_enum(self.time_dtype), self.variant, _lib.ptr(workspace), workspace.numel(),
+            _lib.stream_ptr(self.device)), "cde_rk4_adjoint_linear")
+        if begin is not None:
+            _Plan.event_log.append(("adjoint", begin, self._mark()))
+        return grad_z0, grad_w, grad_b
+
+
+class _FusedRK4(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z0, weight, bias, plan, wants):
+        out = plan.run_forward(z0, weight, bias)
+        ctx.plan, ctx.wants = plan, wants
+        ctx.save_for_backward(out, weight, bias)
+        return out.reshape(*plan.batch, plan.n_out, plan.H)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        plan = ctx.plan
+        if not plan.adjoint:
+            raise NotImplementedError(
+                "torchcde_amd: backpropagating through the solver's internal operations (adjoint=False) is not "
+                "implemented on the native path; use adjoint=True (continuous adjoint, the reference's default).")
+        z_saved, weight, bias = ctx.saved_tensors
+        grad_z0, grad_w, grad_b = plan.run_adjoint(z_saved, grad_out, weight, bias)
+        want_w, want_b = ctx.wants
+        return (grad_z0.reshape(*plan.batch, plan.H) if ctx.needs_input_grad[0] else None,
+                grad_w.view_as(weight) if (ctx.needs_input_grad[1] and want_w) else None,
+                grad_b.view_as(bias) if (ctx.needs_input_grad[2] and want_b) else None,
+                None, None)
+
+
+# ------------------------------------------------------------------------------------------ front end
+def _shape_errors(dX_shape, system_shape, z0):
+    # messages of reference solver.py:7-33
+    if tuple(dX_shape[:-1]) != tuple(z0.shape[:-1]):
+        raise ValueError("X.derivative did not return a tensor with the same number of batch dimensions as z0. "
+                         "X.derivative returned shape {} (meaning {} batch dimensions), whilst z0 has shape {} "
+                         "(meaning {} batch dimensions)."
+                         "".format(tuple(dX_shape), tuple(dX_shape[:-1]), tuple(z0.shape), tuple(z0.shape[:-1])))
+    if tuple(system_shape[:-2]) != tuple(z0.shape[:-1]):
+        raise ValueError("func did not return a tensor with the same number of batch dimensions as z0. func returned "
+                         "shape {} (meaning {} batch dimensions), whilst z0 has shape {} (meaning {} batch"
+                         " dimensions)."
+                         "".format(tuple(system_shape), tuple(system_shape[:-2]), tuple(z0.shape),
+                                   tuple(z0.shape[:-1])))
+    if system_shape[-2] != z0.size(-1):
+        raise ValueError("func did not return a tensor with the same number of hidden channels as z0. func returned "
+                         "shape {} (meaning {} channels), whilst z0 has shape {} (meaning {} channels)."
+                         "".format(tuple(system_shape), system_shape[-2], tuple(z0.shape), z0.size(-1)))
+    if system_shape[-1] != dX_shape[-1]:
+        raise ValueError("func did not return a tensor with the same number of input channels as X.derivative "
+                         "returned. func returned shape {} (meaning {} channels), whilst X.derivative returned shape "
+                         "{} (meaning {} channels)."
+                         "".format(tuple(system_shape), system_shape[-1], tuple(dX_shape), dX_shape[-1]))
+
+
+def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
+    r"""Solve  z_t = z_{t_0} + \int_{t_0}^t f(s, z_s) dX_s  on the MI355X.
+
+    Arguments, return value (shape ``(..., len(t), hidden_channels)``) and errors as reference
+    ``torchcde.cdeint`` (solver.py:144-194).  ``variant=`` (extra keyword, one of
+    "auto" | "generic" | "mfma") selects the kernel and exists for testing."""
+    variant = {"auto": _lib.VARIANT_AUTO, "generic": _lib.VARIANT_GENERIC,
+               "mfma": _lib.VARIANT_MFMA}[kwargs.pop("variant", "auto")]
+    # tolerance defaults of solver.py:195-203 (only adaptive methods read them)
+    kwargs.setdefault("atol", 1e-6)
+    kwargs.setdefault("rtol", 1e-4)
+    if adjoint:
+        kwargs.setdefault("adjoint_atol", kwargs["atol"])
+        kwargs.setdefault("adjoint_rtol", kwargs["rtol"])
+
+    if not hasattr(X, "derivative"):
+        raise ValueError("X must have a 'derivative' method.")
+    if isinstance(z0, (tuple, list)):
+        raise NotImplementedError("torchcde_amd: tuple/list state is outside the native hot path.")
+    if not isinstance(z0, torch.Tensor):
+        raise ValueError("z0 must either a tensor or a tuple/list of tensors.")
+    if backend == "torchsde":
+        raise NotImplementedError("torchcde_amd: the torchsde backend is outside the native hot path.")
+    if backend != "torchdiffeq":
+        raise ValueError(f"Unrecognised backend={backend}")
+    if hasattr(func, "prod"):
+        raise NotImplementedError("torchcde_amd: vector fields given through `func.prod` are not supported natively.")
+    if not isinstance(X, _NativePath):
+        raise NotImplementedError("torchcde_amd: X must be a torchcde_amd.CubicSpline or LinearInterpolation.")
+    _lib.require_gpu(z0, "z0")
+    packed = X._packed()
+    _lib.require_gpu(packed, "the control path")
+    batch = tuple(packed.shape[:-2])
+    C = X._channels()
+    H = z0.size(-1)
+
+    # compatibility probe of solver.py:44-67: one evaluation of func at t[0], shapes checked against z0;
+    # the same evaluation establishes (bitwise) whether func belongs to the fused affine family.
+    field, system = probe(func, t[0].to(z0.device) if isinstance(t, torch.Tensor) else t, z0)
+    if not isinstance(system, torch.Tensor):
+        raise ValueError("z0 is a tensor and so func must return a tensor as well.")
+    _shape_errors(batch + (C,), tuple(system.shape), z0)
+    if field is None:
+        raise NotImplementedError(
+            "torchcde_amd: func is not of the fused affine family (one nn.Linear(hidden, hidden*input) applied to z, "
+            "optionally followed by tanh, viewed as (..., hidden, input)); generic vector fields are not implemented "
+            "on the native path yet (SURVEY section 8(f), rank 1).")
+    weight, bias = field.weight, field.bias
+    if tuple(weight.shape) != (H * C, H):
+        raise NotImplementedError("torchcde_amd: recognised Linear has shape {} but (hidden*input, hidden) = {} was "
+                                  "expected".format(tuple(weight.shape), (H * C, H)))
+    if not (z0.dtype == packed.dtype == weight.dtype):
+        raise NotImplementedError("torchcde_amd: z0, control coefficients and func parameters must share one dtype "
+                                  "(got {}, {}, {}).".format(z0.dtype, packed.dtype, weight.dtype))
+
+    if adjoint and "adjoint_params" not in kwargs:
+        for buffer in X.buffers():
+            if buffer.requires_grad:
+                warnings.warn(_GRAD_WARNING)
+
+    # solver configuration (what the reference forwards verbatim to torchdiffeq, solver.py:175-176,227)
+    method = kwargs.pop("method", None)
+    options = kwargs.pop("options", None)
+    if method is None:
+        method = "dopri5"
+    if method != "rk4":
+        raise NotImplementedError("torchcde_amd: method={!r} is not implemented natively yet; use method='rk4' with "
+                                  "options={{'step_size': ...}} (torchdiffeq's default dopri5 is the next kernel on "
+                                  "the list).".format(method))
+    step_size = _parse_fixed_options(options, "solver")
+    adjoint_method = kwargs.pop("adjoint_method", None)
+    adjoint_options = kwargs.pop("adjoint_options", None)
+    adjoint_params = kwargs.pop("adjoint_params", None)
+    for key in ("atol", "rtol", "adjoint_atol", "adjoint_rtol"):
+        kwargs.pop(key, None)
+    if kwargs:
+        raise NotImplementedError("torchcde_amd: unsupported cdeint keyword arguments {}".format(sorted(kwargs)))
+    if adjoint_method not in (None, "rk4"):
+        raise NotImplementedError("torchcde_amd: adjoint_method must equal the forward method ('rk4').")
+    adjoint_step = step_size if adjoint_options is None else _parse_fixed_options(adjoint_options, "adjoint")
+
+    if not (isinstance(t, torch.Tensor) and t.dim() == 1 and t.is_floating_point()):
+        raise ValueError("t must be a one dimensional floating point tensor.")
+    if t.numel() < 1:
+        raise ValueError("t must contain at least one time.")
+    if t.requires_grad and torch.is_grad_enabled():
+        raise NotImplementedError("torchcde_amd: gradients with respect to the output times are not implemented.")
+    t_host = t.detach().cpu()
+    if t_host.numel() > 1 and not bool((t_host[1:] > t_host[:-1]).all()):
+        raise NotImplementedError("torchcde_amd: t must be strictly increasing on the native path.")
+
+    want_w = want_b = True
+    if adjoint_params is not None:
+        adjoint_params = tuple(adjoint_params)
+        for p in adjoint_params:
+            if p is not weight and p is not bias:
+                raise NotImplementedError("torchcde_amd: adjoint_params may only contain the vector field's weight "
+                                          "and bias on the native path (gradients w.r.t. the control are rank 3 of "
+                                          "SURVEY section 8(f)).")
+        want_w = any(p is weight for p in adjoint_params)
+        want_b = any(p is bias for p in adjoint_params)
+
+    plan = _Plan(X, field, batch, H, C, t, step_size, adjoint_step, adjoint, variant)
+    return _FusedRK4.apply(z0, weight, bias, plan, (want_w, want_b))

@@ -1,0 +1,128 @@
+"""Vector-field recognition for the fused solvers.
+
+``cdeint`` accepts an arbitrary callable ``func(t, z) -> (..., H, C)`` (reference solver.py:159-165).
+The fused kernels implement the affine family
+        f(t, z) = act( Linear(H, H*C)(z) ) viewed as (..., H, C),      act in {identity, tanh}
+i.e. the README field (reference README.md:42-49) and ``example/irregular_data.py:36-46``.  A module is
+recognised by *probing*, not by tracing source: the module must own exactly one nn.Linear (and no
+other parameter); during the compatibility evaluation ``func(t[0], z0)`` that the reference performs
+anyway, a forward hook records that Linear's input and output, and the module's result must be
+BITWISE equal to ``reshape(act(linear(z0)))`` -- view/reshape never change values, so any other
+arithmetic (scaling, skip connections, time dependence, a second layer) fails the comparison and the
+module is refused rather than mis-solved.
+"""
+import weakref
+
+import torch
+
+from . import _lib
+
+
+class AffineField:
+    """(linear module, activation enum) extracted from a user module."""
+
+    def __init__(self, linear, act):
+        self.linear = linear
+        self.act = act
+
+    @property
+    def weight(self):
+        return self.linear.weight
+
+    @property
+    def bias(self):
+        return self.linear.bias
+
+
+class LinearCDEFunc(torch.nn.Module):
+    """Ready-made member of the fused family: ``Linear(H, H*C)`` (+ optional tanh) viewed (..., H, C)."""
+
+    def __init__(self, input_channels, hidden_channels, tanh=False, **kwargs):
+        super().__init__()
+        self.input_channels = input_channels
+        self.hidden_channels = hidden_channels
+        self.use_tanh = tanh
+        self.linear = torch.nn.Linear(hidden_channels, hidden_channels * input_channels, **kwargs)
+
+    def forward(self, t, z):
+        out = self.linear(z)
+        if self.use_tanh:
+            out = out.tanh()
+        return out.view(*z.shape[:-1], self.hidden_channels, self.input_channels)
+
+
+_verified = weakref.WeakKeyDictionary()   # func -> AffineField, after the two-time probe passed once
+
+
+def _single_linear(func):
+    if isinstance(func, LinearCDEFunc):
+        return func.linear
+    if not isinstance(func, torch.nn.Module):
+        return None
+    linears = [m for m in func.modules() if isinstance(m, torch.nn.Linear)]
+    if len(linears) != 1 or linears[0].bias is None:
+        return None
+    own = {id(p) for p in linears[0].parameters()}
+    if any(id(p) not in own for p in func.parameters()):
+        return None       # other trainable tensors take part: not the affine family
+    return linears[0]
+
+
+def _evaluate_recording(func, linear, t, z):
+    calls = []
+    handle = linear.register_forward_hook(lambda mod, inp, out: calls.append((inp[0], out)))
+    try:
+        with torch.no_grad():
+            system = func(t, z)
+    finally:
+        handle.remove()
+    return system, calls
+
+
+def _classify(system, calls, z):
+    """ACT enum if ``system`` is exactly reshape(act(linear(z))), else None (bitwise comparison:
+    view/reshape never change values, so any other arithmetic in ``func`` is detected)."""
+    if not isinstance(system, torch.Tensor) or len(calls) != 1:
+        return None
+    seen_input, linear_out = calls[0]
+    if seen_input.shape != z.shape or not torch.equal(seen_input, z):
+        return None
+    if system.numel() != linear_out.numel():
+        return None
+    flat = system.reshape(-1)
+    if torch.equal(flat, linear_out.reshape(-1)):
+        return _lib.ACT_NONE
+    if torch.equal(flat, linear_out.tanh().reshape(-1)):
+        return _lib.ACT_TANH
+    return None
+
+
+def probe(func, t0, z0):
+    """Evaluate ``func(t0, z0)`` once (the compatibility probe the reference performs anyway,
+    solver.py:47-53) while watching the module's single nn.Linear.
+
+    Returns ``(field_or_None, system)``.  The first time a module is seen it is also evaluated at a
+    second time value to establish that it does not depend on ``t``."""
+    linear = _single_linear(func)
+    if linear is None:
+        with torch.no_grad():
+            return None, func(t0, z0)
+    system, calls = _evaluate_recording(func, linear, t0, z0)
+    act = _classify(system, calls, z0)
+    if act is None:
+        return None, system
+    try:
+        known = _verified.get(func)
+    except TypeError:
+        known = None
+    if known is None or known.linear is not linear or known.act != act:
+        other_t = t0.detach() + 0.8125
+        system2, calls2 = _evaluate_recording(func, linear, other_t, z0)
+        if _classify(system2, calls2, z0) != act or not torch.equal(system2, system):
+            return None, system
+        known = AffineField(linear, act)
+        try:
+            _verified[func] = known
+        except TypeError:
+            pass
+    return known, system

@@ -1,0 +1,252 @@
+"""Control paths: coefficient construction and the piecewise-polynomial path modules.
+
+Host-side mirror (same names, argument meaning and error behaviour) of the reference's
+    hermite_cubic_coefficients_with_backward_differences  interpolation_hermite_cubic_bdiff.py:23-44
+    linear_interpolation_coeffs                           interpolation_linear.py:131-171
+    CubicSpline / LinearInterpolation                     interpolation_cubic.py:268-336 / interpolation_linear.py:174-225
+    InterpolationBase                                     interpolation_base.py:5-22
+with every tensor operation executed by the HIP kernels of libcde_mi355x.so (K1, K1b).
+"""
+import abc
+import math
+import warnings
+
+import torch
+
+from . import _lib
+
+
+# --------------------------------------------------------------------------------------- validation
+def _validate_input_path(x, t):
+    # error messages follow reference misc.py:70-100
+    if not x.is_floating_point():
+        raise ValueError("X must both be floating point.")
+    if x.ndimension() < 2:
+        raise ValueError("X must have at least two dimensions, corresponding to time and channels. It instead has "
+                         "shape {}.".format(tuple(x.shape)))
+    generated = t is None
+    if generated:
+        t = torch.linspace(0, x.size(-2) - 1, x.size(-2), dtype=x.dtype, device=x.device)
+    if not t.is_floating_point():
+        raise ValueError("t must both be floating point.")
+    if len(t.shape) != 1:
+        raise ValueError("t must be one dimensional. It instead has shape {}.".format(tuple(t.shape)))
+    if not generated:
+        # one device->host copy instead of the reference's per-element loop (misc.py:85-89)
+        previous = -math.inf
+        for value in t.detach().cpu().tolist():
+            if value <= previous:
+                raise ValueError("t must be monotonically increasing.")
+            previous = value
+    if x.size(-2) != t.size(0):
+        raise ValueError("The time dimension of X must equal the length of t. X has shape {} and t has shape {}, "
+                         "corresponding to time dimensions of {} and {} respectively."
+                         .format(tuple(x.shape), tuple(t.shape), x.size(-2), t.size(0)))
+    if t.size(0) < 2:
+        raise ValueError("Must have a time dimension of size at least 2. It instead has shape {}, corresponding to a "
+                         "time dimension of size {}.".format(tuple(t.shape), t.size(0)))
+    return t
+
+
+def _no_grad_through_path(*tensors):
+    if torch.is_grad_enabled() and any(isinstance(x, torch.Tensor) and x.requires_grad for x in tensors):
+        raise NotImplementedError(
+            "torchcde_amd: gradients with respect to the control path (raw data, coefficients or knot times) are not "
+            "implemented on the native path yet (SURVEY section 8(f), rank 3). Detach these inputs.")
+
+
+def linear_interpolation_coeffs(x, t=None, rectilinear=None):
+    """Knots of the piecewise-linear control (reference interpolation_linear.py:131-171).
+
+    Native scope: data without missing values and ``rectilinear=None``; then, exactly like the
+    reference, ``x`` itself is returned (same tensor object)."""
+    if rectilinear is not None:
+        raise NotImplementedError("torchcde_amd: rectilinear interpolation is outside the native hot path "
+                                  "(SURVEY section 8(f), rank 2).")
+    _validate_input_path(x, t)
+    _lib.require_gpu(x, "x")
+    if torch.isnan(x).any():
+        raise NotImplementedError("torchcde_amd: missing values (NaN) need the reference's fill logic, which is not "
+                                  "part of the native hot path yet (SURVEY section 8(f), rank 2).")
+    return x
+
+
+def hermite_cubic_coefficients_with_backward_differences(x, t=None):
+    """Hermite cubic spline coefficients with backward differences, (..., L-1, 4C) = [a | b | 2c | 3d].
+
+    Same contract as reference interpolation_hermite_cubic_bdiff.py:23-44; computed by K1
+    (``cde_hermite_bdiff_coeffs``) in one pass over ``x``."""
+    coeffs = linear_interpolation_coeffs(x, t=t, rectilinear=None)
+    _no_grad_through_path(x, t)
+    if t is None:
+        t = torch.linspace(0, coeffs.size(-2) - 1, coeffs.size(-2), dtype=coeffs.dtype, device=coeffs.device)
+    else:
+        t = t.to(device=coeffs.device, dtype=coeffs.dtype)
+    L, C = coeffs.size(-2), coeffs.size(-1)
+    batch = coeffs.shape[:-2]
+    B = 1
+    for b in batch:
+        B *= b
+    src = coeffs.detach().contiguous()
+    out = torch.empty(*batch, L - 1, 4 * C, dtype=coeffs.dtype, device=coeffs.device)
+    lib = _lib.load()
+    _lib.check(lib.cde_hermite_bdiff_coeffs(_lib.ptr(src), _lib.ptr(t.contiguous()), _lib.ptr(out), B, L, C,
+                                            _lib.dtype_enum(coeffs.dtype), _lib.stream_ptr(coeffs.device)),
+               "cde_hermite_bdiff_coeffs")
+    return out
+
+
+# --------------------------------------------------------------------------------------- path modules
+class InterpolationBase(torch.nn.Module, metaclass=abc.ABCMeta):
+    """Contract every control satisfies (reference interpolation_base.py:5-22)."""
+
+    @property
+    @abc.abstractmethod
+    def grid_points(self):
+        raise NotImplementedError
+
+    @property
+    @abc.abstractmethod
+    def interval(self):
+        raise NotImplementedError
+
+    @abc.abstractmethod
+    def evaluate(self, t):
+        raise NotImplementedError
+
+    @abc.abstractmethod
+    def derivative(self, t):
+        raise NotImplementedError
+
+
+class _NativePath(InterpolationBase):
+    """Shared machinery: flatten batch dims, call K1b, restore the reference's output shape
+    ``batch_dims + t.shape + (channels,)``."""
+
+    _degree = None
+
+    def _packed(self):
+        raise NotImplementedError
+
+    def _channels(self):
+        raise NotImplementedError
+
+    def _n_intervals(self):
+        return self._t.size(0) - 1
+
+    @property
+    def grid_points(self):
+        return self._t
+
+    @property
+    def interval(self):
+        return torch.stack([self._t[0], self._t[-1]])
+
+    def _native_inputs(self):
+        """(coeffs flattened to (B, rows, width) contiguous, knots, batch_shape)"""
+        coeffs = self._packed()
+        _lib.require_gpu(coeffs, "the control path")
+        knots = self._t
+        if knots.dtype != coeffs.dtype or knots.device != coeffs.device:
+            knots = knots.to(device=coeffs.device, dtype=coeffs.dtype)
+        batch = coeffs.shape[:-2]
+        flat = coeffs.detach().reshape(-1, coeffs.size(-2), coeffs.size(-1)).contiguous()
+        return flat, knots.detach().contiguous(), batch
+
+    def _interpret_t(self, t):
+        """(fractional_part, index) exactly as the reference's ``_interpret_t`` (int64 index)."""
+        coeffs, knots, _ = self._native_inputs()
+        tq = torch.as_tensor(t, dtype=coeffs.dtype, device=coeffs.device)
+        flat = tq.detach().reshape(-1).contiguous()
+        index = torch.empty(flat.numel(), dtype=torch.int64, device=coeffs.device)
+        frac = torch.empty(flat.numel(), dtype=coeffs.dtype, device=coeffs.device)
+        lib = _lib.load()
+        _lib.check(lib.cde_interpret_t(_lib.ptr(knots), self._n_intervals(), _lib.ptr(flat), flat.numel(),
+                                       _lib.ptr(index), _lib.ptr(frac), _lib.dtype_enum(coeffs.dtype),
+                                       _lib.stream_ptr(coeffs.device)), "cde_interpret_t")
+        return frac.reshape(tq.shape), index.reshape(tq.shape)
+
+    def _eval(self, t, what):
+        coeffs, knots, batch = self._native_inputs()
+        _no_grad_through_path(self._packed(), t if isinstance(t, torch.Tensor) else None)
+        tq = torch.as_tensor(t, dtype=coeffs.dtype, device=coeffs.device)
+        flat = tq.detach().reshape(-1).contiguous()
+        C = self._channels()
+        out = torch.empty(coeffs.size(0), flat.numel(), C, dtype=coeffs.dtype, device=coeffs.device)
+        lib = _lib.load()
+        _lib.check(lib.cde_path_eval(_lib.ptr(coeffs), _lib.ptr(knots), _lib.ptr(flat), flat.numel(), _lib.ptr(out),
+                                     coeffs.size(0), self._n_intervals(), C, self._degree, what,
+                                     _lib.dtype_enum(coeffs.dtype), _lib.stream_ptr(coeffs.device)), "cde_path_eval")
+        return out.reshape(*batch, *tq.shape, C)
+
+    def evaluate(self, t):
+        return self._eval(t, _lib.EVAL_VALUE)
+
+    def derivative(self, t):
+        return self._eval(t, _lib.EVAL_DERIVATIVE)
+
+
+class CubicSpline(_NativePath):
+    """Piecewise-cubic control built from packed coefficients (reference interpolation_cubic.py:268-336).
+
+    Buffers keep the reference's names (``_t, _a, _b, _two_c, _three_d``: views of the packed tensor)
+    so ``state_dict`` / ``.to()`` / the requires-grad warning of ``cdeint`` behave the same."""
+
+    _degree = _lib.PATH_CUBIC
+
+    def __init__(self, coeffs, t=None, **kwargs):
+        super().__init__(**kwargs)
+        if t is None:
+            t = torch.linspace(0, coeffs.size(-2), coeffs.size(-2) + 1, dtype=coeffs.dtype, device=coeffs.device)
+        channels = coeffs.size(-1) // 4
+        if channels * 4 != coeffs.size(-1):
+            raise ValueError("Passed invalid coeffs.")
+        self._C = channels
+        self.register_buffer("_t", t)
+        self.register_buffer("_a", coeffs[..., :channels])
+        self.register_buffer("_b", coeffs[..., channels:2 * channels])
+        self.register_buffer("_two_c", coeffs[..., 2 * channels:3 * channels])
+        self.register_buffer("_three_d", coeffs[..., 3 * channels:])
+
+    def _channels(self):
+        return self._C
+
+    def _packed(self):
+        a, b, c, d = self._a, self._b, self._two_c, self._three_d
+        C = self._C
+        # fast path: the four buffers are still adjacent views of one packed (..., L-1, 4C) tensor
+        try:
+            same = (a.untyped_storage().data_ptr() == d.untyped_storage().data_ptr()
+                    and a.stride() == b.stride() == c.stride() == d.stride() and a.stride(-1) == 1
+                    and a.stride(-2) == 4 * C
+                    and b.storage_offset() == a.storage_offset() + C and c.storage_offset() == a.storage_offset() + 2 * C
+                    and d.storage_offset() == a.storage_offset() + 3 * C)
+        except RuntimeError:
+            same = False
+        if same:
+            shape = tuple(a.shape[:-1]) + (4 * C,)
+            return torch.as_strided(a, shape, a.stride(), a.storage_offset())
+        return torch.cat([a, b, c, d], dim=-1)
+
+
+class NaturalCubicSpline(CubicSpline):
+    """Deprecated alias kept by the reference (interpolation_cubic.py:339-346)."""
+
+
+class LinearInterpolation(_NativePath):
+    """Piecewise-linear control (reference interpolation_linear.py:174-225)."""
+
+    _degree = _lib.PATH_LINEAR
+
+    def __init__(self, coeffs, t=None, **kwargs):
+        super().__init__(**kwargs)
+        if t is None:
+            t = torch.linspace(0, coeffs.size(-2) - 1, coeffs.size(-2), dtype=coeffs.dtype, device=coeffs.device)
+        self.register_buffer("_t", t)
+        self.register_buffer("_coeffs", coeffs)
+
+    def _channels(self):
+        return self._coeffs.size(-1)
+
+    def _packed(self):
+        return self._coeffs
