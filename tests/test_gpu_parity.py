@@ -86,7 +86,7 @@ def test_path_output_shapes_follow_reference_contract(native):
     coeffs = torch.randn(2, 3, 7, 12, device=DEV)
     X = native.CubicSpline(coeffs)
     for tshape in ((), (5,), (2, 4)):
-        t = torch.rand(*tshape, device=DEV) * 7
+        t = torch.rand(tshape, device=DEV) * 7
         assert X.evaluate(t).shape == (2, 3) + tshape + (3,)
         assert X.derivative(t).shape == (2, 3) + tshape + (3,)
 
