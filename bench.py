@@ -45,30 +45,51 @@ def make_workload(device, seed):
     return x, func, z0
 
 
-def cpu_baseline(sample):
-    """The oracle (torch CPU restatement of the reference path) on a bounded sample of the same workload."""
+def _log(msg):
+    print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(max_sample, budget_s=12.0):
+    """The oracle (torch CPU restatement of the reference path) on a bounded sample of the same workload.
+
+    Threads = the cores this process may actually run on (cgroup/affinity aware -- os.cpu_count() can
+    over-report on a shared box).  The sample size is calibrated from a 256-series probe so that the timed
+    run takes about ``budget_s`` seconds."""
     from oracle import cde as oracle_cde, interp as oracle_interp
     from helpers import LinearField, make_series
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, torch.get_num_threads(), 64))
     torch.set_num_threads(cores)
-    x = make_series(sample, L, C, seed=0)
     func = LinearField(H, C, scale=0.25, seed=0)
-    z0 = torch.randn(sample, H, generator=torch.Generator().manual_seed(0))
-    X = oracle_interp.CubicPath(oracle_interp.hermite_bdiff_coeffs(x))
 
-    def one():
+    def run(n):
+        x = make_series(n, L, C, seed=0)
+        z0 = torch.randn(n, H, generator=torch.Generator().manual_seed(0))
+        X = oracle_interp.CubicPath(oracle_interp.hermite_bdiff_coeffs(x))
         z = z0.clone().requires_grad_(True)
         func.zero_grad()
+        t0 = time.perf_counter()
         out = oracle_cde.cdeint(X, func, z, X.interval, adjoint=True, method="rk4", options=dict(step_size=1.0))
         out[:, -1].sum().backward()
+        return time.perf_counter() - t0
 
-    one()                                   # warm-up (thread pool, allocator)
-    t0 = time.perf_counter()
-    one()
-    dt = time.perf_counter() - t0
-    return {"value": sample / dt, "unit": "series/s", "cores": torch.get_num_threads(), "kind": "port",
+    run(64)                                   # warm-up (thread pool, allocator)
+    probe = run(256)
+    _log("cpu baseline probe: 256 series in %.2f s on %d threads" % (probe, cores))
+    sample = int(min(max_sample, 2048, max(256, 256 * budget_s / max(probe, 1e-3))))
+    sample = max(256, (sample // 256) * 256)
+    dt = run(sample)
+    if sample == 2048 and max_sample > 2048 and dt < budget_s / 2:      # large batches amortise eager overheads
+        bigger = int(min(max_sample, 2048 * budget_s / dt)) // 256 * 256
+        if bigger > sample:
+            sample = bigger
+            dt = run(sample)
+    return {"value": sample / dt, "unit": "series/s", "cores": cores, "kind": "port",
             "sample": "oracle (torch-CPU restatement of reference CubicSpline + _VectorField + torchdiffeq rk4/"
-                      "adjoint) on the first %d of the %d series, L=%d, 1 warm-up + 1 timed fwd+adjoint (%.1f s)"
+                      "adjoint) on %d of the %d series, L=%d, one timed fwd+adjoint after warm-up (%.1f s)"
                       % (sample, B, L, dt)}
 
 
@@ -96,6 +117,7 @@ def main():
     from torchcde_amd.distributed import allreduce_gradients
     cde.load()
 
+    _log("rank %d/%d building workload" % (rank, world))
     x, func, z0 = make_workload(device, seed=rank)
 
     # K1 outside the timed region, timed on its own
@@ -123,8 +145,11 @@ def main():
             allreduce_gradients(params)
         return out
 
+    _log("hermite fit %.3f ms; warm-up" % fit_ms)
     for _ in range(args.warmup):
         step()
+    torch.cuda.synchronize()
+    _log("timing %d steps" % args.steps)
 
     _Plan.event_log = []                                   # HIP events around the K2 / K3 C-ABI calls
     torch.cuda.synchronize()
@@ -151,6 +176,7 @@ def main():
     fwd_avg = sum(fwd_ms) / max(len(fwd_ms), 1)
     adj_avg = sum(adj_ms) / max(len(adj_ms), 1)
 
+    _log("timed region done: %.3f s" % elapsed)
     if rank == 0:
         total_series = B * world * args.steps
         value = total_series / elapsed
