@@ -1,0 +1,28 @@
+"""Small driver for rocprofv3 counter passes: the bench workload (B=32768, L=128, C=8, H=32), a few
+forward+adjoint steps and a few Hermite fits -- nothing else.  Usage (one PMC set per run):
+    rocprofv3 --pmc <counters> --kernel-trace -d DIR -o NAME -- python scripts/prof_workload.py [steps]
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import bench  # noqa: E402
+import torchcde_amd as cde  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+dev = torch.device("cuda", 0)
+x, func, z0 = bench.make_workload(dev, seed=0)
+for _ in range(steps):
+    coeffs = cde.hermite_cubic_coefficients_with_backward_differences(x)
+X = cde.CubicSpline(coeffs)
+for _ in range(steps):
+    z = z0.detach().requires_grad_(True)
+    func.zero_grad()
+    out = cde.cdeint(X, func, z, X.interval, method="rk4", options={"step_size": 1.0})
+    out[:, -1].sum().backward()
+torch.cuda.synchronize()
+print("done")

@@ -4,7 +4,10 @@ golden fixtures generated from the reference, and size-independent properties at
 Tolerances (stated once, used below):
   * interval indices: bit-exact (int64 equality)
   * coefficients / frac / spline value & slope: bit-exact against the reference's floats
-  * trajectories: rtol 1e-4, atol 1e-6 (the north star's bar) in float32; 1e-9 / 1e-11 in float64
+  * trajectories: rtol 1e-4, atol 1e-6 (the north star's bar) in float32; 1e-9 / 1e-11 in float64.
+    At the full 127-step length float32 round-off accumulated over 508 stages reaches a few 1e-6 absolute on
+    O(1) states (the CPU float32 oracle deviates from float64 by the same amount, which the test measures), so
+    there atol is 1e-5 and the kernel's error is additionally bounded by 4x the CPU-float32 error.
   * gradients: rtol 1e-3 (float32 kernels vs float64 oracle), 1e-8 in float64
 """
 import math
@@ -341,14 +344,21 @@ def test_full_size_properties_config2_config3(native):
     zs = z0[sample].clone().requires_grad_(True)
     func_g = LinearField(H, C, scale=0.25, seed=0).to(DEV)
     out_g = native.cdeint(Xs, func_g, zs, X.interval, variant="generic", **kw)
-    _close(out.detach()[sample], out_g, 1e-4, 1e-6)
+    _close(out.detach()[sample], out_g, 1e-4, 1e-5)
     out_g[:, -1].sum().backward()
     _close(gz[sample], zs.grad, 1e-3, 1e-5)
+    lw = torch.cat([torch.zeros(len(sample), 1, H), torch.ones(len(sample), 1, H)], 1)
     ref_out, ref_gz, _, _ = _oracle_solution(coeffs[sample].cpu(), None, LinearField(H, C, scale=0.25, seed=0),
-                                             z0[sample].cpu(), X.interval.cpu(), 1.0,
-                                             torch.cat([torch.zeros(len(sample), 1, H), torch.ones(len(sample), 1, H)], 1))
-    _close(out.detach()[sample], ref_out, 1e-4, 1e-6)
+                                             z0[sample].cpu(), X.interval.cpu(), 1.0, lw)
+    _close(out.detach()[sample], ref_out, 1e-4, 1e-5)
     _close(gz[sample], ref_gz, 1e-3, 1e-5)
+    # calibration: how far is the CPU float32 path (the reference's own arithmetic) from float64?
+    cpu32 = oracle_cde.cdeint(oracle_interp.CubicPath(coeffs[sample].cpu()), LinearField(H, C, scale=0.25, seed=0),
+                              z0[sample].cpu(), X.interval.cpu(), adjoint=False, method="rk4",
+                              options=dict(step_size=1.0))
+    err_cpu32 = (cpu32.double() - ref_out).abs().max().item()
+    err_kernel = (out.detach()[sample].double().cpu() - ref_out).abs().max().item()
+    assert err_kernel <= 4 * err_cpu32 + 1e-6, (err_kernel, err_cpu32)
 
     # parameter gradients: MFMA kernel vs generic kernel on a 4096-series slab
     slab = slice(0, 4096)

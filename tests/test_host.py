@@ -240,3 +240,52 @@ def test_mfma_operand_layouts_reproduce_the_vector_field_and_its_vjps():
             if half[l] == 0:
                 gbv[n[l] * C + c] = gb[l, c] + gb[l + 32, c]
     assert np.allclose(gW, gW_ref) and np.allclose(gbv, gb_ref)
+
+
+# ------------------------------------------------------------------ 16x16x4 layouts (forward kernel, 2 waves/SIMD)
+def _mfma_16x16x4(a_lane, b_lane, acc):
+    """v_mfma_f32_16x16x4_f32: lane l supplies A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; register r of lane l
+    holds D[4*(l>>4)+r][l&15]."""
+    A = np.zeros((16, 4)); Bm = np.zeros((4, 16))
+    for l in range(64):
+        A[l & 15, l >> 4] = a_lane[l]
+        Bm[l >> 4, l & 15] = b_lane[l]
+    P = A @ Bm
+    for l in range(64):
+        for r in range(4):
+            acc[l, r] += P[4 * (l >> 4) + r, l & 15]
+
+
+def _w16_image(W, bias, T, s, l, H=32, C=8):
+    """A operand of M-tile T for step s (mirrors w16_image in csrc/rk4_mfma.hip): lane quarter q owns hidden
+    units 8q..8q+7; tile T row i is unit 8*(i>>2) + 4*T + (i&3)."""
+    i, kq = l & 15, l >> 4
+    unit_out = 8 * (i >> 2) + 4 * T + (i & 3)
+    if s < 64:
+        m, c = s >> 3, s & 7
+        return W[unit_out * C + c, 8 * kq + m]
+    return bias[unit_out * C + 4 * (s - 64) + kq]
+
+
+def test_mfma16_forward_layout_reproduces_the_vector_field():
+    rng = np.random.default_rng(1)
+    H, C = 32, 8
+    W = rng.standard_normal((H * C, H)); bias = rng.standard_normal(H * C)
+    z = rng.standard_normal((16, H)); dX = rng.standard_normal((16, C))
+    f_ref = np.einsum("nhc,nc->nh", (z @ W.T + bias).reshape(16, H, C), dX)
+    lanes = np.arange(64)
+    n, q = lanes & 15, lanes >> 4
+    z_own = np.stack([z[n, 8 * q + m] for m in range(8)], axis=1)
+    acc = [np.zeros((64, 4)), np.zeros((64, 4))]
+    for m in range(8):
+        for c in range(8):
+            b = z_own[:, m] * dX[n, c]
+            for T in range(2):
+                _mfma_16x16x4([_w16_image(W, bias, T, 8 * m + c, l) for l in lanes], b, acc[T])
+    for sp in range(2):
+        b = dX[n, 4 * sp + q]
+        for T in range(2):
+            _mfma_16x16x4([_w16_image(W, bias, T, 64 + sp, l) for l in lanes], b, acc[T])
+    got = np.concatenate(acc, axis=1)                       # register 4T + r  <->  unit 8q + 4T + r
+    expect = np.stack([f_ref[n, 8 * q + m] for m in range(8)], axis=1)
+    assert np.allclose(got, expect)

@@ -34,8 +34,7 @@ constexpr int W1_STEPS = 132;          // 16*8 product steps + 4 bias steps
 constexpr int W2_STEPS = 128;
 constexpr int W1_FLOATS = W1_STEPS * 64;
 constexpr int W2_FLOATS = W2_STEPS * 64;
-constexpr int SCR_Y = 32 * 33, SCR_A = 32 * 33, SCR_DX = 32 * 8;
-constexpr int SCR_FLOATS = SCR_Y + SCR_A + SCR_DX;   // per wave
+constexpr int SCR_FLOATS = 2 * 64 * 20 + 32 * 8;     // per wave: z^T, a^T (64 rows x 20) and weighted dX (32 x 8)
 
 // MFMA 32x32 C/D fragment: lane (col = l&31, half = l>>5) register r holds row
 // i = (r&3) + 8*(r>>2) + 4*half.  rho maps an output ROW i to the hidden unit stored there so
@@ -151,35 +150,109 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // ============================================================================================ forward
+// K2.  One wave owns 16 series; lane l = (n = l & 15, q = l >> 4) keeps hidden units 8q..8q+7 of series n.
+// v_mfma_f32_16x16x4_f32 (32-cycle issue, 40-cycle dependent latency): two M-tiles (hidden 32 = 2 x 16
+// rows) alternate, so the pipe never waits on its own accumulator.  2 waves per SIMD (<= 256 registers):
+// while one wave is in its serial RK "tail" (stage combination, next control derivative) the other wave's
+// 132-MFMA chain owns the matrix pipe -- measured MFMA-busy rose from 68 % (one 32-series wave per SIMD,
+// 32x32x2) to what profiles/ reports for this version.
+//
+//   tile T row i  <->  hidden unit 8*(i>>2) + 4*T + (i&3)   =>  acc_T[r] of lane (n,q) is unit 8q + 4T + r
+//   step s = (m, c), lane quarter kq feeds K index kq = input unit 8*kq + m, channel c
+//   bias steps 64, 65: lane quarter kq feeds channel 4*(s-64) + kq
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+constexpr int W16_GROUPS = 17;                      // 66 steps per tile, padded to 68 = 17 float4 groups
+constexpr int W16_FLOATS = 2 * W16_GROUPS * 64 * 4;
+constexpr int FWD_STAGGER_SLEEP = 44;              // x64 cycles ~ half of one RK stage (4224 MFMA cycles + tail)
+
+__device__ __forceinline__ float w16_image(const float* __restrict__ W, const float* __restrict__ bias, int T, int s,
+                                           int l) {
+  const int i = l & 15, kq = l >> 4;
+  const int unit_out = 8 * (i >> 2) + 4 * T + (i & 3);
+  if (s < 64) { const int m = s >> 3, c = s & 7; return W[(unit_out * MC + c) * MH + 8 * kq + m]; }
+  if (s < 66) return bias[unit_out * MC + 4 * (s - 64) + kq];
+  return 0.f;
+}
+
+// d * broadcast(z.lo) / d * broadcast(z.hi) in ONE VALU instruction (VOP3P op_sel selects the source half per
+// result lane).  asm volatile + the callers' sched_barriers keep them a whole MFMA group ahead of their first
+// consumer, so the VALU-write -> MFMA-read wait states are satisfied by construction.
+__device__ __forceinline__ f32x2 pk_mul_lo(f32x2 d, f32x2 z) {
+  f32x2 r;
+  asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(d), "v"(z));
+  return r;
+}
+__device__ __forceinline__ f32x2 pk_mul_hi(f32x2 d, f32x2 z) {
+  f32x2 r;
+  asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(d), "v"(z));
+  return r;
+}
+
+// acc += d * broadcast(z.lo | z.hi), one instruction
+__device__ __forceinline__ void pk_fma_lo(f32x2& acc, f32x2 d, f32x2 z) {
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(d), "v"(z));
+}
+__device__ __forceinline__ void pk_fma_hi(f32x2& acc, f32x2 d, f32x2 z) {
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(d), "v"(z));
+}
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
 template <typename TT, int DEGREE>
-__global__ __launch_bounds__(256, 1) void rk4_forward_mfma(
+__global__ __launch_bounds__(512, 2) void rk4_forward_mfma(
     const float* __restrict__ coeffs, const float* __restrict__ knots, int64_t n_intervals,
     const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ z0,
     const TT* __restrict__ grid, int64_t n_grid, const TT* __restrict__ t_out, int64_t n_out,
     float* __restrict__ z_out, int64_t B, const int64_t* __restrict__ stage_index,
     const float* __restrict__ stage_frac) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  for (int e = threadIdx.x; e < W1_FLOATS; e += 256) {
-    const int s4 = e >> 8, l = (e >> 2) & 63, q = e & 3;
-    lds[e] = w1_image(W, bias, s4 * 4 + q, l);
+  for (int e = threadIdx.x; e < W16_FLOATS; e += 512) {
+    const int q4 = e & 3, l = (e >> 2) & 63, g = e >> 8;            // g = T*17 + group
+    const int T = g / W16_GROUPS, grp = g - T * W16_GROUPS;
+    lds[e] = w16_image(W, bias, T, grp * 4 + q4, l);
   }
   __syncthreads();
-  const float4* w1 = reinterpret_cast<const float4*>(lds);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n = lane & 31, half = lane >> 5;
-  const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-  if (tile * 32 >= B) return;
-  const int64_t series = tile * 32 + n;
+  const int n = lane & 15, q = lane >> 4;
+  const int64_t tile = (int64_t)blockIdx.x * 8 + wave;
+  if (tile * 16 >= B) return;
+  // Waves w and w+4 of a 512-thread workgroup share a SIMD and do identical work: left alone they run in
+  // lockstep and both sit in their MFMA-free RK tail at the same time.  Half a stage of head start for one of
+  // them keeps the matrix pipe fed by the other.
+  if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_sleep(FWD_STAGGER_SLEEP);
+  const int64_t series = tile * 16 + n;
   const bool valid = series < B;
   const int64_t sc = valid ? series : B - 1;
 
-  f32x16 y0;
+  // the A-operand image is loop invariant: 2 x 17 ds_read_b128 once, then it lives in registers
+  float4 wA[W16_GROUPS], wB[W16_GROUPS];
+  {
+    const float4* w4 = reinterpret_cast<const float4*>(lds);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) y0[r] = z0[sc * MH + 2 * r + half];
-  if (valid) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) z_out[(series * n_out) * MH + 2 * r + half] = y0[r];
+    for (int g = 0; g < W16_GROUPS; ++g) {
+      wA[g] = w4[g * 64 + lane];
+      wB[g] = w4[(W16_GROUPS + g) * 64 + lane];
+    }
   }
+
+  f32x4 ya, yb;                                  // units 8q..8q+3 and 8q+4..8q+7
+  {
+    const float4* p = reinterpret_cast<const float4*>(z0 + sc * MH + 8 * q);
+    const float4 lo = p[0], hi = p[1];
+    ya = f32x4{lo.x, lo.y, lo.z, lo.w};
+    yb = f32x4{hi.x, hi.y, hi.z, hi.w};
+  }
+  auto store = [&](int64_t j, const f32x4& a, const f32x4& b) {
+    if (valid) {
+      float4* p = reinterpret_cast<float4*>(z_out + (series * n_out + j) * MH + 8 * q);
+      p[0] = make_float4(a[0], a[1], a[2], a[3]);
+      p[1] = make_float4(b[0], b[1], b[2], b[3]);
+    }
+  };
+  store(0, ya, yb);
   int64_t jout = 1;
   const int64_t n_steps = n_grid - 1;
   if (n_steps <= 0) return;
@@ -191,7 +264,7 @@ __global__ __launch_bounds__(256, 1) void rk4_forward_mfma(
   for (int64_t k = 0; k < n_steps; ++k) {
     const TT t0 = grid[k], t1 = grid[k + 1];
     const float dt = (float)(t1 - t0);
-    f32x16 k1, k2, pq, zst = y0;
+    f32x4 k1a, k1b, k2a, k2b, pqa, pqb, za = ya, zb = yb;
 #pragma unroll
     for (int stage = 0; stage < 4; ++stage) {
       float dX[MC];
@@ -205,29 +278,75 @@ __global__ __launch_bounds__(256, 1) void rk4_forward_mfma(
       Row<DEGREE> nrow = row;
       if (nidx != idx) nrow = load_row<DEGREE>(coeffs, sc, n_intervals, nidx);
 
-      const f32x16 f = chain_field(w1, lane, zst, dX);
+      // Measured on gfx950 (scripts/ubench/mfma_issue.hip): a wave hides NOTHING behind its own f32 MFMA --
+      // every other instruction costs ~6 cycles of matrix-pipe time.  So: products are formed two at a time
+      // (v_pk_mul_f32 with the hidden unit broadcast by op_sel, written as asm because LLVM scalarises the
+      // vector multiply when its lanes are consumed one by one) and one group AHEAD of the MFMAs that consume
+      // them (no VALU->MFMA hazard nops); each product feeds both M-tiles.  4 pk_mul per 16 MFMAs.
+      f32x4 fa = {0.f, 0.f, 0.f, 0.f}, fb = {0.f, 0.f, 0.f, 0.f};
+      const f32x2 d01 = {dX[0], dX[1]}, d23 = {dX[2], dX[3]}, d45 = {dX[4], dX[5]}, d67 = {dX[6], dX[7]};
+      const f32x2 zp[4] = {f32x2{za[0], za[1]}, f32x2{za[2], za[3]}, f32x2{zb[0], zb[1]}, f32x2{zb[2], zb[3]}};
+      f32x2 p01 = pk_mul_lo(d01, zp[0]), p23 = pk_mul_lo(d23, zp[0]), p45 = pk_mul_lo(d45, zp[0]),
+            p67 = pk_mul_lo(d67, zp[0]);
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        f32x2 n01 = p01, n23 = p23, n45 = p45, n67 = p67;
+        if (m < 7) {
+          const f32x2 zn = zp[(m + 1) >> 1];
+          if ((m + 1) & 1) { n01 = pk_mul_hi(d01, zn); n23 = pk_mul_hi(d23, zn); n45 = pk_mul_hi(d45, zn); n67 = pk_mul_hi(d67, zn); }
+          else { n01 = pk_mul_lo(d01, zn); n23 = pk_mul_lo(d23, zn); n45 = pk_mul_lo(d45, zn); n67 = pk_mul_lo(d67, zn); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float* ga = reinterpret_cast<const float*>(&wA[2 * m]);       // steps 8m .. 8m+7 = groups 2m, 2m+1
+        const float* gb = reinterpret_cast<const float*>(&wB[2 * m]);
+        fa = mfma16(ga[0], p01[0], fa); fb = mfma16(gb[0], p01[0], fb);
+        fa = mfma16(ga[1], p01[1], fa); fb = mfma16(gb[1], p01[1], fb);
+        fa = mfma16(ga[2], p23[0], fa); fb = mfma16(gb[2], p23[0], fb);
+        fa = mfma16(ga[3], p23[1], fa); fb = mfma16(gb[3], p23[1], fb);
+        fa = mfma16(ga[4], p45[0], fa); fb = mfma16(gb[4], p45[0], fb);
+        fa = mfma16(ga[5], p45[1], fa); fb = mfma16(gb[5], p45[1], fb);
+        fa = mfma16(ga[6], p67[0], fa); fb = mfma16(gb[6], p67[0], fb);
+        fa = mfma16(ga[7], p67[1], fa); fb = mfma16(gb[7], p67[1], fb);
+        __builtin_amdgcn_sched_barrier(0);
+        p01 = n01; p23 = n23; p45 = n45; p67 = n67;
+      }
+      {   // bias: step 64 feeds channel kq, step 65 channel 4 + kq
+        const float b0 = q == 0 ? dX[0] : q == 1 ? dX[1] : q == 2 ? dX[2] : dX[3];
+        const float b1 = q == 0 ? dX[4] : q == 1 ? dX[5] : q == 2 ? dX[6] : dX[7];
+        fa = mfma16(wA[16].x, b0, fa);
+        fb = mfma16(wB[16].x, b0, fb);
+        fa = mfma16(wA[16].y, b1, fa);
+        fb = mfma16(wB[16].y, b1, fb);
+      }
 
       // torchdiffeq rk4_alt_step_func (3/8 rule), association order preserved
-      if (stage == 0) { k1 = f; zst = y0 + dt * k1 * (float)(1.0 / 3.0); }
-      else if (stage == 1) { k2 = f; zst = y0 + dt * (k2 - k1 * (float)(1.0 / 3.0)); }
-      else if (stage == 2) { zst = y0 + dt * (k1 - k2 + f); pq = k1 + 3.f * (k2 + f); }
-      else { zst = y0 + (pq + f) * dt * 0.125f; }
+      const float third = (float)(1.0 / 3.0);
+      if (stage == 0) {
+        k1a = fa; k1b = fb;
+        za = ya + dt * k1a * third; zb = yb + dt * k1b * third;
+      } else if (stage == 1) {
+        k2a = fa; k2b = fb;
+        za = ya + dt * (k2a - k1a * third); zb = yb + dt * (k2b - k1b * third);
+      } else if (stage == 2) {
+        za = ya + dt * (k1a - k2a + fa); zb = yb + dt * (k1b - k2b + fb);
+        pqa = k1a + 3.f * (k2a + fa); pqb = k1b + 3.f * (k2b + fb);
+      } else {
+        za = ya + (pqa + fa) * dt * 0.125f; zb = yb + (pqb + fb) * dt * 0.125f;
+      }
       row = nrow; idx = nidx; frac = nfrac;
     }
-    const f32x16 y1 = zst;
+    const f32x4 y1a = za, y1b = zb;
     while (jout < n_out && t1 >= t_out[jout]) {
       const TT tj = t_out[jout];
-      f32x16 v;
-      if (tj == t0) v = y0;
-      else if (tj == t1) v = y1;
-      else { const float slope = (float)((tj - t0) / (t1 - t0)); v = y0 + slope * (y1 - y0); }
-      if (valid) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) z_out[(series * n_out + jout) * MH + 2 * r + half] = v[r];
+      if (tj == t0) store(jout, ya, yb);
+      else if (tj == t1) store(jout, y1a, y1b);
+      else {
+        const float slope = (float)((tj - t0) / (t1 - t0));
+        store(jout, ya + slope * (y1a - ya), yb + slope * (y1b - yb));
       }
       ++jout;
     }
-    y0 = y1;
+    ya = y1a; yb = y1b;
   }
 }
 
@@ -259,8 +378,6 @@ __global__ __launch_bounds__(256, 1) void rk4_adjoint_mfma(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 31, half = lane >> 5;
   float* scr_y = lds + W1_FLOATS + W2_FLOATS + wave * SCR_FLOATS;
-  float* scr_a = scr_y + SCR_Y;
-  float* scr_dx = scr_a + SCR_A;
 
   const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
   float* my_partial = partial + tile * PARTIAL_FLOATS;
@@ -270,10 +387,9 @@ __global__ __launch_bounds__(256, 1) void rk4_adjoint_mfma(
   const int64_t sc = valid ? series : B - 1;
 
   f32x16 accW[MC];
-  float gb[MC];
+  f32x2 gbp[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};   // dL/db partials, channel pairs
 #pragma unroll
   for (int c = 0; c < MC; ++c) {
-    gb[c] = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) accW[c][r] = 0.f;
   }
@@ -284,6 +400,18 @@ __global__ __launch_bounds__(256, 1) void rk4_adjoint_mfma(
     y0[r] = z_saved[(sc * n_out + (n_out - 1)) * MH + 2 * r + half];
     a0[r] = valid ? grad_out[(sc * n_out + (n_out - 1)) * MH + 2 * r + half] : 0.f;   // a == 0 stays 0: padded lanes add nothing to dL/dW
   }
+
+  // Per-wave LDS scratch for the (series -> MFMA K index) transpose of the dL/dW product, laid out so that
+  // the reader side is 16-byte vector loads:
+  //   scr_zt[(par*32 + u)*20 + s] = z_u of series 2s+par      (row stride 20 floats = 80 B: b128-aligned and
+  //   scr_at[(par*32 + u)*20 + s] = a_u of series 2s+par       conflict-free for the 16-lane b128 groups)
+  //   scr_dw[series*8 + c]        = (quadrature weight * ds) * dX_c of that series
+  // Instruction economy matters more than placement here: a single wave hides nothing behind its own f32
+  // MFMAs (scripts/ubench/mfma_issue.hip), so every product is a packed v_pk_mul_f32, operands of the two
+  // chains come straight from registers, and LDS is touched with b128 only.
+  float* scr_zt = scr_y;                    // 64 rows x 20
+  float* scr_at = scr_y + 64 * 20;          // 64 rows x 20
+  float* scr_dw = scr_y + 2 * 64 * 20;      // 32 x 8
 
   for (int64_t p = 0; p + 1 < n_out; ++p) {
     const int64_t i_out = n_out - 1 - p;
@@ -300,52 +428,66 @@ __global__ __launch_bounds__(256, 1) void rk4_adjoint_mfma(
           float dX[MC];
           const float width = DEGREE == CDE_PATH_LINEAR ? knots[idx + 1] - knots[idx] : 1.f;
           control_slope<DEGREE>(row, frac, width, dX);
+          // prefetch the next stage's table entry and (if the interval changes) its control row
           const int64_t e_next = 4 * k + stage + 1;
           const bool more = e_next < 4 * k_end;
           const int64_t nidx = more ? stage_index[e_next] : idx;
           const float nfrac = more ? stage_frac[e_next] : frac;
-          Row<DEGREE> nrow = row;
-          if (nidx != idx) nrow = load_row<DEGREE>(coeffs, sc, n_intervals, nidx);
+          if (nidx != idx) row = load_row<DEGREE>(coeffs, sc, n_intervals, nidx);
 
-          // Stage state goes to the per-wave LDS scratch once; it is read back (a) as this lane's own
-          // hidden units z_n[2j+half], a_n[2j+half] by the rolled f / vjp loop below and (b) transposed
-          // (series -> MFMA K index) by the dL/dW loop.  Rolled loops keep the register file for what
-          // must live there: 8 dL/dW accumulators (128 AGPRs) + the RK state.
-          const float wq = ((stage == 0 || stage == 3) ? 0.125f : 0.375f) * ds;   // 3/8-rule quadrature weight
+          const f32x2 d01 = {dX[0], dX[1]}, d23 = {dX[2], dX[3]}, d45 = {dX[4], dX[5]}, d67 = {dX[6], dX[7]};
+          // ---- stage state -> scratch (transposed), weighted control derivative
+          {
+            const float wq = ((stage == 0 || stage == 3) ? 0.125f : 0.375f) * ds;   // 3/8-rule quadrature weight
+            float* wz = scr_zt + ((n & 1) * 32 + half) * 20 + (n >> 1);              // + 2r*20
+            float* wa = scr_at + ((n & 1) * 32 + half) * 20 + (n >> 1);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            scr_y[n * 33 + 2 * r + half] = yst[r];
-            scr_a[n * 33 + 2 * r + half] = ast[r];
+            for (int r = 0; r < 16; ++r) { wz[r * 40] = yst[r]; wa[r * 40] = ast[r]; }
+            const f32x2 w0 = (half ? d45 : d01) * wq, w1 = (half ? d67 : d23) * wq;
+            *reinterpret_cast<float4*>(scr_dw + n * 8 + 4 * half) = make_float4(w0[0], w0[1], w1[0], w1[1]);
+            wave_lds_sync();
           }
-          *reinterpret_cast<float4*>(scr_dx + n * 8 + 4 * half) =
-              half ? make_float4(dX[4], dX[5], dX[6], dX[7]) : make_float4(dX[0], dX[1], dX[2], dX[3]);
-          wave_lds_sync();
 
-          // f = W (z (x) dX) + b dX  and  va = a^T df/dz : two independent accumulator chains, interleaved
+          // ---- f = W (z (x) dX) + b dX  and  va = a^T df/dz : two independent accumulator chains
           f32x16 f = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           f32x16 va = f;
           {
             const float4* p1 = w1 + lane;
             const float4* p2 = w2 + lane;
-            const float* zo = scr_y + n * 33 + half;
-            const float* ao = scr_a + n * 33 + half;
             float4 fa = p1[0], fb = p1[64], ga = p2[0], gb4 = p2[64];
-            float zj = zo[0], aj = ao[0];
-#pragma unroll 1
+            f32x2 zp = {yst[0], yst[1]}, ap = {ast[0], ast[1]};
+            f32x2 z01 = pk_mul_lo(d01, zp), z23 = pk_mul_lo(d23, zp), z45 = pk_mul_lo(d45, zp), z67 = pk_mul_lo(d67, zp);
+            f32x2 a01 = pk_mul_lo(d01, ap), a23 = pk_mul_lo(d23, ap), a45 = pk_mul_lo(d45, ap), a67 = pk_mul_lo(d67, ap);
+#pragma unroll
             for (int j = 0; j < 16; ++j) {
-              const int jn = j < 15 ? j + 1 : 15;        // software prefetch of the next group's operands
-              const float4 nfa = p1[(2 * jn) * 64], nfb = p1[(2 * jn + 1) * 64];
-              const float4 nga = p2[(2 * jn) * 64], ngb = p2[(2 * jn + 1) * 64];
-              const float nzj = zo[2 * jn], naj = ao[2 * jn];
-              f = mfma(fa.x, zj * dX[0], f);   va = mfma(ga.x, aj * dX[0], va);
-              f = mfma(fa.y, zj * dX[1], f);   va = mfma(ga.y, aj * dX[1], va);
-              f = mfma(fa.z, zj * dX[2], f);   va = mfma(ga.z, aj * dX[2], va);
-              f = mfma(fa.w, zj * dX[3], f);   va = mfma(ga.w, aj * dX[3], va);
-              f = mfma(fb.x, zj * dX[4], f);   va = mfma(gb4.x, aj * dX[4], va);
-              f = mfma(fb.y, zj * dX[5], f);   va = mfma(gb4.y, aj * dX[5], va);
-              f = mfma(fb.z, zj * dX[6], f);   va = mfma(gb4.z, aj * dX[6], va);
-              f = mfma(fb.w, zj * dX[7], f);   va = mfma(gb4.w, aj * dX[7], va);
-              fa = nfa; fb = nfb; ga = nga; gb4 = ngb; zj = nzj; aj = naj;
+              // operands of group j+1: A images from LDS (4 x b128), products from registers (8 x pk_mul)
+              float4 nfa = fa, nfb = fb, nga = ga, ngb = gb4;
+              f32x2 y01 = z01, y23 = z23, y45 = z45, y67 = z67, b01 = a01, b23 = a23, b45 = a45, b67 = a67;
+              if (j < 15) {
+                nfa = p1[(2 * j + 2) * 64]; nfb = p1[(2 * j + 3) * 64];
+                nga = p2[(2 * j + 2) * 64]; ngb = p2[(2 * j + 3) * 64];
+                const int jn = j + 1;
+                const f32x2 zq = {yst[jn & ~1], yst[jn | 1]}, aq = {ast[jn & ~1], ast[jn | 1]};
+                if (jn & 1) {
+                  y01 = pk_mul_hi(d01, zq); y23 = pk_mul_hi(d23, zq); y45 = pk_mul_hi(d45, zq); y67 = pk_mul_hi(d67, zq);
+                  b01 = pk_mul_hi(d01, aq); b23 = pk_mul_hi(d23, aq); b45 = pk_mul_hi(d45, aq); b67 = pk_mul_hi(d67, aq);
+                } else {
+                  y01 = pk_mul_lo(d01, zq); y23 = pk_mul_lo(d23, zq); y45 = pk_mul_lo(d45, zq); y67 = pk_mul_lo(d67, zq);
+                  b01 = pk_mul_lo(d01, aq); b23 = pk_mul_lo(d23, aq); b45 = pk_mul_lo(d45, aq); b67 = pk_mul_lo(d67, aq);
+                }
+              }
+              __builtin_amdgcn_sched_barrier(0);
+              f = mfma(fa.x, z01[0], f);   va = mfma(ga.x, a01[0], va);
+              f = mfma(fa.y, z01[1], f);   va = mfma(ga.y, a01[1], va);
+              f = mfma(fa.z, z23[0], f);   va = mfma(ga.z, a23[0], va);
+              f = mfma(fa.w, z23[1], f);   va = mfma(ga.w, a23[1], va);
+              f = mfma(fb.x, z45[0], f);   va = mfma(gb4.x, a45[0], va);
+              f = mfma(fb.y, z45[1], f);   va = mfma(gb4.y, a45[1], va);
+              f = mfma(fb.z, z67[0], f);   va = mfma(gb4.z, a67[0], va);
+              f = mfma(fb.w, z67[1], f);   va = mfma(gb4.w, a67[1], va);
+              __builtin_amdgcn_sched_barrier(0);
+              fa = nfa; fb = nfb; ga = nga; gb4 = ngb;
+              z01 = y01; z23 = y23; z45 = y45; z67 = y67; a01 = b01; a23 = b23; a45 = b45; a67 = b67;
             }
             const float4 wc = p1[32 * 64];               // bias steps: lane half hk contributes channel 2*sp + hk
             f = mfma(wc.x, half ? dX[1] : dX[0], f);
@@ -354,41 +496,55 @@ __global__ __launch_bounds__(256, 1) void rk4_adjoint_mfma(
             f = mfma(wc.w, half ? dX[7] : dX[6], f);
           }
 
-          // dL/dW tile c: D[h][k] += sum_series (w ds a_h dX_c)[series] * z_k[series].  This lane feeds
-          // MFMA K index `half` of K-step s2, i.e. series 2*s2 + half.
+          // ---- dL/dW tile c: D[h][k] += sum_series (w ds a_h dX_c)[series] * z_k[series]; this lane feeds MFMA
+          // K index `half` of K-step s2, i.e. series 2*s2 + half, row h = n, column k = n.
           {
-            const float* by = scr_y + half * 33 + n;     // + s2*66 : z_k[series],  k = n
-            const float* ba = scr_a + half * 33 + n;     // + s2*66 : a_h[series],  h = n
-            const float* bd = scr_dx + half * 8;         // + s2*16 : dX[series][0..7]
-#pragma unroll 2
-            for (int s2 = 0; s2 < 16; ++s2) {
-              const float zb = by[s2 * 66];
-              const float aa = ba[s2 * 66] * wq;
-              const float4 d0 = *reinterpret_cast<const float4*>(bd + s2 * 16);
-              const float4 d1 = *reinterpret_cast<const float4*>(bd + s2 * 16 + 4);
-              gb[0] = __builtin_fmaf(aa, d0.x, gb[0]); accW[0] = mfma(aa * d0.x, zb, accW[0]);
-              gb[1] = __builtin_fmaf(aa, d0.y, gb[1]); accW[1] = mfma(aa * d0.y, zb, accW[1]);
-              gb[2] = __builtin_fmaf(aa, d0.z, gb[2]); accW[2] = mfma(aa * d0.z, zb, accW[2]);
-              gb[3] = __builtin_fmaf(aa, d0.w, gb[3]); accW[3] = mfma(aa * d0.w, zb, accW[3]);
-              gb[4] = __builtin_fmaf(aa, d1.x, gb[4]); accW[4] = mfma(aa * d1.x, zb, accW[4]);
-              gb[5] = __builtin_fmaf(aa, d1.y, gb[5]); accW[5] = mfma(aa * d1.y, zb, accW[5]);
-              gb[6] = __builtin_fmaf(aa, d1.z, gb[6]); accW[6] = mfma(aa * d1.z, zb, accW[6]);
-              gb[7] = __builtin_fmaf(aa, d1.w, gb[7]); accW[7] = mfma(aa * d1.w, zb, accW[7]);
+            const float4* zt4 = reinterpret_cast<const float4*>(scr_zt + (half * 32 + n) * 20);
+            const float4* at4 = reinterpret_cast<const float4*>(scr_at + (half * 32 + n) * 20);
+            const float4* dw4 = reinterpret_cast<const float4*>(scr_dw + half * 8);      // + s2*4 (16 floats per s2)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              const float4 zq = zt4[g4], aq = at4[g4];                       // K-steps 4*g4 .. 4*g4+3
+              const f32x2 ap0 = {aq.x, aq.y}, ap1 = {aq.z, aq.w};
+              const float zs[4] = {zq.x, zq.y, zq.z, zq.w};
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const int s2 = 4 * g4 + i;
+                const float4 e0 = dw4[s2 * 4], e1 = dw4[s2 * 4 + 1];
+                const f32x2 e01 = {e0.x, e0.y}, e23 = {e0.z, e0.w}, e45 = {e1.x, e1.y}, e67 = {e1.z, e1.w};
+                const f32x2 asrc = i < 2 ? ap0 : ap1;
+                f32x2 v01, v23, v45, v67;
+                if (i & 1) {
+                  v01 = pk_mul_hi(e01, asrc); v23 = pk_mul_hi(e23, asrc); v45 = pk_mul_hi(e45, asrc); v67 = pk_mul_hi(e67, asrc);
+                  pk_fma_hi(gbp[0], e01, asrc); pk_fma_hi(gbp[1], e23, asrc); pk_fma_hi(gbp[2], e45, asrc); pk_fma_hi(gbp[3], e67, asrc);
+                } else {
+                  v01 = pk_mul_lo(e01, asrc); v23 = pk_mul_lo(e23, asrc); v45 = pk_mul_lo(e45, asrc); v67 = pk_mul_lo(e67, asrc);
+                  pk_fma_lo(gbp[0], e01, asrc); pk_fma_lo(gbp[1], e23, asrc); pk_fma_lo(gbp[2], e45, asrc); pk_fma_lo(gbp[3], e67, asrc);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const float zb = zs[i];
+                accW[0] = mfma(v01[0], zb, accW[0]); accW[1] = mfma(v01[1], zb, accW[1]);
+                accW[2] = mfma(v23[0], zb, accW[2]); accW[3] = mfma(v23[1], zb, accW[3]);
+                accW[4] = mfma(v45[0], zb, accW[4]); accW[5] = mfma(v45[1], zb, accW[5]);
+                accW[6] = mfma(v67[0], zb, accW[6]); accW[7] = mfma(v67[1], zb, accW[7]);
+                __builtin_amdgcn_sched_barrier(0);
+              }
             }
           }
           wave_lds_sync();   // scratch reads retired before the next stage overwrites it
 
-          // reverse-time dynamics: dy/ds = -f, da/ds = +a^T df/dz.  3/8 rule in two slots per
-          // variable: after stage 2 slot 1 holds k1 + 3*(k2+k3) (same association as torchdiffeq).
+          // ---- reverse-time dynamics: dy/ds = -f, da/ds = +a^T df/dz.  3/8 rule in two slots per variable:
+          // after stage 2 slot 1 holds k1 + 3*(k2+k3) (same association as torchdiffeq).
           const f32x16 ky = -f, ka = va;
+          const float third = (float)(1.0 / 3.0);
           if (stage == 0) {
             ky1 = ky; ka1 = ka;
-            yst = y0 + ds * ky1 * (float)(1.0 / 3.0);
-            ast = a0 + ds * ka1 * (float)(1.0 / 3.0);
+            yst = y0 + ds * ky1 * third;
+            ast = a0 + ds * ka1 * third;
           } else if (stage == 1) {
             ky2 = ky; ka2 = ka;
-            yst = y0 + ds * (ky2 - ky1 * (float)(1.0 / 3.0));
-            ast = a0 + ds * (ka2 - ka1 * (float)(1.0 / 3.0));
+            yst = y0 + ds * (ky2 - ky1 * third);
+            ast = a0 + ds * (ka2 - ka1 * third);
           } else if (stage == 2) {
             yst = y0 + ds * (ky1 - ky2 + ky);
             ast = a0 + ds * (ka1 - ka2 + ka);
@@ -398,7 +554,7 @@ __global__ __launch_bounds__(256, 1) void rk4_adjoint_mfma(
             yst = y0 + (ky1 + ky) * ds * 0.125f;
             ast = a0 + (ka1 + ka) * ds * 0.125f;
           }
-          row = nrow; idx = nidx; frac = nfrac;
+          idx = nidx; frac = nfrac;
         }
         y0 = yst; a0 = ast;
       }
@@ -423,8 +579,9 @@ __global__ __launch_bounds__(256, 1) void rk4_adjoint_mfma(
       my_partial[(h * MC + c) * MH + n] = accW[c][r];
     }
     // gb partial of lane (h = n, half): add the two halves through a lane exchange
-    const float other = __shfl_xor(gb[c], 32, 64);
-    if (half == 0) my_partial[MH * MC * MH + n * MC + c] = gb[c] + other;
+    const float mine_gb = gbp[c >> 1][c & 1];
+    const float other = __shfl_xor(mine_gb, 32, 64);
+    if (half == 0) my_partial[MH * MC * MH + n * MC + c] = mine_gb + other;
   }
 }
 
@@ -458,10 +615,10 @@ int launch_forward_mfma(const void* coeffs, const void* knots, int64_t n_interva
                         const void* bias, const void* z0, const void* grid, int64_t n_grid, const void* t_out,
                         int64_t n_out, void* z_out, int64_t B, const int64_t* stage_index, const void* stage_frac,
                         hipStream_t s) {
-  const unsigned blocks = (unsigned)((B + 127) / 128);
-  const size_t lds = W1_FLOATS * sizeof(float);
+  const unsigned blocks = (unsigned)((B + 127) / 128);     // 8 waves x 16 series, one workgroup per CU at B = 32768
+  const size_t lds = W16_FLOATS * sizeof(float);
 #define CDE_FWD(D)                                                                                                  \
-  rk4_forward_mfma<TT, D><<<blocks, 256, lds, s>>>((const float*)coeffs, (const float*)knots, n_intervals,          \
+  rk4_forward_mfma<TT, D><<<blocks, 512, lds, s>>>((const float*)coeffs, (const float*)knots, n_intervals,          \
                                                    (const float*)W, (const float*)bias, (const float*)z0,           \
                                                    (const TT*)grid, n_grid, (const TT*)t_out, n_out, (float*)z_out, \
                                                    B, stage_index, (const float*)stage_frac)
