@@ -216,19 +216,21 @@ def test_mfma_operand_layouts_reproduce_the_vector_field_and_its_vjps():
             _mfma_32x32x2([_w2_image(W, 8 * j + c, l) for l in lanes], a_own[:, j] * dX[n, c], acc)
     assert np.allclose(acc, own(vjp_ref))
 
-    # dL/dW through the (series -> K) LDS transpose: scratch rows have stride 33
-    scr_y = np.zeros(32 * 33); scr_a = np.zeros(32 * 33); scr_dx = np.zeros(32 * 8)
+    # dL/dW through the (series -> K) LDS transpose (layout of rk4_adjoint_mfma):
+    #   scr_zt[(par*32 + u)*20 + s] = z_u of series 2s+par,  scr_dw[series*8 + c] = wq*dX_c
+    wq = 0.375
+    scr_zt = np.zeros(64 * 20); scr_at = np.zeros(64 * 20); scr_dw = np.zeros(32 * 8)
     for l in lanes:
         for r in range(16):
-            scr_y[n[l] * 33 + 2 * r + half[l]] = z_own[l, r]
-            scr_a[n[l] * 33 + 2 * r + half[l]] = a_own[l, r]
-        scr_dx[n[l] * 8 + 4 * half[l]: n[l] * 8 + 4 * half[l] + 4] = dX[n[l], 4 * half[l]: 4 * half[l] + 4]
+            scr_zt[((n[l] & 1) * 32 + half[l]) * 20 + (n[l] >> 1) + r * 40] = z_own[l, r]
+            scr_at[((n[l] & 1) * 32 + half[l]) * 20 + (n[l] >> 1) + r * 40] = a_own[l, r]
+        scr_dw[n[l] * 8 + 4 * half[l]: n[l] * 8 + 4 * half[l] + 4] = wq * dX[n[l], 4 * half[l]: 4 * half[l] + 4]
     accW = np.zeros((8, 64, 16)); gb = np.zeros((64, 8))
     for s2 in range(16):
-        zb = scr_y[half * 33 + n + s2 * 66]
-        aa = scr_a[half * 33 + n + s2 * 66]
+        zb = scr_zt[(half * 32 + n) * 20 + s2]          # reader lane (k = n, half) -> series 2*s2 + half
+        aa = scr_at[(half * 32 + n) * 20 + s2]          # row h = n
         for c in range(8):
-            d = scr_dx[half * 8 + s2 * 16 + c]
+            d = scr_dw[(2 * s2 + half) * 8 + c]
             gb[:, c] += aa * d
             _mfma_32x32x2(aa * d, zb, accW[c])
     gW = np.zeros((H * C, H)); gbv = np.zeros(H * C)
@@ -239,7 +241,7 @@ def test_mfma_operand_layouts_reproduce_the_vector_field_and_its_vjps():
                 gW[h * C + c, n[l]] = accW[c, l, r]
             if half[l] == 0:
                 gbv[n[l] * C + c] = gb[l, c] + gb[l + 32, c]
-    assert np.allclose(gW, gW_ref) and np.allclose(gbv, gb_ref)
+    assert np.allclose(gW, wq * gW_ref) and np.allclose(gbv, wq * gb_ref)
 
 
 # ------------------------------------------------------------------ 16x16x4 layouts (forward kernel, 2 waves/SIMD)

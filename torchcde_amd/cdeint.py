@@ -15,6 +15,7 @@ Native scope (round 1):
 """
 import math
 import warnings
+import weakref
 
 import torch
 
@@ -66,6 +67,58 @@ def _parse_fixed_options(options, what):
     return step_size
 
 
+_host_copies = {}      # id(time tensor) -> (weakref, version, host copy): avoids a D2H sync per call
+_grid_cache = {}       # (times, dtype, steps, device) -> device-resident solver grids
+
+
+def _to_host(t):
+    """CPU copy of a (small) time tensor.  A GPU tensor costs one synchronising D2H copy the first time it is
+    seen; ``CubicSpline.interval`` hands out one cached tensor object, so steady-state calls do not sync.
+    (Keyed by id + weakref: tensors cannot be WeakKeyDictionary keys because ``==`` is elementwise.)"""
+    if not t.is_cuda:
+        return t.detach()
+    key = id(t)
+    hit = _host_copies.get(key)
+    if hit is not None and hit[0]() is t and hit[1] == t._version:
+        return hit[2]
+    host = t.detach().cpu()
+    if len(_host_copies) > 256:
+        for k in [k for k, v in _host_copies.items() if v[0]() is None]:
+            del _host_copies[k]
+    _host_copies[key] = (weakref.ref(t), t._version, host)
+    return host
+
+
+class _Grids:
+    """Solver grids for one (output times, step sizes) combination, resident on the device."""
+
+    def __init__(self, t_host, step_size, adjoint_step_size, device):
+        self.n_out = t_host.numel()
+        self.time_dtype = t_host.dtype
+        self.t_out = t_host.to(device)
+        self.grid = _fixed_grid(t_host, step_size).to(device)
+        # reversed-time grids, one per output interval, in processing order i = T-1 .. 1
+        pieces, offsets = [], [0]
+        for i in range(self.n_out - 1, 0, -1):
+            seg_t = -(t_host[i - 1:i + 1].flip(0))     # torchdiffeq: t[i-1:i+1].flip(0) is decreasing -> solved on -t
+            pieces.append(_fixed_grid(seg_t, adjoint_step_size))
+            offsets.append(offsets[-1] + pieces[-1].numel())
+        sgrid = torch.cat(pieces) if pieces else torch.zeros(0, dtype=t_host.dtype)
+        self.n_sgrid = sgrid.numel()
+        self.sgrid = sgrid.to(device)
+        self.seg_off = torch.tensor(offsets, dtype=torch.int64).to(device)
+
+
+def _grids_for(t_host, step_size, adjoint_step_size, device):
+    key = (t_host.numpy().tobytes(), str(t_host.dtype), step_size, adjoint_step_size, str(device))
+    hit = _grid_cache.get(key)
+    if hit is None:
+        if len(_grid_cache) > 64:
+            _grid_cache.clear()
+        hit = _grid_cache[key] = _Grids(t_host, step_size, adjoint_step_size, device)
+    return hit
+
+
 class _Plan:
     """Everything one cdeint call needs besides the differentiable tensors."""
 
@@ -92,13 +145,10 @@ class _Plan:
         self.device = coeffs.device
         self.adjoint = adjoint
         self.variant = variant
-        t_host = t.detach().cpu()
-        self.time_dtype = t_host.dtype
-        self.n_out = t_host.numel()
-        self.t_out = t_host.to(self.device)
-        self.grid = _fixed_grid(t_host, step_size).to(self.device)
-        self.adjoint_step_size = adjoint_step_size
-        self._t_host = t_host
+        grids = _grids_for(_to_host(t), step_size, adjoint_step_size, self.device)
+        self.grids = grids
+        self.time_dtype, self.n_out = grids.time_dtype, grids.n_out
+        self.t_out, self.grid = grids.t_out, grids.grid
         self.stage_index = None
         self.stage_frac = None
 
@@ -124,23 +174,9 @@ class _Plan:
         return out
 
     # backward: K3
-    def reverse_grids(self):
-        """Concatenated reversed-time grids, one per output interval, in processing order i = T-1 .. 1."""
-        t = self._t_host
-        pieces, offsets = [], [0]
-        for i in range(self.n_out - 1, 0, -1):
-            seg_t = -(t[i - 1:i + 1].flip(0))          # torchdiffeq: t[i-1:i+1].flip(0) is decreasing -> solved on -t
-            pieces.append(_fixed_grid(seg_t, self.adjoint_step_size))
-            offsets.append(offsets[-1] + pieces[-1].numel())
-        if pieces:
-            sgrid = torch.cat(pieces)
-        else:
-            sgrid = torch.zeros(0, dtype=t.dtype)
-        return sgrid.to(self.device), torch.tensor(offsets, dtype=torch.int64).to(self.device), sgrid.numel()
-
     def run_adjoint(self, z_saved, grad_out, weight, bias):
         lib = _lib.load()
-        sgrid, seg_off, n_sgrid = self.reverse_grids()
+        sgrid, seg_off, n_sgrid = self.grids.sgrid, self.grids.seg_off, self.grids.n_sgrid
         dt = _lib.dtype_enum(self.dtype)
         nbytes = lib.cde_rk4_adjoint_workspace_bytes(self.B, self.C, self.H, n_sgrid, dt, self.variant)
         workspace = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
@@ -299,7 +335,7 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         raise ValueError("t must contain at least one time.")
     if t.requires_grad and torch.is_grad_enabled():
         raise NotImplementedError("torchcde_amd: gradients with respect to the output times are not implemented.")
-    t_host = t.detach().cpu()
+    t_host = _to_host(t)
     if t_host.numel() > 1 and not bool((t_host[1:] > t_host[:-1]).all()):
         raise NotImplementedError("torchcde_amd: t must be strictly increasing on the native path.")
 

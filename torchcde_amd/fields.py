@@ -24,6 +24,7 @@ class AffineField:
     def __init__(self, linear, act):
         self.linear = linear
         self.act = act
+        self.shapes = {}          # verified input signature -> output shape of func
 
     @property
     def weight(self):
@@ -107,6 +108,16 @@ def probe(func, t0, z0):
     if linear is None:
         with torch.no_grad():
             return None, func(t0, z0)
+    signature = (tuple(z0.shape), z0.dtype, str(z0.device))
+    try:
+        known = _verified.get(func)
+    except TypeError:
+        known = None
+    if known is not None and known.linear is linear and signature in known.shapes:
+        # Verified before on an input of this very shape/dtype/device: the structural facts (one Linear fed by z,
+        # only reshapes / tanh after it, no time dependence) do not change with the VALUES of z or the weights, so
+        # the compatibility evaluation -- two launches plus synchronising comparisons -- is not repeated.
+        return known, torch.empty(known.shapes[signature], dtype=z0.dtype, device="meta")
     system, calls = _evaluate_recording(func, linear, t0, z0)
     act = _classify(system, calls, z0)
     if act is None:
@@ -125,4 +136,5 @@ def probe(func, t0, z0):
             _verified[func] = known
         except TypeError:
             pass
+    known.shapes[signature] = tuple(system.shape)
     return known, system

@@ -140,7 +140,14 @@ class _NativePath(InterpolationBase):
 
     @property
     def interval(self):
-        return torch.stack([self._t[0], self._t[-1]])
+        # One tensor object per (knots tensor, version): lets cdeint recognise repeated calls with
+        # ``t=X.interval`` without reading the values back from the device every time.
+        t = self._t
+        cached = getattr(self, "_interval_cache", None)
+        if cached is None or cached[0] is not t or cached[1] != t._version:
+            cached = (t, t._version, torch.stack([t[0], t[-1]]))
+            object.__setattr__(self, "_interval_cache", cached)
+        return cached[2]
 
     def _native_inputs(self):
         """(coeffs flattened to (B, rows, width) contiguous, knots, batch_shape)"""
