@@ -10,10 +10,11 @@ struct Vec {
 };
 
 // ------------------------------------------------------------------------------------------ K1
-// One lane produces V consecutive floats of one output row [a|b|2c|3d]; V divides C, so a lane's
-// elements share one coefficient kind and cover V consecutive channels.  Consecutive lanes write
-// consecutive 16-B pieces: a wave stores 1 KiB contiguous.  x is re-read from L1/L2 (each x row is
-// touched by the 3 neighbouring intervals x 4 kinds); HBM sees x once and coeffs once.
+// One lane produces, for one interval of one series, all four coefficient kinds of V consecutive channels
+// (V = 16 B worth): the IEEE divisions -- the expensive part, they must stay true divisions for bit parity --
+// are shared between the kinds (4 per channel instead of 10), and the knot derivative entering the interval is
+// taken from the lane that owns the previous interval of the same series when that lane is in the same wave.
+// Each of the 4 stores writes V*4-byte pieces; the four together cover whole 4C-float rows, which L2 merges.
 //
 // Arithmetic follows interpolation_hermite_cubic_bdiff.py:39 and :10-18 literally:
 //   secant_i = (x[i+1]-x[i]) / (t[i+1]-t[i])
@@ -23,59 +24,63 @@ struct Vec {
 template <typename T, int V>
 __global__ __launch_bounds__(256) void hermite_bdiff_kernel(const T* __restrict__ x, const T* __restrict__ t,
                                                             T* __restrict__ out, int64_t B, int64_t L, int64_t C) {
-  const int64_t row_vecs = 4 * C / V;
-  const int64_t n_rows = B * (L - 1);
-  const int64_t total = n_rows * row_vecs;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = e / row_vecs;
-    const int64_t q = (e - row * row_vecs) * V;  // first element inside the 4C-wide row
-    const int kind = (int)(q / C);
-    const int64_t c = q - (int64_t)kind * C;
-    const int64_t b = row / (L - 1);
-    const int64_t i = row - b * (L - 1);
-    const T* xi = x + (b * L + i) * C + c;
-    const T h = t[i + 1] - t[i];
-    const T h_prev = i > 0 ? t[i] - t[i - 1] : h;
-    Vec<T, V> lo = *reinterpret_cast<const Vec<T, V>*>(xi);
-    Vec<T, V> res;
-    if (kind == 0) {
-      res = lo;
-    } else {
-      Vec<T, V> hi = *reinterpret_cast<const Vec<T, V>*>(xi + C);
-      Vec<T, V> before = lo;
-      if (i > 0) before = *reinterpret_cast<const Vec<T, V>*>(xi - C);
+  const int64_t groups = C / V;                       // lanes per interval row
+  const int64_t total = B * (L - 1) * groups;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = e < total;
+  const int64_t ec = live ? e : total - 1;
+  const int64_t row = ec / groups;
+  const int64_t c = (ec - row * groups) * V;
+  const int64_t b = row / (L - 1);
+  const int64_t i = row - b * (L - 1);
+  const T* xi = x + (b * L + i) * C + c;
+  const T h = t[i + 1] - t[i];
+  const Vec<T, V> lo = *reinterpret_cast<const Vec<T, V>*>(xi);
+  const Vec<T, V> hi = *reinterpret_cast<const Vec<T, V>*>(xi + C);
+  Vec<T, V> rise, secant;
 #pragma unroll
-      for (int k = 0; k < V; ++k) {
-        const T rise = hi.v[k] - lo.v[k];
-        const T secant = rise / h;
-        const T enter = i > 0 ? (lo.v[k] - before.v[k]) / h_prev : secant;
-        if (kind == 1) {
-          res.v[k] = enter;
-        } else {
-          const T two_c = (T)2 * ((T)3 * (rise / h - enter) - secant + enter) / h;
-          if (kind == 2) {
-            res.v[k] = two_c;
-          } else {
-            res.v[k] = ((T)1 / (h * h)) * (secant - enter) - two_c / h;
-          }
-        }
-      }
+  for (int k = 0; k < V; ++k) { rise.v[k] = hi.v[k] - lo.v[k]; secant.v[k] = rise.v[k] / h; }
+  // previous interval of the same series lives `groups` lanes below (same wave) unless i == 0
+  const int lane = threadIdx.x & 63;
+  const bool from_neighbour = groups <= 32 && lane >= (int)groups && i > 0;
+  Vec<T, V> enter;
+#pragma unroll
+  for (int k = 0; k < V; ++k) enter.v[k] = __shfl_up(secant.v[k], (unsigned)(groups <= 32 ? groups : 1), 64);
+  if (!from_neighbour) {
+    if (i > 0) {
+      const Vec<T, V> before = *reinterpret_cast<const Vec<T, V>*>(xi - C);
+      const T h_prev = t[i] - t[i - 1];
+#pragma unroll
+      for (int k = 0; k < V; ++k) enter.v[k] = (lo.v[k] - before.v[k]) / h_prev;
+    } else {
+      enter = secant;
     }
-    *reinterpret_cast<Vec<T, V>*>(out + row * 4 * C + q) = res;
   }
+  if (!live) return;
+  const T inv_h2 = (T)1 / (h * h);
+  Vec<T, V> two_c, three_d;
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    two_c.v[k] = (T)2 * ((T)3 * (secant.v[k] - enter.v[k]) - secant.v[k] + enter.v[k]) / h;   // rise/h == secant
+    three_d.v[k] = inv_h2 * (secant.v[k] - enter.v[k]) - two_c.v[k] / h;
+  }
+  T* o = out + row * 4 * C + c;
+  *reinterpret_cast<Vec<T, V>*>(o) = lo;
+  *reinterpret_cast<Vec<T, V>*>(o + C) = enter;
+  *reinterpret_cast<Vec<T, V>*>(o + 2 * C) = two_c;
+  *reinterpret_cast<Vec<T, V>*>(o + 3 * C) = three_d;
 }
 
 template <typename T>
 static int launch_hermite(const void* x, const void* t, void* out, int64_t B, int64_t L, int64_t C, hipStream_t s) {
   constexpr int VMAX = 16 / sizeof(T);
-  const int64_t total_scalar = B * (L - 1) * 4 * C;
-  if (total_scalar == 0) return CDE_OK;
+  if (B * (L - 1) * C == 0) return CDE_OK;
   const bool aligned = ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0);
-  auto grid_for = [](int64_t n) { int64_t g = (n + 255) / 256; return (unsigned)(g > 262144 ? 262144 : g); };
+  auto grid_for = [](int64_t n) { return (unsigned)((n + 255) / 256); };
   if (aligned && C % VMAX == 0) {
-    hermite_bdiff_kernel<T, VMAX><<<grid_for(total_scalar / VMAX), 256, 0, s>>>((const T*)x, (const T*)t, (T*)out, B, L, C);
+    hermite_bdiff_kernel<T, VMAX><<<grid_for(B * (L - 1) * (C / VMAX)), 256, 0, s>>>((const T*)x, (const T*)t, (T*)out, B, L, C);
   } else {
-    hermite_bdiff_kernel<T, 1><<<grid_for(total_scalar), 256, 0, s>>>((const T*)x, (const T*)t, (T*)out, B, L, C);
+    hermite_bdiff_kernel<T, 1><<<grid_for(B * (L - 1) * C), 256, 0, s>>>((const T*)x, (const T*)t, (T*)out, B, L, C);
   }
   return check_launch();
 }
