@@ -35,6 +35,7 @@ FLOP_FWD = N_EVAL * (2 * H * (H * C) + 2 * H * C)                               
 FLOP_ADJ = N_EVAL * ((2 * H * H * C + 2 * H * C) + 2 * H * C + 2 * H * C * H + 2 * H * C * H + H * C)   # 25.6 MFLOP
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
+K3_HBM_BYTES_PER_LAUNCH = int(2 * 268.8e6 + 37.9e6)   # measured, see roofline.traffic_source
 
 
 def make_workload(device, seed):
@@ -199,7 +200,11 @@ def main():
                        "batch_per_gpu": B, "length": L, "input_channels": C, "hidden_channels": H,
                        "global_batch": B * world, "parallelism": "batch-sharded x%d, no data-path collective" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": K3_HBM_BYTES_PER_LAUNCH,
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload "
+                                           "(profiles/r01_pmc_summary.csv): 2 x 268.8 MB fetched (gfx950 half-count "
+                                           "correction for 16 B/lane reads) + 37.9 MB written; algorithmic bytes: "
+                                           "32768 x 12,704 B = 416 MB (whole 128 B rows: 550 MB)",
                          "kernel": "rk4_adjoint_mfma (K3)", "kernel_ms": adj_avg,
                          "algorithmic_flop_per_launch": B * FLOP_ADJ},
             "extra": {
