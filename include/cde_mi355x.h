@@ -150,6 +150,34 @@ int cde_rk4_adjoint_linear(const void* coeffs, const void* knots, int64_t n_inte
                            void* grad_b, int64_t B, int64_t C, int64_t H, int dtype, int time_dtype, int variant,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * K4  Adaptive Dormand-Prince 5(4) solve (torchdiffeq's default method, what cdeint runs when the
+ * caller passes no `method`: reference solver.py:226-227, README.md:174) for the affine family.
+ * Replaces torchdiffeq.odeint(method='dopri5', rtol, atol, options={'jump_t': ...}) including the
+ * batch-global error norm, step-size controller, jump handling and dense output.
+ *   t_out  (n_out) float64 DEVICE array, strictly increasing; jump_t (n_jump) float64 DEVICE array,
+ *          sorted ascending (may be NULL when n_jump == 0)
+ *   z_out  (B, n_out, H)
+ *   One call queues `n_launches` attempt kernels (one attempted step each; the first three launches
+ *   of a solve establish the initial step).  Call with first_launch = 0 to start, then continue with
+ *   first_launch += n_launches until the controller block at the head of `workspace` reports done:
+ *   workspace begins with two `cde_dopri5_status`-compatible structs; the one at index
+ *   (total_launches & 1) is current.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  double t_lo, t_hi, dt, t1_try, dt_try, h0;
+  int64_t i_out, i_jump, n_accept, n_reject;
+  int32_t phase; /* 4 == done */
+  int32_t on_jump, refresh, pad;
+} cde_dopri5_status;
+size_t cde_dopri5_workspace_bytes(int64_t B, int64_t C, int64_t H, int dtype);
+int cde_dopri5_advance(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
+                       const void* bias, int act, const void* z0, const double* t_out, int64_t n_out,
+                       const double* jump_t, int64_t n_jump, double rtol, double atol, double safety,
+                       double ifactor, double dfactor, void* z_out, int64_t B, int64_t C, int64_t H, int dtype,
+                       void* workspace, size_t workspace_bytes, int64_t first_launch, int64_t n_launches,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libcde_mi355x.so")
-SOURCES = ["interp_kernels.hip", "rk4_generic.hip", "rk4_mfma.hip", "api.hip"]
+SOURCES = ["interp_kernels.hip", "rk4_generic.hip", "rk4_mfma.hip", "dopri5.hip", "api.hip"]
 HEADERS = [os.path.join(_CSRC, "cde_common.h"), os.path.join(_HERE, "..", "include", "cde_mi355x.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC"]
 
@@ -54,7 +54,7 @@ def build(force=False, verbose=False):
     return SO_PATH
 
 
-_p, _i, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
+_p, _i, _i64, _sz, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_double
 _SIGNATURES = {
     "cde_abi_version": (_i, []),
     "cde_error_string": (ctypes.c_char_p, [_i]),
@@ -65,10 +65,22 @@ _SIGNATURES = {
     "cde_rk4_forward_linear": (_i, [_p, _p, _i64, _i, _p, _p, _i, _p, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i, _i,
                                     _i, _p, _p, _p]),
     "cde_rk4_adjoint_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i, _i]),
+    "cde_dopri5_workspace_bytes": (_sz, [_i64, _i64, _i64, _i]),
+    "cde_dopri5_advance": (_i, [_p, _p, _i64, _i, _p, _p, _i, _p, _p, _i64, _p, _i64, _d, _d, _d, _d, _d, _p, _i64, _i64,
+                                _i64, _i, _p, _sz, _i64, _i64, _p]),
     "cde_rk4_adjoint_linear": (_i, [_p, _p, _i64, _i, _p, _p, _i, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _i64, _i64,
                                     _i64, _i, _i, _i, _p, _sz, _p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class DopriStatus(ctypes.Structure):
+    """Mirror of cde_dopri5_status (include/cde_mi355x.h)."""
+    _fields_ = [("t_lo", ctypes.c_double), ("t_hi", ctypes.c_double), ("dt", ctypes.c_double),
+                ("t1_try", ctypes.c_double), ("dt_try", ctypes.c_double), ("h0", ctypes.c_double),
+                ("i_out", ctypes.c_int64), ("i_jump", ctypes.c_int64), ("n_accept", ctypes.c_int64),
+                ("n_reject", ctypes.c_int64), ("phase", ctypes.c_int32), ("on_jump", ctypes.c_int32),
+                ("refresh", ctypes.c_int32), ("pad", ctypes.c_int32)]
 
 
 def load():

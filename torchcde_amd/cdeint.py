@@ -10,9 +10,12 @@ Native scope (round 1):
   * X: ``torchcde_amd.CubicSpline`` or ``torchcde_amd.LinearInterpolation``
   * func: the affine family recognised by ``torchcde_amd.fields`` (Linear(H, H*C) [+ tanh] viewed (..., H, C))
   * backend "torchdiffeq", ``method='rk4'`` (torchdiffeq's 3/8-rule), ``options={'step_size': h}`` or no options
-    (grid = t, torchdiffeq's behaviour), increasing ``t``, tensor state
-  * gradients: continuous adjoint (``adjoint=True``) for z0 and the field's weight / bias
+    (grid = t, torchdiffeq's behaviour), increasing ``t``, tensor state; gradients by the continuous adjoint
+    (``adjoint=True``) for z0 and the field's weight / bias
+  * ``method='dopri5'`` (also the default when no method is passed, as in the reference): adaptive solve with
+    torchdiffeq's batch-global controller, ``rtol/atol`` and ``options={'jump_t': ...}``; forward only
 """
+import ctypes
 import math
 import warnings
 import weakref
@@ -223,6 +226,86 @@ class _FusedRK4(torch.autograd.Function):
                 None, None)
 
 
+# ------------------------------------------------------------------------------------------ dopri5 (K4)
+last_dopri5_stats = {}     # {"n_accept", "n_reject", "launches"} of the most recent adaptive solve (for tests / logging)
+_DOPRI_CHUNK = 48          # attempt kernels queued between two looks at the done flag
+
+
+class _Dopri5Plan:
+    def __init__(self, path, field, batch, H, C, t, rtol, atol, options):
+        options = {} if options is None else dict(options)
+        jump_t = options.pop("jump_t", None)
+        self.safety = float(options.pop("safety", 0.9))
+        self.ifactor = float(options.pop("ifactor", 10.0))
+        self.dfactor = float(options.pop("dfactor", 0.2))
+        for key in ("first_step", "step_t", "min_step", "max_step", "max_num_steps", "dtype", "norm"):
+            if options.get(key, None) is not None:
+                raise NotImplementedError("torchcde_amd: dopri5 option %r is not supported natively" % key)
+            options.pop(key, None)
+        if options:
+            raise NotImplementedError("torchcde_amd: unsupported dopri5 options %s" % sorted(options))
+        coeffs, knots, _ = path._native_inputs()
+        self.coeffs, self.knots = coeffs, knots
+        self.n_intervals, self.degree, self.act = path._n_intervals(), path._degree, field.act
+        self.batch, self.B, self.H, self.C = batch, coeffs.size(0), H, C
+        self.dtype, self.device = coeffs.dtype, coeffs.device
+        self.rtol = float(rtol)
+        self.atol = float(atol)
+        t_host = _to_host(t).to(torch.float64)
+        self.n_out = t_host.numel()
+        self.t_out = t_host.to(self.device)
+        if jump_t is None:
+            self.jump_t, self.n_jump = None, 0
+        else:
+            jt = _to_host(torch.as_tensor(jump_t)).to(torch.float64).reshape(-1)
+            jt = torch.sort(jt).values
+            self.jump_t, self.n_jump = jt.to(self.device), jt.numel()
+
+    def run(self, z0, weight, bias):
+        lib = _lib.load()
+        out = torch.empty(self.B, self.n_out, self.H, dtype=self.dtype, device=self.device)
+        z0c = z0.detach().reshape(self.B, self.H).contiguous()
+        if self.n_out == 1:
+            out[:, 0] = z0c
+            return out
+        w, b = weight.detach().contiguous(), bias.detach().contiguous()
+        dt = _lib.dtype_enum(self.dtype)
+        nbytes = lib.cde_dopri5_workspace_bytes(self.B, self.C, self.H, dt)
+        workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        size = ctypes.sizeof(_lib.DopriStatus)
+        launched = 0
+        while True:
+            _lib.check(lib.cde_dopri5_advance(
+                _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w), _lib.ptr(b),
+                self.act, _lib.ptr(z0c), _lib.ptr(self.t_out), self.n_out, _lib.ptr(self.jump_t), self.n_jump,
+                self.rtol, self.atol, self.safety, self.ifactor, self.dfactor, _lib.ptr(out), self.B, self.C, self.H, dt,
+                _lib.ptr(workspace), workspace.numel(), launched, _DOPRI_CHUNK, _lib.stream_ptr(self.device)),
+                "cde_dopri5_advance")
+            launched += _DOPRI_CHUNK
+            raw = workspace[(launched & 1) * size:(launched & 1) * size + size].cpu().numpy().tobytes()   # one sync per chunk
+            status = _lib.DopriStatus.from_buffer_copy(raw)
+            if status.phase == 4:
+                break
+            if launched > 2_000_000:
+                raise RuntimeError("torchcde_amd: dopri5 did not reach t[-1] after %d attempted steps (t = %g, dt = %g)"
+                                   % (launched, status.t_hi, status.dt))
+        last_dopri5_stats.clear()
+        last_dopri5_stats.update(n_accept=status.n_accept, n_reject=status.n_reject, launches=launched)
+        return out
+
+
+class _FusedDopri5(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z0, weight, bias, plan):
+        out = plan.run(z0, weight, bias)
+        return out.reshape(*plan.batch, plan.n_out, plan.H)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        raise NotImplementedError("torchcde_amd: gradients through the adaptive dopri5 solve are not implemented on "
+                                  "the native path yet; use method='rk4' for training or run dopri5 under no_grad.")
+
+
 # ------------------------------------------------------------------------------------------ front end
 def _shape_errors(dX_shape, system_shape, z0):
     # messages of reference solver.py:7-33
@@ -313,10 +396,28 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
     options = kwargs.pop("options", None)
     if method is None:
         method = "dopri5"
-    if method != "rk4":
-        raise NotImplementedError("torchcde_amd: method={!r} is not implemented natively yet; use method='rk4' with "
-                                  "options={{'step_size': ...}} (torchdiffeq's default dopri5 is the next kernel on "
-                                  "the list).".format(method))
+    if method not in ("rk4", "dopri5"):
+        raise NotImplementedError("torchcde_amd: method={!r} is not implemented natively; use 'rk4' (torchdiffeq's "
+                                  "3/8-rule, options={{'step_size': ...}}) or 'dopri5'.".format(method))
+    if not (isinstance(t, torch.Tensor) and t.dim() == 1 and t.is_floating_point()):
+        raise ValueError("t must be a one dimensional floating point tensor.")
+    if t.numel() < 1:
+        raise ValueError("t must contain at least one time.")
+    if t.requires_grad and torch.is_grad_enabled():
+        raise NotImplementedError("torchcde_amd: gradients with respect to the output times are not implemented.")
+    t_host = _to_host(t)
+    if t_host.numel() > 1 and not bool((t_host[1:] > t_host[:-1]).all()):
+        raise NotImplementedError("torchcde_amd: t must be strictly increasing on the native path.")
+    if method == "dopri5":
+        for key in ("adjoint_method", "adjoint_options", "adjoint_params"):
+            kwargs.pop(key, None)
+        rtol, atol = kwargs.pop("rtol"), kwargs.pop("atol")
+        for key in ("adjoint_atol", "adjoint_rtol"):
+            kwargs.pop(key, None)
+        if kwargs:
+            raise NotImplementedError("torchcde_amd: unsupported cdeint keyword arguments {}".format(sorted(kwargs)))
+        plan = _Dopri5Plan(X, field, batch, H, C, t, rtol, atol, options)
+        return _FusedDopri5.apply(z0, weight, bias, plan)
     step_size = _parse_fixed_options(options, "solver")
     adjoint_method = kwargs.pop("adjoint_method", None)
     adjoint_options = kwargs.pop("adjoint_options", None)
@@ -328,16 +429,6 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
     if adjoint_method not in (None, "rk4"):
         raise NotImplementedError("torchcde_amd: adjoint_method must equal the forward method ('rk4').")
     adjoint_step = step_size if adjoint_options is None else _parse_fixed_options(adjoint_options, "adjoint")
-
-    if not (isinstance(t, torch.Tensor) and t.dim() == 1 and t.is_floating_point()):
-        raise ValueError("t must be a one dimensional floating point tensor.")
-    if t.numel() < 1:
-        raise ValueError("t must contain at least one time.")
-    if t.requires_grad and torch.is_grad_enabled():
-        raise NotImplementedError("torchcde_amd: gradients with respect to the output times are not implemented.")
-    t_host = _to_host(t)
-    if t_host.numel() > 1 and not bool((t_host[1:] > t_host[:-1]).all()):
-        raise NotImplementedError("torchcde_amd: t must be strictly increasing on the native path.")
 
     want_w = want_b = True
     if adjoint_params is not None:

@@ -1,0 +1,425 @@
+// dopri5.hip -- K4: adaptive Dormand-Prince 5(4) CDE solve for the affine vector-field family.
+//
+// Replaces torchdiffeq.odeint(method='dopri5') behind reference solver.py:226-227 (torchcde's DEFAULT method:
+// cdeint passes no `method` unless the user does, README.md:174) together with _VectorField.forward
+// (solver.py:117-135) and the control derivative inside it.  Semantics restated in oracle/odeint.py (_Dopri5):
+//   * ONE step size for the whole batch: error ratio = RMS over all B*H elements of err/(atol+rtol*max|y0|,|y1|)
+//   * time-like quantities (t, dt, tolerances, controller) in float64, state in `dtype`
+//   * stage times formed in the state dtype: t0 + alpha_i*dt, the two alpha == 1 stages at nextafter(t1, -inf)
+//   * jump_t: steps are clipped to land exactly on the next jump time and f is re-evaluated just after it
+//   * first step by Hairer's rule (two extra evaluations), outputs by the 4th-order dense interpolant
+//
+// Execution model.  A batch-global decision per attempted step needs a grid-wide reduction; instead of a host
+// round trip or a cooperative grid barrier, every launch of `dopri5_attempt_kernel` is "finish the previous
+// attempt, start the next": in its prologue each workgroup re-derives the accept/reject decision from the
+// per-workgroup error partials the previous launch left in global memory (summed in a fixed order: the decision
+// is bit-identical in every workgroup and run-to-run), commits its series' state, emits any outputs the accepted
+// step covered, and then runs the 6 new stages.  The controller state ping-pongs between two structs.  The host
+// only queues launches and looks at a done flag every few dozen of them.
+#include "cde_common.h"
+
+namespace cde {
+
+struct DopriCtrl {
+  double t_lo, t_hi, dt;        // dense-output interval of the last accepted step, next step size
+  double t1_try, dt_try;        // the attempt whose partial sums are pending
+  double h0;                    // Hairer initial step, phase 1 -> 2
+  int64_t i_out, i_jump;        // next output index, next jump index
+  int64_t n_accept, n_reject;
+  int32_t phase;                // 0 start, 1 after f0 norms, 2 after f1 norm, 3 stepping, 4 done
+  int32_t on_jump;              // pending attempt was clipped to a jump time
+  int32_t refresh;              // k0 must be recomputed just after t_hi (we stepped onto a jump)
+  int32_t pad;
+};
+
+template <typename T>
+struct DopriArgs {
+  const T* coeffs; const T* knots; int64_t n_intervals; int degree;
+  const T* W; const T* bias; int act;
+  const T* z0; const double* t_out; int64_t n_out; const double* jump_t; int64_t n_jump;
+  double rtol, atol, safety, ifactor, dfactor;
+  T* z_out; int64_t B, C, H; int NS;
+  DopriCtrl* ctrl;              // [2]
+  T* state;                     // [2][9][B*H]: y0, y1, k0..k6
+  double* partial;              // [2][n_blocks][2], accumulated in float64 whatever the state dtype
+  int64_t n_blocks_alloc;
+};
+
+__device__ __forceinline__ float next_toward(float x, float dir) { return nextafterf(x, x + dir); }
+__device__ __forceinline__ double next_toward(double x, double dir) { return nextafter(x, x + dir); }
+
+// Dormand-Prince tableau (identical numbers to oracle/odeint.py)
+__device__ constexpr double DP_ALPHA[6] = {1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1.0, 1.0};
+__device__ constexpr double DP_BETA[6][6] = {
+    {1.0 / 5, 0, 0, 0, 0, 0},
+    {3.0 / 40, 9.0 / 40, 0, 0, 0, 0},
+    {44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0, 0},
+    {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0, 0},
+    {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656, 0},
+    {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84}};
+__device__ constexpr double DP_CERR[7] = {35.0 / 384 - 1951.0 / 21600, 0, 500.0 / 1113 - 22642.0 / 50085,
+                                          125.0 / 192 - 451.0 / 720, -2187.0 / 6784 - -12231.0 / 42400,
+                                          11.0 / 84 - 649.0 / 6300, -1.0 / 60};
+__device__ constexpr double DP_CMID[7] = {6025192743.0 / 30085553152.0 / 2, 0, 51252292925.0 / 65400821598.0 / 2,
+                                          -2691868925.0 / 45128329728.0 / 2, 187940372067.0 / 1594534317056.0 / 2,
+                                          -1776094331.0 / 19743644256.0 / 2, 11237099.0 / 235043384.0 / 2};
+
+// vector field row for lane (s,h): sum_c act(bias + W z) dX_c, control derivative at time ts
+template <typename T>
+__device__ __forceinline__ T dopri_field(const DopriArgs<T>& g, T* zs, T* dx, T zval, T ts, int64_t tile, int s, int h,
+                                         bool lane_on) {
+  const int H = (int)g.H, C = (int)g.C, NS = g.NS;
+  T frac;
+  const int64_t idx = locate(g.knots, g.n_intervals, ts, frac);
+  __syncthreads();
+  if (lane_on) zs[s * H + h] = zval;
+  for (int e = threadIdx.x; e < NS * C; e += blockDim.x) {
+    const int s2 = e / C, c = e - s2 * C;
+    int64_t ser = tile * NS + s2;
+    ser = ser < g.B ? ser : g.B - 1;
+    T d;
+    if (g.degree == CDE_PATH_CUBIC) {
+      const T* row = g.coeffs + (ser * g.n_intervals + idx) * 4 * C;
+      d = cubic_derivative(row[C + c], row[2 * C + c], row[3 * C + c], frac);
+    } else {
+      const T* lo = g.coeffs + (ser * (g.n_intervals + 1) + idx) * C;
+      d = (lo[C + c] - lo[c]) / (g.knots[idx + 1] - g.knots[idx]);
+    }
+    dx[e] = d;
+  }
+  __syncthreads();
+  T acc = (T)0;
+  if (lane_on) {
+    const T* zrow = zs + s * H;
+    const T* drow = dx + s * C;
+    for (int c = 0; c < C; ++c) {
+      const T* w = g.W + ((int64_t)h * C + c) * H;
+      T y = g.bias[h * C + c];
+      for (int k = 0; k < H; ++k) y = fma_t(w[k], zrow[k], y);
+      if (g.act == CDE_ACT_TANH) y = tanh_t(y);
+      acc = fma_t(y, drow[c], acc);
+    }
+  }
+  return acc;
+}
+
+// block-wide sum of two values, result valid in every thread (fixed tree order)
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* red) {
+  const int tid = threadIdx.x, n = blockDim.x;
+  __syncthreads();
+  red[tid] = a; red[n + tid] = b;
+  __syncthreads();
+  for (int off = 1; off < n; off <<= 1) {
+    double va = 0.0, vb = 0.0;
+    const bool act = (tid % (2 * off)) == 0 && tid + off < n;
+    if (act) { va = red[tid + off]; vb = red[n + tid + off]; }
+    __syncthreads();
+    if (act) { red[tid] += va; red[n + tid] += vb; }
+    __syncthreads();
+  }
+  a = red[0]; b = red[n];
+  __syncthreads();
+}
+
+template <typename T>
+__global__ void dopri5_attempt_kernel(DopriArgs<T> g, int parity) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int H = (int)g.H, C = (int)g.C, NS = g.NS;
+  T* zs = reinterpret_cast<T*>(smem_raw);
+  T* dx = zs + NS * H;
+  double* red = reinterpret_cast<double*>(smem_raw + (((size_t)(NS * (H + C)) * sizeof(T) + 15) / 16) * 16);   // 2 * blockDim doubles
+  const int tid = threadIdx.x;
+  const int s = tid / H, h = tid - s * H;
+  const bool lane_on = s < NS;
+  const int64_t n_tiles = (g.B + NS - 1) / NS;
+  const int64_t BH = g.B * g.H;
+  const int p = parity, q = parity ^ 1;
+  DopriCtrl c = g.ctrl[p];
+  if (c.phase == 4) {                                           // finished: keep the flag alive in both structs
+    if (blockIdx.x == 0 && tid == 0) g.ctrl[q] = c;
+    return;
+  }
+  T* Sp = g.state + (int64_t)p * 9 * BH;                        // what the previous launch produced
+  T* Sq = g.state + (int64_t)q * 9 * BH;                        // what this launch produces
+  const double* Pp = g.partial + (int64_t)p * g.n_blocks_alloc * 2;
+  double* Pq = g.partial + (int64_t)q * g.n_blocks_alloc * 2;
+  const double n_elems = (double)BH;
+  const T rtol = (T)g.rtol, atol = (T)g.atol;
+
+  // ---- pending global sums of the previous launch (fixed order -> identical in every workgroup)
+  double sum0 = 0.0, sum1 = 0.0;
+  if (c.phase != 0) {
+    for (int64_t b = tid; b < (int64_t)gridDim.x; b += blockDim.x) { sum0 += Pp[2 * b]; sum1 += Pp[2 * b + 1]; }
+    block_sum2(sum0, sum1, red);
+  }
+
+  // ---- controller (uniform arithmetic, every thread computes the same values)
+  bool accept = false;
+  int mode;                     // what this launch computes: 0 = f0 norms, 1 = f1 norm, 2 = attempt, 3 = nothing more
+  double t0 = 0, t1 = 0, dt = 0;
+  T h0_state = (T)0;
+  int on_jump = 0;
+  if (c.phase == 0) {
+    mode = 0;
+    c.t_lo = c.t_hi = g.t_out[0];
+    c.i_out = 1; c.i_jump = 0; c.n_accept = c.n_reject = 0; c.refresh = 0;
+    // first jump strictly after nothing: torchdiffeq keeps jump times >= t0 and starts at bisect(jump_t, t0)
+    int64_t j = 0;
+    while (j < g.n_jump && g.jump_t[j] < c.t_hi) ++j;          // drop jumps before t0
+    int64_t first = j;
+    while (j < g.n_jump && g.jump_t[j] <= c.t_hi) ++j;         // bisect_right
+    c.i_jump = j - first;
+    if (g.n_jump - first > 0 && c.i_jump > g.n_jump - first - 1) c.i_jump = g.n_jump - first - 1;
+    c.pad = (int32_t)first;                                    // offset of the first kept jump time
+  } else if (c.phase == 1) {
+    // Hairer: d0 = ||y0/scale||, d1 = ||f0/scale||
+    const T d0 = (T)sqrt(sum0 / n_elems), d1 = (T)sqrt(sum1 / n_elems);
+    T h0;
+    if (d0 < (T)1e-5 || d1 < (T)1e-5) h0 = (T)1e-6; else h0 = (T)0.01 * d0 / d1;
+    h0 = h0 < 0 ? -h0 : h0;
+    c.h0 = (double)h0;
+    h0_state = h0;
+    c.dt = (double)d1;                                          // park d1 for phase 2
+    mode = 1;
+  } else if (c.phase == 2) {
+    const T h0 = (T)c.h0, d1 = (T)c.dt;
+    const T d2 = (T)sqrt(sum0 / n_elems) / h0;
+    T h1;
+    if (d1 <= (T)1e-15 && d2 <= (T)1e-15) {
+      const T a = (T)1e-6, b = h0 * (T)1e-3;
+      h1 = a > b ? a : b;
+    } else {
+      // torch: (0.01 / max(d1, d2)) ** (1/5) on a 0-d tensor of the state dtype
+      const T m = d1 > d2 ? d1 : d2;
+      if (sizeof(T) == 4) h1 = (T)powf((float)((T)0.01 / m), (float)(1.0 / 5.0));
+      else h1 = (T)pow((double)((T)0.01 / m), 1.0 / 5.0);
+    }
+    h1 = h1 < 0 ? -h1 : h1;
+    const T hundred = (T)100 * h0;
+    c.dt = (double)(hundred < h1 ? hundred : h1);
+    mode = 2;
+  } else {
+    // decide the pending attempt: ratio = sqrt(mean((err/tol)^2))
+    const T ratio_t = (T)sqrt(sum0 / n_elems);
+    accept = ratio_t <= (T)1;
+    // (min_step = 0, max_step = inf: the extra accept/reject overrides of torchdiffeq never fire)
+    if (accept) {
+      c.n_accept++;
+      c.t_lo = c.t_hi; c.t_hi = c.t1_try;
+      c.refresh = 0;
+      if (c.on_jump) {
+        const int64_t kept = g.n_jump - c.pad;
+        if (c.i_jump != kept - 1) c.i_jump++;
+        c.refresh = 1;
+      }
+    } else {
+      c.n_reject++;
+      c.t_lo = c.t_hi;                                          // oracle: t_lo, t_hi = t0, t0
+    }
+    // next step size (float64)
+    const double ratio = (double)ratio_t;
+    double factor;
+    if (ratio == 0.0) factor = g.ifactor;
+    else {
+      const double dfac = ratio < 1.0 ? 1.0 : g.dfactor;
+      double f = g.safety / pow(ratio, 1.0 / 5.0);
+      f = f > dfac ? f : dfac;
+      factor = g.ifactor < f ? g.ifactor : f;
+    }
+    c.dt = c.dt_try * factor;
+    mode = 2;
+  }
+
+  // ---- per-series work
+  double acc0 = 0.0, acc1 = 0.0;
+  const double t_end = g.t_out[g.n_out - 1];
+  // how many outputs does the accepted interval [t_lo, t_hi] cover?
+  int64_t emit_from = c.i_out, emit_to = c.i_out;
+  if (c.phase == 3 && accept) {
+    while (emit_to < g.n_out && !(g.t_out[emit_to] > c.t_hi)) ++emit_to;
+    c.i_out = emit_to;
+  }
+  const bool finished = (c.phase == 3 && c.i_out >= g.n_out);
+  if (finished) mode = 3;
+  const double dt_done = c.dt_try;                              // step size of the attempt just decided (dense output)
+
+  if (mode == 2) {
+    // new attempt from t_hi
+    t0 = c.t_hi;
+    dt = c.dt;
+    if (!(dt == dt) || dt > 1e300 || dt < -1e300) dt = 0.0;     // non-finite -> min_step (0)
+    t1 = t0 + dt;
+    const int64_t kept = g.n_jump - c.pad;
+    if (kept > 0) {
+      const double nxt = g.jump_t[c.pad + c.i_jump];
+      if (t0 < nxt && nxt < t0 + dt) { on_jump = 1; t1 = nxt; dt = t1 - t0; }
+    }
+    c.t1_try = t1; c.dt_try = dt; c.on_jump = on_jump;
+  }
+
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t series = tile * NS + s;
+    const bool valid = lane_on && series < g.B;
+    const int64_t e = valid ? series * H + h : 0;
+    T y = (T)0, k0 = (T)0;
+    if (c.phase == 0) {
+      y = valid ? g.z0[e] : (T)0;
+      if (valid) g.z_out[(series * g.n_out) * H + h] = y;
+    } else if (c.phase == 1 || c.phase == 2) {
+      y = valid ? Sp[0 * BH + e] : (T)0;
+      k0 = valid ? Sp[2 * BH + e] : (T)0;
+    } else {
+      // commit the pending attempt
+      const T y0p = valid ? Sp[0 * BH + e] : (T)0, y1p = valid ? Sp[1 * BH + e] : (T)0;
+      T kk[7];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) kk[j] = valid ? Sp[(2 + j) * BH + e] : (T)0;
+      if (accept) {
+        // dense output over [t_lo, t_hi] for every output time the step covered (oracle _fit_dense/_eval_dense)
+        if (emit_to > emit_from) {
+          const T dtf = (T)dt_done;
+          T ymid = (T)0;
+#pragma unroll
+          for (int j = 0; j < 7; ++j) ymid += kk[j] * (dtf * (T)DP_CMID[j]);
+          ymid = y0p + ymid;
+          const T f0 = kk[0], f1 = kk[6];
+          const T ca = (T)2 * dtf * (f1 - f0) - (T)8 * (y1p + y0p) + (T)16 * ymid;
+          const T cb = dtf * ((T)5 * f0 - (T)3 * f1) + (T)18 * y0p + (T)14 * y1p - (T)32 * ymid;
+          const T cc = dtf * (f1 - (T)4 * f0) - (T)11 * y0p - (T)5 * y1p + (T)16 * ymid;
+          const T cd = dtf * f0;
+          for (int64_t io = emit_from; io < emit_to; ++io) {
+            const T x = (T)((g.t_out[io] - c.t_lo) / (c.t_hi - c.t_lo));
+            T total = y0p + x * cd;
+            T xp = x;
+            xp = xp * x; total = total + xp * cc;
+            xp = xp * x; total = total + xp * cb;
+            xp = xp * x; total = total + xp * ca;
+            if (valid) g.z_out[(series * g.n_out + io) * H + h] = total;
+          }
+        }
+        y = y1p; k0 = kk[6];
+      } else {
+        y = y0p; k0 = kk[0];
+      }
+    }
+    if (mode == 3) continue;
+
+    if (mode == 0) {
+      const T ts = (T)c.t_hi;
+      k0 = dopri_field(g, zs, dx, y, ts, tile, s, h, lane_on);
+      const T scale = atol + (y < 0 ? -y : y) * rtol;
+      if (valid) {
+        const T a = y / scale, b = k0 / scale;
+        acc0 += (double)(a * a); acc1 += (double)(b * b);
+        Sq[0 * BH + e] = y; Sq[2 * BH + e] = k0;
+      }
+    } else if (mode == 1) {
+      const T yy = y + h0_state * k0;
+      const T ts = (T)(c.t_hi + (double)h0_state);              // t0 (float64) + h0, cast by the field wrapper
+      const T f1 = dopri_field(g, zs, dx, yy, ts, tile, s, h, lane_on);
+      const T scale = atol + (y < 0 ? -y : y) * rtol;
+      if (valid) {
+        const T a = (f1 - k0) / scale;
+        acc0 += (double)(a * a);
+        Sq[0 * BH + e] = y; Sq[2 * BH + e] = k0;
+      }
+    } else {
+      const T t0f = (T)t0, dtf = (T)dt, t1f = (T)t1;
+      if (c.refresh) k0 = dopri_field(g, zs, dx, y, next_toward(t0f, (T)1), tile, s, h, lane_on);   // just after the jump
+      T kk[7];
+      kk[0] = k0;
+      T yi = y;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        T ti;
+        if (i >= 4) ti = next_toward(t1f, (T)-1); else ti = t0f + (T)DP_ALPHA[i] * dtf;
+        T inc = (T)0;
+#pragma unroll
+        for (int j = 0; j <= i; ++j) inc += kk[j] * ((T)DP_BETA[i][j] * dtf);
+        yi = y + inc;
+        kk[i + 1] = dopri_field(g, zs, dx, yi, ti, tile, s, h, lane_on);
+      }
+      const T y1 = yi;
+      T err = (T)0;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) err += kk[j] * (dtf * (T)DP_CERR[j]);
+      const T ay = y < 0 ? -y : y, ay1 = y1 < 0 ? -y1 : y1;
+      const T tol = atol + rtol * (ay > ay1 ? ay : ay1);
+      if (valid) {
+        const T r = err / tol;
+        acc0 += (double)(r * r);
+        Sq[0 * BH + e] = y; Sq[1 * BH + e] = y1;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) Sq[(2 + j) * BH + e] = kk[j];
+      }
+    }
+  }
+  (void)t_end;
+  // ---- publish this launch's partial sums and the controller state for the next launch
+  block_sum2(acc0, acc1, red);
+  if (tid == 0) { Pq[2 * blockIdx.x] = acc0; Pq[2 * blockIdx.x + 1] = acc1; }
+  if (blockIdx.x == 0 && tid == 0) {
+    if (mode == 0) c.phase = 1;
+    else if (mode == 1) c.phase = 2;
+    else if (mode == 2) c.phase = 3;
+    else c.phase = 4;
+    g.ctrl[q] = c;
+  }
+}
+
+static inline int dopri_ns(int64_t H) { int ns = (int)(256 / H); return ns < 1 ? 1 : (ns > 16 ? 16 : ns); }
+static inline int64_t dopri_blocks(int64_t B, int64_t H) {
+  const int ns = dopri_ns(H);
+  int64_t tiles = (B + ns - 1) / ns;
+  return tiles < 1 ? 1 : (tiles > 2048 ? 2048 : tiles);
+}
+static inline size_t al256(size_t x) { return (x + 255) / 256 * 256; }
+
+}  // namespace cde
+
+// ================================================================================================ C ABI
+extern "C" size_t cde_dopri5_workspace_bytes(int64_t B, int64_t C, int64_t H, int dtype) {
+  (void)C;
+  const size_t elem = dtype == CDE_F64 ? 8 : 4;
+  return cde::al256(2 * sizeof(cde::DopriCtrl)) + cde::al256((size_t)2 * cde::dopri_blocks(B, H) * 2 * sizeof(double)) +
+         (size_t)2 * 9 * B * H * elem;
+}
+
+extern "C" int cde_dopri5_advance(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
+                                  const void* bias, int act, const void* z0, const double* t_out, int64_t n_out,
+                                  const double* jump_t, int64_t n_jump, double rtol, double atol, double safety,
+                                  double ifactor, double dfactor, void* z_out, int64_t B, int64_t C, int64_t H,
+                                  int dtype, void* workspace, size_t workspace_bytes, int64_t first_launch,
+                                  int64_t n_launches, void* stream) {
+  if (B < 1 || C < 1 || H < 1 || H > 256 || n_intervals < 1 || n_out < 1 || n_launches < 0 || n_jump < 0) return CDE_ERR_SHAPE;
+  if (act != CDE_ACT_NONE && act != CDE_ACT_TANH) return CDE_ERR_UNSUPPORTED;
+  if (degree != CDE_PATH_CUBIC && degree != CDE_PATH_LINEAR) return CDE_ERR_UNSUPPORTED;
+  if (!coeffs || !knots || !W || !bias || !z0 || !t_out || !z_out || !workspace) return CDE_ERR_NULL;
+  if (n_jump > 0 && !jump_t) return CDE_ERR_NULL;
+  if (workspace_bytes < cde_dopri5_workspace_bytes(B, C, H, dtype)) return CDE_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t blocks = cde::dopri_blocks(B, H);
+  unsigned char* base = (unsigned char*)workspace;
+  cde::DopriCtrl* ctrl = (cde::DopriCtrl*)base;
+  double* partial = (double*)(base + cde::al256(2 * sizeof(cde::DopriCtrl)));
+  void* state = base + cde::al256(2 * sizeof(cde::DopriCtrl)) + cde::al256((size_t)2 * blocks * 2 * sizeof(double));
+  if (first_launch == 0) {
+    if (hipMemsetAsync(ctrl, 0, 2 * sizeof(cde::DopriCtrl), s) != hipSuccess) return CDE_ERR_LAUNCH;   // phase 0
+  }
+  const int ns = cde::dopri_ns(H);
+  const int nt = ((ns * (int)H + 63) / 64) * 64;
+#define CDE_DOPRI(T)                                                                                              \
+  do {                                                                                                            \
+    cde::DopriArgs<T> g{(const T*)coeffs, (const T*)knots, n_intervals, degree, (const T*)W, (const T*)bias, act, \
+                        (const T*)z0, t_out, n_out, jump_t, n_jump, rtol, atol, safety, ifactor, dfactor,         \
+                        (T*)z_out, B, C, H, ns, ctrl, (T*)state, partial, blocks};                                 \
+    const size_t lds = (((size_t)ns * (H + C) * sizeof(T) + 15) / 16) * 16 + 2 * nt * sizeof(double);                                 \
+    for (int64_t i = 0; i < n_launches; ++i)                                                                      \
+      cde::dopri5_attempt_kernel<T><<<(unsigned)blocks, nt, lds, s>>>(g, (int)((first_launch + i) & 1));          \
+  } while (0)
+  if (dtype == CDE_F32) CDE_DOPRI(float);
+  else if (dtype == CDE_F64) CDE_DOPRI(double);
+  else return CDE_ERR_DTYPE;
+#undef CDE_DOPRI
+  return cde::check_launch();
+}
