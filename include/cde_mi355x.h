@@ -175,8 +175,8 @@ int cde_dopri5_advance(const void* coeffs, const void* knots, int64_t n_interval
                        const void* bias, int act, const void* z0, const double* t_out, int64_t n_out,
                        const double* jump_t, int64_t n_jump, double rtol, double atol, double safety,
                        double ifactor, double dfactor, void* z_out, int64_t B, int64_t C, int64_t H, int dtype,
-                       void* workspace, size_t workspace_bytes, int64_t first_launch, int64_t n_launches,
-                       void* stream);
+                       int variant, void* workspace, size_t workspace_bytes, int64_t first_launch,
+                       int64_t n_launches, void* stream);
 
 #ifdef __cplusplus
 }

@@ -46,7 +46,7 @@ size = ctypes.sizeof(_lib.DopriStatus)
 native = []
 for launched in range(0, 400):
     _lib.check(lib.cde_dopri5_advance(_lib.ptr(plan.coeffs), _lib.ptr(plan.knots), plan.n_intervals, plan.degree, _lib.ptr(w), _lib.ptr(b),
-        plan.act, _lib.ptr(z0c), _lib.ptr(plan.t_out), plan.n_out, _lib.ptr(None), 0, 1e-8, 1e-10, 0.9, 10.0, 0.2, _lib.ptr(out), B, Cc, H, 1,
+        plan.act, _lib.ptr(z0c), _lib.ptr(plan.t_out), plan.n_out, _lib.ptr(None), 0, 1e-8, 1e-10, 0.9, 10.0, 0.2, _lib.ptr(out), B, Cc, H, 1, 0,
         _lib.ptr(ws), ws.numel(), launched, 1, _lib.stream_ptr(out.device)), "adv")
     k = (launched + 1) & 1
     st = _lib.DopriStatus.from_buffer_copy(ws[k * size:(k + 1) * size].cpu().numpy().tobytes())

@@ -364,6 +364,27 @@ def test_dopri5_controller_matches_oracle_step_for_step(native, dtype):
         _close(out, ref, 2e-3, 2e-3 * ref.abs().max().item())
 
 
+def test_dopri5_mfma_kernel_equals_generic_kernel(native):
+    """Same controller, same state layout: the MFMA attempt kernel must take the generic kernel's step sequence."""
+    from torchcde_amd.cdeint import last_dopri5_stats
+    B, L, C, H = 300, 20, 8, 32                                 # ragged: 300 = 2*128 + 44
+    x = make_series(B, L, C, seed=41).to(DEV)
+    func = LinearField(H, C, scale=0.25, seed=4).to(DEV)
+    z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(4)).to(DEV)
+    t_out = torch.tensor([0., 3.3, 19.], device=DEV)
+    res = {}
+    for control in ("linear", "cubic"):
+        X = (native.LinearInterpolation(x) if control == "linear"
+             else native.CubicSpline(native.hermite_cubic_coefficients_with_backward_differences(x)))
+        for variant in ("mfma", "generic"):
+            with torch.no_grad():
+                out = native.cdeint(X, func, z0, t_out, method="dopri5", options=dict(jump_t=X.grid_points),
+                                    variant=variant)
+            res[variant] = (out, last_dopri5_stats["n_accept"], last_dopri5_stats["n_reject"])
+        assert abs(res["mfma"][1] - res["generic"][1]) <= 2
+        _close(res["mfma"][0], res["generic"][0], 1e-3, 1e-4)
+
+
 def test_dopri5_cubic_control_without_jumps_and_backward_refusal(native):
     B, L, C, H = 10, 9, 3, 5
     x = make_series(B, L, C, torch.float64, seed=5)

@@ -232,7 +232,8 @@ _DOPRI_CHUNK = 48          # attempt kernels queued between two looks at the don
 
 
 class _Dopri5Plan:
-    def __init__(self, path, field, batch, H, C, t, rtol, atol, options):
+    def __init__(self, path, field, batch, H, C, t, rtol, atol, options, variant=_lib.VARIANT_AUTO):
+        self.variant = variant
         options = {} if options is None else dict(options)
         jump_t = options.pop("jump_t", None)
         self.safety = float(options.pop("safety", 0.9))
@@ -279,7 +280,7 @@ class _Dopri5Plan:
                 _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w), _lib.ptr(b),
                 self.act, _lib.ptr(z0c), _lib.ptr(self.t_out), self.n_out, _lib.ptr(self.jump_t), self.n_jump,
                 self.rtol, self.atol, self.safety, self.ifactor, self.dfactor, _lib.ptr(out), self.B, self.C, self.H, dt,
-                _lib.ptr(workspace), workspace.numel(), launched, _DOPRI_CHUNK, _lib.stream_ptr(self.device)),
+                self.variant, _lib.ptr(workspace), workspace.numel(), launched, _DOPRI_CHUNK, _lib.stream_ptr(self.device)),
                 "cde_dopri5_advance")
             launched += _DOPRI_CHUNK
             raw = workspace[(launched & 1) * size:(launched & 1) * size + size].cpu().numpy().tobytes()   # one sync per chunk
@@ -416,7 +417,7 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
             kwargs.pop(key, None)
         if kwargs:
             raise NotImplementedError("torchcde_amd: unsupported cdeint keyword arguments {}".format(sorted(kwargs)))
-        plan = _Dopri5Plan(X, field, batch, H, C, t, rtol, atol, options)
+        plan = _Dopri5Plan(X, field, batch, H, C, t, rtol, atol, options, variant)
         return _FusedDopri5.apply(z0, weight, bias, plan)
     step_size = _parse_fixed_options(options, "solver")
     adjoint_method = kwargs.pop("adjoint_method", None)

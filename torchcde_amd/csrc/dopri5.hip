@@ -16,7 +16,7 @@
 // is bit-identical in every workgroup and run-to-run), commits its series' state, emits any outputs the accepted
 // step covered, and then runs the 6 new stages.  The controller state ping-pongs between two structs.  The host
 // only queues launches and looks at a done flag every few dozen of them.
-#include "cde_common.h"
+#include "cde_mfma.h"
 
 namespace cde {
 
@@ -121,39 +121,19 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* red) {
   __syncthreads();
 }
 
+// What one launch has to do, derived identically by every thread from the controller struct and the pending sums.
 template <typename T>
-__global__ void dopri5_attempt_kernel(DopriArgs<T> g, int parity) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int H = (int)g.H, C = (int)g.C, NS = g.NS;
-  T* zs = reinterpret_cast<T*>(smem_raw);
-  T* dx = zs + NS * H;
-  double* red = reinterpret_cast<double*>(smem_raw + (((size_t)(NS * (H + C)) * sizeof(T) + 15) / 16) * 16);   // 2 * blockDim doubles
-  const int tid = threadIdx.x;
-  const int s = tid / H, h = tid - s * H;
-  const bool lane_on = s < NS;
-  const int64_t n_tiles = (g.B + NS - 1) / NS;
-  const int64_t BH = g.B * g.H;
-  const int p = parity, q = parity ^ 1;
-  DopriCtrl c = g.ctrl[p];
-  if (c.phase == 4) {                                           // finished: keep the flag alive in both structs
-    if (blockIdx.x == 0 && tid == 0) g.ctrl[q] = c;
-    return;
-  }
-  T* Sp = g.state + (int64_t)p * 9 * BH;                        // what the previous launch produced
-  T* Sq = g.state + (int64_t)q * 9 * BH;                        // what this launch produces
-  const double* Pp = g.partial + (int64_t)p * g.n_blocks_alloc * 2;
-  double* Pq = g.partial + (int64_t)q * g.n_blocks_alloc * 2;
-  const double n_elems = (double)BH;
-  const T rtol = (T)g.rtol, atol = (T)g.atol;
+struct DopriPlan {
+  bool accept;                  // decision on the pending attempt (phase 3 only)
+  int mode;                     // this launch: 0 = f0 norms, 1 = f1 norm, 2 = attempt, 3 = nothing more
+  double t0, t1, dt, dt_done;   // new attempt [t0, t1]; dt_done = step size of the attempt just decided
+  T h0_state;
+  int64_t emit_from, emit_to;   // outputs covered by the step just accepted
+};
 
-  // ---- pending global sums of the previous launch (fixed order -> identical in every workgroup)
-  double sum0 = 0.0, sum1 = 0.0;
-  if (c.phase != 0) {
-    for (int64_t b = tid; b < (int64_t)gridDim.x; b += blockDim.x) { sum0 += Pp[2 * b]; sum1 += Pp[2 * b + 1]; }
-    block_sum2(sum0, sum1, red);
-  }
-
-  // ---- controller (uniform arithmetic, every thread computes the same values)
+template <typename T>
+__device__ __forceinline__ DopriPlan<T> dopri_controller(const DopriArgs<T>& g, DopriCtrl& c, double sum0, double sum1) {
+  const double n_elems = (double)(g.B * g.H);
   bool accept = false;
   int mode;                     // what this launch computes: 0 = f0 norms, 1 = f1 norm, 2 = attempt, 3 = nothing more
   double t0 = 0, t1 = 0, dt = 0;
@@ -230,9 +210,6 @@ __global__ void dopri5_attempt_kernel(DopriArgs<T> g, int parity) {
     mode = 2;
   }
 
-  // ---- per-series work
-  double acc0 = 0.0, acc1 = 0.0;
-  const double t_end = g.t_out[g.n_out - 1];
   // how many outputs does the accepted interval [t_lo, t_hi] cover?
   int64_t emit_from = c.i_out, emit_to = c.i_out;
   if (c.phase == 3 && accept) {
@@ -257,6 +234,50 @@ __global__ void dopri5_attempt_kernel(DopriArgs<T> g, int parity) {
     c.t1_try = t1; c.dt_try = dt; c.on_jump = on_jump;
   }
 
+  DopriPlan<T> plan;
+  plan.accept = accept; plan.mode = mode; plan.t0 = t0; plan.t1 = t1; plan.dt = dt; plan.dt_done = dt_done;
+  plan.h0_state = h0_state; plan.emit_from = emit_from; plan.emit_to = emit_to;
+  return plan;
+}
+
+template <typename T>
+__global__ void dopri5_attempt_kernel(DopriArgs<T> g, int parity) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int H = (int)g.H, C = (int)g.C, NS = g.NS;
+  T* zs = reinterpret_cast<T*>(smem_raw);
+  T* dx = zs + NS * H;
+  double* red = reinterpret_cast<double*>(smem_raw + (((size_t)(NS * (H + C)) * sizeof(T) + 15) / 16) * 16);   // 2 * blockDim doubles
+  const int tid = threadIdx.x;
+  const int s = tid / H, h = tid - s * H;
+  const bool lane_on = s < NS;
+  const int64_t n_tiles = (g.B + NS - 1) / NS;
+  const int64_t BH = g.B * g.H;
+  const int p = parity, q = parity ^ 1;
+  DopriCtrl c = g.ctrl[p];
+  if (c.phase == 4) {                                           // finished: keep the flag alive in both structs
+    if (blockIdx.x == 0 && tid == 0) g.ctrl[q] = c;
+    return;
+  }
+  T* Sp = g.state + (int64_t)p * 9 * BH;                        // what the previous launch produced
+  T* Sq = g.state + (int64_t)q * 9 * BH;                        // what this launch produces
+  const double* Pp = g.partial + (int64_t)p * g.n_blocks_alloc * 2;
+  double* Pq = g.partial + (int64_t)q * g.n_blocks_alloc * 2;
+  const T rtol = (T)g.rtol, atol = (T)g.atol;
+
+  // ---- pending global sums of the previous launch (fixed order -> identical in every workgroup)
+  double sum0 = 0.0, sum1 = 0.0;
+  if (c.phase != 0) {
+    for (int64_t b = tid; b < (int64_t)gridDim.x; b += blockDim.x) { sum0 += Pp[2 * b]; sum1 += Pp[2 * b + 1]; }
+    block_sum2(sum0, sum1, red);
+  }
+
+  DopriPlan<T> plan = dopri_controller<T>(g, c, sum0, sum1);
+  const bool accept = plan.accept;
+  const int mode = plan.mode;
+  const double t0 = plan.t0, t1 = plan.t1, dt = plan.dt, dt_done = plan.dt_done;
+  const T h0_state = plan.h0_state;
+  const int64_t emit_from = plan.emit_from, emit_to = plan.emit_to;
+  double acc0 = 0.0, acc1 = 0.0;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t series = tile * NS + s;
     const bool valid = lane_on && series < g.B;
@@ -354,7 +375,6 @@ __global__ void dopri5_attempt_kernel(DopriArgs<T> g, int parity) {
       }
     }
   }
-  (void)t_end;
   // ---- publish this launch's partial sums and the controller state for the next launch
   block_sum2(acc0, acc1, red);
   if (tid == 0) { Pq[2 * blockIdx.x] = acc0; Pq[2 * blockIdx.x + 1] = acc1; }
@@ -367,6 +387,173 @@ __global__ void dopri5_attempt_kernel(DopriArgs<T> g, int parity) {
   }
 }
 
+// ------------------------------------------------------------------------------------------ MFMA attempt kernel
+// f32, H = 32, C = 8, no activation: 16 series per wave on v_mfma_f32_16x16x4_f32 exactly like K2 (field16), six
+// stage evaluations per launch.  Same controller, same state / partial layout as the generic kernel.
+__device__ __forceinline__ f32x4 ld4(const float* p) { const float4 v = *reinterpret_cast<const float4*>(p); return f32x4{v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ void st4(float* p, const f32x4& v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ f32x4 abs4(const f32x4& v) { return f32x4{fabsf(v[0]), fabsf(v[1]), fabsf(v[2]), fabsf(v[3])}; }
+__device__ __forceinline__ f32x4 max4(const f32x4& a, const f32x4& b) {
+  return f32x4{fmaxf(a[0], b[0]), fmaxf(a[1], b[1]), fmaxf(a[2], b[2]), fmaxf(a[3], b[3])};
+}
+__device__ __forceinline__ double sq4(const f32x4& v) {
+  return (double)(v[0] * v[0]) + (double)(v[1] * v[1]) + (double)(v[2] * v[2]) + (double)(v[3] * v[3]);
+}
+
+template <int DEGREE>
+__global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g, int parity) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  using T = float;
+  const int tid = threadIdx.x;
+  const int p = parity, q2 = parity ^ 1;
+  DopriCtrl c = g.ctrl[p];
+  if (c.phase == 4) {
+    if (blockIdx.x == 0 && tid == 0) g.ctrl[q2] = c;
+    return;
+  }
+  float4 wA[W16_GROUPS], wB[W16_GROUPS];
+  load_w16(g.W, g.bias, lds, wA, wB);
+  double* red = reinterpret_cast<double*>(lds + W16_FLOATS);       // 2 * 512 doubles
+  const int64_t BH = g.B * g.H;
+  float* Sp = g.state + (int64_t)p * 9 * BH;
+  float* Sq = g.state + (int64_t)q2 * 9 * BH;
+  const double* Pp = g.partial + (int64_t)p * g.n_blocks_alloc * 2;
+  double* Pq = g.partial + (int64_t)q2 * g.n_blocks_alloc * 2;
+  const T rtol = (T)g.rtol, atol = (T)g.atol;
+
+  double sum0 = 0.0, sum1 = 0.0;
+  if (c.phase != 0) {
+    for (int64_t b = tid; b < (int64_t)gridDim.x; b += blockDim.x) { sum0 += Pp[2 * b]; sum1 += Pp[2 * b + 1]; }
+    block_sum2(sum0, sum1, red);
+  }
+  const DopriPlan<T> plan = dopri_controller<T>(g, c, sum0, sum1);
+  const int mode = plan.mode;
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, q = lane >> 4;
+  const int64_t series = ((int64_t)blockIdx.x * 8 + wave) * 16 + n;
+  const bool valid = series < g.B;
+  const int64_t sc = valid ? series : g.B - 1;
+  const int64_t e = sc * MH + 8 * q;                                  // this lane's 8 hidden units
+
+  // control derivative at a (wave-uniform) time; the row is re-fetched only when the interval changes
+  int64_t row_idx = -1;
+  Row<DEGREE> row;
+  auto slope_at = [&](T ts, float (&dX)[MC]) {
+    T frac;
+    const int64_t idx = locate(g.knots, g.n_intervals, ts, frac);
+    if (idx != row_idx) { row = load_row<DEGREE>(g.coeffs, sc, g.n_intervals, idx); row_idx = idx; }
+    const float width = DEGREE == CDE_PATH_LINEAR ? g.knots[idx + 1] - g.knots[idx] : 1.f;
+    control_slope<DEGREE>(row, frac, width, dX);
+  };
+
+  f32x4 ya, yb, k0a, k0b;
+  double acc0 = 0.0, acc1 = 0.0;
+  if (c.phase == 0) {
+    ya = ld4(g.z0 + e); yb = ld4(g.z0 + e + 4);
+    if (valid) { st4(g.z_out + (series * g.n_out) * MH + 8 * q, ya); st4(g.z_out + (series * g.n_out) * MH + 8 * q + 4, yb); }
+    k0a = k0b = f32x4{0.f, 0.f, 0.f, 0.f};
+  } else if (c.phase == 1 || c.phase == 2) {
+    ya = ld4(Sp + e); yb = ld4(Sp + e + 4);
+    k0a = ld4(Sp + 2 * BH + e); k0b = ld4(Sp + 2 * BH + e + 4);
+  } else {
+    const f32x4 y0a = ld4(Sp + e), y0b = ld4(Sp + e + 4), y1a = ld4(Sp + BH + e), y1b = ld4(Sp + BH + e + 4);
+    if (plan.accept) {
+      if (plan.emit_to > plan.emit_from) {
+        const T dtf = (T)plan.dt_done;
+        f32x4 ma = {0.f, 0.f, 0.f, 0.f}, mb = ma;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+          const T w = dtf * (T)DP_CMID[j];
+          ma += ld4(Sp + (2 + j) * BH + e) * w; mb += ld4(Sp + (2 + j) * BH + e + 4) * w;
+        }
+        ma = y0a + ma; mb = y0b + mb;
+        const f32x4 f0a = ld4(Sp + 2 * BH + e), f0b = ld4(Sp + 2 * BH + e + 4);
+        const f32x4 f1a = ld4(Sp + 8 * BH + e), f1b = ld4(Sp + 8 * BH + e + 4);
+        const f32x4 caa = 2.f * dtf * (f1a - f0a) - 8.f * (y1a + y0a) + 16.f * ma;
+        const f32x4 cab = 2.f * dtf * (f1b - f0b) - 8.f * (y1b + y0b) + 16.f * mb;
+        const f32x4 cba = dtf * (5.f * f0a - 3.f * f1a) + 18.f * y0a + 14.f * y1a - 32.f * ma;
+        const f32x4 cbb = dtf * (5.f * f0b - 3.f * f1b) + 18.f * y0b + 14.f * y1b - 32.f * mb;
+        const f32x4 cca = dtf * (f1a - 4.f * f0a) - 11.f * y0a - 5.f * y1a + 16.f * ma;
+        const f32x4 ccb = dtf * (f1b - 4.f * f0b) - 11.f * y0b - 5.f * y1b + 16.f * mb;
+        const f32x4 cda = dtf * f0a, cdb = dtf * f0b;
+        for (int64_t io = plan.emit_from; io < plan.emit_to; ++io) {
+          const T x = (T)((g.t_out[io] - c.t_lo) / (c.t_hi - c.t_lo));
+          f32x4 ta = y0a + x * cda, tb = y0b + x * cdb;
+          T xp = x;
+          xp = xp * x; ta = ta + xp * cca; tb = tb + xp * ccb;
+          xp = xp * x; ta = ta + xp * cba; tb = tb + xp * cbb;
+          xp = xp * x; ta = ta + xp * caa; tb = tb + xp * cab;
+          if (valid) { st4(g.z_out + (series * g.n_out + io) * MH + 8 * q, ta); st4(g.z_out + (series * g.n_out + io) * MH + 8 * q + 4, tb); }
+        }
+      }
+      ya = y1a; yb = y1b;
+      k0a = ld4(Sp + 8 * BH + e); k0b = ld4(Sp + 8 * BH + e + 4);
+    } else {
+      ya = y0a; yb = y0b;
+      k0a = ld4(Sp + 2 * BH + e); k0b = ld4(Sp + 2 * BH + e + 4);
+    }
+  }
+
+  float dX[MC];
+  if (mode == 0) {
+    slope_at((T)c.t_hi, dX);
+    field16(wA, wB, ya, yb, dX, q, k0a, k0b);
+    const f32x4 sa = atol + abs4(ya) * rtol, sb = atol + abs4(yb) * rtol;
+    if (valid) {
+      acc0 = sq4(ya / sa) + sq4(yb / sb);
+      acc1 = sq4(k0a / sa) + sq4(k0b / sb);
+      st4(Sq + e, ya); st4(Sq + e + 4, yb); st4(Sq + 2 * BH + e, k0a); st4(Sq + 2 * BH + e + 4, k0b);
+    }
+  } else if (mode == 1) {
+    const T h0 = plan.h0_state;
+    const f32x4 za = ya + h0 * k0a, zb = yb + h0 * k0b;
+    slope_at((T)(c.t_hi + (double)h0), dX);
+    f32x4 f1a, f1b;
+    field16(wA, wB, za, zb, dX, q, f1a, f1b);
+    const f32x4 sa = atol + abs4(ya) * rtol, sb = atol + abs4(yb) * rtol;
+    if (valid) {
+      acc0 = sq4((f1a - k0a) / sa) + sq4((f1b - k0b) / sb);
+      st4(Sq + e, ya); st4(Sq + e + 4, yb); st4(Sq + 2 * BH + e, k0a); st4(Sq + 2 * BH + e + 4, k0b);
+    }
+  } else if (mode == 2) {
+    const T t0f = (T)plan.t0, dtf = (T)plan.dt, t1f = (T)plan.t1;
+    if (c.refresh) {                                                  // just after the jump we landed on
+      slope_at(next_toward(t0f, 1.f), dX);
+      field16(wA, wB, ya, yb, dX, q, k0a, k0b);
+    }
+    f32x4 ka[7], kb[7];
+    ka[0] = k0a; kb[0] = k0b;
+    f32x4 zia = ya, zib = yb;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const T ti = i >= 4 ? next_toward(t1f, -1.f) : t0f + (T)DP_ALPHA[i] * dtf;
+      f32x4 ia = {0.f, 0.f, 0.f, 0.f}, ib = ia;
+#pragma unroll
+      for (int j = 0; j <= i; ++j) { const T w = (T)DP_BETA[i][j] * dtf; ia += ka[j] * w; ib += kb[j] * w; }
+      zia = ya + ia; zib = yb + ib;
+      slope_at(ti, dX);
+      field16(wA, wB, zia, zib, dX, q, ka[i + 1], kb[i + 1]);
+    }
+    f32x4 ea = {0.f, 0.f, 0.f, 0.f}, eb = ea;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) { const T w = dtf * (T)DP_CERR[j]; ea += ka[j] * w; eb += kb[j] * w; }
+    const f32x4 ta = atol + rtol * max4(abs4(ya), abs4(zia)), tb = atol + rtol * max4(abs4(yb), abs4(zib));
+    if (valid) {
+      acc0 = sq4(ea / ta) + sq4(eb / tb);
+      st4(Sq + e, ya); st4(Sq + e + 4, yb); st4(Sq + BH + e, zia); st4(Sq + BH + e + 4, zib);
+#pragma unroll
+      for (int j = 0; j < 7; ++j) { st4(Sq + (2 + j) * BH + e, ka[j]); st4(Sq + (2 + j) * BH + e + 4, kb[j]); }
+    }
+  }
+  block_sum2(acc0, acc1, red);
+  if (tid == 0) { Pq[2 * blockIdx.x] = acc0; Pq[2 * blockIdx.x + 1] = acc1; }
+  if (blockIdx.x == 0 && tid == 0) {
+    c.phase = mode == 0 ? 1 : mode == 1 ? 2 : mode == 2 ? 3 : 4;
+    g.ctrl[q2] = c;
+  }
+}
+
 static inline int dopri_ns(int64_t H) { int ns = (int)(256 / H); return ns < 1 ? 1 : (ns > 16 ? 16 : ns); }
 static inline int64_t dopri_blocks(int64_t B, int64_t H) {
   const int ns = dopri_ns(H);
@@ -374,6 +561,13 @@ static inline int64_t dopri_blocks(int64_t B, int64_t H) {
   return tiles < 1 ? 1 : (tiles > 2048 ? 2048 : tiles);
 }
 static inline size_t al256(size_t x) { return (x + 255) / 256 * 256; }
+static inline bool dopri_use_mfma(int64_t C, int64_t H, int dtype, int act, int variant) {
+  return variant != CDE_VARIANT_GENERIC && dtype == CDE_F32 && H == MH && C == MC && act == CDE_ACT_NONE;
+}
+static inline int64_t dopri_blocks_any(int64_t B, int64_t H) {          // partial buffer must fit either kernel's grid
+  const int64_t a = dopri_blocks(B, H), b = (B + 127) / 128;
+  return a > b ? a : b;
+}
 
 }  // namespace cde
 
@@ -381,7 +575,7 @@ static inline size_t al256(size_t x) { return (x + 255) / 256 * 256; }
 extern "C" size_t cde_dopri5_workspace_bytes(int64_t B, int64_t C, int64_t H, int dtype) {
   (void)C;
   const size_t elem = dtype == CDE_F64 ? 8 : 4;
-  return cde::al256(2 * sizeof(cde::DopriCtrl)) + cde::al256((size_t)2 * cde::dopri_blocks(B, H) * 2 * sizeof(double)) +
+  return cde::al256(2 * sizeof(cde::DopriCtrl)) + cde::al256((size_t)2 * cde::dopri_blocks_any(B, H) * 2 * sizeof(double)) +
          (size_t)2 * 9 * B * H * elem;
 }
 
@@ -389,8 +583,8 @@ extern "C" int cde_dopri5_advance(const void* coeffs, const void* knots, int64_t
                                   const void* bias, int act, const void* z0, const double* t_out, int64_t n_out,
                                   const double* jump_t, int64_t n_jump, double rtol, double atol, double safety,
                                   double ifactor, double dfactor, void* z_out, int64_t B, int64_t C, int64_t H,
-                                  int dtype, void* workspace, size_t workspace_bytes, int64_t first_launch,
-                                  int64_t n_launches, void* stream) {
+                                  int dtype, int variant, void* workspace, size_t workspace_bytes,
+                                  int64_t first_launch, int64_t n_launches, void* stream) {
   if (B < 1 || C < 1 || H < 1 || H > 256 || n_intervals < 1 || n_out < 1 || n_launches < 0 || n_jump < 0) return CDE_ERR_SHAPE;
   if (act != CDE_ACT_NONE && act != CDE_ACT_TANH) return CDE_ERR_UNSUPPORTED;
   if (degree != CDE_PATH_CUBIC && degree != CDE_PATH_LINEAR) return CDE_ERR_UNSUPPORTED;
@@ -398,7 +592,9 @@ extern "C" int cde_dopri5_advance(const void* coeffs, const void* knots, int64_t
   if (n_jump > 0 && !jump_t) return CDE_ERR_NULL;
   if (workspace_bytes < cde_dopri5_workspace_bytes(B, C, H, dtype)) return CDE_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  const int64_t blocks = cde::dopri_blocks(B, H);
+  const bool use_mfma = cde::dopri_use_mfma(C, H, dtype, act, variant);
+  if (variant == CDE_VARIANT_MFMA && !use_mfma) return CDE_ERR_UNSUPPORTED;
+  const int64_t blocks = cde::dopri_blocks_any(B, H);          // allocation stride of the partial sums
   unsigned char* base = (unsigned char*)workspace;
   cde::DopriCtrl* ctrl = (cde::DopriCtrl*)base;
   double* partial = (double*)(base + cde::al256(2 * sizeof(cde::DopriCtrl)));
@@ -415,8 +611,21 @@ extern "C" int cde_dopri5_advance(const void* coeffs, const void* knots, int64_t
                         (T*)z_out, B, C, H, ns, ctrl, (T*)state, partial, blocks};                                 \
     const size_t lds = (((size_t)ns * (H + C) * sizeof(T) + 15) / 16) * 16 + 2 * nt * sizeof(double);                                 \
     for (int64_t i = 0; i < n_launches; ++i)                                                                      \
-      cde::dopri5_attempt_kernel<T><<<(unsigned)blocks, nt, lds, s>>>(g, (int)((first_launch + i) & 1));          \
+      cde::dopri5_attempt_kernel<T><<<(unsigned)cde::dopri_blocks(B, H), nt, lds, s>>>(g, (int)((first_launch + i) & 1)); \
   } while (0)
+  if (use_mfma) {
+    cde::DopriArgs<float> g{(const float*)coeffs, (const float*)knots, n_intervals, degree, (const float*)W,
+                            (const float*)bias, act, (const float*)z0, t_out, n_out, jump_t, n_jump, rtol, atol, safety,
+                            ifactor, dfactor, (float*)z_out, B, C, H, 16, ctrl, (float*)state, partial, blocks};
+    const size_t lds = cde::W16_FLOATS * sizeof(float) + 2 * 512 * sizeof(double);
+    const unsigned grid = (unsigned)((B + 127) / 128);
+    for (int64_t i = 0; i < n_launches; ++i) {
+      const int par = (int)((first_launch + i) & 1);
+      if (degree == CDE_PATH_CUBIC) cde::dopri5_attempt_mfma<CDE_PATH_CUBIC><<<grid, 512, lds, s>>>(g, par);
+      else cde::dopri5_attempt_mfma<CDE_PATH_LINEAR><<<grid, 512, lds, s>>>(g, par);
+    }
+    return cde::check_launch();
+  }
   if (dtype == CDE_F32) CDE_DOPRI(float);
   else if (dtype == CDE_F64) CDE_DOPRI(double);
   else return CDE_ERR_DTYPE;

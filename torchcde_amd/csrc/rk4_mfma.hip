@@ -22,126 +22,9 @@
 //   dL/db                          128 v_fma in the shadow of the MFMAs
 // The interval index / fractional part of every stage time comes from the stage table written by
 // stage_table_kernel (api.hip) -- the same numbers CubicSpline._interpret_t would produce.
-#include "cde_common.h"
+#include "cde_mfma.h"
 
 namespace cde {
-
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-
-constexpr int MH = 32;                 // hidden
-constexpr int MC = 8;                  // channels
-constexpr int W1_STEPS = 132;          // 16*8 product steps + 4 bias steps
-constexpr int W2_STEPS = 128;
-constexpr int W1_FLOATS = W1_STEPS * 64;
-constexpr int W2_FLOATS = W2_STEPS * 64;
-constexpr int SCR_FLOATS = 2 * 64 * 20 + 32 * 8;     // per wave: z^T, a^T (64 rows x 20) and weighted dX (32 x 8)
-
-// MFMA 32x32 C/D fragment: lane (col = l&31, half = l>>5) register r holds row
-// i = (r&3) + 8*(r>>2) + 4*half.  rho maps an output ROW i to the hidden unit stored there so
-// that register r of half `half` is hidden unit 2r + half.
-__host__ __device__ __forceinline__ int rho(int i) { return 2 * ((i & 3) + 4 * (i >> 3)) + ((i >> 2) & 1); }
-
-// A-operand images (value for MFMA step s, lane l)
-__device__ __forceinline__ float w1_image(const float* __restrict__ W, const float* __restrict__ bias, int s, int l) {
-  const int h_out = rho(l & 31), hk = l >> 5;
-  if (s < 128) { const int j = s >> 3, c = s & 7; return W[(h_out * MC + c) * MH + 2 * j + hk]; }
-  const int c = 2 * (s - 128) + hk;
-  return bias[h_out * MC + c];
-}
-__device__ __forceinline__ float w2_image(const float* __restrict__ W, int s, int l) {
-  const int k_out = rho(l & 31), hk = l >> 5;
-  const int j = s >> 3, c = s & 7;
-  return W[((2 * j + hk) * MC + c) * MH + k_out];
-}
-
-__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
-
-// one control row held in registers: cubic -> b, 2c, 3d (24 floats); linear -> x[idx], x[idx+1] (16 floats)
-template <int DEGREE>
-struct Row {
-  float4 v[DEGREE == CDE_PATH_CUBIC ? 6 : 4];
-};
-
-template <int DEGREE>
-__device__ __forceinline__ Row<DEGREE> load_row(const float* __restrict__ coeffs, int64_t series, int64_t n_intervals,
-                                                 int64_t idx) {
-  Row<DEGREE> r;
-  if (DEGREE == CDE_PATH_CUBIC) {
-    const float4* p = reinterpret_cast<const float4*>(coeffs + (series * n_intervals + idx) * 4 * MC + MC);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) r.v[i] = p[i];
-  } else {
-    const float4* p = reinterpret_cast<const float4*>(coeffs + (series * (n_intervals + 1) + idx) * MC);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) r.v[i] = p[i];
-  }
-  return r;
-}
-
-template <int DEGREE>
-__device__ __forceinline__ void control_slope(const Row<DEGREE>& r, float frac, float width, float (&dX)[MC]) {
-  const float* f = reinterpret_cast<const float*>(r.v);
-#pragma unroll
-  for (int c = 0; c < MC; ++c) {
-    if (DEGREE == CDE_PATH_CUBIC) dX[c] = cubic_derivative(f[c], f[MC + c], f[2 * MC + c], frac);
-    else dX[c] = (f[MC + c] - f[c]) / width;
-  }
-}
-
-// f-chain: acc[r] = f_n[2r+half].  PIN: fence the instruction scheduler after every 8-MFMA group so
-// that (in the register-starved adjoint kernel) it cannot hoist a whole stage's LDS reads up front.
-template <bool PIN = false>
-__device__ __forceinline__ f32x16 chain_field(const float4* __restrict__ w1, int lane, const f32x16& z,
-                                              const float (&dX)[MC]) {
-  f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const float4 wa = w1[(2 * j) * 64 + lane];
-    const float4 wb = w1[(2 * j + 1) * 64 + lane];
-    const float zj = z[j];
-    acc = mfma(wa.x, zj * dX[0], acc);
-    acc = mfma(wa.y, zj * dX[1], acc);
-    acc = mfma(wa.z, zj * dX[2], acc);
-    acc = mfma(wa.w, zj * dX[3], acc);
-    acc = mfma(wb.x, zj * dX[4], acc);
-    acc = mfma(wb.y, zj * dX[5], acc);
-    acc = mfma(wb.z, zj * dX[6], acc);
-    acc = mfma(wb.w, zj * dX[7], acc);
-    if (PIN) __builtin_amdgcn_sched_barrier(0);
-  }
-  const float4 wc = w1[32 * 64 + lane];   // bias steps: lane half hk contributes channel 2*sp + hk
-  const bool hi = lane >= 32;
-  acc = mfma(wc.x, hi ? dX[1] : dX[0], acc);
-  acc = mfma(wc.y, hi ? dX[3] : dX[2], acc);
-  acc = mfma(wc.z, hi ? dX[5] : dX[4], acc);
-  acc = mfma(wc.w, hi ? dX[7] : dX[6], acc);
-  return acc;
-}
-
-// vjp-chain: acc[r] = (a^T df/dz)_n[2r+half]
-template <bool PIN = false>
-__device__ __forceinline__ f32x16 chain_vjp(const float4* __restrict__ w2, int lane, const f32x16& a,
-                                            const float (&dX)[MC]) {
-  f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const float4 wa = w2[(2 * j) * 64 + lane];
-    const float4 wb = w2[(2 * j + 1) * 64 + lane];
-    const float aj = a[j];
-    acc = mfma(wa.x, aj * dX[0], acc);
-    acc = mfma(wa.y, aj * dX[1], acc);
-    acc = mfma(wa.z, aj * dX[2], acc);
-    acc = mfma(wa.w, aj * dX[3], acc);
-    acc = mfma(wb.x, aj * dX[4], acc);
-    acc = mfma(wb.y, aj * dX[5], acc);
-    acc = mfma(wb.z, aj * dX[6], acc);
-    acc = mfma(wb.w, aj * dX[7], acc);
-    if (PIN) __builtin_amdgcn_sched_barrier(0);
-  }
-  return acc;
-}
 
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -160,47 +43,6 @@ __device__ __forceinline__ void wave_lds_sync() {
 //   tile T row i  <->  hidden unit 8*(i>>2) + 4*T + (i&3)   =>  acc_T[r] of lane (n,q) is unit 8q + 4T + r
 //   step s = (m, c), lane quarter kq feeds K index kq = input unit 8*kq + m, channel c
 //   bias steps 64, 65: lane quarter kq feeds channel 4*(s-64) + kq
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-using f32x2 = __attribute__((ext_vector_type(2))) float;
-constexpr int W16_GROUPS = 17;                      // 66 steps per tile, padded to 68 = 17 float4 groups
-constexpr int W16_FLOATS = 2 * W16_GROUPS * 64 * 4;
-constexpr int FWD_STAGGER_SLEEP = 44;              // x64 cycles ~ half of one RK stage (4224 MFMA cycles + tail)
-
-__device__ __forceinline__ float w16_image(const float* __restrict__ W, const float* __restrict__ bias, int T, int s,
-                                           int l) {
-  const int i = l & 15, kq = l >> 4;
-  const int unit_out = 8 * (i >> 2) + 4 * T + (i & 3);
-  if (s < 64) { const int m = s >> 3, c = s & 7; return W[(unit_out * MC + c) * MH + 8 * kq + m]; }
-  if (s < 66) return bias[unit_out * MC + 4 * (s - 64) + kq];
-  return 0.f;
-}
-
-// d * broadcast(z.lo) / d * broadcast(z.hi) in ONE VALU instruction (VOP3P op_sel selects the source half per
-// result lane).  asm volatile + the callers' sched_barriers keep them a whole MFMA group ahead of their first
-// consumer, so the VALU-write -> MFMA-read wait states are satisfied by construction.
-__device__ __forceinline__ f32x2 pk_mul_lo(f32x2 d, f32x2 z) {
-  f32x2 r;
-  asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(d), "v"(z));
-  return r;
-}
-__device__ __forceinline__ f32x2 pk_mul_hi(f32x2 d, f32x2 z) {
-  f32x2 r;
-  asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(d), "v"(z));
-  return r;
-}
-
-// acc += d * broadcast(z.lo | z.hi), one instruction
-__device__ __forceinline__ void pk_fma_lo(f32x2& acc, f32x2 d, f32x2 z) {
-  asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(d), "v"(z));
-}
-__device__ __forceinline__ void pk_fma_hi(f32x2& acc, f32x2 d, f32x2 z) {
-  asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(d), "v"(z));
-}
-
-__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-
 template <typename TT, int DEGREE>
 __global__ __launch_bounds__(512, 2) void rk4_forward_mfma(
     const float* __restrict__ coeffs, const float* __restrict__ knots, int64_t n_intervals,
@@ -209,12 +51,9 @@ __global__ __launch_bounds__(512, 2) void rk4_forward_mfma(
     float* __restrict__ z_out, int64_t B, const int64_t* __restrict__ stage_index,
     const float* __restrict__ stage_frac) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  for (int e = threadIdx.x; e < W16_FLOATS; e += 512) {
-    const int q4 = e & 3, l = (e >> 2) & 63, g = e >> 8;            // g = T*17 + group
-    const int T = g / W16_GROUPS, grp = g - T * W16_GROUPS;
-    lds[e] = w16_image(W, bias, T, grp * 4 + q4, l);
-  }
-  __syncthreads();
+  // the A-operand image is loop invariant: staged once through LDS, then it lives in registers
+  float4 wA[W16_GROUPS], wB[W16_GROUPS];
+  load_w16(W, bias, lds, wA, wB);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, q = lane >> 4;
   const int64_t tile = (int64_t)blockIdx.x * 8 + wave;
@@ -226,17 +65,6 @@ __global__ __launch_bounds__(512, 2) void rk4_forward_mfma(
   const int64_t series = tile * 16 + n;
   const bool valid = series < B;
   const int64_t sc = valid ? series : B - 1;
-
-  // the A-operand image is loop invariant: 2 x 17 ds_read_b128 once, then it lives in registers
-  float4 wA[W16_GROUPS], wB[W16_GROUPS];
-  {
-    const float4* w4 = reinterpret_cast<const float4*>(lds);
-#pragma unroll
-    for (int g = 0; g < W16_GROUPS; ++g) {
-      wA[g] = w4[g * 64 + lane];
-      wB[g] = w4[(W16_GROUPS + g) * 64 + lane];
-    }
-  }
 
   f32x4 ya, yb;                                  // units 8q..8q+3 and 8q+4..8q+7
   {
@@ -278,46 +106,8 @@ __global__ __launch_bounds__(512, 2) void rk4_forward_mfma(
       Row<DEGREE> nrow = row;
       if (nidx != idx) nrow = load_row<DEGREE>(coeffs, sc, n_intervals, nidx);
 
-      // Measured on gfx950 (scripts/ubench/mfma_issue.hip): a wave hides NOTHING behind its own f32 MFMA --
-      // every other instruction costs ~6 cycles of matrix-pipe time.  So: products are formed two at a time
-      // (v_pk_mul_f32 with the hidden unit broadcast by op_sel, written as asm because LLVM scalarises the
-      // vector multiply when its lanes are consumed one by one) and one group AHEAD of the MFMAs that consume
-      // them (no VALU->MFMA hazard nops); each product feeds both M-tiles.  4 pk_mul per 16 MFMAs.
-      f32x4 fa = {0.f, 0.f, 0.f, 0.f}, fb = {0.f, 0.f, 0.f, 0.f};
-      const f32x2 d01 = {dX[0], dX[1]}, d23 = {dX[2], dX[3]}, d45 = {dX[4], dX[5]}, d67 = {dX[6], dX[7]};
-      const f32x2 zp[4] = {f32x2{za[0], za[1]}, f32x2{za[2], za[3]}, f32x2{zb[0], zb[1]}, f32x2{zb[2], zb[3]}};
-      f32x2 p01 = pk_mul_lo(d01, zp[0]), p23 = pk_mul_lo(d23, zp[0]), p45 = pk_mul_lo(d45, zp[0]),
-            p67 = pk_mul_lo(d67, zp[0]);
-#pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        f32x2 n01 = p01, n23 = p23, n45 = p45, n67 = p67;
-        if (m < 7) {
-          const f32x2 zn = zp[(m + 1) >> 1];
-          if ((m + 1) & 1) { n01 = pk_mul_hi(d01, zn); n23 = pk_mul_hi(d23, zn); n45 = pk_mul_hi(d45, zn); n67 = pk_mul_hi(d67, zn); }
-          else { n01 = pk_mul_lo(d01, zn); n23 = pk_mul_lo(d23, zn); n45 = pk_mul_lo(d45, zn); n67 = pk_mul_lo(d67, zn); }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const float* ga = reinterpret_cast<const float*>(&wA[2 * m]);       // steps 8m .. 8m+7 = groups 2m, 2m+1
-        const float* gb = reinterpret_cast<const float*>(&wB[2 * m]);
-        fa = mfma16(ga[0], p01[0], fa); fb = mfma16(gb[0], p01[0], fb);
-        fa = mfma16(ga[1], p01[1], fa); fb = mfma16(gb[1], p01[1], fb);
-        fa = mfma16(ga[2], p23[0], fa); fb = mfma16(gb[2], p23[0], fb);
-        fa = mfma16(ga[3], p23[1], fa); fb = mfma16(gb[3], p23[1], fb);
-        fa = mfma16(ga[4], p45[0], fa); fb = mfma16(gb[4], p45[0], fb);
-        fa = mfma16(ga[5], p45[1], fa); fb = mfma16(gb[5], p45[1], fb);
-        fa = mfma16(ga[6], p67[0], fa); fb = mfma16(gb[6], p67[0], fb);
-        fa = mfma16(ga[7], p67[1], fa); fb = mfma16(gb[7], p67[1], fb);
-        __builtin_amdgcn_sched_barrier(0);
-        p01 = n01; p23 = n23; p45 = n45; p67 = n67;
-      }
-      {   // bias: step 64 feeds channel kq, step 65 channel 4 + kq
-        const float b0 = q == 0 ? dX[0] : q == 1 ? dX[1] : q == 2 ? dX[2] : dX[3];
-        const float b1 = q == 0 ? dX[4] : q == 1 ? dX[5] : q == 2 ? dX[6] : dX[7];
-        fa = mfma16(wA[16].x, b0, fa);
-        fb = mfma16(wB[16].x, b0, fb);
-        fa = mfma16(wA[16].y, b1, fa);
-        fb = mfma16(wB[16].y, b1, fb);
-      }
+      f32x4 fa, fb;
+      field16(wA, wB, za, zb, dX, q, fa, fb);
 
       // torchdiffeq rk4_alt_step_func (3/8 rule), association order preserved
       const float third = (float)(1.0 / 3.0);
