@@ -13,7 +13,10 @@ Native scope (round 1):
     (grid = t, torchdiffeq's behaviour), increasing ``t``, tensor state; gradients by the continuous adjoint
     (``adjoint=True``) for z0 and the field's weight / bias
   * ``method='dopri5'`` (also the default when no method is passed, as in the reference): adaptive solve with
-    torchdiffeq's batch-global controller, ``rtol/atol`` and ``options={'jump_t': ...}``; forward only
+    torchdiffeq's batch-global controller, ``rtol/atol`` and ``options={'jump_t': ...}``; fused forward
+  * everything else -- arbitrary ``func`` modules (MLPs ...), ``midpoint``/``euler``, ``adjoint=False`` backprop,
+    gradients through ``dopri5`` -- runs step-wise (``torchcde_amd/stepwise.py``): host-driven stepping on the GPU
+    with the native control-derivative and contraction kernels under every vector-field evaluation
 """
 import ctypes
 import math
@@ -361,6 +364,7 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         raise NotImplementedError("torchcde_amd: vector fields given through `func.prod` are not supported natively.")
     if not isinstance(X, _NativePath):
         raise NotImplementedError("torchcde_amd: X must be a torchcde_amd.CubicSpline or LinearInterpolation.")
+    stepwise_kwargs = dict(kwargs)      # what the step-wise path would receive (the reference forwards these verbatim)
     _lib.require_gpu(z0, "z0")
     packed = X._packed()
     _lib.require_gpu(packed, "the control path")
@@ -374,18 +378,10 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
     if not isinstance(system, torch.Tensor):
         raise ValueError("z0 is a tensor and so func must return a tensor as well.")
     _shape_errors(batch + (C,), tuple(system.shape), z0)
-    if field is None:
-        raise NotImplementedError(
-            "torchcde_amd: func is not of the fused affine family (one nn.Linear(hidden, hidden*input) applied to z, "
-            "optionally followed by tanh, viewed as (..., hidden, input)); generic vector fields are not implemented "
-            "on the native path yet (SURVEY section 8(f), rank 1).")
-    weight, bias = field.weight, field.bias
-    if tuple(weight.shape) != (H * C, H):
-        raise NotImplementedError("torchcde_amd: recognised Linear has shape {} but (hidden*input, hidden) = {} was "
-                                  "expected".format(tuple(weight.shape), (H * C, H)))
-    if not (z0.dtype == packed.dtype == weight.dtype):
-        raise NotImplementedError("torchcde_amd: z0, control coefficients and func parameters must share one dtype "
-                                  "(got {}, {}, {}).".format(z0.dtype, packed.dtype, weight.dtype))
+    if field is not None:
+        weight, bias = field.weight, field.bias
+        if tuple(weight.shape) != (H * C, H) or not (z0.dtype == packed.dtype == weight.dtype):
+            field = None              # not a shape / dtype the fused kernels take: solve it step by step instead
 
     if adjoint and "adjoint_params" not in kwargs:
         for buffer in X.buffers():
@@ -397,9 +393,18 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
     options = kwargs.pop("options", None)
     if method is None:
         method = "dopri5"
-    if method not in ("rk4", "dopri5"):
-        raise NotImplementedError("torchcde_amd: method={!r} is not implemented natively; use 'rk4' (torchdiffeq's "
-                                  "3/8-rule, options={{'step_size': ...}}) or 'dopri5'.".format(method))
+    wants_grad = torch.is_grad_enabled() and (z0.requires_grad or any(
+        p.requires_grad for p in (func.parameters() if isinstance(func, torch.nn.Module) else ())))
+    fused = (field is not None and ((method == "rk4" and (adjoint or not wants_grad))
+                                    or (method == "dopri5" and not wants_grad)))
+    if not fused:
+        # Arbitrary vector fields / methods / differentiation modes: host-driven stepping with the native control
+        # derivative and contraction kernels under every evaluation (torchcde_amd/stepwise.py).
+        from . import stepwise
+        kw = stepwise_kwargs
+        return stepwise.solve(X, func, z0, t, adjoint, method, options, kw["rtol"], kw["atol"],
+                              kw.get("adjoint_method"), kw.get("adjoint_options"), kw.get("adjoint_rtol"),
+                              kw.get("adjoint_atol"), kw.get("adjoint_params"))
     if not (isinstance(t, torch.Tensor) and t.dim() == 1 and t.is_floating_point()):
         raise ValueError("t must be a one dimensional floating point tensor.")
     if t.numel() < 1:

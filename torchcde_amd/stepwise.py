@@ -1,0 +1,371 @@
+"""Step-wise solve for vector fields the fused kernels do not recognise.
+
+``func`` is arbitrary user PyTorch code, so it cannot be fused; what the reference owns around it still runs
+natively on every vector-field evaluation:
+
+    dX/dt        K1b  ``cde_path_eval``     (replaces CubicSpline.derivative, interpolation_cubic.py:331-336)
+    f(t,z) @ dX  ``cde_contract``           (replaces the batched mat-vec of _VectorField.forward, solver.py:130)
+
+and the time stepping that the reference delegates to torchdiffeq (solver.py:226-227) is driven from the host with
+the same semantics as the fused kernels / SURVEY appendix A: fixed-grid ``rk4`` (3/8 rule), ``midpoint``, ``euler``;
+adaptive ``dopri5`` with the batch-global controller; linear / dense output interpolation; continuous adjoint
+(augmented state integrated backwards with the forward method) or plain autograd through the steps
+(``adjoint=False``).  Everything stays on the GPU; there is no CPU fallback here either.
+"""
+import bisect
+
+import torch
+
+from . import _lib
+
+
+# ------------------------------------------------------------------------------------------ native pieces
+class _Contract(torch.autograd.Function):
+    """out[..., h] = sum_c F[..., h, c] * dX[..., c]  (native forward; the backward is an outer product)."""
+
+    @staticmethod
+    def forward(ctx, F, dX):
+        lib = _lib.load()
+        _lib.require_gpu(F, "func(t, z)")
+        H, C = F.size(-2), F.size(-1)
+        Fc = F.detach().contiguous()
+        dXc = dX.detach().to(F.dtype).contiguous()
+        B = Fc.numel() // (H * C)
+        out = torch.empty(F.shape[:-1], dtype=F.dtype, device=F.device)
+        _lib.check(lib.cde_contract(_lib.ptr(Fc), _lib.ptr(dXc), _lib.ptr(out), B, H, C, _lib.dtype_enum(F.dtype),
+                                    _lib.stream_ptr(F.device)), "cde_contract")
+        ctx.save_for_backward(dXc)
+        ctx.f_shape = F.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        (dX,) = ctx.saved_tensors
+        return (grad.unsqueeze(-1) * dX.reshape(ctx.f_shape[:-2] + (1, ctx.f_shape[-1]))), None
+
+
+class ControlledField:
+    """t, z -> f(t, z) dX/dt with the reference's shape contract (solver.py:117-135)."""
+
+    def __init__(self, X, func):
+        self.X, self.func = X, func
+
+    def __call__(self, t, z):
+        dX = self.X.derivative(t.detach())
+        return _Contract.apply(self.func(t, z), dX)
+
+
+# ------------------------------------------------------------------------------------------ helpers
+_NONE, _PREV, _NEXT = 0, 1, 2
+
+
+def _rms(x):
+    return x.abs().pow(2).mean().sqrt()
+
+
+def _nudge(t, direction):
+    with torch.no_grad():
+        delta = torch.nextafter(t, t + direction) - t
+    return t + delta
+
+
+def _flatten(parts):
+    return torch.cat([p.reshape(-1) for p in parts])
+
+
+def _unflatten(flat, lead, shapes):
+    out, offset = [], 0
+    for shape in shapes:
+        n = 1
+        for s in shape:
+            n *= s
+        out.append(flat[..., offset:offset + n].reshape(tuple(lead) + tuple(shape)))
+        offset += n
+    return tuple(out)
+
+
+class _Wrapped:
+    """torchdiffeq's function wrappers in one place: tuple flattening, time reversal, time cast, ulp nudges."""
+
+    def __init__(self, func, shapes=None, reverse=False):
+        self.func, self.shapes, self.reverse = func, shapes, reverse
+
+    def __call__(self, t, y, perturb=_NONE):
+        t = t.to(y.dtype)
+        if perturb == _NEXT:
+            t = _nudge(t, 1)
+        elif perturb == _PREV:
+            t = _nudge(t, -1)
+        if self.reverse:
+            t = -t
+        if self.shapes is None:
+            out = self.func(t, y)
+        else:
+            out = _flatten(self.func(t, _unflatten(y, (), self.shapes)))
+        return -1.0 * out if self.reverse else out
+
+
+# ------------------------------------------------------------------------------------------ fixed grid
+def _grid(t, step_size):
+    if step_size is None:
+        return t
+    n = torch.ceil((t[-1] - t[0]) / step_size + 1).item()
+    grid = torch.arange(0, n, dtype=t.dtype, device=t.device) * step_size + t[0]
+    grid[-1] = t[-1]
+    return grid
+
+
+def _inc_rk4(f, t0, dt, t1, y0):
+    third, two_thirds = 1 / 3, 2 / 3
+    k1 = f(t0, y0)
+    k2 = f(t0 + dt * third, y0 + dt * k1 * third)
+    k3 = f(t0 + dt * two_thirds, y0 + dt * (k2 - k1 * third))
+    k4 = f(t1, y0 + dt * (k1 - k2 + k3))
+    return (k1 + 3 * (k2 + k3) + k4) * dt * 0.125
+
+
+def _inc_midpoint(f, t0, dt, t1, y0):
+    half = 0.5 * dt
+    return dt * f(t0 + half, y0 + f(t0, y0) * half)
+
+
+def _inc_euler(f, t0, dt, t1, y0):
+    return dt * f(t0, y0)
+
+
+_FIXED = {"rk4": _inc_rk4, "midpoint": _inc_midpoint, "euler": _inc_euler}
+
+
+def _solve_fixed(increment, f, y0, t, step_size):
+    t_host = t.detach().cpu()                       # the grid and the output bookkeeping live on the host
+    grid = _grid(t_host, step_size)
+    out = [y0]
+    j = 1
+    on_device = lambda v: v.to(y0.device)
+    for t0h, t1h in zip(grid[:-1], grid[1:]):
+        t0, t1 = on_device(t0h), on_device(t1h)
+        dt = t1 - t0
+        y1 = y0 + increment(f, t0, dt, t1, y0)
+        while j < len(t_host) and bool(t1h >= t_host[j]):
+            tj = t_host[j]
+            if bool(tj == t0h):
+                out.append(y0)
+            elif bool(tj == t1h):
+                out.append(y1)
+            else:
+                slope = on_device((tj - t0h) / (t1h - t0h)).to(y0.dtype)
+                out.append(y0 + slope * (y1 - y0))
+            j += 1
+        y0 = y1
+    return torch.stack(out)
+
+
+# ------------------------------------------------------------------------------------------ dopri5
+_ALPHA = [1 / 5, 3 / 10, 4 / 5, 8 / 9, 1., 1.]
+_BETA = [[1 / 5], [3 / 40, 9 / 40], [44 / 45, -56 / 15, 32 / 9], [19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729],
+         [9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656],
+         [35 / 384, 0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84]]
+_C_ERR = [35 / 384 - 1951 / 21600, 0, 500 / 1113 - 22642 / 50085, 125 / 192 - 451 / 720,
+          -2187 / 6784 - -12231 / 42400, 11 / 84 - 649 / 6300, -1. / 60.]
+_C_MID = [6025192743 / 30085553152 / 2, 0, 51252292925 / 65400821598 / 2, -2691868925 / 45128329728 / 2,
+          187940372067 / 1594534317056 / 2, -1776094331 / 19743644256 / 2, 11237099 / 235043384 / 2]
+
+
+def _solve_dopri5(f, y0, t, rtol, atol, norm, jump_t=None, safety=0.9, ifactor=10.0, dfactor=0.2,
+                  max_num_steps=2 ** 31 - 1):
+    """Host-driven Dormand-Prince with torchdiffeq's controller (float64 time, batch-global RMS error norm)."""
+    dev, ydt = y0.device, y0.dtype
+    td = torch.float64
+    as_t = lambda v: torch.as_tensor(v, dtype=td, device=dev)
+    rtol, atol, safety, ifactor, dfactor = as_t(rtol), as_t(atol), as_t(safety), as_t(ifactor), as_t(dfactor)
+    beta = [torch.tensor(b, dtype=ydt, device=dev) for b in _BETA]
+    alpha = torch.tensor(_ALPHA, dtype=ydt, device=dev)
+    c_err = torch.tensor(_C_ERR, dtype=ydt, device=dev)
+    c_mid = torch.tensor(_C_MID, dtype=ydt, device=dev)
+    t = t.to(td)
+    out = [y0]
+    f0 = f(t[0], y0)
+    # Hairer's initial step (order 4 -> exponent 1/5)
+    scale = atol + torch.abs(y0) * rtol
+    d0, d1 = norm(y0 / scale).abs(), norm(f0 / scale).abs()
+    h0 = torch.tensor(1e-6, dtype=ydt, device=dev) if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
+    h0 = h0.abs()
+    f1 = f(t[0] + h0, y0 + h0 * f0)
+    d2 = torch.abs(norm((f1 - f0) / scale) / h0)
+    if d1 <= 1e-15 and d2 <= 1e-15:
+        h1 = torch.max(torch.tensor(1e-6, dtype=ydt, device=dev), h0 * 1e-3)
+    else:
+        h1 = (0.01 / max(d1, d2)) ** (1. / 5.)
+    dt = torch.min(100 * h0, h1.abs()).to(td)
+    if jump_t is None:
+        jumps = []
+    else:
+        jt = torch.as_tensor(jump_t).detach().to(device=dev, dtype=td).reshape(-1)
+        jumps = torch.sort(jt[jt >= t[0]]).values.tolist()
+    i_jump = min(bisect.bisect(jumps, t[0].item()), len(jumps) - 1)
+    y, fy, t_lo, t_hi, dense = y0, f0, t[0], t[0], None
+    n = 0
+    for i in range(1, len(t)):
+        target = t[i]
+        while target > t_hi:
+            assert n < max_num_steps, "max_num_steps exceeded"
+            n += 1
+            t0 = t_hi
+            t1 = t0 + dt
+            on_jump = False
+            if jumps:
+                nxt = jumps[i_jump]
+                if t0.item() < nxt < (t0 + dt).item():
+                    on_jump, t1 = True, as_t(nxt)
+                    dt = t1 - t0
+            t0y, dty, t1y = t0.to(ydt), dt.to(ydt), t1.to(ydt)
+            ks = [fy]
+            yi = y
+            for s, (a, b) in enumerate(zip(alpha, beta)):
+                ti, perturb = (t1y, _PREV) if s >= 4 else (t0y + a * dty, _NONE)
+                yi = y + torch.stack(ks, dim=-1).matmul(b * dty).view_as(fy)
+                ks.append(f(ti, yi, perturb=perturb))
+            k = torch.stack(ks, dim=-1)
+            y1, f1 = yi, ks[-1]
+            tol = atol + rtol * torch.max(y.abs(), y1.abs())
+            ratio = norm(k.matmul(dty * c_err) / tol).abs()
+            if bool(ratio <= 1):
+                ymid = y + k.matmul(dty * c_mid).view_as(y)
+                dense = (y, dty * fy, dty * (f1 - 4 * fy) - 11 * y - 5 * y1 + 16 * ymid,
+                         dty * (5 * fy - 3 * f1) + 18 * y + 14 * y1 - 32 * ymid,
+                         2 * dty * (f1 - fy) - 8 * (y1 + y) + 16 * ymid)
+                if on_jump:
+                    if i_jump != len(jumps) - 1:
+                        i_jump += 1
+                    f1 = f(t1, y1, perturb=_NEXT)
+                y, fy, t_lo, t_hi = y1, f1, t0, t1
+            else:
+                t_lo, t_hi = t0, t0
+            if ratio == 0:
+                dt = dt * ifactor
+            else:
+                df = torch.ones((), dtype=td, device=dev) if ratio < 1 else dfactor
+                dt = dt * torch.min(ifactor, torch.max(safety / ratio.to(td) ** 0.2, df))
+        x = ((target - t_lo) / (t_hi - t_lo)).to(ydt)
+        total, xp = dense[0] + x * dense[1], x
+        for coeff in dense[2:]:
+            xp = xp * x
+            total = total + xp * coeff
+        out.append(total)
+    return torch.stack(out)
+
+
+# ------------------------------------------------------------------------------------------ front end
+def odeint(func, y0, t, *, method, options, rtol, atol):
+    """(len(t), *y0.shape) solution, tensor or tuple state, increasing or decreasing ``t``."""
+    options = {} if options is None else dict(options)
+    shapes = None
+    if not isinstance(y0, torch.Tensor):
+        shapes = [tuple(p.shape) for p in y0]
+        y0 = _flatten(y0)
+    reverse = len(t) > 1 and bool(t[0] > t[1])
+    if reverse:
+        t = -t
+        if options.get("jump_t") is not None:
+            options["jump_t"] = -torch.as_tensor(options["jump_t"]).flip(0)
+    f = _Wrapped(func, shapes, reverse)
+    norm = options.pop("norm", None)
+    if norm is None:
+        norm = _rms if shapes is None else (lambda flat: max(_rms(p) for p in _unflatten(flat, (), shapes)))
+    elif shapes is not None:
+        user_norm = norm
+        norm = lambda flat: user_norm(_unflatten(flat, (), shapes))
+    if method in _FIXED:
+        step_size = options.pop("step_size", None)
+        for key in ("grid_constructor", "perturb"):
+            if options.pop(key, None):
+                raise NotImplementedError("torchcde_amd: option %r is not supported on the step-wise path" % key)
+        if options.pop("interp", "linear") != "linear" or options:
+            raise NotImplementedError("torchcde_amd: unsupported fixed-grid options %s" % sorted(options))
+        sol = _solve_fixed(_FIXED[method], f, y0, t, step_size)
+    elif method == "dopri5":
+        allowed = {k: options.pop(k) for k in ("jump_t", "safety", "ifactor", "dfactor", "max_num_steps") if k in options}
+        if any(v is not None for v in options.values()):
+            raise NotImplementedError("torchcde_amd: unsupported dopri5 options %s" % sorted(options))
+        sol = _solve_dopri5(f, y0, t, rtol, atol, norm, **allowed)
+    else:
+        raise NotImplementedError("torchcde_amd: method %r is not implemented (rk4, midpoint, euler, dopri5 are)" % method)
+    if shapes is not None:
+        sol = _unflatten(sol, (len(t),), shapes)
+    return sol
+
+
+class _Adjoint(torch.autograd.Function):
+    """Continuous adjoint, torchdiffeq's scheme: augmented state (vjp_t, y, a_y, a_params...)
+    integrated backwards per output interval; y re-seeded from the stored solution, a_y bumped by the incoming
+    gradient at every output time."""
+
+    @staticmethod
+    def forward(ctx, cfg, y0, t, *params):
+        ctx.cfg = cfg
+        with torch.no_grad():
+            ans = odeint(cfg["func"], y0, t, method=cfg["method"], options=cfg["options"], rtol=cfg["rtol"],
+                         atol=cfg["atol"])
+        ctx.save_for_backward(t, ans, *params)
+        return ans
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        cfg = ctx.cfg
+        func = cfg["func"]
+        t, y, *params = ctx.saved_tensors
+        params = tuple(params)
+        with torch.no_grad():
+            aug = [torch.zeros((), dtype=y.dtype, device=y.device), y[-1], grad_y[-1]]
+            aug.extend(torch.zeros_like(p) for p in params)
+
+            def dynamics(time, state):
+                yy, aa = state[1], state[2]
+                with torch.enable_grad():
+                    tt = time.detach()
+                    yy = yy.detach().requires_grad_(True)
+                    fe = func(tt.to(yy.dtype), yy)
+                    vy, *vp = torch.autograd.grad(fe, (yy,) + params, -aa, allow_unused=True)
+                vy = torch.zeros_like(yy) if vy is None else vy
+                vp = [torch.zeros_like(p) if g is None else g for p, g in zip(params, vp)]
+                return (torch.zeros_like(state[0]), fe, vy, *vp)
+
+            adj_options = dict(cfg["adjoint_options"])
+            if cfg["adjoint_method"] == "dopri5" and "norm" not in adj_options:
+                def adjoint_norm(parts):
+                    tt, yy, aa, *pp = parts
+                    extra = max([_rms(p) for p in pp]) if pp else 0.0
+                    return max(tt.abs(), _rms(yy), _rms(aa), extra)
+                adj_options["norm"] = adjoint_norm
+            for i in range(len(t) - 1, 0, -1):
+                sol = odeint(dynamics, tuple(aug), t[i - 1:i + 1].flip(0), method=cfg["adjoint_method"],
+                             options=adj_options, rtol=cfg["adjoint_rtol"], atol=cfg["adjoint_atol"])
+                aug = [s[1] for s in sol]
+                aug[1] = y[i - 1]
+                aug[2] = aug[2] + grad_y[i - 1]
+        return (None, aug[2], None, *aug[3:])
+
+
+def solve(X, func, z0, t, adjoint, method, options, rtol, atol, adjoint_method, adjoint_options, adjoint_rtol,
+          adjoint_atol, adjoint_params):
+    """Step-wise cdeint: returns (..., len(t), H) like the fused path."""
+    field = ControlledField(X, func)
+    t = t.to(z0.device)
+    if adjoint:
+        if adjoint_params is None:
+            if not isinstance(func, torch.nn.Module):
+                raise ValueError("func must be an instance of nn.Module to specify the adjoint parameters; alternatively "
+                                 "they can be specified explicitly via the `adjoint_params` argument. If there are no "
+                                 "parameters then it is allowable to set `adjoint_params=()`.")
+            adjoint_params = tuple(func.parameters())
+        params = tuple(p for p in adjoint_params if p.requires_grad)
+        fixed_opts = {k: v for k, v in (options or {}).items() if k != "norm"}
+        cfg = dict(func=field, method=method, options=options, rtol=rtol, atol=atol,
+                   adjoint_method=adjoint_method or method,
+                   adjoint_options=fixed_opts if adjoint_options is None else dict(adjoint_options),
+                   adjoint_rtol=adjoint_rtol, adjoint_atol=adjoint_atol)
+        out = _Adjoint.apply(cfg, z0, t, *params)
+    else:
+        out = odeint(field, z0, t, method=method, options=options, rtol=rtol, atol=atol)
+    lead = range(1, out.dim() - 1)
+    return out.permute(*lead, 0, -1)
