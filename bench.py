@@ -138,6 +138,16 @@ def main():
     ev[1].record()
     torch.cuda.synchronize()
     fit_ms = ev[0].elapsed_time(ev[1]) / 10
+    # K0 (missing-value fill) on the survey's irregular workload: 10 % of the entries missing
+    x_nan = x.masked_fill(torch.rand(x.shape, device=device) < 0.1, float("nan"))
+    cde.linear_interpolation_coeffs(x_nan)
+    ev[0].record()
+    for _ in range(5):
+        cde.linear_interpolation_coeffs(x_nan)
+    ev[1].record()
+    torch.cuda.synchronize()
+    fill_ms = ev[0].elapsed_time(ev[1]) / 5
+    del x_nan
     X = cde.CubicSpline(coeffs)
     t = X.interval
     params = list(func.parameters())
@@ -221,6 +231,8 @@ def main():
                 "hermite_fit_series_per_s": B / (fit_ms * 1e-3),
                 "hermite_fit_hbm_gbs": B * 20352 / (fit_ms * 1e-3) / 1e9,
                 "hermite_fit_hbm_frac_of_8TBs": B * 20352 / (fit_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "missing_value_fill_ms_10pct_nan": fill_ms,
+                "missing_value_fill_series_per_s": B / (fill_ms * 1e-3),
             },
         }
         if world == 1 and args.cpu_sample > 0:

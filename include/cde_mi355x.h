@@ -75,6 +75,15 @@ int cde_hermite_bdiff_coeffs(const void* x, const void* t, void* coeffs, int64_t
                              void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * K0  Missing-value construction: the NaN path of linear_interpolation_coeffs
+ * (torchcde/interpolation_linear.py:13-84, reached from :169-170 and therefore also the first step
+ * of hermite_cubic_coefficients_with_backward_differences on irregular data).
+ *   x (B, L, C) with NaN = missing; t (L); out (B, L, C) without NaNs, same floats as the reference.
+ * ------------------------------------------------------------------------------------------- */
+int cde_linear_fill_missing(const void* x, const void* t, void* out, int64_t B, int64_t L, int64_t C, int dtype,
+                            void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K1b  Interval lookup and path evaluation for a vector of query times.
  * cde_interpret_t replaces CubicSpline._interpret_t (interpolation_cubic.py:315-322) and
  * LinearInterpolation._interpret_t (interpolation_linear.py:203-210):

@@ -51,13 +51,39 @@ def check_path(x, t):
     return t
 
 
-def linear_coeffs(x, t=None):
-    """interpolation_linear.py:131-171, restricted to the path the north star names:
-    no rectilinear preparation, no missing values (the reference then returns ``x`` itself)."""
-    check_path(x, t)
-    if torch.isnan(x).any():
-        raise NotImplementedError("oracle: NaN-fill path is outside the hot-path scope (SURVEY 8(f) rank 2)")
+def _fill_scalar_path(t, x):
+    """interpolation_linear.py:13-69 for one scalar path (length,): missing values (NaN) are replaced by the
+    linear interpolant between the nearest OBSERVED neighbours; leading / trailing gaps take the first / last
+    observation; an all-NaN path becomes zeros.  Same arithmetic: prev + ((t - t_prev)/(t_next - t_prev))*(next - prev)."""
+    observed = ~torch.isnan(x)
+    n_obs = int(observed.sum())
+    if n_obs == 0:
+        return torch.zeros_like(x)
+    if n_obs == x.numel():
+        return x
+    x = x.clone()
+    obs_idx = observed.nonzero().flatten().tolist()
+    if not observed[0]:
+        x[0] = x[obs_idx[0]]
+    if not observed[-1]:
+        x[-1] = x[obs_idx[-1]]
+    anchors = sorted(set(obs_idx) | {0, x.numel() - 1})
+    for lo, hi in zip(anchors[:-1], anchors[1:]):
+        for i in range(lo + 1, hi):
+            ratio = (t[i] - t[lo]) / (t[hi] - t[lo])
+            x[i] = x[lo] + ratio * (x[hi] - x[lo])
     return x
+
+
+def linear_coeffs(x, t=None):
+    """interpolation_linear.py:131-171 without rectilinear preparation: ``x`` itself when nothing is missing,
+    otherwise every scalar path (one per series and channel) filled by ``_fill_scalar_path`` (:72-84)."""
+    t = check_path(x, t)
+    if not torch.isnan(x).any():
+        return x
+    flat = x.transpose(-1, -2).reshape(-1, x.size(-2))
+    filled = torch.stack([_fill_scalar_path(t, row) for row in flat])
+    return filled.reshape(*x.shape[:-2], x.size(-1), x.size(-2)).transpose(-1, -2)
 
 
 # ----------------------------------------------------------------------------- Hermite fit

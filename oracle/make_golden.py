@@ -96,6 +96,32 @@ def interpolation_cases(ref):
     return cases
 
 
+def nan_fill_cases(ref):
+    """Missing-value construction (reference interpolation_linear.py:13-84) incl. the edge cases its own test
+    exercises (test/test_linear_interpolation.py:6-48): leading / trailing gaps, long runs, all-NaN channels."""
+    from oracle import interp
+    gen = torch.Generator().manual_seed(4242)
+    cases = []
+    for dtype in (torch.float32, torch.float64):
+        for batch, L, C, p_nan, explicit_t in (((3,), 7, 2, 0.3, False), ((2, 2), 12, 3, 0.5, True),
+                                               ((4,), 20, 8, 0.15, True), ((1,), 5, 1, 0.6, False)):
+            x = torch.randn(*batch, L, C, generator=gen, dtype=dtype)
+            mask = torch.rand(*batch, L, C, generator=gen) < p_nan
+            x = x.masked_fill(mask, float("nan"))
+            flat = x.view(-1, L, C)
+            flat[0, :, 0] = float("nan")                       # an all-NaN scalar path
+            flat[-1, :2, -1] = float("nan")                    # leading gap
+            flat[-1, -2:, -1] = float("nan")                   # trailing gap
+            t = _irregular_t(L, dtype, gen) if explicit_t else None
+            filled = ref.linear_interpolation_coeffs(x, t)
+            assert not torch.isnan(filled).any()
+            assert torch.equal(filled, interp.linear_coeffs(x, t)), "oracle NaN fill != reference"
+            hermite = ref.hermite_cubic_coefficients_with_backward_differences(x, t)
+            assert torch.equal(hermite, interp.hermite_bdiff_coeffs(x, t))
+            cases.append(dict(x=x, t=t, filled=filled, hermite=hermite))
+    return cases
+
+
 class LinearField(torch.nn.Module):
     """The README vector field (reference README.md:42-49): Linear(H, H*C) viewed (..., H, C)."""
 
@@ -204,6 +230,9 @@ def main():
     interp_cases = interpolation_cases(ref)
     torch.save(interp_cases, os.path.join(OUT, "interpolation.pt"))
     print("interpolation.pt: %d cases (oracle bit-identical to reference on all)" % len(interp_cases))
+    nan_cases = nan_fill_cases(ref)
+    torch.save(nan_cases, os.path.join(OUT, "nan_fill.pt"))
+    print("nan_fill.pt: %d cases (oracle bit-identical to reference on all)" % len(nan_cases))
     cde_cases = cdeint_cases(ref)
     torch.save(cde_cases, os.path.join(OUT, "cdeint.pt"))
     print("cdeint.pt: %d cases (oracle.cde bit-identical to reference solver.py over oracle.odeint)" % len(cde_cases))

@@ -56,10 +56,35 @@ def test_hermite_coefficients_vs_oracle_seeded(native, dtype, C):
 def test_linear_coeffs_returns_same_tensor(native):
     x = torch.randn(3, 6, 2, device=DEV)
     assert native.linear_interpolation_coeffs(x) is x
-    with pytest.raises(NotImplementedError, match="missing values"):
-        y = x.clone()
-        y[0, 2, 1] = float("nan")
-        native.linear_interpolation_coeffs(y)
+    with pytest.raises(NotImplementedError, match="rectilinear"):
+        native.linear_interpolation_coeffs(x, rectilinear=0)
+
+
+def test_missing_values_bit_exact_vs_reference_golden(native):
+    """NaN-aware construction (interpolation_linear.py:13-84) and the Hermite fit on top of it: bit-exact against
+    fixtures from the reference, incl. leading/trailing gaps and all-NaN channels."""
+    import os
+    from conftest import GOLDEN
+    cases = torch.load(os.path.join(GOLDEN, "nan_fill.pt"))
+    for case in cases:
+        x = case["x"].to(DEV)
+        t = None if case["t"] is None else case["t"].to(DEV)
+        filled = native.linear_interpolation_coeffs(x, t)
+        assert filled is not x and not torch.isnan(filled).any()
+        assert torch.equal(filled.cpu(), case["filled"])
+        assert torch.equal(native.hermite_cubic_coefficients_with_backward_differences(x, t).cpu(), case["hermite"])
+
+
+def test_missing_values_large_batch_vs_oracle(native):
+    B, L, C = 2048, 64, 8
+    gen = torch.Generator().manual_seed(77)
+    x = torch.randn(B, L, C, generator=gen)
+    x = x.masked_fill(torch.rand(B, L, C, generator=gen) < 0.1, float("nan"))      # the survey's 10 % NaN workload
+    got = native.linear_interpolation_coeffs(x.to(DEV)).cpu()
+    sample = torch.arange(0, B, 97)
+    assert torch.equal(got[sample], oracle_interp.linear_coeffs(x[sample]))
+    keep = ~torch.isnan(x)
+    assert torch.equal(got[keep], x[keep]) and not torch.isnan(got).any()          # observations untouched everywhere
 
 
 def test_interpret_t_evaluate_derivative_bit_exact_vs_reference_golden(native, golden_interp):

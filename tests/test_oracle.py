@@ -31,6 +31,14 @@ def test_locate_evaluate_derivative_match_reference_golden(golden_interp):
         assert torch.equal(lin.derivative(tq), case["lin_slope"])
 
 
+def test_missing_value_fill_matches_reference_golden():
+    import os
+    from conftest import GOLDEN
+    for case in torch.load(os.path.join(GOLDEN, "nan_fill.pt")):
+        assert torch.equal(interp.linear_coeffs(case["x"], case["t"]), case["filled"])
+        assert torch.equal(interp.hermite_bdiff_coeffs(case["x"], case["t"]), case["hermite"])
+
+
 def test_hermite_unit_time_known_answer():
     """The reference's closed-form KAT (test/test_hermite_cubic.py:6-38): with unit knot spacing
     two_c = 4(d_next - d_prev), three_d = -3(d_next - d_prev)."""

@@ -58,17 +58,28 @@ def _no_grad_through_path(*tensors):
 def linear_interpolation_coeffs(x, t=None, rectilinear=None):
     """Knots of the piecewise-linear control (reference interpolation_linear.py:131-171).
 
-    Native scope: data without missing values and ``rectilinear=None``; then, exactly like the
-    reference, ``x`` itself is returned (same tensor object)."""
+    Without missing values ``x`` itself is returned (same tensor object), exactly like the reference.  With NaNs
+    every scalar path is filled by K0 (``cde_linear_fill_missing``): observed values stay, gaps become straight
+    lines between the nearest observed neighbours, leading/trailing gaps are constant, all-NaN paths are zero.
+    ``rectilinear`` preparation is not part of the native path."""
     if rectilinear is not None:
         raise NotImplementedError("torchcde_amd: rectilinear interpolation is outside the native hot path "
                                   "(SURVEY section 8(f), rank 2).")
-    _validate_input_path(x, t)
+    t = _validate_input_path(x, t)
     _lib.require_gpu(x, "x")
-    if torch.isnan(x).any():
-        raise NotImplementedError("torchcde_amd: missing values (NaN) need the reference's fill logic, which is not "
-                                  "part of the native hot path yet (SURVEY section 8(f), rank 2).")
-    return x
+    if not torch.isnan(x).any():
+        return x
+    _no_grad_through_path(x, t)
+    src = x.detach().contiguous()
+    knots = t.detach().to(device=x.device, dtype=x.dtype).contiguous()
+    out = torch.empty_like(src)
+    L, C = src.size(-2), src.size(-1)
+    B = src.numel() // (L * C)
+    lib = _lib.load()
+    _lib.check(lib.cde_linear_fill_missing(_lib.ptr(src), _lib.ptr(knots), _lib.ptr(out), B, L, C,
+                                           _lib.dtype_enum(x.dtype), _lib.stream_ptr(x.device)),
+               "cde_linear_fill_missing")
+    return out
 
 
 def hermite_cubic_coefficients_with_backward_differences(x, t=None):
