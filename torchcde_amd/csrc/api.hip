@@ -18,11 +18,12 @@ bool mfma_applicable(int64_t C, int64_t H, int dtype, int act);
 size_t mfma_adjoint_partial_bytes(int64_t B);
 template <typename TT>
 int launch_forward_mfma(const void*, const void*, int64_t, int, const void*, const void*, const void*, const void*,
-                        int64_t, const void*, int64_t, void*, int64_t, const int64_t*, const void*, hipStream_t);
+                        int64_t, const void*, int64_t, void*, int64_t, int64_t, int64_t, const int64_t*, const void*,
+                        hipStream_t);
 template <typename TT>
 int launch_adjoint_mfma(const void*, const void*, int64_t, int, const void*, const void*, const void*, const void*,
-                        const void*, const int64_t*, int64_t, void*, void*, void*, int64_t, const int64_t*,
-                        const void*, float*, hipStream_t);
+                        const void*, const int64_t*, int64_t, void*, void*, void*, int64_t, int64_t, int64_t,
+                        const int64_t*, const void*, float*, hipStream_t);
 
 // Stage table: for solver step k over [grid[k], grid[k+1]] and RK stage j, the control interval
 // and fractional part at the stage time -- what CubicSpline._interpret_t (interpolation_cubic.py:
@@ -74,7 +75,7 @@ static int forward_typed(const void* coeffs, const void* knots, int64_t n_interv
   if (rc != CDE_OK) return rc;
   if (use_mfma)
     return launch_forward_mfma<TT>(coeffs, knots, n_intervals, degree, W, bias, z0, grid, n_grid, t_out, n_out, z_out,
-                                   B, stage_index, stage_frac, s);
+                                   B, C, H, stage_index, stage_frac, s);
   return launch_forward_generic<T, TT>(coeffs, knots, n_intervals, degree, W, bias, act, z0, grid, n_grid, t_out, n_out,
                                        z_out, B, C, H, stage_index, stage_frac, s);
 }
@@ -101,7 +102,7 @@ static int adjoint_typed(const void* coeffs, const void* knots, int64_t n_interv
   if (rc != CDE_OK) return rc;
   if (use_mfma)
     return launch_adjoint_mfma<TT>(coeffs, knots, n_intervals, degree, W, bias, z_saved, grad_out, sgrid, seg_off, n_out,
-                                   grad_z0, grad_W, grad_b, B, stage_index, stage_frac, (float*)partial, s);
+                                   grad_z0, grad_W, grad_b, B, C, H, stage_index, stage_frac, (float*)partial, s);
   return launch_adjoint_generic<T, TT>(coeffs, knots, n_intervals, degree, W, bias, act, z_saved, grad_out, sgrid,
                                        seg_off, n_out, grad_z0, grad_W, grad_b, B, C, H, stage_index, stage_frac,
                                        partial, s);

@@ -6,9 +6,14 @@
 namespace cde {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 
-constexpr int MH = 32;                 // hidden
-constexpr int MC = 8;                  // channels
+constexpr int MH = 32;                 // hidden units the MFMA tiles are built for
+constexpr int MC = 8;                  // channels the MFMA tiles are built for
+// Smaller problems (H <= 32, C <= 8) run on the same tiles zero-padded: weight images return 0 outside the real
+// (H, C), missing hidden units / channels are carried as zeros and never stored.  `Dims` is the real shape.
+struct Dims { int H, C; };
 constexpr int W1_STEPS = 132;          // 16*8 product steps + 4 bias steps
 constexpr int W2_STEPS = 128;
 constexpr int W1_FLOATS = W1_STEPS * 64;
@@ -21,23 +26,29 @@ constexpr int SCR_FLOATS = 2 * 64 * 20 + 32 * 8;     // per wave: z^T, a^T (64 r
 __host__ __device__ __forceinline__ int rho(int i) { return 2 * ((i & 3) + 4 * (i >> 3)) + ((i >> 2) & 1); }
 
 // A-operand images (value for MFMA step s, lane l)
-__device__ __forceinline__ float w1_image(const float* __restrict__ W, const float* __restrict__ bias, int s, int l) {
+__device__ __forceinline__ float w1_image(const float* __restrict__ W, const float* __restrict__ bias, int s, int l,
+                                          Dims d) {
   const int h_out = rho(l & 31), hk = l >> 5;
-  if (s < 128) { const int j = s >> 3, c = s & 7; return W[(h_out * MC + c) * MH + 2 * j + hk]; }
+  if (h_out >= d.H) return 0.f;
+  if (s < 128) {
+    const int j = s >> 3, c = s & 7, k_in = 2 * j + hk;
+    return (c < d.C && k_in < d.H) ? W[(h_out * d.C + c) * d.H + k_in] : 0.f;
+  }
   const int c = 2 * (s - 128) + hk;
-  return bias[h_out * MC + c];
+  return c < d.C ? bias[h_out * d.C + c] : 0.f;
 }
-__device__ __forceinline__ float w2_image(const float* __restrict__ W, int s, int l) {
+__device__ __forceinline__ float w2_image(const float* __restrict__ W, int s, int l, Dims d) {
   const int k_out = rho(l & 31), hk = l >> 5;
-  const int j = s >> 3, c = s & 7;
-  return W[((2 * j + hk) * MC + c) * MH + k_out];
+  const int j = s >> 3, c = s & 7, h_in = 2 * j + hk;
+  return (k_out < d.H && c < d.C && h_in < d.H) ? W[(h_in * d.C + c) * d.H + k_out] : 0.f;
 }
 
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// one control row held in registers: cubic -> b, 2c, 3d (24 floats); linear -> x[idx], x[idx+1] (16 floats)
+// one control row held in registers, always in the 8-channel layout (missing channels are zero):
+// cubic -> b, 2c, 3d (24 floats); linear -> x[idx], x[idx+1] (16 floats)
 template <int DEGREE>
 struct Row {
   float4 v[DEGREE == CDE_PATH_CUBIC ? 6 : 4];
@@ -45,18 +56,50 @@ struct Row {
 
 template <int DEGREE>
 __device__ __forceinline__ Row<DEGREE> load_row(const float* __restrict__ coeffs, int64_t series, int64_t n_intervals,
-                                                 int64_t idx) {
+                                                 int64_t idx, int C = MC) {
   Row<DEGREE> r;
-  if (DEGREE == CDE_PATH_CUBIC) {
-    const float4* p = reinterpret_cast<const float4*>(coeffs + (series * n_intervals + idx) * 4 * MC + MC);
+  if (C == MC) {                                   // 16-byte vector loads (rows are 16-byte aligned when C == 8)
+    if (DEGREE == CDE_PATH_CUBIC) {
+      const float4* p = reinterpret_cast<const float4*>(coeffs + (series * n_intervals + idx) * 4 * MC + MC);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) r.v[i] = p[i];
-  } else {
-    const float4* p = reinterpret_cast<const float4*>(coeffs + (series * (n_intervals + 1) + idx) * MC);
+      for (int i = 0; i < 6; ++i) r.v[i] = p[i];
+    } else {
+      const float4* p = reinterpret_cast<const float4*>(coeffs + (series * (n_intervals + 1) + idx) * MC);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r.v[i] = p[i];
+      for (int i = 0; i < 4; ++i) r.v[i] = p[i];
+    }
+  } else {                                         // narrower control: scalar loads into the padded layout
+    float* f = reinterpret_cast<float*>(r.v);
+    if (DEGREE == CDE_PATH_CUBIC) {
+      const float* p = coeffs + (series * n_intervals + idx) * 4 * C;
+#pragma unroll
+      for (int part = 0; part < 3; ++part)
+#pragma unroll
+        for (int c = 0; c < MC; ++c) f[part * MC + c] = c < C ? p[(part + 1) * C + c] : 0.f;
+    } else {
+      const float* p = coeffs + (series * (n_intervals + 1) + idx) * C;
+#pragma unroll
+      for (int part = 0; part < 2; ++part)
+#pragma unroll
+        for (int c = 0; c < MC; ++c) f[part * MC + c] = c < C ? p[part * C + c] : 0.f;
+    }
   }
   return r;
+}
+
+// 4 consecutive hidden units of one series starting at `unit` (zeros beyond the real H; vector access when the
+// real H is the padded one)
+__device__ __forceinline__ f32x4 load_units4(const float* __restrict__ row, int unit, int H) {
+  if (H == MH) { const float4 v = *reinterpret_cast<const float4*>(row + unit); return f32x4{v.x, v.y, v.z, v.w}; }
+  f32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = unit + i < H ? row[unit + i] : 0.f;
+  return r;
+}
+__device__ __forceinline__ void store_units4(float* __restrict__ row, int unit, int H, const f32x4& v) {
+  if (H == MH) { *reinterpret_cast<float4*>(row + unit) = make_float4(v[0], v[1], v[2], v[3]); return; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) if (unit + i < H) row[unit + i] = v[i];
 }
 
 template <int DEGREE>
@@ -69,18 +112,20 @@ __device__ __forceinline__ void control_slope(const Row<DEGREE>& r, float frac, 
   }
 }
 
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-using f32x2 = __attribute__((ext_vector_type(2))) float;
 constexpr int W16_GROUPS = 17;                      // 66 steps per tile, padded to 68 = 17 float4 groups
 constexpr int W16_FLOATS = 2 * W16_GROUPS * 64 * 4;
 constexpr int FWD_STAGGER_SLEEP = 44;              // x64 cycles ~ half of one RK stage (4224 MFMA cycles + tail)
 
 __device__ __forceinline__ float w16_image(const float* __restrict__ W, const float* __restrict__ bias, int T, int s,
-                                           int l) {
+                                           int l, Dims d) {
   const int i = l & 15, kq = l >> 4;
   const int unit_out = 8 * (i >> 2) + 4 * T + (i & 3);
-  if (s < 64) { const int m = s >> 3, c = s & 7; return W[(unit_out * MC + c) * MH + 8 * kq + m]; }
-  if (s < 66) return bias[unit_out * MC + 4 * (s - 64) + kq];
+  if (unit_out >= d.H) return 0.f;
+  if (s < 64) {
+    const int m = s >> 3, c = s & 7, unit_in = 8 * kq + m;
+    return (c < d.C && unit_in < d.H) ? W[(unit_out * d.C + c) * d.H + unit_in] : 0.f;
+  }
+  if (s < 66) { const int c = 4 * (s - 64) + kq; return c < d.C ? bias[unit_out * d.C + c] : 0.f; }
   return 0.f;
 }
 
@@ -161,11 +206,11 @@ __device__ __forceinline__ void field16(const float4 (&wA)[W16_GROUPS], const fl
 
 // stage the two 16x16x4 weight images in LDS (blockDim threads), then pull this lane's copy into registers
 __device__ __forceinline__ void load_w16(const float* __restrict__ W, const float* __restrict__ bias, float* lds,
-                                         float4 (&wA)[W16_GROUPS], float4 (&wB)[W16_GROUPS]) {
+                                         float4 (&wA)[W16_GROUPS], float4 (&wB)[W16_GROUPS], Dims d) {
   for (int e = threadIdx.x; e < W16_FLOATS; e += blockDim.x) {
     const int q4 = e & 3, l = (e >> 2) & 63, g = e >> 8;            // g = T*17 + group
     const int T = g / W16_GROUPS, grp = g - T * W16_GROUPS;
-    lds[e] = w16_image(W, bias, T, grp * 4 + q4, l);
+    lds[e] = w16_image(W, bias, T, grp * 4 + q4, l, d);
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;

@@ -390,8 +390,6 @@ __global__ void dopri5_attempt_kernel(DopriArgs<T> g, int parity) {
 // ------------------------------------------------------------------------------------------ MFMA attempt kernel
 // f32, H = 32, C = 8, no activation: 16 series per wave on v_mfma_f32_16x16x4_f32 exactly like K2 (field16), six
 // stage evaluations per launch.  Same controller, same state / partial layout as the generic kernel.
-__device__ __forceinline__ f32x4 ld4(const float* p) { const float4 v = *reinterpret_cast<const float4*>(p); return f32x4{v.x, v.y, v.z, v.w}; }
-__device__ __forceinline__ void st4(float* p, const f32x4& v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
 __device__ __forceinline__ f32x4 abs4(const f32x4& v) { return f32x4{fabsf(v[0]), fabsf(v[1]), fabsf(v[2]), fabsf(v[3])}; }
 __device__ __forceinline__ f32x4 max4(const f32x4& a, const f32x4& b) {
   return f32x4{fmaxf(a[0], b[0]), fmaxf(a[1], b[1]), fmaxf(a[2], b[2]), fmaxf(a[3], b[3])};
@@ -412,7 +410,9 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
     return;
   }
   float4 wA[W16_GROUPS], wB[W16_GROUPS];
-  load_w16(g.W, g.bias, lds, wA, wB);
+  const Dims dims{(int)g.H, (int)g.C};
+  const int Hr = dims.H;
+  load_w16(g.W, g.bias, lds, wA, wB, dims);
   double* red = reinterpret_cast<double*>(lds + W16_FLOATS);       // 2 * 512 doubles
   const int64_t BH = g.B * g.H;
   float* Sp = g.state + (int64_t)p * 9 * BH;
@@ -434,7 +434,8 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   const int64_t series = ((int64_t)blockIdx.x * 8 + wave) * 16 + n;
   const bool valid = series < g.B;
   const int64_t sc = valid ? series : g.B - 1;
-  const int64_t e = sc * MH + 8 * q;                                  // this lane's 8 hidden units
+  const int64_t e = sc * Hr;                                          // this series' row in the state arrays
+  const int u0 = 8 * q;                                               // this lane's 8 hidden units: u0 .. u0+7
 
   // control derivative at a (wave-uniform) time; the row is re-fetched only when the interval changes
   int64_t row_idx = -1;
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   auto slope_at = [&](T ts, float (&dX)[MC]) {
     T frac;
     const int64_t idx = locate(g.knots, g.n_intervals, ts, frac);
-    if (idx != row_idx) { row = load_row<DEGREE>(g.coeffs, sc, g.n_intervals, idx); row_idx = idx; }
+    if (idx != row_idx) { row = load_row<DEGREE>(g.coeffs, sc, g.n_intervals, idx, dims.C); row_idx = idx; }
     const float width = DEGREE == CDE_PATH_LINEAR ? g.knots[idx + 1] - g.knots[idx] : 1.f;
     control_slope<DEGREE>(row, frac, width, dX);
   };
@@ -450,14 +451,14 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   f32x4 ya, yb, k0a, k0b;
   double acc0 = 0.0, acc1 = 0.0;
   if (c.phase == 0) {
-    ya = ld4(g.z0 + e); yb = ld4(g.z0 + e + 4);
-    if (valid) { st4(g.z_out + (series * g.n_out) * MH + 8 * q, ya); st4(g.z_out + (series * g.n_out) * MH + 8 * q + 4, yb); }
+    ya = load_units4(g.z0 + e, u0, Hr); yb = load_units4(g.z0 + e, u0 + 4, Hr);
+    if (valid) { store_units4(g.z_out + (series * g.n_out) * Hr, u0, Hr, ya); store_units4(g.z_out + (series * g.n_out) * Hr, u0 + 4, Hr, yb); }
     k0a = k0b = f32x4{0.f, 0.f, 0.f, 0.f};
   } else if (c.phase == 1 || c.phase == 2) {
-    ya = ld4(Sp + e); yb = ld4(Sp + e + 4);
-    k0a = ld4(Sp + 2 * BH + e); k0b = ld4(Sp + 2 * BH + e + 4);
+    ya = load_units4(Sp + e, u0, Hr); yb = load_units4(Sp + e, u0 + 4, Hr);
+    k0a = load_units4(Sp + 2 * BH + e, u0, Hr); k0b = load_units4(Sp + 2 * BH + e, u0 + 4, Hr);
   } else {
-    const f32x4 y0a = ld4(Sp + e), y0b = ld4(Sp + e + 4), y1a = ld4(Sp + BH + e), y1b = ld4(Sp + BH + e + 4);
+    const f32x4 y0a = load_units4(Sp + e, u0, Hr), y0b = load_units4(Sp + e, u0 + 4, Hr), y1a = load_units4(Sp + BH + e, u0, Hr), y1b = load_units4(Sp + BH + e, u0 + 4, Hr);
     if (plan.accept) {
       if (plan.emit_to > plan.emit_from) {
         const T dtf = (T)plan.dt_done;
@@ -465,11 +466,11 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
           const T w = dtf * (T)DP_CMID[j];
-          ma += ld4(Sp + (2 + j) * BH + e) * w; mb += ld4(Sp + (2 + j) * BH + e + 4) * w;
+          ma += load_units4(Sp + (2 + j) * BH + e, u0, Hr) * w; mb += load_units4(Sp + (2 + j) * BH + e, u0 + 4, Hr) * w;
         }
         ma = y0a + ma; mb = y0b + mb;
-        const f32x4 f0a = ld4(Sp + 2 * BH + e), f0b = ld4(Sp + 2 * BH + e + 4);
-        const f32x4 f1a = ld4(Sp + 8 * BH + e), f1b = ld4(Sp + 8 * BH + e + 4);
+        const f32x4 f0a = load_units4(Sp + 2 * BH + e, u0, Hr), f0b = load_units4(Sp + 2 * BH + e, u0 + 4, Hr);
+        const f32x4 f1a = load_units4(Sp + 8 * BH + e, u0, Hr), f1b = load_units4(Sp + 8 * BH + e, u0 + 4, Hr);
         const f32x4 caa = 2.f * dtf * (f1a - f0a) - 8.f * (y1a + y0a) + 16.f * ma;
         const f32x4 cab = 2.f * dtf * (f1b - f0b) - 8.f * (y1b + y0b) + 16.f * mb;
         const f32x4 cba = dtf * (5.f * f0a - 3.f * f1a) + 18.f * y0a + 14.f * y1a - 32.f * ma;
@@ -484,14 +485,14 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
           xp = xp * x; ta = ta + xp * cca; tb = tb + xp * ccb;
           xp = xp * x; ta = ta + xp * cba; tb = tb + xp * cbb;
           xp = xp * x; ta = ta + xp * caa; tb = tb + xp * cab;
-          if (valid) { st4(g.z_out + (series * g.n_out + io) * MH + 8 * q, ta); st4(g.z_out + (series * g.n_out + io) * MH + 8 * q + 4, tb); }
+          if (valid) { store_units4(g.z_out + (series * g.n_out + io) * Hr, u0, Hr, ta); store_units4(g.z_out + (series * g.n_out + io) * Hr, u0 + 4, Hr, tb); }
         }
       }
       ya = y1a; yb = y1b;
-      k0a = ld4(Sp + 8 * BH + e); k0b = ld4(Sp + 8 * BH + e + 4);
+      k0a = load_units4(Sp + 8 * BH + e, u0, Hr); k0b = load_units4(Sp + 8 * BH + e, u0 + 4, Hr);
     } else {
       ya = y0a; yb = y0b;
-      k0a = ld4(Sp + 2 * BH + e); k0b = ld4(Sp + 2 * BH + e + 4);
+      k0a = load_units4(Sp + 2 * BH + e, u0, Hr); k0b = load_units4(Sp + 2 * BH + e, u0 + 4, Hr);
     }
   }
 
@@ -503,7 +504,7 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
     if (valid) {
       acc0 = sq4(ya / sa) + sq4(yb / sb);
       acc1 = sq4(k0a / sa) + sq4(k0b / sb);
-      st4(Sq + e, ya); st4(Sq + e + 4, yb); st4(Sq + 2 * BH + e, k0a); st4(Sq + 2 * BH + e + 4, k0b);
+      store_units4(Sq + e, u0, Hr, ya); store_units4(Sq + e, u0 + 4, Hr, yb); store_units4(Sq + 2 * BH + e, u0, Hr, k0a); store_units4(Sq + 2 * BH + e, u0 + 4, Hr, k0b);
     }
   } else if (mode == 1) {
     const T h0 = plan.h0_state;
@@ -514,7 +515,7 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
     const f32x4 sa = atol + abs4(ya) * rtol, sb = atol + abs4(yb) * rtol;
     if (valid) {
       acc0 = sq4((f1a - k0a) / sa) + sq4((f1b - k0b) / sb);
-      st4(Sq + e, ya); st4(Sq + e + 4, yb); st4(Sq + 2 * BH + e, k0a); st4(Sq + 2 * BH + e + 4, k0b);
+      store_units4(Sq + e, u0, Hr, ya); store_units4(Sq + e, u0 + 4, Hr, yb); store_units4(Sq + 2 * BH + e, u0, Hr, k0a); store_units4(Sq + 2 * BH + e, u0 + 4, Hr, k0b);
     }
   } else if (mode == 2) {
     const T t0f = (T)plan.t0, dtf = (T)plan.dt, t1f = (T)plan.t1;
@@ -541,9 +542,9 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
     const f32x4 ta = atol + rtol * max4(abs4(ya), abs4(zia)), tb = atol + rtol * max4(abs4(yb), abs4(zib));
     if (valid) {
       acc0 = sq4(ea / ta) + sq4(eb / tb);
-      st4(Sq + e, ya); st4(Sq + e + 4, yb); st4(Sq + BH + e, zia); st4(Sq + BH + e + 4, zib);
+      store_units4(Sq + e, u0, Hr, ya); store_units4(Sq + e, u0 + 4, Hr, yb); store_units4(Sq + BH + e, u0, Hr, zia); store_units4(Sq + BH + e, u0 + 4, Hr, zib);
 #pragma unroll
-      for (int j = 0; j < 7; ++j) { st4(Sq + (2 + j) * BH + e, ka[j]); st4(Sq + (2 + j) * BH + e + 4, kb[j]); }
+      for (int j = 0; j < 7; ++j) { store_units4(Sq + (2 + j) * BH + e, u0, Hr, ka[j]); store_units4(Sq + (2 + j) * BH + e, u0 + 4, Hr, kb[j]); }
     }
   }
   block_sum2(acc0, acc1, red);
@@ -562,7 +563,7 @@ static inline int64_t dopri_blocks(int64_t B, int64_t H) {
 }
 static inline size_t al256(size_t x) { return (x + 255) / 256 * 256; }
 static inline bool dopri_use_mfma(int64_t C, int64_t H, int dtype, int act, int variant) {
-  return variant != CDE_VARIANT_GENERIC && dtype == CDE_F32 && H == MH && C == MC && act == CDE_ACT_NONE;
+  return variant != CDE_VARIANT_GENERIC && dtype == CDE_F32 && H <= MH && C <= MC && act == CDE_ACT_NONE;
 }
 static inline int64_t dopri_blocks_any(int64_t B, int64_t H) {          // partial buffer must fit either kernel's grid
   const int64_t a = dopri_blocks(B, H), b = (B + 127) / 128;

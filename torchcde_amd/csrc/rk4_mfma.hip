@@ -49,11 +49,12 @@ __global__ __launch_bounds__(512, 2) void rk4_forward_mfma(
     const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ z0,
     const TT* __restrict__ grid, int64_t n_grid, const TT* __restrict__ t_out, int64_t n_out,
     float* __restrict__ z_out, int64_t B, const int64_t* __restrict__ stage_index,
-    const float* __restrict__ stage_frac) {
+    const float* __restrict__ stage_frac, Dims dims) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // the A-operand image is loop invariant: staged once through LDS, then it lives in registers
   float4 wA[W16_GROUPS], wB[W16_GROUPS];
-  load_w16(W, bias, lds, wA, wB);
+  load_w16(W, bias, lds, wA, wB, dims);
+  const int Hr = dims.H, Cr = dims.C;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, q = lane >> 4;
   const int64_t tile = (int64_t)blockIdx.x * 8 + wave;
@@ -66,18 +67,13 @@ __global__ __launch_bounds__(512, 2) void rk4_forward_mfma(
   const bool valid = series < B;
   const int64_t sc = valid ? series : B - 1;
 
-  f32x4 ya, yb;                                  // units 8q..8q+3 and 8q+4..8q+7
-  {
-    const float4* p = reinterpret_cast<const float4*>(z0 + sc * MH + 8 * q);
-    const float4 lo = p[0], hi = p[1];
-    ya = f32x4{lo.x, lo.y, lo.z, lo.w};
-    yb = f32x4{hi.x, hi.y, hi.z, hi.w};
-  }
+  // units 8q..8q+3 and 8q+4..8q+7 (zero beyond the real hidden size)
+  f32x4 ya = load_units4(z0 + sc * Hr, 8 * q, Hr), yb = load_units4(z0 + sc * Hr, 8 * q + 4, Hr);
   auto store = [&](int64_t j, const f32x4& a, const f32x4& b) {
     if (valid) {
-      float4* p = reinterpret_cast<float4*>(z_out + (series * n_out + j) * MH + 8 * q);
-      p[0] = make_float4(a[0], a[1], a[2], a[3]);
-      p[1] = make_float4(b[0], b[1], b[2], b[3]);
+      float* row = z_out + (series * n_out + j) * Hr;
+      store_units4(row, 8 * q, Hr, a);
+      store_units4(row, 8 * q + 4, Hr, b);
     }
   };
   store(0, ya, yb);
@@ -87,7 +83,7 @@ __global__ __launch_bounds__(512, 2) void rk4_forward_mfma(
 
   int64_t idx = stage_index[0];
   float frac = stage_frac[0];
-  Row<DEGREE> row = load_row<DEGREE>(coeffs, sc, n_intervals, idx);
+  Row<DEGREE> row = load_row<DEGREE>(coeffs, sc, n_intervals, idx, Cr);
 
   for (int64_t k = 0; k < n_steps; ++k) {
     const TT t0 = grid[k], t1 = grid[k + 1];
@@ -104,7 +100,7 @@ __global__ __launch_bounds__(512, 2) void rk4_forward_mfma(
       const int64_t nidx = more ? stage_index[e_next] : idx;
       const float nfrac = more ? stage_frac[e_next] : frac;
       Row<DEGREE> nrow = row;
-      if (nidx != idx) nrow = load_row<DEGREE>(coeffs, sc, n_intervals, nidx);
+      if (nidx != idx) nrow = load_row<DEGREE>(coeffs, sc, n_intervals, nidx, Cr);
 
       f32x4 fa, fb;
       field16(wA, wB, za, zb, dX, q, fa, fb);
@@ -150,17 +146,18 @@ __global__ __launch_bounds__(256, 1) void rk4_adjoint_mfma(
     const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ z_saved,
     const float* __restrict__ grad_out, const TT* __restrict__ sgrid, const int64_t* __restrict__ seg_off,
     int64_t n_out, float* __restrict__ grad_z0, float* __restrict__ partial, int64_t B,
-    const int64_t* __restrict__ stage_index, const float* __restrict__ stage_frac) {
+    const int64_t* __restrict__ stage_index, const float* __restrict__ stage_frac, Dims dims) {
+  const int Hr = dims.H, Cr = dims.C;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* w1f = lds;
   float* w2f = lds + W1_FLOATS;
   for (int e = threadIdx.x; e < W1_FLOATS; e += 256) {
     const int s4 = e >> 8, l = (e >> 2) & 63, q = e & 3;
-    w1f[e] = w1_image(W, bias, s4 * 4 + q, l);
+    w1f[e] = w1_image(W, bias, s4 * 4 + q, l, dims);
   }
   for (int e = threadIdx.x; e < W2_FLOATS; e += 256) {
     const int s4 = e >> 8, l = (e >> 2) & 63, q = e & 3;
-    w2f[e] = w2_image(W, s4 * 4 + q, l);
+    w2f[e] = w2_image(W, s4 * 4 + q, l, dims);
   }
   __syncthreads();
   const float4* w1 = reinterpret_cast<const float4*>(w1f);
@@ -187,8 +184,10 @@ __global__ __launch_bounds__(256, 1) void rk4_adjoint_mfma(
   f32x16 y0, a0;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    y0[r] = z_saved[(sc * n_out + (n_out - 1)) * MH + 2 * r + half];
-    a0[r] = valid ? grad_out[(sc * n_out + (n_out - 1)) * MH + 2 * r + half] : 0.f;   // a == 0 stays 0: padded lanes add nothing to dL/dW
+    const int u = 2 * r + half;
+    const bool on = u < Hr;
+    y0[r] = on ? z_saved[(sc * n_out + (n_out - 1)) * Hr + u] : 0.f;
+    a0[r] = (valid && on) ? grad_out[(sc * n_out + (n_out - 1)) * Hr + u] : 0.f;   // a == 0 stays 0: padded lanes add nothing to dL/dW
   }
 
   // Per-wave LDS scratch for the (series -> MFMA K index) transpose of the dL/dW product, laid out so that
@@ -209,7 +208,7 @@ __global__ __launch_bounds__(256, 1) void rk4_adjoint_mfma(
     if (k_end > k_begin) {
       int64_t idx = stage_index[4 * k_begin];
       float frac = stage_frac[4 * k_begin];
-      Row<DEGREE> row = load_row<DEGREE>(coeffs, sc, n_intervals, idx);
+      Row<DEGREE> row = load_row<DEGREE>(coeffs, sc, n_intervals, idx, Cr);
       for (int64_t k = k_begin; k < k_end; ++k) {
         const float ds = (float)(sgrid[k + 1] - sgrid[k]);
         f32x16 ky1, ky2, ka1, ka2, yst = y0, ast = a0;
@@ -223,7 +222,7 @@ __global__ __launch_bounds__(256, 1) void rk4_adjoint_mfma(
           const bool more = e_next < 4 * k_end;
           const int64_t nidx = more ? stage_index[e_next] : idx;
           const float nfrac = more ? stage_frac[e_next] : frac;
-          if (nidx != idx) row = load_row<DEGREE>(coeffs, sc, n_intervals, nidx);
+          if (nidx != idx) row = load_row<DEGREE>(coeffs, sc, n_intervals, nidx, Cr);
 
           const f32x2 d01 = {dX[0], dX[1]}, d23 = {dX[2], dX[3]}, d45 = {dX[4], dX[5]}, d67 = {dX[6], dX[7]};
           // ---- stage state -> scratch (transposed), weighted control derivative
@@ -352,13 +351,16 @@ __global__ __launch_bounds__(256, 1) void rk4_adjoint_mfma(
     // torchdiffeq adjoint: re-seed y from the stored forward value, add the incoming gradient
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      y0[r] = z_saved[(sc * n_out + (i_out - 1)) * MH + 2 * r + half];
-      if (valid) a0[r] += grad_out[(sc * n_out + (i_out - 1)) * MH + 2 * r + half];
+      const int u = 2 * r + half;
+      if (u < Hr) {
+        y0[r] = z_saved[(sc * n_out + (i_out - 1)) * Hr + u];
+        if (valid) a0[r] += grad_out[(sc * n_out + (i_out - 1)) * Hr + u];
+      }
     }
   }
   if (valid) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) grad_z0[series * MH + 2 * r + half] = a0[r];
+    for (int r = 0; r < 16; ++r) if (2 * r + half < Hr) grad_z0[series * Hr + 2 * r + half] = a0[r];
   }
   // per-wave partial parameter gradients (summed in tile order by reduce_mfma_partials)
 #pragma unroll
@@ -377,9 +379,15 @@ __global__ __launch_bounds__(256, 1) void rk4_adjoint_mfma(
 
 // sum per-wave partials in tile order (deterministic)
 __global__ __launch_bounds__(256) void reduce_mfma_partials(const float* __restrict__ partial, int64_t n_tiles,
-                                                            float* __restrict__ grad_W, float* __restrict__ grad_b) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= PARTIAL_FLOATS) return;
+                                                            float* __restrict__ grad_W, float* __restrict__ grad_b,
+                                                            Dims d) {
+  // one lane per REAL gradient entry; `e` is its position in the padded (32, 8, 32) + (32, 8) partial layout
+  const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n_w = (int64_t)d.H * d.C * d.H, n_b = (int64_t)d.H * d.C;
+  if (id >= n_w + n_b) return;
+  int64_t e;
+  if (id < n_w) { const int64_t k = id % d.H, hc = id / d.H, c = hc % d.C, h = hc / d.C; e = (h * MC + c) * MH + k; }
+  else { const int64_t hc = id - n_w, c = hc % d.C, h = hc / d.C; e = (int64_t)MH * MC * MH + h * MC + c; }
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int64_t t = 0;
   for (; t + 3 < n_tiles; t += 4) {
@@ -390,12 +398,12 @@ __global__ __launch_bounds__(256) void reduce_mfma_partials(const float* __restr
   }
   for (; t < n_tiles; ++t) s0 += partial[t * PARTIAL_FLOATS + e];
   const float sum = (s0 + s1) + (s2 + s3);
-  if (e < MH * MC * MH) grad_W[e] = sum; else grad_b[e - MH * MC * MH] = sum;
+  if (id < n_w) grad_W[id] = sum; else grad_b[id - n_w] = sum;
 }
 
 // ------------------------------------------------------------------------------------------ host side
 bool mfma_applicable(int64_t C, int64_t H, int dtype, int act) {
-  return dtype == CDE_F32 && H == MH && C == MC && act == CDE_ACT_NONE;
+  return dtype == CDE_F32 && H >= 1 && H <= MH && C >= 1 && C <= MC && act == CDE_ACT_NONE;
 }
 
 size_t mfma_adjoint_partial_bytes(int64_t B) { return (size_t)((B + 31) / 32) * PARTIAL_FLOATS * sizeof(float); }
@@ -403,15 +411,16 @@ size_t mfma_adjoint_partial_bytes(int64_t B) { return (size_t)((B + 31) / 32) * 
 template <typename TT>
 int launch_forward_mfma(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
                         const void* bias, const void* z0, const void* grid, int64_t n_grid, const void* t_out,
-                        int64_t n_out, void* z_out, int64_t B, const int64_t* stage_index, const void* stage_frac,
-                        hipStream_t s) {
+                        int64_t n_out, void* z_out, int64_t B, int64_t C, int64_t H, const int64_t* stage_index,
+                        const void* stage_frac, hipStream_t s) {
+  const Dims dims{(int)H, (int)C};
   const unsigned blocks = (unsigned)((B + 127) / 128);     // 8 waves x 16 series, one workgroup per CU at B = 32768
   const size_t lds = W16_FLOATS * sizeof(float);
 #define CDE_FWD(D)                                                                                                  \
   rk4_forward_mfma<TT, D><<<blocks, 512, lds, s>>>((const float*)coeffs, (const float*)knots, n_intervals,          \
                                                    (const float*)W, (const float*)bias, (const float*)z0,           \
                                                    (const TT*)grid, n_grid, (const TT*)t_out, n_out, (float*)z_out, \
-                                                   B, stage_index, (const float*)stage_frac)
+                                                   B, stage_index, (const float*)stage_frac, dims)
   if (degree == CDE_PATH_CUBIC) CDE_FWD(CDE_PATH_CUBIC);
   else if (degree == CDE_PATH_LINEAR) CDE_FWD(CDE_PATH_LINEAR);
   else return CDE_ERR_UNSUPPORTED;
@@ -423,7 +432,9 @@ template <typename TT>
 int launch_adjoint_mfma(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
                         const void* bias, const void* z_saved, const void* grad_out, const void* sgrid,
                         const int64_t* seg_off, int64_t n_out, void* grad_z0, void* grad_W, void* grad_b, int64_t B,
-                        const int64_t* stage_index, const void* stage_frac, float* partial, hipStream_t s) {
+                        int64_t C, int64_t H, const int64_t* stage_index, const void* stage_frac, float* partial,
+                        hipStream_t s) {
+  const Dims dims{(int)H, (int)C};
   const unsigned blocks = (unsigned)((B + 127) / 128);
   const size_t lds = (size_t)(W1_FLOATS + W2_FLOATS + 4 * SCR_FLOATS) * sizeof(float);
 #define CDE_ADJ(D)                                                                                                   \
@@ -434,7 +445,7 @@ int launch_adjoint_mfma(const void* coeffs, const void* knots, int64_t n_interva
                                                      (const float*)W, (const float*)bias, (const float*)z_saved,     \
                                                      (const float*)grad_out, (const TT*)sgrid, seg_off, n_out,       \
                                                      (float*)grad_z0, partial, B, stage_index,                       \
-                                                     (const float*)stage_frac);                                      \
+                                                     (const float*)stage_frac, dims);                                \
   } while (0)
   if (degree == CDE_PATH_CUBIC) CDE_ADJ(CDE_PATH_CUBIC);
   else if (degree == CDE_PATH_LINEAR) CDE_ADJ(CDE_PATH_LINEAR);
@@ -442,22 +453,22 @@ int launch_adjoint_mfma(const void* coeffs, const void* knots, int64_t n_interva
 #undef CDE_ADJ
   int rc = check_launch();
   if (rc != CDE_OK) return rc;
-  reduce_mfma_partials<<<(unsigned)((PARTIAL_FLOATS + 255) / 256), 256, 0, s>>>(partial, (B + 31) / 32, (float*)grad_W,
-                                                                              (float*)grad_b);
+  reduce_mfma_partials<<<(unsigned)((H * C * H + H * C + 255) / 256), 256, 0, s>>>(partial, (B + 31) / 32, (float*)grad_W,
+                                                                                 (float*)grad_b, dims);
   return check_launch();
 }
 
 template int launch_forward_mfma<float>(const void*, const void*, int64_t, int, const void*, const void*, const void*,
-                                        const void*, int64_t, const void*, int64_t, void*, int64_t, const int64_t*,
-                                        const void*, hipStream_t);
+                                        const void*, int64_t, const void*, int64_t, void*, int64_t, int64_t, int64_t,
+                                        const int64_t*, const void*, hipStream_t);
 template int launch_forward_mfma<double>(const void*, const void*, int64_t, int, const void*, const void*, const void*,
-                                         const void*, int64_t, const void*, int64_t, void*, int64_t, const int64_t*,
-                                         const void*, hipStream_t);
+                                         const void*, int64_t, const void*, int64_t, void*, int64_t, int64_t, int64_t,
+                                         const int64_t*, const void*, hipStream_t);
 template int launch_adjoint_mfma<float>(const void*, const void*, int64_t, int, const void*, const void*, const void*,
                                         const void*, const void*, const int64_t*, int64_t, void*, void*, void*, int64_t,
-                                        const int64_t*, const void*, float*, hipStream_t);
+                                        int64_t, int64_t, const int64_t*, const void*, float*, hipStream_t);
 template int launch_adjoint_mfma<double>(const void*, const void*, int64_t, int, const void*, const void*, const void*,
                                          const void*, const void*, const int64_t*, int64_t, void*, void*, void*,
-                                         int64_t, const int64_t*, const void*, float*, hipStream_t);
+                                         int64_t, int64_t, int64_t, const int64_t*, const void*, float*, hipStream_t);
 
 }  // namespace cde
