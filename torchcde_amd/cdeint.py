@@ -187,8 +187,11 @@ class _Plan:
         nbytes = lib.cde_rk4_adjoint_workspace_bytes(self.B, self.C, self.H, n_sgrid, dt, self.variant)
         workspace = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
         grad_z0 = torch.empty(self.B, self.H, dtype=self.dtype, device=self.device)
-        grad_w = torch.empty(self.H * self.C, self.H, dtype=self.dtype, device=self.device)
-        grad_b = torch.empty(self.H * self.C, dtype=self.dtype, device=self.device)
+        # weight and bias gradients are two views of ONE flat buffer: a data-parallel caller can all-reduce that
+        # buffer in a single collective without gather/scatter copies (torchcde_amd.distributed.allreduce_gradients)
+        n_w = self.H * self.C * self.H
+        flat = torch.empty(n_w + self.H * self.C, dtype=self.dtype, device=self.device)
+        grad_w, grad_b = flat[:n_w].view(self.H * self.C, self.H), flat[n_w:]
         zs = z_saved.detach().contiguous()
         go = grad_out.detach().reshape(self.B, self.n_out, self.H).contiguous()
         w = weight.detach().contiguous()

@@ -114,7 +114,7 @@ __device__ __forceinline__ void control_slope(const Row<DEGREE>& r, float frac, 
 
 constexpr int W16_GROUPS = 17;                      // 66 steps per tile, padded to 68 = 17 float4 groups
 constexpr int W16_FLOATS = 2 * W16_GROUPS * 64 * 4;
-constexpr int FWD_STAGGER_SLEEP = 44;              // x64 cycles ~ half of one RK stage (4224 MFMA cycles + tail)
+constexpr int FWD_STAGGER_SLEEP = 44;              // x64 cycles ~ half of one RK stage; measured effect: within noise (+0.4 %)
 
 __device__ __forceinline__ float w16_image(const float* __restrict__ W, const float* __restrict__ bias, int T, int s,
                                            int l, Dims d) {

@@ -29,7 +29,13 @@ def shard(tensor, rank=None, world=None):
 def allreduce_gradients(params, group=None):
     """Sum ``.grad`` of every parameter across ranks with ONE flat all-reduce."""
     grads = [p.grad for p in params if p.grad is not None]
-    if not grads or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not grads or not dist.is_initialized():
+        return
+    # fast path: the fused adjoint hands out weight/bias gradients as adjacent views of one flat buffer
+    base = grads[0]._base
+    if (base is not None and all(g._base is base for g in grads) and base.is_contiguous()
+            and sum(g.numel() for g in grads) == base.numel()):
+        dist.all_reduce(base, op=dist.ReduceOp.SUM, group=group)
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
