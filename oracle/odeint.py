@@ -26,7 +26,6 @@ Semantics that matter for bit-level agreement with the HIP kernels:
     ``a_y`` bumped by the incoming gradient at every output time.
 """
 import bisect
-import math
 
 import torch
 

@@ -10,7 +10,6 @@ Tolerances (stated once, used below):
     there atol is 1e-5 and the kernel's error is additionally bounded by 4x the CPU-float32 error.
   * gradients: rtol 1e-3 (float32 kernels vs float64 oracle), 1e-8 in float64
 """
-import math
 
 import pytest
 import torch

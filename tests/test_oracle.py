@@ -1,6 +1,5 @@
 """CPU tests of the oracle itself: pinned against the reference's golden vectors and known answers
 (interpolation half) and anchored by mathematics (solver half, PARITY UNPINNED -- see oracle/odeint.py)."""
-import math
 
 import pytest
 import torch

@@ -19,7 +19,6 @@ Native scope (round 1):
     with the native control-derivative and contraction kernels under every vector-field evaluation
 """
 import ctypes
-import math
 import warnings
 import weakref
 

@@ -40,7 +40,8 @@ struct DopriArgs {
   double rtol, atol, safety, ifactor, dfactor;
   T* z_out; int64_t B, C, H; int NS;
   DopriCtrl* ctrl;              // [2]
-  T* state;                     // [2][9][B*H]: y0, y1, k0..k6
+  T* state;                     // [2][5][B*H]: y0, y1, k0 (f at t0), k6 (f at t1), y_mid (dense-output midpoint)
+  const float* w16;             // MFMA kernels: the two 16x16x4 weight images, built once per solve
   double* partial;              // [2][n_blocks][2], accumulated in float64 whatever the state dtype
   int64_t n_blocks_alloc;
 };
@@ -258,8 +259,8 @@ __global__ void dopri5_attempt_kernel(DopriArgs<T> g, int parity) {
     if (blockIdx.x == 0 && tid == 0) g.ctrl[q] = c;
     return;
   }
-  T* Sp = g.state + (int64_t)p * 9 * BH;                        // what the previous launch produced
-  T* Sq = g.state + (int64_t)q * 9 * BH;                        // what this launch produces
+  T* Sp = g.state + (int64_t)p * 5 * BH;                        // what the previous launch produced
+  T* Sq = g.state + (int64_t)q * 5 * BH;                        // what this launch produces
   const double* Pp = g.partial + (int64_t)p * g.n_blocks_alloc * 2;
   double* Pq = g.partial + (int64_t)q * g.n_blocks_alloc * 2;
   const T rtol = (T)g.rtol, atol = (T)g.atol;
@@ -292,18 +293,12 @@ __global__ void dopri5_attempt_kernel(DopriArgs<T> g, int parity) {
     } else {
       // commit the pending attempt
       const T y0p = valid ? Sp[0 * BH + e] : (T)0, y1p = valid ? Sp[1 * BH + e] : (T)0;
-      T kk[7];
-#pragma unroll
-      for (int j = 0; j < 7; ++j) kk[j] = valid ? Sp[(2 + j) * BH + e] : (T)0;
+      const T f0 = valid ? Sp[2 * BH + e] : (T)0, f1 = valid ? Sp[3 * BH + e] : (T)0;
       if (accept) {
         // dense output over [t_lo, t_hi] for every output time the step covered (oracle _fit_dense/_eval_dense)
         if (emit_to > emit_from) {
           const T dtf = (T)dt_done;
-          T ymid = (T)0;
-#pragma unroll
-          for (int j = 0; j < 7; ++j) ymid += kk[j] * (dtf * (T)DP_CMID[j]);
-          ymid = y0p + ymid;
-          const T f0 = kk[0], f1 = kk[6];
+          const T ymid = valid ? Sp[4 * BH + e] : (T)0;
           const T ca = (T)2 * dtf * (f1 - f0) - (T)8 * (y1p + y0p) + (T)16 * ymid;
           const T cb = dtf * ((T)5 * f0 - (T)3 * f1) + (T)18 * y0p + (T)14 * y1p - (T)32 * ymid;
           const T cc = dtf * (f1 - (T)4 * f0) - (T)11 * y0p - (T)5 * y1p + (T)16 * ymid;
@@ -318,9 +313,9 @@ __global__ void dopri5_attempt_kernel(DopriArgs<T> g, int parity) {
             if (valid) g.z_out[(series * g.n_out + io) * H + h] = total;
           }
         }
-        y = y1p; k0 = kk[6];
+        y = y1p; k0 = f1;
       } else {
-        y = y0p; k0 = kk[0];
+        y = y0p; k0 = f0;
       }
     }
     if (mode == 3) continue;
@@ -361,17 +356,16 @@ __global__ void dopri5_attempt_kernel(DopriArgs<T> g, int parity) {
         kk[i + 1] = dopri_field(g, zs, dx, yi, ti, tile, s, h, lane_on);
       }
       const T y1 = yi;
-      T err = (T)0;
+      T err = (T)0, mid = (T)0;
 #pragma unroll
-      for (int j = 0; j < 7; ++j) err += kk[j] * (dtf * (T)DP_CERR[j]);
+      for (int j = 0; j < 7; ++j) { err += kk[j] * (dtf * (T)DP_CERR[j]); mid += kk[j] * (dtf * (T)DP_CMID[j]); }
       const T ay = y < 0 ? -y : y, ay1 = y1 < 0 ? -y1 : y1;
       const T tol = atol + rtol * (ay > ay1 ? ay : ay1);
       if (valid) {
         const T r = err / tol;
         acc0 += (double)(r * r);
-        Sq[0 * BH + e] = y; Sq[1 * BH + e] = y1;
-#pragma unroll
-        for (int j = 0; j < 7; ++j) Sq[(2 + j) * BH + e] = kk[j];
+        Sq[0 * BH + e] = y; Sq[1 * BH + e] = y1; Sq[2 * BH + e] = kk[0]; Sq[3 * BH + e] = kk[6];
+        Sq[4 * BH + e] = y + mid;                                  // y_mid = y0 + k @ (dt * c_mid)
       }
     }
   }
@@ -386,6 +380,8 @@ __global__ void dopri5_attempt_kernel(DopriArgs<T> g, int parity) {
     g.ctrl[q] = c;
   }
 }
+
+constexpr int64_t DOPRI_MAX_LDS_KNOTS = 8192;
 
 // ------------------------------------------------------------------------------------------ MFMA attempt kernel
 // f32, H = 32, C = 8, no activation: 16 series per wave on v_mfma_f32_16x16x4_f32 exactly like K2 (field16), six
@@ -409,14 +405,26 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
     if (blockIdx.x == 0 && tid == 0) g.ctrl[q2] = c;
     return;
   }
+  // weight images: built once per solve (w16_image_kernel), here one coalesced 16-byte load per group and lane
   float4 wA[W16_GROUPS], wB[W16_GROUPS];
   const Dims dims{(int)g.H, (int)g.C};
   const int Hr = dims.H;
-  load_w16(g.W, g.bias, lds, wA, wB, dims);
-  double* red = reinterpret_cast<double*>(lds + W16_FLOATS);       // 2 * 512 doubles
+  {
+    const float4* img = reinterpret_cast<const float4*>(g.w16) + (tid & 63);
+#pragma unroll
+    for (int grp = 0; grp < W16_GROUPS; ++grp) { wA[grp] = img[grp * 64]; wB[grp] = img[(W16_GROUPS + grp) * 64]; }
+  }
+  double* red = reinterpret_cast<double*>(lds);                    // 2 * 512 doubles
+  // The knot search of every stage time is a chain of dependent loads: from global memory that is ~7 x 0.3 us per
+  // stage (it dominated this kernel); the knots are copied to LDS once per launch instead.
+  float* knots_lds = lds + 2 * 512 * 2;
+  const bool knots_in_lds = g.n_intervals + 1 <= DOPRI_MAX_LDS_KNOTS;
+  if (knots_in_lds) for (int64_t i = tid; i <= g.n_intervals; i += blockDim.x) knots_lds[i] = g.knots[i];
+  const float* kn = knots_in_lds ? knots_lds : g.knots;
+  __syncthreads();
   const int64_t BH = g.B * g.H;
-  float* Sp = g.state + (int64_t)p * 9 * BH;
-  float* Sq = g.state + (int64_t)q2 * 9 * BH;
+  float* Sp = g.state + (int64_t)p * 5 * BH;
+  float* Sq = g.state + (int64_t)q2 * 5 * BH;
   const double* Pp = g.partial + (int64_t)p * g.n_blocks_alloc * 2;
   double* Pq = g.partial + (int64_t)q2 * g.n_blocks_alloc * 2;
   const T rtol = (T)g.rtol, atol = (T)g.atol;
@@ -442,9 +450,9 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   Row<DEGREE> row;
   auto slope_at = [&](T ts, float (&dX)[MC]) {
     T frac;
-    const int64_t idx = locate(g.knots, g.n_intervals, ts, frac);
+    const int64_t idx = locate(kn, g.n_intervals, ts, frac);
     if (idx != row_idx) { row = load_row<DEGREE>(g.coeffs, sc, g.n_intervals, idx, dims.C); row_idx = idx; }
-    const float width = DEGREE == CDE_PATH_LINEAR ? g.knots[idx + 1] - g.knots[idx] : 1.f;
+    const float width = DEGREE == CDE_PATH_LINEAR ? kn[idx + 1] - kn[idx] : 1.f;
     control_slope<DEGREE>(row, frac, width, dX);
   };
 
@@ -458,19 +466,14 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
     ya = load_units4(Sp + e, u0, Hr); yb = load_units4(Sp + e, u0 + 4, Hr);
     k0a = load_units4(Sp + 2 * BH + e, u0, Hr); k0b = load_units4(Sp + 2 * BH + e, u0 + 4, Hr);
   } else {
-    const f32x4 y0a = load_units4(Sp + e, u0, Hr), y0b = load_units4(Sp + e, u0 + 4, Hr), y1a = load_units4(Sp + BH + e, u0, Hr), y1b = load_units4(Sp + BH + e, u0 + 4, Hr);
+    const f32x4 y0a = load_units4(Sp + e, u0, Hr), y0b = load_units4(Sp + e, u0 + 4, Hr);
     if (plan.accept) {
+      const f32x4 y1a = load_units4(Sp + BH + e, u0, Hr), y1b = load_units4(Sp + BH + e, u0 + 4, Hr);
+      const f32x4 f1a = load_units4(Sp + 3 * BH + e, u0, Hr), f1b = load_units4(Sp + 3 * BH + e, u0 + 4, Hr);
       if (plan.emit_to > plan.emit_from) {
         const T dtf = (T)plan.dt_done;
-        f32x4 ma = {0.f, 0.f, 0.f, 0.f}, mb = ma;
-#pragma unroll
-        for (int j = 0; j < 7; ++j) {
-          const T w = dtf * (T)DP_CMID[j];
-          ma += load_units4(Sp + (2 + j) * BH + e, u0, Hr) * w; mb += load_units4(Sp + (2 + j) * BH + e, u0 + 4, Hr) * w;
-        }
-        ma = y0a + ma; mb = y0b + mb;
         const f32x4 f0a = load_units4(Sp + 2 * BH + e, u0, Hr), f0b = load_units4(Sp + 2 * BH + e, u0 + 4, Hr);
-        const f32x4 f1a = load_units4(Sp + 8 * BH + e, u0, Hr), f1b = load_units4(Sp + 8 * BH + e, u0 + 4, Hr);
+        const f32x4 ma = load_units4(Sp + 4 * BH + e, u0, Hr), mb = load_units4(Sp + 4 * BH + e, u0 + 4, Hr);
         const f32x4 caa = 2.f * dtf * (f1a - f0a) - 8.f * (y1a + y0a) + 16.f * ma;
         const f32x4 cab = 2.f * dtf * (f1b - f0b) - 8.f * (y1b + y0b) + 16.f * mb;
         const f32x4 cba = dtf * (5.f * f0a - 3.f * f1a) + 18.f * y0a + 14.f * y1a - 32.f * ma;
@@ -488,8 +491,7 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
           if (valid) { store_units4(g.z_out + (series * g.n_out + io) * Hr, u0, Hr, ta); store_units4(g.z_out + (series * g.n_out + io) * Hr, u0 + 4, Hr, tb); }
         }
       }
-      ya = y1a; yb = y1b;
-      k0a = load_units4(Sp + 8 * BH + e, u0, Hr); k0b = load_units4(Sp + 8 * BH + e, u0 + 4, Hr);
+      ya = y1a; yb = y1b; k0a = f1a; k0b = f1b;
     } else {
       ya = y0a; yb = y0b;
       k0a = load_units4(Sp + 2 * BH + e, u0, Hr); k0b = load_units4(Sp + 2 * BH + e, u0 + 4, Hr);
@@ -536,15 +538,20 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
       slope_at(ti, dX);
       field16(wA, wB, zia, zib, dX, q, ka[i + 1], kb[i + 1]);
     }
-    f32x4 ea = {0.f, 0.f, 0.f, 0.f}, eb = ea;
+    f32x4 ea = {0.f, 0.f, 0.f, 0.f}, eb = ea, ma = ea, mb = ea;
 #pragma unroll
-    for (int j = 0; j < 7; ++j) { const T w = dtf * (T)DP_CERR[j]; ea += ka[j] * w; eb += kb[j] * w; }
+    for (int j = 0; j < 7; ++j) {
+      const T we = dtf * (T)DP_CERR[j], wm = dtf * (T)DP_CMID[j];
+      ea += ka[j] * we; eb += kb[j] * we; ma += ka[j] * wm; mb += kb[j] * wm;
+    }
     const f32x4 ta = atol + rtol * max4(abs4(ya), abs4(zia)), tb = atol + rtol * max4(abs4(yb), abs4(zib));
     if (valid) {
       acc0 = sq4(ea / ta) + sq4(eb / tb);
-      store_units4(Sq + e, u0, Hr, ya); store_units4(Sq + e, u0 + 4, Hr, yb); store_units4(Sq + BH + e, u0, Hr, zia); store_units4(Sq + BH + e, u0 + 4, Hr, zib);
-#pragma unroll
-      for (int j = 0; j < 7; ++j) { store_units4(Sq + (2 + j) * BH + e, u0, Hr, ka[j]); store_units4(Sq + (2 + j) * BH + e, u0 + 4, Hr, kb[j]); }
+      store_units4(Sq + e, u0, Hr, ya); store_units4(Sq + e, u0 + 4, Hr, yb);
+      store_units4(Sq + BH + e, u0, Hr, zia); store_units4(Sq + BH + e, u0 + 4, Hr, zib);
+      store_units4(Sq + 2 * BH + e, u0, Hr, ka[0]); store_units4(Sq + 2 * BH + e, u0 + 4, Hr, kb[0]);
+      store_units4(Sq + 3 * BH + e, u0, Hr, ka[6]); store_units4(Sq + 3 * BH + e, u0 + 4, Hr, kb[6]);
+      store_units4(Sq + 4 * BH + e, u0, Hr, ya + ma); store_units4(Sq + 4 * BH + e, u0 + 4, Hr, yb + mb);
     }
   }
   block_sum2(acc0, acc1, red);
@@ -553,6 +560,14 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
     c.phase = mode == 0 ? 1 : mode == 1 ? 2 : mode == 2 ? 3 : 4;
     g.ctrl[q2] = c;
   }
+}
+
+__global__ void w16_image_kernel(const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ img, Dims d) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= W16_FLOATS) return;
+  const int q4 = e & 3, l = (e >> 2) & 63, g = e >> 8;
+  const int T = g / W16_GROUPS, grp = g - T * W16_GROUPS;
+  img[e] = w16_image(W, bias, T, grp * 4 + q4, l, d);
 }
 
 static inline int dopri_ns(int64_t H) { int ns = (int)(256 / H); return ns < 1 ? 1 : (ns > 16 ? 16 : ns); }
@@ -577,7 +592,7 @@ extern "C" size_t cde_dopri5_workspace_bytes(int64_t B, int64_t C, int64_t H, in
   (void)C;
   const size_t elem = dtype == CDE_F64 ? 8 : 4;
   return cde::al256(2 * sizeof(cde::DopriCtrl)) + cde::al256((size_t)2 * cde::dopri_blocks_any(B, H) * 2 * sizeof(double)) +
-         (size_t)2 * 9 * B * H * elem;
+         (size_t)2 * 5 * B * H * elem + cde::al256(cde::W16_FLOATS * sizeof(float));
 }
 
 extern "C" int cde_dopri5_advance(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
@@ -599,7 +614,8 @@ extern "C" int cde_dopri5_advance(const void* coeffs, const void* knots, int64_t
   unsigned char* base = (unsigned char*)workspace;
   cde::DopriCtrl* ctrl = (cde::DopriCtrl*)base;
   double* partial = (double*)(base + cde::al256(2 * sizeof(cde::DopriCtrl)));
-  void* state = base + cde::al256(2 * sizeof(cde::DopriCtrl)) + cde::al256((size_t)2 * blocks * 2 * sizeof(double));
+  float* w16 = (float*)(base + cde::al256(2 * sizeof(cde::DopriCtrl)) + cde::al256((size_t)2 * blocks * 2 * sizeof(double)));
+  void* state = (unsigned char*)w16 + cde::al256(cde::W16_FLOATS * sizeof(float));
   if (first_launch == 0) {
     if (hipMemsetAsync(ctrl, 0, 2 * sizeof(cde::DopriCtrl), s) != hipSuccess) return CDE_ERR_LAUNCH;   // phase 0
   }
@@ -609,7 +625,7 @@ extern "C" int cde_dopri5_advance(const void* coeffs, const void* knots, int64_t
   do {                                                                                                            \
     cde::DopriArgs<T> g{(const T*)coeffs, (const T*)knots, n_intervals, degree, (const T*)W, (const T*)bias, act, \
                         (const T*)z0, t_out, n_out, jump_t, n_jump, rtol, atol, safety, ifactor, dfactor,         \
-                        (T*)z_out, B, C, H, ns, ctrl, (T*)state, partial, blocks};                                 \
+                        (T*)z_out, B, C, H, ns, ctrl, (T*)state, nullptr, partial, blocks};                        \
     const size_t lds = (((size_t)ns * (H + C) * sizeof(T) + 15) / 16) * 16 + 2 * nt * sizeof(double);                                 \
     for (int64_t i = 0; i < n_launches; ++i)                                                                      \
       cde::dopri5_attempt_kernel<T><<<(unsigned)cde::dopri_blocks(B, H), nt, lds, s>>>(g, (int)((first_launch + i) & 1)); \
@@ -617,8 +633,12 @@ extern "C" int cde_dopri5_advance(const void* coeffs, const void* knots, int64_t
   if (use_mfma) {
     cde::DopriArgs<float> g{(const float*)coeffs, (const float*)knots, n_intervals, degree, (const float*)W,
                             (const float*)bias, act, (const float*)z0, t_out, n_out, jump_t, n_jump, rtol, atol, safety,
-                            ifactor, dfactor, (float*)z_out, B, C, H, 16, ctrl, (float*)state, partial, blocks};
-    const size_t lds = cde::W16_FLOATS * sizeof(float) + 2 * 512 * sizeof(double);
+                            ifactor, dfactor, (float*)z_out, B, C, H, 16, ctrl, (float*)state, w16, partial, blocks};
+    if (first_launch == 0)
+      cde::w16_image_kernel<<<(cde::W16_FLOATS + 255) / 256, 256, 0, s>>>((const float*)W, (const float*)bias, w16,
+                                                                         cde::Dims{(int)H, (int)C});
+    const int64_t n_knots = n_intervals + 1;
+    const size_t lds = 2 * 512 * sizeof(double) + (n_knots <= cde::DOPRI_MAX_LDS_KNOTS ? (size_t)n_knots * sizeof(float) : 0);
     const unsigned grid = (unsigned)((B + 127) / 128);
     for (int64_t i = 0; i < n_launches; ++i) {
       const int par = (int)((first_launch + i) & 1);

@@ -9,7 +9,6 @@ with every tensor operation executed by the HIP kernels of libcde_mi355x.so (K1,
 """
 import abc
 import math
-import warnings
 
 import torch
 
