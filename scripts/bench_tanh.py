@@ -1,0 +1,54 @@
+"""Timing of the Linear -> tanh vector field on the full-size workload (B=32768, L=128, C=8, H=32), rk4.
+
+    python scripts/bench_tanh.py [--adjoint] [--variants mfma,generic]
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import torchcde_amd as native  # noqa: E402
+from helpers import LinearField, make_series  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--adjoint", action="store_true")
+    ap.add_argument("--variants", default="mfma,generic")
+    ap.add_argument("--batch", type=int, default=32768)
+    ap.add_argument("--reps", type=int, default=5)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    B, L, C, H = args.batch, 128, 8, 32
+    x = make_series(B, L, C).to(dev)
+    coeffs = native.hermite_cubic_coefficients_with_backward_differences(x)
+    X = native.CubicSpline(coeffs)
+    func = LinearField(H, C, scale=1.0, tanh=True, seed=0).to(dev)
+    z0 = torch.randn(B, H, device=dev)
+    for variant in args.variants.split(","):
+        def step():
+            if args.adjoint:
+                z = z0.clone().requires_grad_(True)
+                out = native.cdeint(X, func, z, X.interval, method="rk4", options=dict(step_size=1.0), variant=variant)
+                out[:, -1].sum().backward()
+            else:
+                with torch.no_grad():
+                    native.cdeint(X, func, z0, X.interval, method="rk4", options=dict(step_size=1.0), variant=variant)
+        reps = args.reps if variant != "generic" else 1
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        print(f"tanh field {'fwd+adjoint' if args.adjoint else 'forward'} variant={variant}: {ms:.2f} ms "
+              f"({B / ms * 1e3 / 1e6:.2f} M series/s)", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -197,7 +197,7 @@ def _oracle_solution(coeffs, knots, func, z0, t_out, step, loss_weight=None):
     return out.detach(), z.grad, f64.linear.weight.grad, f64.linear.bias.grad
 
 
-@pytest.mark.parametrize("variant,act", [("mfma", False), ("generic", False), ("generic", True)])
+@pytest.mark.parametrize("variant,act", [("mfma", False), ("generic", False), ("generic", True), ("mfma", True)])
 def test_cdeint_vs_float64_oracle_ragged_batch(native, variant, act):
     """B = 203 (not a multiple of the 32-series wave tile), 3 output times, fp32 kernels vs fp64 oracle."""
     B, L, C, H = 203, 24, 8, 32
@@ -221,20 +221,49 @@ def test_cdeint_vs_float64_oracle_ragged_batch(native, variant, act):
     _close(dfunc.linear.bias.grad, ref_gb, 1e-3, 1e-3 * ref_gb.abs().max().item())
 
 
+@pytest.mark.parametrize("H,C,degree", [(32, 8, 3), (32, 8, 1), (20, 5, 3)])
+def test_tanh_field_forward_on_mfma_tiles(native, H, C, degree):
+    """Linear -> tanh -> view(H, C) fields run the pre-activation tiling (cde_mfma.h: field_act16): forward solve
+    vs the float64 oracle and vs the generic kernel, cubic and linear control, padded shapes."""
+    B, L = 203, 24
+    x = make_series(B, L, C, torch.float32, seed=31)
+    coeffs = oracle_interp.hermite_bdiff_coeffs(x) if degree == 3 else x
+    func = LinearField(H, C, torch.float32, scale=0.5, tanh=True, seed=9)
+    gen = torch.Generator().manual_seed(10)
+    z0 = torch.randn(B, H, generator=gen)
+    t_out = torch.tensor([0., 7.5, 23.])
+    f64 = LinearField(H, C, torch.float64, scale=0.5, tanh=True, seed=9)
+    f64.linear.weight.data.copy_(func.linear.weight.double()); f64.linear.bias.data.copy_(func.linear.bias.double())
+    path64 = (oracle_interp.CubicPath if degree == 3 else oracle_interp.LinearPath)(coeffs.double())
+    with torch.no_grad():
+        ref = oracle_cde.cdeint(path64, f64, z0.double(), t_out.double(), adjoint=False, method="rk4",
+                                options=dict(step_size=1.0))
+    dfunc = LinearField(H, C, torch.float32, scale=0.5, tanh=True, seed=9).to(DEV)
+    X = (native.CubicSpline if degree == 3 else native.LinearInterpolation)(coeffs.to(DEV))
+    res = {}
+    with torch.no_grad():
+        for variant in ("mfma", "generic"):
+            res[variant] = native.cdeint(X, dfunc, z0.to(DEV), t_out.to(DEV), method="rk4", options=dict(step_size=1.0),
+                                         variant=variant)
+    _close(res["mfma"], ref, 1e-4, 5e-6)
+    _close(res["mfma"], res["generic"], 1e-4, 5e-6)
+
+
+@pytest.mark.parametrize("act", [False, True])
 @pytest.mark.parametrize("H,C", [(16, 4), (32, 3), (5, 2), (24, 8)])
-def test_mfma_kernels_on_zero_padded_shapes(native, H, C):
+def test_mfma_kernels_on_zero_padded_shapes(native, H, C, act):
     """H <= 32, C <= 8 run on the MFMA tiles zero-padded (weight images, hidden units and channels outside the real
     shape are zeros that are never stored): forward, adjoint and dopri5 against the float64 oracle / generic kernel."""
     B, L = 75, 12
     x = make_series(B, L, C, torch.float32, seed=50 + H)
     coeffs = oracle_interp.hermite_bdiff_coeffs(x)
-    func = LinearField(H, C, torch.float32, scale=0.3, seed=H)
+    func = LinearField(H, C, torch.float32, scale=0.3, tanh=act, seed=H)
     gen = torch.Generator().manual_seed(H)
     z0 = torch.randn(B, H, generator=gen)
     t_out = torch.tensor([0., 4.5, 11.])
     lw = torch.rand(B, 3, H, generator=gen) + 0.5
     ref_out, ref_gz, ref_gw, ref_gb = _oracle_solution(coeffs, None, func, z0, t_out, 1.0, lw)
-    dfunc = LinearField(H, C, torch.float32, scale=0.3, seed=H).to(DEV)
+    dfunc = LinearField(H, C, torch.float32, scale=0.3, tanh=act, seed=H).to(DEV)
     X = native.CubicSpline(coeffs.to(DEV))
     z = z0.to(DEV).requires_grad_(True)
     out = native.cdeint(X, dfunc, z, t_out.to(DEV), method="rk4", options=dict(step_size=1.0), variant="mfma")
@@ -487,12 +516,13 @@ def test_dopri5_controller_matches_oracle_step_for_step(native, dtype):
         _close(out, ref, 2e-3, 2e-3 * ref.abs().max().item())
 
 
-def test_dopri5_mfma_kernel_equals_generic_kernel(native):
+@pytest.mark.parametrize("act", [False, True])
+def test_dopri5_mfma_kernel_equals_generic_kernel(native, act):
     """Same controller, same state layout: the MFMA attempt kernel must take the generic kernel's step sequence."""
     from torchcde_amd.cdeint import last_dopri5_stats
     B, L, C, H = 300, 20, 8, 32                                 # ragged: 300 = 2*128 + 44
     x = make_series(B, L, C, seed=41).to(DEV)
-    func = LinearField(H, C, scale=0.25, seed=4).to(DEV)
+    func = LinearField(H, C, scale=0.25, tanh=act, seed=4).to(DEV)
     z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(4)).to(DEV)
     t_out = torch.tensor([0., 3.3, 19.], device=DEV)
     res = {}

@@ -14,16 +14,16 @@ int launch_adjoint_generic(const void*, const void*, int64_t, int, const void*, 
                            const void*, const void*, const int64_t*, int64_t, void*, void*, void*, int64_t, int64_t,
                            int64_t, const int64_t*, const void*, void*, hipStream_t);
 // from rk4_mfma.hip
-bool mfma_applicable(int64_t C, int64_t H, int dtype, int act);
+bool mfma_applicable(int64_t C, int64_t H, int dtype, int act, bool adjoint);
 size_t mfma_adjoint_partial_bytes(int64_t B);
 template <typename TT>
-int launch_forward_mfma(const void*, const void*, int64_t, int, const void*, const void*, const void*, const void*,
-                        int64_t, const void*, int64_t, void*, int64_t, int64_t, int64_t, const int64_t*, const void*,
-                        hipStream_t);
+int launch_forward_mfma(const void*, const void*, int64_t, int, const void*, const void*, int, const void*,
+                        const void*, int64_t, const void*, int64_t, void*, int64_t, int64_t, int64_t, const int64_t*,
+                        const void*, hipStream_t);
 template <typename TT>
-int launch_adjoint_mfma(const void*, const void*, int64_t, int, const void*, const void*, const void*, const void*,
-                        const void*, const int64_t*, int64_t, void*, void*, void*, int64_t, int64_t, int64_t,
-                        const int64_t*, const void*, float*, hipStream_t);
+int launch_adjoint_mfma(const void*, const void*, int64_t, int, const void*, const void*, int, const void*,
+                        const void*, const void*, const int64_t*, int64_t, void*, void*, void*, int64_t, int64_t,
+                        int64_t, const int64_t*, const void*, float*, hipStream_t);
 
 // Stage table: for solver step k over [grid[k], grid[k+1]] and RK stage j, the control interval
 // and fractional part at the stage time -- what CubicSpline._interpret_t (interpolation_cubic.py:
@@ -55,8 +55,8 @@ static int fill_stage_table(const void* knots, int64_t n_intervals, const void* 
 
 static inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
-static bool pick_mfma(int variant, int64_t C, int64_t H, int dtype, int act, int* rc) {
-  const bool ok = mfma_applicable(C, H, dtype, act);
+static bool pick_mfma(int variant, int64_t C, int64_t H, int dtype, int act, bool adjoint, int* rc) {
+  const bool ok = mfma_applicable(C, H, dtype, act, adjoint);
   *rc = CDE_OK;
   if (variant == CDE_VARIANT_MFMA) { if (!ok) *rc = CDE_ERR_UNSUPPORTED; return ok; }
   if (variant == CDE_VARIANT_GENERIC) return false;
@@ -71,10 +71,10 @@ static int forward_typed(const void* coeffs, const void* knots, int64_t n_interv
                          int variant, int64_t* stage_index, void* stage_frac, hipStream_t s) {
   int rc = fill_stage_table<T, TT>(knots, n_intervals, grid, n_grid - 1, 0, stage_index, stage_frac, s);
   if (rc != CDE_OK) return rc;
-  const bool use_mfma = pick_mfma(variant, C, H, dtype, act, &rc);
+  const bool use_mfma = pick_mfma(variant, C, H, dtype, act, false, &rc);
   if (rc != CDE_OK) return rc;
   if (use_mfma)
-    return launch_forward_mfma<TT>(coeffs, knots, n_intervals, degree, W, bias, z0, grid, n_grid, t_out, n_out, z_out,
+    return launch_forward_mfma<TT>(coeffs, knots, n_intervals, degree, W, bias, act, z0, grid, n_grid, t_out, n_out, z_out,
                                    B, C, H, stage_index, stage_frac, s);
   return launch_forward_generic<T, TT>(coeffs, knots, n_intervals, degree, W, bias, act, z0, grid, n_grid, t_out, n_out,
                                        z_out, B, C, H, stage_index, stage_frac, s);
@@ -87,7 +87,7 @@ static int adjoint_typed(const void* coeffs, const void* knots, int64_t n_interv
                          void* grad_b, int64_t B, int64_t C, int64_t H, int dtype, int variant, void* workspace,
                          size_t workspace_bytes, hipStream_t s) {
   int rc;
-  const bool use_mfma = pick_mfma(variant, C, H, dtype, act, &rc);
+  const bool use_mfma = pick_mfma(variant, C, H, dtype, act, true, &rc);
   if (rc != CDE_OK) return rc;
   // workspace: [stage_index: 4*(n_sgrid-1) int64][stage_frac: 4*(n_sgrid-1) T][partials]
   const int64_t n_steps = n_sgrid - 1;
@@ -101,7 +101,7 @@ static int adjoint_typed(const void* coeffs, const void* knots, int64_t n_interv
   rc = fill_stage_table<T, TT>(knots, n_intervals, sgrid, n_steps, 1, stage_index, stage_frac, s);
   if (rc != CDE_OK) return rc;
   if (use_mfma)
-    return launch_adjoint_mfma<TT>(coeffs, knots, n_intervals, degree, W, bias, z_saved, grad_out, sgrid, seg_off, n_out,
+    return launch_adjoint_mfma<TT>(coeffs, knots, n_intervals, degree, W, bias, act, z_saved, grad_out, sgrid, seg_off, n_out,
                                    grad_z0, grad_W, grad_b, B, C, H, stage_index, stage_frac, (float*)partial, s);
   return launch_adjoint_generic<T, TT>(coeffs, knots, n_intervals, degree, W, bias, act, z_saved, grad_out, sgrid,
                                        seg_off, n_out, grad_z0, grad_W, grad_b, B, C, H, stage_index, stage_frac,
@@ -138,7 +138,7 @@ extern "C" size_t cde_rk4_adjoint_workspace_bytes(int64_t B, int64_t C, int64_t 
   const int64_t n_steps = n_sgrid > 1 ? n_sgrid - 1 : 0;
   size_t bytes = cde::align256((size_t)(4 * n_steps) * sizeof(int64_t)) + cde::align256((size_t)(4 * n_steps) * elem);
   int rc;
-  const bool use_mfma = cde::pick_mfma(variant, C, H, dtype, CDE_ACT_NONE, &rc);
+  const bool use_mfma = cde::pick_mfma(variant, C, H, dtype, CDE_ACT_NONE, true, &rc);
   // AUTO may resolve to either kernel depending on the activation: reserve the larger need
   const size_t a = cde::mfma_adjoint_partial_bytes(B);
   const size_t b = cde::generic_adjoint_workspace_bytes(B, C, H, elem);

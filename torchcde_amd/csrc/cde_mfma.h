@@ -87,19 +87,24 @@ __device__ __forceinline__ Row<DEGREE> load_row(const float* __restrict__ coeffs
   return r;
 }
 
-// 4 consecutive hidden units of one series starting at `unit` (zeros beyond the real H; vector access when the
-// real H is the padded one)
+// 4 hidden units of one series, `unit`, `unit + STRIDE`, ... (zeros beyond the real H; vector access when they are
+// consecutive and the real H is the padded one)
+template <int STRIDE = 1>
 __device__ __forceinline__ f32x4 load_units4(const float* __restrict__ row, int unit, int H) {
-  if (H == MH) { const float4 v = *reinterpret_cast<const float4*>(row + unit); return f32x4{v.x, v.y, v.z, v.w}; }
+  if (STRIDE == 1 && H == MH) {
+    const float4 v = *reinterpret_cast<const float4*>(row + unit);
+    return f32x4{v.x, v.y, v.z, v.w};
+  }
   f32x4 r;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) r[i] = unit + i < H ? row[unit + i] : 0.f;
+  for (int i = 0; i < 4; ++i) r[i] = unit + i * STRIDE < H ? row[unit + i * STRIDE] : 0.f;
   return r;
 }
+template <int STRIDE = 1>
 __device__ __forceinline__ void store_units4(float* __restrict__ row, int unit, int H, const f32x4& v) {
-  if (H == MH) { *reinterpret_cast<float4*>(row + unit) = make_float4(v[0], v[1], v[2], v[3]); return; }
+  if (STRIDE == 1 && H == MH) { *reinterpret_cast<float4*>(row + unit) = make_float4(v[0], v[1], v[2], v[3]); return; }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) if (unit + i < H) row[unit + i] = v[i];
+  for (int i = 0; i < 4; ++i) if (unit + i * STRIDE < H) row[unit + i * STRIDE] = v[i];
 }
 
 template <int DEGREE>
@@ -219,6 +224,94 @@ __device__ __forceinline__ void load_w16(const float* __restrict__ W, const floa
   for (int g = 0; g < W16_GROUPS; ++g) {
     wA[g] = w4[g * 64 + lane];
     wB[g] = w4[(W16_GROUPS + g) * 64 + lane];
+  }
+}
+
+// ============================================================================ fields with an activation
+// f(z) = reshape_{HxC}(act(W z + b)) dX cannot use the product form above (the activation sits between the GEMM
+// and the contraction with dX), so the GEMM produces the pre-activation Y = W z + b itself and each lane contracts
+// its own rows with dX:
+//   16x16x4 tiles, tile T = 2P + tb (16 of them), row i  <->  hidden unit h = 4P + (i>>2), channel c = 4tb + (i&3)
+//   => the C/D fragment of lane (n, q): tile 2P holds Y[h = 4P+q][c = 0..3], tile 2P+1 holds c = 4..7 of series n
+//   K step s (8 of them), lane quarter kq feeds input unit 4s + kq  => lane (n, q) OWNS units 4m + q (m = 0..7):
+//   its state registers are the B operands as they are (no products at all), and f comes back for the same units.
+// 128 MFMAs per evaluation; the bias is the accumulator's initial value (LDS image, one b128 per tile).
+constexpr int WY_GROUPS = 32;                       // 16 tiles x 8 K steps = 32 float4 groups per lane
+constexpr int WY_FLOATS = WY_GROUPS * 64 * 4;
+constexpr int BY_FLOATS = 16 * 4 * 4;               // bias image [tile][q][r]
+constexpr int ACT16_LDS_FLOATS = WY_FLOATS + BY_FLOATS;
+
+__device__ __forceinline__ float wy16_image(const float* __restrict__ W, int T, int s, int l, Dims d) {
+  const int i = l & 15, kq = l >> 4;
+  const int h = 4 * (T >> 1) + (i >> 2), c = 4 * (T & 1) + (i & 3), k = 4 * s + kq;
+  return (h < d.H && c < d.C && k < d.H) ? W[(h * d.C + c) * d.H + k] : 0.f;
+}
+__device__ __forceinline__ float by16_image(const float* __restrict__ bias, int T, int q, int r, Dims d) {
+  const int h = 4 * (T >> 1) + q, c = 4 * (T & 1) + r;
+  return (h < d.H && c < d.C) ? bias[h * d.C + c] : 0.f;
+}
+
+// tanh to ~1e-7 absolute AND relative error in a dozen VALU instructions (v_exp_f32 / v_rcp_f32 are 1 ulp):
+// 1 - 2/(exp(2|x|) + 1) away from zero, the odd Taylor polynomial through x^9 below 1/4 (where the first form
+// cancels).  libm's tanhf costs ~3x as much and the vector field evaluates 256 of these per series per stage.
+__device__ __forceinline__ float tanh_fast(float x) {
+  const float ax = __builtin_fabsf(x);
+  const float e = __builtin_amdgcn_exp2f(ax * 2.885390081777927f);            // exp(2|x|)
+  const float big = __builtin_fmaf(-2.f, __builtin_amdgcn_rcpf(e + 1.f), 1.f);
+  const float x2 = ax * ax;
+  float p = __builtin_fmaf(x2, 62.f / 2835.f, -17.f / 315.f);
+  p = __builtin_fmaf(x2, p, 2.f / 15.f);
+  p = __builtin_fmaf(x2, p, -1.f / 3.f);
+  const float small = __builtin_fmaf(ax * x2, p, ax);
+  return __builtin_copysignf(ax < 0.25f ? small : big, x);
+}
+template <int ACT>
+__device__ __forceinline__ float activate(float y) { return ACT == CDE_ACT_TANH ? tanh_fast(y) : y; }
+
+// stage the weight and bias images in LDS (they stay there: [WY_FLOATS weight][BY_FLOATS bias])
+__device__ __forceinline__ void stage_wy16(const float* __restrict__ W, const float* __restrict__ bias, float* lds,
+                                           Dims d) {
+  for (int e = threadIdx.x; e < WY_FLOATS; e += blockDim.x) {
+    const int j = e & 3, l = (e >> 2) & 63, g = e >> 8;              // g = 2T + (s>>2)
+    lds[e] = wy16_image(W, g >> 1, 4 * (g & 1) + j, l, d);
+  }
+  for (int e = threadIdx.x; e < BY_FLOATS; e += blockDim.x) lds[WY_FLOATS + e] = by16_image(bias, e >> 4, (e >> 2) & 3, e & 3, d);
+  __syncthreads();
+}
+
+// lane (n, q): za/zb = units q, 4+q, .., 28+q of series n; returns f for the same units.
+// wy = weight image + lane, by = bias image + q (both LDS).  The A operands are re-read from LDS every call
+// (32 x ds_read_b128): holding them in registers (128) leaves too little for the activation's temporaries, and
+// with two waves per SIMD the reads sit in the shadow of the other wave's MFMAs.
+template <int ACT>
+__device__ __forceinline__ void field_act16(const float4* wy, const float4* by, const f32x4& za, const f32x4& zb,
+                                            const float (&dX)[MC], f32x4& fa, f32x4& fb) {
+  const float zs[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
+  int opaque = 0;                             // unknown to the compiler: otherwise LICM hoists the reads out of the solve
+  asm volatile("" : "+v"(opaque));
+  wy += opaque;
+  by += opaque;
+  float4 g00 = wy[0], g01 = wy[64], g10 = wy[128], g11 = wy[192];
+  float4 b0 = by[0], b1 = by[4];
+#pragma unroll
+  for (int P = 0; P < 8; ++P) {
+    f32x4 y0 = {b0.x, b0.y, b0.z, b0.w}, y1 = {b1.x, b1.y, b1.z, b1.w};
+    const float a0[8] = {g00.x, g00.y, g00.z, g00.w, g01.x, g01.y, g01.z, g01.w};     // tile 2P,   K steps 0..7
+    const float a1[8] = {g10.x, g10.y, g10.z, g10.w, g11.x, g11.y, g11.z, g11.w};     // tile 2P+1
+    if (P < 7) {                                                                     // next pair's operands
+      g00 = wy[(4 * P + 4) * 64]; g01 = wy[(4 * P + 5) * 64]; g10 = wy[(4 * P + 6) * 64]; g11 = wy[(4 * P + 7) * 64];
+      b0 = by[8 * P + 8]; b1 = by[8 * P + 12];
+    }
+    __builtin_amdgcn_sched_barrier(0);        // one region per tile pair, the two accumulator chains alternating
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { y0 = mfma16(a0[s], zs[s], y0); y1 = mfma16(a1[s], zs[s], y1); }
+    __builtin_amdgcn_sched_barrier(0);
+    float f = activate<ACT>(y0[0]) * dX[0];
+#pragma unroll
+    for (int c = 1; c < 4; ++c) f = __builtin_fmaf(activate<ACT>(y0[c]), dX[c], f);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) f = __builtin_fmaf(activate<ACT>(y1[c]), dX[4 + c], f);
+    if (P < 4) fa[P] = f; else fb[P - 4] = f;
   }
 }
 

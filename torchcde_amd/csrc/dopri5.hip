@@ -394,7 +394,7 @@ __device__ __forceinline__ double sq4(const f32x4& v) {
   return (double)(v[0] * v[0]) + (double)(v[1] * v[1]) + (double)(v[2] * v[2]) + (double)(v[3] * v[3]);
 }
 
-template <int DEGREE>
+template <int DEGREE, int ACT>
 __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g, int parity) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using T = float;
@@ -405,11 +405,14 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
     if (blockIdx.x == 0 && tid == 0) g.ctrl[q2] = c;
     return;
   }
-  // weight images: built once per solve (w16_image_kernel), here one coalesced 16-byte load per group and lane
-  float4 wA[W16_GROUPS], wB[W16_GROUPS];
+  // weight images: built once per solve (w16_image_kernel / wy16_image_kernel).  Product form: one coalesced
+  // 16-byte load per group and lane into registers; activation form: copied to LDS (field_act16 reads it there).
+  constexpr bool PRODUCT = ACT == CDE_ACT_NONE;
+  constexpr int STRIDE = PRODUCT ? 1 : 4;
+  float4 wA[PRODUCT ? W16_GROUPS : 1], wB[PRODUCT ? W16_GROUPS : 1];
   const Dims dims{(int)g.H, (int)g.C};
   const int Hr = dims.H;
-  {
+  if constexpr (PRODUCT) {
     const float4* img = reinterpret_cast<const float4*>(g.w16) + (tid & 63);
 #pragma unroll
     for (int grp = 0; grp < W16_GROUPS; ++grp) { wA[grp] = img[grp * 64]; wB[grp] = img[(W16_GROUPS + grp) * 64]; }
@@ -421,6 +424,12 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   const bool knots_in_lds = g.n_intervals + 1 <= DOPRI_MAX_LDS_KNOTS;
   if (knots_in_lds) for (int64_t i = tid; i <= g.n_intervals; i += blockDim.x) knots_lds[i] = g.knots[i];
   const float* kn = knots_in_lds ? knots_lds : g.knots;
+  float* img_lds = knots_lds + (knots_in_lds ? (g.n_intervals + 4) / 4 * 4 : 0);          // 16-byte aligned
+  if constexpr (!PRODUCT) {
+    const float4* src = reinterpret_cast<const float4*>(g.w16);
+    float4* dst = reinterpret_cast<float4*>(img_lds);
+    for (int i = tid; i < ACT16_LDS_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
+  }
   __syncthreads();
   const int64_t BH = g.B * g.H;
   float* Sp = g.state + (int64_t)p * 5 * BH;
@@ -443,7 +452,14 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   const bool valid = series < g.B;
   const int64_t sc = valid ? series : g.B - 1;
   const int64_t e = sc * Hr;                                          // this series' row in the state arrays
-  const int u0 = 8 * q;                                               // this lane's 8 hidden units: u0 .. u0+7
+  // this lane's 8 hidden units in two groups of 4: product form 8q..8q+7, activation form q, 4+q, .., 28+q
+  const int u0 = PRODUCT ? 8 * q : q, u1 = PRODUCT ? 8 * q + 4 : 16 + q;
+  const float4* wy = reinterpret_cast<const float4*>(img_lds) + lane;
+  const float4* by = reinterpret_cast<const float4*>(img_lds + WY_FLOATS) + q;
+  auto field = [&](const f32x4& za, const f32x4& zb, const float (&dXv)[MC], f32x4& fa, f32x4& fb) {
+    if constexpr (PRODUCT) field16(wA, wB, za, zb, dXv, q, fa, fb);
+    else field_act16<ACT>(wy, by, za, zb, dXv, fa, fb);
+  };
 
   // control derivative at a (wave-uniform) time; the row is re-fetched only when the interval changes
   int64_t row_idx = -1;
@@ -459,21 +475,21 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   f32x4 ya, yb, k0a, k0b;
   double acc0 = 0.0, acc1 = 0.0;
   if (c.phase == 0) {
-    ya = load_units4(g.z0 + e, u0, Hr); yb = load_units4(g.z0 + e, u0 + 4, Hr);
-    if (valid) { store_units4(g.z_out + (series * g.n_out) * Hr, u0, Hr, ya); store_units4(g.z_out + (series * g.n_out) * Hr, u0 + 4, Hr, yb); }
+    ya = load_units4<STRIDE>(g.z0 + e, u0, Hr); yb = load_units4<STRIDE>(g.z0 + e, u1, Hr);
+    if (valid) { store_units4<STRIDE>(g.z_out + (series * g.n_out) * Hr, u0, Hr, ya); store_units4<STRIDE>(g.z_out + (series * g.n_out) * Hr, u1, Hr, yb); }
     k0a = k0b = f32x4{0.f, 0.f, 0.f, 0.f};
   } else if (c.phase == 1 || c.phase == 2) {
-    ya = load_units4(Sp + e, u0, Hr); yb = load_units4(Sp + e, u0 + 4, Hr);
-    k0a = load_units4(Sp + 2 * BH + e, u0, Hr); k0b = load_units4(Sp + 2 * BH + e, u0 + 4, Hr);
+    ya = load_units4<STRIDE>(Sp + e, u0, Hr); yb = load_units4<STRIDE>(Sp + e, u1, Hr);
+    k0a = load_units4<STRIDE>(Sp + 2 * BH + e, u0, Hr); k0b = load_units4<STRIDE>(Sp + 2 * BH + e, u1, Hr);
   } else {
-    const f32x4 y0a = load_units4(Sp + e, u0, Hr), y0b = load_units4(Sp + e, u0 + 4, Hr);
+    const f32x4 y0a = load_units4<STRIDE>(Sp + e, u0, Hr), y0b = load_units4<STRIDE>(Sp + e, u1, Hr);
     if (plan.accept) {
-      const f32x4 y1a = load_units4(Sp + BH + e, u0, Hr), y1b = load_units4(Sp + BH + e, u0 + 4, Hr);
-      const f32x4 f1a = load_units4(Sp + 3 * BH + e, u0, Hr), f1b = load_units4(Sp + 3 * BH + e, u0 + 4, Hr);
+      const f32x4 y1a = load_units4<STRIDE>(Sp + BH + e, u0, Hr), y1b = load_units4<STRIDE>(Sp + BH + e, u1, Hr);
+      const f32x4 f1a = load_units4<STRIDE>(Sp + 3 * BH + e, u0, Hr), f1b = load_units4<STRIDE>(Sp + 3 * BH + e, u1, Hr);
       if (plan.emit_to > plan.emit_from) {
         const T dtf = (T)plan.dt_done;
-        const f32x4 f0a = load_units4(Sp + 2 * BH + e, u0, Hr), f0b = load_units4(Sp + 2 * BH + e, u0 + 4, Hr);
-        const f32x4 ma = load_units4(Sp + 4 * BH + e, u0, Hr), mb = load_units4(Sp + 4 * BH + e, u0 + 4, Hr);
+        const f32x4 f0a = load_units4<STRIDE>(Sp + 2 * BH + e, u0, Hr), f0b = load_units4<STRIDE>(Sp + 2 * BH + e, u1, Hr);
+        const f32x4 ma = load_units4<STRIDE>(Sp + 4 * BH + e, u0, Hr), mb = load_units4<STRIDE>(Sp + 4 * BH + e, u1, Hr);
         const f32x4 caa = 2.f * dtf * (f1a - f0a) - 8.f * (y1a + y0a) + 16.f * ma;
         const f32x4 cab = 2.f * dtf * (f1b - f0b) - 8.f * (y1b + y0b) + 16.f * mb;
         const f32x4 cba = dtf * (5.f * f0a - 3.f * f1a) + 18.f * y0a + 14.f * y1a - 32.f * ma;
@@ -488,42 +504,42 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
           xp = xp * x; ta = ta + xp * cca; tb = tb + xp * ccb;
           xp = xp * x; ta = ta + xp * cba; tb = tb + xp * cbb;
           xp = xp * x; ta = ta + xp * caa; tb = tb + xp * cab;
-          if (valid) { store_units4(g.z_out + (series * g.n_out + io) * Hr, u0, Hr, ta); store_units4(g.z_out + (series * g.n_out + io) * Hr, u0 + 4, Hr, tb); }
+          if (valid) { store_units4<STRIDE>(g.z_out + (series * g.n_out + io) * Hr, u0, Hr, ta); store_units4<STRIDE>(g.z_out + (series * g.n_out + io) * Hr, u1, Hr, tb); }
         }
       }
       ya = y1a; yb = y1b; k0a = f1a; k0b = f1b;
     } else {
       ya = y0a; yb = y0b;
-      k0a = load_units4(Sp + 2 * BH + e, u0, Hr); k0b = load_units4(Sp + 2 * BH + e, u0 + 4, Hr);
+      k0a = load_units4<STRIDE>(Sp + 2 * BH + e, u0, Hr); k0b = load_units4<STRIDE>(Sp + 2 * BH + e, u1, Hr);
     }
   }
 
   float dX[MC];
   if (mode == 0) {
     slope_at((T)c.t_hi, dX);
-    field16(wA, wB, ya, yb, dX, q, k0a, k0b);
+    field(ya, yb, dX, k0a, k0b);
     const f32x4 sa = atol + abs4(ya) * rtol, sb = atol + abs4(yb) * rtol;
     if (valid) {
       acc0 = sq4(ya / sa) + sq4(yb / sb);
       acc1 = sq4(k0a / sa) + sq4(k0b / sb);
-      store_units4(Sq + e, u0, Hr, ya); store_units4(Sq + e, u0 + 4, Hr, yb); store_units4(Sq + 2 * BH + e, u0, Hr, k0a); store_units4(Sq + 2 * BH + e, u0 + 4, Hr, k0b);
+      store_units4<STRIDE>(Sq + e, u0, Hr, ya); store_units4<STRIDE>(Sq + e, u1, Hr, yb); store_units4<STRIDE>(Sq + 2 * BH + e, u0, Hr, k0a); store_units4<STRIDE>(Sq + 2 * BH + e, u1, Hr, k0b);
     }
   } else if (mode == 1) {
     const T h0 = plan.h0_state;
     const f32x4 za = ya + h0 * k0a, zb = yb + h0 * k0b;
     slope_at((T)(c.t_hi + (double)h0), dX);
     f32x4 f1a, f1b;
-    field16(wA, wB, za, zb, dX, q, f1a, f1b);
+    field(za, zb, dX, f1a, f1b);
     const f32x4 sa = atol + abs4(ya) * rtol, sb = atol + abs4(yb) * rtol;
     if (valid) {
       acc0 = sq4((f1a - k0a) / sa) + sq4((f1b - k0b) / sb);
-      store_units4(Sq + e, u0, Hr, ya); store_units4(Sq + e, u0 + 4, Hr, yb); store_units4(Sq + 2 * BH + e, u0, Hr, k0a); store_units4(Sq + 2 * BH + e, u0 + 4, Hr, k0b);
+      store_units4<STRIDE>(Sq + e, u0, Hr, ya); store_units4<STRIDE>(Sq + e, u1, Hr, yb); store_units4<STRIDE>(Sq + 2 * BH + e, u0, Hr, k0a); store_units4<STRIDE>(Sq + 2 * BH + e, u1, Hr, k0b);
     }
   } else if (mode == 2) {
     const T t0f = (T)plan.t0, dtf = (T)plan.dt, t1f = (T)plan.t1;
     if (c.refresh) {                                                  // just after the jump we landed on
       slope_at(next_toward(t0f, 1.f), dX);
-      field16(wA, wB, ya, yb, dX, q, k0a, k0b);
+      field(ya, yb, dX, k0a, k0b);
     }
     f32x4 ka[7], kb[7];
     ka[0] = k0a; kb[0] = k0b;
@@ -536,7 +552,7 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
       for (int j = 0; j <= i; ++j) { const T w = (T)DP_BETA[i][j] * dtf; ia += ka[j] * w; ib += kb[j] * w; }
       zia = ya + ia; zib = yb + ib;
       slope_at(ti, dX);
-      field16(wA, wB, zia, zib, dX, q, ka[i + 1], kb[i + 1]);
+      field(zia, zib, dX, ka[i + 1], kb[i + 1]);
     }
     f32x4 ea = {0.f, 0.f, 0.f, 0.f}, eb = ea, ma = ea, mb = ea;
 #pragma unroll
@@ -547,11 +563,11 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
     const f32x4 ta = atol + rtol * max4(abs4(ya), abs4(zia)), tb = atol + rtol * max4(abs4(yb), abs4(zib));
     if (valid) {
       acc0 = sq4(ea / ta) + sq4(eb / tb);
-      store_units4(Sq + e, u0, Hr, ya); store_units4(Sq + e, u0 + 4, Hr, yb);
-      store_units4(Sq + BH + e, u0, Hr, zia); store_units4(Sq + BH + e, u0 + 4, Hr, zib);
-      store_units4(Sq + 2 * BH + e, u0, Hr, ka[0]); store_units4(Sq + 2 * BH + e, u0 + 4, Hr, kb[0]);
-      store_units4(Sq + 3 * BH + e, u0, Hr, ka[6]); store_units4(Sq + 3 * BH + e, u0 + 4, Hr, kb[6]);
-      store_units4(Sq + 4 * BH + e, u0, Hr, ya + ma); store_units4(Sq + 4 * BH + e, u0 + 4, Hr, yb + mb);
+      store_units4<STRIDE>(Sq + e, u0, Hr, ya); store_units4<STRIDE>(Sq + e, u1, Hr, yb);
+      store_units4<STRIDE>(Sq + BH + e, u0, Hr, zia); store_units4<STRIDE>(Sq + BH + e, u1, Hr, zib);
+      store_units4<STRIDE>(Sq + 2 * BH + e, u0, Hr, ka[0]); store_units4<STRIDE>(Sq + 2 * BH + e, u1, Hr, kb[0]);
+      store_units4<STRIDE>(Sq + 3 * BH + e, u0, Hr, ka[6]); store_units4<STRIDE>(Sq + 3 * BH + e, u1, Hr, kb[6]);
+      store_units4<STRIDE>(Sq + 4 * BH + e, u0, Hr, ya + ma); store_units4<STRIDE>(Sq + 4 * BH + e, u1, Hr, yb + mb);
     }
   }
   block_sum2(acc0, acc1, red);
@@ -577,8 +593,21 @@ static inline int64_t dopri_blocks(int64_t B, int64_t H) {
   return tiles < 1 ? 1 : (tiles > 2048 ? 2048 : tiles);
 }
 static inline size_t al256(size_t x) { return (x + 255) / 256 * 256; }
+__global__ void wy16_image_kernel(const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ img, Dims d) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < WY_FLOATS) {
+    const int j = e & 3, l = (e >> 2) & 63, g = e >> 8;
+    img[e] = wy16_image(W, g >> 1, 4 * (g & 1) + j, l, d);
+  } else if (e < ACT16_LDS_FLOATS) {
+    const int b = e - WY_FLOATS;
+    img[e] = by16_image(bias, b >> 4, (b >> 2) & 3, b & 3, d);
+  }
+}
+static_assert(ACT16_LDS_FLOATS <= W16_FLOATS, "both image forms share one workspace slot");
+
 static inline bool dopri_use_mfma(int64_t C, int64_t H, int dtype, int act, int variant) {
-  return variant != CDE_VARIANT_GENERIC && dtype == CDE_F32 && H <= MH && C <= MC && act == CDE_ACT_NONE;
+  return variant != CDE_VARIANT_GENERIC && dtype == CDE_F32 && H <= MH && C <= MC &&
+         (act == CDE_ACT_NONE || act == CDE_ACT_TANH);
 }
 static inline int64_t dopri_blocks_any(int64_t B, int64_t H) {          // partial buffer must fit either kernel's grid
   const int64_t a = dopri_blocks(B, H), b = (B + 127) / 128;
@@ -634,16 +663,27 @@ extern "C" int cde_dopri5_advance(const void* coeffs, const void* knots, int64_t
     cde::DopriArgs<float> g{(const float*)coeffs, (const float*)knots, n_intervals, degree, (const float*)W,
                             (const float*)bias, act, (const float*)z0, t_out, n_out, jump_t, n_jump, rtol, atol, safety,
                             ifactor, dfactor, (float*)z_out, B, C, H, 16, ctrl, (float*)state, w16, partial, blocks};
-    if (first_launch == 0)
-      cde::w16_image_kernel<<<(cde::W16_FLOATS + 255) / 256, 256, 0, s>>>((const float*)W, (const float*)bias, w16,
-                                                                         cde::Dims{(int)H, (int)C});
+    const cde::Dims dims{(int)H, (int)C};
+    if (first_launch == 0) {
+      if (act == CDE_ACT_NONE)
+        cde::w16_image_kernel<<<(cde::W16_FLOATS + 255) / 256, 256, 0, s>>>((const float*)W, (const float*)bias, w16, dims);
+      else
+        cde::wy16_image_kernel<<<(cde::ACT16_LDS_FLOATS + 255) / 256, 256, 0, s>>>((const float*)W, (const float*)bias, w16, dims);
+    }
     const int64_t n_knots = n_intervals + 1;
-    const size_t lds = 2 * 512 * sizeof(double) + (n_knots <= cde::DOPRI_MAX_LDS_KNOTS ? (size_t)n_knots * sizeof(float) : 0);
+    const size_t lds = 2 * 512 * sizeof(double) +
+                       (n_knots <= cde::DOPRI_MAX_LDS_KNOTS ? (size_t)((n_knots + 3) / 4 * 4) * sizeof(float) : 0) +
+                       (act == CDE_ACT_NONE ? 0 : cde::ACT16_LDS_FLOATS * sizeof(float));
     const unsigned grid = (unsigned)((B + 127) / 128);
     for (int64_t i = 0; i < n_launches; ++i) {
       const int par = (int)((first_launch + i) & 1);
-      if (degree == CDE_PATH_CUBIC) cde::dopri5_attempt_mfma<CDE_PATH_CUBIC><<<grid, 512, lds, s>>>(g, par);
-      else cde::dopri5_attempt_mfma<CDE_PATH_LINEAR><<<grid, 512, lds, s>>>(g, par);
+      if (act == CDE_ACT_NONE) {
+        if (degree == CDE_PATH_CUBIC) cde::dopri5_attempt_mfma<CDE_PATH_CUBIC, CDE_ACT_NONE><<<grid, 512, lds, s>>>(g, par);
+        else cde::dopri5_attempt_mfma<CDE_PATH_LINEAR, CDE_ACT_NONE><<<grid, 512, lds, s>>>(g, par);
+      } else {
+        if (degree == CDE_PATH_CUBIC) cde::dopri5_attempt_mfma<CDE_PATH_CUBIC, CDE_ACT_TANH><<<grid, 512, lds, s>>>(g, par);
+        else cde::dopri5_attempt_mfma<CDE_PATH_LINEAR, CDE_ACT_TANH><<<grid, 512, lds, s>>>(g, par);
+      }
     }
     return cde::check_launch();
   }

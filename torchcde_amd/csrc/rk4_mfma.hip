@@ -43,7 +43,10 @@ __device__ __forceinline__ void wave_lds_sync() {
 //   tile T row i  <->  hidden unit 8*(i>>2) + 4*T + (i&3)   =>  acc_T[r] of lane (n,q) is unit 8q + 4T + r
 //   step s = (m, c), lane quarter kq feeds K index kq = input unit 8*kq + m, channel c
 //   bias steps 64, 65: lane quarter kq feeds channel 4*(s-64) + kq
-template <typename TT, int DEGREE>
+//
+// ACT != CDE_ACT_NONE: same skeleton on the pre-activation form (cde_mfma.h: field_act16) -- the lane then owns
+// units q, 4+q, .., 28+q instead of 8q..8q+7.
+template <typename TT, int DEGREE, int ACT>
 __global__ __launch_bounds__(512, 2) void rk4_forward_mfma(
     const float* __restrict__ coeffs, const float* __restrict__ knots, int64_t n_intervals,
     const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ z0,
@@ -52,8 +55,11 @@ __global__ __launch_bounds__(512, 2) void rk4_forward_mfma(
     const float* __restrict__ stage_frac, Dims dims) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // the A-operand image is loop invariant: staged once through LDS, then it lives in registers
-  float4 wA[W16_GROUPS], wB[W16_GROUPS];
-  load_w16(W, bias, lds, wA, wB, dims);
+  constexpr bool PRODUCT = ACT == CDE_ACT_NONE;
+  constexpr int STRIDE = PRODUCT ? 1 : 4;          // distance between a lane's consecutive hidden units
+  float4 wA[PRODUCT ? W16_GROUPS : 1], wB[PRODUCT ? W16_GROUPS : 1];
+  if constexpr (PRODUCT) load_w16(W, bias, lds, wA, wB, dims);
+  else stage_wy16(W, bias, lds, dims);
   const int Hr = dims.H, Cr = dims.C;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, q = lane >> 4;
@@ -67,13 +73,16 @@ __global__ __launch_bounds__(512, 2) void rk4_forward_mfma(
   const bool valid = series < B;
   const int64_t sc = valid ? series : B - 1;
 
-  // units 8q..8q+3 and 8q+4..8q+7 (zero beyond the real hidden size)
-  f32x4 ya = load_units4(z0 + sc * Hr, 8 * q, Hr), yb = load_units4(z0 + sc * Hr, 8 * q + 4, Hr);
+  // this lane's 8 hidden units in two groups of 4 (zero beyond the real hidden size)
+  const int ua = PRODUCT ? 8 * q : q, ub = PRODUCT ? 8 * q + 4 : 16 + q;
+  const float4* wy = reinterpret_cast<const float4*>(lds) + lane;              // activation form: LDS images
+  const float4* by = reinterpret_cast<const float4*>(lds + WY_FLOATS) + q;
+  f32x4 ya = load_units4<STRIDE>(z0 + sc * Hr, ua, Hr), yb = load_units4<STRIDE>(z0 + sc * Hr, ub, Hr);
   auto store = [&](int64_t j, const f32x4& a, const f32x4& b) {
     if (valid) {
       float* row = z_out + (series * n_out + j) * Hr;
-      store_units4(row, 8 * q, Hr, a);
-      store_units4(row, 8 * q + 4, Hr, b);
+      store_units4<STRIDE>(row, ua, Hr, a);
+      store_units4<STRIDE>(row, ub, Hr, b);
     }
   };
   store(0, ya, yb);
@@ -103,7 +112,8 @@ __global__ __launch_bounds__(512, 2) void rk4_forward_mfma(
       if (nidx != idx) nrow = load_row<DEGREE>(coeffs, sc, n_intervals, nidx, Cr);
 
       f32x4 fa, fb;
-      field16(wA, wB, za, zb, dX, q, fa, fb);
+      if constexpr (PRODUCT) field16(wA, wB, za, zb, dX, q, fa, fb);
+      else field_act16<ACT>(wy, by, za, zb, dX, fa, fb);
 
       // torchdiffeq rk4_alt_step_func (3/8 rule), association order preserved
       const float third = (float)(1.0 / 3.0);
@@ -377,6 +387,273 @@ __global__ __launch_bounds__(256, 1) void rk4_adjoint_mfma(
   }
 }
 
+// ============================================================================================ adjoint, fields with an activation
+// K3a.  f = reshape(act(W z + b)) dX.  Same ownership as K3 (one wave = 32 series, lane (n, half) keeps hidden
+// units 2r + half), but the GEMMs are the pre-activation ones, processed in 8 row tiles of 4 hidden units x 8
+// channels (32x32x2 MFMAs, 48 per tile, 384 per stage):
+//   Y_T   = W_T z + b_T               16 MFMAs: row i <-> (h = 4T + (i>>3), c = i&7); K step s: half hk feeds unit 2s+hk
+//                                       => lane (n, half) register r = Y[h = 4T + (r>>2)][c = (r&3) + 4*half]
+//   in-lane: t = act(Y), partial f_h = sum_c t dX_c over this half's 4 channels, u = act'(Y) dX_c
+//            v_permlane32_swap adds the two halves' partial sums and leaves f for unit 2r+half in its owner;
+//            it also broadcasts the adjoint state of the tile's 4 units to both halves: g = a_h u  (= dL/dY)
+//   va   += W_T^T g                   16 MFMAs: K step r: half hk feeds (h = 4T + (r>>2), c = (r&3) + 4hk) = its OWN
+//                                       register r; row i <-> output unit rho(i)
+//   dW_T += (w ds g)^T z              16 MFMAs with the series as K: g goes through a per-wave LDS transpose
+//                                       (rows of 16 series + 4 pad, ds_read_b128 on the reader side); dL/db is the
+//                                       row sum of the same transposed tile.
+template <int ACT>
+__device__ __forceinline__ float activate_slope(float t) { return ACT == CDE_ACT_TANH ? __builtin_fmaf(-t, t, 1.f) : 1.f; }
+
+constexpr int WV32_FLOATS = 8 * 16 * 64;          // one 32x32x2 image: 8 tiles x 16 K steps x 64 lanes
+constexpr int BY32_FLOATS = 8 * 2 * 16;           // bias image [tile][half][register]
+constexpr int SCRA_FLOATS = 2 * 64 * 20;          // per wave: z^T and one transposed g tile
+constexpr int ACT_ADJ_LDS_FLOATS = 2 * WV32_FLOATS + BY32_FLOATS + 4 * SCRA_FLOATS;
+
+__device__ __forceinline__ float wy32_image(const float* __restrict__ W, int T, int s, int l, Dims d) {
+  const int i = l & 31, hk = l >> 5;
+  const int h = 4 * T + (i >> 3), c = i & 7, k = 2 * s + hk;
+  return (h < d.H && c < d.C && k < d.H) ? W[(h * d.C + c) * d.H + k] : 0.f;
+}
+__device__ __forceinline__ float wv32_image(const float* __restrict__ W, int T, int r, int l, Dims d) {
+  const int k = rho(l & 31), hk = l >> 5;
+  const int h = 4 * T + (r >> 2), c = (r & 3) + 4 * hk;
+  return (h < d.H && c < d.C && k < d.H) ? W[(h * d.C + c) * d.H + k] : 0.f;
+}
+
+__device__ __forceinline__ void swap32(float& x, float& y) {      // x[lanes 32..63] <-> y[lanes 0..31]
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  x = __uint_as_float(r[0]);
+  y = __uint_as_float(r[1]);
+}
+
+template <typename TT, int DEGREE, int ACT>
+__global__ __launch_bounds__(256, 1) void rk4_adjoint_act_mfma(
+    const float* __restrict__ coeffs, const float* __restrict__ knots, int64_t n_intervals,
+    const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ z_saved,
+    const float* __restrict__ grad_out, const TT* __restrict__ sgrid, const int64_t* __restrict__ seg_off,
+    int64_t n_out, float* __restrict__ grad_z0, float* __restrict__ partial, int64_t B,
+    const int64_t* __restrict__ stage_index, const float* __restrict__ stage_frac, Dims dims) {
+  const int Hr = dims.H, Cr = dims.C;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* wyf = lds;
+  float* wvf = lds + WV32_FLOATS;
+  float* byf = lds + 2 * WV32_FLOATS;
+  for (int e = threadIdx.x; e < WV32_FLOATS; e += 256) {
+    const int j = e & 3, l = (e >> 2) & 63, g = e >> 8;             // g = 4T + (step >> 2)
+    wyf[e] = wy32_image(W, g >> 2, 4 * (g & 3) + j, l, dims);
+    wvf[e] = wv32_image(W, g >> 2, 4 * (g & 3) + j, l, dims);
+  }
+  for (int e = threadIdx.x; e < BY32_FLOATS; e += 256) {
+    const int r = e & 15, hf = (e >> 4) & 1, T = e >> 5;
+    const int h = 4 * T + (r >> 2), c = (r & 3) + 4 * hf;
+    byf[e] = (h < Hr && c < Cr) ? bias[h * Cr + c] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 31, half = lane >> 5;
+  const float4* wy = reinterpret_cast<const float4*>(wyf) + lane;
+  const float4* wv = reinterpret_cast<const float4*>(wvf) + lane;
+  const float4* by = reinterpret_cast<const float4*>(byf) + 4 * half;
+  float* scr_zt = lds + 2 * WV32_FLOATS + BY32_FLOATS + wave * SCRA_FLOATS;      // 64 rows x 20
+  float* scr_g = scr_zt + 64 * 20;                                               // 64 rows x 20
+
+  const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  float* my_partial = partial + tile * PARTIAL_FLOATS;
+  if (tile * 32 >= B) return;
+  const int64_t series = tile * 32 + n;
+  const bool valid = series < B;
+  const int64_t sc = valid ? series : B - 1;
+
+  f32x16 accW[8];
+  float gb[8];
+#pragma unroll
+  for (int T = 0; T < 8; ++T) {
+    gb[T] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accW[T][r] = 0.f;
+  }
+  f32x16 y0, a0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int u = 2 * r + half;
+    const bool on = u < Hr;
+    y0[r] = on ? z_saved[(sc * n_out + (n_out - 1)) * Hr + u] : 0.f;
+    a0[r] = (valid && on) ? grad_out[(sc * n_out + (n_out - 1)) * Hr + u] : 0.f;
+  }
+
+  for (int64_t p = 0; p + 1 < n_out; ++p) {
+    const int64_t i_out = n_out - 1 - p;
+    const int64_t k_begin = seg_off[p], k_end = seg_off[p + 1] - 1;
+    if (k_end > k_begin) {
+      int64_t idx = stage_index[4 * k_begin];
+      float frac = stage_frac[4 * k_begin];
+      Row<DEGREE> row = load_row<DEGREE>(coeffs, sc, n_intervals, idx, Cr);
+      for (int64_t k = k_begin; k < k_end; ++k) {
+        const float ds = (float)(sgrid[k + 1] - sgrid[k]);
+        f32x16 ky1, ky2, ka1, ka2, yst = y0, ast = a0;
+#pragma unroll
+        for (int stage = 0; stage < 4; ++stage) {
+          float dX[MC];
+          const float width = DEGREE == CDE_PATH_LINEAR ? knots[idx + 1] - knots[idx] : 1.f;
+          control_slope<DEGREE>(row, frac, width, dX);
+          const int64_t e_next = 4 * k + stage + 1;
+          const bool more = e_next < 4 * k_end;
+          const int64_t nidx = more ? stage_index[e_next] : idx;
+          const float nfrac = more ? stage_frac[e_next] : frac;
+          if (nidx != idx) row = load_row<DEGREE>(coeffs, sc, n_intervals, nidx, Cr);
+          // this half's 4 channels
+          const float dh[4] = {half ? dX[4] : dX[0], half ? dX[5] : dX[1], half ? dX[6] : dX[2], half ? dX[7] : dX[3]};
+          const float wq = ((stage == 0 || stage == 3) ? 0.125f : 0.375f) * ds;     // 3/8-rule quadrature weight
+
+          // z^T for the dL/dW products (same layout as K3): scr_zt[(par*32 + u)*20 + s] = z_u of series 2s+par
+          {
+            float* wz = scr_zt + ((n & 1) * 32 + half) * 20 + (n >> 1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wz[r * 40] = yst[r];
+            wave_lds_sync();
+          }
+          float zB[16];
+          {
+            const float4* zt4 = reinterpret_cast<const float4*>(scr_zt + (half * 32 + n) * 20);
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              const float4 v = zt4[g4];
+              zB[4 * g4] = v.x; zB[4 * g4 + 1] = v.y; zB[4 * g4 + 2] = v.z; zB[4 * g4 + 3] = v.w;
+            }
+          }
+
+          f32x16 f, va = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          int opaque = 0;
+          asm volatile("" : "+v"(opaque));          // keeps the image reads inside the stage (no hoisting)
+          const float4* wys = wy + opaque;
+          const float4* wvs = wv + opaque;
+          const float4* bys = by + opaque;
+#pragma unroll
+          for (int T = 0; T < 8; ++T) {
+            // ---- Y tile
+            f32x16 y;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              const float4 b4 = bys[T * 8 + g4];
+              y[4 * g4] = b4.x; y[4 * g4 + 1] = b4.y; y[4 * g4 + 2] = b4.z; y[4 * g4 + 3] = b4.w;
+            }
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              const float4 a4 = wys[(4 * T + g4) * 64];
+              y = mfma(a4.x, yst[4 * g4], y);
+              y = mfma(a4.y, yst[4 * g4 + 1], y);
+              y = mfma(a4.z, yst[4 * g4 + 2], y);
+              y = mfma(a4.w, yst[4 * g4 + 3], y);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- activation, contraction with dX, dL/dY
+            // adjoint state of units 4T..4T+3 in every lane: swap32 of two copies broadcasts both halves' values
+            float ae0 = ast[2 * T], ao0 = ast[2 * T], ae1 = ast[2 * T + 1], ao1 = ast[2 * T + 1];
+            swap32(ae0, ao0);
+            swap32(ae1, ao1);
+            const float a4u[4] = {ae0, ao0, ae1, ao1};
+            float ps[4], g[16];
+#pragma unroll
+            for (int hl = 0; hl < 4; ++hl) {
+              float acc = 0.f;
+#pragma unroll
+              for (int cl = 0; cl < 4; ++cl) {
+                const float t = activate<ACT>(y[4 * hl + cl]);
+                acc = cl == 0 ? t * dh[0] : __builtin_fmaf(t, dh[cl], acc);
+                g[4 * hl + cl] = a4u[hl] * (dh[cl] * activate_slope<ACT>(t));
+              }
+              ps[hl] = acc;
+            }
+            swap32(ps[0], ps[1]);
+            swap32(ps[2], ps[3]);
+            f[2 * T] = ps[0] + ps[1];
+            f[2 * T + 1] = ps[2] + ps[3];
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- va += W_T^T g
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              const float4 a4 = wvs[(4 * T + g4) * 64];
+              va = mfma(a4.x, g[4 * g4], va);
+              va = mfma(a4.y, g[4 * g4 + 1], va);
+              va = mfma(a4.z, g[4 * g4 + 2], va);
+              va = mfma(a4.w, g[4 * g4 + 3], va);
+            }
+            // ---- dW_T += (wq g)^T z through the transposed scratch tile
+            {
+              float* wg = scr_g + ((n & 1) * 32 + 4 * half) * 20 + (n >> 1);     // + row(r) * 20, row = (r&3) + 8*(r>>2)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) wg[((r & 3) + 8 * (r >> 2)) * 20] = g[r] * wq;
+              wave_lds_sync();
+              const float4* g4p = reinterpret_cast<const float4*>(scr_g + (half * 32 + n) * 20);
+              float gA[16];
+#pragma unroll
+              for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 v = g4p[g4];
+                gA[4 * g4] = v.x; gA[4 * g4 + 1] = v.y; gA[4 * g4 + 2] = v.z; gA[4 * g4 + 3] = v.w;
+              }
+              wave_lds_sync();                       // reads retired before the next tile overwrites the scratch
+              float rs = 0.f;
+#pragma unroll
+              for (int s2 = 0; s2 < 16; ++s2) {
+                accW[T] = mfma(gA[s2], zB[s2], accW[T]);
+                rs += gA[s2];
+              }
+              gb[T] += rs;
+            }
+            __builtin_amdgcn_sched_barrier(0);       // one tile at a time: bounds the live registers
+          }
+
+          const f32x16 ky = -f, ka = va;
+          const float third = (float)(1.0 / 3.0);
+          if (stage == 0) {
+            ky1 = ky; ka1 = ka;
+            yst = y0 + ds * ky1 * third;
+            ast = a0 + ds * ka1 * third;
+          } else if (stage == 1) {
+            ky2 = ky; ka2 = ka;
+            yst = y0 + ds * (ky2 - ky1 * third);
+            ast = a0 + ds * (ka2 - ka1 * third);
+          } else if (stage == 2) {
+            yst = y0 + ds * (ky1 - ky2 + ky);
+            ast = a0 + ds * (ka1 - ka2 + ka);
+            ky1 = ky1 + 3.f * (ky2 + ky);
+            ka1 = ka1 + 3.f * (ka2 + ka);
+          } else {
+            yst = y0 + (ky1 + ky) * ds * 0.125f;
+            ast = a0 + (ka1 + ka) * ds * 0.125f;
+          }
+          idx = nidx; frac = nfrac;
+        }
+        y0 = yst; a0 = ast;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int u = 2 * r + half;
+      if (u < Hr) {
+        y0[r] = z_saved[(sc * n_out + (i_out - 1)) * Hr + u];
+        if (valid) a0[r] += grad_out[(sc * n_out + (i_out - 1)) * Hr + u];
+      }
+    }
+  }
+  if (valid) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) if (2 * r + half < Hr) grad_z0[series * Hr + 2 * r + half] = a0[r];
+  }
+  // per-wave partials in the K3 layout: tile T register r of lane (n, half) is dW[h = 4T + (r>>2)][c = (r&3) + 4 half][k = n]
+#pragma unroll
+  for (int T = 0; T < 8; ++T) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int h = 4 * T + (r >> 2), c = (r & 3) + 4 * half;
+      my_partial[(h * MC + c) * MH + n] = accW[T][r];
+    }
+    // row sums: lane (i = n, half) summed row i = (h = 4T + (n>>3), c = n&7) over the series of its parity
+    const float other = __shfl_xor(gb[T], 32, 64);
+    if (half == 0) my_partial[MH * MC * MH + 32 * T + n] = gb[T] + other;
+  }
+}
+
 // sum per-wave partials in tile order (deterministic)
 __global__ __launch_bounds__(256) void reduce_mfma_partials(const float* __restrict__ partial, int64_t n_tiles,
                                                             float* __restrict__ grad_W, float* __restrict__ grad_b,
@@ -402,54 +679,60 @@ __global__ __launch_bounds__(256) void reduce_mfma_partials(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------ host side
-bool mfma_applicable(int64_t C, int64_t H, int dtype, int act) {
-  return dtype == CDE_F32 && H >= 1 && H <= MH && C >= 1 && C <= MC && act == CDE_ACT_NONE;
+bool mfma_applicable(int64_t C, int64_t H, int dtype, int act, bool adjoint) {
+  (void)adjoint;
+  const bool act_ok = act == CDE_ACT_NONE || act == CDE_ACT_TANH;
+  return dtype == CDE_F32 && H >= 1 && H <= MH && C >= 1 && C <= MC && act_ok;
 }
 
 size_t mfma_adjoint_partial_bytes(int64_t B) { return (size_t)((B + 31) / 32) * PARTIAL_FLOATS * sizeof(float); }
 
 template <typename TT>
 int launch_forward_mfma(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
-                        const void* bias, const void* z0, const void* grid, int64_t n_grid, const void* t_out,
+                        const void* bias, int act, const void* z0, const void* grid, int64_t n_grid, const void* t_out,
                         int64_t n_out, void* z_out, int64_t B, int64_t C, int64_t H, const int64_t* stage_index,
                         const void* stage_frac, hipStream_t s) {
   const Dims dims{(int)H, (int)C};
   const unsigned blocks = (unsigned)((B + 127) / 128);     // 8 waves x 16 series, one workgroup per CU at B = 32768
-  const size_t lds = W16_FLOATS * sizeof(float);
-#define CDE_FWD(D)                                                                                                  \
-  rk4_forward_mfma<TT, D><<<blocks, 512, lds, s>>>((const float*)coeffs, (const float*)knots, n_intervals,          \
-                                                   (const float*)W, (const float*)bias, (const float*)z0,           \
-                                                   (const TT*)grid, n_grid, (const TT*)t_out, n_out, (float*)z_out, \
-                                                   B, stage_index, (const float*)stage_frac, dims)
-  if (degree == CDE_PATH_CUBIC) CDE_FWD(CDE_PATH_CUBIC);
-  else if (degree == CDE_PATH_LINEAR) CDE_FWD(CDE_PATH_LINEAR);
-  else return CDE_ERR_UNSUPPORTED;
+#define CDE_FWD(D, A)                                                                                               \
+  rk4_forward_mfma<TT, D, A><<<blocks, 512, (A == CDE_ACT_NONE ? W16_FLOATS : ACT16_LDS_FLOATS) * sizeof(float), s>>>( \
+      (const float*)coeffs, (const float*)knots, n_intervals, (const float*)W, (const float*)bias, (const float*)z0, \
+      (const TT*)grid, n_grid, (const TT*)t_out, n_out, (float*)z_out, B, stage_index, (const float*)stage_frac, dims)
+  if (degree != CDE_PATH_CUBIC && degree != CDE_PATH_LINEAR) return CDE_ERR_UNSUPPORTED;
+  if (act == CDE_ACT_NONE) {
+    if (degree == CDE_PATH_CUBIC) CDE_FWD(CDE_PATH_CUBIC, CDE_ACT_NONE); else CDE_FWD(CDE_PATH_LINEAR, CDE_ACT_NONE);
+  } else if (act == CDE_ACT_TANH) {
+    if (degree == CDE_PATH_CUBIC) CDE_FWD(CDE_PATH_CUBIC, CDE_ACT_TANH); else CDE_FWD(CDE_PATH_LINEAR, CDE_ACT_TANH);
+  } else return CDE_ERR_UNSUPPORTED;
 #undef CDE_FWD
   return check_launch();
 }
 
 template <typename TT>
 int launch_adjoint_mfma(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
-                        const void* bias, const void* z_saved, const void* grad_out, const void* sgrid,
+                        const void* bias, int act, const void* z_saved, const void* grad_out, const void* sgrid,
                         const int64_t* seg_off, int64_t n_out, void* grad_z0, void* grad_W, void* grad_b, int64_t B,
                         int64_t C, int64_t H, const int64_t* stage_index, const void* stage_frac, float* partial,
                         hipStream_t s) {
   const Dims dims{(int)H, (int)C};
   const unsigned blocks = (unsigned)((B + 127) / 128);
-  const size_t lds = (size_t)(W1_FLOATS + W2_FLOATS + 4 * SCR_FLOATS) * sizeof(float);
-#define CDE_ADJ(D)                                                                                                   \
+  if (degree != CDE_PATH_CUBIC && degree != CDE_PATH_LINEAR) return CDE_ERR_UNSUPPORTED;
+#define CDE_ADJ(KERNEL, LDS_FLOATS)                                                                                  \
   do {                                                                                                               \
-    (void)hipFuncSetAttribute((const void*)rk4_adjoint_mfma<TT, D>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
-                              (int)lds);                                                                             \
-    rk4_adjoint_mfma<TT, D><<<blocks, 256, lds, s>>>((const float*)coeffs, (const float*)knots, n_intervals,         \
-                                                     (const float*)W, (const float*)bias, (const float*)z_saved,     \
-                                                     (const float*)grad_out, (const TT*)sgrid, seg_off, n_out,       \
-                                                     (float*)grad_z0, partial, B, stage_index,                       \
-                                                     (const float*)stage_frac, dims);                                \
+    const size_t lds = (size_t)(LDS_FLOATS) * sizeof(float);                                                         \
+    (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
+    KERNEL<<<blocks, 256, lds, s>>>((const float*)coeffs, (const float*)knots, n_intervals, (const float*)W,         \
+                                    (const float*)bias, (const float*)z_saved, (const float*)grad_out,               \
+                                    (const TT*)sgrid, seg_off, n_out, (float*)grad_z0, partial, B, stage_index,      \
+                                    (const float*)stage_frac, dims);                                                 \
   } while (0)
-  if (degree == CDE_PATH_CUBIC) CDE_ADJ(CDE_PATH_CUBIC);
-  else if (degree == CDE_PATH_LINEAR) CDE_ADJ(CDE_PATH_LINEAR);
-  else return CDE_ERR_UNSUPPORTED;
+  if (act == CDE_ACT_NONE) {
+    if (degree == CDE_PATH_CUBIC) CDE_ADJ((rk4_adjoint_mfma<TT, CDE_PATH_CUBIC>), W1_FLOATS + W2_FLOATS + 4 * SCR_FLOATS);
+    else CDE_ADJ((rk4_adjoint_mfma<TT, CDE_PATH_LINEAR>), W1_FLOATS + W2_FLOATS + 4 * SCR_FLOATS);
+  } else if (act == CDE_ACT_TANH) {
+    if (degree == CDE_PATH_CUBIC) CDE_ADJ((rk4_adjoint_act_mfma<TT, CDE_PATH_CUBIC, CDE_ACT_TANH>), ACT_ADJ_LDS_FLOATS);
+    else CDE_ADJ((rk4_adjoint_act_mfma<TT, CDE_PATH_LINEAR, CDE_ACT_TANH>), ACT_ADJ_LDS_FLOATS);
+  } else return CDE_ERR_UNSUPPORTED;
 #undef CDE_ADJ
   int rc = check_launch();
   if (rc != CDE_OK) return rc;
@@ -458,17 +741,19 @@ int launch_adjoint_mfma(const void* coeffs, const void* knots, int64_t n_interva
   return check_launch();
 }
 
-template int launch_forward_mfma<float>(const void*, const void*, int64_t, int, const void*, const void*, const void*,
-                                        const void*, int64_t, const void*, int64_t, void*, int64_t, int64_t, int64_t,
-                                        const int64_t*, const void*, hipStream_t);
-template int launch_forward_mfma<double>(const void*, const void*, int64_t, int, const void*, const void*, const void*,
-                                         const void*, int64_t, const void*, int64_t, void*, int64_t, int64_t, int64_t,
-                                         const int64_t*, const void*, hipStream_t);
-template int launch_adjoint_mfma<float>(const void*, const void*, int64_t, int, const void*, const void*, const void*,
-                                        const void*, const void*, const int64_t*, int64_t, void*, void*, void*, int64_t,
-                                        int64_t, int64_t, const int64_t*, const void*, float*, hipStream_t);
-template int launch_adjoint_mfma<double>(const void*, const void*, int64_t, int, const void*, const void*, const void*,
-                                         const void*, const void*, const int64_t*, int64_t, void*, void*, void*,
-                                         int64_t, int64_t, int64_t, const int64_t*, const void*, float*, hipStream_t);
+template int launch_forward_mfma<float>(const void*, const void*, int64_t, int, const void*, const void*, int,
+                                        const void*, const void*, int64_t, const void*, int64_t, void*, int64_t, int64_t,
+                                        int64_t, const int64_t*, const void*, hipStream_t);
+template int launch_forward_mfma<double>(const void*, const void*, int64_t, int, const void*, const void*, int,
+                                         const void*, const void*, int64_t, const void*, int64_t, void*, int64_t,
+                                         int64_t, int64_t, const int64_t*, const void*, hipStream_t);
+template int launch_adjoint_mfma<float>(const void*, const void*, int64_t, int, const void*, const void*, int,
+                                        const void*, const void*, const void*, const int64_t*, int64_t, void*, void*,
+                                        void*, int64_t, int64_t, int64_t, const int64_t*, const void*, float*,
+                                        hipStream_t);
+template int launch_adjoint_mfma<double>(const void*, const void*, int64_t, int, const void*, const void*, int,
+                                         const void*, const void*, const void*, const int64_t*, int64_t, void*, void*,
+                                         void*, int64_t, int64_t, int64_t, const int64_t*, const void*, float*,
+                                         hipStream_t);
 
 }  // namespace cde
