@@ -134,6 +134,22 @@ int cde_rk4_forward_linear(const void* coeffs, const void* knots, int64_t n_inte
                            int time_dtype, int variant, int64_t* stage_index, void* stage_frac, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * K2m  K2 for the two-layer vector field of the reference's examples
+ *        f(z) = reshape_{HxC}( act( W2 relu(W1 z + b1) + b2 ) )
+ * (example/time_series_classification.py:20-51: Linear(H,128) -> relu -> Linear(128,H*C) -> tanh);
+ * replaces the same reference code as K2 plus the user module's two nn.Linear calls per stage.
+ *   W1 (width, H), bias1 (width), W2 (H*C, width), bias2 (H*C);  act applies after the second layer.
+ * f32 only, H <= 32, C <= 8, width <= 128 (MFMA tiles, zero padded); otherwise CDE_ERR_UNSUPPORTED.
+ * Forward solves only: gradients of this family take the step-wise path of the Python layer.
+ * All other arguments as cde_rk4_forward_linear.
+ * ------------------------------------------------------------------------------------------- */
+int cde_rk4_forward_mlp(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W1,
+                        const void* bias1, int64_t width, const void* W2, const void* bias2, int act, const void* z0,
+                        const void* grid, int64_t n_grid, const void* t_out, int64_t n_out, void* z_out, int64_t B,
+                        int64_t C, int64_t H, int dtype, int time_dtype, int64_t* stage_index, void* stage_frac,
+                        void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K3  Fused continuous-adjoint reverse sweep for K2.
  * Replaces torchdiffeq.odeint_adjoint's backward (behind solver.py:226): for every output
  * interval, RK4 (3/8) integration in reversed time of the augmented state (z, a_z, a_W, a_b),

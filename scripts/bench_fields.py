@@ -1,6 +1,8 @@
-"""Timing of the Linear -> tanh vector field on the full-size workload (B=32768, L=128, C=8, H=32), rk4.
+"""Timing of the non-linear vector fields on the full-size workload (B=32768, L=128, C=8, H=32), rk4:
+Linear -> tanh (example/irregular_data.py) and Linear -> relu -> Linear -> tanh, width 128
+(example/time_series_classification.py).  variant "generic" = VALU kernel (tanh field) / step-wise path (mlp).
 
-    python scripts/bench_tanh.py [--adjoint] [--variants mfma,generic]
+    python scripts/bench_fields.py [--field tanh|mlp] [--adjoint] [--variants mfma,generic]
 """
 import argparse
 import os
@@ -17,6 +19,7 @@ from helpers import LinearField, make_series  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--field", default="tanh", choices=["tanh", "mlp"])
     ap.add_argument("--adjoint", action="store_true")
     ap.add_argument("--variants", default="mfma,generic")
     ap.add_argument("--batch", type=int, default=32768)
@@ -27,7 +30,18 @@ def main():
     x = make_series(B, L, C).to(dev)
     coeffs = native.hermite_cubic_coefficients_with_backward_differences(x)
     X = native.CubicSpline(coeffs)
-    func = LinearField(H, C, scale=1.0, tanh=True, seed=0).to(dev)
+    if args.field == "tanh":
+        func = LinearField(H, C, scale=1.0, tanh=True, seed=0).to(dev)
+    else:
+        class TwoLayer(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.linear1, self.linear2 = torch.nn.Linear(H, 128), torch.nn.Linear(128, H * C)
+
+            def forward(self, t, z):
+                return self.linear2(self.linear1(z).relu()).tanh().view(*z.shape[:-1], H, C)
+        torch.manual_seed(0)
+        func = TwoLayer().to(dev)
     z0 = torch.randn(B, H, device=dev)
     for variant in args.variants.split(","):
         def step():
@@ -38,6 +52,8 @@ def main():
             else:
                 with torch.no_grad():
                     native.cdeint(X, func, z0, X.interval, method="rk4", options=dict(step_size=1.0), variant=variant)
+        if args.field == "mlp" and variant == "mfma":
+            variant = "auto"
         reps = args.reps if variant != "generic" else 1
         step()
         torch.cuda.synchronize()
@@ -46,7 +62,7 @@ def main():
             step()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / reps * 1e3
-        print(f"tanh field {'fwd+adjoint' if args.adjoint else 'forward'} variant={variant}: {ms:.2f} ms "
+        print(f"{args.field} field {'fwd+adjoint' if args.adjoint else 'forward'} variant={variant}: {ms:.2f} ms "
               f"({B / ms * 1e3 / 1e6:.2f} M series/s)", flush=True)
 
 

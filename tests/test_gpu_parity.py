@@ -249,6 +249,57 @@ def test_tanh_field_forward_on_mfma_tiles(native, H, C, degree):
     _close(res["mfma"], res["generic"], 1e-4, 5e-6)
 
 
+class _TwoLayerField(torch.nn.Module):
+    """reference example/time_series_classification.py:20-51"""
+
+    def __init__(self, H, C, width, dtype=torch.float32, seed=0, final_tanh=True):
+        super().__init__()
+        self.H, self.C, self.final_tanh = H, C, final_tanh
+        gen = torch.Generator().manual_seed(seed)
+        self.linear1 = torch.nn.Linear(H, width).to(dtype)
+        self.linear2 = torch.nn.Linear(width, H * C).to(dtype)
+        with torch.no_grad():
+            for lin in (self.linear1, self.linear2):
+                bound = 1 / lin.in_features ** 0.5
+                lin.weight.copy_((torch.rand(lin.weight.shape, generator=gen, dtype=torch.float64) * 2 - 1) * bound)
+                lin.bias.copy_((torch.rand(lin.bias.shape, generator=gen, dtype=torch.float64) * 2 - 1) * bound)
+
+    def forward(self, t, z):
+        y = self.linear2(self.linear1(z).relu())
+        if self.final_tanh:
+            y = y.tanh()
+        return y.view(*z.shape[:-1], self.H, self.C)
+
+
+@pytest.mark.parametrize("H,C,width,degree,final_tanh", [(32, 8, 128, 3, True), (16, 4, 64, 1, True), (8, 3, 100, 3, False)])
+def test_two_layer_field_forward_fused(native, H, C, width, degree, final_tanh):
+    """Linear -> relu -> Linear -> tanh fields: the fused forward kernel (K2m) vs the float64 oracle and vs the
+    step-wise path running the user module itself."""
+    from torchcde_amd import fields
+    B, L = 203, 24
+    x = make_series(B, L, C, torch.float32, seed=61)
+    coeffs = oracle_interp.hermite_bdiff_coeffs(x) if degree == 3 else x
+    func = _TwoLayerField(H, C, width, seed=3, final_tanh=final_tanh)
+    f64 = _TwoLayerField(H, C, width, torch.float64, seed=3, final_tanh=final_tanh)
+    z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(62))
+    t_out = torch.tensor([0., 7.5, 23.])
+    path64 = (oracle_interp.CubicPath if degree == 3 else oracle_interp.LinearPath)(coeffs.double())
+    with torch.no_grad():
+        ref = oracle_cde.cdeint(path64, f64, z0.double(), t_out.double(), adjoint=False, method="rk4",
+                                options=dict(step_size=1.0))
+    dfunc = _TwoLayerField(H, C, width, seed=3, final_tanh=final_tanh).to(DEV)
+    X = (native.CubicSpline if degree == 3 else native.LinearInterpolation)(coeffs.to(DEV))
+    found, _ = fields.probe(dfunc, t_out[0].to(DEV), z0.to(DEV))
+    assert found is not None and found.kind == "mlp2"
+    with torch.no_grad():
+        fused = native.cdeint(X, dfunc, z0.to(DEV), t_out.to(DEV), method="rk4", options=dict(step_size=1.0))
+        stepwise = native.cdeint(X, dfunc, z0.to(DEV), t_out.to(DEV), method="rk4", options=dict(step_size=1.0),
+                                 variant="generic")
+    _close(fused, ref, 1e-4, 5e-6)
+    _close(fused, stepwise, 1e-4, 5e-6)
+    assert not torch.equal(fused, stepwise)          # two different code paths did run
+
+
 @pytest.mark.parametrize("act", [False, True])
 @pytest.mark.parametrize("H,C", [(16, 4), (32, 3), (5, 2), (24, 8)])
 def test_mfma_kernels_on_zero_padded_shapes(native, H, C, act):

@@ -108,7 +108,7 @@ def test_option_parsing():
 
 
 # ------------------------------------------------------------------ vector-field recognition
-def test_probe_accepts_exactly_the_affine_family():
+def test_probe_accepts_exactly_the_fused_families():
     z, t = torch.randn(4, 3), torch.tensor(0.25)
 
     class Readme(torch.nn.Module):                       # reference README.md:42-49
@@ -145,7 +145,28 @@ def test_probe_accepts_exactly_the_affine_family():
     assert field is not None and field.act == _lib.ACT_TANH
     field, _ = probe(torchcde_amd.LinearCDEFunc(2, 3, tanh=True), t, z)
     assert field is not None and field.act == _lib.ACT_TANH
-    for bad in (TimeDependent(), Scaled(), TwoLayer()):
+    field, system = probe(TwoLayer(), t, z)
+    assert field is not None and field.kind == "mlp2" and field.act == _lib.ACT_TANH and system.shape == (4, 3, 2)
+    assert field.hidden.out_features == 5 and field.output.out_features == 6
+
+    class TwoLayerTanhInside(TwoLayer):                  # another hidden activation: not the fused formula
+        def forward(self, t, z):
+            return self.l2(self.l1(z).tanh()).tanh().view(4, 3, 2)
+
+    class TwoLayerSkip(TwoLayer):
+        def forward(self, t, z):
+            return (self.l2(self.l1(z).relu()) + z.repeat(1, 2)).tanh().view(4, 3, 2)
+
+    class SharedLayer(torch.nn.Module):                  # one Linear applied twice
+        def __init__(self):
+            super().__init__()
+            self.l = torch.nn.Linear(3, 3)
+            self.out = torch.nn.Linear(3, 6)
+
+        def forward(self, t, z):
+            return self.out(self.l(self.l(z).relu()).relu()).view(4, 3, 2)
+
+    for bad in (TimeDependent(), Scaled(), TwoLayerTanhInside(), TwoLayerSkip(), SharedLayer()):
         field, system = probe(bad, t, z)
         assert field is None and system.shape == (4, 3, 2)
 

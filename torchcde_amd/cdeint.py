@@ -207,6 +207,42 @@ class _Plan:
         return grad_z0, grad_w, grad_b
 
 
+class _MlpPlan:
+    """Forward-only fused RK4 solve for the two-layer field (K2m, cde_rk4_forward_mlp)."""
+
+    def __init__(self, path, field, batch, H, C, t, step_size):
+        coeffs, knots, _ = path._native_inputs()
+        self.coeffs, self.knots = coeffs, knots
+        self.n_intervals, self.degree = path._n_intervals(), path._degree
+        self.field, self.batch, self.B, self.H, self.C = field, batch, coeffs.size(0), H, C
+        self.device = coeffs.device
+        self.grids = _grids_for(_to_host(t), step_size, step_size, self.device)
+
+    def run(self, z0):
+        lib = _lib.load()
+        g, f = self.grids, self.field
+        out = torch.empty(self.B, g.n_out, self.H, dtype=torch.float32, device=self.device)
+        n_stage = 4 * max(g.grid.numel() - 1, 0)
+        stage_index = torch.empty(max(n_stage, 1), dtype=torch.int64, device=self.device)
+        stage_frac = torch.empty(max(n_stage, 1), dtype=torch.float32, device=self.device)
+        z0c = z0.detach().reshape(self.B, self.H).contiguous()
+        w1, b1 = f.hidden.weight.detach().contiguous(), f.hidden.bias.detach().contiguous()
+        w2, b2 = f.output.weight.detach().contiguous(), f.output.bias.detach().contiguous()
+        _lib.check(lib.cde_rk4_forward_mlp(
+            _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w1), _lib.ptr(b1),
+            w1.size(0), _lib.ptr(w2), _lib.ptr(b2), f.act, _lib.ptr(z0c), _lib.ptr(g.grid), g.grid.numel(),
+            _lib.ptr(g.t_out), g.n_out, _lib.ptr(out), self.B, self.C, self.H, _lib.dtype_enum(torch.float32),
+            _lib.dtype_enum(g.time_dtype), _lib.ptr(stage_index), _lib.ptr(stage_frac), _lib.stream_ptr(self.device)),
+            "cde_rk4_forward_mlp")
+        return out.reshape(*self.batch, g.n_out, self.H)
+
+
+def _mlp_fusable(field, H, C, z0, packed):
+    w1, w2 = field.hidden.weight, field.output.weight
+    return (z0.dtype == packed.dtype == w1.dtype == w2.dtype == torch.float32 and H <= 32 and C <= 8
+            and w1.size(0) <= 128 and tuple(w1.shape) == (w1.size(0), H) and tuple(w2.shape) == (H * C, w1.size(0)))
+
+
 class _FusedRK4(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z0, weight, bias, plan, wants):
@@ -380,6 +416,9 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
     if not isinstance(system, torch.Tensor):
         raise ValueError("z0 is a tensor and so func must return a tensor as well.")
     _shape_errors(batch + (C,), tuple(system.shape), z0)
+    mlp = None
+    if field is not None and field.kind == "mlp2":
+        mlp, field = (field if _mlp_fusable(field, H, C, z0, packed) else None), None
     if field is not None:
         weight, bias = field.weight, field.bias
         if tuple(weight.shape) != (H * C, H) or not (z0.dtype == packed.dtype == weight.dtype):
@@ -389,6 +428,10 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         for buffer in X.buffers():
             if buffer.requires_grad:
                 warnings.warn(_GRAD_WARNING)
+    if not adjoint and torch.is_grad_enabled() and any(b.requires_grad for b in X.buffers()):
+        # backpropagating through the solver would have to differentiate the control evaluation itself
+        raise NotImplementedError("torchcde_amd: gradients with respect to the control path are not implemented on "
+                                  "the native path yet (SURVEY section 8(f), rank 3). Detach the coefficients.")
 
     # solver configuration (what the reference forwards verbatim to torchdiffeq, solver.py:175-176,227)
     method = kwargs.pop("method", None)
@@ -399,6 +442,13 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         p.requires_grad for p in (func.parameters() if isinstance(func, torch.nn.Module) else ())))
     fused = (field is not None and ((method == "rk4" and (adjoint or not wants_grad))
                                     or (method == "dopri5" and not wants_grad)))
+    if (mlp is not None and method == "rk4" and not wants_grad and variant != _lib.VARIANT_GENERIC
+            and set(options or ()) <= {"step_size"}
+            and isinstance(t, torch.Tensor) and t.dim() == 1 and t.is_floating_point() and t.numel() >= 1):
+        # two-layer field, nothing to differentiate: the fused forward kernel (K2m)
+        t_host = _to_host(t)
+        if t_host.numel() == 1 or bool((t_host[1:] > t_host[:-1]).all()):
+            return _MlpPlan(X, mlp, batch, H, C, t, _parse_fixed_options(options, "solver")).run(z0)
     if not fused:
         # Arbitrary vector fields / methods / differentiation modes: host-driven stepping with the native control
         # derivative and contraction kernels under every evaluation (torchcde_amd/stepwise.py).

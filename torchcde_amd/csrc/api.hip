@@ -21,6 +21,10 @@ int launch_forward_mfma(const void*, const void*, int64_t, int, const void*, con
                         const void*, int64_t, const void*, int64_t, void*, int64_t, int64_t, int64_t, const int64_t*,
                         const void*, hipStream_t);
 template <typename TT>
+int launch_forward_mlp(const void*, const void*, int64_t, int, const void*, const void*, int64_t, const void*,
+                       const void*, int, const void*, const void*, int64_t, const void*, int64_t, void*, int64_t,
+                       int64_t, int64_t, const int64_t*, const void*, hipStream_t);
+template <typename TT>
 int launch_adjoint_mfma(const void*, const void*, int64_t, int, const void*, const void*, int, const void*,
                         const void*, const void*, const int64_t*, int64_t, void*, void*, void*, int64_t, int64_t,
                         int64_t, const int64_t*, const void*, float*, hipStream_t);
@@ -129,6 +133,33 @@ extern "C" int cde_rk4_forward_linear(const void* coeffs, const void* knots, int
   if (dtype == CDE_F64 && time_dtype == CDE_F64) CDE_CALL(double, double);
   if (dtype == CDE_F64 && time_dtype == CDE_F32) CDE_CALL(double, float);
 #undef CDE_CALL
+  return CDE_ERR_DTYPE;
+}
+
+extern "C" int cde_rk4_forward_mlp(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
+                                   const void* W1, const void* bias1, int64_t width, const void* W2, const void* bias2,
+                                   int act, const void* z0, const void* grid, int64_t n_grid, const void* t_out,
+                                   int64_t n_out, void* z_out, int64_t B, int64_t C, int64_t H, int dtype,
+                                   int time_dtype, int64_t* stage_index, void* stage_frac, void* stream) {
+  if (B < 0 || C < 1 || H < 1 || width < 1 || n_intervals < 1 || n_grid < 1 || n_out < 1) return CDE_ERR_SHAPE;
+  if (dtype != CDE_F32) return dtype == CDE_F64 ? CDE_ERR_UNSUPPORTED : CDE_ERR_DTYPE;
+  if (B == 0) return CDE_OK;
+  if (!coeffs || !knots || !W1 || !bias1 || !W2 || !bias2 || !z0 || !grid || !t_out || !z_out) return CDE_ERR_NULL;
+  if (n_grid > 1 && (!stage_index || !stage_frac)) return CDE_ERR_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if (time_dtype == CDE_F32) {
+    rc = cde::fill_stage_table<float, float>(knots, n_intervals, grid, n_grid - 1, 0, stage_index, stage_frac, s);
+    if (rc != CDE_OK) return rc;
+    return cde::launch_forward_mlp<float>(coeffs, knots, n_intervals, degree, W1, bias1, width, W2, bias2, act, z0, grid,
+                                          n_grid, t_out, n_out, z_out, B, C, H, stage_index, stage_frac, s);
+  }
+  if (time_dtype == CDE_F64) {
+    rc = cde::fill_stage_table<float, double>(knots, n_intervals, grid, n_grid - 1, 0, stage_index, stage_frac, s);
+    if (rc != CDE_OK) return rc;
+    return cde::launch_forward_mlp<double>(coeffs, knots, n_intervals, degree, W1, bias1, width, W2, bias2, act, z0, grid,
+                                           n_grid, t_out, n_out, z_out, B, C, H, stage_index, stage_frac, s);
+  }
   return CDE_ERR_DTYPE;
 }
 

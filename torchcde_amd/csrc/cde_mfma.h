@@ -315,4 +315,93 @@ __device__ __forceinline__ void field_act16(const float4* wy, const float4* by, 
   }
 }
 
+// ============================================================================ two-layer fields
+// f(z) = reshape_{HxC}(act(W2 relu(W1 z + b1) + b2)) dX   (reference example/time_series_classification.py:20-51:
+// Linear(H, width) -> relu -> Linear(width, H*C) -> tanh, width = 128).  Same tiling as field_act16 with a hidden
+// layer in front: layer 1 is 8 tiles (width padded to 128) x 8 K steps whose C/D fragment -- lane (n, q) holds
+// hidden-layer units 16*T1 + 4q + r -- is exactly the B operand of layer 2's K step (T1, r), so the hidden layer
+// never leaves the registers.  64 + 512 MFMAs per evaluation; both weight images live in LDS (16 + 128 KB).
+constexpr int MW = 128;                              // hidden-layer width the tiles are built for
+constexpr int W1M_FLOATS = 8 * 2 * 64 * 4;           // layer 1: 8 tiles x 2 groups of 4 K steps
+constexpr int B1M_FLOATS = 8 * 4 * 4;                // [tile][q][r]
+constexpr int W2M_FLOATS = 16 * 8 * 64 * 4;          // layer 2: 16 tiles x 8 groups of 4 K steps
+constexpr int MLP16_LDS_FLOATS = W1M_FLOATS + B1M_FLOATS + W2M_FLOATS + BY_FLOATS;
+struct MlpDims { int H, C, width; };
+
+__device__ __forceinline__ void stage_mlp16(const float* __restrict__ W1, const float* __restrict__ b1,
+                                            const float* __restrict__ W2, const float* __restrict__ b2, float* lds,
+                                            MlpDims d) {
+  float* w1 = lds;
+  float* bb1 = lds + W1M_FLOATS;
+  float* w2 = bb1 + B1M_FLOATS;
+  float* bb2 = w2 + W2M_FLOATS;
+  for (int e = threadIdx.x; e < W1M_FLOATS; e += blockDim.x) {
+    const int j = e & 3, l = (e >> 2) & 63, g = e >> 8;              // g = 2*T1 + (s>>2)
+    const int row = 16 * (g >> 1) + (l & 15), k = 4 * (4 * (g & 1) + j) + (l >> 4);
+    w1[e] = (row < d.width && k < d.H) ? W1[row * d.H + k] : 0.f;
+  }
+  for (int e = threadIdx.x; e < B1M_FLOATS; e += blockDim.x) {
+    const int unit = 16 * (e >> 4) + 4 * ((e >> 2) & 3) + (e & 3);
+    bb1[e] = unit < d.width ? b1[unit] : 0.f;
+  }
+  for (int e = threadIdx.x; e < W2M_FLOATS; e += blockDim.x) {
+    const int j = e & 3, l = (e >> 2) & 63, g = e >> 8;              // g = 8*T2 + T1, K step (T1, r = j)
+    const int T2 = g >> 3, T1 = g & 7, i = l & 15, kq = l >> 4;
+    const int h = 4 * (T2 >> 1) + (i >> 2), c = 4 * (T2 & 1) + (i & 3), col = 16 * T1 + 4 * kq + j;
+    w2[e] = (h < d.H && c < d.C && col < d.width) ? W2[(h * d.C + c) * d.width + col] : 0.f;
+  }
+  for (int e = threadIdx.x; e < BY_FLOATS; e += blockDim.x) bb2[e] = by16_image(b2, e >> 4, (e >> 2) & 3, e & 3, Dims{d.H, d.C});
+  __syncthreads();
+}
+
+// img = staged images + nothing else; lane (n, q): za/zb = units q, 4+q, .., 28+q of series n
+template <int ACT>
+__device__ __forceinline__ void field_mlp16(const float* img, int lane, int q, const f32x4& za, const f32x4& zb,
+                                            const float (&dX)[MC], f32x4& fa, f32x4& fb) {
+  int opaque = 0;                             // as in field_act16: keeps the LDS reads inside the call
+  asm volatile("" : "+v"(opaque));
+  const float4* w1 = reinterpret_cast<const float4*>(img) + lane + opaque;
+  const float4* bb1 = reinterpret_cast<const float4*>(img + W1M_FLOATS) + q + opaque;
+  const float4* w2 = reinterpret_cast<const float4*>(img + W1M_FLOATS + B1M_FLOATS) + lane + opaque;
+  const float4* bb2 = reinterpret_cast<const float4*>(img + W1M_FLOATS + B1M_FLOATS + W2M_FLOATS) + q + opaque;
+  const float zs[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
+  float u[32];
+  // ---- layer 1, two tiles at a time (two independent accumulator chains)
+#pragma unroll
+  for (int TP = 0; TP < 4; ++TP) {
+    const float4 c0 = bb1[8 * TP], c1 = bb1[8 * TP + 4];
+    f32x4 y0 = {c0.x, c0.y, c0.z, c0.w}, y1 = {c1.x, c1.y, c1.z, c1.w};
+    const float4 g00 = w1[(4 * TP) * 64], g01 = w1[(4 * TP + 1) * 64], g10 = w1[(4 * TP + 2) * 64], g11 = w1[(4 * TP + 3) * 64];
+    const float a0[8] = {g00.x, g00.y, g00.z, g00.w, g01.x, g01.y, g01.z, g01.w};
+    const float a1[8] = {g10.x, g10.y, g10.z, g10.w, g11.x, g11.y, g11.z, g11.w};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { y0 = mfma16(a0[s], zs[s], y0); y1 = mfma16(a1[s], zs[s], y1); }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { u[8 * TP + r] = fmaxf(y0[r], 0.f); u[8 * TP + 4 + r] = fmaxf(y1[r], 0.f); }
+  }
+  // ---- layer 2 + activation + contraction, one tile pair (4 hidden units x 8 channels) at a time
+#pragma unroll
+  for (int P = 0; P < 8; ++P) {
+    const float4 c0 = bb2[8 * P], c1 = bb2[8 * P + 4];
+    f32x4 y0 = {c0.x, c0.y, c0.z, c0.w}, y1 = {c1.x, c1.y, c1.z, c1.w};
+    const float4* t0 = w2 + (16 * P) * 64;           // tile 2P:   groups 16P .. 16P+7
+    const float4* t1 = w2 + (16 * P + 8) * 64;       // tile 2P+1: groups 16P+8 .. 16P+15
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const float4 a0 = t0[g * 64], a1 = t1[g * 64];
+      y0 = mfma16(a0.x, u[4 * g], y0);     y1 = mfma16(a1.x, u[4 * g], y1);
+      y0 = mfma16(a0.y, u[4 * g + 1], y0); y1 = mfma16(a1.y, u[4 * g + 1], y1);
+      y0 = mfma16(a0.z, u[4 * g + 2], y0); y1 = mfma16(a1.z, u[4 * g + 2], y1);
+      y0 = mfma16(a0.w, u[4 * g + 3], y0); y1 = mfma16(a1.w, u[4 * g + 3], y1);
+    }
+    float f = activate<ACT>(y0[0]) * dX[0];
+#pragma unroll
+    for (int c = 1; c < 4; ++c) f = __builtin_fmaf(activate<ACT>(y0[c]), dX[c], f);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) f = __builtin_fmaf(activate<ACT>(y1[c]), dX[4 + c], f);
+    if (P < 4) fa[P] = f; else fb[P - 4] = f;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 }  // namespace cde

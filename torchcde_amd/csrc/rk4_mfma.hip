@@ -46,19 +46,22 @@ __device__ __forceinline__ void wave_lds_sync() {
 //
 // ACT != CDE_ACT_NONE: same skeleton on the pre-activation form (cde_mfma.h: field_act16) -- the lane then owns
 // units q, 4+q, .., 28+q instead of 8q..8q+7.
-template <typename TT, int DEGREE, int ACT>
+// MLP: two-layer field (cde_mfma.h: field_mlp16), W1/bias1/width describe the hidden layer.
+template <typename TT, int DEGREE, int ACT, bool MLP = false>
 __global__ __launch_bounds__(512, 2) void rk4_forward_mfma(
     const float* __restrict__ coeffs, const float* __restrict__ knots, int64_t n_intervals,
     const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ z0,
     const TT* __restrict__ grid, int64_t n_grid, const TT* __restrict__ t_out, int64_t n_out,
     float* __restrict__ z_out, int64_t B, const int64_t* __restrict__ stage_index,
-    const float* __restrict__ stage_frac, Dims dims) {
+    const float* __restrict__ stage_frac, Dims dims, const float* __restrict__ W1 = nullptr,
+    const float* __restrict__ bias1 = nullptr, int width = 0) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // the A-operand image is loop invariant: staged once through LDS, then it lives in registers
-  constexpr bool PRODUCT = ACT == CDE_ACT_NONE;
+  constexpr bool PRODUCT = ACT == CDE_ACT_NONE && !MLP;
   constexpr int STRIDE = PRODUCT ? 1 : 4;          // distance between a lane's consecutive hidden units
   float4 wA[PRODUCT ? W16_GROUPS : 1], wB[PRODUCT ? W16_GROUPS : 1];
   if constexpr (PRODUCT) load_w16(W, bias, lds, wA, wB, dims);
+  else if constexpr (MLP) stage_mlp16(W1, bias1, W, bias, lds, MlpDims{dims.H, dims.C, width});
   else stage_wy16(W, bias, lds, dims);
   const int Hr = dims.H, Cr = dims.C;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -113,6 +116,7 @@ __global__ __launch_bounds__(512, 2) void rk4_forward_mfma(
 
       f32x4 fa, fb;
       if constexpr (PRODUCT) field16(wA, wB, za, zb, dX, q, fa, fb);
+      else if constexpr (MLP) field_mlp16<ACT>(lds, lane, q, za, zb, dX, fa, fb);
       else field_act16<ACT>(wy, by, za, zb, dX, fa, fb);
 
       // torchdiffeq rk4_alt_step_func (3/8 rule), association order preserved
@@ -709,6 +713,35 @@ int launch_forward_mfma(const void* coeffs, const void* knots, int64_t n_interva
 }
 
 template <typename TT>
+int launch_forward_mlp(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W1,
+                       const void* bias1, int64_t width, const void* W2, const void* bias2, int act, const void* z0,
+                       const void* grid, int64_t n_grid, const void* t_out, int64_t n_out, void* z_out, int64_t B,
+                       int64_t C, int64_t H, const int64_t* stage_index, const void* stage_frac, hipStream_t s) {
+  if (H < 1 || H > MH || C < 1 || C > MC || width < 1 || width > MW) return CDE_ERR_UNSUPPORTED;
+  if (degree != CDE_PATH_CUBIC && degree != CDE_PATH_LINEAR) return CDE_ERR_UNSUPPORTED;
+  if (act != CDE_ACT_NONE && act != CDE_ACT_TANH) return CDE_ERR_UNSUPPORTED;
+  const Dims dims{(int)H, (int)C};
+  const unsigned blocks = (unsigned)((B + 127) / 128);
+  const size_t lds = (size_t)MLP16_LDS_FLOATS * sizeof(float);
+#define CDE_FWD(D, A)                                                                                               \
+  do {                                                                                                              \
+    (void)hipFuncSetAttribute((const void*)rk4_forward_mfma<TT, D, A, true>,                                        \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
+    rk4_forward_mfma<TT, D, A, true><<<blocks, 512, lds, s>>>(                                                      \
+        (const float*)coeffs, (const float*)knots, n_intervals, (const float*)W2, (const float*)bias2,              \
+        (const float*)z0, (const TT*)grid, n_grid, (const TT*)t_out, n_out, (float*)z_out, B, stage_index,          \
+        (const float*)stage_frac, dims, (const float*)W1, (const float*)bias1, (int)width);                         \
+  } while (0)
+  if (act == CDE_ACT_NONE) {
+    if (degree == CDE_PATH_CUBIC) CDE_FWD(CDE_PATH_CUBIC, CDE_ACT_NONE); else CDE_FWD(CDE_PATH_LINEAR, CDE_ACT_NONE);
+  } else {
+    if (degree == CDE_PATH_CUBIC) CDE_FWD(CDE_PATH_CUBIC, CDE_ACT_TANH); else CDE_FWD(CDE_PATH_LINEAR, CDE_ACT_TANH);
+  }
+#undef CDE_FWD
+  return check_launch();
+}
+
+template <typename TT>
 int launch_adjoint_mfma(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
                         const void* bias, int act, const void* z_saved, const void* grad_out, const void* sgrid,
                         const int64_t* seg_off, int64_t n_out, void* grad_z0, void* grad_W, void* grad_b, int64_t B,
@@ -747,6 +780,14 @@ template int launch_forward_mfma<float>(const void*, const void*, int64_t, int, 
 template int launch_forward_mfma<double>(const void*, const void*, int64_t, int, const void*, const void*, int,
                                          const void*, const void*, int64_t, const void*, int64_t, void*, int64_t,
                                          int64_t, int64_t, const int64_t*, const void*, hipStream_t);
+template int launch_forward_mlp<float>(const void*, const void*, int64_t, int, const void*, const void*, int64_t,
+                                       const void*, const void*, int, const void*, const void*, int64_t, const void*,
+                                       int64_t, void*, int64_t, int64_t, int64_t, const int64_t*, const void*,
+                                       hipStream_t);
+template int launch_forward_mlp<double>(const void*, const void*, int64_t, int, const void*, const void*, int64_t,
+                                        const void*, const void*, int, const void*, const void*, int64_t, const void*,
+                                        int64_t, void*, int64_t, int64_t, int64_t, const int64_t*, const void*,
+                                        hipStream_t);
 template int launch_adjoint_mfma<float>(const void*, const void*, int64_t, int, const void*, const void*, int,
                                         const void*, const void*, const void*, const int64_t*, int64_t, void*, void*,
                                         void*, int64_t, int64_t, int64_t, const int64_t*, const void*, float*,

@@ -1,15 +1,17 @@
 """Vector-field recognition for the fused solvers.
 
 ``cdeint`` accepts an arbitrary callable ``func(t, z) -> (..., H, C)`` (reference solver.py:159-165).
-The fused kernels implement the affine family
+The fused kernels implement two families:
         f(t, z) = act( Linear(H, H*C)(z) ) viewed as (..., H, C),      act in {identity, tanh}
-i.e. the README field (reference README.md:42-49) and ``example/irregular_data.py:36-46``.  A module is
-recognised by *probing*, not by tracing source: the module must own exactly one nn.Linear (and no
-other parameter); during the compatibility evaluation ``func(t[0], z0)`` that the reference performs
-anyway, a forward hook records that Linear's input and output, and the module's result must be
-BITWISE equal to ``reshape(act(linear(z0)))`` -- view/reshape never change values, so any other
-arithmetic (scaling, skip connections, time dependence, a second layer) fails the comparison and the
-module is refused rather than mis-solved.
+i.e. the README field (reference README.md:42-49) and ``example/irregular_data.py:36-46``, and
+        f(t, z) = act( Linear(W, H*C)( relu( Linear(H, W)(z) ) ) ) viewed as (..., H, C)
+i.e. ``example/time_series_classification.py:20-51`` (forward solves only).  A module is recognised by
+*probing*, not by tracing source: it must own exactly one (two) nn.Linear and no other parameter; during
+the compatibility evaluation ``func(t[0], z0)`` that the reference performs anyway, forward hooks record
+the Linears' inputs and outputs, and the module's result must be BITWISE equal to the family's formula
+applied to those recordings -- view/reshape never change values, so any other arithmetic (scaling, skip
+connections, time dependence, another activation) fails the comparison and the module is refused (and
+solved step by step) rather than mis-solved.
 """
 import weakref
 
@@ -20,9 +22,11 @@ from . import _lib
 
 class AffineField:
     """(linear module, activation enum) extracted from a user module."""
+    kind = "affine"
 
     def __init__(self, linear, act):
         self.linear = linear
+        self.linears = (linear,)
         self.act = act
         self.shapes = {}          # verified input signature -> output shape of func
 
@@ -33,6 +37,25 @@ class AffineField:
     @property
     def bias(self):
         return self.linear.bias
+
+
+class MLPField:
+    """(hidden Linear, output Linear, final activation enum): Linear -> relu -> Linear -> act."""
+    kind = "mlp2"
+
+    def __init__(self, hidden, output, act):
+        self.hidden, self.output = hidden, output
+        self.linears = (hidden, output)
+        self.act = act
+        self.shapes = {}
+
+    @property
+    def weight(self):            # the layer that produces the (H, C) matrix
+        return self.output.weight
+
+    @property
+    def bias(self):
+        return self.output.bias
 
 
 class LinearCDEFunc(torch.nn.Module):
@@ -55,57 +78,71 @@ class LinearCDEFunc(torch.nn.Module):
 _verified = weakref.WeakKeyDictionary()   # func -> AffineField, after the two-time probe passed once
 
 
-def _single_linear(func):
+def _linears(func):
+    """The module's nn.Linear layers if they hold ALL of its parameters (1 or 2 layers, with bias), else None."""
     if isinstance(func, LinearCDEFunc):
-        return func.linear
+        return (func.linear,)
     if not isinstance(func, torch.nn.Module):
         return None
-    linears = [m for m in func.modules() if isinstance(m, torch.nn.Linear)]
-    if len(linears) != 1 or linears[0].bias is None:
+    linears = tuple(m for m in func.modules() if isinstance(m, torch.nn.Linear))
+    if len(linears) not in (1, 2) or any(m.bias is None for m in linears) or len({id(m) for m in linears}) != len(linears):
         return None
-    own = {id(p) for p in linears[0].parameters()}
+    own = {id(p) for m in linears for p in m.parameters()}
     if any(id(p) not in own for p in func.parameters()):
-        return None       # other trainable tensors take part: not the affine family
-    return linears[0]
+        return None       # other trainable tensors take part: not one of the fused families
+    return linears
 
 
-def _evaluate_recording(func, linear, t, z):
+def _evaluate_recording(func, linears, t, z):
     calls = []
-    handle = linear.register_forward_hook(lambda mod, inp, out: calls.append((inp[0], out)))
+    handles = [m.register_forward_hook(lambda mod, inp, out: calls.append((mod, inp[0], out))) for m in linears]
     try:
         with torch.no_grad():
             system = func(t, z)
     finally:
-        handle.remove()
+        for handle in handles:
+            handle.remove()
     return system, calls
 
 
-def _classify(system, calls, z):
-    """ACT enum if ``system`` is exactly reshape(act(linear(z))), else None (bitwise comparison:
-    view/reshape never change values, so any other arithmetic in ``func`` is detected)."""
-    if not isinstance(system, torch.Tensor) or len(calls) != 1:
-        return None
-    seen_input, linear_out = calls[0]
-    if seen_input.shape != z.shape or not torch.equal(seen_input, z):
-        return None
-    if system.numel() != linear_out.numel():
+def _final_activation(system, last_out):
+    if system.numel() != last_out.numel():
         return None
     flat = system.reshape(-1)
-    if torch.equal(flat, linear_out.reshape(-1)):
+    if torch.equal(flat, last_out.reshape(-1)):
         return _lib.ACT_NONE
-    if torch.equal(flat, linear_out.tanh().reshape(-1)):
+    if torch.equal(flat, last_out.tanh().reshape(-1)):
         return _lib.ACT_TANH
     return None
 
 
+def _classify(system, calls, z):
+    """(kind, act, ordered layers) if ``system`` is exactly one of the fused formulas applied to the recorded layer
+    inputs/outputs, else None (bitwise comparison: view/reshape never change values, so any other arithmetic in
+    ``func`` is detected)."""
+    if not isinstance(system, torch.Tensor) or len(calls) not in (1, 2):
+        return None
+    first, seen_input, first_out = calls[0]
+    if seen_input.shape != z.shape or not torch.equal(seen_input, z):
+        return None
+    if len(calls) == 1:
+        act = _final_activation(system, first_out)
+        return None if act is None else ("affine", act, (first,))
+    second, hidden_in, second_out = calls[1]
+    if second is first or hidden_in.shape != first_out.shape or not torch.equal(hidden_in, first_out.relu()):
+        return None
+    act = _final_activation(system, second_out)
+    return None if act is None else ("mlp2", act, (first, second))
+
+
 def probe(func, t0, z0):
     """Evaluate ``func(t0, z0)`` once (the compatibility probe the reference performs anyway,
-    solver.py:47-53) while watching the module's single nn.Linear.
+    solver.py:47-53) while watching the module's nn.Linear layers.
 
     Returns ``(field_or_None, system)``.  The first time a module is seen it is also evaluated at a
     second time value to establish that it does not depend on ``t``."""
-    linear = _single_linear(func)
-    if linear is None:
+    linears = _linears(func)
+    if linears is None:
         with torch.no_grad():
             return None, func(t0, z0)
     signature = (tuple(z0.shape), z0.dtype, str(z0.device))
@@ -113,25 +150,22 @@ def probe(func, t0, z0):
         known = _verified.get(func)
     except TypeError:
         known = None
-    if known is not None and known.linear is linear and signature in known.shapes:
-        # Verified before on an input of this very shape/dtype/device: the structural facts (one Linear fed by z,
-        # only reshapes / tanh after it, no time dependence) do not change with the VALUES of z or the weights, so
-        # the compatibility evaluation -- two launches plus synchronising comparisons -- is not repeated.
+    if known is not None and set(map(id, known.linears)) == set(map(id, linears)) and signature in known.shapes:
+        # Verified before on an input of this very shape/dtype/device: the structural facts (which layer is fed by
+        # z, only relu / reshapes / tanh around them, no time dependence) do not change with the VALUES of z or the
+        # weights, so the compatibility evaluation -- launches plus synchronising comparisons -- is not repeated.
         return known, torch.empty(known.shapes[signature], dtype=z0.dtype, device="meta")
-    system, calls = _evaluate_recording(func, linear, t0, z0)
-    act = _classify(system, calls, z0)
-    if act is None:
+    system, calls = _evaluate_recording(func, linears, t0, z0)
+    found = _classify(system, calls, z0)
+    if found is None or len(found[2]) != len(linears):
         return None, system
-    try:
-        known = _verified.get(func)
-    except TypeError:
-        known = None
-    if known is None or known.linear is not linear or known.act != act:
+    kind, act, ordered = found
+    if known is None or known.kind != kind or known.act != act or known.linears != ordered:
         other_t = t0.detach() + 0.8125
-        system2, calls2 = _evaluate_recording(func, linear, other_t, z0)
-        if _classify(system2, calls2, z0) != act or not torch.equal(system2, system):
+        system2, calls2 = _evaluate_recording(func, linears, other_t, z0)
+        if _classify(system2, calls2, z0) != found or not torch.equal(system2, system):
             return None, system
-        known = AffineField(linear, act)
+        known = AffineField(ordered[0], act) if kind == "affine" else MLPField(ordered[0], ordered[1], act)
         try:
             _verified[func] = known
         except TypeError:
