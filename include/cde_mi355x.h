@@ -203,6 +203,16 @@ int cde_dopri5_advance(const void* coeffs, const void* knots, int64_t n_interval
                        int variant, void* workspace, size_t workspace_bytes, int64_t first_launch,
                        int64_t n_launches, void* stream);
 
+/* K4 for the two-layer field of K2m (W1/bias1/width = hidden layer, W2/bias2 = output layer); f32, H <= 32,
+ * C <= 8, width <= 128.  Same protocol, workspace (cde_dopri5_workspace_bytes) and status block as
+ * cde_dopri5_advance. */
+int cde_dopri5_advance_mlp(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W1,
+                           const void* bias1, int64_t width, const void* W2, const void* bias2, int act,
+                           const void* z0, const double* t_out, int64_t n_out, const double* jump_t, int64_t n_jump,
+                           double rtol, double atol, double safety, double ifactor, double dfactor, void* z_out,
+                           int64_t B, int64_t C, int64_t H, int dtype, void* workspace, size_t workspace_bytes,
+                           int64_t first_launch, int64_t n_launches, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -298,6 +298,23 @@ def test_two_layer_field_forward_fused(native, H, C, width, degree, final_tanh):
     _close(fused, ref, 1e-4, 5e-6)
     _close(fused, stepwise, 1e-4, 5e-6)
     assert not torch.equal(fused, stepwise)          # two different code paths did run
+    # the reference's default method: adaptive dopri5 (fused attempt kernel vs the host-driven controller vs float64)
+    from torchcde_amd.cdeint import last_dopri5_stats
+    kw = dict(method="dopri5", options=dict(jump_t=X.grid_points)) if degree == 1 else {}
+    with torch.no_grad():
+        last_dopri5_stats.clear()
+        fused5 = native.cdeint(X, dfunc, z0.to(DEV), t_out.to(DEV), **kw)
+        assert last_dopri5_stats["n_accept"] > 0                       # the fused K4 loop ran
+        stepwise5 = native.cdeint(X, dfunc, z0.to(DEV), t_out.to(DEV), variant="generic", **kw)
+        fine = oracle_cde.cdeint(path64, f64, z0.double(), t_out.double(), adjoint=False, method="rk4",
+                                 options=dict(step_size=0.0625))
+    # Two float32 controllers with independent rounding take different step sequences, so they agree with each other
+    # only to the GLOBAL error of an rtol=1e-4 solve (a few 1e-3 of the state here: relu kinks, piecewise-cubic
+    # control); measure both against a finely stepped float64 solution instead.
+    scale = fine.abs().max().item()
+    err_fused = (fused5.double().cpu() - fine).abs().max().item()
+    err_step = (stepwise5.double().cpu() - fine).abs().max().item()
+    assert err_fused <= 4 * err_step + 2e-3 * scale, (err_fused, err_step, scale)
 
 
 @pytest.mark.parametrize("act", [False, True])

@@ -289,6 +289,7 @@ class _Dopri5Plan:
         coeffs, knots, _ = path._native_inputs()
         self.coeffs, self.knots = coeffs, knots
         self.n_intervals, self.degree, self.act = path._n_intervals(), path._degree, field.act
+        self.hidden = field.hidden if field.kind == "mlp2" else None      # two-layer field: its first Linear
         self.batch, self.B, self.H, self.C = batch, coeffs.size(0), H, C
         self.dtype, self.device = coeffs.dtype, coeffs.device
         self.rtol = float(rtol)
@@ -316,13 +317,23 @@ class _Dopri5Plan:
         workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         size = ctypes.sizeof(_lib.DopriStatus)
         launched = 0
+        if self.hidden is not None:
+            w1, b1 = self.hidden.weight.detach().contiguous(), self.hidden.bias.detach().contiguous()
         while True:
-            _lib.check(lib.cde_dopri5_advance(
-                _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w), _lib.ptr(b),
-                self.act, _lib.ptr(z0c), _lib.ptr(self.t_out), self.n_out, _lib.ptr(self.jump_t), self.n_jump,
-                self.rtol, self.atol, self.safety, self.ifactor, self.dfactor, _lib.ptr(out), self.B, self.C, self.H, dt,
-                self.variant, _lib.ptr(workspace), workspace.numel(), launched, _DOPRI_CHUNK, _lib.stream_ptr(self.device)),
-                "cde_dopri5_advance")
+            if self.hidden is None:
+                _lib.check(lib.cde_dopri5_advance(
+                    _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w), _lib.ptr(b),
+                    self.act, _lib.ptr(z0c), _lib.ptr(self.t_out), self.n_out, _lib.ptr(self.jump_t), self.n_jump,
+                    self.rtol, self.atol, self.safety, self.ifactor, self.dfactor, _lib.ptr(out), self.B, self.C, self.H,
+                    dt, self.variant, _lib.ptr(workspace), workspace.numel(), launched, _DOPRI_CHUNK,
+                    _lib.stream_ptr(self.device)), "cde_dopri5_advance")
+            else:
+                _lib.check(lib.cde_dopri5_advance_mlp(
+                    _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w1), _lib.ptr(b1),
+                    w1.size(0), _lib.ptr(w), _lib.ptr(b), self.act, _lib.ptr(z0c), _lib.ptr(self.t_out), self.n_out,
+                    _lib.ptr(self.jump_t), self.n_jump, self.rtol, self.atol, self.safety, self.ifactor, self.dfactor,
+                    _lib.ptr(out), self.B, self.C, self.H, dt, _lib.ptr(workspace), workspace.numel(), launched,
+                    _DOPRI_CHUNK, _lib.stream_ptr(self.device)), "cde_dopri5_advance_mlp")
             launched += _DOPRI_CHUNK
             raw = workspace[(launched & 1) * size:(launched & 1) * size + size].cpu().numpy().tobytes()   # one sync per chunk
             status = _lib.DopriStatus.from_buffer_copy(raw)
@@ -442,13 +453,16 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         p.requires_grad for p in (func.parameters() if isinstance(func, torch.nn.Module) else ())))
     fused = (field is not None and ((method == "rk4" and (adjoint or not wants_grad))
                                     or (method == "dopri5" and not wants_grad)))
-    if (mlp is not None and method == "rk4" and not wants_grad and variant != _lib.VARIANT_GENERIC
-            and set(options or ()) <= {"step_size"}
+    if (mlp is not None and not wants_grad and variant != _lib.VARIANT_GENERIC
             and isinstance(t, torch.Tensor) and t.dim() == 1 and t.is_floating_point() and t.numel() >= 1):
-        # two-layer field, nothing to differentiate: the fused forward kernel (K2m)
+        # two-layer field, nothing to differentiate: the fused forward kernels (K2m / K4 with the two-layer field)
         t_host = _to_host(t)
-        if t_host.numel() == 1 or bool((t_host[1:] > t_host[:-1]).all()):
+        increasing = t_host.numel() == 1 or bool((t_host[1:] > t_host[:-1]).all())
+        if increasing and method == "rk4" and set(options or ()) <= {"step_size"}:
             return _MlpPlan(X, mlp, batch, H, C, t, _parse_fixed_options(options, "solver")).run(z0)
+        if increasing and method == "dopri5" and set(options or ()) <= {"jump_t", "safety", "ifactor", "dfactor"}:
+            plan = _Dopri5Plan(X, mlp, batch, H, C, t, kwargs["rtol"], kwargs["atol"], options)
+            return plan.run(z0, mlp.weight, mlp.bias).reshape(*batch, plan.n_out, H)
     if not fused:
         # Arbitrary vector fields / methods / differentiation modes: host-driven stepping with the native control
         # derivative and contraction kernels under every evaluation (torchcde_amd/stepwise.py).

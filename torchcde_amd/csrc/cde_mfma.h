@@ -328,29 +328,35 @@ constexpr int W2M_FLOATS = 16 * 8 * 64 * 4;          // layer 2: 16 tiles x 8 gr
 constexpr int MLP16_LDS_FLOATS = W1M_FLOATS + B1M_FLOATS + W2M_FLOATS + BY_FLOATS;
 struct MlpDims { int H, C, width; };
 
-__device__ __forceinline__ void stage_mlp16(const float* __restrict__ W1, const float* __restrict__ b1,
-                                            const float* __restrict__ W2, const float* __restrict__ b2, float* lds,
-                                            MlpDims d) {
-  float* w1 = lds;
-  float* bb1 = lds + W1M_FLOATS;
-  float* w2 = bb1 + B1M_FLOATS;
-  float* bb2 = w2 + W2M_FLOATS;
-  for (int e = threadIdx.x; e < W1M_FLOATS; e += blockDim.x) {
+// value of the combined image [layer-1 weights | layer-1 bias | layer-2 weights | layer-2 bias] at flat index e
+__device__ __forceinline__ float mlp16_image(const float* __restrict__ W1, const float* __restrict__ b1,
+                                             const float* __restrict__ W2, const float* __restrict__ b2, int e,
+                                             MlpDims d) {
+  if (e < W1M_FLOATS) {
     const int j = e & 3, l = (e >> 2) & 63, g = e >> 8;              // g = 2*T1 + (s>>2)
     const int row = 16 * (g >> 1) + (l & 15), k = 4 * (4 * (g & 1) + j) + (l >> 4);
-    w1[e] = (row < d.width && k < d.H) ? W1[row * d.H + k] : 0.f;
+    return (row < d.width && k < d.H) ? W1[row * d.H + k] : 0.f;
   }
-  for (int e = threadIdx.x; e < B1M_FLOATS; e += blockDim.x) {
+  e -= W1M_FLOATS;
+  if (e < B1M_FLOATS) {
     const int unit = 16 * (e >> 4) + 4 * ((e >> 2) & 3) + (e & 3);
-    bb1[e] = unit < d.width ? b1[unit] : 0.f;
+    return unit < d.width ? b1[unit] : 0.f;
   }
-  for (int e = threadIdx.x; e < W2M_FLOATS; e += blockDim.x) {
+  e -= B1M_FLOATS;
+  if (e < W2M_FLOATS) {
     const int j = e & 3, l = (e >> 2) & 63, g = e >> 8;              // g = 8*T2 + T1, K step (T1, r = j)
     const int T2 = g >> 3, T1 = g & 7, i = l & 15, kq = l >> 4;
     const int h = 4 * (T2 >> 1) + (i >> 2), c = 4 * (T2 & 1) + (i & 3), col = 16 * T1 + 4 * kq + j;
-    w2[e] = (h < d.H && c < d.C && col < d.width) ? W2[(h * d.C + c) * d.width + col] : 0.f;
+    return (h < d.H && c < d.C && col < d.width) ? W2[(h * d.C + c) * d.width + col] : 0.f;
   }
-  for (int e = threadIdx.x; e < BY_FLOATS; e += blockDim.x) bb2[e] = by16_image(b2, e >> 4, (e >> 2) & 3, e & 3, Dims{d.H, d.C});
+  e -= W2M_FLOATS;
+  return by16_image(b2, e >> 4, (e >> 2) & 3, e & 3, Dims{d.H, d.C});
+}
+
+__device__ __forceinline__ void stage_mlp16(const float* __restrict__ W1, const float* __restrict__ b1,
+                                            const float* __restrict__ W2, const float* __restrict__ b2, float* lds,
+                                            MlpDims d) {
+  for (int e = threadIdx.x; e < MLP16_LDS_FLOATS; e += blockDim.x) lds[e] = mlp16_image(W1, b1, W2, b2, e, d);
   __syncthreads();
 }
 

@@ -44,6 +44,7 @@ struct DopriArgs {
   const float* w16;             // MFMA kernels: the two 16x16x4 weight images, built once per solve
   double* partial;              // [2][n_blocks][2], accumulated in float64 whatever the state dtype
   int64_t n_blocks_alloc;
+  const T* W1; const T* bias1; int width;      // two-layer fields: the hidden layer (W, bias are then the output layer)
 };
 
 __device__ __forceinline__ float next_toward(float x, float dir) { return nextafterf(x, x + dir); }
@@ -382,6 +383,7 @@ __global__ void dopri5_attempt_kernel(DopriArgs<T> g, int parity) {
 }
 
 constexpr int64_t DOPRI_MAX_LDS_KNOTS = 8192;
+constexpr int64_t DOPRI_MAX_LDS_KNOTS_MLP = 1536;   // 160 KB LDS - 145.5 KB of weight images - 8 KB reduction scratch
 
 // ------------------------------------------------------------------------------------------ MFMA attempt kernel
 // f32, H = 32, C = 8, no activation: 16 series per wave on v_mfma_f32_16x16x4_f32 exactly like K2 (field16), six
@@ -394,7 +396,7 @@ __device__ __forceinline__ double sq4(const f32x4& v) {
   return (double)(v[0] * v[0]) + (double)(v[1] * v[1]) + (double)(v[2] * v[2]) + (double)(v[3] * v[3]);
 }
 
-template <int DEGREE, int ACT>
+template <int DEGREE, int ACT, bool MLP = false>
 __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g, int parity) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using T = float;
@@ -407,8 +409,10 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   }
   // weight images: built once per solve (w16_image_kernel / wy16_image_kernel).  Product form: one coalesced
   // 16-byte load per group and lane into registers; activation form: copied to LDS (field_act16 reads it there).
-  constexpr bool PRODUCT = ACT == CDE_ACT_NONE;
+  constexpr bool PRODUCT = ACT == CDE_ACT_NONE && !MLP;
   constexpr int STRIDE = PRODUCT ? 1 : 4;
+  constexpr int IMG_FLOATS = MLP ? MLP16_LDS_FLOATS : ACT16_LDS_FLOATS;
+  constexpr int64_t MAX_LDS_KNOTS = MLP ? DOPRI_MAX_LDS_KNOTS_MLP : DOPRI_MAX_LDS_KNOTS;
   float4 wA[PRODUCT ? W16_GROUPS : 1], wB[PRODUCT ? W16_GROUPS : 1];
   const Dims dims{(int)g.H, (int)g.C};
   const int Hr = dims.H;
@@ -421,14 +425,14 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   // The knot search of every stage time is a chain of dependent loads: from global memory that is ~7 x 0.3 us per
   // stage (it dominated this kernel); the knots are copied to LDS once per launch instead.
   float* knots_lds = lds + 2 * 512 * 2;
-  const bool knots_in_lds = g.n_intervals + 1 <= DOPRI_MAX_LDS_KNOTS;
+  const bool knots_in_lds = g.n_intervals + 1 <= MAX_LDS_KNOTS;
   if (knots_in_lds) for (int64_t i = tid; i <= g.n_intervals; i += blockDim.x) knots_lds[i] = g.knots[i];
   const float* kn = knots_in_lds ? knots_lds : g.knots;
   float* img_lds = knots_lds + (knots_in_lds ? (g.n_intervals + 4) / 4 * 4 : 0);          // 16-byte aligned
   if constexpr (!PRODUCT) {
     const float4* src = reinterpret_cast<const float4*>(g.w16);
     float4* dst = reinterpret_cast<float4*>(img_lds);
-    for (int i = tid; i < ACT16_LDS_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
+    for (int i = tid; i < IMG_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
   }
   __syncthreads();
   const int64_t BH = g.B * g.H;
@@ -458,6 +462,7 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   const float4* by = reinterpret_cast<const float4*>(img_lds + WY_FLOATS) + q;
   auto field = [&](const f32x4& za, const f32x4& zb, const float (&dXv)[MC], f32x4& fa, f32x4& fb) {
     if constexpr (PRODUCT) field16(wA, wB, za, zb, dXv, q, fa, fb);
+    else if constexpr (MLP) field_mlp16<ACT>(img_lds, lane, q, za, zb, dXv, fa, fb);
     else field_act16<ACT>(wy, by, za, zb, dXv, fa, fb);
   };
 
@@ -603,7 +608,14 @@ __global__ void wy16_image_kernel(const float* __restrict__ W, const float* __re
     img[e] = by16_image(bias, b >> 4, (b >> 2) & 3, b & 3, d);
   }
 }
-static_assert(ACT16_LDS_FLOATS <= W16_FLOATS, "both image forms share one workspace slot");
+__global__ void mlp16_image_kernel(const float* __restrict__ W1, const float* __restrict__ b1,
+                                   const float* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ img,
+                                   MlpDims d) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < MLP16_LDS_FLOATS) img[e] = mlp16_image(W1, b1, W2, b2, e, d);
+}
+static_assert(ACT16_LDS_FLOATS <= W16_FLOATS && W16_FLOATS <= MLP16_LDS_FLOATS, "all image forms share one workspace slot");
+constexpr size_t DOPRI_IMAGE_BYTES = (size_t)MLP16_LDS_FLOATS * sizeof(float);
 
 static inline bool dopri_use_mfma(int64_t C, int64_t H, int dtype, int act, int variant) {
   return variant != CDE_VARIANT_GENERIC && dtype == CDE_F32 && H <= MH && C <= MC &&
@@ -621,30 +633,35 @@ extern "C" size_t cde_dopri5_workspace_bytes(int64_t B, int64_t C, int64_t H, in
   (void)C;
   const size_t elem = dtype == CDE_F64 ? 8 : 4;
   return cde::al256(2 * sizeof(cde::DopriCtrl)) + cde::al256((size_t)2 * cde::dopri_blocks_any(B, H) * 2 * sizeof(double)) +
-         (size_t)2 * 5 * B * H * elem + cde::al256(cde::W16_FLOATS * sizeof(float));
+         (size_t)2 * 5 * B * H * elem + cde::al256(cde::DOPRI_IMAGE_BYTES);
 }
 
-extern "C" int cde_dopri5_advance(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
-                                  const void* bias, int act, const void* z0, const double* t_out, int64_t n_out,
-                                  const double* jump_t, int64_t n_jump, double rtol, double atol, double safety,
-                                  double ifactor, double dfactor, void* z_out, int64_t B, int64_t C, int64_t H,
-                                  int dtype, int variant, void* workspace, size_t workspace_bytes,
-                                  int64_t first_launch, int64_t n_launches, void* stream) {
+// W1 == nullptr: one-layer field (W, bias); otherwise W1/bias1/width is the hidden layer and W/bias the output layer
+static int dopri5_advance_impl(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W1,
+                               const void* bias1, int64_t width, const void* W, const void* bias, int act,
+                               const void* z0, const double* t_out, int64_t n_out, const double* jump_t, int64_t n_jump,
+                               double rtol, double atol, double safety, double ifactor, double dfactor, void* z_out,
+                               int64_t B, int64_t C, int64_t H, int dtype, int variant, void* workspace,
+                               size_t workspace_bytes, int64_t first_launch, int64_t n_launches, void* stream) {
+  const bool mlp = W1 != nullptr;
   if (B < 1 || C < 1 || H < 1 || H > 256 || n_intervals < 1 || n_out < 1 || n_launches < 0 || n_jump < 0) return CDE_ERR_SHAPE;
+  if (mlp && (width < 1 || !bias1)) return width < 1 ? CDE_ERR_SHAPE : CDE_ERR_NULL;
+  if (mlp && (dtype != CDE_F32 || H > cde::MH || C > cde::MC || width > cde::MW || variant == CDE_VARIANT_GENERIC))
+    return CDE_ERR_UNSUPPORTED;
   if (act != CDE_ACT_NONE && act != CDE_ACT_TANH) return CDE_ERR_UNSUPPORTED;
   if (degree != CDE_PATH_CUBIC && degree != CDE_PATH_LINEAR) return CDE_ERR_UNSUPPORTED;
   if (!coeffs || !knots || !W || !bias || !z0 || !t_out || !z_out || !workspace) return CDE_ERR_NULL;
   if (n_jump > 0 && !jump_t) return CDE_ERR_NULL;
   if (workspace_bytes < cde_dopri5_workspace_bytes(B, C, H, dtype)) return CDE_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  const bool use_mfma = cde::dopri_use_mfma(C, H, dtype, act, variant);
+  const bool use_mfma = mlp || cde::dopri_use_mfma(C, H, dtype, act, variant);
   if (variant == CDE_VARIANT_MFMA && !use_mfma) return CDE_ERR_UNSUPPORTED;
   const int64_t blocks = cde::dopri_blocks_any(B, H);          // allocation stride of the partial sums
   unsigned char* base = (unsigned char*)workspace;
   cde::DopriCtrl* ctrl = (cde::DopriCtrl*)base;
   double* partial = (double*)(base + cde::al256(2 * sizeof(cde::DopriCtrl)));
   float* w16 = (float*)(base + cde::al256(2 * sizeof(cde::DopriCtrl)) + cde::al256((size_t)2 * blocks * 2 * sizeof(double)));
-  void* state = (unsigned char*)w16 + cde::al256(cde::W16_FLOATS * sizeof(float));
+  void* state = (unsigned char*)w16 + cde::al256(cde::DOPRI_IMAGE_BYTES);
   if (first_launch == 0) {
     if (hipMemsetAsync(ctrl, 0, 2 * sizeof(cde::DopriCtrl), s) != hipSuccess) return CDE_ERR_LAUNCH;   // phase 0
   }
@@ -662,19 +679,43 @@ extern "C" int cde_dopri5_advance(const void* coeffs, const void* knots, int64_t
   if (use_mfma) {
     cde::DopriArgs<float> g{(const float*)coeffs, (const float*)knots, n_intervals, degree, (const float*)W,
                             (const float*)bias, act, (const float*)z0, t_out, n_out, jump_t, n_jump, rtol, atol, safety,
-                            ifactor, dfactor, (float*)z_out, B, C, H, 16, ctrl, (float*)state, w16, partial, blocks};
+                            ifactor, dfactor, (float*)z_out, B, C, H, 16, ctrl, (float*)state, w16, partial, blocks,
+                            (const float*)W1, (const float*)bias1, (int)width};
     const cde::Dims dims{(int)H, (int)C};
+    const unsigned grid = (unsigned)((B + 127) / 128);
+    const int64_t n_knots = n_intervals + 1;
+    if (mlp) {
+      if (first_launch == 0)
+        cde::mlp16_image_kernel<<<(cde::MLP16_LDS_FLOATS + 255) / 256, 256, 0, s>>>(
+            (const float*)W1, (const float*)bias1, (const float*)W, (const float*)bias, w16,
+            cde::MlpDims{(int)H, (int)C, (int)width});
+      const size_t lds = 2 * 512 * sizeof(double) +
+                         (n_knots <= cde::DOPRI_MAX_LDS_KNOTS_MLP ? (size_t)((n_knots + 3) / 4 * 4) * sizeof(float) : 0) +
+                         cde::DOPRI_IMAGE_BYTES;
+#define CDE_MLP(D, A)                                                                                              \
+  do {                                                                                                             \
+    (void)hipFuncSetAttribute((const void*)cde::dopri5_attempt_mfma<D, A, true>,                                   \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
+    for (int64_t i = 0; i < n_launches; ++i)                                                                       \
+      cde::dopri5_attempt_mfma<D, A, true><<<grid, 512, lds, s>>>(g, (int)((first_launch + i) & 1));               \
+  } while (0)
+      if (act == CDE_ACT_NONE) {
+        if (degree == CDE_PATH_CUBIC) CDE_MLP(CDE_PATH_CUBIC, CDE_ACT_NONE); else CDE_MLP(CDE_PATH_LINEAR, CDE_ACT_NONE);
+      } else {
+        if (degree == CDE_PATH_CUBIC) CDE_MLP(CDE_PATH_CUBIC, CDE_ACT_TANH); else CDE_MLP(CDE_PATH_LINEAR, CDE_ACT_TANH);
+      }
+#undef CDE_MLP
+      return cde::check_launch();
+    }
     if (first_launch == 0) {
       if (act == CDE_ACT_NONE)
         cde::w16_image_kernel<<<(cde::W16_FLOATS + 255) / 256, 256, 0, s>>>((const float*)W, (const float*)bias, w16, dims);
       else
         cde::wy16_image_kernel<<<(cde::ACT16_LDS_FLOATS + 255) / 256, 256, 0, s>>>((const float*)W, (const float*)bias, w16, dims);
     }
-    const int64_t n_knots = n_intervals + 1;
     const size_t lds = 2 * 512 * sizeof(double) +
                        (n_knots <= cde::DOPRI_MAX_LDS_KNOTS ? (size_t)((n_knots + 3) / 4 * 4) * sizeof(float) : 0) +
                        (act == CDE_ACT_NONE ? 0 : cde::ACT16_LDS_FLOATS * sizeof(float));
-    const unsigned grid = (unsigned)((B + 127) / 128);
     for (int64_t i = 0; i < n_launches; ++i) {
       const int par = (int)((first_launch + i) & 1);
       if (act == CDE_ACT_NONE) {
@@ -692,4 +733,28 @@ extern "C" int cde_dopri5_advance(const void* coeffs, const void* knots, int64_t
   else return CDE_ERR_DTYPE;
 #undef CDE_DOPRI
   return cde::check_launch();
+}
+
+extern "C" int cde_dopri5_advance(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
+                                  const void* bias, int act, const void* z0, const double* t_out, int64_t n_out,
+                                  const double* jump_t, int64_t n_jump, double rtol, double atol, double safety,
+                                  double ifactor, double dfactor, void* z_out, int64_t B, int64_t C, int64_t H,
+                                  int dtype, int variant, void* workspace, size_t workspace_bytes,
+                                  int64_t first_launch, int64_t n_launches, void* stream) {
+  return dopri5_advance_impl(coeffs, knots, n_intervals, degree, nullptr, nullptr, 0, W, bias, act, z0, t_out, n_out,
+                             jump_t, n_jump, rtol, atol, safety, ifactor, dfactor, z_out, B, C, H, dtype, variant,
+                             workspace, workspace_bytes, first_launch, n_launches, stream);
+}
+
+extern "C" int cde_dopri5_advance_mlp(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
+                                      const void* W1, const void* bias1, int64_t width, const void* W2,
+                                      const void* bias2, int act, const void* z0, const double* t_out, int64_t n_out,
+                                      const double* jump_t, int64_t n_jump, double rtol, double atol, double safety,
+                                      double ifactor, double dfactor, void* z_out, int64_t B, int64_t C, int64_t H,
+                                      int dtype, void* workspace, size_t workspace_bytes, int64_t first_launch,
+                                      int64_t n_launches, void* stream) {
+  if (!W1) return CDE_ERR_NULL;
+  return dopri5_advance_impl(coeffs, knots, n_intervals, degree, W1, bias1, width, W2, bias2, act, z0, t_out, n_out,
+                             jump_t, n_jump, rtol, atol, safety, ifactor, dfactor, z_out, B, C, H, dtype,
+                             CDE_VARIANT_AUTO, workspace, workspace_bytes, first_launch, n_launches, stream);
 }
