@@ -150,6 +150,35 @@ int cde_rk4_forward_mlp(const void* coeffs, const void* knots, int64_t n_interva
                         void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * K3m  Continuous-adjoint reverse sweep for K2m (the two-layer field), replacing torchdiffeq.odeint_adjoint's
+ * backward behind solver.py:226 for that vector field.  The parameter gradient of the output layer is a
+ * (H*C) x width matrix per wave -- too large for on-chip accumulation -- so the sweep integrates (z, a) backwards
+ * and STREAMS the per-stage factors to caller-provided HBM scratch; the caller reduces them with two GEMMs:
+ *     [dL/dW2 | dL/db2] = G2^T U        [dL/dW1 | dL/db1] = G1^T Z
+ *   scratch rows: row = (local_stage * B + series), local_stage = 4*(k - k_begin) + rk_stage
+ *     U  (rows, 132) f32: relu(W1 z + b1) in columns 0..127 (zero beyond `width`); the CALLER sets column 128 to 1
+ *                         and 129..131 to 0 once (the kernel never writes them)
+ *     G2 (rows, 256) f32: quadrature-weighted dL/dY2, column h*8 + c (zero beyond the real H, C)
+ *     G1 (rows, 128) f32: quadrature-weighted dL/dY1
+ *     Z  (rows, 36)  f32: z in columns 0..H-1; the CALLER zeroes the buffer and sets column 32 to 1 once
+ *   cde_rk4_adjoint_mlp_prepare   once per backward: stage table of the reversed-time grid `sgrid` (as for K3) and
+ *                                 the MFMA weight images, into `workspace`
+ *   cde_rk4_adjoint_mlp_sweep     integrates steps k_begin .. k_end-1 of `sgrid`; y_state / a_state (B, H) hold
+ *                                 (z, a) on entry and on return (the caller re-seeds z and adds the incoming
+ *                                 gradient between output intervals, as torchdiffeq does)
+ * f32, H <= 32, C <= 8, width <= 128.
+ * ------------------------------------------------------------------------------------------- */
+size_t cde_rk4_adjoint_mlp_workspace_bytes(int64_t n_sgrid);
+int cde_rk4_adjoint_mlp_prepare(const void* knots, int64_t n_intervals, const void* sgrid, int64_t n_sgrid,
+                                const void* W1, const void* bias1, int64_t width, const void* W2, const void* bias2,
+                                int64_t C, int64_t H, int dtype, int time_dtype, void* workspace,
+                                size_t workspace_bytes, void* stream);
+int cde_rk4_adjoint_mlp_sweep(const void* coeffs, const void* knots, int64_t n_intervals, int degree, int act,
+                              void* y_state, void* a_state, const void* sgrid, int64_t n_sgrid, int64_t k_begin,
+                              int64_t k_end, void* U, void* G2, void* G1, void* Z, int64_t B, int64_t C, int64_t H,
+                              int dtype, int time_dtype, const void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K3  Fused continuous-adjoint reverse sweep for K2.
  * Replaces torchdiffeq.odeint_adjoint's backward (behind solver.py:226): for every output
  * interval, RK4 (3/8) integration in reversed time of the augmented state (z, a_z, a_W, a_b),

@@ -317,6 +317,60 @@ def test_two_layer_field_forward_fused(native, H, C, width, degree, final_tanh):
     assert err_fused <= 4 * err_step + 2e-3 * scale, (err_fused, err_step, scale)
 
 
+@pytest.mark.parametrize("H,C,width,degree,final_tanh,chunk_bytes",
+                         [(32, 8, 128, 3, True, None), (16, 4, 64, 1, True, 1), (8, 3, 100, 3, False, None)])
+def test_two_layer_field_adjoint_fused(native, H, C, width, degree, final_tanh, chunk_bytes):
+    """Training path of the example model: fused forward + continuous-adjoint sweep (K3m) + GEMM reduction against
+    the float64 oracle's odeint_adjoint restatement.  3 output times (two reverse segments with re-seeding),
+    ragged batch; `chunk_bytes=1` forces one sweep launch per step (state carried through HBM between launches)."""
+    import importlib
+    cdeint_mod = importlib.import_module("torchcde_amd.cdeint")      # the package attribute `cdeint` is the function
+    B, L = 203, 24
+    x = make_series(B, L, C, torch.float32, seed=71)
+    coeffs = oracle_interp.hermite_bdiff_coeffs(x) if degree == 3 else x
+    gen = torch.Generator().manual_seed(72)
+    z0 = torch.randn(B, H, generator=gen)
+    t_out = torch.tensor([0., 7.5, 23.])
+    lw = torch.rand(B, 3, H, generator=gen) + 0.5
+    f64 = _TwoLayerField(H, C, width, torch.float64, seed=5, final_tanh=final_tanh)
+    path64 = (oracle_interp.CubicPath if degree == 3 else oracle_interp.LinearPath)(coeffs.double())
+    zr = z0.double().clone().requires_grad_(True)
+    ref = oracle_cde.cdeint(path64, f64, zr, t_out.double(), adjoint=True, method="rk4", options=dict(step_size=1.0))
+    (ref * lw.double()).sum().backward()
+    # The relu makes the gradient discontinuous in z: float32 and float64 trajectories differ by ~1e-6, a few of the
+    # 203 * 508 * 128 hidden units sit within that distance of zero and flip, and each flip moves the gradient by a
+    # discrete amount.  The CPU float32 run of the same algorithm measures how large that effect is here.
+    f32 = _TwoLayerField(H, C, width, torch.float32, seed=5, final_tanh=final_tanh)
+    path32 = (oracle_interp.CubicPath if degree == 3 else oracle_interp.LinearPath)(coeffs)
+    z32 = z0.clone().requires_grad_(True)
+    (oracle_cde.cdeint(path32, f32, z32, t_out, adjoint=True, method="rk4", options=dict(step_size=1.0)) * lw).sum().backward()
+
+    def bar(want, cpu32):          # rtol 1e-3 of the largest entry, or 4x what float32 costs on the CPU
+        return max(1e-3 * want.abs().max().item(), 4 * (cpu32.double() - want).abs().max().item())
+
+    dfunc = _TwoLayerField(H, C, width, seed=5, final_tanh=final_tanh).to(DEV)
+    X = (native.CubicSpline if degree == 3 else native.LinearInterpolation)(coeffs.to(DEV))
+    z = z0.to(DEV).requires_grad_(True)
+    budget = cdeint_mod._MlpPlan.scratch_budget
+    try:
+        if chunk_bytes is not None:
+            cdeint_mod._MlpPlan.scratch_budget = chunk_bytes
+        out = native.cdeint(X, dfunc, z, t_out.to(DEV), method="rk4", options=dict(step_size=1.0))
+        assert type(out.grad_fn).__name__ == "_FusedMlpRK4Backward"          # the fused path, not the step-wise one
+        (out * lw.to(DEV)).sum().backward()
+    finally:
+        cdeint_mod._MlpPlan.scratch_budget = budget
+    _close(out, ref, 1e-4, 5e-6)
+    _close(z.grad, zr.grad, 1e-3, bar(zr.grad, z32.grad))
+    for name in ("linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias"):
+        layer, kind = name.split(".")
+        got = getattr(getattr(dfunc, layer), kind).grad
+        want = getattr(getattr(f64, layer), kind).grad
+        cpu32 = getattr(getattr(f32, layer), kind).grad
+        assert got.shape == want.shape
+        _close(got, want, 1e-3, bar(want, cpu32))
+
+
 @pytest.mark.parametrize("act", [False, True])
 @pytest.mark.parametrize("H,C", [(16, 4), (32, 3), (5, 2), (24, 8)])
 def test_mfma_kernels_on_zero_padded_shapes(native, H, C, act):

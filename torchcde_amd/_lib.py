@@ -13,8 +13,9 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libcde_mi355x.so")
-SOURCES = ["interp_kernels.hip", "rk4_generic.hip", "rk4_mfma.hip", "dopri5.hip", "api.hip"]
-HEADERS = [os.path.join(_CSRC, "cde_common.h"), os.path.join(_HERE, "..", "include", "cde_mi355x.h")]
+SOURCES = ["interp_kernels.hip", "rk4_generic.hip", "rk4_mfma.hip", "rk4_mlp_adjoint.hip", "dopri5.hip", "api.hip"]
+HEADERS = [os.path.join(_CSRC, "cde_common.h"), os.path.join(_CSRC, "cde_mfma.h"),
+           os.path.join(_HERE, "..", "include", "cde_mi355x.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC"]
 
 F32, F64 = 0, 1
@@ -73,6 +74,10 @@ _SIGNATURES = {
                                 _i64, _i, _i, _p, _sz, _i64, _i64, _p]),
     "cde_dopri5_advance_mlp": (_i, [_p, _p, _i64, _i, _p, _p, _i64, _p, _p, _i, _p, _p, _i64, _p, _i64, _d, _d, _d, _d, _d,
                                     _p, _i64, _i64, _i64, _i, _p, _sz, _i64, _i64, _p]),
+    "cde_rk4_adjoint_mlp_workspace_bytes": (_sz, [_i64]),
+    "cde_rk4_adjoint_mlp_prepare": (_i, [_p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _i64, _i64, _i, _i, _p, _sz, _p]),
+    "cde_rk4_adjoint_mlp_sweep": (_i, [_p, _p, _i64, _i, _i, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64,
+                                       _i64, _i, _i, _p, _sz, _p]),
     "cde_rk4_adjoint_linear": (_i, [_p, _p, _i64, _i, _p, _p, _i, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _i64, _i64,
                                     _i64, _i, _i, _i, _p, _sz, _p]),
 }

@@ -112,6 +112,7 @@ class _Grids:
         self.n_sgrid = sgrid.numel()
         self.sgrid = sgrid.to(device)
         self.seg_off = torch.tensor(offsets, dtype=torch.int64).to(device)
+        self.seg_off_host = offsets
 
 
 def _grids_for(t_host, step_size, adjoint_step_size, device):
@@ -208,15 +209,25 @@ class _Plan:
 
 
 class _MlpPlan:
-    """Forward-only fused RK4 solve for the two-layer field (K2m, cde_rk4_forward_mlp)."""
+    """Fused RK4 solves for the two-layer field: forward (K2m, cde_rk4_forward_mlp) and continuous-adjoint backward
+    (K3m sweep + two library GEMMs, cde_rk4_adjoint_mlp_*)."""
 
-    def __init__(self, path, field, batch, H, C, t, step_size):
+    scratch_budget = 3 << 30        # bytes of HBM the backward sweep may use for its per-stage factors
+
+    def __init__(self, path, field, batch, H, C, t, step_size, adjoint_step_size=None):
         coeffs, knots, _ = path._native_inputs()
         self.coeffs, self.knots = coeffs, knots
         self.n_intervals, self.degree = path._n_intervals(), path._degree
         self.field, self.batch, self.B, self.H, self.C = field, batch, coeffs.size(0), H, C
         self.device = coeffs.device
-        self.grids = _grids_for(_to_host(t), step_size, step_size, self.device)
+        self.grids = _grids_for(_to_host(t), step_size, step_size if adjoint_step_size is None else adjoint_step_size,
+                                self.device)
+        self.n_out = self.grids.n_out
+
+    def _weights(self):
+        f = self.field
+        return (f.hidden.weight.detach().contiguous(), f.hidden.bias.detach().contiguous(),
+                f.output.weight.detach().contiguous(), f.output.bias.detach().contiguous())
 
     def run(self, z0):
         lib = _lib.load()
@@ -226,8 +237,7 @@ class _MlpPlan:
         stage_index = torch.empty(max(n_stage, 1), dtype=torch.int64, device=self.device)
         stage_frac = torch.empty(max(n_stage, 1), dtype=torch.float32, device=self.device)
         z0c = z0.detach().reshape(self.B, self.H).contiguous()
-        w1, b1 = f.hidden.weight.detach().contiguous(), f.hidden.bias.detach().contiguous()
-        w2, b2 = f.output.weight.detach().contiguous(), f.output.bias.detach().contiguous()
+        w1, b1, w2, b2 = self._weights()
         _lib.check(lib.cde_rk4_forward_mlp(
             _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w1), _lib.ptr(b1),
             w1.size(0), _lib.ptr(w2), _lib.ptr(b2), f.act, _lib.ptr(z0c), _lib.ptr(g.grid), g.grid.numel(),
@@ -235,6 +245,87 @@ class _MlpPlan:
             _lib.dtype_enum(g.time_dtype), _lib.ptr(stage_index), _lib.ptr(stage_frac), _lib.stream_ptr(self.device)),
             "cde_rk4_forward_mlp")
         return out.reshape(*self.batch, g.n_out, self.H)
+
+    @staticmethod
+    def _reduce(left, right, stages, B):
+        """left^T @ right over (stages * B) rows, split into enough batched GEMMs to fill the GPU."""
+        split = 8 if B % 8 == 0 and B >= 4096 else 1
+        groups = stages * split
+        return torch.bmm(left.view(groups, -1, left.size(1)).transpose(1, 2), right.view(groups, -1, right.size(1))).sum(0)
+
+    def run_adjoint(self, z_saved, grad_out):
+        """torchdiffeq's odeint_adjoint backward for this field: per output interval (last to first) the augmented
+        state is integrated in reversed time by K3m in chunks of steps; each chunk's per-stage factors (in HBM) are
+        reduced into the parameter gradients by two GEMMs whose extra "ones" column yields the bias gradients."""
+        lib = _lib.load()
+        g, f = self.grids, self.field
+        B, H, C = self.B, self.H, self.C
+        dev, f32 = self.device, _lib.dtype_enum(torch.float32)
+        w1, b1, w2, b2 = self._weights()
+        width = w1.size(0)
+        nbytes = lib.cde_rk4_adjoint_mlp_workspace_bytes(g.n_sgrid)
+        workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        stream = _lib.stream_ptr(dev)
+        tdt = _lib.dtype_enum(g.time_dtype)
+        z_saved = z_saved.detach().reshape(B, self.n_out, H)
+        grad_out = grad_out.detach().reshape(B, self.n_out, H)
+        y = z_saved[:, -1].contiguous()
+        a = grad_out[:, -1].to(torch.float32).contiguous()
+        acc2 = torch.zeros(256, 132, dtype=torch.float32, device=dev)
+        acc1 = torch.zeros(128, 36, dtype=torch.float32, device=dev)
+        if g.n_sgrid > 1:
+            _lib.check(lib.cde_rk4_adjoint_mlp_prepare(
+                _lib.ptr(self.knots), self.n_intervals, _lib.ptr(g.sgrid), g.n_sgrid, _lib.ptr(w1), _lib.ptr(b1), width,
+                _lib.ptr(w2), _lib.ptr(b2), C, H, f32, tdt, _lib.ptr(workspace), nbytes, stream),
+                "cde_rk4_adjoint_mlp_prepare")
+            row_bytes = (132 + 256 + 128 + 36) * 4
+            longest = max(g.seg_off_host[p + 1] - 1 - g.seg_off_host[p] for p in range(self.n_out - 1))
+            chunk = max(1, min(longest, self.scratch_budget // (row_bytes * 4 * B)))
+            rows = chunk * 4 * B
+            U = torch.zeros(rows, 132, dtype=torch.float32, device=dev)
+            U[:, 128] = 1
+            Z = torch.zeros(rows, 36, dtype=torch.float32, device=dev)
+            Z[:, 32] = 1
+            G2 = torch.empty(rows, 256, dtype=torch.float32, device=dev)
+            G1 = torch.empty(rows, 128, dtype=torch.float32, device=dev)
+        for p in range(self.n_out - 1):
+            k, k_end = g.seg_off_host[p], g.seg_off_host[p + 1] - 1
+            while k < k_end:
+                ke = min(k_end, k + chunk)
+                _lib.check(lib.cde_rk4_adjoint_mlp_sweep(
+                    _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, f.act, _lib.ptr(y),
+                    _lib.ptr(a), _lib.ptr(g.sgrid), g.n_sgrid, k, ke, _lib.ptr(U), _lib.ptr(G2), _lib.ptr(G1),
+                    _lib.ptr(Z), B, C, H, f32, tdt, _lib.ptr(workspace), nbytes, stream), "cde_rk4_adjoint_mlp_sweep")
+                stages = 4 * (ke - k)
+                n = stages * B
+                acc2 += self._reduce(G2[:n], U[:n], stages, B)
+                acc1 += self._reduce(G1[:n], Z[:n], stages, B)
+                k = ke
+            i_out = self.n_out - 1 - p
+            y.copy_(z_saved[:, i_out - 1])                 # torchdiffeq: re-seed z from the stored forward solution
+            a += grad_out[:, i_out - 1]                    # and add the incoming gradient at that output time
+        grad_w2 = acc2[:, :width].reshape(32, 8, width)[:H, :C].reshape(H * C, width)
+        grad_b2 = acc2[:, 128].reshape(32, 8)[:H, :C].reshape(H * C)
+        grad_w1 = acc1[:width, :H].contiguous()
+        grad_b1 = acc1[:width, 32].contiguous()
+        return a.reshape(*self.batch, H), grad_w1, grad_b1, grad_w2, grad_b2
+
+
+class _FusedMlpRK4(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z0, w1, b1, w2, b2, plan):
+        out = plan.run(z0)
+        ctx.plan = plan
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (out,) = ctx.saved_tensors
+        grad_z0, gw1, gb1, gw2, gb2 = ctx.plan.run_adjoint(out, grad_out)
+        need = ctx.needs_input_grad
+        return (grad_z0 if need[0] else None, gw1 if need[1] else None, gb1 if need[2] else None,
+                gw2 if need[3] else None, gb2 if need[4] else None, None)
 
 
 def _mlp_fusable(field, H, C, z0, packed):
@@ -453,6 +544,19 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         p.requires_grad for p in (func.parameters() if isinstance(func, torch.nn.Module) else ())))
     fused = (field is not None and ((method == "rk4" and (adjoint or not wants_grad))
                                     or (method == "dopri5" and not wants_grad)))
+    if (mlp is not None and wants_grad and adjoint and method == "rk4" and variant != _lib.VARIANT_GENERIC
+            and set(options or ()) <= {"step_size"} and set(kwargs.get("adjoint_options") or ()) <= {"step_size"}
+            and kwargs.get("adjoint_method") in (None, "rk4") and kwargs.get("adjoint_params") is None
+            and isinstance(t, torch.Tensor) and t.dim() == 1 and t.is_floating_point() and t.numel() >= 1
+            and not t.requires_grad):
+        # two-layer field, training: fused forward (K2m) + continuous-adjoint sweep (K3m) and two GEMMs
+        t_host = _to_host(t)
+        if t_host.numel() == 1 or bool((t_host[1:] > t_host[:-1]).all()):
+            step = _parse_fixed_options(options, "solver")
+            adj_opts = kwargs.get("adjoint_options")
+            adj_step = step if adj_opts is None else _parse_fixed_options(adj_opts, "adjoint")
+            plan = _MlpPlan(X, mlp, batch, H, C, t, step, adj_step)
+            return _FusedMlpRK4.apply(z0, mlp.hidden.weight, mlp.hidden.bias, mlp.output.weight, mlp.output.bias, plan)
     if (mlp is not None and not wants_grad and variant != _lib.VARIANT_GENERIC
             and isinstance(t, torch.Tensor) and t.dim() == 1 and t.is_floating_point() and t.numel() >= 1):
         # two-layer field, nothing to differentiate: the fused forward kernels (K2m / K4 with the two-layer field)

@@ -29,6 +29,15 @@ int launch_adjoint_mfma(const void*, const void*, int64_t, int, const void*, con
                         const void*, const void*, const int64_t*, int64_t, void*, void*, void*, int64_t, int64_t,
                         int64_t, const int64_t*, const void*, float*, hipStream_t);
 
+// from rk4_mlp_adjoint.hip
+size_t mlp_adjoint_image_bytes();
+int launch_mlp_adjoint_images(const void*, const void*, int64_t, const void*, const void*, int64_t, int64_t, float*,
+                              hipStream_t);
+template <typename TT>
+int launch_mlp_adjoint_sweep(const void*, const void*, int64_t, int, int, const float*, void*, void*, const void*,
+                             int64_t, int64_t, const int64_t*, const void*, void*, void*, void*, void*, int64_t,
+                             int64_t, int64_t, hipStream_t);
+
 // Stage table: for solver step k over [grid[k], grid[k+1]] and RK stage j, the control interval
 // and fractional part at the stage time -- what CubicSpline._interpret_t (interpolation_cubic.py:
 // 315-322) returns when torchdiffeq's rk4 evaluates the vector field there.  One lane per entry.
@@ -200,5 +209,66 @@ extern "C" int cde_rk4_adjoint_linear(const void* coeffs, const void* knots, int
   if (dtype == CDE_F64 && time_dtype == CDE_F64) CDE_CALL(double, double);
   if (dtype == CDE_F64 && time_dtype == CDE_F32) CDE_CALL(double, float);
 #undef CDE_CALL
+  return CDE_ERR_DTYPE;
+}
+
+// ---------------------------------------------------------------------------------------------- K3m
+// workspace: [stage_index: 4*(n_sgrid-1) int64][stage_frac: 4*(n_sgrid-1) f32][weight images]
+static inline size_t mlp_ws_frac_offset(int64_t n_steps) { return cde::align256((size_t)(4 * n_steps) * sizeof(int64_t)); }
+static inline size_t mlp_ws_image_offset(int64_t n_steps) {
+  return mlp_ws_frac_offset(n_steps) + cde::align256((size_t)(4 * n_steps) * sizeof(float));
+}
+
+extern "C" size_t cde_rk4_adjoint_mlp_workspace_bytes(int64_t n_sgrid) {
+  const int64_t n_steps = n_sgrid > 1 ? n_sgrid - 1 : 0;
+  return mlp_ws_image_offset(n_steps) + cde::align256(cde::mlp_adjoint_image_bytes());
+}
+
+extern "C" int cde_rk4_adjoint_mlp_prepare(const void* knots, int64_t n_intervals, const void* sgrid, int64_t n_sgrid,
+                                           const void* W1, const void* bias1, int64_t width, const void* W2,
+                                           const void* bias2, int64_t C, int64_t H, int dtype, int time_dtype,
+                                           void* workspace, size_t workspace_bytes, void* stream) {
+  if (C < 1 || H < 1 || width < 1 || n_intervals < 1 || n_sgrid < 0) return CDE_ERR_SHAPE;
+  if (dtype != CDE_F32) return dtype == CDE_F64 ? CDE_ERR_UNSUPPORTED : CDE_ERR_DTYPE;
+  if (H > 32 || C > 8 || width > 128) return CDE_ERR_UNSUPPORTED;
+  if (!knots || !W1 || !bias1 || !W2 || !bias2 || !workspace || (n_sgrid > 1 && !sgrid)) return CDE_ERR_NULL;
+  if (workspace_bytes < cde_rk4_adjoint_mlp_workspace_bytes(n_sgrid)) return CDE_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n_steps = n_sgrid > 1 ? n_sgrid - 1 : 0;
+  unsigned char* base = (unsigned char*)workspace;
+  int rc;
+  if (time_dtype == CDE_F32)
+    rc = cde::fill_stage_table<float, float>(knots, n_intervals, sgrid, n_steps, 1, (int64_t*)base,
+                                             base + mlp_ws_frac_offset(n_steps), s);
+  else if (time_dtype == CDE_F64)
+    rc = cde::fill_stage_table<float, double>(knots, n_intervals, sgrid, n_steps, 1, (int64_t*)base,
+                                              base + mlp_ws_frac_offset(n_steps), s);
+  else return CDE_ERR_DTYPE;
+  if (rc != CDE_OK) return rc;
+  return cde::launch_mlp_adjoint_images(W1, bias1, width, W2, bias2, C, H, (float*)(base + mlp_ws_image_offset(n_steps)), s);
+}
+
+extern "C" int cde_rk4_adjoint_mlp_sweep(const void* coeffs, const void* knots, int64_t n_intervals, int degree, int act,
+                                         void* y_state, void* a_state, const void* sgrid, int64_t n_sgrid,
+                                         int64_t k_begin, int64_t k_end, void* U, void* G2, void* G1, void* Z, int64_t B,
+                                         int64_t C, int64_t H, int dtype, int time_dtype, const void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  if (B < 1 || C < 1 || H < 1 || n_intervals < 1 || k_begin < 0 || k_end < k_begin || k_end > n_sgrid - 1) return CDE_ERR_SHAPE;
+  if (dtype != CDE_F32) return dtype == CDE_F64 ? CDE_ERR_UNSUPPORTED : CDE_ERR_DTYPE;
+  if (H > 32 || C > 8) return CDE_ERR_UNSUPPORTED;
+  if (!coeffs || !knots || !y_state || !a_state || !sgrid || !U || !G2 || !G1 || !Z || !workspace) return CDE_ERR_NULL;
+  if (workspace_bytes < cde_rk4_adjoint_mlp_workspace_bytes(n_sgrid)) return CDE_ERR_WORKSPACE;
+  const int64_t n_steps = n_sgrid - 1;
+  const unsigned char* base = (const unsigned char*)workspace;
+  const int64_t* stage_index = (const int64_t*)base;
+  const void* stage_frac = base + mlp_ws_frac_offset(n_steps);
+  const float* img = (const float*)(base + mlp_ws_image_offset(n_steps));
+  hipStream_t s = (hipStream_t)stream;
+  if (time_dtype == CDE_F32)
+    return cde::launch_mlp_adjoint_sweep<float>(coeffs, knots, n_intervals, degree, act, img, y_state, a_state, sgrid,
+                                                k_begin, k_end, stage_index, stage_frac, U, G2, G1, Z, B, C, H, s);
+  if (time_dtype == CDE_F64)
+    return cde::launch_mlp_adjoint_sweep<double>(coeffs, knots, n_intervals, degree, act, img, y_state, a_state, sgrid,
+                                                 k_begin, k_end, stage_index, stage_frac, U, G2, G1, Z, B, C, H, s);
   return CDE_ERR_DTYPE;
 }

@@ -1,0 +1,304 @@
+// rk4_mlp_adjoint.hip -- K3m: continuous-adjoint reverse sweep for the two-layer vector field
+//   f(z) = reshape_{HxC}( act( W2 relu(W1 z + b1) + b2 ) ) dX          (example/time_series_classification.py:20-51)
+//
+// K3 keeps dL/dW (256 x 32 per wave) in accumulator registers for the whole sweep.  Here dL/dW2 is 256 x 128 per
+// wave -- four register files' worth -- so the sweep kernel only integrates the augmented state (z, a) backwards
+// and streams the per-stage factors of the parameter gradients to HBM,
+//     U  [row][132]  relu(W1 z + b1) (128 padded) | 1 | 0 0 0          row = (stage, series)
+//     G2 [row][256]  w ds dL/dY2      (h*8 + c, padded layout)
+//     G1 [row][128]  w ds dL/dY1
+//     Z  [row][36]   z (32 padded) | 1 | 0 0 0
+// and the host turns them into   dW2 | db2 = G2^T U,   dW1 | db1 = G1^T Z   with library GEMMs (the "1" columns
+// yield the bias gradients).  288 GB of HBM make this cheap: 2.2 KB per series and stage, swept in chunks of steps.
+//
+// Per stage and wave (16 series, lane (n, q) owns hidden units q, 4+q, .., 28+q of z and a; 16x16x4 MFMAs):
+//   layer 1       64 MFMAs   pre1 = W1 z + b1  -> u = relu(pre1), mask            (A from LDS)
+//   layer 2      512 MFMAs   Y2 = W2 u + b2 per tile pair P (4 hidden units x 8 channels) (A from LDS)
+//                in-lane     t = act(Y2), f_h = sum_c t dX_c, g2 = a_h dX_c act'(Y2)
+//   gu          512 MFMAs   gu += W2[(h,c), :]^T g2   K step (P, c): the lane feeds its OWN g2 register; A operands
+//                            streamed from L2 (a second 128 KB image does not fit the LDS beside the first)
+//   va           64 MFMAs   va = W1^T (gu * mask)                                  (A from L2)
+// 1152 MFMAs per stage = 76.3 MFLOP per series per solve for the sweep itself.
+#include "cde_mfma.h"
+
+namespace cde {
+
+constexpr int W2T_FLOATS = 8 * 8 * 2 * 64 * 4;            // [P][T1][group of 4 channels][lane][4]
+constexpr int W1T_FLOATS = 2 * 8 * 64 * 4;                // [tile][T1][lane][4]
+constexpr int MLP_ADJ_IMAGE_FLOATS = MLP16_LDS_FLOATS + W2T_FLOATS + W1T_FLOATS;
+constexpr int U_COLS = 132, G2_COLS = 256, G1_COLS = 128, Z_COLS = 36;
+
+__device__ __forceinline__ float mlp_adj_image(const float* __restrict__ W1, const float* __restrict__ b1,
+                                               const float* __restrict__ W2, const float* __restrict__ b2, int e,
+                                               MlpDims d) {
+  if (e < MLP16_LDS_FLOATS) return mlp16_image(W1, b1, W2, b2, e, d);
+  e -= MLP16_LDS_FLOATS;
+  const int j = e & 3, l = (e >> 2) & 63, i = l & 15, kq = l >> 4;
+  if (e < W2T_FLOATS) {
+    // gu tile T1 (rows = hidden-layer units 16*T1 + i), K step (P, c = 4*grp + j): lane quarter kq feeds (h = 4P+kq, c)
+    const int g = e >> 8, grp = g & 1, T1 = (g >> 1) & 7, P = g >> 4;
+    const int h = 4 * P + kq, c = 4 * grp + j, col = 16 * T1 + i;
+    return (h < d.H && c < d.C && col < d.width) ? W2[(h * d.C + c) * d.width + col] : 0.f;
+  }
+  e -= W2T_FLOATS;
+  // va tile T (row i <-> z unit 4*(4T + (i&3)) + (i>>2), so register r of lane (n, q) is unit 4*(4T+r) + q),
+  // K step (T1, r = j): lane quarter kq feeds hidden-layer unit 16*T1 + 4*kq + j
+  const int g = (e >> 8), T = g >> 3, T1 = g & 7;
+  const int unit = 16 * T1 + 4 * kq + j, k = 4 * (4 * T + (i & 3)) + (i >> 2);
+  return (unit < d.width && k < d.H) ? W1[unit * d.H + k] : 0.f;
+}
+
+__global__ void mlp_adj_image_kernel(const float* __restrict__ W1, const float* __restrict__ b1,
+                                     const float* __restrict__ W2, const float* __restrict__ b2,
+                                     float* __restrict__ img, MlpDims d) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < MLP_ADJ_IMAGE_FLOATS) img[e] = mlp_adj_image(W1, b1, W2, b2, e, d);
+}
+
+__device__ __forceinline__ void stream_store4(float* p, float a, float b, float c, float d) {
+  // written once, read once by the GEMM much later: keep it out of the way of the L2-resident weight images
+  __builtin_nontemporal_store(f32x4{a, b, c, d}, reinterpret_cast<f32x4*>(p));
+}
+
+template <typename TT, int DEGREE, int ACT>
+__global__ __launch_bounds__(512, 2) void rk4_adjoint_mlp_sweep(
+    const float* __restrict__ coeffs, const float* __restrict__ knots, int64_t n_intervals,
+    const float* __restrict__ img, float* __restrict__ y_state, float* __restrict__ a_state,
+    const TT* __restrict__ sgrid, int64_t k_begin, int64_t k_end, const int64_t* __restrict__ stage_index,
+    const float* __restrict__ stage_frac, float* __restrict__ U, float* __restrict__ G2, float* __restrict__ G1,
+    float* __restrict__ Z, int64_t B, Dims dims) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  {
+    const float4* src = reinterpret_cast<const float4*>(img);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    for (int i = threadIdx.x; i < MLP16_LDS_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int Hr = dims.H, Cr = dims.C;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 15, q = lane >> 4;
+  const int64_t tile = (int64_t)blockIdx.x * 8 + wave;
+  if (tile * 16 >= B) return;
+  const int64_t series = tile * 16 + n;
+  const bool valid = series < B;
+  const int64_t sc = valid ? series : B - 1;
+  const float4* w2t_base = reinterpret_cast<const float4*>(img + MLP16_LDS_FLOATS) + lane;
+  const float4* w1t_base = reinterpret_cast<const float4*>(img + MLP16_LDS_FLOATS + W2T_FLOATS) + lane;
+
+  const int ua = q, ub = 16 + q;                                     // this lane's units: q, 4+q, .., 28+q
+  f32x4 ya = load_units4<4>(y_state + sc * Hr, ua, Hr), yb = load_units4<4>(y_state + sc * Hr, ub, Hr);
+  f32x4 aa = load_units4<4>(a_state + sc * Hr, ua, Hr), ab = load_units4<4>(a_state + sc * Hr, ub, Hr);
+  if (!valid) { aa = f32x4{0.f, 0.f, 0.f, 0.f}; ab = aa; }          // a == 0 stays 0: padded lanes contribute nothing
+
+  int64_t idx = stage_index[4 * k_begin];
+  float frac = stage_frac[4 * k_begin];
+  Row<DEGREE> row = load_row<DEGREE>(coeffs, sc, n_intervals, idx, Cr);
+
+  for (int64_t k = k_begin; k < k_end; ++k) {
+    const float ds = (float)(sgrid[k + 1] - sgrid[k]);
+    f32x4 ky1a, ky1b, ky2a, ky2b, ka1a, ka1b, ka2a, ka2b;
+    f32x4 za = ya, zb = yb, sa = aa, sb = ab;                        // stage values of z and a
+#pragma unroll
+    for (int stage = 0; stage < 4; ++stage) {
+      float dX[MC];
+      const float width = DEGREE == CDE_PATH_LINEAR ? knots[idx + 1] - knots[idx] : 1.f;
+      control_slope<DEGREE>(row, frac, width, dX);
+      const int64_t e_next = 4 * k + stage + 1;
+      const bool more = e_next < 4 * k_end;
+      const int64_t nidx = more ? stage_index[e_next] : idx;
+      const float nfrac = more ? stage_frac[e_next] : frac;
+      if (nidx != idx) row = load_row<DEGREE>(coeffs, sc, n_intervals, nidx, Cr);
+      const float wq = ((stage == 0 || stage == 3) ? 0.125f : 0.375f) * ds;     // 3/8-rule quadrature weight
+      const int64_t out_row = ((k - k_begin) * 4 + stage) * B + series;          // (stage, series)
+
+      int opaque = 0;                                                // keeps the LDS reads inside the stage
+      asm volatile("" : "+v"(opaque));
+      const float4* w1 = reinterpret_cast<const float4*>(lds) + lane + opaque;
+      const float4* bb1 = reinterpret_cast<const float4*>(lds + W1M_FLOATS) + q + opaque;
+      const float4* w2 = reinterpret_cast<const float4*>(lds + W1M_FLOATS + B1M_FLOATS) + lane + opaque;
+      const float4* bb2 = reinterpret_cast<const float4*>(lds + W1M_FLOATS + B1M_FLOATS + W2M_FLOATS) + q + opaque;
+      const float4* w2t = w2t_base + opaque;                         // L2-resident images: same trick, or LICM hoists
+      const float4* w1t = w1t_base + opaque;                         // all 144 loads out of the solve
+      const float zs[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
+      const float as[8] = {sa[0], sa[1], sa[2], sa[3], sb[0], sb[1], sb[2], sb[3]};
+
+      // ---- layer 1: u = relu(W1 z + b1); `mask` bit s2 = (pre-activation of the lane's s2-th hidden unit > 0)
+      float u[32];
+      unsigned mask = 0;
+#pragma unroll
+      for (int TP = 0; TP < 4; ++TP) {
+        const float4 c0 = bb1[8 * TP], c1 = bb1[8 * TP + 4];
+        f32x4 y0 = {c0.x, c0.y, c0.z, c0.w}, y1 = {c1.x, c1.y, c1.z, c1.w};
+        const float4 g00 = w1[(4 * TP) * 64], g01 = w1[(4 * TP + 1) * 64], g10 = w1[(4 * TP + 2) * 64], g11 = w1[(4 * TP + 3) * 64];
+        const float a0[8] = {g00.x, g00.y, g00.z, g00.w, g01.x, g01.y, g01.z, g01.w};
+        const float a1[8] = {g10.x, g10.y, g10.z, g10.w, g11.x, g11.y, g11.z, g11.w};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { y0 = mfma16(a0[s], zs[s], y0); y1 = mfma16(a1[s], zs[s], y1); }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          u[8 * TP + r] = fmaxf(y0[r], 0.f);
+          u[8 * TP + 4 + r] = fmaxf(y1[r], 0.f);
+          mask |= (y0[r] > 0.f ? 1u : 0u) << (8 * TP + r);
+          mask |= (y1[r] > 0.f ? 1u : 0u) << (8 * TP + 4 + r);
+        }
+      }
+      if (valid) {
+        float* urow = U + out_row * U_COLS + 4 * q;                  // hidden-layer units 16*T1 + 4q + r
+#pragma unroll
+        for (int T1 = 0; T1 < 8; ++T1) stream_store4(urow + 16 * T1, u[4 * T1], u[4 * T1 + 1], u[4 * T1 + 2], u[4 * T1 + 3]);
+        float* zrow = Z + out_row * Z_COLS;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) if (4 * m + q < Hr) zrow[4 * m + q] = zs[m];
+      }
+
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- layer 2, activation, contraction, dL/dY2, and gu += W2^T dL/dY2, one tile pair at a time
+      f32x4 gu[8];
+#pragma unroll
+      for (int T1 = 0; T1 < 8; ++T1) gu[T1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 fa, fb;
+#pragma unroll
+      for (int P = 0; P < 8; ++P) {
+        const float4 c0 = bb2[8 * P], c1 = bb2[8 * P + 4];
+        f32x4 y0 = {c0.x, c0.y, c0.z, c0.w}, y1 = {c1.x, c1.y, c1.z, c1.w};
+        const float4* t0 = w2 + (16 * P) * 64;
+        const float4* t1 = w2 + (16 * P + 8) * 64;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          const float4 a0 = t0[g * 64], a1 = t1[g * 64];
+          y0 = mfma16(a0.x, u[4 * g], y0);     y1 = mfma16(a1.x, u[4 * g], y1);
+          y0 = mfma16(a0.y, u[4 * g + 1], y0); y1 = mfma16(a1.y, u[4 * g + 1], y1);
+          y0 = mfma16(a0.z, u[4 * g + 2], y0); y1 = mfma16(a1.z, u[4 * g + 2], y1);
+          y0 = mfma16(a0.w, u[4 * g + 3], y0); y1 = mfma16(a1.w, u[4 * g + 3], y1);
+        }
+        float g2[8];
+        float f = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const float t = activate<ACT>(c < 4 ? y0[c] : y1[c - 4]);
+          f = c == 0 ? t * dX[0] : __builtin_fmaf(t, dX[c], f);
+          const float slope = ACT == CDE_ACT_TANH ? __builtin_fmaf(-t, t, 1.f) : 1.f;
+          g2[c] = as[P] * (dX[c] * slope);
+        }
+        if (P < 4) fa[P] = f; else fb[P - 4] = f;
+        if (valid) {
+          float* grow = G2 + out_row * G2_COLS + 32 * P + 8 * q;     // rows (h = 4P+q, c = 0..7) of the padded layout
+          stream_store4(grow, g2[0] * wq, g2[1] * wq, g2[2] * wq, g2[3] * wq);
+          stream_store4(grow + 4, g2[4] * wq, g2[5] * wq, g2[6] * wq, g2[7] * wq);
+        }
+        const float4* tp = w2t + (P * 16) * 64;                      // [(P*8 + T1)*2 + grp]
+#pragma unroll
+        for (int grp = 0; grp < 2; ++grp) {
+#pragma unroll
+          for (int T1 = 0; T1 < 8; ++T1) {
+            const float4 a4 = tp[(2 * T1 + grp) * 64];
+            gu[T1] = mfma16(a4.x, g2[4 * grp], gu[T1]);
+            gu[T1] = mfma16(a4.y, g2[4 * grp + 1], gu[T1]);
+            gu[T1] = mfma16(a4.z, g2[4 * grp + 2], gu[T1]);
+            gu[T1] = mfma16(a4.w, g2[4 * grp + 3], gu[T1]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- dL/dY1 = gu * relu'(pre1);  va = W1^T dL/dY1
+      float g1[32];
+#pragma unroll
+      for (int s2 = 0; s2 < 32; ++s2) g1[s2] = (mask >> s2) & 1u ? gu[s2 >> 2][s2 & 3] : 0.f;
+      if (valid) {
+        float* grow = G1 + out_row * G1_COLS + 4 * q;
+#pragma unroll
+        for (int T1 = 0; T1 < 8; ++T1)
+          stream_store4(grow + 16 * T1, g1[4 * T1] * wq, g1[4 * T1 + 1] * wq, g1[4 * T1 + 2] * wq, g1[4 * T1 + 3] * wq);
+      }
+      f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = va;
+#pragma unroll
+      for (int T1 = 0; T1 < 8; ++T1) {
+        const float4 a0 = w1t[T1 * 64], a1 = w1t[(8 + T1) * 64];
+        va = mfma16(a0.x, g1[4 * T1], va);     vb = mfma16(a1.x, g1[4 * T1], vb);
+        va = mfma16(a0.y, g1[4 * T1 + 1], va); vb = mfma16(a1.y, g1[4 * T1 + 1], vb);
+        va = mfma16(a0.z, g1[4 * T1 + 2], va); vb = mfma16(a1.z, g1[4 * T1 + 2], vb);
+        va = mfma16(a0.w, g1[4 * T1 + 3], va); vb = mfma16(a1.w, g1[4 * T1 + 3], vb);
+      }
+
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- reverse-time dynamics: dz/ds = -f, da/ds = +a^T df/dz; torchdiffeq 3/8 rule, association preserved
+      const f32x4 kya = -fa, kyb = -fb, kaa = va, kab = vb;
+      const float third = (float)(1.0 / 3.0);
+      if (stage == 0) {
+        ky1a = kya; ky1b = kyb; ka1a = kaa; ka1b = kab;
+        za = ya + ds * ky1a * third; zb = yb + ds * ky1b * third;
+        sa = aa + ds * ka1a * third; sb = ab + ds * ka1b * third;
+      } else if (stage == 1) {
+        ky2a = kya; ky2b = kyb; ka2a = kaa; ka2b = kab;
+        za = ya + ds * (ky2a - ky1a * third); zb = yb + ds * (ky2b - ky1b * third);
+        sa = aa + ds * (ka2a - ka1a * third); sb = ab + ds * (ka2b - ka1b * third);
+      } else if (stage == 2) {
+        za = ya + ds * (ky1a - ky2a + kya); zb = yb + ds * (ky1b - ky2b + kyb);
+        sa = aa + ds * (ka1a - ka2a + kaa); sb = ab + ds * (ka1b - ka2b + kab);
+        ky1a = ky1a + 3.f * (ky2a + kya); ky1b = ky1b + 3.f * (ky2b + kyb);
+        ka1a = ka1a + 3.f * (ka2a + kaa); ka1b = ka1b + 3.f * (ka2b + kab);
+      } else {
+        za = ya + (ky1a + kya) * ds * 0.125f; zb = yb + (ky1b + kyb) * ds * 0.125f;
+        sa = aa + (ka1a + kaa) * ds * 0.125f; sb = ab + (ka1b + kab) * ds * 0.125f;
+      }
+      idx = nidx; frac = nfrac;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    ya = za; yb = zb; aa = sa; ab = sb;
+  }
+  if (valid) {
+    store_units4<4>(y_state + series * Hr, ua, Hr, ya);
+    store_units4<4>(y_state + series * Hr, ub, Hr, yb);
+    store_units4<4>(a_state + series * Hr, ua, Hr, aa);
+    store_units4<4>(a_state + series * Hr, ub, Hr, ab);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ host side
+size_t mlp_adjoint_image_bytes() { return (size_t)MLP_ADJ_IMAGE_FLOATS * sizeof(float); }
+
+int launch_mlp_adjoint_images(const void* W1, const void* b1, int64_t width, const void* W2, const void* b2, int64_t C,
+                              int64_t H, float* img, hipStream_t s) {
+  mlp_adj_image_kernel<<<(MLP_ADJ_IMAGE_FLOATS + 255) / 256, 256, 0, s>>>(
+      (const float*)W1, (const float*)b1, (const float*)W2, (const float*)b2, img, MlpDims{(int)H, (int)C, (int)width});
+  return check_launch();
+}
+
+template <typename TT>
+int launch_mlp_adjoint_sweep(const void* coeffs, const void* knots, int64_t n_intervals, int degree, int act,
+                             const float* img, void* y_state, void* a_state, const void* sgrid, int64_t k_begin,
+                             int64_t k_end, const int64_t* stage_index, const void* stage_frac, void* U, void* G2,
+                             void* G1, void* Z, int64_t B, int64_t C, int64_t H, hipStream_t s) {
+  if (k_end <= k_begin) return CDE_OK;
+  const Dims dims{(int)H, (int)C};
+  const unsigned blocks = (unsigned)((B + 127) / 128);
+  const size_t lds = (size_t)MLP16_LDS_FLOATS * sizeof(float);
+#define CDE_SWEEP(D, A)                                                                                            \
+  do {                                                                                                             \
+    (void)hipFuncSetAttribute((const void*)rk4_adjoint_mlp_sweep<TT, D, A>,                                        \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
+    rk4_adjoint_mlp_sweep<TT, D, A><<<blocks, 512, lds, s>>>(                                                      \
+        (const float*)coeffs, (const float*)knots, n_intervals, img, (float*)y_state, (float*)a_state,             \
+        (const TT*)sgrid, k_begin, k_end, stage_index, (const float*)stage_frac, (float*)U, (float*)G2, (float*)G1, \
+        (float*)Z, B, dims);                                                                                       \
+  } while (0)
+  if (degree != CDE_PATH_CUBIC && degree != CDE_PATH_LINEAR) return CDE_ERR_UNSUPPORTED;
+  if (act == CDE_ACT_NONE) {
+    if (degree == CDE_PATH_CUBIC) CDE_SWEEP(CDE_PATH_CUBIC, CDE_ACT_NONE); else CDE_SWEEP(CDE_PATH_LINEAR, CDE_ACT_NONE);
+  } else if (act == CDE_ACT_TANH) {
+    if (degree == CDE_PATH_CUBIC) CDE_SWEEP(CDE_PATH_CUBIC, CDE_ACT_TANH); else CDE_SWEEP(CDE_PATH_LINEAR, CDE_ACT_TANH);
+  } else return CDE_ERR_UNSUPPORTED;
+#undef CDE_SWEEP
+  return check_launch();
+}
+
+template int launch_mlp_adjoint_sweep<float>(const void*, const void*, int64_t, int, int, const float*, void*, void*,
+                                             const void*, int64_t, int64_t, const int64_t*, const void*, void*, void*,
+                                             void*, void*, int64_t, int64_t, int64_t, hipStream_t);
+template int launch_mlp_adjoint_sweep<double>(const void*, const void*, int64_t, int, int, const float*, void*, void*,
+                                              const void*, int64_t, int64_t, const int64_t*, const void*, void*, void*,
+                                              void*, void*, int64_t, int64_t, int64_t, hipStream_t);
+
+}  // namespace cde
