@@ -15,34 +15,52 @@
 //   layer 1       64 MFMAs   pre1 = W1 z + b1  -> u = relu(pre1), mask            (A from LDS)
 //   layer 2      512 MFMAs   Y2 = W2 u + b2 per tile pair P (4 hidden units x 8 channels) (A from LDS)
 //                in-lane     t = act(Y2), f_h = sum_c t dX_c, g2 = a_h dX_c act'(Y2)
-//   gu          512 MFMAs   gu += W2[(h,c), :]^T g2   K step (P, c): the lane feeds its OWN g2 register; A operands
-//                            streamed from L2 (a second 128 KB image does not fit the LDS beside the first)
-//   va           64 MFMAs   va = W1^T (gu * mask)                                  (A from L2)
+//   gu          512 MFMAs   gu += W2[(h,c), :]^T g2   K step (P, c): the lane feeds its OWN g2 register
+//   va           64 MFMAs   va = W1^T (gu * mask)                                  (A from L2, 16 loads)
+// W2 is needed as the A operand of two products (rows = (h,c) for Y2, rows = hidden-layer units for gu); two MFMA
+// images (2 x 128 KB) do not fit the LDS and streaming one from L2 left the matrix pipe waiting on load latency
+// (measured: 34 ms per sweep vs 17 ms of MFMA time).  Instead ONE plain copy of W2 lives in LDS, row stride 132
+// floats, rows permuted so that both access patterns are bank-conflict free:
+//     physical row pr(h, c) = ((h>>2)*4 + (c>>2)*2 + ((h>>1)&1))*8 + (2*(h&3) + (c&1) + 4*((c>>1)&1)) % 8
+//   Y2:  lane (i, kq) reads 4 consecutive floats (4 K steps) of row (h = 4P + (i>>2), c = 4tb + (i&3)) at column
+//        16*T1 + 4*kq  -> ds_read_b128, every 8-lane group covers all 8 bank slots
+//   gu:  lane (i, kq) reads row (h = 4P + kq, c) at column 16*T1 + i -> ds_read_b32, 2 lanes per bank (the minimum)
+// with every (P, tb, T1) offset an instruction immediate.
 // 1152 MFMAs per stage = 76.3 MFLOP per series per solve for the sweep itself.
 #include "cde_mfma.h"
 
 namespace cde {
 
-constexpr int W2T_FLOATS = 8 * 8 * 2 * 64 * 4;            // [P][T1][group of 4 channels][lane][4]
+constexpr int W2P_STRIDE = 132;                           // floats per row of the plain W2 copy
+constexpr int W2P_FLOATS = 256 * W2P_STRIDE;
 constexpr int W1T_FLOATS = 2 * 8 * 64 * 4;                // [tile][T1][lane][4]
-constexpr int MLP_ADJ_IMAGE_FLOATS = MLP16_LDS_FLOATS + W2T_FLOATS + W1T_FLOATS;
+constexpr int ADJ_LDS_FLOATS = W1M_FLOATS + B1M_FLOATS + W2P_FLOATS + BY_FLOATS;   // [W1 image | b1 | W2 plain | b2]
+constexpr int MLP_ADJ_IMAGE_FLOATS = ADJ_LDS_FLOATS + W1T_FLOATS;
+__host__ __device__ constexpr int w2p_residue(int h3, int c3) { return (2 * h3 + (c3 & 1) + 4 * ((c3 >> 1) & 1)) & 7; }
 constexpr int U_COLS = 132, G2_COLS = 256, G1_COLS = 128, Z_COLS = 36;
 
 __device__ __forceinline__ float mlp_adj_image(const float* __restrict__ W1, const float* __restrict__ b1,
                                                const float* __restrict__ W2, const float* __restrict__ b2, int e,
                                                MlpDims d) {
-  if (e < MLP16_LDS_FLOATS) return mlp16_image(W1, b1, W2, b2, e, d);
-  e -= MLP16_LDS_FLOATS;
-  const int j = e & 3, l = (e >> 2) & 63, i = l & 15, kq = l >> 4;
-  if (e < W2T_FLOATS) {
-    // gu tile T1 (rows = hidden-layer units 16*T1 + i), K step (P, c = 4*grp + j): lane quarter kq feeds (h = 4P+kq, c)
-    const int g = e >> 8, grp = g & 1, T1 = (g >> 1) & 7, P = g >> 4;
-    const int h = 4 * P + kq, c = 4 * grp + j, col = 16 * T1 + i;
-    return (h < d.H && c < d.C && col < d.width) ? W2[(h * d.C + c) * d.width + col] : 0.f;
+  if (e < W1M_FLOATS + B1M_FLOATS) return mlp16_image(W1, b1, W2, b2, e, d);        // same layer-1 image as K2m
+  e -= W1M_FLOATS + B1M_FLOATS;
+  if (e < W2P_FLOATS) {
+    const int pr = e / W2P_STRIDE, col = e - pr * W2P_STRIDE;
+    const int r8 = pr & 7, hi = pr >> 3, hb = hi & 1, tb = (hi >> 1) & 1, P = hi >> 2;
+    // invert w2p_residue: r8 = (2*(h&3) + g(c&3)) % 8 with (h&3)>>1 == hb
+    int h3 = 0, c3 = 0;
+    for (int hh = 2 * hb; hh < 2 * hb + 2; ++hh)
+      for (int cc = 0; cc < 4; ++cc)
+        if (w2p_residue(hh, cc) == r8) { h3 = hh; c3 = cc; }
+    const int h = 4 * P + h3, c = 4 * tb + c3;
+    return (col < d.width && h < d.H && c < d.C) ? W2[(h * d.C + c) * d.width + col] : 0.f;
   }
-  e -= W2T_FLOATS;
+  e -= W2P_FLOATS;
+  if (e < BY_FLOATS) return by16_image(b2, e >> 4, (e >> 2) & 3, e & 3, Dims{d.H, d.C});
+  e -= BY_FLOATS;
   // va tile T (row i <-> z unit 4*(4T + (i&3)) + (i>>2), so register r of lane (n, q) is unit 4*(4T+r) + q),
   // K step (T1, r = j): lane quarter kq feeds hidden-layer unit 16*T1 + 4*kq + j
+  const int j = e & 3, l = (e >> 2) & 63, i = l & 15, kq = l >> 4;
   const int g = (e >> 8), T = g >> 3, T1 = g & 7;
   const int unit = 16 * T1 + 4 * kq + j, k = 4 * (4 * T + (i & 3)) + (i >> 2);
   return (unit < d.width && k < d.H) ? W1[unit * d.H + k] : 0.f;
@@ -71,7 +89,7 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_mlp_sweep(
   {
     const float4* src = reinterpret_cast<const float4*>(img);
     float4* dst = reinterpret_cast<float4*>(lds);
-    for (int i = threadIdx.x; i < MLP16_LDS_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
+    for (int i = threadIdx.x; i < ADJ_LDS_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
   }
   __syncthreads();
   const int Hr = dims.H, Cr = dims.C;
@@ -82,8 +100,12 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_mlp_sweep(
   const int64_t series = tile * 16 + n;
   const bool valid = series < B;
   const int64_t sc = valid ? series : B - 1;
-  const float4* w2t_base = reinterpret_cast<const float4*>(img + MLP16_LDS_FLOATS) + lane;
-  const float4* w1t_base = reinterpret_cast<const float4*>(img + MLP16_LDS_FLOATS + W2T_FLOATS) + lane;
+  const float4* w1t_base = reinterpret_cast<const float4*>(img + ADJ_LDS_FLOATS) + lane;
+  // lane offsets into the plain W2 copy (see the header): Y2 rows (h&3 = n>>2, c&3 = n&3), gu rows (h&3 = q, c&3 = cl)
+  const int w2y_off = ((n >> 3) * 8 + w2p_residue(n >> 2, n & 3)) * W2P_STRIDE + 4 * q;
+  int w2g_off[4];
+#pragma unroll
+  for (int cl = 0; cl < 4; ++cl) w2g_off[cl] = ((q >> 1) * 8 + w2p_residue(q, cl)) * W2P_STRIDE + n;
 
   const int ua = q, ub = 16 + q;                                     // this lane's units: q, 4+q, .., 28+q
   f32x4 ya = load_units4<4>(y_state + sc * Hr, ua, Hr), yb = load_units4<4>(y_state + sc * Hr, ub, Hr);
@@ -115,10 +137,11 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_mlp_sweep(
       asm volatile("" : "+v"(opaque));
       const float4* w1 = reinterpret_cast<const float4*>(lds) + lane + opaque;
       const float4* bb1 = reinterpret_cast<const float4*>(lds + W1M_FLOATS) + q + opaque;
-      const float4* w2 = reinterpret_cast<const float4*>(lds + W1M_FLOATS + B1M_FLOATS) + lane + opaque;
-      const float4* bb2 = reinterpret_cast<const float4*>(lds + W1M_FLOATS + B1M_FLOATS + W2M_FLOATS) + q + opaque;
-      const float4* w2t = w2t_base + opaque;                         // L2-resident images: same trick, or LICM hoists
-      const float4* w1t = w1t_base + opaque;                         // all 144 loads out of the solve
+      const float* w2p = lds + W1M_FLOATS + B1M_FLOATS + opaque;
+      const float4* bb2 = reinterpret_cast<const float4*>(lds + W1M_FLOATS + B1M_FLOATS + W2P_FLOATS) + q + opaque;
+      const float* w2y = w2p + w2y_off;
+      const float* w2g[4] = {w2p + w2g_off[0], w2p + w2g_off[1], w2p + w2g_off[2], w2p + w2g_off[3]};
+      const float4* w1t = w1t_base + opaque;                         // L2-resident image: same trick against LICM
       const float zs[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
       const float as[8] = {sa[0], sa[1], sa[2], sa[3], sb[0], sb[1], sb[2], sb[3]};
 
@@ -161,11 +184,11 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_mlp_sweep(
       for (int P = 0; P < 8; ++P) {
         const float4 c0 = bb2[8 * P], c1 = bb2[8 * P + 4];
         f32x4 y0 = {c0.x, c0.y, c0.z, c0.w}, y1 = {c1.x, c1.y, c1.z, c1.w};
-        const float4* t0 = w2 + (16 * P) * 64;
-        const float4* t1 = w2 + (16 * P + 8) * 64;
+        const float* t0 = w2y + (4 * P) * 8 * W2P_STRIDE;            // tile 2P   (tb = 0)
+        const float* t1 = w2y + (4 * P + 2) * 8 * W2P_STRIDE;        // tile 2P+1 (tb = 1)
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-          const float4 a0 = t0[g * 64], a1 = t1[g * 64];
+          const float4 a0 = *reinterpret_cast<const float4*>(t0 + 16 * g), a1 = *reinterpret_cast<const float4*>(t1 + 16 * g);
           y0 = mfma16(a0.x, u[4 * g], y0);     y1 = mfma16(a1.x, u[4 * g], y1);
           y0 = mfma16(a0.y, u[4 * g + 1], y0); y1 = mfma16(a1.y, u[4 * g + 1], y1);
           y0 = mfma16(a0.z, u[4 * g + 2], y0); y1 = mfma16(a1.z, u[4 * g + 2], y1);
@@ -186,17 +209,11 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_mlp_sweep(
           stream_store4(grow, g2[0] * wq, g2[1] * wq, g2[2] * wq, g2[3] * wq);
           stream_store4(grow + 4, g2[4] * wq, g2[5] * wq, g2[6] * wq, g2[7] * wq);
         }
-        const float4* tp = w2t + (P * 16) * 64;                      // [(P*8 + T1)*2 + grp]
 #pragma unroll
-        for (int grp = 0; grp < 2; ++grp) {
+        for (int c = 0; c < 8; ++c) {                                // K step (P, c); 8 independent accumulator chains
+          const float* rowp = w2g[c & 3] + (4 * P + 2 * (c >> 2)) * 8 * W2P_STRIDE;
 #pragma unroll
-          for (int T1 = 0; T1 < 8; ++T1) {
-            const float4 a4 = tp[(2 * T1 + grp) * 64];
-            gu[T1] = mfma16(a4.x, g2[4 * grp], gu[T1]);
-            gu[T1] = mfma16(a4.y, g2[4 * grp + 1], gu[T1]);
-            gu[T1] = mfma16(a4.z, g2[4 * grp + 2], gu[T1]);
-            gu[T1] = mfma16(a4.w, g2[4 * grp + 3], gu[T1]);
-          }
+          for (int T1 = 0; T1 < 8; ++T1) gu[T1] = mfma16(rowp[16 * T1], g2[c], gu[T1]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -274,7 +291,7 @@ int launch_mlp_adjoint_sweep(const void* coeffs, const void* knots, int64_t n_in
   if (k_end <= k_begin) return CDE_OK;
   const Dims dims{(int)H, (int)C};
   const unsigned blocks = (unsigned)((B + 127) / 128);
-  const size_t lds = (size_t)MLP16_LDS_FLOATS * sizeof(float);
+  const size_t lds = (size_t)ADJ_LDS_FLOATS * sizeof(float);
 #define CDE_SWEEP(D, A)                                                                                            \
   do {                                                                                                             \
     (void)hipFuncSetAttribute((const void*)rk4_adjoint_mlp_sweep<TT, D, A>,                                        \
