@@ -99,6 +99,41 @@ def cpu_baseline(max_sample, budget_s=15.0):
                       "{8,16,32,64} threads (%d cores available)" % (sample, B, L, dt, avail)}
 
 
+def other_fields(cde, X, z0, device, reps=2):
+    """Same workload with the non-linear vector fields of the reference's examples (outside the timed region, not part
+    of `value`): Linear -> tanh (example/irregular_data.py) and Linear -> relu -> Linear -> tanh, width 128
+    (example/time_series_classification.py).  ms per solve, wall clock over `reps` after one warm-up."""
+    class TwoLayer(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.linear1, self.linear2 = torch.nn.Linear(H, 128), torch.nn.Linear(128, H * C)
+
+        def forward(self, t, z):
+            return self.linear2(self.linear1(z).relu()).tanh().view(*z.shape[:-1], H, C)
+
+    from helpers import LinearField
+    torch.manual_seed(0)
+    fields = {"tanh": LinearField(H, C, scale=1.0, tanh=True, seed=0).to(device), "two_layer": TwoLayer().to(device)}
+    out = {}
+    for name, func in fields.items():
+        for mode in ("forward", "forward_adjoint"):
+            def once():
+                if mode == "forward":
+                    with torch.no_grad():
+                        cde.cdeint(X, func, z0, X.interval, method="rk4", options={"step_size": 1.0})
+                else:
+                    z = z0.detach().requires_grad_(True)
+                    cde.cdeint(X, func, z, X.interval, method="rk4", options={"step_size": 1.0})[:, -1].sum().backward()
+            once()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                once()
+            torch.cuda.synchronize()
+            out["%s_%s_ms" % (name, mode)] = (time.perf_counter() - t0) / reps * 1e3
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -235,6 +270,8 @@ def main():
                 "missing_value_fill_series_per_s": B / (fill_ms * 1e-3),
             },
         }
+        if world == 1:
+            result["extra"]["other_fields"] = other_fields(cde, X, z0, device)
         if world == 1 and args.cpu_sample > 0:
             result["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, B))
         print(json.dumps(result))
