@@ -204,6 +204,19 @@ int cde_rk4_adjoint_linear(const void* coeffs, const void* knots, int64_t n_inte
                            void* grad_b, int64_t B, int64_t C, int64_t H, int dtype, int time_dtype, int variant,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* K3 with the gradient w.r.t. the control as well (adjoint_params containing the coefficient tensor, reference
+ * solver.py:207-222 / README.md:251-270):
+ *   grad_coeffs   same shape and layout as `coeffs`, ZEROED by the caller; on return dL/dcoeffs (cubic: the `a`
+ *                 block stays zero -- the derivative of the spline does not read it; linear: dL/d(knot values)).
+ * f32, H <= 32, C <= 8 (MFMA kernels; CDE_ERR_UNSUPPORTED otherwise).  Workspace as for cde_rk4_adjoint_linear with
+ * variant = CDE_VARIANT_MFMA. */
+int cde_rk4_adjoint_linear_dcontrol(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
+                                    const void* W, const void* bias, int act, const void* z_saved,
+                                    const void* grad_out, const void* sgrid, int64_t n_sgrid, const int64_t* seg_off,
+                                    int64_t n_out, void* grad_z0, void* grad_W, void* grad_b, void* grad_coeffs,
+                                    int64_t B, int64_t C, int64_t H, int dtype, int time_dtype, void* workspace,
+                                    size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K4  Adaptive Dormand-Prince 5(4) solve (torchdiffeq's default method, what cdeint runs when the
  * caller passes no `method`: reference solver.py:226-227, README.md:174) for the affine family.

@@ -249,6 +249,46 @@ def test_tanh_field_forward_on_mfma_tiles(native, H, C, degree):
     _close(res["mfma"], res["generic"], 1e-4, 5e-6)
 
 
+@pytest.mark.parametrize("H,C,degree,act", [(32, 8, 3, False), (32, 8, 3, True), (16, 5, 1, True), (8, 3, 1, False)])
+def test_gradient_wrt_control_coefficients(native, H, C, degree, act):
+    """adjoint_params = func parameters + the coefficient tensor (reference README.md:251-270, solver.py:207-222):
+    dL/dcoeffs from the fused adjoint against the float64 oracle, cubic and linear control, 3 output times."""
+    B, L = 70, 12
+    x = make_series(B, L, C, torch.float32, seed=81)
+    base = oracle_interp.hermite_bdiff_coeffs(x) if degree == 3 else x
+    gen = torch.Generator().manual_seed(82)
+    z0 = torch.randn(B, H, generator=gen)
+    t_out = torch.tensor([0., 4.5, 11.])
+    lw = torch.rand(B, 3, H, generator=gen) + 0.5
+    # oracle, float64
+    f64 = LinearField(H, C, torch.float64, scale=0.4, tanh=act, seed=7)
+    c64 = base.double().clone().requires_grad_(True)
+    path64 = (oracle_interp.CubicPath if degree == 3 else oracle_interp.LinearPath)(c64)
+    ref = oracle_cde.cdeint(path64, f64, z0.double(), t_out.double(), adjoint=True, method="rk4",
+                            options=dict(step_size=1.0), adjoint_params=tuple(f64.parameters()) + (c64,))
+    (ref * lw.double()).sum().backward()
+    assert c64.grad is not None and c64.grad.abs().max() > 0
+    # native
+    dfunc = LinearField(H, C, torch.float32, scale=0.4, tanh=act, seed=7).to(DEV)
+    coeffs = base.to(DEV).requires_grad_(True)
+    X = (native.CubicSpline if degree == 3 else native.LinearInterpolation)(coeffs)
+    out = native.cdeint(X, dfunc, z0.to(DEV), t_out.to(DEV), method="rk4", options=dict(step_size=1.0),
+                        adjoint_params=tuple(dfunc.parameters()) + (coeffs,))
+    _close(out, ref, 1e-4, 5e-6)
+    (out * lw.to(DEV)).sum().backward()
+    assert coeffs.grad is not None and coeffs.grad.shape == coeffs.shape
+    _close(coeffs.grad, c64.grad, 1e-3, 1e-3 * c64.grad.abs().max().item())
+    _close(dfunc.linear.weight.grad, f64.linear.weight.grad, 1e-3, 1e-3 * f64.linear.weight.grad.abs().max().item())
+    if degree == 3:
+        assert torch.count_nonzero(coeffs.grad[..., :C]) == 0        # the derivative never reads the `a` block
+    # without adjoint_params the reference only warns (solver.py:207-222) and leaves the control without gradient
+    coeffs.grad = None
+    with pytest.warns(UserWarning):
+        out = native.cdeint(X, dfunc, z0.to(DEV), t_out.to(DEV), method="rk4", options=dict(step_size=1.0))
+    out.sum().backward()
+    assert coeffs.grad is None
+
+
 class _TwoLayerField(torch.nn.Module):
     """reference example/time_series_classification.py:20-51"""
 

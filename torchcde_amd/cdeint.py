@@ -180,11 +180,12 @@ class _Plan:
         return out
 
     # backward: K3
-    def run_adjoint(self, z_saved, grad_out, weight, bias):
+    def run_adjoint(self, z_saved, grad_out, weight, bias, want_control=False):
         lib = _lib.load()
         sgrid, seg_off, n_sgrid = self.grids.sgrid, self.grids.seg_off, self.grids.n_sgrid
         dt = _lib.dtype_enum(self.dtype)
-        nbytes = lib.cde_rk4_adjoint_workspace_bytes(self.B, self.C, self.H, n_sgrid, dt, self.variant)
+        variant = _lib.VARIANT_MFMA if want_control else self.variant
+        nbytes = lib.cde_rk4_adjoint_workspace_bytes(self.B, self.C, self.H, n_sgrid, dt, variant)
         workspace = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
         grad_z0 = torch.empty(self.B, self.H, dtype=self.dtype, device=self.device)
         # weight and bias gradients are two views of ONE flat buffer: a data-parallel caller can all-reduce that
@@ -197,15 +198,25 @@ class _Plan:
         w = weight.detach().contiguous()
         b = bias.detach().contiguous()
         begin = self._mark()
-        _lib.check(lib.cde_rk4_adjoint_linear(
-            _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w), _lib.ptr(b),
-            self.act, _lib.ptr(zs), _lib.ptr(go), _lib.ptr(sgrid), n_sgrid, _lib.ptr(seg_off), self.n_out,
-            _lib.ptr(grad_z0), _lib.ptr(grad_w), _lib.ptr(grad_b), self.B, self.C, self.H, dt,
-            _lib.dtype_enum(self.time_dtype), self.variant, _lib.ptr(workspace), workspace.numel(),
-            _lib.stream_ptr(self.device)), "cde_rk4_adjoint_linear")
+        grad_x = None
+        if want_control:
+            grad_x = torch.zeros_like(self.coeffs)          # (B, rows, width) like the packed coefficients
+            _lib.check(lib.cde_rk4_adjoint_linear_dcontrol(
+                _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w), _lib.ptr(b),
+                self.act, _lib.ptr(zs), _lib.ptr(go), _lib.ptr(sgrid), n_sgrid, _lib.ptr(seg_off), self.n_out,
+                _lib.ptr(grad_z0), _lib.ptr(grad_w), _lib.ptr(grad_b), _lib.ptr(grad_x), self.B, self.C, self.H, dt,
+                _lib.dtype_enum(self.time_dtype), _lib.ptr(workspace), workspace.numel(),
+                _lib.stream_ptr(self.device)), "cde_rk4_adjoint_linear_dcontrol")
+        else:
+            _lib.check(lib.cde_rk4_adjoint_linear(
+                _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w), _lib.ptr(b),
+                self.act, _lib.ptr(zs), _lib.ptr(go), _lib.ptr(sgrid), n_sgrid, _lib.ptr(seg_off), self.n_out,
+                _lib.ptr(grad_z0), _lib.ptr(grad_w), _lib.ptr(grad_b), self.B, self.C, self.H, dt,
+                _lib.dtype_enum(self.time_dtype), self.variant, _lib.ptr(workspace), workspace.numel(),
+                _lib.stream_ptr(self.device)), "cde_rk4_adjoint_linear")
         if begin is not None:
             _Plan.event_log.append(("adjoint", begin, self._mark()))
-        return grad_z0, grad_w, grad_b
+        return grad_z0, grad_w, grad_b, grad_x
 
 
 class _MlpPlan:
@@ -336,7 +347,9 @@ def _mlp_fusable(field, H, C, z0, packed):
 
 class _FusedRK4(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, z0, weight, bias, plan, wants):
+    def forward(ctx, z0, weight, bias, plan, wants, *control):
+        # `control`: the path's differentiable buffer views (cubic: b, 2c, 3d; linear: the knot values) when the
+        # gradient w.r.t. the coefficients was requested through adjoint_params -- only their gradient slots are used
         out = plan.run_forward(z0, weight, bias)
         ctx.plan, ctx.wants = plan, wants
         ctx.save_for_backward(out, weight, bias)
@@ -350,12 +363,18 @@ class _FusedRK4(torch.autograd.Function):
                 "torchcde_amd: backpropagating through the solver's internal operations (adjoint=False) is not "
                 "implemented on the native path; use adjoint=True (continuous adjoint, the reference's default).")
         z_saved, weight, bias = ctx.saved_tensors
-        grad_z0, grad_w, grad_b = plan.run_adjoint(z_saved, grad_out, weight, bias)
-        want_w, want_b = ctx.wants
+        want_w, want_b, want_x = ctx.wants
+        grad_z0, grad_w, grad_b, grad_x = plan.run_adjoint(z_saved, grad_out, weight, bias, want_x)
+        control_grads = ()
+        if want_x:
+            C = plan.C
+            gx = grad_x.reshape(*plan.batch, grad_x.size(-2), grad_x.size(-1))
+            pieces = (gx[..., C:2 * C], gx[..., 2 * C:3 * C], gx[..., 3 * C:]) if plan.degree == _lib.PATH_CUBIC else (gx,)
+            control_grads = tuple(g if need else None for g, need in zip(pieces, ctx.needs_input_grad[5:]))
         return (grad_z0.reshape(*plan.batch, plan.H) if ctx.needs_input_grad[0] else None,
                 grad_w.view_as(weight) if (ctx.needs_input_grad[1] and want_w) else None,
                 grad_b.view_as(bias) if (ctx.needs_input_grad[2] and want_b) else None,
-                None, None)
+                None, None) + control_grads
 
 
 # ------------------------------------------------------------------------------------------ dopri5 (K4)
@@ -607,15 +626,28 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
     adjoint_step = step_size if adjoint_options is None else _parse_fixed_options(adjoint_options, "adjoint")
 
     want_w = want_b = True
+    want_x = False
     if adjoint_params is not None:
         adjoint_params = tuple(adjoint_params)
+        control = X._control_buffers()
+        control_storage = {b.untyped_storage().data_ptr() for b in control}
         for p in adjoint_params:
-            if p is not weight and p is not bias:
-                raise NotImplementedError("torchcde_amd: adjoint_params may only contain the vector field's weight "
-                                          "and bias on the native path (gradients w.r.t. the control are rank 3 of "
-                                          "SURVEY section 8(f)).")
+            if p is weight or p is bias:
+                continue
+            if isinstance(p, torch.Tensor) and p.untyped_storage().data_ptr() in control_storage:
+                # the coefficient tensor the path was built from (README.md:251-270): dL/dcoeffs flows back to it
+                # through the path's buffer views
+                want_x = want_x or (p.requires_grad and torch.is_grad_enabled())
+                continue
+            raise NotImplementedError("torchcde_amd: adjoint_params may only contain the vector field's weight and "
+                                      "bias and the control's coefficient tensor on the native path.")
         want_w = any(p is weight for p in adjoint_params)
         want_b = any(p is bias for p in adjoint_params)
+    if want_x and not (adjoint and z0.dtype == torch.float32 and H <= 32 and C <= 8
+                       and variant != _lib.VARIANT_GENERIC):
+        raise NotImplementedError("torchcde_amd: gradients w.r.t. the control need adjoint=True, float32, "
+                                  "hidden_channels <= 32 and input_channels <= 8 (MFMA kernels).")
 
     plan = _Plan(X, field, batch, H, C, t, step_size, adjoint_step, adjoint, variant)
-    return _FusedRK4.apply(z0, weight, bias, plan, (want_w, want_b))
+    control_inputs = X._control_buffers() if want_x else ()
+    return _FusedRK4.apply(z0, weight, bias, plan, (want_w, want_b, want_x), *control_inputs)

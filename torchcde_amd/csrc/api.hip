@@ -27,7 +27,7 @@ int launch_forward_mlp(const void*, const void*, int64_t, int, const void*, cons
 template <typename TT>
 int launch_adjoint_mfma(const void*, const void*, int64_t, int, const void*, const void*, int, const void*,
                         const void*, const void*, const int64_t*, int64_t, void*, void*, void*, int64_t, int64_t,
-                        int64_t, const int64_t*, const void*, float*, hipStream_t);
+                        int64_t, const int64_t*, const void*, float*, void*, hipStream_t);
 
 // from rk4_mlp_adjoint.hip
 size_t mlp_adjoint_image_bytes();
@@ -98,10 +98,11 @@ static int adjoint_typed(const void* coeffs, const void* knots, int64_t n_interv
                          const void* bias, int act, const void* z_saved, const void* grad_out, const void* sgrid,
                          int64_t n_sgrid, const int64_t* seg_off, int64_t n_out, void* grad_z0, void* grad_W,
                          void* grad_b, int64_t B, int64_t C, int64_t H, int dtype, int variant, void* workspace,
-                         size_t workspace_bytes, hipStream_t s) {
+                         size_t workspace_bytes, void* grad_coeffs, hipStream_t s) {
   int rc;
   const bool use_mfma = pick_mfma(variant, C, H, dtype, act, true, &rc);
   if (rc != CDE_OK) return rc;
+  if (grad_coeffs && !use_mfma) return CDE_ERR_UNSUPPORTED;      // control gradients: MFMA kernels only
   // workspace: [stage_index: 4*(n_sgrid-1) int64][stage_frac: 4*(n_sgrid-1) T][partials]
   const int64_t n_steps = n_sgrid - 1;
   const size_t off_frac = align256((size_t)(4 * n_steps) * sizeof(int64_t));
@@ -115,7 +116,8 @@ static int adjoint_typed(const void* coeffs, const void* knots, int64_t n_interv
   if (rc != CDE_OK) return rc;
   if (use_mfma)
     return launch_adjoint_mfma<TT>(coeffs, knots, n_intervals, degree, W, bias, act, z_saved, grad_out, sgrid, seg_off, n_out,
-                                   grad_z0, grad_W, grad_b, B, C, H, stage_index, stage_frac, (float*)partial, s);
+                                   grad_z0, grad_W, grad_b, B, C, H, stage_index, stage_frac, (float*)partial,
+                                   grad_coeffs, s);
   return launch_adjoint_generic<T, TT>(coeffs, knots, n_intervals, degree, W, bias, act, z_saved, grad_out, sgrid,
                                        seg_off, n_out, grad_z0, grad_W, grad_b, B, C, H, stage_index, stage_frac,
                                        partial, s);
@@ -188,12 +190,11 @@ extern "C" size_t cde_rk4_adjoint_workspace_bytes(int64_t B, int64_t C, int64_t 
   return bytes;
 }
 
-extern "C" int cde_rk4_adjoint_linear(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
-                                      const void* W, const void* bias, int act, const void* z_saved,
-                                      const void* grad_out, const void* sgrid, int64_t n_sgrid, const int64_t* seg_off,
-                                      int64_t n_out, void* grad_z0, void* grad_W, void* grad_b, int64_t B, int64_t C,
-                                      int64_t H, int dtype, int time_dtype, int variant, void* workspace,
-                                      size_t workspace_bytes, void* stream) {
+static int adjoint_linear_impl(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
+                               const void* bias, int act, const void* z_saved, const void* grad_out, const void* sgrid,
+                               int64_t n_sgrid, const int64_t* seg_off, int64_t n_out, void* grad_z0, void* grad_W,
+                               void* grad_b, void* grad_coeffs, int64_t B, int64_t C, int64_t H, int dtype,
+                               int time_dtype, int variant, void* workspace, size_t workspace_bytes, void* stream) {
   if (B < 1 || C < 1 || H < 1 || n_intervals < 1 || n_out < 1 || n_sgrid < 0) return CDE_ERR_SHAPE;
   if (act != CDE_ACT_NONE && act != CDE_ACT_TANH) return CDE_ERR_UNSUPPORTED;
   if (!coeffs || !knots || !W || !bias || !z_saved || !grad_out || !grad_z0 || !grad_W || !grad_b || !workspace)
@@ -203,13 +204,37 @@ extern "C" int cde_rk4_adjoint_linear(const void* coeffs, const void* knots, int
 #define CDE_CALL(T, TT)                                                                                               \
   return cde::adjoint_typed<T, TT>(coeffs, knots, n_intervals, degree, W, bias, act, z_saved, grad_out, sgrid,        \
                                    n_sgrid, seg_off, n_out, grad_z0, grad_W, grad_b, B, C, H, dtype, variant,         \
-                                   workspace, workspace_bytes, s)
+                                   workspace, workspace_bytes, grad_coeffs, s)
   if (dtype == CDE_F32 && time_dtype == CDE_F32) CDE_CALL(float, float);
   if (dtype == CDE_F32 && time_dtype == CDE_F64) CDE_CALL(float, double);
   if (dtype == CDE_F64 && time_dtype == CDE_F64) CDE_CALL(double, double);
   if (dtype == CDE_F64 && time_dtype == CDE_F32) CDE_CALL(double, float);
 #undef CDE_CALL
   return CDE_ERR_DTYPE;
+}
+
+extern "C" int cde_rk4_adjoint_linear(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
+                                      const void* W, const void* bias, int act, const void* z_saved,
+                                      const void* grad_out, const void* sgrid, int64_t n_sgrid, const int64_t* seg_off,
+                                      int64_t n_out, void* grad_z0, void* grad_W, void* grad_b, int64_t B, int64_t C,
+                                      int64_t H, int dtype, int time_dtype, int variant, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+  return adjoint_linear_impl(coeffs, knots, n_intervals, degree, W, bias, act, z_saved, grad_out, sgrid, n_sgrid, seg_off,
+                             n_out, grad_z0, grad_W, grad_b, nullptr, B, C, H, dtype, time_dtype, variant, workspace,
+                             workspace_bytes, stream);
+}
+
+extern "C" int cde_rk4_adjoint_linear_dcontrol(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
+                                               const void* W, const void* bias, int act, const void* z_saved,
+                                               const void* grad_out, const void* sgrid, int64_t n_sgrid,
+                                               const int64_t* seg_off, int64_t n_out, void* grad_z0, void* grad_W,
+                                               void* grad_b, void* grad_coeffs, int64_t B, int64_t C, int64_t H,
+                                               int dtype, int time_dtype, void* workspace, size_t workspace_bytes,
+                                               void* stream) {
+  if (!grad_coeffs) return CDE_ERR_NULL;
+  return adjoint_linear_impl(coeffs, knots, n_intervals, degree, W, bias, act, z_saved, grad_out, sgrid, n_sgrid, seg_off,
+                             n_out, grad_z0, grad_W, grad_b, grad_coeffs, B, C, H, dtype, time_dtype, CDE_VARIANT_MFMA,
+                             workspace, workspace_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------- K3m

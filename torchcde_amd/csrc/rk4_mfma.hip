@@ -430,13 +430,22 @@ __device__ __forceinline__ void swap32(float& x, float& y) {      // x[lanes 32.
   y = __uint_as_float(r[1]);
 }
 
-template <typename TT, int DEGREE, int ACT>
+//
+// DCOEFF: also produce dL/d(control coefficients) (adjoint_params containing the coefficient tensor, reference
+// solver.py:207-222).  f depends on the control only through dX_c, and d(a.f)/d(dX_c) = sum_h a_h act(Y)_hc is a sum
+// over rows this lane already holds (its 4 channels, all 32 hidden units after the 8 tiles): no cross-lane traffic.
+// The chain to the row of the interval in use -- cubic: d/db = 1, d/d(2c) = frac, d/d(3d) = frac^2; linear:
+// -+1/width on the two knots -- is accumulated in registers while the interval stays the same and added to
+// `grad_coeffs` (zeroed by the caller, same layout as `coeffs`) when it changes; one lane owns a (series, channel), so
+// the read-modify-write needs no atomics and the result is run-to-run deterministic.
+template <typename TT, int DEGREE, int ACT, bool DCOEFF = false>
 __global__ __launch_bounds__(256, 1) void rk4_adjoint_act_mfma(
     const float* __restrict__ coeffs, const float* __restrict__ knots, int64_t n_intervals,
     const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ z_saved,
     const float* __restrict__ grad_out, const TT* __restrict__ sgrid, const int64_t* __restrict__ seg_off,
     int64_t n_out, float* __restrict__ grad_z0, float* __restrict__ partial, int64_t B,
-    const int64_t* __restrict__ stage_index, const float* __restrict__ stage_frac, Dims dims) {
+    const int64_t* __restrict__ stage_index, const float* __restrict__ stage_frac, Dims dims,
+    float* __restrict__ grad_coeffs = nullptr) {
   const int Hr = dims.H, Cr = dims.C;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* wyf = lds;
@@ -485,6 +494,27 @@ __global__ __launch_bounds__(256, 1) void rk4_adjoint_act_mfma(
     a0[r] = (valid && on) ? grad_out[(sc * n_out + (n_out - 1)) * Hr + u] : 0.f;
   }
 
+  // dL/d(coefficient row in use), this lane's 4 channels: cubic (b, 2c, 3d), linear (left knot, right knot)
+  float gc0[4] = {0.f, 0.f, 0.f, 0.f}, gc1[4] = {0.f, 0.f, 0.f, 0.f}, gc2[4] = {0.f, 0.f, 0.f, 0.f};
+  auto flush_control_grad = [&](int64_t at) {
+    if constexpr (DCOEFF) {
+#pragma unroll
+      for (int cl = 0; cl < 4; ++cl) {
+        const int c = cl + 4 * half;
+        if (valid && c < Cr) {
+          if (DEGREE == CDE_PATH_CUBIC) {
+            float* g = grad_coeffs + (series * n_intervals + at) * 4 * Cr;
+            g[Cr + c] += gc0[cl]; g[2 * Cr + c] += gc1[cl]; g[3 * Cr + c] += gc2[cl];
+          } else {
+            float* g = grad_coeffs + (series * (n_intervals + 1) + at) * Cr;
+            g[c] += gc0[cl]; g[Cr + c] += gc1[cl];
+          }
+        }
+        gc0[cl] = 0.f; gc1[cl] = 0.f; gc2[cl] = 0.f;
+      }
+    }
+  };
+
   for (int64_t p = 0; p + 1 < n_out; ++p) {
     const int64_t i_out = n_out - 1 - p;
     const int64_t k_begin = seg_off[p], k_end = seg_off[p + 1] - 1;
@@ -527,6 +557,7 @@ __global__ __launch_bounds__(256, 1) void rk4_adjoint_act_mfma(
           }
 
           f32x16 f, va = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          float gdx[4] = {0.f, 0.f, 0.f, 0.f};      // d(a.f)/d(dX_c), this lane's 4 channels (DCOEFF)
           int opaque = 0;
           asm volatile("" : "+v"(opaque));          // keeps the image reads inside the stage (no hoisting)
           const float4* wys = wy + opaque;
@@ -565,6 +596,7 @@ __global__ __launch_bounds__(256, 1) void rk4_adjoint_act_mfma(
                 const float t = activate<ACT>(y[4 * hl + cl]);
                 acc = cl == 0 ? t * dh[0] : __builtin_fmaf(t, dh[cl], acc);
                 g[4 * hl + cl] = a4u[hl] * (dh[cl] * activate_slope<ACT>(t));
+                if constexpr (DCOEFF) gdx[cl] = __builtin_fmaf(a4u[hl], t, gdx[cl]);
               }
               ps[hl] = acc;
             }
@@ -607,6 +639,15 @@ __global__ __launch_bounds__(256, 1) void rk4_adjoint_act_mfma(
             __builtin_amdgcn_sched_barrier(0);       // one tile at a time: bounds the live registers
           }
 
+          if constexpr (DCOEFF) {
+#pragma unroll
+            for (int cl = 0; cl < 4; ++cl) {
+              const float w = wq * gdx[cl];
+              if (DEGREE == CDE_PATH_CUBIC) { gc0[cl] += w; gc1[cl] += w * frac; gc2[cl] += w * frac * frac; }
+              else { gc0[cl] -= w / width; gc1[cl] += w / width; }
+            }
+            if (nidx != idx) flush_control_grad(idx);
+          }
           const f32x16 ky = -f, ka = va;
           const float third = (float)(1.0 / 3.0);
           if (stage == 0) {
@@ -630,6 +671,7 @@ __global__ __launch_bounds__(256, 1) void rk4_adjoint_act_mfma(
         }
         y0 = yst; a0 = ast;
       }
+      flush_control_grad(idx);                 // end of this output interval's sweep
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -746,7 +788,7 @@ int launch_adjoint_mfma(const void* coeffs, const void* knots, int64_t n_interva
                         const void* bias, int act, const void* z_saved, const void* grad_out, const void* sgrid,
                         const int64_t* seg_off, int64_t n_out, void* grad_z0, void* grad_W, void* grad_b, int64_t B,
                         int64_t C, int64_t H, const int64_t* stage_index, const void* stage_frac, float* partial,
-                        hipStream_t s) {
+                        void* grad_coeffs, hipStream_t s) {
   const Dims dims{(int)H, (int)C};
   const unsigned blocks = (unsigned)((B + 127) / 128);
   if (degree != CDE_PATH_CUBIC && degree != CDE_PATH_LINEAR) return CDE_ERR_UNSUPPORTED;
@@ -759,7 +801,24 @@ int launch_adjoint_mfma(const void* coeffs, const void* knots, int64_t n_interva
                                     (const TT*)sgrid, seg_off, n_out, (float*)grad_z0, partial, B, stage_index,      \
                                     (const float*)stage_frac, dims);                                                 \
   } while (0)
-  if (act == CDE_ACT_NONE) {
+#define CDE_ADJ_DX(KERNEL)                                                                                           \
+  do {                                                                                                               \
+    const size_t lds = (size_t)(ACT_ADJ_LDS_FLOATS) * sizeof(float);                                                 \
+    (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
+    KERNEL<<<blocks, 256, lds, s>>>((const float*)coeffs, (const float*)knots, n_intervals, (const float*)W,         \
+                                    (const float*)bias, (const float*)z_saved, (const float*)grad_out,               \
+                                    (const TT*)sgrid, seg_off, n_out, (float*)grad_z0, partial, B, stage_index,      \
+                                    (const float*)stage_frac, dims, (float*)grad_coeffs);                            \
+  } while (0)
+  if (grad_coeffs) {                       // control gradients: the pre-activation kernel (it holds act(Y) in-lane)
+    if (act == CDE_ACT_NONE) {
+      if (degree == CDE_PATH_CUBIC) CDE_ADJ_DX((rk4_adjoint_act_mfma<TT, CDE_PATH_CUBIC, CDE_ACT_NONE, true>));
+      else CDE_ADJ_DX((rk4_adjoint_act_mfma<TT, CDE_PATH_LINEAR, CDE_ACT_NONE, true>));
+    } else if (act == CDE_ACT_TANH) {
+      if (degree == CDE_PATH_CUBIC) CDE_ADJ_DX((rk4_adjoint_act_mfma<TT, CDE_PATH_CUBIC, CDE_ACT_TANH, true>));
+      else CDE_ADJ_DX((rk4_adjoint_act_mfma<TT, CDE_PATH_LINEAR, CDE_ACT_TANH, true>));
+    } else return CDE_ERR_UNSUPPORTED;
+  } else if (act == CDE_ACT_NONE) {
     if (degree == CDE_PATH_CUBIC) CDE_ADJ((rk4_adjoint_mfma<TT, CDE_PATH_CUBIC>), W1_FLOATS + W2_FLOATS + 4 * SCR_FLOATS);
     else CDE_ADJ((rk4_adjoint_mfma<TT, CDE_PATH_LINEAR>), W1_FLOATS + W2_FLOATS + 4 * SCR_FLOATS);
   } else if (act == CDE_ACT_TANH) {
@@ -767,6 +826,7 @@ int launch_adjoint_mfma(const void* coeffs, const void* knots, int64_t n_interva
     else CDE_ADJ((rk4_adjoint_act_mfma<TT, CDE_PATH_LINEAR, CDE_ACT_TANH>), ACT_ADJ_LDS_FLOATS);
   } else return CDE_ERR_UNSUPPORTED;
 #undef CDE_ADJ
+#undef CDE_ADJ_DX
   int rc = check_launch();
   if (rc != CDE_OK) return rc;
   reduce_mfma_partials<<<(unsigned)((H * C * H + H * C + 255) / 256), 256, 0, s>>>(partial, (B + 31) / 32, (float*)grad_W,
@@ -790,11 +850,11 @@ template int launch_forward_mlp<double>(const void*, const void*, int64_t, int, 
                                         hipStream_t);
 template int launch_adjoint_mfma<float>(const void*, const void*, int64_t, int, const void*, const void*, int,
                                         const void*, const void*, const void*, const int64_t*, int64_t, void*, void*,
-                                        void*, int64_t, int64_t, int64_t, const int64_t*, const void*, float*,
+                                        void*, int64_t, int64_t, int64_t, const int64_t*, const void*, float*, void*,
                                         hipStream_t);
 template int launch_adjoint_mfma<double>(const void*, const void*, int64_t, int, const void*, const void*, int,
                                          const void*, const void*, const void*, const int64_t*, int64_t, void*, void*,
-                                         void*, int64_t, int64_t, int64_t, const int64_t*, const void*, float*,
+                                         void*, int64_t, int64_t, int64_t, const int64_t*, const void*, float*, void*,
                                          hipStream_t);
 
 }  // namespace cde

@@ -228,6 +228,10 @@ class CubicSpline(_NativePath):
     def _channels(self):
         return self._C
 
+    def _control_buffers(self):
+        """Buffers the control derivative reads (gradient targets for adjoint_params=(..., coeffs))."""
+        return (self._b, self._two_c, self._three_d)
+
     def _packed(self):
         a, b, c, d = self._a, self._b, self._two_c, self._three_d
         C = self._C
@@ -264,6 +268,9 @@ class LinearInterpolation(_NativePath):
 
     def _channels(self):
         return self._coeffs.size(-1)
+
+    def _control_buffers(self):
+        return (self._coeffs,)
 
     def _packed(self):
         return self._coeffs
