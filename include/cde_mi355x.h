@@ -83,6 +83,18 @@ int cde_hermite_bdiff_coeffs(const void* x, const void* t, void* coeffs, int64_t
 int cde_linear_fill_missing(const void* x, const void* t, void* out, int64_t B, int64_t L, int64_t C, int dtype,
                             void* stream);
 
+/* K0b  Forward fill along the length axis (torchcde/misc.py:103-126, the helper rectilinear preparation and the
+ * reference's data pipelines use): x (B, L, C) -> out (B, L, C); NaNs take the latest earlier observation of their
+ * scalar path, leading NaNs stay NaN.  Bit-exact (data movement only). */
+int cde_forward_fill(const void* x, void* out, int64_t B, int64_t L, int64_t C, int dtype, void* stream);
+
+/* K0c  Rectilinear preparation (torchcde/interpolation_linear.py:86-128, reached from
+ * linear_interpolation_coeffs(x, rectilinear=time_index) at :152-162): x (B, L, C) -> out (B, 2L-1, C) with
+ *   out[j][c] = forward_fill(x)[j/2][c]  (c != time_index),   out[j][time_index] = x[(j+1)/2][time_index].
+ * The caller checks (as the reference asserts) that the time column holds no NaN.  Bit-exact. */
+int cde_rectilinear_prepare(const void* x, void* out, int64_t B, int64_t L, int64_t C, int64_t time_index, int dtype,
+                            void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K1b  Interval lookup and path evaluation for a vector of query times.
  * cde_interpret_t replaces CubicSpline._interpret_t (interpolation_cubic.py:315-322) and

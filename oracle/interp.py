@@ -4,7 +4,9 @@ Restates, operation-for-operation (so that float results are bit-identical to
 the reference on CPU), the interpolation half of the hot path:
 
   check_path                 <- torchcde/misc.py:70-100            (validate_input_path)
-  linear_coeffs              <- torchcde/interpolation_linear.py:131-171 (no-NaN, non-rectilinear path)
+  forward_fill               <- torchcde/misc.py:103-126
+  rectilinear_prepare        <- torchcde/interpolation_linear.py:86-128
+  linear_coeffs              <- torchcde/interpolation_linear.py:131-171 (incl. the NaN fill :13-84 and rectilinear)
   hermite_bdiff_coeffs       <- torchcde/interpolation_hermite_cubic_bdiff.py:5-44
   locate                     <- torchcde/interpolation_cubic.py:315-322  (== interpolation_linear.py:203-210)
   cubic_value / cubic_slope  <- torchcde/interpolation_cubic.py:324-336
@@ -75,9 +77,36 @@ def _fill_scalar_path(t, x):
     return x
 
 
-def linear_coeffs(x, t=None):
-    """interpolation_linear.py:131-171 without rectilinear preparation: ``x`` itself when nothing is missing,
+def forward_fill(x):
+    """misc.py:103-126 along the length axis (-2), as a plain loop: NaNs take the latest earlier observation of their
+    scalar path; leading NaNs stay."""
+    out = x.clone()
+    for i in range(1, x.size(-2)):
+        cur = out[..., i, :]
+        out[..., i, :] = torch.where(torch.isnan(cur), out[..., i - 1, :], cur)
+    return out
+
+
+def rectilinear_prepare(x, time_index):
+    """interpolation_linear.py:86-128: forward fill, repeat every row twice, advance the time channel by one row,
+    drop the last row -> (..., 2L-1, C)."""
+    assert isinstance(time_index, int) and 0 <= time_index < x.size(-1)
+    assert not torch.isnan(x[..., time_index]).any()
+    filled = forward_fill(x)
+    L = x.size(-2)
+    rows = []
+    for j in range(2 * L - 1):
+        row = filled[..., j // 2, :].clone()
+        row[..., time_index] = filled[..., (j + 1) // 2, time_index]
+        rows.append(row)
+    return torch.stack(rows, dim=-2)
+
+
+def linear_coeffs(x, t=None, rectilinear=None):
+    """interpolation_linear.py:131-171: optional rectilinear preparation, then ``x`` itself when nothing is missing,
     otherwise every scalar path (one per series and channel) filled by ``_fill_scalar_path`` (:72-84)."""
+    if rectilinear is not None:
+        x = rectilinear_prepare(x, rectilinear)
     t = check_path(x, t)
     if not torch.isnan(x).any():
         return x

@@ -122,6 +122,51 @@ def nan_fill_cases(ref):
     return cases
 
 
+def rectilinear_cases(ref):
+    """forward_fill (reference misc.py:103-126) and rectilinear preparation (interpolation_linear.py:86-128, :152-162),
+    incl. the literal known-answer case of the reference's own test (test/test_linear_interpolation.py:117-152)."""
+    from oracle import interp
+    nan = float("nan")
+    gen = torch.Generator().manual_seed(777)
+    cases = []
+    # the reference test's hand-written example: two series of lengths 3 and 2, padded with NaN, time in channel 0
+    t1 = torch.tensor([0.1, 0.2, 0.9]).view(-1, 1)
+    t2 = torch.tensor([0.2, 0.3]).view(-1, 1)
+    x1 = torch.tensor([0.4, nan, 1.1]).view(-1, 1)
+    x2 = torch.tensor([nan, 2.]).view(-1, 1)
+    x = torch.nn.utils.rnn.pad_sequence([torch.cat((t1, x1), -1), torch.cat((t2, x2), -1)], batch_first=True,
+                                        padding_value=nan)
+    x[:, :, 0] = ref.misc.forward_fill(x[:, :, 0], fill_index=-1)
+    x1_true = torch.tensor([[0.1, 0.2, 0.2, 0.9, 0.9], [0.4, 0.4, 0.4, 0.4, 1.1]]).T.view(-1, 2)
+    x2_true = torch.tensor([[0.2, 0.3, 0.3, 0.3, 0.3], [2., 2., 2., 2., 2.]]).T.view(-1, 2)
+    known = torch.stack((x1_true, x2_true))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = ref.linear_interpolation_coeffs(x, rectilinear=0)
+        assert torch.equal(known, got)
+        assert torch.equal(got, interp.linear_coeffs(x, rectilinear=0))
+        cases.append(dict(x=x, time_index=0, filled=ref.misc.forward_fill(x), prepared=ref.interpolation_linear
+                          ._prepare_rectilinear_interpolation(x, 0), coeffs=got, known_answer=True))
+        for dtype in (torch.float32, torch.float64):
+            for batch, L, C, time_index, p_nan in (((5,), 9, 4, 0, 0.4), ((2, 3), 17, 6, 3, 0.25), ((1,), 2, 2, 1, 0.5),
+                                                   ((7,), 33, 8, 7, 0.1)):
+                data = torch.randn(*batch, L, C, generator=gen, dtype=dtype)
+                data = data.masked_fill(torch.rand(*batch, L, C, generator=gen) < p_nan, nan)
+                data[..., time_index] = torch.rand(*batch, L, generator=gen, dtype=dtype).cumsum(-1)   # time: no NaN
+                filled = ref.misc.forward_fill(data)
+                prepared = ref.interpolation_linear._prepare_rectilinear_interpolation(data, time_index)
+                coeffs = ref.linear_interpolation_coeffs(data, rectilinear=time_index)
+                same = lambda a, b: torch.equal(torch.nan_to_num(a, nan=1e30), torch.nan_to_num(b, nan=1e30)) and \
+                    torch.equal(torch.isnan(a), torch.isnan(b))
+                assert same(filled, interp.forward_fill(data)), "oracle forward_fill != reference"
+                assert same(prepared, interp.rectilinear_prepare(data, time_index)), "oracle rectilinear != reference"
+                assert torch.equal(coeffs, interp.linear_coeffs(data, rectilinear=time_index))
+                cases.append(dict(x=data, time_index=time_index, filled=filled, prepared=prepared, coeffs=coeffs,
+                                  known_answer=False))
+    return cases
+
+
 class LinearField(torch.nn.Module):
     """The README vector field (reference README.md:42-49): Linear(H, H*C) viewed (..., H, C)."""
 
@@ -233,6 +278,10 @@ def main():
     nan_cases = nan_fill_cases(ref)
     torch.save(nan_cases, os.path.join(OUT, "nan_fill.pt"))
     print("nan_fill.pt: %d cases (oracle bit-identical to reference on all)" % len(nan_cases))
+    rect_cases = rectilinear_cases(ref)
+    torch.save(rect_cases, os.path.join(OUT, "rectilinear.pt"))
+    print("rectilinear.pt: %d cases (oracle bit-identical to reference on all; known-answer case of the reference's "
+          "test included)" % len(rect_cases))
     cde_cases = cdeint_cases(ref)
     torch.save(cde_cases, os.path.join(OUT, "cdeint.pt"))
     print("cdeint.pt: %d cases (oracle.cde bit-identical to reference solver.py over oracle.odeint)" % len(cde_cases))

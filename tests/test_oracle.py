@@ -38,6 +38,28 @@ def test_missing_value_fill_matches_reference_golden():
         assert torch.equal(interp.hermite_bdiff_coeffs(case["x"], case["t"]), case["hermite"])
 
 
+def _same_with_nans(a, b):
+    return torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a, nan=0.0), torch.nan_to_num(b, nan=0.0))
+
+
+def test_forward_fill_and_rectilinear_match_reference_golden():
+    """misc.py:103-126 and interpolation_linear.py:86-128 / :152-162; the first fixture is the literal known-answer
+    example of the reference's test/test_linear_interpolation.py:117-152."""
+    import os
+    from conftest import GOLDEN
+    oracle_interp = interp
+    cases = torch.load(os.path.join(GOLDEN, "rectilinear.pt"))
+    assert cases[0]["known_answer"]
+    x1_true = torch.tensor([[0.1, 0.2, 0.2, 0.9, 0.9], [0.4, 0.4, 0.4, 0.4, 1.1]]).T
+    x2_true = torch.tensor([[0.2, 0.3, 0.3, 0.3, 0.3], [2., 2., 2., 2., 2.]]).T
+    assert torch.equal(cases[0]["coeffs"], torch.stack((x1_true, x2_true)))
+    for case in cases:
+        assert _same_with_nans(oracle_interp.forward_fill(case["x"]), case["filled"])
+        assert _same_with_nans(oracle_interp.rectilinear_prepare(case["x"], case["time_index"]), case["prepared"])
+        assert torch.equal(oracle_interp.linear_coeffs(case["x"], rectilinear=case["time_index"]), case["coeffs"])
+        assert case["prepared"].size(-2) == 2 * case["x"].size(-2) - 1
+
+
 def test_hermite_unit_time_known_answer():
     """The reference's closed-form KAT (test/test_hermite_cubic.py:6-38): with unit knot spacing
     two_c = 4(d_next - d_prev), three_d = -3(d_next - d_prev)."""

@@ -10,5 +10,6 @@ from .paths import (InterpolationBase, CubicSpline, NaturalCubicSpline, LinearIn
                     hermite_cubic_coefficients_with_backward_differences, linear_interpolation_coeffs)
 from .fields import LinearCDEFunc
 from .cdeint import cdeint
+from . import misc  # noqa: F401  (torchcde.misc.forward_fill)
 
 __version__ = "0.1.0"

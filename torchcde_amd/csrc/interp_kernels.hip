@@ -130,6 +130,55 @@ __global__ __launch_bounds__(256) void linear_fill_kernel(const T* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------------ K0b / K0c
+// K0b forward fill along the length axis (reference misc.py:103-126: gather at the cummax of the observed-count
+// cumsum): every NaN takes the latest earlier observation of its scalar path; leading NaNs stay NaN.
+// K0c rectilinear preparation (interpolation_linear.py:86-128): forward fill, every sample repeated twice with the
+// time channel advanced by one row, last row dropped -> 2L-1 rows, so that LINEAR interpolation of the result is the
+// rectilinear (causal) interpolation of the data:   out[j][c] = filled[j/2][c],  out[j][time] = time[(j+1)/2].
+// Pure data movement (bit-exact); one lane per scalar path walks its L samples once, as in K0.
+template <typename T>
+__global__ __launch_bounds__(256) void forward_fill_kernel(const T* __restrict__ x, T* __restrict__ out, int64_t B,
+                                                           int64_t L, int64_t C) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * C) return;
+  const int64_t b = e / C, c = e - b * C;
+  const T* src = x + b * L * C + c;
+  T* dst = out + b * L * C + c;
+  T held = src[0];
+  for (int64_t i = 0; i < L; ++i) {
+    const T v = src[i * C];
+    if (v == v) held = v;
+    dst[i * C] = held;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rectilinear_prepare_kernel(const T* __restrict__ x, T* __restrict__ out,
+                                                                  int64_t B, int64_t L, int64_t C, int64_t time_index) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * C) return;
+  const int64_t b = e / C, c = e - b * C;
+  const T* src = x + b * L * C + c;
+  T* dst = out + b * (2 * L - 1) * C + c;
+  if (c == time_index) {
+    // the host has checked that the time column holds no NaN (the reference asserts it)
+    for (int64_t i = 0; i < L; ++i) {
+      const T v = src[i * C];
+      dst[(2 * i) * C] = v;
+      if (i > 0) dst[(2 * i - 1) * C] = v;
+    }
+    return;
+  }
+  T held = src[0];
+  for (int64_t i = 0; i < L; ++i) {
+    const T v = src[i * C];
+    if (v == v) held = v;
+    dst[(2 * i) * C] = held;
+    if (i + 1 < L) dst[(2 * i + 1) * C] = held;
+  }
+}
+
 // ------------------------------------------------------------------------------------------ K1b
 template <typename T>
 __global__ void interpret_t_kernel(const T* __restrict__ knots, int64_t n_intervals, const T* __restrict__ tq,
@@ -237,6 +286,33 @@ extern "C" int cde_linear_fill_missing(const void* x, const void* t, void* out, 
     cde::linear_fill_kernel<double><<<grid, 256, 0, s>>>((const double*)x, (const double*)t, (double*)out, B, L, C);
   else
     return CDE_ERR_DTYPE;
+  return cde::check_launch();
+}
+
+extern "C" int cde_forward_fill(const void* x, void* out, int64_t B, int64_t L, int64_t C, int dtype, void* stream) {
+  if (B < 0 || L < 1 || C < 1) return CDE_ERR_SHAPE;
+  if (B == 0) return CDE_OK;
+  if (!x || !out) return CDE_ERR_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((B * C + 255) / 256);
+  if (dtype == CDE_F32) cde::forward_fill_kernel<float><<<grid, 256, 0, s>>>((const float*)x, (float*)out, B, L, C);
+  else if (dtype == CDE_F64) cde::forward_fill_kernel<double><<<grid, 256, 0, s>>>((const double*)x, (double*)out, B, L, C);
+  else return CDE_ERR_DTYPE;
+  return cde::check_launch();
+}
+
+extern "C" int cde_rectilinear_prepare(const void* x, void* out, int64_t B, int64_t L, int64_t C, int64_t time_index,
+                                       int dtype, void* stream) {
+  if (B < 0 || L < 1 || C < 1 || time_index < 0 || time_index >= C) return CDE_ERR_SHAPE;
+  if (B == 0) return CDE_OK;
+  if (!x || !out) return CDE_ERR_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((B * C + 255) / 256);
+  if (dtype == CDE_F32)
+    cde::rectilinear_prepare_kernel<float><<<grid, 256, 0, s>>>((const float*)x, (float*)out, B, L, C, time_index);
+  else if (dtype == CDE_F64)
+    cde::rectilinear_prepare_kernel<double><<<grid, 256, 0, s>>>((const double*)x, (double*)out, B, L, C, time_index);
+  else return CDE_ERR_DTYPE;
   return cde::check_launch();
 }
 

@@ -9,6 +9,7 @@ with every tensor operation executed by the HIP kernels of libcde_mi355x.so (K1,
 """
 import abc
 import math
+import warnings
 
 import torch
 
@@ -54,16 +55,69 @@ def _no_grad_through_path(*tensors):
             "implemented on the native path yet (SURVEY section 8(f), rank 3). Detach these inputs.")
 
 
+def _flat3(x):
+    L, C = x.size(-2), x.size(-1)
+    return x.detach().contiguous(), x.numel() // max(L * C, 1), L, C
+
+
+def forward_fill(x, fill_index=-2):
+    """Forward fill along ``fill_index`` (reference misc.py:103-126): every NaN takes the latest earlier
+    observation, leading NaNs stay.  Returns ``x`` itself when nothing is missing, like the reference.  K0b."""
+    assert isinstance(x, torch.Tensor)
+    assert x.dim() >= 2
+    _lib.require_gpu(x, "x")
+    if not torch.isnan(x).any():
+        return x
+    _no_grad_through_path(x)
+    dim = fill_index % x.dim()
+    moved = x.movedim(dim, -2) if dim != x.dim() - 2 else x
+    src, B, L, C = _flat3(moved)
+    out = torch.empty_like(src)
+    lib = _lib.load()
+    _lib.check(lib.cde_forward_fill(_lib.ptr(src), _lib.ptr(out), B, L, C, _lib.dtype_enum(x.dtype),
+                                    _lib.stream_ptr(x.device)), "cde_forward_fill")
+    return out.movedim(-2, dim) if dim != x.dim() - 2 else out
+
+
+_RECTILINEAR_WARNING = ("The data `x` begins with missing values in some channels. The path will be constructed by "
+                        "backward-filling the first observed value, which is not causal. Raising a warning as the "
+                        "`rectilinear` argument has also been passed, which is nearly always only used when "
+                        "causality is desired. If you need causality then fill in the missing value at the start of "
+                        "each channel with whatever you'd like it to be. (The mean over that channel is a common "
+                        "choice.)")
+
+
+def _prepare_rectilinear_interpolation(data, time_index):
+    """reference interpolation_linear.py:86-128 on the GPU (K0c): (..., L, C) -> (..., 2L-1, C)."""
+    n_channels = data.size(-1)
+    assert isinstance(time_index, int), "Index of the time channel must be an integer in [0, {}]".format(n_channels - 1)
+    assert 0 <= time_index < n_channels, "Time index must be in [0, {}], was given {}." \
+                                         "".format(n_channels - 1, time_index)
+    _lib.require_gpu(data, "x")
+    assert not torch.isnan(data[..., time_index]).any(), \
+        "There exist nan values in the time column which is not allowed. If the times are padded with nans after " \
+        "final time, a simple solution is to forward fill the final time."
+    _no_grad_through_path(data)
+    src, B, L, C = _flat3(data)
+    out = torch.empty(*data.shape[:-2], 2 * L - 1, C, dtype=data.dtype, device=data.device)
+    lib = _lib.load()
+    _lib.check(lib.cde_rectilinear_prepare(_lib.ptr(src), _lib.ptr(out), B, L, C, time_index,
+                                           _lib.dtype_enum(data.dtype), _lib.stream_ptr(data.device)),
+               "cde_rectilinear_prepare")
+    return out
+
+
 def linear_interpolation_coeffs(x, t=None, rectilinear=None):
     """Knots of the piecewise-linear control (reference interpolation_linear.py:131-171).
 
     Without missing values ``x`` itself is returned (same tensor object), exactly like the reference.  With NaNs
     every scalar path is filled by K0 (``cde_linear_fill_missing``): observed values stay, gaps become straight
     lines between the nearest observed neighbours, leading/trailing gaps are constant, all-NaN paths are zero.
-    ``rectilinear`` preparation is not part of the native path."""
+    ``rectilinear=time_channel`` first applies the rectilinear preparation (K0c), as the reference does."""
     if rectilinear is not None:
-        raise NotImplementedError("torchcde_amd: rectilinear interpolation is outside the native hot path "
-                                  "(SURVEY section 8(f), rank 2).")
+        if x.dim() >= 2 and torch.isnan(x[..., 0, :]).any():
+            warnings.warn(_RECTILINEAR_WARNING)
+        x = _prepare_rectilinear_interpolation(x, rectilinear)
     t = _validate_input_path(x, t)
     _lib.require_gpu(x, "x")
     if not torch.isnan(x).any():
