@@ -74,6 +74,12 @@ const char* cde_error_string(int code);
 int cde_hermite_bdiff_coeffs(const void* x, const void* t, void* coeffs, int64_t B, int64_t L, int64_t C, int dtype,
                              void* stream);
 
+/* K1 backward: dL/dx (B, L, C) from dL/dcoeffs (B, L-1, 4C) -- what autograd produces through the reference's eager
+ * ops at interpolation_hermite_cubic_bdiff.py:5-44 (the fit is linear in x; this is its transpose).  Gradients
+ * w.r.t. `t` are not produced. */
+int cde_hermite_bdiff_coeffs_backward(const void* grad_coeffs, const void* t, void* grad_x, int64_t B, int64_t L,
+                                      int64_t C, int dtype, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K0  Missing-value construction: the NaN path of linear_interpolation_coeffs
  * (torchcde/interpolation_linear.py:13-84, reached from :169-170 and therefore also the first step

@@ -85,6 +85,39 @@ static int launch_hermite(const void* x, const void* t, void* out, int64_t B, in
   return check_launch();
 }
 
+// K1 backward: the fit is linear in x, so dL/dx is the transposed map applied to dL/dcoeffs.  With
+//   u_j = secant_j - enter_j:   two_c_j = 4 u_j / h_j,   three_d_j = -3 u_j / h_j^2   (what :17-18 reduce to)
+//   dL/du_j = 4 gc_j / h_j - 3 gd_j / h_j^2,   dL/denter_j = gb_j - dL/du_j,
+//   dL/dsecant_j = dL/du_j + dL/denter_{j+1} (+ dL/denter_0 for j = 0)          [enter_j = secant_{j-1}, enter_0 = secant_0]
+//   dL/dx_i = ga_i + dL/dsecant_{i-1} / h_{i-1} - dL/dsecant_i / h_i
+// One lane per element of dL/dx gathers the (at most) three coefficient rows it depends on: no atomics.
+template <typename T>
+__global__ __launch_bounds__(256) void hermite_bdiff_backward_kernel(const T* __restrict__ g, const T* __restrict__ t,
+                                                                     T* __restrict__ gx, int64_t B, int64_t L, int64_t C) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * L * C) return;
+  const int64_t c = e % C, bi = e / C, i = bi % L, b = bi / L;
+  const T* gs = g + b * (L - 1) * 4 * C + c;            // + j*4C + {0, C, 2C, 3C}
+  auto d_enter = [&](int64_t j, T& du) {                 // returns dL/denter_j, sets dL/du_j
+    const T h = t[j + 1] - t[j];
+    const T* r = gs + j * 4 * C;
+    du = (T)4 * r[2 * C] / h - (T)3 * r[3 * C] / (h * h);
+    return r[C] - du;
+  };
+  auto d_secant_over_h = [&](int64_t j) {                // dL/dsecant_j / h_j
+    T du, dun;
+    const T de = d_enter(j, du);
+    T ds = du;
+    if (j + 1 <= L - 2) ds += d_enter(j + 1, dun);
+    if (j == 0) ds += de;
+    return ds / (t[j + 1] - t[j]);
+  };
+  T acc = (T)0;
+  if (i <= L - 2) acc = gs[i * 4 * C] - d_secant_over_h(i);
+  if (i >= 1) acc += d_secant_over_h(i - 1);
+  gx[e] = acc;
+}
+
 // ------------------------------------------------------------------------------------------ K0 missing values
 // linear_interpolation_coeffs on data with NaNs (interpolation_linear.py:13-84): every scalar path (one series,
 // one channel) is filled independently -- observed values stay, a gap is the straight line between its nearest
@@ -286,6 +319,21 @@ extern "C" int cde_linear_fill_missing(const void* x, const void* t, void* out, 
     cde::linear_fill_kernel<double><<<grid, 256, 0, s>>>((const double*)x, (const double*)t, (double*)out, B, L, C);
   else
     return CDE_ERR_DTYPE;
+  return cde::check_launch();
+}
+
+extern "C" int cde_hermite_bdiff_coeffs_backward(const void* grad_coeffs, const void* t, void* grad_x, int64_t B,
+                                                 int64_t L, int64_t C, int dtype, void* stream) {
+  if (B < 0 || L < 2 || C < 1) return CDE_ERR_SHAPE;
+  if (B == 0) return CDE_OK;
+  if (!grad_coeffs || !t || !grad_x) return CDE_ERR_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((B * L * C + 255) / 256);
+  if (dtype == CDE_F32)
+    cde::hermite_bdiff_backward_kernel<float><<<grid, 256, 0, s>>>((const float*)grad_coeffs, (const float*)t, (float*)grad_x, B, L, C);
+  else if (dtype == CDE_F64)
+    cde::hermite_bdiff_backward_kernel<double><<<grid, 256, 0, s>>>((const double*)grad_coeffs, (const double*)t, (double*)grad_x, B, L, C);
+  else return CDE_ERR_DTYPE;
   return cde::check_launch();
 }
 

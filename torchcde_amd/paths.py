@@ -135,13 +135,48 @@ def linear_interpolation_coeffs(x, t=None, rectilinear=None):
     return out
 
 
+class _HermiteFit(torch.autograd.Function):
+    """K1 with its transpose as the backward (the fit is linear in x)."""
+
+    @staticmethod
+    def forward(ctx, x, knots):
+        L, C = x.size(-2), x.size(-1)
+        batch = x.shape[:-2]
+        src, B, _, _ = _flat3(x)
+        out = torch.empty(*batch, L - 1, 4 * C, dtype=x.dtype, device=x.device)
+        lib = _lib.load()
+        _lib.check(lib.cde_hermite_bdiff_coeffs(_lib.ptr(src), _lib.ptr(knots), _lib.ptr(out), B, L, C,
+                                                _lib.dtype_enum(x.dtype), _lib.stream_ptr(x.device)),
+                   "cde_hermite_bdiff_coeffs")
+        ctx.save_for_backward(knots)
+        ctx.shape = tuple(x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_coeffs):
+        (knots,) = ctx.saved_tensors
+        L, C = ctx.shape[-2], ctx.shape[-1]
+        g = grad_coeffs.contiguous()
+        grad_x = torch.empty(ctx.shape, dtype=g.dtype, device=g.device)
+        lib = _lib.load()
+        _lib.check(lib.cde_hermite_bdiff_coeffs_backward(_lib.ptr(g), _lib.ptr(knots), _lib.ptr(grad_x),
+                                                         grad_x.numel() // (L * C), L, C, _lib.dtype_enum(g.dtype),
+                                                         _lib.stream_ptr(g.device)), "cde_hermite_bdiff_coeffs_backward")
+        return grad_x, None
+
+
 def hermite_cubic_coefficients_with_backward_differences(x, t=None):
     """Hermite cubic spline coefficients with backward differences, (..., L-1, 4C) = [a | b | 2c | 3d].
 
     Same contract as reference interpolation_hermite_cubic_bdiff.py:23-44; computed by K1
-    (``cde_hermite_bdiff_coeffs``) in one pass over ``x``."""
+    (``cde_hermite_bdiff_coeffs``) in one pass over ``x``.  Differentiable w.r.t. ``x`` (data without missing
+    values), like the reference's eager ops; not w.r.t. ``t``."""
     coeffs = linear_interpolation_coeffs(x, t=t, rectilinear=None)
-    _no_grad_through_path(x, t)
+    _no_grad_through_path(t)
+    if torch.is_grad_enabled() and coeffs.requires_grad:
+        knots = (torch.linspace(0, coeffs.size(-2) - 1, coeffs.size(-2), dtype=coeffs.dtype, device=coeffs.device)
+                 if t is None else t.detach().to(device=coeffs.device, dtype=coeffs.dtype)).contiguous()
+        return _HermiteFit.apply(coeffs, knots)
     if t is None:
         t = torch.linspace(0, coeffs.size(-2) - 1, coeffs.size(-2), dtype=coeffs.dtype, device=coeffs.device)
     else:
