@@ -170,6 +170,20 @@ def test_probe_accepts_exactly_the_fused_families():
         field, system = probe(bad, t, z)
         assert field is None and system.shape == (4, 3, 2)
 
+    class WithDropout(Readme):                           # identity in eval(), random in train()
+        def __init__(self):
+            super().__init__()
+            self.drop = torch.nn.Dropout(0.5)
+
+        def forward(self, t, z):
+            return self.drop(self.linear(z)).view(4, 3, 2)
+
+    module = WithDropout().eval()
+    assert probe(module, t, z)[0] is not None            # verified (and cached) as the affine field
+    assert probe(module, t, z)[0] is not None
+    module.train()
+    assert probe(module, t, z)[0] is None                # the cached verdict does not survive the mode switch
+
 
 # ------------------------------------------------------------------ MFMA operand layouts (emulated)
 def _mfma_32x32x2(a_lane, b_lane, acc):

@@ -145,7 +145,11 @@ def probe(func, t0, z0):
     if linears is None:
         with torch.no_grad():
             return None, func(t0, z0)
-    signature = (tuple(z0.shape), z0.dtype, str(z0.device))
+    # The verified structure is cached per input signature; anything that commonly changes what forward() computes
+    # without changing the parameters -- train/eval mode of any submodule -- is part of the key, so e.g. a Dropout
+    # that was the identity in eval() is probed again (and refused) after train().
+    mode = tuple(m.training for m in func.modules()) if isinstance(func, torch.nn.Module) else ()
+    signature = (tuple(z0.shape), z0.dtype, str(z0.device), mode)
     try:
         known = _verified.get(func)
     except TypeError:
