@@ -1,18 +1,24 @@
 #!/bin/bash
 # Counter passes for the roofline evidence (one --pmc set per run, kernel-trace only: see the gpurun rules).
-# Usage on the GPU box:  bash scripts/pmc_passes.sh <tag>     -> gpurun_out/pmc_<tag>/*.db
+# Usage on the GPU box:  bash scripts/pmc_passes.sh <tag> [workload.py] [passes]   -> gpurun_out/pmc_<tag>/*.db
 set -u
 TAG=${1:-r01}
+WORKLOAD=${2:-scripts/prof_workload.py}
+PASSES=${3:-"mfma waves fetch write"}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() {  # name, counters...
   local name=$1; shift
-  timeout 180 rocprofv3 --pmc "$@" --kernel-trace -d $OUT -o $name -- python $GRAFT_REPO_ROOT/scripts/prof_workload.py 3 > $OUT/$name.log 2>&1
+  timeout 180 rocprofv3 --pmc "$@" --kernel-trace -d $OUT -o $name -- python $GRAFT_REPO_ROOT/$WORKLOAD 3 > $OUT/$name.log 2>&1
   echo "$name rc=$?"
 }
-run mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES
-run waves SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT
-run fetch FETCH_SIZE
-run write WRITE_SIZE
+for pass in $PASSES; do
+  case $pass in
+    mfma) run mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES ;;
+    waves) run waves SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT ;;
+    fetch) run fetch FETCH_SIZE ;;
+    write) run write WRITE_SIZE ;;
+  esac
+done
 ls -la $OUT

@@ -21,10 +21,10 @@
 // images (2 x 128 KB) do not fit the LDS and streaming one from L2 left the matrix pipe waiting on load latency
 // (measured: 34 ms per sweep vs 17 ms of MFMA time).  Instead ONE plain copy of W2 lives in LDS, row stride 132
 // floats, rows permuted so that both access patterns are bank-conflict free:
-//     physical row pr(h, c) = ((h>>2)*4 + (c>>2)*2 + ((h>>1)&1))*8 + (2*(h&3) + (c&1) + 4*((c>>1)&1)) % 8
+//     physical row pr(h, c) = ((h>>2)*4 + (c>>2)*2 + ((h>>1)&1))*8 + (2*bitrev2(h&3) + (c&3)) % 8
 //   Y2:  lane (i, kq) reads 4 consecutive floats (4 K steps) of row (h = 4P + (i>>2), c = 4tb + (i&3)) at column
 //        16*T1 + 4*kq  -> ds_read_b128, every 8-lane group covers all 8 bank slots
-//   gu:  lane (i, kq) reads row (h = 4P + kq, c) at column 16*T1 + i -> ds_read_b32, 2 lanes per bank (the minimum)
+//   gu:  lane (i, kq) reads row (h = 4P + kq, c) at column 16*T1 + i -> ds_read_b32, each half-wave on 32 distinct banks
 // with every (P, tb, T1) offset an instruction immediate.
 // 1152 MFMAs per stage = 76.3 MFLOP per series per solve for the sweep itself.
 #include "cde_mfma.h"
@@ -36,7 +36,10 @@ constexpr int W2P_FLOATS = 256 * W2P_STRIDE;
 constexpr int W1T_FLOATS = 2 * 8 * 64 * 4;                // [tile][T1][lane][4]
 constexpr int ADJ_LDS_FLOATS = W1M_FLOATS + B1M_FLOATS + W2P_FLOATS + BY_FLOATS;   // [W1 image | b1 | W2 plain | b2]
 constexpr int MLP_ADJ_IMAGE_FLOATS = ADJ_LDS_FLOATS + W1T_FLOATS;
-__host__ __device__ constexpr int w2p_residue(int h3, int c3) { return (2 * h3 + (c3 & 1) + 4 * ((c3 >> 1) & 1)) & 7; }
+// h3 = h&3 enters bit-reversed so that the four lane quarters of a gu read are shifted by 0, 16, 8, 24 banks: the LDS
+// serves a b32 read in two half-waves (lanes 0-31 = quarters 0,1; lanes 32-63 = quarters 2,3) and each half must
+// cover 32 distinct banks.  (With shifts 0, 8, 16, 24 rocprofv3 counted 1.3e8 SQ_LDS_BANK_CONFLICT cycles per launch.)
+__host__ __device__ constexpr int w2p_residue(int h3, int c3) { return (2 * (((h3 & 1) << 1) | (h3 >> 1)) + c3) & 7; }
 constexpr int U_COLS = 132, G2_COLS = 256, G1_COLS = 128, Z_COLS = 36;
 
 __device__ __forceinline__ float mlp_adj_image(const float* __restrict__ W1, const float* __restrict__ b1,
@@ -129,7 +132,8 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_mlp_sweep(
       const bool more = e_next < 4 * k_end;
       const int64_t nidx = more ? stage_index[e_next] : idx;
       const float nfrac = more ? stage_frac[e_next] : frac;
-      if (nidx != idx) row = load_row<DEGREE>(coeffs, sc, n_intervals, nidx, Cr);
+      // `row` is dead from here to the end of the tile loop: the next stage's row is (re)loaded only then, so its 24
+      // registers are free while the register pressure peaks (reloading costs 6 KB of L2 traffic per wave and stage)
       const float wq = ((stage == 0 || stage == 3) ? 0.125f : 0.375f) * ds;     // 3/8-rule quadrature weight
       const int64_t out_row = ((k - k_begin) * 4 + stage) * B + series;          // (stage, series)
 
@@ -219,6 +223,7 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_mlp_sweep(
       }
 
       __builtin_amdgcn_sched_barrier(0);
+      row = load_row<DEGREE>(coeffs, sc, n_intervals, nidx, Cr);     // for the next stage; lands during the va phase
       // ---- dL/dY1 = gu * relu'(pre1);  va = W1^T dL/dY1
       float g1[32];
 #pragma unroll
