@@ -326,3 +326,112 @@ def test_mfma16_forward_layout_reproduces_the_vector_field():
     got = np.concatenate(acc, axis=1)                       # register 4T + r  <->  unit 8q + 4T + r
     expect = np.stack([f_ref[n, 8 * q + m] for m in range(8)], axis=1)
     assert np.allclose(got, expect)
+
+
+# ------------------------------------------------------------------ pre-activation / two-layer layouts (emulated)
+def _lane_units(n, q):
+    """field_act16 / field_mlp16 ownership: lane (n, q) holds hidden units q, 4+q, .., 28+q of series n."""
+    return [4 * m + q for m in range(8)]
+
+
+def test_preactivation_tiling_reproduces_tanh_field_and_two_layer_field():
+    """Lane-level emulation of cde_mfma.h: field_act16 and field_mlp16 (index math of the weight/bias images, the
+    in-lane contraction with dX, and the register hand-over from layer 1 to layer 2)."""
+    rng = np.random.default_rng(5)
+    H, C, Wd = 32, 8, 128
+    z = rng.standard_normal((16, H))
+    dX = rng.standard_normal((16, C))
+    lanes = [(l & 15, l >> 4) for l in range(64)]
+
+    # ---- one layer + tanh: tile T = 2P + tb, row i <-> (h = 4P + (i>>2), c = 4tb + (i&3)), K step s feeds unit 4s + kq
+    W = rng.standard_normal((H * C, H)) * 0.2
+    b = rng.standard_normal(H * C) * 0.2
+    want = np.einsum("nhc,nc->nh", np.tanh(z @ W.T + b).reshape(16, H, C), dX)
+    got = np.zeros((16, H))
+    for P in range(8):
+        acc = [np.zeros((64, 4)), np.zeros((64, 4))]
+        for tb in range(2):
+            for l, (n, q) in enumerate(lanes):                       # bias = initial accumulator: by16_image(T, q, r)
+                for r in range(4):
+                    acc[tb][l, r] = b[(4 * P + q) * C + 4 * tb + r]
+            for s in range(8):
+                a_lane = [W[(4 * P + (i >> 2)) * C + 4 * tb + (i & 3), 4 * s + kq] for i, kq in lanes]   # wy16_image
+                b_lane = [z[n, _lane_units(n, kq)[s]] for n, kq in lanes]                                # own register s
+                _mfma_16x16x4(a_lane, b_lane, acc[tb])
+        for l, (n, q) in enumerate(lanes):
+            y = np.concatenate([acc[0][l], acc[1][l]])                # channels 0..7 of unit 4P+q, all in this lane
+            got[n, 4 * P + q] = np.tanh(y) @ dX[n]
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-12)
+
+    # ---- two layers: layer-1 C/D fragment (unit 16*T1 + 4q + r) is layer 2's B operand of K step (T1, r)
+    W1 = rng.standard_normal((Wd, H)) * 0.2
+    b1 = rng.standard_normal(Wd) * 0.2
+    W2 = rng.standard_normal((H * C, Wd)) * 0.1
+    b2 = rng.standard_normal(H * C) * 0.1
+    hidden = np.maximum(z @ W1.T + b1, 0)
+    want = np.einsum("nhc,nc->nh", np.tanh(hidden @ W2.T + b2).reshape(16, H, C), dX)
+    u = np.zeros((64, 32))                                            # per-lane registers u[4*T1 + r]
+    for T1 in range(8):
+        acc = np.zeros((64, 4))
+        for l, (n, q) in enumerate(lanes):
+            for r in range(4):
+                acc[l, r] = b1[16 * T1 + 4 * q + r]
+        for s in range(8):
+            a_lane = [W1[16 * T1 + i, 4 * s + kq] for i, kq in lanes]
+            b_lane = [z[n, 4 * s + kq] for n, kq in lanes]
+            _mfma_16x16x4(a_lane, b_lane, acc)
+        u[:, 4 * T1:4 * T1 + 4] = np.maximum(acc, 0)
+    for l, (n, q) in enumerate(lanes):                                # ownership claimed in the header comment
+        for T1 in range(8):
+            assert np.allclose(u[l, 4 * T1:4 * T1 + 4], hidden[n, 16 * T1 + 4 * q:16 * T1 + 4 * q + 4])
+    got = np.zeros((16, H))
+    for P in range(8):
+        acc = [np.zeros((64, 4)), np.zeros((64, 4))]
+        for tb in range(2):
+            for l, (n, q) in enumerate(lanes):
+                for r in range(4):
+                    acc[tb][l, r] = b2[(4 * P + q) * C + 4 * tb + r]
+            for T1 in range(8):
+                for j in range(4):                                    # K step (T1, r = j): column 16*T1 + 4*kq + j
+                    a_lane = [W2[(4 * P + (i >> 2)) * C + 4 * tb + (i & 3), 16 * T1 + 4 * kq + j] for i, kq in lanes]
+                    b_lane = [u[l, 4 * T1 + j] for l in range(64)]
+                    _mfma_16x16x4(a_lane, b_lane, acc[tb])
+        for l, (n, q) in enumerate(lanes):
+            got[n, 4 * P + q] = np.tanh(np.concatenate([acc[0][l], acc[1][l]])) @ dX[n]
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-12)
+
+
+def test_plain_w2_copy_permutation_is_bijective_and_bank_conflict_free():
+    """rk4_mlp_adjoint.hip keeps ONE copy of W2 in LDS (row stride 132 floats, permuted rows) for two access patterns.
+    Checks: the row permutation is a bijection, the lane-offset formulas of the kernel address the intended element, a
+    ds_read_b128 wave access puts every 8-lane group on 8 distinct 16-byte bank slots, and a ds_read_b32 access puts
+    each half-wave on 32 distinct banks."""
+    S = 132
+
+    def residue(h3, c3):
+        return (2 * (((h3 & 1) << 1) | (h3 >> 1)) + c3) & 7
+
+    def prow(h, c):
+        return ((h >> 2) * 4 + (c >> 2) * 2 + ((h >> 1) & 1)) * 8 + residue(h & 3, c & 3)
+
+    assert {prow(h, c) for h in range(32) for c in range(8)} == set(range(256))
+    for P in range(8):
+        for c in range(8):
+            tb = c >> 2
+            for T1 in range(8):
+                for half in range(2):                                 # gu: lane (n, q) reads row (4P+q, c), column 16*T1 + n
+                    banks = set()
+                    for l in range(32 * half, 32 * half + 32):
+                        n, q = l & 15, l >> 4
+                        off = ((q >> 1) * 8 + residue(q, c & 3)) * S + n + (4 * P + 2 * tb) * 8 * S + 16 * T1
+                        assert off == prow(4 * P + q, c) * S + 16 * T1 + n
+                        banks.add(off % 32)
+                    assert len(banks) == 32
+                for group in range(8):                                # Y2: lane (n, q) reads 4 floats of row (4P+(n>>2), 4tb+(n&3))
+                    slots = set()
+                    for l in range(8 * group, 8 * group + 8):
+                        n, q = l & 15, l >> 4
+                        off = ((n >> 3) * 8 + residue(n >> 2, n & 3)) * S + 4 * q + (4 * P + 2 * tb) * 8 * S + 16 * T1
+                        assert off == prow(4 * P + (n >> 2), 4 * tb + (n & 3)) * S + 16 * T1 + 4 * q and off % 4 == 0
+                        slots.add((off // 4) % 8)
+                    assert len(slots) == 8
