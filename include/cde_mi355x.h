@@ -183,7 +183,9 @@ int cde_rk4_forward_mlp(const void* coeffs, const void* knots, int64_t n_interva
  *                                 the MFMA weight images, into `workspace`
  *   cde_rk4_adjoint_mlp_sweep     integrates steps k_begin .. k_end-1 of `sgrid`; y_state / a_state (B, H) hold
  *                                 (z, a) on entry and on return (the caller re-seeds z and adds the incoming
- *                                 gradient between output intervals, as torchdiffeq does)
+ *                                 gradient between output intervals, as torchdiffeq does); `grad_coeffs` is NULL or a
+ *                                 caller-zeroed buffer shaped like `coeffs` that accumulates dL/dcoeffs over the calls
+ *                                 (as cde_rk4_adjoint_linear_dcontrol)
  * f32, H <= 32, C <= 8, width <= 128.
  * ------------------------------------------------------------------------------------------- */
 size_t cde_rk4_adjoint_mlp_workspace_bytes(int64_t n_sgrid);
@@ -193,8 +195,9 @@ int cde_rk4_adjoint_mlp_prepare(const void* knots, int64_t n_intervals, const vo
                                 size_t workspace_bytes, void* stream);
 int cde_rk4_adjoint_mlp_sweep(const void* coeffs, const void* knots, int64_t n_intervals, int degree, int act,
                               void* y_state, void* a_state, const void* sgrid, int64_t n_sgrid, int64_t k_begin,
-                              int64_t k_end, void* U, void* G2, void* G1, void* Z, int64_t B, int64_t C, int64_t H,
-                              int dtype, int time_dtype, const void* workspace, size_t workspace_bytes, void* stream);
+                              int64_t k_end, void* U, void* G2, void* G1, void* Z, void* grad_coeffs, int64_t B,
+                              int64_t C, int64_t H, int dtype, int time_dtype, const void* workspace,
+                              size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K3  Fused continuous-adjoint reverse sweep for K2.

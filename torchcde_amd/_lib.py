@@ -91,8 +91,8 @@ _SIGNATURES = {
                                     _p, _i64, _i64, _i64, _i, _p, _sz, _i64, _i64, _p]),
     "cde_rk4_adjoint_mlp_workspace_bytes": (_sz, [_i64]),
     "cde_rk4_adjoint_mlp_prepare": (_i, [_p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _i64, _i64, _i, _i, _p, _sz, _p]),
-    "cde_rk4_adjoint_mlp_sweep": (_i, [_p, _p, _i64, _i, _i, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64,
-                                       _i64, _i, _i, _p, _sz, _p]),
+    "cde_rk4_adjoint_mlp_sweep": (_i, [_p, _p, _i64, _i, _i, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _i64,
+                                       _i64, _i64, _i, _i, _p, _sz, _p]),
     "cde_rk4_adjoint_linear_dcontrol": (_i, [_p, _p, _i64, _i, _p, _p, _i, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _p,
                                              _i64, _i64, _i64, _i, _i, _p, _sz, _p]),
     "cde_rk4_adjoint_linear": (_i, [_p, _p, _i64, _i, _p, _p, _i, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _i64, _i64,

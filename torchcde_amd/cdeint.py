@@ -264,7 +264,7 @@ class _MlpPlan:
         groups = stages * split
         return torch.bmm(left.view(groups, -1, left.size(1)).transpose(1, 2), right.view(groups, -1, right.size(1))).sum(0)
 
-    def run_adjoint(self, z_saved, grad_out):
+    def run_adjoint(self, z_saved, grad_out, want_control=False):
         """torchdiffeq's odeint_adjoint backward for this field: per output interval (last to first) the augmented
         state is integrated in reversed time by K3m in chunks of steps; each chunk's per-stage factors (in HBM) are
         reduced into the parameter gradients by two GEMMs whose extra "ones" column yields the bias gradients."""
@@ -284,6 +284,7 @@ class _MlpPlan:
         a = grad_out[:, -1].to(torch.float32).contiguous()
         acc2 = torch.zeros(256, 132, dtype=torch.float32, device=dev)
         acc1 = torch.zeros(128, 36, dtype=torch.float32, device=dev)
+        grad_x = torch.zeros_like(self.coeffs) if want_control else None     # accumulated by the sweep launches
         if g.n_sgrid > 1:
             _lib.check(lib.cde_rk4_adjoint_mlp_prepare(
                 _lib.ptr(self.knots), self.n_intervals, _lib.ptr(g.sgrid), g.n_sgrid, _lib.ptr(w1), _lib.ptr(b1), width,
@@ -306,7 +307,8 @@ class _MlpPlan:
                 _lib.check(lib.cde_rk4_adjoint_mlp_sweep(
                     _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, f.act, _lib.ptr(y),
                     _lib.ptr(a), _lib.ptr(g.sgrid), g.n_sgrid, k, ke, _lib.ptr(U), _lib.ptr(G2), _lib.ptr(G1),
-                    _lib.ptr(Z), B, C, H, f32, tdt, _lib.ptr(workspace), nbytes, stream), "cde_rk4_adjoint_mlp_sweep")
+                    _lib.ptr(Z), _lib.ptr(grad_x), B, C, H, f32, tdt, _lib.ptr(workspace), nbytes, stream),
+                    "cde_rk4_adjoint_mlp_sweep")
                 stages = 4 * (ke - k)
                 n = stages * B
                 acc2 += self._reduce(G2[:n], U[:n], stages, B)
@@ -319,24 +321,31 @@ class _MlpPlan:
         grad_b2 = acc2[:, 128].reshape(32, 8)[:H, :C].reshape(H * C)
         grad_w1 = acc1[:width, :H].contiguous()
         grad_b1 = acc1[:width, 32].contiguous()
-        return a.reshape(*self.batch, H), grad_w1, grad_b1, grad_w2, grad_b2
+        return a.reshape(*self.batch, H), grad_w1, grad_b1, grad_w2, grad_b2, grad_x
 
 
 class _FusedMlpRK4(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, z0, w1, b1, w2, b2, plan):
+    def forward(ctx, z0, w1, b1, w2, b2, plan, want_x, *control):
         out = plan.run(z0)
-        ctx.plan = plan
+        ctx.plan, ctx.want_x = plan, want_x
         ctx.save_for_backward(out)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         (out,) = ctx.saved_tensors
-        grad_z0, gw1, gb1, gw2, gb2 = ctx.plan.run_adjoint(out, grad_out)
+        plan = ctx.plan
+        grad_z0, gw1, gb1, gw2, gb2, grad_x = plan.run_adjoint(out, grad_out, ctx.want_x)
         need = ctx.needs_input_grad
+        control_grads = ()
+        if ctx.want_x:
+            C = plan.C
+            gx = grad_x.reshape(*plan.batch, grad_x.size(-2), grad_x.size(-1))
+            pieces = (gx[..., C:2 * C], gx[..., 2 * C:3 * C], gx[..., 3 * C:]) if plan.degree == _lib.PATH_CUBIC else (gx,)
+            control_grads = tuple(g if n else None for g, n in zip(pieces, need[7:]))
         return (grad_z0 if need[0] else None, gw1 if need[1] else None, gb1 if need[2] else None,
-                gw2 if need[3] else None, gb2 if need[4] else None, None)
+                gw2 if need[3] else None, gb2 if need[4] else None, None, None) + control_grads
 
 
 def _mlp_fusable(field, H, C, z0, packed):
@@ -563,9 +572,21 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         p.requires_grad for p in (func.parameters() if isinstance(func, torch.nn.Module) else ())))
     fused = (field is not None and ((method == "rk4" and (adjoint or not wants_grad))
                                     or (method == "dopri5" and not wants_grad)))
-    if (mlp is not None and wants_grad and adjoint and method == "rk4" and variant != _lib.VARIANT_GENERIC
+    mlp_want_x = False
+    mlp_params_ok = mlp is not None and kwargs.get("adjoint_params") is None
+    if mlp is not None and kwargs.get("adjoint_params") is not None:
+        # adjoint_params = all four layer parameters, optionally + the control's coefficient tensor
+        given = tuple(kwargs["adjoint_params"])
+        own = (mlp.hidden.weight, mlp.hidden.bias, mlp.output.weight, mlp.output.bias)
+        storages = {b.untyped_storage().data_ptr() for b in X._control_buffers()}
+        extra = [p for p in given if not any(p is o for o in own)]
+        mlp_params_ok = (all(any(p is o for p in given) for o in own)
+                         and all(isinstance(p, torch.Tensor) and p.untyped_storage().data_ptr() in storages for p in extra))
+        mlp_want_x = mlp_params_ok and any(p.requires_grad for p in extra) and torch.is_grad_enabled()
+    if (mlp is not None and (wants_grad or mlp_want_x) and adjoint and method == "rk4"
+            and variant != _lib.VARIANT_GENERIC
             and set(options or ()) <= {"step_size"} and set(kwargs.get("adjoint_options") or ()) <= {"step_size"}
-            and kwargs.get("adjoint_method") in (None, "rk4") and kwargs.get("adjoint_params") is None
+            and kwargs.get("adjoint_method") in (None, "rk4") and mlp_params_ok
             and isinstance(t, torch.Tensor) and t.dim() == 1 and t.is_floating_point() and t.numel() >= 1
             and not t.requires_grad):
         # two-layer field, training: fused forward (K2m) + continuous-adjoint sweep (K3m) and two GEMMs
@@ -575,7 +596,9 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
             adj_opts = kwargs.get("adjoint_options")
             adj_step = step if adj_opts is None else _parse_fixed_options(adj_opts, "adjoint")
             plan = _MlpPlan(X, mlp, batch, H, C, t, step, adj_step)
-            return _FusedMlpRK4.apply(z0, mlp.hidden.weight, mlp.hidden.bias, mlp.output.weight, mlp.output.bias, plan)
+            control_inputs = X._control_buffers() if mlp_want_x else ()
+            return _FusedMlpRK4.apply(z0, mlp.hidden.weight, mlp.hidden.bias, mlp.output.weight, mlp.output.bias, plan,
+                                      mlp_want_x, *control_inputs)
     if (mlp is not None and not wants_grad and variant != _lib.VARIANT_GENERIC
             and isinstance(t, torch.Tensor) and t.dim() == 1 and t.is_floating_point() and t.numel() >= 1):
         # two-layer field, nothing to differentiate: the fused forward kernels (K2m / K4 with the two-layer field)

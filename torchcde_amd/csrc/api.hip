@@ -36,7 +36,7 @@ int launch_mlp_adjoint_images(const void*, const void*, int64_t, const void*, co
 template <typename TT>
 int launch_mlp_adjoint_sweep(const void*, const void*, int64_t, int, int, const float*, void*, void*, const void*,
                              int64_t, int64_t, const int64_t*, const void*, void*, void*, void*, void*, int64_t,
-                             int64_t, int64_t, hipStream_t);
+                             int64_t, int64_t, void*, hipStream_t);
 
 // Stage table: for solver step k over [grid[k], grid[k+1]] and RK stage j, the control interval
 // and fractional part at the stage time -- what CubicSpline._interpret_t (interpolation_cubic.py:
@@ -275,9 +275,9 @@ extern "C" int cde_rk4_adjoint_mlp_prepare(const void* knots, int64_t n_interval
 
 extern "C" int cde_rk4_adjoint_mlp_sweep(const void* coeffs, const void* knots, int64_t n_intervals, int degree, int act,
                                          void* y_state, void* a_state, const void* sgrid, int64_t n_sgrid,
-                                         int64_t k_begin, int64_t k_end, void* U, void* G2, void* G1, void* Z, int64_t B,
-                                         int64_t C, int64_t H, int dtype, int time_dtype, const void* workspace,
-                                         size_t workspace_bytes, void* stream) {
+                                         int64_t k_begin, int64_t k_end, void* U, void* G2, void* G1, void* Z,
+                                         void* grad_coeffs, int64_t B, int64_t C, int64_t H, int dtype, int time_dtype,
+                                         const void* workspace, size_t workspace_bytes, void* stream) {
   if (B < 1 || C < 1 || H < 1 || n_intervals < 1 || k_begin < 0 || k_end < k_begin || k_end > n_sgrid - 1) return CDE_ERR_SHAPE;
   if (dtype != CDE_F32) return dtype == CDE_F64 ? CDE_ERR_UNSUPPORTED : CDE_ERR_DTYPE;
   if (H > 32 || C > 8) return CDE_ERR_UNSUPPORTED;
@@ -291,9 +291,11 @@ extern "C" int cde_rk4_adjoint_mlp_sweep(const void* coeffs, const void* knots, 
   hipStream_t s = (hipStream_t)stream;
   if (time_dtype == CDE_F32)
     return cde::launch_mlp_adjoint_sweep<float>(coeffs, knots, n_intervals, degree, act, img, y_state, a_state, sgrid,
-                                                k_begin, k_end, stage_index, stage_frac, U, G2, G1, Z, B, C, H, s);
+                                                k_begin, k_end, stage_index, stage_frac, U, G2, G1, Z, B, C, H,
+                                                grad_coeffs, s);
   if (time_dtype == CDE_F64)
     return cde::launch_mlp_adjoint_sweep<double>(coeffs, knots, n_intervals, degree, act, img, y_state, a_state, sgrid,
-                                                 k_begin, k_end, stage_index, stage_frac, U, G2, G1, Z, B, C, H, s);
+                                                 k_begin, k_end, stage_index, stage_frac, U, G2, G1, Z, B, C, H,
+                                                grad_coeffs, s);
   return CDE_ERR_DTYPE;
 }

@@ -81,13 +81,16 @@ __device__ __forceinline__ void stream_store4(float* p, float a, float b, float 
   __builtin_nontemporal_store(f32x4{a, b, c, d}, reinterpret_cast<f32x4*>(p));
 }
 
-template <typename TT, int DEGREE, int ACT>
+// DCOEFF: also accumulate dL/d(control coefficients) into `grad_coeffs` (zeroed by the caller, layout of `coeffs`),
+// as K3a does: d(a.f)/d(dX_c) = sum_h a_h act(Y2)_hc, here summed in-lane over the lane's 8 hidden units and then
+// over the four lane quarters with two shuffles; quarter q carries channels 2q, 2q+1 to the coefficient row.
+template <typename TT, int DEGREE, int ACT, bool DCOEFF = false>
 __global__ __launch_bounds__(512, 2) void rk4_adjoint_mlp_sweep(
     const float* __restrict__ coeffs, const float* __restrict__ knots, int64_t n_intervals,
     const float* __restrict__ img, float* __restrict__ y_state, float* __restrict__ a_state,
     const TT* __restrict__ sgrid, int64_t k_begin, int64_t k_end, const int64_t* __restrict__ stage_index,
     const float* __restrict__ stage_frac, float* __restrict__ U, float* __restrict__ G2, float* __restrict__ G1,
-    float* __restrict__ Z, int64_t B, Dims dims) {
+    float* __restrict__ Z, int64_t B, Dims dims, float* __restrict__ grad_coeffs = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   {
     const float4* src = reinterpret_cast<const float4*>(img);
@@ -118,6 +121,27 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_mlp_sweep(
   int64_t idx = stage_index[4 * k_begin];
   float frac = stage_frac[4 * k_begin];
   Row<DEGREE> row = load_row<DEGREE>(coeffs, sc, n_intervals, idx, Cr);
+
+  // dL/d(coefficient row in use) for channels 2q, 2q+1: cubic (b, 2c, 3d), linear (left knot, right knot)
+  float gc0[2] = {0.f, 0.f}, gc1[2] = {0.f, 0.f}, gc2[2] = {0.f, 0.f};
+  auto flush_control_grad = [&](int64_t at) {
+    if constexpr (DCOEFF) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int c = 2 * q + j;
+        if (valid && c < Cr) {
+          if (DEGREE == CDE_PATH_CUBIC) {
+            float* g = grad_coeffs + (series * n_intervals + at) * 4 * Cr;
+            g[Cr + c] += gc0[j]; g[2 * Cr + c] += gc1[j]; g[3 * Cr + c] += gc2[j];
+          } else {
+            float* g = grad_coeffs + (series * (n_intervals + 1) + at) * Cr;
+            g[c] += gc0[j]; g[Cr + c] += gc1[j];
+          }
+        }
+        gc0[j] = 0.f; gc1[j] = 0.f; gc2[j] = 0.f;
+      }
+    }
+  };
 
   for (int64_t k = k_begin; k < k_end; ++k) {
     const float ds = (float)(sgrid[k + 1] - sgrid[k]);
@@ -184,6 +208,7 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_mlp_sweep(
 #pragma unroll
       for (int T1 = 0; T1 < 8; ++T1) gu[T1] = f32x4{0.f, 0.f, 0.f, 0.f};
       f32x4 fa, fb;
+      float gdx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // d(a.f)/d(dX_c), this lane's hidden units (DCOEFF)
 #pragma unroll
       for (int P = 0; P < 8; ++P) {
         const float4 c0 = bb2[8 * P], c1 = bb2[8 * P + 4];
@@ -206,6 +231,7 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_mlp_sweep(
           f = c == 0 ? t * dX[0] : __builtin_fmaf(t, dX[c], f);
           const float slope = ACT == CDE_ACT_TANH ? __builtin_fmaf(-t, t, 1.f) : 1.f;
           g2[c] = as[P] * (dX[c] * slope);
+          if constexpr (DCOEFF) gdx[c] = __builtin_fmaf(as[P], t, gdx[c]);
         }
         if (P < 4) fa[P] = f; else fb[P - 4] = f;
         if (valid) {
@@ -223,6 +249,26 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_mlp_sweep(
       }
 
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (DCOEFF) {
+        float mine[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          // sum over the four lane quarters (lanes n, n+16, n+32, n+48), then quarter q keeps channels 2q, 2q+1
+          float v[4];
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            float x = gdx[2 * qq + j];
+            x += __shfl_xor(x, 16, 64);
+            x += __shfl_xor(x, 32, 64);
+            v[qq] = x;
+          }
+          mine[j] = q == 0 ? v[0] : q == 1 ? v[1] : q == 2 ? v[2] : v[3];
+          const float w = wq * mine[j];
+          if (DEGREE == CDE_PATH_CUBIC) { gc0[j] += w; gc1[j] += w * frac; gc2[j] += w * frac * frac; }
+          else { gc0[j] -= w / width; gc1[j] += w / width; }
+        }
+        if (nidx != idx) flush_control_grad(idx);
+      }
       row = load_row<DEGREE>(coeffs, sc, n_intervals, nidx, Cr);     // for the next stage; lands during the va phase
       // ---- dL/dY1 = gu * relu'(pre1);  va = W1^T dL/dY1
       float g1[32];
@@ -270,6 +316,7 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_mlp_sweep(
     }
     ya = za; yb = zb; aa = sa; ab = sb;
   }
+  flush_control_grad(idx);                     // end of this chunk of steps
   if (valid) {
     store_units4<4>(y_state + series * Hr, ua, Hr, ya);
     store_units4<4>(y_state + series * Hr, ub, Hr, yb);
@@ -292,19 +339,23 @@ template <typename TT>
 int launch_mlp_adjoint_sweep(const void* coeffs, const void* knots, int64_t n_intervals, int degree, int act,
                              const float* img, void* y_state, void* a_state, const void* sgrid, int64_t k_begin,
                              int64_t k_end, const int64_t* stage_index, const void* stage_frac, void* U, void* G2,
-                             void* G1, void* Z, int64_t B, int64_t C, int64_t H, hipStream_t s) {
+                             void* G1, void* Z, int64_t B, int64_t C, int64_t H, void* grad_coeffs, hipStream_t s) {
   if (k_end <= k_begin) return CDE_OK;
   const Dims dims{(int)H, (int)C};
   const unsigned blocks = (unsigned)((B + 127) / 128);
   const size_t lds = (size_t)ADJ_LDS_FLOATS * sizeof(float);
-#define CDE_SWEEP(D, A)                                                                                            \
+#define CDE_SWEEP_X(D, A, X)                                                                                       \
   do {                                                                                                             \
-    (void)hipFuncSetAttribute((const void*)rk4_adjoint_mlp_sweep<TT, D, A>,                                        \
+    (void)hipFuncSetAttribute((const void*)rk4_adjoint_mlp_sweep<TT, D, A, X>,                                     \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
-    rk4_adjoint_mlp_sweep<TT, D, A><<<blocks, 512, lds, s>>>(                                                      \
+    rk4_adjoint_mlp_sweep<TT, D, A, X><<<blocks, 512, lds, s>>>(                                                   \
         (const float*)coeffs, (const float*)knots, n_intervals, img, (float*)y_state, (float*)a_state,             \
         (const TT*)sgrid, k_begin, k_end, stage_index, (const float*)stage_frac, (float*)U, (float*)G2, (float*)G1, \
-        (float*)Z, B, dims);                                                                                       \
+        (float*)Z, B, dims, (float*)grad_coeffs);                                                                  \
+  } while (0)
+#define CDE_SWEEP(D, A)                                                                                            \
+  do {                                                                                                             \
+    if (grad_coeffs) CDE_SWEEP_X(D, A, true); else CDE_SWEEP_X(D, A, false);                                       \
   } while (0)
   if (degree != CDE_PATH_CUBIC && degree != CDE_PATH_LINEAR) return CDE_ERR_UNSUPPORTED;
   if (act == CDE_ACT_NONE) {
@@ -313,14 +364,15 @@ int launch_mlp_adjoint_sweep(const void* coeffs, const void* knots, int64_t n_in
     if (degree == CDE_PATH_CUBIC) CDE_SWEEP(CDE_PATH_CUBIC, CDE_ACT_TANH); else CDE_SWEEP(CDE_PATH_LINEAR, CDE_ACT_TANH);
   } else return CDE_ERR_UNSUPPORTED;
 #undef CDE_SWEEP
+#undef CDE_SWEEP_X
   return check_launch();
 }
 
 template int launch_mlp_adjoint_sweep<float>(const void*, const void*, int64_t, int, int, const float*, void*, void*,
                                              const void*, int64_t, int64_t, const int64_t*, const void*, void*, void*,
-                                             void*, void*, int64_t, int64_t, int64_t, hipStream_t);
+                                             void*, void*, int64_t, int64_t, int64_t, void*, hipStream_t);
 template int launch_mlp_adjoint_sweep<double>(const void*, const void*, int64_t, int, int, const float*, void*, void*,
                                               const void*, int64_t, int64_t, const int64_t*, const void*, void*, void*,
-                                              void*, void*, int64_t, int64_t, int64_t, hipStream_t);
+                                              void*, void*, int64_t, int64_t, int64_t, void*, hipStream_t);
 
 }  // namespace cde
