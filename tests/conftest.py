@@ -13,6 +13,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The oracle (the checker) works on small tensors: on a 256-core host torch's default thread count turns every
+    # tiny op into a fork-join over hundreds of threads and the suite spends its time there.
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
 
 
 @pytest.fixture(scope="session")
