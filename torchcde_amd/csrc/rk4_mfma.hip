@@ -47,8 +47,14 @@ __device__ __forceinline__ void wave_lds_sync() {
 // ACT != CDE_ACT_NONE: same skeleton on the pre-activation form (cde_mfma.h: field_act16) -- the lane then owns
 // units q, 4+q, .., 28+q instead of 8q..8q+7.
 // MLP: two-layer field (cde_mfma.h: field_mlp16), W1/bias1/width describe the hidden layer.
+// Workgroup shape: 512 threads, 2 waves per SIMD for every form.  (Tried for the one-layer activation form, which
+// is VALU-co-limited: 256-thread workgroups at 3 waves per SIMD, <= 168 registers -- 4.29 ms vs 4.0-4.2 ms, the
+// spills it forces cost more than the third wave hides.)
+template <int ACT, bool MLP> constexpr int fwd_block_threads() { return 512; }
+template <int ACT, bool MLP> constexpr int fwd_waves_per_simd() { return 2; }
+
 template <typename TT, int DEGREE, int ACT, bool MLP = false>
-__global__ __launch_bounds__(512, 2) void rk4_forward_mfma(
+__global__ __launch_bounds__((fwd_block_threads<ACT, MLP>()), (fwd_waves_per_simd<ACT, MLP>())) void rk4_forward_mfma(
     const float* __restrict__ coeffs, const float* __restrict__ knots, int64_t n_intervals,
     const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ z0,
     const TT* __restrict__ grid, int64_t n_grid, const TT* __restrict__ t_out, int64_t n_out,
@@ -66,7 +72,7 @@ __global__ __launch_bounds__(512, 2) void rk4_forward_mfma(
   const int Hr = dims.H, Cr = dims.C;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, q = lane >> 4;
-  const int64_t tile = (int64_t)blockIdx.x * 8 + wave;
+  const int64_t tile = (int64_t)blockIdx.x * (fwd_block_threads<ACT, MLP>() / 64) + wave;
   if (tile * 16 >= B) return;
   // Waves w and w+4 of a 512-thread workgroup share a SIMD and do identical work: left alone they run in
   // lockstep and both sit in their MFMA-free RK tail at the same time.  Half a stage of head start for one of
@@ -111,13 +117,20 @@ __global__ __launch_bounds__(512, 2) void rk4_forward_mfma(
       const bool more = e_next < 4 * n_steps;
       const int64_t nidx = more ? stage_index[e_next] : idx;
       const float nfrac = more ? stage_frac[e_next] : frac;
+      // product form: the next row is fetched before the MFMA chain (its latency hides behind it); the activation
+      // forms are register-bound, so they fetch it after the field evaluation (it then lands during the RK tail of
+      // this wave / the MFMA phase of the other waves on the SIMD)
       Row<DEGREE> nrow = row;
-      if (nidx != idx) nrow = load_row<DEGREE>(coeffs, sc, n_intervals, nidx, Cr);
+      if constexpr (PRODUCT) { if (nidx != idx) nrow = load_row<DEGREE>(coeffs, sc, n_intervals, nidx, Cr); }
 
       f32x4 fa, fb;
       if constexpr (PRODUCT) field16(wA, wB, za, zb, dX, q, fa, fb);
       else if constexpr (MLP) field_mlp16<ACT>(lds, lane, q, za, zb, dX, fa, fb);
       else field_act16<ACT>(wy, by, za, zb, dX, fa, fb);
+      if constexpr (!PRODUCT) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (nidx != idx) nrow = load_row<DEGREE>(coeffs, sc, n_intervals, nidx, Cr);
+      }
 
       // torchdiffeq rk4_alt_step_func (3/8 rule), association order preserved
       const float third = (float)(1.0 / 3.0);
@@ -739,9 +752,11 @@ int launch_forward_mfma(const void* coeffs, const void* knots, int64_t n_interva
                         int64_t n_out, void* z_out, int64_t B, int64_t C, int64_t H, const int64_t* stage_index,
                         const void* stage_frac, hipStream_t s) {
   const Dims dims{(int)H, (int)C};
-  const unsigned blocks = (unsigned)((B + 127) / 128);     // 8 waves x 16 series, one workgroup per CU at B = 32768
+  // product form: 8 waves x 16 series per workgroup (one per CU at B = 32768); activation form: 4 waves x 16 series
 #define CDE_FWD(D, A)                                                                                               \
-  rk4_forward_mfma<TT, D, A><<<blocks, 512, (A == CDE_ACT_NONE ? W16_FLOATS : ACT16_LDS_FLOATS) * sizeof(float), s>>>( \
+  rk4_forward_mfma<TT, D, A><<<(unsigned)((B + fwd_block_threads<A, false>() / 4 - 1) / (fwd_block_threads<A, false>() / 4)), \
+                               fwd_block_threads<A, false>(),                                                       \
+                               (A == CDE_ACT_NONE ? W16_FLOATS : ACT16_LDS_FLOATS) * sizeof(float), s>>>(           \
       (const float*)coeffs, (const float*)knots, n_intervals, (const float*)W, (const float*)bias, (const float*)z0, \
       (const TT*)grid, n_grid, (const TT*)t_out, n_out, (float*)z_out, B, stage_index, (const float*)stage_frac, dims)
   if (degree != CDE_PATH_CUBIC && degree != CDE_PATH_LINEAR) return CDE_ERR_UNSUPPORTED;
