@@ -268,6 +268,28 @@ __device__ __forceinline__ float tanh_fast(float x) {
 template <int ACT>
 __device__ __forceinline__ float activate(float y) { return ACT == CDE_ACT_TANH ? tanh_fast(y) : y; }
 
+// two at a time: the polynomial / affine parts become v_pk_mul / v_pk_add / v_pk_fma (9 packed + 12 scalar
+// instructions per pair instead of 2 x 14); same operations, same results as tanh_fast
+__device__ __forceinline__ f32x2 tanh_fast2(f32x2 x) {
+  const f32x2 ax = {__builtin_fabsf(x[0]), __builtin_fabsf(x[1])};
+  const f32x2 arg = ax * 2.885390081777927f;
+  const f32x2 e = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+  const f32x2 d = e + 1.f;
+  const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  const f32x2 big = __builtin_elementwise_fma(f32x2{-2.f, -2.f}, r, f32x2{1.f, 1.f});
+  const f32x2 x2 = ax * ax;
+  f32x2 p = __builtin_elementwise_fma(x2, f32x2{62.f / 2835.f, 62.f / 2835.f}, f32x2{-17.f / 315.f, -17.f / 315.f});
+  p = __builtin_elementwise_fma(x2, p, f32x2{2.f / 15.f, 2.f / 15.f});
+  p = __builtin_elementwise_fma(x2, p, f32x2{-1.f / 3.f, -1.f / 3.f});
+  const f32x2 small = __builtin_elementwise_fma(ax * x2, p, ax);
+  return f32x2{__builtin_copysignf(ax[0] < 0.25f ? small[0] : big[0], x[0]),
+               __builtin_copysignf(ax[1] < 0.25f ? small[1] : big[1], x[1])};
+}
+template <int ACT>
+__device__ __forceinline__ f32x2 activate2(float y0, float y1) {
+  return ACT == CDE_ACT_TANH ? tanh_fast2(f32x2{y0, y1}) : f32x2{y0, y1};
+}
+
 // stage the weight and bias images in LDS (they stay there: [WY_FLOATS weight][BY_FLOATS bias])
 __device__ __forceinline__ void stage_wy16(const float* __restrict__ W, const float* __restrict__ bias, float* lds,
                                            Dims d) {
@@ -306,11 +328,12 @@ __device__ __forceinline__ void field_act16(const float4* wy, const float4* by, 
 #pragma unroll
     for (int s = 0; s < 8; ++s) { y0 = mfma16(a0[s], zs[s], y0); y1 = mfma16(a1[s], zs[s], y1); }
     __builtin_amdgcn_sched_barrier(0);
-    float f = activate<ACT>(y0[0]) * dX[0];
-#pragma unroll
-    for (int c = 1; c < 4; ++c) f = __builtin_fmaf(activate<ACT>(y0[c]), dX[c], f);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) f = __builtin_fmaf(activate<ACT>(y1[c]), dX[4 + c], f);
+    const f32x2 t01 = activate2<ACT>(y0[0], y0[1]), t23 = activate2<ACT>(y0[2], y0[3]);
+    const f32x2 t45 = activate2<ACT>(y1[0], y1[1]), t67 = activate2<ACT>(y1[2], y1[3]);
+    float f = t01[0] * dX[0];
+    f = __builtin_fmaf(t01[1], dX[1], f); f = __builtin_fmaf(t23[0], dX[2], f); f = __builtin_fmaf(t23[1], dX[3], f);
+    f = __builtin_fmaf(t45[0], dX[4], f); f = __builtin_fmaf(t45[1], dX[5], f);
+    f = __builtin_fmaf(t67[0], dX[6], f); f = __builtin_fmaf(t67[1], dX[7], f);
     if (P < 4) fa[P] = f; else fb[P - 4] = f;
   }
 }
@@ -400,11 +423,12 @@ __device__ __forceinline__ void field_mlp16(const float* img, int lane, int q, c
       y0 = mfma16(a0.z, u[4 * g + 2], y0); y1 = mfma16(a1.z, u[4 * g + 2], y1);
       y0 = mfma16(a0.w, u[4 * g + 3], y0); y1 = mfma16(a1.w, u[4 * g + 3], y1);
     }
-    float f = activate<ACT>(y0[0]) * dX[0];
-#pragma unroll
-    for (int c = 1; c < 4; ++c) f = __builtin_fmaf(activate<ACT>(y0[c]), dX[c], f);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) f = __builtin_fmaf(activate<ACT>(y1[c]), dX[4 + c], f);
+    const f32x2 t01 = activate2<ACT>(y0[0], y0[1]), t23 = activate2<ACT>(y0[2], y0[3]);
+    const f32x2 t45 = activate2<ACT>(y1[0], y1[1]), t67 = activate2<ACT>(y1[2], y1[3]);
+    float f = t01[0] * dX[0];
+    f = __builtin_fmaf(t01[1], dX[1], f); f = __builtin_fmaf(t23[0], dX[2], f); f = __builtin_fmaf(t23[1], dX[3], f);
+    f = __builtin_fmaf(t45[0], dX[4], f); f = __builtin_fmaf(t45[1], dX[5], f);
+    f = __builtin_fmaf(t67[0], dX[6], f); f = __builtin_fmaf(t67[1], dX[7], f);
     if (P < 4) fa[P] = f; else fb[P - 4] = f;
     __builtin_amdgcn_sched_barrier(0);
   }

@@ -604,9 +604,10 @@ __global__ __launch_bounds__(256, 1) void rk4_adjoint_act_mfma(
 #pragma unroll
             for (int hl = 0; hl < 4; ++hl) {
               float acc = 0.f;
+              const f32x2 tp[2] = {activate2<ACT>(y[4 * hl], y[4 * hl + 1]), activate2<ACT>(y[4 * hl + 2], y[4 * hl + 3])};
 #pragma unroll
               for (int cl = 0; cl < 4; ++cl) {
-                const float t = activate<ACT>(y[4 * hl + cl]);
+                const float t = tp[cl >> 1][cl & 1];
                 acc = cl == 0 ? t * dh[0] : __builtin_fmaf(t, dh[cl], acc);
                 g[4 * hl + cl] = a4u[hl] * (dh[cl] * activate_slope<ACT>(t));
                 if constexpr (DCOEFF) gdx[cl] = __builtin_fmaf(a4u[hl], t, gdx[cl]);

@@ -225,9 +225,11 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_mlp_sweep(
         }
         float g2[8];
         float f = 0.f;
+        const f32x2 tp[4] = {activate2<ACT>(y0[0], y0[1]), activate2<ACT>(y0[2], y0[3]), activate2<ACT>(y1[0], y1[1]),
+                             activate2<ACT>(y1[2], y1[3])};
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-          const float t = activate<ACT>(c < 4 ? y0[c] : y1[c - 4]);
+          const float t = tp[c >> 1][c & 1];
           f = c == 0 ? t * dX[0] : __builtin_fmaf(t, dX[c], f);
           const float slope = ACT == CDE_ACT_TANH ? __builtin_fmaf(-t, t, 1.f) : 1.f;
           g2[c] = as[P] * (dX[c] * slope);
