@@ -147,12 +147,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     # CDE_BENCH_FORCE_DIST=1 exercises the RCCL code path with a single rank (used to validate it on a 1-GPU box)
     distributed = world > 1 or os.environ.get("CDE_BENCH_FORCE_DIST") == "1"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")           # "nccl" is RCCL on ROCm
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+        try:                                              # "nccl" is RCCL on ROCm; bind the communicator to this GPU
+            dist.init_process_group(backend="nccl", device_id=device)
+        except TypeError:
+            dist.init_process_group(backend="nccl")
 
     import torchcde_amd as cde
     from torchcde_amd.cdeint import _Plan
