@@ -528,8 +528,6 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         raise NotImplementedError("torchcde_amd: the torchsde backend is outside the native hot path.")
     if backend != "torchdiffeq":
         raise ValueError(f"Unrecognised backend={backend}")
-    if hasattr(func, "prod"):
-        raise NotImplementedError("torchcde_amd: vector fields given through `func.prod` are not supported natively.")
     if not isinstance(X, _NativePath):
         raise NotImplementedError("torchcde_amd: X must be a torchcde_amd.CubicSpline or LinearInterpolation.")
     stepwise_kwargs = dict(kwargs)      # what the step-wise path would receive (the reference forwards these verbatim)
@@ -539,6 +537,24 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
     batch = tuple(packed.shape[:-2])
     C = X._channels()
     H = z0.size(-1)
+    if hasattr(func, "prod"):
+        # solver.py:48-53, :35-41, :121-123: the module computes f(t, z) dX itself; solved step by step with the native
+        # control derivative under every evaluation
+        if batch != tuple(z0.shape[:-1]):
+            _shape_errors(batch + (C,), tuple(z0.shape) + (C,), z0)
+        with torch.no_grad():
+            probe_t = t[0].to(z0.device) if isinstance(t, torch.Tensor) else t
+            first = func.prod(probe_t, z0, X.derivative(probe_t))
+        if not isinstance(first, torch.Tensor):
+            raise ValueError("z0 is a tensor and so func.prod must return a tensor as well.")
+        if first.shape != z0.shape:
+            raise ValueError("func.prod did not return a tensor with the same shape as z0. func.prod returned shape {} "
+                             "whilst z0 has shape {}.".format(tuple(first.shape), tuple(z0.shape)))
+        from . import stepwise
+        kw = stepwise_kwargs
+        return stepwise.solve(X, func, z0, t, adjoint, kw.pop("method", None) or "dopri5", kw.pop("options", None),
+                              kw["rtol"], kw["atol"], kw.get("adjoint_method"), kw.get("adjoint_options"),
+                              kw.get("adjoint_rtol"), kw.get("adjoint_atol"), kw.get("adjoint_params"))
 
     # compatibility probe of solver.py:44-67: one evaluation of func at t[0], shapes checked against z0;
     # the same evaluation establishes (bitwise) whether func belongs to the fused affine family.

@@ -52,6 +52,8 @@ class ControlledField:
 
     def __call__(self, t, z):
         dX = self.X.derivative(t.detach())
+        if hasattr(self.func, "prod"):                       # solver.py:121-123: the user supplies f(t, z) dX directly
+            return self.func.prod(t, z, dX)
         return _Contract.apply(self.func(t, z), dX)
 
 
