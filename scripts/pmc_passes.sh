@@ -1,16 +1,17 @@
 #!/bin/bash
 # Counter passes for the roofline evidence (one --pmc set per run, kernel-trace only: see the gpurun rules).
-# Usage on the GPU box:  bash scripts/pmc_passes.sh <tag> [workload.py] [passes]   -> gpurun_out/pmc_<tag>/*.db
+# Usage on the GPU box:  bash scripts/pmc_passes.sh <tag> [workload.py] [passes] [workload args]   -> gpurun_out/pmc_<tag>/*.db
 set -u
 TAG=${1:-r01}
 WORKLOAD=${2:-scripts/prof_workload.py}
 PASSES=${3:-"mfma waves fetch write"}
+WARGS=${4:-3}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() {  # name, counters...
   local name=$1; shift
-  timeout 180 rocprofv3 --pmc "$@" --kernel-trace -d $OUT -o $name -- python $GRAFT_REPO_ROOT/$WORKLOAD 3 > $OUT/$name.log 2>&1
+  timeout 180 rocprofv3 --pmc "$@" --kernel-trace -d $OUT -o $name -- python $GRAFT_REPO_ROOT/$WORKLOAD $WARGS > $OUT/$name.log 2>&1
   echo "$name rc=$?"
 }
 for pass in $PASSES; do
