@@ -265,6 +265,7 @@ def main():
                 "forward_kernel_ms": fwd_avg,
                 "forward_tflops": B * FLOP_FWD / (fwd_avg * 1e-3) / 1e12 if fwd_avg > 0 else None,
                 "forward_only_series_per_s": B / (fwd_avg * 1e-3) if fwd_avg > 0 else None,
+                "end_to_end_fit_fwd_adjoint_series_per_s": B * world / ((fit_ms + elapsed / args.steps * 1e3) * 1e-3),
                 "hermite_fit_ms": fit_ms,
                 "hermite_fit_series_per_s": B / (fit_ms * 1e-3),
                 "hermite_fit_hbm_gbs": B * 20352 / (fit_ms * 1e-3) / 1e9,
