@@ -2,7 +2,7 @@
 
 Drop-in names (reference ``torchcde/__init__.py:1-7``): ``hermite_cubic_coefficients_with_backward_differences``,
 ``linear_interpolation_coeffs``, ``CubicSpline`` (+ ``NaturalCubicSpline`` alias), ``LinearInterpolation``,
-``InterpolationBase``, ``cdeint``.  Everything numerical runs in hand-written HIP kernels (gfx950) loaded from
+``InterpolationBase``, ``TupleControl``, ``cdeint``.  Everything numerical runs in hand-written HIP kernels (gfx950) loaded from
 ``libcde_mi355x.so`` through the C ABI of ``include/cde_mi355x.h``; there is no eager or CPU fallback.
 """
 from ._lib import build, load, SO_PATH
@@ -11,5 +11,6 @@ from .paths import (InterpolationBase, CubicSpline, NaturalCubicSpline, LinearIn
 from .fields import LinearCDEFunc
 from .cdeint import cdeint
 from . import misc  # noqa: F401  (torchcde.misc.forward_fill)
+from .misc import TupleControl
 
 __version__ = "0.1.0"

@@ -503,6 +503,61 @@ def _shape_errors(dX_shape, system_shape, z0):
                          "".format(tuple(system_shape), system_shape[-1], tuple(dX_shape), dX_shape[-1]))
 
 
+def _cdeint_tuple(X, func, z0, t, adjoint, backend, kwargs):
+    """Tuple-valued state (reference solver.py:68-95): checks and messages as the reference, then the step-wise solver
+    on the concatenated state (what torchdiffeq does with tuples); returns a tuple of (..., len(t), H_i) tensors."""
+    if backend == "torchsde":
+        raise NotImplementedError("torchcde_amd: the torchsde backend is outside the native hot path.")
+    if backend != "torchdiffeq":
+        raise ValueError(f"Unrecognised backend={backend}")
+    for part in z0:
+        if not isinstance(part, torch.Tensor):
+            raise ValueError("z0 must either a tensor or a tuple/list of tensors.")
+        _lib.require_gpu(part, "z0")
+    probe_t = t[0].to(z0[0].device) if isinstance(t, torch.Tensor) else t
+    with torch.no_grad():
+        dX = X.derivative(probe_t)
+        if not isinstance(dX, (tuple, list)):
+            raise ValueError("z0 is a tuple/list and so X.derivative must return a tuple/list as well.")
+        if len(z0) != len(dX):
+            raise ValueError("z0 and X.derivative(t) must be tuples of the same length.")
+        is_prod = hasattr(func, "prod")
+        system = func.prod(probe_t, z0, dX) if is_prod else func(probe_t, z0)
+    name = "func.prod" if is_prod else "func"
+    if not isinstance(system, (tuple, list)):
+        raise ValueError("z0 is a tuple/list and so %s must return a tuple/list as well." % name)
+    if len(z0) != len(system):
+        raise ValueError("z0 and %s must be tuples of the same length."
+                         % ("func.prod(t, z, dXdt)" if is_prod else "func(t, z)"))
+    for dX_i, system_i, z_i in zip(dX, system, z0):
+        if not isinstance(dX_i, torch.Tensor):
+            raise ValueError("X.derivative must return a tensor or tuple of tensors.")
+        if not isinstance(system_i, torch.Tensor):
+            raise ValueError("%s must return a tensor or tuple/list of tensors." % name)
+        if is_prod:
+            if tuple(dX_i.shape[:-1]) != tuple(z_i.shape[:-1]):
+                _shape_errors(tuple(dX_i.shape), tuple(z_i.shape) + (dX_i.size(-1),), z_i)
+            if system_i.shape != z_i.shape:
+                raise ValueError("func.prod did not return a tensor with the same shape as z0. func.prod returned shape "
+                                 "{} whilst z0 has shape {}.".format(tuple(system_i.shape), tuple(z_i.shape)))
+        else:
+            _shape_errors(tuple(dX_i.shape), tuple(system_i.shape), z_i)
+    from . import stepwise
+    kw = dict(kwargs)
+    kw.pop("variant", None)
+    kw.setdefault("atol", 1e-6)
+    kw.setdefault("rtol", 1e-4)
+    if adjoint:
+        kw.setdefault("adjoint_atol", kw["atol"])
+        kw.setdefault("adjoint_rtol", kw["rtol"])
+    sizes = [part.size(-1) for part in z0]
+    field = stepwise.TupleField(X, func, sizes)
+    out = stepwise.solve(X, func, torch.cat(z0, dim=-1), t, adjoint, kw.get("method") or "dopri5", kw.get("options"),
+                         kw["rtol"], kw["atol"], kw.get("adjoint_method"), kw.get("adjoint_options"),
+                         kw.get("adjoint_rtol"), kw.get("adjoint_atol"), kw.get("adjoint_params"), field=field)
+    return tuple(out.split(sizes, dim=-1))
+
+
 def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
     r"""Solve  z_t = z_{t_0} + \int_{t_0}^t f(s, z_s) dX_s  on the MI355X.
 
@@ -521,7 +576,7 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
     if not hasattr(X, "derivative"):
         raise ValueError("X must have a 'derivative' method.")
     if isinstance(z0, (tuple, list)):
-        raise NotImplementedError("torchcde_amd: tuple/list state is outside the native hot path.")
+        return _cdeint_tuple(X, func, tuple(z0), t, adjoint, backend, kwargs)
     if not isinstance(z0, torch.Tensor):
         raise ValueError("z0 must either a tensor or a tuple/list of tensors.")
     if backend == "torchsde":

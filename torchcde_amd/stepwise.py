@@ -348,10 +348,28 @@ class _Adjoint(torch.autograd.Function):
         return (None, aug[2], None, *aug[3:])
 
 
+class TupleField:
+    """Tuple state (reference solver.py:68-95, :131-133): z = (z_1, .., z_k), X.derivative(t) = (dX_1, .., dX_k), func
+    returns one (.., H_i, C_i) matrix per component (or func.prod the products).  torchdiffeq solves such systems on
+    the concatenated state; so does this wrapper (components are concatenated along the hidden axis)."""
+
+    def __init__(self, X, func, sizes):
+        self.X, self.func, self.sizes = X, func, tuple(sizes)
+
+    def __call__(self, t, z):
+        parts = z.split(self.sizes, dim=-1)
+        dX = self.X.derivative(t.detach())
+        if hasattr(self.func, "prod"):
+            out = self.func.prod(t, parts, dX)
+        else:
+            out = tuple(_Contract.apply(f, d) for f, d in zip(self.func(t, parts), dX))
+        return torch.cat(tuple(out), dim=-1)
+
+
 def solve(X, func, z0, t, adjoint, method, options, rtol, atol, adjoint_method, adjoint_options, adjoint_rtol,
-          adjoint_atol, adjoint_params):
+          adjoint_atol, adjoint_params, field=None):
     """Step-wise cdeint: returns (..., len(t), H) like the fused path."""
-    field = ControlledField(X, func)
+    field = ControlledField(X, func) if field is None else field
     t = t.to(z0.device)
     if adjoint:
         if adjoint_params is None:
