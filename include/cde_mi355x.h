@@ -80,6 +80,14 @@ int cde_hermite_bdiff_coeffs(const void* x, const void* t, void* coeffs, int64_t
 int cde_hermite_bdiff_coeffs_backward(const void* grad_coeffs, const void* t, void* grad_x, int64_t B, int64_t L,
                                       int64_t C, int dtype, void* stream);
 
+/* K1n  Natural cubic spline coefficients: natural_cubic_coeffs (version 1) / natural_cubic_spline_coeffs (version 0),
+ * torchcde/interpolation_cubic.py:7-266 with the tridiagonal solve of misc.py:14-67; NaN = missing value.
+ *   x (B, L, C), t (L) -> coeffs (B, L-1, 4C) = [a | b | 2c | 3d], same floats as the reference.
+ *   has_missing: whether ANY entry of x is NaN (the reference then re-centres every interval of every path,
+ *   :149-160; passing 0 for NaN-free data skips that pass -- the floats are the same either way). */
+int cde_natural_cubic_coeffs(const void* x, const void* t, void* coeffs, int64_t B, int64_t L, int64_t C, int version,
+                             int has_missing, int dtype, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K0  Missing-value construction: the NaN path of linear_interpolation_coeffs
  * (torchcde/interpolation_linear.py:13-84, reached from :169-170 and therefore also the first step

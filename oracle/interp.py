@@ -7,6 +7,7 @@ the reference on CPU), the interpolation half of the hot path:
   forward_fill               <- torchcde/misc.py:103-126
   rectilinear_prepare        <- torchcde/interpolation_linear.py:86-128
   linear_coeffs              <- torchcde/interpolation_linear.py:131-171 (incl. the NaN fill :13-84 and rectilinear)
+  natural_cubic_coeffs       <- torchcde/interpolation_cubic.py:7-266 + misc.py:14-67 (tridiagonal solve)
   hermite_bdiff_coeffs       <- torchcde/interpolation_hermite_cubic_bdiff.py:5-44
   locate                     <- torchcde/interpolation_cubic.py:315-322  (== interpolation_linear.py:203-210)
   cubic_value / cubic_slope  <- torchcde/interpolation_cubic.py:324-336
@@ -139,6 +140,97 @@ def hermite_bdiff_coeffs(x, t=None):
     two_c = 2 * (3 * (rise / h - b) - secant + enter) / h          # :17
     three_d = (1 / h ** 2) * (secant - b) - (two_c) / h            # :18
     return torch.cat([a, b, two_c, three_d], dim=-1)
+
+
+# ----------------------------------------------------------------------------- natural cubic splines
+def _natural_pieces(times, values):
+    """interpolation_cubic.py:7-54 for ONE scalar path without missing values: (a, b, two_c, three_d) per piece, with
+    the tridiagonal solve of misc.py:14-67 written out (same operation order)."""
+    m = values.numel()
+    if m == 2:
+        zero = torch.zeros(1, dtype=values.dtype)
+        return values[:1], (values[1:] - values[:1]) / (times[1:] - times[:1]), zero, zero.clone()
+    r = (times[1:] - times[:-1]).reciprocal()
+    r2 = r ** 2
+    three = 3 * (values[1:] - values[:-1])
+    six = 2 * three
+    scaled = three * r2
+    diag = torch.empty(m, dtype=values.dtype)
+    diag[:-1] = r
+    diag[-1] = 0
+    diag[1:] += r
+    diag *= 2
+    rhs = torch.empty(m, dtype=values.dtype)
+    rhs[:-1] = scaled
+    rhs[-1] = 0
+    rhs[1:] += scaled
+    new_d, new_b = [diag[0]], [rhs[0]]
+    for i in range(1, m):
+        w = r[i - 1] / new_d[i - 1]
+        new_d.append(diag[i] - w * r[i - 1])
+        new_b.append(rhs[i] - w * new_b[i - 1])
+    kd = [None] * m
+    kd[m - 1] = new_b[m - 1] / new_d[m - 1]
+    for i in range(m - 2, -1, -1):
+        kd[i] = (new_b[i] - r[i] * kd[i + 1]) / new_d[i]
+    kd = torch.stack(kd)
+    a = values[:-1]
+    b = kd[:-1]
+    two_c = (six * r - 4 * kd[:-1] - 2 * kd[1:]) * r
+    three_d = (-six * r + 3 * (kd[:-1] + kd[1:])) * r2
+    return a, b, two_c, three_d
+
+
+def _natural_scalar_path(t, x, version):
+    """interpolation_cubic.py:83-166 for one scalar path (length,) with NaN = missing."""
+    L = x.numel()
+    observed = ~torch.isnan(x)
+    if not bool(observed.any()):
+        z = torch.zeros(L - 1, dtype=x.dtype)
+        return z, z.clone(), z.clone(), z.clone()
+    x = x.clone()
+    obs = observed.nonzero().flatten().tolist()
+    if version == 0:                       # impute only the two end points
+        if not observed[0]:
+            x[0] = x[obs[0]]
+        if not observed[-1]:
+            x[-1] = x[obs[-1]]
+    else:                                  # fill backward / forward from the first / last observation
+        x[:obs[0]] = x[obs[0]]
+        x[obs[-1] + 1:] = x[obs[-1]]
+    keep = ~torch.isnan(x)
+    tk, xk = t[keep], x[keep]
+    pa, pb, pc, pd = _natural_pieces(tk, xk)
+    a, b, c, d = [], [], [], []
+    k = -1
+    nxt = 0                                # index into tk of the next knot
+    for j in range(L - 1):
+        if t[j] >= tk[nxt]:
+            prev_time = tk[nxt]
+            nxt += 1
+            k += 1
+        offset = prev_time - t[j]
+        inner = (0.5 * pc[k] - pd[k] * offset / 3) * offset
+        a.append(pa[k] + (inner - pb[k]) * offset)
+        b.append(pb[k] + (pd[k] * offset - pc[k]) * offset)
+        c.append(pc[k] - 2 * pd[k] * offset)
+        d.append(pd[k])
+    return torch.stack(a), torch.stack(b), torch.stack(c), torch.stack(d)
+
+
+def natural_cubic_coeffs(x, t=None, version=1):
+    """natural_cubic_coeffs (version 1) / natural_cubic_spline_coeffs (version 0), interpolation_cubic.py:172-266.
+    Without missing values every scalar path goes through ``_natural_pieces`` (the vectorised branch of the reference
+    performs the same operations per element)."""
+    t = check_path(x, t)
+    flat = x.transpose(-1, -2).reshape(-1, x.size(-2))
+    has_nan = bool(torch.isnan(x).any())
+    parts = [(_natural_scalar_path(t, row, version) if has_nan else _natural_pieces(t, row)) for row in flat]
+    out = []
+    for which in range(4):
+        block = torch.stack([p[which] for p in parts]).reshape(*x.shape[:-2], x.size(-1), x.size(-2) - 1)
+        out.append(block.transpose(-1, -2))
+    return torch.cat(out, dim=-1)
 
 
 # ----------------------------------------------------------------------------- lookup

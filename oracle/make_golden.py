@@ -167,6 +167,29 @@ def rectilinear_cases(ref):
     return cases
 
 
+def natural_cases(ref):
+    """natural_cubic_coeffs / natural_cubic_spline_coeffs (reference interpolation_cubic.py:7-266), with and without
+    missing values, default and irregular t, float32 and float64, L = 2 and 3 included."""
+    from oracle import interp
+    gen = torch.Generator().manual_seed(991)
+    cases = []
+    for dtype in (torch.float32, torch.float64):
+        for batch, L, C, p_nan, explicit_t in (((3,), 2, 2, 0.0, False), ((1,), 3, 1, 0.0, False), ((4,), 7, 3, 0.0, True),
+                                               ((2, 2), 12, 3, 0.3, True), ((5,), 9, 2, 0.5, False),
+                                               ((6,), 20, 4, 0.6, True), ((8,), 33, 8, 0.0, False)):
+            x = torch.randn(*batch, L, C, generator=gen, dtype=dtype)
+            if p_nan > 0:
+                x = x.masked_fill(torch.rand(*batch, L, C, generator=gen) < p_nan, float("nan"))
+                x.view(-1, L, C)[0, :, 0] = float("nan")                 # an all-NaN scalar path
+            t = _irregular_t(L, dtype, gen) if explicit_t else None
+            v1 = ref.natural_cubic_coeffs(x, t)
+            v0 = ref.natural_cubic_spline_coeffs(x, t)
+            assert torch.equal(v1, interp.natural_cubic_coeffs(x, t, 1)), "oracle natural cubic (v1) != reference"
+            assert torch.equal(v0, interp.natural_cubic_coeffs(x, t, 0)), "oracle natural cubic (v0) != reference"
+            cases.append(dict(x=x, t=t, coeffs=v1, coeffs_v0=v0))
+    return cases
+
+
 class LinearField(torch.nn.Module):
     """The README vector field (reference README.md:42-49): Linear(H, H*C) viewed (..., H, C)."""
 
@@ -278,6 +301,9 @@ def main():
     nan_cases = nan_fill_cases(ref)
     torch.save(nan_cases, os.path.join(OUT, "nan_fill.pt"))
     print("nan_fill.pt: %d cases (oracle bit-identical to reference on all)" % len(nan_cases))
+    nat_cases = natural_cases(ref)
+    torch.save(nat_cases, os.path.join(OUT, "natural_cubic.pt"))
+    print("natural_cubic.pt: %d cases (oracle bit-identical to reference on all)" % len(nat_cases))
     rect_cases = rectilinear_cases(ref)
     torch.save(rect_cases, os.path.join(OUT, "rectilinear.pt"))
     print("rectilinear.pt: %d cases (oracle bit-identical to reference on all; known-answer case of the reference's "

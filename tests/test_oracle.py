@@ -60,6 +60,23 @@ def test_forward_fill_and_rectilinear_match_reference_golden():
         assert case["prepared"].size(-2) == 2 * case["x"].size(-2) - 1
 
 
+def test_natural_cubic_coeffs_match_reference_golden():
+    import os
+    from conftest import GOLDEN
+    for case in torch.load(os.path.join(GOLDEN, "natural_cubic.pt")):
+        assert torch.equal(interp.natural_cubic_coeffs(case["x"], case["t"], 1), case["coeffs"])
+        assert torch.equal(interp.natural_cubic_coeffs(case["x"], case["t"], 0), case["coeffs_v0"])
+    # a natural spline interpolates its knots and has zero second derivative at both ends (two_c of the first piece;
+    # two_c + 2*three_d*h of the last)
+    x = torch.randn(3, 11, 2, dtype=torch.float64)
+    c = interp.natural_cubic_coeffs(x)
+    path = interp.CubicPath(c)
+    for i in range(11):
+        assert torch.allclose(path.evaluate(torch.tensor(float(i), dtype=torch.float64)), x[:, i], atol=1e-10)
+    assert torch.allclose(c[:, 0, 4:6], torch.zeros(3, 2, dtype=torch.float64), atol=1e-10)
+    assert torch.allclose(c[:, -1, 4:6] + 2 * c[:, -1, 6:8], torch.zeros(3, 2, dtype=torch.float64), atol=1e-9)
+
+
 def test_hermite_unit_time_known_answer():
     """The reference's closed-form KAT (test/test_hermite_cubic.py:6-38): with unit knot spacing
     two_c = 4(d_next - d_prev), three_d = -3(d_next - d_prev)."""

@@ -1,13 +1,14 @@
 """torchcde_amd -- the MI355X-native Neural-CDE hot path behind torchcde's API.
 
 Drop-in names (reference ``torchcde/__init__.py:1-7``): ``hermite_cubic_coefficients_with_backward_differences``,
-``linear_interpolation_coeffs``, ``CubicSpline`` (+ ``NaturalCubicSpline`` alias), ``LinearInterpolation``,
+``natural_cubic_coeffs`` / ``natural_cubic_spline_coeffs``, ``linear_interpolation_coeffs``, ``CubicSpline`` (+ ``NaturalCubicSpline`` alias), ``LinearInterpolation``,
 ``InterpolationBase``, ``TupleControl``, ``cdeint``.  Everything numerical runs in hand-written HIP kernels (gfx950) loaded from
 ``libcde_mi355x.so`` through the C ABI of ``include/cde_mi355x.h``; there is no eager or CPU fallback.
 """
 from ._lib import build, load, SO_PATH
 from .paths import (InterpolationBase, CubicSpline, NaturalCubicSpline, LinearInterpolation,
-                    hermite_cubic_coefficients_with_backward_differences, linear_interpolation_coeffs)
+                    hermite_cubic_coefficients_with_backward_differences, linear_interpolation_coeffs,
+                    natural_cubic_coeffs, natural_cubic_spline_coeffs)
 from .fields import LinearCDEFunc
 from .cdeint import cdeint
 from . import misc  # noqa: F401  (torchcde.misc.forward_fill)

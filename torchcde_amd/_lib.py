@@ -75,6 +75,7 @@ _SIGNATURES = {
     "cde_linear_fill_missing": (_i, [_p, _p, _p, _i64, _i64, _i64, _i, _p]),
     "cde_interpret_t": (_i, [_p, _i64, _p, _i64, _p, _p, _i, _p]),
     "cde_hermite_bdiff_coeffs_backward": (_i, [_p, _p, _p, _i64, _i64, _i64, _i, _p]),
+    "cde_natural_cubic_coeffs": (_i, [_p, _p, _p, _i64, _i64, _i64, _i, _i, _i, _p]),
     "cde_forward_fill": (_i, [_p, _p, _i64, _i64, _i64, _i, _p]),
     "cde_rectilinear_prepare": (_i, [_p, _p, _i64, _i64, _i64, _i64, _i, _p]),
     "cde_path_eval": (_i, [_p, _p, _p, _i64, _p, _i64, _i64, _i64, _i, _i, _i, _p]),

@@ -212,6 +212,121 @@ __global__ __launch_bounds__(256) void rectilinear_prepare_kernel(const T* __res
   }
 }
 
+// ------------------------------------------------------------------------------------------ K1n natural cubic splines
+// natural_cubic_coeffs / natural_cubic_spline_coeffs (interpolation_cubic.py:7-266 with the tridiagonal solve of
+// misc.py:14-67), missing values included.  One lane per scalar path (series, channel), three sequential passes over
+// its L samples, every floating-point operation in the reference's order (bit-exact):
+//   1. forward sweep of the Thomas algorithm over the KEPT points (observed, or imputed at the ends: version 0 copies
+//      the first/last observation to the two end points, version 1 fills everything before/after them); the system
+//      rows need the next kept point, so a row is finished one kept point late.  Temporaries live in the path's own
+//      output rows at the compact index k:  a-slot = value_k, b-slot = new_b[k], 2c-slot = new_diag[k], 3d-slot = time_k
+//   2. backward substitution, emitting the coefficients of compact piece k in place as soon as both knot derivatives
+//      are known
+//   3. (paths with gaps) expansion from compact pieces to all L-1 intervals, back to front so that nothing unread is
+//      overwritten: interval j re-centres the piece that contains it (:149-160).
+template <typename T>
+__global__ __launch_bounds__(256) void natural_cubic_kernel(const T* __restrict__ x, const T* __restrict__ t,
+                                                            T* __restrict__ out, int64_t B, int64_t L, int64_t C,
+                                                            int version, int expand_all) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * C) return;
+  const int64_t b = e / C, c = e - b * C;
+  const T* src = x + b * L * C + c;
+  T* row0 = out + b * (L - 1) * 4 * C + c;
+  const int64_t RS = 4 * C;                                // row stride; slots a, b, 2c, 3d at +0, +C, +2C, +3C
+  int64_t first = -1, last = -1;
+  for (int64_t i = 0; i < L; ++i) { const T v = src[i * C]; if (v == v) { if (first < 0) first = i; last = i; } }
+  if (first < 0) {
+    for (int64_t j = 0; j < L - 1; ++j) { T* r = row0 + j * RS; r[0] = (T)0; r[C] = (T)0; r[2 * C] = (T)0; r[3 * C] = (T)0; }
+    return;
+  }
+  const T v_first = src[first * C], v_last = src[last * C];
+  auto value = [&](int64_t i, bool& kept) -> T {
+    const T v = src[i * C];
+    kept = true;
+    if (v == v) return v;
+    if (version == 0) { if (i == 0) return v_first; if (i == L - 1) return v_last; }
+    else { if (i < first) return v_first; if (i > last) return v_last; }
+    kept = false;
+    return v;
+  };
+  // ---- pass 1
+  int64_t m = 0;
+  T tau_pp = 0, v_pp = 0;          // kept point k-1 (the row being finished)
+  T tau_p = 0, v_p = 0;            // kept point k   (the newest)
+  T r_prev = 0, s_prev = 0;        // r_{k-2}, scaled_{k-2}: piece before the row being finished
+  T nd_prev = 0, nb_prev = 0;      // new_diag / new_b of the row before the one being finished
+  for (int64_t i = 0; i < L; ++i) {
+    bool kept;
+    const T v = value(i, kept);
+    if (!kept) continue;
+    const T tau = t[i];
+    if (m >= 1) {
+      // piece (m-1): between kept points m-1 (tau_p, v_p) and m (tau, v); finishes row m-1
+      const T r = (T)1 / (tau - tau_p);
+      const T scaled = ((T)3 * (v - v_p)) * (r * r);
+      const int64_t k = m - 1;
+      T diag, rhs;
+      if (k == 0) { diag = r * (T)2; rhs = scaled; }
+      else { diag = (r + r_prev) * (T)2; rhs = scaled + s_prev; }
+      T nd, nb;
+      if (k == 0) { nd = diag; nb = rhs; }
+      else { const T w = r_prev / nd_prev; nd = diag - w * r_prev; nb = rhs - w * nb_prev; }
+      T* slot = row0 + k * RS;
+      slot[0] = v_p; slot[C] = nb; slot[2 * C] = nd; slot[3 * C] = tau_p;
+      nd_prev = nd; nb_prev = nb; r_prev = r; s_prev = scaled;
+    }
+    tau_pp = tau_p; v_pp = v_p; tau_p = tau; v_p = v;
+    ++m;
+  }
+  (void)tau_pp; (void)v_pp;
+  // last row (k = m-1): diag = (0 + r_{m-2}) * 2, rhs = 0 + scaled_{m-2}
+  if (m == 2) {
+    T* slot = row0;
+    const T a0 = slot[0], t0 = slot[3 * C];
+    slot[C] = (v_p - a0) / (tau_p - t0); slot[2 * C] = (T)0; slot[3 * C] = (T)0;
+  } else {
+    const T w = r_prev / nd_prev;
+    const T nd_last = ((T)0 + r_prev) * (T)2 - w * r_prev;
+    const T nb_last = ((T)0 + s_prev) - w * nb_prev;
+    // ---- pass 2
+    T kd_next = nb_last / nd_last, tau_next = tau_p, v_next = v_p;
+    for (int64_t k = m - 2; k >= 0; --k) {
+      T* slot = row0 + k * RS;
+      const T vk = slot[0], nb = slot[C], nd = slot[2 * C], tk = slot[3 * C];
+      const T r = (T)1 / (tau_next - tk);
+      const T kd = (nb - r * kd_next) / nd;
+      const T six = (T)2 * ((T)3 * (v_next - vk));
+      const T r2 = r * r;
+      slot[C] = kd;
+      slot[2 * C] = (six * r - (T)4 * kd - (T)2 * kd_next) * r;
+      slot[3 * C] = (-six * r + (T)3 * (kd + kd_next)) * r2;
+      kd_next = kd; tau_next = tk; v_next = vk;
+    }
+  }
+  // ---- pass 3: only when the batch had gaps (the reference then re-centres EVERY interval, :149-160)
+  if (!expand_all) return;
+  int64_t k = m - 2, kidx = L - 1;
+  { bool kept = false; kidx = L - 2; while (true) { (void)value(kidx, kept); if (kept) break; --kidx; } }   // kept point <= L-2
+  T pa = row0[k * RS], pb = row0[k * RS + C], pc = row0[k * RS + 2 * C], pd = row0[k * RS + 3 * C];
+  for (int64_t j = L - 2; j >= 0; --j) {
+    if (kidx > j) {
+      bool kept = false;
+      kidx = j;
+      while (true) { (void)value(kidx, kept); if (kept) break; --kidx; }
+      --k;
+      pa = row0[k * RS]; pb = row0[k * RS + C]; pc = row0[k * RS + 2 * C]; pd = row0[k * RS + 3 * C];
+    }
+    const T offset = t[kidx] - t[j];
+    const T inner = ((T)0.5 * pc - pd * offset / (T)3) * offset;
+    T* slot = row0 + j * RS;
+    slot[0] = pa + (inner - pb) * offset;
+    slot[C] = pb + (pd * offset - pc) * offset;
+    slot[2 * C] = pc - (T)2 * pd * offset;
+    slot[3 * C] = pd;
+  }
+}
+
 // ------------------------------------------------------------------------------------------ K1b
 template <typename T>
 __global__ void interpret_t_kernel(const T* __restrict__ knots, int64_t n_intervals, const T* __restrict__ tq,
@@ -333,6 +448,21 @@ extern "C" int cde_hermite_bdiff_coeffs_backward(const void* grad_coeffs, const 
     cde::hermite_bdiff_backward_kernel<float><<<grid, 256, 0, s>>>((const float*)grad_coeffs, (const float*)t, (float*)grad_x, B, L, C);
   else if (dtype == CDE_F64)
     cde::hermite_bdiff_backward_kernel<double><<<grid, 256, 0, s>>>((const double*)grad_coeffs, (const double*)t, (double*)grad_x, B, L, C);
+  else return CDE_ERR_DTYPE;
+  return cde::check_launch();
+}
+
+extern "C" int cde_natural_cubic_coeffs(const void* x, const void* t, void* coeffs, int64_t B, int64_t L, int64_t C,
+                                        int version, int has_missing, int dtype, void* stream) {
+  if (B < 0 || L < 2 || C < 1 || (version != 0 && version != 1)) return CDE_ERR_SHAPE;
+  if (B == 0) return CDE_OK;
+  if (!x || !t || !coeffs) return CDE_ERR_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((B * C + 255) / 256);
+  if (dtype == CDE_F32)
+    cde::natural_cubic_kernel<float><<<grid, 256, 0, s>>>((const float*)x, (const float*)t, (float*)coeffs, B, L, C, version, has_missing);
+  else if (dtype == CDE_F64)
+    cde::natural_cubic_kernel<double><<<grid, 256, 0, s>>>((const double*)x, (const double*)t, (double*)coeffs, B, L, C, version, has_missing);
   else return CDE_ERR_DTYPE;
   return cde::check_launch();
 }

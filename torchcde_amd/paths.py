@@ -135,6 +135,32 @@ def linear_interpolation_coeffs(x, t=None, rectilinear=None):
     return out
 
 
+def _natural_cubic(x, t, version):
+    t = _validate_input_path(x, t)
+    _lib.require_gpu(x, "x")
+    _no_grad_through_path(x, t)
+    src, B, L, C = _flat3(x)
+    knots = t.detach().to(device=x.device, dtype=x.dtype).contiguous()
+    out = torch.empty(*x.shape[:-2], L - 1, 4 * C, dtype=x.dtype, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.cde_natural_cubic_coeffs(_lib.ptr(src), _lib.ptr(knots), _lib.ptr(out), B, L, C, version,
+                                            int(bool(torch.isnan(x).any())), _lib.dtype_enum(x.dtype),
+                                            _lib.stream_ptr(x.device)), "cde_natural_cubic_coeffs")
+    return out
+
+
+def natural_cubic_coeffs(x, t=None):
+    """Natural cubic spline coefficients (reference interpolation_cubic.py:226-266), missing values (NaN) supported;
+    pass the result to ``CubicSpline``.  K1n: one kernel, bit-exact."""
+    return _natural_cubic(x, t, 1)
+
+
+def natural_cubic_spline_coeffs(x, t=None):
+    """Deprecated variant kept by the reference (interpolation_cubic.py:186-223): differs from ``natural_cubic_coeffs``
+    only in how missing values at the two ends of a series are imputed."""
+    return _natural_cubic(x, t, 0)
+
+
 class _HermiteFit(torch.autograd.Function):
     """K1 with its transpose as the backward (the fit is linear in x)."""
 
