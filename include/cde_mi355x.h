@@ -109,6 +109,18 @@ int cde_forward_fill(const void* x, void* out, int64_t B, int64_t L, int64_t C, 
 int cde_rectilinear_prepare(const void* x, void* out, int64_t B, int64_t L, int64_t C, int64_t time_index, int dtype,
                             void* stream);
 
+/* K5  The log-ODE transform: logsig_windows / logsignature_windows (torchcde/log_ode.py:15-133).  The caller has
+ * merged the window boundaries into the series and filled them (log_ode.py:18-49; cde_linear_fill_missing).
+ *   x (B, L, C) filled series;  rows (n_windows + 1) int64 boundary row of every window end (device);
+ *   scale (n_windows) factor per window (1, or the window length for the deprecated variant);
+ *   words (n_words, 2) int32 (level, flat index) of every Lyndon word in signatory's order;
+ *   out (B, n_windows + 1, n_words): first row = first observation (padded with zeros), then the running sum of the
+ *   windows' logsignatures.
+ * depth <= 3, C <= 8, n_words <= 64 (CDE_ERR_UNSUPPORTED otherwise).  The logsignature arithmetic replaces the
+ * third-party `signatory` calls at log_ode.py:53,57,59 ("words" mode): parity with that package is unpinned. */
+int cde_logsig_windows(const void* x, const int64_t* rows, const void* scale, const int32_t* words, void* out, int64_t B,
+                       int64_t L, int64_t C, int depth, int64_t n_windows, int n_words, int dtype, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K1b  Interval lookup and path evaluation for a vector of query times.
  * cde_interpret_t replaces CubicSpline._interpret_t (interpolation_cubic.py:315-322) and

@@ -36,6 +36,8 @@ def import_reference():
     shim.odeint_adjoint = oracle_ode.odeint_adjoint
     sys.modules["torchdiffeq"] = shim
     sys.modules["torchsde"] = types.ModuleType("torchsde")
+    from oracle import logsig as oracle_logsig
+    sys.modules["signatory"] = oracle_logsig.as_signatory_module()      # log_ode.py:1-8 imports it at module load
     sys.path.insert(0, REFERENCE)
     import torchcde
     assert os.path.realpath(torchcde.__file__).startswith(REFERENCE)
@@ -190,6 +192,30 @@ def natural_cases(ref):
     return cases
 
 
+def logsig_cases(ref):
+    """logsig_windows / logsignature_windows (reference log_ode.py:15-133) run ON TOP OF oracle.logsig standing in for
+    signatory: pins the windowing, merging, filling and accumulation of the oracle restatement; the logsignature
+    arithmetic itself is parity-unpinned (see oracle/logsig.py)."""
+    from oracle import logsig
+    gen = torch.Generator().manual_seed(4711)
+    cases = []
+    for dtype in (torch.float32, torch.float64):
+        for batch, L, C, depth, window, p_nan, explicit_t in (((3,), 17, 3, 3, 4.0, 0.0, False), ((2, 2), 13, 2, 2, 2.5, 0.0, False),
+                                                              ((4,), 21, 3, 3, 3.0, 0.2, True), ((1,), 9, 1, 3, 8.0, 0.0, False),
+                                                              ((5,), 12, 4, 1, 1.0, 0.0, False), ((2,), 30, 3, 2, 7.0, 0.3, True)):
+            x = torch.randn(*batch, L, C, generator=gen, dtype=dtype).cumsum(-2) * 0.3
+            if p_nan > 0:
+                x = x.masked_fill(torch.rand(*batch, L, C, generator=gen) < p_nan, float("nan"))
+            t = _irregular_t(L, dtype, gen) if explicit_t else None
+            v1 = ref.logsig_windows(x, depth, window, t)
+            v0, times0 = ref.logsignature_windows(x, depth, window, t)
+            o1 = logsig.logsig_windows(x, depth, window, t, version=1)
+            o0, ot = logsig.logsig_windows(x, depth, window, t, version=0)
+            assert torch.equal(v1, o1) and torch.equal(v0, o0) and torch.equal(times0, ot), "oracle windowing != reference"
+            cases.append(dict(x=x, t=t, depth=depth, window_length=window, out=v1, out_v0=v0, times_v0=times0))
+    return cases
+
+
 class LinearField(torch.nn.Module):
     """The README vector field (reference README.md:42-49): Linear(H, H*C) viewed (..., H, C)."""
 
@@ -282,7 +308,7 @@ def cdeint_cases(ref):
 def run_reference_tests():
     import pytest
     files = ["test_hermite_cubic.py", "test_natural_cubic_spline.py", "test_linear_interpolation.py", "test_misc.py",
-             "test_cdeint.py", "test_tricks.py"]
+             "test_cdeint.py", "test_tricks.py", "test_log_ode.py"]
     args = [os.path.join(REFERENCE, "test", f) for f in files]
     # torchsde-backed parametrisations cannot run (package absent): deselect them by keyword
     return pytest.main(args + ["-q", "-p", "no:cacheprovider", "-k", "not torchsde and not test_backend",
@@ -304,6 +330,10 @@ def main():
     nat_cases = natural_cases(ref)
     torch.save(nat_cases, os.path.join(OUT, "natural_cubic.pt"))
     print("natural_cubic.pt: %d cases (oracle bit-identical to reference on all)" % len(nat_cases))
+    ls_cases = logsig_cases(ref)
+    torch.save(ls_cases, os.path.join(OUT, "logsig_windows.pt"))
+    print("logsig_windows.pt: %d cases (oracle windowing bit-identical to the reference's, both over oracle.logsig)"
+          % len(ls_cases))
     rect_cases = rectilinear_cases(ref)
     torch.save(rect_cases, os.path.join(OUT, "rectilinear.pt"))
     print("rectilinear.pt: %d cases (oracle bit-identical to reference on all; known-answer case of the reference's "

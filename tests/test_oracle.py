@@ -77,6 +77,63 @@ def test_natural_cubic_coeffs_match_reference_golden():
     assert torch.allclose(c[:, -1, 4:6] + 2 * c[:, -1, 6:8], torch.zeros(3, 2, dtype=torch.float64), atol=1e-9)
 
 
+def test_logsignature_known_answers():
+    """oracle/logsig.py stands in for the absent `signatory` package (parity unpinned): anchor it by mathematics."""
+    import numpy as np
+    from oracle import logsig
+    assert logsig.lyndon_words(2, 3) == [(0,), (1,), (0, 1), (0, 0, 1), (0, 1, 1)]
+    assert [logsig.logsignature_channels(3, d) for d in (1, 2, 3, 4)] == [3, 6, 14, 32]       # Witt's formula
+    gen = torch.Generator().manual_seed(0)
+    p = torch.randn(4, 7, 3, generator=gen, dtype=torch.float64)
+    l3 = logsig.logsignature(p, 3)
+    words = logsig.lyndon_words(3, 3)
+    assert torch.allclose(l3[:, :3], p[:, -1] - p[:, 0])                                      # depth 1: the increment
+    line = torch.linspace(0, 1, 5, dtype=torch.float64)[:, None] * torch.tensor([1.0, -2.0, 0.5], dtype=torch.float64)
+    assert torch.allclose(logsig.logsignature(line[None], 3)[0, 3:], torch.zeros(11, dtype=torch.float64), atol=1e-14)
+    d, x = p[:, 1:] - p[:, :-1], p[:, :-1] - p[:, :1]
+    for w, val in zip(words, l3.unbind(-1)):                                                  # depth 2: Levy areas
+        if len(w) == 2:
+            i, j = w
+            assert torch.allclose(val, 0.5 * (x[..., i] * d[..., j] - x[..., j] * d[..., i]).sum(-1), atol=1e-12)
+    # depth 3: Baker-Campbell-Hausdorff for two straight segments, log(e^a e^b) = a + b + [a,b]/2 + ([a,[a,b]] - [b,[a,b]])/12,
+    # expanded bracket by bracket in the tensor algebra with numpy (independent of the code under test)
+    a, b = np.random.default_rng(1).standard_normal(3), np.random.default_rng(2).standard_normal(3)
+
+    def bracket(u, v):
+        return np.multiply.outer(u, v) - np.multiply.outer(v, u)
+
+    ab = bracket(a, b)
+    level2, level3 = 0.5 * ab, (bracket(a, ab) - bracket(b, ab)) / 12.0
+    got = logsig.logsignature(torch.tensor(np.stack([np.zeros(3), a, a + b]))[None], 3)[0]
+    for w, val in zip(words, got):
+        want = (a + b)[w[0]] if len(w) == 1 else level2[w] if len(w) == 2 else level3[w]
+        assert abs(val.item() - want) < 1e-12
+    # inserting a collinear point (re-parametrisation) changes nothing; Chen: windows concatenate multiplicatively,
+    # which at depth 1 means the window logsignatures add up to the whole
+    q = torch.cat([p[:, :3], 0.3 * p[:, 2:3] + 0.7 * p[:, 3:4], p[:, 3:]], 1)
+    assert torch.allclose(logsig.logsignature(q, 3), l3, atol=1e-12)
+
+
+def test_logsig_windows_match_reference_windowing_golden():
+    """The windowing / merging / accumulation of log_ode.py:15-75 (pinned: fixtures come from the reference's own code
+    running over oracle.logsig), plus the property the reference's test checks (test_log_ode.py:7-33): the derivative of
+    the linear interpolation of the result over window k is that window's logsignature."""
+    import os
+    from conftest import GOLDEN
+    from oracle import logsig
+    for case in torch.load(os.path.join(GOLDEN, "logsig_windows.pt")):
+        got = logsig.logsig_windows(case["x"], case["depth"], case["window_length"], case["t"], version=1)
+        assert torch.equal(got, case["out"])
+        got0, times = logsig.logsig_windows(case["x"], case["depth"], case["window_length"], case["t"], version=0)
+        assert torch.equal(got0, case["out_v0"]) and torch.equal(times, case["times_v0"])
+    x = torch.randn(13, 3, dtype=torch.float64)
+    out = logsig.logsig_windows(x, 3, 4.0)
+    path = interp.LinearPath(out)
+    for k in range(3):
+        window = logsig.logsignature(x[4 * k:4 * k + 5][None], 3)[0]
+        assert torch.allclose(path.derivative(torch.tensor(k + 0.5, dtype=torch.float64)), window, atol=1e-12)
+
+
 def test_hermite_unit_time_known_answer():
     """The reference's closed-form KAT (test/test_hermite_cubic.py:6-38): with unit knot spacing
     two_c = 4(d_next - d_prev), three_d = -3(d_next - d_prev)."""
