@@ -334,65 +334,75 @@ __global__ __launch_bounds__(256) void natural_cubic_kernel(const T* __restrict_
 // The arithmetic the reference gets from the `signatory` package (absent here; see oracle/logsig.py): signature by
 // Chen's identity  S <- S (x) exp(d)  over the increments, tensor-algebra logarithm, coefficients of the Lyndon words
 // (`words`: (level, flat index) pairs in signatory's order, built by the host).
-// One lane per series walks its windows in order, so the running sum of log_ode.py:63 is a register accumulation.
 constexpr int LS_MAXC = 8;
+// pass 1: one lane per (series, window) -- the windows of a series are independent until the running sum
 template <typename T>
 __global__ __launch_bounds__(64) void logsig_windows_kernel(const T* __restrict__ x, const int64_t* __restrict__ rows,
                                                             const T* __restrict__ scale, const int32_t* __restrict__ words,
                                                             T* __restrict__ out, int64_t B, int64_t L, int C, int depth,
                                                             int64_t n_windows, int n_words) {
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+  const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= B * n_windows) return;
+  const int64_t b = id / n_windows, win = id - b * n_windows;
   const T* src = x + b * L * C;
-  T* dst = out + b * (n_windows + 1) * n_words;
+  T* dst = out + (b * (n_windows + 1) + win + 1) * n_words;
   T S1[LS_MAXC], S2[LS_MAXC * LS_MAXC], S3[LS_MAXC * LS_MAXC * LS_MAXC];
-  T cum[64];                                             // n_words <= 64 is checked by the launcher
-  for (int w = 0; w < n_words; ++w) cum[w] = w < C ? src[w] : (T)0;          // first "increment" = the first observation
-  for (int w = 0; w < n_words; ++w) dst[w] = cum[w];
   const int C2 = C * C;
-  for (int64_t win = 0; win < n_windows; ++win) {
-    for (int i = 0; i < C; ++i) S1[i] = (T)0;
-    if (depth >= 2) for (int i = 0; i < C2; ++i) S2[i] = (T)0;
-    if (depth >= 3) for (int i = 0; i < C2 * C; ++i) S3[i] = (T)0;
-    for (int64_t r = rows[win]; r < rows[win + 1]; ++r) {
-      T d[LS_MAXC];
-      for (int i = 0; i < C; ++i) d[i] = src[(r + 1) * C + i] - src[r * C + i];
-      // levels of S (x) exp(d), highest first (they read the old lower levels); exp(d): e1 = d, e2 = e1 (x) d / 2, ...
-      if (depth >= 3)
-        for (int i = 0; i < C; ++i)
-          for (int j = 0; j < C; ++j) {
-            const T e2 = d[i] * d[j] / (T)2;
-            for (int k = 0; k < C; ++k) {
-              T acc = S3[(i * C + j) * C + k] + e2 * d[k] / (T)3;
-              acc = acc + S1[i] * (d[j] * d[k] / (T)2);
-              acc = acc + S2[i * C + j] * d[k];
-              S3[(i * C + j) * C + k] = acc;
-            }
+  for (int i = 0; i < C; ++i) S1[i] = (T)0;
+  if (depth >= 2) for (int i = 0; i < C2; ++i) S2[i] = (T)0;
+  if (depth >= 3) for (int i = 0; i < C2 * C; ++i) S3[i] = (T)0;
+  for (int64_t r = rows[win]; r < rows[win + 1]; ++r) {
+    T d[LS_MAXC];
+    for (int i = 0; i < C; ++i) d[i] = src[(r + 1) * C + i] - src[r * C + i];
+    // levels of S (x) exp(d), highest first (they read the old lower levels); exp(d): e1 = d, e2 = e1 (x) d / 2, ...
+    if (depth >= 3)
+      for (int i = 0; i < C; ++i)
+        for (int j = 0; j < C; ++j) {
+          const T e2 = d[i] * d[j] / (T)2;
+          for (int k = 0; k < C; ++k) {
+            T acc = S3[(i * C + j) * C + k] + e2 * d[k] / (T)3;
+            acc = acc + S1[i] * (d[j] * d[k] / (T)2);
+            acc = acc + S2[i * C + j] * d[k];
+            S3[(i * C + j) * C + k] = acc;
           }
-      if (depth >= 2)
-        for (int i = 0; i < C; ++i)
-          for (int j = 0; j < C; ++j) S2[i * C + j] = (S2[i * C + j] + d[i] * d[j] / (T)2) + S1[i] * d[j];
-      for (int i = 0; i < C; ++i) S1[i] = S1[i] + d[i];
-    }
-    // logarithm: log(1 + S) = S - S^2/2 + S^3/3, level by level, then the Lyndon-word coordinates
-    const T sc = scale[win];
-    for (int w = 0; w < n_words; ++w) {
-      const int level = words[2 * w], flat = words[2 * w + 1];
-      T value;
-      if (level == 1) value = S1[flat];
-      else if (level == 2) {
-        const int i = flat / C, j = flat - i * C;
-        value = S2[flat] + (-(S1[i] * S1[j])) / (T)2;
-      } else {
-        const int i = flat / C2, jk = flat - i * C2, j = jk / C, k = jk - j * C;
-        const T p2 = (S1[i] * S2[j * C + k]) + S2[i * C + j] * S1[k];          // (S^2)_3
-        const T p3 = (S1[i] * S1[j]) * S1[k];                                   // (S^3)_3
-        value = (S3[flat] + (-p2) / (T)2) + p3 / (T)3;
-      }
-      cum[w] = cum[w] + value * sc;
-      dst[(win + 1) * n_words + w] = cum[w];
-    }
+        }
+    if (depth >= 2)
+      for (int i = 0; i < C; ++i)
+        for (int j = 0; j < C; ++j) S2[i * C + j] = (S2[i * C + j] + d[i] * d[j] / (T)2) + S1[i] * d[j];
+    for (int i = 0; i < C; ++i) S1[i] = S1[i] + d[i];
   }
+  // logarithm: log(1 + S) = S - S^2/2 + S^3/3, level by level, then the Lyndon-word coordinates
+  const T sc = scale[win];
+  for (int w = 0; w < n_words; ++w) {
+    const int level = words[2 * w], flat = words[2 * w + 1];
+    T value;
+    if (level == 1) value = S1[flat];
+    else if (level == 2) {
+      const int i = flat / C, j = flat - i * C;
+      value = S2[flat] + (-(S1[i] * S1[j])) / (T)2;
+    } else {
+      const int i = flat / C2, jk = flat - i * C2, j = jk / C, k = jk - j * C;
+      const T p2 = (S1[i] * S2[j * C + k]) + S2[i * C + j] * S1[k];          // (S^2)_3
+      const T p3 = (S1[i] * S1[j]) * S1[k];                                   // (S^3)_3
+      value = (S3[flat] + (-p2) / (T)2) + p3 / (T)3;
+    }
+    dst[w] = value * sc;
+  }
+}
+
+// pass 2: the running sum of log_ode.py:63 (sequential, like torch.cumsum on the CPU), one lane per (series, coordinate);
+// row 0 = the first observation padded with zeros (log_ode.py:50-52)
+template <typename T>
+__global__ __launch_bounds__(256) void logsig_accumulate_kernel(const T* __restrict__ x, T* __restrict__ out, int64_t B,
+                                                                int64_t L, int C, int64_t n_windows, int n_words) {
+  const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= B * n_words) return;
+  const int64_t b = id / n_words;
+  const int w = (int)(id - b * n_words);
+  T* col = out + b * (n_windows + 1) * n_words + w;
+  T run = w < C ? x[b * L * C + w] : (T)0;
+  col[0] = run;
+  for (int64_t win = 1; win <= n_windows; ++win) { run = run + col[win * n_words]; col[win * n_words] = run; }
 }
 
 // ------------------------------------------------------------------------------------------ K1b
@@ -543,14 +553,18 @@ extern "C" int cde_logsig_windows(const void* x, const int64_t* rows, const void
   if (B == 0) return CDE_OK;
   if (!x || !rows || !scale || !words || !out) return CDE_ERR_NULL;
   hipStream_t s = (hipStream_t)stream;
-  const unsigned grid = (unsigned)((B + 63) / 64);
-  if (dtype == CDE_F32)
-    cde::logsig_windows_kernel<float><<<grid, 64, 0, s>>>((const float*)x, rows, (const float*)scale, words, (float*)out, B, L,
-                                                          (int)C, depth, n_windows, n_words);
-  else if (dtype == CDE_F64)
-    cde::logsig_windows_kernel<double><<<grid, 64, 0, s>>>((const double*)x, rows, (const double*)scale, words, (double*)out, B,
-                                                           L, (int)C, depth, n_windows, n_words);
-  else return CDE_ERR_DTYPE;
+  const unsigned grid = (unsigned)((B * n_windows + 63) / 64), grid2 = (unsigned)((B * n_words + 255) / 256);
+  if (dtype == CDE_F32) {
+    if (n_windows > 0)
+      cde::logsig_windows_kernel<float><<<grid, 64, 0, s>>>((const float*)x, rows, (const float*)scale, words, (float*)out, B,
+                                                            L, (int)C, depth, n_windows, n_words);
+    cde::logsig_accumulate_kernel<float><<<grid2, 256, 0, s>>>((const float*)x, (float*)out, B, L, (int)C, n_windows, n_words);
+  } else if (dtype == CDE_F64) {
+    if (n_windows > 0)
+      cde::logsig_windows_kernel<double><<<grid, 64, 0, s>>>((const double*)x, rows, (const double*)scale, words, (double*)out,
+                                                             B, L, (int)C, depth, n_windows, n_words);
+    cde::logsig_accumulate_kernel<double><<<grid2, 256, 0, s>>>((const double*)x, (double*)out, B, L, (int)C, n_windows, n_words);
+  } else return CDE_ERR_DTYPE;
   return cde::check_launch();
 }
 
