@@ -139,6 +139,12 @@ int cde_interpret_t(const void* knots, int64_t n_intervals, const void* tq, int6
 int cde_path_eval(const void* coeffs, const void* knots, const void* tq, int64_t nq, void* out, int64_t B,
                   int64_t n_intervals, int64_t C, int degree, int what, int dtype, void* stream);
 
+/* Backward of cde_path_eval w.r.t. the coefficients (what autograd produces through the gathers of
+ * interpolation_cubic.py:324-336 / interpolation_linear.py:212-225): grad_out (B, nq, C) -> grad_coeffs, shaped like
+ * `coeffs` and ZEROED by the caller.  Gradients w.r.t. the query times are not produced. */
+int cde_path_eval_backward(const void* grad_out, const void* knots, const void* tq, int64_t nq, void* grad_coeffs,
+                           int64_t B, int64_t n_intervals, int64_t C, int degree, int what, int dtype, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Contraction of a materialised vector field with the control derivative,
  *   out[b, h] = sum_c F[b, h, c] * dX[b, c]

@@ -629,10 +629,6 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         for buffer in X.buffers():
             if buffer.requires_grad:
                 warnings.warn(_GRAD_WARNING)
-    if not adjoint and torch.is_grad_enabled() and any(b.requires_grad for b in X.buffers()):
-        # backpropagating through the solver would have to differentiate the control evaluation itself
-        raise NotImplementedError("torchcde_amd: gradients with respect to the control path are not implemented on "
-                                  "the native path yet (SURVEY section 8(f), rank 3). Detach the coefficients.")
 
     # solver configuration (what the reference forwards verbatim to torchdiffeq, solver.py:175-176,227)
     method = kwargs.pop("method", None)
@@ -641,6 +637,8 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         method = "dopri5"
     wants_grad = torch.is_grad_enabled() and (z0.requires_grad or any(
         p.requires_grad for p in (func.parameters() if isinstance(func, torch.nn.Module) else ())))
+    if not adjoint and torch.is_grad_enabled() and any(b.requires_grad for b in X.buffers()):
+        wants_grad = True            # backprop through the solver reaches the control: the step-wise path differentiates it
     fused = (field is not None and ((method == "rk4" and (adjoint or not wants_grad))
                                     or (method == "dopri5" and not wants_grad)))
     mlp_want_x = False

@@ -451,6 +451,54 @@ __global__ __launch_bounds__(256) void path_eval_kernel(const T* __restrict__ co
   }
 }
 
+// Backward of path_eval w.r.t. the coefficients: grad_coeffs (zeroed by the caller) += d out / d coeffs ^T grad_out.
+// Several query times may fall into one interval, so one lane owns a (series, channel) and walks the queries in order:
+// no atomics, deterministic.
+template <typename T, int DEGREE, int WHAT>
+__global__ __launch_bounds__(256) void path_eval_backward_kernel(const T* __restrict__ grad_out, const T* __restrict__ knots,
+                                                                 const T* __restrict__ tq, int64_t nq,
+                                                                 T* __restrict__ grad_coeffs, int64_t B,
+                                                                 int64_t n_intervals, int64_t C) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * C) return;
+  const int64_t b = e / C, c = e - b * C;
+  for (int64_t q = 0; q < nq; ++q) {
+    T frac;
+    const int64_t idx = locate(knots, n_intervals, tq[q], frac);
+    const T g = grad_out[(b * nq + q) * C + c];
+    if (DEGREE == CDE_PATH_CUBIC) {
+      T* row = grad_coeffs + (b * n_intervals + idx) * 4 * C + c;
+      if (WHAT == CDE_EVAL_DERIVATIVE) {            // b + (2c + 3d*frac)*frac
+        row[C] += g; row[2 * C] += g * frac; row[3 * C] += g * frac * frac;
+      } else {                                      // a + (b + (0.5*2c + 3d*frac/3)*frac)*frac
+        row[0] += g; row[C] += g * frac; row[2 * C] += g * ((T)0.5 * frac * frac); row[3 * C] += g * (frac * frac * frac / (T)3);
+      }
+    } else {
+      T* lo = grad_coeffs + (b * (n_intervals + 1) + idx) * C + c;
+      const T width = knots[idx + 1] - knots[idx];
+      const T w = WHAT == CDE_EVAL_DERIVATIVE ? (T)1 / width : frac / width;
+      if (WHAT == CDE_EVAL_VALUE) lo[0] += g;
+      lo[0] -= g * w; lo[C] += g * w;
+    }
+  }
+}
+
+template <typename T>
+static int launch_path_eval_backward(const void* grad_out, const void* knots, const void* tq, int64_t nq, void* grad_coeffs,
+                                     int64_t B, int64_t n_intervals, int64_t C, int degree, int what, hipStream_t s) {
+  if (B * C == 0 || nq == 0) return CDE_OK;
+  const unsigned grid = (unsigned)((B * C + 255) / 256);
+#define CDE_PB(D, W) \
+  path_eval_backward_kernel<T, D, W><<<grid, 256, 0, s>>>((const T*)grad_out, (const T*)knots, (const T*)tq, nq, (T*)grad_coeffs, B, n_intervals, C)
+  if (degree == CDE_PATH_CUBIC && what == CDE_EVAL_DERIVATIVE) CDE_PB(CDE_PATH_CUBIC, CDE_EVAL_DERIVATIVE);
+  else if (degree == CDE_PATH_CUBIC && what == CDE_EVAL_VALUE) CDE_PB(CDE_PATH_CUBIC, CDE_EVAL_VALUE);
+  else if (degree == CDE_PATH_LINEAR && what == CDE_EVAL_DERIVATIVE) CDE_PB(CDE_PATH_LINEAR, CDE_EVAL_DERIVATIVE);
+  else if (degree == CDE_PATH_LINEAR && what == CDE_EVAL_VALUE) CDE_PB(CDE_PATH_LINEAR, CDE_EVAL_VALUE);
+  else return CDE_ERR_UNSUPPORTED;
+#undef CDE_PB
+  return check_launch();
+}
+
 template <typename T>
 static int launch_path_eval(const void* coeffs, const void* knots, const void* tq, int64_t nq, void* out, int64_t B,
                             int64_t n_intervals, int64_t C, int degree, int what, hipStream_t s) {
@@ -619,6 +667,18 @@ extern "C" int cde_path_eval(const void* coeffs, const void* knots, const void* 
   hipStream_t s = (hipStream_t)stream;
   if (dtype == CDE_F32) return cde::launch_path_eval<float>(coeffs, knots, tq, nq, out, B, n_intervals, C, degree, what, s);
   if (dtype == CDE_F64) return cde::launch_path_eval<double>(coeffs, knots, tq, nq, out, B, n_intervals, C, degree, what, s);
+  return CDE_ERR_DTYPE;
+}
+
+extern "C" int cde_path_eval_backward(const void* grad_out, const void* knots, const void* tq, int64_t nq,
+                                      void* grad_coeffs, int64_t B, int64_t n_intervals, int64_t C, int degree, int what,
+                                      int dtype, void* stream) {
+  if (B < 0 || n_intervals < 1 || C < 1 || nq < 0) return CDE_ERR_SHAPE;
+  if (B == 0 || nq == 0) return CDE_OK;
+  if (!grad_out || !knots || !tq || !grad_coeffs) return CDE_ERR_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CDE_F32) return cde::launch_path_eval_backward<float>(grad_out, knots, tq, nq, grad_coeffs, B, n_intervals, C, degree, what, s);
+  if (dtype == CDE_F64) return cde::launch_path_eval_backward<double>(grad_out, knots, tq, nq, grad_coeffs, B, n_intervals, C, degree, what, s);
   return CDE_ERR_DTYPE;
 }
 

@@ -161,6 +161,42 @@ def natural_cubic_spline_coeffs(x, t=None):
     return _natural_cubic(x, t, 0)
 
 
+def _path_eval(coeffs, knots, flat, n_intervals, C, degree, what):
+    out = torch.empty(coeffs.size(0), flat.numel(), C, dtype=coeffs.dtype, device=coeffs.device)
+    lib = _lib.load()
+    _lib.check(lib.cde_path_eval(_lib.ptr(coeffs), _lib.ptr(knots), _lib.ptr(flat), flat.numel(), _lib.ptr(out),
+                                 coeffs.size(0), n_intervals, C, degree, what, _lib.dtype_enum(coeffs.dtype),
+                                 _lib.stream_ptr(coeffs.device)), "cde_path_eval")
+    return out
+
+
+class _PathEval(torch.autograd.Function):
+    """evaluate / derivative as a differentiable function of the path's coefficient buffers (cubic: a, b, 2c, 3d;
+    linear: the knot values)."""
+
+    @staticmethod
+    def forward(ctx, coeffs, knots, flat, n_intervals, C, degree, what, *pieces):
+        ctx.save_for_backward(knots, flat)
+        ctx.meta = (tuple(coeffs.shape), n_intervals, C, degree, what, [tuple(p.shape) for p in pieces])
+        return _path_eval(coeffs, knots, flat, n_intervals, C, degree, what)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        knots, flat = ctx.saved_tensors
+        flat_shape, n_intervals, C, degree, what, shapes = ctx.meta
+        g = grad_out.contiguous()
+        grad = torch.zeros(flat_shape, dtype=g.dtype, device=g.device)
+        lib = _lib.load()
+        _lib.check(lib.cde_path_eval_backward(_lib.ptr(g), _lib.ptr(knots), _lib.ptr(flat), flat.numel(), _lib.ptr(grad),
+                                              flat_shape[0], n_intervals, C, degree, what, _lib.dtype_enum(g.dtype),
+                                              _lib.stream_ptr(g.device)), "cde_path_eval_backward")
+        if len(shapes) == 1:
+            parts = (grad.reshape(shapes[0]),)
+        else:
+            parts = tuple(grad[..., k * C:(k + 1) * C].reshape(shape) for k, shape in enumerate(shapes))
+        return (None,) * 7 + tuple(p if need else None for p, need in zip(parts, ctx.needs_input_grad[7:]))
+
+
 class _HermiteFit(torch.autograd.Function):
     """K1 with its transpose as the backward (the fit is linear in x)."""
 
@@ -300,15 +336,18 @@ class _NativePath(InterpolationBase):
 
     def _eval(self, t, what):
         coeffs, knots, batch = self._native_inputs()
-        _no_grad_through_path(self._packed(), t if isinstance(t, torch.Tensor) else None)
+        _no_grad_through_path(t if isinstance(t, torch.Tensor) else None)
         tq = torch.as_tensor(t, dtype=coeffs.dtype, device=coeffs.device)
         flat = tq.detach().reshape(-1).contiguous()
         C = self._channels()
-        out = torch.empty(coeffs.size(0), flat.numel(), C, dtype=coeffs.dtype, device=coeffs.device)
-        lib = _lib.load()
-        _lib.check(lib.cde_path_eval(_lib.ptr(coeffs), _lib.ptr(knots), _lib.ptr(flat), flat.numel(), _lib.ptr(out),
-                                     coeffs.size(0), self._n_intervals(), C, self._degree, what,
-                                     _lib.dtype_enum(coeffs.dtype), _lib.stream_ptr(coeffs.device)), "cde_path_eval")
+        pieces = self._coefficient_buffers()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in pieces):
+            # differentiable w.r.t. the coefficients (like the reference's gathers): K1b forward, scatter kernel backward.
+            # The buffers themselves are the autograd inputs (a view re-assembled with as_strided would only carry the
+            # gradient of its first block).
+            out = _PathEval.apply(coeffs, knots, flat, self._n_intervals(), C, self._degree, what, *pieces)
+        else:
+            out = _path_eval(coeffs, knots, flat, self._n_intervals(), C, self._degree, what)
         return out.reshape(*batch, *tq.shape, C)
 
     def evaluate(self, t):
@@ -346,6 +385,9 @@ class CubicSpline(_NativePath):
     def _control_buffers(self):
         """Buffers the control derivative reads (gradient targets for adjoint_params=(..., coeffs))."""
         return (self._b, self._two_c, self._three_d)
+
+    def _coefficient_buffers(self):
+        return (self._a, self._b, self._two_c, self._three_d)
 
     def _packed(self):
         a, b, c, d = self._a, self._b, self._two_c, self._three_d
@@ -385,6 +427,9 @@ class LinearInterpolation(_NativePath):
         return self._coeffs.size(-1)
 
     def _control_buffers(self):
+        return (self._coeffs,)
+
+    def _coefficient_buffers(self):
         return (self._coeffs,)
 
     def _packed(self):

@@ -34,14 +34,18 @@ class _Contract(torch.autograd.Function):
         out = torch.empty(F.shape[:-1], dtype=F.dtype, device=F.device)
         _lib.check(lib.cde_contract(_lib.ptr(Fc), _lib.ptr(dXc), _lib.ptr(out), B, H, C, _lib.dtype_enum(F.dtype),
                                     _lib.stream_ptr(F.device)), "cde_contract")
-        ctx.save_for_backward(dXc)
-        ctx.f_shape = F.shape
+        ctx.save_for_backward(dXc, Fc if dX.requires_grad else None)
+        ctx.f_shape, ctx.dx_shape = F.shape, dX.shape
         return out
 
     @staticmethod
     def backward(ctx, grad):
-        (dX,) = ctx.saved_tensors
-        return (grad.unsqueeze(-1) * dX.reshape(ctx.f_shape[:-2] + (1, ctx.f_shape[-1]))), None
+        dX, F = ctx.saved_tensors
+        grad_F = grad.unsqueeze(-1) * dX.reshape(ctx.f_shape[:-2] + (1, ctx.f_shape[-1]))
+        grad_dX = None
+        if F is not None and ctx.needs_input_grad[1]:          # the control derivative carries gradient to the coefficients
+            grad_dX = (grad.unsqueeze(-1) * F.reshape(ctx.f_shape)).sum(-2).reshape(ctx.dx_shape)
+        return grad_F, grad_dX
 
 
 class ControlledField:
