@@ -34,6 +34,25 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert b"workspace" in lib.cde_error_string(-5)
 
 
+def test_ctypes_signatures_match_the_header_prototypes():
+    """Every prototype of include/cde_mi355x.h against the ctypes table of torchcde_amd/_lib.py: same number of
+    parameters, pointers bound as c_void_p, integers / doubles / size_t as such, same return type."""
+    header = open(os.path.join(ROOT, "include", "cde_mi355x.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    protos = re.findall(r"\b(int|size_t|const char\*)\s+(cde_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", header, flags=re.S)
+    assert len(protos) == len(_lib.EXPORTED_SYMBOLS)
+    kinds = {ctypes.c_void_p: "ptr", ctypes.c_int: "int", ctypes.c_int64: "int64_t", ctypes.c_size_t: "size_t",
+             ctypes.c_double: "double"}
+    for ret, name, params in protos:
+        restype, argtypes = _lib._SIGNATURES[name]
+        params = [p.strip() for p in params.replace("\n", " ").split(",")] if params.strip() not in ("", "void") else []
+        assert len(params) == len(argtypes), (name, len(params), len(argtypes))
+        for text, ctype in zip(params, argtypes):
+            want = "ptr" if "*" in text else text.split()[-2] if len(text.split()) > 1 else text
+            assert kinds[ctype] == want, (name, text, ctype)
+        assert {"int": ctypes.c_int, "size_t": ctypes.c_size_t, "const char*": ctypes.c_char_p}[ret] is restype, name
+
+
 def test_argument_errors_come_back_as_codes_without_a_gpu():
     lib = torchcde_amd.load()
     null = ctypes.c_void_p(0)
