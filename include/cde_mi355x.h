@@ -56,8 +56,11 @@ enum { CDE_ACT_NONE = 0, CDE_ACT_TANH = 1 };
 enum {
   CDE_VARIANT_AUTO = 0,    /* MFMA kernel when (f32, H == 32, C == 8, ACT_NONE), else generic */
   CDE_VARIANT_GENERIC = 1, /* VALU kernel: any H, C, f32 or f64                             */
-  CDE_VARIANT_MFMA = 2     /* fail with CDE_ERR_UNSUPPORTED unless the MFMA kernel applies   */
+  CDE_VARIANT_MFMA = 2,    /* fail with CDE_ERR_UNSUPPORTED unless the MFMA kernel applies   */
+  CDE_VARIANT_SPLIT = 3    /* MFMA, one workgroup (4 waves) per 16 series: the latency-oriented kernels for small
+                              per-GPU batches (strong scaling); AUTO picks them when B <= CDE_SPLIT_MAX_BATCH */
 };
+#define CDE_SPLIT_MAX_BATCH 16384
 
 int cde_abi_version(void);
 const char* cde_error_string(int code);

@@ -13,7 +13,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libcde_mi355x.so")
-SOURCES = ["interp_kernels.hip", "rk4_generic.hip", "rk4_mfma.hip", "rk4_mlp_adjoint.hip", "dopri5.hip", "api.hip"]
+SOURCES = ["interp_kernels.hip", "rk4_generic.hip", "rk4_mfma.hip", "rk4_split.hip", "rk4_mlp_adjoint.hip", "dopri5.hip",
+           "api.hip"]
 HEADERS = [os.path.join(_CSRC, "cde_common.h"), os.path.join(_CSRC, "cde_mfma.h"),
            os.path.join(_HERE, "..", "include", "cde_mi355x.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC"]
@@ -22,7 +23,7 @@ F32, F64 = 0, 1
 PATH_LINEAR, PATH_CUBIC = 1, 3
 EVAL_VALUE, EVAL_DERIVATIVE = 0, 1
 ACT_NONE, ACT_TANH = 0, 1
-VARIANT_AUTO, VARIANT_GENERIC, VARIANT_MFMA = 0, 1, 2
+VARIANT_AUTO, VARIANT_GENERIC, VARIANT_MFMA, VARIANT_SPLIT = 0, 1, 2, 3
 
 _lib = None
 

@@ -29,6 +29,17 @@ int launch_adjoint_mfma(const void*, const void*, int64_t, int, const void*, con
                         const void*, const void*, const int64_t*, int64_t, void*, void*, void*, int64_t, int64_t,
                         int64_t, const int64_t*, const void*, float*, void*, hipStream_t);
 
+// from rk4_split.hip: one workgroup (4 waves) per 16 series -- the latency-oriented variant for small batches
+size_t split_adjoint_partial_bytes(int64_t B);
+template <typename TT>
+int launch_forward_split(const void*, const void*, int64_t, int, const void*, const void*, int, const void*,
+                         const void*, int64_t, const void*, int64_t, void*, int64_t, int64_t, int64_t, const int64_t*,
+                         const void*, hipStream_t);
+template <typename TT>
+int launch_adjoint_split(const void*, const void*, int64_t, int, const void*, const void*, int, const void*,
+                         const void*, const void*, const int64_t*, int64_t, void*, void*, void*, int64_t, int64_t,
+                         int64_t, const int64_t*, const void*, float*, hipStream_t);
+
 // from rk4_mlp_adjoint.hip
 size_t mlp_adjoint_image_bytes();
 int launch_mlp_adjoint_images(const void*, const void*, int64_t, const void*, const void*, int64_t, int64_t, float*,
@@ -71,10 +82,18 @@ static inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 static bool pick_mfma(int variant, int64_t C, int64_t H, int dtype, int act, bool adjoint, int* rc) {
   const bool ok = mfma_applicable(C, H, dtype, act, adjoint);
   *rc = CDE_OK;
-  if (variant == CDE_VARIANT_MFMA) { if (!ok) *rc = CDE_ERR_UNSUPPORTED; return ok; }
+  if (variant == CDE_VARIANT_MFMA || variant == CDE_VARIANT_SPLIT) { if (!ok) *rc = CDE_ERR_UNSUPPORTED; return ok; }
   if (variant == CDE_VARIANT_GENERIC) return false;
   if (variant != CDE_VARIANT_AUTO) { *rc = CDE_ERR_UNSUPPORTED; return false; }
   return ok;
+}
+
+// Among the MFMA kernels: the one-wave-per-series-tile kernels (K2/K3) need B/16 (B/32) waves to fill 1024 SIMDs twice
+// (once); below CDE_SPLIT_MAX_BATCH series the workgroup-per-tile kernels of rk4_split.hip finish sooner.
+static bool pick_split(int variant, int64_t B, bool control_grad) {
+  if (control_grad) return false;                  // dL/dcoeffs lives in the pre-activation K3 kernel only
+  if (variant == CDE_VARIANT_SPLIT) return true;
+  return variant == CDE_VARIANT_AUTO && B <= CDE_SPLIT_MAX_BATCH;
 }
 
 template <typename T, typename TT>
@@ -86,6 +105,9 @@ static int forward_typed(const void* coeffs, const void* knots, int64_t n_interv
   if (rc != CDE_OK) return rc;
   const bool use_mfma = pick_mfma(variant, C, H, dtype, act, false, &rc);
   if (rc != CDE_OK) return rc;
+  if (use_mfma && pick_split(variant, B, false))
+    return launch_forward_split<TT>(coeffs, knots, n_intervals, degree, W, bias, act, z0, grid, n_grid, t_out, n_out,
+                                    z_out, B, C, H, stage_index, stage_frac, s);
   if (use_mfma)
     return launch_forward_mfma<TT>(coeffs, knots, n_intervals, degree, W, bias, act, z0, grid, n_grid, t_out, n_out, z_out,
                                    B, C, H, stage_index, stage_frac, s);
@@ -107,13 +129,19 @@ static int adjoint_typed(const void* coeffs, const void* knots, int64_t n_interv
   const int64_t n_steps = n_sgrid - 1;
   const size_t off_frac = align256((size_t)(4 * n_steps) * sizeof(int64_t));
   const size_t off_part = off_frac + align256((size_t)(4 * n_steps) * sizeof(T));
-  const size_t part_bytes = use_mfma ? mfma_adjoint_partial_bytes(B) : generic_adjoint_workspace_bytes(B, C, H, sizeof(T));
+  const bool use_split = use_mfma && pick_split(variant, B, grad_coeffs != nullptr);
+  if (variant == CDE_VARIANT_SPLIT && !use_split) return CDE_ERR_UNSUPPORTED;
+  const size_t part_bytes = use_split ? split_adjoint_partial_bytes(B)
+                            : use_mfma ? mfma_adjoint_partial_bytes(B) : generic_adjoint_workspace_bytes(B, C, H, sizeof(T));
   if (workspace_bytes < off_part + part_bytes) return CDE_ERR_WORKSPACE;
   int64_t* stage_index = (int64_t*)workspace;
   void* stage_frac = (unsigned char*)workspace + off_frac;
   void* partial = (unsigned char*)workspace + off_part;
   rc = fill_stage_table<T, TT>(knots, n_intervals, sgrid, n_steps, 1, stage_index, stage_frac, s);
   if (rc != CDE_OK) return rc;
+  if (use_split)
+    return launch_adjoint_split<TT>(coeffs, knots, n_intervals, degree, W, bias, act, z_saved, grad_out, sgrid, seg_off,
+                                    n_out, grad_z0, grad_W, grad_b, B, C, H, stage_index, stage_frac, (float*)partial, s);
   if (use_mfma)
     return launch_adjoint_mfma<TT>(coeffs, knots, n_intervals, degree, W, bias, act, z_saved, grad_out, sgrid, seg_off, n_out,
                                    grad_z0, grad_W, grad_b, B, C, H, stage_index, stage_frac, (float*)partial,
@@ -182,9 +210,10 @@ extern "C" size_t cde_rk4_adjoint_workspace_bytes(int64_t B, int64_t C, int64_t 
   int rc;
   const bool use_mfma = cde::pick_mfma(variant, C, H, dtype, CDE_ACT_NONE, true, &rc);
   // AUTO may resolve to either kernel depending on the activation: reserve the larger need
-  const size_t a = cde::mfma_adjoint_partial_bytes(B);
+  size_t a = cde::mfma_adjoint_partial_bytes(B);
+  if (cde::pick_split(variant, B, false)) { const size_t sp = cde::split_adjoint_partial_bytes(B); a = sp > a ? sp : a; }
   const size_t b = cde::generic_adjoint_workspace_bytes(B, C, H, elem);
-  if (variant == CDE_VARIANT_MFMA) bytes += a;
+  if (variant == CDE_VARIANT_MFMA || variant == CDE_VARIANT_SPLIT) bytes += a;
   else if (variant == CDE_VARIANT_GENERIC || !use_mfma) bytes += b;
   else bytes += (a > b ? a : b);
   return bytes;

@@ -739,6 +739,12 @@ __global__ __launch_bounds__(256) void reduce_mfma_partials(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------ host side
+int launch_reduce_partials(const float* partial, int64_t n_tiles, void* grad_W, void* grad_b, int H, int C, hipStream_t s) {
+  reduce_mfma_partials<<<(unsigned)((H * C * H + H * C + 255) / 256), 256, 0, s>>>(partial, n_tiles, (float*)grad_W,
+                                                                                 (float*)grad_b, Dims{H, C});
+  return check_launch();
+}
+
 bool mfma_applicable(int64_t C, int64_t H, int dtype, int act, bool adjoint) {
   (void)adjoint;
   const bool act_ok = act == CDE_ACT_NONE || act == CDE_ACT_TANH;
@@ -845,9 +851,7 @@ int launch_adjoint_mfma(const void* coeffs, const void* knots, int64_t n_interva
 #undef CDE_ADJ_DX
   int rc = check_launch();
   if (rc != CDE_OK) return rc;
-  reduce_mfma_partials<<<(unsigned)((H * C * H + H * C + 255) / 256), 256, 0, s>>>(partial, (B + 31) / 32, (float*)grad_W,
-                                                                                 (float*)grad_b, dims);
-  return check_launch();
+  return launch_reduce_partials(partial, (B + 31) / 32, grad_W, grad_b, (int)H, (int)C, s);
 }
 
 template int launch_forward_mfma<float>(const void*, const void*, int64_t, int, const void*, const void*, int,
