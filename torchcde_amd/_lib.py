@@ -18,6 +18,9 @@ SOURCES = ["interp_kernels.hip", "rk4_generic.hip", "rk4_mfma.hip", "rk4_split.h
 HEADERS = [os.path.join(_CSRC, "cde_common.h"), os.path.join(_CSRC, "cde_mfma.h"),
            os.path.join(_HERE, "..", "include", "cde_mi355x.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC"]
+# per-file additions.  rk4_split.hip: keep MFMA accumulators in VGPRs -- its tiles are consumed by VALU code right
+# away, and on gfx950 every v_accvgpr_read costs matrix-pipe time (f32 MFMA and VALU do not overlap within a wave).
+EXTRA_FLAGS = {"rk4_split.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 F32, F64 = 0, 1
 PATH_LINEAR, PATH_CUBIC = 1, 3
@@ -62,7 +65,7 @@ def build(force=False, verbose=False):
     with tempfile.TemporaryDirectory(prefix="cde_build_") as tmp:
         objects = [os.path.join(tmp, os.path.splitext(src)[0] + ".o") for src in SOURCES]
         with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
-            list(pool.map(run, [[_hipcc()] + compile_flags + ["-c", os.path.join(_CSRC, src), "-o", obj]
+            list(pool.map(run, [[_hipcc()] + compile_flags + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(_CSRC, src), "-o", obj]
                                 for src, obj in zip(SOURCES, objects)]))
         run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objects + ["-o", SO_PATH])
     return SO_PATH

@@ -32,10 +32,12 @@ constexpr int SPL_ZROW = 36;                  // stage-state buffer: 32 units + 
 constexpr int SPL_ZBUF = 16 * SPL_ZROW;
 constexpr int SPL_TROW = 20;                  // transposed tiles: 16 series + 4 pad floats per row
 constexpr int SPL_ZT = 32 * SPL_TROW;
-constexpr int SPL_VROW = 12;                  // va partials: [w_dst][lane][w_src*2 + j], 8 + 4 pad floats per lane
-constexpr int SPL_VA = 4 * 64 * SPL_VROW;
+constexpr int SPL_VROW = 12;                  // va partials: [w_dst][q][n][w_src*2 + j], 8 + 4 pad floats per lane
+constexpr int SPL_VA = 4 * 64 * SPL_VROW;     //   (n fastest: conflict-free b64 writes per 16-lane group and b128 reads)
+constexpr int SPL_DXROW = 12;                 // shared control derivative: [series][8 channels + 4 pad]
+constexpr int SPL_DX = 16 * SPL_DXROW;
 constexpr int SPL_GT = 64 * SPL_TROW;         // per wave: transposed weighted dL/dY tile (64 rows)
-constexpr int SPL_ADJ_LDS_FLOATS = 2 * SPL_ZBUF + 2 * SPL_ZT + 2 * SPL_VA + 4 * SPL_GT;
+constexpr int SPL_ADJ_LDS_FLOATS = 2 * SPL_ZBUF + 2 * SPL_ZT + 2 * SPL_VA + 2 * SPL_DX + 4 * SPL_GT;
 constexpr int64_t SPL_PARTIAL_FLOATS = MH * MC * MH + MH * MC;     // == PARTIAL_FLOATS of rk4_mfma.hip
 
 // position of series n inside a transposed row: MFMA K step s, quarter kq <-> series 4s + kq is read as float4[kq][s]
@@ -61,15 +63,89 @@ __device__ __forceinline__ void spl_load_wy(const float* __restrict__ W, const f
   }
 }
 
+// ---------------------------------------------------------------------------------------------- control feed
+// dX/dt of the tile's 16 series is produced ONCE per stage and shared through LDS (dxb[series][channel]) instead of
+// 16 times (4 waves x 4 lane quarters): lane (n, q) of wave w produces channel c = 2w + (q & 1) of series n (the
+// q >= 2 copies compute the same value and do not store).  The feed runs one stage ahead of its consumers: during
+// stage e the producers publish dX for stage e+1, from coefficients that were requested during stage e-1, at table
+// entries that were requested during stage e-2 -- no load is waited for in the stage that issued it.
+//   cubic : raw = (b, 2c, 3d) of the interval,   dX = b + (2c + 3d frac) frac      (interpolation_cubic.py:334-335)
+//   linear: raw = (x_i, x_{i+1}, t_{i+1} - t_i), dX = (x_{i+1} - x_i) / width      (interpolation_linear.py:222-225),
+//           the division happens once per interval (when the coefficients are installed), not per stage.
+template <int DEGREE>
+struct Feed {
+  const float* __restrict__ coeffs;
+  const float* __restrict__ knots;
+  const int64_t* __restrict__ sidx;
+  const float* __restrict__ sfrac;
+  int64_t n_intervals, sc, e_last;
+  int Cr, c;
+  int64_t idx1, idx2;          // table entries e+1, e+2 (uniform)
+  float frac1, frac2;
+  float cur[3], raw[3];
+  bool pending;                // raw holds the coefficients of idx1, not yet installed in cur (uniform)
+
+  __device__ __forceinline__ void request(int64_t idx) {
+    const int cc = c < Cr ? c : Cr - 1;
+    if (DEGREE == CDE_PATH_CUBIC) {
+      const float* p = coeffs + (sc * n_intervals + idx) * 4 * Cr + cc;
+      raw[0] = p[Cr]; raw[1] = p[2 * Cr]; raw[2] = p[3 * Cr];
+    } else {
+      const float* p = coeffs + (sc * (n_intervals + 1) + idx) * Cr + cc;
+      raw[0] = p[0]; raw[1] = p[Cr]; raw[2] = knots[idx + 1] - knots[idx];
+    }
+  }
+  __device__ __forceinline__ void install() {
+    if (DEGREE == CDE_PATH_CUBIC) { cur[0] = raw[0]; cur[1] = raw[1]; cur[2] = raw[2]; }
+    else cur[0] = (raw[1] - raw[0]) / raw[2];
+  }
+  __device__ __forceinline__ float value(float frac) const {
+    const float v = DEGREE == CDE_PATH_CUBIC ? cubic_derivative(cur[0], cur[1], cur[2], frac) : cur[0];
+    return c < Cr ? v : 0.f;
+  }
+  __device__ __forceinline__ int64_t clamp(int64_t e) const { return e < e_last ? e : e_last; }
+
+  // start at table entry e0 (entries e0 .. e_last belong to this sweep): returns dX of entry e0
+  __device__ __forceinline__ float begin(int64_t e0, int64_t last) {
+    e_last = last;
+    const int64_t idx0 = sidx[e0];
+    const float frac0 = sfrac[e0];
+    request(idx0);
+    install();
+    const float v0 = value(frac0);
+    idx1 = sidx[clamp(e0 + 1)]; frac1 = sfrac[clamp(e0 + 1)];
+    idx2 = sidx[clamp(e0 + 2)]; frac2 = sfrac[clamp(e0 + 2)];
+    pending = idx1 != idx0;
+    if (pending) request(idx1);
+    return v0;
+  }
+  // during stage e: returns dX of entry e+1 and moves the pipeline on
+  __device__ __forceinline__ float advance(int64_t e) {
+    const int64_t idx3 = sidx[clamp(e + 3)];
+    const float frac3 = sfrac[clamp(e + 3)];
+    // opaque to the optimiser: otherwise it merges this install into the request of the previous stage (same
+    // condition) and the load is waited for right where it was issued
+    asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]));
+    if (pending) install();
+    const float v = value(frac1);
+    pending = idx2 != idx1;
+    if (pending) request(idx2);
+    idx1 = idx2; frac1 = frac2; idx2 = idx3; frac2 = frac3;
+    return v;
+  }
+};
+
+
 // ============================================================================================ forward
 template <typename TT, int DEGREE, int ACT>
-__global__ __launch_bounds__(256, 1) void rk4_forward_split(
+__global__ __launch_bounds__(256, 2) void rk4_forward_split(
     const float* __restrict__ coeffs, const float* __restrict__ knots, int64_t n_intervals,
     const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ z0,
     const TT* __restrict__ grid, int64_t n_grid, const TT* __restrict__ t_out, int64_t n_out,
     float* __restrict__ z_out, int64_t B, const int64_t* __restrict__ stage_index,
     const float* __restrict__ stage_frac, Dims dims) {
   __shared__ __attribute__((aligned(16))) float zbuf[2 * SPL_ZBUF];
+  __shared__ __attribute__((aligned(16))) float dxb[2 * SPL_DX];
   const int Hr = dims.H, Cr = dims.C;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int n = lane & 15, q = lane >> 4;
@@ -96,15 +172,21 @@ __global__ __launch_bounds__(256, 1) void rk4_forward_split(
 
   float* zw = zbuf + n * SPL_ZROW + q * 8 + 2 * w;          // writer: units (kq = q, s = 2w), (kq = q, s = 2w + 1)
   const float* zr = zbuf + n * SPL_ZROW + q * 8;            // reader: kq = q, s = 0..7
+  Feed<DEGREE> feed;
+  feed.coeffs = coeffs; feed.knots = knots; feed.sidx = stage_index; feed.sfrac = stage_frac;
+  feed.n_intervals = n_intervals; feed.sc = sc; feed.Cr = Cr; feed.c = 2 * w + (q & 1);
+  float* dxw = dxb + n * SPL_DXROW + feed.c;
+  const float* dxr = dxb + n * SPL_DXROW;
+  const bool feeds = q < 2;
   int par = 0;
-  *reinterpret_cast<float2*>(zw) = make_float2(ya, yb);
+  {
+    const float d0 = feed.begin(0, 4 * n_steps - 1);
+    *reinterpret_cast<float2*>(zw) = make_float2(ya, yb);
+    if (feeds) dxw[0] = d0;
+  }
   __syncthreads();
 
   int64_t jout = 1;
-  int64_t idx = stage_index[0];
-  float frac = stage_frac[0];
-  Row<DEGREE> row = load_row<DEGREE>(coeffs, sc, n_intervals, idx, Cr);
-
   for (int64_t k = 0; k < n_steps; ++k) {
     const TT t0 = grid[k], t1 = grid[k + 1];
     const float dt = (float)(t1 - t0);
@@ -113,15 +195,14 @@ __global__ __launch_bounds__(256, 1) void rk4_forward_split(
     for (int stage = 0; stage < 4; ++stage) {
       const float4 z03 = *reinterpret_cast<const float4*>(zr + par * SPL_ZBUF);
       const float4 z47 = *reinterpret_cast<const float4*>(zr + par * SPL_ZBUF + 4);
+      const float4 d03 = *reinterpret_cast<const float4*>(dxr + par * SPL_DX);
+      const float4 d47 = *reinterpret_cast<const float4*>(dxr + par * SPL_DX + 4);
       const float zs[8] = {z03.x, z03.y, z03.z, z03.w, z47.x, z47.y, z47.z, z47.w};
-      float dX[MC];
-      const float width = DEGREE == CDE_PATH_LINEAR ? knots[idx + 1] - knots[idx] : 1.f;
-      control_slope<DEGREE>(row, frac, width, dX);
-      const int64_t e_next = 4 * k + stage + 1;
-      const bool more = e_next < 4 * n_steps;
-      const int64_t nidx = more ? stage_index[e_next] : idx;
-      const float nfrac = more ? stage_frac[e_next] : frac;
-      if (nidx != idx) row = load_row<DEGREE>(coeffs, sc, n_intervals, nidx, Cr);
+      const float dX[MC] = {d03.x, d03.y, d03.z, d03.w, d47.x, d47.y, d47.z, d47.w};
+      // next stage's control derivative (fills the LDS latency of the reads above)
+      const float dnext = feed.advance(4 * k + stage);
+      if (feeds) dxw[(par ^ 1) * SPL_DX] = dnext;
+      __builtin_amdgcn_sched_barrier(0);
 
       f32x4 y00 = by[0], y01 = by[1], y10 = by[2], y11 = by[3];
 #pragma unroll
@@ -159,7 +240,6 @@ __global__ __launch_bounds__(256, 1) void rk4_forward_split(
       *reinterpret_cast<float2*>(zw + (par ^ 1) * SPL_ZBUF) = make_float2(za, zb);
       __syncthreads();
       par ^= 1;
-      idx = nidx; frac = nfrac;
     }
     const float y1a = za, y1b = zb;
     while (jout < n_out && t1 >= t_out[jout]) {
@@ -177,6 +257,16 @@ __global__ __launch_bounds__(256, 1) void rk4_forward_split(
 }
 
 // ============================================================================================ adjoint
+// Stage body, between two workgroup barriers (e = this stage, e-1 = the previous one):
+//   reads of what the other waves published (z, z^T, dX, va partials of e-1)      <- LDS latency ...
+//   dW += g(e-1)^T (wq z(e-1)), first half: operands were parked in registers      <- ... hidden behind 16 MFMAs
+//   a-path RK update from the partials; control feed for e+1
+//   Y tiles (32 MFMAs) -> f, g -> y-path RK update -> publish z(e+1), write g^T (wave-private)
+//   va partials (32 MFMAs, cover the g^T write latency) -> read g^T back as the A operand of dW, publish partials
+//   dW, second half of e-1 (16 MFMAs: cover the partial-write and g^T-read latency)
+//   park g^T(e), wq z^T(e) for the next body; barrier
+// so every LDS round trip has matrix work in front of it, and the only VALU left is what the stage really needs
+// (on gfx950 f32 MFMA and VALU instructions of a wave do not overlap: instruction count is time).
 template <int ACT>
 __device__ __forceinline__ float spl_slope(float t) { return ACT == CDE_ACT_TANH ? __builtin_fmaf(-t, t, 1.f) : 1.f; }
 
@@ -194,7 +284,8 @@ __global__ __launch_bounds__(256, 1) void rk4_adjoint_split(
   float* zbuf = lds;
   float* ztb = lds + 2 * SPL_ZBUF;
   float* vab = ztb + 2 * SPL_ZT;
-  float* gT = vab + 2 * SPL_VA + w * SPL_GT;
+  float* dxb = vab + 2 * SPL_VA;
+  float* gT = dxb + 2 * SPL_DX + w * SPL_GT;
   const int64_t series = (int64_t)blockIdx.x * 16 + n;
   const bool valid = series < B;
   const int64_t sc = valid ? series : B - 1;
@@ -222,6 +313,25 @@ __global__ __launch_bounds__(256, 1) void rk4_adjoint_split(
     accW[Tm][0] = f32x4{0.f, 0.f, 0.f, 0.f};
     accW[Tm][1] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  // parked operands of the deferred dW product (zeros: the first, empty product adds nothing)
+  float4 gAh[4], zbh0 = make_float4(0.f, 0.f, 0.f, 0.f), zbh1 = zbh0;
+  float wqh = 0.f;
+#pragma unroll
+  for (int Tm = 0; Tm < 4; ++Tm) gAh[Tm] = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto dw_half = [&](int half) {
+    const float b0[4] = {zbh0.x, zbh0.y, zbh0.z, zbh0.w}, b1[4] = {zbh1.x, zbh1.y, zbh1.z, zbh1.w};
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      const int Tm = 2 * half + t2;
+      const float ga[4] = {gAh[Tm].x, gAh[Tm].y, gAh[Tm].z, gAh[Tm].w};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        accW[Tm][0] = mfma16(ga[s], b0[s], accW[Tm][0]);
+        accW[Tm][1] = mfma16(ga[s], b1[s], accW[Tm][1]);
+      }
+      gb[Tm] = __builtin_fmaf((ga[0] + ga[1]) + (ga[2] + ga[3]), wqh, gb[Tm]);     // dL/db: row sums
+    }
+  };
 
   const int ua = 8 * w + q, ub = ua + 4;
   const int pos = spl_pos(n);
@@ -234,47 +344,85 @@ __global__ __launch_bounds__(256, 1) void rk4_adjoint_split(
   const float* zr = zbuf + n * SPL_ZROW + q * 8;
   float* ztw = ztb + ua * SPL_TROW + pos;                          // second unit: + 4 rows
   const float* ztr = ztb + n * SPL_TROW + 4 * q;                   // N tile 1: + 16 rows
-  float* vw = vab + (n * 4 + q) * SPL_VROW + 2 * w;                // + w_dst * 64 * SPL_VROW
-  const float* vr = vab + ((w * 16 + n) * 4 + q) * SPL_VROW;
+  float* vw = vab + (q * 16 + n) * SPL_VROW + 2 * w;               // + w_dst * 64 * SPL_VROW
+  const float* vr = vab + ((w * 4 + q) * 16 + n) * SPL_VROW;
   float* gw_ = gT + (4 * q) * SPL_TROW + pos;                      // + (T*16 + r) rows
   const float* gr = gT + n * SPL_TROW + 4 * q;                     // + Tm*16 rows
+  Feed<DEGREE> feed;
+  feed.coeffs = coeffs; feed.knots = knots; feed.sidx = stage_index; feed.sfrac = stage_frac;
+  feed.n_intervals = n_intervals; feed.sc = sc; feed.Cr = Cr; feed.c = 2 * w + (q & 1);
+  float* dxw = dxb + n * SPL_DXROW + feed.c;
+  const float* dxr = dxb + n * SPL_DXROW;
+  const bool feeds = q < 2;
   int par = 0;
   auto publish = [&](int p, float za, float zb) {
     *reinterpret_cast<float2*>(zw + p * SPL_ZBUF) = make_float2(za, zb);
     ztw[p * SPL_ZT] = za;
     ztw[p * SPL_ZT + 4 * SPL_TROW] = zb;
   };
+  // the four waves' partial sums of this wave's two units (fixed order): da/ds = +a^T df/dz
+  auto read_ka = [&](int p, float& kaa, float& kab) {
+    const float4 p03 = *reinterpret_cast<const float4*>(vr + p * SPL_VA);
+    const float4 p47 = *reinterpret_cast<const float4*>(vr + p * SPL_VA + 4);
+    kaa = (p03.x + p03.z) + (p47.x + p47.z);
+    kab = (p03.y + p03.w) + (p47.y + p47.w);
+  };
+  const float third = (float)(1.0 / 3.0);
 
   for (int64_t p = 0; p + 1 < n_out; ++p) {
     const int64_t i_out = n_out - 1 - p;
     const int64_t k_begin = seg_off[p], k_end = seg_off[p + 1] - 1;   // steps k_begin .. k_end-1
     if (k_end > k_begin) {
-      publish(par, y0a, y0b);
+      {
+        const float d0 = feed.begin(4 * k_begin, 4 * k_end - 1);
+        publish(par, y0a, y0b);
+        if (feeds) dxw[par * SPL_DX] = d0;
+      }
       __syncthreads();
-      int64_t idx = stage_index[4 * k_begin];
-      float frac = stage_frac[4 * k_begin];
-      Row<DEGREE> row = load_row<DEGREE>(coeffs, sc, n_intervals, idx, Cr);
+      float ds_prev = 0.f;
+      float ka1a = 0.f, ka1b = 0.f, ka2a = 0.f, ka2b = 0.f, asa = a0a, asb = a0b;
       for (int64_t k = k_begin; k < k_end; ++k) {
         const float ds = (float)(sgrid[k + 1] - sgrid[k]);
-        float ky1a = 0.f, ky1b = 0.f, ky2a = 0.f, ky2b = 0.f, ka1a = 0.f, ka1b = 0.f, ka2a = 0.f, ka2b = 0.f;
-        float ysa = y0a, ysb = y0b, asa = a0a, asb = a0b;
+        float ky1a = 0.f, ky1b = 0.f, ky2a = 0.f, ky2b = 0.f;
+        float ysa = y0a, ysb = y0b;
 #pragma unroll
         for (int stage = 0; stage < 4; ++stage) {
-          // ---- stage state of all 32 units (B operand of Y) and its transposed copy (B operand of dW)
+          // ---- everything the other waves published before the barrier
           const float4 z03 = *reinterpret_cast<const float4*>(zr + par * SPL_ZBUF);
           const float4 z47 = *reinterpret_cast<const float4*>(zr + par * SPL_ZBUF + 4);
+          const float4 d03 = *reinterpret_cast<const float4*>(dxr + par * SPL_DX);
+          const float4 d47 = *reinterpret_cast<const float4*>(dxr + par * SPL_DX + 4);
           const float4 zt0 = *reinterpret_cast<const float4*>(ztr + par * SPL_ZT);
           const float4 zt1 = *reinterpret_cast<const float4*>(ztr + par * SPL_ZT + 16 * SPL_TROW);
+          float kaa = 0.f, kab = 0.f;
+          const bool first = stage == 0 && k == k_begin;               // no previous stage in this sweep
+          if (!first) read_ka(par, kaa, kab);
+          __builtin_amdgcn_sched_barrier(0);
+          dw_half(0);                                                   // deferred dW of stage e-1, first half
+          __builtin_amdgcn_sched_barrier(0);
+          // ---- a path: RK update that stage e-1 left open
+          if (stage == 1) {
+            ka1a = kaa; ka1b = kab;
+            asa = a0a + ds * ka1a * third; asb = a0b + ds * ka1b * third;
+          } else if (stage == 2) {
+            ka2a = kaa; ka2b = kab;
+            asa = a0a + ds * (ka2a - ka1a * third); asb = a0b + ds * (ka2b - ka1b * third);
+          } else if (stage == 3) {
+            asa = a0a + ds * (ka1a - ka2a + kaa); asb = a0b + ds * (ka1b - ka2b + kab);
+            ka1a = ka1a + 3.f * (ka2a + kaa); ka1b = ka1b + 3.f * (ka2b + kab);
+          } else if (!first) {
+            asa = a0a + (ka1a + kaa) * ds_prev * 0.125f; asb = a0b + (ka1b + kab) * ds_prev * 0.125f;
+            a0a = asa; a0b = asb;
+          }
           const float zs[8] = {z03.x, z03.y, z03.z, z03.w, z47.x, z47.y, z47.z, z47.w};
-          float dX[MC];
-          const float width = DEGREE == CDE_PATH_LINEAR ? knots[idx + 1] - knots[idx] : 1.f;
-          control_slope<DEGREE>(row, frac, width, dX);
-          const int64_t e_next = 4 * k + stage + 1;
-          const bool more = e_next < 4 * k_end;
-          const int64_t nidx = more ? stage_index[e_next] : idx;
-          const float nfrac = more ? stage_frac[e_next] : frac;
-          if (nidx != idx) row = load_row<DEGREE>(coeffs, sc, n_intervals, nidx, Cr);
+          const float dX[MC] = {d03.x, d03.y, d03.z, d03.w, d47.x, d47.y, d47.z, d47.w};
+          const float dnext = feed.advance(4 * k + stage);
+          if (feeds) dxw[(par ^ 1) * SPL_DX] = dnext;
           const float wq = ((stage == 0 || stage == 3) ? 0.125f : 0.375f) * ds;     // 3/8-rule quadrature weight
+          // B operand of this stage's dW (executed during the next body): the quadrature weight rides on z
+          const f32x2 zq[4] = {f32x2{zt0.x, zt0.y} * wq, f32x2{zt0.z, zt0.w} * wq, f32x2{zt1.x, zt1.y} * wq,
+                               f32x2{zt1.z, zt1.w} * wq};
+          __builtin_amdgcn_sched_barrier(0);
 
           // ---- Y tiles of this wave's 8 hidden units
           f32x4 yt[4] = {by[0], by[1], by[2], by[3]};
@@ -285,25 +433,28 @@ __global__ __launch_bounds__(256, 1) void rk4_adjoint_split(
             yt[2] = mfma16(wy[2][s], zs[s], yt[2]);
             yt[3] = mfma16(wy[3][s], zs[s], yt[3]);
           }
-          // ---- activation, f for the two own units, g = dL/dY (unweighted: B operand of va; weighted: dW, db)
-          float g[16];
-          float fa = 0.f, fb = 0.f;
+          // ---- activation, f for the two own units, g = dL/dY: B operand of va as it is, A operand of dW after the
+          // wave-private transpose.  Pairs = two neighbouring channels of one unit (consecutive registers of a tile
+          // and of the dX row): packed instructions without register shuffles.
+          f32x2 gq[4][2];                    // gq[T][j] = g[unit P = T >> 1][channels 4 (T & 1) + 2j, + 1]
+          f32x2 fpa = {0.f, 0.f}, fpb = {0.f, 0.f};
 #pragma unroll
           for (int T = 0; T < 4; ++T) {
             const float aown = (T >> 1) ? asb : asa;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float dx = dX[4 * (T & 1) + r];
-              const float t = activate<ACT>(yt[T][r]);
-              if (T >> 1) fb = __builtin_fmaf(t, dx, fb); else fa = __builtin_fmaf(t, dx, fa);
-              const float gv = aown * (dx * spl_slope<ACT>(t));
-              g[4 * T + r] = gv;
-              gw_[(T * 16 + r) * SPL_TROW] = gv * wq;
+            for (int j = 0; j < 2; ++j) {
+              const f32x2 dx = {dX[4 * (T & 1) + 2 * j], dX[4 * (T & 1) + 2 * j + 1]};
+              const f32x2 t = activate2<ACT>(yt[T][2 * j], yt[T][2 * j + 1]);
+              if (T >> 1) fpb = __builtin_elementwise_fma(t, dx, fpb); else fpa = __builtin_elementwise_fma(t, dx, fpa);
+              if (ACT == CDE_ACT_NONE) gq[T][j] = dx * aown;
+              else gq[T][j] = (f32x2{spl_slope<ACT>(t[0]), spl_slope<ACT>(t[1])} * dx) * aown;
+              gw_[(T * 16 + 2 * j) * SPL_TROW] = gq[T][j][0];
+              gw_[(T * 16 + 2 * j + 1) * SPL_TROW] = gq[T][j][1];
             }
           }
+          const f32x2 fp = {fpa[0] + fpa[1], fpb[0] + fpb[1]};
           // ---- the y path does not wait for anything else: next stage state of the own units -> LDS
-          const float kya = -fa, kyb = -fb;          // reverse time: dy/ds = -f
-          const float third = (float)(1.0 / 3.0);
+          const float kya = -fp[0], kyb = -fp[1];          // reverse time: dy/ds = -f
           float nya, nyb;
           if (stage == 0) {
             ky1a = kya; ky1b = kyb;
@@ -319,66 +470,59 @@ __global__ __launch_bounds__(256, 1) void rk4_adjoint_split(
           }
           publish(par ^ 1, nya, nyb);
           ysa = nya; ysb = nyb;
+          __builtin_amdgcn_sched_barrier(0);
 
-          // ---- va partial over this wave's 64 (h, c) rows, all 32 output units
+          // ---- va partial over this wave's 64 (h, c) rows, all 32 output units (K step 8P + c)
           f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
 #pragma unroll
           for (int sp = 0; sp < 16; ++sp) {
-            v0 = mfma16(wv[0][sp], g[sp], v0);
-            v1 = mfma16(wv[1][sp], g[sp], v1);
+            const float gv = gq[2 * (sp >> 3) + ((sp >> 2) & 1)][(sp >> 1) & 1][sp & 1];     // g[P = sp >> 3][c = sp & 7]
+            v0 = mfma16(wv[0][sp], gv, v0);
+            v1 = mfma16(wv[1][sp], gv, v1);
           }
+          // ---- g^T back as the A operand of this stage's dW (wave-private: only this wave's LDS writes are awaited,
+          // and only AFTER the va chain -- the empty asm ties the wait to the chain's results, volatile asms keep
+          // their order -- so the write latency is behind 32 MFMAs instead of in front of them)
+          asm volatile("" : "+v"(v0), "+v"(v1));
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_wave_barrier();
+          float4 gAn[4];
+#pragma unroll
+          for (int Tm = 0; Tm < 4; ++Tm) gAn[Tm] = *reinterpret_cast<const float4*>(gr + Tm * 16 * SPL_TROW);
           // register r of tile T -> destination wave 2T + (r >> 1), its unit j = r & 1
           float* vwp = vw + (par ^ 1) * SPL_VA;
           *reinterpret_cast<float2*>(vwp) = make_float2(v0[0], v0[1]);
           *reinterpret_cast<float2*>(vwp + 64 * SPL_VROW) = make_float2(v0[2], v0[3]);
           *reinterpret_cast<float2*>(vwp + 2 * 64 * SPL_VROW) = make_float2(v1[0], v1[1]);
           *reinterpret_cast<float2*>(vwp + 3 * 64 * SPL_VROW) = make_float2(v1[2], v1[3]);
-
-          // ---- dW_w += (wq g)^T z, dL/db row sums (wave-private transpose: only this wave's writes are awaited)
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-          const float zb0[4] = {zt0.x, zt0.y, zt0.z, zt0.w}, zb1[4] = {zt1.x, zt1.y, zt1.z, zt1.w};
+          __builtin_amdgcn_sched_barrier(0);
+          dw_half(1);                                                   // deferred dW of stage e-1, second half
+          __builtin_amdgcn_sched_barrier(0);
+          // ---- park this stage's operands (the quadrature weight rides on z)
 #pragma unroll
-          for (int Tm = 0; Tm < 4; ++Tm) {
-            const float4 ga4 = *reinterpret_cast<const float4*>(gr + Tm * 16 * SPL_TROW);
-            const float ga[4] = {ga4.x, ga4.y, ga4.z, ga4.w};
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-              accW[Tm][0] = mfma16(ga[s], zb0[s], accW[Tm][0]);
-              accW[Tm][1] = mfma16(ga[s], zb1[s], accW[Tm][1]);
-            }
-            gb[Tm] += (ga[0] + ga[1]) + (ga[2] + ga[3]);
-          }
+          for (int Tm = 0; Tm < 4; ++Tm) gAh[Tm] = gAn[Tm];
+          zbh0 = make_float4(zq[0][0], zq[0][1], zq[1][0], zq[1][1]);
+          zbh1 = make_float4(zq[2][0], zq[2][1], zq[3][0], zq[3][1]);
+          wqh = wq;
           __syncthreads();
           par ^= 1;
-
-          // ---- a path: the four waves' partial sums of this wave's units (fixed order)
-          const float4 p03 = *reinterpret_cast<const float4*>(vr + par * SPL_VA);
-          const float4 p47 = *reinterpret_cast<const float4*>(vr + par * SPL_VA + 4);
-          const float kaa = (p03.x + p03.z) + (p47.x + p47.z);        // da/ds = +a^T df/dz
-          const float kab = (p03.y + p03.w) + (p47.y + p47.w);
-          if (stage == 0) {
-            ka1a = kaa; ka1b = kab;
-            asa = a0a + ds * ka1a * third; asb = a0b + ds * ka1b * third;
-          } else if (stage == 1) {
-            ka2a = kaa; ka2b = kab;
-            asa = a0a + ds * (ka2a - ka1a * third); asb = a0b + ds * (ka2b - ka1b * third);
-          } else if (stage == 2) {
-            asa = a0a + ds * (ka1a - ka2a + kaa); asb = a0b + ds * (ka1b - ka2b + kab);
-            ka1a = ka1a + 3.f * (ka2a + kaa); ka1b = ka1b + 3.f * (ka2b + kab);
-          } else {
-            asa = a0a + (ka1a + kaa) * ds * 0.125f; asb = a0b + (ka1b + kab) * ds * 0.125f;
-          }
-          idx = nidx; frac = nfrac;
         }
-        y0a = ysa; y0b = ysb; a0a = asa; a0b = asb;
+        y0a = ysa; y0b = ysb;
+        ds_prev = ds;
+      }
+      // the last stage's a-path update
+      {
+        float kaa, kab;
+        read_ka(par, kaa, kab);
+        a0a = a0a + (ka1a + kaa) * ds_prev * 0.125f; a0b = a0b + (ka1b + kab) * ds_prev * 0.125f;
       }
     }
     // torchdiffeq adjoint: re-seed y from the stored forward value, add the incoming gradient
     y0a = saved(i_out - 1, ua); y0b = saved(i_out - 1, ub);
     a0a += gout(i_out - 1, ua); a0b += gout(i_out - 1, ub);
   }
+  dw_half(0);                                                           // the last stage's dW
+  dw_half(1);
   if (valid) {
     if (ua < Hr) grad_z0[series * Hr + ua] = a0a;
     if (ub < Hr) grad_z0[series * Hr + ub] = a0b;
