@@ -12,9 +12,13 @@ BASELINE.json configs[2] ("same as [1] with adjoint=True backprop through solver
 configuration the metric is quoted on.  Coefficients are fitted once outside the timed region (K1; the
 reference treats it as dataset pre-processing) and its rate is reported separately under "extra".
 
-Multi-GPU: series are independent, so the batch shards across ranks with NO data-path collective; every
-rank solves its own 32768 series (weak scaling) and the only communication is the all-reduce of the
-8,448 parameter gradients, included in the timed step when N > 1.
+Multi-GPU: series are independent, so the batch shards across ranks with NO data-path collective; the only
+communication is the all-reduce of the 8,448 parameter gradients, included in the timed step when N > 1.
+``--scaling strong`` (default; what BASELINE.json asks for: ONE 32768-series job on N GPUs) gives every rank
+32768 / N series -- below 16384 series per GPU cdeint switches to the workgroup-per-tile kernels (rk4_split.hip),
+which keep every SIMD busy down to 16 series per CU.  ``--scaling weak`` keeps 32768 series per rank.
+``python bench.py --gpus N`` without a torchrun environment re-executes itself under torch.distributed.run with N
+ranks on 127.0.0.1.
 """
 import argparse
 import json
@@ -35,14 +39,20 @@ FLOP_FWD = N_EVAL * (2 * H * (H * C) + 2 * H * C)                               
 FLOP_ADJ = N_EVAL * ((2 * H * H * C + 2 * H * C) + 2 * H * C + 2 * H * C * H + 2 * H * C * H + H * C)   # 25.6 MFLOP
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
-K3_HBM_BYTES_PER_LAUNCH = int(2 * 268.8e6 + 37.9e6)   # measured, see roofline.traffic_source
+# HBM bytes per launch of the dominant kernel from rocprofv3 counter passes (see roofline.traffic_source); keyed by the
+# per-GPU batch the pass was run at, None where no pass exists
+ADJOINT_HBM_BYTES_PER_LAUNCH = {32768: int(2 * 268.8e6 + 37.9e6)}
 
 
-def make_workload(device, seed):
+def make_workload(device, seed, n=None, first=0, count=None):
+    """The SURVEY 8(d) workload: n series generated on the CPU from `seed` (identical bits on every rank and on the
+    CPU baseline), rows [first, first + count) moved to `device`."""
     from helpers import LinearField, make_series
-    x = make_series(B, L, C, seed=seed).to(device)
+    n = B if n is None else n
+    count = n if count is None else count
+    x = make_series(n, L, C, seed=seed)[first:first + count].contiguous().to(device)
     func = LinearField(H, C, scale=0.25, seed=0).to(device)
-    z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(seed)).to(device)
+    z0 = torch.randn(n, H, generator=torch.Generator().manual_seed(seed))[first:first + count].contiguous().to(device)
     return x, func, z0
 
 
@@ -50,12 +60,14 @@ def _log(msg):
     print("[bench] " + msg, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(max_sample, budget_s=15.0):
-    """The oracle (torch-CPU restatement of the reference path) on a bounded sample of the same workload.
+def cpu_baseline(max_sample, budget_s=20.0):
+    """The oracle (torch-CPU restatement of the reference path) on a bounded sample of the same workload, timed per
+    BASELINE.md section 3: 1 warm-up + 3 timed runs of the same sample, min and median reported, `value` = median.
 
     The CPU gets its best shot: the thread count is chosen among {8, 16, 32, 64} (capped by the cores this process
-    may run on -- cgroup/affinity aware) by a 1024-series probe, and the timed sample is sized from that probe so the
-    run takes about ``budget_s`` seconds (large batches amortise eager-op overheads, so bigger is fairer)."""
+    may run on -- cgroup/affinity aware) by a 1024-series probe, and the sample is sized from that probe so that the
+    four runs together take about ``budget_s`` seconds (large batches amortise eager-op overheads: bigger is
+    fairer to the CPU; the per-series rate at 8192 series is within a few per cent of the full-batch rate)."""
     from oracle import cde as oracle_cde, interp as oracle_interp
     from helpers import LinearField, make_series
     try:
@@ -91,12 +103,54 @@ def cpu_baseline(max_sample, budget_s=15.0):
         run(128)
         best_time = run(1024)
     torch.set_num_threads(best_threads)
-    sample = int(min(max_sample, max(1024, 1024 * budget_s / best_time))) // 1024 * 1024
-    dt = run(sample)
-    return {"value": sample / dt, "unit": "series/s", "cores": best_threads, "kind": "port",
+    sample = int(min(max_sample, max(1024, 1024 * budget_s / 4 / best_time))) // 1024 * 1024
+    run(sample)                               # warm-up at the timed size
+    times = sorted(run(sample) for _ in range(3))
+    return {"value": sample / times[1], "unit": "series/s", "cores": best_threads, "kind": "port",
+            "best_value": sample / times[0], "runs_s": times,
             "sample": "oracle (torch-CPU restatement of reference CubicSpline + _VectorField + torchdiffeq rk4/"
-                      "adjoint) on %d of the %d series, L=%d, one timed fwd+adjoint (%.1f s) with the fastest of "
-                      "{8,16,32,64} threads (%d cores available)" % (sample, B, L, dt, avail)}
+                      "adjoint) on %d of the %d series, L=%d, fwd+adjoint: 1 warm-up + 3 timed runs, median %.2f s "
+                      "(min %.2f s), the fastest of {8,16,32,64} threads (%d cores available); container-side figure "
+                      "with the reference's own CubicSpline/_VectorField classes: profiles/r02_cpu_reference_container"
+                      ".json" % (sample, B, L, times[1], times[0], avail)}
+
+
+TRAFFIC_SOURCE = {
+    32768: "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload (profiles/r01_pmc_summary.csv): 2 x 268.8 "
+           "MB fetched (gfx950 half-count correction for 16 B/lane reads) + 37.9 MB written; algorithmic bytes: "
+           "32768 x 12,704 B = 416 MB (whole 128 B rows: 550 MB)",
+}
+
+
+def strong_scaling_proxy(cde, x, func, z0, full_ms):
+    """What ONE GPU of an N-GPU strong-scaling run does, measured on this GPU: forward + adjoint on 32768/N series
+    (N = 2, 4, 8) against the full batch.  Wall clock over 20 steps after 3 warm-ups; no communication (the real run
+    adds one 33 KB all-reduce)."""
+    out = {"batch_32768_ms": full_ms}
+    params = list(func.parameters())
+    for n_gpus in (2, 4, 8):
+        b = 32768 // n_gpus
+        if b > x.size(0):
+            continue
+        X = cde.CubicSpline(cde.hermite_cubic_coefficients_with_backward_differences(x[:b].contiguous()))
+        zz = z0[:b].contiguous()
+
+        def once():
+            z = zz.detach().requires_grad_(True)
+            for p in params:
+                p.grad = None
+            cde.cdeint(X, func, z, X.interval, method="rk4", options={"step_size": 1.0})[:, -1].sum().backward()
+        for _ in range(3):
+            once()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            once()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 20 * 1e3
+        out["batch_%d_ms" % b] = ms
+        out["speedup_at_%d_gpus_compute_only" % n_gpus] = full_ms / ms
+    return out
 
 
 def other_fields(cde, X, z0, device, reps=2):
@@ -139,31 +193,63 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--cpu-sample", type=int, default=32768, help="series in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="strong: 32768 series in total (32768/N per GPU); weak: 32768 series per GPU")
+    ap.add_argument("--cpu-sample", type=int, default=8192, help="series in the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # not under torchrun: launch the N ranks ourselves (one process per GPU, RCCL over xGMI, rendezvous on 127.0.0.1)
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                                  "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+                                  "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    # CDE_BENCH_FORCE_DIST=1 exercises the RCCL code path with a single rank (used to validate it on a 1-GPU box)
+    if world != args.gpus and rank == 0:
+        _log("note: --gpus %d but WORLD_SIZE=%d; the launcher's world size is what runs and what is reported"
+             % (args.gpus, world))
+    global B
+    B_TOTAL = B
+    if args.scaling == "strong":
+        if B_TOTAL % world:
+            raise SystemExit("strong scaling needs 32768 %% n_gpus == 0, got n_gpus=%d" % world)
+        B = B_TOTAL // world                      # per-rank batch; FLOP/byte bookkeeping below is per rank
+    # CDE_BENCH_FORCE_DIST=1 exercises the RCCL code path with a single rank (used to validate it on a 1-GPU box).
+    # CDE_BENCH_SHARE_GPU=1 is a LAUNCHER check for 1-GPU boxes only: every rank uses cuda:0 and the process group is
+    # gloo (RCCL refuses two ranks on one device) -- it validates self-launch / sharding / reporting, not a number.
     distributed = world > 1 or os.environ.get("CDE_BENCH_FORCE_DIST") == "1"
+    share_gpu = os.environ.get("CDE_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        try:                                              # "nccl" is RCCL on ROCm; bind the communicator to this GPU
-            dist.init_process_group(backend="nccl", device_id=device)
-        except TypeError:
-            dist.init_process_group(backend="nccl")
+        if share_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            try:                                          # "nccl" is RCCL on ROCm; bind the communicator to this GPU
+                dist.init_process_group(backend="nccl", device_id=device)
+            except TypeError:
+                dist.init_process_group(backend="nccl")
 
     import torchcde_amd as cde
     from torchcde_amd.cdeint import _Plan
     from torchcde_amd.distributed import allreduce_gradients
     cde.load()
 
-    _log("rank %d/%d building workload" % (rank, world))
-    x, func, z0 = make_workload(device, seed=rank)
+    _log("rank %d/%d building workload (%d series on this rank, %s scaling)" % (rank, world, B, args.scaling))
+    if args.scaling == "strong":                  # this rank's shard of THE 32768-series job
+        x, func, z0 = make_workload(device, seed=0, n=B_TOTAL, first=rank * B, count=B)
+    else:
+        x, func, z0 = make_workload(device, seed=rank)
 
     # K1 outside the timed region, timed on its own
     torch.cuda.synchronize()
@@ -236,6 +322,9 @@ def main():
         total_series = B * world * args.steps
         value = total_series / elapsed
         achieved = B * FLOP_ADJ / (adj_avg * 1e-3) / 1e12 if adj_avg > 0 else 0.0
+        split = B <= 16384                      # CDE_SPLIT_MAX_BATCH: workgroup-per-tile kernels below, K2/K3 above
+        kernel = "rk4_adjoint_split8 (K3s)" if split else "rk4_adjoint_mfma (K3)"
+        traffic = ADJOINT_HBM_BYTES_PER_LAUNCH.get(B)
         result = {
             "metric": "series/sec (fwd+adjoint) for cdeint RK4, batch=32k L=128 C=8 H=32",
             "value": value,
@@ -245,21 +334,22 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" + (" (LAUNCHER CHECK: all ranks share cuda:0 over gloo -- not a measurement)"
+                                   if share_gpu else ""),
             "config": {"workload": "BASELINE configs[2]: Hermite-cubic control, linear func Linear(32,256), RK4 "
-                                   "step 1.0 (127 steps), cdeint forward + adjoint=True backward, per GPU",
+                                   "step 1.0 (127 steps), cdeint forward + adjoint=True backward; %s"
+                                   % ("ONE 32768-series batch sharded over the GPUs" if args.scaling == "strong"
+                                      else "32768 series per GPU"),
                        "batch_per_gpu": B, "length": L, "input_channels": C, "hidden_channels": H,
-                       "global_batch": B * world, "parallelism": "batch-sharded x%d, no data-path collective" % world},
+                       "global_batch": B * world, "parallelism": "batch-sharded x%d, no data-path collective, one "
+                                                                  "33 KB gradient all-reduce per step" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": K3_HBM_BYTES_PER_LAUNCH,
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload "
-                                           "(profiles/r01_pmc_summary.csv): 2 x 268.8 MB fetched (gfx950 half-count "
-                                           "correction for 16 B/lane reads) + 37.9 MB written; algorithmic bytes: "
-                                           "32768 x 12,704 B = 416 MB (whole 128 B rows: 550 MB)",
-                         "kernel": "rk4_adjoint_mfma (K3)", "kernel_ms": adj_avg,
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                         "traffic_source": TRAFFIC_SOURCE.get(B),
+                         "kernel": kernel, "kernel_ms": adj_avg,
                          "algorithmic_flop_per_launch": B * FLOP_ADJ},
             "extra": {
                 "forward_kernel_ms": fwd_avg,
@@ -274,6 +364,8 @@ def main():
                 "missing_value_fill_series_per_s": B / (fill_ms * 1e-3),
             },
         }
+        if world == 1:
+            result["extra"]["strong_scaling_proxy_1gpu"] = strong_scaling_proxy(cde, x, func, z0, elapsed / args.steps * 1e3)
         if world == 1:
             result["extra"]["other_fields"] = other_fields(cde, X, z0, device)
         if world == 1 and args.cpu_sample > 0:
