@@ -288,6 +288,13 @@ typedef struct {
   int32_t on_jump, refresh, pad;
 } cde_dopri5_status;
 size_t cde_dopri5_workspace_bytes(int64_t B, int64_t C, int64_t H, int dtype);
+/* The solve's step sequence: the workspace holds, at byte offset cde_dopri5_trace_offset(...), up to
+ * CDE_DOPRI5_TRACE_STEPS pairs of float64 (t0, t1), one per ACCEPTED step in order (status.n_accept of them, later
+ * steps are not recorded).  torchdiffeq has one controller for the whole batch; shards of a batch solved on
+ * several GPUs take their own sequences, and this trace is how a caller (or a test replaying the steps through the
+ * oracle) sees which. */
+#define CDE_DOPRI5_TRACE_STEPS 4096
+size_t cde_dopri5_trace_offset(int64_t B, int64_t C, int64_t H, int dtype);
 int cde_dopri5_advance(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
                        const void* bias, int act, const void* z0, const double* t_out, int64_t n_out,
                        const double* jump_t, int64_t n_jump, double rtol, double atol, double safety,

@@ -183,7 +183,8 @@ class _Dopri5:
     order = 5
 
     def __init__(self, f, y0, rtol, atol, norm, first_step=None, step_t=None, jump_t=None, safety=0.9, ifactor=10.0,
-                 dfactor=0.2, max_num_steps=2 ** 31 - 1, min_step=0, max_step=float("inf"), dtype=torch.float64):
+                 dfactor=0.2, max_num_steps=2 ** 31 - 1, min_step=0, max_step=float("inf"), dtype=torch.float64,
+                 replay_steps=None):
         tdtype = torch.promote_types(dtype, y0.dtype)
         dev = y0.device
         self.f, self.y0, self.norm, self.tdtype = f, y0, norm, tdtype
@@ -203,6 +204,11 @@ class _Dopri5:
         self.c_mid = torch.tensor(_DP_C_MID, **yd)
         self.n_accept = 0
         self.n_reject = 0
+        self.accepted = []           # (t0, t1) of every accepted step (test infrastructure: compared with the GPU trace)
+        # TEST INFRASTRUCTURE, not a torchdiffeq option: a list / (n, 2) tensor of accepted (t0, t1) steps.  The
+        # controller is bypassed and exactly these steps are taken -- used to check a SAMPLE of a large batch against
+        # the step sequence the batch-global controller chose for the WHOLE batch (tests/test_gpu_parity.py, config 4).
+        self.replay_steps = None if replay_steps is None else torch.as_tensor(replay_steps, dtype=tdtype).reshape(-1, 2)
 
     # -- initial step (Hairer), order argument = self.order - 1
     def _initial_step(self, t0, f0):
@@ -276,7 +282,33 @@ class _Dopri5:
         factor = torch.min(self.ifactor, torch.max(self.safety / ratio ** exponent, dfactor))
         return last * factor
 
+    def _integrate_replay(self, t):
+        y0 = self.y0
+        out = torch.empty(len(t), *y0.shape, dtype=y0.dtype, device=y0.device)
+        out[0] = y0
+        t = t.to(self.tdtype)
+        jumps = set() if self.jump_t is None else set(self.jump_t.tolist())
+        y, f = y0, self.f(t[0], y0)
+        i = 1
+        for t0, t1 in self.replay_steps:
+            if i >= len(t):
+                break
+            y1, f1, _, k = self._rk_step(y, f, t0, t1 - t0, t1)
+            dense = self._fit_dense(y, y1, k, t1 - t0)
+            if t1.item() in jumps:                      # the step landed on a jump: f re-evaluated just after it
+                f1 = self.f(t1, y1, perturb=_NEXT)
+            self.n_accept += 1
+            self.accepted.append((t0.item(), t1.item()))
+            while i < len(t) and not (t[i] > t1):
+                out[i] = self._eval_dense(dense, t0, t1, t[i])
+                i += 1
+            y, f = y1, f1
+        assert i == len(t), "replayed steps end before the last output time"
+        return out
+
     def integrate(self, t):
+        if self.replay_steps is not None:
+            return self._integrate_replay(t)
         y0 = self.y0
         out = torch.empty(len(t), *y0.shape, dtype=y0.dtype, device=y0.device)
         out[0] = y0
@@ -331,6 +363,7 @@ class _Dopri5:
                     accept = True
                 if accept:
                     self.n_accept += 1
+                    self.accepted.append((t0.item(), t1.item()))
                     dense = self._fit_dense(y, y1, k, dt)
                     if on_step and i_step != len(step_t) - 1:
                         i_step += 1

@@ -92,6 +92,7 @@ _SIGNATURES = {
                                  _i, _i, _p, _p, _p]),
     "cde_rk4_adjoint_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i, _i]),
     "cde_dopri5_workspace_bytes": (_sz, [_i64, _i64, _i64, _i]),
+    "cde_dopri5_trace_offset": (_sz, [_i64, _i64, _i64, _i]),
     "cde_dopri5_advance": (_i, [_p, _p, _i64, _i, _p, _p, _i, _p, _p, _i64, _p, _i64, _d, _d, _d, _d, _d, _p, _i64, _i64,
                                 _i64, _i, _i, _p, _sz, _i64, _i64, _p]),
     "cde_dopri5_advance_mlp": (_i, [_p, _p, _i64, _i, _p, _p, _i64, _p, _p, _i, _p, _p, _i64, _p, _i64, _d, _d, _d, _d, _d,

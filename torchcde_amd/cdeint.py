@@ -388,6 +388,7 @@ class _FusedRK4(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------ dopri5 (K4)
 last_dopri5_stats = {}     # {"n_accept", "n_reject", "launches"} of the most recent adaptive solve (for tests / logging)
+record_dopri5_steps = False   # tests: also fetch the accepted (t0, t1) step sequence into last_dopri5_stats["steps"]
 _DOPRI_CHUNK = 48          # attempt kernels queued between two looks at the done flag
 
 
@@ -463,6 +464,10 @@ class _Dopri5Plan:
                                    % (launched, status.t_hi, status.dt))
         last_dopri5_stats.clear()
         last_dopri5_stats.update(n_accept=status.n_accept, n_reject=status.n_reject, launches=launched)
+        if record_dopri5_steps:
+            off = lib.cde_dopri5_trace_offset(self.B, self.C, self.H, dt)
+            n = min(status.n_accept, 4096)            # CDE_DOPRI5_TRACE_STEPS
+            last_dopri5_stats["steps"] = workspace[off:off + 16 * n].view(torch.float64).view(n, 2).cpu()
         return out
 
 

@@ -45,6 +45,7 @@ struct DopriArgs {
   double* partial;              // [2][n_blocks][2], accumulated in float64 whatever the state dtype
   int64_t n_blocks_alloc;
   const T* W1; const T* bias1; int width;      // two-layer fields: the hidden layer (W, bias are then the output layer)
+  double* trace;                // [CDE_DOPRI5_TRACE_STEPS][2]: (t0, t1) of every accepted step, in order
 };
 
 __device__ __forceinline__ float next_toward(float x, float dir) { return nextafterf(x, x + dir); }
@@ -188,6 +189,10 @@ __device__ __forceinline__ DopriPlan<T> dopri_controller(const DopriArgs<T>& g, 
     if (accept) {
       c.n_accept++;
       c.t_lo = c.t_hi; c.t_hi = c.t1_try;
+      if (g.trace && blockIdx.x == 0 && threadIdx.x == 0 && c.n_accept <= CDE_DOPRI5_TRACE_STEPS) {
+        g.trace[2 * (c.n_accept - 1)] = c.t_lo;                  // the step sequence of the solve (tests replay it
+        g.trace[2 * (c.n_accept - 1) + 1] = c.t_hi;              // through the oracle; sharded runs can compare it)
+      }
       c.refresh = 0;
       if (c.on_jump) {
         const int64_t kept = g.n_jump - c.pad;
@@ -629,11 +634,16 @@ static inline int64_t dopri_blocks_any(int64_t B, int64_t H) {          // parti
 }  // namespace cde
 
 // ================================================================================================ C ABI
-extern "C" size_t cde_dopri5_workspace_bytes(int64_t B, int64_t C, int64_t H, int dtype) {
+extern "C" size_t cde_dopri5_trace_offset(int64_t B, int64_t C, int64_t H, int dtype) {
   (void)C;
   const size_t elem = dtype == CDE_F64 ? 8 : 4;
-  return cde::al256(2 * sizeof(cde::DopriCtrl)) + cde::al256((size_t)2 * cde::dopri_blocks_any(B, H) * 2 * sizeof(double)) +
-         (size_t)2 * 5 * B * H * elem + cde::al256(cde::DOPRI_IMAGE_BYTES);
+  return cde::al256(cde::al256(2 * sizeof(cde::DopriCtrl)) +
+                    cde::al256((size_t)2 * cde::dopri_blocks_any(B, H) * 2 * sizeof(double)) +
+                    (size_t)2 * 5 * B * H * elem + cde::al256(cde::DOPRI_IMAGE_BYTES));
+}
+
+extern "C" size_t cde_dopri5_workspace_bytes(int64_t B, int64_t C, int64_t H, int dtype) {
+  return cde_dopri5_trace_offset(B, C, H, dtype) + cde::al256((size_t)CDE_DOPRI5_TRACE_STEPS * 2 * sizeof(double));
 }
 
 // W1 == nullptr: one-layer field (W, bias); otherwise W1/bias1/width is the hidden layer and W/bias the output layer
@@ -662,6 +672,7 @@ static int dopri5_advance_impl(const void* coeffs, const void* knots, int64_t n_
   double* partial = (double*)(base + cde::al256(2 * sizeof(cde::DopriCtrl)));
   float* w16 = (float*)(base + cde::al256(2 * sizeof(cde::DopriCtrl)) + cde::al256((size_t)2 * blocks * 2 * sizeof(double)));
   void* state = (unsigned char*)w16 + cde::al256(cde::DOPRI_IMAGE_BYTES);
+  double* trace = (double*)(base + cde_dopri5_trace_offset(B, C, H, dtype));
   if (first_launch == 0) {
     if (hipMemsetAsync(ctrl, 0, 2 * sizeof(cde::DopriCtrl), s) != hipSuccess) return CDE_ERR_LAUNCH;   // phase 0
   }
@@ -672,6 +683,7 @@ static int dopri5_advance_impl(const void* coeffs, const void* knots, int64_t n_
     cde::DopriArgs<T> g{(const T*)coeffs, (const T*)knots, n_intervals, degree, (const T*)W, (const T*)bias, act, \
                         (const T*)z0, t_out, n_out, jump_t, n_jump, rtol, atol, safety, ifactor, dfactor,         \
                         (T*)z_out, B, C, H, ns, ctrl, (T*)state, nullptr, partial, blocks};                        \
+    g.trace = trace;                                                                                              \
     const size_t lds = (((size_t)ns * (H + C) * sizeof(T) + 15) / 16) * 16 + 2 * nt * sizeof(double);                                 \
     for (int64_t i = 0; i < n_launches; ++i)                                                                      \
       cde::dopri5_attempt_kernel<T><<<(unsigned)cde::dopri_blocks(B, H), nt, lds, s>>>(g, (int)((first_launch + i) & 1)); \
@@ -680,7 +692,7 @@ static int dopri5_advance_impl(const void* coeffs, const void* knots, int64_t n_
     cde::DopriArgs<float> g{(const float*)coeffs, (const float*)knots, n_intervals, degree, (const float*)W,
                             (const float*)bias, act, (const float*)z0, t_out, n_out, jump_t, n_jump, rtol, atol, safety,
                             ifactor, dfactor, (float*)z_out, B, C, H, 16, ctrl, (float*)state, w16, partial, blocks,
-                            (const float*)W1, (const float*)bias1, (int)width};
+                            (const float*)W1, (const float*)bias1, (int)width, trace};
     const cde::Dims dims{(int)H, (int)C};
     const unsigned grid = (unsigned)((B + 127) / 128);
     const int64_t n_knots = n_intervals + 1;
