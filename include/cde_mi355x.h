@@ -156,6 +156,12 @@ int cde_path_eval_backward(const void* grad_out, const void* knots, const void* 
  * ------------------------------------------------------------------------------------------- */
 int cde_contract(const void* F, const void* dX, void* out, int64_t B, int64_t H, int64_t C, int dtype, void* stream);
 
+/* Whether the fused RK4 kernels take a vector field of this shape (1) or not (0): the MFMA kernels need f32,
+ * H <= 32, C <= 8; the generic kernels H <= 256 and one series' stage data (adjoint: H + C + H*C values) within
+ * 64 KB of LDS.  The Python host solves anything else step by step (torchcde_amd/stepwise.py) instead of failing in
+ * the backward pass. */
+int cde_rk4_supported(int64_t C, int64_t H, int dtype, int act, int adjoint, int variant);
+
 /* ---------------------------------------------------------------------------------------------
  * K2  Fused fixed-grid RK4 (3/8 rule) solve of  dz/dt = f(t, z) dX/dt  for the affine family.
  * Replaces, for one cdeint call: _VectorField.forward (solver.py:117-135) x 4 per step,

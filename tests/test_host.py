@@ -454,3 +454,65 @@ def test_plain_w2_copy_permutation_is_bijective_and_bank_conflict_free():
                         assert off == prow(4 * P + (n >> 2), 4 * tb + (n & 3)) * S + 16 * T1 + 4 * q and off % 4 == 0
                         slots.add((off // 4) % 8)
                     assert len(slots) == 8
+
+
+def test_probe_refuses_value_dependent_lookalikes_and_tracks_module_state():
+    """relu6 / hardtanh / clamp agree with relu / identity on small values; a Python switch or a patched
+    forward changes the field without changing a parameter.  The probe must refuse / re-verify (CPU tensors: the probe
+    is host logic)."""
+    import torch
+    from torchcde_amd.fields import probe, LinearCDEFunc
+    z = torch.randn(5, 4) * 1e-3
+    t0 = torch.tensor(0.)
+
+    class Relu6(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b = torch.nn.Linear(4, 16), torch.nn.Linear(16, 12)
+
+        def forward(self, t, z):
+            return self.b(torch.nn.functional.relu6(self.a(z))).tanh().view(-1, 4, 3)
+
+    class HardTanh(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(4, 12)
+
+        def forward(self, t, z):
+            return torch.nn.functional.hardtanh(self.a(z)).view(-1, 4, 3)
+
+    class Clamp(HardTanh):
+        def forward(self, t, z):
+            return self.a(z).clamp(-1, 1).view(-1, 4, 3)
+
+    class Dropout(HardTanh):
+        def __init__(self):
+            super().__init__()
+            self.drop = torch.nn.Dropout(0.5)
+
+        def forward(self, t, z):
+            return self.drop(self.a(z)).view(-1, 4, 3)
+
+    for cls in (Relu6, HardTanh, Clamp):
+        assert probe(cls(), t0, z)[0] is None, cls.__name__
+    d = Dropout().eval()
+    assert probe(d, t0, z)[0] is not None                      # eval mode: dropout is the identity, no operator runs
+    d.train()                                                  # the train flag is part of the fingerprint: probed again,
+    assert probe(d, t0, z)[0] is None                          # and now a foreign operator shows up
+
+    f = LinearCDEFunc(3, 4)
+    assert probe(f, t0, z)[0].act == 0
+    assert probe(f, t0, z)[1].device.type == "meta"            # cached: no second evaluation
+    f.use_tanh = True                                          # plain attribute flips the field
+    assert probe(f, t0, z)[0].act == 1
+    f.forward = lambda t, zz: f.linear(zz).view(-1, 4, 3) * 2  # instance-level monkey patch
+    assert probe(f, t0, z)[0] is None
+    g = LinearCDEFunc(3, 4)
+    assert probe(g, t0, z)[0] is not None
+    original = LinearCDEFunc.forward
+    try:
+        LinearCDEFunc.forward = lambda self, t, zz: self.linear(zz).view(-1, 4, 3) + 1.0   # class-level patch
+        assert probe(g, t0, z)[0] is None
+    finally:
+        LinearCDEFunc.forward = original
+    assert probe(g, t0, z)[0] is not None

@@ -86,6 +86,7 @@ _SIGNATURES = {
     "cde_path_eval": (_i, [_p, _p, _p, _i64, _p, _i64, _i64, _i64, _i, _i, _i, _p]),
     "cde_path_eval_backward": (_i, [_p, _p, _p, _i64, _p, _i64, _i64, _i64, _i, _i, _i, _p]),
     "cde_contract": (_i, [_p, _p, _p, _i64, _i64, _i64, _i, _p]),
+    "cde_rk4_supported": (_i, [_i64, _i64, _i, _i, _i, _i]),
     "cde_rk4_forward_linear": (_i, [_p, _p, _i64, _i, _p, _p, _i, _p, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i, _i,
                                     _i, _p, _p, _p]),
     "cde_rk4_forward_mlp": (_i, [_p, _p, _i64, _i, _p, _p, _i64, _p, _p, _i, _p, _p, _i64, _p, _i64, _p, _i64, _i64, _i64,

@@ -125,6 +125,45 @@ def _grids_for(t_host, step_size, adjoint_step_size, device):
     return hit
 
 
+def _plan_time_gradients(plan, z_saved, grad_out, weight, bias, grad_x, t, want_t, want_knots):
+    """Gradients with respect to times from what the adjoint sweep already produced (torchdiffeq's odeint_adjoint,
+    SURVEY appendix A.4, for f(t, z) = F(z) dX/dt(t)):
+      dL/dt_i (i >= 1) = f(t_i, z_i) . dL/dz_i                       -- one field evaluation per output time
+      dL/dt_0          = - sum_i dL/dt_i + int a^T F(z) d2X/dt2 dt    -- the integral in the solver's own quadrature
+      dL/d knot_j      = - int_{interval j} a^T F(z) d2X/dt2 dt       -- the reference's `frac = t - t_j` chain
+    With a cubic control d2X/dt2 = 2c + 2 (3d) frac, so both integrals are per-interval contractions of the control
+    gradient the sweep accumulates anyway: sum_c (2c . dL/db + 2 (3d) . dL/d(2c)).  A piecewise-linear control has no
+    such term."""
+    B, H, C = plan.B, plan.H, plan.C
+    dev = plan.device
+    coeffs = plan.coeffs                                              # (B, rows, width)
+    if plan.degree == _lib.PATH_CUBIC:
+        two_c, three_d = coeffs[..., 2 * C:3 * C], coeffs[..., 3 * C:]
+        q = (two_c * grad_x[..., C:2 * C] + 2 * three_d * grad_x[..., 2 * C:3 * C]).sum(-1)      # (B, intervals)
+        per_interval = q.sum(0)
+    else:
+        per_interval = torch.zeros(coeffs.size(1) - 1, dtype=coeffs.dtype, device=dev)
+    grad_t = grad_knots = None
+    if want_t:
+        zs = z_saved.reshape(B, plan.n_out, H)
+        go = grad_out.reshape(B, plan.n_out, H)
+        vals = [None] * plan.n_out
+        total = torch.zeros((), dtype=coeffs.dtype, device=dev)
+        for i in range(1, plan.n_out):
+            y = torch.nn.functional.linear(zs[:, i], weight, bias)
+            if plan.act == _lib.ACT_TANH:
+                y = y.tanh()
+            dX = plan.path.derivative(plan.t_out[i]).reshape(B, C)
+            f = (y.view(B, H, C) * dX.unsqueeze(1)).sum(-1)
+            vals[i] = (f * go[:, i]).sum()
+            total = total + vals[i]
+        vals[0] = per_interval.sum() - total
+        grad_t = torch.stack(vals).to(t.dtype) if plan.n_out > 1 else torch.zeros_like(t)
+    if want_knots:
+        grad_knots = torch.cat([-per_interval, per_interval.new_zeros(1)])
+    return grad_t, grad_knots
+
+
 class _Plan:
     """Everything one cdeint call needs besides the differentiable tensors."""
 
@@ -143,6 +182,7 @@ class _Plan:
     def __init__(self, path, field, batch, H, C, t, step_size, adjoint_step_size, adjoint, variant):
         coeffs, knots, _ = path._native_inputs()
         self.coeffs, self.knots = coeffs, knots
+        self.path = path
         self.n_intervals = path._n_intervals()
         self.degree = path._degree
         self.act = field.act
@@ -157,6 +197,8 @@ class _Plan:
         self.t_out, self.grid = grids.t_out, grids.grid
         self.stage_index = None
         self.stage_frac = None
+
+    time_gradients = _plan_time_gradients
 
     # forward: K2
     def run_forward(self, z0, weight, bias):
@@ -235,10 +277,10 @@ class _MlpPlan:
                                 self.device)
         self.n_out = self.grids.n_out
 
-    def _weights(self):
+    def _weights(self, saved=None):
         f = self.field
-        return (f.hidden.weight.detach().contiguous(), f.hidden.bias.detach().contiguous(),
-                f.output.weight.detach().contiguous(), f.output.bias.detach().contiguous())
+        tensors = (f.hidden.weight, f.hidden.bias, f.output.weight, f.output.bias) if saved is None else saved
+        return tuple(p.detach().contiguous() for p in tensors)
 
     def run(self, z0):
         lib = _lib.load()
@@ -264,15 +306,17 @@ class _MlpPlan:
         groups = stages * split
         return torch.bmm(left.view(groups, -1, left.size(1)).transpose(1, 2), right.view(groups, -1, right.size(1))).sum(0)
 
-    def run_adjoint(self, z_saved, grad_out, want_control=False):
+    def run_adjoint(self, z_saved, grad_out, want_control=False, weights=None):
         """torchdiffeq's odeint_adjoint backward for this field: per output interval (last to first) the augmented
         state is integrated in reversed time by K3m in chunks of steps; each chunk's per-stage factors (in HBM) are
-        reduced into the parameter gradients by two GEMMs whose extra "ones" column yields the bias gradients."""
+        reduced into the parameter gradients by two GEMMs whose extra "ones" column yields the bias gradients.
+        ``weights``: the parameter tensors saved by the forward pass (an in-place update between forward and backward
+        then trips autograd's version check instead of silently using the new values)."""
         lib = _lib.load()
         g, f = self.grids, self.field
         B, H, C = self.B, self.H, self.C
         dev, f32 = self.device, _lib.dtype_enum(torch.float32)
-        w1, b1, w2, b2 = self._weights()
+        w1, b1, w2, b2 = self._weights(weights)
         width = w1.size(0)
         nbytes = lib.cde_rk4_adjoint_mlp_workspace_bytes(g.n_sgrid)
         workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -329,14 +373,14 @@ class _FusedMlpRK4(torch.autograd.Function):
     def forward(ctx, z0, w1, b1, w2, b2, plan, want_x, *control):
         out = plan.run(z0)
         ctx.plan, ctx.want_x = plan, want_x
-        ctx.save_for_backward(out)
+        ctx.save_for_backward(out, w1, b1, w2, b2)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        (out,) = ctx.saved_tensors
+        out, *weights = ctx.saved_tensors
         plan = ctx.plan
-        grad_z0, gw1, gb1, gw2, gb2, grad_x = plan.run_adjoint(out, grad_out, ctx.want_x)
+        grad_z0, gw1, gb1, gw2, gb2, grad_x = plan.run_adjoint(out, grad_out, ctx.want_x, weights)
         need = ctx.needs_input_grad
         control_grads = ()
         if ctx.want_x:
@@ -356,12 +400,14 @@ def _mlp_fusable(field, H, C, z0, packed):
 
 class _FusedRK4(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, z0, weight, bias, plan, wants, *control):
+    def forward(ctx, z0, weight, bias, plan, wants, t, knots, *control):
         # `control`: the path's differentiable buffer views (cubic: b, 2c, 3d; linear: the knot values) when the
-        # gradient w.r.t. the coefficients was requested through adjoint_params -- only their gradient slots are used
+        # gradient w.r.t. the coefficients was requested through adjoint_params -- only their gradient slots are used.
+        # `t` / `knots`: the output times / the path's knot times when THEIR gradient is wanted (else None).
         out = plan.run_forward(z0, weight, bias)
         ctx.plan, ctx.wants = plan, wants
-        ctx.save_for_backward(out, weight, bias)
+        ctx.has_t, ctx.has_knots = t is not None, knots is not None
+        ctx.save_for_backward(out, weight, bias, *((t,) if t is not None else ()))
         return out.reshape(*plan.batch, plan.n_out, plan.H)
 
     @staticmethod
@@ -371,19 +417,26 @@ class _FusedRK4(torch.autograd.Function):
             raise NotImplementedError(
                 "torchcde_amd: backpropagating through the solver's internal operations (adjoint=False) is not "
                 "implemented on the native path; use adjoint=True (continuous adjoint, the reference's default).")
-        z_saved, weight, bias = ctx.saved_tensors
+        z_saved, weight, bias, *rest = ctx.saved_tensors
         want_w, want_b, want_x = ctx.wants
-        grad_z0, grad_w, grad_b, grad_x = plan.run_adjoint(z_saved, grad_out, weight, bias, want_x)
+        want_t = ctx.has_t and ctx.needs_input_grad[5]
+        want_knots = ctx.has_knots and ctx.needs_input_grad[6]
+        times = want_t or want_knots
+        grad_z0, grad_w, grad_b, grad_x = plan.run_adjoint(z_saved, grad_out, weight, bias, want_x or times)
+        grad_t = grad_knots = None
+        if times:
+            grad_t, grad_knots = plan.time_gradients(z_saved, grad_out, weight, bias, grad_x, rest[0] if ctx.has_t else None,
+                                                     want_t, want_knots)
         control_grads = ()
         if want_x:
             C = plan.C
             gx = grad_x.reshape(*plan.batch, grad_x.size(-2), grad_x.size(-1))
             pieces = (gx[..., C:2 * C], gx[..., 2 * C:3 * C], gx[..., 3 * C:]) if plan.degree == _lib.PATH_CUBIC else (gx,)
-            control_grads = tuple(g if need else None for g, need in zip(pieces, ctx.needs_input_grad[5:]))
+            control_grads = tuple(g if need else None for g, need in zip(pieces, ctx.needs_input_grad[7:]))
         return (grad_z0.reshape(*plan.batch, plan.H) if ctx.needs_input_grad[0] else None,
                 grad_w.view_as(weight) if (ctx.needs_input_grad[1] and want_w) else None,
                 grad_b.view_as(bias) if (ctx.needs_input_grad[2] and want_b) else None,
-                None, None) + control_grads
+                None, None, grad_t, grad_knots) + control_grads
 
 
 # ------------------------------------------------------------------------------------------ dopri5 (K4)
@@ -629,6 +682,8 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         weight, bias = field.weight, field.bias
         if tuple(weight.shape) != (H * C, H) or not (z0.dtype == packed.dtype == weight.dtype):
             field = None              # not a shape / dtype the fused kernels take: solve it step by step instead
+        elif not _lib.load().cde_rk4_supported(C, H, _lib.dtype_enum(z0.dtype), field.act, int(bool(adjoint)), variant):
+            field = None              # beyond the fused kernels' tiles (LDS / lane limits): step-wise, not a late error
 
     if adjoint and "adjoint_params" not in kwargs:
         for buffer in X.buffers():
@@ -640,24 +695,41 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
     options = kwargs.pop("options", None)
     if method is None:
         method = "dopri5"
-    wants_grad = torch.is_grad_enabled() and (z0.requires_grad or any(
-        p.requires_grad for p in (func.parameters() if isinstance(func, torch.nn.Module) else ())))
-    if not adjoint and torch.is_grad_enabled() and any(b.requires_grad for b in X.buffers()):
+    grad_mode = torch.is_grad_enabled()
+    given_params = kwargs.get("adjoint_params")
+    if given_params is not None:
+        given_params = tuple(given_params)
+    # what must be differentiated: z0, the field's parameters (or the caller's adjoint_params -- which may name the
+    # control's coefficient / knot tensors, README.md:251-270), the output times
+    param_source = given_params if (adjoint and given_params is not None) else (
+        tuple(func.parameters()) if isinstance(func, torch.nn.Module) else ())
+    wants_grad = grad_mode and (z0.requires_grad or any(isinstance(p, torch.Tensor) and p.requires_grad
+                                                        for p in param_source))
+    if not adjoint and grad_mode and any(b.requires_grad for b in X.buffers()):
         wants_grad = True            # backprop through the solver reaches the control: the step-wise path differentiates it
+    wants_t = grad_mode and isinstance(t, torch.Tensor) and t.requires_grad
+    wants_grad = wants_grad or wants_t
+    # gradients w.r.t. the control's tensors or the times come out of the pre-activation MFMA adjoint kernel only
+    control_ids = {b.untyped_storage().data_ptr() for b in X._control_buffers()} | {X._t.untyped_storage().data_ptr()}
+    control_wants = grad_mode and adjoint and given_params is not None and any(
+        isinstance(p, torch.Tensor) and p.requires_grad and p.untyped_storage().data_ptr() in control_ids
+        for p in given_params)
+    mfma_shape = z0.dtype == torch.float32 and H <= 32 and C <= 8 and variant != _lib.VARIANT_GENERIC
     fused = (field is not None and ((method == "rk4" and (adjoint or not wants_grad))
-                                    or (method == "dopri5" and not wants_grad)))
+                                    or (method == "dopri5" and not wants_grad))
+             and not ((wants_t or control_wants) and not (adjoint and mfma_shape)))
     mlp_want_x = False
-    mlp_params_ok = mlp is not None and kwargs.get("adjoint_params") is None
-    if mlp is not None and kwargs.get("adjoint_params") is not None:
+    mlp_params_ok = mlp is not None and given_params is None
+    if mlp is not None and given_params is not None:
         # adjoint_params = all four layer parameters, optionally + the control's coefficient tensor
-        given = tuple(kwargs["adjoint_params"])
         own = (mlp.hidden.weight, mlp.hidden.bias, mlp.output.weight, mlp.output.bias)
         storages = {b.untyped_storage().data_ptr() for b in X._control_buffers()}
-        extra = [p for p in given if not any(p is o for o in own)]
-        mlp_params_ok = (all(any(p is o for p in given) for o in own)
-                         and all(isinstance(p, torch.Tensor) and p.untyped_storage().data_ptr() in storages for p in extra))
-        mlp_want_x = mlp_params_ok and any(p.requires_grad for p in extra) and torch.is_grad_enabled()
-    if (mlp is not None and (wants_grad or mlp_want_x) and adjoint and method == "rk4"
+        extra = [p for p in given_params if not any(p is o for o in own)]
+        mlp_params_ok = (all(any(p is o for p in given_params) for o in own)
+                         and all(isinstance(p, torch.Tensor) and p is not X._t
+                                 and p.untyped_storage().data_ptr() in storages for p in extra))
+        mlp_want_x = mlp_params_ok and any(p.requires_grad for p in extra) and grad_mode
+    if (mlp is not None and wants_grad and not wants_t and adjoint and method == "rk4"
             and variant != _lib.VARIANT_GENERIC
             and set(options or ()) <= {"step_size"} and set(kwargs.get("adjoint_options") or ()) <= {"step_size"}
             and kwargs.get("adjoint_method") in (None, "rk4") and mlp_params_ok
@@ -695,8 +767,6 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         raise ValueError("t must be a one dimensional floating point tensor.")
     if t.numel() < 1:
         raise ValueError("t must contain at least one time.")
-    if t.requires_grad and torch.is_grad_enabled():
-        raise NotImplementedError("torchcde_amd: gradients with respect to the output times are not implemented.")
     t_host = _to_host(t)
     if t_host.numel() > 1 and not bool((t_host[1:] > t_host[:-1]).all()):
         raise NotImplementedError("torchcde_amd: t must be strictly increasing on the native path.")
@@ -723,7 +793,7 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
     adjoint_step = step_size if adjoint_options is None else _parse_fixed_options(adjoint_options, "adjoint")
 
     want_w = want_b = True
-    want_x = False
+    want_x = want_knots = False
     if adjoint_params is not None:
         adjoint_params = tuple(adjoint_params)
         control = X._control_buffers()
@@ -731,20 +801,25 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         for p in adjoint_params:
             if p is weight or p is bias:
                 continue
+            if p is X._t:
+                # the knot times of the control (reference test/test_tricks.py:21-49 passes them): the chain through
+                # `frac = t - t_j` of the spline evaluation
+                want_knots = want_knots or (p.requires_grad and grad_mode)
+                continue
             if isinstance(p, torch.Tensor) and p.untyped_storage().data_ptr() in control_storage:
                 # the coefficient tensor the path was built from (README.md:251-270): dL/dcoeffs flows back to it
                 # through the path's buffer views
-                want_x = want_x or (p.requires_grad and torch.is_grad_enabled())
+                want_x = want_x or (p.requires_grad and grad_mode)
                 continue
             raise NotImplementedError("torchcde_amd: adjoint_params may only contain the vector field's weight and "
-                                      "bias and the control's coefficient tensor on the native path.")
+                                      "bias, the control's coefficient tensor and its knot times on the native path.")
         want_w = any(p is weight for p in adjoint_params)
         want_b = any(p is bias for p in adjoint_params)
-    if want_x and not (adjoint and z0.dtype == torch.float32 and H <= 32 and C <= 8
-                       and variant != _lib.VARIANT_GENERIC):
-        raise NotImplementedError("torchcde_amd: gradients w.r.t. the control need adjoint=True, float32, "
-                                  "hidden_channels <= 32 and input_channels <= 8 (MFMA kernels).")
+    if want_knots and X._degree != _lib.PATH_CUBIC:
+        raise NotImplementedError("torchcde_amd: gradients with respect to the knot times are implemented for "
+                                  "CubicSpline controls only.")
 
     plan = _Plan(X, field, batch, H, C, t, step_size, adjoint_step, adjoint, variant)
     control_inputs = X._control_buffers() if want_x else ()
-    return _FusedRK4.apply(z0, weight, bias, plan, (want_w, want_b, want_x), *control_inputs)
+    return _FusedRK4.apply(z0, weight, bias, plan, (want_w, want_b, want_x), t if wants_t else None,
+                           X._t if want_knots else None, *control_inputs)

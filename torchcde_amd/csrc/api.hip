@@ -5,6 +5,7 @@ namespace cde {
 
 // from rk4_generic.hip
 size_t generic_adjoint_workspace_bytes(int64_t B, int64_t C, int64_t H, size_t elem);
+bool generic_applicable(int64_t C, int64_t H, size_t elem, bool adjoint);
 template <typename T, typename TT>
 int launch_forward_generic(const void*, const void*, int64_t, int, const void*, const void*, int, const void*,
                            const void*, int64_t, const void*, int64_t, void*, int64_t, int64_t, int64_t,
@@ -152,6 +153,16 @@ static int adjoint_typed(const void* coeffs, const void* knots, int64_t n_interv
 }
 
 }  // namespace cde
+
+extern "C" int cde_rk4_supported(int64_t C, int64_t H, int dtype, int act, int adjoint, int variant) {
+  if (C < 1 || H < 1 || (dtype != CDE_F32 && dtype != CDE_F64)) return 0;
+  if (act != CDE_ACT_NONE && act != CDE_ACT_TANH) return 0;
+  int rc;
+  const bool mfma = cde::pick_mfma(variant, C, H, dtype, act, adjoint != 0, &rc);
+  if (rc != CDE_OK) return 0;
+  if (mfma) return 1;
+  return cde::generic_applicable(C, H, dtype == CDE_F64 ? 8 : 4, adjoint != 0) ? 1 : 0;
+}
 
 extern "C" int cde_rk4_forward_linear(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
                                       const void* W, const void* bias, int act, const void* z0, const void* grid,

@@ -225,15 +225,28 @@ __global__ void reduce_partials_kernel(const T* __restrict__ partial, int64_t n_
 }
 
 // ------------------------------------------------------------------------------------------ host side
-static inline int generic_ns(int64_t H) { int ns = (int)(256 / H); return ns < 1 ? 1 : (ns > 16 ? 16 : ns); }
-static inline int64_t generic_blocks(int64_t B, int64_t H) {
-  const int ns = generic_ns(H);
+// series per workgroup tile: at most 256 lanes, at most 16 series, and the tile's LDS (stage state, control slope and
+// -- adjoint -- the H*C dL/dY values per series) within 64 KB; 0 = the shape does not fit at all
+constexpr size_t GENERIC_LDS_LIMIT = 64 * 1024;
+static inline int generic_ns(int64_t H, int64_t C, size_t elem, bool adjoint) {
+  if (H < 1 || H > 256 || C < 1) return 0;
+  int ns = (int)(256 / H);
+  ns = ns > 16 ? 16 : ns;
+  const size_t per_series = (size_t)(adjoint ? H + C + H * C : H + C) * elem;
+  const size_t fit = GENERIC_LDS_LIMIT / per_series;
+  return fit < (size_t)ns ? (int)fit : ns;
+}
+static inline int64_t generic_blocks(int64_t B, int ns) {
   int64_t tiles = (B + ns - 1) / ns;
   return tiles < 1 ? 1 : (tiles > 1024 ? 1024 : tiles);
 }
 
+bool generic_applicable(int64_t C, int64_t H, size_t elem, bool adjoint) { return generic_ns(H, C, elem, adjoint) >= 1; }
+
 size_t generic_adjoint_workspace_bytes(int64_t B, int64_t C, int64_t H, size_t elem) {
-  return (size_t)generic_blocks(B, H) * (size_t)(H * C * H + H * C) * elem;
+  const int ns = generic_ns(H, C, elem, true);
+  if (ns < 1) return 0;
+  return (size_t)generic_blocks(B, ns) * (size_t)(H * C * H + H * C) * elem;
 }
 
 template <typename T, typename TT>
@@ -241,12 +254,12 @@ int launch_forward_generic(const void* coeffs, const void* knots, int64_t n_inte
                            const void* bias, int act, const void* z0, const void* grid, int64_t n_grid,
                            const void* t_out, int64_t n_out, void* z_out, int64_t B, int64_t C, int64_t H,
                            const int64_t* stage_index, const void* stage_frac, hipStream_t s) {
-  if (H > 256) return CDE_ERR_SHAPE;
-  GenericArgs<T> g{(const T*)coeffs, (const T*)knots, n_intervals, (const T*)W, (const T*)bias, act, B, C, H, generic_ns(H)};
+  const int ns = generic_ns(H, C, sizeof(T), false);
+  if (ns < 1) return CDE_ERR_SHAPE;
+  GenericArgs<T> g{(const T*)coeffs, (const T*)knots, n_intervals, (const T*)W, (const T*)bias, act, B, C, H, ns};
   const int nt = ((g.NS * (int)H + 63) / 64) * 64;
   const size_t lds = (size_t)g.NS * (H + C) * sizeof(T);
-  if (lds > 64 * 1024) return CDE_ERR_SHAPE;
-  const unsigned blocks = (unsigned)generic_blocks(B, H);
+  const unsigned blocks = (unsigned)generic_blocks(B, ns);
   if (degree == CDE_PATH_CUBIC)
     rk4_forward_generic<T, TT, CDE_PATH_CUBIC><<<blocks, nt, lds, s>>>(g, (const T*)z0, (const TT*)grid, n_grid, (const TT*)t_out, n_out, (T*)z_out, stage_index, (const T*)stage_frac);
   else if (degree == CDE_PATH_LINEAR)
@@ -262,12 +275,12 @@ int launch_adjoint_generic(const void* coeffs, const void* knots, int64_t n_inte
                            const int64_t* seg_off, int64_t n_out, void* grad_z0, void* grad_W, void* grad_b,
                            int64_t B, int64_t C, int64_t H, const int64_t* stage_index, const void* stage_frac,
                            void* partial_v, hipStream_t s) {
-  if (H > 256) return CDE_ERR_SHAPE;
-  GenericArgs<T> g{(const T*)coeffs, (const T*)knots, n_intervals, (const T*)W, (const T*)bias, act, B, C, H, generic_ns(H)};
+  const int ns = generic_ns(H, C, sizeof(T), true);
+  if (ns < 1) return CDE_ERR_SHAPE;
+  GenericArgs<T> g{(const T*)coeffs, (const T*)knots, n_intervals, (const T*)W, (const T*)bias, act, B, C, H, ns};
   const int nt = ((g.NS * (int)H + 63) / 64) * 64;
   const size_t lds = (size_t)g.NS * (H + C + H * C) * sizeof(T);
-  if (lds > 64 * 1024) return CDE_ERR_SHAPE;
-  const int64_t blocks = generic_blocks(B, H);
+  const int64_t blocks = generic_blocks(B, ns);
   const int64_t P = H * C * H + H * C;
   T* partial = (T*)partial_v;
   if (degree == CDE_PATH_CUBIC)

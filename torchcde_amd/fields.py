@@ -12,10 +12,23 @@ the Linears' inputs and outputs, and the module's result must be BITWISE equal t
 applied to those recordings -- view/reshape never change values, so any other arithmetic (scaling, skip
 connections, time dependence, another activation) fails the comparison and the module is refused (and
 solved step by step) rather than mis-solved.
+
+Value-dependent look-alikes (relu6 == relu while every pre-activation is below 6, hardtanh / clamp == identity
+inside [-1, 1], dropout in eval mode ...) are excluded STRUCTURALLY, not by luck of the probed values: the
+verification runs under a dispatch-mode recorder and refuses the module if it executes any operator outside
+{matrix products, bias add, relu, tanh, pure layout ops}; it is repeated on an input scaled far outside the
+data range and at a second time value.  The verdict is cached per module and re-used only while the module's
+*fingerprint* -- class and ``forward`` function of every submodule (monkey-patching on the class or the
+instance), train/eval flags and every plain Python attribute (e.g. a ``use_tanh`` switch) -- is unchanged.
+What cannot be seen from one evaluation is Python control flow that branches on the VALUES of ``z``; such a
+module must not be handed to the fused path (pass ``variant="generic"``-free step-wise solving by wrapping it
+so that it owns a non-Linear parameter, or simply avoid value-dependent branches: the reference's own
+adjoint also assumes ``func`` is a fixed differentiable map).
 """
 import weakref
 
 import torch
+import torch.utils._python_dispatch
 
 from . import _lib
 
@@ -77,6 +90,37 @@ class LinearCDEFunc(torch.nn.Module):
 
 _verified = weakref.WeakKeyDictionary()   # func -> AffineField, after the two-time probe passed once
 
+# operators a member of the fused families may execute (aten names at dispatch level); anything else -> step-wise
+_ALLOWED_OPS = {
+    "addmm", "mm", "bmm", "matmul", "linear", "add", "relu", "tanh",                      # arithmetic of the families
+    "t", "transpose", "permute", "view", "_unsafe_view", "reshape", "_reshape_alias", "expand", "unsqueeze", "squeeze",
+    "alias", "detach", "clone", "contiguous", "as_strided", "unflatten", "flatten", "select", "slice",   # layout only
+}
+
+
+class _OpRecorder(torch.utils._python_dispatch.TorchDispatchMode):
+    def __init__(self):
+        super().__init__()
+        self.foreign = []
+
+    def __torch_dispatch__(self, op, types, args=(), kwargs=None):
+        name = op.overloadpacket.__name__ if hasattr(op, "overloadpacket") else str(op)
+        if name not in _ALLOWED_OPS:
+            self.foreign.append(name)
+        return op(*args, **(kwargs or {}))
+
+
+def _fingerprint(func):
+    """Everything that can change what ``forward`` computes without touching a parameter value."""
+    if not isinstance(func, torch.nn.Module):
+        return None
+    items = []
+    for name, m in func.named_modules():
+        plain = tuple(sorted((k, v) for k, v in vars(m).items()
+                             if not k.startswith("_") and isinstance(v, (bool, int, float, str, type(None)))))
+        items.append((name, type(m), type(m).forward, vars(m).get("forward"), m.training, plain))
+    return tuple(items)
+
 
 def _linears(func):
     """The module's nn.Linear layers if they hold ALL of its parameters (1 or 2 layers, with bias), else None."""
@@ -94,15 +138,17 @@ def _linears(func):
 
 
 def _evaluate_recording(func, linears, t, z):
+    """(result, recorded Linear calls, names of operators outside the families' whitelist)"""
     calls = []
     handles = [m.register_forward_hook(lambda mod, inp, out: calls.append((mod, inp[0], out))) for m in linears]
+    recorder = _OpRecorder()
     try:
-        with torch.no_grad():
+        with torch.no_grad(), recorder:
             system = func(t, z)
     finally:
         for handle in handles:
             handle.remove()
-    return system, calls
+    return system, calls, recorder.foreign
 
 
 def _final_activation(system, last_out):
@@ -139,40 +185,43 @@ def probe(func, t0, z0):
     """Evaluate ``func(t0, z0)`` once (the compatibility probe the reference performs anyway,
     solver.py:47-53) while watching the module's nn.Linear layers.
 
-    Returns ``(field_or_None, system)``.  The first time a module is seen it is also evaluated at a
-    second time value to establish that it does not depend on ``t``."""
+    Returns ``(field_or_None, system)``.  The first time a module (in its current fingerprint) is seen it is also
+    evaluated at a second time value and on an input far outside the data range."""
     linears = _linears(func)
     if linears is None:
         with torch.no_grad():
             return None, func(t0, z0)
-    # The verified structure is cached per input signature; anything that commonly changes what forward() computes
-    # without changing the parameters -- train/eval mode of any submodule -- is part of the key, so e.g. a Dropout
-    # that was the identity in eval() is probed again (and refused) after train().
-    mode = tuple(m.training for m in func.modules()) if isinstance(func, torch.nn.Module) else ()
-    signature = (tuple(z0.shape), z0.dtype, str(z0.device), mode)
+    signature = (tuple(z0.shape), z0.dtype, str(z0.device), _fingerprint(func))
     try:
         known = _verified.get(func)
     except TypeError:
         known = None
     if known is not None and set(map(id, known.linears)) == set(map(id, linears)) and signature in known.shapes:
-        # Verified before on an input of this very shape/dtype/device: the structural facts (which layer is fed by
-        # z, only relu / reshapes / tanh around them, no time dependence) do not change with the VALUES of z or the
-        # weights, so the compatibility evaluation -- launches plus synchronising comparisons -- is not repeated.
+        # Verified before in this very state (same classes, same forward functions, same flags and plain attributes) on
+        # an input of this shape/dtype/device: the structural facts do not change with the VALUES of z or the weights,
+        # so the compatibility evaluation -- launches plus synchronising comparisons -- is not repeated.
         return known, torch.empty(known.shapes[signature], dtype=z0.dtype, device="meta")
-    system, calls = _evaluate_recording(func, linears, t0, z0)
-    found = _classify(system, calls, z0)
+    system, calls, foreign = _evaluate_recording(func, linears, t0, z0)
+    found = None if foreign else _classify(system, calls, z0)
     if found is None or len(found[2]) != len(linears):
         return None, system
     kind, act, ordered = found
+    # second time value (no time dependence) and an input scaled far outside the data range (saturating look-alikes
+    # of identity / relu / tanh differ there even if they agreed on the data)
+    other_t = t0.detach() + 0.8125
+    system2, calls2, foreign2 = _evaluate_recording(func, linears, other_t, z0)
+    if foreign2 or _classify(system2, calls2, z0) != found or not torch.equal(system2, system):
+        return None, system
+    far = z0.detach() * 37.0 + 11.0
+    system3, calls3, foreign3 = _evaluate_recording(func, linears, t0, far)
+    if foreign3 or _classify(system3, calls3, far) != found:
+        return None, system
     if known is None or known.kind != kind or known.act != act or known.linears != ordered:
-        other_t = t0.detach() + 0.8125
-        system2, calls2 = _evaluate_recording(func, linears, other_t, z0)
-        if _classify(system2, calls2, z0) != found or not torch.equal(system2, system):
-            return None, system
         known = AffineField(ordered[0], act) if kind == "affine" else MLPField(ordered[0], ordered[1], act)
         try:
             _verified[func] = known
         except TypeError:
             pass
+    known.shapes = {k: v for k, v in known.shapes.items() if k[3] == signature[3]}     # drop other fingerprints
     known.shapes[signature] = tuple(system.shape)
     return known, system

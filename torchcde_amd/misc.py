@@ -37,3 +37,6 @@ class TupleControl(torch.nn.Module):
 
     def derivative(self, t):
         return tuple(c.derivative(t) for c in self.controls)
+
+    def _second_derivative(self, t):
+        return tuple(c._second_derivative(t) for c in self.controls)

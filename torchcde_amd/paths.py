@@ -356,6 +356,12 @@ class _NativePath(InterpolationBase):
     def derivative(self, t):
         return self._eval(t, _lib.EVAL_DERIVATIVE)
 
+    def _second_derivative(self, t):
+        """d/dt of ``derivative(t)`` for a scalar ``t`` (what autograd gives the reference through ``frac = t - t_i``,
+        interpolation_cubic.py:331-336; zero for a piecewise-linear control, interpolation_linear.py:222-225).  Used only
+        for gradients with respect to times; a few torch ops on the coefficient buffers, no gradient of its own."""
+        raise NotImplementedError
+
 
 class CubicSpline(_NativePath):
     """Piecewise-cubic control built from packed coefficients (reference interpolation_cubic.py:268-336).
@@ -385,6 +391,12 @@ class CubicSpline(_NativePath):
     def _control_buffers(self):
         """Buffers the control derivative reads (gradient targets for adjoint_params=(..., coeffs))."""
         return (self._b, self._two_c, self._three_d)
+
+    def _second_derivative(self, t):
+        with torch.no_grad():
+            frac, index = self._interpret_t(t)
+            index = index.reshape(())
+            return self._two_c[..., index, :] + 2 * self._three_d[..., index, :] * frac.reshape(())
 
     def _coefficient_buffers(self):
         return (self._a, self._b, self._two_c, self._three_d)
@@ -431,6 +443,9 @@ class LinearInterpolation(_NativePath):
 
     def _coefficient_buffers(self):
         return (self._coeffs,)
+
+    def _second_derivative(self, t):
+        return torch.zeros_like(self._coeffs[..., 0, :])
 
     def _packed(self):
         return self._coeffs

@@ -60,6 +60,15 @@ class ControlledField:
             return self.func.prod(t, z, dX)
         return _Contract.apply(self.func(t, z), dX)
 
+    def time_partial(self, t, z):
+        """The part of d f(t, z)/dt that autograd cannot see here: f depends on t through dX/dt(t), which is a native
+        kernel call on detached times -- f(t, z) with dX/dt replaced by d2X/dt2 (f is linear in the control slope)."""
+        with torch.no_grad():
+            d2X = self.X._second_derivative(t.detach())
+            if hasattr(self.func, "prod"):
+                return self.func.prod(t, z, d2X)
+            return _Contract.apply(self.func(t, z), d2X)
+
 
 # ------------------------------------------------------------------------------------------ helpers
 _NONE, _PREV, _NEXT = 0, 1, 2
@@ -210,9 +219,9 @@ def _solve_dopri5(f, y0, t, rtol, atol, norm, jump_t=None, safety=0.9, ifactor=1
         jumps = torch.sort(jt[jt >= t[0]]).values.tolist()
     i_jump = min(bisect.bisect(jumps, t[0].item()), len(jumps) - 1)
     y, fy, t_lo, t_hi, dense = y0, f0, t[0], t[0], None
-    n = 0
     for i in range(1, len(t)):
         target = t[i]
+        n = 0                                   # torchdiffeq counts max_num_steps per output interval
         while target > t_hi:
             assert n < max_num_steps, "max_num_steps exceeded"
             n += 1
@@ -322,19 +331,31 @@ class _Adjoint(torch.autograd.Function):
         t, y, *params = ctx.saved_tensors
         params = tuple(params)
         with torch.no_grad():
+            need_t = cfg["t_requires_grad"]
             aug = [torch.zeros((), dtype=y.dtype, device=y.device), y[-1], grad_y[-1]]
             aug.extend(torch.zeros_like(p) for p in params)
 
             def dynamics(time, state):
                 yy, aa = state[1], state[2]
                 with torch.enable_grad():
-                    tt = time.detach()
+                    # the "detach trick" (reference test/test_tricks.py:111-131): t joins the graph only when its
+                    # gradient is wanted, so parameter gradients are bitwise the same either way
+                    tt = time.detach().to(yy.dtype)
+                    if need_t:
+                        tt = tt.requires_grad_(True)
                     yy = yy.detach().requires_grad_(True)
-                    fe = func(tt.to(yy.dtype), yy)
-                    vy, *vp = torch.autograd.grad(fe, (yy,) + params, -aa, allow_unused=True)
+                    fe = func(tt, yy)
+                    if need_t:
+                        vt, vy, *vp = torch.autograd.grad(fe, (tt, yy) + params, -aa, allow_unused=True)
+                    else:
+                        vt = None
+                        vy, *vp = torch.autograd.grad(fe, (yy,) + params, -aa, allow_unused=True)
+                vt = torch.zeros_like(state[0]) if vt is None else vt.to(state[0].dtype)
+                if need_t and hasattr(func, "time_partial"):           # d f/dt through the control slope dX/dt(t)
+                    vt = vt - (aa * func.time_partial(tt.detach(), yy.detach())).sum().to(vt.dtype)
                 vy = torch.zeros_like(yy) if vy is None else vy
                 vp = [torch.zeros_like(p) if g is None else g for p, g in zip(params, vp)]
-                return (torch.zeros_like(state[0]), fe, vy, *vp)
+                return (vt, fe, vy, *vp)
 
             adj_options = dict(cfg["adjoint_options"])
             if cfg["adjoint_method"] == "dopri5" and "norm" not in adj_options:
@@ -343,13 +364,22 @@ class _Adjoint(torch.autograd.Function):
                     extra = max([_rms(p) for p in pp]) if pp else 0.0
                     return max(tt.abs(), _rms(yy), _rms(aa), extra)
                 adj_options["norm"] = adjoint_norm
+            time_vjps = [None] * len(t)
             for i in range(len(t) - 1, 0, -1):
+                if need_t:                       # the effect of moving this output time: dL/dt_i = f(t_i, y_i) . dL/dy_i
+                    dldt = (func(t[i].to(y.dtype), y[i]) * grad_y[i]).sum()
+                    aug[0] = aug[0] - dldt
+                    time_vjps[i] = dldt
                 sol = odeint(dynamics, tuple(aug), t[i - 1:i + 1].flip(0), method=cfg["adjoint_method"],
                              options=adj_options, rtol=cfg["adjoint_rtol"], atol=cfg["adjoint_atol"])
                 aug = [s[1] for s in sol]
                 aug[1] = y[i - 1]
                 aug[2] = aug[2] + grad_y[i - 1]
-        return (None, aug[2], None, *aug[3:])
+            grad_t = None
+            if need_t:
+                time_vjps[0] = aug[0]
+                grad_t = torch.stack([v.to(t.dtype) for v in time_vjps]) if len(t) > 1 else torch.zeros_like(t)
+        return (None, aug[2], grad_t, *aug[3:])
 
 
 class TupleField:
@@ -369,6 +399,16 @@ class TupleField:
             out = tuple(_Contract.apply(f, d) for f, d in zip(self.func(t, parts), dX))
         return torch.cat(tuple(out), dim=-1)
 
+    def time_partial(self, t, z):
+        with torch.no_grad():
+            parts = z.split(self.sizes, dim=-1)
+            d2X = self.X._second_derivative(t.detach())
+            if hasattr(self.func, "prod"):
+                out = self.func.prod(t, parts, d2X)
+            else:
+                out = tuple(_Contract.apply(f, d) for f, d in zip(self.func(t, parts), d2X))
+            return torch.cat(tuple(out), dim=-1)
+
 
 def solve(X, func, z0, t, adjoint, method, options, rtol, atol, adjoint_method, adjoint_options, adjoint_rtol,
           adjoint_atol, adjoint_params, field=None):
@@ -383,11 +423,16 @@ def solve(X, func, z0, t, adjoint, method, options, rtol, atol, adjoint_method, 
                                  "parameters then it is allowable to set `adjoint_params=()`.")
             adjoint_params = tuple(func.parameters())
         params = tuple(p for p in adjoint_params if p.requires_grad)
+        knots = getattr(X, "_t", None)
+        if knots is not None and any(p is knots for p in params):
+            raise NotImplementedError("torchcde_amd: gradients with respect to the control's knot times are only "
+                                      "implemented for CubicSpline controls on the fused rk4 path.")
         fixed_opts = {k: v for k, v in (options or {}).items() if k != "norm"}
         cfg = dict(func=field, method=method, options=options, rtol=rtol, atol=atol,
                    adjoint_method=adjoint_method or method,
                    adjoint_options=fixed_opts if adjoint_options is None else dict(adjoint_options),
-                   adjoint_rtol=adjoint_rtol, adjoint_atol=adjoint_atol)
+                   adjoint_rtol=adjoint_rtol, adjoint_atol=adjoint_atol,
+                   t_requires_grad=bool(t.requires_grad and torch.is_grad_enabled()))
         out = _Adjoint.apply(cfg, z0, t, *params)
     else:
         out = odeint(field, z0, t, method=method, options=options, rtol=rtol, atol=atol)
