@@ -422,9 +422,14 @@ class _FusedRK4(torch.autograd.Function):
         want_t = ctx.has_t and ctx.needs_input_grad[5]
         want_knots = ctx.has_knots and ctx.needs_input_grad[6]
         times = want_t or want_knots
-        grad_z0, grad_w, grad_b, grad_x = plan.run_adjoint(z_saved, grad_out, weight, bias, want_x or times)
+        grad_z0, grad_w, grad_b, grad_x = plan.run_adjoint(z_saved, grad_out, weight, bias, want_x)
         grad_t = grad_knots = None
         if times:
+            if grad_x is None:
+                # The time terms come out of the control-gradient sweep.  It is run IN ADDITION to the sweep above, so
+                # that dL/dz0, dL/dW, dL/db are bitwise the same whether or not a time requires grad (the reference's
+                # "detach trick" invariance, test/test_tricks.py:111-131); requesting time gradients is rare.
+                grad_x = plan.run_adjoint(z_saved, grad_out, weight, bias, True)[3]
             grad_t, grad_knots = plan.time_gradients(z_saved, grad_out, weight, bias, grad_x, rest[0] if ctx.has_t else None,
                                                      want_t, want_knots)
         control_grads = ()
