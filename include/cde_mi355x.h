@@ -295,8 +295,9 @@ typedef struct {
 } cde_dopri5_status;
 size_t cde_dopri5_workspace_bytes(int64_t B, int64_t C, int64_t H, int dtype);
 /* The solve's step sequence: the workspace holds, at byte offset cde_dopri5_trace_offset(...), up to
- * CDE_DOPRI5_TRACE_STEPS pairs of float64 (t0, t1), one per ACCEPTED step in order (status.n_accept of them, later
- * steps are not recorded).  torchdiffeq has one controller for the whole batch; shards of a batch solved on
+ * CDE_DOPRI5_TRACE_STEPS triples of float64 (t0, t1, j), one per ACCEPTED step in order (status.n_accept of them,
+ * later steps are not recorded); j = 1.0 when the step was clipped onto a jump time (f is then re-evaluated just
+ * after it), else 0.0.  torchdiffeq has one controller for the whole batch; shards of a batch solved on
  * several GPUs take their own sequences, and this trace is how a caller (or a test replaying the steps through the
  * oracle) sees which. */
 #define CDE_DOPRI5_TRACE_STEPS 4096

@@ -204,11 +204,11 @@ class _Dopri5:
         self.c_mid = torch.tensor(_DP_C_MID, **yd)
         self.n_accept = 0
         self.n_reject = 0
-        self.accepted = []           # (t0, t1) of every accepted step (test infrastructure: compared with the GPU trace)
-        # TEST INFRASTRUCTURE, not a torchdiffeq option: a list / (n, 2) tensor of accepted (t0, t1) steps.  The
+        self.accepted = []           # (t0, t1, on_jump) of every accepted step (test infrastructure: the GPU trace's twin)
+        # TEST INFRASTRUCTURE, not a torchdiffeq option: a list / (n, 3) tensor of accepted (t0, t1, on_jump) steps.  The
         # controller is bypassed and exactly these steps are taken -- used to check a SAMPLE of a large batch against
         # the step sequence the batch-global controller chose for the WHOLE batch (tests/test_gpu_parity.py, config 4).
-        self.replay_steps = None if replay_steps is None else torch.as_tensor(replay_steps, dtype=tdtype).reshape(-1, 2)
+        self.replay_steps = None if replay_steps is None else torch.as_tensor(replay_steps, dtype=tdtype).reshape(-1, 3)
 
     # -- initial step (Hairer), order argument = self.order - 1
     def _initial_step(self, t0, f0):
@@ -287,18 +287,17 @@ class _Dopri5:
         out = torch.empty(len(t), *y0.shape, dtype=y0.dtype, device=y0.device)
         out[0] = y0
         t = t.to(self.tdtype)
-        jumps = set() if self.jump_t is None else set(self.jump_t.tolist())
         y, f = y0, self.f(t[0], y0)
         i = 1
-        for t0, t1 in self.replay_steps:
+        for t0, t1, on_jump in self.replay_steps:
             if i >= len(t):
                 break
             y1, f1, _, k = self._rk_step(y, f, t0, t1 - t0, t1)
             dense = self._fit_dense(y, y1, k, t1 - t0)
-            if t1.item() in jumps:                      # the step landed on a jump: f re-evaluated just after it
+            if on_jump != 0:                            # the step was clipped onto a jump: f re-evaluated just after it
                 f1 = self.f(t1, y1, perturb=_NEXT)
             self.n_accept += 1
-            self.accepted.append((t0.item(), t1.item()))
+            self.accepted.append((t0.item(), t1.item(), float(on_jump)))
             while i < len(t) and not (t[i] > t1):
                 out[i] = self._eval_dense(dense, t0, t1, t[i])
                 i += 1
@@ -363,7 +362,7 @@ class _Dopri5:
                     accept = True
                 if accept:
                     self.n_accept += 1
-                    self.accepted.append((t0.item(), t1.item()))
+                    self.accepted.append((t0.item(), t1.item(), float(on_jump)))
                     dense = self._fit_dense(y, y1, k, dt)
                     if on_step and i_step != len(step_t) - 1:
                         i_step += 1

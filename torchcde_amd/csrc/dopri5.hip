@@ -45,7 +45,7 @@ struct DopriArgs {
   double* partial;              // [2][n_blocks][2], accumulated in float64 whatever the state dtype
   int64_t n_blocks_alloc;
   const T* W1; const T* bias1; int width;      // two-layer fields: the hidden layer (W, bias are then the output layer)
-  double* trace;                // [CDE_DOPRI5_TRACE_STEPS][2]: (t0, t1) of every accepted step, in order
+  double* trace;                // [CDE_DOPRI5_TRACE_STEPS][3]: (t0, t1, clipped onto a jump time) of every accepted step
 };
 
 __device__ __forceinline__ float next_toward(float x, float dir) { return nextafterf(x, x + dir); }
@@ -190,8 +190,9 @@ __device__ __forceinline__ DopriPlan<T> dopri_controller(const DopriArgs<T>& g, 
       c.n_accept++;
       c.t_lo = c.t_hi; c.t_hi = c.t1_try;
       if (g.trace && blockIdx.x == 0 && threadIdx.x == 0 && c.n_accept <= CDE_DOPRI5_TRACE_STEPS) {
-        g.trace[2 * (c.n_accept - 1)] = c.t_lo;                  // the step sequence of the solve (tests replay it
-        g.trace[2 * (c.n_accept - 1) + 1] = c.t_hi;              // through the oracle; sharded runs can compare it)
+        g.trace[3 * (c.n_accept - 1)] = c.t_lo;                  // the step sequence of the solve (tests replay it
+        g.trace[3 * (c.n_accept - 1) + 1] = c.t_hi;              // through the oracle; sharded runs can compare it)
+        g.trace[3 * (c.n_accept - 1) + 2] = c.on_jump ? 1.0 : 0.0;
       }
       c.refresh = 0;
       if (c.on_jump) {
@@ -643,7 +644,7 @@ extern "C" size_t cde_dopri5_trace_offset(int64_t B, int64_t C, int64_t H, int d
 }
 
 extern "C" size_t cde_dopri5_workspace_bytes(int64_t B, int64_t C, int64_t H, int dtype) {
-  return cde_dopri5_trace_offset(B, C, H, dtype) + cde::al256((size_t)CDE_DOPRI5_TRACE_STEPS * 2 * sizeof(double));
+  return cde_dopri5_trace_offset(B, C, H, dtype) + cde::al256((size_t)CDE_DOPRI5_TRACE_STEPS * 3 * sizeof(double));
 }
 
 // W1 == nullptr: one-layer field (W, bias); otherwise W1/bias1/width is the hidden layer and W/bias the output layer
