@@ -77,6 +77,13 @@ const char* cde_error_string(int code);
 int cde_hermite_bdiff_coeffs(const void* x, const void* t, void* coeffs, int64_t B, int64_t L, int64_t C, int dtype,
                              void* stream);
 
+/* K1 with the reference's NaN scan (interpolation_linear.py:169) riding on the fit's own loads: *nan_flag (a zeroed
+ * DEVICE int) is OR-ed with 1 when any value of x is NaN.  The caller then knows -- from 4 bytes instead of a second
+ * pass over x -- whether `coeffs` stands or the missing values must be filled first (cde_linear_fill_missing) and the
+ * fit repeated. */
+int cde_hermite_bdiff_coeffs_checked(const void* x, const void* t, void* coeffs, int64_t B, int64_t L, int64_t C,
+                                     int dtype, int* nan_flag, void* stream);
+
 /* K1 backward: dL/dx (B, L, C) from dL/dcoeffs (B, L-1, 4C) -- what autograd produces through the reference's eager
  * ops at interpolation_hermite_cubic_bdiff.py:5-44 (the fit is linear in x; this is its transpose).  Gradients
  * w.r.t. `t` are not produced. */

@@ -14,16 +14,24 @@ struct Vec {
 // (V = 16 B worth): the IEEE divisions -- the expensive part, they must stay true divisions for bit parity --
 // are shared between the kinds (4 per channel instead of 10), and the knot derivative entering the interval is
 // taken from the lane that owns the previous interval of the same series when that lane is in the same wave.
-// Each of the 4 stores writes V*4-byte pieces; the four together cover whole 4C-float rows, which L2 merges.
 //
 // Arithmetic follows interpolation_hermite_cubic_bdiff.py:39 and :10-18 literally:
 //   secant_i = (x[i+1]-x[i]) / (t[i+1]-t[i])
 //   enter_i  = secant_{i-1}   (enter_0 = secant_0)
 //   two_c    = 2*(3*((x[i+1]-x[i])/h - enter) - secant + enter) / h
 //   three_d  = (1/h**2)*(secant - enter) - two_c/h
-template <typename T, int V>
+// Unit knot spacing (the reference's default t = linspace(0, L-1, L): every h is exactly 1.0): q / 1.0 == q and
+// 1 / (1*1) == 1 in IEEE arithmetic, so the divisions are skipped -- same bits, and the kernel is then a pure stream.
+// Stores: the 64 lanes of a wave own 64 consecutive (interval, channel group) entries = one contiguous span of
+// 256*V output values, but lane by lane the four kinds of a row sit 4C values apart.  The tile goes through a
+// per-wave LDS buffer and leaves as four fully coalesced stores (64 lanes x 16 B contiguous each).
+// CHECK: OR "some input value is NaN" into *nan_flag (the reference scans x for NaNs before fitting,
+// interpolation_linear.py:169; here the scan rides on the loads the fit does anyway).
+template <typename T, int V, bool CHECK>
 __global__ __launch_bounds__(256) void hermite_bdiff_kernel(const T* __restrict__ x, const T* __restrict__ t,
-                                                            T* __restrict__ out, int64_t B, int64_t L, int64_t C) {
+                                                            T* __restrict__ out, int64_t B, int64_t L, int64_t C,
+                                                            int* __restrict__ nan_flag) {
+  __shared__ __attribute__((aligned(16))) T stage[V > 1 ? 4 * 256 * V : 1];
   const int64_t groups = C / V;                       // lanes per interval row
   const int64_t total = B * (L - 1) * groups;
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -37,9 +45,16 @@ __global__ __launch_bounds__(256) void hermite_bdiff_kernel(const T* __restrict_
   const T h = t[i + 1] - t[i];
   const Vec<T, V> lo = *reinterpret_cast<const Vec<T, V>*>(xi);
   const Vec<T, V> hi = *reinterpret_cast<const Vec<T, V>*>(xi + C);
+  if (CHECK) {
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < V; ++k) bad = bad || (lo.v[k] != lo.v[k]) || (hi.v[k] != hi.v[k]);
+    if (__builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(nan_flag, 1);
+  }
+  const bool unit = h == (T)1;
   Vec<T, V> rise, secant;
 #pragma unroll
-  for (int k = 0; k < V; ++k) { rise.v[k] = hi.v[k] - lo.v[k]; secant.v[k] = rise.v[k] / h; }
+  for (int k = 0; k < V; ++k) { rise.v[k] = hi.v[k] - lo.v[k]; secant.v[k] = unit ? rise.v[k] : rise.v[k] / h; }
   // previous interval of the same series lives `groups` lanes below (same wave) unless i == 0
   const int lane = threadIdx.x & 63;
   const bool from_neighbour = groups <= 32 && lane >= (int)groups && i > 0;
@@ -51,19 +66,63 @@ __global__ __launch_bounds__(256) void hermite_bdiff_kernel(const T* __restrict_
       const Vec<T, V> before = *reinterpret_cast<const Vec<T, V>*>(xi - C);
       const T h_prev = t[i] - t[i - 1];
 #pragma unroll
-      for (int k = 0; k < V; ++k) enter.v[k] = (lo.v[k] - before.v[k]) / h_prev;
+      for (int k = 0; k < V; ++k) enter.v[k] = h_prev == (T)1 ? lo.v[k] - before.v[k] : (lo.v[k] - before.v[k]) / h_prev;
     } else {
       enter = secant;
     }
   }
-  if (!live) return;
-  const T inv_h2 = (T)1 / (h * h);
   Vec<T, V> two_c, three_d;
+  if (unit) {
 #pragma unroll
-  for (int k = 0; k < V; ++k) {
-    two_c.v[k] = (T)2 * ((T)3 * (secant.v[k] - enter.v[k]) - secant.v[k] + enter.v[k]) / h;   // rise/h == secant
-    three_d.v[k] = inv_h2 * (secant.v[k] - enter.v[k]) - two_c.v[k] / h;
+    for (int k = 0; k < V; ++k) {
+      two_c.v[k] = (T)2 * ((T)3 * (secant.v[k] - enter.v[k]) - secant.v[k] + enter.v[k]);
+      three_d.v[k] = (secant.v[k] - enter.v[k]) - two_c.v[k];
+    }
+  } else {
+    const T inv_h2 = (T)1 / (h * h);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      two_c.v[k] = (T)2 * ((T)3 * (secant.v[k] - enter.v[k]) - secant.v[k] + enter.v[k]) / h;   // rise/h == secant
+      three_d.v[k] = inv_h2 * (secant.v[k] - enter.v[k]) - two_c.v[k] / h;
+    }
   }
+  if (V == 1) {                                       // narrow / unaligned shapes: direct stores
+    if (!live) return;
+    T* o = out + row * 4 * C + c;
+    o[0] = lo.v[0]; o[C] = enter.v[0]; o[2 * C] = two_c.v[0]; o[3 * C] = three_d.v[0];
+    return;
+  }
+  // stage the wave's tile: value index inside the tile = (row - first row of the wave) * 4C + kind * C + c
+  const int wave = threadIdx.x >> 6;
+  T* tile = stage + wave * 256 * V;
+  const int64_t e0 = e - lane;                        // first entry of this wave
+  const int64_t row0 = e0 / groups;                   // its first row
+  const int64_t rel = (row - row0) * 4 * C + c;       // this lane's kind-0 piece inside the tile
+  if ((64 % groups) == 0) {
+    // whole rows per wave (C*sizeof(T) divides 1 KB): the tile is exactly 256 V contiguous values of `out`
+    if (live) {
+      *reinterpret_cast<Vec<T, V>*>(tile + rel) = lo;
+      *reinterpret_cast<Vec<T, V>*>(tile + rel + C) = enter;
+      *reinterpret_cast<Vec<T, V>*>(tile + rel + 2 * C) = two_c;
+      *reinterpret_cast<Vec<T, V>*>(tile + rel + 3 * C) = three_d;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    T* o = out + row0 * 4 * C;
+    const int64_t limit = (B * (L - 1) - row0) * 4 * C;                  // values of `out` from row0 to the end
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t at = (int64_t)(j * 64 + lane) * V;
+      if (at < limit) {                                                  // written once, never re-read here: streaming store
+        using Raw = __attribute__((ext_vector_type(4))) unsigned;
+        static_assert(sizeof(Vec<T, V>) == 16 || V == 1, "16-byte tiles");
+        __builtin_nontemporal_store(*reinterpret_cast<const Raw*>(tile + at), reinterpret_cast<Raw*>(o + at));
+      }
+    }
+    return;
+  }
+  if (!live) return;
   T* o = out + row * 4 * C + c;
   *reinterpret_cast<Vec<T, V>*>(o) = lo;
   *reinterpret_cast<Vec<T, V>*>(o + C) = enter;
@@ -72,16 +131,20 @@ __global__ __launch_bounds__(256) void hermite_bdiff_kernel(const T* __restrict_
 }
 
 template <typename T>
-static int launch_hermite(const void* x, const void* t, void* out, int64_t B, int64_t L, int64_t C, hipStream_t s) {
+static int launch_hermite(const void* x, const void* t, void* out, int64_t B, int64_t L, int64_t C, int* nan_flag,
+                          hipStream_t s) {
   constexpr int VMAX = 16 / sizeof(T);
   if (B * (L - 1) * C == 0) return CDE_OK;
   const bool aligned = ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0);
   auto grid_for = [](int64_t n) { return (unsigned)((n + 255) / 256); };
+#define CDE_K1(V, CHECK, N)                                                                                         \
+  hermite_bdiff_kernel<T, V, CHECK><<<grid_for(N), 256, 0, s>>>((const T*)x, (const T*)t, (T*)out, B, L, C, nan_flag)
   if (aligned && C % VMAX == 0) {
-    hermite_bdiff_kernel<T, VMAX><<<grid_for(B * (L - 1) * (C / VMAX)), 256, 0, s>>>((const T*)x, (const T*)t, (T*)out, B, L, C);
+    if (nan_flag) CDE_K1(VMAX, true, B * (L - 1) * (C / VMAX)); else CDE_K1(VMAX, false, B * (L - 1) * (C / VMAX));
   } else {
-    hermite_bdiff_kernel<T, 1><<<grid_for(B * (L - 1) * C), 256, 0, s>>>((const T*)x, (const T*)t, (T*)out, B, L, C);
+    if (nan_flag) CDE_K1(1, true, B * (L - 1) * C); else CDE_K1(1, false, B * (L - 1) * C);
   }
+#undef CDE_K1
   return check_launch();
 }
 
@@ -542,8 +605,19 @@ extern "C" int cde_hermite_bdiff_coeffs(const void* x, const void* t, void* coef
   if (B == 0) return CDE_OK;
   if (!x || !t || !coeffs) return CDE_ERR_NULL;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == CDE_F32) return cde::launch_hermite<float>(x, t, coeffs, B, L, C, s);
-  if (dtype == CDE_F64) return cde::launch_hermite<double>(x, t, coeffs, B, L, C, s);
+  if (dtype == CDE_F32) return cde::launch_hermite<float>(x, t, coeffs, B, L, C, nullptr, s);
+  if (dtype == CDE_F64) return cde::launch_hermite<double>(x, t, coeffs, B, L, C, nullptr, s);
+  return CDE_ERR_DTYPE;
+}
+
+extern "C" int cde_hermite_bdiff_coeffs_checked(const void* x, const void* t, void* coeffs, int64_t B, int64_t L,
+                                                int64_t C, int dtype, int* nan_flag, void* stream) {
+  if (B < 0 || L < 2 || C < 1) return CDE_ERR_SHAPE;
+  if (B == 0) return CDE_OK;
+  if (!x || !t || !coeffs || !nan_flag) return CDE_ERR_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CDE_F32) return cde::launch_hermite<float>(x, t, coeffs, B, L, C, nan_flag, s);
+  if (dtype == CDE_F64) return cde::launch_hermite<double>(x, t, coeffs, B, L, C, nan_flag, s);
   return CDE_ERR_DTYPE;
 }
 

@@ -233,27 +233,34 @@ def hermite_cubic_coefficients_with_backward_differences(x, t=None):
     Same contract as reference interpolation_hermite_cubic_bdiff.py:23-44; computed by K1
     (``cde_hermite_bdiff_coeffs``) in one pass over ``x``.  Differentiable w.r.t. ``x`` (data without missing
     values), like the reference's eager ops; not w.r.t. ``t``."""
-    coeffs = linear_interpolation_coeffs(x, t=t, rectilinear=None)
-    _no_grad_through_path(t)
-    if torch.is_grad_enabled() and coeffs.requires_grad:
+    if torch.is_grad_enabled() and x.requires_grad:
+        coeffs = linear_interpolation_coeffs(x, t=t, rectilinear=None)
+        _no_grad_through_path(t)
         knots = (torch.linspace(0, coeffs.size(-2) - 1, coeffs.size(-2), dtype=coeffs.dtype, device=coeffs.device)
                  if t is None else t.detach().to(device=coeffs.device, dtype=coeffs.dtype)).contiguous()
         return _HermiteFit.apply(coeffs, knots)
-    if t is None:
-        t = torch.linspace(0, coeffs.size(-2) - 1, coeffs.size(-2), dtype=coeffs.dtype, device=coeffs.device)
-    else:
-        t = t.to(device=coeffs.device, dtype=coeffs.dtype)
-    L, C = coeffs.size(-2), coeffs.size(-1)
-    batch = coeffs.shape[:-2]
-    B = 1
-    for b in batch:
-        B *= b
-    src = coeffs.detach().contiguous()
-    out = torch.empty(*batch, L - 1, 4 * C, dtype=coeffs.dtype, device=coeffs.device)
+    # No gradient wanted: the reference's NaN scan (linear_interpolation_coeffs, interpolation_linear.py:169) rides on
+    # the fit itself -- K1 reads every value anyway and raises a device flag; only if it is set are the gaps filled
+    # (K0) and the fit repeated.  One 4-byte read-back instead of a second pass over x.
+    knots = _validate_input_path(x, t)
+    _lib.require_gpu(x, "x")
+    _no_grad_through_path(t)
+    knots = knots.detach().to(device=x.device, dtype=x.dtype).contiguous()
+    L, C = x.size(-2), x.size(-1)
+    batch = x.shape[:-2]
+    src = x.detach().contiguous()
+    B = src.numel() // (L * C)
+    out = torch.empty(*batch, L - 1, 4 * C, dtype=x.dtype, device=x.device)
+    flag = torch.zeros(1, dtype=torch.int32, device=x.device)
     lib = _lib.load()
-    _lib.check(lib.cde_hermite_bdiff_coeffs(_lib.ptr(src), _lib.ptr(t.contiguous()), _lib.ptr(out), B, L, C,
-                                            _lib.dtype_enum(coeffs.dtype), _lib.stream_ptr(coeffs.device)),
-               "cde_hermite_bdiff_coeffs")
+    _lib.check(lib.cde_hermite_bdiff_coeffs_checked(_lib.ptr(src), _lib.ptr(knots), _lib.ptr(out), B, L, C,
+                                                    _lib.dtype_enum(x.dtype), _lib.ptr(flag),
+                                                    _lib.stream_ptr(x.device)), "cde_hermite_bdiff_coeffs_checked")
+    if flag.item():                                    # irregular data: fill, then fit the filled series
+        filled = linear_interpolation_coeffs(x, t=t, rectilinear=None)
+        _lib.check(lib.cde_hermite_bdiff_coeffs(_lib.ptr(filled.contiguous()), _lib.ptr(knots), _lib.ptr(out), B, L, C,
+                                                _lib.dtype_enum(x.dtype), _lib.stream_ptr(x.device)),
+                   "cde_hermite_bdiff_coeffs")
     return out
 
 
