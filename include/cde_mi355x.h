@@ -316,6 +316,32 @@ int cde_dopri5_advance(const void* coeffs, const void* knots, int64_t n_interval
                        int variant, void* workspace, size_t workspace_bytes, int64_t first_launch,
                        int64_t n_launches, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * K4a  Backward of the adaptive solve: torchdiffeq.odeint_adjoint(method='dopri5') behind reference solver.py:226,
+ * i.e. loss.backward() through torchcde's DEFAULT call cdeint(X, func, z0, t) (adjoint=True, no method).
+ * f32, H <= 32, C <= 8, identity or tanh.  The host walks the output intervals from the last to the first; for
+ * interval [t_{i-1}, t_i] it passes the reversed-time bounds s0 = -t_i < s1 = -t_{i-1}, the jump times negated and
+ * ascending, y_init = z(t_i) (B, H) as stored by the forward solve and a_init = dL/dz(t_i) accumulated so far, and
+ * calls cde_dopri5_adjoint_advance with first_launch = 0, n, 2n, ... until the cde_dopri5_status at the head of the
+ * workspace (index total_launches & 1) reports phase == 4; a_out (B, H) then holds dL/dz(t_{i-1}) before the
+ * incoming gradient of that output time is added.  first_interval != 0 zeroes the running parameter gradients;
+ * after the last interval cde_dopri5_adjoint_finish writes grad_W (H*C, H) and grad_b (H*C).
+ * The accepted steps of the CURRENT interval are traced like K4's, at cde_dopri5_adjoint_trace_offset(...).
+ * Two stated deviations from torchdiffeq (csrc/dopri5_adjoint.hip): the error norm is max(rms over y, rms over a)
+ * (torchdiffeq's "seminorm": the parameter-gradient blocks are not part of it), and the last step of an interval is
+ * clipped onto the interval end instead of overshooting and interpolating.
+ * ------------------------------------------------------------------------------------------- */
+size_t cde_dopri5_adjoint_workspace_bytes(int64_t B, int64_t C, int64_t H);
+size_t cde_dopri5_adjoint_trace_offset(int64_t B, int64_t C, int64_t H);
+int cde_dopri5_adjoint_advance(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
+                               const void* bias, int act, const void* y_init, const void* a_init, double s0, double s1,
+                               const double* jump_s, int64_t n_jump, double rtol, double atol, double safety,
+                               double ifactor, double dfactor, void* a_out, int64_t B, int64_t C, int64_t H, int dtype,
+                               int first_interval, void* workspace, size_t workspace_bytes, int64_t first_launch,
+                               int64_t n_launches, void* stream);
+int cde_dopri5_adjoint_finish(const void* workspace, size_t workspace_bytes, void* grad_W, void* grad_b, int64_t B,
+                              int64_t C, int64_t H, void* stream);
+
 /* K4 for the two-layer field of K2m (W1/bias1/width = hidden layer, W2/bias2 = output layer); f32, H <= 32,
  * C <= 8, width <= 128.  Same protocol, workspace (cde_dopri5_workspace_bytes) and status block as
  * cde_dopri5_advance. */

@@ -14,13 +14,15 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libcde_mi355x.so")
 SOURCES = ["interp_kernels.hip", "rk4_generic.hip", "rk4_mfma.hip", "rk4_split.hip", "rk4_mlp_adjoint.hip", "dopri5.hip",
-           "api.hip"]
-HEADERS = [os.path.join(_CSRC, "cde_common.h"), os.path.join(_CSRC, "cde_mfma.h"),
+           "dopri5_adjoint.hip", "api.hip"]
+HEADERS = [os.path.join(_CSRC, "cde_common.h"), os.path.join(_CSRC, "cde_mfma.h"), os.path.join(_CSRC, "cde_split.h"),
+           os.path.join(_CSRC, "cde_dopri.h"),
            os.path.join(_HERE, "..", "include", "cde_mi355x.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC"]
 # per-file additions.  rk4_split.hip: keep MFMA accumulators in VGPRs -- its tiles are consumed by VALU code right
 # away, and on gfx950 every v_accvgpr_read costs matrix-pipe time (f32 MFMA and VALU do not overlap within a wave).
-EXTRA_FLAGS = {"rk4_split.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+EXTRA_FLAGS = {"rk4_split.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+               "dopri5_adjoint.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 F32, F64 = 0, 1
 PATH_LINEAR, PATH_CUBIC = 1, 3
@@ -99,6 +101,11 @@ _SIGNATURES = {
                                 _i64, _i, _i, _p, _sz, _i64, _i64, _p]),
     "cde_dopri5_advance_mlp": (_i, [_p, _p, _i64, _i, _p, _p, _i64, _p, _p, _i, _p, _p, _i64, _p, _i64, _d, _d, _d, _d, _d,
                                     _p, _i64, _i64, _i64, _i, _p, _sz, _i64, _i64, _p]),
+    "cde_dopri5_adjoint_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "cde_dopri5_adjoint_trace_offset": (_sz, [_i64, _i64, _i64]),
+    "cde_dopri5_adjoint_advance": (_i, [_p, _p, _i64, _i, _p, _p, _i, _p, _p, _d, _d, _p, _i64, _d, _d, _d, _d, _d, _p,
+                                        _i64, _i64, _i64, _i, _i, _p, _sz, _i64, _i64, _p]),
+    "cde_dopri5_adjoint_finish": (_i, [_p, _sz, _p, _p, _i64, _i64, _i64, _p]),
     "cde_rk4_adjoint_mlp_workspace_bytes": (_sz, [_i64]),
     "cde_rk4_adjoint_mlp_prepare": (_i, [_p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _i64, _i64, _i, _i, _p, _sz, _p]),
     "cde_rk4_adjoint_mlp_sweep": (_i, [_p, _p, _i64, _i, _i, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _i64,

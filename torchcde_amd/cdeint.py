@@ -446,13 +446,17 @@ class _FusedRK4(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------ dopri5 (K4)
 last_dopri5_stats = {}     # {"n_accept", "n_reject", "launches"} of the most recent adaptive solve (for tests / logging)
+last_dopri5_adjoint_stats = {}   # the same for the most recent fused adaptive backward (summed over the output intervals)
 record_dopri5_steps = False   # tests: also fetch the accepted (t0, t1, on_jump) steps into last_dopri5_stats["steps"]
 _DOPRI_CHUNK = 48          # attempt kernels queued between two looks at the done flag
 
 
 class _Dopri5Plan:
-    def __init__(self, path, field, batch, H, C, t, rtol, atol, options, variant=_lib.VARIANT_AUTO):
+    def __init__(self, path, field, batch, H, C, t, rtol, atol, options, variant=_lib.VARIANT_AUTO,
+                 adjoint_rtol=None, adjoint_atol=None):
         self.variant = variant
+        self.adjoint_rtol = float(rtol if adjoint_rtol is None else adjoint_rtol)
+        self.adjoint_atol = float(atol if adjoint_atol is None else adjoint_atol)
         options = {} if options is None else dict(options)
         jump_t = options.pop("jump_t", None)
         self.safety = float(options.pop("safety", 0.9))
@@ -474,13 +478,70 @@ class _Dopri5Plan:
         self.atol = float(atol)
         t_host = _to_host(t).to(torch.float64)
         self.n_out = t_host.numel()
+        self.t_host = t_host
         self.t_out = t_host.to(self.device)
         if jump_t is None:
-            self.jump_t, self.n_jump = None, 0
+            self.jump_t, self.n_jump, self.jump_s = None, 0, None
         else:
             jt = _to_host(torch.as_tensor(jump_t)).to(torch.float64).reshape(-1)
             jt = torch.sort(jt).values
             self.jump_t, self.n_jump = jt.to(self.device), jt.numel()
+            self.jump_s = (-jt).flip(0).contiguous().to(self.device)      # the backward solve runs in s = -t
+
+    def run_adjoint(self, z_saved, grad_out, weight, bias):
+        """K4a: torchdiffeq's odeint_adjoint backward for the adaptive solve, one attempt kernel per attempted step
+        (csrc/dopri5_adjoint.hip), output intervals from the last to the first."""
+        lib = _lib.load()
+        B, H, C, dev = self.B, self.H, self.C, self.device
+        z_saved = z_saved.detach().reshape(B, self.n_out, H)
+        grad_out = grad_out.detach().reshape(B, self.n_out, H).to(torch.float32)
+        w, b = weight.detach().contiguous(), bias.detach().contiguous()
+        n_w = H * C * H
+        flat = torch.zeros(n_w + H * C, dtype=torch.float32, device=dev)       # one buffer: a single all-reduce upstream
+        grad_w, grad_b = flat[:n_w].view(H * C, H), flat[n_w:]
+        a = grad_out[:, -1].contiguous()
+        if self.n_out == 1:
+            return a, grad_w, grad_b
+        nbytes = lib.cde_dopri5_adjoint_workspace_bytes(B, C, H)
+        workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        size = ctypes.sizeof(_lib.DopriStatus)
+        a_out = torch.empty(B, H, dtype=torch.float32, device=dev)
+        stats = dict(n_accept=0, n_reject=0, launches=0)
+        steps = []
+        for i in range(self.n_out - 1, 0, -1):
+            y = z_saved[:, i].contiguous()
+            s0, s1 = -float(self.t_host[i]), -float(self.t_host[i - 1])
+            launched = 0
+            while True:
+                _lib.check(lib.cde_dopri5_adjoint_advance(
+                    _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w), _lib.ptr(b),
+                    self.act, _lib.ptr(y), _lib.ptr(a), s0, s1, _lib.ptr(self.jump_s), self.n_jump, self.adjoint_rtol,
+                    self.adjoint_atol, self.safety, self.ifactor, self.dfactor, _lib.ptr(a_out), B, C, H,
+                    _lib.dtype_enum(torch.float32), int(i == self.n_out - 1), _lib.ptr(workspace), workspace.numel(),
+                    launched, _DOPRI_CHUNK, _lib.stream_ptr(dev)), "cde_dopri5_adjoint_advance")
+                launched += _DOPRI_CHUNK
+                raw = workspace[(launched & 1) * size:(launched & 1) * size + size].cpu().numpy().tobytes()
+                status = _lib.DopriStatus.from_buffer_copy(raw)
+                if status.phase == 4:
+                    break
+                if launched > 2_000_000:
+                    raise RuntimeError("torchcde_amd: the dopri5 adjoint did not reach t = %g after %d attempted steps"
+                                       % (-s1, launched))
+            stats["n_accept"] += status.n_accept
+            stats["n_reject"] += status.n_reject
+            stats["launches"] += launched
+            if record_dopri5_steps:
+                off = lib.cde_dopri5_adjoint_trace_offset(B, C, H)
+                n = min(status.n_accept, 4096)
+                steps.append(workspace[off:off + 24 * n].view(torch.float64).view(n, 3).cpu())
+            a = a_out + grad_out[:, i - 1]
+        _lib.check(lib.cde_dopri5_adjoint_finish(_lib.ptr(workspace), workspace.numel(), _lib.ptr(grad_w), _lib.ptr(grad_b),
+                                                 B, C, H, _lib.stream_ptr(dev)), "cde_dopri5_adjoint_finish")
+        last_dopri5_adjoint_stats.clear()
+        last_dopri5_adjoint_stats.update(stats)
+        if record_dopri5_steps:
+            last_dopri5_adjoint_stats["steps"] = steps           # one (n, 3) tensor per output interval, last first
+        return a, grad_w, grad_b
 
     def run(self, z0, weight, bias):
         lib = _lib.load()
@@ -531,14 +592,21 @@ class _Dopri5Plan:
 
 class _FusedDopri5(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, z0, weight, bias, plan):
+    def forward(ctx, z0, weight, bias, plan, wants):
         out = plan.run(z0, weight, bias)
+        ctx.plan, ctx.wants = plan, wants
+        ctx.save_for_backward(out, weight, bias)
         return out.reshape(*plan.batch, plan.n_out, plan.H)
 
     @staticmethod
     def backward(ctx, grad_out):
-        raise NotImplementedError("torchcde_amd: gradients through the adaptive dopri5 solve are not implemented on "
-                                  "the native path yet; use method='rk4' for training or run dopri5 under no_grad.")
+        plan = ctx.plan
+        out, weight, bias = ctx.saved_tensors
+        grad_z0, grad_w, grad_b = plan.run_adjoint(out, grad_out, weight, bias)
+        want_w, want_b = ctx.wants
+        return (grad_z0.reshape(*plan.batch, plan.H) if ctx.needs_input_grad[0] else None,
+                grad_w.view_as(weight) if (ctx.needs_input_grad[1] and want_w) else None,
+                grad_b.view_as(bias) if (ctx.needs_input_grad[2] and want_b) else None, None, None)
 
 
 # ------------------------------------------------------------------------------------------ front end
@@ -720,8 +788,14 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         isinstance(p, torch.Tensor) and p.requires_grad and p.untyped_storage().data_ptr() in control_ids
         for p in given_params)
     mfma_shape = z0.dtype == torch.float32 and H <= 32 and C <= 8 and variant != _lib.VARIANT_GENERIC
+    # the adaptive backward (K4a): affine family on the MFMA tiles, adjoint solver = forward solver with the same
+    # options (the reference's default: solver.py:199-203 only copies the tolerances), parameters of the field only
+    dopri_adjoint = (method == "dopri5" and adjoint and wants_grad and not wants_t and not control_wants and mfma_shape
+                     and field is not None and kwargs.get("adjoint_method") in (None, "dopri5")
+                     and kwargs.get("adjoint_options") is None and set(options or ()) <= {"jump_t", "safety", "ifactor", "dfactor"}
+                     and (given_params is None or all(p is field.weight or p is field.bias for p in given_params)))
     fused = (field is not None and ((method == "rk4" and (adjoint or not wants_grad))
-                                    or (method == "dopri5" and not wants_grad))
+                                    or (method == "dopri5" and (not wants_grad or dopri_adjoint)))
              and not ((wants_t or control_wants) and not (adjoint and mfma_shape)))
     mlp_want_x = False
     mlp_params_ok = mlp is not None and given_params is None
@@ -776,15 +850,16 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
     if t_host.numel() > 1 and not bool((t_host[1:] > t_host[:-1]).all()):
         raise NotImplementedError("torchcde_amd: t must be strictly increasing on the native path.")
     if method == "dopri5":
-        for key in ("adjoint_method", "adjoint_options", "adjoint_params"):
+        for key in ("adjoint_method", "adjoint_options"):
             kwargs.pop(key, None)
+        given = kwargs.pop("adjoint_params", None)
         rtol, atol = kwargs.pop("rtol"), kwargs.pop("atol")
-        for key in ("adjoint_atol", "adjoint_rtol"):
-            kwargs.pop(key, None)
+        adjoint_rtol, adjoint_atol = kwargs.pop("adjoint_rtol", None), kwargs.pop("adjoint_atol", None)
         if kwargs:
             raise NotImplementedError("torchcde_amd: unsupported cdeint keyword arguments {}".format(sorted(kwargs)))
-        plan = _Dopri5Plan(X, field, batch, H, C, t, rtol, atol, options, variant)
-        return _FusedDopri5.apply(z0, weight, bias, plan)
+        plan = _Dopri5Plan(X, field, batch, H, C, t, rtol, atol, options, variant, adjoint_rtol, adjoint_atol)
+        wants = (True, True) if given is None else (any(p is weight for p in given), any(p is bias for p in given))
+        return _FusedDopri5.apply(z0, weight, bias, plan, wants)
     step_size = _parse_fixed_options(options, "solver")
     adjoint_method = kwargs.pop("adjoint_method", None)
     adjoint_options = kwargs.pop("adjoint_options", None)

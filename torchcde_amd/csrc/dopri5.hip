@@ -16,21 +16,9 @@
 // is bit-identical in every workgroup and run-to-run), commits its series' state, emits any outputs the accepted
 // step covered, and then runs the 6 new stages.  The controller state ping-pongs between two structs.  The host
 // only queues launches and looks at a done flag every few dozen of them.
-#include "cde_mfma.h"
+#include "cde_dopri.h"
 
 namespace cde {
-
-struct DopriCtrl {
-  double t_lo, t_hi, dt;        // dense-output interval of the last accepted step, next step size
-  double t1_try, dt_try;        // the attempt whose partial sums are pending
-  double h0;                    // Hairer initial step, phase 1 -> 2
-  int64_t i_out, i_jump;        // next output index, next jump index
-  int64_t n_accept, n_reject;
-  int32_t phase;                // 0 start, 1 after f0 norms, 2 after f1 norm, 3 stepping, 4 done
-  int32_t on_jump;              // pending attempt was clipped to a jump time
-  int32_t refresh;              // k0 must be recomputed just after t_hi (we stepped onto a jump)
-  int32_t pad;
-};
 
 template <typename T>
 struct DopriArgs {
@@ -47,25 +35,6 @@ struct DopriArgs {
   const T* W1; const T* bias1; int width;      // two-layer fields: the hidden layer (W, bias are then the output layer)
   double* trace;                // [CDE_DOPRI5_TRACE_STEPS][3]: (t0, t1, clipped onto a jump time) of every accepted step
 };
-
-__device__ __forceinline__ float next_toward(float x, float dir) { return nextafterf(x, x + dir); }
-__device__ __forceinline__ double next_toward(double x, double dir) { return nextafter(x, x + dir); }
-
-// Dormand-Prince tableau (identical numbers to oracle/odeint.py)
-__device__ constexpr double DP_ALPHA[6] = {1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1.0, 1.0};
-__device__ constexpr double DP_BETA[6][6] = {
-    {1.0 / 5, 0, 0, 0, 0, 0},
-    {3.0 / 40, 9.0 / 40, 0, 0, 0, 0},
-    {44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0, 0},
-    {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0, 0},
-    {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656, 0},
-    {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84}};
-__device__ constexpr double DP_CERR[7] = {35.0 / 384 - 1951.0 / 21600, 0, 500.0 / 1113 - 22642.0 / 50085,
-                                          125.0 / 192 - 451.0 / 720, -2187.0 / 6784 - -12231.0 / 42400,
-                                          11.0 / 84 - 649.0 / 6300, -1.0 / 60};
-__device__ constexpr double DP_CMID[7] = {6025192743.0 / 30085553152.0 / 2, 0, 51252292925.0 / 65400821598.0 / 2,
-                                          -2691868925.0 / 45128329728.0 / 2, 187940372067.0 / 1594534317056.0 / 2,
-                                          -1776094331.0 / 19743644256.0 / 2, 11237099.0 / 235043384.0 / 2};
 
 // vector field row for lane (s,h): sum_c act(bias + W z) dX_c, control derivative at time ts
 template <typename T>

@@ -27,43 +27,9 @@
 // On gfx950 f32 MFMA and VALU instructions of a wave do not overlap (scripts/ubench/mfma_issue.hip): instruction count
 // is time, hence packed VALU, VGPR-form MFMA (no v_accvgpr moves; -mllvm -amdgpu-mfma-vgpr-form for this file) and
 // the control derivative computed once per tile and stage.
-#include "cde_mfma.h"
+#include "cde_split.h"
 
 namespace cde {
-
-constexpr int SPL_ZROW = 36;                  // stage-state buffer: 32 units + 4 pad floats per series
-constexpr int SPL_ZBUF = 16 * SPL_ZROW;
-constexpr int SPL_TROW = 20;                  // transposed tiles: 16 series + 4 pad floats per row
-constexpr int SPL_ZT = 32 * SPL_TROW;
-constexpr int SPL_VROW = 12;                  // va partials: [w_dst][q][n][w_src*2 + j], 8 + 4 pad floats per lane
-constexpr int SPL_VA = 4 * 64 * SPL_VROW;     //   (n fastest: conflict-free b64 writes per 16-lane group and b128 reads)
-constexpr int SPL_DXROW = 12;                 // shared control derivative: [series][8 channels + 4 pad]
-constexpr int SPL_DX = 16 * SPL_DXROW;
-constexpr int SPL_GT = 64 * SPL_TROW;         // per wave: transposed weighted dL/dY tile (64 rows)
-constexpr int64_t SPL_PARTIAL_FLOATS = MH * MC * MH + MH * MC;     // == PARTIAL_FLOATS of rk4_mfma.hip
-
-// position of series n inside a transposed row: MFMA K step s, quarter kq <-> series 4s + kq is read as float4[kq][s]
-__device__ __forceinline__ int spl_pos(int n) { return (n & 3) * 4 + (n >> 2); }
-
-// Y-tile A image and bias of wave w (registers)
-__device__ __forceinline__ void spl_load_wy(const float* __restrict__ W, const float* __restrict__ bias, int w, int n,
-                                            int q, Dims d, float (&wy)[4][8], f32x4 (&by)[4]) {
-#pragma unroll
-  for (int T = 0; T < 4; ++T) {
-    const int hA = 8 * w + 4 * (T >> 1) + (n >> 2), cA = 4 * (T & 1) + (n & 3);
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const int k = 4 * s + q;
-      wy[T][s] = (hA < d.H && cA < d.C && k < d.H) ? W[(hA * d.C + cA) * d.H + k] : 0.f;
-    }
-    const int hD = 8 * w + 4 * (T >> 1) + q;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int cD = 4 * (T & 1) + r;
-      by[T][r] = (hD < d.H && cD < d.C) ? bias[hD * d.C + cD] : 0.f;
-    }
-  }
-}
 
 // ---------------------------------------------------------------------------------------------- control feed
 // dX/dt of the tile's 16 series is produced ONCE per stage and shared through LDS (dxb[series][channel]) instead of
@@ -288,9 +254,6 @@ __global__ __launch_bounds__(256, 2) void rk4_forward_split(
   }
 }
 
-template <int ACT>
-__device__ __forceinline__ float spl_slope(float t) { return ACT == CDE_ACT_TANH ? __builtin_fmaf(-t, t, 1.f) : 1.f; }
-
 // ============================================================================================ adjoint
 // Eight waves per tile, two per SIMD, with different ROLES (waves i and i + 4 of a workgroup share a SIMD):
 //   chain wave w  (0..3): the sequential part -- Y tiles, f, g, y-/a-path RK updates, va partials: 64 MFMAs per stage
@@ -301,10 +264,6 @@ __device__ __forceinline__ float spl_slope(float t) { return ACT == CDE_ACT_TANH
 // this kernel that did all three products itself: the matrix pipe idled 35 % of the time at one tile per CU, 1.04 ms
 // at B = 4096 against 0.87 ms here); the helper's MFMA chain runs in exactly those gaps.
 constexpr int SPL8_LDS_FLOATS = 2 * SPL_ZBUF + 2 * SPL_ZT + 2 * SPL_VA + 2 * SPL_DX + 2 * 4 * SPL_GT;
-
-__device__ __forceinline__ void spl_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
 
 template <typename TT, int DEGREE, int ACT>
 __global__ __launch_bounds__(512, 1) void rk4_adjoint_split8(
@@ -416,16 +375,7 @@ __global__ __launch_bounds__(512, 1) void rk4_adjoint_split8(
   float wy[4][8], wv[2][16];
   f32x4 by[4];
   spl_load_wy(W, bias, w, n, q, dims, wy, by);
-#pragma unroll
-  for (int T = 0; T < 2; ++T) {
-    const int qi = n >> 2, r = n & 3;
-    const int k_out = 8 * (2 * T + (r >> 1)) + 4 * (r & 1) + qi;
-#pragma unroll
-    for (int sp = 0; sp < 16; ++sp) {
-      const int h = 8 * w + 4 * (sp >> 3) + q, c = sp & 7;
-      wv[T][sp] = (h < Hr && c < Cr && k_out < Hr) ? W[(h * Cr + c) * Hr + k_out] : 0.f;
-    }
-  }
+  spl_load_wv(W, w, n, q, dims, wv);
   const int ua = 8 * w + q, ub = ua + 4;
   const int pos = spl_pos(n);
   auto saved = [&](int64_t j, int u) { return u < Hr ? z_saved[(sc * n_out + j) * Hr + u] : 0.f; };
