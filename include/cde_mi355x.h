@@ -338,9 +338,27 @@ int cde_dopri5_adjoint_advance(const void* coeffs, const void* knots, int64_t n_
                                const double* jump_s, int64_t n_jump, double rtol, double atol, double safety,
                                double ifactor, double dfactor, void* a_out, int64_t B, int64_t C, int64_t H, int dtype,
                                int first_interval, void* workspace, size_t workspace_bytes, int64_t first_launch,
-                               int64_t n_launches, void* stream);
+                               int64_t n_launches, const double* reduced_sums, int64_t B_global, void* stream);
+/* sharded batches, one controller: reduced_sums (4 doubles, all-reduced output of cde_dopri5_adjoint_pending_sums) and
+ * the global batch size, n_launches == 1 per all-reduce; NULL / 0 for an unsharded solve. */
+int cde_dopri5_adjoint_pending_sums(const void* workspace, size_t workspace_bytes, int64_t B, int64_t C, int64_t H,
+                                    int64_t total_launches, double* sums, void* stream);
 int cde_dopri5_adjoint_finish(const void* workspace, size_t workspace_bytes, void* grad_W, void* grad_b, int64_t B,
                               int64_t C, int64_t H, void* stream);
+
+/* Sharded batches under ONE step controller -- torchdiffeq's semantics for the whole batch when the batch lives on
+ * several GPUs.  Per attempted step every shard (1) calls cde_dopri5_pending_sums(total_launches so far) -> 2 doubles on
+ * the device, (2) all-reduces them (sum) with the other shards, (3) runs ONE launch through cde_dopri5_advance_sharded
+ * with the reduced sums and the global number of series.  All shards then take bit-identical decisions and the same
+ * (t0, t1) sequence; without this every shard runs its own controller (a valid solve, different steps). */
+int cde_dopri5_pending_sums(const void* workspace, size_t workspace_bytes, int64_t B, int64_t C, int64_t H, int dtype,
+                            int variant, int act, int64_t total_launches, double* sums, void* stream);
+int cde_dopri5_advance_sharded(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
+                               const void* bias, int act, const void* z0, const double* t_out, int64_t n_out,
+                               const double* jump_t, int64_t n_jump, double rtol, double atol, double safety,
+                               double ifactor, double dfactor, void* z_out, int64_t B, int64_t C, int64_t H, int dtype,
+                               int variant, void* workspace, size_t workspace_bytes, int64_t first_launch,
+                               const double* reduced_sums, int64_t B_global, void* stream);
 
 /* K4 for the two-layer field of K2m (W1/bias1/width = hidden layer, W2/bias2 = output layer); f32, H <= 32,
  * C <= 8, width <= 128.  Same protocol, workspace (cde_dopri5_workspace_bytes) and status block as

@@ -35,6 +35,15 @@ def _worker(rank, world, port, tmp):
     allreduce_gradients(list(func.parameters()))
     full = gather_batch(out.detach(), B)
     gz = gather_batch(z.grad, B)
+    # shared step control of the adaptive solves: the default reducer is a sum all-reduce of the pending error sums
+    from torchcde_amd.distributed import shared_step_control, step_control
+    assert step_control() is None
+    with shared_step_control(B):
+        reduce, global_batch = step_control()
+        sums = torch.tensor([1.0 + rank, 10.0 * (rank + 1)], dtype=torch.float64)
+        reduce(sums)
+        assert global_batch == B and torch.equal(sums, torch.tensor([3.0, 30.0], dtype=torch.float64))
+    assert step_control() is None
     if rank == 0:
         torch.save(dict(out=full, gz=gz, gw=func.linear.weight.grad, gb=func.linear.bias.grad), tmp)
     dist.barrier()

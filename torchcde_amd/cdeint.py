@@ -457,6 +457,8 @@ class _Dopri5Plan:
         self.variant = variant
         self.adjoint_rtol = float(rtol if adjoint_rtol is None else adjoint_rtol)
         self.adjoint_atol = float(atol if adjoint_atol is None else adjoint_atol)
+        from .distributed import step_control
+        self.shared = step_control()      # one controller across the shards of a distributed batch (or None)
         options = {} if options is None else dict(options)
         jump_t = options.pop("jump_t", None)
         self.safety = float(options.pop("safety", 0.9))
@@ -488,6 +490,41 @@ class _Dopri5Plan:
             self.jump_t, self.n_jump = jt.to(self.device), jt.numel()
             self.jump_s = (-jt).flip(0).contiguous().to(self.device)      # the backward solve runs in s = -t
 
+    def _run_shared(self, lib, shared, out, z0c, w, b, dt, workspace):
+        """One controller for all shards: per attempted step the pending error sums are all-reduced before the launch
+        that consumes them (torchcde_amd.distributed.shared_step_control)."""
+        reduce, global_batch = shared
+        sums = torch.zeros(2, dtype=torch.float64, device=self.device)
+        size = ctypes.sizeof(_lib.DopriStatus)
+        stream = _lib.stream_ptr(self.device)
+        launched = 0
+        while True:
+            for _ in range(_DOPRI_CHUNK):
+                _lib.check(lib.cde_dopri5_pending_sums(_lib.ptr(workspace), workspace.numel(), self.B, self.C, self.H, dt,
+                                                       self.variant, self.act, launched, _lib.ptr(sums), stream),
+                           "cde_dopri5_pending_sums")
+                reduce(sums)
+                _lib.check(lib.cde_dopri5_advance_sharded(
+                    _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w), _lib.ptr(b),
+                    self.act, _lib.ptr(z0c), _lib.ptr(self.t_out), self.n_out, _lib.ptr(self.jump_t), self.n_jump,
+                    self.rtol, self.atol, self.safety, self.ifactor, self.dfactor, _lib.ptr(out), self.B, self.C, self.H,
+                    dt, self.variant, _lib.ptr(workspace), workspace.numel(), launched, _lib.ptr(sums), global_batch,
+                    stream), "cde_dopri5_advance_sharded")
+                launched += 1
+            raw = workspace[(launched & 1) * size:(launched & 1) * size + size].cpu().numpy().tobytes()
+            status = _lib.DopriStatus.from_buffer_copy(raw)
+            if status.phase == 4:
+                break
+            if launched > 2_000_000:
+                raise RuntimeError("torchcde_amd: dopri5 did not reach t[-1] after %d attempted steps" % launched)
+        last_dopri5_stats.clear()
+        last_dopri5_stats.update(n_accept=status.n_accept, n_reject=status.n_reject, launches=launched)
+        if record_dopri5_steps:
+            off = lib.cde_dopri5_trace_offset(self.B, self.C, self.H, dt)
+            n = min(status.n_accept, 4096)
+            last_dopri5_stats["steps"] = workspace[off:off + 24 * n].view(torch.float64).view(n, 3).cpu()
+        return out
+
     def run_adjoint(self, z_saved, grad_out, weight, bias):
         """K4a: torchdiffeq's odeint_adjoint backward for the adaptive solve, one attempt kernel per attempted step
         (csrc/dopri5_adjoint.hip), output intervals from the last to the first."""
@@ -506,6 +543,8 @@ class _Dopri5Plan:
         workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         size = ctypes.sizeof(_lib.DopriStatus)
         a_out = torch.empty(B, H, dtype=torch.float32, device=dev)
+        shared = self.shared
+        sums = torch.zeros(4, dtype=torch.float64, device=dev)
         stats = dict(n_accept=0, n_reject=0, launches=0)
         steps = []
         for i in range(self.n_out - 1, 0, -1):
@@ -513,13 +552,25 @@ class _Dopri5Plan:
             s0, s1 = -float(self.t_host[i]), -float(self.t_host[i - 1])
             launched = 0
             while True:
-                _lib.check(lib.cde_dopri5_adjoint_advance(
-                    _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w), _lib.ptr(b),
-                    self.act, _lib.ptr(y), _lib.ptr(a), s0, s1, _lib.ptr(self.jump_s), self.n_jump, self.adjoint_rtol,
-                    self.adjoint_atol, self.safety, self.ifactor, self.dfactor, _lib.ptr(a_out), B, C, H,
-                    _lib.dtype_enum(torch.float32), int(i == self.n_out - 1), _lib.ptr(workspace), workspace.numel(),
-                    launched, _DOPRI_CHUNK, _lib.stream_ptr(dev)), "cde_dopri5_adjoint_advance")
-                launched += _DOPRI_CHUNK
+                def advance(first, count, sums_ptr, global_batch):
+                    _lib.check(lib.cde_dopri5_adjoint_advance(
+                        _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w),
+                        _lib.ptr(b), self.act, _lib.ptr(y), _lib.ptr(a), s0, s1, _lib.ptr(self.jump_s), self.n_jump,
+                        self.adjoint_rtol, self.adjoint_atol, self.safety, self.ifactor, self.dfactor, _lib.ptr(a_out), B,
+                        C, H, _lib.dtype_enum(torch.float32), int(i == self.n_out - 1), _lib.ptr(workspace),
+                        workspace.numel(), first, count, sums_ptr, global_batch, _lib.stream_ptr(dev)),
+                        "cde_dopri5_adjoint_advance")
+                if shared is None:
+                    advance(launched, _DOPRI_CHUNK, None, 0)
+                    launched += _DOPRI_CHUNK
+                else:
+                    for _ in range(_DOPRI_CHUNK):
+                        _lib.check(lib.cde_dopri5_adjoint_pending_sums(_lib.ptr(workspace), workspace.numel(), B, C, H,
+                                                                       launched, _lib.ptr(sums), _lib.stream_ptr(dev)),
+                                   "cde_dopri5_adjoint_pending_sums")
+                        shared[0](sums)
+                        advance(launched, 1, _lib.ptr(sums), shared[1])
+                        launched += 1
                 raw = workspace[(launched & 1) * size:(launched & 1) * size + size].cpu().numpy().tobytes()
                 status = _lib.DopriStatus.from_buffer_copy(raw)
                 if status.phase == 4:
@@ -558,6 +609,11 @@ class _Dopri5Plan:
         launched = 0
         if self.hidden is not None:
             w1, b1 = self.hidden.weight.detach().contiguous(), self.hidden.bias.detach().contiguous()
+        shared = self.shared
+        if shared is not None:
+            if self.hidden is not None:
+                raise NotImplementedError("torchcde_amd: shared_step_control covers the one-layer fields (K4 / K4a).")
+            return self._run_shared(lib, shared, out, z0c, w, b, dt, workspace)
         while True:
             if self.hidden is None:
                 _lib.check(lib.cde_dopri5_advance(

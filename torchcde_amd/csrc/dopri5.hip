@@ -34,6 +34,8 @@ struct DopriArgs {
   int64_t n_blocks_alloc;
   const T* W1; const T* bias1; int width;      // two-layer fields: the hidden layer (W, bias are then the output layer)
   double* trace;                // [CDE_DOPRI5_TRACE_STEPS][3]: (t0, t1, clipped onto a jump time) of every accepted step
+  const double* ext_sums;       // sharded batch: the pending sums, already added up over ALL shards (else nullptr)
+  int64_t B_global;             // number of series the error norm runs over (0: this call's B)
 };
 
 // vector field row for lane (s,h): sum_c act(bias + W z) dX_c, control derivative at time ts
@@ -105,7 +107,7 @@ struct DopriPlan {
 
 template <typename T>
 __device__ __forceinline__ DopriPlan<T> dopri_controller(const DopriArgs<T>& g, DopriCtrl& c, double sum0, double sum1) {
-  const double n_elems = (double)(g.B * g.H);
+  const double n_elems = (double)((g.B_global > 0 ? g.B_global : g.B) * g.H);
   bool accept = false;
   int mode;                     // what this launch computes: 0 = f0 norms, 1 = f1 norm, 2 = attempt, 3 = nothing more
   double t0 = 0, t1 = 0, dt = 0;
@@ -243,7 +245,9 @@ __global__ void dopri5_attempt_kernel(DopriArgs<T> g, int parity) {
 
   // ---- pending global sums of the previous launch (fixed order -> identical in every workgroup)
   double sum0 = 0.0, sum1 = 0.0;
-  if (c.phase != 0) {
+  if (c.phase != 0 && g.ext_sums) {                               // one controller for all shards of the batch
+    sum0 = g.ext_sums[0]; sum1 = g.ext_sums[1];
+  } else if (c.phase != 0) {
     for (int64_t b = tid; b < (int64_t)gridDim.x; b += blockDim.x) { sum0 += Pp[2 * b]; sum1 += Pp[2 * b + 1]; }
     block_sum2(sum0, sum1, red);
   }
@@ -418,7 +422,9 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   const T rtol = (T)g.rtol, atol = (T)g.atol;
 
   double sum0 = 0.0, sum1 = 0.0;
-  if (c.phase != 0) {
+  if (c.phase != 0 && g.ext_sums) {                               // one controller for all shards of the batch
+    sum0 = g.ext_sums[0]; sum1 = g.ext_sums[1];
+  } else if (c.phase != 0) {
     for (int64_t b = tid; b < (int64_t)gridDim.x; b += blockDim.x) { sum0 += Pp[2 * b]; sum1 += Pp[2 * b + 1]; }
     block_sum2(sum0, sum1, red);
   }
@@ -573,6 +579,16 @@ static inline int64_t dopri_blocks(int64_t B, int64_t H) {
   return tiles < 1 ? 1 : (tiles > 2048 ? 2048 : tiles);
 }
 static inline size_t al256(size_t x) { return (x + 255) / 256 * 256; }
+
+// sharded batches: this shard's pending partial sums, added up in block order (what the next launch would do itself)
+__global__ __launch_bounds__(64) void dopri_pending_sums_kernel(const double* __restrict__ partial, int64_t n_blocks,
+                                                                int width, double* __restrict__ out) {
+  const int k = threadIdx.x;
+  if (k >= width) return;
+  double s = 0.0;
+  for (int64_t b = 0; b < n_blocks; ++b) s += partial[b * width + k];
+  out[k] = s;
+}
 __global__ void wy16_image_kernel(const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ img, Dims d) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < WY_FLOATS) {
@@ -622,7 +638,8 @@ static int dopri5_advance_impl(const void* coeffs, const void* knots, int64_t n_
                                const void* z0, const double* t_out, int64_t n_out, const double* jump_t, int64_t n_jump,
                                double rtol, double atol, double safety, double ifactor, double dfactor, void* z_out,
                                int64_t B, int64_t C, int64_t H, int dtype, int variant, void* workspace,
-                               size_t workspace_bytes, int64_t first_launch, int64_t n_launches, void* stream) {
+                               size_t workspace_bytes, int64_t first_launch, int64_t n_launches, void* stream,
+                               const double* ext_sums = nullptr, int64_t B_global = 0) {
   const bool mlp = W1 != nullptr;
   if (B < 1 || C < 1 || H < 1 || H > 256 || n_intervals < 1 || n_out < 1 || n_launches < 0 || n_jump < 0) return CDE_ERR_SHAPE;
   if (mlp && (width < 1 || !bias1)) return width < 1 ? CDE_ERR_SHAPE : CDE_ERR_NULL;
@@ -653,7 +670,7 @@ static int dopri5_advance_impl(const void* coeffs, const void* knots, int64_t n_
     cde::DopriArgs<T> g{(const T*)coeffs, (const T*)knots, n_intervals, degree, (const T*)W, (const T*)bias, act, \
                         (const T*)z0, t_out, n_out, jump_t, n_jump, rtol, atol, safety, ifactor, dfactor,         \
                         (T*)z_out, B, C, H, ns, ctrl, (T*)state, nullptr, partial, blocks};                        \
-    g.trace = trace;                                                                                              \
+    g.trace = trace; g.ext_sums = ext_sums; g.B_global = B_global;                                                \
     const size_t lds = (((size_t)ns * (H + C) * sizeof(T) + 15) / 16) * 16 + 2 * nt * sizeof(double);                                 \
     for (int64_t i = 0; i < n_launches; ++i)                                                                      \
       cde::dopri5_attempt_kernel<T><<<(unsigned)cde::dopri_blocks(B, H), nt, lds, s>>>(g, (int)((first_launch + i) & 1)); \
@@ -662,7 +679,7 @@ static int dopri5_advance_impl(const void* coeffs, const void* knots, int64_t n_
     cde::DopriArgs<float> g{(const float*)coeffs, (const float*)knots, n_intervals, degree, (const float*)W,
                             (const float*)bias, act, (const float*)z0, t_out, n_out, jump_t, n_jump, rtol, atol, safety,
                             ifactor, dfactor, (float*)z_out, B, C, H, 16, ctrl, (float*)state, w16, partial, blocks,
-                            (const float*)W1, (const float*)bias1, (int)width, trace};
+                            (const float*)W1, (const float*)bias1, (int)width, trace, ext_sums, B_global};
     const cde::Dims dims{(int)H, (int)C};
     const unsigned grid = (unsigned)((B + 127) / 128);
     const int64_t n_knots = n_intervals + 1;
@@ -726,6 +743,36 @@ extern "C" int cde_dopri5_advance(const void* coeffs, const void* knots, int64_t
   return dopri5_advance_impl(coeffs, knots, n_intervals, degree, nullptr, nullptr, 0, W, bias, act, z0, t_out, n_out,
                              jump_t, n_jump, rtol, atol, safety, ifactor, dfactor, z_out, B, C, H, dtype, variant,
                              workspace, workspace_bytes, first_launch, n_launches, stream);
+}
+
+// Sharded batches with ONE step controller (torchdiffeq's semantics for the whole batch): per attempted step every
+// shard calls cde_dopri5_pending_sums, the 2 doubles are all-reduced (sum) across the shards, and every shard runs ONE
+// launch of cde_dopri5_advance_sharded with the reduced sums and the global batch size.
+extern "C" int cde_dopri5_pending_sums(const void* workspace, size_t workspace_bytes, int64_t B, int64_t C, int64_t H,
+                                       int dtype, int variant, int act, int64_t total_launches, double* sums, void* stream) {
+  if (B < 1 || C < 1 || H < 1) return CDE_ERR_SHAPE;
+  if (!workspace || !sums) return CDE_ERR_NULL;
+  if (workspace_bytes < cde_dopri5_workspace_bytes(B, C, H, dtype)) return CDE_ERR_WORKSPACE;
+  const int64_t stride = cde::dopri_blocks_any(B, H);
+  const bool use_mfma = cde::dopri_use_mfma(C, H, dtype, act, variant);
+  const int64_t live = use_mfma ? (B + 127) / 128 : cde::dopri_blocks(B, H);       // the grid of the attempt kernel
+  const double* partial = (const double*)((const unsigned char*)workspace + cde::al256(2 * sizeof(cde::DopriCtrl))) +
+                          (total_launches & 1) * stride * 2;
+  cde::dopri_pending_sums_kernel<<<1, 64, 0, (hipStream_t)stream>>>(partial, live, 2, sums);
+  return cde::check_launch();
+}
+
+extern "C" int cde_dopri5_advance_sharded(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
+                                          const void* W, const void* bias, int act, const void* z0, const double* t_out,
+                                          int64_t n_out, const double* jump_t, int64_t n_jump, double rtol, double atol,
+                                          double safety, double ifactor, double dfactor, void* z_out, int64_t B,
+                                          int64_t C, int64_t H, int dtype, int variant, void* workspace,
+                                          size_t workspace_bytes, int64_t first_launch, const double* reduced_sums,
+                                          int64_t B_global, void* stream) {
+  if (!reduced_sums || B_global < B) return reduced_sums ? CDE_ERR_SHAPE : CDE_ERR_NULL;
+  return dopri5_advance_impl(coeffs, knots, n_intervals, degree, nullptr, nullptr, 0, W, bias, act, z0, t_out, n_out,
+                             jump_t, n_jump, rtol, atol, safety, ifactor, dfactor, z_out, B, C, H, dtype, variant,
+                             workspace, workspace_bytes, first_launch, 1, stream, reduced_sums, B_global);
 }
 
 extern "C" int cde_dopri5_advance_mlp(const void* coeffs, const void* knots, int64_t n_intervals, int degree,

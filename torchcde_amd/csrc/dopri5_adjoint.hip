@@ -51,6 +51,8 @@ struct DopriAdjArgs {
   double s0, s1;                    // the interval in reversed time, s0 < s1
   const double* jump_s; int64_t n_jump;    // jump times in reversed time, ascending
   double rtol, atol, safety, ifactor, dfactor;
+  const double* ext_sums;           // sharded batch: the 4 pending sums added up over all shards (else nullptr)
+  int64_t B_global;                 // series the error norm runs over (0: B)
 };
 
 struct AdjPlan {
@@ -89,7 +91,7 @@ __device__ __forceinline__ void block_sum4(double (&v)[4], double* red) {
 // torchdiffeq's controller (dopri5.hip: dopri_controller) for the two-block state (y, a): every thread derives the
 // same plan from the controller struct and the pending sums.
 __device__ __forceinline__ AdjPlan adj_controller(const DopriAdjArgs& g, DopriCtrl& c, const double (&sum)[4]) {
-  const double n_elems = (double)(g.B * g.dims.H);
+  const double n_elems = (double)((g.B_global > 0 ? g.B_global : g.B) * g.dims.H);
   auto rms = [&](double s) { return (float)sqrt(s / n_elems); };
   auto maxf = [](float a, float b) { return a > b ? a : b; };
   AdjPlan plan{};
@@ -208,7 +210,10 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
 
   // ---- pending global sums (fixed order: the decision is identical in every workgroup and run to run)
   double sum[4] = {0.0, 0.0, 0.0, 0.0};
-  if (c.phase != 0) {
+  if (c.phase != 0 && g.ext_sums) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sum[k] = g.ext_sums[k];
+  } else if (c.phase != 0) {
     for (int64_t b = tid; b < (int64_t)gridDim.x; b += blockDim.x) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) sum[k] += Pp[4 * b + k];
@@ -560,7 +565,8 @@ extern "C" int cde_dopri5_adjoint_advance(const void* coeffs, const void* knots,
                                           double rtol, double atol, double safety, double ifactor, double dfactor,
                                           void* a_out, int64_t B, int64_t C, int64_t H, int dtype, int first_interval,
                                           void* workspace, size_t workspace_bytes, int64_t first_launch,
-                                          int64_t n_launches, void* stream) {
+                                          int64_t n_launches, const double* reduced_sums, int64_t B_global,
+                                          void* stream) {
   if (B < 1 || C < 1 || H < 1 || n_intervals < 1 || n_launches < 0 || n_jump < 0 || !(s0 < s1)) return CDE_ERR_SHAPE;
   if (dtype != CDE_F32) return dtype == CDE_F64 ? CDE_ERR_UNSUPPORTED : CDE_ERR_DTYPE;
   if (H > cde::MH || C > cde::MC) return CDE_ERR_UNSUPPORTED;
@@ -584,6 +590,8 @@ extern "C" int cde_dopri5_adjoint_advance(const void* coeffs, const void* knots,
   g.y_init = (const float*)y_init; g.a_init = (const float*)a_init; g.a_out = (float*)a_out;
   g.s0 = s0; g.s1 = s1; g.jump_s = jump_s; g.n_jump = n_jump;
   g.rtol = rtol; g.atol = atol; g.safety = safety; g.ifactor = ifactor; g.dfactor = dfactor;
+  g.ext_sums = reduced_sums; g.B_global = B_global;
+  if (reduced_sums && (n_launches != 1 || B_global < B)) return CDE_ERR_SHAPE;      // sharded: one launch per all-reduce
   const int grid = cde::adj_grid(B);
   if (first_launch == 0) {
     if (hipMemsetAsync(g.ctrl, 0, 2 * sizeof(cde::DopriCtrl), s) != hipSuccess) return CDE_ERR_LAUNCH;     // phase 0
@@ -604,6 +612,27 @@ extern "C" int cde_dopri5_adjoint_advance(const void* coeffs, const void* knots,
     if (degree == CDE_PATH_CUBIC) CDE_ADJ(CDE_PATH_CUBIC, CDE_ACT_TANH); else CDE_ADJ(CDE_PATH_LINEAR, CDE_ACT_TANH);
   }
 #undef CDE_ADJ
+  return cde::check_launch();
+}
+
+// sharded batches (one controller for all shards): this shard's 4 pending sums, to be all-reduced before the next launch
+__global__ __launch_bounds__(64) void dopri_adjoint_pending_sums_kernel(const double* __restrict__ partial, int n_wg,
+                                                                        double* __restrict__ out) {
+  const int k = threadIdx.x;
+  if (k >= 4) return;
+  double s = 0.0;
+  for (int b = 0; b < n_wg; ++b) s += partial[4 * b + k];
+  out[k] = s;
+}
+
+extern "C" int cde_dopri5_adjoint_pending_sums(const void* workspace, size_t workspace_bytes, int64_t B, int64_t C,
+                                               int64_t H, int64_t total_launches, double* sums, void* stream) {
+  if (B < 1 || C < 1 || H < 1) return CDE_ERR_SHAPE;
+  if (!workspace || !sums) return CDE_ERR_NULL;
+  if (workspace_bytes < cde_dopri5_adjoint_workspace_bytes(B, C, H)) return CDE_ERR_WORKSPACE;
+  const double* partial = (const double*)((const unsigned char*)workspace + adj_off_partial()) +
+                          (total_launches & 1) * cde::ADJ_MAX_WG * 4;
+  dopri_adjoint_pending_sums_kernel<<<1, 64, 0, (hipStream_t)stream>>>(partial, cde::adj_grid(B), sums);
   return cde::check_launch();
 }
 

@@ -7,8 +7,39 @@ solve needs NO data-path collective.  The only exchanges are
   * ``shard`` / ``gather_batch``: optional helpers when the data is not born sharded.
 Works with any ``torch.distributed`` backend ("nccl" == RCCL on ROCm; "gloo" in the CPU tests).
 """
+import contextlib
+import threading
+
 import torch
 import torch.distributed as dist
+
+# ---------------------------------------------------------------------------------------------- adaptive solves
+# torchdiffeq's dopri5 has ONE step controller for the whole batch (the error norm is an RMS over all series).  When
+# the batch is sharded over ranks, every rank running its own controller gives valid but different step sequences.
+# Inside `shared_step_control()` the fused adaptive solves (forward K4 and backward K4a) instead all-reduce the two
+# (four) error sums of every attempted step, so that all shards take exactly the step sequence of the unsharded batch.
+_local = threading.local()    # .control = (reduce(tensor) -> None, global number of series); read when a solve is planned
+
+
+@contextlib.contextmanager
+def shared_step_control(global_batch, group=None, reduce=None):
+    """``with shared_step_control(B_total): z = cdeint(X_shard, func, z0_shard, t)`` (and its ``backward()`` inside the
+    same block: the plan made by the forward call keeps the setting).  ``reduce`` defaults to a sum all-reduce over ``group``; every rank must make the same calls."""
+    if reduce is None:
+        def reduce(sums):
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    previous = getattr(_local, "control", None)
+    _local.control = (reduce, int(global_batch))
+    try:
+        yield
+    finally:
+        _local.control = previous
+
+
+def step_control():
+    """The active (reduce, global_batch) pair, or None.  cdeint reads it when it plans an adaptive solve; the plan carries
+    it into the backward pass (which autograd runs on its own thread)."""
+    return getattr(_local, "control", None)
 
 
 def shard_bounds(n, rank=None, world=None):
