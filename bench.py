@@ -41,7 +41,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 # HBM bytes per launch of the dominant kernel from rocprofv3 counter passes (see roofline.traffic_source); keyed by the
 # per-GPU batch the pass was run at, None where no pass exists
-ADJOINT_HBM_BYTES_PER_LAUNCH = {32768: int(2 * 268.8e6 + 37.9e6)}
+ADJOINT_HBM_BYTES_PER_LAUNCH = {32768: int(2 * 268.9e6 + 37.9e6), 4096: int(2 * 33.87e6 + 8.96e6)}
 
 
 def make_workload(device, seed, n=None, first=0, count=None):
@@ -116,9 +116,12 @@ def cpu_baseline(max_sample, budget_s=20.0):
 
 
 TRAFFIC_SOURCE = {
-    32768: "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload (profiles/r01_pmc_summary.csv): 2 x 268.8 "
-           "MB fetched (gfx950 half-count correction for 16 B/lane reads) + 37.9 MB written; algorithmic bytes: "
-           "32768 x 12,704 B = 416 MB (whole 128 B rows: 550 MB)",
+    32768: "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload (profiles/r02_k3_traffic_summary.csv, same "
+           "as r01): 2 x 268.9 MB fetched (gfx950 half-count correction for 16 B/lane reads) + 37.9 MB written; "
+           "algorithmic bytes: 32768 x 12,704 B = 416 MB (whole 128 B rows: 550 MB)",
+    4096: "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of rk4_adjoint_split8 at 4096 series "
+          "(profiles/r02_split_pmc_summary.csv): 2 x 33.9 MB fetched + 9.0 MB written (8.7 MB of it the 256 per-tile "
+          "parameter-gradient partials); algorithmic bytes: 4096 x 12,704 B = 52 MB",
 }
 
 

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Counter passes for the roofline evidence (one --pmc set per run, kernel-trace only: see the gpurun rules).
-# Usage on the GPU box:  bash scripts/pmc_passes.sh <tag> [workload.py] [passes] [workload args]   -> gpurun_out/pmc_<tag>/*.db
+# Usage on the GPU box:  bash scripts/pmc_passes.sh <tag> [workload.py] [passes] [workload args]   -> /tmp/pmc_<tag>/*.db
 set -u
 TAG=${1:-r01}
 WORKLOAD=${2:-scripts/prof_workload.py}
 PASSES=${3:-"mfma waves fetch write"}
 WARGS=${4:-3}
-OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
+OUT=${PMC_OUT:-/tmp}/pmc_$TAG     # the .db files are large: summarise on the box (scripts/pmc_summary.py), copy the CSVs
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() {  # name, counters...
