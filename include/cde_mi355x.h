@@ -126,7 +126,7 @@ int cde_rectilinear_prepare(const void* x, void* out, int64_t B, int64_t L, int6
  *   words (n_words, 2) int32 (level, flat index) of every Lyndon word in signatory's order;
  *   out (B, n_windows + 1, n_words): first row = first observation (padded with zeros), then the running sum of the
  *   windows' logsignatures.
- * depth <= 3, C <= 8, n_words <= 64 (CDE_ERR_UNSUPPORTED otherwise).  The logsignature arithmetic replaces the
+ * (C <= 8, depth <= 3), (C <= 5, depth 4) or (C <= 32, depth <= 2); CDE_ERR_UNSUPPORTED otherwise.  The logsignature arithmetic replaces the
  * third-party `signatory` calls at log_ode.py:53,57,59 ("words" mode): parity with that package is unpinned. */
 int cde_logsig_windows(const void* x, const int64_t* rows, const void* scale, const int32_t* words, void* out, int64_t B,
                        int64_t L, int64_t C, int depth, int64_t n_windows, int n_words, int dtype, void* stream);

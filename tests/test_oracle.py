@@ -112,6 +112,18 @@ def test_logsignature_known_answers():
     # which at depth 1 means the window logsignatures add up to the whole
     q = torch.cat([p[:, :3], 0.3 * p[:, 2:3] + 0.7 * p[:, 3:4], p[:, 3:]], 1)
     assert torch.allclose(logsig.logsignature(q, 3), l3, atol=1e-12)
+    # depth 4: the fourth BCH term -[b,[a,[a,b]]]/24 for two straight segments; straight lines and re-parametrisation
+    # as above; the lower levels of a depth-4 logsignature are the depth-3 logsignature
+    level4 = -bracket(b, bracket(a, ab)) / 24.0
+    words4 = logsig.lyndon_words(3, 4)
+    got4 = logsig.logsignature(torch.tensor(np.stack([np.zeros(3), a, a + b]))[None], 4)[0]
+    for w, val in zip(words4, got4):
+        want = (a + b)[w[0]] if len(w) == 1 else level2[w] if len(w) == 2 else level3[w] if len(w) == 3 else level4[w]
+        assert abs(val.item() - want) < 1e-12, w
+    l4 = logsig.logsignature(p, 4)
+    assert torch.allclose(l4[:, :14], l3, atol=1e-14)
+    assert torch.allclose(logsig.logsignature(line[None], 4)[0, 3:], torch.zeros(29, dtype=torch.float64), atol=1e-14)
+    assert torch.allclose(logsig.logsignature(q, 4), l4, atol=1e-12)
 
 
 def test_logsig_windows_match_reference_windowing_golden():

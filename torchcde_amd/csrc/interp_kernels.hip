@@ -397,9 +397,14 @@ __global__ __launch_bounds__(256) void natural_cubic_kernel(const T* __restrict_
 // The arithmetic the reference gets from the `signatory` package (absent here; see oracle/logsig.py): signature by
 // Chen's identity  S <- S (x) exp(d)  over the increments, tensor-algebra logarithm, coefficients of the Lyndon words
 // (`words`: (level, flat index) pairs in signatory's order, built by the host).
-constexpr int LS_MAXC = 8;
+// The signature levels live in per-lane arrays, so the kernel is instantiated for the (channels, depth) envelopes that
+// occur: up to 8 channels to depth 3 (config 5 and the examples), up to 5 channels to depth 4 (the reference's test
+// runs depth 1-4 on 1-3 channels), up to 32 channels to depth 2.
+template <int N, int P> struct IPow { static constexpr int value = N * IPow<N, P - 1>::value; };
+template <int N> struct IPow<N, 0> { static constexpr int value = 1; };
+
 // pass 1: one lane per (series, window) -- the windows of a series are independent until the running sum
-template <typename T>
+template <typename T, int MAXC, int MAXD>
 __global__ __launch_bounds__(64) void logsig_windows_kernel(const T* __restrict__ x, const int64_t* __restrict__ rows,
                                                             const T* __restrict__ scale, const int32_t* __restrict__ words,
                                                             T* __restrict__ out, int64_t B, int64_t L, int C, int depth,
@@ -409,16 +414,36 @@ __global__ __launch_bounds__(64) void logsig_windows_kernel(const T* __restrict_
   const int64_t b = id / n_windows, win = id - b * n_windows;
   const T* src = x + b * L * C;
   T* dst = out + (b * (n_windows + 1) + win + 1) * n_words;
-  T S1[LS_MAXC], S2[LS_MAXC * LS_MAXC], S3[LS_MAXC * LS_MAXC * LS_MAXC];
-  const int C2 = C * C;
+  T S1[MAXC], S2[MAXD >= 2 ? IPow<MAXC, 2>::value : 1], S3[MAXD >= 3 ? IPow<MAXC, 3>::value : 1],
+      S4[MAXD >= 4 ? IPow<MAXC, 4>::value : 1];
+  const int C2 = C * C, C3 = C2 * C;
   for (int i = 0; i < C; ++i) S1[i] = (T)0;
-  if (depth >= 2) for (int i = 0; i < C2; ++i) S2[i] = (T)0;
-  if (depth >= 3) for (int i = 0; i < C2 * C; ++i) S3[i] = (T)0;
+  if (MAXD >= 2 && depth >= 2) for (int i = 0; i < C2; ++i) S2[i] = (T)0;
+  if (MAXD >= 3 && depth >= 3) for (int i = 0; i < C3; ++i) S3[i] = (T)0;
+  if (MAXD >= 4 && depth >= 4) for (int i = 0; i < C3 * C; ++i) S4[i] = (T)0;
   for (int64_t r = rows[win]; r < rows[win + 1]; ++r) {
-    T d[LS_MAXC];
+    T d[MAXC];
     for (int i = 0; i < C; ++i) d[i] = src[(r + 1) * C + i] - src[r * C + i];
     // levels of S (x) exp(d), highest first (they read the old lower levels); exp(d): e1 = d, e2 = e1 (x) d / 2, ...
-    if (depth >= 3)
+    // level k = S_k + e_k + S_1 (x) e_(k-1) + ... + S_(k-1) (x) e_1, added in that order (oracle/logsig.py)
+    if (MAXD >= 4 && depth >= 4)
+      for (int i = 0; i < C; ++i)
+        for (int j = 0; j < C; ++j) {
+          const T e2ij = d[i] * d[j] / (T)2;
+          for (int k = 0; k < C; ++k) {
+            const T e3ijk = e2ij * d[k] / (T)3;
+            const T e2jk = d[j] * d[k] / (T)2;
+            for (int l = 0; l < C; ++l) {
+              const int at = ((i * C + j) * C + k) * C + l;
+              T acc = S4[at] + e3ijk * d[l] / (T)4;
+              acc = acc + S1[i] * (e2jk * d[l] / (T)3);
+              acc = acc + S2[i * C + j] * (d[k] * d[l] / (T)2);
+              acc = acc + S3[(i * C + j) * C + k] * d[l];
+              S4[at] = acc;
+            }
+          }
+        }
+    if (MAXD >= 3 && depth >= 3)
       for (int i = 0; i < C; ++i)
         for (int j = 0; j < C; ++j) {
           const T e2 = d[i] * d[j] / (T)2;
@@ -429,12 +454,12 @@ __global__ __launch_bounds__(64) void logsig_windows_kernel(const T* __restrict_
             S3[(i * C + j) * C + k] = acc;
           }
         }
-    if (depth >= 2)
+    if (MAXD >= 2 && depth >= 2)
       for (int i = 0; i < C; ++i)
         for (int j = 0; j < C; ++j) S2[i * C + j] = (S2[i * C + j] + d[i] * d[j] / (T)2) + S1[i] * d[j];
     for (int i = 0; i < C; ++i) S1[i] = S1[i] + d[i];
   }
-  // logarithm: log(1 + S) = S - S^2/2 + S^3/3, level by level, then the Lyndon-word coordinates
+  // logarithm: log(1 + S) = S - S^2/2 + S^3/3 - S^4/4, level by level, then the Lyndon-word coordinates
   const T sc = scale[win];
   for (int w = 0; w < n_words; ++w) {
     const int level = words[2 * w], flat = words[2 * w + 1];
@@ -443,11 +468,19 @@ __global__ __launch_bounds__(64) void logsig_windows_kernel(const T* __restrict_
     else if (level == 2) {
       const int i = flat / C, j = flat - i * C;
       value = S2[flat] + (-(S1[i] * S1[j])) / (T)2;
-    } else {
+    } else if (level == 3) {
       const int i = flat / C2, jk = flat - i * C2, j = jk / C, k = jk - j * C;
       const T p2 = (S1[i] * S2[j * C + k]) + S2[i * C + j] * S1[k];          // (S^2)_3
       const T p3 = (S1[i] * S1[j]) * S1[k];                                   // (S^3)_3
       value = (S3[flat] + (-p2) / (T)2) + p3 / (T)3;
+    } else {
+      const int i = flat / C3, jkl = flat - i * C3, j = jkl / C2, kl = jkl - j * C2, k = kl / C, l = kl - k * C;
+      const int ij = i * C + j, ijk = ij * C + k;
+      const T p2 = ((S1[i] * S3[jkl]) + S2[ij] * S2[kl]) + S3[ijk] * S1[l];                      // (S^2)_4
+      const T s2_3 = (S1[i] * S2[j * C + k]) + S2[ij] * S1[k];                                   // (S^2)_3 at ijk
+      const T p3 = ((S1[i] * S1[j]) * S2[kl]) + s2_3 * S1[l];                                    // (S^3)_4
+      const T p4 = ((S1[i] * S1[j]) * S1[k]) * S1[l];                                            // (S^4)_4
+      value = ((S4[flat] + (-p2) / (T)2) + p3 / (T)3) + (-p4) / (T)4;
     }
     dst[w] = value * sc;
   }
@@ -671,22 +704,24 @@ extern "C" int cde_logsig_windows(const void* x, const int64_t* rows, const void
                                   int64_t B, int64_t L, int64_t C, int depth, int64_t n_windows, int n_words, int dtype,
                                   void* stream) {
   if (B < 0 || L < 1 || C < 1 || n_windows < 0 || n_words < 1) return CDE_ERR_SHAPE;
-  if (C > cde::LS_MAXC || depth < 1 || depth > 3 || n_words > 64) return CDE_ERR_UNSUPPORTED;
+  // envelopes of the per-lane signature arrays: (8 channels, depth 3), (5, 4), (32, 2)
+  const int env = (depth >= 1 && depth <= 3 && C <= 8) ? 0 : (depth == 4 && C <= 5) ? 1 : (depth >= 1 && depth <= 2 && C <= 32) ? 2 : -1;
+  if (env < 0) return CDE_ERR_UNSUPPORTED;
   if (B == 0) return CDE_OK;
   if (!x || !rows || !scale || !words || !out) return CDE_ERR_NULL;
   hipStream_t s = (hipStream_t)stream;
   const unsigned grid = (unsigned)((B * n_windows + 63) / 64), grid2 = (unsigned)((B * n_words + 255) / 256);
+#define CDE_LS(T, MAXC, MAXD)                                                                                          \
+  cde::logsig_windows_kernel<T, MAXC, MAXD><<<grid, 64, 0, s>>>((const T*)x, rows, (const T*)scale, words, (T*)out, B, L, \
+                                                                (int)C, depth, n_windows, n_words)
   if (dtype == CDE_F32) {
-    if (n_windows > 0)
-      cde::logsig_windows_kernel<float><<<grid, 64, 0, s>>>((const float*)x, rows, (const float*)scale, words, (float*)out, B,
-                                                            L, (int)C, depth, n_windows, n_words);
+    if (n_windows > 0) { if (env == 0) CDE_LS(float, 8, 3); else if (env == 1) CDE_LS(float, 5, 4); else CDE_LS(float, 32, 2); }
     cde::logsig_accumulate_kernel<float><<<grid2, 256, 0, s>>>((const float*)x, (float*)out, B, L, (int)C, n_windows, n_words);
   } else if (dtype == CDE_F64) {
-    if (n_windows > 0)
-      cde::logsig_windows_kernel<double><<<grid, 64, 0, s>>>((const double*)x, rows, (const double*)scale, words, (double*)out,
-                                                             B, L, (int)C, depth, n_windows, n_words);
+    if (n_windows > 0) { if (env == 0) CDE_LS(double, 8, 3); else if (env == 1) CDE_LS(double, 5, 4); else CDE_LS(double, 32, 2); }
     cde::logsig_accumulate_kernel<double><<<grid2, 256, 0, s>>>((const double*)x, (double*)out, B, L, (int)C, n_windows, n_words);
   } else return CDE_ERR_DTYPE;
+#undef CDE_LS
   return cde::check_launch();
 }
 

@@ -35,13 +35,12 @@ def _windows(x, depth, window_length, t, version):
     t = _validate_input_path(x, t)
     _lib.require_gpu(x, "x")
     _no_grad_through_path(x, t)
-    if not (1 <= depth <= 3) or x.size(-1) > 8:
-        raise NotImplementedError("torchcde_amd: logsignatures are implemented natively for depth <= 3 and at most 8 "
-                                  "channels (got depth=%d, channels=%d)." % (depth, x.size(-1)))
-    words = _lyndon_words(x.size(-1), depth)
-    if len(words) > 64:
-        raise NotImplementedError("torchcde_amd: more than 64 logsignature channels (%d) are not supported natively."
-                                  % len(words))
+    C_in = x.size(-1)
+    if not ((1 <= depth <= 3 and C_in <= 8) or (depth == 4 and C_in <= 5) or (1 <= depth <= 2 and C_in <= 32)):
+        raise NotImplementedError("torchcde_amd: logsignatures are implemented natively for depth <= 3 with at most 8 "
+                                  "channels, depth 4 with at most 5 and depth <= 2 with at most 32 (got depth=%d, "
+                                  "channels=%d)." % (depth, C_in))
+    words = _lyndon_words(C_in, depth)
     th = t.detach().cpu()
     # log_ode.py:18-40 on the host copy of the times
     timespan = th[-1] - th[0]
