@@ -91,10 +91,13 @@ static bool pick_mfma(int variant, int64_t C, int64_t H, int dtype, int act, boo
 
 // Among the MFMA kernels: the one-wave-per-series-tile kernels (K2/K3) need B/16 (B/32) waves to fill 1024 SIMDs twice
 // (once); below CDE_SPLIT_MAX_BATCH series the workgroup-per-tile kernels of rk4_split.hip finish sooner.
-static bool pick_split(int variant, int64_t B, bool control_grad) {
+// The tanh field is VALU-co-limited in the one-wave-per-tile kernels (K3a: 46 % MFMA-busy); the 8-wave tile kernel
+// overlaps the activation work of its chain waves with the helper waves' dW products and wins at EVERY batch size
+// (32768 series, forward + adjoint: 12.9 ms against 15.0 ms).
+static bool pick_split(int variant, int64_t B, bool control_grad, int act = CDE_ACT_NONE) {
   if (control_grad) return false;                  // dL/dcoeffs lives in the pre-activation K3 kernel only
   if (variant == CDE_VARIANT_SPLIT) return true;
-  return variant == CDE_VARIANT_AUTO && B <= CDE_SPLIT_MAX_BATCH;
+  return variant == CDE_VARIANT_AUTO && (B <= CDE_SPLIT_MAX_BATCH || act == CDE_ACT_TANH);
 }
 
 template <typename T, typename TT>
@@ -106,7 +109,7 @@ static int forward_typed(const void* coeffs, const void* knots, int64_t n_interv
   if (rc != CDE_OK) return rc;
   const bool use_mfma = pick_mfma(variant, C, H, dtype, act, false, &rc);
   if (rc != CDE_OK) return rc;
-  if (use_mfma && pick_split(variant, B, false))
+  if (use_mfma && pick_split(variant, B, false, act))
     return launch_forward_split<TT>(coeffs, knots, n_intervals, degree, W, bias, act, z0, grid, n_grid, t_out, n_out,
                                     z_out, B, C, H, stage_index, stage_frac, s);
   if (use_mfma)
@@ -130,7 +133,7 @@ static int adjoint_typed(const void* coeffs, const void* knots, int64_t n_interv
   const int64_t n_steps = n_sgrid - 1;
   const size_t off_frac = align256((size_t)(4 * n_steps) * sizeof(int64_t));
   const size_t off_part = off_frac + align256((size_t)(4 * n_steps) * sizeof(T));
-  const bool use_split = use_mfma && pick_split(variant, B, grad_coeffs != nullptr);
+  const bool use_split = use_mfma && pick_split(variant, B, grad_coeffs != nullptr, act);
   if (variant == CDE_VARIANT_SPLIT && !use_split) return CDE_ERR_UNSUPPORTED;
   const size_t part_bytes = use_split ? split_adjoint_partial_bytes(B)
                             : use_mfma ? mfma_adjoint_partial_bytes(B) : generic_adjoint_workspace_bytes(B, C, H, sizeof(T));
@@ -222,7 +225,10 @@ extern "C" size_t cde_rk4_adjoint_workspace_bytes(int64_t B, int64_t C, int64_t 
   const bool use_mfma = cde::pick_mfma(variant, C, H, dtype, CDE_ACT_NONE, true, &rc);
   // AUTO may resolve to either kernel depending on the activation: reserve the larger need
   size_t a = cde::mfma_adjoint_partial_bytes(B);
-  if (cde::pick_split(variant, B, false)) { const size_t sp = cde::split_adjoint_partial_bytes(B); a = sp > a ? sp : a; }
+  if (variant != CDE_VARIANT_MFMA && variant != CDE_VARIANT_GENERIC) {    // AUTO may resolve to the tile kernels (tanh: at any B)
+    const size_t sp = cde::split_adjoint_partial_bytes(B);
+    a = sp > a ? sp : a;
+  }
   const size_t b = cde::generic_adjoint_workspace_bytes(B, C, H, elem);
   if (variant == CDE_VARIANT_MFMA || variant == CDE_VARIANT_SPLIT) bytes += a;
   else if (variant == CDE_VARIANT_GENERIC || !use_mfma) bytes += b;

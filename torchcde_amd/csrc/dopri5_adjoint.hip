@@ -34,7 +34,7 @@ namespace cde {
 constexpr int ADJ_IMAGE = 36;                                    // per helper lane: 32 dW accumulators + 4 bias sums
 constexpr int ADJ_IMAGE_FLOATS = 4 * 64 * ADJ_IMAGE;             // per workgroup
 constexpr int ADJ_MAX_WG = 256;
-constexpr int ADJ_LDS_FLOATS = 2 * SPL_ZBUF + 2 * SPL_ZT + 2 * SPL_VA + 7 * SPL_DX + 2 * 4 * SPL_GT;
+constexpr int ADJ_LDS_FLOATS = 2 * SPL_ZBUF + 2 * SPL_ZT + 2 * SPL_VA + 2 * 7 * SPL_DX + 2 * 4 * SPL_GT;
 constexpr size_t ADJ_LDS_BYTES = (size_t)ADJ_LDS_FLOATS * sizeof(float) + 4 * 512 * sizeof(double);
 
 struct DopriAdjArgs {
@@ -198,8 +198,8 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
   float* zbuf = lds;
   float* ztb = lds + 2 * SPL_ZBUF;
   float* vab = ztb + 2 * SPL_ZT;
-  float* dxb = vab + 2 * SPL_VA;                                   // [7 stages][16 series][SPL_DXROW]
-  float* gT = dxb + 7 * SPL_DX + w * SPL_GT;                       // + (parity) * 4 * SPL_GT
+  float* dxb = vab + 2 * SPL_VA;                                   // [2 tiles in flight][7 stages][16 series][SPL_DXROW]
+  float* gT = dxb + 2 * 7 * SPL_DX + w * SPL_GT;                   // + (parity) * 4 * SPL_GT
   double* red = reinterpret_cast<double*>(lds + ADJ_LDS_FLOATS);
   const int64_t BH = g.B * g.dims.H;
   const float* Sp = g.state + (int64_t)p * 4 * BH;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
 #pragma unroll
   for (int j = 0; j < 7; ++j) { cerr[j] = dtf * (float)DP_CERR[j]; csol[j] = j < 6 ? dtf * (float)DP_BETA[5][j] : 0.f; }
 
-  int par = 0, gpar = 0;
+  int par = 0, gpar = 0, dbuf = 0;
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
 
   if (helper) {
@@ -283,25 +283,40 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
     const int fc = 2 * w + (q & 1);                                // the control channel this lane feeds
     const bool feeds = q < 2;
     const int fcc = fc < Cr ? fc : Cr - 1;
-    for (int64_t tile = blockIdx.x; tile < g.n_tiles; tile += gridDim.x) {
-      if (mode == 3) continue;
+    // control derivative of a tile at every stage time: requested one tile ahead (its global-load latency would
+    // otherwise be exposed once per tile and attempt), finished and stored to dxb[buffer][stage] when that tile is next
+    float raw[7][3];
+    auto feed_request = [&](int64_t tile) {
       const int64_t series = tile * 16 + n;
       const int64_t sc = series < g.B ? series : g.B - 1;
-      // control derivative of this tile at every stage time -> dxb[stage]
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
         if (i < ns) {
-          float v;
           if (DEGREE == CDE_PATH_CUBIC) {
             const float* pr = g.coeffs + ((sc * g.n_intervals + sidx[i]) * 4 + 1) * Cr + fcc;
-            v = cubic_derivative(pr[0], pr[Cr], pr[2 * Cr], sfrac[i]);
+            raw[i][0] = pr[0]; raw[i][1] = pr[Cr]; raw[i][2] = pr[2 * Cr];
           } else {
             const float* pr = g.coeffs + (sc * (g.n_intervals + 1) + sidx[i]) * Cr + fcc;
-            v = (pr[Cr] - pr[0]) / (g.knots[sidx[i] + 1] - g.knots[sidx[i]]);
+            raw[i][0] = pr[0]; raw[i][1] = pr[Cr]; raw[i][2] = g.knots[sidx[i] + 1] - g.knots[sidx[i]];
           }
-          if (feeds) dxb[i * SPL_DX + n * SPL_DXROW + fc] = fc < Cr ? v : 0.f;
         }
       }
+    };
+    auto feed_store = [&](int buf) {
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        if (i < ns) {
+          const float v = DEGREE == CDE_PATH_CUBIC ? cubic_derivative(raw[i][0], raw[i][1], raw[i][2], sfrac[i])
+                                                   : (raw[i][1] - raw[i][0]) / raw[i][2];
+          if (feeds) dxb[(buf * 7 + i) * SPL_DX + n * SPL_DXROW + fc] = fc < Cr ? v : 0.f;
+        }
+      }
+    };
+    if (mode != 3 && (int64_t)blockIdx.x < g.n_tiles) { feed_request(blockIdx.x); feed_store(0); }
+    for (int64_t tile = blockIdx.x; tile < g.n_tiles; tile += gridDim.x) {
+      if (mode == 3) continue;
+      const bool has_next = tile + gridDim.x < g.n_tiles;
+      if (has_next) feed_request(tile + gridDim.x);
       spl_barrier();
       f32x2 zq[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
       float wprev = 0.f;
@@ -336,6 +351,8 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
         }
       }
       // (the last stage carries weight c_sol[6] = 0: nothing left to add)
+      if (has_next) feed_store(dbuf ^ 1);
+      dbuf ^= 1;
     }
     if (mode == 2) {
 #pragma unroll
@@ -372,21 +389,29 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
       kaa = (p03.x + p03.z) + (p47.x + p47.z);
       kab = (p03.y + p03.w) + (p47.y + p47.w);
     };
+    // the committed state of this lane's two units, requested one tile ahead
+    auto state_request = [&](int64_t tile, float (&st)[4]) {
+      const int64_t series = tile * 16 + n;
+      const int64_t sc = series < g.B ? series : g.B - 1;
+      const int64_t ea = sc * Hr + (ua < Hr ? ua : 0), eb = sc * Hr + (ub < Hr ? ub : 0);
+      if (phase_in == 0) {
+        st[0] = g.y_init[ea]; st[1] = g.y_init[eb]; st[2] = g.a_init[ea]; st[3] = g.a_init[eb];
+      } else {
+        const int off = commit ? 2 : 0;
+        st[0] = Sp[(off + 0) * BH + ea]; st[1] = Sp[(off + 0) * BH + eb];
+        st[2] = Sp[(off + 1) * BH + ea]; st[3] = Sp[(off + 1) * BH + eb];
+      }
+    };
+    float st_next[4] = {0.f, 0.f, 0.f, 0.f};
+    if ((int64_t)blockIdx.x < g.n_tiles) state_request(blockIdx.x, st_next);
     for (int64_t tile = blockIdx.x; tile < g.n_tiles; tile += gridDim.x) {
       const int64_t series = tile * 16 + n;
       const bool valid = series < g.B;
       const int64_t sc = valid ? series : g.B - 1;
       const bool ona = valid && ua < Hr, onb = valid && ub < Hr;
       const int64_t ea = sc * Hr + (ua < Hr ? ua : 0), eb = sc * Hr + (ub < Hr ? ub : 0);
-      // ---- the committed state of this lane's two units
-      float y0a, y0b, a0a, a0b;
-      if (phase_in == 0) {
-        y0a = g.y_init[ea]; y0b = g.y_init[eb]; a0a = g.a_init[ea]; a0b = g.a_init[eb];
-      } else {
-        const int off = commit ? 2 : 0;
-        y0a = Sp[(off + 0) * BH + ea]; y0b = Sp[(off + 0) * BH + eb];
-        a0a = Sp[(off + 1) * BH + ea]; a0b = Sp[(off + 1) * BH + eb];
-      }
+      float y0a = st_next[0], y0b = st_next[1], a0a = st_next[2], a0b = st_next[3];
+      if (tile + gridDim.x < g.n_tiles) state_request(tile + gridDim.x, st_next);
       if (ua >= Hr) { y0a = 0.f; a0a = 0.f; }
       if (ub >= Hr) { y0b = 0.f; a0b = 0.f; }
       if (!valid) { a0a = 0.f; a0b = 0.f; }                      // padded lanes add nothing to dL/dW
@@ -406,8 +431,8 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
         if (i < ns) {
           const float4 z03 = *reinterpret_cast<const float4*>(zr + par * SPL_ZBUF);
           const float4 z47 = *reinterpret_cast<const float4*>(zr + par * SPL_ZBUF + 4);
-          const float4 d03 = *reinterpret_cast<const float4*>(dxr + i * SPL_DX);
-          const float4 d47 = *reinterpret_cast<const float4*>(dxr + i * SPL_DX + 4);
+          const float4 d03 = *reinterpret_cast<const float4*>(dxr + (dbuf * 7 + i) * SPL_DX);
+          const float4 d47 = *reinterpret_cast<const float4*>(dxr + (dbuf * 7 + i) * SPL_DX + 4);
           if (i >= 1) {
             // a path: the slope stage i-1 left open, then the state of this stage
             read_ka(par, kaa[i - 1], kab[i - 1]);
@@ -496,6 +521,7 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
         if (ona) { acc[0] += sq(eya / tya); acc[1] += sq(eaa / taa); Sq[2 * BH + ea] = ysa; Sq[3 * BH + ea] = asa; }
         if (onb) { acc[0] += sq(eyb / tyb); acc[1] += sq(eab / tab); Sq[2 * BH + eb] = ysb; Sq[3 * BH + eb] = asb; }
       }
+      dbuf ^= 1;
     }
   }
   // ---- publish this launch's partial sums and the controller state for the next launch
