@@ -209,6 +209,15 @@ int cde_rk4_forward_mlp(const void* coeffs, const void* knots, int64_t n_interva
                         int64_t C, int64_t H, int dtype, int time_dtype, int64_t* stage_index, void* stage_frac,
                         void* stream);
 
+/* K3m's parameter-gradient reduction (replaces the two library GEMMs of round 1): acc += G^T [X | 1] over `rows`
+ * (stage, series) rows that cde_rk4_adjoint_mlp_sweep streamed to HBM.  layer = 2: G (rows, 256), X (rows, 132),
+ * acc (256, 132); layer = 1: G (rows, 128), X (rows, 36), acc (128, 36); the bias gradient is column 128 / 32.
+ * Split-K on the matrix pipe with a fixed-order second pass: deterministic.  `workspace`: scratch of
+ * cde_mlp_grad_reduce_workspace_bytes(). */
+size_t cde_mlp_grad_reduce_workspace_bytes(void);
+int cde_mlp_grad_reduce(const void* G, const void* X, int64_t rows, int layer, void* acc, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K3m  Continuous-adjoint reverse sweep for K2m (the two-layer field), replacing torchdiffeq.odeint_adjoint's
  * backward behind solver.py:226 for that vector field.  The parameter gradient of the output layer is a

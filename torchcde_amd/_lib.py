@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libcde_mi355x.so")
 SOURCES = ["interp_kernels.hip", "rk4_generic.hip", "rk4_mfma.hip", "rk4_split.hip", "rk4_mlp_adjoint.hip", "dopri5.hip",
-           "dopri5_adjoint.hip", "api.hip"]
+           "dopri5_adjoint.hip", "mlp_grad_reduce.hip", "api.hip"]
 HEADERS = [os.path.join(_CSRC, "cde_common.h"), os.path.join(_CSRC, "cde_mfma.h"), os.path.join(_CSRC, "cde_split.h"),
            os.path.join(_CSRC, "cde_dopri.h"),
            os.path.join(_HERE, "..", "include", "cde_mi355x.h")]
@@ -110,6 +110,8 @@ _SIGNATURES = {
     "cde_dopri5_advance_sharded": (_i, [_p, _p, _i64, _i, _p, _p, _i, _p, _p, _i64, _p, _i64, _d, _d, _d, _d, _d, _p, _i64,
                                         _i64, _i64, _i, _i, _p, _sz, _i64, _p, _i64, _p]),
     "cde_dopri5_adjoint_finish": (_i, [_p, _sz, _p, _p, _i64, _i64, _i64, _p]),
+    "cde_mlp_grad_reduce_workspace_bytes": (_sz, []),
+    "cde_mlp_grad_reduce": (_i, [_p, _p, _i64, _i, _p, _p, _sz, _p]),
     "cde_rk4_adjoint_mlp_workspace_bytes": (_sz, [_i64]),
     "cde_rk4_adjoint_mlp_prepare": (_i, [_p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _i64, _i64, _i, _i, _p, _sz, _p]),
     "cde_rk4_adjoint_mlp_sweep": (_i, [_p, _p, _i64, _i, _i, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _i64,

@@ -299,17 +299,11 @@ class _MlpPlan:
             "cde_rk4_forward_mlp")
         return out.reshape(*self.batch, g.n_out, self.H)
 
-    @staticmethod
-    def _reduce(left, right, stages, B):
-        """left^T @ right over (stages * B) rows, split into enough batched GEMMs to fill the GPU."""
-        split = 8 if B % 8 == 0 and B >= 4096 else 1
-        groups = stages * split
-        return torch.bmm(left.view(groups, -1, left.size(1)).transpose(1, 2), right.view(groups, -1, right.size(1))).sum(0)
-
     def run_adjoint(self, z_saved, grad_out, want_control=False, weights=None):
         """torchdiffeq's odeint_adjoint backward for this field: per output interval (last to first) the augmented
         state is integrated in reversed time by K3m in chunks of steps; each chunk's per-stage factors (in HBM) are
-        reduced into the parameter gradients by two GEMMs whose extra "ones" column yields the bias gradients.
+        reduced into the parameter gradients by the split-K MFMA reduction (cde_mlp_grad_reduce; the bias gradients are
+        the column sums of the same factors).
         ``weights``: the parameter tensors saved by the forward pass (an in-place update between forward and backward
         then trips autograd's version check instead of silently using the new values)."""
         lib = _lib.load()
@@ -344,6 +338,7 @@ class _MlpPlan:
             Z[:, 32] = 1
             G2 = torch.empty(rows, 256, dtype=torch.float32, device=dev)
             G1 = torch.empty(rows, 128, dtype=torch.float32, device=dev)
+            reduce_ws = torch.empty(lib.cde_mlp_grad_reduce_workspace_bytes(), dtype=torch.uint8, device=dev)
         for p in range(self.n_out - 1):
             k, k_end = g.seg_off_host[p], g.seg_off_host[p + 1] - 1
             while k < k_end:
@@ -353,10 +348,11 @@ class _MlpPlan:
                     _lib.ptr(a), _lib.ptr(g.sgrid), g.n_sgrid, k, ke, _lib.ptr(U), _lib.ptr(G2), _lib.ptr(G1),
                     _lib.ptr(Z), _lib.ptr(grad_x), B, C, H, f32, tdt, _lib.ptr(workspace), nbytes, stream),
                     "cde_rk4_adjoint_mlp_sweep")
-                stages = 4 * (ke - k)
-                n = stages * B
-                acc2 += self._reduce(G2[:n], U[:n], stages, B)
-                acc1 += self._reduce(G1[:n], Z[:n], stages, B)
+                n = 4 * (ke - k) * B
+                _lib.check(lib.cde_mlp_grad_reduce(_lib.ptr(G2), _lib.ptr(U), n, 2, _lib.ptr(acc2), _lib.ptr(reduce_ws),
+                                                   reduce_ws.numel(), stream), "cde_mlp_grad_reduce")
+                _lib.check(lib.cde_mlp_grad_reduce(_lib.ptr(G1), _lib.ptr(Z), n, 1, _lib.ptr(acc1), _lib.ptr(reduce_ws),
+                                                   reduce_ws.numel(), stream), "cde_mlp_grad_reduce")
                 k = ke
             i_out = self.n_out - 1 - p
             y.copy_(z_saved[:, i_out - 1])                 # torchdiffeq: re-seed z from the stored forward solution

@@ -1,0 +1,169 @@
+// mlp_grad_reduce.hip -- the parameter-gradient reduction of the two-layer field's adjoint (K3m), hand-written.
+//
+// K3m streams, per RK stage and series, the factors of the parameter gradients to HBM (rk4_mlp_adjoint.hip):
+//     G [row][M]   dL/d(pre-activation) of a layer, already weighted by the quadrature weight
+//     X [row][XC]  the layer's input, a "1" in column N, zeros behind it              row = (stage, series)
+// and the gradients are   dW | db = G^T [X | 1]   -- an (M x N) result over a K dimension of up to 10^6..10^7 rows
+// (M x N = 256 x 128 for the output layer, 128 x 32 for the hidden layer).  Round 1 left this to torch.bmm
+// (hipBLASLt / Tensile kernels: 15 of the 52 ms of a two-layer backward).  Here: split-K over workgroups on
+// v_mfma_f32_16x16x4_f32, every operand fetched with 16-byte loads straight from the row-major factors:
+//   * a wave owns MT*16 rows of M; its M tiles are INTERLEAVED (tile t holds rows base + MT*i + t), so that ONE
+//     vector load of MT consecutive floats of a G row is the A operand of all MT tiles for one K index;
+//   * the N tiles are interleaved the same way in groups of 4 (tile 4g + t holds columns 64 g + 4 j + t): one float4
+//     of an X row is the B operand of 4 tiles;  K step s, lane quarter kq  <->  row 4 s + kq of the slab;
+//   * the bias gradient is the column sum of G: the lanes add up the A operands they load anyway;
+//   * every workgroup reduces its slab of rows into registers (MT x NT tiles per wave) and writes one partial; a second
+//     kernel adds the partials in slab order into the caller's accumulator -- deterministic, no atomics.
+#include "cde_mfma.h"
+
+namespace cde {
+
+template <int MT> struct VecOf;
+template <> struct VecOf<4> { using type = float4; };
+template <> struct VecOf<2> { using type = float2; };
+
+template <int MT> __device__ __forceinline__ void unpack(const typename VecOf<MT>::type& v, float (&o)[MT]);
+template <> __device__ __forceinline__ void unpack<4>(const float4& v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+template <> __device__ __forceinline__ void unpack<2>(const float2& v, float (&o)[2]) { o[0] = v.x; o[1] = v.y; }
+
+// M = 4 waves * MT * 16 rows; N = NG * (NV * 16) columns, NV = floats per B load (4 or 2), NG groups of NV tiles
+template <int MT, int NV, int NG>
+__global__ __launch_bounds__(256, 2) void mlp_grad_partial_kernel(const float* __restrict__ G, const float* __restrict__ X,
+                                                                  int64_t rows, int64_t rows_per_slab, int xc,
+                                                                  float* __restrict__ partial) {
+  constexpr int M = 4 * MT * 16, NT = NG * NV, N = NT * 16;
+  using AV = typename VecOf<MT>::type;
+  using BV = typename VecOf<NV>::type;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int64_t lo = (int64_t)blockIdx.x * rows_per_slab;
+  int64_t hi = lo + rows_per_slab;
+  hi = hi < rows ? hi : rows;
+  f32x4 acc[MT][NT];
+  float bsum[MT];
+#pragma unroll
+  for (int tm = 0; tm < MT; ++tm) {
+    bsum[tm] = 0.f;
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float* ga = G + (w * MT * 16 + MT * i);              // + row * M
+  const float* xb = X + NV * i;                              // + row * xc + g * NV * 16
+  auto load = [&](int64_t row, AV& a, BV (&b)[NG]) {
+    const bool on = row < hi;
+    const int64_t r = on ? row : (hi - 1);
+    a = *reinterpret_cast<const AV*>(ga + r * M);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) b[g] = *reinterpret_cast<const BV*>(xb + r * xc + g * NV * 16);
+    if (!on) {                                              // rows past the slab contribute nothing
+      a = AV{};
+    }
+  };
+  // software pipeline: the loads of the NEXT group of KU K steps (16 rows at KU = 4) are in flight while the current
+  // group's KU * MT * NT MFMAs run -- an HBM round trip is about as long as one group
+  constexpr int KU = 4;
+  AV a_cur[KU], a_nxt[KU];
+  BV b_cur[KU][NG], b_nxt[KU][NG];
+#pragma unroll
+  for (int u = 0; u < KU; ++u) load(lo + 4 * u + kq, a_cur[u], b_cur[u]);
+  for (int64_t r0 = lo; r0 < hi; r0 += 4 * KU) {
+#pragma unroll
+    for (int u = 0; u < KU; ++u) load(r0 + 4 * (KU + u) + kq, a_nxt[u], b_nxt[u]);
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      float av[MT];
+      unpack<MT>(a_cur[u], av);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        float bv[NV];
+        unpack<NV>(b_cur[u][g], bv);
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+#pragma unroll
+          for (int tm = 0; tm < MT; ++tm) acc[tm][g * NV + t] = mfma16(av[tm], bv[t], acc[tm][g * NV + t]);
+        }
+      }
+#pragma unroll
+      for (int tm = 0; tm < MT; ++tm) bsum[tm] += av[tm];
+    }
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      a_cur[u] = a_nxt[u];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) b_cur[u][g] = b_nxt[u][g];
+    }
+  }
+  // partial[slab][m][N + 1]: D fragment of tile (tm, tn): lane (j = i, q = kq), register r = row 4q + r of the tile
+  float* out = partial + (int64_t)blockIdx.x * M * (N + 1);
+#pragma unroll
+  for (int tm = 0; tm < MT; ++tm) {
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn) {
+      const int col = (tn / NV) * NV * 16 + NV * i + (tn % NV);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = w * MT * 16 + MT * (4 * kq + r) + tm;
+        out[m * (N + 1) + col] = acc[tm][tn][r];
+      }
+    }
+    float s = bsum[tm];                                       // column sums: this lane saw rows kq, kq+4, ...
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (kq == 0) out[(w * MT * 16 + MT * i + tm) * (N + 1) + N] = s;
+  }
+}
+
+// acc[m][0..N] += sum over slabs: acc has row stride `acc_stride`, the bias gradient lands in column N.  A block takes 64
+// consecutive elements; its four waves each add up every fourth slab (coalesced 256-byte reads), the four sums meet
+// in LDS and are combined in a fixed order -- deterministic.
+__global__ __launch_bounds__(256) void mlp_grad_finish_kernel(const float* __restrict__ partial, int n_slabs, int M, int N,
+                                                              float* __restrict__ acc, int acc_stride) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int id = blockIdx.x * 64 + lane;
+  const int total = M * (N + 1);
+  const int64_t stride = (int64_t)M * (N + 1);
+  float s0 = 0.f, s1 = 0.f;
+  if (id < total) {
+    int b = w;
+    for (; b + 4 < n_slabs; b += 8) { s0 += partial[b * stride + id]; s1 += partial[(b + 4) * stride + id]; }
+    for (; b < n_slabs; b += 4) s0 += partial[b * stride + id];
+  }
+  part[w][lane] = s0 + s1;
+  __syncthreads();
+  if (w == 0 && id < total) {
+    const int m = id / (N + 1), col = id - m * (N + 1);
+    acc[m * acc_stride + col] += (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+  }
+}
+
+constexpr int GRAD_SLABS = 512;
+
+}  // namespace cde
+
+// workspace for one reduction call: GRAD_SLABS partials of the larger layer (256 x 129 floats each)
+extern "C" size_t cde_mlp_grad_reduce_workspace_bytes(void) { return (size_t)cde::GRAD_SLABS * 256 * 129 * sizeof(float); }
+
+// layer = 2: G (rows, 256), X (rows, 132) = [u (128) | 1 | 0 0 0]  ->  acc (256, 132) += G^T X   (columns 0..128)
+// layer = 1: G (rows, 128), X (rows, 36)  = [z (32)  | 1 | 0 0 0]  ->  acc (128, 36)  += G^T X   (columns 0..32)
+extern "C" int cde_mlp_grad_reduce(const void* G, const void* X, int64_t rows, int layer, void* acc, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  if (rows < 0 || (layer != 1 && layer != 2)) return CDE_ERR_SHAPE;
+  if (rows == 0) return CDE_OK;
+  if (!G || !X || !acc || !workspace) return CDE_ERR_NULL;
+  if (workspace_bytes < cde_mlp_grad_reduce_workspace_bytes()) return CDE_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  int64_t per = (rows + cde::GRAD_SLABS - 1) / cde::GRAD_SLABS;
+  per = (per + 15) / 16 * 16;
+  const int slabs = (int)((rows + per - 1) / per);
+  if (layer == 2) {
+    cde::mlp_grad_partial_kernel<4, 4, 2><<<slabs, 256, 0, s>>>((const float*)G, (const float*)X, rows, per, 132,
+                                                                  (float*)workspace);
+    cde::mlp_grad_finish_kernel<<<(256 * 129 + 63) / 64, 256, 0, s>>>((const float*)workspace, slabs, 256, 128, (float*)acc, 132);
+  } else {
+    cde::mlp_grad_partial_kernel<2, 2, 1><<<slabs, 256, 0, s>>>((const float*)G, (const float*)X, rows, per, 36,
+                                                                  (float*)workspace);
+    cde::mlp_grad_finish_kernel<<<(128 * 33 + 63) / 64, 256, 0, s>>>((const float*)workspace, slabs, 128, 32, (float*)acc, 36);
+  }
+  return cde::check_launch();
+}
