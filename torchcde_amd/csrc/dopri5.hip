@@ -450,12 +450,23 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   // control derivative at a (wave-uniform) time; the row is re-fetched only when the interval changes
   int64_t row_idx = -1;
   Row<DEGREE> row;
+  float dX_lin[MC];                                   // piecewise-linear control: the slope of the interval in use
   auto slope_at = [&](T ts, float (&dX)[MC]) {
     T frac;
     const int64_t idx = locate(kn, g.n_intervals, ts, frac);
-    if (idx != row_idx) { row = load_row<DEGREE>(g.coeffs, sc, g.n_intervals, idx, dims.C); row_idx = idx; }
-    const float width = DEGREE == CDE_PATH_LINEAR ? kn[idx + 1] - kn[idx] : 1.f;
-    control_slope<DEGREE>(row, frac, width, dX);
+    if (idx != row_idx) {
+      row = load_row<DEGREE>(g.coeffs, sc, g.n_intervals, idx, dims.C);
+      row_idx = idx;
+      // the 8 IEEE divisions of a linear slope once per interval, not once per stage (with jump_t on the knots all
+      // stages of an attempt share the interval: the divisions were a fifth of this kernel's VALU instructions)
+      if (DEGREE == CDE_PATH_LINEAR) control_slope<DEGREE>(row, frac, kn[idx + 1] - kn[idx], dX_lin);
+    }
+    if (DEGREE == CDE_PATH_LINEAR) {
+#pragma unroll
+      for (int cc = 0; cc < MC; ++cc) dX[cc] = dX_lin[cc];
+    } else {
+      control_slope<DEGREE>(row, frac, 1.f, dX);
+    }
   };
 
   f32x4 ya, yb, k0a, k0b;
@@ -535,7 +546,12 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
       const T ti = i >= 4 ? next_toward(t1f, -1.f) : t0f + (T)DP_ALPHA[i] * dtf;
       f32x4 ia = {0.f, 0.f, 0.f, 0.f}, ib = ia;
 #pragma unroll
-      for (int j = 0; j <= i; ++j) { const T w = (T)DP_BETA[i][j] * dtf; ia += ka[j] * w; ib += kb[j] * w; }
+      for (int j = 0; j <= i; ++j) {                      // torchdiffeq forms this sum inside a matmul: fused
+        const T w = (T)DP_BETA[i][j] * dtf;               // multiply-adds are as faithful as separate roundings
+        if (DP_BETA[i][j] == 0.0) continue;
+        const f32x4 wv = {w, w, w, w};
+        ia = __builtin_elementwise_fma(ka[j], wv, ia); ib = __builtin_elementwise_fma(kb[j], wv, ib);
+      }
       zia = ya + ia; zib = yb + ib;
       slope_at(ti, dX);
       field(zia, zib, dX, ka[i + 1], kb[i + 1]);
@@ -544,7 +560,10 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
       const T we = dtf * (T)DP_CERR[j], wm = dtf * (T)DP_CMID[j];
-      ea += ka[j] * we; eb += kb[j] * we; ma += ka[j] * wm; mb += kb[j] * wm;
+      if (DP_CERR[j] == 0.0) continue;                    // c_err[1] == c_mid[1] == 0
+      const f32x4 wev = {we, we, we, we}, wmv = {wm, wm, wm, wm};
+      ea = __builtin_elementwise_fma(ka[j], wev, ea); eb = __builtin_elementwise_fma(kb[j], wev, eb);
+      ma = __builtin_elementwise_fma(ka[j], wmv, ma); mb = __builtin_elementwise_fma(kb[j], wmv, mb);
     }
     const f32x4 ta = atol + rtol * max4(abs4(ya), abs4(zia)), tb = atol + rtol * max4(abs4(yb), abs4(zib));
     if (valid) {
