@@ -199,8 +199,9 @@ int cde_rk4_forward_linear(const void* coeffs, const void* knots, int64_t n_inte
  * (example/time_series_classification.py:20-51: Linear(H,128) -> relu -> Linear(128,H*C) -> tanh);
  * replaces the same reference code as K2 plus the user module's two nn.Linear calls per stage.
  *   W1 (width, H), bias1 (width), W2 (H*C, width), bias2 (H*C);  act applies after the second layer.
- * f32 only, H <= 32, C <= 8, width <= 128 (MFMA tiles, zero padded); otherwise CDE_ERR_UNSUPPORTED.
- * Forward solves only: gradients of this family take the step-wise path of the Python layer.
+ * f32 only, width <= 128, and (H <= 32, C <= 8) or (H <= 16, C <= 16) -- the sixteen 16-row MFMA tiles of the
+ * second layer hold 32 hidden units x 8 channels or 16 x 16, zero padded; otherwise CDE_ERR_UNSUPPORTED.
+ * (The 16 x 16 tiling takes the 14-channel depth-3 logsignature control of example/logsignature_example.py:22.)
  * All other arguments as cde_rk4_forward_linear.
  * ------------------------------------------------------------------------------------------- */
 int cde_rk4_forward_mlp(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W1,
@@ -237,7 +238,8 @@ int cde_mlp_grad_reduce(const void* G, const void* X, int64_t rows, int layer, v
  *                                 gradient between output intervals, as torchdiffeq does); `grad_coeffs` is NULL or a
  *                                 caller-zeroed buffer shaped like `coeffs` that accumulates dL/dcoeffs over the calls
  *                                 (as cde_rk4_adjoint_linear_dcontrol)
- * f32, H <= 32, C <= 8, width <= 128.
+ * f32, width <= 128, (H <= 32, C <= 8) or (H <= 16, C <= 16) as K2m; `grad_coeffs` only with C <= 8.  G2's
+ * columns are (hidden unit)*8 + channel for C <= 8 and (hidden unit)*16 + channel for 8 < C <= 16.
  * ------------------------------------------------------------------------------------------- */
 size_t cde_rk4_adjoint_mlp_workspace_bytes(int64_t n_sgrid);
 int cde_rk4_adjoint_mlp_prepare(const void* knots, int64_t n_intervals, const void* sgrid, int64_t n_sgrid,
@@ -369,8 +371,8 @@ int cde_dopri5_advance_sharded(const void* coeffs, const void* knots, int64_t n_
                                int variant, void* workspace, size_t workspace_bytes, int64_t first_launch,
                                const double* reduced_sums, int64_t B_global, void* stream);
 
-/* K4 for the two-layer field of K2m (W1/bias1/width = hidden layer, W2/bias2 = output layer); f32, H <= 32,
- * C <= 8, width <= 128.  Same protocol, workspace (cde_dopri5_workspace_bytes) and status block as
+/* K4 for the two-layer field of K2m (W1/bias1/width = hidden layer, W2/bias2 = output layer); f32, width <= 128,
+ * (H <= 32, C <= 8) or (H <= 16, C <= 16).  Same protocol, workspace (cde_dopri5_workspace_bytes) and status block as
  * cde_dopri5_advance. */
 int cde_dopri5_advance_mlp(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W1,
                            const void* bias1, int64_t width, const void* W2, const void* bias2, int act,

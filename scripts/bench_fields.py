@@ -24,9 +24,12 @@ def main():
     ap.add_argument("--variants", default="mfma,generic")
     ap.add_argument("--batch", type=int, default=32768)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--length", type=int, default=128)
+    ap.add_argument("--channels", type=int, default=8)
+    ap.add_argument("--hidden", type=int, default=32)      # config 5's solve: --field mlp --length 65 --channels 14 --hidden 8
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    B, L, C, H = args.batch, 128, 8, 32
+    B, L, C, H = args.batch, args.length, args.channels, args.hidden
     x = make_series(B, L, C).to(dev)
     coeffs = native.hermite_cubic_coefficients_with_backward_differences(x)
     X = native.CubicSpline(coeffs)

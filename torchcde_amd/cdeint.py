@@ -357,8 +357,9 @@ class _MlpPlan:
             i_out = self.n_out - 1 - p
             y.copy_(z_saved[:, i_out - 1])                 # torchdiffeq: re-seed z from the stored forward solution
             a += grad_out[:, i_out - 1]                    # and add the incoming gradient at that output time
-        grad_w2 = acc2[:, :width].reshape(32, 8, width)[:H, :C].reshape(H * C, width)
-        grad_b2 = acc2[:, 128].reshape(32, 8)[:H, :C].reshape(H * C)
+        units, channels = (32, 8) if C <= 8 else (16, 16)        # padded (hidden unit, channel) layout of the G2 rows
+        grad_w2 = acc2[:, :width].reshape(units, channels, width)[:H, :C].reshape(H * C, width)
+        grad_b2 = acc2[:, 128].reshape(units, channels)[:H, :C].reshape(H * C)
         grad_w1 = acc1[:width, :H].contiguous()
         grad_b1 = acc1[:width, 32].contiguous()
         return a.reshape(*self.batch, H), grad_w1, grad_b1, grad_w2, grad_b2, grad_x
@@ -390,7 +391,9 @@ class _FusedMlpRK4(torch.autograd.Function):
 
 def _mlp_fusable(field, H, C, z0, packed):
     w1, w2 = field.hidden.weight, field.output.weight
-    return (z0.dtype == packed.dtype == w1.dtype == w2.dtype == torch.float32 and H <= 32 and C <= 8
+    # tiles of the two-layer kernels: 32 hidden units x 8 channels, or 16 x 16 (cde_mi355x.h: cde_rk4_forward_mlp)
+    return (z0.dtype == packed.dtype == w1.dtype == w2.dtype == torch.float32
+            and ((H <= 32 and C <= 8) or (H <= 16 and C <= 16))
             and w1.size(0) <= 128 and tuple(w1.shape) == (w1.size(0), H) and tuple(w2.shape) == (H * C, w1.size(0)))
 
 
@@ -860,6 +863,8 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
                          and all(isinstance(p, torch.Tensor) and p is not X._t
                                  and p.untyped_storage().data_ptr() in storages for p in extra))
         mlp_want_x = mlp_params_ok and any(p.requires_grad for p in extra) and grad_mode
+        if mlp_want_x and C > 8:
+            mlp = None                # control gradients come out of the 8-channel sweep only: step-wise instead
     if (mlp is not None and wants_grad and not wants_t and adjoint and method == "rk4"
             and variant != _lib.VARIANT_GENERIC
             and set(options or ()) <= {"step_size"} and set(kwargs.get("adjoint_options") or ()) <= {"step_size"}

@@ -49,24 +49,26 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
 
 // one control row held in registers, always in the 8-channel layout (missing channels are zero):
 // cubic -> b, 2c, 3d (24 floats); linear -> x[idx], x[idx+1] (16 floats)
-template <int DEGREE>
+// CT: channels of the tile layout (8 everywhere; 16 in the two-layer kernels' wide variant: 16 channels x 16 hidden units)
+template <int DEGREE, int CT = MC>
 struct Row {
-  float4 v[DEGREE == CDE_PATH_CUBIC ? 6 : 4];
+  float4 v[(DEGREE == CDE_PATH_CUBIC ? 3 : 2) * CT / 4];
 };
 
-template <int DEGREE>
-__device__ __forceinline__ Row<DEGREE> load_row(const float* __restrict__ coeffs, int64_t series, int64_t n_intervals,
-                                                 int64_t idx, int C = MC) {
-  Row<DEGREE> r;
-  if (C == MC) {                                   // 16-byte vector loads (rows are 16-byte aligned when C == 8)
+template <int DEGREE, int CT = MC>
+__device__ __forceinline__ Row<DEGREE, CT> load_row(const float* __restrict__ coeffs, int64_t series,
+                                                     int64_t n_intervals, int64_t idx, int C = CT) {
+  Row<DEGREE, CT> r;
+  constexpr int NV = (DEGREE == CDE_PATH_CUBIC ? 3 : 2) * CT / 4;
+  if (C == CT) {                                   // 16-byte vector loads (rows are 16-byte aligned when C == CT)
     if (DEGREE == CDE_PATH_CUBIC) {
-      const float4* p = reinterpret_cast<const float4*>(coeffs + (series * n_intervals + idx) * 4 * MC + MC);
+      const float4* p = reinterpret_cast<const float4*>(coeffs + (series * n_intervals + idx) * 4 * CT + CT);
 #pragma unroll
-      for (int i = 0; i < 6; ++i) r.v[i] = p[i];
+      for (int i = 0; i < NV; ++i) r.v[i] = p[i];
     } else {
-      const float4* p = reinterpret_cast<const float4*>(coeffs + (series * (n_intervals + 1) + idx) * MC);
+      const float4* p = reinterpret_cast<const float4*>(coeffs + (series * (n_intervals + 1) + idx) * CT);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) r.v[i] = p[i];
+      for (int i = 0; i < NV; ++i) r.v[i] = p[i];
     }
   } else {                                         // narrower control: scalar loads into the padded layout
     float* f = reinterpret_cast<float*>(r.v);
@@ -75,13 +77,13 @@ __device__ __forceinline__ Row<DEGREE> load_row(const float* __restrict__ coeffs
 #pragma unroll
       for (int part = 0; part < 3; ++part)
 #pragma unroll
-        for (int c = 0; c < MC; ++c) f[part * MC + c] = c < C ? p[(part + 1) * C + c] : 0.f;
+        for (int c = 0; c < CT; ++c) f[part * CT + c] = c < C ? p[(part + 1) * C + c] : 0.f;
     } else {
       const float* p = coeffs + (series * (n_intervals + 1) + idx) * C;
 #pragma unroll
       for (int part = 0; part < 2; ++part)
 #pragma unroll
-        for (int c = 0; c < MC; ++c) f[part * MC + c] = c < C ? p[part * C + c] : 0.f;
+        for (int c = 0; c < CT; ++c) f[part * CT + c] = c < C ? p[part * C + c] : 0.f;
     }
   }
   return r;
@@ -107,13 +109,13 @@ __device__ __forceinline__ void store_units4(float* __restrict__ row, int unit, 
   for (int i = 0; i < 4; ++i) if (unit + i * STRIDE < H) row[unit + i * STRIDE] = v[i];
 }
 
-template <int DEGREE>
-__device__ __forceinline__ void control_slope(const Row<DEGREE>& r, float frac, float width, float (&dX)[MC]) {
+template <int DEGREE, int CT = MC>
+__device__ __forceinline__ void control_slope(const Row<DEGREE, CT>& r, float frac, float width, float (&dX)[CT]) {
   const float* f = reinterpret_cast<const float*>(r.v);
 #pragma unroll
-  for (int c = 0; c < MC; ++c) {
-    if (DEGREE == CDE_PATH_CUBIC) dX[c] = cubic_derivative(f[c], f[MC + c], f[2 * MC + c], frac);
-    else dX[c] = (f[MC + c] - f[c]) / width;
+  for (int c = 0; c < CT; ++c) {
+    if (DEGREE == CDE_PATH_CUBIC) dX[c] = cubic_derivative(f[c], f[CT + c], f[2 * CT + c], frac);
+    else dX[c] = (f[CT + c] - f[c]) / width;
   }
 }
 
@@ -246,8 +248,9 @@ __device__ __forceinline__ float wy16_image(const float* __restrict__ W, int T, 
   const int h = 4 * (T >> 1) + (i >> 2), c = 4 * (T & 1) + (i & 3), k = 4 * s + kq;
   return (h < d.H && c < d.C && k < d.H) ? W[(h * d.C + c) * d.H + k] : 0.f;
 }
-__device__ __forceinline__ float by16_image(const float* __restrict__ bias, int T, int q, int r, Dims d) {
-  const int h = 4 * (T >> 1) + q, c = 4 * (T & 1) + r;
+// nb = channel blocks of 4 per unit group: 2 (8 channels x 32 units) or 4 (16 channels x 16 units); 16 tiles either way
+__device__ __forceinline__ float by16_image(const float* __restrict__ bias, int T, int q, int r, Dims d, int nb = 2) {
+  const int h = 4 * (T / nb) + q, c = 4 * (T % nb) + r;
   return (h < d.H && c < d.C) ? bias[h * d.C + c] : 0.f;
 }
 
@@ -350,11 +353,12 @@ constexpr int B1M_FLOATS = 8 * 4 * 4;                // [tile][q][r]
 constexpr int W2M_FLOATS = 16 * 8 * 64 * 4;          // layer 2: 16 tiles x 8 groups of 4 K steps
 constexpr int MLP16_LDS_FLOATS = W1M_FLOATS + B1M_FLOATS + W2M_FLOATS + BY_FLOATS;
 struct MlpDims { int H, C, width; };
+bool mlp_shape_ok(int64_t C, int64_t H, int64_t width);     // rk4_mfma.hip
 
 // value of the combined image [layer-1 weights | layer-1 bias | layer-2 weights | layer-2 bias] at flat index e
 __device__ __forceinline__ float mlp16_image(const float* __restrict__ W1, const float* __restrict__ b1,
                                              const float* __restrict__ W2, const float* __restrict__ b2, int e,
-                                             MlpDims d) {
+                                             MlpDims d, int nb = 2) {
   if (e < W1M_FLOATS) {
     const int j = e & 3, l = (e >> 2) & 63, g = e >> 8;              // g = 2*T1 + (s>>2)
     const int row = 16 * (g >> 1) + (l & 15), k = 4 * (4 * (g & 1) + j) + (l >> 4);
@@ -369,24 +373,27 @@ __device__ __forceinline__ float mlp16_image(const float* __restrict__ W1, const
   if (e < W2M_FLOATS) {
     const int j = e & 3, l = (e >> 2) & 63, g = e >> 8;              // g = 8*T2 + T1, K step (T1, r = j)
     const int T2 = g >> 3, T1 = g & 7, i = l & 15, kq = l >> 4;
-    const int h = 4 * (T2 >> 1) + (i >> 2), c = 4 * (T2 & 1) + (i & 3), col = 16 * T1 + 4 * kq + j;
+    const int h = 4 * (T2 / nb) + (i >> 2), c = 4 * (T2 % nb) + (i & 3), col = 16 * T1 + 4 * kq + j;
     return (h < d.H && c < d.C && col < d.width) ? W2[(h * d.C + c) * d.width + col] : 0.f;
   }
   e -= W2M_FLOATS;
-  return by16_image(b2, e >> 4, (e >> 2) & 3, e & 3, Dims{d.H, d.C});
+  return by16_image(b2, e >> 4, (e >> 2) & 3, e & 3, Dims{d.H, d.C}, nb);
 }
 
 __device__ __forceinline__ void stage_mlp16(const float* __restrict__ W1, const float* __restrict__ b1,
                                             const float* __restrict__ W2, const float* __restrict__ b2, float* lds,
-                                            MlpDims d) {
-  for (int e = threadIdx.x; e < MLP16_LDS_FLOATS; e += blockDim.x) lds[e] = mlp16_image(W1, b1, W2, b2, e, d);
+                                            MlpDims d, int nb = 2) {
+  for (int e = threadIdx.x; e < MLP16_LDS_FLOATS; e += blockDim.x) lds[e] = mlp16_image(W1, b1, W2, b2, e, d, nb);
   __syncthreads();
 }
 
-// img = staged images + nothing else; lane (n, q): za/zb = units q, 4+q, .., 28+q of series n
-template <int ACT>
+// img = staged images + nothing else; lane (n, q): za/zb = units q, 4+q, .., 28+q of series n.
+// CT = 8: 8 unit groups P of 2 tiles (4 units x 8 channels each); CT = 16: 4 unit groups of 4 tiles (4 units x 16
+// channels; units 16.. do not exist: zb is zero in, fb zero out).  Tile index T = (CT/4) P + tb in both cases.
+template <int ACT, int CT = MC>
 __device__ __forceinline__ void field_mlp16(const float* img, int lane, int q, const f32x4& za, const f32x4& zb,
-                                            const float (&dX)[MC], f32x4& fa, f32x4& fb) {
+                                            const float (&dX)[CT], f32x4& fa, f32x4& fb) {
+  constexpr int NB = CT / 4, NP = 16 / NB;
   int opaque = 0;                             // as in field_act16: keeps the LDS reads inside the call
   asm volatile("" : "+v"(opaque));
   const float4* w1 = reinterpret_cast<const float4*>(img) + lane + opaque;
@@ -408,27 +415,41 @@ __device__ __forceinline__ void field_mlp16(const float* img, int lane, int q, c
 #pragma unroll
     for (int r = 0; r < 4; ++r) { u[8 * TP + r] = fmaxf(y0[r], 0.f); u[8 * TP + 4 + r] = fmaxf(y1[r], 0.f); }
   }
-  // ---- layer 2 + activation + contraction, one tile pair (4 hidden units x 8 channels) at a time
+  // ---- layer 2 + activation + contraction, one unit group (4 hidden units x CT channels = NB tiles) at a time
+  fa = f32x4{0.f, 0.f, 0.f, 0.f};
+  fb = fa;
 #pragma unroll
-  for (int P = 0; P < 8; ++P) {
-    const float4 c0 = bb2[8 * P], c1 = bb2[8 * P + 4];
-    f32x4 y0 = {c0.x, c0.y, c0.z, c0.w}, y1 = {c1.x, c1.y, c1.z, c1.w};
-    const float4* t0 = w2 + (16 * P) * 64;           // tile 2P:   groups 16P .. 16P+7
-    const float4* t1 = w2 + (16 * P + 8) * 64;       // tile 2P+1: groups 16P+8 .. 16P+15
+  for (int P = 0; P < NP; ++P) {
+    f32x4 y[NB];
+#pragma unroll
+    for (int tb = 0; tb < NB; ++tb) {
+      const float4 c0 = bb2[4 * (NB * P + tb)];
+      y[tb] = f32x4{c0.x, c0.y, c0.z, c0.w};
+    }
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
-      const float4 a0 = t0[g * 64], a1 = t1[g * 64];
-      y0 = mfma16(a0.x, u[4 * g], y0);     y1 = mfma16(a1.x, u[4 * g], y1);
-      y0 = mfma16(a0.y, u[4 * g + 1], y0); y1 = mfma16(a1.y, u[4 * g + 1], y1);
-      y0 = mfma16(a0.z, u[4 * g + 2], y0); y1 = mfma16(a1.z, u[4 * g + 2], y1);
-      y0 = mfma16(a0.w, u[4 * g + 3], y0); y1 = mfma16(a1.w, u[4 * g + 3], y1);
+      float4 a[NB];
+#pragma unroll
+      for (int tb = 0; tb < NB; ++tb) a[tb] = w2[(8 * (NB * P + tb) + g) * 64];    // tile NB*P + tb: groups 8T .. 8T+7
+      // the NB accumulator chains alternate, so no MFMA waits for its own predecessor
+#pragma unroll
+      for (int tb = 0; tb < NB; ++tb) y[tb] = mfma16(a[tb].x, u[4 * g], y[tb]);
+#pragma unroll
+      for (int tb = 0; tb < NB; ++tb) y[tb] = mfma16(a[tb].y, u[4 * g + 1], y[tb]);
+#pragma unroll
+      for (int tb = 0; tb < NB; ++tb) y[tb] = mfma16(a[tb].z, u[4 * g + 2], y[tb]);
+#pragma unroll
+      for (int tb = 0; tb < NB; ++tb) y[tb] = mfma16(a[tb].w, u[4 * g + 3], y[tb]);
     }
-    const f32x2 t01 = activate2<ACT>(y0[0], y0[1]), t23 = activate2<ACT>(y0[2], y0[3]);
-    const f32x2 t45 = activate2<ACT>(y1[0], y1[1]), t67 = activate2<ACT>(y1[2], y1[3]);
-    float f = t01[0] * dX[0];
-    f = __builtin_fmaf(t01[1], dX[1], f); f = __builtin_fmaf(t23[0], dX[2], f); f = __builtin_fmaf(t23[1], dX[3], f);
-    f = __builtin_fmaf(t45[0], dX[4], f); f = __builtin_fmaf(t45[1], dX[5], f);
-    f = __builtin_fmaf(t67[0], dX[6], f); f = __builtin_fmaf(t67[1], dX[7], f);
+    float f = 0.f;
+#pragma unroll
+    for (int tb = 0; tb < NB; ++tb) {
+      const f32x2 t01 = activate2<ACT>(y[tb][0], y[tb][1]), t23 = activate2<ACT>(y[tb][2], y[tb][3]);
+      f = (tb == 0) ? t01[0] * dX[0] : __builtin_fmaf(t01[0], dX[4 * tb], f);
+      f = __builtin_fmaf(t01[1], dX[4 * tb + 1], f);
+      f = __builtin_fmaf(t23[0], dX[4 * tb + 2], f);
+      f = __builtin_fmaf(t23[1], dX[4 * tb + 3], f);
+    }
     if (P < 4) fa[P] = f; else fb[P - 4] = f;
     __builtin_amdgcn_sched_barrier(0);
   }

@@ -375,7 +375,7 @@ __device__ __forceinline__ double sq4(const f32x4& v) {
   return (double)(v[0] * v[0]) + (double)(v[1] * v[1]) + (double)(v[2] * v[2]) + (double)(v[3] * v[3]);
 }
 
-template <int DEGREE, int ACT, bool MLP = false>
+template <int DEGREE, int ACT, bool MLP = false, int CT = MC>
 __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g, int parity) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using T = float;
@@ -441,31 +441,33 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   const int u0 = PRODUCT ? 8 * q : q, u1 = PRODUCT ? 8 * q + 4 : 16 + q;
   const float4* wy = reinterpret_cast<const float4*>(img_lds) + lane;
   const float4* by = reinterpret_cast<const float4*>(img_lds + WY_FLOATS) + q;
-  auto field = [&](const f32x4& za, const f32x4& zb, const float (&dXv)[MC], f32x4& fa, f32x4& fb) {
-    if constexpr (PRODUCT) field16(wA, wB, za, zb, dXv, q, fa, fb);
-    else if constexpr (MLP) field_mlp16<ACT>(img_lds, lane, q, za, zb, dXv, fa, fb);
-    else field_act16<ACT>(wy, by, za, zb, dXv, fa, fb);
+  auto field = [&](const f32x4& za, const f32x4& zb, const float (&dXv)[CT], f32x4& fa, f32x4& fb) {
+    if constexpr (MLP) field_mlp16<ACT, CT>(img_lds, lane, q, za, zb, dXv, fa, fb);
+    else if constexpr (CT == MC) {
+      if constexpr (PRODUCT) field16(wA, wB, za, zb, dXv, q, fa, fb);
+      else field_act16<ACT>(wy, by, za, zb, dXv, fa, fb);
+    }
   };
 
   // control derivative at a (wave-uniform) time; the row is re-fetched only when the interval changes
   int64_t row_idx = -1;
-  Row<DEGREE> row;
-  float dX_lin[MC];                                   // piecewise-linear control: the slope of the interval in use
-  auto slope_at = [&](T ts, float (&dX)[MC]) {
+  Row<DEGREE, CT> row;
+  float dX_lin[CT];                                   // piecewise-linear control: the slope of the interval in use
+  auto slope_at = [&](T ts, float (&dX)[CT]) {
     T frac;
     const int64_t idx = locate(kn, g.n_intervals, ts, frac);
     if (idx != row_idx) {
-      row = load_row<DEGREE>(g.coeffs, sc, g.n_intervals, idx, dims.C);
+      row = load_row<DEGREE, CT>(g.coeffs, sc, g.n_intervals, idx, dims.C);
       row_idx = idx;
       // the 8 IEEE divisions of a linear slope once per interval, not once per stage (with jump_t on the knots all
       // stages of an attempt share the interval: the divisions were a fifth of this kernel's VALU instructions)
-      if (DEGREE == CDE_PATH_LINEAR) control_slope<DEGREE>(row, frac, kn[idx + 1] - kn[idx], dX_lin);
+      if (DEGREE == CDE_PATH_LINEAR) control_slope<DEGREE, CT>(row, frac, kn[idx + 1] - kn[idx], dX_lin);
     }
     if (DEGREE == CDE_PATH_LINEAR) {
 #pragma unroll
-      for (int cc = 0; cc < MC; ++cc) dX[cc] = dX_lin[cc];
+      for (int cc = 0; cc < CT; ++cc) dX[cc] = dX_lin[cc];
     } else {
-      control_slope<DEGREE>(row, frac, 1.f, dX);
+      control_slope<DEGREE, CT>(row, frac, 1.f, dX);
     }
   };
 
@@ -511,7 +513,7 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
     }
   }
 
-  float dX[MC];
+  float dX[CT];
   if (mode == 0) {
     slope_at((T)c.t_hi, dX);
     field(ya, yb, dX, k0a, k0b);
@@ -620,9 +622,9 @@ __global__ void wy16_image_kernel(const float* __restrict__ W, const float* __re
 }
 __global__ void mlp16_image_kernel(const float* __restrict__ W1, const float* __restrict__ b1,
                                    const float* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ img,
-                                   MlpDims d) {
+                                   MlpDims d, int nb) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < MLP16_LDS_FLOATS) img[e] = mlp16_image(W1, b1, W2, b2, e, d);
+  if (e < MLP16_LDS_FLOATS) img[e] = mlp16_image(W1, b1, W2, b2, e, d, nb);
 }
 static_assert(ACT16_LDS_FLOATS <= W16_FLOATS && W16_FLOATS <= MLP16_LDS_FLOATS, "all image forms share one workspace slot");
 constexpr size_t DOPRI_IMAGE_BYTES = (size_t)MLP16_LDS_FLOATS * sizeof(float);
@@ -662,7 +664,7 @@ static int dopri5_advance_impl(const void* coeffs, const void* knots, int64_t n_
   const bool mlp = W1 != nullptr;
   if (B < 1 || C < 1 || H < 1 || H > 256 || n_intervals < 1 || n_out < 1 || n_launches < 0 || n_jump < 0) return CDE_ERR_SHAPE;
   if (mlp && (width < 1 || !bias1)) return width < 1 ? CDE_ERR_SHAPE : CDE_ERR_NULL;
-  if (mlp && (dtype != CDE_F32 || H > cde::MH || C > cde::MC || width > cde::MW || variant == CDE_VARIANT_GENERIC))
+  if (mlp && (dtype != CDE_F32 || !cde::mlp_shape_ok(C, H, width) || variant == CDE_VARIANT_GENERIC))
     return CDE_ERR_UNSUPPORTED;
   if (act != CDE_ACT_NONE && act != CDE_ACT_TANH) return CDE_ERR_UNSUPPORTED;
   if (degree != CDE_PATH_CUBIC && degree != CDE_PATH_LINEAR) return CDE_ERR_UNSUPPORTED;
@@ -706,16 +708,20 @@ static int dopri5_advance_impl(const void* coeffs, const void* knots, int64_t n_
       if (first_launch == 0)
         cde::mlp16_image_kernel<<<(cde::MLP16_LDS_FLOATS + 255) / 256, 256, 0, s>>>(
             (const float*)W1, (const float*)bias1, (const float*)W, (const float*)bias, w16,
-            cde::MlpDims{(int)H, (int)C, (int)width});
+            cde::MlpDims{(int)H, (int)C, (int)width}, C > cde::MC ? 4 : 2);
       const size_t lds = 2 * 512 * sizeof(double) +
                          (n_knots <= cde::DOPRI_MAX_LDS_KNOTS_MLP ? (size_t)((n_knots + 3) / 4 * 4) * sizeof(float) : 0) +
                          cde::DOPRI_IMAGE_BYTES;
-#define CDE_MLP(D, A)                                                                                              \
+#define CDE_MLP_CT(D, A, CTV)                                                                                      \
   do {                                                                                                             \
-    (void)hipFuncSetAttribute((const void*)cde::dopri5_attempt_mfma<D, A, true>,                                   \
+    (void)hipFuncSetAttribute((const void*)cde::dopri5_attempt_mfma<D, A, true, CTV>,                              \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
     for (int64_t i = 0; i < n_launches; ++i)                                                                       \
-      cde::dopri5_attempt_mfma<D, A, true><<<grid, 512, lds, s>>>(g, (int)((first_launch + i) & 1));               \
+      cde::dopri5_attempt_mfma<D, A, true, CTV><<<grid, 512, lds, s>>>(g, (int)((first_launch + i) & 1));          \
+  } while (0)
+#define CDE_MLP(D, A)                                                                                              \
+  do {                                                                                                             \
+    if (C > cde::MC) CDE_MLP_CT(D, A, 16); else CDE_MLP_CT(D, A, cde::MC);                                         \
   } while (0)
       if (act == CDE_ACT_NONE) {
         if (degree == CDE_PATH_CUBIC) CDE_MLP(CDE_PATH_CUBIC, CDE_ACT_NONE); else CDE_MLP(CDE_PATH_LINEAR, CDE_ACT_NONE);
@@ -723,6 +729,7 @@ static int dopri5_advance_impl(const void* coeffs, const void* knots, int64_t n_
         if (degree == CDE_PATH_CUBIC) CDE_MLP(CDE_PATH_CUBIC, CDE_ACT_TANH); else CDE_MLP(CDE_PATH_LINEAR, CDE_ACT_TANH);
       }
 #undef CDE_MLP
+#undef CDE_MLP_CT
       return cde::check_launch();
     }
     if (first_launch == 0) {

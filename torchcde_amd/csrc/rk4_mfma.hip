@@ -53,7 +53,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 template <int ACT, bool MLP> constexpr int fwd_block_threads() { return 512; }
 template <int ACT, bool MLP> constexpr int fwd_waves_per_simd() { return 2; }
 
-template <typename TT, int DEGREE, int ACT, bool MLP = false>
+template <typename TT, int DEGREE, int ACT, bool MLP = false, int CT = MC>
 __global__ __launch_bounds__((fwd_block_threads<ACT, MLP>()), (fwd_waves_per_simd<ACT, MLP>())) void rk4_forward_mfma(
     const float* __restrict__ coeffs, const float* __restrict__ knots, int64_t n_intervals,
     const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ z0,
@@ -67,7 +67,7 @@ __global__ __launch_bounds__((fwd_block_threads<ACT, MLP>()), (fwd_waves_per_sim
   constexpr int STRIDE = PRODUCT ? 1 : 4;          // distance between a lane's consecutive hidden units
   float4 wA[PRODUCT ? W16_GROUPS : 1], wB[PRODUCT ? W16_GROUPS : 1];
   if constexpr (PRODUCT) load_w16(W, bias, lds, wA, wB, dims);
-  else if constexpr (MLP) stage_mlp16(W1, bias1, W, bias, lds, MlpDims{dims.H, dims.C, width});
+  else if constexpr (MLP) stage_mlp16(W1, bias1, W, bias, lds, MlpDims{dims.H, dims.C, width}, CT / 4);
   else stage_wy16(W, bias, lds, dims);
   const int Hr = dims.H, Cr = dims.C;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__((fwd_block_threads<ACT, MLP>()), (fwd_waves_per_sim
 
   int64_t idx = stage_index[0];
   float frac = stage_frac[0];
-  Row<DEGREE> row = load_row<DEGREE>(coeffs, sc, n_intervals, idx, Cr);
+  Row<DEGREE, CT> row = load_row<DEGREE, CT>(coeffs, sc, n_intervals, idx, Cr);
 
   for (int64_t k = 0; k < n_steps; ++k) {
     const TT t0 = grid[k], t1 = grid[k + 1];
@@ -109,9 +109,9 @@ __global__ __launch_bounds__((fwd_block_threads<ACT, MLP>()), (fwd_waves_per_sim
     f32x4 k1a, k1b, k2a, k2b, pqa, pqb, za = ya, zb = yb;
 #pragma unroll
     for (int stage = 0; stage < 4; ++stage) {
-      float dX[MC];
+      float dX[CT];
       const float width = DEGREE == CDE_PATH_LINEAR ? knots[idx + 1] - knots[idx] : 1.f;
-      control_slope<DEGREE>(row, frac, width, dX);
+      control_slope<DEGREE, CT>(row, frac, width, dX);
       // prefetch the next stage's table entry and (if the interval changes) its control row
       const int64_t e_next = 4 * k + stage + 1;
       const bool more = e_next < 4 * n_steps;
@@ -120,16 +120,16 @@ __global__ __launch_bounds__((fwd_block_threads<ACT, MLP>()), (fwd_waves_per_sim
       // product form: the next row is fetched before the MFMA chain (its latency hides behind it); the activation
       // forms are register-bound, so they fetch it after the field evaluation (it then lands during the RK tail of
       // this wave / the MFMA phase of the other waves on the SIMD)
-      Row<DEGREE> nrow = row;
-      if constexpr (PRODUCT) { if (nidx != idx) nrow = load_row<DEGREE>(coeffs, sc, n_intervals, nidx, Cr); }
+      Row<DEGREE, CT> nrow = row;
+      if constexpr (PRODUCT) { if (nidx != idx) nrow = load_row<DEGREE, CT>(coeffs, sc, n_intervals, nidx, Cr); }
 
       f32x4 fa, fb;
-      if constexpr (PRODUCT) field16(wA, wB, za, zb, dX, q, fa, fb);
-      else if constexpr (MLP) field_mlp16<ACT>(lds, lane, q, za, zb, dX, fa, fb);
-      else field_act16<ACT>(wy, by, za, zb, dX, fa, fb);
+      if constexpr (PRODUCT) { if constexpr (CT == MC) field16(wA, wB, za, zb, dX, q, fa, fb); }
+      else if constexpr (MLP) field_mlp16<ACT, CT>(lds, lane, q, za, zb, dX, fa, fb);
+      else { if constexpr (CT == MC) field_act16<ACT>(wy, by, za, zb, dX, fa, fb); }
       if constexpr (!PRODUCT) {
         __builtin_amdgcn_sched_barrier(0);
-        if (nidx != idx) nrow = load_row<DEGREE>(coeffs, sc, n_intervals, nidx, Cr);
+        if (nidx != idx) nrow = load_row<DEGREE, CT>(coeffs, sc, n_intervals, nidx, Cr);
       }
 
       // torchdiffeq rk4_alt_step_func (3/8 rule), association order preserved
@@ -739,6 +739,11 @@ __global__ __launch_bounds__(256) void reduce_mfma_partials(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------ host side
+// shapes the two-layer kernels take: the 16 output tiles hold 32 units x 8 channels or 16 units x 16 channels
+bool mlp_shape_ok(int64_t C, int64_t H, int64_t width) {
+  return width >= 1 && width <= MW && H >= 1 && C >= 1 && ((C <= MC && H <= MH) || (C <= 16 && H <= 16));
+}
+
 int launch_reduce_partials(const float* partial, int64_t n_tiles, void* grad_W, void* grad_b, int H, int C, hipStream_t s) {
   reduce_mfma_partials<<<(unsigned)((H * C * H + H * C + 255) / 256), 256, 0, s>>>(partial, n_tiles, (float*)grad_W,
                                                                                  (float*)grad_b, Dims{H, C});
@@ -781,20 +786,25 @@ int launch_forward_mlp(const void* coeffs, const void* knots, int64_t n_interval
                        const void* bias1, int64_t width, const void* W2, const void* bias2, int act, const void* z0,
                        const void* grid, int64_t n_grid, const void* t_out, int64_t n_out, void* z_out, int64_t B,
                        int64_t C, int64_t H, const int64_t* stage_index, const void* stage_frac, hipStream_t s) {
-  if (H < 1 || H > MH || C < 1 || C > MC || width < 1 || width > MW) return CDE_ERR_UNSUPPORTED;
+  if (!mlp_shape_ok(C, H, width)) return CDE_ERR_UNSUPPORTED;
   if (degree != CDE_PATH_CUBIC && degree != CDE_PATH_LINEAR) return CDE_ERR_UNSUPPORTED;
   if (act != CDE_ACT_NONE && act != CDE_ACT_TANH) return CDE_ERR_UNSUPPORTED;
   const Dims dims{(int)H, (int)C};
   const unsigned blocks = (unsigned)((B + 127) / 128);
   const size_t lds = (size_t)MLP16_LDS_FLOATS * sizeof(float);
-#define CDE_FWD(D, A)                                                                                               \
+  const bool wide = C > MC;                 // 16 channels x 16 hidden units on the same 16 tiles
+#define CDE_FWD_CT(D, A, CTV)                                                                                       \
   do {                                                                                                              \
-    (void)hipFuncSetAttribute((const void*)rk4_forward_mfma<TT, D, A, true>,                                        \
+    (void)hipFuncSetAttribute((const void*)rk4_forward_mfma<TT, D, A, true, CTV>,                                   \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
-    rk4_forward_mfma<TT, D, A, true><<<blocks, 512, lds, s>>>(                                                      \
+    rk4_forward_mfma<TT, D, A, true, CTV><<<blocks, 512, lds, s>>>(                                                 \
         (const float*)coeffs, (const float*)knots, n_intervals, (const float*)W2, (const float*)bias2,              \
         (const float*)z0, (const TT*)grid, n_grid, (const TT*)t_out, n_out, (float*)z_out, B, stage_index,          \
         (const float*)stage_frac, dims, (const float*)W1, (const float*)bias1, (int)width);                         \
+  } while (0)
+#define CDE_FWD(D, A)                                                                                               \
+  do {                                                                                                              \
+    if (wide) CDE_FWD_CT(D, A, 16); else CDE_FWD_CT(D, A, MC);                                                      \
   } while (0)
   if (act == CDE_ACT_NONE) {
     if (degree == CDE_PATH_CUBIC) CDE_FWD(CDE_PATH_CUBIC, CDE_ACT_NONE); else CDE_FWD(CDE_PATH_LINEAR, CDE_ACT_NONE);
@@ -802,6 +812,7 @@ int launch_forward_mlp(const void* coeffs, const void* knots, int64_t n_interval
     if (degree == CDE_PATH_CUBIC) CDE_FWD(CDE_PATH_CUBIC, CDE_ACT_TANH); else CDE_FWD(CDE_PATH_LINEAR, CDE_ACT_TANH);
   }
 #undef CDE_FWD
+#undef CDE_FWD_CT
   return check_launch();
 }
 

@@ -44,12 +44,12 @@ constexpr int U_COLS = 132, G2_COLS = 256, G1_COLS = 128, Z_COLS = 36;
 
 __device__ __forceinline__ float mlp_adj_image(const float* __restrict__ W1, const float* __restrict__ b1,
                                                const float* __restrict__ W2, const float* __restrict__ b2, int e,
-                                               MlpDims d) {
-  if (e < W1M_FLOATS + B1M_FLOATS) return mlp16_image(W1, b1, W2, b2, e, d);        // same layer-1 image as K2m
+                                               MlpDims d, int nb) {
+  if (e < W1M_FLOATS + B1M_FLOATS) return mlp16_image(W1, b1, W2, b2, e, d, nb);    // same layer-1 image as K2m
   e -= W1M_FLOATS + B1M_FLOATS;
   if (e < W2P_FLOATS) {
     const int pr = e / W2P_STRIDE, col = e - pr * W2P_STRIDE;
-    const int r8 = pr & 7, hi = pr >> 3, hb = hi & 1, tb = (hi >> 1) & 1, P = hi >> 2;
+    const int r8 = pr & 7, hi = pr >> 3, hb = hi & 1, T = hi >> 1, tb = T % nb, P = T / nb;   // tile T = nb*P + tb
     // invert w2p_residue: r8 = (2*(h&3) + g(c&3)) % 8 with (h&3)>>1 == hb
     int h3 = 0, c3 = 0;
     for (int hh = 2 * hb; hh < 2 * hb + 2; ++hh)
@@ -59,7 +59,7 @@ __device__ __forceinline__ float mlp_adj_image(const float* __restrict__ W1, con
     return (col < d.width && h < d.H && c < d.C) ? W2[(h * d.C + c) * d.width + col] : 0.f;
   }
   e -= W2P_FLOATS;
-  if (e < BY_FLOATS) return by16_image(b2, e >> 4, (e >> 2) & 3, e & 3, Dims{d.H, d.C});
+  if (e < BY_FLOATS) return by16_image(b2, e >> 4, (e >> 2) & 3, e & 3, Dims{d.H, d.C}, nb);
   e -= BY_FLOATS;
   // va tile T (row i <-> z unit 4*(4T + (i&3)) + (i>>2), so register r of lane (n, q) is unit 4*(4T+r) + q),
   // K step (T1, r = j): lane quarter kq feeds hidden-layer unit 16*T1 + 4*kq + j
@@ -71,9 +71,9 @@ __device__ __forceinline__ float mlp_adj_image(const float* __restrict__ W1, con
 
 __global__ void mlp_adj_image_kernel(const float* __restrict__ W1, const float* __restrict__ b1,
                                      const float* __restrict__ W2, const float* __restrict__ b2,
-                                     float* __restrict__ img, MlpDims d) {
+                                     float* __restrict__ img, MlpDims d, int nb) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < MLP_ADJ_IMAGE_FLOATS) img[e] = mlp_adj_image(W1, b1, W2, b2, e, d);
+  if (e < MLP_ADJ_IMAGE_FLOATS) img[e] = mlp_adj_image(W1, b1, W2, b2, e, d, nb);
 }
 
 __device__ __forceinline__ void stream_store4(float* p, float a, float b, float c, float d) {
@@ -84,7 +84,7 @@ __device__ __forceinline__ void stream_store4(float* p, float a, float b, float 
 // DCOEFF: also accumulate dL/d(control coefficients) into `grad_coeffs` (zeroed by the caller, layout of `coeffs`),
 // as K3a does: d(a.f)/d(dX_c) = sum_h a_h act(Y2)_hc, here summed in-lane over the lane's 8 hidden units and then
 // over the four lane quarters with two shuffles; quarter q carries channels 2q, 2q+1 to the coefficient row.
-template <typename TT, int DEGREE, int ACT, bool DCOEFF = false>
+template <typename TT, int DEGREE, int ACT, bool DCOEFF = false, int CT = MC>
 __global__ __launch_bounds__(512, 2) void rk4_adjoint_mlp_sweep(
     const float* __restrict__ coeffs, const float* __restrict__ knots, int64_t n_intervals,
     const float* __restrict__ img, float* __restrict__ y_state, float* __restrict__ a_state,
@@ -98,6 +98,8 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_mlp_sweep(
     for (int i = threadIdx.x; i < ADJ_LDS_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
   }
   __syncthreads();
+  constexpr int NB = CT / 4, NP = 16 / NB;      // channel blocks per unit group, unit groups (of 4 hidden units)
+  static_assert(!(DCOEFF && CT != MC), "control gradients: 8-channel layout only");
   const int Hr = dims.H, Cr = dims.C;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, q = lane >> 4;
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_mlp_sweep(
 
   int64_t idx = stage_index[4 * k_begin];
   float frac = stage_frac[4 * k_begin];
-  Row<DEGREE> row = load_row<DEGREE>(coeffs, sc, n_intervals, idx, Cr);
+  Row<DEGREE, CT> row = load_row<DEGREE, CT>(coeffs, sc, n_intervals, idx, Cr);
 
   // dL/d(coefficient row in use) for channels 2q, 2q+1: cubic (b, 2c, 3d), linear (left knot, right knot)
   float gc0[2] = {0.f, 0.f}, gc1[2] = {0.f, 0.f}, gc2[2] = {0.f, 0.f};
@@ -149,9 +151,9 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_mlp_sweep(
     f32x4 za = ya, zb = yb, sa = aa, sb = ab;                        // stage values of z and a
 #pragma unroll
     for (int stage = 0; stage < 4; ++stage) {
-      float dX[MC];
+      float dX[CT];
       const float width = DEGREE == CDE_PATH_LINEAR ? knots[idx + 1] - knots[idx] : 1.f;
-      control_slope<DEGREE>(row, frac, width, dX);
+      control_slope<DEGREE, CT>(row, frac, width, dX);
       const int64_t e_next = 4 * k + stage + 1;
       const bool more = e_next < 4 * k_end;
       const int64_t nidx = more ? stage_index[e_next] : idx;
@@ -207,43 +209,58 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_mlp_sweep(
       f32x4 gu[8];
 #pragma unroll
       for (int T1 = 0; T1 < 8; ++T1) gu[T1] = f32x4{0.f, 0.f, 0.f, 0.f};
-      f32x4 fa, fb;
+      f32x4 fa = {0.f, 0.f, 0.f, 0.f}, fb = fa;
       float gdx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // d(a.f)/d(dX_c), this lane's hidden units (DCOEFF)
 #pragma unroll
-      for (int P = 0; P < 8; ++P) {
-        const float4 c0 = bb2[8 * P], c1 = bb2[8 * P + 4];
-        f32x4 y0 = {c0.x, c0.y, c0.z, c0.w}, y1 = {c1.x, c1.y, c1.z, c1.w};
-        const float* t0 = w2y + (4 * P) * 8 * W2P_STRIDE;            // tile 2P   (tb = 0)
-        const float* t1 = w2y + (4 * P + 2) * 8 * W2P_STRIDE;        // tile 2P+1 (tb = 1)
+      for (int P = 0; P < NP; ++P) {                                 // unit group P: 4 hidden units x CT channels = NB tiles
+        f32x4 y[NB];
+        const float* tp_[NB];
+#pragma unroll
+        for (int tb = 0; tb < NB; ++tb) {
+          const float4 c0 = bb2[4 * (NB * P + tb)];
+          y[tb] = f32x4{c0.x, c0.y, c0.z, c0.w};
+          tp_[tb] = w2y + 2 * (NB * P + tb) * 8 * W2P_STRIDE;        // tile T = NB*P + tb: physical rows (2T + hb)*8 + r8
+        }
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-          const float4 a0 = *reinterpret_cast<const float4*>(t0 + 16 * g), a1 = *reinterpret_cast<const float4*>(t1 + 16 * g);
-          y0 = mfma16(a0.x, u[4 * g], y0);     y1 = mfma16(a1.x, u[4 * g], y1);
-          y0 = mfma16(a0.y, u[4 * g + 1], y0); y1 = mfma16(a1.y, u[4 * g + 1], y1);
-          y0 = mfma16(a0.z, u[4 * g + 2], y0); y1 = mfma16(a1.z, u[4 * g + 2], y1);
-          y0 = mfma16(a0.w, u[4 * g + 3], y0); y1 = mfma16(a1.w, u[4 * g + 3], y1);
-        }
-        float g2[8];
-        float f = 0.f;
-        const f32x2 tp[4] = {activate2<ACT>(y0[0], y0[1]), activate2<ACT>(y0[2], y0[3]), activate2<ACT>(y1[0], y1[1]),
-                             activate2<ACT>(y1[2], y1[3])};
+          float4 a[NB];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const float t = tp[c >> 1][c & 1];
-          f = c == 0 ? t * dX[0] : __builtin_fmaf(t, dX[c], f);
-          const float slope = ACT == CDE_ACT_TANH ? __builtin_fmaf(-t, t, 1.f) : 1.f;
-          g2[c] = as[P] * (dX[c] * slope);
-          if constexpr (DCOEFF) gdx[c] = __builtin_fmaf(as[P], t, gdx[c]);
+          for (int tb = 0; tb < NB; ++tb) a[tb] = *reinterpret_cast<const float4*>(tp_[tb] + 16 * g);
+#pragma unroll
+          for (int tb = 0; tb < NB; ++tb) y[tb] = mfma16(a[tb].x, u[4 * g], y[tb]);
+#pragma unroll
+          for (int tb = 0; tb < NB; ++tb) y[tb] = mfma16(a[tb].y, u[4 * g + 1], y[tb]);
+#pragma unroll
+          for (int tb = 0; tb < NB; ++tb) y[tb] = mfma16(a[tb].z, u[4 * g + 2], y[tb]);
+#pragma unroll
+          for (int tb = 0; tb < NB; ++tb) y[tb] = mfma16(a[tb].w, u[4 * g + 3], y[tb]);
+        }
+        float g2[CT];
+        float f = 0.f;
+#pragma unroll
+        for (int tb = 0; tb < NB; ++tb) {
+          const f32x2 t01 = activate2<ACT>(y[tb][0], y[tb][1]), t23 = activate2<ACT>(y[tb][2], y[tb][3]);
+          const float tv[4] = {t01[0], t01[1], t23[0], t23[1]};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int c = 4 * tb + r;
+            const float t = tv[r];
+            f = c == 0 ? t * dX[0] : __builtin_fmaf(t, dX[c], f);
+            const float slope = ACT == CDE_ACT_TANH ? __builtin_fmaf(-t, t, 1.f) : 1.f;
+            g2[c] = as[P] * (dX[c] * slope);
+            if constexpr (DCOEFF) gdx[c] = __builtin_fmaf(as[P], t, gdx[c]);
+          }
         }
         if (P < 4) fa[P] = f; else fb[P - 4] = f;
         if (valid) {
-          float* grow = G2 + out_row * G2_COLS + 32 * P + 8 * q;     // rows (h = 4P+q, c = 0..7) of the padded layout
-          stream_store4(grow, g2[0] * wq, g2[1] * wq, g2[2] * wq, g2[3] * wq);
-          stream_store4(grow + 4, g2[4] * wq, g2[5] * wq, g2[6] * wq, g2[7] * wq);
+          float* grow = G2 + out_row * G2_COLS + 4 * CT * P + CT * q;     // rows (h = 4P+q, c = 0..CT-1) of the padded layout
+#pragma unroll
+          for (int c4 = 0; c4 < CT; c4 += 4)
+            stream_store4(grow + c4, g2[c4] * wq, g2[c4 + 1] * wq, g2[c4 + 2] * wq, g2[c4 + 3] * wq);
         }
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {                                // K step (P, c); 8 independent accumulator chains
-          const float* rowp = w2g[c & 3] + (4 * P + 2 * (c >> 2)) * 8 * W2P_STRIDE;
+        for (int c = 0; c < CT; ++c) {                               // K step (P, c); 8 independent accumulator chains
+          const float* rowp = w2g[c & 3] + 2 * (NB * P + (c >> 2)) * 8 * W2P_STRIDE;
 #pragma unroll
           for (int T1 = 0; T1 < 8; ++T1) gu[T1] = mfma16(rowp[16 * T1], g2[c], gu[T1]);
         }
@@ -271,7 +288,7 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_mlp_sweep(
         }
         if (nidx != idx) flush_control_grad(idx);
       }
-      row = load_row<DEGREE>(coeffs, sc, n_intervals, nidx, Cr);     // for the next stage; lands during the va phase
+      row = load_row<DEGREE, CT>(coeffs, sc, n_intervals, nidx, Cr);     // for the next stage; lands during the va phase
       // ---- dL/dY1 = gu * relu'(pre1);  va = W1^T dL/dY1
       float g1[32];
 #pragma unroll
@@ -333,7 +350,8 @@ size_t mlp_adjoint_image_bytes() { return (size_t)MLP_ADJ_IMAGE_FLOATS * sizeof(
 int launch_mlp_adjoint_images(const void* W1, const void* b1, int64_t width, const void* W2, const void* b2, int64_t C,
                               int64_t H, float* img, hipStream_t s) {
   mlp_adj_image_kernel<<<(MLP_ADJ_IMAGE_FLOATS + 255) / 256, 256, 0, s>>>(
-      (const float*)W1, (const float*)b1, (const float*)W2, (const float*)b2, img, MlpDims{(int)H, (int)C, (int)width});
+      (const float*)W1, (const float*)b1, (const float*)W2, (const float*)b2, img, MlpDims{(int)H, (int)C, (int)width},
+      C > MC ? 4 : 2);                          // channel blocks per unit group: 32 units x 8 channels or 16 x 16
   return check_launch();
 }
 
@@ -348,6 +366,16 @@ int launch_mlp_adjoint_sweep(const void* coeffs, const void* knots, int64_t n_in
   const size_t lds = (size_t)ADJ_LDS_FLOATS * sizeof(float);
 #define CDE_SWEEP_X(D, A, X)                                                                                       \
   do {                                                                                                             \
+    if (C > MC) {                              /* 16 channels x 16 units; control gradients: 8-channel layout only */ \
+      if (X) return CDE_ERR_UNSUPPORTED;                                                                           \
+      (void)hipFuncSetAttribute((const void*)rk4_adjoint_mlp_sweep<TT, D, A, false, 16>,                           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                             \
+      rk4_adjoint_mlp_sweep<TT, D, A, false, 16><<<blocks, 512, lds, s>>>(                                         \
+          (const float*)coeffs, (const float*)knots, n_intervals, img, (float*)y_state, (float*)a_state,           \
+          (const TT*)sgrid, k_begin, k_end, stage_index, (const float*)stage_frac, (float*)U, (float*)G2,          \
+          (float*)G1, (float*)Z, B, dims, nullptr);                                                                \
+      break;                                                                                                       \
+    }                                                                                                              \
     (void)hipFuncSetAttribute((const void*)rk4_adjoint_mlp_sweep<TT, D, A, X>,                                     \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
     rk4_adjoint_mlp_sweep<TT, D, A, X><<<blocks, 512, lds, s>>>(                                                   \
