@@ -191,6 +191,74 @@ def other_fields(cde, X, z0, device, reps=2):
     return out
 
 
+def other_configs(cde, device, reps=2):
+    """BASELINE configs[3] (one GPU's shard) and configs[4] on this GPU, outside the timed region (ms, wall clock over
+    `reps` after one warm-up):
+      configs[3]: 32768 x 128 x 8, linear_interpolation_coeffs + LinearInterpolation, dopri5 (rtol 1e-4, atol 1e-6,
+                  jump_t = the knots), linear func; forward, and forward + adaptive adjoint backward (K4 / K4a)
+      configs[4]: 32768 x 512 x 3 -> depth-3 logsignatures over windows of 8 (65 x 14) -> LinearInterpolation ->
+                  two-layer field (hidden size 8 as example/logsignature_example.py:22, width 128), rk4, adjoint."""
+    from helpers import LinearField, make_series
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    out = {}
+    x = make_series(B, L, C, seed=0).to(device)
+    X = cde.LinearInterpolation(cde.linear_interpolation_coeffs(x))
+    func = LinearField(H, C, scale=0.5, seed=0).to(device)
+    z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(0)).to(device)
+    kw = dict(method="dopri5", rtol=1e-4, atol=1e-6, options=dict(jump_t=X.grid_points))
+
+    def dopri_forward():
+        with torch.no_grad():
+            cde.cdeint(X, func, z0, X.interval, **kw)
+
+    def dopri_adjoint():
+        z = z0.detach().requires_grad_(True)
+        cde.cdeint(X, func, z, X.interval, **kw)[:, -1].sum().backward()
+
+    out["config4_shard_dopri5_forward_ms"] = timed(dopri_forward)
+    out["config4_shard_dopri5_forward_adjoint_ms"] = timed(dopri_adjoint)
+
+    class TwoLayer(torch.nn.Module):
+        def __init__(self, hidden, channels):
+            super().__init__()
+            self.hidden, self.channels = hidden, channels
+            self.linear1, self.linear2 = torch.nn.Linear(hidden, 128), torch.nn.Linear(128, hidden * channels)
+
+        def forward(self, t, z):
+            return self.linear2(self.linear1(z).relu()).tanh().view(*z.shape[:-1], self.hidden, self.channels)
+
+    gen = torch.Generator().manual_seed(1)
+    raw = (torch.randn(B, 512, 3, generator=gen) * 0.1).cumsum(1)
+    raw[..., 0] = torch.linspace(0, 1, 512)
+    raw = raw.to(device)
+    torch.manual_seed(0)
+    field = TwoLayer(8, 14).to(device)
+    z8 = torch.randn(B, 8, generator=gen).to(device)
+    state = {}
+
+    def transform():
+        state["X"] = cde.LinearInterpolation(cde.linear_interpolation_coeffs(cde.logsig_windows(raw, 3, 8.0)))
+
+    def solve():
+        z = z8.detach().requires_grad_(True)
+        Xl = state["X"]
+        cde.cdeint(Xl, field, z, Xl.interval, method="rk4", options={"step_size": 1.0})[:, -1].sum().backward()
+
+    out["config5_logsig_transform_ms"] = timed(transform)
+    out["config5_two_layer_forward_adjoint_ms"] = timed(solve)
+    out["config5_series_per_s"] = B / ((out["config5_logsig_transform_ms"] + out["config5_two_layer_forward_adjoint_ms"]) * 1e-3)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -371,6 +439,7 @@ def main():
             result["extra"]["strong_scaling_proxy_1gpu"] = strong_scaling_proxy(cde, x, func, z0, elapsed / args.steps * 1e3)
         if world == 1:
             result["extra"]["other_fields"] = other_fields(cde, X, z0, device)
+            result["extra"]["other_configs"] = other_configs(cde, device)
         if world == 1 and args.cpu_sample > 0:
             result["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, B))
         print(json.dumps(result))

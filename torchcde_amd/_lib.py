@@ -130,7 +130,8 @@ class DopriStatus(ctypes.Structure):
                 ("t1_try", ctypes.c_double), ("dt_try", ctypes.c_double), ("h0", ctypes.c_double),
                 ("i_out", ctypes.c_int64), ("i_jump", ctypes.c_int64), ("n_accept", ctypes.c_int64),
                 ("n_reject", ctypes.c_int64), ("phase", ctypes.c_int32), ("on_jump", ctypes.c_int32),
-                ("refresh", ctypes.c_int32), ("pad", ctypes.c_int32)]
+                ("refresh", ctypes.c_int32), ("pad", ctypes.c_int32), ("slot", ctypes.c_int32),
+                ("stored", ctypes.c_int32)]
 
 
 def load():

@@ -31,6 +31,42 @@ __device__ __forceinline__ int64_t locate(const T* __restrict__ knots, int64_t n
   return idx;
 }
 
+// locate() when the answer of a nearby earlier query is known (the stages of one adaptive step almost always share
+// their interval): two comparisons instead of the search; identical result in every case, NaN queries included
+// (interior idx <=> !(knots[idx] >= t) && knots[idx+1] >= t; the first / last interval also take everything
+// below / above them because of the clamp).
+template <typename T>
+__device__ __forceinline__ int64_t locate_near(const T* __restrict__ knots, int64_t n_intervals, T t, int64_t hint, T& frac) {
+  if (hint >= 0) {
+    const T k0 = knots[hint], k1 = knots[hint + 1];
+    const bool above = hint == 0 || !(k0 >= t);
+    const bool below = hint == n_intervals - 1 ? !(k0 >= t) || hint == 0 : k1 >= t;
+    if (above && below) { frac = t - k0; return hint; }
+  }
+  return locate(knots, n_intervals, t, frac);
+}
+
+// ... and when the answer is `hint` or one of its neighbours (consecutive steps of an adaptive solve): four
+// independent loads instead of the search's chain of dependent ones.
+template <typename T>
+__device__ __forceinline__ int64_t locate_around(const T* __restrict__ knots, int64_t n_intervals, T t, int64_t hint, T& frac) {
+  if (hint >= 0 && hint < n_intervals) {
+    const int64_t lo = hint > 0 ? hint - 1 : 0, hi = hint < n_intervals - 1 ? hint + 1 : n_intervals - 1;
+    T k[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) k[j] = knots[lo + j <= n_intervals ? lo + j : n_intervals];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int64_t cand = lo + j;
+      if (cand > hi) break;
+      const bool above = cand == 0 || !(k[j] >= t);
+      const bool below = cand == n_intervals - 1 ? !(k[j] >= t) || cand == 0 : k[j + 1] >= t;
+      if (above && below) { frac = t - k[j]; return cand; }
+    }
+  }
+  return locate(knots, n_intervals, t, frac);
+}
+
 // ---------------------------------------------------------------- RK4 3/8-rule stage clock
 // torchdiffeq rk4_alt_step_func: stage times t0, t0 + dt*(1/3), t0 + dt*(2/3), t1 formed in the
 // grid's dtype (python floats 1/3, 2/3 rounded to that dtype), then cast to the state dtype.

@@ -15,7 +15,32 @@ struct DopriCtrl {
   int32_t on_jump;              // pending attempt was clipped to a jump time
   int32_t refresh;              // k0 must be recomputed just after t_hi (we stepped onto a jump)
   int32_t pad;
+  int32_t slot;                 // MFMA attempt kernel: which of the two (y, k) state slots holds the step's start
+  int32_t stored;               // ... and what the pending attempt left in the other one: bit 0 k6, bit 1 the midpoint
 };
+
+// Sums of NV doubles over the workgroup, the result in every thread.  Fixed order (xor-shuffle tree inside each wave,
+// then the waves in index order): bit-identical in every workgroup that sums the same values, and run to run.
+// `red`: NV * (blockDim.x / 64) doubles of LDS.
+template <int NV>
+__device__ __forceinline__ void block_total(double (&v)[NV], double* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
+  __syncthreads();                                               // `red` may still be in use by an earlier call
+  if (lane == 0)
+#pragma unroll
+    for (int k = 0; k < NV; ++k) red[k * nw + wave] = v[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    double s = 0.0;
+    for (int w = 0; w < nw; ++w) s += red[k * nw + w];
+    v[k] = s;
+  }
+}
 
 __device__ __forceinline__ float next_toward(float x, float dir) { return nextafterf(x, x + dir); }
 __device__ __forceinline__ double next_toward(double x, double dir) { return nextafter(x, x + dir); }

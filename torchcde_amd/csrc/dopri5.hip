@@ -415,21 +415,17 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   }
   __syncthreads();
   const int64_t BH = g.B * g.H;
-  float* Sp = g.state + (int64_t)p * 5 * BH;
-  float* Sq = g.state + (int64_t)q2 * 5 * BH;
+  // State: two (y, k) slots and one midpoint array.  Slot `c.slot` holds the start of the pending attempt (y0, k0 = f
+  // at t0), the other slot what the attempt produced (y1, and k6 = f at t1 when that is ever read: a step clipped
+  // onto a jump time re-evaluates f just after the jump instead).  Accepting a step swaps the roles, rejecting it
+  // changes nothing, so an attempt moves 2 + 2 arrays of B*H floats through HBM (the round-1 layout rewrote all five
+  // arrays every attempt: 38 MB and 8 us per attempt on the 32768-series shard, all of it after the last MFMA).
+  float* const Ys[2] = {g.state, g.state + BH};
+  float* const Ks[2] = {g.state + 2 * BH, g.state + 3 * BH};
+  float* const Mid = g.state + 4 * BH;
   const double* Pp = g.partial + (int64_t)p * g.n_blocks_alloc * 2;
   double* Pq = g.partial + (int64_t)q2 * g.n_blocks_alloc * 2;
   const T rtol = (T)g.rtol, atol = (T)g.atol;
-
-  double sum0 = 0.0, sum1 = 0.0;
-  if (c.phase != 0 && g.ext_sums) {                               // one controller for all shards of the batch
-    sum0 = g.ext_sums[0]; sum1 = g.ext_sums[1];
-  } else if (c.phase != 0) {
-    for (int64_t b = tid; b < (int64_t)gridDim.x; b += blockDim.x) { sum0 += Pp[2 * b]; sum1 += Pp[2 * b + 1]; }
-    block_sum2(sum0, sum1, red);
-  }
-  const DopriPlan<T> plan = dopri_controller<T>(g, c, sum0, sum1);
-  const int mode = plan.mode;
 
   const int lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, q = lane >> 4;
@@ -439,6 +435,33 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   const int64_t e = sc * Hr;                                          // this series' row in the state arrays
   // this lane's 8 hidden units in two groups of 4: product form 8q..8q+7, activation form q, 4+q, .., 28+q
   const int u0 = PRODUCT ? 8 * q : q, u1 = PRODUCT ? 8 * q + 4 : 16 + q;
+
+  // the state the next attempt starts from if the pending one is accepted (nearly always): requested before the
+  // partial sums and the controller, whose latency then hides the loads
+  const int old_slot = c.slot, cand = c.slot ^ 1;
+  f32x4 ya, yb, k0a, k0b;
+  if (c.phase == 3) {
+    ya = load_units4<STRIDE>(Ys[cand] + e, u0, Hr); yb = load_units4<STRIDE>(Ys[cand] + e, u1, Hr);
+    if (c.stored & 1) { k0a = load_units4<STRIDE>(Ks[cand] + e, u0, Hr); k0b = load_units4<STRIDE>(Ks[cand] + e, u1, Hr); }
+  }
+
+  double sums[2] = {0.0, 0.0};
+  if (c.phase != 0 && g.ext_sums) {                               // one controller for all shards of the batch
+    sums[0] = g.ext_sums[0]; sums[1] = g.ext_sums[1];
+  } else if (c.phase != 0) {
+    for (int64_t b = tid; b < (int64_t)gridDim.x; b += blockDim.x) { sums[0] += Pp[2 * b]; sums[1] += Pp[2 * b + 1]; }
+    block_total<2>(sums, red);
+  }
+  const int was_refresh_pending = c.phase == 3 ? c.on_jump : 0;   // (the controller overwrites on_jump)
+  (void)was_refresh_pending;
+  const int pending_stored = c.stored;
+  const double t_lo_prev = c.t_hi;                                 // start of the pending attempt
+  (void)t_lo_prev;
+  const DopriPlan<T> plan = dopri_controller<T>(g, c, sums[0], sums[1]);
+  const int mode = plan.mode;
+  const int slot = (c.phase == 3 && plan.accept) ? cand : old_slot;    // where the next attempt starts from
+  const int other = slot ^ 1;
+
   const float4* wy = reinterpret_cast<const float4*>(img_lds) + lane;
   const float4* by = reinterpret_cast<const float4*>(img_lds + WY_FLOATS) + q;
   auto field = [&](const f32x4& za, const f32x4& zb, const float (&dXv)[CT], f32x4& fa, f32x4& fb) {
@@ -455,7 +478,9 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   float dX_lin[CT];                                   // piecewise-linear control: the slope of the interval in use
   auto slope_at = [&](T ts, float (&dX)[CT]) {
     T frac;
-    const int64_t idx = locate(kn, g.n_intervals, ts, frac);
+    // the stages of an attempt almost always share their interval (always, with jump_t on the knots): two comparisons
+    // against the interval in use instead of the 8 dependent LDS reads of the search (6.5 us per attempt)
+    const int64_t idx = locate_near(kn, g.n_intervals, ts, row_idx, frac);
     if (idx != row_idx) {
       row = load_row<DEGREE, CT>(g.coeffs, sc, g.n_intervals, idx, dims.C);
       row_idx = idx;
@@ -471,57 +496,58 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
     }
   };
 
-  f32x4 ya, yb, k0a, k0b;
-  double acc0 = 0.0, acc1 = 0.0;
+  double acc[2] = {0.0, 0.0};
   if (c.phase == 0) {
     ya = load_units4<STRIDE>(g.z0 + e, u0, Hr); yb = load_units4<STRIDE>(g.z0 + e, u1, Hr);
     if (valid) { store_units4<STRIDE>(g.z_out + (series * g.n_out) * Hr, u0, Hr, ya); store_units4<STRIDE>(g.z_out + (series * g.n_out) * Hr, u1, Hr, yb); }
     k0a = k0b = f32x4{0.f, 0.f, 0.f, 0.f};
   } else if (c.phase == 1 || c.phase == 2) {
-    ya = load_units4<STRIDE>(Sp + e, u0, Hr); yb = load_units4<STRIDE>(Sp + e, u1, Hr);
-    k0a = load_units4<STRIDE>(Sp + 2 * BH + e, u0, Hr); k0b = load_units4<STRIDE>(Sp + 2 * BH + e, u1, Hr);
-  } else {
-    const f32x4 y0a = load_units4<STRIDE>(Sp + e, u0, Hr), y0b = load_units4<STRIDE>(Sp + e, u1, Hr);
-    if (plan.accept) {
-      const f32x4 y1a = load_units4<STRIDE>(Sp + BH + e, u0, Hr), y1b = load_units4<STRIDE>(Sp + BH + e, u1, Hr);
-      const f32x4 f1a = load_units4<STRIDE>(Sp + 3 * BH + e, u0, Hr), f1b = load_units4<STRIDE>(Sp + 3 * BH + e, u1, Hr);
-      if (plan.emit_to > plan.emit_from) {
-        const T dtf = (T)plan.dt_done;
-        const f32x4 f0a = load_units4<STRIDE>(Sp + 2 * BH + e, u0, Hr), f0b = load_units4<STRIDE>(Sp + 2 * BH + e, u1, Hr);
-        const f32x4 ma = load_units4<STRIDE>(Sp + 4 * BH + e, u0, Hr), mb = load_units4<STRIDE>(Sp + 4 * BH + e, u1, Hr);
-        const f32x4 caa = 2.f * dtf * (f1a - f0a) - 8.f * (y1a + y0a) + 16.f * ma;
-        const f32x4 cab = 2.f * dtf * (f1b - f0b) - 8.f * (y1b + y0b) + 16.f * mb;
-        const f32x4 cba = dtf * (5.f * f0a - 3.f * f1a) + 18.f * y0a + 14.f * y1a - 32.f * ma;
-        const f32x4 cbb = dtf * (5.f * f0b - 3.f * f1b) + 18.f * y0b + 14.f * y1b - 32.f * mb;
-        const f32x4 cca = dtf * (f1a - 4.f * f0a) - 11.f * y0a - 5.f * y1a + 16.f * ma;
-        const f32x4 ccb = dtf * (f1b - 4.f * f0b) - 11.f * y0b - 5.f * y1b + 16.f * mb;
-        const f32x4 cda = dtf * f0a, cdb = dtf * f0b;
-        for (int64_t io = plan.emit_from; io < plan.emit_to; ++io) {
-          const T x = (T)((g.t_out[io] - c.t_lo) / (c.t_hi - c.t_lo));
-          f32x4 ta = y0a + x * cda, tb = y0b + x * cdb;
-          T xp = x;
-          xp = xp * x; ta = ta + xp * cca; tb = tb + xp * ccb;
-          xp = xp * x; ta = ta + xp * cba; tb = tb + xp * cbb;
-          xp = xp * x; ta = ta + xp * caa; tb = tb + xp * cab;
-          if (valid) { store_units4<STRIDE>(g.z_out + (series * g.n_out + io) * Hr, u0, Hr, ta); store_units4<STRIDE>(g.z_out + (series * g.n_out + io) * Hr, u1, Hr, tb); }
-        }
+    ya = load_units4<STRIDE>(Ys[slot] + e, u0, Hr); yb = load_units4<STRIDE>(Ys[slot] + e, u1, Hr);
+    k0a = load_units4<STRIDE>(Ks[slot] + e, u0, Hr); k0b = load_units4<STRIDE>(Ks[slot] + e, u1, Hr);
+  } else if (plan.accept) {
+    // (ya, yb) = y1 and -- unless f is re-evaluated after a jump -- (k0a, k0b) = k6 of the accepted step are in flight
+    if (plan.emit_to > plan.emit_from) {
+      // outputs covered by the accepted step: 4th-order dense interpolant (oracle _fit_dense / _eval_dense); such an
+      // attempt always stores k6 and the midpoint
+      const T dtf = (T)plan.dt_done;
+      const f32x4 y0a = load_units4<STRIDE>(Ys[old_slot] + e, u0, Hr), y0b = load_units4<STRIDE>(Ys[old_slot] + e, u1, Hr);
+      const f32x4 f0a = load_units4<STRIDE>(Ks[old_slot] + e, u0, Hr), f0b = load_units4<STRIDE>(Ks[old_slot] + e, u1, Hr);
+      const f32x4 ma = load_units4<STRIDE>(Mid + e, u0, Hr), mb = load_units4<STRIDE>(Mid + e, u1, Hr);
+      const f32x4 y1a = ya, y1b = yb, f1a = k0a, f1b = k0b;
+      const f32x4 caa = 2.f * dtf * (f1a - f0a) - 8.f * (y1a + y0a) + 16.f * ma;
+      const f32x4 cab = 2.f * dtf * (f1b - f0b) - 8.f * (y1b + y0b) + 16.f * mb;
+      const f32x4 cba = dtf * (5.f * f0a - 3.f * f1a) + 18.f * y0a + 14.f * y1a - 32.f * ma;
+      const f32x4 cbb = dtf * (5.f * f0b - 3.f * f1b) + 18.f * y0b + 14.f * y1b - 32.f * mb;
+      const f32x4 cca = dtf * (f1a - 4.f * f0a) - 11.f * y0a - 5.f * y1a + 16.f * ma;
+      const f32x4 ccb = dtf * (f1b - 4.f * f0b) - 11.f * y0b - 5.f * y1b + 16.f * mb;
+      const f32x4 cda = dtf * f0a, cdb = dtf * f0b;
+      for (int64_t io = plan.emit_from; io < plan.emit_to; ++io) {
+        const T x = (T)((g.t_out[io] - c.t_lo) / (c.t_hi - c.t_lo));
+        f32x4 ta = y0a + x * cda, tb = y0b + x * cdb;
+        T xp = x;
+        xp = xp * x; ta = ta + xp * cca; tb = tb + xp * ccb;
+        xp = xp * x; ta = ta + xp * cba; tb = tb + xp * cbb;
+        xp = xp * x; ta = ta + xp * caa; tb = tb + xp * cab;
+        if (valid) { store_units4<STRIDE>(g.z_out + (series * g.n_out + io) * Hr, u0, Hr, ta); store_units4<STRIDE>(g.z_out + (series * g.n_out + io) * Hr, u1, Hr, tb); }
       }
-      ya = y1a; yb = y1b; k0a = f1a; k0b = f1b;
-    } else {
-      ya = y0a; yb = y0b;
-      k0a = load_units4<STRIDE>(Sp + 2 * BH + e, u0, Hr); k0b = load_units4<STRIDE>(Sp + 2 * BH + e, u1, Hr);
     }
+  } else {                                                            // rejected: back to the start of that attempt
+    ya = load_units4<STRIDE>(Ys[slot] + e, u0, Hr); yb = load_units4<STRIDE>(Ys[slot] + e, u1, Hr);
+    k0a = load_units4<STRIDE>(Ks[slot] + e, u0, Hr); k0b = load_units4<STRIDE>(Ks[slot] + e, u1, Hr);
   }
+  (void)pending_stored;
 
   float dX[CT];
+  int stored = 0;
   if (mode == 0) {
     slope_at((T)c.t_hi, dX);
     field(ya, yb, dX, k0a, k0b);
     const f32x4 sa = atol + abs4(ya) * rtol, sb = atol + abs4(yb) * rtol;
     if (valid) {
-      acc0 = sq4(ya / sa) + sq4(yb / sb);
-      acc1 = sq4(k0a / sa) + sq4(k0b / sb);
-      store_units4<STRIDE>(Sq + e, u0, Hr, ya); store_units4<STRIDE>(Sq + e, u1, Hr, yb); store_units4<STRIDE>(Sq + 2 * BH + e, u0, Hr, k0a); store_units4<STRIDE>(Sq + 2 * BH + e, u1, Hr, k0b);
+      acc[0] = sq4(ya / sa) + sq4(yb / sb);
+      acc[1] = sq4(k0a / sa) + sq4(k0b / sb);
+      store_units4<STRIDE>(Ys[slot] + e, u0, Hr, ya); store_units4<STRIDE>(Ys[slot] + e, u1, Hr, yb);
+      store_units4<STRIDE>(Ks[slot] + e, u0, Hr, k0a); store_units4<STRIDE>(Ks[slot] + e, u1, Hr, k0b);
     }
   } else if (mode == 1) {
     const T h0 = plan.h0_state;
@@ -530,16 +556,20 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
     f32x4 f1a, f1b;
     field(za, zb, dX, f1a, f1b);
     const f32x4 sa = atol + abs4(ya) * rtol, sb = atol + abs4(yb) * rtol;
-    if (valid) {
-      acc0 = sq4((f1a - k0a) / sa) + sq4((f1b - k0b) / sb);
-      store_units4<STRIDE>(Sq + e, u0, Hr, ya); store_units4<STRIDE>(Sq + e, u1, Hr, yb); store_units4<STRIDE>(Sq + 2 * BH + e, u0, Hr, k0a); store_units4<STRIDE>(Sq + 2 * BH + e, u1, Hr, k0b);
-    }
+    if (valid) acc[0] = sq4((f1a - k0a) / sa) + sq4((f1b - k0b) / sb);
   } else if (mode == 2) {
     const T t0f = (T)plan.t0, dtf = (T)plan.dt, t1f = (T)plan.t1;
     if (c.refresh) {                                                  // just after the jump we landed on
       slope_at(next_toward(t0f, 1.f), dX);
       field(ya, yb, dX, k0a, k0b);
+      if (valid) {                                                    // a rejected attempt restarts from this k0
+        store_units4<STRIDE>(Ks[slot] + e, u0, Hr, k0a); store_units4<STRIDE>(Ks[slot] + e, u1, Hr, k0b);
+      }
     }
+    // will the step, if accepted, cover an output time?  Only then are k6 (when the step ends on a jump) and the
+    // midpoint ever read
+    const bool will_emit = c.i_out < g.n_out && !(g.t_out[c.i_out] > plan.t1);
+    stored = ((!c.on_jump || will_emit) ? 1 : 0) | (will_emit ? 2 : 0);
     f32x4 ka[7], kb[7];
     ka[0] = k0a; kb[0] = k0b;
     f32x4 zia = ya, zib = yb;
@@ -558,29 +588,37 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
       slope_at(ti, dX);
       field(zia, zib, dX, ka[i + 1], kb[i + 1]);
     }
-    f32x4 ea = {0.f, 0.f, 0.f, 0.f}, eb = ea, ma = ea, mb = ea;
+    f32x4 ea = {0.f, 0.f, 0.f, 0.f}, eb = ea;
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
-      const T we = dtf * (T)DP_CERR[j], wm = dtf * (T)DP_CMID[j];
+      const T we = dtf * (T)DP_CERR[j];
       if (DP_CERR[j] == 0.0) continue;                    // c_err[1] == c_mid[1] == 0
-      const f32x4 wev = {we, we, we, we}, wmv = {wm, wm, wm, wm};
+      const f32x4 wev = {we, we, we, we};
       ea = __builtin_elementwise_fma(ka[j], wev, ea); eb = __builtin_elementwise_fma(kb[j], wev, eb);
-      ma = __builtin_elementwise_fma(ka[j], wmv, ma); mb = __builtin_elementwise_fma(kb[j], wmv, mb);
     }
     const f32x4 ta = atol + rtol * max4(abs4(ya), abs4(zia)), tb = atol + rtol * max4(abs4(yb), abs4(zib));
     if (valid) {
-      acc0 = sq4(ea / ta) + sq4(eb / tb);
-      store_units4<STRIDE>(Sq + e, u0, Hr, ya); store_units4<STRIDE>(Sq + e, u1, Hr, yb);
-      store_units4<STRIDE>(Sq + BH + e, u0, Hr, zia); store_units4<STRIDE>(Sq + BH + e, u1, Hr, zib);
-      store_units4<STRIDE>(Sq + 2 * BH + e, u0, Hr, ka[0]); store_units4<STRIDE>(Sq + 2 * BH + e, u1, Hr, kb[0]);
-      store_units4<STRIDE>(Sq + 3 * BH + e, u0, Hr, ka[6]); store_units4<STRIDE>(Sq + 3 * BH + e, u1, Hr, kb[6]);
-      store_units4<STRIDE>(Sq + 4 * BH + e, u0, Hr, ya + ma); store_units4<STRIDE>(Sq + 4 * BH + e, u1, Hr, yb + mb);
+      acc[0] = sq4(ea / ta) + sq4(eb / tb);
+      store_units4<STRIDE>(Ys[other] + e, u0, Hr, zia); store_units4<STRIDE>(Ys[other] + e, u1, Hr, zib);
+      if (stored & 1) { store_units4<STRIDE>(Ks[other] + e, u0, Hr, ka[6]); store_units4<STRIDE>(Ks[other] + e, u1, Hr, kb[6]); }
+    }
+    if (stored & 2) {
+      f32x4 ma = {0.f, 0.f, 0.f, 0.f}, mb = ma;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const T wm = dtf * (T)DP_CMID[j];
+        if (DP_CMID[j] == 0.0) continue;
+        const f32x4 wmv = {wm, wm, wm, wm};
+        ma = __builtin_elementwise_fma(ka[j], wmv, ma); mb = __builtin_elementwise_fma(kb[j], wmv, mb);
+      }
+      if (valid) { store_units4<STRIDE>(Mid + e, u0, Hr, ya + ma); store_units4<STRIDE>(Mid + e, u1, Hr, yb + mb); }
     }
   }
-  block_sum2(acc0, acc1, red);
-  if (tid == 0) { Pq[2 * blockIdx.x] = acc0; Pq[2 * blockIdx.x + 1] = acc1; }
+  block_total<2>(acc, red);
+  if (tid == 0) { Pq[2 * blockIdx.x] = acc[0]; Pq[2 * blockIdx.x + 1] = acc[1]; }
   if (blockIdx.x == 0 && tid == 0) {
     c.phase = mode == 0 ? 1 : mode == 1 ? 2 : mode == 2 ? 3 : 4;
+    c.slot = slot; c.stored = stored;
     g.ctrl[q2] = c;
   }
 }

@@ -63,31 +63,6 @@ struct AdjPlan {
   int kind0;            // perturbation of the stage-0 time: 0 none, -1 just before, +1 just after
 };
 
-__device__ __forceinline__ void block_sum4(double (&v)[4], double* red) {
-  const int tid = threadIdx.x, n = blockDim.x;
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 4; ++k) red[k * n + tid] = v[k];
-  __syncthreads();
-  for (int off = 1; off < n; off <<= 1) {
-    double add[4] = {0.0, 0.0, 0.0, 0.0};
-    const bool act = (tid % (2 * off)) == 0 && tid + off < n;
-    if (act) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) add[k] = red[k * n + tid + off];
-    }
-    __syncthreads();
-    if (act) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) red[k * n + tid] += add[k];
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) v[k] = red[k * n];
-  __syncthreads();
-}
-
 // torchdiffeq's controller (dopri5.hip: dopri_controller) for the two-block state (y, a): every thread derives the
 // same plan from the controller struct and the pending sums.
 __device__ __forceinline__ AdjPlan adj_controller(const DopriAdjArgs& g, DopriCtrl& c, const double (&sum)[4]) {
@@ -218,7 +193,7 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
 #pragma unroll
       for (int k = 0; k < 4; ++k) sum[k] += Pp[4 * b + k];
     }
-    block_sum4(sum, red);
+    block_total<4>(sum, red);
   }
   const int phase_in = c.phase;
   const AdjPlan plan = adj_controller(g, c, sum);
@@ -239,7 +214,10 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
     else if (i <= 4) ts = t0f + (float)DP_ALPHA[i - 1] * dtf;
     else ts = next_toward(t1f, -1.f);
     float frac;
-    const int idx = (int)locate(g.knots, g.n_intervals, -ts, frac);       // the field lives at t = -s
+    // the field lives at t = -s.  Consecutive steps sit in the same or in neighbouring intervals: the interval of the
+    // previous launch's stage 0 (kept in the controller block) turns the search's eight dependent global loads -- paid
+    // by every launch before anything else can start -- into four independent ones
+    const int idx = (int)locate_around(g.knots, g.n_intervals, -ts, phase_in == 0 ? (int64_t)-1 : (int64_t)c.slot, frac);
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
       sidx[k] = __builtin_amdgcn_readlane(idx, k);
@@ -525,13 +503,14 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
     }
   }
   // ---- publish this launch's partial sums and the controller state for the next launch
-  block_sum4(acc, red);
+  block_total<4>(acc, red);
   if (tid == 0) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) Pq[4 * blockIdx.x + k] = acc[k];
   }
   if (blockIdx.x == 0 && tid == 0) {
     c.phase = mode == 0 ? 1 : mode == 1 ? 2 : mode == 2 ? 3 : 4;
+    c.slot = sidx[0];                                              // search hint for the next launch's stage times
     g.ctrl[p2] = c;
   }
 }
