@@ -159,7 +159,8 @@ def strong_scaling_proxy(cde, x, func, z0, full_ms):
 def other_fields(cde, X, z0, device, reps=2):
     """Same workload with the non-linear vector fields of the reference's examples (outside the timed region, not part
     of `value`): Linear -> tanh (example/irregular_data.py) and Linear -> relu -> Linear -> tanh, width 128
-    (example/time_series_classification.py).  ms per solve, wall clock over `reps` after one warm-up."""
+    (example/time_series_classification.py); and the linear field with 64 hidden units (wide tile kernels).  ms per solve,
+    wall clock over `reps` after one warm-up."""
     class TwoLayer(torch.nn.Module):
         def __init__(self):
             super().__init__()
@@ -170,16 +171,20 @@ def other_fields(cde, X, z0, device, reps=2):
 
     from helpers import LinearField
     torch.manual_seed(0)
-    fields = {"tanh": LinearField(H, C, scale=1.0, tanh=True, seed=0).to(device), "two_layer": TwoLayer().to(device)}
+    fields = {"tanh": LinearField(H, C, scale=1.0, tanh=True, seed=0).to(device), "two_layer": TwoLayer().to(device),
+              # the same control with 64 hidden units: the wide tile kernels (csrc/rk4_wide.hip)
+              "linear_hidden64": LinearField(64, C, scale=0.5, seed=0).to(device)}
+    starts = {"linear_hidden64": torch.randn(z0.size(0), 64, generator=torch.Generator().manual_seed(1)).to(device)}
     out = {}
     for name, func in fields.items():
+        start = starts.get(name, z0)
         for mode in ("forward", "forward_adjoint"):
             def once():
                 if mode == "forward":
                     with torch.no_grad():
-                        cde.cdeint(X, func, z0, X.interval, method="rk4", options={"step_size": 1.0})
+                        cde.cdeint(X, func, start, X.interval, method="rk4", options={"step_size": 1.0})
                 else:
-                    z = z0.detach().requires_grad_(True)
+                    z = start.detach().requires_grad_(True)
                     cde.cdeint(X, func, z, X.interval, method="rk4", options={"step_size": 1.0})[:, -1].sum().backward()
             once()
             torch.cuda.synchronize()

@@ -54,7 +54,8 @@ enum { CDE_ACT_NONE = 0, CDE_ACT_TANH = 1 };
 
 /* kernel selection for the fused solvers */
 enum {
-  CDE_VARIANT_AUTO = 0,    /* MFMA kernel when (f32, H == 32, C == 8, ACT_NONE), else generic */
+  CDE_VARIANT_AUTO = 0,    /* f32: the MFMA kernels for H <= 32, C <= 8 (identity or tanh), the wide tile kernels for
+                              H <= 64, C <= 8 or H <= 32, C <= 16 (rk4 only); anything else: the generic kernels */
   CDE_VARIANT_GENERIC = 1, /* VALU kernel: any H, C, f32 or f64                             */
   CDE_VARIANT_MFMA = 2,    /* fail with CDE_ERR_UNSUPPORTED unless the MFMA kernel applies   */
   CDE_VARIANT_SPLIT = 3    /* MFMA, one workgroup (4 waves) per 16 series: the latency-oriented kernels for small
@@ -164,8 +165,8 @@ int cde_path_eval_backward(const void* grad_out, const void* knots, const void* 
 int cde_contract(const void* F, const void* dX, void* out, int64_t B, int64_t H, int64_t C, int dtype, void* stream);
 
 /* Whether the fused RK4 kernels take a vector field of this shape (1) or not (0): the MFMA kernels need f32,
- * H <= 32, C <= 8; the generic kernels H <= 256 and one series' stage data (adjoint: H + C + H*C values) within
- * 64 KB of LDS.  The Python host solves anything else step by step (torchcde_amd/stepwise.py) instead of failing in
+ * H <= 32, C <= 8, the wide tile kernels f32 and H <= 64, C <= 8 or H <= 32, C <= 16 (variant AUTO only); the
+ * generic kernels H <= 256 and one series' stage data (adjoint: H + C + H*C values) within 64 KB of LDS.  The Python host solves anything else step by step (torchcde_amd/stepwise.py) instead of failing in
  * the backward pass. */
 int cde_rk4_supported(int64_t C, int64_t H, int dtype, int act, int adjoint, int variant);
 
@@ -270,6 +271,11 @@ int cde_rk4_adjoint_mlp_sweep(const void* coeffs, const void* knots, int64_t n_i
  *   workspace / workspace_bytes : device scratch of at least cde_rk4_adjoint_workspace_bytes()
  *            bytes: the reverse-sweep stage table plus per-workgroup partial parameter
  *            gradients, which are reduced in a fixed order (run-to-run deterministic, no atomics).
+ * Wide shapes (H <= 64, C <= 8 or H <= 32, C <= 16 beyond the 32 x 8 tiles; csrc/rk4_wide.hip): the sweep keeps no
+ * parameter gradients in registers; it streams 2.3 KB of per-stage factors per series to the workspace (chunks of RK
+ * steps, at most 4 GB at a time; CDE_WIDE_SCRATCH_BYTES in the environment overrides the bound) and a split-K MFMA
+ * reduction adds each chunk up.  That chunk loop runs on the host, so this call copies `seg_off` back and
+ * synchronises the stream once before it queues its launches.
  * ------------------------------------------------------------------------------------------- */
 size_t cde_rk4_adjoint_workspace_bytes(int64_t B, int64_t C, int64_t H, int64_t n_sgrid, int dtype, int variant);
 int cde_rk4_adjoint_linear(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,

@@ -19,7 +19,7 @@ from helpers import LinearField, make_series  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--field", default="tanh", choices=["tanh", "mlp"])
+    ap.add_argument("--field", default="tanh", choices=["tanh", "linear", "mlp"])
     ap.add_argument("--adjoint", action="store_true")
     ap.add_argument("--variants", default="mfma,generic")
     ap.add_argument("--batch", type=int, default=32768)
@@ -33,8 +33,8 @@ def main():
     x = make_series(B, L, C).to(dev)
     coeffs = native.hermite_cubic_coefficients_with_backward_differences(x)
     X = native.CubicSpline(coeffs)
-    if args.field == "tanh":
-        func = LinearField(H, C, scale=1.0, tanh=True, seed=0).to(dev)
+    if args.field in ("tanh", "linear"):
+        func = LinearField(H, C, scale=1.0 if args.field == "tanh" else 0.5, tanh=args.field == "tanh", seed=0).to(dev)
     else:
         class TwoLayer(torch.nn.Module):
             def __init__(self):

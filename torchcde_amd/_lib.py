@@ -13,8 +13,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libcde_mi355x.so")
-SOURCES = ["interp_kernels.hip", "rk4_generic.hip", "rk4_mfma.hip", "rk4_split.hip", "rk4_mlp_adjoint.hip", "dopri5.hip",
-           "dopri5_adjoint.hip", "mlp_grad_reduce.hip", "api.hip"]
+SOURCES = ["interp_kernels.hip", "rk4_generic.hip", "rk4_mfma.hip", "rk4_split.hip", "rk4_wide.hip", "rk4_mlp_adjoint.hip",
+           "dopri5.hip", "dopri5_adjoint.hip", "mlp_grad_reduce.hip", "api.hip"]
 HEADERS = [os.path.join(_CSRC, "cde_common.h"), os.path.join(_CSRC, "cde_mfma.h"), os.path.join(_CSRC, "cde_split.h"),
            os.path.join(_CSRC, "cde_dopri.h"),
            os.path.join(_HERE, "..", "include", "cde_mi355x.h")]
@@ -22,6 +22,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 # per-file additions.  rk4_split.hip: keep MFMA accumulators in VGPRs -- its tiles are consumed by VALU code right
 # away, and on gfx950 every v_accvgpr_read costs matrix-pipe time (f32 MFMA and VALU do not overlap within a wave).
 EXTRA_FLAGS = {"rk4_split.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+               "rk4_wide.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                "dopri5_adjoint.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 F32, F64 = 0, 1

@@ -43,6 +43,18 @@ int launch_adjoint_split(const void*, const void*, int64_t, int, const void*, co
 
 bool mlp_shape_ok(int64_t C, int64_t H, int64_t width);        // rk4_mfma.hip
 
+// from rk4_wide.hip: affine fields with H <= 64, C <= 8 or H <= 32, C <= 16
+bool wide_applicable(int64_t C, int64_t H, int dtype, int act);
+size_t wide_adjoint_workspace_bytes(int64_t B, int64_t C, int64_t H, int64_t n_steps);
+template <typename TT>
+int launch_forward_wide(const void*, const void*, int64_t, int, const void*, const void*, int, const void*, const void*,
+                        int64_t, const void*, int64_t, void*, int64_t, int64_t, int64_t, const int64_t*, const void*,
+                        hipStream_t);
+template <typename TT>
+int launch_adjoint_wide(const void*, const void*, int64_t, int, const void*, const void*, int, const void*, const void*,
+                        const void*, int64_t, const int64_t*, int64_t, void*, void*, void*, int64_t, int64_t, int64_t,
+                        const int64_t*, const void*, void*, hipStream_t);
+
 // from rk4_mlp_adjoint.hip
 size_t mlp_adjoint_image_bytes();
 int launch_mlp_adjoint_images(const void*, const void*, int64_t, const void*, const void*, int64_t, int64_t, float*,
@@ -102,6 +114,11 @@ static bool pick_split(int variant, int64_t B, bool control_grad, int act = CDE_
   return variant == CDE_VARIANT_AUTO && (B <= CDE_SPLIT_MAX_BATCH || act == CDE_ACT_TANH);
 }
 
+// Shapes beyond the 32 x 8 tiles (H <= 64, C <= 8 or H <= 32, C <= 16): the wide tile kernels under AUTO
+static bool pick_wide(int variant, int64_t C, int64_t H, int dtype, int act) {
+  return variant == CDE_VARIANT_AUTO && !mfma_applicable(C, H, dtype, act, false) && wide_applicable(C, H, dtype, act);
+}
+
 template <typename T, typename TT>
 static int forward_typed(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
                          const void* bias, int act, const void* z0, const void* grid, int64_t n_grid,
@@ -117,6 +134,9 @@ static int forward_typed(const void* coeffs, const void* knots, int64_t n_interv
   if (use_mfma)
     return launch_forward_mfma<TT>(coeffs, knots, n_intervals, degree, W, bias, act, z0, grid, n_grid, t_out, n_out, z_out,
                                    B, C, H, stage_index, stage_frac, s);
+  if (pick_wide(variant, C, H, dtype, act))
+    return launch_forward_wide<TT>(coeffs, knots, n_intervals, degree, W, bias, act, z0, grid, n_grid, t_out, n_out,
+                                   z_out, B, C, H, stage_index, stage_frac, s);
   return launch_forward_generic<T, TT>(coeffs, knots, n_intervals, degree, W, bias, act, z0, grid, n_grid, t_out, n_out,
                                        z_out, B, C, H, stage_index, stage_frac, s);
 }
@@ -137,8 +157,11 @@ static int adjoint_typed(const void* coeffs, const void* knots, int64_t n_interv
   const size_t off_part = off_frac + align256((size_t)(4 * n_steps) * sizeof(T));
   const bool use_split = use_mfma && pick_split(variant, B, grad_coeffs != nullptr, act);
   if (variant == CDE_VARIANT_SPLIT && !use_split) return CDE_ERR_UNSUPPORTED;
+  const bool use_wide = !use_mfma && pick_wide(variant, C, H, dtype, act);
   const size_t part_bytes = use_split ? split_adjoint_partial_bytes(B)
-                            : use_mfma ? mfma_adjoint_partial_bytes(B) : generic_adjoint_workspace_bytes(B, C, H, sizeof(T));
+                            : use_mfma ? mfma_adjoint_partial_bytes(B)
+                            : use_wide ? wide_adjoint_workspace_bytes(B, C, H, n_steps)
+                                       : generic_adjoint_workspace_bytes(B, C, H, sizeof(T));
   if (workspace_bytes < off_part + part_bytes) return CDE_ERR_WORKSPACE;
   int64_t* stage_index = (int64_t*)workspace;
   void* stage_frac = (unsigned char*)workspace + off_frac;
@@ -152,6 +175,9 @@ static int adjoint_typed(const void* coeffs, const void* knots, int64_t n_interv
     return launch_adjoint_mfma<TT>(coeffs, knots, n_intervals, degree, W, bias, act, z_saved, grad_out, sgrid, seg_off, n_out,
                                    grad_z0, grad_W, grad_b, B, C, H, stage_index, stage_frac, (float*)partial,
                                    grad_coeffs, s);
+  if (use_wide)
+    return launch_adjoint_wide<TT>(coeffs, knots, n_intervals, degree, W, bias, act, z_saved, grad_out, sgrid, n_sgrid,
+                                   seg_off, n_out, grad_z0, grad_W, grad_b, B, C, H, stage_index, stage_frac, partial, s);
   return launch_adjoint_generic<T, TT>(coeffs, knots, n_intervals, degree, W, bias, act, z_saved, grad_out, sgrid,
                                        seg_off, n_out, grad_z0, grad_W, grad_b, B, C, H, stage_index, stage_frac,
                                        partial, s);
@@ -166,6 +192,7 @@ extern "C" int cde_rk4_supported(int64_t C, int64_t H, int dtype, int act, int a
   const bool mfma = cde::pick_mfma(variant, C, H, dtype, act, adjoint != 0, &rc);
   if (rc != CDE_OK) return 0;
   if (mfma) return 1;
+  if (cde::pick_wide(variant, C, H, dtype, act)) return 1;
   return cde::generic_applicable(C, H, dtype == CDE_F64 ? 8 : 4, adjoint != 0) ? 1 : 0;
 }
 
@@ -231,7 +258,11 @@ extern "C" size_t cde_rk4_adjoint_workspace_bytes(int64_t B, int64_t C, int64_t 
     const size_t sp = cde::split_adjoint_partial_bytes(B);
     a = sp > a ? sp : a;
   }
-  const size_t b = cde::generic_adjoint_workspace_bytes(B, C, H, elem);
+  size_t b = cde::generic_adjoint_workspace_bytes(B, C, H, elem);
+  if (!use_mfma && (cde::pick_wide(variant, C, H, dtype, CDE_ACT_NONE))) {
+    const size_t wb = cde::wide_adjoint_workspace_bytes(B, C, H, n_steps);
+    b = wb > b ? wb : b;
+  }
   if (variant == CDE_VARIANT_MFMA || variant == CDE_VARIANT_SPLIT) bytes += a;
   else if (variant == CDE_VARIANT_GENERIC || !use_mfma) bytes += b;
   else bytes += (a > b ? a : b);

@@ -57,6 +57,84 @@ __device__ __forceinline__ void spl_load_wv(const float* __restrict__ W, int w, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------- control feed
+// dX/dt of the tile's 16 series is produced ONCE per stage and shared through LDS (dxb[series][channel]) instead of
+// 16 times (4 waves x 4 lane quarters): lane (n, q) of wave w produces channel c = 2w + (q & 1) of series n (the
+// q >= 2 copies compute the same value and do not store).  The feed runs one stage ahead of its consumers: during
+// stage e the producers publish dX for stage e+1, from coefficients that were requested during stage e-1, at table
+// entries that were requested during stage e-2 -- no load is waited for in the stage that issued it.
+//   cubic : raw = (b, 2c, 3d) of the interval,   dX = b + (2c + 3d frac) frac      (interpolation_cubic.py:334-335)
+//   linear: raw = (x_i, x_{i+1}, t_{i+1} - t_i), dX = (x_{i+1} - x_i) / width      (interpolation_linear.py:222-225),
+//           the division happens once per interval (when the coefficients are installed), not per stage.
+template <int DEGREE>
+struct Feed {
+  const float* __restrict__ base;      // this lane's (series, channel) entry of interval 0
+  const float* __restrict__ knots;
+  const int64_t* __restrict__ sidx;    // stage table (interval index: int64 in memory, < 2^31)
+  const float* __restrict__ sfrac;
+  int stride, part;                    // floats between two intervals / between the parts of one interval
+  int e_last;
+  bool live;                           // channel < real channel count
+  int idx1, idx2;                      // table entries e+1, e+2 (uniform)
+  float frac1, frac2;
+  float cur[3], raw[3];
+  bool pending;                        // raw holds the coefficients of idx1, not yet installed in cur (uniform)
+
+  __device__ __forceinline__ void init(const float* coeffs, const float* knots_, const int64_t* si, const float* sf,
+                                       int64_t n_intervals, int64_t sc, int Cr, int c) {
+    const int cc = c < Cr ? c : Cr - 1;
+    live = c < Cr;
+    knots = knots_; sidx = si; sfrac = sf;
+    part = Cr;
+    if (DEGREE == CDE_PATH_CUBIC) { stride = 4 * Cr; base = coeffs + sc * n_intervals * 4 * Cr + Cr + cc; }
+    else { stride = Cr; base = coeffs + sc * (n_intervals + 1) * Cr + cc; }
+  }
+  __device__ __forceinline__ int index_at(int e) const { return (int)sidx[e < e_last ? e : e_last]; }
+  __device__ __forceinline__ float frac_at(int e) const { return sfrac[e < e_last ? e : e_last]; }
+  __device__ __forceinline__ void request(int idx) {
+    const float* p = base + (int64_t)idx * stride;
+    if (DEGREE == CDE_PATH_CUBIC) { raw[0] = p[0]; raw[1] = p[part]; raw[2] = p[2 * part]; }
+    else { raw[0] = p[0]; raw[1] = p[part]; raw[2] = knots[idx + 1] - knots[idx]; }
+  }
+  __device__ __forceinline__ void install() {
+    if (DEGREE == CDE_PATH_CUBIC) { cur[0] = raw[0]; cur[1] = raw[1]; cur[2] = raw[2]; }
+    else cur[0] = (raw[1] - raw[0]) / raw[2];
+  }
+  __device__ __forceinline__ float value(float frac) const {
+    const float v = DEGREE == CDE_PATH_CUBIC ? cubic_derivative(cur[0], cur[1], cur[2], frac) : cur[0];
+    return live ? v : 0.f;
+  }
+
+  // start at table entry e0 (entries e0 .. last belong to this sweep): returns dX of entry e0
+  __device__ __forceinline__ float begin(int e0, int last) {
+    e_last = last;
+    const int idx0 = index_at(e0);
+    const float frac0 = frac_at(e0);
+    request(idx0);
+    install();
+    const float v0 = value(frac0);
+    idx1 = index_at(e0 + 1); frac1 = frac_at(e0 + 1);
+    idx2 = index_at(e0 + 2); frac2 = frac_at(e0 + 2);
+    pending = idx1 != idx0;
+    if (pending) request(idx1);
+    return v0;
+  }
+  // during stage e: returns dX of entry e+1 and moves the pipeline on
+  __device__ __forceinline__ float advance(int e) {
+    const int idx3 = index_at(e + 3);
+    const float frac3 = frac_at(e + 3);
+    // opaque to the optimiser: otherwise it merges this install into the request of the previous stage (same
+    // condition) and the load is waited for right where it was issued
+    asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]));
+    if (pending) install();
+    const float v = value(frac1);
+    pending = idx2 != idx1;
+    if (pending) request(idx2);
+    idx1 = idx2; frac1 = frac2; idx2 = idx3; frac2 = frac3;
+    return v;
+  }
+};
+
 // workgroup barrier that waits for this wave's LDS traffic only (no vmcnt: global loads stay in flight)
 __device__ __forceinline__ void spl_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");

@@ -26,12 +26,14 @@ template <int MT> __device__ __forceinline__ void unpack(const typename VecOf<MT
 template <> __device__ __forceinline__ void unpack<4>(const float4& v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
 template <> __device__ __forceinline__ void unpack<2>(const float2& v, float (&o)[2]) { o[0] = v.x; o[1] = v.y; }
 
-// M = 4 waves * MT * 16 rows; N = NG * (NV * 16) columns, NV = floats per B load (4 or 2), NG groups of NV tiles
+// M = 4 waves * MT * 16 rows per workgroup (blockIdx.y selects the block of M rows when a G row is wider: `gc` floats);
+// N = NG * (NV * 16) columns, NV = floats per B load (4 or 2), NG groups of NV tiles
 template <int MT, int NV, int NG>
 __global__ __launch_bounds__(256, 2) void mlp_grad_partial_kernel(const float* __restrict__ G, const float* __restrict__ X,
                                                                   int64_t rows, int64_t rows_per_slab, int xc,
-                                                                  float* __restrict__ partial) {
+                                                                  float* __restrict__ partial, int gc) {
   constexpr int M = 4 * MT * 16, NT = NG * NV, N = NT * 16;
+  const int m0 = blockIdx.y * M;
   using AV = typename VecOf<MT>::type;
   using BV = typename VecOf<NV>::type;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -47,12 +49,12 @@ __global__ __launch_bounds__(256, 2) void mlp_grad_partial_kernel(const float* _
 #pragma unroll
     for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const float* ga = G + (w * MT * 16 + MT * i);              // + row * M
+  const float* ga = G + (m0 + w * MT * 16 + MT * i);         // + row * gc
   const float* xb = X + NV * i;                              // + row * xc + g * NV * 16
   auto load = [&](int64_t row, AV& a, BV (&b)[NG]) {
     const bool on = row < hi;
     const int64_t r = on ? row : (hi - 1);
-    a = *reinterpret_cast<const AV*>(ga + r * M);
+    a = *reinterpret_cast<const AV*>(ga + r * gc);
 #pragma unroll
     for (int g = 0; g < NG; ++g) b[g] = *reinterpret_cast<const BV*>(xb + r * xc + g * NV * 16);
     if (!on) {                                              // rows past the slab contribute nothing
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void mlp_grad_partial_kernel(const float* _
     }
   }
   // partial[slab][m][N + 1]: D fragment of tile (tm, tn): lane (j = i, q = kq), register r = row 4q + r of the tile
-  float* out = partial + (int64_t)blockIdx.x * M * (N + 1);
+  float* out = partial + ((int64_t)blockIdx.x * gc + m0) * (N + 1);
 #pragma unroll
   for (int tm = 0; tm < MT; ++tm) {
 #pragma unroll
@@ -139,6 +141,23 @@ __global__ __launch_bounds__(256) void mlp_grad_finish_kernel(const float* __res
 
 constexpr int GRAD_SLABS = 512;
 
+// Kw (rk4_wide.hip): acc (M, N + 1) += G^T [Z | 1], G (rows, M = 512), Z (rows, N = 64 or 32)
+size_t wide_grad_reduce_partial_bytes(int M, int N) { return (size_t)GRAD_SLABS * M * (N + 1) * sizeof(float); }
+
+int launch_wide_grad_reduce(const float* G, const float* Z, int64_t rows, int M, int N, float* acc, float* partial,
+                            hipStream_t s) {
+  if (rows <= 0) return CDE_OK;
+  if (M % 256 != 0 || (N != 64 && N != 32)) return CDE_ERR_UNSUPPORTED;
+  int64_t per = (rows + GRAD_SLABS - 1) / GRAD_SLABS;
+  per = (per + 15) / 16 * 16;
+  const int slabs = (int)((rows + per - 1) / per);
+  const dim3 grid((unsigned)slabs, (unsigned)(M / 256));
+  if (N == 64) mlp_grad_partial_kernel<4, 4, 1><<<grid, 256, 0, s>>>(G, Z, rows, per, N, partial, M);
+  else mlp_grad_partial_kernel<4, 2, 1><<<grid, 256, 0, s>>>(G, Z, rows, per, N, partial, M);
+  mlp_grad_finish_kernel<<<(M * (N + 1) + 63) / 64, 256, 0, s>>>(partial, slabs, M, N, acc, N + 1);
+  return check_launch();
+}
+
 }  // namespace cde
 
 // workspace for one reduction call: GRAD_SLABS partials of the larger layer (256 x 129 floats each)
@@ -158,11 +177,11 @@ extern "C" int cde_mlp_grad_reduce(const void* G, const void* X, int64_t rows, i
   const int slabs = (int)((rows + per - 1) / per);
   if (layer == 2) {
     cde::mlp_grad_partial_kernel<4, 4, 2><<<slabs, 256, 0, s>>>((const float*)G, (const float*)X, rows, per, 132,
-                                                                  (float*)workspace);
+                                                                  (float*)workspace, 256);
     cde::mlp_grad_finish_kernel<<<(256 * 129 + 63) / 64, 256, 0, s>>>((const float*)workspace, slabs, 256, 128, (float*)acc, 132);
   } else {
     cde::mlp_grad_partial_kernel<2, 2, 1><<<slabs, 256, 0, s>>>((const float*)G, (const float*)X, rows, per, 36,
-                                                                  (float*)workspace);
+                                                                  (float*)workspace, 128);
     cde::mlp_grad_finish_kernel<<<(128 * 33 + 63) / 64, 256, 0, s>>>((const float*)workspace, slabs, 128, 32, (float*)acc, 36);
   }
   return cde::check_launch();
