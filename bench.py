@@ -217,7 +217,7 @@ def other_configs(cde, device, reps=2):
     out = {}
     x = make_series(B, L, C, seed=0).to(device)
     X = cde.LinearInterpolation(cde.linear_interpolation_coeffs(x))
-    func = LinearField(H, C, scale=0.5, seed=0).to(device)
+    func = LinearField(H, C, scale=0.25, seed=0).to(device)          # as scripts/bench_dopri5.py: 129 accepted steps
     z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(0)).to(device)
     kw = dict(method="dopri5", rtol=1e-4, atol=1e-6, options=dict(jump_t=X.grid_points))
 
