@@ -107,6 +107,10 @@ int cde_natural_cubic_coeffs(const void* x, const void* t, void* coeffs, int64_t
  * ------------------------------------------------------------------------------------------- */
 int cde_linear_fill_missing(const void* x, const void* t, void* out, int64_t B, int64_t L, int64_t C, int dtype,
                             void* stream);
+/* Its backward w.r.t. the observed values (what autograd produces through interpolation_linear.py:58-69): grad_out
+ * (B, L, C) -> grad_x (B, L, C), zero at the missing entries; `x` is the forward call's input (its NaN pattern). */
+int cde_linear_fill_missing_backward(const void* grad_out, const void* x, const void* t, void* grad_x, int64_t B,
+                                     int64_t L, int64_t C, int dtype, void* stream);
 
 /* K0b  Forward fill along the length axis (torchcde/misc.py:103-126, the helper rectilinear preparation and the
  * reference's data pipelines use): x (B, L, C) -> out (B, L, C); NaNs take the latest earlier observation of their

@@ -226,6 +226,51 @@ __global__ __launch_bounds__(256) void linear_fill_kernel(const T* __restrict__ 
   }
 }
 
+// Backward of linear_fill_kernel w.r.t. the observed values: every filled entry is x_lo + r (x_hi - x_lo) of its two
+// anchors (or a copy of the first / last observation), so its incoming gradient goes to them with weights (1 - r, r).
+// One lane per scalar path walks the gaps exactly like the forward kernel and adds in place: fixed order, no atomics.
+template <typename T>
+__global__ __launch_bounds__(256) void linear_fill_backward_kernel(const T* __restrict__ grad_out, const T* __restrict__ x,
+                                                                   const T* __restrict__ t, T* __restrict__ grad_x,
+                                                                   int64_t B, int64_t L, int64_t C) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * C) return;
+  const int64_t b = e / C, c = e - b * C;
+  const T* src = x + b * L * C + c;
+  const T* g = grad_out + b * L * C + c;
+  T* dst = grad_x + b * L * C + c;
+  int64_t first = -1, last = -1;
+  for (int64_t i = 0; i < L; ++i) {
+    const T v = src[i * C];
+    dst[i * C] = (T)0;
+    if (v == v) { if (first < 0) first = i; last = i; }
+  }
+  if (first < 0) return;                                    // an all-NaN path is filled with constants
+  const T head = src[0], tail = src[(L - 1) * C];
+  const int64_t s0 = head == head ? 0 : first;              // where the values at the two ends come from
+  const int64_t sL = tail == tail ? L - 1 : last;
+  dst[s0 * C] += g[0];
+  int64_t lo = 0, src_lo = s0;
+  for (int64_t i = 1; i < L; ++i) {
+    const bool anchor = i == L - 1 || src[i * C] == src[i * C];
+    if (anchor) {
+      const int64_t src_i = i == L - 1 ? sL : i;
+      const T t_lo = t[lo], span = t[i] - t_lo;
+      T to_lo = (T)0, to_i = g[i * C];
+      for (int64_t j = lo + 1; j < i; ++j) {
+        const T ratio = (t[j] - t_lo) / span;
+        const T gj = g[j * C];
+        to_lo += gj - gj * ratio;
+        to_i += gj * ratio;
+      }
+      dst[src_lo * C] += to_lo;
+      dst[src_i * C] += to_i;
+      lo = i;
+      src_lo = src_i;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ K0b / K0c
 // K0b forward fill along the length axis (reference misc.py:103-126: gather at the cummax of the observed-count
 // cumsum): every NaN takes the latest earlier observation of its scalar path; leading NaNs stay NaN.
@@ -669,6 +714,25 @@ extern "C" int cde_linear_fill_missing(const void* x, const void* t, void* out, 
     return CDE_ERR_DTYPE;
   return cde::check_launch();
 }
+
+extern "C" int cde_linear_fill_missing_backward(const void* grad_out, const void* x, const void* t, void* grad_x,
+                                                int64_t B, int64_t L, int64_t C, int dtype, void* stream) {
+  if (B < 0 || L < 2 || C < 1) return CDE_ERR_SHAPE;
+  if (B == 0) return CDE_OK;
+  if (!grad_out || !x || !t || !grad_x) return CDE_ERR_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((B * C + 255) / 256);
+  if (dtype == CDE_F32)
+    cde::linear_fill_backward_kernel<float><<<grid, 256, 0, s>>>((const float*)grad_out, (const float*)x, (const float*)t,
+                                                                 (float*)grad_x, B, L, C);
+  else if (dtype == CDE_F64)
+    cde::linear_fill_backward_kernel<double><<<grid, 256, 0, s>>>((const double*)grad_out, (const double*)x,
+                                                                  (const double*)t, (double*)grad_x, B, L, C);
+  else
+    return CDE_ERR_DTYPE;
+  return cde::check_launch();
+}
+
 
 extern "C" int cde_hermite_bdiff_coeffs_backward(const void* grad_coeffs, const void* t, void* grad_x, int64_t B,
                                                  int64_t L, int64_t C, int dtype, void* stream) {

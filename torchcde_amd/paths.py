@@ -122,17 +122,38 @@ def linear_interpolation_coeffs(x, t=None, rectilinear=None):
     _lib.require_gpu(x, "x")
     if not torch.isnan(x).any():
         return x
-    _no_grad_through_path(x, t)
-    src = x.detach().contiguous()
+    _no_grad_through_path(t)
     knots = t.detach().to(device=x.device, dtype=x.dtype).contiguous()
-    out = torch.empty_like(src)
-    L, C = src.size(-2), src.size(-1)
-    B = src.numel() // (L * C)
-    lib = _lib.load()
-    _lib.check(lib.cde_linear_fill_missing(_lib.ptr(src), _lib.ptr(knots), _lib.ptr(out), B, L, C,
-                                           _lib.dtype_enum(x.dtype), _lib.stream_ptr(x.device)),
-               "cde_linear_fill_missing")
-    return out
+    return _LinearFill.apply(x, knots)
+
+
+class _LinearFill(torch.autograd.Function):
+    """K0 with its backward: the gradient of every filled entry goes to the two observations it was interpolated from
+    (``test/test_tricks.py:21-49`` differentiates through the coefficient construction)."""
+
+    @staticmethod
+    def forward(ctx, x, knots):
+        src = x.detach().contiguous()
+        out = torch.empty_like(src)
+        L, C = src.size(-2), src.size(-1)
+        B = src.numel() // (L * C)
+        _lib.check(_lib.load().cde_linear_fill_missing(_lib.ptr(src), _lib.ptr(knots), _lib.ptr(out), B, L, C,
+                                                       _lib.dtype_enum(x.dtype), _lib.stream_ptr(x.device)),
+                   "cde_linear_fill_missing")
+        ctx.save_for_backward(src, knots)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        src, knots = ctx.saved_tensors
+        grad_out = grad_out.contiguous()
+        grad_x = torch.empty_like(src)
+        L, C = src.size(-2), src.size(-1)
+        B = src.numel() // (L * C)
+        _lib.check(_lib.load().cde_linear_fill_missing_backward(
+            _lib.ptr(grad_out), _lib.ptr(src), _lib.ptr(knots), _lib.ptr(grad_x), B, L, C, _lib.dtype_enum(src.dtype),
+            _lib.stream_ptr(src.device)), "cde_linear_fill_missing_backward")
+        return grad_x, None
 
 
 def _natural_cubic(x, t, version):
