@@ -5,7 +5,7 @@ hermite_cubic_coefficients_with_backward_differences, driven by the oracle's res
 the `torchdiffeq` module: the real package is not installable here).  Runs only where /root/reference exists (the
 build container, not the GPU box); writes profiles/r02_cpu_reference_container.json.
 
-    python scripts/cpu_reference_baseline.py [series=4096] [threads=all]
+    python tests/tools/cpu_reference_baseline.py [series=4096] [threads=all]
 """
 import json
 import os
@@ -15,7 +15,7 @@ import time
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))

@@ -1,7 +1,7 @@
 """Debug aid: per-launch controller trace of the native dopri5 vs the oracle's attempt sequence."""
 import os, sys, ctypes
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torchcde_amd as cde
 from torchcde_amd import _lib
