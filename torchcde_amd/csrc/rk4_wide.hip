@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64 * NW, 2) void rk4_forward_wide(
 // All NW waves are alike (rk4_split.hip's chain waves without their helpers: there is no dW product to hand over).
 // (4 waves x 4 channel blocks: one wave per SIMD -- the register allocator then has the accumulation registers as spill
 // space.  With two workgroups per CU the same kernel spilled ~2 registers per stage to scratch, and every scratch
-// reload waits on vmcnt, i.e. for ALL the factor stores in flight: 13 % MFMA-busy, 50 ms per sweep instead of 12.)
+// reload waits on vmcnt, i.e. for ALL the factor stores in flight.)
 template <typename TT, int DEGREE, int ACT, int NW, int NB>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void rk4_adjoint_wide_sweep(
     const float* __restrict__ coeffs, const float* __restrict__ knots, int64_t n_intervals,
@@ -308,9 +308,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void rk4_adjoint_wide_swe
       }
       const float wq = ((stage == 0 || stage == 3) ? 0.125f : 0.375f) * ds;     // 3/8-rule quadrature weight
       // (stage, series) -- rows exist for the padding lanes of the last tile too (their a is 0, so g is 0 and they
-      // add nothing): the factor stores are then branch-free, and the compiler's s_waitcnt bookkeeping stays exact.
-      // With the stores under `if (valid)` every one of them carried an s_waitcnt vmcnt(2), i.e. waited for all but
-      // the last two stores before it to reach memory: 13 % MFMA-busy, 50 ms per sweep instead of 10.
+      // add nothing): the factor stores are then branch-free and the compiler's s_waitcnt bookkeeping stays exact
+      // (under `if (valid)` it could not count them and put an s_waitcnt vmcnt(2) in front of every store).
       const int64_t out_row = ((k - k_begin) * 4 + stage) * B16 + (int64_t)blockIdx.x * 16 + n;
       {
         float* zrow = Zout + out_row * G::HP;
