@@ -55,7 +55,8 @@ enum { CDE_ACT_NONE = 0, CDE_ACT_TANH = 1 };
 /* kernel selection for the fused solvers */
 enum {
   CDE_VARIANT_AUTO = 0,    /* f32: the MFMA kernels for H <= 32, C <= 8 (identity or tanh), the wide tile kernels for
-                              H <= 64, C <= 8 or H <= 32, C <= 16 (rk4 only); anything else: the generic kernels */
+                              H <= 64, C <= 8 or H <= 32, C <= 16 (rk4 forward / adjoint, dopri5 forward); anything
+                              else: the generic kernels */
   CDE_VARIANT_GENERIC = 1, /* VALU kernel: any H, C, f32 or f64                             */
   CDE_VARIANT_MFMA = 2,    /* fail with CDE_ERR_UNSUPPORTED unless the MFMA kernel applies   */
   CDE_VARIANT_SPLIT = 3    /* MFMA, one workgroup (4 waves) per 16 series: the latency-oriented kernels for small
@@ -314,6 +315,8 @@ int cde_rk4_adjoint_linear_dcontrol(const void* coeffs, const void* knots, int64
  *   first_launch += n_launches until the controller block at the head of `workspace` reports done:
  *   workspace begins with two `cde_dopri5_status`-compatible structs; the one at index
  *   (total_launches & 1) is current.
+ * Attempt kernels (variant AUTO): MFMA tiles for f32, H <= 32, C <= 8; the wide tile kernel for f32 and H <= 64,
+ * C <= 8 or H <= 32, C <= 16; the generic kernel otherwise (any H <= 256, f32 / f64).
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
   double t_lo, t_hi, dt, t1_try, dt_try, h0;

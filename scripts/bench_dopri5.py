@@ -13,8 +13,10 @@ ap.add_argument("--variant", default="auto")
 ap.add_argument("--batch", type=int, default=32768)
 ap.add_argument("--repeats", type=int, default=3)
 ap.add_argument("--field", default="linear", choices=["linear", "tanh", "two_layer"])
+ap.add_argument("--hidden", type=int, default=32)
+ap.add_argument("--channels", type=int, default=8)
 a = ap.parse_args()
-B, L, C, H = a.batch, 128, 8, 32
+B, L, C, H = a.batch, 128, a.channels, a.hidden
 dev = torch.device("cuda", 0)
 x = make_series(B, L, C, seed=0).to(dev)
 if a.field == "two_layer":
@@ -48,5 +50,5 @@ evals = 6 * (st["n_accept"] + st["n_reject"]) + st["n_accept"] + 2     # stages 
 print(json.dumps({"field": a.field, "config": "dopri5 + LinearInterpolation, B=%d L=%d C=%d H=%d, rtol 1e-4 atol 1e-6, jump_t=knots" % (B, L, C, H),
                   "variant": a.variant, "seconds": best, "series_per_s": B / best, "stats": st,
                   "us_per_attempt_launch": best / st["launches"] * 1e6,
-                  "field_evals": evals, "tflops": evals * B * (74240 if a.field == "two_layer" else 16896) / best / 1e12,
+                  "field_evals": evals, "tflops": evals * B * (74240 if a.field == "two_layer" else 2 * H * C * H + 2 * H * C) / best / 1e12,
                   "finite": bool(torch.isfinite(out).all())}))

@@ -135,6 +135,18 @@ struct Feed {
   }
 };
 
+// tile counts of the wide kernels (rk4_wide.hip, the wide dopri5 attempt kernel): NW waves per 16-series tile (wave w
+// owns hidden units 8w..8w+7), NB channel blocks of 4
+template <int NW, int NB>
+struct Wide {
+  static constexpr int HP = 8 * NW, CT = 4 * NB, KS = 2 * NW, NT = 2 * NB, MV = NW / 2, KV = 2 * CT;
+  static constexpr int ZROW = HP + 4, ZBUF = 16 * ZROW;          // stage state [series][kq * KS + s], unit k = 4 s + kq
+  static constexpr int VROW = 2 * NW + 4, VA = NW * 64 * VROW;   // va partials [w_dst][q][n][2 w_src + j]
+  static constexpr int DXROW = CT + 4, DX = 16 * DXROW;          // shared control derivative [series][channel]
+  static constexpr int CPW = CT / NW;                            // control channels produced per wave (4 or 1)
+  static constexpr int GC = HP * CT;                             // columns of a G row
+};
+
 // workgroup barrier that waits for this wave's LDS traffic only (no vmcnt: global loads stay in flight)
 __device__ __forceinline__ void spl_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");

@@ -17,6 +17,7 @@
 // step covered, and then runs the 6 new stages.  The controller state ping-pongs between two structs.  The host
 // only queues launches and looks at a done flag every few dozen of them.
 #include "cde_dopri.h"
+#include "cde_split.h"
 
 namespace cde {
 
@@ -623,6 +624,335 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   }
 }
 
+// ------------------------------------------------------------------------------------------ wide attempt kernel
+// K4 for the shapes of rk4_wide.hip (one-layer field, f32, H <= 64 and C <= 8, or H <= 32 and C <= 16): a workgroup of
+// NW waves per 16-series tile, wave w owns hidden units 8w..8w+7 and lane (n = l & 15, q = l >> 4) units ua = 8w + q,
+// ub = ua + 4 of series n -- their state and their seven slopes live in that lane; Y = W z + b from a register image
+// (v_mfma_f32_16x16x4_f32), the stage state crosses the waves through LDS once per evaluation.  A bounded grid of
+// workgroups walks the tiles; the control derivative of a tile at all stage times and the tile's state are requested
+// one tile ahead.  Same controller, same two state slots, same partial sums as dopri5_attempt_mfma.
+// wave-uniform copies: the controller's outputs derive from LDS reads (the block sums), so the compiler keeps them --
+// and everything computed from them -- in vector registers; read back through lane 0 they live in scalar registers
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uni(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
+__device__ __forceinline__ double uni(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ int64_t uni(int64_t v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)((uint64_t)v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+constexpr int64_t DOPRI_MAX_LDS_KNOTS_WIDE = 8192;
+constexpr int DOPRI_WIDE_RED_FLOATS = 128;               // 2 * (waves) doubles of reduction scratch, padded
+
+template <int NW, int NB>
+constexpr size_t dopri_wide_lds_bytes(int64_t n_knots) {
+  using G = Wide<NW, NB>;
+  return (size_t)(DOPRI_WIDE_RED_FLOATS + 2 * G::ZBUF + 2 * 7 * G::DX + G::GC) * sizeof(float) +
+         (n_knots <= DOPRI_MAX_LDS_KNOTS_WIDE ? (size_t)((n_knots + 3) / 4 * 4) * sizeof(float) : 0);
+}
+
+template <int DEGREE, int ACT, int NW, int NB>
+__global__ __launch_bounds__(64 * NW, 2) void dopri5_attempt_wide(DopriArgs<float> g, int parity) {
+  using G = Wide<NW, NB>;
+  using T = float;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int p = parity, q2 = parity ^ 1;
+  DopriCtrl c = g.ctrl[p];
+  if (c.phase == 4) {
+    if (blockIdx.x == 0 && tid == 0) g.ctrl[q2] = c;
+    return;
+  }
+  const int Hr = (int)g.H, Cr = (int)g.C;
+  const int lane = tid & 63, w = tid >> 6;
+  const int n = lane & 15, q = lane >> 4;
+  double* red = reinterpret_cast<double*>(lds);
+  float* zbuf = lds + DOPRI_WIDE_RED_FLOATS;
+  float* dxb = zbuf + 2 * G::ZBUF;                                   // [tile parity][evaluation][series][channel]
+  float* bias_lds = dxb + 2 * 7 * G::DX;                             // zero-padded [unit][CT]: the C/D rows of a lane
+  float* knots_lds = bias_lds + G::GC;
+  for (int e = tid; e < G::GC; e += blockDim.x) {
+    const int h = e / G::CT, cc = e % G::CT;
+    bias_lds[e] = (h < Hr && cc < Cr) ? g.bias[h * Cr + cc] : 0.f;
+  }
+  const bool knots_in_lds = g.n_intervals + 1 <= DOPRI_MAX_LDS_KNOTS_WIDE;
+  if (knots_in_lds) for (int64_t i = tid; i <= g.n_intervals; i += blockDim.x) knots_lds[i] = g.knots[i];
+  const float* kn = knots_in_lds ? knots_lds : g.knots;
+
+  // Y image of this wave: tile T = NB*P + tb, row i <-> (h = 8w + 4P + (i >> 2), c = 4 tb + (i & 3)); K step s: unit 4s + q
+  float wy[G::NT][G::KS];
+#pragma unroll
+  for (int Tt = 0; Tt < G::NT; ++Tt) {
+    const int P = Tt / NB, tb = Tt % NB;
+    const int hA = 8 * w + 4 * P + (n >> 2), cA = 4 * tb + (n & 3);
+#pragma unroll
+    for (int s = 0; s < G::KS; ++s) {
+      const int k = 4 * s + q;
+      wy[Tt][s] = (hA < Hr && cA < Cr && k < Hr) ? g.W[(hA * Cr + cA) * Hr + k] : 0.f;
+    }
+  }
+  __syncthreads();
+
+  const int64_t BH = g.B * g.H;
+  float* const Ys[2] = {g.state, g.state + BH};
+  float* const Ks[2] = {g.state + 2 * BH, g.state + 3 * BH};
+  float* const Mid = g.state + 4 * BH;
+  const double* Pp = g.partial + (int64_t)p * g.n_blocks_alloc * 2;
+  double* Pq = g.partial + (int64_t)q2 * g.n_blocks_alloc * 2;
+  const T rtol = (T)g.rtol, atol = (T)g.atol;
+
+  double sums[2] = {0.0, 0.0};
+  if (c.phase != 0 && g.ext_sums) {
+    sums[0] = g.ext_sums[0]; sums[1] = g.ext_sums[1];
+  } else if (c.phase != 0) {
+    for (int64_t b = tid; b < (int64_t)gridDim.x; b += blockDim.x) { sums[0] += Pp[2 * b]; sums[1] += Pp[2 * b + 1]; }
+    block_total<2>(sums, red);
+  }
+  const int phase_in = uni(c.phase), old_slot = uni(c.slot), pending_stored = uni(c.stored);
+  const DopriPlan<T> plan = dopri_controller<T>(g, c, sums[0], sums[1]);
+  const int mode = uni(plan.mode);
+  const bool accepted = uni((int)plan.accept) != 0;
+  const bool commit = phase_in == 3 && accepted;
+  const int slot = commit ? (old_slot ^ 1) : old_slot;               // where the next attempt starts from
+  const int other = slot ^ 1;
+  const int64_t emit_from = uni(plan.emit_from), emit_to = uni(plan.emit_to);
+  const bool emits = commit && emit_to > emit_from;
+  const bool refresh = uni((int)c.refresh) != 0;
+  const T t0f = uni((T)plan.t0), dtf = uni((T)plan.dt), t1f = uni((T)plan.t1), h0f = uni(plan.h0_state);
+  const T dt_done = uni((T)plan.dt_done);
+  const double t_lo = uni(c.t_lo), t_hi = uni(c.t_hi);
+  const bool will_emit = mode == 2 && c.i_out < g.n_out && !(g.t_out[c.i_out] > plan.t1);
+  const int stored = uni(mode == 2 ? (((!c.on_jump || will_emit) ? 1 : 0) | (will_emit ? 2 : 0)) : 0);
+  // the controller block for the next launch: everything in it is known now, and `c` need not stay live
+  if (blockIdx.x == 0 && tid == 0) {
+    c.phase = mode == 0 ? 1 : mode == 1 ? 2 : mode == 2 ? 3 : 4;
+    c.slot = slot; c.stored = stored;
+    g.ctrl[q2] = c;
+  }
+
+  // ---- evaluation times of this launch (wave-uniform): e = 0 the refresh / Hairer evaluation, e = 1..6 the stages
+  const bool use0 = mode == 0 || mode == 1 || (mode == 2 && refresh);
+  const int n_eval = mode == 2 ? 7 : (mode == 3 ? 0 : 1);
+  int eidx[7];
+  float efrac[7];
+  {
+    int64_t hint = -1;
+#pragma unroll
+    for (int e = 0; e < 7; ++e) {
+      T ts;
+      if (e == 0) ts = mode == 0 ? (T)t_hi : mode == 1 ? (T)(t_hi + (double)h0f) : next_toward(t0f, 1.f);
+      else ts = e - 1 >= 4 ? next_toward(t1f, -1.f) : t0f + (T)DP_ALPHA[e - 1] * dtf;
+      T frac = 0.f;
+      int64_t idx = 0;
+      if (e < n_eval && (e > 0 || use0)) { idx = locate_near(kn, g.n_intervals, ts, hint, frac); hint = idx; }
+      eidx[e] = uni((int)idx); efrac[e] = uni(frac);
+    }
+  }
+
+  const int ua = 8 * w + q, ub = ua + 4;
+  const bool has_a = ua < Hr, has_b = ub < Hr;
+  const int fc = G::CPW * w + (q % G::CPW);                          // the control channel this lane feeds
+  const bool feeds = q < G::CPW;
+  const int fcc = fc < Cr ? fc : Cr - 1;
+  const int64_t n_tiles = (g.B + 15) / 16;
+  float* zw = zbuf + n * G::ZROW + q * G::KS + 2 * w;
+  const float* zr = zbuf + n * G::ZROW + q * G::KS;
+  int par = 0, dbuf = 0;
+
+  // control derivative of a tile at every evaluation time: requested one tile ahead, finished into dxb when that tile is next
+  float raw[7][3];
+  auto feed_request = [&](int64_t tile) {
+    const int64_t series = tile * 16 + n;
+    const int64_t sc = series < g.B ? series : g.B - 1;
+#pragma unroll
+    for (int e = 0; e < 7; ++e) {
+      if (e < n_eval && (e > 0 || use0)) {
+        if (DEGREE == CDE_PATH_CUBIC) {
+          const float* pr = g.coeffs + ((sc * g.n_intervals + eidx[e]) * 4 + 1) * Cr + fcc;
+          raw[e][0] = pr[0]; raw[e][1] = pr[Cr]; raw[e][2] = pr[2 * Cr];
+        } else {
+          const float* pr = g.coeffs + (sc * (g.n_intervals + 1) + eidx[e]) * Cr + fcc;
+          raw[e][0] = pr[0]; raw[e][1] = pr[Cr]; raw[e][2] = kn[eidx[e] + 1] - kn[eidx[e]];
+        }
+      }
+    }
+  };
+  auto feed_store = [&](int buf) {
+#pragma unroll
+    for (int e = 0; e < 7; ++e) {
+      if (e < n_eval && (e > 0 || use0)) {
+        float v = DEGREE == CDE_PATH_CUBIC ? cubic_derivative(raw[e][0], raw[e][1], raw[e][2], efrac[e])
+                                           : (raw[e][1] - raw[e][0]) / raw[e][2];
+        if (fc >= Cr) v = 0.f;
+        if (feeds) dxb[(buf * 7 + e) * G::DX + n * G::DXROW + fc] = v;
+      }
+    }
+  };
+  // the state a tile starts from (its lane's two units), requested one tile ahead
+  const bool k_known = phase_in == 1 || phase_in == 2 || (phase_in == 3 && (!accepted || (pending_stored & 1)));
+  auto state_request = [&](int64_t tile, float (&st)[4]) {
+    const int64_t series = tile * 16 + n;
+    const int64_t sc = series < g.B ? series : g.B - 1;
+    const int64_t ea = sc * Hr + (has_a ? ua : 0), eb = sc * Hr + (has_b ? ub : 0);
+    if (phase_in == 0) { st[0] = g.z0[ea]; st[1] = g.z0[eb]; st[2] = 0.f; st[3] = 0.f; }
+    else {
+      st[0] = Ys[slot][ea]; st[1] = Ys[slot][eb];
+      if (k_known) { st[2] = Ks[slot][ea]; st[3] = Ks[slot][eb]; } else { st[2] = 0.f; st[3] = 0.f; }
+    }
+  };
+
+  // one evaluation of the vector field for the tile: publish the lane's two units, read everybody's, Y tiles, contraction
+  auto evaluate = [&](float za, float zb, int e, float& fa, float& fb) {
+    *reinterpret_cast<float2*>(zw + par * G::ZBUF) = make_float2(za, zb);
+    spl_barrier();
+    float4 z4[G::KS / 4], d4[NB];
+#pragma unroll
+    for (int i = 0; i < G::KS / 4; ++i) z4[i] = *reinterpret_cast<const float4*>(zr + par * G::ZBUF + 4 * i);
+#pragma unroll
+    for (int tb = 0; tb < NB; ++tb)
+      d4[tb] = *reinterpret_cast<const float4*>(dxb + (dbuf * 7 + e) * G::DX + n * G::DXROW + 4 * tb);
+    f32x4 y[G::NT];                                                  // bias rows of the lane's two units (LDS)
+#pragma unroll
+    for (int Tt = 0; Tt < G::NT; ++Tt) {
+      const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + ((Tt / NB) ? ub : ua) * G::CT + 4 * (Tt % NB));
+      y[Tt] = f32x4{b4.x, b4.y, b4.z, b4.w};
+    }
+#pragma unroll
+    for (int i = 0; i < G::KS / 4; ++i) {
+      const float zs[4] = {z4[i].x, z4[i].y, z4[i].z, z4[i].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int Tt = 0; Tt < G::NT; ++Tt) y[Tt] = mfma16(wy[Tt][4 * i + j], zs[j], y[Tt]);
+    }
+    f32x2 fpa = {0.f, 0.f}, fpb = {0.f, 0.f};
+#pragma unroll
+    for (int tb = 0; tb < NB; ++tb) {
+      const f32x2 d01 = {d4[tb].x, d4[tb].y}, d23 = {d4[tb].z, d4[tb].w};
+      fpa = __builtin_elementwise_fma(activate2<ACT>(y[tb][0], y[tb][1]), d01, fpa);
+      fpb = __builtin_elementwise_fma(activate2<ACT>(y[NB + tb][0], y[NB + tb][1]), d01, fpb);
+      fpa = __builtin_elementwise_fma(activate2<ACT>(y[tb][2], y[tb][3]), d23, fpa);
+      fpb = __builtin_elementwise_fma(activate2<ACT>(y[NB + tb][2], y[NB + tb][3]), d23, fpb);
+    }
+    fa = fpa[0] + fpa[1]; fb = fpb[0] + fpb[1];
+    par ^= 1;
+  };
+
+  double acc[2] = {0.0, 0.0};
+  float st_next[4] = {0.f, 0.f, 0.f, 0.f};
+  if ((int64_t)blockIdx.x < n_tiles) {
+    state_request(blockIdx.x, st_next);
+    if (mode != 3) { feed_request(blockIdx.x); feed_store(0); }
+  }
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t series = tile * 16 + n;
+    const bool valid = series < g.B;
+    const int64_t sc = valid ? series : g.B - 1;
+    const bool ona = valid && has_a, onb = valid && has_b;
+    const int64_t ea = sc * Hr + (has_a ? ua : 0), eb = sc * Hr + (has_b ? ub : 0);
+    float ya = has_a ? st_next[0] : 0.f, yb = has_b ? st_next[1] : 0.f;
+    float k0a = has_a ? st_next[2] : 0.f, k0b = has_b ? st_next[3] : 0.f;
+    const bool has_next = tile + gridDim.x < n_tiles;
+    if (has_next) { state_request(tile + gridDim.x, st_next); if (mode != 3) feed_request(tile + gridDim.x); }
+    if (phase_in == 0) {
+      if (ona) g.z_out[(series * g.n_out) * Hr + ua] = ya;
+      if (onb) g.z_out[(series * g.n_out) * Hr + ub] = yb;
+    }
+    if (emits) {
+      // outputs covered by the accepted step: 4th-order dense interpolant (oracle _fit_dense / _eval_dense); (ya, yb) is
+      // y1 and (k0a, k0b) the stored k6 of that step (an attempt that covers an output always stores k6 and the midpoint)
+      const T dtd = dt_done;
+      const int old = slot ^ 1;
+      const float y0a = has_a ? Ys[old][ea] : 0.f, y0b = has_b ? Ys[old][eb] : 0.f;
+      const float f0a = has_a ? Ks[old][ea] : 0.f, f0b = has_b ? Ks[old][eb] : 0.f;
+      const float ma = has_a ? Mid[ea] : 0.f, mb = has_b ? Mid[eb] : 0.f;
+      const float y1a = ya, y1b = yb, f1a = k0a, f1b = k0b;
+      const float caa = 2.f * dtd * (f1a - f0a) - 8.f * (y1a + y0a) + 16.f * ma;
+      const float cab = 2.f * dtd * (f1b - f0b) - 8.f * (y1b + y0b) + 16.f * mb;
+      const float cba = dtd * (5.f * f0a - 3.f * f1a) + 18.f * y0a + 14.f * y1a - 32.f * ma;
+      const float cbb = dtd * (5.f * f0b - 3.f * f1b) + 18.f * y0b + 14.f * y1b - 32.f * mb;
+      const float cca = dtd * (f1a - 4.f * f0a) - 11.f * y0a - 5.f * y1a + 16.f * ma;
+      const float ccb = dtd * (f1b - 4.f * f0b) - 11.f * y0b - 5.f * y1b + 16.f * mb;
+      const float cda = dtd * f0a, cdb = dtd * f0b;
+      for (int64_t io = emit_from; io < emit_to; ++io) {
+        const T x = (T)((g.t_out[io] - t_lo) / (t_hi - t_lo));
+        float ta = y0a + x * cda, tb = y0b + x * cdb;
+        T xp = x;
+        xp = xp * x; ta = ta + xp * cca; tb = tb + xp * ccb;
+        xp = xp * x; ta = ta + xp * cba; tb = tb + xp * cbb;
+        xp = xp * x; ta = ta + xp * caa; tb = tb + xp * cab;
+        if (ona) g.z_out[(series * g.n_out + io) * Hr + ua] = ta;
+        if (onb) g.z_out[(series * g.n_out + io) * Hr + ub] = tb;
+      }
+    }
+    if (mode == 3) continue;
+
+    if (mode == 0) {
+      evaluate(ya, yb, 0, k0a, k0b);
+      const float sa = atol + fabsf(ya) * rtol, sb = atol + fabsf(yb) * rtol;
+      if (ona) { const float u = ya / sa, v = k0a / sa; acc[0] += (double)(u * u); acc[1] += (double)(v * v); Ys[slot][ea] = ya; Ks[slot][ea] = k0a; }
+      if (onb) { const float u = yb / sb, v = k0b / sb; acc[0] += (double)(u * u); acc[1] += (double)(v * v); Ys[slot][eb] = yb; Ks[slot][eb] = k0b; }
+    } else if (mode == 1) {
+      const T h0 = h0f;
+      float f1a, f1b;
+      evaluate(ya + h0 * k0a, yb + h0 * k0b, 0, f1a, f1b);
+      const float sa = atol + fabsf(ya) * rtol, sb = atol + fabsf(yb) * rtol;
+      if (ona) { const float u = (f1a - k0a) / sa; acc[0] += (double)(u * u); }
+      if (onb) { const float u = (f1b - k0b) / sb; acc[0] += (double)(u * u); }
+    } else {
+      if (refresh) {                                                   // just after the jump we landed on
+        evaluate(ya, yb, 0, k0a, k0b);
+        if (ona) Ks[slot][ea] = k0a;                                   // a rejected attempt restarts from this k0
+        if (onb) Ks[slot][eb] = k0b;
+      }
+      float ka[7], kb[7];
+      ka[0] = k0a; kb[0] = k0b;
+      float zia = ya, zib = yb;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        float ia = 0.f, ib = 0.f;
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {                    // torchdiffeq forms this sum inside a matmul: fused
+          if (DP_BETA[i][j] == 0.0) continue;             // multiply-adds are as faithful as separate roundings
+          const T wgt = (T)DP_BETA[i][j] * dtf;
+          ia = __builtin_fmaf(ka[j], wgt, ia); ib = __builtin_fmaf(kb[j], wgt, ib);
+        }
+        zia = ya + ia; zib = yb + ib;
+        evaluate(zia, zib, i + 1, ka[i + 1], kb[i + 1]);
+      }
+      float era = 0.f, erb = 0.f;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        if (DP_CERR[j] == 0.0) continue;
+        const T we = dtf * (T)DP_CERR[j];
+        era = __builtin_fmaf(ka[j], we, era); erb = __builtin_fmaf(kb[j], we, erb);
+      }
+      const float ta = atol + rtol * fmaxf(fabsf(ya), fabsf(zia)), tb = atol + rtol * fmaxf(fabsf(yb), fabsf(zib));
+      if (ona) { const float u = era / ta; acc[0] += (double)(u * u); Ys[other][ea] = zia; if (stored & 1) Ks[other][ea] = ka[6]; }
+      if (onb) { const float u = erb / tb; acc[0] += (double)(u * u); Ys[other][eb] = zib; if (stored & 1) Ks[other][eb] = kb[6]; }
+      if (stored & 2) {
+        float ma = 0.f, mb = 0.f;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+          if (DP_CMID[j] == 0.0) continue;
+          const T wm = dtf * (T)DP_CMID[j];
+          ma = __builtin_fmaf(ka[j], wm, ma); mb = __builtin_fmaf(kb[j], wm, mb);
+        }
+        if (ona) Mid[ea] = ya + ma;
+        if (onb) Mid[eb] = yb + mb;
+      }
+    }
+    if (has_next) feed_store(dbuf ^ 1);
+    dbuf ^= 1;
+  }
+  block_total<2>(acc, red);
+  if (tid == 0) { Pq[2 * blockIdx.x] = acc[0]; Pq[2 * blockIdx.x + 1] = acc[1]; }
+}
+
 __global__ void w16_image_kernel(const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ img, Dims d) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= W16_FLOATS) return;
@@ -671,9 +1001,19 @@ static inline bool dopri_use_mfma(int64_t C, int64_t H, int dtype, int act, int 
   return variant != CDE_VARIANT_GENERIC && dtype == CDE_F32 && H <= MH && C <= MC &&
          (act == CDE_ACT_NONE || act == CDE_ACT_TANH);
 }
-static inline int64_t dopri_blocks_any(int64_t B, int64_t H) {          // partial buffer must fit either kernel's grid
+bool wide_applicable(int64_t C, int64_t H, int dtype, int act);         // rk4_wide.hip
+// one-layer fields beyond the 32 x 8 tiles (H <= 64, C <= 8 or H <= 32, C <= 16): the wide attempt kernel under AUTO
+static inline bool dopri_use_wide(int64_t C, int64_t H, int dtype, int act, int variant) {
+  return variant == CDE_VARIANT_AUTO && !dopri_use_mfma(C, H, dtype, act, variant) && wide_applicable(C, H, dtype, act);
+}
+static inline int64_t dopri_wide_grid(int64_t B, int64_t C) {           // workgroups walking the 16-series tiles
+  const int64_t tiles = (B + 15) / 16, cap = C > MC ? 512 : 256;
+  return tiles < cap ? tiles : cap;
+}
+static inline int64_t dopri_blocks_any(int64_t B, int64_t H) {          // partial buffer must fit every kernel's grid
   const int64_t a = dopri_blocks(B, H), b = (B + 127) / 128;
-  return a > b ? a : b;
+  const int64_t m = a > b ? a : b;
+  return m > 512 ? m : 512;
 }
 
 }  // namespace cde
@@ -734,6 +1074,34 @@ static int dopri5_advance_impl(const void* coeffs, const void* knots, int64_t n_
     for (int64_t i = 0; i < n_launches; ++i)                                                                      \
       cde::dopri5_attempt_kernel<T><<<(unsigned)cde::dopri_blocks(B, H), nt, lds, s>>>(g, (int)((first_launch + i) & 1)); \
   } while (0)
+  if (!mlp && cde::dopri_use_wide(C, H, dtype, act, variant)) {
+    cde::DopriArgs<float> g{(const float*)coeffs, (const float*)knots, n_intervals, degree, (const float*)W,
+                            (const float*)bias, act, (const float*)z0, t_out, n_out, jump_t, n_jump, rtol, atol, safety,
+                            ifactor, dfactor, (float*)z_out, B, C, H, 16, ctrl, (float*)state, w16, partial, blocks,
+                            nullptr, nullptr, 0, trace, ext_sums, B_global};
+    const unsigned grid = (unsigned)cde::dopri_wide_grid(B, C);
+    const int64_t n_knots = n_intervals + 1;
+#define CDE_WIDE(D, A, NWV, NBV)                                                                                   \
+  do {                                                                                                             \
+    const size_t lds = cde::dopri_wide_lds_bytes<NWV, NBV>(n_knots);                                               \
+    (void)hipFuncSetAttribute((const void*)cde::dopri5_attempt_wide<D, A, NWV, NBV>,                               \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
+    for (int64_t i = 0; i < n_launches; ++i)                                                                       \
+      cde::dopri5_attempt_wide<D, A, NWV, NBV><<<grid, 64 * NWV, lds, s>>>(g, (int)((first_launch + i) & 1));      \
+  } while (0)
+#define CDE_WIDE_SHAPE(D, A)                                                                                       \
+  do {                                                                                                             \
+    if (C <= cde::MC) CDE_WIDE(D, A, 8, 2); else CDE_WIDE(D, A, 4, 4);                                             \
+  } while (0)
+    if (act == CDE_ACT_NONE) {
+      if (degree == CDE_PATH_CUBIC) CDE_WIDE_SHAPE(CDE_PATH_CUBIC, CDE_ACT_NONE); else CDE_WIDE_SHAPE(CDE_PATH_LINEAR, CDE_ACT_NONE);
+    } else {
+      if (degree == CDE_PATH_CUBIC) CDE_WIDE_SHAPE(CDE_PATH_CUBIC, CDE_ACT_TANH); else CDE_WIDE_SHAPE(CDE_PATH_LINEAR, CDE_ACT_TANH);
+    }
+#undef CDE_WIDE_SHAPE
+#undef CDE_WIDE
+    return cde::check_launch();
+  }
   if (use_mfma) {
     cde::DopriArgs<float> g{(const float*)coeffs, (const float*)knots, n_intervals, degree, (const float*)W,
                             (const float*)bias, act, (const float*)z0, t_out, n_out, jump_t, n_jump, rtol, atol, safety,
@@ -819,7 +1187,9 @@ extern "C" int cde_dopri5_pending_sums(const void* workspace, size_t workspace_b
   if (workspace_bytes < cde_dopri5_workspace_bytes(B, C, H, dtype)) return CDE_ERR_WORKSPACE;
   const int64_t stride = cde::dopri_blocks_any(B, H);
   const bool use_mfma = cde::dopri_use_mfma(C, H, dtype, act, variant);
-  const int64_t live = use_mfma ? (B + 127) / 128 : cde::dopri_blocks(B, H);       // the grid of the attempt kernel
+  const int64_t live = use_mfma ? (B + 127) / 128
+                       : cde::dopri_use_wide(C, H, dtype, act, variant) ? cde::dopri_wide_grid(B, C)
+                                                                        : cde::dopri_blocks(B, H);   // the grid of the attempt kernel
   const double* partial = (const double*)((const unsigned char*)workspace + cde::al256(2 * sizeof(cde::DopriCtrl))) +
                           (total_launches & 1) * stride * 2;
   cde::dopri_pending_sums_kernel<<<1, 64, 0, (hipStream_t)stream>>>(partial, live, 2, sums);

@@ -29,16 +29,6 @@
 
 namespace cde {
 
-template <int NW, int NB>
-struct Wide {
-  static constexpr int HP = 8 * NW, CT = 4 * NB, KS = 2 * NW, NT = 2 * NB, MV = NW / 2, KV = 2 * CT;
-  static constexpr int ZROW = HP + 4, ZBUF = 16 * ZROW;          // stage state [series][kq * KS + s], unit k = 4 s + kq
-  static constexpr int VROW = 2 * NW + 4, VA = NW * 64 * VROW;   // va partials [w_dst][q][n][2 w_src + j]
-  static constexpr int DXROW = CT + 4, DX = 16 * DXROW;          // shared control derivative [series][channel]
-  static constexpr int CPW = CT / NW;                            // control channels produced per wave (4 or 1)
-  static constexpr int GC = HP * CT;                             // columns of a G row
-};
-
 // ============================================================================================ forward
 // rk4_forward_split with the tile counts as parameters (see there for the wave-local K order: local step j <-> global
 // step (2w + j) mod KS, so that steps 0 and 1 take the wave's own units and can be issued around the barrier).
