@@ -19,6 +19,20 @@ struct DopriCtrl {
   int32_t stored;               // ... and what the pending attempt left in the other one: bit 0 k6, bit 1 the midpoint
 };
 
+// wave-uniform copies: the controller's outputs derive from LDS reads (the block sums), so the compiler keeps them --
+// and everything computed from them -- in vector registers; read back through lane 0 they live in scalar registers
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uni(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
+__device__ __forceinline__ double uni(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ int64_t uni(int64_t v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)((uint64_t)v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
 // Sums of NV doubles over the workgroup, the result in every thread.  Fixed order (xor-shuffle tree inside each wave,
 // then the waves in index order): bit-identical in every workgroup that sums the same values, and run to run.
 // `red`: NV * (blockDim.x / 64) doubles of LDS.

@@ -439,29 +439,40 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
 
   // the state the next attempt starts from if the pending one is accepted (nearly always): requested before the
   // partial sums and the controller, whose latency then hides the loads
-  const int old_slot = c.slot, cand = c.slot ^ 1;
+  const int phase_in = uni(c.phase), old_slot = uni(c.slot), cand = old_slot ^ 1, pending_stored = uni(c.stored);
   f32x4 ya, yb, k0a, k0b;
-  if (c.phase == 3) {
+  if (phase_in == 3) {
     ya = load_units4<STRIDE>(Ys[cand] + e, u0, Hr); yb = load_units4<STRIDE>(Ys[cand] + e, u1, Hr);
-    if (c.stored & 1) { k0a = load_units4<STRIDE>(Ks[cand] + e, u0, Hr); k0b = load_units4<STRIDE>(Ks[cand] + e, u1, Hr); }
+    if (pending_stored & 1) { k0a = load_units4<STRIDE>(Ks[cand] + e, u0, Hr); k0b = load_units4<STRIDE>(Ks[cand] + e, u1, Hr); }
   }
 
   double sums[2] = {0.0, 0.0};
-  if (c.phase != 0 && g.ext_sums) {                               // one controller for all shards of the batch
+  if (phase_in != 0 && g.ext_sums) {                              // one controller for all shards of the batch
     sums[0] = g.ext_sums[0]; sums[1] = g.ext_sums[1];
-  } else if (c.phase != 0) {
+  } else if (phase_in != 0) {
     for (int64_t b = tid; b < (int64_t)gridDim.x; b += blockDim.x) { sums[0] += Pp[2 * b]; sums[1] += Pp[2 * b + 1]; }
     block_total<2>(sums, red);
   }
-  const int was_refresh_pending = c.phase == 3 ? c.on_jump : 0;   // (the controller overwrites on_jump)
-  (void)was_refresh_pending;
-  const int pending_stored = c.stored;
-  const double t_lo_prev = c.t_hi;                                 // start of the pending attempt
-  (void)t_lo_prev;
   const DopriPlan<T> plan = dopri_controller<T>(g, c, sums[0], sums[1]);
-  const int mode = plan.mode;
-  const int slot = (c.phase == 3 && plan.accept) ? cand : old_slot;    // where the next attempt starts from
+  // The controller's outputs derive from LDS reads (the block sums), so the compiler would keep them -- and every
+  // stage time, interval index and slot pointer computed from them -- in vector registers; read back through lane 0
+  // they are scalars.
+  const int mode = uni(plan.mode);
+  const bool accepted = uni((int)plan.accept) != 0;
+  const int slot = (phase_in == 3 && accepted) ? cand : old_slot;      // where the next attempt starts from
   const int other = slot ^ 1;
+  const int64_t emit_from = uni(plan.emit_from), emit_to = uni(plan.emit_to);
+  const bool refresh = uni((int)c.refresh) != 0;
+  const T plan_t0 = uni((T)plan.t0), plan_dt = uni((T)plan.dt), plan_t1 = uni((T)plan.t1), h0f = uni(plan.h0_state);
+  const T dt_done = uni((T)plan.dt_done);
+  const double t_lo = uni(c.t_lo), t_hi = uni(c.t_hi);
+  const bool will_emit = mode == 2 && c.i_out < g.n_out && !(g.t_out[c.i_out] > plan.t1);
+  const int stored = uni(mode == 2 ? (((!c.on_jump || will_emit) ? 1 : 0) | (will_emit ? 2 : 0)) : 0);
+  if (blockIdx.x == 0 && tid == 0) {                               // the controller block for the next launch
+    c.phase = mode == 0 ? 1 : mode == 1 ? 2 : mode == 2 ? 3 : 4;
+    c.slot = slot; c.stored = stored;
+    g.ctrl[q2] = c;
+  }
 
   const float4* wy = reinterpret_cast<const float4*>(img_lds) + lane;
   const float4* by = reinterpret_cast<const float4*>(img_lds + WY_FLOATS) + q;
@@ -498,19 +509,19 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   };
 
   double acc[2] = {0.0, 0.0};
-  if (c.phase == 0) {
+  if (phase_in == 0) {
     ya = load_units4<STRIDE>(g.z0 + e, u0, Hr); yb = load_units4<STRIDE>(g.z0 + e, u1, Hr);
     if (valid) { store_units4<STRIDE>(g.z_out + (series * g.n_out) * Hr, u0, Hr, ya); store_units4<STRIDE>(g.z_out + (series * g.n_out) * Hr, u1, Hr, yb); }
     k0a = k0b = f32x4{0.f, 0.f, 0.f, 0.f};
-  } else if (c.phase == 1 || c.phase == 2) {
+  } else if (phase_in == 1 || phase_in == 2) {
     ya = load_units4<STRIDE>(Ys[slot] + e, u0, Hr); yb = load_units4<STRIDE>(Ys[slot] + e, u1, Hr);
     k0a = load_units4<STRIDE>(Ks[slot] + e, u0, Hr); k0b = load_units4<STRIDE>(Ks[slot] + e, u1, Hr);
-  } else if (plan.accept) {
+  } else if (accepted) {
     // (ya, yb) = y1 and -- unless f is re-evaluated after a jump -- (k0a, k0b) = k6 of the accepted step are in flight
-    if (plan.emit_to > plan.emit_from) {
+    if (emit_to > emit_from) {
       // outputs covered by the accepted step: 4th-order dense interpolant (oracle _fit_dense / _eval_dense); such an
       // attempt always stores k6 and the midpoint
-      const T dtf = (T)plan.dt_done;
+      const T dtf = dt_done;
       const f32x4 y0a = load_units4<STRIDE>(Ys[old_slot] + e, u0, Hr), y0b = load_units4<STRIDE>(Ys[old_slot] + e, u1, Hr);
       const f32x4 f0a = load_units4<STRIDE>(Ks[old_slot] + e, u0, Hr), f0b = load_units4<STRIDE>(Ks[old_slot] + e, u1, Hr);
       const f32x4 ma = load_units4<STRIDE>(Mid + e, u0, Hr), mb = load_units4<STRIDE>(Mid + e, u1, Hr);
@@ -522,8 +533,8 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
       const f32x4 cca = dtf * (f1a - 4.f * f0a) - 11.f * y0a - 5.f * y1a + 16.f * ma;
       const f32x4 ccb = dtf * (f1b - 4.f * f0b) - 11.f * y0b - 5.f * y1b + 16.f * mb;
       const f32x4 cda = dtf * f0a, cdb = dtf * f0b;
-      for (int64_t io = plan.emit_from; io < plan.emit_to; ++io) {
-        const T x = (T)((g.t_out[io] - c.t_lo) / (c.t_hi - c.t_lo));
+      for (int64_t io = emit_from; io < emit_to; ++io) {
+        const T x = (T)((g.t_out[io] - t_lo) / (t_hi - t_lo));
         f32x4 ta = y0a + x * cda, tb = y0b + x * cdb;
         T xp = x;
         xp = xp * x; ta = ta + xp * cca; tb = tb + xp * ccb;
@@ -536,12 +547,10 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
     ya = load_units4<STRIDE>(Ys[slot] + e, u0, Hr); yb = load_units4<STRIDE>(Ys[slot] + e, u1, Hr);
     k0a = load_units4<STRIDE>(Ks[slot] + e, u0, Hr); k0b = load_units4<STRIDE>(Ks[slot] + e, u1, Hr);
   }
-  (void)pending_stored;
 
   float dX[CT];
-  int stored = 0;
   if (mode == 0) {
-    slope_at((T)c.t_hi, dX);
+    slope_at((T)t_hi, dX);
     field(ya, yb, dX, k0a, k0b);
     const f32x4 sa = atol + abs4(ya) * rtol, sb = atol + abs4(yb) * rtol;
     if (valid) {
@@ -551,26 +560,24 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
       store_units4<STRIDE>(Ks[slot] + e, u0, Hr, k0a); store_units4<STRIDE>(Ks[slot] + e, u1, Hr, k0b);
     }
   } else if (mode == 1) {
-    const T h0 = plan.h0_state;
+    const T h0 = h0f;
     const f32x4 za = ya + h0 * k0a, zb = yb + h0 * k0b;
-    slope_at((T)(c.t_hi + (double)h0), dX);
+    slope_at((T)(t_hi + (double)h0), dX);
     f32x4 f1a, f1b;
     field(za, zb, dX, f1a, f1b);
     const f32x4 sa = atol + abs4(ya) * rtol, sb = atol + abs4(yb) * rtol;
     if (valid) acc[0] = sq4((f1a - k0a) / sa) + sq4((f1b - k0b) / sb);
   } else if (mode == 2) {
-    const T t0f = (T)plan.t0, dtf = (T)plan.dt, t1f = (T)plan.t1;
-    if (c.refresh) {                                                  // just after the jump we landed on
+    const T t0f = plan_t0, dtf = plan_dt, t1f = plan_t1;
+    if (refresh) {                                                    // just after the jump we landed on
       slope_at(next_toward(t0f, 1.f), dX);
       field(ya, yb, dX, k0a, k0b);
       if (valid) {                                                    // a rejected attempt restarts from this k0
         store_units4<STRIDE>(Ks[slot] + e, u0, Hr, k0a); store_units4<STRIDE>(Ks[slot] + e, u1, Hr, k0b);
       }
     }
-    // will the step, if accepted, cover an output time?  Only then are k6 (when the step ends on a jump) and the
-    // midpoint ever read
-    const bool will_emit = c.i_out < g.n_out && !(g.t_out[c.i_out] > plan.t1);
-    stored = ((!c.on_jump || will_emit) ? 1 : 0) | (will_emit ? 2 : 0);
+    // (`stored`: will the step, if accepted, cover an output time?  Only then are k6 -- when the step ends on a jump --
+    // and the midpoint ever read)
     f32x4 ka[7], kb[7];
     ka[0] = k0a; kb[0] = k0b;
     f32x4 zia = ya, zib = yb;
@@ -617,11 +624,6 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   }
   block_total<2>(acc, red);
   if (tid == 0) { Pq[2 * blockIdx.x] = acc[0]; Pq[2 * blockIdx.x + 1] = acc[1]; }
-  if (blockIdx.x == 0 && tid == 0) {
-    c.phase = mode == 0 ? 1 : mode == 1 ? 2 : mode == 2 ? 3 : 4;
-    c.slot = slot; c.stored = stored;
-    g.ctrl[q2] = c;
-  }
 }
 
 // ------------------------------------------------------------------------------------------ wide attempt kernel
@@ -631,20 +633,6 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
 // (v_mfma_f32_16x16x4_f32), the stage state crosses the waves through LDS once per evaluation.  A bounded grid of
 // workgroups walks the tiles; the control derivative of a tile at all stage times and the tile's state are requested
 // one tile ahead.  Same controller, same two state slots, same partial sums as dopri5_attempt_mfma.
-// wave-uniform copies: the controller's outputs derive from LDS reads (the block sums), so the compiler keeps them --
-// and everything computed from them -- in vector registers; read back through lane 0 they live in scalar registers
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ float uni(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
-__device__ __forceinline__ double uni(double v) {
-  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
-  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-__device__ __forceinline__ int64_t uni(int64_t v) {
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)((uint64_t)v >> 32));
-  return (int64_t)(((uint64_t)hi << 32) | lo);
-}
-
 constexpr int64_t DOPRI_MAX_LDS_KNOTS_WIDE = 8192;
 constexpr int DOPRI_WIDE_RED_FLOATS = 128;               // 2 * (waves) doubles of reduction scratch, padded
 
