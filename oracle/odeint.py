@@ -516,6 +516,10 @@ def odeint_adjoint(func, y0, t, *, rtol=1e-7, atol=1e-9, method=None, options=No
     func_uncast = func_flat
     func_flat = lambda tt, yy: func_uncast(tt.to(yy.dtype), yy)
 
+    # adjoint_options=dict(norm="seminorm"): torchdiffeq replaces the string by max(|vjp_t|, rms(y), rms(a_y)) -- the
+    # parameter blocks do not take part in the step-size control
+    if adjoint_options.get("norm") == "seminorm":
+        adjoint_options["norm"] = lambda parts: max(parts[0].abs(), _rms(parts[1]), _rms(parts[2]))
     # default adjoint norm for adaptive methods: max(|vjp_t|, rms(y), rms(a_y), max_p rms(a_p))
     if "norm" not in adjoint_options:
         def adjoint_norm(parts):

@@ -452,7 +452,7 @@ _DOPRI_CHUNK = 48          # attempt kernels queued between two looks at the don
 
 class _Dopri5Plan:
     def __init__(self, path, field, batch, H, C, t, rtol, atol, options, variant=_lib.VARIANT_AUTO,
-                 adjoint_rtol=None, adjoint_atol=None):
+                 adjoint_rtol=None, adjoint_atol=None, adjoint_options=None):
         self.variant = variant
         self.adjoint_rtol = float(rtol if adjoint_rtol is None else adjoint_rtol)
         self.adjoint_atol = float(atol if adjoint_atol is None else adjoint_atol)
@@ -488,6 +488,22 @@ class _Dopri5Plan:
             jt = torch.sort(jt).values
             self.jump_t, self.n_jump = jt.to(self.device), jt.numel()
             self.jump_s = (-jt).flip(0).contiguous().to(self.device)      # the backward solve runs in s = -t
+        self.n_jump_s = self.n_jump
+        self.adj_safety, self.adj_ifactor, self.adj_dfactor = self.safety, self.ifactor, self.dfactor
+        if adjoint_options is not None:
+            # torchdiffeq: explicit adjoint_options REPLACE the forward options for the backward solve (no jump_t unless
+            # it is repeated there); the only norm accepted here is "seminorm", which is K4a's norm
+            adj = dict(adjoint_options)
+            adj.pop("norm", None)
+            jump_b = adj.pop("jump_t", None)
+            self.adj_safety = float(adj.pop("safety", 0.9))
+            self.adj_ifactor = float(adj.pop("ifactor", 10.0))
+            self.adj_dfactor = float(adj.pop("dfactor", 0.2))
+            if jump_b is None:
+                self.jump_s, self.n_jump_s = None, 0
+            else:
+                jb = torch.sort(_to_host(torch.as_tensor(jump_b)).to(torch.float64).reshape(-1)).values
+                self.jump_s, self.n_jump_s = (-jb).flip(0).contiguous().to(self.device), jb.numel()
 
     def _run_shared(self, lib, shared, out, z0c, w, b, dt, workspace):
         """One controller for all shards: per attempted step the pending error sums are all-reduced before the launch
@@ -554,8 +570,8 @@ class _Dopri5Plan:
                 def advance(first, count, sums_ptr, global_batch):
                     _lib.check(lib.cde_dopri5_adjoint_advance(
                         _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w),
-                        _lib.ptr(b), self.act, _lib.ptr(y), _lib.ptr(a), s0, s1, _lib.ptr(self.jump_s), self.n_jump,
-                        self.adjoint_rtol, self.adjoint_atol, self.safety, self.ifactor, self.dfactor, _lib.ptr(a_out), B,
+                        _lib.ptr(b), self.act, _lib.ptr(y), _lib.ptr(a), s0, s1, _lib.ptr(self.jump_s), self.n_jump_s,
+                        self.adjoint_rtol, self.adjoint_atol, self.adj_safety, self.adj_ifactor, self.adj_dfactor, _lib.ptr(a_out), B,
                         C, H, _lib.dtype_enum(torch.float32), int(i == self.n_out - 1), _lib.ptr(workspace),
                         workspace.numel(), first, count, sums_ptr, global_batch, _lib.stream_ptr(dev)),
                         "cde_dopri5_adjoint_advance")
@@ -845,9 +861,14 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
     mfma_shape = z0.dtype == torch.float32 and H <= 32 and C <= 8 and variant != _lib.VARIANT_GENERIC
     # the adaptive backward (K4a): affine family on the MFMA tiles, adjoint solver = forward solver with the same
     # options (the reference's default: solver.py:199-203 only copies the tolerances), parameters of the field only
+    # adjoint_options: none (the backward inherits the forward options and torchdiffeq's mixed norm, of which K4a keeps
+    # the state blocks: a stated deviation), or norm="seminorm" -- torchdiffeq's own state-only norm, i.e. K4a's
+    adj_opts = kwargs.get("adjoint_options")
+    adj_opts_ok = adj_opts is None or (isinstance(adj_opts, dict) and adj_opts.get("norm") == "seminorm"
+                                       and set(adj_opts) <= {"norm", "jump_t", "safety", "ifactor", "dfactor"})
     dopri_adjoint = (method == "dopri5" and adjoint and wants_grad and not wants_t and not control_wants and mfma_shape
                      and field is not None and kwargs.get("adjoint_method") in (None, "dopri5")
-                     and kwargs.get("adjoint_options") is None and set(options or ()) <= {"jump_t", "safety", "ifactor", "dfactor"}
+                     and adj_opts_ok and set(options or ()) <= {"jump_t", "safety", "ifactor", "dfactor"}
                      and (given_params is None or all(p is field.weight or p is field.bias for p in given_params)))
     fused = (field is not None and ((method == "rk4" and (adjoint or not wants_grad))
                                     or (method == "dopri5" and (not wants_grad or dopri_adjoint)))
@@ -914,7 +935,7 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         adjoint_rtol, adjoint_atol = kwargs.pop("adjoint_rtol", None), kwargs.pop("adjoint_atol", None)
         if kwargs:
             raise NotImplementedError("torchcde_amd: unsupported cdeint keyword arguments {}".format(sorted(kwargs)))
-        plan = _Dopri5Plan(X, field, batch, H, C, t, rtol, atol, options, variant, adjoint_rtol, adjoint_atol)
+        plan = _Dopri5Plan(X, field, batch, H, C, t, rtol, atol, options, variant, adjoint_rtol, adjoint_atol, adj_opts)
         wants = (True, True) if given is None else (any(p is weight for p in given), any(p is bias for p in given))
         return _FusedDopri5.apply(z0, weight, bias, plan, wants)
     step_size = _parse_fixed_options(options, "solver")

@@ -358,6 +358,8 @@ class _Adjoint(torch.autograd.Function):
                 return (vt, fe, vy, *vp)
 
             adj_options = dict(cfg["adjoint_options"])
+            if adj_options.get("norm") == "seminorm":        # torchdiffeq: the parameter blocks stay out of the error norm
+                adj_options["norm"] = lambda parts: max(parts[0].abs(), _rms(parts[1]), _rms(parts[2]))
             if cfg["adjoint_method"] == "dopri5" and "norm" not in adj_options:
                 def adjoint_norm(parts):
                     tt, yy, aa, *pp = parts
