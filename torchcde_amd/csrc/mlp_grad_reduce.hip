@@ -19,24 +19,35 @@
 namespace cde {
 
 template <int MT> struct VecOf;
-template <> struct VecOf<4> { using type = float4; };
-template <> struct VecOf<2> { using type = float2; };
-
-template <int MT> __device__ __forceinline__ void unpack(const typename VecOf<MT>::type& v, float (&o)[MT]);
-template <> __device__ __forceinline__ void unpack<4>(const float4& v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
-template <> __device__ __forceinline__ void unpack<2>(const float2& v, float (&o)[2]) { o[0] = v.x; o[1] = v.y; }
+template <> struct VecOf<4> { using type = f32x4; };
+template <> struct VecOf<2> { using type = f32x2; };
 
 // M = 4 waves * MT * 16 rows per workgroup (blockIdx.y selects the block of M rows when a G row is wider: `gc` floats);
-// N = NG * (NV * 16) columns, NV = floats per B load (4 or 2), NG groups of NV tiles
+// N = NG * (NV * 16) columns, NV = floats per B operand read (4 or 2), NG groups of NV tiles.
+// The slab is walked in tiles of GRAD_TILE_ROWS rows staged through LDS, double buffered: while the MFMAs of tile k run
+// from LDS, the global loads of tile k+1 are in flight into registers, and are written to the other LDS buffer after
+// the MFMAs.  (The first version fed the MFMAs straight from global loads with one group of 16 rows in flight: an HBM
+// round trip under load is longer than the 128 MFMAs of such a group -- 57 % of the MFMA peak at 2.1 TB/s.  Deeper
+// register rings do not survive the compiler's s_waitcnt placement across the loop's back edge; see DESIGN.md.)
+constexpr int GRAD_TILE_ROWS = 16;
+
+template <int MT, int NV, int NG>
+constexpr size_t grad_partial_lds_bytes() {
+  return (size_t)2 * GRAD_TILE_ROWS * ((4 * MT * 16 + 4) + (NG * NV * 16 + 4)) * sizeof(float);
+}
+
 template <int MT, int NV, int NG>
 __global__ __launch_bounds__(256, 2) void mlp_grad_partial_kernel(const float* __restrict__ G, const float* __restrict__ X,
                                                                   int64_t rows, int64_t rows_per_slab, int xc,
                                                                   float* __restrict__ partial, int gc) {
-  constexpr int M = 4 * MT * 16, NT = NG * NV, N = NT * 16;
-  const int m0 = blockIdx.y * M;
+  constexpr int M = 4 * MT * 16, NT = NG * NV, N = NT * 16, R = GRAD_TILE_ROWS;
+  constexpr int GS = M + 4, XS = N + 4;                      // LDS row strides (floats)
+  constexpr int GV = R * M / 4 / 256, XV = (R * N / 4 + 255) / 256;     // float4 per thread and tile
   using AV = typename VecOf<MT>::type;
   using BV = typename VecOf<NV>::type;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int m0 = blockIdx.y * M;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
   const int64_t lo = (int64_t)blockIdx.x * rows_per_slab;
   int64_t hi = lo + rows_per_slab;
@@ -49,51 +60,65 @@ __global__ __launch_bounds__(256, 2) void mlp_grad_partial_kernel(const float* _
 #pragma unroll
     for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const float* ga = G + (m0 + w * MT * 16 + MT * i);         // + row * gc
-  const float* xb = X + NV * i;                              // + row * xc + g * NV * 16
-  auto load = [&](int64_t row, AV& a, BV (&b)[NG]) {
-    const bool on = row < hi;
-    const int64_t r = on ? row : (hi - 1);
-    a = *reinterpret_cast<const AV*>(ga + r * gc);
+  float4 gst[GV], xst[XV];                                   // the tile in flight
+  auto fetch = [&](int64_t r0) {
 #pragma unroll
-    for (int g = 0; g < NG; ++g) b[g] = *reinterpret_cast<const BV*>(xb + r * xc + g * NV * 16);
-    if (!on) {                                              // rows past the slab contribute nothing
-      a = AV{};
+    for (int j = 0; j < GV; ++j) {
+      const int f = tid + 256 * j, row = f / (M / 4), c4 = f % (M / 4);
+      const int64_t r = r0 + row;
+      gst[j] = r < hi ? *reinterpret_cast<const float4*>(G + r * gc + m0 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+      const int f = tid + 256 * j, row = f / (N / 4), c4 = f % (N / 4);
+      const int64_t r = r0 + row;
+      xst[j] = (r < hi && row < R) ? *reinterpret_cast<const float4*>(X + r * xc + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  // software pipeline: the loads of the NEXT group of KU K steps (16 rows at KU = 4) are in flight while the current
-  // group's KU * MT * NT MFMAs run -- an HBM round trip is about as long as one group
-  constexpr int KU = 4;
-  AV a_cur[KU], a_nxt[KU];
-  BV b_cur[KU][NG], b_nxt[KU][NG];
+  auto stage = [&](int buf) {
+    float* g_lds = lds + buf * R * (GS + XS);
+    float* x_lds = g_lds + R * GS;
 #pragma unroll
-  for (int u = 0; u < KU; ++u) load(lo + 4 * u + kq, a_cur[u], b_cur[u]);
-  for (int64_t r0 = lo; r0 < hi; r0 += 4 * KU) {
+    for (int j = 0; j < GV; ++j) {
+      const int f = tid + 256 * j, row = f / (M / 4), c4 = f % (M / 4);
+      *reinterpret_cast<float4*>(g_lds + row * GS + 4 * c4) = gst[j];
+    }
 #pragma unroll
-    for (int u = 0; u < KU; ++u) load(r0 + 4 * (KU + u) + kq, a_nxt[u], b_nxt[u]);
+    for (int j = 0; j < XV; ++j) {
+      const int f = tid + 256 * j, row = f / (N / 4), c4 = f % (N / 4);
+      if (row < R) *reinterpret_cast<float4*>(x_lds + row * XS + 4 * c4) = xst[j];
+    }
+  };
+  fetch(lo);
+  stage(0);
+  __syncthreads();
+  int buf = 0;
+  for (int64_t r0 = lo; r0 < hi; r0 += R) {
+    const bool more = r0 + R < hi;
+    if (more) fetch(r0 + R);
+    const float* g_lds = lds + buf * R * (GS + XS) + (w * MT * 16 + MT * i);
+    const float* x_lds = lds + buf * R * (GS + XS) + R * GS + NV * i;
 #pragma unroll
-    for (int u = 0; u < KU; ++u) {
-      float av[MT];
-      unpack<MT>(a_cur[u], av);
+    for (int s = 0; s < R / 4; ++s) {                        // K step s, lane quarter kq <-> row 4 s + kq of the tile
+      const int row = 4 * s + kq;
+      const AV a = *reinterpret_cast<const AV*>(g_lds + row * GS);
+      BV b[NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) b[g] = *reinterpret_cast<const BV*>(x_lds + row * XS + g * NV * 16);
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
-        float bv[NV];
-        unpack<NV>(b_cur[u][g], bv);
 #pragma unroll
         for (int t = 0; t < NV; ++t) {
 #pragma unroll
-          for (int tm = 0; tm < MT; ++tm) acc[tm][g * NV + t] = mfma16(av[tm], bv[t], acc[tm][g * NV + t]);
+          for (int tm = 0; tm < MT; ++tm) acc[tm][g * NV + t] = mfma16(a[tm], b[g][t], acc[tm][g * NV + t]);
         }
       }
 #pragma unroll
-      for (int tm = 0; tm < MT; ++tm) bsum[tm] += av[tm];
+      for (int tm = 0; tm < MT; ++tm) bsum[tm] += a[tm];
     }
-#pragma unroll
-    for (int u = 0; u < KU; ++u) {
-      a_cur[u] = a_nxt[u];
-#pragma unroll
-      for (int g = 0; g < NG; ++g) b_cur[u][g] = b_nxt[u][g];
-    }
+    if (more) stage(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
   }
   // partial[slab][m][N + 1]: D fragment of tile (tm, tn): lane (j = i, q = kq), register r = row 4q + r of the tile
   float* out = partial + ((int64_t)blockIdx.x * gc + m0) * (N + 1);
@@ -141,6 +166,14 @@ __global__ __launch_bounds__(256) void mlp_grad_finish_kernel(const float* __res
 
 constexpr int GRAD_SLABS = 512;
 
+#define CDE_GRAD_PARTIAL(MTV, NVV, NGV, GRID, ...)                                                                 \
+  do {                                                                                                             \
+    const size_t lds_bytes = cde::grad_partial_lds_bytes<MTV, NVV, NGV>();                                         \
+    (void)hipFuncSetAttribute((const void*)cde::mlp_grad_partial_kernel<MTV, NVV, NGV>,                            \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                         \
+    cde::mlp_grad_partial_kernel<MTV, NVV, NGV><<<GRID, 256, lds_bytes, s>>>(__VA_ARGS__);                         \
+  } while (0)
+
 // Kw (rk4_wide.hip): acc (M, N + 1) += G^T [Z | 1], G (rows, M = 512), Z (rows, N = 64 or 32)
 size_t wide_grad_reduce_partial_bytes(int M, int N) { return (size_t)GRAD_SLABS * M * (N + 1) * sizeof(float); }
 
@@ -152,8 +185,8 @@ int launch_wide_grad_reduce(const float* G, const float* Z, int64_t rows, int M,
   per = (per + 15) / 16 * 16;
   const int slabs = (int)((rows + per - 1) / per);
   const dim3 grid((unsigned)slabs, (unsigned)(M / 256));
-  if (N == 64) mlp_grad_partial_kernel<4, 4, 1><<<grid, 256, 0, s>>>(G, Z, rows, per, N, partial, M);
-  else mlp_grad_partial_kernel<4, 2, 1><<<grid, 256, 0, s>>>(G, Z, rows, per, N, partial, M);
+  if (N == 64) CDE_GRAD_PARTIAL(4, 4, 1, grid, G, Z, rows, per, N, partial, M);
+  else CDE_GRAD_PARTIAL(4, 2, 1, grid, G, Z, rows, per, N, partial, M);
   mlp_grad_finish_kernel<<<(M * (N + 1) + 63) / 64, 256, 0, s>>>(partial, slabs, M, N, acc, N + 1);
   return check_launch();
 }
@@ -176,12 +209,10 @@ extern "C" int cde_mlp_grad_reduce(const void* G, const void* X, int64_t rows, i
   per = (per + 15) / 16 * 16;
   const int slabs = (int)((rows + per - 1) / per);
   if (layer == 2) {
-    cde::mlp_grad_partial_kernel<4, 4, 2><<<slabs, 256, 0, s>>>((const float*)G, (const float*)X, rows, per, 132,
-                                                                  (float*)workspace, 256);
+    CDE_GRAD_PARTIAL(4, 4, 2, dim3((unsigned)slabs), (const float*)G, (const float*)X, rows, per, 132, (float*)workspace, 256);
     cde::mlp_grad_finish_kernel<<<(256 * 129 + 63) / 64, 256, 0, s>>>((const float*)workspace, slabs, 256, 128, (float*)acc, 132);
   } else {
-    cde::mlp_grad_partial_kernel<2, 2, 1><<<slabs, 256, 0, s>>>((const float*)G, (const float*)X, rows, per, 36,
-                                                                  (float*)workspace, 128);
+    CDE_GRAD_PARTIAL(2, 2, 1, dim3((unsigned)slabs), (const float*)G, (const float*)X, rows, per, 36, (float*)workspace, 128);
     cde::mlp_grad_finish_kernel<<<(128 * 33 + 63) / 64, 256, 0, s>>>((const float*)workspace, slabs, 128, 32, (float*)acc, 36);
   }
   return cde::check_launch();
