@@ -24,16 +24,22 @@ template <> struct VecOf<2> { using type = f32x2; };
 
 // M = 4 waves * MT * 16 rows per workgroup (blockIdx.y selects the block of M rows when a G row is wider: `gc` floats);
 // N = NG * (NV * 16) columns, NV = floats per B operand read (4 or 2), NG groups of NV tiles.
-// The slab is walked in tiles of GRAD_TILE_ROWS rows staged through LDS, double buffered: while the MFMAs of tile k run
-// from LDS, the global loads of tile k+1 are in flight into registers, and are written to the other LDS buffer after
-// the MFMAs.  (The first version fed the MFMAs straight from global loads with one group of 16 rows in flight: an HBM
-// round trip under load is longer than the 128 MFMAs of such a group -- 57 % of the MFMA peak at 2.1 TB/s.  Deeper
-// register rings do not survive the compiler's s_waitcnt placement across the loop's back edge; see DESIGN.md.)
-constexpr int GRAD_TILE_ROWS = 16;
+// The slab is walked in tiles of GRAD_TILE_ROWS rows that go from HBM straight into a ring of three LDS buffers
+// (global_load_lds_dwordx4: one wave-wide load lands 1 KB of consecutive LDS, no staging registers): while the MFMAs
+// of tile t run from LDS, the loads of tiles t+1 and t+2 are in flight.  These loads return into LDS, not into
+// registers, so the wait for tile t can be written by hand -- s_waitcnt vmcnt(loads of two tiles), then a barrier that
+// does NOT wait on vmcnt -- which is exactly what the compiler's own s_waitcnt placement would not do across the
+// loop's back edge.  (History, DESIGN.md: straight from global loads with one group of 16 rows in flight, 57 % of the
+// MFMA peak; register rings defeated by the compiler's waits or unsafe; register-staged LDS double buffering, 67 %.)
+constexpr int GRAD_TILE_ROWS = 16, GRAD_RING = 3;
 
 template <int MT, int NV, int NG>
 constexpr size_t grad_partial_lds_bytes() {
-  return (size_t)2 * GRAD_TILE_ROWS * ((4 * MT * 16 + 4) + (NG * NV * 16 + 4)) * sizeof(float);
+  return (size_t)(GRAD_RING * GRAD_TILE_ROWS * (4 * MT * 16 + NG * NV * 16) + 256) * sizeof(float);
+}
+
+__device__ __forceinline__ void ring_barrier() {           // LDS traffic of this wave done, then the workgroup barrier
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 template <int MT, int NV, int NG>
@@ -41,11 +47,15 @@ __global__ __launch_bounds__(256, 2) void mlp_grad_partial_kernel(const float* _
                                                                   int64_t rows, int64_t rows_per_slab, int xc,
                                                                   float* __restrict__ partial, int gc) {
   constexpr int M = 4 * MT * 16, NT = NG * NV, N = NT * 16, R = GRAD_TILE_ROWS;
-  constexpr int GS = M + 4, XS = N + 4;                      // LDS row strides (floats)
-  constexpr int GV = R * M / 4 / 256, XV = (R * N / 4 + 255) / 256;     // float4 per thread and tile
+  constexpr int TILE = R * (M + N);                          // floats per ring buffer: [G rows | X rows]
+  // wave-wide loads (256 floats each) per tile and wave; every wave issues the same number (idle slots load into a
+  // dummy area) so that one vmcnt value is right for all of them
+  constexpr int GROWS = 256 / M, XROWS = 256 / N;            // rows covered by one wave-wide load
+  constexpr int LG = (R / GROWS + 3) / 4, LX = (R / XROWS + 3) / 4, LOADS = LG + LX;
   using AV = typename VecOf<MT>::type;
   using BV = typename VecOf<NV>::type;
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* dummy = lds + GRAD_RING * TILE;
   const int m0 = blockIdx.y * M;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
@@ -60,51 +70,48 @@ __global__ __launch_bounds__(256, 2) void mlp_grad_partial_kernel(const float* _
 #pragma unroll
     for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  float4 gst[GV], xst[XV];                                   // the tile in flight
-  auto fetch = [&](int64_t r0) {
+  auto fetch = [&](int64_t r0, int buf) {                    // rows past the factors: a valid address, masked at use
+    float* g_lds = lds + buf * TILE;
+    float* x_lds = g_lds + R * M;
 #pragma unroll
-    for (int j = 0; j < GV; ++j) {
-      const int f = tid + 256 * j, row = f / (M / 4), c4 = f % (M / 4);
-      const int64_t r = r0 + row;
-      gst[j] = r < hi ? *reinterpret_cast<const float4*>(G + r * gc + m0 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < LG; ++j) {
+      const int ld = w + 4 * j;                              // wave-wide load `ld` covers rows ld*GROWS ..
+      const bool real = ld * GROWS < R;
+      const int row = ld * GROWS + lane / (M / 4), c4 = lane % (M / 4);
+      int64_t r = r0 + (real ? row : 0);
+      r = r < rows ? r : rows - 1;
+      __builtin_amdgcn_global_load_lds(G + r * gc + m0 + 4 * c4, real ? g_lds + ld * 256 : dummy, 16, 0, 0);
     }
 #pragma unroll
-    for (int j = 0; j < XV; ++j) {
-      const int f = tid + 256 * j, row = f / (N / 4), c4 = f % (N / 4);
-      const int64_t r = r0 + row;
-      xst[j] = (r < hi && row < R) ? *reinterpret_cast<const float4*>(X + r * xc + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  auto stage = [&](int buf) {
-    float* g_lds = lds + buf * R * (GS + XS);
-    float* x_lds = g_lds + R * GS;
-#pragma unroll
-    for (int j = 0; j < GV; ++j) {
-      const int f = tid + 256 * j, row = f / (M / 4), c4 = f % (M / 4);
-      *reinterpret_cast<float4*>(g_lds + row * GS + 4 * c4) = gst[j];
-    }
-#pragma unroll
-    for (int j = 0; j < XV; ++j) {
-      const int f = tid + 256 * j, row = f / (N / 4), c4 = f % (N / 4);
-      if (row < R) *reinterpret_cast<float4*>(x_lds + row * XS + 4 * c4) = xst[j];
+    for (int j = 0; j < LX; ++j) {
+      const int ld = w + 4 * j;
+      const bool real = ld * XROWS < R;
+      const int row = ld * XROWS + lane / (N / 4), c4 = lane % (N / 4);
+      int64_t r = r0 + (real ? row : 0);
+      r = r < rows ? r : rows - 1;
+      __builtin_amdgcn_global_load_lds(X + r * xc + 4 * c4, real ? x_lds + ld * 256 : dummy, 16, 0, 0);
     }
   };
-  fetch(lo);
-  stage(0);
-  __syncthreads();
+  fetch(lo, 0);
+  fetch(lo + R, 1);
   int buf = 0;
   for (int64_t r0 = lo; r0 < hi; r0 += R) {
-    const bool more = r0 + R < hi;
-    if (more) fetch(r0 + R);
-    const float* g_lds = lds + buf * R * (GS + XS) + (w * MT * 16 + MT * i);
-    const float* x_lds = lds + buf * R * (GS + XS) + R * GS + NV * i;
+    const int nxt = buf >= 1 ? buf - 1 : GRAD_RING - 1;      // (buf + 2) % 3
+    fetch(r0 + 2 * R, nxt);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");     // this wave's part of tile r0 has landed
+    ring_barrier();                                                      // ... and everybody else's
+    const float* g_lds = lds + buf * TILE + (w * MT * 16 + MT * i);
+    const float* x_lds = lds + buf * TILE + R * M + NV * i;
 #pragma unroll
     for (int s = 0; s < R / 4; ++s) {                        // K step s, lane quarter kq <-> row 4 s + kq of the tile
       const int row = 4 * s + kq;
-      const AV a = *reinterpret_cast<const AV*>(g_lds + row * GS);
+      const bool on = r0 + row < hi;
+      AV a = *reinterpret_cast<const AV*>(g_lds + row * M);
+#pragma unroll
+      for (int tm = 0; tm < MT; ++tm) a[tm] = on ? a[tm] : 0.f;
       BV b[NG];
 #pragma unroll
-      for (int g = 0; g < NG; ++g) b[g] = *reinterpret_cast<const BV*>(x_lds + row * XS + g * NV * 16);
+      for (int g = 0; g < NG; ++g) b[g] = *reinterpret_cast<const BV*>(x_lds + row * N + g * NV * 16);
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
 #pragma unroll
@@ -116,10 +123,10 @@ __global__ __launch_bounds__(256, 2) void mlp_grad_partial_kernel(const float* _
 #pragma unroll
       for (int tm = 0; tm < MT; ++tm) bsum[tm] += a[tm];
     }
-    if (more) stage(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
+    ring_barrier();                                          // the buffer may be refilled two iterations from now
+    buf = buf == GRAD_RING - 1 ? 0 : buf + 1;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // nothing may still be landing in LDS when the workgroup ends
   // partial[slab][m][N + 1]: D fragment of tile (tm, tn): lane (j = i, q = kq), register r = row 4q + r of the tile
   float* out = partial + ((int64_t)blockIdx.x * gc + m0) * (N + 1);
 #pragma unroll
