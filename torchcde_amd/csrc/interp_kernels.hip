@@ -435,6 +435,73 @@ __global__ __launch_bounds__(256) void natural_cubic_kernel(const T* __restrict_
   }
 }
 
+// Backward of natural_cubic_kernel w.r.t. the values, paths WITHOUT missing entries (what autograd produces through
+// interpolation_cubic.py:7-54 and the tridiagonal solve of misc.py:14-67; reference test/test_tricks.py:21-49
+// differentiates through the coefficient construction).  The coefficients are linear in the values for fixed knots:
+//   kd = T^-1 rhs(v),  b_k = kd_k,  2c_k = 6 dv_k r_k^2 - (4 kd_k + 2 kd_{k+1}) r_k,  3d_k = -6 dv_k r_k^3 + 3 (kd_k + kd_{k+1}) r_k^2
+// so the gradient is the transposed map: collect dL/dkd from the three blocks, solve with the same (symmetric)
+// tridiagonal matrix, push the solution through rhs_k = s_{k-1} + s_k, s_k = 3 dv_k r_k^2, dv_k = v_{k+1} - v_k.
+// The elimination factors depend on the knots only: natural_cubic_aux_kernel computes them once per call
+// (aux[k] = c'_k, aux[L + k] = 1 / pivot_k); one lane per scalar path then does a forward and a backward sweep, its
+// own output row doubling as the temporary of the forward sweep.
+template <typename T>
+__global__ void natural_cubic_aux_kernel(const T* __restrict__ t, T* __restrict__ aux, int64_t L) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  T c_prev = 0;
+  for (int64_t k = 0; k < L; ++k) {
+    const T r_lo = k >= 1 ? (T)1 / (t[k] - t[k - 1]) : (T)0, r_hi = k <= L - 2 ? (T)1 / (t[k + 1] - t[k]) : (T)0;
+    const T pivot = (r_lo + r_hi) * (T)2 - r_lo * c_prev;
+    const T inv = (T)1 / pivot;
+    c_prev = r_hi * inv;
+    aux[k] = c_prev;
+    aux[L + k] = inv;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void natural_cubic_backward_kernel(const T* __restrict__ grad, const T* __restrict__ t,
+                                                                     const T* __restrict__ aux, T* __restrict__ grad_x,
+                                                                     int64_t B, int64_t L, int64_t C) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * C) return;
+  const int64_t b = e / C, c = e - b * C;
+  const T* g = grad + b * (L - 1) * 4 * C + c;              // piece k: a, b, 2c, 3d at g[k*4C + {0, C, 2C, 3C}]
+  T* out = grad_x + b * L * C + c;
+  const int64_t RS = 4 * C;
+  if (L == 2) {
+    const T gb = g[C] / (t[1] - t[0]);
+    out[0] = g[0] - gb;
+    out[C] = gb;
+    return;
+  }
+  // forward sweep of T y = dL/dkd; out[k] <- d'_k
+  T d_prev = 0, r_prev = 0, gc_prev = 0, gd_prev = 0;
+  for (int64_t k = 0; k < L; ++k) {
+    T gkd = 0, r = 0, gc = 0, gd = 0;
+    if (k <= L - 2) {
+      r = (T)1 / (t[k + 1] - t[k]);
+      gc = g[k * RS + 2 * C]; gd = g[k * RS + 3 * C];
+      gkd = g[k * RS + C] - (T)4 * r * gc + (T)3 * r * r * gd;
+    }
+    if (k >= 1) gkd += (T)3 * r_prev * r_prev * gd_prev - (T)2 * r_prev * gc_prev;
+    const T d = (gkd - r_prev * d_prev) * aux[L + k];
+    out[k * C] = d;
+    d_prev = d; r_prev = r; gc_prev = gc; gd_prev = gd;
+  }
+  // backward sweep: y_k, and with y_k, y_{k+1} the gradient of dv_k = v_{k+1} - v_k
+  T y_next = out[(L - 1) * C];                              // y_{L-1} = d'_{L-1}
+  T gv_next = 0;                                            // what v_{k+1} has collected so far (-(dL/d dv_{k+1}))
+  for (int64_t k = L - 2; k >= 0; --k) {
+    const T y = out[k * C] - aux[k] * y_next;
+    const T r = (T)1 / (t[k + 1] - t[k]), r2 = r * r;
+    const T gdv = (T)6 * r2 * g[k * RS + 2 * C] - (T)6 * r2 * r * g[k * RS + 3 * C] + (T)3 * r2 * (y + y_next);
+    out[(k + 1) * C] = gv_next + gdv + (k + 1 <= L - 2 ? g[(k + 1) * RS] : (T)0);
+    gv_next = -gdv;
+    y_next = y;
+  }
+  out[0] = gv_next + g[0];
+}
+
 // ------------------------------------------------------------------------------------------ K5 log-ODE windows
 // logsig_windows / logsignature_windows (reference log_ode.py:15-133) after the host has merged the window
 // boundaries into the series and filled them linearly: for every window the logsignature (depth <= 3) of the
@@ -763,6 +830,33 @@ extern "C" int cde_natural_cubic_coeffs(const void* x, const void* t, void* coef
   else return CDE_ERR_DTYPE;
   return cde::check_launch();
 }
+
+extern "C" size_t cde_natural_cubic_coeffs_backward_workspace_bytes(int64_t L, int dtype) {
+  return (size_t)2 * (size_t)L * (dtype == CDE_F64 ? 8 : 4);
+}
+
+extern "C" int cde_natural_cubic_coeffs_backward(const void* grad_coeffs, const void* t, void* grad_x, void* workspace,
+                                                 size_t workspace_bytes, int64_t B, int64_t L, int64_t C, int dtype,
+                                                 void* stream) {
+  if (B < 0 || L < 2 || C < 1) return CDE_ERR_SHAPE;
+  if (B == 0) return CDE_OK;
+  if (!grad_coeffs || !t || !grad_x || !workspace) return CDE_ERR_NULL;
+  if (dtype != CDE_F32 && dtype != CDE_F64) return CDE_ERR_DTYPE;
+  if (workspace_bytes < cde_natural_cubic_coeffs_backward_workspace_bytes(L, dtype)) return CDE_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((B * C + 255) / 256);
+  if (dtype == CDE_F32) {
+    cde::natural_cubic_aux_kernel<float><<<1, 64, 0, s>>>((const float*)t, (float*)workspace, L);
+    cde::natural_cubic_backward_kernel<float><<<grid, 256, 0, s>>>((const float*)grad_coeffs, (const float*)t,
+                                                                   (const float*)workspace, (float*)grad_x, B, L, C);
+  } else {
+    cde::natural_cubic_aux_kernel<double><<<1, 64, 0, s>>>((const double*)t, (double*)workspace, L);
+    cde::natural_cubic_backward_kernel<double><<<grid, 256, 0, s>>>((const double*)grad_coeffs, (const double*)t,
+                                                                    (const double*)workspace, (double*)grad_x, B, L, C);
+  }
+  return cde::check_launch();
+}
+
 
 extern "C" int cde_logsig_windows(const void* x, const int64_t* rows, const void* scale, const int32_t* words, void* out,
                                   int64_t B, int64_t L, int64_t C, int depth, int64_t n_windows, int n_words, int dtype,

@@ -159,15 +159,55 @@ class _LinearFill(torch.autograd.Function):
 def _natural_cubic(x, t, version):
     t = _validate_input_path(x, t)
     _lib.require_gpu(x, "x")
-    _no_grad_through_path(x, t)
-    src, B, L, C = _flat3(x)
+    _no_grad_through_path(t)
     knots = t.detach().to(device=x.device, dtype=x.dtype).contiguous()
+    has_missing = bool(torch.isnan(x).any())
+    if torch.is_grad_enabled() and x.requires_grad:
+        if has_missing:
+            raise NotImplementedError("torchcde_amd: gradients through the natural cubic fit are implemented for data "
+                                      "without missing values only.")
+        return _NaturalCubicFit.apply(x, knots, version)
+    return _natural_cubic_forward(x, knots, version, has_missing)
+
+
+def _natural_cubic_forward(x, knots, version, has_missing):
+    src, B, L, C = _flat3(x)
     out = torch.empty(*x.shape[:-2], L - 1, 4 * C, dtype=x.dtype, device=x.device)
     lib = _lib.load()
     _lib.check(lib.cde_natural_cubic_coeffs(_lib.ptr(src), _lib.ptr(knots), _lib.ptr(out), B, L, C, version,
-                                            int(bool(torch.isnan(x).any())), _lib.dtype_enum(x.dtype),
+                                            int(has_missing), _lib.dtype_enum(x.dtype),
                                             _lib.stream_ptr(x.device)), "cde_natural_cubic_coeffs")
     return out
+
+
+class _NaturalCubicFit(torch.autograd.Function):
+    """K1n with its backward (data without missing values): the coefficients are linear in the values, the gradient is
+    one more solve with the same tridiagonal matrix (``cde_natural_cubic_coeffs_backward``)."""
+
+    @staticmethod
+    def forward(ctx, x, knots, version):
+        ctx.save_for_backward(knots)
+        ctx.shape = x.shape
+        return _natural_cubic_forward(x, knots, version, False)
+
+    @staticmethod
+    def backward(ctx, grad):
+        knots, = ctx.saved_tensors
+        shape = ctx.shape
+        L, C = shape[-2], shape[-1]
+        B = 1
+        for d in shape[:-2]:
+            B *= d
+        grad = grad.contiguous()
+        grad_x = torch.empty(shape, dtype=grad.dtype, device=grad.device)
+        lib = _lib.load()
+        dt = _lib.dtype_enum(grad.dtype)
+        nbytes = lib.cde_natural_cubic_coeffs_backward_workspace_bytes(L, dt)
+        workspace = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=grad.device)
+        _lib.check(lib.cde_natural_cubic_coeffs_backward(_lib.ptr(grad), _lib.ptr(knots), _lib.ptr(grad_x),
+                                                         _lib.ptr(workspace), nbytes, B, L, C, dt,
+                                                         _lib.stream_ptr(grad.device)), "cde_natural_cubic_coeffs_backward")
+        return grad_x, None, None
 
 
 def natural_cubic_coeffs(x, t=None):
