@@ -99,12 +99,16 @@ int cde_hermite_bdiff_coeffs_backward(const void* grad_coeffs, const void* t, vo
  *   :149-160; passing 0 for NaN-free data skips that pass -- the floats are the same either way). */
 int cde_natural_cubic_coeffs(const void* x, const void* t, void* coeffs, int64_t B, int64_t L, int64_t C, int version,
                              int has_missing, int dtype, void* stream);
-/* Its backward w.r.t. the values for paths WITHOUT missing entries: grad_coeffs (B, L-1, 4C) -> grad_x (B, L, C)
- * (autograd through interpolation_cubic.py:7-54 and the tridiagonal solve misc.py:14-67).  `workspace`: at least
- * cde_natural_cubic_coeffs_backward_workspace_bytes(L, dtype) bytes (the elimination factors of the knots). */
+/* Its backward for paths WITHOUT missing entries: grad_coeffs (B, L-1, 4C) -> grad_x (B, L, C) (autograd through
+ * interpolation_cubic.py:7-54 and the tridiagonal solve misc.py:14-67).  `workspace`: at least
+ * cde_natural_cubic_coeffs_backward_workspace_bytes(L, dtype) bytes (the elimination factors of the knots).
+ * grad_t_rows != NULL: also the gradient w.r.t. the knot times (reference test/test_tricks.py:21-49 passes the same
+ * `t` to the fit and to the spline): pass `x` (the forward input) and two (B, L, C) buffers; grad_t_rows receives one
+ * partial dL/dt row per scalar path, to be summed over B and C. */
 size_t cde_natural_cubic_coeffs_backward_workspace_bytes(int64_t L, int dtype);
 int cde_natural_cubic_coeffs_backward(const void* grad_coeffs, const void* t, void* grad_x, void* workspace,
-                                      size_t workspace_bytes, int64_t B, int64_t L, int64_t C, int dtype, void* stream);
+                                      size_t workspace_bytes, int64_t B, int64_t L, int64_t C, int dtype, const void* x,
+                                      void* kd_scratch, void* grad_t_rows, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K0  Missing-value construction: the NaN path of linear_interpolation_coeffs

@@ -458,21 +458,48 @@ __global__ void natural_cubic_aux_kernel(const T* __restrict__ t, T* __restrict_
   }
 }
 
-template <typename T>
+// WITH_T: also the gradient w.r.t. the knot times, as one partial row per scalar path (summed over the paths by the
+// caller): the solve's solution kd is recomputed from the values into `kd_buf` (B, L, C), and with y = T^-1 dL/dkd
+//   dL/dr_k = gc_k [12 dv_k r_k - (4 kd_k + 2 kd_{k+1})] + gd_k [-18 dv_k r_k^2 + 6 (kd_k + kd_{k+1}) r_k]
+//           + 6 dv_k r_k (y_k + y_{k+1}) - [2 y_k kd_k + 2 y_{k+1} kd_{k+1} + y_k kd_{k+1} + y_{k+1} kd_k],
+//   r_k = 1 / (t_{k+1} - t_k):  dL/dt_{k+1} -= r_k^2 dL/dr_k,  dL/dt_k += r_k^2 dL/dr_k.
+template <typename T, bool WITH_T>
 __global__ __launch_bounds__(256) void natural_cubic_backward_kernel(const T* __restrict__ grad, const T* __restrict__ t,
                                                                      const T* __restrict__ aux, T* __restrict__ grad_x,
-                                                                     int64_t B, int64_t L, int64_t C) {
+                                                                     int64_t B, int64_t L, int64_t C,
+                                                                     const T* __restrict__ x, T* __restrict__ kd_buf,
+                                                                     T* __restrict__ grad_t_rows) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= B * C) return;
   const int64_t b = e / C, c = e - b * C;
   const T* g = grad + b * (L - 1) * 4 * C + c;              // piece k: a, b, 2c, 3d at g[k*4C + {0, C, 2C, 3C}]
   T* out = grad_x + b * L * C + c;
+  const T* v = WITH_T ? x + b * L * C + c : nullptr;
+  T* kd = WITH_T ? kd_buf + b * L * C + c : nullptr;
+  T* gt = WITH_T ? grad_t_rows + b * L * C + c : nullptr;
   const int64_t RS = 4 * C;
   if (L == 2) {
     const T gb = g[C] / (t[1] - t[0]);
     out[0] = g[0] - gb;
     out[C] = gb;
+    if (WITH_T) {                                           // b_0 = (v_1 - v_0) / (t_1 - t_0)
+      const T w = g[C] * (v[C] - v[0]) / ((t[1] - t[0]) * (t[1] - t[0]));
+      gt[0] = w; gt[C] = -w;
+    }
     return;
+  }
+  if (WITH_T) {                                             // the forward solve again: kd = T^-1 rhs(v)
+    T d_prev = 0, r_prev = 0, s_prev = 0;
+    for (int64_t k = 0; k < L; ++k) {
+      T r = 0, sc = 0;
+      if (k <= L - 2) { r = (T)1 / (t[k + 1] - t[k]); sc = (T)3 * (v[(k + 1) * C] - v[k * C]) * r * r; }
+      const T d = ((s_prev + sc) - r_prev * d_prev) * aux[L + k];
+      kd[k * C] = d;
+      d_prev = d; r_prev = r; s_prev = sc;
+    }
+    T next = kd[(L - 1) * C];
+    gt[(L - 1) * C] = (T)0;
+    for (int64_t k = L - 2; k >= 0; --k) { next = kd[k * C] - aux[k] * next; kd[k * C] = next; gt[k * C] = (T)0; }
   }
   // forward sweep of T y = dL/dkd; out[k] <- d'_k
   T d_prev = 0, r_prev = 0, gc_prev = 0, gd_prev = 0;
@@ -497,6 +524,14 @@ __global__ __launch_bounds__(256) void natural_cubic_backward_kernel(const T* __
     const T gdv = (T)6 * r2 * g[k * RS + 2 * C] - (T)6 * r2 * r * g[k * RS + 3 * C] + (T)3 * r2 * (y + y_next);
     out[(k + 1) * C] = gv_next + gdv + (k + 1 <= L - 2 ? g[(k + 1) * RS] : (T)0);
     gv_next = -gdv;
+    if (WITH_T) {
+      const T dv = v[(k + 1) * C] - v[k * C], k0 = kd[k * C], k1 = kd[(k + 1) * C];
+      const T gc = g[k * RS + 2 * C], gd = g[k * RS + 3 * C];
+      const T gr = gc * ((T)12 * dv * r - ((T)4 * k0 + (T)2 * k1)) + gd * ((T)-18 * dv * r2 + (T)6 * (k0 + k1) * r) +
+                   (T)6 * dv * r * (y + y_next) - ((T)2 * y * k0 + (T)2 * y_next * k1 + y * k1 + y_next * k0);
+      gt[(k + 1) * C] -= r2 * gr;
+      gt[k * C] += r2 * gr;
+    }
     y_next = y;
   }
   out[0] = gv_next + g[0];
@@ -835,25 +870,31 @@ extern "C" size_t cde_natural_cubic_coeffs_backward_workspace_bytes(int64_t L, i
   return (size_t)2 * (size_t)L * (dtype == CDE_F64 ? 8 : 4);
 }
 
+// grad_t_rows == NULL: gradient w.r.t. the values only.  Otherwise also `x` (the forward input), `kd_scratch` and
+// `grad_t_rows`, each (B, L, C): grad_t_rows receives one partial dL/dt row per scalar path (sum them over B and C).
 extern "C" int cde_natural_cubic_coeffs_backward(const void* grad_coeffs, const void* t, void* grad_x, void* workspace,
                                                  size_t workspace_bytes, int64_t B, int64_t L, int64_t C, int dtype,
-                                                 void* stream) {
+                                                 const void* x, void* kd_scratch, void* grad_t_rows, void* stream) {
   if (B < 0 || L < 2 || C < 1) return CDE_ERR_SHAPE;
   if (B == 0) return CDE_OK;
   if (!grad_coeffs || !t || !grad_x || !workspace) return CDE_ERR_NULL;
+  if (grad_t_rows && (!x || !kd_scratch)) return CDE_ERR_NULL;
   if (dtype != CDE_F32 && dtype != CDE_F64) return CDE_ERR_DTYPE;
   if (workspace_bytes < cde_natural_cubic_coeffs_backward_workspace_bytes(L, dtype)) return CDE_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   const unsigned grid = (unsigned)((B * C + 255) / 256);
-  if (dtype == CDE_F32) {
-    cde::natural_cubic_aux_kernel<float><<<1, 64, 0, s>>>((const float*)t, (float*)workspace, L);
-    cde::natural_cubic_backward_kernel<float><<<grid, 256, 0, s>>>((const float*)grad_coeffs, (const float*)t,
-                                                                   (const float*)workspace, (float*)grad_x, B, L, C);
-  } else {
-    cde::natural_cubic_aux_kernel<double><<<1, 64, 0, s>>>((const double*)t, (double*)workspace, L);
-    cde::natural_cubic_backward_kernel<double><<<grid, 256, 0, s>>>((const double*)grad_coeffs, (const double*)t,
-                                                                    (const double*)workspace, (double*)grad_x, B, L, C);
-  }
+#define CDE_NCB(T)                                                                                                  \
+  do {                                                                                                              \
+    cde::natural_cubic_aux_kernel<T><<<1, 64, 0, s>>>((const T*)t, (T*)workspace, L);                               \
+    if (grad_t_rows)                                                                                                \
+      cde::natural_cubic_backward_kernel<T, true><<<grid, 256, 0, s>>>((const T*)grad_coeffs, (const T*)t,          \
+          (const T*)workspace, (T*)grad_x, B, L, C, (const T*)x, (T*)kd_scratch, (T*)grad_t_rows);                  \
+    else                                                                                                            \
+      cde::natural_cubic_backward_kernel<T, false><<<grid, 256, 0, s>>>((const T*)grad_coeffs, (const T*)t,         \
+          (const T*)workspace, (T*)grad_x, B, L, C, nullptr, nullptr, nullptr);                                     \
+  } while (0)
+  if (dtype == CDE_F32) CDE_NCB(float); else CDE_NCB(double);
+#undef CDE_NCB
   return cde::check_launch();
 }
 

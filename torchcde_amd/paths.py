@@ -159,14 +159,13 @@ class _LinearFill(torch.autograd.Function):
 def _natural_cubic(x, t, version):
     t = _validate_input_path(x, t)
     _lib.require_gpu(x, "x")
-    _no_grad_through_path(t)
-    knots = t.detach().to(device=x.device, dtype=x.dtype).contiguous()
     has_missing = bool(torch.isnan(x).any())
-    if torch.is_grad_enabled() and x.requires_grad:
+    if torch.is_grad_enabled() and (x.requires_grad or t.requires_grad):
         if has_missing:
             raise NotImplementedError("torchcde_amd: gradients through the natural cubic fit are implemented for data "
                                       "without missing values only.")
-        return _NaturalCubicFit.apply(x, knots, version)
+        return _NaturalCubicFit.apply(x, t, version)
+    knots = t.detach().to(device=x.device, dtype=x.dtype).contiguous()
     return _natural_cubic_forward(x, knots, version, has_missing)
 
 
@@ -181,33 +180,42 @@ def _natural_cubic_forward(x, knots, version, has_missing):
 
 
 class _NaturalCubicFit(torch.autograd.Function):
-    """K1n with its backward (data without missing values): the coefficients are linear in the values, the gradient is
-    one more solve with the same tridiagonal matrix (``cde_natural_cubic_coeffs_backward``)."""
+    """K1n with its backward (data without missing values): the coefficients are linear in the values -- the gradient
+    is one more solve with the same tridiagonal matrix -- and smooth in the knot times
+    (``cde_natural_cubic_coeffs_backward``; reference test/test_tricks.py:21-49 differentiates w.r.t. both)."""
 
     @staticmethod
-    def forward(ctx, x, knots, version):
-        ctx.save_for_backward(knots)
-        ctx.shape = x.shape
+    def forward(ctx, x, t, version):
+        knots = t.detach().to(device=x.device, dtype=x.dtype).contiguous()
+        src = x.detach().contiguous()
+        ctx.save_for_backward(knots, src)
+        ctx.t_meta = (t.dtype, t.device)
         return _natural_cubic_forward(x, knots, version, False)
 
     @staticmethod
     def backward(ctx, grad):
-        knots, = ctx.saved_tensors
-        shape = ctx.shape
+        knots, src = ctx.saved_tensors
+        shape = src.shape
         L, C = shape[-2], shape[-1]
-        B = 1
-        for d in shape[:-2]:
-            B *= d
+        B = src.numel() // (L * C)
         grad = grad.contiguous()
         grad_x = torch.empty(shape, dtype=grad.dtype, device=grad.device)
         lib = _lib.load()
         dt = _lib.dtype_enum(grad.dtype)
         nbytes = lib.cde_natural_cubic_coeffs_backward_workspace_bytes(L, dt)
         workspace = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=grad.device)
-        _lib.check(lib.cde_natural_cubic_coeffs_backward(_lib.ptr(grad), _lib.ptr(knots), _lib.ptr(grad_x),
-                                                         _lib.ptr(workspace), nbytes, B, L, C, dt,
-                                                         _lib.stream_ptr(grad.device)), "cde_natural_cubic_coeffs_backward")
-        return grad_x, None, None
+        want_t = ctx.needs_input_grad[1]
+        kd = torch.empty_like(src) if want_t else None
+        rows = torch.empty_like(src) if want_t else None
+        _lib.check(lib.cde_natural_cubic_coeffs_backward(
+            _lib.ptr(grad), _lib.ptr(knots), _lib.ptr(grad_x), _lib.ptr(workspace), nbytes, B, L, C, dt,
+            _lib.ptr(src) if want_t else None, _lib.ptr(kd), _lib.ptr(rows), _lib.stream_ptr(grad.device)),
+            "cde_natural_cubic_coeffs_backward")
+        grad_t = None
+        if want_t:
+            t_dtype, t_device = ctx.t_meta
+            grad_t = rows.reshape(-1, L, C).sum(dim=(0, 2)).to(device=t_device, dtype=t_dtype)
+        return (grad_x if ctx.needs_input_grad[0] else None), grad_t, None
 
 
 def natural_cubic_coeffs(x, t=None):
@@ -233,29 +241,62 @@ def _path_eval(coeffs, knots, flat, n_intervals, C, degree, what):
 
 class _PathEval(torch.autograd.Function):
     """evaluate / derivative as a differentiable function of the path's coefficient buffers (cubic: a, b, 2c, 3d;
-    linear: the knot values)."""
+    linear: the knot values), of the query times and, for a cubic spline, of its knot times (both through
+    ``frac = t - t_i``, interpolation_cubic.py:315-336; reference test/test_tricks.py:21-49 asks for these gradients)."""
 
     @staticmethod
-    def forward(ctx, coeffs, knots, flat, n_intervals, C, degree, what, *pieces):
-        ctx.save_for_backward(knots, flat)
+    def forward(ctx, coeffs, knots, flat, n_intervals, C, degree, what, knot_times, query, *pieces):
+        ctx.save_for_backward(knots, flat, coeffs)
+        ctx.query_shape = None if query is None else tuple(query.shape)
         ctx.meta = (tuple(coeffs.shape), n_intervals, C, degree, what, [tuple(p.shape) for p in pieces])
         return _path_eval(coeffs, knots, flat, n_intervals, C, degree, what)
 
     @staticmethod
     def backward(ctx, grad_out):
-        knots, flat = ctx.saved_tensors
+        knots, flat, coeffs = ctx.saved_tensors
         flat_shape, n_intervals, C, degree, what, shapes = ctx.meta
         g = grad_out.contiguous()
-        grad = torch.zeros(flat_shape, dtype=g.dtype, device=g.device)
         lib = _lib.load()
-        _lib.check(lib.cde_path_eval_backward(_lib.ptr(g), _lib.ptr(knots), _lib.ptr(flat), flat.numel(), _lib.ptr(grad),
-                                              flat_shape[0], n_intervals, C, degree, what, _lib.dtype_enum(g.dtype),
-                                              _lib.stream_ptr(g.device)), "cde_path_eval_backward")
-        if len(shapes) == 1:
-            parts = (grad.reshape(shapes[0]),)
-        else:
-            parts = tuple(grad[..., k * C:(k + 1) * C].reshape(shape) for k, shape in enumerate(shapes))
-        return (None,) * 7 + tuple(p if need else None for p, need in zip(parts, ctx.needs_input_grad[7:]))
+        parts = (None,) * len(shapes)
+        if any(ctx.needs_input_grad[9:]):
+            grad = torch.zeros(flat_shape, dtype=g.dtype, device=g.device)
+            _lib.check(lib.cde_path_eval_backward(_lib.ptr(g), _lib.ptr(knots), _lib.ptr(flat), flat.numel(), _lib.ptr(grad),
+                                                  flat_shape[0], n_intervals, C, degree, what, _lib.dtype_enum(g.dtype),
+                                                  _lib.stream_ptr(g.device)), "cde_path_eval_backward")
+            if len(shapes) == 1:
+                parts = (grad.reshape(shapes[0]),)
+            else:
+                parts = tuple(grad[..., k * C:(k + 1) * C].reshape(shape) for k, shape in enumerate(shapes))
+        grad_knots = grad_query = None
+        if ctx.needs_input_grad[7] or ctx.needs_input_grad[8]:
+            # d out / d frac at every query; frac = t - knot[index]: a query moves with its own time and against ONE knot
+            nq = flat.numel()
+            index = torch.empty(nq, dtype=torch.int64, device=g.device)
+            frac = torch.empty(nq, dtype=g.dtype, device=g.device)
+            _lib.check(lib.cde_interpret_t(_lib.ptr(knots), n_intervals, _lib.ptr(flat), nq, _lib.ptr(index),
+                                           _lib.ptr(frac), _lib.dtype_enum(g.dtype), _lib.stream_ptr(g.device)),
+                       "cde_interpret_t")
+            fr = frac.reshape(1, nq, 1)
+            if degree == _lib.PATH_CUBIC:
+                rows = coeffs[:, index]                                          # (B, nq, 4C)
+                b, two_c, three_d = rows[..., C:2 * C], rows[..., 2 * C:3 * C], rows[..., 3 * C:]
+                dfrac = two_c + 2 * three_d * fr if what == _lib.EVAL_DERIVATIVE else b + (two_c + three_d * fr) * fr
+            else:
+                if ctx.needs_input_grad[7]:
+                    raise NotImplementedError("torchcde_amd: gradients with respect to the knot times of a "
+                                              "piecewise-linear control are not implemented.")
+                if what == _lib.EVAL_DERIVATIVE:
+                    dfrac = torch.zeros(coeffs.size(0), nq, C, dtype=g.dtype, device=g.device)
+                else:
+                    width = (knots[index + 1] - knots[index]).reshape(1, nq, 1)
+                    dfrac = (coeffs[:, index + 1] - coeffs[:, index]) / width
+            per_query = (g.reshape(-1, nq, C) * dfrac).sum(dim=(0, 2))
+            if ctx.needs_input_grad[7]:
+                grad_knots = torch.zeros(n_intervals + 1, dtype=g.dtype, device=g.device).index_add_(0, index, -per_query)
+            if ctx.needs_input_grad[8]:
+                grad_query = per_query.reshape(ctx.query_shape)
+        return ((None,) * 7 + (grad_knots, grad_query)
+                + tuple(p if need else None for p, need in zip(parts, ctx.needs_input_grad[9:])))
 
 
 class _HermiteFit(torch.autograd.Function):
@@ -404,16 +445,19 @@ class _NativePath(InterpolationBase):
 
     def _eval(self, t, what):
         coeffs, knots, batch = self._native_inputs()
-        _no_grad_through_path(t if isinstance(t, torch.Tensor) else None)
         tq = torch.as_tensor(t, dtype=coeffs.dtype, device=coeffs.device)
         flat = tq.detach().reshape(-1).contiguous()
         C = self._channels()
         pieces = self._coefficient_buffers()
-        if torch.is_grad_enabled() and any(p.requires_grad for p in pieces):
-            # differentiable w.r.t. the coefficients (like the reference's gathers): K1b forward, scatter kernel backward.
-            # The buffers themselves are the autograd inputs (a view re-assembled with as_strided would only carry the
-            # gradient of its first block).
-            out = _PathEval.apply(coeffs, knots, flat, self._n_intervals(), C, self._degree, what, *pieces)
+        grad_mode = torch.is_grad_enabled()
+        knot_times = self._t if (grad_mode and self._t.requires_grad) else None
+        query = tq if (grad_mode and tq.requires_grad) else None
+        if grad_mode and (knot_times is not None or query is not None or any(p.requires_grad for p in pieces)):
+            # differentiable w.r.t. the coefficients (like the reference's gathers): K1b forward, scatter kernel backward;
+            # w.r.t. the query times and a cubic spline's knot times through frac = t - t_i.  The buffers themselves are
+            # the autograd inputs (a view re-assembled with as_strided would only carry the gradient of its first block).
+            out = _PathEval.apply(coeffs, knots, flat, self._n_intervals(), C, self._degree, what, knot_times, query,
+                                  *pieces)
         else:
             out = _path_eval(coeffs, knots, flat, self._n_intervals(), C, self._degree, what)
         return out.reshape(*batch, *tq.shape, C)

@@ -53,9 +53,10 @@ class ControlledField:
 
     def __init__(self, X, func):
         self.X, self.func = X, func
+        self.through_time = False      # backprop through the solver: dX/dt(t) itself is differentiated w.r.t. t
 
     def __call__(self, t, z):
-        dX = self.X.derivative(t.detach())
+        dX = self.X.derivative(t if self.through_time else t.detach())
         if hasattr(self.func, "prod"):                       # solver.py:121-123: the user supplies f(t, z) dX directly
             return self.func.prod(t, z, dX)
         return _Contract.apply(self.func(t, z), dX)
@@ -154,11 +155,21 @@ _FIXED = {"rk4": _inc_rk4, "midpoint": _inc_midpoint, "euler": _inc_euler}
 def _solve_fixed(increment, f, y0, t, step_size):
     t_host = t.detach().cpu()                       # the grid and the output bookkeeping live on the host
     grid = _grid(t_host, step_size)
+    # backprop through the solver w.r.t. the times: the device copy of the grid stays a function of `t`, built as
+    # torchdiffeq builds it (the output times themselves, or t[0] + i * step_size with the last point replaced by t[-1])
+    through = torch.is_grad_enabled() and t.requires_grad
+    if through:
+        t_dev = t.to(y0.device)
+        if step_size is None:
+            grid_dev = t_dev
+        else:
+            steps = torch.arange(0, len(grid), dtype=t_dev.dtype, device=t_dev.device) * step_size + t_dev[0]
+            grid_dev = torch.cat([steps[:-1], t_dev[-1:]])
     out = [y0]
     j = 1
     on_device = lambda v: v.to(y0.device)
-    for t0h, t1h in zip(grid[:-1], grid[1:]):
-        t0, t1 = on_device(t0h), on_device(t1h)
+    for i, (t0h, t1h) in enumerate(zip(grid[:-1], grid[1:])):
+        t0, t1 = (grid_dev[i], grid_dev[i + 1]) if through else (on_device(t0h), on_device(t1h))
         dt = t1 - t0
         y1 = y0 + increment(f, t0, dt, t1, y0)
         while j < len(t_host) and bool(t1h >= t_host[j]):
@@ -168,7 +179,7 @@ def _solve_fixed(increment, f, y0, t, step_size):
             elif bool(tj == t1h):
                 out.append(y1)
             else:
-                slope = on_device((tj - t0h) / (t1h - t0h)).to(y0.dtype)
+                slope = ((t_dev[j] - t0) / (t1 - t0) if through else on_device((tj - t0h) / (t1h - t0h))).to(y0.dtype)
                 out.append(y0 + slope * (y1 - y0))
             j += 1
         y0 = y1
@@ -346,10 +357,14 @@ class _Adjoint(torch.autograd.Function):
                     yy = yy.detach().requires_grad_(True)
                     fe = func(tt, yy)
                     if need_t:
-                        vt, vy, *vp = torch.autograd.grad(fe, (tt, yy) + params, -aa, allow_unused=True)
+                        vt, vy, *vp = torch.autograd.grad(fe, (tt, yy) + params, -aa, allow_unused=True,
+                                                          retain_graph=True)
                     else:
                         vt = None
-                        vy, *vp = torch.autograd.grad(fe, (yy,) + params, -aa, allow_unused=True)
+                        # retain_graph as torchdiffeq: an adjoint_param may itself be the output of a differentiable
+                        # construction (the reference's own test passes `coeffs = natural_cubic_coeffs(path, t)`), whose
+                        # graph every evaluation then walks
+                        vy, *vp = torch.autograd.grad(fe, (yy,) + params, -aa, allow_unused=True, retain_graph=True)
                 vt = torch.zeros_like(state[0]) if vt is None else vt.to(state[0].dtype)
                 if need_t and hasattr(func, "time_partial"):           # d f/dt through the control slope dX/dt(t)
                     vt = vt - (aa * func.time_partial(tt.detach(), yy.detach())).sum().to(vt.dtype)
@@ -426,9 +441,9 @@ def solve(X, func, z0, t, adjoint, method, options, rtol, atol, adjoint_method, 
             adjoint_params = tuple(func.parameters())
         params = tuple(p for p in adjoint_params if p.requires_grad)
         knots = getattr(X, "_t", None)
-        if knots is not None and any(p is knots for p in params):
+        if knots is not None and any(p is knots for p in params) and getattr(X, "_degree", None) != 3:
             raise NotImplementedError("torchcde_amd: gradients with respect to the control's knot times are only "
-                                      "implemented for CubicSpline controls on the fused rk4 path.")
+                                      "implemented for CubicSpline controls.")
         fixed_opts = {k: v for k, v in (options or {}).items() if k != "norm"}
         cfg = dict(func=field, method=method, options=options, rtol=rtol, atol=atol,
                    adjoint_method=adjoint_method or method,
@@ -437,6 +452,8 @@ def solve(X, func, z0, t, adjoint, method, options, rtol, atol, adjoint_method, 
                    t_requires_grad=bool(t.requires_grad and torch.is_grad_enabled()))
         out = _Adjoint.apply(cfg, z0, t, *params)
     else:
+        if isinstance(field, ControlledField):
+            field.through_time = bool(torch.is_grad_enabled() and t.requires_grad)
         out = odeint(field, z0, t, method=method, options=options, rtol=rtol, atol=atol)
     lead = range(1, out.dim() - 1)
     return out.permute(*lead, 0, -1)
