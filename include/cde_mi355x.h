@@ -91,6 +91,11 @@ int cde_hermite_bdiff_coeffs_checked(const void* x, const void* t, void* coeffs,
  * w.r.t. `t` are not produced. */
 int cde_hermite_bdiff_coeffs_backward(const void* grad_coeffs, const void* t, void* grad_x, int64_t B, int64_t L,
                                       int64_t C, int dtype, void* stream);
+/* The same fit w.r.t. the knot times (data without missing values): grad_h (B, L-1, C) = dL/d(t_{j+1} - t_j) per
+ * series and channel; summed over B and C it gives dL/dt_{j+1} += . and dL/dt_j -= . (the reference's eager ops are
+ * differentiable in `t` as well). */
+int cde_hermite_bdiff_coeffs_backward_dt(const void* grad_coeffs, const void* x, const void* t, void* grad_h, int64_t B,
+                                         int64_t L, int64_t C, int dtype, void* stream);
 
 /* K1n  Natural cubic spline coefficients: natural_cubic_coeffs (version 1) / natural_cubic_spline_coeffs (version 0),
  * torchcde/interpolation_cubic.py:7-266 with the tridiagonal solve of misc.py:14-67; NaN = missing value.

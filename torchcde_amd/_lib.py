@@ -84,6 +84,7 @@ _SIGNATURES = {
     "cde_linear_fill_missing_backward": (_i, [_p, _p, _p, _p, _i64, _i64, _i64, _i, _p]),
     "cde_interpret_t": (_i, [_p, _i64, _p, _i64, _p, _p, _i, _p]),
     "cde_hermite_bdiff_coeffs_backward": (_i, [_p, _p, _p, _i64, _i64, _i64, _i, _p]),
+    "cde_hermite_bdiff_coeffs_backward_dt": (_i, [_p, _p, _p, _p, _i64, _i64, _i64, _i, _p]),
     "cde_natural_cubic_coeffs": (_i, [_p, _p, _p, _i64, _i64, _i64, _i, _i, _i, _p]),
     "cde_natural_cubic_coeffs_backward_workspace_bytes": (_sz, [_i64, _i]),
     "cde_natural_cubic_coeffs_backward": (_i, [_p, _p, _p, _p, _sz, _i64, _i64, _i64, _i, _p, _p, _p, _p]),

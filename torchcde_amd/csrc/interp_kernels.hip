@@ -181,6 +181,30 @@ __global__ __launch_bounds__(256) void hermite_bdiff_backward_kernel(const T* __
   gx[e] = acc;
 }
 
+// dL/dh_j of the same fit, h_j = t_{j+1} - t_j, one lane per (series, interval, channel); the caller sums over series
+// and channels and distributes dL/dt_{j+1} += dL/dh_j, dL/dt_j -= dL/dh_j.  With s_j = rise_j / h_j, e_j = s_{j-1}
+// (e_0 = s_0), u_j = s_j - e_j the fit is b_j = e_j, 2c_j = 4 u_j / h_j, 3d_j = -3 u_j / h_j^2 (the reference's
+// expressions :17-18 simplify to these), so
+//   dL/dh_j = dL/ds_j (-s_j / h_j) + g2c_j (-4 u_j / h_j^2) + g3d_j (6 u_j / h_j^3).
+template <typename T>
+__global__ __launch_bounds__(256) void hermite_bdiff_backward_dt_kernel(const T* __restrict__ g, const T* __restrict__ x,
+                                                                        const T* __restrict__ t, T* __restrict__ gh,
+                                                                        int64_t B, int64_t L, int64_t C) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * (L - 1) * C) return;
+  const int64_t c = e % C, bj = e / C, j = bj % (L - 1), b = bj / (L - 1);
+  const T* gs = g + b * (L - 1) * 4 * C + c;
+  const T* xs = x + b * L * C + c;
+  auto secant = [&](int64_t k) { return (xs[(k + 1) * C] - xs[k * C]) / (t[k + 1] - t[k]); };
+  auto d_u = [&](int64_t k) { const T h = t[k + 1] - t[k]; return (T)4 * gs[k * 4 * C + 2 * C] / h - (T)3 * gs[k * 4 * C + 3 * C] / (h * h); };
+  const T h = t[j + 1] - t[j];
+  const T sj = secant(j), ej = j == 0 ? sj : secant(j - 1), uj = sj - ej;
+  T gsj = d_u(j);                                            // dL/ds_j: through u_j, e_{j+1} (and e_0 for j == 0)
+  if (j + 1 <= L - 2) gsj += gs[(j + 1) * 4 * C + C] - d_u(j + 1);
+  if (j == 0) gsj += gs[C] - d_u(0);
+  gh[e] = gsj * (-sj / h) + gs[j * 4 * C + 2 * C] * ((T)-4 * uj / (h * h)) + gs[j * 4 * C + 3 * C] * ((T)6 * uj / (h * h * h));
+}
+
 // ------------------------------------------------------------------------------------------ K0 missing values
 // linear_interpolation_coeffs on data with NaNs (interpolation_linear.py:13-84): every scalar path (one series,
 // one channel) is filled independently -- observed values stay, a gap is the straight line between its nearest
@@ -847,6 +871,25 @@ extern "C" int cde_hermite_bdiff_coeffs_backward(const void* grad_coeffs, const 
     cde::hermite_bdiff_backward_kernel<float><<<grid, 256, 0, s>>>((const float*)grad_coeffs, (const float*)t, (float*)grad_x, B, L, C);
   else if (dtype == CDE_F64)
     cde::hermite_bdiff_backward_kernel<double><<<grid, 256, 0, s>>>((const double*)grad_coeffs, (const double*)t, (double*)grad_x, B, L, C);
+  else return CDE_ERR_DTYPE;
+  return cde::check_launch();
+}
+
+// dL/dh (B, L-1, C) of the fit, h_j = t_{j+1} - t_j (data without missing values): sum over B and C, then
+// dL/dt_{j+1} += dL/dh_j and dL/dt_j -= dL/dh_j give the gradient w.r.t. the knot times.
+extern "C" int cde_hermite_bdiff_coeffs_backward_dt(const void* grad_coeffs, const void* x, const void* t, void* grad_h,
+                                                    int64_t B, int64_t L, int64_t C, int dtype, void* stream) {
+  if (B < 0 || L < 2 || C < 1) return CDE_ERR_SHAPE;
+  if (B == 0) return CDE_OK;
+  if (!grad_coeffs || !x || !t || !grad_h) return CDE_ERR_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((B * (L - 1) * C + 255) / 256);
+  if (dtype == CDE_F32)
+    cde::hermite_bdiff_backward_dt_kernel<float><<<grid, 256, 0, s>>>((const float*)grad_coeffs, (const float*)x,
+                                                                      (const float*)t, (float*)grad_h, B, L, C);
+  else if (dtype == CDE_F64)
+    cde::hermite_bdiff_backward_dt_kernel<double><<<grid, 256, 0, s>>>((const double*)grad_coeffs, (const double*)x,
+                                                                       (const double*)t, (double*)grad_h, B, L, C);
   else return CDE_ERR_DTYPE;
   return cde::check_launch();
 }

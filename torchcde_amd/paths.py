@@ -300,33 +300,50 @@ class _PathEval(torch.autograd.Function):
 
 
 class _HermiteFit(torch.autograd.Function):
-    """K1 with its transpose as the backward (the fit is linear in x)."""
+    """K1 with its transpose as the backward (the fit is linear in x) and, when the knot times require a gradient, the
+    derivative w.r.t. the interval widths (``cde_hermite_bdiff_coeffs_backward_dt``)."""
 
     @staticmethod
-    def forward(ctx, x, knots):
+    def forward(ctx, x, t):
         L, C = x.size(-2), x.size(-1)
         batch = x.shape[:-2]
+        knots = t.detach().to(device=x.device, dtype=x.dtype).contiguous()
         src, B, _, _ = _flat3(x)
         out = torch.empty(*batch, L - 1, 4 * C, dtype=x.dtype, device=x.device)
         lib = _lib.load()
         _lib.check(lib.cde_hermite_bdiff_coeffs(_lib.ptr(src), _lib.ptr(knots), _lib.ptr(out), B, L, C,
                                                 _lib.dtype_enum(x.dtype), _lib.stream_ptr(x.device)),
                    "cde_hermite_bdiff_coeffs")
-        ctx.save_for_backward(knots)
+        ctx.save_for_backward(knots, src if t.requires_grad else None)
         ctx.shape = tuple(x.shape)
+        ctx.t_meta = (t.dtype, t.device)
         return out
 
     @staticmethod
     def backward(ctx, grad_coeffs):
-        (knots,) = ctx.saved_tensors
+        knots, src = ctx.saved_tensors
         L, C = ctx.shape[-2], ctx.shape[-1]
         g = grad_coeffs.contiguous()
-        grad_x = torch.empty(ctx.shape, dtype=g.dtype, device=g.device)
+        B = g.numel() // ((L - 1) * 4 * C)
         lib = _lib.load()
-        _lib.check(lib.cde_hermite_bdiff_coeffs_backward(_lib.ptr(g), _lib.ptr(knots), _lib.ptr(grad_x),
-                                                         grad_x.numel() // (L * C), L, C, _lib.dtype_enum(g.dtype),
-                                                         _lib.stream_ptr(g.device)), "cde_hermite_bdiff_coeffs_backward")
-        return grad_x, None
+        grad_x = grad_t = None
+        if ctx.needs_input_grad[0]:
+            grad_x = torch.empty(ctx.shape, dtype=g.dtype, device=g.device)
+            _lib.check(lib.cde_hermite_bdiff_coeffs_backward(_lib.ptr(g), _lib.ptr(knots), _lib.ptr(grad_x), B, L, C,
+                                                             _lib.dtype_enum(g.dtype), _lib.stream_ptr(g.device)),
+                       "cde_hermite_bdiff_coeffs_backward")
+        if ctx.needs_input_grad[1]:
+            gh = torch.empty(B, L - 1, C, dtype=g.dtype, device=g.device)
+            _lib.check(lib.cde_hermite_bdiff_coeffs_backward_dt(_lib.ptr(g), _lib.ptr(src), _lib.ptr(knots), _lib.ptr(gh),
+                                                                B, L, C, _lib.dtype_enum(g.dtype),
+                                                                _lib.stream_ptr(g.device)),
+                       "cde_hermite_bdiff_coeffs_backward_dt")
+            per_interval = gh.sum(dim=(0, 2))
+            grad_t = torch.zeros(L, dtype=g.dtype, device=g.device)
+            grad_t[1:] += per_interval
+            grad_t[:-1] -= per_interval
+            grad_t = grad_t.to(device=ctx.t_meta[1], dtype=ctx.t_meta[0])
+        return grad_x, grad_t
 
 
 def hermite_cubic_coefficients_with_backward_differences(x, t=None):
@@ -334,13 +351,18 @@ def hermite_cubic_coefficients_with_backward_differences(x, t=None):
 
     Same contract as reference interpolation_hermite_cubic_bdiff.py:23-44; computed by K1
     (``cde_hermite_bdiff_coeffs``) in one pass over ``x``.  Differentiable w.r.t. ``x`` (data without missing
-    values), like the reference's eager ops; not w.r.t. ``t``."""
-    if torch.is_grad_enabled() and x.requires_grad:
-        coeffs = linear_interpolation_coeffs(x, t=t, rectilinear=None)
-        _no_grad_through_path(t)
-        knots = (torch.linspace(0, coeffs.size(-2) - 1, coeffs.size(-2), dtype=coeffs.dtype, device=coeffs.device)
-                 if t is None else t.detach().to(device=coeffs.device, dtype=coeffs.dtype)).contiguous()
-        return _HermiteFit.apply(coeffs, knots)
+    values) and w.r.t. ``t`` (data without missing values), like the reference's eager ops."""
+    t_grad = torch.is_grad_enabled() and isinstance(t, torch.Tensor) and t.requires_grad
+    if t_grad or (torch.is_grad_enabled() and x.requires_grad):
+        if t_grad and bool(torch.isnan(x).any()):
+            raise NotImplementedError("torchcde_amd: gradients with respect to the knot times through the fit are "
+                                      "implemented for data without missing values only.")
+        filled = x if t_grad else linear_interpolation_coeffs(x, t=t, rectilinear=None)
+        if t is None:
+            t = torch.linspace(0, filled.size(-2) - 1, filled.size(-2), dtype=filled.dtype, device=filled.device)
+        else:
+            _validate_input_path(filled, t)
+        return _HermiteFit.apply(filled, t)
     # No gradient wanted: the reference's NaN scan (linear_interpolation_coeffs, interpolation_linear.py:169) rides on
     # the fit itself -- K1 reads every value anyway and raises a device flag; only if it is set are the gaps filled
     # (K0) and the fit repeated.  One 4-byte read-back instead of a second pass over x.
