@@ -282,17 +282,19 @@ class _PathEval(torch.autograd.Function):
                 b, two_c, three_d = rows[..., C:2 * C], rows[..., 2 * C:3 * C], rows[..., 3 * C:]
                 dfrac = two_c + 2 * three_d * fr if what == _lib.EVAL_DERIVATIVE else b + (two_c + three_d * fr) * fr
             else:
-                if ctx.needs_input_grad[7]:
-                    raise NotImplementedError("torchcde_amd: gradients with respect to the knot times of a "
-                                              "piecewise-linear control are not implemented.")
-                if what == _lib.EVAL_DERIVATIVE:
-                    dfrac = torch.zeros(coeffs.size(0), nq, C, dtype=g.dtype, device=g.device)
-                else:
-                    width = (knots[index + 1] - knots[index]).reshape(1, nq, 1)
-                    dfrac = (coeffs[:, index + 1] - coeffs[:, index]) / width
-            per_query = (g.reshape(-1, nq, C) * dfrac).sum(dim=(0, 2))
+                width = (knots[index + 1] - knots[index]).reshape(1, nq, 1)
+                slope = (coeffs[:, index + 1] - coeffs[:, index]) / width
+                dfrac = torch.zeros_like(slope) if what == _lib.EVAL_DERIVATIVE else slope
+            gq = g.reshape(-1, nq, C)
+            per_query = (gq * dfrac).sum(dim=(0, 2))
             if ctx.needs_input_grad[7]:
                 grad_knots = torch.zeros(n_intervals + 1, dtype=g.dtype, device=g.device).index_add_(0, index, -per_query)
+                if degree != _lib.PATH_CUBIC:
+                    # piecewise linear (interpolation_linear.py:212-225): the slope (x_{i+1} - x_i) / (t_{i+1} - t_i)
+                    # also moves with both knots of its interval
+                    scale = 1 / width if what == _lib.EVAL_DERIVATIVE else fr / width
+                    widen = (gq * slope * scale).sum(dim=(0, 2))
+                    grad_knots.index_add_(0, index, widen).index_add_(0, index + 1, -widen)
             if ctx.needs_input_grad[8]:
                 grad_query = per_query.reshape(ctx.query_shape)
         return ((None,) * 7 + (grad_knots, grad_query)

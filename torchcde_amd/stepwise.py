@@ -440,10 +440,6 @@ def solve(X, func, z0, t, adjoint, method, options, rtol, atol, adjoint_method, 
                                  "parameters then it is allowable to set `adjoint_params=()`.")
             adjoint_params = tuple(func.parameters())
         params = tuple(p for p in adjoint_params if p.requires_grad)
-        knots = getattr(X, "_t", None)
-        if knots is not None and any(p is knots for p in params) and getattr(X, "_degree", None) != 3:
-            raise NotImplementedError("torchcde_amd: gradients with respect to the control's knot times are only "
-                                      "implemented for CubicSpline controls.")
         fixed_opts = {k: v for k, v in (options or {}).items() if k != "norm"}
         cfg = dict(func=field, method=method, options=options, rtol=rtol, atol=atol,
                    adjoint_method=adjoint_method or method,
