@@ -318,8 +318,10 @@ class _MlpPlan:
         tdt = _lib.dtype_enum(g.time_dtype)
         z_saved = z_saved.detach().reshape(B, self.n_out, H)
         grad_out = grad_out.detach().reshape(B, self.n_out, H)
-        y = z_saved[:, -1].contiguous()
-        a = grad_out[:, -1].to(torch.float32).contiguous()
+        # the sweep integrates (y, a) IN PLACE: private copies -- for a single series `[:, -1]` is already contiguous and
+        # .contiguous() would hand the kernel the caller's own output / gradient tensors
+        y = z_saved[:, -1].clone(memory_format=torch.contiguous_format)
+        a = grad_out[:, -1].to(torch.float32).clone(memory_format=torch.contiguous_format)
         acc2 = torch.zeros(256, 132, dtype=torch.float32, device=dev)
         acc1 = torch.zeros(128, 36, dtype=torch.float32, device=dev)
         grad_x = torch.zeros_like(self.coeffs) if want_control else None     # accumulated by the sweep launches
