@@ -31,7 +31,54 @@ def logsignature_channels(channels, depth):
     return len(_lyndon_words(channels, depth))
 
 
+_plans = {}          # window bookkeeping per (times, window length, shape): host work done once, device tables reused
+
+
+def _plan(t, given, window_length, L, C_in, depth, version, dtype, device):
+    """log_ode.py:18-49 for one set of times: which rows of the (merged) series bound the windows, which new times have
+    to be merged in, the per-window scale and the Lyndon-word table -- as device tensors.  The reference's loop
+    (`value <= t[pointer]` or `value.allclose(t[pointer])`, pointer never moving back) is evaluated for all window ends
+    at once with the same elementwise arithmetic (`torch.isclose` is allclose's formula)."""
+    key = ((t.data_ptr(), t._version) if given else None, float(window_length), L, C_in, depth, version, dtype, str(device))
+    plan = _plans.get(key)
+    if plan is not None:
+        return plan
+    th = t.detach().cpu()
+    timespan = th[-1] - th[0]
+    pieces = int((timespan / window_length).ceil().item())
+    new_t = torch.linspace(th[0].item(), (th[0] + pieces * window_length).item(), pieces + 1, dtype=th.dtype)
+    new_t = torch.min(new_t, th.max())
+    close = torch.isclose(new_t[:, None], th[None, :])
+    hit = (new_t[:, None] <= th[None, :]) | close
+    pointer = hit.to(torch.int8).argmax(dim=1)                   # first time at or after (or close to) every window end
+    is_close = close[torch.arange(new_t.numel()), pointer]
+    n_fresh_before = torch.cumsum((~is_close).to(torch.int64), 0) - (~is_close).to(torch.int64)
+    rows = (pointer + n_fresh_before).tolist()
+    fresh = new_t[~is_close]
+    order_dev = merged_dev = None
+    if fresh.numel():                                           # the new times join the series as missing observations
+        merged, order = torch.cat([th, fresh]).sort()
+        order_dev, merged_dev = order.clamp(0, L).to(device), merged.to(device)
+    n_windows = len(rows) - 1
+    scale = (new_t[1:] - new_t[:-1]) if version == 0 else torch.ones(n_windows, dtype=th.dtype)
+    table = []
+    for word in _lyndon_words(C_in, depth):
+        flat = 0
+        for letter in word:
+            flat = flat * C_in + letter
+        table.append((len(word), flat))
+    plan = dict(rows=torch.tensor(rows, dtype=torch.int64).to(device), order=order_dev, merged=merged_dev,
+                scale=scale.to(device=device, dtype=dtype).contiguous(),
+                words=torch.tensor(table, dtype=torch.int32).to(device), n_windows=n_windows, n_words=len(table),
+                new_t=new_t.to(device))
+    if len(_plans) > 64:
+        _plans.clear()
+    _plans[key] = plan
+    return plan
+
+
 def _windows(x, depth, window_length, t, version):
+    given = t is not None
     t = _validate_input_path(x, t)
     _lib.require_gpu(x, "x")
     _no_grad_through_path(x, t)
@@ -40,53 +87,25 @@ def _windows(x, depth, window_length, t, version):
         raise NotImplementedError("torchcde_amd: logsignatures are implemented natively for depth <= 3 with at most 8 "
                                   "channels, depth 4 with at most 5 and depth <= 2 with at most 32 (got depth=%d, "
                                   "channels=%d)." % (depth, C_in))
-    words = _lyndon_words(C_in, depth)
-    th = t.detach().cpu()
-    # log_ode.py:18-40 on the host copy of the times
-    timespan = th[-1] - th[0]
-    pieces = int((timespan / window_length).ceil().item())
-    new_t = torch.linspace(th[0].item(), (th[0] + pieces * window_length).item(), pieces + 1, dtype=th.dtype)
-    new_t = torch.min(new_t, th.max())
-    pointer, fresh, rows = 0, [], []
-    for value in new_t:
-        while True:
-            at_or_before = bool(value <= th[pointer])
-            close = bool(value.allclose(th[pointer]))
-            if at_or_before or close:
-                break
-            pointer += 1
-        rows.append(pointer + len(fresh))
-        if not close:
-            fresh.append(value.unsqueeze(0))
+    plan = _plan(t, given, window_length, x.size(-2), C_in, depth, version, x.dtype, x.device)
     batch = x.shape[:-2]
     t_dev = t.to(x.device)
-    if fresh:                                                  # merge the new times in as missing observations
-        merged, order = torch.cat([th, *fresh]).sort()
+    if plan["order"] is not None:                              # merge the new times in as missing observations
         missing = torch.full((*batch, 1, x.size(-1)), float("nan"), dtype=x.dtype, device=x.device)
-        x = torch.cat([x, missing], dim=-2)[..., order.clamp(0, x.size(-2)).to(x.device), :]
-        t_dev = merged.to(x.device)
+        x = torch.cat([x, missing], dim=-2)[..., plan["order"], :]
+        t_dev = plan["merged"]
     x = linear_interpolation_coeffs(x, t_dev)                  # fills the NaNs (the new rows and any in the data)
     L, C = x.size(-2), x.size(-1)
     src = x.detach().contiguous()
     B = src.numel() // (L * C)
-    n_windows = len(rows) - 1
-    rows_dev = torch.tensor(rows, dtype=torch.int64).to(x.device)
-    scale = (new_t[1:] - new_t[:-1]) if version == 0 else torch.ones(n_windows, dtype=th.dtype)
-    scale_dev = scale.to(device=x.device, dtype=x.dtype).contiguous()
-    table = []
-    for word in words:
-        flat = 0
-        for letter in word:
-            flat = flat * C + letter
-        table.append((len(word), flat))
-    words_dev = torch.tensor(table, dtype=torch.int32).to(x.device)
-    out = torch.empty(*batch, n_windows + 1, len(words), dtype=x.dtype, device=x.device)
+    n_windows = plan["n_windows"]
+    out = torch.empty(*batch, n_windows + 1, plan["n_words"], dtype=x.dtype, device=x.device)
     lib = _lib.load()
-    _lib.check(lib.cde_logsig_windows(_lib.ptr(src), _lib.ptr(rows_dev), _lib.ptr(scale_dev), _lib.ptr(words_dev),
-                                      _lib.ptr(out), B, L, C, depth, n_windows, len(words), _lib.dtype_enum(x.dtype),
-                                      _lib.stream_ptr(x.device)), "cde_logsig_windows")
+    _lib.check(lib.cde_logsig_windows(_lib.ptr(src), _lib.ptr(plan["rows"]), _lib.ptr(plan["scale"]),
+                                      _lib.ptr(plan["words"]), _lib.ptr(out), B, L, C, depth, n_windows, plan["n_words"],
+                                      _lib.dtype_enum(x.dtype), _lib.stream_ptr(x.device)), "cde_logsig_windows")
     if version == 0:
-        return out, new_t.to(x.device)
+        return out, plan["new_t"]
     return out
 
 
