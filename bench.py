@@ -156,11 +156,11 @@ def strong_scaling_proxy(cde, x, func, z0, full_ms):
     return out
 
 
-def other_fields(cde, X, z0, device, reps=2):
+def other_fields(cde, X, z0, device, reps=3):
     """Same workload with the non-linear vector fields of the reference's examples (outside the timed region, not part
     of `value`): Linear -> tanh (example/irregular_data.py) and Linear -> relu -> Linear -> tanh, width 128
     (example/time_series_classification.py); and the linear field with 64 hidden units (wide tile kernels).  ms per solve,
-    wall clock over `reps` after one warm-up."""
+    best of `reps` single solves after one warm-up."""
     class TwoLayer(torch.nn.Module):
         def __init__(self):
             super().__init__()
@@ -188,17 +188,19 @@ def other_fields(cde, X, z0, device, reps=2):
                     cde.cdeint(X, func, z, X.interval, method="rk4", options={"step_size": 1.0})[:, -1].sum().backward()
             once()
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(reps):
+            best = float("inf")
+            for _ in range(reps):                  # best of `reps` single solves (each one synchronised)
+                t0 = time.perf_counter()
                 once()
-            torch.cuda.synchronize()
-            out["%s_%s_ms" % (name, mode)] = (time.perf_counter() - t0) / reps * 1e3
+                torch.cuda.synchronize()
+                best = min(best, time.perf_counter() - t0)
+            out["%s_%s_ms" % (name, mode)] = best * 1e3
     return out
 
 
-def other_configs(cde, device, reps=2):
-    """BASELINE configs[3] (one GPU's shard) and configs[4] on this GPU, outside the timed region (ms, wall clock over
-    `reps` after one warm-up):
+def other_configs(cde, device, reps=3):
+    """BASELINE configs[3] (one GPU's shard) and configs[4] on this GPU, outside the timed region (ms, best of `reps` single
+    runs after one warm-up):
       configs[3]: 32768 x 128 x 8, linear_interpolation_coeffs + LinearInterpolation, dopri5 (rtol 1e-4, atol 1e-6,
                   jump_t = the knots), linear func; forward, and forward + adaptive adjoint backward (K4 / K4a)
       configs[4]: 32768 x 512 x 3 -> depth-3 logsignatures over windows of 8 (65 x 14) -> LinearInterpolation ->
@@ -208,11 +210,13 @@ def other_configs(cde, device, reps=2):
     def timed(fn):
         fn()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
+        best = float("inf")
+        for _ in range(reps):                      # best of `reps` single runs (each one synchronised)
+            t0 = time.perf_counter()
             fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / reps * 1e3
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        return best * 1e3
 
     out = {}
     x = make_series(B, L, C, seed=0).to(device)
