@@ -1,8 +1,11 @@
+"""The training call of the reference's example model (example/time_series_classification.py: two-layer field,
+cdeint without `method`: dopri5 forward + adjoint) on the step-wise path.  python scripts/bench_default_call.py [B] [seminorm]"""
 import sys, time, torch
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import torchcde_amd as cde
 from helpers import make_series
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+extra = dict(adjoint_options=dict(norm="seminorm")) if len(sys.argv) > 2 and sys.argv[2] == "seminorm" else {}
 L, C, H = 128, 8, 32
 dev = torch.device("cuda", 0)
 class TwoLayer(torch.nn.Module):
@@ -22,7 +25,7 @@ for rep in range(2):
     func.n = 0
     z = z0.clone().requires_grad_(True)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    out = cde.cdeint(X, func, z, X.interval)          # the example's call: default dopri5, adjoint=True
+    out = cde.cdeint(X, func, z, X.interval, **extra)  # the example's call: default dopri5, adjoint=True
     torch.cuda.synchronize(); t1 = time.perf_counter()
     nf = func.n
     out[:, -1].sum().backward()
