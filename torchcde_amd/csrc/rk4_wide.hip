@@ -25,6 +25,8 @@
 // (2.3 KB per series and stage; the host code below sweeps in chunks of steps that fit the workspace).
 #include <stdlib.h>
 
+#include <vector>
+
 #include "cde_split.h"
 
 namespace cde {
@@ -513,8 +515,8 @@ int launch_adjoint_wide(const void* coeffs, const void* knots, int64_t n_interva
   if (degree != CDE_PATH_CUBIC && degree != CDE_PATH_LINEAR) return CDE_ERR_UNSUPPORTED;
   if (act != CDE_ACT_NONE && act != CDE_ACT_TANH) return CDE_ERR_UNSUPPORTED;
   // the chunk loop runs on the host: it needs the segment offsets (a device array for the other kernels) here
-  if (n_out > 4096) return CDE_ERR_UNSUPPORTED;
-  int64_t seg_off_host[4096];
+  std::vector<int64_t> seg_off_vec((size_t)n_out);
+  int64_t* seg_off_host = seg_off_vec.data();
   if (hipMemcpyAsync(seg_off_host, seg_off, (size_t)n_out * sizeof(int64_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
       hipStreamSynchronize(s) != hipSuccess)
     return CDE_ERR_LAUNCH;
