@@ -114,6 +114,14 @@ size_t cde_natural_cubic_coeffs_backward_workspace_bytes(int64_t L, int dtype);
 int cde_natural_cubic_coeffs_backward(const void* grad_coeffs, const void* t, void* grad_x, void* workspace,
                                       size_t workspace_bytes, int64_t B, int64_t L, int64_t C, int dtype, const void* x,
                                       void* kd_scratch, void* grad_t_rows, void* stream);
+/* The same for batches WITH missing entries (gradient w.r.t. the values only; autograd through
+ * interpolation_cubic.py:83-166: the compact solve over each path's own observed knots and the re-centring of every
+ * interval).  `x` (B, L, C) is the forward input (NaN = missing), `version` as in the forward; `workspace` has the
+ * size of the coefficients (B, L-1, 4C).  Missing entries receive 0, imputed end points pass their gradient to the
+ * observation they copied. */
+int cde_natural_cubic_coeffs_backward_missing(const void* grad_coeffs, const void* x, const void* t, void* grad_x,
+                                              void* workspace, int64_t B, int64_t L, int64_t C, int version, int dtype,
+                                              void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K0  Missing-value construction: the NaN path of linear_interpolation_coeffs

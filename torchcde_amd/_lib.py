@@ -88,6 +88,7 @@ _SIGNATURES = {
     "cde_natural_cubic_coeffs": (_i, [_p, _p, _p, _i64, _i64, _i64, _i, _i, _i, _p]),
     "cde_natural_cubic_coeffs_backward_workspace_bytes": (_sz, [_i64, _i]),
     "cde_natural_cubic_coeffs_backward": (_i, [_p, _p, _p, _p, _sz, _i64, _i64, _i64, _i, _p, _p, _p, _p]),
+    "cde_natural_cubic_coeffs_backward_missing": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i, _p]),
     "cde_logsig_windows": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i64, _i, _i, _p]),
     "cde_forward_fill": (_i, [_p, _p, _i64, _i64, _i64, _i, _p]),
     "cde_rectilinear_prepare": (_i, [_p, _p, _i64, _i64, _i64, _i64, _i, _p]),

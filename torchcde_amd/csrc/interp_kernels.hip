@@ -561,6 +561,113 @@ __global__ __launch_bounds__(256) void natural_cubic_backward_kernel(const T* __
   out[0] = gv_next + g[0];
 }
 
+// Backward of natural_cubic_kernel w.r.t. the values for batches WITH missing entries (autograd through
+// interpolation_cubic.py:83-166: index selection of the observed points, the compact solve, the re-centring of every
+// interval).  One lane per scalar path, `work` (B, L-1, 4C) holds the path's temporaries at the COMPACT piece index:
+//   1. transposed re-centring: the gradient of interval j folds into the gradient of the compact piece that contains
+//      it (offset o = t_kept - t_j:  a_j = pa - pb o + pc o^2 / 2 - pd o^3 / 3,  b_j = pb - pc o + pd o^2,
+//      c_j = pc - 2 pd o,  d_j = pd)
+//   2. the compact solve transposed, as in natural_cubic_backward_kernel but with the path's OWN kept knots: forward
+//      sweep over the kept points (a row is finished when the next kept point is known), the elimination factor c'_k
+//      parked in the b slot of piece k, d'_k in grad_x at the point's original index; backward sweep from the last
+//      kept point
+//   3. imputed end points hand their gradient to the observation they copied (:109-131 version 0, :226-266 version 1);
+//      missing entries get 0.
+template <typename T>
+__global__ __launch_bounds__(256) void natural_cubic_backward_missing_kernel(const T* __restrict__ grad,
+                                                                             const T* __restrict__ x,
+                                                                             const T* __restrict__ t,
+                                                                             T* __restrict__ grad_x, T* __restrict__ work,
+                                                                             int64_t B, int64_t L, int64_t C, int version) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * C) return;
+  const int64_t b = e / C, c = e - b * C;
+  const T* src = x + b * L * C + c;
+  const T* g = grad + b * (L - 1) * 4 * C + c;
+  T* w = work + b * (L - 1) * 4 * C + c;
+  T* out = grad_x + b * L * C + c;
+  const int64_t RS = 4 * C;
+  int64_t first = -1, last = -1;
+  for (int64_t i = 0; i < L; ++i) { const T v = src[i * C]; if (v == v) { if (first < 0) first = i; last = i; } out[i * C] = (T)0; }
+  if (first < 0) return;
+  auto kept = [&](int64_t i) -> bool {
+    const T v = src[i * C];
+    if (v == v) return true;
+    return version == 0 ? (i == 0 || i == L - 1) : (i < first || i > last);
+  };
+  // ---- 1. fold the interval gradients into the compact pieces (positions 0 and L-1 are always kept)
+  int64_t k = -1, kidx = 0;
+  for (int64_t j = 0; j <= L - 2; ++j) {
+    if (kept(j)) { ++k; kidx = j; T* slot = w + k * RS; slot[0] = (T)0; slot[C] = (T)0; slot[2 * C] = (T)0; slot[3 * C] = (T)0; }
+    const T o = t[kidx] - t[j], o2 = o * o;
+    const T ga = g[j * RS], gb = g[j * RS + C], gc = g[j * RS + 2 * C], gd = g[j * RS + 3 * C];
+    T* slot = w + k * RS;
+    slot[0] += ga;
+    slot[C] += gb - o * ga;
+    slot[2 * C] += gc - o * gb + (T)0.5 * o2 * ga;
+    slot[3 * C] += gd - (T)2 * o * gc + o2 * gb - o2 * o * ga / (T)3;
+  }
+  const int64_t m = k + 2;                                    // kept points
+  if (m == 2) {                                               // one straight piece: a = v_0, b = (v_1 - v_0) / (tau_1 - tau_0)
+    const T gb = w[C] / (t[L - 1] - t[0]);
+    out[0] = w[0] - gb;
+    out[(L - 1) * C] = gb;
+  } else {
+    // ---- 2a. forward sweep of T y = dL/dkd over the kept points
+    int64_t i_prev = -1;
+    k = -1;
+    T tau_p = 0, r_prev = 0, gc_prev = 0, gd_prev = 0, d_prev = 0, c_prev = 0;
+    for (int64_t i = 0; i < L; ++i) {
+      if (!kept(i)) continue;
+      const T tau = t[i];
+      if (k >= 0) {
+        T* slot = w + k * RS;
+        const T r = (T)1 / (tau - tau_p);
+        const T gc = slot[2 * C], gd = slot[3 * C];
+        T gkd = slot[C] - (T)4 * r * gc + (T)3 * r * r * gd;
+        if (k >= 1) gkd += (T)3 * r_prev * r_prev * gd_prev - (T)2 * r_prev * gc_prev;
+        const T inv = (T)1 / ((r_prev + r) * (T)2 - r_prev * c_prev);
+        const T d = (gkd - r_prev * d_prev) * inv;
+        c_prev = r * inv;
+        slot[C] = c_prev;
+        out[i_prev * C] = d;
+        d_prev = d; r_prev = r; gc_prev = gc; gd_prev = gd;
+      }
+      ++k; i_prev = i; tau_p = tau;
+    }
+    // last row (kept point m-1, no piece to its right)
+    T y_next;
+    {
+      const T gkd = (T)3 * r_prev * r_prev * gd_prev - (T)2 * r_prev * gc_prev;
+      y_next = (gkd - r_prev * d_prev) / (r_prev * (T)2 - r_prev * c_prev);
+    }
+    // ---- 2b. backward sweep
+    int64_t i_next = i_prev;
+    T tau_next = tau_p, gv_next = 0;
+    k = m - 2;
+    for (int64_t i = i_prev - 1; i >= 0; --i) {
+      if (!kept(i)) continue;
+      T* slot = w + k * RS;
+      const T y = out[i * C] - slot[C] * y_next;
+      const T r = (T)1 / (tau_next - t[i]), r2 = r * r;
+      const T gdv = (T)6 * r2 * slot[2 * C] - (T)6 * r2 * r * slot[3 * C] + (T)3 * r2 * (y + y_next);
+      out[i_next * C] = gv_next + gdv + (k + 1 <= m - 2 ? w[(k + 1) * RS] : (T)0);
+      gv_next = -gdv;
+      y_next = y; i_next = i; tau_next = t[i];
+      --k;
+    }
+    out[0] = gv_next + w[0];
+  }
+  // ---- 3. imputed end points
+  for (int64_t i = 0; i < L; ++i) {
+    const T v = src[i * C];
+    if (v == v || !kept(i)) continue;
+    const int64_t to = i < first ? first : last;
+    out[to * C] += out[i * C];
+    out[i * C] = (T)0;
+  }
+}
+
 // ------------------------------------------------------------------------------------------ K5 log-ODE windows
 // logsig_windows / logsignature_windows (reference log_ode.py:15-133) after the host has merged the window
 // boundaries into the series and filled them linearly: for every window the logsignature (depth <= 3) of the
@@ -938,6 +1045,26 @@ extern "C" int cde_natural_cubic_coeffs_backward(const void* grad_coeffs, const 
   } while (0)
   if (dtype == CDE_F32) CDE_NCB(float); else CDE_NCB(double);
 #undef CDE_NCB
+  return cde::check_launch();
+}
+
+
+// Batches with missing entries (values only): `x` is the forward input, `workspace` has the shape of the coefficients.
+extern "C" int cde_natural_cubic_coeffs_backward_missing(const void* grad_coeffs, const void* x, const void* t,
+                                                         void* grad_x, void* workspace, int64_t B, int64_t L, int64_t C,
+                                                         int version, int dtype, void* stream) {
+  if (B < 0 || L < 2 || C < 1 || (version != 0 && version != 1)) return CDE_ERR_SHAPE;
+  if (B == 0) return CDE_OK;
+  if (!grad_coeffs || !x || !t || !grad_x || !workspace) return CDE_ERR_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((B * C + 255) / 256);
+  if (dtype == CDE_F32)
+    cde::natural_cubic_backward_missing_kernel<float><<<grid, 256, 0, s>>>((const float*)grad_coeffs, (const float*)x,
+        (const float*)t, (float*)grad_x, (float*)workspace, B, L, C, version);
+  else if (dtype == CDE_F64)
+    cde::natural_cubic_backward_missing_kernel<double><<<grid, 256, 0, s>>>((const double*)grad_coeffs, (const double*)x,
+        (const double*)t, (double*)grad_x, (double*)workspace, B, L, C, version);
+  else return CDE_ERR_DTYPE;
   return cde::check_launch();
 }
 

@@ -162,8 +162,10 @@ def _natural_cubic(x, t, version):
     has_missing = bool(torch.isnan(x).any())
     if torch.is_grad_enabled() and (x.requires_grad or t.requires_grad):
         if has_missing:
-            raise NotImplementedError("torchcde_amd: gradients through the natural cubic fit are implemented for data "
-                                      "without missing values only.")
+            if t.requires_grad:
+                raise NotImplementedError("torchcde_amd: gradients of the natural cubic fit w.r.t. the knot times are "
+                                          "implemented for data without missing values only.")
+            return _NaturalCubicFitMissing.apply(x, t, version)
         return _NaturalCubicFit.apply(x, t, version)
     knots = t.detach().to(device=x.device, dtype=x.dtype).contiguous()
     return _natural_cubic_forward(x, knots, version, has_missing)
@@ -216,6 +218,32 @@ class _NaturalCubicFit(torch.autograd.Function):
             t_dtype, t_device = ctx.t_meta
             grad_t = rows.reshape(-1, L, C).sum(dim=(0, 2)).to(device=t_device, dtype=t_dtype)
         return (grad_x if ctx.needs_input_grad[0] else None), grad_t, None
+
+
+class _NaturalCubicFitMissing(torch.autograd.Function):
+    """K1n on data with missing values, gradient w.r.t. the observed values
+    (``cde_natural_cubic_coeffs_backward_missing``; autograd through interpolation_cubic.py:83-166)."""
+
+    @staticmethod
+    def forward(ctx, x, t, version):
+        knots = t.detach().to(device=x.device, dtype=x.dtype).contiguous()
+        src = x.detach().contiguous()
+        ctx.save_for_backward(knots, src)
+        ctx.version = version
+        return _natural_cubic_forward(x, knots, version, True)
+
+    @staticmethod
+    def backward(ctx, grad):
+        knots, src = ctx.saved_tensors
+        L, C = src.shape[-2], src.shape[-1]
+        B = src.numel() // (L * C)
+        grad = grad.contiguous()
+        grad_x = torch.empty_like(src)
+        workspace = torch.empty_like(grad)
+        _lib.check(_lib.load().cde_natural_cubic_coeffs_backward_missing(
+            _lib.ptr(grad), _lib.ptr(src), _lib.ptr(knots), _lib.ptr(grad_x), _lib.ptr(workspace), B, L, C, ctx.version,
+            _lib.dtype_enum(grad.dtype), _lib.stream_ptr(grad.device)), "cde_natural_cubic_coeffs_backward_missing")
+        return grad_x, None, None
 
 
 def natural_cubic_coeffs(x, t=None):
