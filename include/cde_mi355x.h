@@ -147,6 +147,14 @@ int cde_forward_fill(const void* x, void* out, int64_t B, int64_t L, int64_t C, 
  * The caller checks (as the reference asserts) that the time column holds no NaN.  Bit-exact. */
 int cde_rectilinear_prepare(const void* x, void* out, int64_t B, int64_t L, int64_t C, int64_t time_index, int dtype,
                             void* stream);
+/* Backward of K0b / K0c (the reference's index gathers are differentiable): every output entry is a copy of one input
+ * entry, the gradients of all copies flow back to it; missing entries get 0.  `x` is the forward call's input.
+ *   cde_forward_fill_backward:        grad_out (B, L, C)     -> grad_x (B, L, C)
+ *   cde_rectilinear_prepare_backward: grad_out (B, 2L-1, C)  -> grad_x (B, L, C) */
+int cde_forward_fill_backward(const void* grad_out, const void* x, void* grad_x, int64_t B, int64_t L, int64_t C, int dtype,
+                              void* stream);
+int cde_rectilinear_prepare_backward(const void* grad_out, const void* x, void* grad_x, int64_t B, int64_t L, int64_t C,
+                                     int64_t time_index, int dtype, void* stream);
 
 /* K5  The log-ODE transform: logsig_windows / logsignature_windows (torchcde/log_ode.py:15-133).  The caller has
  * merged the window boundaries into the series and filled them (log_ode.py:18-49; cde_linear_fill_missing).
@@ -159,6 +167,14 @@ int cde_rectilinear_prepare(const void* x, void* out, int64_t B, int64_t L, int6
  * third-party `signatory` calls at log_ode.py:53,57,59 ("words" mode): parity with that package is unpinned. */
 int cde_logsig_windows(const void* x, const int64_t* rows, const void* scale, const int32_t* words, void* out, int64_t B,
                        int64_t L, int64_t C, int depth, int64_t n_windows, int n_words, int dtype, void* stream);
+/* K5 backward: grad_out (B, n_windows + 1, n_words) -> grad_x (B, L, C), the gradient w.r.t. the FILLED series the
+ * forward call was given (what autograd produces through signatory's logsignature and the running sum of
+ * log_ode.py:53-63; the merge and the fill in front of it have their own backward, cde_linear_fill_missing_backward).
+ * Same tables and limits as the forward call; `workspace` has the size of grad_out.  The signature is stepped back
+ * with S (x) exp(-d) instead of being stored (the reversibility signatory's backward uses). */
+int cde_logsig_windows_backward(const void* grad_out, const void* x, const int64_t* rows, const void* scale,
+                                const int32_t* words, void* grad_x, void* workspace, int64_t B, int64_t L, int64_t C,
+                                int depth, int64_t n_windows, int n_words, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K1b  Interval lookup and path evaluation for a vector of query times.

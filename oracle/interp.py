@@ -80,11 +80,14 @@ def _fill_scalar_path(t, x):
 
 def forward_fill(x):
     """misc.py:103-126 along the length axis (-2), as a plain loop: NaNs take the latest earlier observation of their
-    scalar path; leading NaNs stay."""
+    scalar path; leading NaNs stay -- each one is its own entry (the reference's gather indexes a leading NaN to
+    itself, which matters to autograd only)."""
     out = x.clone()
+    seen = ~torch.isnan(x[..., 0, :])
     for i in range(1, x.size(-2)):
         cur = out[..., i, :]
-        out[..., i, :] = torch.where(torch.isnan(cur), out[..., i - 1, :], cur)
+        out[..., i, :] = torch.where(torch.isnan(cur) & seen, out[..., i - 1, :], cur)
+        seen = seen | ~torch.isnan(cur)
     return out
 
 

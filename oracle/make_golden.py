@@ -305,6 +305,75 @@ def cdeint_cases(ref):
     return cases
 
 
+def gradient_cases(ref):
+    """Gradients autograd produces through the REFERENCE's own construction code (test/test_tricks.py:21-49
+    differentiates through it): fits with and without missing values, both fills, rectilinear preparation, spline
+    evaluation w.r.t. coefficients / knot times / query times, and the log-ODE windows (the reference's windowing over
+    oracle.logsig).  Every case: inputs, the loss weights `w` (loss = sum(out * w)), and the gradients."""
+    gen = torch.Generator().manual_seed(77001)
+    cases = []
+
+    def gaps(x, p):
+        x = x.masked_fill(torch.rand(x.shape, generator=gen) < p, float("nan"))
+        flat = x.view(-1, x.size(-2), x.size(-1))
+        flat[0, :, 0] = float("nan")
+        flat[-1, :2, -1] = float("nan")
+        flat[-1, -2:, -1] = float("nan")
+        if flat.size(0) > 2:
+            flat[1, :, 0] = float("nan")
+            flat[1, x.size(-2) // 2, 0] = 0.25          # a single observation
+        return x
+
+    def record(kind, fn, x, t, want_t, **extra):
+        xg = x.clone().requires_grad_(True)
+        tg = None if t is None else t.clone().requires_grad_(want_t)
+        out = fn(xg, tg)
+        w = torch.randn(out.shape, generator=gen, dtype=out.dtype)
+        (torch.nan_to_num(out) * w).sum().backward()
+        cases.append(dict(kind=kind, x=x, t=t, w=w, out=out.detach(), grad_x=xg.grad,
+                          grad_t=tg.grad if want_t else None, **extra))
+
+    for dtype in (torch.float64, torch.float32):
+        for batch, L, C in (((3,), 9, 2), ((2, 2), 14, 3), ((4,), 2, 2), ((4,), 3, 1)):
+            x = torch.randn(*batch, L, C, generator=gen, dtype=dtype)
+            t = _irregular_t(L, dtype, gen)
+            record("hermite", ref.hermite_cubic_coefficients_with_backward_differences, x, t, True)
+            record("natural", ref.natural_cubic_coeffs, x, t, True)
+            xn = gaps(x.clone(), 0.3)
+            record("hermite_nan", ref.hermite_cubic_coefficients_with_backward_differences, xn, t, False)
+            record("natural_nan", ref.natural_cubic_coeffs, xn, t, False)
+            record("natural_v0_nan", ref.natural_cubic_spline_coeffs, xn, t, False)
+            record("linear_nan", ref.linear_interpolation_coeffs, xn, t, False)
+            record("forward_fill", lambda a, _: ref.misc.forward_fill(a), xn, None, False)
+            xr = xn.clone()
+            xr[..., 0] = torch.arange(L, dtype=dtype) * 0.5
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                record("rectilinear", lambda a, _: ref.linear_interpolation_coeffs(a, rectilinear=0), xr, None, False)
+        # evaluation of both controls: d/d(coefficients), d/d(knot times), d/d(query times)
+        x = torch.randn(3, 11, 2, generator=gen, dtype=dtype)
+        t = _irregular_t(11, dtype, gen)
+        tq = _query_times(t, gen)
+        for kind, make, coeffs in (("cubic", ref.CubicSpline, ref.natural_cubic_coeffs(x, t)),
+                                   ("linear", ref.LinearInterpolation, x)):
+            for what in ("evaluate", "derivative"):
+                cg, tg, qg = coeffs.clone().requires_grad_(True), t.clone().requires_grad_(True), tq.clone().requires_grad_(True)
+                out = getattr(make(cg, tg), what)(qg)
+                w = torch.randn(out.shape, generator=gen, dtype=dtype)
+                (out * w).sum().backward()
+                cases.append(dict(kind="eval_" + kind + "_" + what, coeffs=coeffs, t=t, tq=tq, w=w, out=out.detach(),
+                                  grad_coeffs=cg.grad, grad_t=tg.grad, grad_tq=qg.grad))
+        # log-ODE windows (window ends between observations; gaps in the data)
+        for C, depth, window in ((3, 3, 2.6), (2, 4, 4.0), (5, 2, 3.3)):
+            x = (torch.randn(3, 17, C, generator=gen, dtype=dtype) * 0.4).cumsum(1)
+            x[1, 4:7, 0] = float("nan")
+            t = _irregular_t(17, dtype, gen)
+            record("logsig", lambda a, tt, d=depth, wl=window: ref.logsig_windows(a, d, wl, tt), x, t, False,
+                   depth=depth, window_length=window)
+    return cases
+
+
 def run_reference_tests():
     import pytest
     files = ["test_hermite_cubic.py", "test_natural_cubic_spline.py", "test_linear_interpolation.py", "test_misc.py",
@@ -318,9 +387,15 @@ def run_reference_tests():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--run-reference-tests", action="store_true")
+    ap.add_argument("--only-gradients", action="store_true", help="write gradients.pt and leave the other fixtures alone")
     opts = ap.parse_args()
     ref = import_reference()
     os.makedirs(OUT, exist_ok=True)
+    grad_cases = gradient_cases(ref)
+    torch.save(grad_cases, os.path.join(OUT, "gradients.pt"))
+    print("gradients.pt: %d cases (autograd through the reference's own code)" % len(grad_cases))
+    if opts.only_gradients:
+        return
     interp_cases = interpolation_cases(ref)
     torch.save(interp_cases, os.path.join(OUT, "interpolation.pt"))
     print("interpolation.pt: %d cases (oracle bit-identical to reference on all)" % len(interp_cases))

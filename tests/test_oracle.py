@@ -368,3 +368,53 @@ def test_dopri5_replay_of_the_accepted_steps_reproduces_the_adaptive_solve():
     # a step that lands on a knot WITHOUT having been clipped must not trigger the just-after-the-jump re-evaluation:
     # that is what the third trace column is for
     assert any(s[2] == 0.0 and s[1] in (1., 2., 3., 4., 5., 6., 7., 8.) for s in solver.accepted) or True
+
+
+def _oracle_gradient_case(case):
+    """Run the oracle on one case of tests/golden/gradients.pt (made by oracle/make_golden.py:gradient_cases from
+    autograd through the reference's own code); returns (out, dict of gradients)."""
+    import warnings
+    from oracle import logsig as oracle_logsig
+    kind = case["kind"]
+    if kind.startswith("eval_"):
+        _, control, what = kind.split("_")
+        cg, tg, qg = (case[k].clone().requires_grad_(True) for k in ("coeffs", "t", "tq"))
+        path = (interp.CubicPath if control == "cubic" else interp.LinearPath)(cg, tg)
+        out = getattr(path, what)(qg)
+        (out * case["w"]).sum().backward()
+        return out.detach(), dict(grad_coeffs=cg.grad, grad_t=tg.grad, grad_tq=qg.grad)
+    xg = case["x"].clone().requires_grad_(True)
+    want_t = case["grad_t"] is not None
+    tg = None if case["t"] is None else case["t"].clone().requires_grad_(want_t)
+    fns = {"hermite": interp.hermite_bdiff_coeffs, "hermite_nan": lambda a, t: interp.hermite_bdiff_coeffs(interp.linear_coeffs(a, t), t),
+           "natural": interp.natural_cubic_coeffs, "natural_nan": interp.natural_cubic_coeffs,
+           "natural_v0_nan": lambda a, t: interp.natural_cubic_coeffs(a, t, version=0),
+           "linear_nan": interp.linear_coeffs, "forward_fill": lambda a, t: interp.forward_fill(a),
+           "rectilinear": lambda a, t: interp.linear_coeffs(a, rectilinear=0),
+           "logsig": lambda a, t: oracle_logsig.logsig_windows(a, case["depth"], case["window_length"], t)}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = fns[kind](xg, tg)
+    (torch.nan_to_num(out) * case["w"]).sum().backward()
+    return out.detach(), dict(grad_x=xg.grad, grad_t=tg.grad if want_t else None)
+
+
+def test_oracle_gradients_match_autograd_through_the_reference():
+    """The oracle's restatements are differentiated by autograd in the gradient parity tests: here their gradients are
+    pinned to the ones autograd produces through the reference's own code (fixtures: tests/golden/gradients.pt) --
+    fits with / without missing values, fills, rectilinear preparation, evaluation, log-ODE windows."""
+    import os
+    from conftest import GOLDEN
+    cases = torch.load(os.path.join(GOLDEN, "gradients.pt"))
+    assert len({c["kind"] for c in cases}) >= 13
+    for case in cases:
+        out, grads = _oracle_gradient_case(case)
+        f32 = out.dtype == torch.float32
+        assert torch.equal(torch.nan_to_num(out, nan=-7.0), torch.nan_to_num(case["out"], nan=-7.0)), case["kind"]
+        for name, got in grads.items():
+            want = case[name]
+            if want is None:
+                continue
+            tol = (2e-5 if f32 else 1e-12) * max(1.0, want.abs().max().item())
+            assert torch.allclose(got, want, rtol=1e-4 if f32 else 1e-10, atol=tol), (case["kind"], name,
+                                                                                     (got - want).abs().max().item())

@@ -90,8 +90,11 @@ _SIGNATURES = {
     "cde_natural_cubic_coeffs_backward": (_i, [_p, _p, _p, _p, _sz, _i64, _i64, _i64, _i, _p, _p, _p, _p]),
     "cde_natural_cubic_coeffs_backward_missing": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i, _p]),
     "cde_logsig_windows": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i64, _i, _i, _p]),
+    "cde_logsig_windows_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i64, _i, _i, _p]),
     "cde_forward_fill": (_i, [_p, _p, _i64, _i64, _i64, _i, _p]),
     "cde_rectilinear_prepare": (_i, [_p, _p, _i64, _i64, _i64, _i64, _i, _p]),
+    "cde_forward_fill_backward": (_i, [_p, _p, _p, _i64, _i64, _i64, _i, _p]),
+    "cde_rectilinear_prepare_backward": (_i, [_p, _p, _p, _i64, _i64, _i64, _i64, _i, _p]),
     "cde_path_eval": (_i, [_p, _p, _p, _i64, _p, _i64, _i64, _i64, _i, _i, _i, _p]),
     "cde_path_eval_backward": (_i, [_p, _p, _p, _i64, _p, _i64, _i64, _i64, _i, _i, _i, _p]),
     "cde_contract": (_i, [_p, _p, _p, _i64, _i64, _i64, _i, _p]),

@@ -344,6 +344,38 @@ __global__ __launch_bounds__(256) void rectilinear_prepare_kernel(const T* __res
   }
 }
 
+// Backward of the two kernels above (the reference's gathers are differentiable): every output entry was copied from
+// one input entry, so the gradients of all the copies of an observation flow back to it.  One lane per scalar path,
+// walking backwards; RECT: grad_out has 2L-1 rows, rows 2i and 2i+1 are copies of filled row i (time channel: rows
+// 2i-1 and 2i are copies of row i).  Missing entries get 0.
+template <typename T, bool RECT>
+__global__ __launch_bounds__(256) void forward_fill_backward_kernel(const T* __restrict__ grad_out,
+                                                                    const T* __restrict__ x, T* __restrict__ grad_x,
+                                                                    int64_t B, int64_t L, int64_t C, int64_t time_index) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * C) return;
+  const int64_t b = e / C, c = e - b * C;
+  const T* src = x + b * L * C + c;
+  const T* g = grad_out + b * (RECT ? 2 * L - 1 : L) * C + c;
+  T* dst = grad_x + b * L * C + c;
+  if (RECT && c == time_index) {
+    for (int64_t i = 0; i < L; ++i) dst[i * C] = i > 0 ? g[(2 * i - 1) * C] + g[(2 * i) * C] : g[0];
+    return;
+  }
+  int64_t first = L;                                        // leading NaNs are copies of themselves (the reference's
+  for (int64_t i = 0; i < L; ++i) { const T v = src[i * C]; if (v == v) { first = i; break; } }   // gather index)
+  T run = (T)0;
+  for (int64_t i = L - 1; i >= 0; --i) {
+    T own;
+    if (RECT) own = i + 1 < L ? g[(2 * i + 1) * C] + g[(2 * i) * C] : g[(2 * i) * C];
+    else own = g[i * C];
+    run = run + own;
+    const T v = src[i * C];
+    if (v == v) { dst[i * C] = run; run = (T)0; }
+    else dst[i * C] = i < first ? own : (T)0;
+  }
+}
+
 // ------------------------------------------------------------------------------------------ K1n natural cubic splines
 // natural_cubic_coeffs / natural_cubic_spline_coeffs (interpolation_cubic.py:7-266 with the tridiagonal solve of
 // misc.py:14-67), missing values included.  One lane per scalar path (series, channel), three sequential passes over
@@ -779,6 +811,190 @@ __global__ __launch_bounds__(256) void logsig_accumulate_kernel(const T* __restr
   for (int64_t win = 1; win <= n_windows; ++win) { run = run + col[win * n_words]; col[win * n_words] = run; }
 }
 
+// ---- K5 backward (autograd through signatory's logsignature and the running sum of log_ode.py:53-63)
+// pass 1: the running sum transposed -- suffix sums of grad_out along the windows, one lane per (series, coordinate);
+// row k of `gsum` = sum of the rows >= k.  Row 0 is the gradient of the first observation (first C coordinates).
+template <typename T>
+__global__ __launch_bounds__(256) void logsig_suffix_kernel(const T* __restrict__ grad_out, T* __restrict__ gsum,
+                                                            T* __restrict__ grad_x, int64_t B, int64_t L, int C,
+                                                            int64_t n_windows, int n_words) {
+  const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= B * n_words) return;
+  const int64_t b = id / n_words;
+  const int w = (int)(id - b * n_words);
+  const T* src = grad_out + b * (n_windows + 1) * n_words + w;
+  T* dst = gsum + b * (n_windows + 1) * n_words + w;
+  T run = (T)0;
+  for (int64_t win = n_windows; win >= 0; --win) { run = run + src[win * n_words]; dst[win * n_words] = run; }
+  if (w < C) grad_x[b * L * C + w] = run;                  // grad_x was zeroed by the caller; pass 2 adds to it
+}
+
+// pass 2: one lane per (series, window).  The signature levels below the top one are rebuilt (the logarithm's and the
+// Chen step's derivatives never read the top level), the word coordinates and the logarithm are differentiated into
+// gS, and the Chen recursion is walked BACKWARDS: before increment r is differentiated the signature is stepped back
+// with  S <- S (x) exp(-d_r)  (the reversibility signatory's own backward relies on), then
+//   new_k = S_k + e_k(d) + sum_j S_j (x) e_(k-j)(d),  e_m(d) = d^(x m) / m!
+// is transposed level by level, LOWEST level first (level k reads gS_k of the new signature, which the lower levels'
+// updates have not touched, and adds to the lower gS).  Rows interior to a window get both of their increments'
+// contributions from this lane (one atomic add per row and channel); a boundary row gets one add from each of its two
+// windows, so the sum does not depend on the order.
+template <typename T, int MAXC, int MAXD>
+__global__ __launch_bounds__(64) void logsig_windows_backward_kernel(const T* __restrict__ gsum, const T* __restrict__ x,
+                                                                     const int64_t* __restrict__ rows,
+                                                                     const T* __restrict__ scale,
+                                                                     const int32_t* __restrict__ words,
+                                                                     T* __restrict__ grad_x, int64_t B, int64_t L, int C,
+                                                                     int depth, int64_t n_windows, int n_words) {
+  const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= B * n_windows) return;
+  const int64_t b = id / n_windows, win = id - b * n_windows;
+  const T* src = x + b * L * C;
+  T* gx = grad_x + b * L * C;
+  const T* gw = gsum + (b * (n_windows + 1) + win + 1) * n_words;
+  T S1[MAXC], S2[MAXD >= 3 ? IPow<MAXC, 2>::value : 1], S3[MAXD >= 4 ? IPow<MAXC, 3>::value : 1];
+  T g1[MAXC], g2[MAXD >= 2 ? IPow<MAXC, 2>::value : 1], g3[MAXD >= 3 ? IPow<MAXC, 3>::value : 1],
+      g4[MAXD >= 4 ? IPow<MAXC, 4>::value : 1];
+  const int C2 = C * C, C3 = C2 * C;
+  for (int i = 0; i < C; ++i) { S1[i] = (T)0; g1[i] = (T)0; }
+  if (MAXD >= 2 && depth >= 2) for (int i = 0; i < C2; ++i) g2[i] = (T)0;
+  if (MAXD >= 3 && depth >= 3) for (int i = 0; i < C2; ++i) S2[i] = (T)0;
+  if (MAXD >= 3 && depth >= 3) for (int i = 0; i < C3; ++i) g3[i] = (T)0;
+  if (MAXD >= 4 && depth >= 4) for (int i = 0; i < C3; ++i) S3[i] = (T)0;
+  if (MAXD >= 4 && depth >= 4) for (int i = 0; i < C3 * C; ++i) g4[i] = (T)0;
+  const int64_t r_lo = rows[win], r_hi = rows[win + 1];
+  // ---- the signature of the window, levels 1 .. depth-1 (same operations as the forward kernel)
+  for (int64_t r = r_lo; r < r_hi; ++r) {
+    T d[MAXC];
+    for (int i = 0; i < C; ++i) d[i] = src[(r + 1) * C + i] - src[r * C + i];
+    if (MAXD >= 4 && depth >= 4)
+      for (int i = 0; i < C; ++i)
+        for (int j = 0; j < C; ++j) {
+          const T e2 = d[i] * d[j] / (T)2;
+          for (int k = 0; k < C; ++k) {
+            T acc = S3[(i * C + j) * C + k] + e2 * d[k] / (T)3;
+            acc = acc + S1[i] * (d[j] * d[k] / (T)2);
+            acc = acc + S2[i * C + j] * d[k];
+            S3[(i * C + j) * C + k] = acc;
+          }
+        }
+    if (MAXD >= 3 && depth >= 3)
+      for (int i = 0; i < C; ++i)
+        for (int j = 0; j < C; ++j) S2[i * C + j] = (S2[i * C + j] + d[i] * d[j] / (T)2) + S1[i] * d[j];
+    for (int i = 0; i < C; ++i) S1[i] = S1[i] + d[i];
+  }
+  // ---- word coordinates and logarithm, transposed
+  const T sc = scale[win];
+  for (int w = 0; w < n_words; ++w) {
+    const int level = words[2 * w], flat = words[2 * w + 1];
+    const T g = gw[w] * sc;
+    if (level == 1) g1[flat] += g;
+    else if (level == 2) {
+      if (MAXD >= 2) {
+        const int i = flat / C, j = flat - i * C;
+        g2[flat] += g;
+        const T h = -g / (T)2;
+        const T si = S1[i], sj = S1[j];
+        g1[i] += h * sj; g1[j] += h * si;
+      }
+    } else if (level == 3) {
+      if (MAXD >= 3) {
+        const int i = flat / C2, jk = flat - i * C2, j = jk / C, k = jk - j * C, ij = i * C + j;
+        g3[flat] += g;
+        const T h2 = -g / (T)2, h3 = g / (T)3;
+        const T si = S1[i], sj = S1[j], sk = S1[k], sjk = S2[jk], sij = S2[ij];
+        g1[i] += h2 * sjk + h3 * sj * sk;
+        g1[j] += h3 * si * sk;
+        g1[k] += h2 * sij + h3 * si * sj;
+        g2[jk] += h2 * si;
+        g2[ij] += h2 * sk;
+      }
+    } else {
+      if (MAXD >= 4) {
+        const int i = flat / C3, jkl = flat - i * C3, j = jkl / C2, kl = jkl - j * C2, k = kl / C, l = kl - k * C;
+        const int ij = i * C + j, jk = j * C + k, ijk = ij * C + k;
+        g4[flat] += g;
+        const T h2 = -g / (T)2, h3 = g / (T)3, h4 = -g / (T)4;
+        const T si = S1[i], sj = S1[j], sk = S1[k], sl = S1[l];
+        const T sij = S2[ij], sjk = S2[jk], skl = S2[kl], sijk = S3[ijk], sjkl = S3[jkl];
+        // (S^2)_4 = S1_i S3_jkl + S2_ij S2_kl + S3_ijk S1_l
+        g1[i] += h2 * sjkl; g3[jkl] += h2 * si;
+        g2[ij] += h2 * skl; g2[kl] += h2 * sij;
+        g3[ijk] += h2 * sl; g1[l] += h2 * sijk;
+        // (S^3)_4 = S1_i S1_j S2_kl + (S1_i S2_jk + S2_ij S1_k) S1_l
+        const T s23 = si * sjk + sij * sk, hs = h3 * sl;
+        g1[i] += h3 * sj * skl + hs * sjk;
+        g1[j] += h3 * si * skl;
+        g2[kl] += h3 * si * sj;
+        g1[l] += h3 * s23;
+        g2[jk] += hs * si;
+        g2[ij] += hs * sk;
+        g1[k] += hs * sij;
+        // (S^4)_4 = S1_i S1_j S1_k S1_l
+        g1[i] += h4 * sj * sk * sl; g1[j] += h4 * si * sk * sl; g1[k] += h4 * si * sj * sl; g1[l] += h4 * si * sj * sk;
+      }
+    }
+  }
+  // ---- Chen's recursion backwards
+  T carry[MAXC];                                            // -(dL/dd) of the increment above: what row r+1 still owes
+  for (int i = 0; i < C; ++i) carry[i] = (T)0;
+  for (int64_t r = r_hi - 1; r >= r_lo; --r) {
+    T d[MAXC], gd[MAXC];
+    for (int i = 0; i < C; ++i) d[i] = src[(r + 1) * C + i] - src[r * C + i];
+    // step the signature back: S <- S (x) exp(-d), highest level first
+    if (MAXD >= 4 && depth >= 4)
+      for (int i = 0; i < C; ++i)
+        for (int j = 0; j < C; ++j) {
+          const T e2 = d[i] * d[j] / (T)2;
+          for (int k = 0; k < C; ++k)
+            S3[(i * C + j) * C + k] = ((S3[(i * C + j) * C + k] - e2 * d[k] / (T)3) + S1[i] * (d[j] * d[k] / (T)2)) - S2[i * C + j] * d[k];
+        }
+    if (MAXD >= 3 && depth >= 3)
+      for (int i = 0; i < C; ++i)
+        for (int j = 0; j < C; ++j) S2[i * C + j] = (S2[i * C + j] + d[i] * d[j] / (T)2) - S1[i] * d[j];
+    if (depth >= 2) for (int i = 0; i < C; ++i) S1[i] = S1[i] - d[i];
+    // transposed step, lowest level first
+    for (int i = 0; i < C; ++i) gd[i] = g1[i];
+    if (MAXD >= 2 && depth >= 2)
+      for (int i = 0; i < C; ++i)
+        for (int j = 0; j < C; ++j) {
+          const T G = g2[i * C + j];
+          gd[i] += G * d[j] / (T)2;
+          gd[j] += G * (d[i] / (T)2 + S1[i]);
+          g1[i] += G * d[j];
+        }
+    if (MAXD >= 3 && depth >= 3)
+      for (int i = 0; i < C; ++i)
+        for (int j = 0; j < C; ++j)
+          for (int k = 0; k < C; ++k) {
+            const T G = g3[(i * C + j) * C + k];
+            const T s1 = S1[i], s2 = S2[i * C + j];
+            gd[i] += G * d[j] * d[k] / (T)6;
+            gd[j] += G * (d[i] * d[k] / (T)6 + s1 * d[k] / (T)2);
+            gd[k] += G * (d[i] * d[j] / (T)6 + s1 * d[j] / (T)2 + s2);
+            g1[i] += G * d[j] * d[k] / (T)2;
+            g2[i * C + j] += G * d[k];
+          }
+    if (MAXD >= 4 && depth >= 4)
+      for (int i = 0; i < C; ++i)
+        for (int j = 0; j < C; ++j)
+          for (int k = 0; k < C; ++k)
+            for (int l = 0; l < C; ++l) {
+              const T G = g4[((i * C + j) * C + k) * C + l];
+              const T s1 = S1[i], s2 = S2[i * C + j], s3 = S3[(i * C + j) * C + k];
+              gd[i] += G * d[j] * d[k] * d[l] / (T)24;
+              gd[j] += G * (d[i] * d[k] * d[l] / (T)24 + s1 * d[k] * d[l] / (T)6);
+              gd[k] += G * (d[i] * d[j] * d[l] / (T)24 + s1 * d[j] * d[l] / (T)6 + s2 * d[l] / (T)2);
+              gd[l] += G * (d[i] * d[j] * d[k] / (T)24 + s1 * d[j] * d[k] / (T)6 + s2 * d[k] / (T)2 + s3);
+              g1[i] += G * d[j] * d[k] * d[l] / (T)6;
+              g2[i * C + j] += G * d[k] * d[l] / (T)2;
+              g3[(i * C + j) * C + k] += G * d[l];
+            }
+    // d = x_{r+1} - x_r
+    for (int i = 0; i < C; ++i) { atomicAdd(gx + (r + 1) * C + i, gd[i] + carry[i]); carry[i] = -gd[i]; }
+  }
+  if (r_hi > r_lo) for (int i = 0; i < C; ++i) atomicAdd(gx + r_lo * C + i, carry[i]);
+}
+
 // ------------------------------------------------------------------------------------------ K1b
 template <typename T>
 __global__ void interpret_t_kernel(const T* __restrict__ knots, int64_t n_intervals, const T* __restrict__ tq,
@@ -1094,6 +1310,34 @@ extern "C" int cde_logsig_windows(const void* x, const int64_t* rows, const void
   return cde::check_launch();
 }
 
+// grad_out (B, n_windows + 1, n_words) -> grad_x (B, L, C) w.r.t. the filled series the forward call was given;
+// `workspace` has the size of grad_out.
+extern "C" int cde_logsig_windows_backward(const void* grad_out, const void* x, const int64_t* rows, const void* scale,
+                                           const int32_t* words, void* grad_x, void* workspace, int64_t B, int64_t L,
+                                           int64_t C, int depth, int64_t n_windows, int n_words, int dtype, void* stream) {
+  if (B < 0 || L < 1 || C < 1 || n_windows < 0 || n_words < 1) return CDE_ERR_SHAPE;
+  const int env = (depth >= 1 && depth <= 3 && C <= 8) ? 0 : (depth == 4 && C <= 5) ? 1 : (depth >= 1 && depth <= 2 && C <= 32) ? 2 : -1;
+  if (env < 0) return CDE_ERR_UNSUPPORTED;
+  if (B == 0) return CDE_OK;
+  if (!grad_out || !x || !rows || !scale || !words || !grad_x || !workspace) return CDE_ERR_NULL;
+  if (dtype != CDE_F32 && dtype != CDE_F64) return CDE_ERR_DTYPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(grad_x, 0, (size_t)(B * L * C) * (dtype == CDE_F64 ? 8 : 4), s) != hipSuccess) return CDE_ERR_LAUNCH;
+  const unsigned grid = (unsigned)((B * n_windows + 63) / 64), grid2 = (unsigned)((B * n_words + 255) / 256);
+#define CDE_LSB(T, MAXC, MAXD)                                                                                         \
+  cde::logsig_windows_backward_kernel<T, MAXC, MAXD><<<grid, 64, 0, s>>>((const T*)workspace, (const T*)x, rows,       \
+      (const T*)scale, words, (T*)grad_x, B, L, (int)C, depth, n_windows, n_words)
+  if (dtype == CDE_F32) {
+    cde::logsig_suffix_kernel<float><<<grid2, 256, 0, s>>>((const float*)grad_out, (float*)workspace, (float*)grad_x, B, L, (int)C, n_windows, n_words);
+    if (n_windows > 0) { if (env == 0) CDE_LSB(float, 8, 3); else if (env == 1) CDE_LSB(float, 5, 4); else CDE_LSB(float, 32, 2); }
+  } else {
+    cde::logsig_suffix_kernel<double><<<grid2, 256, 0, s>>>((const double*)grad_out, (double*)workspace, (double*)grad_x, B, L, (int)C, n_windows, n_words);
+    if (n_windows > 0) { if (env == 0) CDE_LSB(double, 8, 3); else if (env == 1) CDE_LSB(double, 5, 4); else CDE_LSB(double, 32, 2); }
+  }
+#undef CDE_LSB
+  return cde::check_launch();
+}
+
 extern "C" int cde_forward_fill(const void* x, void* out, int64_t B, int64_t L, int64_t C, int dtype, void* stream) {
   if (B < 0 || L < 1 || C < 1) return CDE_ERR_SHAPE;
   if (B == 0) return CDE_OK;
@@ -1117,6 +1361,36 @@ extern "C" int cde_rectilinear_prepare(const void* x, void* out, int64_t B, int6
     cde::rectilinear_prepare_kernel<float><<<grid, 256, 0, s>>>((const float*)x, (float*)out, B, L, C, time_index);
   else if (dtype == CDE_F64)
     cde::rectilinear_prepare_kernel<double><<<grid, 256, 0, s>>>((const double*)x, (double*)out, B, L, C, time_index);
+  else return CDE_ERR_DTYPE;
+  return cde::check_launch();
+}
+
+extern "C" int cde_forward_fill_backward(const void* grad_out, const void* x, void* grad_x, int64_t B, int64_t L, int64_t C,
+                                         int dtype, void* stream) {
+  if (B < 0 || L < 1 || C < 1) return CDE_ERR_SHAPE;
+  if (B == 0) return CDE_OK;
+  if (!grad_out || !x || !grad_x) return CDE_ERR_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((B * C + 255) / 256);
+  if (dtype == CDE_F32)
+    cde::forward_fill_backward_kernel<float, false><<<grid, 256, 0, s>>>((const float*)grad_out, (const float*)x, (float*)grad_x, B, L, C, -1);
+  else if (dtype == CDE_F64)
+    cde::forward_fill_backward_kernel<double, false><<<grid, 256, 0, s>>>((const double*)grad_out, (const double*)x, (double*)grad_x, B, L, C, -1);
+  else return CDE_ERR_DTYPE;
+  return cde::check_launch();
+}
+
+extern "C" int cde_rectilinear_prepare_backward(const void* grad_out, const void* x, void* grad_x, int64_t B, int64_t L,
+                                                int64_t C, int64_t time_index, int dtype, void* stream) {
+  if (B < 0 || L < 1 || C < 1 || time_index < 0 || time_index >= C) return CDE_ERR_SHAPE;
+  if (B == 0) return CDE_OK;
+  if (!grad_out || !x || !grad_x) return CDE_ERR_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((B * C + 255) / 256);
+  if (dtype == CDE_F32)
+    cde::forward_fill_backward_kernel<float, true><<<grid, 256, 0, s>>>((const float*)grad_out, (const float*)x, (float*)grad_x, B, L, C, time_index);
+  else if (dtype == CDE_F64)
+    cde::forward_fill_backward_kernel<double, true><<<grid, 256, 0, s>>>((const double*)grad_out, (const double*)x, (double*)grad_x, B, L, C, time_index);
   else return CDE_ERR_DTYPE;
   return cde::check_launch();
 }

@@ -77,11 +77,45 @@ def _plan(t, given, window_length, L, C_in, depth, version, dtype, device):
     return plan
 
 
+class _LogsigWindows(torch.autograd.Function):
+    """K5 with its backward (``cde_logsig_windows_backward``): signatory's logsignatures are differentiable w.r.t. the
+    path, so the reference's ``logsig_windows`` is too (log_ode.py:53-63)."""
+
+    @staticmethod
+    def forward(ctx, x, rows, scale, words, depth, n_windows, n_words):
+        L, C = x.size(-2), x.size(-1)
+        src = x.detach().contiguous()
+        B = src.numel() // (L * C)
+        out = torch.empty(*x.shape[:-2], n_windows + 1, n_words, dtype=x.dtype, device=x.device)
+        _lib.check(_lib.load().cde_logsig_windows(_lib.ptr(src), _lib.ptr(rows), _lib.ptr(scale), _lib.ptr(words),
+                                                  _lib.ptr(out), B, L, C, depth, n_windows, n_words,
+                                                  _lib.dtype_enum(x.dtype), _lib.stream_ptr(x.device)),
+                   "cde_logsig_windows")
+        ctx.save_for_backward(src, rows, scale, words)
+        ctx.meta = (depth, n_windows, n_words)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        src, rows, scale, words = ctx.saved_tensors
+        depth, n_windows, n_words = ctx.meta
+        L, C = src.size(-2), src.size(-1)
+        B = src.numel() // (L * C)
+        grad_out = grad_out.contiguous()
+        grad_x = torch.empty_like(src)
+        workspace = torch.empty_like(grad_out)
+        _lib.check(_lib.load().cde_logsig_windows_backward(
+            _lib.ptr(grad_out), _lib.ptr(src), _lib.ptr(rows), _lib.ptr(scale), _lib.ptr(words), _lib.ptr(grad_x),
+            _lib.ptr(workspace), B, L, C, depth, n_windows, n_words, _lib.dtype_enum(src.dtype),
+            _lib.stream_ptr(src.device)), "cde_logsig_windows_backward")
+        return grad_x, None, None, None, None, None, None
+
+
 def _windows(x, depth, window_length, t, version):
     given = t is not None
     t = _validate_input_path(x, t)
     _lib.require_gpu(x, "x")
-    _no_grad_through_path(x, t)
+    _no_grad_through_path(t)
     C_in = x.size(-1)
     if not ((1 <= depth <= 3 and C_in <= 8) or (depth == 4 and C_in <= 5) or (1 <= depth <= 2 and C_in <= 32)):
         raise NotImplementedError("torchcde_amd: logsignatures are implemented natively for depth <= 3 with at most 8 "
@@ -95,15 +129,7 @@ def _windows(x, depth, window_length, t, version):
         x = torch.cat([x, missing], dim=-2)[..., plan["order"], :]
         t_dev = plan["merged"]
     x = linear_interpolation_coeffs(x, t_dev)                  # fills the NaNs (the new rows and any in the data)
-    L, C = x.size(-2), x.size(-1)
-    src = x.detach().contiguous()
-    B = src.numel() // (L * C)
-    n_windows = plan["n_windows"]
-    out = torch.empty(*batch, n_windows + 1, plan["n_words"], dtype=x.dtype, device=x.device)
-    lib = _lib.load()
-    _lib.check(lib.cde_logsig_windows(_lib.ptr(src), _lib.ptr(plan["rows"]), _lib.ptr(plan["scale"]),
-                                      _lib.ptr(plan["words"]), _lib.ptr(out), B, L, C, depth, n_windows, plan["n_words"],
-                                      _lib.dtype_enum(x.dtype), _lib.stream_ptr(x.device)), "cde_logsig_windows")
+    out = _LogsigWindows.apply(x, plan["rows"], plan["scale"], plan["words"], depth, plan["n_windows"], plan["n_words"])
     if version == 0:
         return out, plan["new_t"]
     return out

@@ -51,8 +51,9 @@ def _validate_input_path(x, t):
 def _no_grad_through_path(*tensors):
     if torch.is_grad_enabled() and any(isinstance(x, torch.Tensor) and x.requires_grad for x in tensors):
         raise NotImplementedError(
-            "torchcde_amd: gradients with respect to the control path (raw data, coefficients or knot times) are not "
-            "implemented on the native path yet (SURVEY section 8(f), rank 3). Detach these inputs.")
+            "torchcde_amd: gradients with respect to the knot times are not implemented for this construction "
+            "(they are for the Hermite and natural cubic fits of data without missing values and for spline "
+            "evaluation). Detach `t`.")
 
 
 def _flat3(x):
@@ -68,15 +69,51 @@ def forward_fill(x, fill_index=-2):
     _lib.require_gpu(x, "x")
     if not torch.isnan(x).any():
         return x
-    _no_grad_through_path(x)
     dim = fill_index % x.dim()
     moved = x.movedim(dim, -2) if dim != x.dim() - 2 else x
-    src, B, L, C = _flat3(moved)
-    out = torch.empty_like(src)
-    lib = _lib.load()
-    _lib.check(lib.cde_forward_fill(_lib.ptr(src), _lib.ptr(out), B, L, C, _lib.dtype_enum(x.dtype),
-                                    _lib.stream_ptr(x.device)), "cde_forward_fill")
+    out = _CopyFill.apply(moved, None)
     return out.movedim(-2, dim) if dim != x.dim() - 2 else out
+
+
+class _CopyFill(torch.autograd.Function):
+    """K0b (``time_index is None``) / K0c with their backward: outputs are copies of input entries, the gradients of
+    the copies flow back to the entry they were taken from (the reference's gathers, misc.py:103-126 and
+    interpolation_linear.py:86-128, are differentiable)."""
+
+    @staticmethod
+    def forward(ctx, x, time_index):
+        src, B, L, C = _flat3(x)
+        lib = _lib.load()
+        if time_index is None:
+            out = torch.empty_like(src)
+            _lib.check(lib.cde_forward_fill(_lib.ptr(src), _lib.ptr(out), B, L, C, _lib.dtype_enum(x.dtype),
+                                            _lib.stream_ptr(x.device)), "cde_forward_fill")
+        else:
+            out = torch.empty(*x.shape[:-2], 2 * L - 1, C, dtype=x.dtype, device=x.device)
+            _lib.check(lib.cde_rectilinear_prepare(_lib.ptr(src), _lib.ptr(out), B, L, C, time_index,
+                                                   _lib.dtype_enum(x.dtype), _lib.stream_ptr(x.device)),
+                       "cde_rectilinear_prepare")
+        ctx.save_for_backward(src)
+        ctx.time_index = time_index
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        src, = ctx.saved_tensors
+        L, C = src.size(-2), src.size(-1)
+        B = src.numel() // max(L * C, 1)
+        grad_out = grad_out.contiguous()
+        grad_x = torch.empty_like(src)
+        lib = _lib.load()
+        dt, stream = _lib.dtype_enum(src.dtype), _lib.stream_ptr(src.device)
+        if ctx.time_index is None:
+            _lib.check(lib.cde_forward_fill_backward(_lib.ptr(grad_out), _lib.ptr(src), _lib.ptr(grad_x), B, L, C, dt,
+                                                     stream), "cde_forward_fill_backward")
+        else:
+            _lib.check(lib.cde_rectilinear_prepare_backward(_lib.ptr(grad_out), _lib.ptr(src), _lib.ptr(grad_x), B, L, C,
+                                                            ctx.time_index, dt, stream),
+                       "cde_rectilinear_prepare_backward")
+        return grad_x, None
 
 
 _RECTILINEAR_WARNING = ("The data `x` begins with missing values in some channels. The path will be constructed by "
@@ -97,14 +134,7 @@ def _prepare_rectilinear_interpolation(data, time_index):
     assert not torch.isnan(data[..., time_index]).any(), \
         "There exist nan values in the time column which is not allowed. If the times are padded with nans after " \
         "final time, a simple solution is to forward fill the final time."
-    _no_grad_through_path(data)
-    src, B, L, C = _flat3(data)
-    out = torch.empty(*data.shape[:-2], 2 * L - 1, C, dtype=data.dtype, device=data.device)
-    lib = _lib.load()
-    _lib.check(lib.cde_rectilinear_prepare(_lib.ptr(src), _lib.ptr(out), B, L, C, time_index,
-                                           _lib.dtype_enum(data.dtype), _lib.stream_ptr(data.device)),
-               "cde_rectilinear_prepare")
-    return out
+    return _CopyFill.apply(data, time_index)
 
 
 def linear_interpolation_coeffs(x, t=None, rectilinear=None):
