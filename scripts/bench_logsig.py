@@ -20,3 +20,14 @@ best = min(times)
 print(json.dumps({"config": "logsig_windows depth=%d, B=%d L=%d C=%d window=%g" % (depth, B, L, C, window),
                   "out_shape": list(out.shape), "seconds": best, "series_per_s": B / best,
                   "input_GBs": x.numel() * 4 / best / 1e9}))
+# the same transform with gradients w.r.t. the raw data (cde_logsig_windows_backward)
+xg = x.clone().requires_grad_(True)
+w = torch.randn_like(out)
+def fwd_bwd():
+    xg.grad = None
+    (cde.logsig_windows(xg, depth, window) * w).sum().backward()
+fwd_bwd(); torch.cuda.synchronize()
+times = []
+for _ in range(5):
+    t0 = time.perf_counter(); fwd_bwd(); torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
+print(json.dumps({"config": "the same, forward + backward w.r.t. x", "seconds": min(times), "series_per_s": B / min(times)}))
