@@ -133,7 +133,9 @@ def _plan_time_gradients(plan, z_saved, grad_out, weight, bias, grad_x, t, want_
       dL/d knot_j      = - int_{interval j} a^T F(z) d2X/dt2 dt       -- the reference's `frac = t - t_j` chain
     With a cubic control d2X/dt2 = 2c + 2 (3d) frac, so both integrals are per-interval contractions of the control
     gradient the sweep accumulates anyway: sum_c (2c . dL/db + 2 (3d) . dL/d(2c)).  A piecewise-linear control has no
-    such term."""
+    such term; its slopes (x_{j+1} - x_j) / h_j depend on the knot times through the widths h_j instead
+    (interpolation_linear.py:189): with G_j = dL/d(slope_j), dL/dh_j = -G_j . slope_j / h_j, and G_j / h_j is minus the
+    running sum of the knot-value gradient the sweep produced (dL/dx_j = G_{j-1} / h_{j-1} - G_j / h_j telescopes)."""
     B, H, C = plan.B, plan.H, plan.C
     dev = plan.device
     coeffs = plan.coeffs                                              # (B, rows, width)
@@ -159,8 +161,15 @@ def _plan_time_gradients(plan, z_saved, grad_out, weight, bias, grad_x, t, want_
             total = total + vals[i]
         vals[0] = per_interval.sum() - total
         grad_t = torch.stack(vals).to(t.dtype) if plan.n_out > 1 else torch.zeros_like(t)
-    if want_knots:
+    if want_knots and plan.degree == _lib.PATH_CUBIC:
         grad_knots = torch.cat([-per_interval, per_interval.new_zeros(1)])
+    elif want_knots:
+        knots = plan.knots.double()
+        values = coeffs.double()
+        slopes = (values[:, 1:] - values[:, :-1]) / (knots[1:] - knots[:-1]).unsqueeze(-1)
+        dh = (grad_x.double().cumsum(1)[:, :-1] * slopes).sum((0, 2))            # dL/dh_j
+        zero = dh.new_zeros(1)
+        grad_knots = (torch.cat([zero, dh]) - torch.cat([dh, zero])).to(coeffs.dtype)
     return grad_t, grad_knots
 
 
@@ -975,10 +984,6 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
                                       "bias, the control's coefficient tensor and its knot times on the native path.")
         want_w = any(p is weight for p in adjoint_params)
         want_b = any(p is bias for p in adjoint_params)
-    if want_knots and X._degree != _lib.PATH_CUBIC:
-        raise NotImplementedError("torchcde_amd: gradients with respect to the knot times are implemented for "
-                                  "CubicSpline controls only.")
-
     plan = _Plan(X, field, batch, H, C, t, step_size, adjoint_step, adjoint, variant)
     control_inputs = X._control_buffers() if want_x else ()
     return _FusedRK4.apply(z0, weight, bias, plan, (want_w, want_b, want_x), t if wants_t else None,
