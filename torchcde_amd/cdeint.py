@@ -830,6 +830,9 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
     if not isinstance(system, torch.Tensor):
         raise ValueError("z0 is a tensor and so func must return a tensor as well.")
     _shape_errors(batch + (C,), tuple(system.shape), z0)
+    # func's formula, when the probe identified it: lets the step-wise adjoint write its dynamics in closed form
+    # (`variant="generic"` keeps autograd: the independent cross-check the tests compare against)
+    recognised = field if variant == _lib.VARIANT_AUTO else None
     mlp = None
     if field is not None and field.kind == "mlp2":
         mlp, field = (field if _mlp_fusable(field, H, C, z0, packed) else None), None
@@ -930,7 +933,7 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         kw = stepwise_kwargs
         return stepwise.solve(X, func, z0, t, adjoint, method, options, kw["rtol"], kw["atol"],
                               kw.get("adjoint_method"), kw.get("adjoint_options"), kw.get("adjoint_rtol"),
-                              kw.get("adjoint_atol"), kw.get("adjoint_params"))
+                              kw.get("adjoint_atol"), kw.get("adjoint_params"), recognised=recognised)
     if not (isinstance(t, torch.Tensor) and t.dim() == 1 and t.is_floating_point()):
         raise ValueError("t must be a one dimensional floating point tensor.")
     if t.numel() < 1:

@@ -54,6 +54,7 @@ class ControlledField:
     def __init__(self, X, func):
         self.X, self.func = X, func
         self.through_time = False      # backprop through the solver: dX/dt(t) itself is differentiated w.r.t. t
+        self.recognised = None         # fields.AffineField / MLPField when the probe identified func's formula
 
     def __call__(self, t, z):
         dX = self.X.derivative(t if self.through_time else t.detach())
@@ -69,6 +70,66 @@ class ControlledField:
             if hasattr(self.func, "prod"):
                 return self.func.prod(t, z, d2X)
             return _Contract.apply(self.func(t, z), d2X)
+
+
+def _explicit_dynamics(field, params):
+    """The augmented dynamics of the continuous adjoint in closed form for a RECOGNISED vector field (fields.py: the
+    probe established bitwise that func is act(Linear(z)) or act(Linear(relu(Linear(z)))) viewed (..., H, C)):
+    (t, y, a) -> (f, -a^T df/dy, [-a^T df/dp for p in params]) with a dozen matrix / elementwise launches instead of an
+    autograd graph of about forty per evaluation -- the step-wise adaptive backward of the reference's example models
+    (two-layer field, default dopri5 + adjoint call) is bound by launches, not by arithmetic.  Returns None when a
+    parameter is not one of the field's weights / biases (autograd then differentiates func as usual)."""
+    rec = getattr(field, "recognised", None)
+    if rec is None or not isinstance(field, ControlledField) or hasattr(field.func, "prod"):
+        return None
+    layers = rec.linears
+    slots = []
+    for p in params:
+        where = [(i, name) for i, lin in enumerate(layers) for name in ("weight", "bias") if getattr(lin, name) is p]
+        if not where:
+            return None
+        slots.append(where[0])
+    tanh = rec.act == _lib.ACT_TANH
+    two = len(layers) == 2
+    out_layer = layers[-1]
+
+    def run(tt, yy, aa):
+        H = yy.size(-1)
+        z, a = yy.reshape(-1, H), aa.reshape(-1, H)
+        dX = field.X.derivative(tt)
+        C = dX.size(-1)
+        dX = dX.reshape(-1, C)
+        if two:
+            w1, b1 = layers[0].weight, layers[0].bias
+            h1 = z @ w1.t() if b1 is None else torch.addmm(b1, z, w1.t())
+            r = h1.relu()
+        else:
+            r = z
+        w, b = out_layer.weight, out_layer.bias
+        u = r @ w.t() if b is None else torch.addmm(b, r, w.t())
+        th = u.tanh() if tanh else u
+        fe = _Contract.apply(th.view(-1, H, C), dX)
+        gu = (a.neg().unsqueeze(-1) * dX.unsqueeze(-2)).reshape(-1, H * C)            # cotangent -a on f = F dX
+        if tanh:
+            gu = torch.addcmul(gu, gu * th, th, value=-1)                             # * (1 - tanh^2)
+        grads = {}
+        need = set(slots)
+        if (len(layers) - 1, "weight") in need:
+            grads[(len(layers) - 1, "weight")] = gu.t() @ r
+        if (len(layers) - 1, "bias") in need:
+            grads[(len(layers) - 1, "bias")] = gu.sum(0)
+        if two:
+            gh1 = (gu @ w) * (h1 > 0)
+            if (0, "weight") in need:
+                grads[(0, "weight")] = gh1.t() @ z
+            if (0, "bias") in need:
+                grads[(0, "bias")] = gh1.sum(0)
+            vy = gh1 @ layers[0].weight
+        else:
+            vy = gu @ w
+        return fe.reshape(yy.shape), vy.reshape(yy.shape), [grads[slot].reshape(p.shape) for slot, p in zip(slots, params)]
+
+    return run
 
 
 # ------------------------------------------------------------------------------------------ helpers
@@ -346,8 +407,17 @@ class _Adjoint(torch.autograd.Function):
             aug = [torch.zeros((), dtype=y.dtype, device=y.device), y[-1], grad_y[-1]]
             aug.extend(torch.zeros_like(p) for p in params)
 
+            explicit = _explicit_dynamics(func, params)
+
             def dynamics(time, state):
                 yy, aa = state[1], state[2]
+                if explicit is not None:
+                    tt = time.detach().to(yy.dtype)
+                    fe, vy, vp = explicit(tt, yy, aa)
+                    vt = torch.zeros_like(state[0])            # a recognised field does not read t itself
+                    if need_t:
+                        vt = vt - (aa * func.time_partial(tt, yy)).sum().to(vt.dtype)
+                    return (vt, fe, vy, *vp)
                 with torch.enable_grad():
                     # the "detach trick" (reference test/test_tricks.py:111-131): t joins the graph only when its
                     # gradient is wanted, so parameter gradients are bitwise the same either way
@@ -428,9 +498,13 @@ class TupleField:
 
 
 def solve(X, func, z0, t, adjoint, method, options, rtol, atol, adjoint_method, adjoint_options, adjoint_rtol,
-          adjoint_atol, adjoint_params, field=None):
-    """Step-wise cdeint: returns (..., len(t), H) like the fused path."""
-    field = ControlledField(X, func) if field is None else field
+          adjoint_atol, adjoint_params, field=None, recognised=None):
+    """Step-wise cdeint: returns (..., len(t), H) like the fused path.  `recognised`: the probe's verdict on func
+    (fields.AffineField / MLPField) when its formula is known -- the adjoint then evaluates its dynamics in closed
+    form (`_explicit_dynamics`)."""
+    if field is None:
+        field = ControlledField(X, func)
+        field.recognised = recognised
     t = t.to(z0.device)
     if adjoint:
         if adjoint_params is None:
