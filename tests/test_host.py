@@ -516,3 +516,76 @@ def test_probe_refuses_value_dependent_lookalikes_and_tracks_module_state():
     finally:
         LinearCDEFunc.forward = original
     assert probe(g, t0, z)[0] is not None
+
+
+def test_closed_form_adjoint_dynamics_equal_autograd(monkeypatch):
+    """stepwise._explicit_dynamics (the augmented dynamics of the continuous adjoint written out for a recognised
+    field) against torch.autograd.grad on the same module: affine / tanh / two-layer fields, a Linear without bias,
+    parameters given as a reordered subset and as views of the same memory (what backward() gets back from
+    save_for_backward), extra batch dimensions; a parameter the field does not own makes it step aside."""
+    from torchcde_amd import stepwise
+
+    class CpuContract:                                    # cde_contract needs the GPU; the formula is all that matters here
+        @staticmethod
+        def apply(F, dX):
+            return (F * dX.unsqueeze(-2)).sum(-1)
+
+    monkeypatch.setattr(stepwise, "_Contract", CpuContract)
+
+    class Path:
+        def __init__(self, slope):
+            self.slope = slope
+
+        def derivative(self, t):
+            return self.slope * (1 + t)
+
+    class Two(torch.nn.Module):
+        def __init__(self, H, C, width, final_tanh, bias):
+            super().__init__()
+            self.H, self.C, self.final_tanh = H, C, final_tanh
+            self.a, self.b = torch.nn.Linear(H, width, bias=bias), torch.nn.Linear(width, H * C, bias=bias)
+
+        def forward(self, t, z):
+            y = self.b(self.a(z).relu())
+            return (y.tanh() if self.final_tanh else y).view(*z.shape[:-1], self.H, self.C)
+
+    class One(torch.nn.Module):
+        def __init__(self, H, C, tanh, bias):
+            super().__init__()
+            self.H, self.C, self.tanh = H, C, tanh
+            self.lin = torch.nn.Linear(H, H * C, bias=bias)
+
+        def forward(self, t, z):
+            y = self.lin(z)
+            return (y.tanh() if self.tanh else y).view(*z.shape[:-1], self.H, self.C)
+
+    torch.manual_seed(3)
+    H, C = 5, 3
+    for lead in ((7,), (2, 4)):
+        for func in (One(H, C, False, True), One(H, C, True, True), Two(H, C, 9, True, True), Two(H, C, 9, False, True)):
+            func = func.double()
+            y = torch.randn(*lead, H, dtype=torch.float64)
+            a = torch.randn(*lead, H, dtype=torch.float64)
+            t = torch.tensor(0.3, dtype=torch.float64)
+            recognised, _ = probe(func, t, y)
+            assert recognised is not None
+            field = stepwise.ControlledField(Path(torch.randn(*lead, C, dtype=torch.float64)), func)
+            field.recognised = recognised
+            params = tuple(reversed([p for p in func.parameters()]))[:3]
+            saved = tuple(p.detach().view_as(p) for p in params)          # same memory, different tensor objects
+            run = stepwise._explicit_dynamics(field, saved)
+            assert run is not None
+            with torch.no_grad():
+                fe, vy, vp = run(t, y, a)
+            yy = y.clone().requires_grad_(True)
+            want_f = field(t, yy)
+            want = torch.autograd.grad(want_f, (yy,) + params, -a, allow_unused=True)
+            assert torch.allclose(fe, want_f.detach(), rtol=1e-12, atol=1e-13)
+            assert torch.allclose(vy, want[0], rtol=1e-11, atol=1e-12)
+            for got, ref, p in zip(vp, want[1:], params):
+                assert got.shape == p.shape
+                assert torch.allclose(got, ref, rtol=1e-11, atol=1e-12)
+            stranger = torch.nn.Parameter(torch.zeros(3, dtype=torch.float64))
+            assert stepwise._explicit_dynamics(field, saved + (stranger,)) is None
+    plain = stepwise.ControlledField(Path(torch.zeros(1, C)), func)
+    assert stepwise._explicit_dynamics(plain, ()) is None                # not recognised: autograd

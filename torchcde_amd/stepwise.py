@@ -84,8 +84,11 @@ def _explicit_dynamics(field, params):
         return None
     layers = rec.linears
     slots = []
+    def same(own, p):            # backward() sees the parameters as saved tensors: identity, or the same memory
+        return own is not None and (own is p or (own.shape == p.shape and own.dtype == p.dtype and
+                                                 own.data_ptr() == p.data_ptr()))
     for p in params:
-        where = [(i, name) for i, lin in enumerate(layers) for name in ("weight", "bias") if getattr(lin, name) is p]
+        where = [(i, name) for i, lin in enumerate(layers) for name in ("weight", "bias") if same(getattr(lin, name), p)]
         if not where:
             return None
         slots.append(where[0])
