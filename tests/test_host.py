@@ -589,3 +589,34 @@ def test_closed_form_adjoint_dynamics_equal_autograd(monkeypatch):
             assert stepwise._explicit_dynamics(field, saved + (stranger,)) is None
     plain = stepwise.ControlledField(Path(torch.zeros(1, C)), func)
     assert stepwise._explicit_dynamics(plain, ()) is None                # not recognised: autograd
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_stepwise_solvers_equal_the_oracle_bitwise_on_plain_functions(dtype):
+    """torchcde_amd/stepwise.py drives torchdiffeq's time stepping from the host; on a plain tensor function (no native
+    kernel involved, so this runs without a GPU) it must reproduce oracle/odeint.py -- the restatement of torchdiffeq --
+    bit for bit: dopri5 with and without jump times, increasing and decreasing output times, two output times inside
+    one step, tuple state; rk4 / midpoint / euler on a fixed grid."""
+    from torchcde_amd import stepwise
+    torch.manual_seed(0)
+    A = (torch.randn(6, 6, dtype=torch.float64) * 0.5).to(dtype)
+
+    def f(t, y):
+        return torch.tanh(y @ A.T) * (1 + 0.1 * torch.sin(t))
+
+    y0 = torch.randn(4, 6, dtype=torch.float64).to(dtype)
+    for t in (torch.tensor([0., 0.7, 1.9, 1.95, 3.0], dtype=dtype), torch.tensor([3.0, 1.1, 0.], dtype=dtype)):
+        for opts in ({}, {"jump_t": torch.tensor([0.5, 1.5, 2.5], dtype=dtype)}):
+            got = stepwise.odeint(f, y0, t, method="dopri5", options=dict(opts), rtol=1e-5, atol=1e-7)
+            want = oracle_ode.odeint(f, y0, t, method="dopri5", options=dict(opts), rtol=1e-5, atol=1e-7)
+            assert torch.equal(got, want)
+    ts = torch.tensor([0., 1., 2.], dtype=dtype)
+    g = lambda t, s: (f(t, s[0]), -s[1])
+    got = stepwise.odeint(g, (y0, y0[:, :2]), ts, method="dopri5", options={}, rtol=1e-6, atol=1e-8)
+    want = oracle_ode.odeint(g, (y0, y0[:, :2]), ts, method="dopri5", options={}, rtol=1e-6, atol=1e-8)
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+    grid = torch.tensor([0., 0.7, 1.9, 3.0], dtype=dtype)
+    for method in ("rk4", "midpoint", "euler"):
+        got = stepwise.odeint(f, y0, grid, method=method, options=dict(step_size=0.25), rtol=0, atol=0)
+        want = oracle_ode.odeint(f, y0, grid, method=method, options=dict(step_size=0.25), rtol=0, atol=0)
+        assert torch.equal(got, want)

@@ -320,10 +320,7 @@ def _solve_dopri5(f, y0, t, rtol, atol, norm, jump_t=None, safety=0.9, ifactor=1
             tol = atol + rtol * torch.max(y.abs(), y1.abs())
             ratio = norm(k.matmul(dty * c_err) / tol).abs()
             if bool(ratio <= 1):
-                ymid = y + k.matmul(dty * c_mid).view_as(y)
-                dense = (y, dty * fy, dty * (f1 - 4 * fy) - 11 * y - 5 * y1 + 16 * ymid,
-                         dty * (5 * fy - 3 * f1) + 18 * y + 14 * y1 - 32 * ymid,
-                         2 * dty * (f1 - fy) - 8 * (y1 + y) + 16 * ymid)
+                dense = (y, fy, y1, f1, k, dty)          # the interpolant's coefficients are formed only if it is evaluated
                 if on_jump:
                     if i_jump != len(jumps) - 1:
                         i_jump += 1
@@ -336,9 +333,14 @@ def _solve_dopri5(f, y0, t, rtol, atol, norm, jump_t=None, safety=0.9, ifactor=1
             else:
                 df = torch.ones((), dtype=td, device=dev) if ratio < 1 else dfactor
                 dt = dt * torch.min(ifactor, torch.max(safety / ratio.to(td) ** 0.2, df))
+        ya, fa, yb, fb, k, dty = dense                  # the step that reached the output time: quartic dense output
+        ymid = ya + k.matmul(dty * c_mid).view_as(ya)
+        coeffs = (ya, dty * fa, dty * (fb - 4 * fa) - 11 * ya - 5 * yb + 16 * ymid,
+                  dty * (5 * fa - 3 * fb) + 18 * ya + 14 * yb - 32 * ymid,
+                  2 * dty * (fb - fa) - 8 * (yb + ya) + 16 * ymid)
         x = ((target - t_lo) / (t_hi - t_lo)).to(ydt)
-        total, xp = dense[0] + x * dense[1], x
-        for coeff in dense[2:]:
+        total, xp = coeffs[0] + x * coeffs[1], x
+        for coeff in coeffs[2:]:
             xp = xp * x
             total = total + xp * coeff
         out.append(total)
