@@ -620,3 +620,48 @@ def test_stepwise_solvers_equal_the_oracle_bitwise_on_plain_functions(dtype):
         got = stepwise.odeint(f, y0, grid, method=method, options=dict(step_size=0.25), rtol=0, atol=0)
         want = oracle_ode.odeint(f, y0, grid, method=method, options=dict(step_size=0.25), rtol=0, atol=0)
         assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_stepwise_adjoint_equals_the_oracle_adjoint_on_plain_modules(dtype):
+    """The host-driven continuous adjoint (stepwise._Adjoint: augmented state, per-interval reverse solves, re-seeding
+    from the stored solution, output-time gradients) against oracle/odeint.py's restatement of torchdiffeq's
+    odeint_adjoint on a plain nn.Module (no native kernel: runs without a GPU): trajectories and the gradients of z0
+    and of every parameter bit for bit, dL/dt to round-off (a sum against a dot product).  rk4 and dopri5, jump times.
+    When `t` needs no gradient the module is time-independent: torchdiffeq's wrapper hands func a time that ALWAYS
+    carries requires_grad (its detach shares the tensor), so for a time-dependent func its |vjp_t| error component is
+    alive even then; the native paths compute vjp_t only when dL/dt is asked for."""
+    from torchcde_amd import stepwise
+
+    class Field(torch.nn.Module):
+        def __init__(self, timed):
+            super().__init__()
+            torch.manual_seed(1)
+            self.lin = torch.nn.Linear(5, 5).to(dtype)
+            self.scale = torch.nn.Parameter(torch.tensor(0.3, dtype=dtype))
+            self.timed = timed
+
+        def forward(self, t, y):
+            return torch.tanh(self.lin(y)) * self.scale * ((1 + 0.2 * torch.cos(t)) if self.timed else 1.0)
+
+    for method, opts in (("rk4", dict(step_size=0.25)), ("dopri5", {}),
+                         ("dopri5", {"jump_t": torch.tensor([0.5, 1.5], dtype=dtype)})):
+        for need_t in (False, True):
+            results = []
+            for which in ("native", "oracle"):
+                func = Field(need_t)
+                y0 = torch.randn(3, 5, generator=torch.Generator().manual_seed(2), dtype=torch.float64).to(dtype)
+                y0.requires_grad_(True)
+                t = torch.tensor([0., 0.8, 2.0], dtype=dtype, requires_grad=need_t)
+                if which == "native":
+                    cfg = dict(func=func, method=method, options=dict(opts), rtol=1e-5, atol=1e-7, adjoint_method=method,
+                               adjoint_options=dict(opts), adjoint_rtol=1e-5, adjoint_atol=1e-7, t_requires_grad=need_t)
+                    out = stepwise._Adjoint.apply(cfg, y0, t, *func.parameters())
+                else:
+                    out = oracle_ode.odeint_adjoint(func, y0, t, method=method, options=dict(opts), rtol=1e-5, atol=1e-7)
+                (out * torch.linspace(0.5, 1.5, out.numel(), dtype=dtype).view_as(out)).sum().backward()
+                results.append(([out.detach(), y0.grad] + [p.grad for p in func.parameters()], t.grad))
+            (got, got_t), (want, want_t) = results
+            assert all(torch.equal(a, b) for a, b in zip(got, want)), (method, need_t)
+            if need_t:
+                assert torch.allclose(got_t, want_t, rtol=1e-5 if dtype == torch.float32 else 1e-13, atol=1e-6 if dtype == torch.float32 else 1e-14)

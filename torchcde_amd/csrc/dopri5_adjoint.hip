@@ -22,7 +22,8 @@
 // Two stated deviations from torchdiffeq's backward (both leave a valid solve at the requested tolerances):
 //   1. the error norm above omits the parameter-gradient blocks that torchdiffeq's default adjoint norm also looks at
 //      (its `adjoint_options=dict(norm="seminorm")` behaviour): the blocks would need a grid-wide reduction of 8,448
-//      values per attempt;
+//      values per attempt; nor does it hold |vjp_t|, which torchdiffeq carries whenever func depends on t (DESIGN.md
+//      section 4);
 //   2. the last step of an output interval is clipped to end on t_{i-1} instead of stepping past it and evaluating
 //      the dense interpolant there (identical when t_{i-1} is a jump time, e.g. t = X.interval with jump_t = knots --
 //      README.md:194-200 -- because torchdiffeq clips onto jump times itself).
