@@ -665,3 +665,42 @@ def test_stepwise_adjoint_equals_the_oracle_adjoint_on_plain_modules(dtype):
             assert all(torch.equal(a, b) for a, b in zip(got, want)), (method, need_t)
             if need_t:
                 assert torch.allclose(got_t, want_t, rtol=1e-5 if dtype == torch.float32 else 1e-13, atol=1e-6 if dtype == torch.float32 else 1e-14)
+
+
+def test_log_ode_window_bookkeeping_equals_the_reference_loop():
+    """torchcde_amd/log_ode.py evaluates the reference's per-window Python loop (log_ode.py:18-49: `value <= t[pointer]`
+    or allclose, pointer never moving back) for all window ends at once; oracle.logsig.window_plan restates the loop
+    itself (pinned to the reference by tests/golden/logsig_windows.pt).  Same boundary rows, same fresh times, same
+    merged order -- regular and irregular times, window lengths that divide the span, overshoot it, or land within
+    allclose of an observation time."""
+    from oracle import logsig as oracle_logsig
+    from torchcde_amd import log_ode
+    gen = torch.Generator().manual_seed(5)
+    cases = []
+    for dtype in (torch.float32, torch.float64):
+        regular = torch.linspace(0, 16, 17, dtype=dtype)
+        irregular = (torch.rand(23, generator=gen, dtype=torch.float64) + 0.2).cumsum(0).to(dtype)
+        for t in (regular, irregular, regular * 0.37 + 2.0):
+            span = (t[-1] - t[0]).item()
+            for window in (span / 4, span / 4 * (1 + 1e-9), 3.0, 2.6, span, span * 1.7, 1.0, 0.73):
+                cases.append((t, float(window)))
+    assert len(cases) == 48
+    for t, window in cases:
+        new_t, rows, fresh = oracle_logsig.window_plan(t, window)
+        log_ode._plans.clear()
+        plan = log_ode._plan(t, True, window, t.numel(), 3, 2, 1, t.dtype, torch.device("cpu"))
+        assert plan["rows"].tolist() == rows
+        assert plan["n_windows"] == len(rows) - 1
+        assert torch.equal(plan["new_t"], new_t)
+        if fresh:
+            merged, order = torch.cat([t, *fresh]).sort()
+            assert torch.equal(plan["merged"], merged)
+            assert torch.equal(plan["order"], order.clamp(0, t.numel()))
+        else:
+            assert plan["order"] is None and plan["merged"] is None
+        scale0 = log_ode._plan(t, True, window, t.numel(), 3, 2, 0, t.dtype, torch.device("cpu"))["scale"]
+        assert torch.equal(scale0, (new_t[1:] - new_t[:-1]).to(t.dtype))
+    # the word table: signatory's order (by length, then lexicographic), flat index = base-C digits of the word
+    words = log_ode._plan(regular, True, 4.0, 17, 3, 3, 1, torch.float64, torch.device("cpu"))["words"].tolist()
+    assert [tuple(w) for w in words[:6]] == [(1, 0), (1, 1), (1, 2), (2, 1), (2, 2), (2, 5)]
+    assert len(words) == log_ode.logsignature_channels(3, 3) == oracle_logsig.logsignature_channels(3, 3) == 14
