@@ -216,6 +216,28 @@ def logsig_cases(ref):
     return cases
 
 
+def logsig_rebuilt_t_cases(ref):
+    """The scenario of the round-2 plan-cache bug: ONE series shape, MANY explicit time grids of the same length and dtype
+    with different values (a `t` rebuilt per batch), each through the reference's log_ode.py:15-133.  A plan cached for
+    one grid and served for another gives wrong windows; every output here belongs to its own grid."""
+    from oracle import logsig
+    gen = torch.Generator().manual_seed(20260925)
+    cases = []
+    for dtype in (torch.float32, torch.float64):
+        L, C, depth = 33, 3, 3
+        x = torch.randn(3, L, C, generator=gen, dtype=dtype).cumsum(-2) * 0.3
+        grids = [torch.linspace(0, 16.0 * k, L, dtype=dtype) for k in (1, 2, 3, 5)]
+        grids += [_irregular_t(L, dtype, gen) for _ in range(4)]
+        for t in grids:
+            for window in (4.0, 6.5):
+                v1 = ref.logsig_windows(x, depth, window, t)
+                v0, times0 = ref.logsignature_windows(x, depth, window, t)
+                o1 = logsig.logsig_windows(x, depth, window, t, version=1)
+                assert torch.equal(v1, o1), "oracle windowing != reference"
+                cases.append(dict(x=x, t=t, depth=depth, window_length=window, out=v1, out_v0=v0, times_v0=times0))
+    return cases
+
+
 class LinearField(torch.nn.Module):
     """The README vector field (reference README.md:42-49): Linear(H, H*C) viewed (..., H, C)."""
 
@@ -388,9 +410,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--run-reference-tests", action="store_true")
     ap.add_argument("--only-gradients", action="store_true", help="write gradients.pt and leave the other fixtures alone")
+    ap.add_argument("--only-rebuilt-t", action="store_true", help="write logsig_rebuilt_t.pt and leave the others alone")
     opts = ap.parse_args()
     ref = import_reference()
     os.makedirs(OUT, exist_ok=True)
+    rebuilt = logsig_rebuilt_t_cases(ref)
+    torch.save(rebuilt, os.path.join(OUT, "logsig_rebuilt_t.pt"))
+    print("logsig_rebuilt_t.pt: %d cases (same shape, different time grids; reference windowing over oracle.logsig)"
+          % len(rebuilt))
+    if opts.only_rebuilt_t:
+        return
     grad_cases = gradient_cases(ref)
     torch.save(grad_cases, os.path.join(OUT, "gradients.pt"))
     print("gradients.pt: %d cases (autograd through the reference's own code)" % len(grad_cases))

@@ -704,3 +704,33 @@ def test_log_ode_window_bookkeeping_equals_the_reference_loop():
     words = log_ode._plan(regular, True, 4.0, 17, 3, 3, 1, torch.float64, torch.device("cpu"))["words"].tolist()
     assert [tuple(w) for w in words[:6]] == [(1, 0), (1, 1), (1, 2), (2, 1), (2, 2), (2, 5)]
     assert len(words) == log_ode.logsignature_channels(3, 3) == oracle_logsig.logsignature_channels(3, 3) == 14
+
+
+def test_log_ode_plan_cache_is_keyed_on_the_values_of_t_not_on_its_address():
+    """Round-2 bug: the window-plan cache was keyed on (t.data_ptr(), t._version).  Allocators recycle addresses, so a
+    DIFFERENT t of the same length at a recycled block (version 0) was served the previous plan -- silently wrong
+    windows.  Here many same-length grids with different values pass through freshly recycled allocations WITHOUT
+    clearing the cache; every plan must equal the reference loop's (oracle.logsig.window_plan) for ITS OWN times, and the
+    returned window times must not alias the cached tensor."""
+    from oracle import logsig as oracle_logsig
+    from torchcde_amd import log_ode
+    log_ode._plans.clear()
+    seen_ptrs = set()
+    recycled = 0
+    for rep in range(200):
+        span = 16.0 * (1 + rep % 7)
+        t = torch.linspace(0, span, 17)                  # same length, same dtype, version 0 -- different values
+        recycled += t.data_ptr() in seen_ptrs
+        seen_ptrs.add(t.data_ptr())
+        new_t, rows, _ = oracle_logsig.window_plan(t, 4.0)
+        plan = log_ode._plan(t, True, 4.0, 17, 3, 2, 0, t.dtype, torch.device("cpu"))
+        assert plan["rows"].tolist() == rows, (rep, span)
+        assert torch.equal(plan["new_t"], new_t)
+        del t, plan
+    assert recycled > 0, "the allocator never recycled a block: the regression scenario did not occur"
+    # in-place edit of a time tensor: new values, same address -- must give the new plan
+    t = torch.linspace(0, 16, 17)
+    first = log_ode._plan(t, True, 4.0, 17, 3, 2, 1, t.dtype, torch.device("cpu"))["rows"].tolist()
+    t.mul_(2.0)
+    second = log_ode._plan(t, True, 4.0, 17, 3, 2, 1, t.dtype, torch.device("cpu"))["rows"].tolist()
+    assert first == [0, 4, 8, 12, 16] and second == oracle_logsig.window_plan(t, 4.0)[1] != first

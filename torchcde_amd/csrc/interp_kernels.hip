@@ -835,11 +835,13 @@ __global__ __launch_bounds__(256) void logsig_suffix_kernel(const T* __restrict_
 // with  S <- S (x) exp(-d_r)  (the reversibility signatory's own backward relies on), then
 //   new_k = S_k + e_k(d) + sum_j S_j (x) e_(k-j)(d),  e_m(d) = d^(x m) / m!
 // is transposed level by level, LOWEST level first (level k reads gS_k of the new signature, which the lower levels'
-// updates have not touched, and adds to the lower gS).  Rows interior to a window get both of their increments'
-// contributions from this lane (one atomic add per row and channel); a boundary row gets one add from each of its two
-// windows, so the sum does not depend on the order.
+// updates have not touched, and adds to the lower gS).  No atomics, fixed summation order: rows interior to a window get
+// both of their increments' contributions from this lane (one plain store); of a boundary row's two contributions the
+// one from the window BELOW it (that window's last increment) is parked in the first C slots of the window's own `gsum`
+// row -- dead once the lane has read it -- and the one from the window above it is added in place by that window's lane,
+// the row's only writer in this pass; pass 3 then adds the parked values window by window.
 template <typename T, int MAXC, int MAXD>
-__global__ __launch_bounds__(64) void logsig_windows_backward_kernel(const T* __restrict__ gsum, const T* __restrict__ x,
+__global__ __launch_bounds__(64) void logsig_windows_backward_kernel(T* gsum, const T* __restrict__ x,
                                                                      const int64_t* __restrict__ rows,
                                                                      const T* __restrict__ scale,
                                                                      const int32_t* __restrict__ words,
@@ -850,7 +852,7 @@ __global__ __launch_bounds__(64) void logsig_windows_backward_kernel(const T* __
   const int64_t b = id / n_windows, win = id - b * n_windows;
   const T* src = x + b * L * C;
   T* gx = grad_x + b * L * C;
-  const T* gw = gsum + (b * (n_windows + 1) + win + 1) * n_words;
+  T* gw = gsum + (b * (n_windows + 1) + win + 1) * n_words;
   T S1[MAXC], S2[MAXD >= 3 ? IPow<MAXC, 2>::value : 1], S3[MAXD >= 4 ? IPow<MAXC, 3>::value : 1];
   T g1[MAXC], g2[MAXD >= 2 ? IPow<MAXC, 2>::value : 1], g3[MAXD >= 3 ? IPow<MAXC, 3>::value : 1],
       g4[MAXD >= 4 ? IPow<MAXC, 4>::value : 1];
@@ -990,9 +992,26 @@ __global__ __launch_bounds__(64) void logsig_windows_backward_kernel(const T* __
               g3[(i * C + j) * C + k] += G * d[l];
             }
     // d = x_{r+1} - x_r
-    for (int i = 0; i < C; ++i) { atomicAdd(gx + (r + 1) * C + i, gd[i] + carry[i]); carry[i] = -gd[i]; }
+    if (r == r_hi - 1) for (int i = 0; i < C; ++i) { gw[i] = gd[i]; carry[i] = -gd[i]; }       // boundary row above: parked
+    else for (int i = 0; i < C; ++i) { gx[(r + 1) * C + i] = gd[i] + carry[i]; carry[i] = -gd[i]; }
   }
-  if (r_hi > r_lo) for (int i = 0; i < C; ++i) atomicAdd(gx + r_lo * C + i, carry[i]);
+  if (r_hi > r_lo) for (int i = 0; i < C; ++i) gx[r_lo * C + i] += carry[i];
+  else for (int i = 0; i < C; ++i) gw[i] = (T)0;           // empty window: nothing parked
+}
+
+// pass 3: the parked boundary contributions, one lane per (series, channel), windows in order (several empty windows may
+// share a row)
+template <typename T>
+__global__ __launch_bounds__(256) void logsig_boundary_kernel(const T* __restrict__ gsum, const int64_t* __restrict__ rows,
+                                                              T* __restrict__ grad_x, int64_t B, int64_t L, int C,
+                                                              int64_t n_windows, int n_words) {
+  const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= B * C) return;
+  const int64_t b = id / C;
+  const int i = (int)(id - b * C);
+  T* gx = grad_x + b * L * C + i;
+  const T* parked = gsum + b * (n_windows + 1) * n_words + i;
+  for (int64_t win = 0; win < n_windows; ++win) gx[rows[win + 1] * C] += parked[(win + 1) * n_words];
 }
 
 // ------------------------------------------------------------------------------------------ K1b
@@ -1325,8 +1344,12 @@ extern "C" int cde_logsig_windows_backward(const void* grad_out, const void* x, 
   if (hipMemsetAsync(grad_x, 0, (size_t)(B * L * C) * (dtype == CDE_F64 ? 8 : 4), s) != hipSuccess) return CDE_ERR_LAUNCH;
   const unsigned grid = (unsigned)((B * n_windows + 63) / 64), grid2 = (unsigned)((B * n_words + 255) / 256);
 #define CDE_LSB(T, MAXC, MAXD)                                                                                         \
-  cde::logsig_windows_backward_kernel<T, MAXC, MAXD><<<grid, 64, 0, s>>>((const T*)workspace, (const T*)x, rows,       \
-      (const T*)scale, words, (T*)grad_x, B, L, (int)C, depth, n_windows, n_words)
+  do {                                                                                                                 \
+    cde::logsig_windows_backward_kernel<T, MAXC, MAXD><<<grid, 64, 0, s>>>((T*)workspace, (const T*)x, rows,           \
+        (const T*)scale, words, (T*)grad_x, B, L, (int)C, depth, n_windows, n_words);                                  \
+    cde::logsig_boundary_kernel<T><<<(unsigned)((B * C + 255) / 256), 256, 0, s>>>((const T*)workspace, rows,          \
+        (T*)grad_x, B, L, (int)C, n_windows, n_words);                                                                 \
+  } while (0)
   if (dtype == CDE_F32) {
     cde::logsig_suffix_kernel<float><<<grid2, 256, 0, s>>>((const float*)grad_out, (float*)workspace, (float*)grad_x, B, L, (int)C, n_windows, n_words);
     if (n_windows > 0) { if (env == 0) CDE_LSB(float, 8, 3); else if (env == 1) CDE_LSB(float, 5, 4); else CDE_LSB(float, 32, 2); }

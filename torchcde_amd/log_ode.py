@@ -39,11 +39,14 @@ def _plan(t, given, window_length, L, C_in, depth, version, dtype, device):
     to be merged in, the per-window scale and the Lyndon-word table -- as device tensors.  The reference's loop
     (`value <= t[pointer]` or `value.allclose(t[pointer])`, pointer never moving back) is evaluated for all window ends
     at once with the same elementwise arithmetic (`torch.isclose` is allclose's formula)."""
-    key = ((t.data_ptr(), t._version) if given else None, float(window_length), L, C_in, depth, version, dtype, str(device))
+    th = t.detach().cpu()
+    # keyed on the VALUES of the times (as cdeint._grids_for does), never on an address: allocators recycle blocks, and a
+    # different `t` of the same length at a recycled address must not be handed the previous plan
+    key = ((th.numpy().tobytes(), str(th.dtype)) if given else None, float(window_length), L, C_in, depth, version, dtype,
+           str(device))
     plan = _plans.get(key)
     if plan is not None:
         return plan
-    th = t.detach().cpu()
     timespan = th[-1] - th[0]
     pieces = int((timespan / window_length).ceil().item())
     new_t = torch.linspace(th[0].item(), (th[0] + pieces * window_length).item(), pieces + 1, dtype=th.dtype)
@@ -131,7 +134,7 @@ def _windows(x, depth, window_length, t, version):
     x = linear_interpolation_coeffs(x, t_dev)                  # fills the NaNs (the new rows and any in the data)
     out = _LogsigWindows.apply(x, plan["rows"], plan["scale"], plan["words"], depth, plan["n_windows"], plan["n_words"])
     if version == 0:
-        return out, plan["new_t"]
+        return out, plan["new_t"].clone()                    # the cached tensor itself is never handed out
     return out
 
 
