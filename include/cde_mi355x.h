@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CDE_ABI_VERSION 1
+#define CDE_ABI_VERSION 2
 
 enum { CDE_F32 = 0, CDE_F64 = 1 };
 
@@ -311,6 +311,10 @@ int cde_rk4_adjoint_mlp_sweep(const void* coeffs, const void* knots, int64_t n_i
  *            odeint(..., t[i-1:i+1].flip(0)).
  *   seg_off  (n_out) DEVICE array of int64: segment p is sgrid[seg_off[p] .. seg_off[p+1])
  *            (so seg_off[0] == 0 and seg_off[n_out-1] == n_sgrid)
+ *   seg_off_host  the same n_out offsets in HOST memory (the caller built them on the host anyway).  Read only by the
+ *            wide-shape path below, whose chunk loop runs on the host; may be NULL for every other shape
+ *            (CDE_ERR_NULL if the wide path needs it).  ABI version 2: replaces the device-to-host copy + stream
+ *            synchronisation version 1 performed inside this call.
  *   grad_z0 (B, H), grad_W (H*C, H), grad_b (H*C)   out
  *   workspace / workspace_bytes : device scratch of at least cde_rk4_adjoint_workspace_bytes()
  *            bytes: the reverse-sweep stage table plus per-workgroup partial parameter
@@ -318,15 +322,16 @@ int cde_rk4_adjoint_mlp_sweep(const void* coeffs, const void* knots, int64_t n_i
  * Wide shapes (H <= 64, C <= 8 or H <= 32, C <= 16 beyond the 32 x 8 tiles; csrc/rk4_wide.hip): the sweep keeps no
  * parameter gradients in registers; it streams 2.3 KB of per-stage factors per series to the workspace (chunks of RK
  * steps, at most 4 GB at a time; CDE_WIDE_SCRATCH_BYTES in the environment overrides the bound) and a split-K MFMA
- * reduction adds each chunk up.  That chunk loop runs on the host, so this call copies `seg_off` back and
- * synchronises the stream once before it queues its launches.
+ * reduction adds each chunk up.  That chunk loop runs on the host and takes its segment bounds from `seg_off_host`.
+ * No entry point of this library synchronises a stream or copies device memory to the host: every call only queues
+ * work on `stream` and can be captured into a hipGraph (tests: test_solver_calls_are_graph_capturable).
  * ------------------------------------------------------------------------------------------- */
 size_t cde_rk4_adjoint_workspace_bytes(int64_t B, int64_t C, int64_t H, int64_t n_sgrid, int dtype, int variant);
 int cde_rk4_adjoint_linear(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
                            const void* bias, int act, const void* z_saved, const void* grad_out, const void* sgrid,
-                           int64_t n_sgrid, const int64_t* seg_off, int64_t n_out, void* grad_z0, void* grad_W,
-                           void* grad_b, int64_t B, int64_t C, int64_t H, int dtype, int time_dtype, int variant,
-                           void* workspace, size_t workspace_bytes, void* stream);
+                           int64_t n_sgrid, const int64_t* seg_off, const int64_t* seg_off_host, int64_t n_out,
+                           void* grad_z0, void* grad_W, void* grad_b, int64_t B, int64_t C, int64_t H, int dtype,
+                           int time_dtype, int variant, void* workspace, size_t workspace_bytes, void* stream);
 
 /* K3 with the gradient w.r.t. the control as well (adjoint_params containing the coefficient tensor, reference
  * solver.py:207-222 / README.md:251-270):

@@ -29,7 +29,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     raw = ctypes.CDLL(_lib.SO_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert lib.cde_abi_version() == 1
+    assert lib.cde_abi_version() == 2
     assert lib.cde_error_string(0) == b"ok"
     assert b"workspace" in lib.cde_error_string(-5)
 

@@ -127,7 +127,7 @@ _SIGNATURES = {
                                        _i64, _i64, _i, _i, _p, _sz, _p]),
     "cde_rk4_adjoint_linear_dcontrol": (_i, [_p, _p, _i64, _i, _p, _p, _i, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _p,
                                              _i64, _i64, _i64, _i, _i, _p, _sz, _p]),
-    "cde_rk4_adjoint_linear": (_i, [_p, _p, _i64, _i, _p, _p, _i, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _i64, _i64,
+    "cde_rk4_adjoint_linear": (_i, [_p, _p, _i64, _i, _p, _p, _i, _p, _p, _p, _i64, _p, _p, _i64, _p, _p, _p, _i64, _i64,
                                     _i64, _i, _i, _i, _p, _sz, _p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -155,7 +155,7 @@ def load():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.cde_abi_version() != 1:
+        if lib.cde_abi_version() != 2:
             raise RuntimeError("torchcde_amd: ABI version mismatch in %s" % SO_PATH)
         _lib = lib
     return _lib

@@ -113,6 +113,7 @@ class _Grids:
         self.sgrid = sgrid.to(device)
         self.seg_off = torch.tensor(offsets, dtype=torch.int64).to(device)
         self.seg_off_host = offsets
+        self.seg_off_c = (ctypes.c_int64 * len(offsets))(*offsets)      # host copy handed to the C ABI (wide shapes)
 
 
 def _grids_for(t_host, step_size, adjoint_step_size, device):
@@ -160,7 +161,8 @@ def _plan_time_gradients(plan, z_saved, grad_out, weight, bias, grad_x, t, want_
             vals[i] = (f * go[:, i]).sum()
             total = total + vals[i]
         vals[0] = per_interval.sum() - total
-        grad_t = torch.stack(vals).to(t.dtype) if plan.n_out > 1 else torch.zeros_like(t)
+        # on `t`'s own device: cdeint accepts a CPU `t` next to GPU data (as the reference does)
+        grad_t = torch.stack(vals).to(device=t.device, dtype=t.dtype) if plan.n_out > 1 else torch.zeros_like(t)
     if want_knots and plan.degree == _lib.PATH_CUBIC:
         grad_knots = torch.cat([-per_interval, per_interval.new_zeros(1)])
     elif want_knots:
@@ -261,7 +263,8 @@ class _Plan:
         else:
             _lib.check(lib.cde_rk4_adjoint_linear(
                 _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w), _lib.ptr(b),
-                self.act, _lib.ptr(zs), _lib.ptr(go), _lib.ptr(sgrid), n_sgrid, _lib.ptr(seg_off), self.n_out,
+                self.act, _lib.ptr(zs), _lib.ptr(go), _lib.ptr(sgrid), n_sgrid, _lib.ptr(seg_off),
+                ctypes.cast(self.grids.seg_off_c, ctypes.c_void_p), self.n_out,
                 _lib.ptr(grad_z0), _lib.ptr(grad_w), _lib.ptr(grad_b), self.B, self.C, self.H, dt,
                 _lib.dtype_enum(self.time_dtype), self.variant, _lib.ptr(workspace), workspace.numel(),
                 _lib.stream_ptr(self.device)), "cde_rk4_adjoint_linear")
@@ -459,6 +462,7 @@ last_dopri5_stats = {}     # {"n_accept", "n_reject", "launches"} of the most re
 last_dopri5_adjoint_stats = {}   # the same for the most recent fused adaptive backward (summed over the output intervals)
 record_dopri5_steps = False   # tests: also fetch the accepted (t0, t1, on_jump) steps into last_dopri5_stats["steps"]
 _DOPRI_CHUNK = 48          # attempt kernels queued between two looks at the done flag
+_WORKSPACE_HEAD = 1 << 20  # bytes at the start of an adaptive workspace that hold the controller blocks and partial sums
 
 
 class _Dopri5Plan:
@@ -567,6 +571,7 @@ class _Dopri5Plan:
             return a, grad_w, grad_b
         nbytes = lib.cde_dopri5_adjoint_workspace_bytes(B, C, H)
         workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        workspace[:_WORKSPACE_HEAD].zero_()     # controller blocks + partial sums: defined before the first launch reads them
         size = ctypes.sizeof(_lib.DopriStatus)
         a_out = torch.empty(B, H, dtype=torch.float32, device=dev)
         shared = self.shared
@@ -631,6 +636,7 @@ class _Dopri5Plan:
         dt = _lib.dtype_enum(self.dtype)
         nbytes = lib.cde_dopri5_workspace_bytes(self.B, self.C, self.H, dt)
         workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        workspace[:_WORKSPACE_HEAD].zero_()     # controller blocks + partial sums (a sharded run all-reduces them from launch 0)
         size = ctypes.sizeof(_lib.DopriStatus)
         launched = 0
         if self.hidden is not None:
@@ -930,6 +936,10 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         # Arbitrary vector fields / methods / differentiation modes: host-driven stepping with the native control
         # derivative and contraction kernels under every evaluation (torchcde_amd/stepwise.py).
         from . import stepwise
+        from .distributed import step_control
+        if step_control() is not None and (method == "dopri5" or kwargs.get("adjoint_method") == "dopri5"):
+            warnings.warn("torchcde_amd: shared_step_control() is active but this adaptive solve runs step-wise, which "
+                          "does not share its step controller across ranks: every rank takes its own step sequence.")
         kw = stepwise_kwargs
         return stepwise.solve(X, func, z0, t, adjoint, method, options, kw["rtol"], kw["atol"],
                               kw.get("adjoint_method"), kw.get("adjoint_options"), kw.get("adjoint_rtol"),
@@ -951,6 +961,11 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
             raise NotImplementedError("torchcde_amd: unsupported cdeint keyword arguments {}".format(sorted(kwargs)))
         plan = _Dopri5Plan(X, field, batch, H, C, t, rtol, atol, options, variant, adjoint_rtol, adjoint_atol, adj_opts)
         wants = (True, True) if given is None else (any(p is weight for p in given), any(p is bias for p in given))
+        if not dopri_adjoint:
+            # chosen because nothing is to be differentiated (`adjoint_params=()` with weights that still require grad,
+            # no_grad ...): run outside autograd -- a graph node here would reach K4a without its eligibility checks
+            with torch.no_grad():
+                return plan.run(z0, weight, bias).reshape(*batch, plan.n_out, H)
         return _FusedDopri5.apply(z0, weight, bias, plan, wants)
     step_size = _parse_fixed_options(options, "solver")
     adjoint_method = kwargs.pop("adjoint_method", None)

@@ -144,9 +144,9 @@ static int forward_typed(const void* coeffs, const void* knots, int64_t n_interv
 template <typename T, typename TT>
 static int adjoint_typed(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
                          const void* bias, int act, const void* z_saved, const void* grad_out, const void* sgrid,
-                         int64_t n_sgrid, const int64_t* seg_off, int64_t n_out, void* grad_z0, void* grad_W,
-                         void* grad_b, int64_t B, int64_t C, int64_t H, int dtype, int variant, void* workspace,
-                         size_t workspace_bytes, void* grad_coeffs, hipStream_t s) {
+                         int64_t n_sgrid, const int64_t* seg_off, const int64_t* seg_off_host, int64_t n_out,
+                         void* grad_z0, void* grad_W, void* grad_b, int64_t B, int64_t C, int64_t H, int dtype,
+                         int variant, void* workspace, size_t workspace_bytes, void* grad_coeffs, hipStream_t s) {
   int rc;
   const bool use_mfma = pick_mfma(variant, C, H, dtype, act, true, &rc);
   if (rc != CDE_OK) return rc;
@@ -177,7 +177,7 @@ static int adjoint_typed(const void* coeffs, const void* knots, int64_t n_interv
                                    grad_coeffs, s);
   if (use_wide)
     return launch_adjoint_wide<TT>(coeffs, knots, n_intervals, degree, W, bias, act, z_saved, grad_out, sgrid, n_sgrid,
-                                   seg_off, n_out, grad_z0, grad_W, grad_b, B, C, H, stage_index, stage_frac, partial, s);
+                                   seg_off_host, n_out, grad_z0, grad_W, grad_b, B, C, H, stage_index, stage_frac, partial, s);
   return launch_adjoint_generic<T, TT>(coeffs, knots, n_intervals, degree, W, bias, act, z_saved, grad_out, sgrid,
                                        seg_off, n_out, grad_z0, grad_W, grad_b, B, C, H, stage_index, stage_frac,
                                        partial, s);
@@ -271,9 +271,10 @@ extern "C" size_t cde_rk4_adjoint_workspace_bytes(int64_t B, int64_t C, int64_t 
 
 static int adjoint_linear_impl(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
                                const void* bias, int act, const void* z_saved, const void* grad_out, const void* sgrid,
-                               int64_t n_sgrid, const int64_t* seg_off, int64_t n_out, void* grad_z0, void* grad_W,
-                               void* grad_b, void* grad_coeffs, int64_t B, int64_t C, int64_t H, int dtype,
-                               int time_dtype, int variant, void* workspace, size_t workspace_bytes, void* stream) {
+                               int64_t n_sgrid, const int64_t* seg_off, const int64_t* seg_off_host, int64_t n_out,
+                               void* grad_z0, void* grad_W, void* grad_b, void* grad_coeffs, int64_t B, int64_t C,
+                               int64_t H, int dtype, int time_dtype, int variant, void* workspace,
+                               size_t workspace_bytes, void* stream) {
   if (B < 1 || C < 1 || H < 1 || n_intervals < 1 || n_out < 1 || n_sgrid < 0) return CDE_ERR_SHAPE;
   if (act != CDE_ACT_NONE && act != CDE_ACT_TANH) return CDE_ERR_UNSUPPORTED;
   if (!coeffs || !knots || !W || !bias || !z_saved || !grad_out || !grad_z0 || !grad_W || !grad_b || !workspace)
@@ -282,8 +283,8 @@ static int adjoint_linear_impl(const void* coeffs, const void* knots, int64_t n_
   hipStream_t s = (hipStream_t)stream;
 #define CDE_CALL(T, TT)                                                                                               \
   return cde::adjoint_typed<T, TT>(coeffs, knots, n_intervals, degree, W, bias, act, z_saved, grad_out, sgrid,        \
-                                   n_sgrid, seg_off, n_out, grad_z0, grad_W, grad_b, B, C, H, dtype, variant,         \
-                                   workspace, workspace_bytes, grad_coeffs, s)
+                                   n_sgrid, seg_off, seg_off_host, n_out, grad_z0, grad_W, grad_b, B, C, H, dtype,    \
+                                   variant, workspace, workspace_bytes, grad_coeffs, s)
   if (dtype == CDE_F32 && time_dtype == CDE_F32) CDE_CALL(float, float);
   if (dtype == CDE_F32 && time_dtype == CDE_F64) CDE_CALL(float, double);
   if (dtype == CDE_F64 && time_dtype == CDE_F64) CDE_CALL(double, double);
@@ -295,11 +296,11 @@ static int adjoint_linear_impl(const void* coeffs, const void* knots, int64_t n_
 extern "C" int cde_rk4_adjoint_linear(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
                                       const void* W, const void* bias, int act, const void* z_saved,
                                       const void* grad_out, const void* sgrid, int64_t n_sgrid, const int64_t* seg_off,
-                                      int64_t n_out, void* grad_z0, void* grad_W, void* grad_b, int64_t B, int64_t C,
-                                      int64_t H, int dtype, int time_dtype, int variant, void* workspace,
-                                      size_t workspace_bytes, void* stream) {
+                                      const int64_t* seg_off_host, int64_t n_out, void* grad_z0, void* grad_W,
+                                      void* grad_b, int64_t B, int64_t C, int64_t H, int dtype, int time_dtype,
+                                      int variant, void* workspace, size_t workspace_bytes, void* stream) {
   return adjoint_linear_impl(coeffs, knots, n_intervals, degree, W, bias, act, z_saved, grad_out, sgrid, n_sgrid, seg_off,
-                             n_out, grad_z0, grad_W, grad_b, nullptr, B, C, H, dtype, time_dtype, variant, workspace,
+                             seg_off_host, n_out, grad_z0, grad_W, grad_b, nullptr, B, C, H, dtype, time_dtype, variant, workspace,
                              workspace_bytes, stream);
 }
 
@@ -312,7 +313,7 @@ extern "C" int cde_rk4_adjoint_linear_dcontrol(const void* coeffs, const void* k
                                                void* stream) {
   if (!grad_coeffs) return CDE_ERR_NULL;
   return adjoint_linear_impl(coeffs, knots, n_intervals, degree, W, bias, act, z_saved, grad_out, sgrid, n_sgrid, seg_off,
-                             n_out, grad_z0, grad_W, grad_b, grad_coeffs, B, C, H, dtype, time_dtype, CDE_VARIANT_MFMA,
+                             nullptr, n_out, grad_z0, grad_W, grad_b, grad_coeffs, B, C, H, dtype, time_dtype, CDE_VARIANT_MFMA,
                              workspace, workspace_bytes, stream);
 }
 

@@ -508,18 +508,15 @@ size_t wide_adjoint_workspace_bytes(int64_t B, int64_t C, int64_t H, int64_t n_s
 template <typename TT>
 int launch_adjoint_wide(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
                         const void* bias, int act, const void* z_saved, const void* grad_out, const void* sgrid,
-                        int64_t n_sgrid, const int64_t* seg_off, int64_t n_out, void* grad_z0, void* grad_W,
+                        int64_t n_sgrid, const int64_t* seg_off_host, int64_t n_out, void* grad_z0, void* grad_W,
                         void* grad_b, int64_t B, int64_t C, int64_t H, const int64_t* stage_index,
                         const void* stage_frac, void* scratch, hipStream_t s) {
   const Dims dims{(int)H, (int)C};
   if (degree != CDE_PATH_CUBIC && degree != CDE_PATH_LINEAR) return CDE_ERR_UNSUPPORTED;
   if (act != CDE_ACT_NONE && act != CDE_ACT_TANH) return CDE_ERR_UNSUPPORTED;
-  // the chunk loop runs on the host: it needs the segment offsets (a device array for the other kernels) here
-  std::vector<int64_t> seg_off_vec((size_t)n_out);
-  int64_t* seg_off_host = seg_off_vec.data();
-  if (hipMemcpyAsync(seg_off_host, seg_off, (size_t)n_out * sizeof(int64_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
-      hipStreamSynchronize(s) != hipSuccess)
-    return CDE_ERR_LAUNCH;
+  // the chunk loop runs on the host and reads the segment offsets from the caller's HOST copy (`seg_off_host` of the C
+  // ABI): no device-to-host copy, no stream synchronisation -- the call only queues work and is graph-capturable
+  if (n_out > 1 && !seg_off_host) return CDE_ERR_NULL;
   const WideLayout L = wide_layout(B, C, H, n_sgrid - 1);
   unsigned char* base = (unsigned char*)scratch;
   float* y_state = (float*)(base + L.off_y);
