@@ -25,5 +25,17 @@ What is restated, and what pins it
   file restates the published algorithm (fixed-grid RK4 3/8-rule, dopri5,
   continuous adjoint) and is validated by mathematics instead -- order-4
   convergence to closed-form linear-CDE solutions, adjoint-vs-autograd
-  agreement and float64 gradcheck (``tests/test_oracle.py``).
+  agreement and float64 gradcheck (``tests/test_oracle.py``).  What CAN be pinned without the package is pinned
+  against scipy's independent Dormand-Prince implementation: the tableau rational for rational, and -- value for
+  value, 1e-13 -- the step, the derivative at its end, the embedded error estimate and the dense output over the
+  oracle's own accepted-step sequence (``test_dopri5_steps_and_dense_output_match_scipy_value_for_value``).
+  ``python oracle/pin_torchdiffeq.py`` closes the rest in one command wherever ``import torchdiffeq`` works: it runs
+  the reference's ``solver.py`` over the REAL package on the seeded problems of ``tests/golden/cdeint.pt`` and diffs
+  ``oracle.odeint`` against it (rk4: bitwise; dopri5: every stage time of every attempt, forward and adjoint, mixed
+  norm and seminorm, ``jump_t``), ``--write`` regenerates the fixture from the real package.  (Its plumbing is
+  exercised here by ``--self-test``, tests/test_oracle.py.)
+* ``oracle.logsig``  -- the third-party ``signatory`` (call sites ``torchcde/log_ode.py:53,57,59``), absent as well.
+  The windowing is pinned to the reference (``make_golden.py``); the logsignature arithmetic is pinned to an EXACT
+  ``fractions.Fraction`` computation in the free tensor algebra on integer paths, depth 1-4, whose signature is itself
+  checked by the shuffle identity (``test_logsignature_equals_an_exact_rational_tensor_algebra_reference``).
 """

@@ -29,7 +29,9 @@ class ControlledField(torch.nn.Module):
         return (F @ dX.unsqueeze(-1)).squeeze(-1)                   # (..., H)
 
 
-def cdeint(X, func, z0, t, adjoint=True, **kwargs):
+def cdeint(X, func, z0, t, adjoint=True, integrators=None, **kwargs):
+    """``integrators``: (odeint, odeint_adjoint) to use instead of oracle.odeint's -- oracle/pin_torchdiffeq.py passes the
+    REAL torchdiffeq functions here when that package is importable."""
     kwargs.setdefault("atol", 1e-6)
     kwargs.setdefault("rtol", 1e-4)
     if adjoint:
@@ -40,7 +42,8 @@ def cdeint(X, func, z0, t, adjoint=True, **kwargs):
     if not isinstance(z0, torch.Tensor):
         raise NotImplementedError("oracle: tuple state is outside the hot-path scope")
     field = ControlledField(X, func)
-    solve = _ode.odeint_adjoint if adjoint else _ode.odeint
+    plain, with_adjoint = (_ode.odeint, _ode.odeint_adjoint) if integrators is None else integrators
+    solve = with_adjoint if adjoint else plain
     out = solve(field, z0, t, **kwargs)                             # (T, ..., H)
     lead = range(1, out.dim() - 1)
     return out.permute(*lead, 0, -1)                                # (..., T, H)
