@@ -392,28 +392,47 @@ int cde_dopri5_advance(const void* coeffs, const void* knots, int64_t n_interval
  * interval [t_{i-1}, t_i] it passes the reversed-time bounds s0 = -t_i < s1 = -t_{i-1}, the jump times negated and
  * ascending, y_init = z(t_i) (B, H) as stored by the forward solve and a_init = dL/dz(t_i) accumulated so far, and
  * calls cde_dopri5_adjoint_advance with first_launch = 0, n, 2n, ... until the cde_dopri5_status at the head of the
- * workspace (index total_launches & 1) reports phase == 4; a_out (B, H) then holds dL/dz(t_{i-1}) before the
- * incoming gradient of that output time is added.  first_interval != 0 zeroes the running parameter gradients;
- * after the last interval cde_dopri5_adjoint_finish writes grad_W (H*C, H) and grad_b (H*C).
- * The accepted steps of the CURRENT interval are traced like K4's, at cde_dopri5_adjoint_trace_offset(...).
- * Two stated deviations from torchdiffeq (csrc/dopri5_adjoint.hip): the error norm is max(rms over y, rms over a)
- * (torchdiffeq's "seminorm": the parameter-gradient blocks are not part of it), and the last step of an interval is
- * clipped onto the interval end instead of overshooting and interpolating.
+ * workspace (block index total_launches & 1, the two blocks cde_dopri5_adjoint_status_stride() bytes apart) reports
+ * phase == 4; a_out (B, H) then holds dL/dz(t_{i-1}) before the incoming gradient of that output time is added.
+ * first_interval != 0 zeroes the running parameter gradients and vjp_t; after the last interval
+ * cde_dopri5_adjoint_finish writes grad_W (H*C, H) and grad_b (H*C).
+ * The accepted steps of the CURRENT interval are traced like K4's, at cde_dopri5_adjoint_trace_offset(...); EVERY decided
+ * attempt (at most 16384), rejected ones included, at cde_dopri5_adjoint_attempt_trace_offset(...) as 5 doubles
+ * (t0, t1, clipped onto a jump, accepted, error ratio) -- the tests replay them through the oracle.
+ * This IS torchdiffeq's algorithm (ABI version 2; version 1 used the state-only norm and clipped the last step):
+ *   norm_kind 0  the default MIXED adjoint norm max(|e_t|, rms e_y, rms e_a, rms e_W, rms e_b) over the augmented state
+ *                (vjp_t, y, a, dL/dW, dL/db) -- every launch of the attempt kernel is followed by a small reduction
+ *                kernel over the workgroups' gradient images, inside this call;
+ *   norm_kind 1  adjoint_options=dict(norm="seminorm"): the same without the parameter blocks;
+ *   the last step of an interval passes the interval end and the dense interpolant is evaluated there.
  * ------------------------------------------------------------------------------------------- */
 size_t cde_dopri5_adjoint_workspace_bytes(int64_t B, int64_t C, int64_t H);
 size_t cde_dopri5_adjoint_trace_offset(int64_t B, int64_t C, int64_t H);
+size_t cde_dopri5_adjoint_attempt_trace_offset(int64_t B, int64_t C, int64_t H);
+size_t cde_dopri5_adjoint_status_stride(void);
 int cde_dopri5_adjoint_advance(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
                                const void* bias, int act, const void* y_init, const void* a_init, double s0, double s1,
                                const double* jump_s, int64_t n_jump, double rtol, double atol, double safety,
-                               double ifactor, double dfactor, void* a_out, int64_t B, int64_t C, int64_t H, int dtype,
-                               int first_interval, void* workspace, size_t workspace_bytes, int64_t first_launch,
-                               int64_t n_launches, const double* reduced_sums, int64_t B_global, void* stream);
-/* sharded batches, one controller: reduced_sums (4 doubles, all-reduced output of cde_dopri5_adjoint_pending_sums) and
- * the global batch size, n_launches == 1 per all-reduce; NULL / 0 for an unsharded solve. */
-int cde_dopri5_adjoint_pending_sums(const void* workspace, size_t workspace_bytes, int64_t B, int64_t C, int64_t H,
+                               double ifactor, double dfactor, int norm_kind, void* a_out, int64_t B, int64_t C,
+                               int64_t H, int dtype, int first_interval, void* workspace, size_t workspace_bytes,
+                               int64_t first_launch, int64_t n_launches, const double* reduced_sums, int64_t B_global,
+                               void* stream);
+/* Sharded batches, ONE controller (B_global > 0, n_launches == 1).  Per attempted step every shard runs
+ *   cde_dopri5_adjoint_advance(first_launch = n, 1 launch, reduced_sums = the buffer below (NULL for n == 0), B_global)
+ *   cde_dopri5_adjoint_pending_sums(total_launches = n + 1) -> cde_dopri5_adjoint_reduced_count() doubles on the device:
+ *       8 state sums, then the A / E / D gradient images of the attempt
+ *   an all-reduce (sum) of that buffer over the shards
+ *   cde_dopri5_adjoint_apply_reduced(total_launches = n + 1, the reduced buffer): commit + parameter norms
+ * and all shards take the unsharded batch's decisions.  cde_dopri5_adjoint_finish(sharded = 1) returns THIS shard's
+ * share of dL/dW, dL/db (the caller all-reduces gradients as for any data-parallel step). */
+size_t cde_dopri5_adjoint_reduced_count(void);
+int cde_dopri5_adjoint_pending_sums(void* workspace, size_t workspace_bytes, int64_t B, int64_t C, int64_t H,
                                     int64_t total_launches, double* sums, void* stream);
+int cde_dopri5_adjoint_apply_reduced(void* workspace, size_t workspace_bytes, int64_t B, int64_t C, int64_t H,
+                                     double rtol, double atol, int64_t total_launches, const double* reduced,
+                                     void* stream);
 int cde_dopri5_adjoint_finish(const void* workspace, size_t workspace_bytes, void* grad_W, void* grad_b, int64_t B,
-                              int64_t C, int64_t H, void* stream);
+                              int64_t C, int64_t H, int sharded, void* stream);
 
 /* Sharded batches under ONE step controller -- torchdiffeq's semantics for the whole batch when the batch lives on
  * several GPUs.  Per attempted step every shard (1) calls cde_dopri5_pending_sums(total_launches so far) -> 2 doubles on

@@ -184,7 +184,7 @@ class _Dopri5:
 
     def __init__(self, f, y0, rtol, atol, norm, first_step=None, step_t=None, jump_t=None, safety=0.9, ifactor=10.0,
                  dfactor=0.2, max_num_steps=2 ** 31 - 1, min_step=0, max_step=float("inf"), dtype=torch.float64,
-                 replay_steps=None):
+                 replay_steps=None, replay_attempts=None):
         tdtype = torch.promote_types(dtype, y0.dtype)
         dev = y0.device
         self.f, self.y0, self.norm, self.tdtype = f, y0, norm, tdtype
@@ -209,6 +209,15 @@ class _Dopri5:
         # controller is bypassed and exactly these steps are taken -- used to check a SAMPLE of a large batch against
         # the step sequence the batch-global controller chose for the WHOLE batch (tests/test_gpu_parity.py, config 4).
         self.replay_steps = None if replay_steps is None else torch.as_tensor(replay_steps, dtype=tdtype).reshape(-1, 3)
+        # TEST INFRASTRUCTURE as well: EVERY attempt another solver made -- rows (t0, t1, on_jump, accepted, ...), rejected
+        # ones included -- is re-made from the state THIS solver has at t0; the error ratio this solver computes for it is
+        # recorded in `self.ratios` (and the initial step it would have chosen in `self.first_dt`), the attempt's own
+        # accept flag decides whether the state moves.  A list is consumed one entry per solver (the adjoint pass creates
+        # one solver per output interval, last interval first).
+        if isinstance(replay_attempts, list):
+            replay_attempts = replay_attempts.pop(0)
+        self.replay_attempts = None if replay_attempts is None else torch.as_tensor(replay_attempts, dtype=tdtype)
+        self.ratios, self.first_dt = [], None
 
     # -- initial step (Hairer), order argument = self.order - 1
     def _initial_step(self, t0, f0):
@@ -305,7 +314,38 @@ class _Dopri5:
         assert i == len(t), "replayed steps end before the last output time"
         return out
 
+    def _integrate_attempts(self, t):
+        y0 = self.y0
+        out = torch.empty(len(t), *y0.shape, dtype=y0.dtype, device=y0.device)
+        out[0] = y0
+        t = t.to(self.tdtype)
+        y, f = y0, self.f(t[0], y0)
+        self.first_dt = self._initial_step(t[0], f)
+        i = 1
+        for row in self.replay_attempts:
+            t0, t1, on_jump, accepted = row[0], row[1], row[2], row[3]
+            dt = t1 - t0
+            y1, f1, y1_err, k = self._rk_step(y, f, t0, dt, t1)
+            tol = self.atol + self.rtol * torch.max(y.abs(), y1.abs())
+            self.ratios.append(float(self.norm(y1_err / tol).abs()))
+            if accepted != 0:
+                dense = self._fit_dense(y, y1, k, dt)
+                if on_jump != 0:
+                    f1 = self.f(t1, y1, perturb=_NEXT)
+                self.n_accept += 1
+                self.accepted.append((t0.item(), t1.item(), float(on_jump)))
+                while i < len(t) and not (t[i] > t1):
+                    out[i] = self._eval_dense(dense, t0, t1, t[i])
+                    i += 1
+                y, f = y1, f1
+            else:
+                self.n_reject += 1
+        assert i == len(t), "replayed attempts end before the last output time"
+        return out
+
     def integrate(self, t):
+        if self.replay_attempts is not None:
+            return self._integrate_attempts(t)
         if self.replay_steps is not None:
             return self._integrate_replay(t)
         y0 = self.y0

@@ -112,13 +112,17 @@ _SIGNATURES = {
                                     _p, _i64, _i64, _i64, _i, _p, _sz, _i64, _i64, _p]),
     "cde_dopri5_adjoint_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "cde_dopri5_adjoint_trace_offset": (_sz, [_i64, _i64, _i64]),
-    "cde_dopri5_adjoint_advance": (_i, [_p, _p, _i64, _i, _p, _p, _i, _p, _p, _d, _d, _p, _i64, _d, _d, _d, _d, _d, _p,
+    "cde_dopri5_adjoint_status_stride": (_sz, []),
+    "cde_dopri5_adjoint_attempt_trace_offset": (_sz, [_i64, _i64, _i64]),
+    "cde_dopri5_adjoint_reduced_count": (_sz, []),
+    "cde_dopri5_adjoint_advance": (_i, [_p, _p, _i64, _i, _p, _p, _i, _p, _p, _d, _d, _p, _i64, _d, _d, _d, _d, _d, _i, _p,
                                         _i64, _i64, _i64, _i, _i, _p, _sz, _i64, _i64, _p, _i64, _p]),
     "cde_dopri5_adjoint_pending_sums": (_i, [_p, _sz, _i64, _i64, _i64, _i64, _p, _p]),
+    "cde_dopri5_adjoint_apply_reduced": (_i, [_p, _sz, _i64, _i64, _i64, _d, _d, _i64, _p, _p]),
     "cde_dopri5_pending_sums": (_i, [_p, _sz, _i64, _i64, _i64, _i, _i, _i, _i64, _p, _p]),
     "cde_dopri5_advance_sharded": (_i, [_p, _p, _i64, _i, _p, _p, _i, _p, _p, _i64, _p, _i64, _d, _d, _d, _d, _d, _p, _i64,
                                         _i64, _i64, _i, _i, _p, _sz, _i64, _p, _i64, _p]),
-    "cde_dopri5_adjoint_finish": (_i, [_p, _sz, _p, _p, _i64, _i64, _i64, _p]),
+    "cde_dopri5_adjoint_finish": (_i, [_p, _sz, _p, _p, _i64, _i64, _i64, _i, _p]),
     "cde_mlp_grad_reduce_workspace_bytes": (_sz, []),
     "cde_mlp_grad_reduce": (_i, [_p, _p, _i64, _i, _p, _p, _sz, _p]),
     "cde_rk4_adjoint_mlp_workspace_bytes": (_sz, [_i64]),

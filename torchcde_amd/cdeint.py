@@ -505,11 +505,12 @@ class _Dopri5Plan:
             self.jump_s = (-jt).flip(0).contiguous().to(self.device)      # the backward solve runs in s = -t
         self.n_jump_s = self.n_jump
         self.adj_safety, self.adj_ifactor, self.adj_dfactor = self.safety, self.ifactor, self.dfactor
+        self.adj_norm_kind = 0      # torchdiffeq's default adjoint norm: mixed over (vjp_t, y, a, parameter gradients)
         if adjoint_options is not None:
             # torchdiffeq: explicit adjoint_options REPLACE the forward options for the backward solve (no jump_t unless
-            # it is repeated there); the only norm accepted here is "seminorm", which is K4a's norm
+            # it is repeated there); norm: absent (the default mixed norm) or "seminorm" (without the parameter blocks)
             adj = dict(adjoint_options)
-            adj.pop("norm", None)
+            self.adj_norm_kind = 1 if adj.pop("norm", None) == "seminorm" else 0
             jump_b = adj.pop("jump_t", None)
             self.adj_safety = float(adj.pop("safety", 0.9))
             self.adj_ifactor = float(adj.pop("ifactor", 10.0))
@@ -556,7 +557,8 @@ class _Dopri5Plan:
         return out
 
     def run_adjoint(self, z_saved, grad_out, weight, bias):
-        """K4a: torchdiffeq's odeint_adjoint backward for the adaptive solve, one attempt kernel per attempted step
+        """K4a: torchdiffeq's odeint_adjoint backward for the adaptive solve -- default mixed norm (or "seminorm"), dense
+        output at the interval ends -- one attempt kernel + one reduction kernel per attempted step
         (csrc/dopri5_adjoint.hip), output intervals from the last to the first."""
         lib = _lib.load()
         B, H, C, dev = self.B, self.H, self.C, self.device
@@ -573,11 +575,15 @@ class _Dopri5Plan:
         workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         workspace[:_WORKSPACE_HEAD].zero_()     # controller blocks + partial sums: defined before the first launch reads them
         size = ctypes.sizeof(_lib.DopriStatus)
+        stride = lib.cde_dopri5_adjoint_status_stride()
         a_out = torch.empty(B, H, dtype=torch.float32, device=dev)
         shared = self.shared
-        sums = torch.zeros(4, dtype=torch.float64, device=dev)
+        reduced = None
+        if shared is not None:
+            reduced = torch.zeros(lib.cde_dopri5_adjoint_reduced_count(), dtype=torch.float64, device=dev)
+        stream = _lib.stream_ptr(dev)
         stats = dict(n_accept=0, n_reject=0, launches=0)
-        steps = []
+        steps, attempts = [], []
         for i in range(self.n_out - 1, 0, -1):
             y = z_saved[:, i].contiguous()
             s0, s1 = -float(self.t_host[i]), -float(self.t_host[i - 1])
@@ -587,22 +593,28 @@ class _Dopri5Plan:
                     _lib.check(lib.cde_dopri5_adjoint_advance(
                         _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w),
                         _lib.ptr(b), self.act, _lib.ptr(y), _lib.ptr(a), s0, s1, _lib.ptr(self.jump_s), self.n_jump_s,
-                        self.adjoint_rtol, self.adjoint_atol, self.adj_safety, self.adj_ifactor, self.adj_dfactor, _lib.ptr(a_out), B,
-                        C, H, _lib.dtype_enum(torch.float32), int(i == self.n_out - 1), _lib.ptr(workspace),
-                        workspace.numel(), first, count, sums_ptr, global_batch, _lib.stream_ptr(dev)),
-                        "cde_dopri5_adjoint_advance")
+                        self.adjoint_rtol, self.adjoint_atol, self.adj_safety, self.adj_ifactor, self.adj_dfactor,
+                        self.adj_norm_kind, _lib.ptr(a_out), B, C, H, _lib.dtype_enum(torch.float32),
+                        int(i == self.n_out - 1), _lib.ptr(workspace), workspace.numel(), first, count, sums_ptr,
+                        global_batch, stream), "cde_dopri5_adjoint_advance")
                 if shared is None:
                     advance(launched, _DOPRI_CHUNK, None, 0)
                     launched += _DOPRI_CHUNK
                 else:
+                    # one controller for all shards: per attempted step the state sums AND the gradient images of the
+                    # attempt are all-reduced, then every shard commits / measures the parameter blocks on the same numbers
                     for _ in range(_DOPRI_CHUNK):
-                        _lib.check(lib.cde_dopri5_adjoint_pending_sums(_lib.ptr(workspace), workspace.numel(), B, C, H,
-                                                                       launched, _lib.ptr(sums), _lib.stream_ptr(dev)),
-                                   "cde_dopri5_adjoint_pending_sums")
-                        shared[0](sums)
-                        advance(launched, 1, _lib.ptr(sums), shared[1])
+                        advance(launched, 1, _lib.ptr(reduced) if launched else None, shared[1])
                         launched += 1
-                raw = workspace[(launched & 1) * size:(launched & 1) * size + size].cpu().numpy().tobytes()
+                        _lib.check(lib.cde_dopri5_adjoint_pending_sums(_lib.ptr(workspace), workspace.numel(), B, C, H,
+                                                                       launched, _lib.ptr(reduced), stream),
+                                   "cde_dopri5_adjoint_pending_sums")
+                        shared[0](reduced)
+                        _lib.check(lib.cde_dopri5_adjoint_apply_reduced(
+                            _lib.ptr(workspace), workspace.numel(), B, C, H, self.adjoint_rtol, self.adjoint_atol, launched,
+                            _lib.ptr(reduced), stream), "cde_dopri5_adjoint_apply_reduced")
+                at = (launched & 1) * stride
+                raw = workspace[at:at + size].cpu().numpy().tobytes()
                 status = _lib.DopriStatus.from_buffer_copy(raw)
                 if status.phase == 4:
                     break
@@ -616,13 +628,17 @@ class _Dopri5Plan:
                 off = lib.cde_dopri5_adjoint_trace_offset(B, C, H)
                 n = min(status.n_accept, 4096)
                 steps.append(workspace[off:off + 24 * n].view(torch.float64).view(n, 3).cpu())
+                off = lib.cde_dopri5_adjoint_attempt_trace_offset(B, C, H)
+                n = min(status.n_accept + status.n_reject, 16384)
+                attempts.append(workspace[off:off + 40 * n].view(torch.float64).view(n, 5).cpu())
             a = a_out + grad_out[:, i - 1]
         _lib.check(lib.cde_dopri5_adjoint_finish(_lib.ptr(workspace), workspace.numel(), _lib.ptr(grad_w), _lib.ptr(grad_b),
-                                                 B, C, H, _lib.stream_ptr(dev)), "cde_dopri5_adjoint_finish")
+                                                 B, C, H, int(shared is not None), stream), "cde_dopri5_adjoint_finish")
         last_dopri5_adjoint_stats.clear()
         last_dopri5_adjoint_stats.update(stats)
         if record_dopri5_steps:
             last_dopri5_adjoint_stats["steps"] = steps           # one (n, 3) tensor per output interval, last first
+            last_dopri5_adjoint_stats["attempts"] = attempts     # (t0, t1, on_jump, accepted, ratio) of EVERY attempt
         return a, grad_w, grad_b
 
     def run(self, z0, weight, bias):
@@ -881,10 +897,10 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
     mfma_shape = z0.dtype == torch.float32 and H <= 32 and C <= 8 and variant != _lib.VARIANT_GENERIC
     # the adaptive backward (K4a): affine family on the MFMA tiles, adjoint solver = forward solver with the same
     # options (the reference's default: solver.py:199-203 only copies the tolerances), parameters of the field only
-    # adjoint_options: none (the backward inherits the forward options and torchdiffeq's mixed norm, of which K4a keeps
-    # the state blocks: a stated deviation), or norm="seminorm" -- torchdiffeq's own state-only norm, i.e. K4a's
+    # adjoint_options: none (the backward inherits the forward options and runs under torchdiffeq's default mixed norm),
+    # or explicit ones with norm absent / "seminorm" (torchdiffeq's norm without the parameter blocks)
     adj_opts = kwargs.get("adjoint_options")
-    adj_opts_ok = adj_opts is None or (isinstance(adj_opts, dict) and adj_opts.get("norm") == "seminorm"
+    adj_opts_ok = adj_opts is None or (isinstance(adj_opts, dict) and adj_opts.get("norm", "seminorm") == "seminorm"
                                        and set(adj_opts) <= {"norm", "jump_t", "safety", "ifactor", "dfactor"})
     dopri_adjoint = (method == "dopri5" and adjoint and wants_grad and not wants_t and not control_wants and mfma_shape
                      and field is not None and kwargs.get("adjoint_method") in (None, "dopri5")

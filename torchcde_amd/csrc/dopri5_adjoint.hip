@@ -3,9 +3,9 @@
 // Replaces the backward of torchdiffeq.odeint_adjoint(method='dopri5') behind reference solver.py:226 -- torchcde's
 // DEFAULT call, cdeint(X, func, z0, t) with adjoint=True and no method (solver.py:144,199-203, README.md:174) -- for
 // the affine vector-field family (identity / tanh), f32, H <= 32, C <= 8.  Per output interval [t_{i-1}, t_i]
-// (processed last to first by the host) the augmented state (y, a, dL/dW, dL/db) is integrated in reversed time
+// (processed last to first by the host) the augmented state (vjp_t, y, a, dL/dW, dL/db) is integrated in reversed time
 // s = -t with Dormand-Prince 5(4) and torchdiffeq's batch-global step controller (semantics restated in
-// oracle/odeint.py: _Dopri5 + _Adjoint; controller arithmetic = dopri5.hip's, float64 times, state-dtype norms).
+// oracle/odeint.py: _Dopri5 + _Adjoint; controller: cde_dopri_adj.h, float64 times, state-dtype norms).
 //
 // Execution model = K4's ("finish the previous attempt, start the next" per launch, no host round trip, no grid
 // barrier) on the workgroup-per-tile decomposition of rk4_split.hip:
@@ -14,146 +14,51 @@
 //     attempt's dt, and a recomputation with the same inputs gives the same bits as the stored value would) run
 //     exactly like the stages of rk4_adjoint_split8: Y tiles, f, g, va partials through LDS, one barrier per stage;
 //     each lane keeps the RK bookkeeping of its two hidden units (7 stage slopes of y and of a: 28 registers);
-//   * the helper waves accumulate this attempt's dL/dW, dL/db (stage weights dt * c_sol: 5 of the 7 stages) over ALL
-//     tiles of the workgroup in registers and leave them in a per-workgroup "attempt" image; the next launch adds the
-//     image to the workgroup's running total iff the attempt was accepted.  One fixed-order reduction over the (at
-//     most 256) workgroup totals at the very end: run-to-run deterministic;
-//   * error control: ratio = max(rms(err_y / tol_y), rms(err_a / tol_a)) over the whole batch.
-// Two stated deviations from torchdiffeq's backward (both leave a valid solve at the requested tolerances):
-//   1. the error norm above omits the parameter-gradient blocks that torchdiffeq's default adjoint norm also looks at
-//      (its `adjoint_options=dict(norm="seminorm")` behaviour): the blocks would need a grid-wide reduction of 8,448
-//      values per attempt; nor does it hold |vjp_t|, which torchdiffeq carries whenever func depends on t (DESIGN.md
-//      section 4);
-//   2. the last step of an output interval is clipped to end on t_{i-1} instead of stepping past it and evaluating
-//      the dense interpolant there (identical when t_{i-1} is a jump time, e.g. t = X.interval with jump_t = knots --
-//      README.md:194-200 -- because torchdiffeq clips onto jump times itself).
-#include "cde_dopri.h"
+//   * the helper waves accumulate, over ALL tiles of the workgroup and in registers, two LINEAR FUNCTIONALS of the seven
+//     stage slopes of (dL/dW, dL/db) -- S: the step's increment (dt c_sol), E: its error estimate (dt c_err)
+//     (cde_dopri_adj.h: adj_stage_weights) -- and leave them as per-workgroup images; `adjoint_reduce_kernel` (one small
+//     launch after every attempt launch) adds the images up in a fixed order, owns the running total G, commits the
+//     previous attempt's S to it when the controller accepted that attempt, and leaves per-block sums of (E / tol)^2
+//     for the next launch's controller;
+//   * error control = torchdiffeq's default MIXED norm over the whole augmented state,
+//         max(|e_t|, rms(e_y), rms(e_a), rms(e_W), rms(e_b)),
+//     or, with adjoint_options=dict(norm="seminorm"), the same without the parameter blocks.  vjp_t (a scalar; the field
+//     depends on t through dX/dt(t): d f / dt = F(z) d2X/dt2) is accumulated by the chain waves next to the state sums;
+//   * the solve of an interval ends as torchdiffeq's does: the last step passes the interval end and the 4th-order dense
+//     interpolant is evaluated there.  The launch that accepts such a step REPEATS it (mode 3: same start state, same
+//     stage times, hence the same slopes) with S := the dense-output functional: `a(s1)` in the chain waves (the
+//     expression order of torchdiffeq's _interp_fit / _interp_evaluate), (dL/dW, dL/db) and vjp_t at s1 through the
+//     image / the state sums, which the R kernel adds to the running totals.
+// Round 2's two stated deviations (state-only norm, clipped last step) are gone.
+#include "cde_dopri_adj.h"
 #include "cde_split.h"
 
 namespace cde {
 
 constexpr int ADJ_IMAGE = 36;                                    // per helper lane: 32 dW accumulators + 4 bias sums
-constexpr int ADJ_IMAGE_FLOATS = 4 * 64 * ADJ_IMAGE;             // per workgroup
+constexpr int ADJ_IMAGE_FLOATS = 4 * 64 * ADJ_IMAGE;             // per workgroup and functional (A, E, D)
 constexpr int ADJ_MAX_WG = 256;
-constexpr int ADJ_LDS_FLOATS = 2 * SPL_ZBUF + 2 * SPL_ZT + 2 * SPL_VA + 2 * 7 * SPL_DX + 2 * 4 * SPL_GT;
+constexpr int ADJ_LDS_FLOATS = 2 * SPL_ZBUF + 2 * SPL_ZT + 2 * SPL_VA + 2 * 2 * 7 * SPL_DX + 2 * 4 * SPL_GT;
 constexpr size_t ADJ_LDS_BYTES = (size_t)ADJ_LDS_FLOATS * sizeof(float) + 4 * 512 * sizeof(double);
+constexpr int ADJ_RBLOCKS = ADJ_IMAGE_FLOATS / 256;              // blocks of the R kernel: one thread per image slot
 
 struct DopriAdjArgs {
   const float* coeffs; const float* knots; int64_t n_intervals;
   const float* W; const float* bias; Dims dims;
   int64_t B, n_tiles;
-  DopriCtrl* ctrl;                  // [2]
+  unsigned char* ctrl;              // [2] AdjCtrl, ADJ_CTRL_STRIDE bytes apart
   float* state;                     // [2][4][B*H]: committed y, a; attempted y1, a1
   const float* y_init; const float* a_init;
-  float* a_out;                     // a at the end of the interval (written by the launch that finishes it)
-  double* partial;                  // [2][ADJ_MAX_WG][4]
-  float* tot; float* att;           // [ADJ_MAX_WG][ADJ_IMAGE_FLOATS] each
-  double* trace;                    // [CDE_DOPRI5_TRACE_STEPS][3]
-  double s0, s1;                    // the interval in reversed time, s0 < s1
-  const double* jump_s; int64_t n_jump;    // jump times in reversed time, ascending
-  double rtol, atol, safety, ifactor, dfactor;
-  const double* ext_sums;           // sharded batch: the 4 pending sums added up over all shards (else nullptr)
-  int64_t B_global;                 // series the error norm runs over (0: B)
+  float* a_out;                     // a at the end of the interval (dense output of the attempt that reaches it)
+  double* partial;                  // [2][ADJ_MAX_WG][ADJ_NS]
+  double* pq;                       // [2][ADJ_RBLOCKS][4]: the R kernel's partial sums, slots (q0, q1) of W then of b
+  float* att;                       // [ADJ_MAX_WG][2][ADJ_IMAGE_FLOATS]: this launch's S and E images
+  AdjCommon com;
+  const double* ext_sums;           // sharded batch: the ADJ_NS pending sums added up over all shards (else nullptr)
 };
 
-struct AdjPlan {
-  bool accept;          // decision on the pending attempt (phase 3)
-  int mode;             // this launch: 0 = f0 norms, 1 = f1 norm, 2 = attempt, 3 = interval finished
-  double t0, t1, dt;
-  float h0;
-  int kind0;            // perturbation of the stage-0 time: 0 none, -1 just before, +1 just after
-};
-
-// torchdiffeq's controller (dopri5.hip: dopri_controller) for the two-block state (y, a): every thread derives the
-// same plan from the controller struct and the pending sums.
-__device__ __forceinline__ AdjPlan adj_controller(const DopriAdjArgs& g, DopriCtrl& c, const double (&sum)[4]) {
-  const double n_elems = (double)((g.B_global > 0 ? g.B_global : g.B) * g.dims.H);
-  auto rms = [&](double s) { return (float)sqrt(s / n_elems); };
-  auto maxf = [](float a, float b) { return a > b ? a : b; };
-  AdjPlan plan{};
-  bool accept = false;
-  int mode;
-  if (c.phase == 0) {
-    mode = 0;
-    c.t_lo = c.t_hi = g.s0;
-    c.i_out = 1; c.n_accept = c.n_reject = 0; c.refresh = 0; c.on_jump = 0;
-    int64_t j = 0;
-    while (j < g.n_jump && g.jump_s[j] < c.t_hi) ++j;             // torchdiffeq keeps jump times >= t0 ...
-    const int64_t first = j;
-    while (j < g.n_jump && g.jump_s[j] <= c.t_hi) ++j;            // ... and starts at bisect_right(jump_t, t0)
-    c.i_jump = j - first;
-    if (g.n_jump - first > 0 && c.i_jump > g.n_jump - first - 1) c.i_jump = g.n_jump - first - 1;
-    c.pad = (int32_t)first;
-  } else if (c.phase == 1) {
-    const float d0 = maxf(rms(sum[0]), rms(sum[1])), d1 = maxf(rms(sum[2]), rms(sum[3]));
-    float h0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : 0.01f * d0 / d1;
-    h0 = h0 < 0 ? -h0 : h0;
-    c.h0 = (double)h0;
-    c.dt = (double)d1;                                            // parked for phase 2
-    plan.h0 = h0;
-    mode = 1;
-  } else if (c.phase == 2) {
-    const float h0 = (float)c.h0, d1 = (float)c.dt;
-    const float d2 = maxf(rms(sum[0]), rms(sum[1])) / h0;
-    float h1;
-    if (d1 <= 1e-15f && d2 <= 1e-15f) { const float a = 1e-6f, b = h0 * 1e-3f; h1 = a > b ? a : b; }
-    else h1 = powf(0.01f / maxf(d1, d2), (float)(1.0 / 5.0));
-    h1 = h1 < 0 ? -h1 : h1;
-    const float hundred = 100.f * h0;
-    c.dt = (double)(hundred < h1 ? hundred : h1);
-    mode = 2;
-  } else {
-    const float ratio_t = maxf(rms(sum[0]), rms(sum[1]));
-    accept = ratio_t <= 1.f;
-    if (accept) {
-      c.n_accept++;
-      c.t_lo = c.t_hi; c.t_hi = c.t1_try;
-      if (g.trace && blockIdx.x == 0 && threadIdx.x == 0 && c.n_accept <= CDE_DOPRI5_TRACE_STEPS) {
-        g.trace[3 * (c.n_accept - 1)] = c.t_lo;
-        g.trace[3 * (c.n_accept - 1) + 1] = c.t_hi;
-        g.trace[3 * (c.n_accept - 1) + 2] = c.on_jump ? 1.0 : 0.0;
-      }
-      c.refresh = 0;
-      if (c.on_jump) {
-        const int64_t kept = g.n_jump - c.pad;
-        if (c.i_jump != kept - 1) c.i_jump++;
-        c.refresh = 1;
-      }
-    } else {
-      c.n_reject++;
-      c.t_lo = c.t_hi;
-    }
-    const double ratio = (double)ratio_t;
-    double factor;
-    if (ratio == 0.0) factor = g.ifactor;
-    else {
-      const double dfac = ratio < 1.0 ? 1.0 : g.dfactor;
-      double f = g.safety / pow(ratio, 1.0 / 5.0);
-      f = f > dfac ? f : dfac;
-      factor = g.ifactor < f ? g.ifactor : f;
-    }
-    c.dt = c.dt_try * factor;
-    mode = 2;
-  }
-  if (c.phase == 3 && accept && !(c.t_hi < g.s1)) mode = 3;       // the interval is done
-  double t0 = 0, t1 = 0, dt = 0;
-  if (mode == 2) {
-    t0 = c.t_hi;
-    dt = c.dt;
-    if (!(dt == dt) || dt > 1e300 || dt < -1e300) dt = 0.0;
-    t1 = t0 + dt;
-    int on_jump = 0;
-    const int64_t kept = g.n_jump - c.pad;
-    if (kept > 0) {
-      const double nxt = g.jump_s[c.pad + c.i_jump];
-      if (t0 < nxt && nxt < t0 + dt) { on_jump = 1; t1 = nxt; dt = t1 - t0; }
-    }
-    if (t1 > g.s1) { t1 = g.s1; dt = t1 - t0; on_jump = 0; }      // deviation 2 (file header): end ON the interval end
-    c.t1_try = t1; c.dt_try = dt; c.on_jump = on_jump;
-  }
-  plan.accept = accept; plan.mode = mode; plan.t0 = t0; plan.t1 = t1; plan.dt = dt;
-  plan.kind0 = c.refresh ? 1 : (c.n_accept > 0 ? -1 : 0);
-  return plan;
+__device__ __forceinline__ AdjCtrl* adj_ctrl(unsigned char* base, int which) {
+  return reinterpret_cast<AdjCtrl*>(base + which * ADJ_CTRL_STRIDE);
 }
 
 template <int DEGREE, int ACT>
@@ -161,9 +66,10 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int p = parity, p2 = parity ^ 1;
-  DopriCtrl c = g.ctrl[p];
+  AdjCtrl k = *adj_ctrl(g.ctrl, p);
+  DopriCtrl& c = k.c;
   if (c.phase == 4) {
-    if (blockIdx.x == 0 && tid == 0) g.ctrl[p2] = c;
+    if (blockIdx.x == 0 && tid == 0) { k.commit = 0; k.mode = 3; *adj_ctrl(g.ctrl, p2) = k; }
     return;
   }
   const int Hr = g.dims.H, Cr = g.dims.C;
@@ -175,32 +81,48 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
   float* ztb = lds + 2 * SPL_ZBUF;
   float* vab = ztb + 2 * SPL_ZT;
   float* dxb = vab + 2 * SPL_VA;                                   // [2 tiles in flight][7 stages][16 series][SPL_DXROW]
-  float* gT = dxb + 2 * 7 * SPL_DX + w * SPL_GT;                   // + (parity) * 4 * SPL_GT
+  float* d2b = dxb + 2 * 7 * SPL_DX;                               // the same for d2X/dt2 (cubic controls: vjp_t)
+  float* gT = d2b + 2 * 7 * SPL_DX + w * SPL_GT;                   // + (parity) * 4 * SPL_GT
   double* red = reinterpret_cast<double*>(lds + ADJ_LDS_FLOATS);
   const int64_t BH = g.B * g.dims.H;
   const float* Sp = g.state + (int64_t)p * 4 * BH;
   float* Sq = g.state + (int64_t)p2 * 4 * BH;
-  const double* Pp = g.partial + (int64_t)p * ADJ_MAX_WG * 4;
-  double* Pq = g.partial + (int64_t)p2 * ADJ_MAX_WG * 4;
-  const float rtol = (float)g.rtol, atol = (float)g.atol;
+  const double* Pp = g.partial + (int64_t)p * ADJ_MAX_WG * ADJ_NS;
+  double* Pq = g.partial + (int64_t)p2 * ADJ_MAX_WG * ADJ_NS;
+  const float rtol = (float)g.com.rtol, atol = (float)g.com.atol;
 
-  // ---- pending global sums (fixed order: the decision is identical in every workgroup and run to run)
-  double sum[4] = {0.0, 0.0, 0.0, 0.0};
-  if (c.phase != 0 && g.ext_sums) {
+  // ---- pending global sums (fixed order: the decision is identical in every workgroup and run to run): the state
+  // sums of the previous attempt launch and the parameter sums its R kernel left
+  double sum[ADJ_NS + 4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) sum[k] = g.ext_sums[k];
-  } else if (c.phase != 0) {
-    for (int64_t b = tid; b < (int64_t)gridDim.x; b += blockDim.x) {
+  for (int i = 0; i < ADJ_NS + 4; ++i) sum[i] = 0.0;
+  if (c.phase != 0) {
+    if (g.ext_sums) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) sum[k] += Pp[4 * b + k];
+      for (int i = 0; i < ADJ_NS; ++i) sum[i] = g.ext_sums[i];
+    } else {
+      for (int64_t b = tid; b < (int64_t)gridDim.x; b += blockDim.x) {
+#pragma unroll
+        for (int i = 0; i < ADJ_NS; ++i) sum[i] += Pp[ADJ_NS * b + i];
+      }
     }
-    block_total<4>(sum, red);
+    const double* Qp = g.pq + (int64_t)p * ADJ_RBLOCKS * 4;
+    for (int b = tid; b < ADJ_RBLOCKS; b += blockDim.x) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sum[ADJ_NS + i] += Qp[4 * b + i];
+    }
+    block_total<ADJ_NS + 4>(sum, red);
+    if (g.ext_sums) {
+#pragma unroll
+      for (int i = 0; i < ADJ_NS; ++i) sum[i] = g.ext_sums[i];      // (block_total summed 512 copies of them)
+    }
   }
   const int phase_in = c.phase;
-  const AdjPlan plan = adj_controller(g, c, sum);
+  const AdjPlan plan = adj_controller(g.com, k, sum, sum + ADJ_NS);
   const int mode = plan.mode;
-  const bool commit = phase_in == 3 && plan.accept;
-  const int ns = mode == 0 ? 1 : mode == 1 ? 2 : mode == 2 ? 7 : 0;
+  // mode 3 repeats the accepted step from ITS start state (the dense output at the interval end needs its slopes)
+  const bool commit = phase_in == 3 && plan.accept && mode != 3;
+  const int ns = mode == 0 ? 1 : mode == 1 ? 2 : 7;
 
   // ---- stage times (reversed time), their knot intervals and the stage weights, all wave-uniform
   const float t0f = (float)plan.t0, dtf = (float)plan.dt, t1f = (float)plan.t1;
@@ -220,43 +142,41 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
     // by every launch before anything else can start -- into four independent ones
     const int idx = (int)locate_around(g.knots, g.n_intervals, -ts, phase_in == 0 ? (int64_t)-1 : (int64_t)c.slot, frac);
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
-      sidx[k] = __builtin_amdgcn_readlane(idx, k);
-      sfrac[k] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(frac), k));
+    for (int j = 0; j < 7; ++j) {
+      sidx[j] = __builtin_amdgcn_readlane(idx, j);
+      sfrac[j] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(frac), j));
     }
   }
-  // bc[i][j]: weight of slope j in the state handed to stage i
+  // bc[i][j]: weight of slope j in the state handed to stage i.  Everything here is wave-uniform but derives from
+  // memory / LDS reads, so the compiler would hold it in vector registers (70 of them): read back through lane 0
   float bc[7][6];
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
 #pragma unroll
-    for (int j = 0; j < 6; ++j) bc[i][j] = (i >= 1 && j < i) ? (float)DP_BETA[i - 1][j] * dtf : 0.f;
+    for (int j = 0; j < 6; ++j) bc[i][j] = (i >= 1 && j < i) ? uni((float)DP_BETA[i - 1][j] * dtf) : 0.f;
   }
-  if (mode == 1) bc[1][0] = plan.h0;
-  float cerr[7], csol[7];
+  if (mode == 1) bc[1][0] = uni(plan.h0);
+  // the two functionals of the stage slopes this launch accumulates (parameter gradients in the helper waves, vjp_t
+  // in the chain waves): S and E of cde_dopri_adj.h; wE doubles as the error weights of the state
+  float wS[7], wE[7];
+  adj_stage_weights(mode, dtf, plan.x_end, wS, wE);
 #pragma unroll
-  for (int j = 0; j < 7; ++j) { cerr[j] = dtf * (float)DP_CERR[j]; csol[j] = j < 6 ? dtf * (float)DP_BETA[5][j] : 0.f; }
+  for (int j = 0; j < 7; ++j) { wS[j] = uni(wS[j]); wE[j] = uni(wE[j]); }
+  const bool img_e = mode == 2 && g.com.norm_kind == 0;            // the E image: only when the parameter blocks are in the norm
 
   int par = 0, gpar = 0, dbuf = 0;
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  double acc[ADJ_NS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 
   if (helper) {
     // ------------------------------------------------------------------------------------------ helper wave
-    f32x4 accW[4][2];
-    float gb[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 accA[4][2], accE[4][2];
+    float gbA[4] = {0.f, 0.f, 0.f, 0.f}, gbE[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int Tm = 0; Tm < 4; ++Tm) { accW[Tm][0] = f32x4{0.f, 0.f, 0.f, 0.f}; accW[Tm][1] = accW[Tm][0]; }
-    float* my_tot = g.tot + ((int64_t)blockIdx.x * 256 + w * 64 + lane) * ADJ_IMAGE;
-    float* my_att = g.att + ((int64_t)blockIdx.x * 256 + w * 64 + lane) * ADJ_IMAGE;
-    if (commit) {                                                  // the attempt the previous launch left behind was accepted
-#pragma unroll
-      for (int r = 0; r < ADJ_IMAGE; r += 4) {
-        float4 t4 = *reinterpret_cast<float4*>(my_tot + r);
-        const float4 a4 = *reinterpret_cast<const float4*>(my_att + r);
-        t4.x += a4.x; t4.y += a4.y; t4.z += a4.z; t4.w += a4.w;
-        *reinterpret_cast<float4*>(my_tot + r) = t4;
-      }
+    for (int Tm = 0; Tm < 4; ++Tm) {
+      accA[Tm][0] = f32x4{0.f, 0.f, 0.f, 0.f}; accA[Tm][1] = accA[Tm][0];
+      accE[Tm][0] = accA[Tm][0]; accE[Tm][1] = accA[Tm][0];
     }
+    float* my_att = g.att + (((int64_t)blockIdx.x * 2) * 256 + w * 64 + lane) * ADJ_IMAGE;      // image S; E follows
     const float* ztr = ztb + n * SPL_TROW + 4 * q;
     const float* gr = gT + n * SPL_TROW + 4 * q;
     const int fc = 2 * w + (q & 1);                                // the control channel this lane feeds
@@ -288,59 +208,77 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
           const float v = DEGREE == CDE_PATH_CUBIC ? cubic_derivative(raw[i][0], raw[i][1], raw[i][2], sfrac[i])
                                                    : (raw[i][1] - raw[i][0]) / raw[i][2];
           if (feeds) dxb[(buf * 7 + i) * SPL_DX + n * SPL_DXROW + fc] = fc < Cr ? v : 0.f;
+          if (DEGREE == CDE_PATH_CUBIC) {
+            // d2X/dt2 = 2c + 2 (3d) frac: what autograd gets from interpolation_cubic.py:334-335 through frac = t - t_i
+            const float v2 = raw[i][1] + 2.f * raw[i][2] * sfrac[i];
+            if (feeds) d2b[(buf * 7 + i) * SPL_DX + n * SPL_DXROW + fc] = fc < Cr ? v2 : 0.f;
+          }
         }
       }
     };
-    if (mode != 3 && (int64_t)blockIdx.x < g.n_tiles) { feed_request(blockIdx.x); feed_store(0); }
+    if ((int64_t)blockIdx.x < g.n_tiles) { feed_request(blockIdx.x); feed_store(0); }
     for (int64_t tile = blockIdx.x; tile < g.n_tiles; tile += gridDim.x) {
-      if (mode == 3) continue;
       const bool has_next = tile + gridDim.x < g.n_tiles;
       if (has_next) feed_request(tile + gridDim.x);
       spl_barrier();
-      f32x2 zq[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
-      float wprev = 0.f;
-      auto dw_round = [&](int gp) {
+      f32x2 zr[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};      // z of the stage whose g tile is next
+      // one stage's contribution to the images: g^T (w z) for each functional with a non-zero weight on that stage
+      auto dw_round = [&](int gp, float a_w, float e_w) {
+        if (a_w == 0.f && e_w == 0.f) return;
         float4 ga4[4];
 #pragma unroll
         for (int Tm = 0; Tm < 4; ++Tm) ga4[Tm] = *reinterpret_cast<const float4*>(gr + gp * 4 * SPL_GT + Tm * 16 * SPL_TROW);
-        const float b0[4] = {zq[0][0], zq[0][1], zq[1][0], zq[1][1]}, b1[4] = {zq[2][0], zq[2][1], zq[3][0], zq[3][1]};
+        float rs[4];
 #pragma unroll
-        for (int Tm = 0; Tm < 4; ++Tm) {
-          const float ga[4] = {ga4[Tm].x, ga4[Tm].y, ga4[Tm].z, ga4[Tm].w};
+        for (int Tm = 0; Tm < 4; ++Tm) rs[Tm] = (ga4[Tm].x + ga4[Tm].y) + (ga4[Tm].z + ga4[Tm].w);
+        auto add = [&](float wgt, f32x4 (&accW)[4][2], float (&gb)[4]) {
+          const f32x2 z0 = zr[0] * wgt, z1 = zr[1] * wgt, z2 = zr[2] * wgt, z3 = zr[3] * wgt;
+          const float b0[4] = {z0[0], z0[1], z1[0], z1[1]}, b1[4] = {z2[0], z2[1], z3[0], z3[1]};
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            accW[Tm][0] = mfma16(ga[s], b0[s], accW[Tm][0]);
-            accW[Tm][1] = mfma16(ga[s], b1[s], accW[Tm][1]);
+          for (int Tm = 0; Tm < 4; ++Tm) {
+            const float ga[4] = {ga4[Tm].x, ga4[Tm].y, ga4[Tm].z, ga4[Tm].w};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              accW[Tm][0] = mfma16(ga[s], b0[s], accW[Tm][0]);
+              accW[Tm][1] = mfma16(ga[s], b1[s], accW[Tm][1]);
+            }
+            gb[Tm] = __builtin_fmaf(rs[Tm], wgt, gb[Tm]);
           }
-          gb[Tm] = __builtin_fmaf((ga[0] + ga[1]) + (ga[2] + ga[3]), wprev, gb[Tm]);
-        }
+        };
+        if (a_w != 0.f) add(a_w, accA, gbA);
+        if (e_w != 0.f) add(e_w, accE, gbE);
       };
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
         if (i < ns) {
           const float4 zt0 = *reinterpret_cast<const float4*>(ztr + par * SPL_ZT);
           const float4 zt1 = *reinterpret_cast<const float4*>(ztr + par * SPL_ZT + 16 * SPL_TROW);
-          if (mode == 2 && i >= 1 && wprev != 0.f) dw_round(gpar ^ 1);      // stage i-1's tile, its weight dt c_sol[i-1]
-          const float wq = mode == 2 ? csol[i] : 0.f;
-          zq[0] = f32x2{zt0.x, zt0.y} * wq; zq[1] = f32x2{zt0.z, zt0.w} * wq;
-          zq[2] = f32x2{zt1.x, zt1.y} * wq; zq[3] = f32x2{zt1.z, zt1.w} * wq;
-          wprev = wq;
+          if (i >= 1) dw_round(gpar ^ 1, wS[i - 1], img_e ? wE[i - 1] : 0.f);      // stage i-1's tile
+          zr[0] = f32x2{zt0.x, zt0.y}; zr[1] = f32x2{zt0.z, zt0.w};
+          zr[2] = f32x2{zt1.x, zt1.y}; zr[3] = f32x2{zt1.z, zt1.w};
           spl_barrier();
           par ^= 1; gpar ^= 1;
         }
       }
-      // (the last stage carries weight c_sol[6] = 0: nothing left to add)
+      // the last stage's tile: the chain waves overwrite this g buffer two barriers from now at the earliest
+      if (ns == 1) dw_round(gpar ^ 1, wS[0], 0.f);
+      else if (ns == 2) dw_round(gpar ^ 1, wS[1], 0.f);
+      else dw_round(gpar ^ 1, wS[6], img_e ? wE[6] : 0.f);
       if (has_next) feed_store(dbuf ^ 1);
       dbuf ^= 1;
     }
-    if (mode == 2) {
+    {
+      auto put = [&](float* dst, f32x4 (&accW)[4][2], float (&gb)[4]) {
 #pragma unroll
-      for (int Tm = 0; Tm < 4; ++Tm) {
+        for (int Tm = 0; Tm < 4; ++Tm) {
 #pragma unroll
-        for (int Tn = 0; Tn < 2; ++Tn)
-          *reinterpret_cast<float4*>(my_att + (Tm * 2 + Tn) * 4) = make_float4(accW[Tm][Tn][0], accW[Tm][Tn][1], accW[Tm][Tn][2], accW[Tm][Tn][3]);
-      }
-      *reinterpret_cast<float4*>(my_att + 32) = make_float4(gb[0], gb[1], gb[2], gb[3]);
+          for (int Tn = 0; Tn < 2; ++Tn)
+            *reinterpret_cast<float4*>(dst + (Tm * 2 + Tn) * 4) = make_float4(accW[Tm][Tn][0], accW[Tm][Tn][1], accW[Tm][Tn][2], accW[Tm][Tn][3]);
+        }
+        *reinterpret_cast<float4*>(dst + 32) = make_float4(gb[0], gb[1], gb[2], gb[3]);
+      };
+      put(my_att, accA, gbA);
+      if (img_e) put(my_att + ADJ_IMAGE_FLOATS, accE, gbE);
     }
   } else {
     // ------------------------------------------------------------------------------------------ chain wave
@@ -357,6 +295,7 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
     const float* vr = vab + ((w * 4 + q) * 16 + n) * SPL_VROW;
     float* gw_ = gT + (4 * q) * SPL_TROW + pos;
     const float* dxr = dxb + n * SPL_DXROW;
+    const float* d2r = d2b + n * SPL_DXROW;
     auto publish = [&](int pp, float za, float zb) {
       *reinterpret_cast<float2*>(zw + pp * SPL_ZBUF) = make_float2(za, zb);
       ztw[pp * SPL_ZT] = za;
@@ -376,13 +315,14 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
       if (phase_in == 0) {
         st[0] = g.y_init[ea]; st[1] = g.y_init[eb]; st[2] = g.a_init[ea]; st[3] = g.a_init[eb];
       } else {
-        const int off = commit ? 2 : 0;
+        const int off = commit ? 2 : 0;                            // (mode 3: the accepted step's own start state)
         st[0] = Sp[(off + 0) * BH + ea]; st[1] = Sp[(off + 0) * BH + eb];
         st[2] = Sp[(off + 1) * BH + ea]; st[3] = Sp[(off + 1) * BH + eb];
       }
     };
     float st_next[4] = {0.f, 0.f, 0.f, 0.f};
     if ((int64_t)blockIdx.x < g.n_tiles) state_request(blockIdx.x, st_next);
+    float vtS = 0.f, vtE = 0.f;                                   // this lane's share of the vjp_t functionals
     for (int64_t tile = blockIdx.x; tile < g.n_tiles; tile += gridDim.x) {
       const int64_t series = tile * 16 + n;
       const bool valid = series < g.B;
@@ -394,13 +334,10 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
       if (ua >= Hr) { y0a = 0.f; a0a = 0.f; }
       if (ub >= Hr) { y0b = 0.f; a0b = 0.f; }
       if (!valid) { a0a = 0.f; a0b = 0.f; }                      // padded lanes add nothing to dL/dW
-      if (mode == 3) {
-        if (ona) g.a_out[ea] = a0a;
-        if (onb) g.a_out[eb] = a0b;
-        continue;
+      if (mode != 3) {
+        if (ona) { Sq[0 * BH + ea] = y0a; Sq[1 * BH + ea] = a0a; }
+        if (onb) { Sq[0 * BH + eb] = y0b; Sq[1 * BH + eb] = a0b; }
       }
-      if (ona) { Sq[0 * BH + ea] = y0a; Sq[1 * BH + ea] = a0a; }
-      if (onb) { Sq[0 * BH + eb] = y0b; Sq[1 * BH + eb] = a0b; }
       publish(par, y0a, y0b);
       spl_barrier();
       float kya[7], kyb[7], kaa[7], kab[7];
@@ -432,6 +369,14 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
           }
           f32x2 gq[4][2];
           f32x2 fpa = {0.f, 0.f}, fpb = {0.f, 0.f};
+          f32x2 hpa = {0.f, 0.f}, hpb = {0.f, 0.f};                // the same contraction with d2X/dt2: d f / dt
+          float d2X[MC];
+          if (DEGREE == CDE_PATH_CUBIC) {
+            const float4 e03 = *reinterpret_cast<const float4*>(d2r + (dbuf * 7 + i) * SPL_DX);
+            const float4 e47 = *reinterpret_cast<const float4*>(d2r + (dbuf * 7 + i) * SPL_DX + 4);
+            d2X[0] = e03.x; d2X[1] = e03.y; d2X[2] = e03.z; d2X[3] = e03.w;
+            d2X[4] = e47.x; d2X[5] = e47.y; d2X[6] = e47.z; d2X[7] = e47.w;
+          }
           float* gwp = gw_ + gpar * 4 * SPL_GT;
 #pragma unroll
           for (int T = 0; T < 4; ++T) {
@@ -441,6 +386,10 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
               const f32x2 dx = {dX[4 * (T & 1) + 2 * j], dX[4 * (T & 1) + 2 * j + 1]};
               const f32x2 t = activate2<ACT>(yt[T][2 * j], yt[T][2 * j + 1]);
               if (T >> 1) fpb = __builtin_elementwise_fma(t, dx, fpb); else fpa = __builtin_elementwise_fma(t, dx, fpa);
+              if (DEGREE == CDE_PATH_CUBIC) {
+                const f32x2 d2 = {d2X[4 * (T & 1) + 2 * j], d2X[4 * (T & 1) + 2 * j + 1]};
+                if (T >> 1) hpb = __builtin_elementwise_fma(t, d2, hpb); else hpa = __builtin_elementwise_fma(t, d2, hpa);
+              }
               if (ACT == CDE_ACT_NONE) gq[T][j] = dx * aown;
               else gq[T][j] = (f32x2{spl_slope<ACT>(t[0]), spl_slope<ACT>(t[1])} * dx) * aown;
               gwp[(T * 16 + 2 * j) * SPL_TROW] = gq[T][j][0];
@@ -448,6 +397,11 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
             }
           }
           kya[i] = -(fpa[0] + fpa[1]); kyb[i] = -(fpb[0] + fpb[1]);          // reverse time: dy/ds = -f
+          // d vjp_t / ds = + a . (df/dt) with the stage value of a (padded lanes carry a == 0)
+          if (DEGREE == CDE_PATH_CUBIC) {
+            const float kt = asa * (hpa[0] + hpa[1]) + asb * (hpb[0] + hpb[1]);
+            vtS = __builtin_fmaf(wS[i], kt, vtS); vtE = __builtin_fmaf(wE[i], kt, vtE);
+          }
           if (i + 1 < ns) {
             // y path: the state of the next stage does not wait for anything else
             float sa = 0.f, sb = 0.f;
@@ -487,60 +441,166 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
       } else if (mode == 1) {
         if (ona) { acc[0] += sq((kya[1] - kya[0]) / sca); acc[1] += sq((kaa[1] - kaa[0]) / saa); }
         if (onb) { acc[0] += sq((kyb[1] - kyb[0]) / scb); acc[1] += sq((kab[1] - kab[0]) / sab); }
-      } else {
+      } else if (mode == 2) {
         // the step: y1 / a1 are the states handed to stage 6 (FSAL row == solution weights)
         float eya = 0.f, eyb = 0.f, eaa = 0.f, eab = 0.f;
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
-          eya = __builtin_fmaf(cerr[j], kya[j], eya); eyb = __builtin_fmaf(cerr[j], kyb[j], eyb);
-          eaa = __builtin_fmaf(cerr[j], kaa[j], eaa); eab = __builtin_fmaf(cerr[j], kab[j], eab);
+          eya = __builtin_fmaf(wE[j], kya[j], eya); eyb = __builtin_fmaf(wE[j], kyb[j], eyb);
+          eaa = __builtin_fmaf(wE[j], kaa[j], eaa); eab = __builtin_fmaf(wE[j], kab[j], eab);
         }
         const float tya = atol + rtol * fmaxf(fabsf(y0a), fabsf(ysa)), tyb = atol + rtol * fmaxf(fabsf(y0b), fabsf(ysb));
         const float taa = atol + rtol * fmaxf(fabsf(a0a), fabsf(asa)), tab = atol + rtol * fmaxf(fabsf(a0b), fabsf(asb));
         if (ona) { acc[0] += sq(eya / tya); acc[1] += sq(eaa / taa); Sq[2 * BH + ea] = ysa; Sq[3 * BH + ea] = asa; }
         if (onb) { acc[0] += sq(eyb / tyb); acc[1] += sq(eab / tab); Sq[2 * BH + eb] = ysb; Sq[3 * BH + eb] = asb; }
+      } else {
+        {
+          // the accepted step that reached the interval end, once more: a(s1) by torchdiffeq's dense output
+          // (_interp_fit / _interp_evaluate, oracle/odeint.py: _fit_dense / _eval_dense, same expression order)
+          float ma = 0.f, mb = 0.f;
+#pragma unroll
+          for (int j = 0; j < 7; ++j) {
+            const float wm = dtf * (float)DP_CMID[j];
+            ma = __builtin_fmaf(wm, kaa[j], ma); mb = __builtin_fmaf(wm, kab[j], mb);
+          }
+          auto dense = [&](float y0, float y1, float f0, float f1, float mid) {
+            const float ym = y0 + mid;
+            const float ca = 2.f * dtf * (f1 - f0) - 8.f * (y1 + y0) + 16.f * ym;
+            const float cb = dtf * (5.f * f0 - 3.f * f1) + 18.f * y0 + 14.f * y1 - 32.f * ym;
+            const float cc = dtf * (f1 - 4.f * f0) - 11.f * y0 - 5.f * y1 + 16.f * ym;
+            const float cd = dtf * f0;
+            const float x = plan.x_end;
+            float total = y0 + x * cd;
+            float xp = x;
+            xp = xp * x; total = total + xp * cc;
+            xp = xp * x; total = total + xp * cb;
+            xp = xp * x; total = total + xp * ca;
+            return total;
+          };
+          if (ona) g.a_out[ea] = dense(a0a, asa, kaa[0], kaa[6], ma);
+          if (onb) g.a_out[eb] = dense(a0b, asb, kab[0], kab[6], mb);
+        }
       }
       dbuf ^= 1;
     }
+    acc[4] = (double)vtS; acc[5] = (double)vtE;
   }
   // ---- publish this launch's partial sums and the controller state for the next launch
-  block_total<4>(acc, red);
+  block_total<ADJ_NS>(acc, red);
   if (tid == 0) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) Pq[4 * blockIdx.x + k] = acc[k];
+    for (int i = 0; i < ADJ_NS; ++i) Pq[ADJ_NS * blockIdx.x + i] = acc[i];
   }
   if (blockIdx.x == 0 && tid == 0) {
     c.phase = mode == 0 ? 1 : mode == 1 ? 2 : mode == 2 ? 3 : 4;
     c.slot = sidx[0];                                              // search hint for the next launch's stage times
-    g.ctrl[p2] = c;
+    *adj_ctrl(g.ctrl, p2) = k;
   }
 }
 
-// dL/dW, dL/db from the workgroups' register images (fixed order over the workgroups).  Image of helper wave w, lane
-// (n = l & 15, q = l >> 4): register (Tm*2 + Tn)*4 + r = dW[h = 8w + 4(Tm>>1) + q][c = 4(Tm&1) + r][k = 16 Tn + n];
-// register 32 + Tm = this lane's share of the row sum of row i = n of tile Tm: h = 8w + 4(Tm>>1) + (n>>2), c = 4(Tm&1) + (n&3).
-__global__ __launch_bounds__(256) void dopri5_adjoint_finish_kernel(const float* __restrict__ tot, int n_wg,
-                                                                    float* __restrict__ grad_W, float* __restrict__ grad_b,
-                                                                    Dims d) {
+// ------------------------------------------------------------------------------------------ the R kernel
+// One thread per slot of the helper-wave image layout (coalesced sums over the workgroups' images, fixed order).
+// Slot (lane l = (w, q, n), register s): s < 32 is a dL/dW element (each exactly once); s = 32 + Tm is lane (q, n)'s
+// share of the bias row sum of (h = 8w + 4(Tm>>1) + (n>>2), c = 4(Tm&1) + (n&3)): the q == 0 lane adds the four shares.
+//   stage 0 (fused) : sums -> commit -> norms        (unsharded solves: one launch per attempt)
+//   stage 1         : sums only, into `sums_out`     (sharded: the host all-reduces them over the ranks ...)
+//   stage 2         : commit + norms from `sums_in`  (... and every rank then holds the same reduced images)
+struct AdjReduceArgs {
+  unsigned char* ctrl; const float* att; int n_wg;
+  float* G;                 // [IMAGE]: running total (sharded: of the GLOBAL batch -- the norm needs that)
+  float* G_local;           // sharded only: this shard's own running total (what the caller gets back); else nullptr
+  float* prevS;             // [2][IMAGE]: the S sums of a launch, kept for the commit one launch later
+  float* prevS_local;       // the same for this shard's own sums (sharded)
+  double* pq;               // [2][ADJ_RBLOCKS][4]
+  const double* partial;    // [2][ADJ_MAX_WG][ADJ_NS]: the attempt launches' state sums (vjp_t at the interval end)
+  double* carry;
+  double* sums_out;         // stage 1: [2][IMAGE] doubles (S, E)
+  const double* sums_in;    // stage 2: the reduced buffer (ADJ_NS state sums, then the images)
+  float rtol, atol;
+};
+
+__global__ __launch_bounds__(256) void adjoint_reduce_kernel(AdjReduceArgs r, int parity, int stage) {
+  __shared__ double red[4 * 4];
+  const int p2 = parity ^ 1;
+  const AdjCtrl k = *adj_ctrl(r.ctrl, p2);                          // written by the attempt launch just before this one
+  if (k.c.phase == 4 && k.commit == 0) return;                     // the interval was finished (and committed) earlier
+  const int j = blockIdx.x * 256 + threadIdx.x;                    // image slot
+  const int s = j % ADJ_IMAGE, l = j / ADJ_IMAGE, q = (l >> 4) & 3;
+  const bool bias_share = s >= 32;
+  const bool owner = !bias_share || q == 0;
+  const bool need_e = k.mode == 2;
+  float S = 0.f, E = 0.f;
+  if (stage != 2 && owner) {
+    const int reps = bias_share ? 4 : 1;
+    for (int rep = 0; rep < reps; ++rep) {
+      const int jj = j + rep * 16 * ADJ_IMAGE;                      // lanes q = 1, 2, 3 of the same (w, n)
+      float a = 0.f, e = 0.f;
+      for (int b = 0; b < r.n_wg; ++b) {
+        const float* img = r.att + (int64_t)b * 2 * ADJ_IMAGE_FLOATS + jj;
+        a += img[0];
+        if (need_e) e += img[ADJ_IMAGE_FLOATS];
+      }
+      S += a; E += e;
+    }
+  }
+  if (stage == 1) {
+    r.sums_out[j] = S; r.sums_out[ADJ_IMAGE_FLOATS + j] = E;
+    r.prevS_local[parity * ADJ_IMAGE_FLOATS + j] = S;               // this shard's own increment, for its own running total
+    return;
+  }
+  if (stage == 2) { S = (float)r.sums_in[ADJ_NS + j]; E = (float)r.sums_in[ADJ_NS + ADJ_IMAGE_FLOATS + j]; }
+  if (k.mode == 3 && j == 0) {
+    // vjp_t at the interval end: its committed value at the step's start + the dense-output functional of its slopes
+    double vt = 0.0;
+    if (stage == 2) vt = r.sums_in[4];
+    else
+      for (int b = 0; b < r.n_wg; ++b) vt += r.partial[((int64_t)p2 * ADJ_MAX_WG + b) * ADJ_NS + 4];
+    r.carry[0] = (double)((float)k.T + (float)vt);
+  }
+  double qv[4] = {0.0, 0.0, 0.0, 0.0};
+  {
+    double q0 = 0.0, q1 = 0.0;
+    const float gn = adj_param_element(k, r.rtol, r.atol, r.G[j], r.prevS[p2 * ADJ_IMAGE_FLOATS + j], S, E, q0, q1);
+    if (k.commit) r.G[j] = gn;
+    if (r.G_local && k.commit)
+      r.G_local[j] += k.commit == 1 ? r.prevS_local[p2 * ADJ_IMAGE_FLOATS + j] : r.prevS_local[parity * ADJ_IMAGE_FLOATS + j];
+    r.prevS[parity * ADJ_IMAGE_FLOATS + j] = S;
+    if (owner) { qv[bias_share ? 2 : 0] = q0; qv[bias_share ? 3 : 1] = q1; }
+  }
+  if (k.mode == 3) return;
+  // block sums (fixed order)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) qv[i] += __shfl_xor(qv[i], off, 64);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[i * 4 + wv] = qv[i];
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int i = threadIdx.x;
+    // slot p2: where the NEXT attempt launch (parity p2) looks for the sums pending on it, like the state sums
+    r.pq[((int64_t)p2 * ADJ_RBLOCKS + blockIdx.x) * 4 + i] = (red[i * 4] + red[i * 4 + 1]) + (red[i * 4 + 2] + red[i * 4 + 3]);
+  }
+}
+
+// dL/dW, dL/db from the running total in image layout.  Image of helper wave w, lane (n = l & 15, q = l >> 4): register
+// (Tm*2 + Tn)*4 + r = dW[h = 8w + 4(Tm>>1) + q][c = 4(Tm&1) + r][k = 16 Tn + n]; register 32 + Tm of the q == 0 lane =
+// the bias gradient of h = 8w + 4(Tm>>1) + (n>>2), c = 4(Tm&1) + (n&3).
+__global__ __launch_bounds__(256) void dopri5_adjoint_finish_kernel(const float* __restrict__ G, float* __restrict__ grad_W,
+                                                                    float* __restrict__ grad_b, Dims d) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   const int n_w = d.H * d.C * d.H, n_b = d.H * d.C;
   if (id >= n_w + n_b) return;
-  float sum = 0.f;
   if (id < n_w) {
-    const int k = id % d.H, hc = id / d.H, c = hc % d.C, h = hc / d.C;
-    const int w = h >> 3, Tm = 2 * ((h >> 2) & 1) + (c >> 2), q = h & 3, r = c & 3, Tn = k >> 4, n = k & 15;
-    const int at = (w * 64 + q * 16 + n) * ADJ_IMAGE + (Tm * 2 + Tn) * 4 + r;
-    for (int b = 0; b < n_wg; ++b) sum += tot[(int64_t)b * ADJ_IMAGE_FLOATS + at];
-    grad_W[id] = sum;
+    const int kk = id % d.H, hc = id / d.H, c = hc % d.C, h = hc / d.C;
+    const int w = h >> 3, Tm = 2 * ((h >> 2) & 1) + (c >> 2), q = h & 3, r = c & 3, Tn = kk >> 4, n = kk & 15;
+    grad_W[id] = G[(w * 64 + q * 16 + n) * ADJ_IMAGE + (Tm * 2 + Tn) * 4 + r];
   } else {
     const int hc = id - n_w, c = hc % d.C, h = hc / d.C;
     const int w = h >> 3, Tm = 2 * ((h >> 2) & 1) + (c >> 2), n = (h & 3) * 4 + (c & 3);
-    for (int b = 0; b < n_wg; ++b) {
-      float s = 0.f;
-      for (int q = 0; q < 4; ++q) s += tot[(int64_t)b * ADJ_IMAGE_FLOATS + (w * 64 + q * 16 + n) * ADJ_IMAGE + 32 + Tm];
-      sum += s;
-    }
-    grad_b[hc] = sum;
+    grad_b[hc] = G[(w * 64 + n) * ADJ_IMAGE + 32 + Tm];
   }
 }
 
@@ -550,67 +610,122 @@ static inline int adj_grid(int64_t B) { const int64_t t = (B + 15) / 16; return 
 }  // namespace cde
 
 // ================================================================================================ C ABI
-// workspace: [ctrl x2][partial sums][state 2x4xBxH][running totals][attempt images][trace]
-static size_t adj_off_partial() { return cde::a256(2 * sizeof(cde::DopriCtrl)); }
-static size_t adj_off_state() { return adj_off_partial() + cde::a256((size_t)2 * cde::ADJ_MAX_WG * 4 * sizeof(double)); }
-static size_t adj_off_tot(int64_t B, int64_t H) { return adj_off_state() + cde::a256((size_t)2 * 4 * B * H * sizeof(float)); }
-static size_t adj_off_att(int64_t B, int64_t H) {
-  return adj_off_tot(B, H) + cde::a256((size_t)cde::ADJ_MAX_WG * cde::ADJ_IMAGE_FLOATS * sizeof(float));
+// workspace: [ctrl x2][state sums][parameter sums][carry][state 2x4xBxH][G][G_local][prev A, D (x2, global + local)]
+//            [attempt images][reduced-sum scratch][trace]
+namespace {
+struct AdjLayout {
+  size_t partial, pq, carry, state, G, G_local, prev, att, trace, trace_all, total;
+};
+AdjLayout adj_layout(int64_t B, int64_t H) {
+  using namespace cde;
+  AdjLayout L;
+  L.partial = a256(2 * ADJ_CTRL_STRIDE);
+  L.pq = L.partial + a256((size_t)2 * ADJ_MAX_WG * ADJ_NS * sizeof(double));
+  L.carry = L.pq + a256((size_t)2 * ADJ_RBLOCKS * 4 * sizeof(double));
+  L.state = L.carry + 256;
+  L.G = L.state + a256((size_t)2 * 4 * B * H * sizeof(float));
+  L.G_local = L.G + a256((size_t)ADJ_IMAGE_FLOATS * sizeof(float));
+  L.prev = L.G_local + a256((size_t)ADJ_IMAGE_FLOATS * sizeof(float));
+  L.att = L.prev + a256((size_t)4 * ADJ_IMAGE_FLOATS * sizeof(float));        // prevS, prevS_local, each [2]
+  L.trace = L.att + a256((size_t)ADJ_MAX_WG * 2 * ADJ_IMAGE_FLOATS * sizeof(float));
+  L.trace_all = L.trace + a256((size_t)CDE_DOPRI5_TRACE_STEPS * 3 * sizeof(double));
+  L.total = L.trace_all + a256((size_t)ADJ_TRACE_ATTEMPTS * 5 * sizeof(double));
+  return L;
 }
+}  // namespace
+
 extern "C" size_t cde_dopri5_adjoint_trace_offset(int64_t B, int64_t C, int64_t H) {
   (void)C;
-  return adj_off_att(B, H) + cde::a256((size_t)cde::ADJ_MAX_WG * cde::ADJ_IMAGE_FLOATS * sizeof(float));
+  return adj_layout(B, H).trace;
 }
 extern "C" size_t cde_dopri5_adjoint_workspace_bytes(int64_t B, int64_t C, int64_t H) {
-  return cde_dopri5_adjoint_trace_offset(B, C, H) + cde::a256((size_t)CDE_DOPRI5_TRACE_STEPS * 3 * sizeof(double));
+  (void)C;
+  return adj_layout(B, H).total;
+}
+extern "C" size_t cde_dopri5_adjoint_attempt_trace_offset(int64_t B, int64_t C, int64_t H) {
+  (void)C;
+  return adj_layout(B, H).trace_all;
+}
+extern "C" size_t cde_dopri5_adjoint_status_stride(void) { return cde::ADJ_CTRL_STRIDE; }
+extern "C" size_t cde_dopri5_adjoint_reduced_count(void) { return (size_t)cde::ADJ_NS + 2 * (size_t)cde::ADJ_IMAGE_FLOATS; }
+
+static cde::AdjReduceArgs adj_reduce_args(unsigned char* base, const AdjLayout& L, int64_t B, double rtol, double atol,
+                                          bool sharded) {
+  using namespace cde;
+  AdjReduceArgs r;
+  r.ctrl = base; r.att = (const float*)(base + L.att); r.n_wg = adj_grid(B);
+  r.G = (float*)(base + L.G);
+  r.G_local = sharded ? (float*)(base + L.G_local) : nullptr;
+  float* prev = (float*)(base + L.prev);
+  r.prevS = prev; r.prevS_local = prev + 2 * ADJ_IMAGE_FLOATS;
+  r.pq = (double*)(base + L.pq);
+  r.partial = (const double*)(base + L.partial);
+  r.carry = (double*)(base + L.carry);
+  r.sums_out = nullptr; r.sums_in = nullptr;
+  r.rtol = (float)rtol; r.atol = (float)atol;
+  return r;
 }
 
 extern "C" int cde_dopri5_adjoint_advance(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
                                           const void* W, const void* bias, int act, const void* y_init,
                                           const void* a_init, double s0, double s1, const double* jump_s, int64_t n_jump,
                                           double rtol, double atol, double safety, double ifactor, double dfactor,
-                                          void* a_out, int64_t B, int64_t C, int64_t H, int dtype, int first_interval,
-                                          void* workspace, size_t workspace_bytes, int64_t first_launch,
-                                          int64_t n_launches, const double* reduced_sums, int64_t B_global,
-                                          void* stream) {
+                                          int norm_kind, void* a_out, int64_t B, int64_t C, int64_t H, int dtype,
+                                          int first_interval, void* workspace, size_t workspace_bytes,
+                                          int64_t first_launch, int64_t n_launches, const double* reduced_sums,
+                                          int64_t B_global, void* stream) {
   if (B < 1 || C < 1 || H < 1 || n_intervals < 1 || n_launches < 0 || n_jump < 0 || !(s0 < s1)) return CDE_ERR_SHAPE;
   if (dtype != CDE_F32) return dtype == CDE_F64 ? CDE_ERR_UNSUPPORTED : CDE_ERR_DTYPE;
   if (H > cde::MH || C > cde::MC) return CDE_ERR_UNSUPPORTED;
   if (act != CDE_ACT_NONE && act != CDE_ACT_TANH) return CDE_ERR_UNSUPPORTED;
   if (degree != CDE_PATH_CUBIC && degree != CDE_PATH_LINEAR) return CDE_ERR_UNSUPPORTED;
+  if (norm_kind != 0 && norm_kind != 1) return CDE_ERR_UNSUPPORTED;
   if (!coeffs || !knots || !W || !bias || !y_init || !a_init || !a_out || !workspace) return CDE_ERR_NULL;
   if (n_jump > 0 && !jump_s) return CDE_ERR_NULL;
   if (workspace_bytes < cde_dopri5_adjoint_workspace_bytes(B, C, H)) return CDE_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   unsigned char* base = (unsigned char*)workspace;
+  const AdjLayout L = adj_layout(B, H);
+  const bool sharded = reduced_sums != nullptr || B_global > 0;
   cde::DopriAdjArgs g;
   g.coeffs = (const float*)coeffs; g.knots = (const float*)knots; g.n_intervals = n_intervals;
   g.W = (const float*)W; g.bias = (const float*)bias; g.dims = cde::Dims{(int)H, (int)C};
   g.B = B; g.n_tiles = (B + 15) / 16;
-  g.ctrl = (cde::DopriCtrl*)base;
-  g.partial = (double*)(base + adj_off_partial());
-  g.state = (float*)(base + adj_off_state());
-  g.tot = (float*)(base + adj_off_tot(B, H));
-  g.att = (float*)(base + adj_off_att(B, H));
-  g.trace = (double*)(base + cde_dopri5_adjoint_trace_offset(B, C, H));
+  g.ctrl = base;
+  g.partial = (double*)(base + L.partial);
+  g.pq = (double*)(base + L.pq);
+  g.state = (float*)(base + L.state);
+  g.att = (float*)(base + L.att);
   g.y_init = (const float*)y_init; g.a_init = (const float*)a_init; g.a_out = (float*)a_out;
-  g.s0 = s0; g.s1 = s1; g.jump_s = jump_s; g.n_jump = n_jump;
-  g.rtol = rtol; g.atol = atol; g.safety = safety; g.ifactor = ifactor; g.dfactor = dfactor;
-  g.ext_sums = reduced_sums; g.B_global = B_global;
-  if (reduced_sums && (n_launches != 1 || B_global < B)) return CDE_ERR_SHAPE;      // sharded: one launch per all-reduce
+  g.com.s0 = s0; g.com.s1 = s1; g.com.jump_s = jump_s; g.com.n_jump = n_jump;
+  g.com.rtol = rtol; g.com.atol = atol; g.com.safety = safety; g.com.ifactor = ifactor; g.com.dfactor = dfactor;
+  g.com.n_state = (B_global > 0 ? B_global : B) * H;
+  g.com.n_pt = 2; g.com.n_param[0] = H * C * H; g.com.n_param[1] = H * C; g.com.n_param[2] = g.com.n_param[3] = 1;
+  g.com.norm_kind = norm_kind;
+  g.com.trace = (double*)(base + L.trace);
+  g.com.trace_all = (double*)(base + L.trace_all);
+  g.com.carry = (double*)(base + L.carry);
+  g.ext_sums = reduced_sums;
+  if (sharded && (n_launches != 1 || B_global < B)) return CDE_ERR_SHAPE;      // sharded: one launch per all-reduce
+  if (first_launch > 0 && sharded && !reduced_sums) return CDE_ERR_NULL;
   const int grid = cde::adj_grid(B);
   if (first_launch == 0) {
-    if (hipMemsetAsync(g.ctrl, 0, 2 * sizeof(cde::DopriCtrl), s) != hipSuccess) return CDE_ERR_LAUNCH;     // phase 0
+    if (hipMemsetAsync(base, 0, 2 * cde::ADJ_CTRL_STRIDE, s) != hipSuccess) return CDE_ERR_LAUNCH;     // phase 0
     if (first_interval &&
-        hipMemsetAsync(g.tot, 0, (size_t)cde::ADJ_MAX_WG * cde::ADJ_IMAGE_FLOATS * sizeof(float), s) != hipSuccess)
+        (hipMemsetAsync(base + L.carry, 0, 256, s) != hipSuccess ||
+         hipMemsetAsync(base + L.G, 0, L.att - L.G, s) != hipSuccess))           // G, G_local, the prev buffers
       return CDE_ERR_LAUNCH;
   }
+  cde::AdjReduceArgs r = adj_reduce_args(base, L, B, rtol, atol, sharded);
 #define CDE_ADJ(D, A)                                                                                                \
   do {                                                                                                               \
     (void)hipFuncSetAttribute((const void*)cde::dopri5_adjoint_attempt<D, A>,                                        \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)cde::ADJ_LDS_BYTES);                  \
-    for (int64_t i = 0; i < n_launches; ++i)                                                                         \
-      cde::dopri5_adjoint_attempt<D, A><<<grid, 512, cde::ADJ_LDS_BYTES, s>>>(g, (int)((first_launch + i) & 1));     \
+    for (int64_t i = 0; i < n_launches; ++i) {                                                                       \
+      const int parity = (int)((first_launch + i) & 1);                                                              \
+      cde::dopri5_adjoint_attempt<D, A><<<grid, 512, cde::ADJ_LDS_BYTES, s>>>(g, parity);                            \
+      if (!sharded) cde::adjoint_reduce_kernel<<<cde::ADJ_RBLOCKS, 256, 0, s>>>(r, parity, 0);                       \
+    }                                                                                                                \
   } while (0)
   if (act == CDE_ACT_NONE) {
     if (degree == CDE_PATH_CUBIC) CDE_ADJ(CDE_PATH_CUBIC, CDE_ACT_NONE); else CDE_ADJ(CDE_PATH_LINEAR, CDE_ACT_NONE);
@@ -621,35 +736,59 @@ extern "C" int cde_dopri5_adjoint_advance(const void* coeffs, const void* knots,
   return cde::check_launch();
 }
 
-// sharded batches (one controller for all shards): this shard's 4 pending sums, to be all-reduced before the next launch
+// sharded batches (one controller for all shards), after the single attempt launch `total_launches - 1`: this shard's
+// pending sums -- ADJ_NS state sums, then the S and E gradient images (cde_dopri5_adjoint_reduced_count() doubles) -- to
+// be all-reduced (sum) over the shards and handed to cde_dopri5_adjoint_apply_reduced and to the next advance call.
 __global__ __launch_bounds__(64) void dopri_adjoint_pending_sums_kernel(const double* __restrict__ partial, int n_wg,
                                                                         double* __restrict__ out) {
-  const int k = threadIdx.x;
-  if (k >= 4) return;
+  const int i = threadIdx.x;
+  if (i >= cde::ADJ_NS) return;
   double s = 0.0;
-  for (int b = 0; b < n_wg; ++b) s += partial[4 * b + k];
-  out[k] = s;
+  for (int b = 0; b < n_wg; ++b) s += partial[cde::ADJ_NS * b + i];
+  out[i] = s;
 }
 
-extern "C" int cde_dopri5_adjoint_pending_sums(const void* workspace, size_t workspace_bytes, int64_t B, int64_t C,
+extern "C" int cde_dopri5_adjoint_pending_sums(void* workspace, size_t workspace_bytes, int64_t B, int64_t C,
                                                int64_t H, int64_t total_launches, double* sums, void* stream) {
-  if (B < 1 || C < 1 || H < 1) return CDE_ERR_SHAPE;
+  if (B < 1 || C < 1 || H < 1 || total_launches < 1) return CDE_ERR_SHAPE;
   if (!workspace || !sums) return CDE_ERR_NULL;
   if (workspace_bytes < cde_dopri5_adjoint_workspace_bytes(B, C, H)) return CDE_ERR_WORKSPACE;
-  const double* partial = (const double*)((const unsigned char*)workspace + adj_off_partial()) +
-                          (total_launches & 1) * cde::ADJ_MAX_WG * 4;
-  dopri_adjoint_pending_sums_kernel<<<1, 64, 0, (hipStream_t)stream>>>(partial, cde::adj_grid(B), sums);
+  unsigned char* base = (unsigned char*)workspace;
+  const AdjLayout L = adj_layout(B, H);
+  const int parity = (int)((total_launches - 1) & 1);               // the launch whose sums are pending
+  const double* partial = (const double*)(base + L.partial) + (int64_t)(parity ^ 1) * cde::ADJ_MAX_WG * cde::ADJ_NS;
+  hipStream_t s = (hipStream_t)stream;
+  dopri_adjoint_pending_sums_kernel<<<1, 64, 0, s>>>(partial, cde::adj_grid(B), sums);
+  cde::AdjReduceArgs r = adj_reduce_args(base, L, B, 0.0, 0.0, true);
+  r.sums_out = sums + cde::ADJ_NS;
+  cde::adjoint_reduce_kernel<<<cde::ADJ_RBLOCKS, 256, 0, s>>>(r, parity, 1);
+  return cde::check_launch();
+}
+
+// ... and after the all-reduce: commit / norms with the reduced images (every shard holds the same ones)
+extern "C" int cde_dopri5_adjoint_apply_reduced(void* workspace, size_t workspace_bytes, int64_t B, int64_t C, int64_t H,
+                                                double rtol, double atol, int64_t total_launches,
+                                                const double* reduced, void* stream) {
+  if (B < 1 || C < 1 || H < 1 || total_launches < 1) return CDE_ERR_SHAPE;
+  if (!workspace || !reduced) return CDE_ERR_NULL;
+  if (workspace_bytes < cde_dopri5_adjoint_workspace_bytes(B, C, H)) return CDE_ERR_WORKSPACE;
+  unsigned char* base = (unsigned char*)workspace;
+  const AdjLayout L = adj_layout(B, H);
+  cde::AdjReduceArgs r = adj_reduce_args(base, L, B, rtol, atol, true);
+  r.sums_in = reduced;
+  cde::adjoint_reduce_kernel<<<cde::ADJ_RBLOCKS, 256, 0, (hipStream_t)stream>>>(r, (int)((total_launches - 1) & 1), 2);
   return cde::check_launch();
 }
 
 extern "C" int cde_dopri5_adjoint_finish(const void* workspace, size_t workspace_bytes, void* grad_W, void* grad_b,
-                                         int64_t B, int64_t C, int64_t H, void* stream) {
+                                         int64_t B, int64_t C, int64_t H, int sharded, void* stream) {
   if (B < 1 || C < 1 || H < 1 || H > cde::MH || C > cde::MC) return CDE_ERR_SHAPE;
   if (!workspace || !grad_W || !grad_b) return CDE_ERR_NULL;
   if (workspace_bytes < cde_dopri5_adjoint_workspace_bytes(B, C, H)) return CDE_ERR_WORKSPACE;
-  const float* tot = (const float*)((const unsigned char*)workspace + adj_off_tot(B, H));
+  const AdjLayout L = adj_layout(B, H);
+  const float* G = (const float*)((const unsigned char*)workspace + (sharded ? L.G_local : L.G));
   const int n = (int)(H * C * H + H * C);
-  cde::dopri5_adjoint_finish_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(tot, cde::adj_grid(B), (float*)grad_W,
-                                                                                     (float*)grad_b, cde::Dims{(int)H, (int)C});
+  cde::dopri5_adjoint_finish_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(G, (float*)grad_W, (float*)grad_b,
+                                                                                     cde::Dims{(int)H, (int)C});
   return cde::check_launch();
 }
