@@ -434,6 +434,29 @@ int cde_dopri5_adjoint_apply_reduced(void* workspace, size_t workspace_bytes, in
 int cde_dopri5_adjoint_finish(const void* workspace, size_t workspace_bytes, void* grad_W, void* grad_b, int64_t B,
                               int64_t C, int64_t H, int sharded, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * K4am  K4a for the two-layer field Linear(H, width) -> relu -> Linear(width, H*C) -> tanh | identity of the reference's
+ * examples (example/time_series_classification.py:20-51; their training call is cdeint(X, func, z0, X.interval): dopri5
+ * with adjoint=True, :83-86).  f32, width <= 128, (H <= 32, C <= 8) or (H <= 16, C <= 16).  Same protocol, controller,
+ * norms (norm_kind) and status / trace blocks as cde_dopri5_adjoint_advance; per attempted step it queues the attempt
+ * kernel, the split-K reduction of the attempt's gradient factors (both layers) and the commit / norm kernel.
+ * The running parameter gradients live in the workspace at cde_dopri5_adjoint_mlp_gradient_offset():
+ *   layer 2 as float [256][129]: row = the padded (hidden unit, channel) index (32 x 8 or 16 x 16 units x channels),
+ *           columns 0..width-1 = dL/dW2, column 128 = dL/db2;   then layer 1 as float [128][33]: row = hidden-layer
+ *           unit, columns 0..H-1 = dL/dW1, column 32 = dL/db1.
+ * cde_dopri5_adjoint_mlp_trace_offset(which = 0 accepted steps | 1 every attempt) as for K4a.
+ * ------------------------------------------------------------------------------------------- */
+size_t cde_dopri5_adjoint_mlp_workspace_bytes(int64_t B, int64_t C, int64_t H);
+size_t cde_dopri5_adjoint_mlp_trace_offset(int64_t B, int64_t C, int64_t H, int which);
+size_t cde_dopri5_adjoint_mlp_gradient_offset(int64_t B, int64_t C, int64_t H);
+int cde_dopri5_adjoint_mlp_advance(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W1,
+                                   const void* bias1, int64_t width, const void* W2, const void* bias2, int act,
+                                   const void* y_init, const void* a_init, double s0, double s1, const double* jump_s,
+                                   int64_t n_jump, double rtol, double atol, double safety, double ifactor,
+                                   double dfactor, int norm_kind, void* a_out, int64_t B, int64_t C, int64_t H, int dtype,
+                                   int first_interval, void* workspace, size_t workspace_bytes, int64_t first_launch,
+                                   int64_t n_launches, void* stream);
+
 /* Sharded batches under ONE step controller -- torchdiffeq's semantics for the whole batch when the batch lives on
  * several GPUs.  Per attempted step every shard (1) calls cde_dopri5_pending_sums(total_launches so far) -> 2 doubles on
  * the device, (2) all-reduces them (sum) with the other shards, (3) runs ONE launch through cde_dopri5_advance_sharded

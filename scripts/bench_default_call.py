@@ -1,11 +1,14 @@
 """The training call of the reference's example model (example/time_series_classification.py: two-layer field,
-cdeint without `method`: dopri5 forward + adjoint) on the step-wise path.  python scripts/bench_default_call.py [B] [seminorm]"""
+cdeint without `method`: dopri5 forward + adjoint).  Fused since round 3 (K4 forward, K4am backward); `stepwise` as a
+third argument forces the host-driven path of round 2.  python scripts/bench_default_call.py [B] [seminorm|mixed] [stepwise]"""
 import sys, time, torch
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import torchcde_amd as cde
 from helpers import make_series
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 extra = dict(adjoint_options=dict(norm="seminorm")) if len(sys.argv) > 2 and sys.argv[2] == "seminorm" else {}
+if len(sys.argv) > 3 and sys.argv[3] == "stepwise":
+    extra["variant"] = "generic"
 L, C, H = 128, 8, 32
 dev = torch.device("cuda", 0)
 class TwoLayer(torch.nn.Module):
@@ -26,8 +29,14 @@ for rep in range(2):
     z = z0.clone().requires_grad_(True)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     out = cde.cdeint(X, func, z, X.interval, **extra)  # the example's call: default dopri5, adjoint=True
+    path = type(out.grad_fn).__name__
     torch.cuda.synchronize(); t1 = time.perf_counter()
     nf = func.n
     out[:, -1].sum().backward()
     torch.cuda.synchronize(); t2 = time.perf_counter()
-    print("B=%d forward %.3f s (%d evals), backward %.3f s (%d evals)" % (B, t1 - t0, nf, t2 - t1, func.n - nf), flush=True)
+    front = sys.modules["torchcde_amd.cdeint"]
+    st = dict(front.last_dopri5_adjoint_stats) if path == "_FusedMlpDopri5Backward" else {}
+    attempts = st.get("n_accept", 0) + st.get("n_reject", 0)
+    print("B=%d %s forward %.4f s (%s), backward %.4f s (%d accepted + %d rejected attempts, %.1f us per attempt)"
+          % (B, path, t1 - t0, dict(front.last_dopri5_stats) if st else "%d evals" % nf, t2 - t1, st.get("n_accept", 0),
+             st.get("n_reject", 0), (t2 - t1) * 1e6 / max(attempts, 1)), flush=True)

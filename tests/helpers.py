@@ -41,3 +41,25 @@ def golden_field(case, dtype=None, device="cpu"):
         f.linear.weight.copy_(case["W"])
         f.linear.bias.copy_(case["b"])
     return f.to(device)
+
+
+class TwoLayerField(torch.nn.Module):
+    """reference example/time_series_classification.py:20-51"""
+
+    def __init__(self, H, C, width, dtype=torch.float32, seed=0, final_tanh=True):
+        super().__init__()
+        self.H, self.C, self.final_tanh = H, C, final_tanh
+        gen = torch.Generator().manual_seed(seed)
+        self.linear1 = torch.nn.Linear(H, width).to(dtype)
+        self.linear2 = torch.nn.Linear(width, H * C).to(dtype)
+        with torch.no_grad():
+            for lin in (self.linear1, self.linear2):
+                bound = 1 / lin.in_features ** 0.5
+                lin.weight.copy_((torch.rand(lin.weight.shape, generator=gen, dtype=torch.float64) * 2 - 1) * bound)
+                lin.bias.copy_((torch.rand(lin.bias.shape, generator=gen, dtype=torch.float64) * 2 - 1) * bound)
+
+    def forward(self, t, z):
+        y = self.linear2(self.linear1(z).relu())
+        if self.final_tanh:
+            y = y.tanh()
+        return y.view(*z.shape[:-1], self.H, self.C)

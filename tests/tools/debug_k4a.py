@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from helpers import LinearField, make_series  # noqa: E402
+from helpers import LinearField, TwoLayerField, make_series  # noqa: E402
 from oracle import cde as oracle_cde, interp as oracle_interp, odeint as oracle_ode  # noqa: E402
 import torchcde_amd as native  # noqa: E402
 
@@ -26,7 +26,26 @@ CASES = {
                            kw=dict(rtol=1e-4, atol=1e-6), adj=dict(adjoint_options=dict(norm="seminorm"))),
     "cubic_identity_loose": dict(B=64, L=12, C=8, H=32, tanh=False, degree=3, t_out=[0., 11.], jumps=False,
                                  kw=dict(rtol=1e-3, atol=1e-5), adj={}),
+    # two-layer fields (K4am): width, final tanh
+    "mlp_cubic": dict(B=70, L=10, C=8, H=32, tanh=True, degree=3, t_out=None, jumps=False, kw=dict(rtol=1e-4, atol=1e-6),
+                      adj={}, width=128),
+    "mlp_linear_jumps_multi": dict(B=150, L=9, C=4, H=16, tanh=True, degree=1, t_out=[0., 3.5, 8.], jumps=True,
+                                   kw=dict(rtol=1e-4, atol=1e-6), adj={}, width=64),
+    "mlp_16x16_seminorm": dict(B=40, L=8, C=14, H=8, tanh=True, degree=1, t_out=None, jumps=False,
+                               kw=dict(rtol=1e-4, atol=1e-6), adj=dict(adjoint_options=dict(norm="seminorm")), width=128),
+    "mlp_identity_many_tiles": dict(B=2100, L=7, C=3, H=8, tanh=False, degree=3, t_out=None, jumps=False,
+                                    kw=dict(rtol=1e-3, atol=1e-5), adj={}, width=100),
 }
+
+
+def make_field(cfg, dtype):
+    if "width" in cfg:
+        return TwoLayerField(cfg["H"], cfg["C"], cfg["width"], dtype, seed=3, final_tanh=cfg["tanh"])
+    return LinearField(cfg["H"], cfg["C"], dtype, scale=0.3, tanh=cfg["tanh"], seed=7)
+
+
+def params_of(f):
+    return [p for _, p in f.named_parameters()]
 
 
 def run(name):
@@ -39,7 +58,7 @@ def run(name):
     t_out = None if cfg["t_out"] is None else torch.tensor(cfg["t_out"])
     n_t = 2 if t_out is None else t_out.numel()
     lw = torch.rand(B, n_t, H, generator=torch.Generator().manual_seed(3)) + 0.5
-    func = LinearField(H, C, scale=0.3, tanh=cfg["tanh"], seed=7).to(DEV)
+    func = make_field(cfg, torch.float32).to(DEV)
     X = (native.CubicSpline(native.hermite_cubic_coefficients_with_backward_differences(x.to(DEV))) if cfg["degree"] == 3
          else native.LinearInterpolation(native.linear_interpolation_coeffs(x.to(DEV))))
     zd = z0.to(DEV).requires_grad_(True)
@@ -48,6 +67,7 @@ def run(name):
     front.record_dopri5_steps = True
     try:
         out = native.cdeint(X, func, zd, times, **opts, **cfg["adj"], **cfg["kw"])
+        print("   grad_fn:", type(out.grad_fn).__name__)
         fwd = dict(front.last_dopri5_stats)
         (out * lw.to(DEV)).sum().backward()
         bwd = dict(front.last_dopri5_adjoint_stats)
@@ -67,7 +87,7 @@ def run(name):
 
     oracle_ode._Dopri5.integrate = integrate
     try:
-        f64 = LinearField(H, C, torch.float64, scale=0.3, tanh=cfg["tanh"], seed=7)
+        f64 = make_field(cfg, torch.float64)
         Xo = (oracle_interp.CubicPath(oracle_interp.hermite_bdiff_coeffs(x.double())) if cfg["degree"] == 3
               else oracle_interp.LinearPath(x.double()))
         zo = z0.double().requires_grad_(True)
@@ -104,8 +124,8 @@ def run(name):
         print("  %-8s max abs err %.3g  (scale %.3g)" % (label, (got - want).abs().max(), want.abs().max()))
     show("z", out, ref)
     show("dz0", zd.grad, zo.grad)
-    show("dW", func.linear.weight.grad, f64.linear.weight.grad)
-    show("db", func.linear.bias.grad, f64.linear.bias.grad)
+    for (name_p, p_gpu), p_ref in zip(func.named_parameters(), params_of(f64)):
+        show(name_p, p_gpu.grad, p_ref.grad)
 
 
 if __name__ == "__main__":

@@ -14,9 +14,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libcde_mi355x.so")
 SOURCES = ["interp_kernels.hip", "rk4_generic.hip", "rk4_mfma.hip", "rk4_split.hip", "rk4_wide.hip", "rk4_mlp_adjoint.hip",
-           "dopri5.hip", "dopri5_adjoint.hip", "mlp_grad_reduce.hip", "api.hip"]
+           "dopri5.hip", "dopri5_adjoint.hip", "dopri5_mlp_adjoint.hip", "mlp_grad_reduce.hip", "api.hip"]
 HEADERS = [os.path.join(_CSRC, "cde_common.h"), os.path.join(_CSRC, "cde_mfma.h"), os.path.join(_CSRC, "cde_split.h"),
-           os.path.join(_CSRC, "cde_dopri.h"),
+           os.path.join(_CSRC, "cde_dopri.h"), os.path.join(_CSRC, "cde_dopri_adj.h"), os.path.join(_CSRC, "cde_mlp_adj.h"),
            os.path.join(_HERE, "..", "include", "cde_mi355x.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC"]
 # per-file additions.  rk4_split.hip: keep MFMA accumulators in VGPRs -- its tiles are consumed by VALU code right
@@ -112,6 +112,11 @@ _SIGNATURES = {
                                     _p, _i64, _i64, _i64, _i, _p, _sz, _i64, _i64, _p]),
     "cde_dopri5_adjoint_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "cde_dopri5_adjoint_trace_offset": (_sz, [_i64, _i64, _i64]),
+    "cde_dopri5_adjoint_mlp_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "cde_dopri5_adjoint_mlp_trace_offset": (_sz, [_i64, _i64, _i64, _i]),
+    "cde_dopri5_adjoint_mlp_gradient_offset": (_sz, [_i64, _i64, _i64]),
+    "cde_dopri5_adjoint_mlp_advance": (_i, [_p, _p, _i64, _i, _p, _p, _i64, _p, _p, _i, _p, _p, _d, _d, _p, _i64, _d, _d, _d,
+                                            _d, _d, _i, _p, _i64, _i64, _i64, _i, _i, _p, _sz, _i64, _i64, _p]),
     "cde_dopri5_adjoint_status_stride": (_sz, []),
     "cde_dopri5_adjoint_attempt_trace_offset": (_sz, [_i64, _i64, _i64]),
     "cde_dopri5_adjoint_reduced_count": (_sz, []),

@@ -641,6 +641,73 @@ class _Dopri5Plan:
             last_dopri5_adjoint_stats["attempts"] = attempts     # (t0, t1, on_jump, accepted, ratio) of EVERY attempt
         return a, grad_w, grad_b
 
+    def run_adjoint_mlp(self, z_saved, grad_out, w1, b1, w2, b2):
+        """K4am: the same backward for the two-layer field (csrc/dopri5_mlp_adjoint.hip): per attempted step the attempt
+        kernel, the split-K reduction of its gradient factors and the commit / norm kernel, queued by one C-ABI call."""
+        lib = _lib.load()
+        B, H, C, dev = self.B, self.H, self.C, self.device
+        z_saved = z_saved.detach().reshape(B, self.n_out, H)
+        grad_out = grad_out.detach().reshape(B, self.n_out, H).to(torch.float32)
+        w1, b1, w2, b2 = (p.detach().contiguous() for p in (w1, b1, w2, b2))
+        width = w1.size(0)
+        a = grad_out[:, -1].contiguous()
+        if self.n_out == 1:
+            return a, torch.zeros_like(w1), torch.zeros_like(b1), torch.zeros_like(w2), torch.zeros_like(b2)
+        nbytes = lib.cde_dopri5_adjoint_mlp_workspace_bytes(B, C, H)
+        workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        workspace[:_WORKSPACE_HEAD].zero_()
+        size = ctypes.sizeof(_lib.DopriStatus)
+        stride = lib.cde_dopri5_adjoint_status_stride()
+        a_out = torch.empty(B, H, dtype=torch.float32, device=dev)
+        stream = _lib.stream_ptr(dev)
+        stats = dict(n_accept=0, n_reject=0, launches=0)
+        steps, attempts = [], []
+        for i in range(self.n_out - 1, 0, -1):
+            y = z_saved[:, i].contiguous()
+            s0, s1 = -float(self.t_host[i]), -float(self.t_host[i - 1])
+            launched = 0
+            while True:
+                _lib.check(lib.cde_dopri5_adjoint_mlp_advance(
+                    _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w1), _lib.ptr(b1),
+                    width, _lib.ptr(w2), _lib.ptr(b2), self.act, _lib.ptr(y), _lib.ptr(a), s0, s1, _lib.ptr(self.jump_s),
+                    self.n_jump_s, self.adjoint_rtol, self.adjoint_atol, self.adj_safety, self.adj_ifactor,
+                    self.adj_dfactor, self.adj_norm_kind, _lib.ptr(a_out), B, C, H, _lib.dtype_enum(torch.float32),
+                    int(i == self.n_out - 1), _lib.ptr(workspace), workspace.numel(), launched, _DOPRI_CHUNK, stream),
+                    "cde_dopri5_adjoint_mlp_advance")
+                launched += _DOPRI_CHUNK
+                at = (launched & 1) * stride
+                status = _lib.DopriStatus.from_buffer_copy(workspace[at:at + size].cpu().numpy().tobytes())
+                if status.phase == 4:
+                    break
+                if launched > 2_000_000:
+                    raise RuntimeError("torchcde_amd: the dopri5 adjoint did not reach t = %g after %d attempted steps"
+                                       % (-s1, launched))
+            stats["n_accept"] += status.n_accept
+            stats["n_reject"] += status.n_reject
+            stats["launches"] += launched
+            if record_dopri5_steps:
+                off = lib.cde_dopri5_adjoint_mlp_trace_offset(B, C, H, 0)
+                n = min(status.n_accept, 4096)
+                steps.append(workspace[off:off + 24 * n].view(torch.float64).view(n, 3).cpu())
+                off = lib.cde_dopri5_adjoint_mlp_trace_offset(B, C, H, 1)
+                n = min(status.n_accept + status.n_reject, 16384)
+                attempts.append(workspace[off:off + 40 * n].view(torch.float64).view(n, 5).cpu())
+            a = a_out + grad_out[:, i - 1]
+        off = lib.cde_dopri5_adjoint_mlp_gradient_offset(B, C, H)
+        totals = workspace[off:off + 4 * (256 * 129 + 128 * 33)].view(torch.float32)
+        acc2, acc1 = totals[:256 * 129].view(256, 129), totals[256 * 129:].view(128, 33)
+        units, channels = (32, 8) if C <= 8 else (16, 16)        # padded (hidden unit, channel) layout of the layer-2 rows
+        grad_w2 = acc2[:, :width].reshape(units, channels, width)[:H, :C].reshape(H * C, width)
+        grad_b2 = acc2[:, 128].reshape(units, channels)[:H, :C].reshape(H * C)
+        grad_w1 = acc1[:width, :H].contiguous()
+        grad_b1 = acc1[:width, 32].contiguous()
+        last_dopri5_adjoint_stats.clear()
+        last_dopri5_adjoint_stats.update(stats)
+        if record_dopri5_steps:
+            last_dopri5_adjoint_stats["steps"] = steps
+            last_dopri5_adjoint_stats["attempts"] = attempts
+        return a, grad_w1, grad_b1, grad_w2, grad_b2
+
     def run(self, z0, weight, bias):
         lib = _lib.load()
         out = torch.empty(self.B, self.n_out, self.H, dtype=self.dtype, device=self.device)
@@ -711,6 +778,27 @@ class _FusedDopri5(torch.autograd.Function):
         return (grad_z0.reshape(*plan.batch, plan.H) if ctx.needs_input_grad[0] else None,
                 grad_w.view_as(weight) if (ctx.needs_input_grad[1] and want_w) else None,
                 grad_b.view_as(bias) if (ctx.needs_input_grad[2] and want_b) else None, None, None)
+
+
+class _FusedMlpDopri5(torch.autograd.Function):
+    """The reference examples' training call with their own model: cdeint(X, CDEFunc, z0, X.interval) -- dopri5 forward
+    (K4 with the two-layer field) and torchdiffeq's adaptive adjoint backward (K4am)."""
+
+    @staticmethod
+    def forward(ctx, z0, w1, b1, w2, b2, plan):
+        out = plan.run(z0, w2, b2)
+        ctx.plan = plan
+        ctx.save_for_backward(out, w1, b1, w2, b2)
+        return out.reshape(*plan.batch, plan.n_out, plan.H)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        out, w1, b1, w2, b2 = ctx.saved_tensors
+        plan = ctx.plan
+        grad_z0, gw1, gb1, gw2, gb2 = plan.run_adjoint_mlp(out, grad_out, w1, b1, w2, b2)
+        need = ctx.needs_input_grad
+        return (grad_z0.reshape(*plan.batch, plan.H) if need[0] else None, gw1 if need[1] else None,
+                gb1 if need[2] else None, gw2 if need[3] else None, gb2 if need[4] else None, None)
 
 
 # ------------------------------------------------------------------------------------------ front end
@@ -938,6 +1026,18 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
             control_inputs = X._control_buffers() if mlp_want_x else ()
             return _FusedMlpRK4.apply(z0, mlp.hidden.weight, mlp.hidden.bias, mlp.output.weight, mlp.output.bias, plan,
                                       mlp_want_x, *control_inputs)
+    if (mlp is not None and wants_grad and not wants_t and adjoint and method == "dopri5" and not mlp_want_x
+            and variant != _lib.VARIANT_GENERIC and adj_opts_ok and kwargs.get("adjoint_method") in (None, "dopri5")
+            and set(options or ()) <= {"jump_t", "safety", "ifactor", "dfactor"}
+            and (given_params is None or mlp_params_ok)
+            and isinstance(t, torch.Tensor) and t.dim() == 1 and t.is_floating_point() and t.numel() >= 1):
+        # two-layer field, the reference examples' own training call (no method: dopri5 + adjoint): K4 forward, K4am backward
+        from .distributed import step_control
+        t_host = _to_host(t)
+        if (t_host.numel() == 1 or bool((t_host[1:] > t_host[:-1]).all())) and step_control() is None:
+            plan = _Dopri5Plan(X, mlp, batch, H, C, t, kwargs["rtol"], kwargs["atol"], options, variant,
+                               kwargs.get("adjoint_rtol"), kwargs.get("adjoint_atol"), adj_opts)
+            return _FusedMlpDopri5.apply(z0, mlp.hidden.weight, mlp.hidden.bias, mlp.output.weight, mlp.output.bias, plan)
     if (mlp is not None and not wants_grad and variant != _lib.VARIANT_GENERIC
             and isinstance(t, torch.Tensor) and t.dim() == 1 and t.is_floating_point() and t.numel() >= 1):
         # two-layer field, nothing to differentiate: the fused forward kernels (K2m / K4 with the two-layer field)

@@ -1,0 +1,167 @@
+// cde_mlp_adj.h -- what the two adjoint kernels of the two-layer field share (K3m: rk4_mlp_adjoint.hip, fixed grid;
+// K4am: dopri5_mlp_adjoint.hip, adaptive): the LDS / image layout of rk4_mlp_adjoint.hip (see that file's header for the
+// bank-conflict analysis of the plain W2 copy), the factor-row layout, and the stage evaluation as a function.
+#pragma once
+#include "cde_mfma.h"
+
+namespace cde {
+
+constexpr int W2P_STRIDE = 132;                           // floats per row of the plain W2 copy
+constexpr int W2P_FLOATS = 256 * W2P_STRIDE;
+constexpr int W1T_FLOATS = 2 * 8 * 64 * 4;                // [tile][T1][lane][4]
+constexpr int ADJ_LDS_FLOATS = W1M_FLOATS + B1M_FLOATS + W2P_FLOATS + BY_FLOATS;   // [W1 image | b1 | W2 plain | b2]
+constexpr int MLP_ADJ_IMAGE_FLOATS = ADJ_LDS_FLOATS + W1T_FLOATS;
+// h3 = h&3 enters bit-reversed so that the four lane quarters of a gu read are shifted by 0, 16, 8, 24 banks: the LDS
+// serves a b32 read in two half-waves (lanes 0-31 = quarters 0,1; lanes 32-63 = quarters 2,3) and each half must
+// cover 32 distinct banks.  (With shifts 0, 8, 16, 24 rocprofv3 counted 1.3e8 SQ_LDS_BANK_CONFLICT cycles per launch.)
+__host__ __device__ constexpr int w2p_residue(int h3, int c3) { return (2 * (((h3 & 1) << 1) | (h3 >> 1)) + c3) & 7; }
+constexpr int U_COLS = 132, G2_COLS = 256, G1_COLS = 128, Z_COLS = 36;
+
+__device__ __forceinline__ void stream_store4(float* p, float a, float b, float c, float d) {
+  // written once, read once by the GEMM much later: keep it out of the way of the L2-resident weight images
+  __builtin_nontemporal_store(f32x4{a, b, c, d}, reinterpret_cast<f32x4*>(p));
+}
+
+
+// One evaluation of the augmented dynamics of the two-layer field for the 16 series of a wave (lane (n, q) owns hidden
+// units q, 4+q, .., 28+q of z and a): f = F(z) dX, va = a^T dF/dz dX, and -- when `stream` -- the UNWEIGHTED factors of
+// the parameter gradients of this evaluation, one row per series:
+//     U  [132]  relu(W1 z + b1) | 1 | 0 0 0        G2 [256]  dL/dY2 = a_h dX_c act'(Y2)   (padded (h, c) layout)
+//     Z  [36]   z | 1 | 0 0 0                      G1 [128]  dL/dY1
+// (the "1" columns are written once by the host; dW2 | db2 = G2^T U, dW1 | db1 = G1^T Z).  The body is K3m's (same
+// MFMA order, same LDS reads); TGRAD adds kt = a . (F(z) d2X/dt2), the slope of vjp_t (cde_dopri_adj.h).
+template <int ACT, int CT, bool TGRAD>
+__device__ __forceinline__ void mlp_adjoint_eval(const float* lds_base, const float4* w1t_base, int lane, int n, int q,
+                                                 int w2y_off, const int (&w2g_off)[4], const float (&zs)[8],
+                                                 const float (&as)[8], const float (&dX)[CT], const float (&d2X)[CT],
+                                                 bool stream, float* urow, float* zrow, float* g2row, float* g1row, int Hr,
+                                                 f32x4& fa, f32x4& fb, f32x4& va, f32x4& vb, float& kt) {
+  constexpr int NB = CT / 4, NP = 16 / NB;      // channel blocks per unit group, unit groups (of 4 hidden units)
+  int opaque = 0;                                                // keeps the LDS reads inside the evaluation
+  asm volatile("" : "+v"(opaque));
+  const float4* w1 = reinterpret_cast<const float4*>(lds_base) + lane + opaque;
+  const float4* bb1 = reinterpret_cast<const float4*>(lds_base + W1M_FLOATS) + q + opaque;
+  const float* w2p = lds_base + W1M_FLOATS + B1M_FLOATS + opaque;
+  const float4* bb2 = reinterpret_cast<const float4*>(lds_base + W1M_FLOATS + B1M_FLOATS + W2P_FLOATS) + q + opaque;
+  const float* w2y = w2p + w2y_off;
+  const float* w2g[4] = {w2p + w2g_off[0], w2p + w2g_off[1], w2p + w2g_off[2], w2p + w2g_off[3]};
+  const float4* w1t = w1t_base + opaque;                         // L2-resident image: same trick against LICM
+
+  // ---- layer 1: u = relu(W1 z + b1); `mask` bit s2 = (pre-activation of the lane's s2-th hidden unit > 0)
+  float u[32];
+  unsigned mask = 0;
+#pragma unroll
+  for (int TP = 0; TP < 4; ++TP) {
+    const float4 c0 = bb1[8 * TP], c1 = bb1[8 * TP + 4];
+    f32x4 y0 = {c0.x, c0.y, c0.z, c0.w}, y1 = {c1.x, c1.y, c1.z, c1.w};
+    const float4 g00 = w1[(4 * TP) * 64], g01 = w1[(4 * TP + 1) * 64], g10 = w1[(4 * TP + 2) * 64], g11 = w1[(4 * TP + 3) * 64];
+    const float a0[8] = {g00.x, g00.y, g00.z, g00.w, g01.x, g01.y, g01.z, g01.w};
+    const float a1[8] = {g10.x, g10.y, g10.z, g10.w, g11.x, g11.y, g11.z, g11.w};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { y0 = mfma16(a0[s], zs[s], y0); y1 = mfma16(a1[s], zs[s], y1); }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      u[8 * TP + r] = fmaxf(y0[r], 0.f);
+      u[8 * TP + 4 + r] = fmaxf(y1[r], 0.f);
+      mask |= (y0[r] > 0.f ? 1u : 0u) << (8 * TP + r);
+      mask |= (y1[r] > 0.f ? 1u : 0u) << (8 * TP + 4 + r);
+    }
+  }
+  if (stream) {
+#pragma unroll
+    for (int T1 = 0; T1 < 8; ++T1) stream_store4(urow + 16 * T1, u[4 * T1], u[4 * T1 + 1], u[4 * T1 + 2], u[4 * T1 + 3]);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) if (4 * m + q < Hr) zrow[4 * m + q] = zs[m];
+  }
+
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- layer 2, activation, contraction, dL/dY2, and gu += W2^T dL/dY2, one tile pair at a time
+  f32x4 gu[8];
+#pragma unroll
+  for (int T1 = 0; T1 < 8; ++T1) gu[T1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  fa = f32x4{0.f, 0.f, 0.f, 0.f}; fb = fa;
+  kt = 0.f;
+#pragma unroll
+  for (int P = 0; P < NP; ++P) {                                 // unit group P: 4 hidden units x CT channels = NB tiles
+    f32x4 y[NB];
+    const float* tp_[NB];
+#pragma unroll
+    for (int tb = 0; tb < NB; ++tb) {
+      const float4 c0 = bb2[4 * (NB * P + tb)];
+      y[tb] = f32x4{c0.x, c0.y, c0.z, c0.w};
+      tp_[tb] = w2y + 2 * (NB * P + tb) * 8 * W2P_STRIDE;        // tile T = NB*P + tb: physical rows (2T + hb)*8 + r8
+    }
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      float4 a[NB];
+#pragma unroll
+      for (int tb = 0; tb < NB; ++tb) a[tb] = *reinterpret_cast<const float4*>(tp_[tb] + 16 * g);
+#pragma unroll
+      for (int tb = 0; tb < NB; ++tb) y[tb] = mfma16(a[tb].x, u[4 * g], y[tb]);
+#pragma unroll
+      for (int tb = 0; tb < NB; ++tb) y[tb] = mfma16(a[tb].y, u[4 * g + 1], y[tb]);
+#pragma unroll
+      for (int tb = 0; tb < NB; ++tb) y[tb] = mfma16(a[tb].z, u[4 * g + 2], y[tb]);
+#pragma unroll
+      for (int tb = 0; tb < NB; ++tb) y[tb] = mfma16(a[tb].w, u[4 * g + 3], y[tb]);
+    }
+    float g2[CT];
+    float f = 0.f, h2 = 0.f;
+#pragma unroll
+    for (int tb = 0; tb < NB; ++tb) {
+      const f32x2 t01 = activate2<ACT>(y[tb][0], y[tb][1]), t23 = activate2<ACT>(y[tb][2], y[tb][3]);
+      const float tv[4] = {t01[0], t01[1], t23[0], t23[1]};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = 4 * tb + r;
+        const float t = tv[r];
+        f = c == 0 ? t * dX[0] : __builtin_fmaf(t, dX[c], f);
+        if (TGRAD) h2 = __builtin_fmaf(t, d2X[c], h2);
+        const float slope = ACT == CDE_ACT_TANH ? __builtin_fmaf(-t, t, 1.f) : 1.f;
+        g2[c] = as[P] * (dX[c] * slope);
+      }
+    }
+    if (P < 4) fa[P] = f; else fb[P - 4] = f;
+    if (TGRAD) kt = __builtin_fmaf(as[P], h2, kt);
+    if (stream) {
+      float* grow = g2row + 4 * CT * P;                          // rows (h = 4P+q, c = 0..CT-1) of the padded layout
+#pragma unroll
+      for (int c4 = 0; c4 < CT; c4 += 4) stream_store4(grow + c4, g2[c4], g2[c4 + 1], g2[c4 + 2], g2[c4 + 3]);
+    }
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {                               // K step (P, c); 8 independent accumulator chains
+      const float* rowp = w2g[c & 3] + 2 * (NB * P + (c >> 2)) * 8 * W2P_STRIDE;
+#pragma unroll
+      for (int T1 = 0; T1 < 8; ++T1) gu[T1] = mfma16(rowp[16 * T1], g2[c], gu[T1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- dL/dY1 = gu * relu'(pre1);  va = W1^T dL/dY1
+  float g1[32];
+#pragma unroll
+  for (int s2 = 0; s2 < 32; ++s2) g1[s2] = (mask >> s2) & 1u ? gu[s2 >> 2][s2 & 3] : 0.f;
+  if (stream) {
+#pragma unroll
+    for (int T1 = 0; T1 < 8; ++T1)
+      stream_store4(g1row + 16 * T1, g1[4 * T1], g1[4 * T1 + 1], g1[4 * T1 + 2], g1[4 * T1 + 3]);
+  }
+  va = f32x4{0.f, 0.f, 0.f, 0.f}; vb = va;
+#pragma unroll
+  for (int T1 = 0; T1 < 8; ++T1) {
+    const float4 a0 = w1t[T1 * 64], a1 = w1t[(8 + T1) * 64];
+    va = mfma16(a0.x, g1[4 * T1], va);     vb = mfma16(a1.x, g1[4 * T1], vb);
+    va = mfma16(a0.y, g1[4 * T1 + 1], va); vb = mfma16(a1.y, g1[4 * T1 + 1], vb);
+    va = mfma16(a0.z, g1[4 * T1 + 2], va); vb = mfma16(a1.z, g1[4 * T1 + 2], vb);
+    va = mfma16(a0.w, g1[4 * T1 + 3], va); vb = mfma16(a1.w, g1[4 * T1 + 3], vb);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// host side of the images (rk4_mlp_adjoint.hip)
+size_t mlp_adjoint_image_bytes();
+int launch_mlp_adjoint_images(const void* W1, const void* b1, int64_t width, const void* W2, const void* b2, int64_t C,
+                              int64_t H, float* img, hipStream_t s);
+
+}  // namespace cde

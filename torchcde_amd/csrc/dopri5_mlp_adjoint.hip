@@ -1,0 +1,524 @@
+// dopri5_mlp_adjoint.hip -- K4am: the continuous-adjoint backward of an ADAPTIVE (dopri5) solve for the two-layer field
+//   f(z) = reshape_{HxC}( act( W2 relu(W1 z + b1) + b2 ) ) dX          (example/time_series_classification.py:20-51)
+//
+// This is the call every example of the reference makes to train its model: cdeint(X, func, z0, X.interval) with no
+// method -- dopri5, adjoint=True (example/time_series_classification.py:83-86, example/irregular_data.py:59,
+// example/logsignature_example.py via the same CDEFunc; semantics solver.py:144,199-203,226).  Until round 3 it ran
+// step-wise (host controller, library GEMMs per evaluation: 34 s per 4096-series backward).
+//
+// Structure = K4a's (dopri5_adjoint.hip) around K3m's stage evaluation (cde_mlp_adj.h: mlp_adjoint_eval):
+//   * one launch of `dopri5_mlp_adjoint_attempt` = "decide the previous attempt, make the next one": the controller of
+//     cde_dopri_adj.h (torchdiffeq's default MIXED adjoint norm over (vjp_t, y, a, dW1, db1, dW2, db2), or "seminorm";
+//     interval ends passed and interpolated: mode 3 repeats the last step with the dense-output functional);
+//   * a wave owns 16 series for the 7 stage evaluations of an attempt (lane (n, q): hidden units q, 4+q, .., 28+q of z and
+//     of a).  The stage body already fills the register file (u[32], gu[32], g1[32] on top of the MFMA operands), so the
+//     7 x 16 stage slopes of a lane live in a per-wave scratch ring in global memory (written once per stage as four
+//     coalesced 16-byte stores, read back by the stage combinations and the error / dense-output sums; 28 KB per wave,
+//     L2-resident);
+//   * dL/dW2 is 256 x 128 per wave -- no register file holds it -- so, as in K3m, every evaluation streams the
+//     UNWEIGHTED factors of the parameter gradients to HBM (2.2 KB per series and stage; stage 1 has weight 0 in every
+//     functional and is skipped), one block of rows per stage; the split-K MFMA reduction of mlp_grad_reduce.hip turns each
+//     stage's rows into that stage's gradient image K_s (per-slab partials, slabs never straddle stages), and
+//     `mlp_adjoint_reduce_kernel` -- the R kernel of this family -- forms S = sum_s wS[s] K_s and E = sum_s wE[s] K_s per
+//     element (adj_stage_weights), owns the running totals, commits the accepted attempt's increment and leaves the
+//     per-block sums of (E / tol)^2 of the four parameter tensors for the next launch's controller.
+// Four launches per attempted step (attempt, factor reduction of each layer, R), no host round trip.
+#include "cde_dopri_adj.h"
+#include "cde_mlp_adj.h"
+
+namespace cde {
+
+constexpr int MADJ_SLOTS = 6;                    // stages whose factors are kept: 0, 2, 3, 4, 5, 6
+constexpr int MADJ_P2 = 256 * 129, MADJ_P1 = 128 * 33;          // elements of a layer-2 / layer-1 slab partial (bias column last)
+constexpr int MADJ_ELEMS = MADJ_P2 + MADJ_P1;
+constexpr int MADJ_RBLOCKS = (MADJ_ELEMS + 255) / 256;
+constexpr int MADJ_MAX_SPS = 40;                 // slabs per stage of the factor reduction
+constexpr int MADJ_NSUM = ADJ_NS + 2 * ADJ_MAX_PT;
+__host__ __device__ constexpr int madj_slot(int stage) { return stage == 0 ? 0 : stage - 1; }      // stage 1 is never stored
+
+struct MlpAdjArgs {
+  const float* coeffs; const float* knots; int64_t n_intervals;
+  const float* img;                 // MLP_ADJ_IMAGE_FLOATS: [LDS image | W1^T image]
+  Dims dims;
+  int64_t B, n_tiles, rows_per_stage;
+  unsigned char* ctrl;              // [2] AdjCtrl, ADJ_CTRL_STRIDE bytes apart
+  float* state;                     // [2][4][B*H]: committed y, a; attempted y1, a1
+  const float* y_init; const float* a_init;
+  float* a_out;
+  double* partial;                  // [2][n_wg_max][ADJ_NS]
+  double* pq;                       // [2][MADJ_RBLOCKS][8]
+  float* slopes;                    // [n_tiles][7][4][64] float4: the stage slopes of every lane
+  float* U; float* G2; float* G1; float* Z;      // factor rows [slot][rows_per_stage]
+  AdjCommon com;
+  int n_wg_max;
+};
+
+template <int DEGREE, int ACT, int CT, int NWAVE>
+__global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adjoint_attempt(MlpAdjArgs g, int parity) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int p = parity, p2 = parity ^ 1;
+  AdjCtrl k = *reinterpret_cast<const AdjCtrl*>(g.ctrl + p * ADJ_CTRL_STRIDE);
+  DopriCtrl& c = k.c;
+  if (c.phase == 4) {
+    if (blockIdx.x == 0 && tid == 0) { k.commit = 0; k.mode = 3; *reinterpret_cast<AdjCtrl*>(g.ctrl + p2 * ADJ_CTRL_STRIDE) = k; }
+    return;
+  }
+  {
+    const float4* src = reinterpret_cast<const float4*>(g.img);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    for (int i = tid; i < ADJ_LDS_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
+  }
+  double* red = reinterpret_cast<double*>(lds + ADJ_LDS_FLOATS);
+  const int Hr = g.dims.H, Cr = g.dims.C;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, q = lane >> 4;
+  const int64_t BH = g.B * Hr;
+  const float* Sp = g.state + (int64_t)p * 4 * BH;
+  float* Sq = g.state + (int64_t)p2 * 4 * BH;
+  const double* Pp = g.partial + (int64_t)p * g.n_wg_max * ADJ_NS;
+  double* Pq = g.partial + (int64_t)p2 * g.n_wg_max * ADJ_NS;
+  const float rtol = (float)g.com.rtol, atol = (float)g.com.atol;
+
+  // ---- pending sums: the state sums of the previous attempt launch, the parameter sums its R kernel left
+  double sum[MADJ_NSUM];
+#pragma unroll
+  for (int i = 0; i < MADJ_NSUM; ++i) sum[i] = 0.0;
+  if (c.phase != 0) {
+    for (int64_t b = tid; b < (int64_t)gridDim.x; b += blockDim.x) {
+#pragma unroll
+      for (int i = 0; i < ADJ_NS; ++i) sum[i] += Pp[ADJ_NS * b + i];
+    }
+    const double* Qp = g.pq + (int64_t)p * MADJ_RBLOCKS * 8;
+    for (int b = tid; b < MADJ_RBLOCKS; b += blockDim.x) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sum[ADJ_NS + i] += Qp[8 * b + i];
+    }
+  }
+  block_total<MADJ_NSUM>(sum, red);                                // (also the barrier after the LDS image copy)
+  const int phase_in = c.phase;
+  const AdjPlan plan = adj_controller(g.com, k, sum, sum + ADJ_NS);
+  const int mode = uni(plan.mode);
+  const bool commit = phase_in == 3 && plan.accept && mode != 3;   // mode 3 repeats the accepted step from ITS start state
+  const int ns = mode == 0 ? 1 : mode == 1 ? 2 : 7;
+
+  // ---- stage times (reversed time), their knot intervals, the stage weights: all wave-uniform, in scalar registers
+  const float t0f = uni((float)plan.t0), dtf = uni((float)plan.dt), t1f = uni((float)plan.t1);
+  int sidx[7];
+  float sfrac[7];
+  {
+    float ts = 0.f;
+    const int i = lane & 7;
+    if (mode == 0) ts = (float)c.t_hi;
+    else if (mode == 1) ts = i == 0 ? (float)c.t_hi : (float)(c.t_hi + (double)plan.h0);
+    else if (i == 0) ts = plan.kind0 == 0 ? t0f : next_toward(t0f, plan.kind0 > 0 ? 1.f : -1.f);
+    else if (i <= 4) ts = t0f + (float)DP_ALPHA[i - 1] * dtf;
+    else ts = next_toward(t1f, -1.f);
+    float frac;
+    const int idx = (int)locate_around(g.knots, g.n_intervals, -ts, phase_in == 0 ? (int64_t)-1 : (int64_t)c.slot, frac);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      sidx[j] = __builtin_amdgcn_readlane(idx, j);
+      sfrac[j] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(frac), j));
+    }
+  }
+  float bc[7][6];                                                  // bc[i][j]: weight of slope j in the state handed to stage i
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) bc[i][j] = (i >= 1 && j < i) ? uni((float)DP_BETA[i - 1][j] * dtf) : 0.f;
+  }
+  if (mode == 1) bc[1][0] = uni(plan.h0);
+  float wS[7], wE[7];
+  adj_stage_weights(mode, dtf, plan.x_end, wS, wE);
+#pragma unroll
+  for (int j = 0; j < 7; ++j) { wS[j] = uni(wS[j]); wE[j] = uni(wE[j]); }
+  const float x_end = uni(plan.x_end);
+
+  if (blockIdx.x == 0 && tid == 0) {                               // the controller block for the next launch / the R kernel
+    c.phase = mode == 0 ? 1 : mode == 1 ? 2 : mode == 2 ? 3 : 4;
+    c.slot = sidx[0];                                              // search hint for the next launch's stage times
+    *reinterpret_cast<AdjCtrl*>(g.ctrl + p2 * ADJ_CTRL_STRIDE) = k;
+  }
+
+  double acc[ADJ_NS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  const int64_t tile = (int64_t)blockIdx.x * NWAVE + wave;
+  if (tile < g.n_tiles) {
+    const int64_t series = tile * 16 + n;
+    const bool valid = series < g.B;
+    const int64_t sc = valid ? series : g.B - 1;
+    const float4* w1t_base = reinterpret_cast<const float4*>(g.img + ADJ_LDS_FLOATS) + lane;
+    const int w2y_off = ((n >> 3) * 8 + w2p_residue(n >> 2, n & 3)) * W2P_STRIDE + 4 * q;
+    int w2g_off[4];
+#pragma unroll
+    for (int cl = 0; cl < 4; ++cl) w2g_off[cl] = ((q >> 1) * 8 + w2p_residue(q, cl)) * W2P_STRIDE + n;
+    const int ua = q, ub = 16 + q;                                 // this lane's units: q, 4+q, .., 28+q
+    // the state this launch starts from
+    const float* ysrc = phase_in == 0 ? g.y_init : Sp + (commit ? 2 : 0) * BH;
+    const float* asrc = phase_in == 0 ? g.a_init : Sp + (commit ? 3 : 1) * BH;
+    f32x4 y0a = load_units4<4>(ysrc + sc * Hr, ua, Hr), y0b = load_units4<4>(ysrc + sc * Hr, ub, Hr);
+    f32x4 a0a = load_units4<4>(asrc + sc * Hr, ua, Hr), a0b = load_units4<4>(asrc + sc * Hr, ub, Hr);
+    if (!valid) { a0a = f32x4{0.f, 0.f, 0.f, 0.f}; a0b = a0a; }   // a == 0 stays 0: padded lanes contribute nothing
+    if (valid && mode != 3) {
+      store_units4<4>(Sq + 0 * BH + series * Hr, ua, Hr, y0a); store_units4<4>(Sq + 0 * BH + series * Hr, ub, Hr, y0b);
+      store_units4<4>(Sq + 1 * BH + series * Hr, ua, Hr, a0a); store_units4<4>(Sq + 1 * BH + series * Hr, ub, Hr, a0b);
+    }
+    float4* ring = reinterpret_cast<float4*>(g.slopes) + (tile * 7 * 4) * 64 + lane;      // [stage][4][64 lanes]
+    float vtS = 0.f, vtE = 0.f;
+
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      if (i >= ns) continue;
+      // ---- the state handed to stage i: y0 + sum_j bc[i][j] k_j (slopes back from the ring)
+      f32x4 za = y0a, zb = y0b, sa = a0a, sb = a0b;
+      if (i > 0) {
+        f32x4 ia = {0.f, 0.f, 0.f, 0.f}, ib = ia, ja = ia, jb = ia;
+#pragma unroll
+        for (int j = 0; j < i; ++j) {
+          const float wgt = bc[i][j];
+          const float4 k0 = ring[(j * 4 + 0) * 64], k1 = ring[(j * 4 + 1) * 64], k2 = ring[(j * 4 + 2) * 64], k3 = ring[(j * 4 + 3) * 64];
+          const f32x4 wv4 = {wgt, wgt, wgt, wgt};
+          ia = __builtin_elementwise_fma(f32x4{k0.x, k0.y, k0.z, k0.w}, wv4, ia);
+          ib = __builtin_elementwise_fma(f32x4{k1.x, k1.y, k1.z, k1.w}, wv4, ib);
+          ja = __builtin_elementwise_fma(f32x4{k2.x, k2.y, k2.z, k2.w}, wv4, ja);
+          jb = __builtin_elementwise_fma(f32x4{k3.x, k3.y, k3.z, k3.w}, wv4, jb);
+        }
+        za = y0a + ia; zb = y0b + ib; sa = a0a + ja; sb = a0b + jb;
+      }
+      // ---- the control at the stage time (and, for vjp_t, its second derivative)
+      float dX[CT], d2X[CT];
+      {
+        const Row<DEGREE, CT> row = load_row<DEGREE, CT>(g.coeffs, sc, g.n_intervals, sidx[i], Cr);
+        const float width = DEGREE == CDE_PATH_LINEAR ? g.knots[sidx[i] + 1] - g.knots[sidx[i]] : 1.f;
+        control_slope<DEGREE, CT>(row, sfrac[i], width, dX);
+        const float* f = reinterpret_cast<const float*>(row.v);
+#pragma unroll
+        for (int cc = 0; cc < CT; ++cc)
+          d2X[cc] = DEGREE == CDE_PATH_CUBIC ? f[CT + cc] + 2.f * f[2 * CT + cc] * sfrac[i] : 0.f;
+      }
+      const float zs[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
+      const float as[8] = {sa[0], sa[1], sa[2], sa[3], sb[0], sb[1], sb[2], sb[3]};
+      const bool stream = valid && (wS[i] != 0.f || wE[i] != 0.f);
+      const int64_t out_row = (int64_t)(mode <= 1 ? i : madj_slot(i)) * g.rows_per_stage + series;
+      f32x4 fa, fb, va, vb;
+      float kt;
+      mlp_adjoint_eval<ACT, CT, DEGREE == CDE_PATH_CUBIC>(
+          lds, w1t_base, lane, n, q, w2y_off, w2g_off, zs, as, dX, d2X, stream, g.U + out_row * U_COLS + 4 * q,
+          g.Z + out_row * Z_COLS, g.G2 + out_row * G2_COLS + CT * q, g.G1 + out_row * G1_COLS + 4 * q, Hr, fa, fb, va, vb, kt);
+      if (DEGREE == CDE_PATH_CUBIC) { vtS = __builtin_fmaf(wS[i], kt, vtS); vtE = __builtin_fmaf(wE[i], kt, vtE); }
+      // ---- reverse-time slopes dy/ds = -f, da/ds = +a^T df/dz into the ring
+      ring[(i * 4 + 0) * 64] = make_float4(-fa[0], -fa[1], -fa[2], -fa[3]);
+      ring[(i * 4 + 1) * 64] = make_float4(-fb[0], -fb[1], -fb[2], -fb[3]);
+      ring[(i * 4 + 2) * 64] = make_float4(va[0], va[1], va[2], va[3]);
+      ring[(i * 4 + 3) * 64] = make_float4(vb[0], vb[1], vb[2], vb[3]);
+    }
+
+    // ---- what this launch owes the controller (one more pass over the slopes)
+    auto sq4f = [](const f32x4& v) { return (double)(v[0] * v[0]) + (double)(v[1] * v[1]) + (double)(v[2] * v[2]) + (double)(v[3] * v[3]); };
+    auto abs4f = [](const f32x4& v) { return f32x4{fabsf(v[0]), fabsf(v[1]), fabsf(v[2]), fabsf(v[3])}; };
+    auto max4f = [](const f32x4& a, const f32x4& b) { return f32x4{fmaxf(a[0], b[0]), fmaxf(a[1], b[1]), fmaxf(a[2], b[2]), fmaxf(a[3], b[3])}; };
+    auto slope = [&](int j, int v) { const float4 t = ring[(j * 4 + v) * 64]; return f32x4{t.x, t.y, t.z, t.w}; };
+    if (mode == 0) {
+      const f32x4 sya = atol + abs4f(y0a) * rtol, syb = atol + abs4f(y0b) * rtol;       // Hairer's scale
+      const f32x4 saa = atol + abs4f(a0a) * rtol, sab = atol + abs4f(a0b) * rtol;
+      if (valid) {
+        acc[0] = sq4f(y0a / sya) + sq4f(y0b / syb); acc[1] = sq4f(a0a / saa) + sq4f(a0b / sab);
+        acc[2] = sq4f(slope(0, 0) / sya) + sq4f(slope(0, 1) / syb); acc[3] = sq4f(slope(0, 2) / saa) + sq4f(slope(0, 3) / sab);
+      }
+    } else if (mode == 1) {
+      const f32x4 sya = atol + abs4f(y0a) * rtol, syb = atol + abs4f(y0b) * rtol;
+      const f32x4 saa = atol + abs4f(a0a) * rtol, sab = atol + abs4f(a0b) * rtol;
+      if (valid) {
+        acc[0] = sq4f((slope(1, 0) - slope(0, 0)) / sya) + sq4f((slope(1, 1) - slope(0, 1)) / syb);
+        acc[1] = sq4f((slope(1, 2) - slope(0, 2)) / saa) + sq4f((slope(1, 3) - slope(0, 3)) / sab);
+      }
+    } else {
+      // y1 / a1 = the state handed to stage 6 (FSAL row == solution weights); error estimate with c_err (mode 2)
+      f32x4 iy[2], ia2[2], ey[2], ea[2], ma[2];
+#pragma unroll
+      for (int v = 0; v < 2; ++v) { iy[v] = f32x4{0.f, 0.f, 0.f, 0.f}; ia2[v] = iy[v]; ey[v] = iy[v]; ea[v] = iy[v]; ma[v] = iy[v]; }
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const float ws = j < 6 ? bc[6][j] : 0.f, we = wE[j], wm = dtf * (float)DP_CMID[j];
+        const f32x4 ws4 = {ws, ws, ws, ws}, we4 = {we, we, we, we}, wm4 = {wm, wm, wm, wm};
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+          const f32x4 ky = slope(j, v), ka = slope(j, 2 + v);
+          iy[v] = __builtin_elementwise_fma(ky, ws4, iy[v]); ia2[v] = __builtin_elementwise_fma(ka, ws4, ia2[v]);
+          ey[v] = __builtin_elementwise_fma(ky, we4, ey[v]); ea[v] = __builtin_elementwise_fma(ka, we4, ea[v]);
+          ma[v] = __builtin_elementwise_fma(ka, wm4, ma[v]);
+        }
+      }
+      const f32x4 y1a = y0a + iy[0], y1b = y0b + iy[1], a1a = a0a + ia2[0], a1b = a0b + ia2[1];
+      if (mode == 2) {
+        const f32x4 tya = atol + rtol * max4f(abs4f(y0a), abs4f(y1a)), tyb = atol + rtol * max4f(abs4f(y0b), abs4f(y1b));
+        const f32x4 taa = atol + rtol * max4f(abs4f(a0a), abs4f(a1a)), tab = atol + rtol * max4f(abs4f(a0b), abs4f(a1b));
+        if (valid) {
+          acc[0] = sq4f(ey[0] / tya) + sq4f(ey[1] / tyb); acc[1] = sq4f(ea[0] / taa) + sq4f(ea[1] / tab);
+          store_units4<4>(Sq + 2 * BH + series * Hr, ua, Hr, y1a); store_units4<4>(Sq + 2 * BH + series * Hr, ub, Hr, y1b);
+          store_units4<4>(Sq + 3 * BH + series * Hr, ua, Hr, a1a); store_units4<4>(Sq + 3 * BH + series * Hr, ub, Hr, a1b);
+        }
+      } else {
+        // mode 3: a(s1) by torchdiffeq's dense output (_interp_fit / _interp_evaluate, the oracle's expression order)
+        auto dense = [&](const f32x4& y0, const f32x4& y1, const f32x4& f0, const f32x4& f1, const f32x4& mid) {
+          const f32x4 ym = y0 + mid;
+          const f32x4 ca = 2.f * dtf * (f1 - f0) - 8.f * (y1 + y0) + 16.f * ym;
+          const f32x4 cb = dtf * (5.f * f0 - 3.f * f1) + 18.f * y0 + 14.f * y1 - 32.f * ym;
+          const f32x4 cc = dtf * (f1 - 4.f * f0) - 11.f * y0 - 5.f * y1 + 16.f * ym;
+          const f32x4 cd = dtf * f0;
+          f32x4 total = y0 + x_end * cd;
+          float xp = x_end;
+          xp = xp * x_end; total = total + xp * cc;
+          xp = xp * x_end; total = total + xp * cb;
+          xp = xp * x_end; total = total + xp * ca;
+          return total;
+        };
+        if (valid) {
+          store_units4<4>(g.a_out + series * Hr, ua, Hr, dense(a0a, a1a, slope(0, 2), slope(6, 2), ma[0]));
+          store_units4<4>(g.a_out + series * Hr, ub, Hr, dense(a0b, a1b, slope(0, 3), slope(6, 3), ma[1]));
+        }
+      }
+    }
+    acc[4] = (double)vtS; acc[5] = (double)vtE;
+  }
+  // ---- publish this launch's partial sums
+  block_total<ADJ_NS>(acc, red);
+  if (tid == 0) {
+#pragma unroll
+    for (int i = 0; i < ADJ_NS; ++i) Pq[ADJ_NS * blockIdx.x + i] = acc[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------ the R kernel of this family
+// One thread per element of the slab-partial layout of the factor reduction: layer 2 [256][129] (row = padded (h, c),
+// columns = hidden-layer unit, last column = the bias), then layer 1 [128][33].  K_s[e] = sum over the slabs of stage s
+// (fixed order); S = sum_s wS[s] K_s, E = sum_s wE[s] K_s with the weights of cde_dopri_adj.h rebuilt from the controller
+// block; then the commit / norm logic of adj_param_element, per-block sums per parameter tensor (W1, b1, W2, b2).
+struct MlpReduceArgs {
+  unsigned char* ctrl;
+  const float* part2; const float* part1;   // slab partials [slot][sps][M][N + 1]
+  int sps;
+  float* G;                 // [MADJ_ELEMS] running totals (layer 2 block, then layer 1 block)
+  float* prevS;             // [2][MADJ_ELEMS]
+  double* pq;               // [2][MADJ_RBLOCKS][8]
+  const double* partial; int n_wg; int n_wg_max;
+  double* carry;
+  float rtol, atol;
+};
+
+__global__ __launch_bounds__(256) void mlp_adjoint_reduce_kernel(MlpReduceArgs r, int parity) {
+  __shared__ double red[8 * 4];
+  const int p2 = parity ^ 1;
+  const AdjCtrl k = *reinterpret_cast<const AdjCtrl*>(r.ctrl + p2 * ADJ_CTRL_STRIDE);
+  if (k.c.phase == 4 && k.commit == 0) return;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  float wS[7], wE[7];
+  adj_stage_weights(k.mode, (float)k.c.dt_try, (float)k.x_end, wS, wE);
+  const int n_slots = k.mode == 0 ? 1 : k.mode == 1 ? 2 : MADJ_SLOTS;
+  float S = 0.f, E = 0.f;
+  int tensor = -1;                                                 // 0 W1, 1 b1, 2 W2, 3 b2 (torch's parameter order)
+  if (e < MADJ_ELEMS) {
+    const bool layer2 = e < MADJ_P2;
+    const float* base = layer2 ? r.part2 + e : r.part1 + (e - MADJ_P2);
+    const int64_t stride = layer2 ? MADJ_P2 : MADJ_P1;
+    const int col = layer2 ? e % 129 : (e - MADJ_P2) % 33;
+    tensor = layer2 ? (col == 128 ? 3 : 2) : (col == 32 ? 1 : 0);
+    for (int slot = 0; slot < n_slots; ++slot) {
+      const int stage = k.mode <= 1 ? slot : (slot == 0 ? 0 : slot + 1);
+      float ks = 0.f;
+      for (int b = 0; b < r.sps; ++b) ks += base[((int64_t)slot * r.sps + b) * stride];
+      S = __builtin_fmaf(wS[stage], ks, S);
+      E = __builtin_fmaf(wE[stage], ks, E);
+    }
+  }
+  if (k.mode == 3 && e == 0) {
+    double vt = 0.0;
+    for (int b = 0; b < r.n_wg; ++b) vt += r.partial[((int64_t)p2 * r.n_wg_max + b) * ADJ_NS + 4];
+    r.carry[0] = (double)((float)k.T + (float)vt);
+  }
+  double qv[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (e < MADJ_ELEMS) {
+    double q0 = 0.0, q1 = 0.0;
+    const float gn = adj_param_element(k, r.rtol, r.atol, r.G[e], r.prevS[p2 * MADJ_ELEMS + e], S, E, q0, q1);
+    if (k.commit) r.G[e] = gn;
+    r.prevS[parity * MADJ_ELEMS + e] = S;
+    qv[2 * tensor] = q0; qv[2 * tensor + 1] = q1;
+  }
+  if (k.mode == 3) return;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) qv[i] += __shfl_xor(qv[i], off, 64);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[i * 4 + wv] = qv[i];
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    const int i = threadIdx.x;
+    r.pq[((int64_t)p2 * MADJ_RBLOCKS + blockIdx.x) * 8 + i] = (red[i * 4] + red[i * 4 + 1]) + (red[i * 4 + 2] + red[i * 4 + 3]);
+  }
+}
+
+// the "1" columns of the U and Z rows (bias gradients = column sums of G): written once per backward pass
+__global__ __launch_bounds__(256) void madj_ones_kernel(float* __restrict__ U, float* __restrict__ Z, int64_t rows) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r < rows) { U[r * U_COLS + 128] = 1.f; Z[r * Z_COLS + 32] = 1.f; }
+}
+
+// from mlp_grad_reduce.hip: the split-K reduction of one attempt's factor rows, both layers, gated by the controller block
+int launch_mlp_adjoint_factor_reduce(const float* G2, const float* U, const float* G1, const float* Z, int64_t rows_per_stage,
+                                     int sps, int64_t rows_per_slab, float* part2, float* part1, const unsigned char* ctrl,
+                                     int parity, hipStream_t s);
+
+static inline size_t m256(size_t x) { return (x + 255) / 256 * 256; }
+
+}  // namespace cde
+
+// ================================================================================================ C ABI
+namespace {
+struct MadjLayout {
+  int64_t n_tiles, rows_per_stage, rows_per_slab;
+  int sps, nwave, n_wg;
+  size_t partial, pq, carry, image, state, G, prev, slopes, part2, part1, U, G2, G1, Z, trace, trace_all, total;
+};
+MadjLayout madj_layout(int64_t B, int64_t H) {
+  using namespace cde;
+  MadjLayout L;
+  L.n_tiles = (B + 15) / 16;
+  L.nwave = L.n_tiles > 1024 ? 8 : 4;              // 16384 series fill the GPU's 1024 SIMDs with one wave each
+  L.n_wg = (int)((L.n_tiles + L.nwave - 1) / L.nwave);
+  int64_t sps = (B + 63) / 64;
+  L.sps = (int)(sps < 1 ? 1 : sps > MADJ_MAX_SPS ? MADJ_MAX_SPS : sps);
+  L.rows_per_slab = ((B + L.sps - 1) / L.sps + 15) / 16 * 16;
+  L.rows_per_stage = L.rows_per_slab * L.sps;
+  const size_t rows = (size_t)MADJ_SLOTS * L.rows_per_stage;
+  L.partial = m256(2 * ADJ_CTRL_STRIDE);
+  L.pq = L.partial + m256((size_t)2 * L.n_wg * ADJ_NS * sizeof(double));
+  L.carry = L.pq + m256((size_t)2 * MADJ_RBLOCKS * 8 * sizeof(double));
+  L.image = L.carry + 256;
+  L.state = L.image + m256(mlp_adjoint_image_bytes());
+  L.G = L.state + m256((size_t)2 * 4 * B * H * sizeof(float));
+  L.prev = L.G + m256((size_t)MADJ_ELEMS * sizeof(float));
+  L.slopes = L.prev + m256((size_t)2 * MADJ_ELEMS * sizeof(float));
+  L.part2 = L.slopes + m256((size_t)L.n_tiles * 7 * 4 * 64 * 16);
+  L.part1 = L.part2 + m256((size_t)MADJ_SLOTS * L.sps * MADJ_P2 * sizeof(float));
+  L.U = L.part1 + m256((size_t)MADJ_SLOTS * L.sps * MADJ_P1 * sizeof(float));
+  L.G2 = L.U + m256(rows * U_COLS * sizeof(float));
+  L.G1 = L.G2 + m256(rows * G2_COLS * sizeof(float));
+  L.Z = L.G1 + m256(rows * G1_COLS * sizeof(float));
+  L.trace = L.Z + m256(rows * Z_COLS * sizeof(float));
+  L.trace_all = L.trace + m256((size_t)CDE_DOPRI5_TRACE_STEPS * 3 * sizeof(double));
+  L.total = L.trace_all + m256((size_t)ADJ_TRACE_ATTEMPTS * 5 * sizeof(double));
+  return L;
+}
+}  // namespace
+
+extern "C" size_t cde_dopri5_adjoint_mlp_workspace_bytes(int64_t B, int64_t C, int64_t H) {
+  (void)C;
+  return B < 1 || H < 1 ? 0 : madj_layout(B, H).total;
+}
+extern "C" size_t cde_dopri5_adjoint_mlp_trace_offset(int64_t B, int64_t C, int64_t H, int which) {
+  (void)C;
+  const MadjLayout L = madj_layout(B, H);
+  return which == 0 ? L.trace : L.trace_all;
+}
+// where the running totals live: layer 2 as [256][129] (row = padded (h, c), bias in column 128), then layer 1 as [128][33]
+extern "C" size_t cde_dopri5_adjoint_mlp_gradient_offset(int64_t B, int64_t C, int64_t H) {
+  (void)C;
+  return madj_layout(B, H).G;
+}
+
+extern "C" int cde_dopri5_adjoint_mlp_advance(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
+                                              const void* W1, const void* bias1, int64_t width, const void* W2,
+                                              const void* bias2, int act, const void* y_init, const void* a_init,
+                                              double s0, double s1, const double* jump_s, int64_t n_jump, double rtol,
+                                              double atol, double safety, double ifactor, double dfactor, int norm_kind,
+                                              void* a_out, int64_t B, int64_t C, int64_t H, int dtype, int first_interval,
+                                              void* workspace, size_t workspace_bytes, int64_t first_launch,
+                                              int64_t n_launches, void* stream) {
+  using namespace cde;
+  if (B < 1 || C < 1 || H < 1 || width < 1 || n_intervals < 1 || n_launches < 0 || n_jump < 0 || !(s0 < s1)) return CDE_ERR_SHAPE;
+  if (dtype != CDE_F32) return dtype == CDE_F64 ? CDE_ERR_UNSUPPORTED : CDE_ERR_DTYPE;
+  if (!mlp_shape_ok(C, H, width)) return CDE_ERR_UNSUPPORTED;
+  if (act != CDE_ACT_NONE && act != CDE_ACT_TANH) return CDE_ERR_UNSUPPORTED;
+  if (degree != CDE_PATH_CUBIC && degree != CDE_PATH_LINEAR) return CDE_ERR_UNSUPPORTED;
+  if (norm_kind != 0 && norm_kind != 1) return CDE_ERR_UNSUPPORTED;
+  if (!coeffs || !knots || !W1 || !bias1 || !W2 || !bias2 || !y_init || !a_init || !a_out || !workspace) return CDE_ERR_NULL;
+  if (n_jump > 0 && !jump_s) return CDE_ERR_NULL;
+  if (workspace_bytes < cde_dopri5_adjoint_mlp_workspace_bytes(B, C, H)) return CDE_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  unsigned char* base = (unsigned char*)workspace;
+  const MadjLayout L = madj_layout(B, H);
+  MlpAdjArgs g;
+  g.coeffs = (const float*)coeffs; g.knots = (const float*)knots; g.n_intervals = n_intervals;
+  g.img = (const float*)(base + L.image);
+  g.dims = Dims{(int)H, (int)C};
+  g.B = B; g.n_tiles = L.n_tiles; g.rows_per_stage = L.rows_per_stage;
+  g.ctrl = base;
+  g.partial = (double*)(base + L.partial); g.pq = (double*)(base + L.pq);
+  g.state = (float*)(base + L.state);
+  g.y_init = (const float*)y_init; g.a_init = (const float*)a_init; g.a_out = (float*)a_out;
+  g.slopes = (float*)(base + L.slopes);
+  g.U = (float*)(base + L.U); g.G2 = (float*)(base + L.G2); g.G1 = (float*)(base + L.G1); g.Z = (float*)(base + L.Z);
+  g.n_wg_max = L.n_wg;
+  g.com.s0 = s0; g.com.s1 = s1; g.com.jump_s = jump_s; g.com.n_jump = n_jump;
+  g.com.rtol = rtol; g.com.atol = atol; g.com.safety = safety; g.com.ifactor = ifactor; g.com.dfactor = dfactor;
+  g.com.n_state = B * H;
+  g.com.n_pt = 4;
+  g.com.n_param[0] = width * H; g.com.n_param[1] = width; g.com.n_param[2] = H * C * width; g.com.n_param[3] = H * C;
+  g.com.norm_kind = norm_kind;
+  g.com.trace = (double*)(base + L.trace);
+  g.com.trace_all = (double*)(base + L.trace_all);
+  g.com.carry = (double*)(base + L.carry);
+  if (first_launch == 0) {
+    if (hipMemsetAsync(base, 0, 2 * ADJ_CTRL_STRIDE, s) != hipSuccess) return CDE_ERR_LAUNCH;     // phase 0
+    if (first_interval) {
+      // vjp_t, the running totals and the factor rows (padding rows must hold zeros; the "1" columns are set below)
+      if (hipMemsetAsync(base + L.carry, 0, 256, s) != hipSuccess ||
+          hipMemsetAsync(base + L.G, 0, L.slopes - L.G, s) != hipSuccess ||
+          hipMemsetAsync(base + L.U, 0, L.trace - L.U, s) != hipSuccess)
+        return CDE_ERR_LAUNCH;
+      const int64_t rows = (int64_t)MADJ_SLOTS * L.rows_per_stage;
+      madj_ones_kernel<<<(unsigned)((rows + 255) / 256), 256, 0, s>>>(g.U, g.Z, rows);
+      const int rc = launch_mlp_adjoint_images(W1, bias1, width, W2, bias2, C, H, (float*)(base + L.image), s);
+      if (rc != CDE_OK) return rc;
+    }
+  }
+  MlpReduceArgs r;
+  r.ctrl = base; r.part2 = (const float*)(base + L.part2); r.part1 = (const float*)(base + L.part1); r.sps = L.sps;
+  r.G = (float*)(base + L.G); r.prevS = (float*)(base + L.prev); r.pq = g.pq;
+  r.partial = g.partial; r.n_wg = L.n_wg; r.n_wg_max = L.n_wg; r.carry = g.com.carry;
+  r.rtol = (float)rtol; r.atol = (float)atol;
+  const size_t lds_bytes = (size_t)ADJ_LDS_FLOATS * sizeof(float) + (size_t)MADJ_NSUM * 8 * sizeof(double);
+#define CDE_MADJ_LAUNCH(D, A, CTV, NWV)                                                                              \
+  do {                                                                                                               \
+    (void)hipFuncSetAttribute((const void*)dopri5_mlp_adjoint_attempt<D, A, CTV, NWV>,                               \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                           \
+    for (int64_t i = 0; i < n_launches; ++i) {                                                                       \
+      const int parity = (int)((first_launch + i) & 1);                                                              \
+      dopri5_mlp_adjoint_attempt<D, A, CTV, NWV><<<L.n_wg, 64 * NWV, lds_bytes, s>>>(g, parity);                     \
+      const int rc = launch_mlp_adjoint_factor_reduce(g.G2, g.U, g.G1, g.Z, L.rows_per_stage, L.sps, L.rows_per_slab, \
+                                                      (float*)(base + L.part2), (float*)(base + L.part1), base, parity, s); \
+      if (rc != CDE_OK) return rc;                                                                                   \
+      mlp_adjoint_reduce_kernel<<<MADJ_RBLOCKS, 256, 0, s>>>(r, parity);                                             \
+    }                                                                                                                \
+  } while (0)
+#define CDE_MADJ_W(D, A, CTV)                                                                                        \
+  do {                                                                                                               \
+    if (L.nwave == 8) CDE_MADJ_LAUNCH(D, A, CTV, 8); else CDE_MADJ_LAUNCH(D, A, CTV, 4);                             \
+  } while (0)
+#define CDE_MADJ(D, A)                                                                                               \
+  do {                                                                                                               \
+    if (C > MC) CDE_MADJ_W(D, A, 16); else CDE_MADJ_W(D, A, 8);                                                      \
+  } while (0)
+  if (act == CDE_ACT_NONE) {
+    if (degree == CDE_PATH_CUBIC) CDE_MADJ(CDE_PATH_CUBIC, CDE_ACT_NONE); else CDE_MADJ(CDE_PATH_LINEAR, CDE_ACT_NONE);
+  } else {
+    if (degree == CDE_PATH_CUBIC) CDE_MADJ(CDE_PATH_CUBIC, CDE_ACT_TANH); else CDE_MADJ(CDE_PATH_LINEAR, CDE_ACT_TANH);
+  }
+#undef CDE_MADJ
+#undef CDE_MADJ_W
+#undef CDE_MADJ_LAUNCH
+  return check_launch();
+}

@@ -15,6 +15,7 @@
 //   * every workgroup reduces its slab of rows into registers (MT x NT tiles per wave) and writes one partial; a second
 //     kernel adds the partials in slab order into the caller's accumulator -- deterministic, no atomics.
 #include "cde_mfma.h"
+#include "cde_dopri_adj.h"
 
 namespace cde {
 
@@ -45,8 +46,19 @@ __device__ __forceinline__ void ring_barrier() {           // LDS traffic of thi
 template <int MT, int NV, int NG>
 __global__ __launch_bounds__(256, 2) void mlp_grad_partial_kernel(const float* __restrict__ G, const float* __restrict__ X,
                                                                   int64_t rows, int64_t rows_per_slab, int xc,
-                                                                  float* __restrict__ partial, int gc) {
+                                                                  float* __restrict__ partial, int gc,
+                                                                  const unsigned char* __restrict__ gate = nullptr,
+                                                                  int gate_parity = 0, int slabs_per_stage = 0) {
   constexpr int M = 4 * MT * 16, NT = NG * NV, N = NT * 16, R = GRAD_TILE_ROWS;
+  if (gate) {
+    // K4am (dopri5_mlp_adjoint.hip): one block of rows per stored stage, `slabs_per_stage` slabs each; the attempt launch
+    // just before this one left, in the controller block, what it computed -- nothing once the interval is finished,
+    // one stage (initial-step norms), two, or the six weighted stages of a step
+    const AdjCtrl* k = reinterpret_cast<const AdjCtrl*>(gate + (gate_parity ^ 1) * ADJ_CTRL_STRIDE);
+    if (k->c.phase == 4 && k->commit == 0) return;
+    const int n_slots = k->mode == 0 ? 1 : k->mode == 1 ? 2 : 6;
+    if ((int)blockIdx.x >= n_slots * slabs_per_stage) return;
+  }
   constexpr int TILE = R * (M + N);                          // floats per ring buffer: [G rows | X rows]
   // wave-wide loads (256 floats each) per tile and wave; every wave issues the same number (idle slots load into a
   // dummy area) so that one vmcnt value is right for all of them
@@ -195,6 +207,18 @@ int launch_wide_grad_reduce(const float* G, const float* Z, int64_t rows, int M,
   if (N == 64) CDE_GRAD_PARTIAL(4, 4, 1, grid, G, Z, rows, per, N, partial, M);
   else CDE_GRAD_PARTIAL(4, 2, 1, grid, G, Z, rows, per, N, partial, M);
   mlp_grad_finish_kernel<<<(M * (N + 1) + 63) / 64, 256, 0, s>>>(partial, slabs, M, N, acc, N + 1);
+  return check_launch();
+}
+
+// K4am: the factor rows of one attempt launch -> per-slab partials of both layers (no second pass: the R kernel of
+// dopri5_mlp_adjoint.hip adds the slabs of each stage in order)
+int launch_mlp_adjoint_factor_reduce(const float* G2, const float* U, const float* G1, const float* Z, int64_t rows_per_stage,
+                                     int sps, int64_t rows_per_slab, float* part2, float* part1, const unsigned char* ctrl,
+                                     int parity, hipStream_t s) {
+  const int64_t rows = 6 * rows_per_stage;
+  const dim3 grid((unsigned)(6 * sps));
+  CDE_GRAD_PARTIAL(4, 4, 2, grid, G2, U, rows, rows_per_slab, 132, part2, 256, ctrl, parity, sps);
+  CDE_GRAD_PARTIAL(2, 2, 1, grid, G1, Z, rows, rows_per_slab, 36, part1, 128, ctrl, parity, sps);
   return check_launch();
 }
 

@@ -27,20 +27,9 @@
 //   gu:  lane (i, kq) reads row (h = 4P + kq, c) at column 16*T1 + i -> ds_read_b32, each half-wave on 32 distinct banks
 // with every (P, tb, T1) offset an instruction immediate.
 // 1152 MFMAs per stage = 76.3 MFLOP per series per solve for the sweep itself.
-#include "cde_mfma.h"
+#include "cde_mlp_adj.h"
 
 namespace cde {
-
-constexpr int W2P_STRIDE = 132;                           // floats per row of the plain W2 copy
-constexpr int W2P_FLOATS = 256 * W2P_STRIDE;
-constexpr int W1T_FLOATS = 2 * 8 * 64 * 4;                // [tile][T1][lane][4]
-constexpr int ADJ_LDS_FLOATS = W1M_FLOATS + B1M_FLOATS + W2P_FLOATS + BY_FLOATS;   // [W1 image | b1 | W2 plain | b2]
-constexpr int MLP_ADJ_IMAGE_FLOATS = ADJ_LDS_FLOATS + W1T_FLOATS;
-// h3 = h&3 enters bit-reversed so that the four lane quarters of a gu read are shifted by 0, 16, 8, 24 banks: the LDS
-// serves a b32 read in two half-waves (lanes 0-31 = quarters 0,1; lanes 32-63 = quarters 2,3) and each half must
-// cover 32 distinct banks.  (With shifts 0, 8, 16, 24 rocprofv3 counted 1.3e8 SQ_LDS_BANK_CONFLICT cycles per launch.)
-__host__ __device__ constexpr int w2p_residue(int h3, int c3) { return (2 * (((h3 & 1) << 1) | (h3 >> 1)) + c3) & 7; }
-constexpr int U_COLS = 132, G2_COLS = 256, G1_COLS = 128, Z_COLS = 36;
 
 __device__ __forceinline__ float mlp_adj_image(const float* __restrict__ W1, const float* __restrict__ b1,
                                                const float* __restrict__ W2, const float* __restrict__ b2, int e,
@@ -74,11 +63,6 @@ __global__ void mlp_adj_image_kernel(const float* __restrict__ W1, const float* 
                                      float* __restrict__ img, MlpDims d, int nb) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < MLP_ADJ_IMAGE_FLOATS) img[e] = mlp_adj_image(W1, b1, W2, b2, e, d, nb);
-}
-
-__device__ __forceinline__ void stream_store4(float* p, float a, float b, float c, float d) {
-  // written once, read once by the GEMM much later: keep it out of the way of the L2-resident weight images
-  __builtin_nontemporal_store(f32x4{a, b, c, d}, reinterpret_cast<f32x4*>(p));
 }
 
 // DCOEFF: also accumulate dL/d(control coefficients) into `grad_coeffs` (zeroed by the caller, layout of `coeffs`),
