@@ -40,7 +40,7 @@ constexpr int ADJ_IMAGE_FLOATS = 4 * 64 * ADJ_IMAGE;             // per workgrou
 constexpr int ADJ_MAX_WG = 256;
 constexpr int ADJ_LDS_FLOATS = 2 * SPL_ZBUF + 2 * SPL_ZT + 2 * SPL_VA + 2 * 2 * 7 * SPL_DX + 2 * 4 * SPL_GT;
 constexpr size_t ADJ_LDS_BYTES = (size_t)ADJ_LDS_FLOATS * sizeof(float) + 4 * 512 * sizeof(double);
-constexpr int ADJ_RBLOCKS = ADJ_IMAGE_FLOATS / 256;              // blocks of the R kernel: one thread per image slot
+constexpr int ADJ_RBLOCKS = ADJ_IMAGE_FLOATS / 16;               // blocks of the R kernel: 16 image slots each
 
 struct DopriAdjArgs {
   const float* coeffs; const float* knots; int64_t n_intervals;
@@ -519,69 +519,82 @@ struct AdjReduceArgs {
   float rtol, atol;
 };
 
+// Launch shape: 16 image slots per block x 16 "parts"; part p adds the images of workgroups p, p + 16, .. (the loads of a
+// thread are independent of each other -- a single thread walking all 256 images was a 256-deep chain of L2 latencies,
+// 250 us per attempted step), the 16 partial sums of a slot meet in LDS and are added in a fixed order.
 __global__ __launch_bounds__(256) void adjoint_reduce_kernel(AdjReduceArgs r, int parity, int stage) {
-  __shared__ double red[4 * 4];
+  __shared__ float psum[2][16][17];
+  __shared__ double red[4][16];
   const int p2 = parity ^ 1;
   const AdjCtrl k = *adj_ctrl(r.ctrl, p2);                          // written by the attempt launch just before this one
   if (k.c.phase == 4 && k.commit == 0) return;                     // the interval was finished (and committed) earlier
-  const int j = blockIdx.x * 256 + threadIdx.x;                    // image slot
+  const int slot = threadIdx.x & 15, part = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + slot;                            // image slot
   const int s = j % ADJ_IMAGE, l = j / ADJ_IMAGE, q = (l >> 4) & 3;
   const bool bias_share = s >= 32;
   const bool owner = !bias_share || q == 0;
   const bool need_e = k.mode == 2;
-  float S = 0.f, E = 0.f;
-  if (stage != 2 && owner) {
-    const int reps = bias_share ? 4 : 1;
-    for (int rep = 0; rep < reps; ++rep) {
-      const int jj = j + rep * 16 * ADJ_IMAGE;                      // lanes q = 1, 2, 3 of the same (w, n)
-      float a = 0.f, e = 0.f;
-      for (int b = 0; b < r.n_wg; ++b) {
-        const float* img = r.att + (int64_t)b * 2 * ADJ_IMAGE_FLOATS + jj;
-        a += img[0];
-        if (need_e) e += img[ADJ_IMAGE_FLOATS];
+  if (stage != 2) {
+    float a = 0.f, e = 0.f;
+    if (owner) {
+      const int reps = bias_share ? 4 : 1;
+      for (int rep = 0; rep < reps; ++rep) {
+        const float* img = r.att + j + rep * 16 * ADJ_IMAGE;        // lanes q = 1, 2, 3 of the same (w, n)
+        // (n_wg <= 256: at most 16 images per part, all loads in flight at once)
+        float av[16], ev[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int b = part + 16 * u;
+          const bool on = b < r.n_wg;
+          av[u] = on ? img[(int64_t)b * 2 * ADJ_IMAGE_FLOATS] : 0.f;
+          ev[u] = on && need_e ? img[(int64_t)b * 2 * ADJ_IMAGE_FLOATS + ADJ_IMAGE_FLOATS] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { a += av[u]; e += ev[u]; }
       }
-      S += a; E += e;
+    }
+    psum[0][slot][part] = a; psum[1][slot][part] = e;
+  }
+  __syncthreads();
+  double qv[4] = {0.0, 0.0, 0.0, 0.0};
+  if (part == 0) {
+    float S = 0.f, E = 0.f;
+    if (stage == 2) { S = (float)r.sums_in[ADJ_NS + j]; E = (float)r.sums_in[ADJ_NS + ADJ_IMAGE_FLOATS + j]; }
+    else
+      for (int pp = 0; pp < 16; ++pp) { S += psum[0][slot][pp]; E += psum[1][slot][pp]; }
+    if (stage == 1) {
+      r.sums_out[j] = S; r.sums_out[ADJ_IMAGE_FLOATS + j] = E;
+      r.prevS_local[parity * ADJ_IMAGE_FLOATS + j] = S;             // this shard's own increment, for its own running total
+    } else {
+      if (k.mode == 3 && j == 0) {
+        // vjp_t at the interval end: its committed value at the step's start + the dense-output functional of its slopes
+        double vt = 0.0;
+        if (stage == 2) vt = r.sums_in[4];
+        else
+          for (int b = 0; b < r.n_wg; ++b) vt += r.partial[((int64_t)p2 * ADJ_MAX_WG + b) * ADJ_NS + 4];
+        r.carry[0] = (double)((float)k.T + (float)vt);
+      }
+      double q0 = 0.0, q1 = 0.0;
+      const float gn = adj_param_element(k, r.rtol, r.atol, r.G[j], r.prevS[p2 * ADJ_IMAGE_FLOATS + j], S, E, q0, q1);
+      if (k.commit) r.G[j] = gn;
+      if (r.G_local && k.commit)
+        r.G_local[j] += k.commit == 1 ? r.prevS_local[p2 * ADJ_IMAGE_FLOATS + j] : r.prevS_local[parity * ADJ_IMAGE_FLOATS + j];
+      r.prevS[parity * ADJ_IMAGE_FLOATS + j] = S;
+      if (owner) { qv[bias_share ? 2 : 0] = q0; qv[bias_share ? 3 : 1] = q1; }
     }
   }
-  if (stage == 1) {
-    r.sums_out[j] = S; r.sums_out[ADJ_IMAGE_FLOATS + j] = E;
-    r.prevS_local[parity * ADJ_IMAGE_FLOATS + j] = S;               // this shard's own increment, for its own running total
-    return;
-  }
-  if (stage == 2) { S = (float)r.sums_in[ADJ_NS + j]; E = (float)r.sums_in[ADJ_NS + ADJ_IMAGE_FLOATS + j]; }
-  if (k.mode == 3 && j == 0) {
-    // vjp_t at the interval end: its committed value at the step's start + the dense-output functional of its slopes
-    double vt = 0.0;
-    if (stage == 2) vt = r.sums_in[4];
-    else
-      for (int b = 0; b < r.n_wg; ++b) vt += r.partial[((int64_t)p2 * ADJ_MAX_WG + b) * ADJ_NS + 4];
-    r.carry[0] = (double)((float)k.T + (float)vt);
-  }
-  double qv[4] = {0.0, 0.0, 0.0, 0.0};
-  {
-    double q0 = 0.0, q1 = 0.0;
-    const float gn = adj_param_element(k, r.rtol, r.atol, r.G[j], r.prevS[p2 * ADJ_IMAGE_FLOATS + j], S, E, q0, q1);
-    if (k.commit) r.G[j] = gn;
-    if (r.G_local && k.commit)
-      r.G_local[j] += k.commit == 1 ? r.prevS_local[p2 * ADJ_IMAGE_FLOATS + j] : r.prevS_local[parity * ADJ_IMAGE_FLOATS + j];
-    r.prevS[parity * ADJ_IMAGE_FLOATS + j] = S;
-    if (owner) { qv[bias_share ? 2 : 0] = q0; qv[bias_share ? 3 : 1] = q1; }
-  }
-  if (k.mode == 3) return;
-  // block sums (fixed order)
+  if (stage == 1 || k.mode == 3) return;
+  // the block's sums over its 16 slots (fixed order)
+  if (part == 0)
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) qv[i] += __shfl_xor(qv[i], off, 64);
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  if (lane == 0)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) red[i * 4 + wv] = qv[i];
+    for (int i = 0; i < 4; ++i) red[i][slot] = qv[i];
   __syncthreads();
   if (threadIdx.x < 4) {
     const int i = threadIdx.x;
+    double t = 0.0;
+    for (int sl = 0; sl < 16; ++sl) t += red[i][sl];
     // slot p2: where the NEXT attempt launch (parity p2) looks for the sums pending on it, like the state sums
-    r.pq[((int64_t)p2 * ADJ_RBLOCKS + blockIdx.x) * 4 + i] = (red[i * 4] + red[i * 4 + 1]) + (red[i * 4 + 2] + red[i * 4 + 3]);
+    r.pq[((int64_t)p2 * ADJ_RBLOCKS + blockIdx.x) * 4 + i] = t;
   }
 }
 

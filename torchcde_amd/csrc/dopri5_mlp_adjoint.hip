@@ -31,7 +31,7 @@ namespace cde {
 constexpr int MADJ_SLOTS = 6;                    // stages whose factors are kept: 0, 2, 3, 4, 5, 6
 constexpr int MADJ_P2 = 256 * 129, MADJ_P1 = 128 * 33;          // elements of a layer-2 / layer-1 slab partial (bias column last)
 constexpr int MADJ_ELEMS = MADJ_P2 + MADJ_P1;
-constexpr int MADJ_RBLOCKS = (MADJ_ELEMS + 255) / 256;
+constexpr int MADJ_RBLOCKS = (MADJ_ELEMS + 31) / 32;
 constexpr int MADJ_MAX_SPS = 40;                 // slabs per stage of the factor reduction
 constexpr int MADJ_NSUM = ADJ_NS + 2 * ADJ_MAX_PT;
 __host__ __device__ constexpr int madj_slot(int stage) { return stage == 0 ? 0 : stage - 1; }      // stage 1 is never stored
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
 }
 
 // ------------------------------------------------------------------------------------------ the R kernel of this family
-// One thread per element of the slab-partial layout of the factor reduction: layer 2 [256][129] (row = padded (h, c),
+// Works on the elements of the slab-partial layout of the factor reduction: layer 2 [256][129] (row = padded (h, c),
 // columns = hidden-layer unit, last column = the bias), then layer 1 [128][33].  K_s[e] = sum over the slabs of stage s
 // (fixed order); S = sum_s wS[s] K_s, E = sum_s wE[s] K_s with the weights of cde_dopri_adj.h rebuilt from the controller
 // block; then the commit / norm logic of adj_param_element, per-block sums per parameter tensor (W1, b1, W2, b2).
@@ -306,57 +306,70 @@ struct MlpReduceArgs {
   float rtol, atol;
 };
 
+// Launch shape: 32 elements per block x 8 lanes; lane s < 6 adds the slabs of stored stage s (independent loads, eight
+// in flight: one thread walking all 6 x 40 slabs was a 240-deep chain of L2 latencies), the stage images of an element
+// meet in LDS and are weighted in stage order.
 __global__ __launch_bounds__(256) void mlp_adjoint_reduce_kernel(MlpReduceArgs r, int parity) {
-  __shared__ double red[8 * 4];
+  __shared__ float ks[8][33];
+  __shared__ double red[8][32];
   const int p2 = parity ^ 1;
   const AdjCtrl k = *reinterpret_cast<const AdjCtrl*>(r.ctrl + p2 * ADJ_CTRL_STRIDE);
   if (k.c.phase == 4 && k.commit == 0) return;
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  float wS[7], wE[7];
-  adj_stage_weights(k.mode, (float)k.c.dt_try, (float)k.x_end, wS, wE);
+  const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + el;
   const int n_slots = k.mode == 0 ? 1 : k.mode == 1 ? 2 : MADJ_SLOTS;
-  float S = 0.f, E = 0.f;
-  int tensor = -1;                                                 // 0 W1, 1 b1, 2 W2, 3 b2 (torch's parameter order)
-  if (e < MADJ_ELEMS) {
-    const bool layer2 = e < MADJ_P2;
-    const float* base = layer2 ? r.part2 + e : r.part1 + (e - MADJ_P2);
-    const int64_t stride = layer2 ? MADJ_P2 : MADJ_P1;
-    const int col = layer2 ? e % 129 : (e - MADJ_P2) % 33;
-    tensor = layer2 ? (col == 128 ? 3 : 2) : (col == 32 ? 1 : 0);
-    for (int slot = 0; slot < n_slots; ++slot) {
-      const int stage = k.mode <= 1 ? slot : (slot == 0 ? 0 : slot + 1);
-      float ks = 0.f;
-      for (int b = 0; b < r.sps; ++b) ks += base[((int64_t)slot * r.sps + b) * stride];
-      S = __builtin_fmaf(wS[stage], ks, S);
-      E = __builtin_fmaf(wE[stage], ks, E);
+  const bool layer2 = e < MADJ_P2;
+  {
+    float sum = 0.f;
+    if (e < MADJ_ELEMS && sl < n_slots) {
+      const float* base = (layer2 ? r.part2 + e : r.part1 + (e - MADJ_P2)) + (int64_t)sl * r.sps * (layer2 ? MADJ_P2 : MADJ_P1);
+      const int64_t stride = layer2 ? MADJ_P2 : MADJ_P1;
+      for (int b0 = 0; b0 < r.sps; b0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = b0 + u < r.sps ? base[(int64_t)(b0 + u) * stride] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum += v[u];
+      }
+    }
+    ks[sl][el] = sum;
+  }
+  __syncthreads();
+  double qv[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (sl == 0) {
+    if (k.mode == 3 && e == 0) {
+      double vt = 0.0;
+      for (int b = 0; b < r.n_wg; ++b) vt += r.partial[((int64_t)p2 * r.n_wg_max + b) * ADJ_NS + 4];
+      r.carry[0] = (double)((float)k.T + (float)vt);
+    }
+    if (e < MADJ_ELEMS) {
+      float wS[7], wE[7];
+      adj_stage_weights(k.mode, (float)k.c.dt_try, (float)k.x_end, wS, wE);
+      float S = 0.f, E = 0.f;
+      for (int slot = 0; slot < n_slots; ++slot) {
+        const int stage = k.mode <= 1 ? slot : (slot == 0 ? 0 : slot + 1);
+        S = __builtin_fmaf(wS[stage], ks[slot][el], S);
+        E = __builtin_fmaf(wE[stage], ks[slot][el], E);
+      }
+      const int col = layer2 ? e % 129 : (e - MADJ_P2) % 33;
+      const int tensor = layer2 ? (col == 128 ? 3 : 2) : (col == 32 ? 1 : 0);      // 0 W1, 1 b1, 2 W2, 3 b2 (torch's order)
+      double q0 = 0.0, q1 = 0.0;
+      const float gn = adj_param_element(k, r.rtol, r.atol, r.G[e], r.prevS[p2 * MADJ_ELEMS + e], S, E, q0, q1);
+      if (k.commit) r.G[e] = gn;
+      r.prevS[parity * MADJ_ELEMS + e] = S;
+      qv[2 * tensor] = q0; qv[2 * tensor + 1] = q1;
     }
   }
-  if (k.mode == 3 && e == 0) {
-    double vt = 0.0;
-    for (int b = 0; b < r.n_wg; ++b) vt += r.partial[((int64_t)p2 * r.n_wg_max + b) * ADJ_NS + 4];
-    r.carry[0] = (double)((float)k.T + (float)vt);
-  }
-  double qv[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  if (e < MADJ_ELEMS) {
-    double q0 = 0.0, q1 = 0.0;
-    const float gn = adj_param_element(k, r.rtol, r.atol, r.G[e], r.prevS[p2 * MADJ_ELEMS + e], S, E, q0, q1);
-    if (k.commit) r.G[e] = gn;
-    r.prevS[parity * MADJ_ELEMS + e] = S;
-    qv[2 * tensor] = q0; qv[2 * tensor + 1] = q1;
-  }
   if (k.mode == 3) return;
+  if (sl == 0)
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) qv[i] += __shfl_xor(qv[i], off, 64);
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  if (lane == 0)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) red[i * 4 + wv] = qv[i];
+    for (int i = 0; i < 8; ++i) red[i][el] = qv[i];
   __syncthreads();
   if (threadIdx.x < 8) {
     const int i = threadIdx.x;
-    r.pq[((int64_t)p2 * MADJ_RBLOCKS + blockIdx.x) * 8 + i] = (red[i * 4] + red[i * 4 + 1]) + (red[i * 4 + 2] + red[i * 4 + 3]);
+    double t = 0.0;
+    for (int x = 0; x < 32; ++x) t += red[i][x];
+    r.pq[((int64_t)p2 * MADJ_RBLOCKS + blockIdx.x) * 8 + i] = t;
   }
 }
 
