@@ -2,6 +2,8 @@
 """bench.py -- series/sec (fwd+adjoint) for cdeint RK4, batch=32768, L=128, C=8, H=32 (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py --config 4 [--controller local|shared] [--adjoint] [--gpus N]     BASELINE configs[3] (see run_adaptive_config)
+    python bench.py --config 5 [--method dopri5|rk4] [--gpus N]                       BASELINE configs[4] (see run_logode_config)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -268,9 +270,174 @@ def other_configs(cde, device, reps=3):
     return out
 
 
+def run_adaptive_config(args, cde, device, rank, world, distributed, share_gpu):
+    """--config 4: BASELINE configs[3] -- 32768 series PER GPU (262,144 over 8), linear_interpolation_coeffs +
+    LinearInterpolation, dopri5 (rtol 1e-4, atol 1e-6, jump_t = the knots), linear func; one step = one adaptive forward
+    solve of this rank's shard (`--adjoint`: + the default adjoint backward and the gradient all-reduce).
+    `--controller local`: every rank runs its own step controller (no collective at all in the forward solve);
+    `--controller shared`: torchcde_amd.distributed.shared_step_control -- the pending error sums of EVERY attempted step
+    are all-reduced over RCCL, so all shards take the step sequence of the unsharded 32768 x N batch (torchdiffeq's
+    controller is batch-global).  With CDE_BENCH_FORCE_DIST=1 on a 1-GPU box the shared mode measures the cost of that
+    per-attempt all-reduce on one rank."""
+    import contextlib
+    import torch.distributed as dist
+    from helpers import LinearField, make_series
+    from torchcde_amd.distributed import allreduce_gradients, shared_step_control
+    front = sys.modules["torchcde_amd.cdeint"]
+    n = 32768
+    x = make_series(n, L, C, seed=rank).to(device)
+    X = cde.LinearInterpolation(cde.linear_interpolation_coeffs(x))
+    func = LinearField(H, C, scale=0.25, seed=0).to(device)
+    z0 = torch.randn(n, H, generator=torch.Generator().manual_seed(rank)).to(device)
+    kw = dict(method="dopri5", rtol=1e-4, atol=1e-6, options=dict(jump_t=X.grid_points))
+    if args.norm == "seminorm":
+        kw["adjoint_options"] = dict(norm="seminorm", jump_t=X.grid_points)
+    params = list(func.parameters())
+    shared = args.controller == "shared"
+    if shared and not distributed:
+        raise SystemExit("--controller shared needs a process group (N > 1, or CDE_BENCH_FORCE_DIST=1 on one GPU)")
+
+    def step():
+        scope = shared_step_control(n * world) if shared else contextlib.nullcontext()
+        with scope:
+            if args.adjoint:
+                z = z0.detach().requires_grad_(True)
+                for p in params:
+                    p.grad = None
+                cde.cdeint(X, func, z, X.interval, **kw)[:, -1].sum().backward()
+                if distributed:
+                    allreduce_gradients(params)
+            else:
+                with torch.no_grad():
+                    cde.cdeint(X, func, z0, X.interval, **kw)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+    if rank == 0:
+        fwd, bwd = dict(front.last_dopri5_stats), dict(front.last_dopri5_adjoint_stats) if args.adjoint else {}
+        attempts = fwd.get("launches", 0) + bwd.get("launches", 0)
+        print(json.dumps({
+            "metric": "series/sec, dopri5 adaptive cdeint %s, 32768 series per GPU, L=128 C=8 H=32 (BASELINE configs[3])"
+                      % ("forward + adjoint" if args.adjoint else "forward"),
+            "value": n * world * args.steps / elapsed, "unit": "series/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" + (" (LAUNCHER CHECK: ranks share cuda:0 over gloo)" if share_gpu else ""),
+            "config": {"workload": "BASELINE configs[3]: linear_interpolation_coeffs + LinearInterpolation, dopri5 rtol 1e-4 "
+                                   "atol 1e-6 jump_t = knots, linear func; %d series in total" % (n * world),
+                       "controller": args.controller, "adjoint": bool(args.adjoint), "adjoint_norm": args.norm,
+                       "batch_per_gpu": n, "global_batch": n * world,
+                       "parallelism": "batch-sharded x%d; %s" % (world, "one 16-byte all-reduce per attempted step (forward)"
+                                                                 if shared else "no collective in the solve")},
+            "extra": {"forward_steps": fwd, "backward_steps": {k: v for k, v in bwd.items() if k in ("n_accept", "n_reject", "launches")},
+                      "kernel_launches_per_step": attempts,
+                      "us_per_attempted_step": elapsed / args.steps * 1e6 / max(attempts, 1)}}))
+
+
+def run_logode_config(args, cde, device, rank, world, distributed, share_gpu):
+    """--config 5: BASELINE configs[4] -- the log-ODE pipeline on 32768 series per GPU: raw (32768, 512, 3) -> depth-3
+    logsignatures over windows of 8 (K5, 65 x 14) -> LinearInterpolation -> the two-layer field of
+    example/logsignature_example.py:21-23 (hidden size 8, width 128), forward + adjoint, gradient all-reduce.
+    `--method dopri5` is the call as the reference's example makes it (no method: K4 + K4am); `--method rk4` the fixed-step
+    solve (K2m + K3m).  One step = transform + solve + backward of this rank's shard."""
+    import torch.distributed as dist
+    from helpers import TwoLayerField
+    from torchcde_amd.distributed import allreduce_gradients
+    front = sys.modules["torchcde_amd.cdeint"]
+    n = 32768
+    gen = torch.Generator().manual_seed(1 + rank)
+    raw = (torch.randn(n, 512, 3, generator=gen) * 0.1).cumsum(1)
+    raw[..., 0] = torch.linspace(0, 1, 512)
+    raw = raw.to(device)
+    field = TwoLayerField(8, 14, 128, seed=0).to(device)
+    z8 = torch.randn(n, 8, generator=gen).to(device)
+    params = list(field.parameters())
+    solver = dict(method="rk4", options={"step_size": 1.0}) if args.method == "rk4" else {}
+    if args.method != "rk4" and args.norm == "seminorm":
+        solver["adjoint_options"] = dict(norm="seminorm")
+    times = {"transform": 0.0}
+
+    def step():
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        Xl = cde.LinearInterpolation(cde.linear_interpolation_coeffs(cde.logsig_windows(raw, 3, 8.0)))
+        ev[1].record()
+        z = z8.detach().requires_grad_(True)
+        for p in params:
+            p.grad = None
+        cde.cdeint(Xl, field, z, Xl.interval, **solver)[:, -1].sum().backward()
+        if distributed:
+            allreduce_gradients(params)
+        return ev
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    events = [step() for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    times["transform"] = sum(a.elapsed_time(b) for a, b in events) / max(len(events), 1)
+    if distributed:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+    if rank == 0:
+        extra = {"logsig_transform_ms": times["transform"]}
+        if args.method != "rk4":
+            extra["forward_steps"] = dict(front.last_dopri5_stats)
+            extra["backward_steps"] = {k: v for k, v in front.last_dopri5_adjoint_stats.items()
+                                       if k in ("n_accept", "n_reject", "launches")}
+        print(json.dumps({
+            "metric": "series/sec, log-ODE pipeline (depth-3 logsignature windows + two-layer field, %s, fwd+adjoint), "
+                      "32768 x 512 x 3 per GPU (BASELINE configs[4])" % args.method,
+            "value": n * world * args.steps / elapsed, "unit": "series/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" + (" (LAUNCHER CHECK: ranks share cuda:0 over gloo)" if share_gpu else ""),
+            "config": {"workload": "BASELINE configs[4]: logsig_windows(depth 3, window 8) -> LinearInterpolation -> "
+                                   "Linear(8,128)-relu-Linear(128,112)-tanh field, method %s, adjoint=True; %d series in total"
+                                   % ("dopri5 (the reference example's default call)" if args.method != "rk4" else "rk4 step 1",
+                                      n * world),
+                       "method": args.method, "adjoint_norm": args.norm, "batch_per_gpu": n, "global_batch": n * world,
+                       "parallelism": "batch-sharded x%d, one gradient all-reduce per step" % world},
+            "extra": extra}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--config", type=int, choices=(3, 4, 5), default=3,
+                    help="3 (default): the headline metric, BASELINE configs[2]; 4: configs[3] (sharded adaptive dopri5 solve); "
+                         "5: configs[4] (log-ODE pipeline)")
+    ap.add_argument("--controller", choices=("local", "shared"), default="local",
+                    help="--config 4: one step controller per rank, or ONE for the whole sharded batch (all-reduce per attempt)")
+    ap.add_argument("--adjoint", action="store_true", help="--config 4: also time the default adjoint backward")
+    ap.add_argument("--method", choices=("dopri5", "rk4"), default="dopri5", help="--config 5: the solver")
+    ap.add_argument("--norm", choices=("mixed", "seminorm"), default="mixed",
+                    help="adaptive adjoint: torchdiffeq's default mixed norm or adjoint_options=dict(norm='seminorm')")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
@@ -296,7 +463,7 @@ def main():
              % (args.gpus, world))
     global B
     B_TOTAL = B
-    if args.scaling == "strong":
+    if args.scaling == "strong" and args.config == 3:
         if B_TOTAL % world:
             raise SystemExit("strong scaling needs 32768 %% n_gpus == 0, got n_gpus=%d" % world)
         B = B_TOTAL // world                      # per-rank batch; FLOP/byte bookkeeping below is per rank
@@ -324,6 +491,12 @@ def main():
     from torchcde_amd.cdeint import _Plan
     from torchcde_amd.distributed import allreduce_gradients
     cde.load()
+    if args.config != 3:
+        runner = run_adaptive_config if args.config == 4 else run_logode_config
+        runner(args, cde, device, rank, world, distributed, share_gpu)
+        if distributed:
+            dist.destroy_process_group()
+        return
 
     _log("rank %d/%d building workload (%d series on this rank, %s scaling)" % (rank, world, B, args.scaling))
     if args.scaling == "strong":                  # this rank's shard of THE 32768-series job
