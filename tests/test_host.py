@@ -734,3 +734,76 @@ def test_log_ode_plan_cache_is_keyed_on_the_values_of_t_not_on_its_address():
     t.mul_(2.0)
     second = log_ode._plan(t, True, 4.0, 17, 3, 2, 1, t.dtype, torch.device("cpu"))["rows"].tolist()
     assert first == [0, 4, 8, 12, 16] and second == oracle_logsig.window_plan(t, 4.0)[1] != first
+
+
+def test_dispatch_table_is_exhaustively_consistent():
+    """torchcde_amd/dispatch.py: the field kind x method x gradient request -> path table that replaced round 2's
+    if-lattice.  ALL combinations of its inputs are enumerated (3 kinds x 3 methods x 2^13 flags x 3 parameter kinds,
+    pruned of contradictory ones) and every verdict is checked against the invariants the kernels rely on; then the rows a
+    user meets are spelled out one by one."""
+    import itertools
+    from torchcde_amd import dispatch as D
+    flags = ["prod", "tiles_ok", "mfma_shape", "adjoint", "wants_grad", "wants_t", "wants_control", "adjoint_method_ok",
+             "options_ok", "adjoint_options_ok", "t_ok", "variant_generic", "shared", "narrow_control"]
+    seen = collections_counter = {}
+    n = 0
+    for kind in (None, "affine", "mlp2"):
+        for method in ("rk4", "dopri5", "midpoint"):
+            for params in ("default", "own", "foreign"):
+                for bits in itertools.product((False, True), repeat=len(flags)):
+                    f = dict(zip(flags, bits))
+                    if (f["wants_t"] or f["wants_control"]) and not f["wants_grad"]:
+                        continue                                 # contradictory requests are never built by cdeint
+                    if f["mfma_shape"] and (kind != "affine" or not f["tiles_ok"] or f["variant_generic"]):
+                        continue
+                    q = D.Request(kind=kind, method=method, params=params, **f)
+                    c = D.select_path(q)
+                    n += 1
+                    seen[c.path] = seen.get(c.path, 0) + 1
+                    assert c.path in D.FUSED_PATHS or c.path == D.STEPWISE
+                    assert (c.path == D.STEPWISE) == bool(c.reason)          # every step-wise verdict says why
+                    if c.path == D.STEPWISE:
+                        continue
+                    # ---- what every fused path may assume
+                    assert not f["prod"] and kind is not None and f["tiles_ok"] and f["t_ok"] and f["options_ok"]
+                    assert method == ("rk4" if "rk4" in c.path else "dopri5")
+                    assert c.path.startswith("mlp_") == (kind == "mlp2")
+                    assert ("forward" in c.path) <= (not f["wants_grad"])    # forward-only kernels: nothing to differentiate
+                    if f["wants_grad"]:
+                        assert f["adjoint"] and f["adjoint_method_ok"] and f["adjoint_options_ok"] and params != "foreign"
+                    if c.path == "dopri5_adjoint":
+                        assert f["mfma_shape"] and not f["wants_t"] and not f["wants_control"]
+                    if c.path == "mlp_dopri5_adjoint":
+                        assert not f["shared"] and not f["wants_t"] and not f["wants_control"]
+                    if kind == "mlp2":
+                        assert not f["variant_generic"]
+                        assert not f["wants_t"] and (not f["wants_control"] or (f["narrow_control"] and method == "rk4"))
+                    if kind == "affine" and (f["wants_t"] or f["wants_control"]):
+                        assert f["mfma_shape"] and method == "rk4"
+    assert n > 100000 and set(seen) == set(D.FUSED_PATHS) | {D.STEPWISE}       # every path is reachable
+
+    def ask(**kw):
+        base = dict(prod=False, kind="affine", tiles_ok=True, mfma_shape=True, method="dopri5", adjoint=True,
+                    wants_grad=True, wants_t=False, wants_control=False, params="default", adjoint_method_ok=True,
+                    options_ok=True, adjoint_options_ok=True, t_ok=True, variant_generic=False, shared=False,
+                    narrow_control=True)
+        base.update(kw)
+        return D.select_path(D.Request(**base))
+    # the rows a user meets
+    assert ask().path == "dopri5_adjoint"                                       # README.md:55: cdeint(X, func, z0, t)
+    assert ask(kind="mlp2", mfma_shape=False).path == "mlp_dopri5_adjoint"      # example/time_series_classification.py:83-86
+    assert ask(method="rk4").path == "rk4"                                      # BASELINE configs[2]
+    assert ask(method="rk4", wants_grad=False, adjoint=False).path == "rk4"     # BASELINE configs[1]
+    assert ask(wants_grad=False).path == "dopri5_forward"                       # BASELINE configs[3]
+    assert ask(kind="mlp2", mfma_shape=False, method="rk4").path == "mlp_rk4_adjoint"      # BASELINE configs[4] with rk4
+    assert ask(shared=True).path == "dopri5_adjoint"                            # one controller over the shards
+    assert ask(method="rk4", wants_control=True, params="own").path == "rk4"    # README.md:251-270
+    for kw, word in ((dict(kind=None), "recognised"), (dict(method="midpoint"), "midpoint"),
+                     (dict(adjoint=False), "adjoint=False"), (dict(options_ok=False), "options"),
+                     (dict(mfma_shape=False), "32 x 8"), (dict(wants_t=True), "time"),
+                     (dict(kind="mlp2", mfma_shape=False, shared=True), "shared_step_control"),
+                     (dict(kind="mlp2", mfma_shape=False, method="rk4", wants_control=True, narrow_control=False), "8 channels"),
+                     (dict(t_ok=False), "increasing"), (dict(params="foreign"), "adjoint_params"),
+                     (dict(prod=True), "prod"), (dict(tiles_ok=False, mfma_shape=False), "tiles")):
+        verdict = ask(**kw)
+        assert verdict.path == D.STEPWISE and word in verdict.reason, (kw, verdict)

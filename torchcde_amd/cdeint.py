@@ -24,7 +24,7 @@ import weakref
 
 import torch
 
-from . import _lib
+from . import _lib, dispatch
 from .fields import probe
 from .paths import _NativePath
 
@@ -458,6 +458,7 @@ class _FusedRK4(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------ dopri5 (K4)
+last_dispatch = dispatch.last      # () -> (Choice(path, reason), Request) of this thread's most recent cdeint call
 last_dopri5_stats = {}     # {"n_accept", "n_reject", "launches"} of the most recent adaptive solve (for tests / logging)
 last_dopri5_adjoint_stats = {}   # the same for the most recent fused adaptive backward (summed over the output intervals)
 record_dopri5_steps = False   # tests: also fetch the accepted (t0, t1, on_jump) steps into last_dopri5_stats["steps"]
@@ -929,6 +930,7 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
             raise ValueError("func.prod did not return a tensor with the same shape as z0. func.prod returned shape {} "
                              "whilst z0 has shape {}.".format(tuple(first.shape), tuple(z0.shape)))
         from . import stepwise
+        dispatch.record(dispatch.Choice(dispatch.STEPWISE, "func.prod multiplies by the control derivative itself"), None)
         kw = stepwise_kwargs
         return stepwise.solve(X, func, z0, t, adjoint, kw.pop("method", None) or "dopri5", kw.pop("options", None),
                               kw["rtol"], kw["atol"], kw.get("adjoint_method"), kw.get("adjoint_options"),
@@ -943,6 +945,7 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
     # func's formula, when the probe identified it: lets the step-wise adjoint write its dynamics in closed form
     # (`variant="generic"` keeps autograd: the independent cross-check the tests compare against)
     recognised = field if variant == _lib.VARIANT_AUTO else None
+    recognised_kind = None if field is None else field.kind
     mlp = None
     if field is not None and field.kind == "mlp2":
         mlp, field = (field if _mlp_fusable(field, H, C, z0, packed) else None), None
@@ -982,142 +985,126 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
     control_wants = grad_mode and adjoint and given_params is not None and any(
         isinstance(p, torch.Tensor) and p.requires_grad and p.untyped_storage().data_ptr() in control_ids
         for p in given_params)
-    mfma_shape = z0.dtype == torch.float32 and H <= 32 and C <= 8 and variant != _lib.VARIANT_GENERIC
-    # the adaptive backward (K4a): affine family on the MFMA tiles, adjoint solver = forward solver with the same
-    # options (the reference's default: solver.py:199-203 only copies the tolerances), parameters of the field only
-    # adjoint_options: none (the backward inherits the forward options and runs under torchdiffeq's default mixed norm),
-    # or explicit ones with norm absent / "seminorm" (torchdiffeq's norm without the parameter blocks)
+    mfma_shape = (field is not None and z0.dtype == torch.float32 and H <= 32 and C <= 8
+                  and variant != _lib.VARIANT_GENERIC)
     adj_opts = kwargs.get("adjoint_options")
-    adj_opts_ok = adj_opts is None or (isinstance(adj_opts, dict) and adj_opts.get("norm", "seminorm") == "seminorm"
-                                       and set(adj_opts) <= {"norm", "jump_t", "safety", "ifactor", "dfactor"})
-    dopri_adjoint = (method == "dopri5" and adjoint and wants_grad and not wants_t and not control_wants and mfma_shape
-                     and field is not None and kwargs.get("adjoint_method") in (None, "dopri5")
-                     and adj_opts_ok and set(options or ()) <= {"jump_t", "safety", "ifactor", "dfactor"}
-                     and (given_params is None or all(p is field.weight or p is field.bias for p in given_params)))
-    fused = (field is not None and ((method == "rk4" and (adjoint or not wants_grad))
-                                    or (method == "dopri5" and (not wants_grad or dopri_adjoint)))
-             and not ((wants_t or control_wants) and not (adjoint and mfma_shape)))
-    mlp_want_x = False
-    mlp_params_ok = mlp is not None and given_params is None
-    if mlp is not None and given_params is not None:
-        # adjoint_params = all four layer parameters, optionally + the control's coefficient tensor
-        own = (mlp.hidden.weight, mlp.hidden.bias, mlp.output.weight, mlp.output.bias)
-        storages = {b.untyped_storage().data_ptr() for b in X._control_buffers()}
+    adjoint_method = kwargs.get("adjoint_method")
+    t_is_vector = isinstance(t, torch.Tensor) and t.dim() == 1 and t.is_floating_point() and t.numel() >= 1
+    t_host = _to_host(t) if t_is_vector else None
+    increasing = t_is_vector and (t_host.numel() == 1 or bool((t_host[1:] > t_host[:-1]).all()))
+
+    # ---- how the caller's adjoint_params relate to the field's own parameters and the control's tensors
+    known = field if field is not None else mlp
+    own = () if known is None else (
+        (field.weight, field.bias) if field is not None else
+        (mlp.hidden.weight, mlp.hidden.bias, mlp.output.weight, mlp.output.bias))
+    params_kind = "default"
+    if given_params is not None and known is not None:
         extra = [p for p in given_params if not any(p is o for o in own)]
-        mlp_params_ok = (all(any(p is o for p in given_params) for o in own)
-                         and all(isinstance(p, torch.Tensor) and p is not X._t
-                                 and p.untyped_storage().data_ptr() in storages for p in extra))
-        mlp_want_x = mlp_params_ok and any(p.requires_grad for p in extra) and grad_mode
-        if mlp_want_x and C > 8:
-            mlp = None                # control gradients come out of the 8-channel sweep only: step-wise instead
-    if (mlp is not None and wants_grad and not wants_t and adjoint and method == "rk4"
-            and variant != _lib.VARIANT_GENERIC
-            and set(options or ()) <= {"step_size"} and set(kwargs.get("adjoint_options") or ()) <= {"step_size"}
-            and kwargs.get("adjoint_method") in (None, "rk4") and mlp_params_ok
-            and isinstance(t, torch.Tensor) and t.dim() == 1 and t.is_floating_point() and t.numel() >= 1
-            and not t.requires_grad):
-        # two-layer field, training: fused forward (K2m) + continuous-adjoint sweep (K3m) and two GEMMs
-        t_host = _to_host(t)
-        if t_host.numel() == 1 or bool((t_host[1:] > t_host[:-1]).all()):
-            step = _parse_fixed_options(options, "solver")
-            adj_opts = kwargs.get("adjoint_options")
-            adj_step = step if adj_opts is None else _parse_fixed_options(adj_opts, "adjoint")
-            plan = _MlpPlan(X, mlp, batch, H, C, t, step, adj_step)
-            control_inputs = X._control_buffers() if mlp_want_x else ()
-            return _FusedMlpRK4.apply(z0, mlp.hidden.weight, mlp.hidden.bias, mlp.output.weight, mlp.output.bias, plan,
-                                      mlp_want_x, *control_inputs)
-    if (mlp is not None and wants_grad and not wants_t and adjoint and method == "dopri5" and not mlp_want_x
-            and variant != _lib.VARIANT_GENERIC and adj_opts_ok and kwargs.get("adjoint_method") in (None, "dopri5")
-            and set(options or ()) <= {"jump_t", "safety", "ifactor", "dfactor"}
-            and (given_params is None or mlp_params_ok)
-            and isinstance(t, torch.Tensor) and t.dim() == 1 and t.is_floating_point() and t.numel() >= 1):
-        # two-layer field, the reference examples' own training call (no method: dopri5 + adjoint): K4 forward, K4am backward
-        from .distributed import step_control
-        t_host = _to_host(t)
-        if (t_host.numel() == 1 or bool((t_host[1:] > t_host[:-1]).all())) and step_control() is None:
-            plan = _Dopri5Plan(X, mlp, batch, H, C, t, kwargs["rtol"], kwargs["atol"], options, variant,
-                               kwargs.get("adjoint_rtol"), kwargs.get("adjoint_atol"), adj_opts)
-            return _FusedMlpDopri5.apply(z0, mlp.hidden.weight, mlp.hidden.bias, mlp.output.weight, mlp.output.bias, plan)
-    if (mlp is not None and not wants_grad and variant != _lib.VARIANT_GENERIC
-            and isinstance(t, torch.Tensor) and t.dim() == 1 and t.is_floating_point() and t.numel() >= 1):
-        # two-layer field, nothing to differentiate: the fused forward kernels (K2m / K4 with the two-layer field)
-        t_host = _to_host(t)
-        increasing = t_host.numel() == 1 or bool((t_host[1:] > t_host[:-1]).all())
-        if increasing and method == "rk4" and set(options or ()) <= {"step_size"}:
-            return _MlpPlan(X, mlp, batch, H, C, t, _parse_fixed_options(options, "solver")).run(z0)
-        if increasing and method == "dopri5" and set(options or ()) <= {"jump_t", "safety", "ifactor", "dfactor"}:
-            plan = _Dopri5Plan(X, mlp, batch, H, C, t, kwargs["rtol"], kwargs["atol"], options)
-            return plan.run(z0, mlp.weight, mlp.bias).reshape(*batch, plan.n_out, H)
-    if not fused:
+        extra_ok = all(isinstance(p, torch.Tensor) and p.untyped_storage().data_ptr() in control_ids for p in extra)
+        complete = field is not None or all(any(p is o for p in given_params) for o in own)    # K3m / K4am: all four or none
+        params_kind = "own" if (extra_ok and complete) else "foreign"
+        if field is None and any(p is X._t for p in extra):
+            params_kind = "foreign"             # knot-time gradients of a two-layer solve: step-wise
+
+    fixed_keys, adaptive_keys = {"step_size"}, {"jump_t", "safety", "ifactor", "dfactor"}
+
+    def within(opts, allowed):
+        return opts is None or (isinstance(opts, dict) and set(k for k, v in opts.items() if v is not None) <= allowed)
+
+    if method == "dopri5":
+        options_ok = within(options, adaptive_keys)
+        adjoint_options_ok = adj_opts is None or (within(adj_opts, adaptive_keys | {"norm"})
+                                                  and adj_opts.get("norm", "seminorm") == "seminorm")
+    else:
+        options_ok = within(options, fixed_keys)
+        adjoint_options_ok = within(adj_opts, fixed_keys)
+    from .distributed import step_control
+    request = dispatch.Request(
+        prod=False, kind=None if known is None else known.kind, tiles_ok=known is not None, mfma_shape=mfma_shape,
+        method=method, adjoint=bool(adjoint), wants_grad=bool(wants_grad), wants_t=bool(wants_t),
+        wants_control=bool(control_wants), params=params_kind,
+        adjoint_method_ok=adjoint_method in (None, method), options_ok=options_ok,
+        adjoint_options_ok=adjoint_options_ok, t_ok=bool(increasing) or not t_is_vector,
+        variant_generic=variant == _lib.VARIANT_GENERIC, shared=step_control() is not None, narrow_control=C <= 8)
+    if recognised_kind is not None and known is None:
+        # the probe recognised the formula but the shape / dtype is beyond the tiles: say so in the record and the warning
+        request = request._replace(kind=recognised_kind, tiles_ok=False)
+    choice = dispatch.select_path(request)
+    dispatch.record(choice, request)
+
+    if choice.path == dispatch.STEPWISE:
         # Arbitrary vector fields / methods / differentiation modes: host-driven stepping with the native control
         # derivative and contraction kernels under every evaluation (torchcde_amd/stepwise.py).
         from . import stepwise
-        from .distributed import step_control
-        if step_control() is not None and (method == "dopri5" or kwargs.get("adjoint_method") == "dopri5"):
+        dispatch.warn_once(func, choice, request)
+        if step_control() is not None and (method == "dopri5" or adjoint_method == "dopri5"):
             warnings.warn("torchcde_amd: shared_step_control() is active but this adaptive solve runs step-wise, which "
                           "does not share its step controller across ranks: every rank takes its own step sequence.")
         kw = stepwise_kwargs
         return stepwise.solve(X, func, z0, t, adjoint, method, options, kw["rtol"], kw["atol"],
                               kw.get("adjoint_method"), kw.get("adjoint_options"), kw.get("adjoint_rtol"),
                               kw.get("adjoint_atol"), kw.get("adjoint_params"), recognised=recognised)
-    if not (isinstance(t, torch.Tensor) and t.dim() == 1 and t.is_floating_point()):
+    if not t_is_vector:
         raise ValueError("t must be a one dimensional floating point tensor.")
-    if t.numel() < 1:
-        raise ValueError("t must contain at least one time.")
-    t_host = _to_host(t)
-    if t_host.numel() > 1 and not bool((t_host[1:] > t_host[:-1]).all()):
-        raise NotImplementedError("torchcde_amd: t must be strictly increasing on the native path.")
-    if method == "dopri5":
-        for key in ("adjoint_method", "adjoint_options"):
-            kwargs.pop(key, None)
-        given = kwargs.pop("adjoint_params", None)
-        rtol, atol = kwargs.pop("rtol"), kwargs.pop("atol")
-        adjoint_rtol, adjoint_atol = kwargs.pop("adjoint_rtol", None), kwargs.pop("adjoint_atol", None)
-        if kwargs:
-            raise NotImplementedError("torchcde_amd: unsupported cdeint keyword arguments {}".format(sorted(kwargs)))
-        plan = _Dopri5Plan(X, field, batch, H, C, t, rtol, atol, options, variant, adjoint_rtol, adjoint_atol, adj_opts)
-        wants = (True, True) if given is None else (any(p is weight for p in given), any(p is bias for p in given))
-        if not dopri_adjoint:
-            # chosen because nothing is to be differentiated (`adjoint_params=()` with weights that still require grad,
-            # no_grad ...): run outside autograd -- a graph node here would reach K4a without its eligibility checks
+
+    unknown = set(kwargs) - {"rtol", "atol", "adjoint_rtol", "adjoint_atol", "adjoint_method", "adjoint_options",
+                             "adjoint_params"}
+    if unknown:
+        raise NotImplementedError("torchcde_amd: unsupported cdeint keyword arguments {}".format(sorted(unknown)))
+
+    # ---- two-layer fields
+    if choice.path == "mlp_rk4_adjoint":
+        step = _parse_fixed_options(options, "solver")
+        adj_step = step if adj_opts is None else _parse_fixed_options(adj_opts, "adjoint")
+        plan = _MlpPlan(X, mlp, batch, H, C, t, step, adj_step)
+        want_x = bool(control_wants)
+        control_inputs = X._control_buffers() if want_x else ()
+        return _FusedMlpRK4.apply(z0, mlp.hidden.weight, mlp.hidden.bias, mlp.output.weight, mlp.output.bias, plan,
+                                  want_x, *control_inputs)
+    if choice.path == "mlp_rk4_forward":
+        with torch.no_grad():
+            return _MlpPlan(X, mlp, batch, H, C, t, _parse_fixed_options(options, "solver")).run(z0)
+    if choice.path in ("mlp_dopri5_forward", "mlp_dopri5_adjoint"):
+        plan = _Dopri5Plan(X, mlp, batch, H, C, t, kwargs["rtol"], kwargs["atol"], options, variant,
+                           kwargs.get("adjoint_rtol"), kwargs.get("adjoint_atol"), adj_opts)
+        if choice.path == "mlp_dopri5_forward":
+            with torch.no_grad():
+                return plan.run(z0, mlp.weight, mlp.bias).reshape(*batch, plan.n_out, H)
+        # the reference examples' own training call (no method: dopri5 + adjoint): K4 forward, K4am backward
+        return _FusedMlpDopri5.apply(z0, mlp.hidden.weight, mlp.hidden.bias, mlp.output.weight, mlp.output.bias, plan)
+
+    # ---- one-layer fields
+    weight, bias = field.weight, field.bias
+    if choice.path in ("dopri5_forward", "dopri5_adjoint"):
+        plan = _Dopri5Plan(X, field, batch, H, C, t, kwargs["rtol"], kwargs["atol"], options, variant,
+                           kwargs.get("adjoint_rtol"), kwargs.get("adjoint_atol"), adj_opts)
+        if choice.path == "dopri5_forward":
+            # nothing is to be differentiated (`adjoint_params=()` with weights that still require grad, no_grad ...): no
+            # autograd node -- one here would reach K4a without its eligibility checks
             with torch.no_grad():
                 return plan.run(z0, weight, bias).reshape(*batch, plan.n_out, H)
+        wants = (True, True) if given_params is None else (any(p is weight for p in given_params),
+                                                           any(p is bias for p in given_params))
         return _FusedDopri5.apply(z0, weight, bias, plan, wants)
     step_size = _parse_fixed_options(options, "solver")
-    adjoint_method = kwargs.pop("adjoint_method", None)
-    adjoint_options = kwargs.pop("adjoint_options", None)
-    adjoint_params = kwargs.pop("adjoint_params", None)
-    for key in ("atol", "rtol", "adjoint_atol", "adjoint_rtol"):
-        kwargs.pop(key, None)
-    if kwargs:
-        raise NotImplementedError("torchcde_amd: unsupported cdeint keyword arguments {}".format(sorted(kwargs)))
-    if adjoint_method not in (None, "rk4"):
-        raise NotImplementedError("torchcde_amd: adjoint_method must equal the forward method ('rk4').")
-    adjoint_step = step_size if adjoint_options is None else _parse_fixed_options(adjoint_options, "adjoint")
-
+    adjoint_step = step_size if adj_opts is None else _parse_fixed_options(adj_opts, "adjoint")
     want_w = want_b = True
     want_x = want_knots = False
-    if adjoint_params is not None:
-        adjoint_params = tuple(adjoint_params)
-        control = X._control_buffers()
-        control_storage = {b.untyped_storage().data_ptr() for b in control}
-        for p in adjoint_params:
+    if given_params is not None and adjoint:
+        for p in given_params:
             if p is weight or p is bias:
                 continue
             if p is X._t:
                 # the knot times of the control (reference test/test_tricks.py:21-49 passes them): the chain through
                 # `frac = t - t_j` of the spline evaluation
                 want_knots = want_knots or (p.requires_grad and grad_mode)
-                continue
-            if isinstance(p, torch.Tensor) and p.untyped_storage().data_ptr() in control_storage:
+            else:
                 # the coefficient tensor the path was built from (README.md:251-270): dL/dcoeffs flows back to it
                 # through the path's buffer views
                 want_x = want_x or (p.requires_grad and grad_mode)
-                continue
-            raise NotImplementedError("torchcde_amd: adjoint_params may only contain the vector field's weight and "
-                                      "bias, the control's coefficient tensor and its knot times on the native path.")
-        want_w = any(p is weight for p in adjoint_params)
-        want_b = any(p is bias for p in adjoint_params)
+        want_w = any(p is weight for p in given_params)
+        want_b = any(p is bias for p in given_params)
     plan = _Plan(X, field, batch, H, C, t, step_size, adjoint_step, adjoint, variant)
     control_inputs = X._control_buffers() if want_x else ()
     return _FusedRK4.apply(z0, weight, bias, plan, (want_w, want_b, want_x), t if wants_t else None,

@@ -1,0 +1,138 @@
+"""Which code path a ``cdeint`` call takes -- as a table, not an if-lattice.
+
+``cdeint`` (reference ``torchcde/solver.py:144-245``) accepts any callable ``func``, any torchdiffeq ``method`` / ``options``
+and several ways of asking for gradients; the fused HIP kernels cover the combinations that matter and
+everything else is solved step by step on the GPU (``stepwise.py``: host-driven, 10-1000x slower).  Round 2 decided this in
+220 lines of nested conditions with silent cliffs.  Here the decision is a pure function of a small description of the
+request (no tensors), so it can be enumerated exhaustively on the CPU (tests/test_host.py), queried after the fact
+(``torchcde_amd.cdeint.last_dispatch``) and explained: every step-wise verdict carries its reason, and a RECOGNISED
+vector field that falls off the fused paths raises one warning per (module class, reason).
+"""
+import collections
+import threading
+import warnings
+
+# what cdeint knows about a call once the compatibility probe has run
+Request = collections.namedtuple("Request", [
+    "prod",              # func.prod exists (solver.py:48-53): the module multiplies by dX itself
+    "kind",              # None: unrecognised module; "affine": act(Linear(z)); "mlp2": act(Linear(relu(Linear(z))))
+    "tiles_ok",          # the field's shape / dtype fit some fused kernel (cde_rk4_supported; _mlp_fusable)
+    "mfma_shape",        # affine field on the 32 x 8 MFMA tiles (float32, H <= 32, C <= 8, variant != "generic")
+    "method",            # "rk4" | "dopri5" | any other torchdiffeq method name
+    "adjoint",           # cdeint's adjoint flag
+    "wants_grad",        # something requires a gradient through the solve
+    "wants_t",           # ... the output times do
+    "wants_control",     # ... the control's coefficient / knot tensors do (through adjoint_params)
+    "params",            # adjoint_params: "default" | "own" (the field's parameters, all of them for mlp2, plus control
+                         #                 tensors) | "foreign" (anything else)
+    "adjoint_method_ok", # adjoint_method absent or equal to the forward method
+    "options_ok",        # forward options within the fused kernels' set (rk4: step_size; dopri5: jump_t, safety, ifactor, dfactor)
+    "adjoint_options_ok",  # the same for adjoint_options (dopri5: norm absent or "seminorm")
+    "t_ok",              # t is strictly increasing
+    "variant_generic",   # variant="generic" (tests: the independent kernels / the step-wise reference path)
+    "shared",            # torchcde_amd.distributed.shared_step_control is active
+    "narrow_control",    # the control has at most 8 channels (control gradients of a two-layer field)
+])
+
+Choice = collections.namedtuple("Choice", ["path", "reason"])
+
+FUSED_PATHS = (
+    "rk4",                    # K2 / K3 (+ split, wide, generic variants behind CDE_VARIANT_AUTO), incl. time / control gradients
+    "dopri5_forward",         # K4 (MFMA, wide or generic attempt kernel), nothing to differentiate
+    "dopri5_adjoint",         # K4 + K4a: the reference's default training call
+    "mlp_rk4_forward",        # K2m
+    "mlp_rk4_adjoint",        # K2m + K3m + factor reduction (optionally with control gradients)
+    "mlp_dopri5_forward",     # K4 with the two-layer field
+    "mlp_dopri5_adjoint",     # K4 + K4am: the reference examples' training call with their own model
+)
+STEPWISE = "stepwise"
+
+
+def _stepwise(reason):
+    return Choice(STEPWISE, reason)
+
+
+def select_path(q):
+    """The capability table.  Rows are tried top to bottom; the first that applies decides."""
+    if q.prod:
+        return _stepwise("func.prod multiplies by the control derivative itself")
+    if q.kind is None:
+        return _stepwise("the vector field is not of a recognised form (arbitrary module)")
+    if not q.tiles_ok:
+        return _stepwise("the field's shape or dtype is beyond the fused kernels' tiles")
+    if not q.t_ok:
+        return _stepwise("the output times are not strictly increasing")
+    if q.method not in ("rk4", "dopri5"):
+        return _stepwise("method %r has no fused kernel (rk4 and dopri5 have)" % (q.method,))
+    if q.wants_grad and not q.adjoint:
+        return _stepwise("adjoint=False with gradients: backpropagation through the solver's own operations")
+    if not q.options_ok:
+        return _stepwise("solver options outside the fused kernels' set")
+    if q.wants_grad and not q.adjoint_method_ok:
+        return _stepwise("adjoint_method differs from the forward method")
+    if q.wants_grad and not q.adjoint_options_ok:
+        return _stepwise("adjoint_options outside the fused kernels' set")
+    if q.wants_grad and q.params == "foreign":
+        return _stepwise("adjoint_params holds tensors other than the field's parameters and the control's")
+    if q.kind == "mlp2":
+        if q.variant_generic:
+            return _stepwise("variant='generic' was requested (the step-wise reference path)")
+        if not q.wants_grad:
+            if q.method == "dopri5" and q.shared:
+                return _stepwise("shared_step_control covers the one-layer fields only")
+            return Choice("mlp_rk4_forward" if q.method == "rk4" else "mlp_dopri5_forward", "")
+        if q.wants_t:
+            return _stepwise("gradients w.r.t. the output times of a two-layer field")
+        if q.wants_control:
+            if q.method == "dopri5":
+                return _stepwise("control gradients through the adaptive backward of a two-layer field")
+            if not q.narrow_control:
+                return _stepwise("control gradients of a two-layer field with more than 8 channels")
+            return Choice("mlp_rk4_adjoint", "")
+        if q.method == "rk4":
+            return Choice("mlp_rk4_adjoint", "")
+        if q.shared:
+            return _stepwise("shared_step_control covers the one-layer fields only")
+        return Choice("mlp_dopri5_adjoint", "")
+    # one-layer (affine) fields
+    if (q.wants_t or q.wants_control) and not q.mfma_shape:
+        return _stepwise("time / control gradients outside the 32 x 8 MFMA tiles")
+    if q.method == "rk4":
+        return Choice("rk4", "")
+    if not q.wants_grad:
+        return Choice("dopri5_forward", "")
+    if q.wants_t or q.wants_control:
+        return _stepwise("time / control gradients through the adaptive backward")
+    if not q.mfma_shape:
+        return _stepwise("the adaptive backward exists for the 32 x 8 MFMA tiles only (float32, H <= 32, C <= 8)")
+    return Choice("dopri5_adjoint", "")
+
+
+# ------------------------------------------------------------------------------------------ record + warnings
+_local = threading.local()
+_warned = set()
+_warned_lock = threading.Lock()
+
+
+def record(choice, request):
+    """Remember the verdict of the calling thread's most recent cdeint call (`last()`)."""
+    _local.last = (choice, request)
+
+
+def last():
+    """(Choice, Request) of this thread's most recent cdeint call, or None."""
+    return getattr(_local, "last", None)
+
+
+def warn_once(func, choice, request):
+    """A recognised field that leaves the fused paths: one warning per (module class, reason)."""
+    if choice.path != STEPWISE or request.kind is None or request.variant_generic:
+        return
+    key = (type(func), choice.reason)
+    with _warned_lock:
+        if key in _warned:
+            return
+        _warned.add(key)
+    warnings.warn("torchcde_amd: this cdeint call runs step-wise (host-driven stepping on the GPU, typically 10-1000x "
+                  "slower than the fused kernels) although %s is a vector field the fused kernels know: %s."
+                  % (type(func).__name__, choice.reason), stacklevel=3)
