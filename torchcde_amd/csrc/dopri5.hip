@@ -1048,7 +1048,7 @@ static int dopri5_advance_impl(const void* coeffs, const void* knots, int64_t n_
   void* state = (unsigned char*)w16 + cde::al256(cde::DOPRI_IMAGE_BYTES);
   double* trace = (double*)(base + cde_dopri5_trace_offset(B, C, H, dtype));
   if (first_launch == 0) {
-    if (hipMemsetAsync(ctrl, 0, 2 * sizeof(cde::DopriCtrl), s) != hipSuccess) return CDE_ERR_LAUNCH;   // phase 0
+    cde::zero_async(ctrl, 2 * sizeof(cde::DopriCtrl), s);                                                // phase 0
   }
   const int ns = cde::dopri_ns(H);
   const int nt = ((ns * (int)H + 63) / 64) * 64;

@@ -723,11 +723,11 @@ extern "C" int cde_dopri5_adjoint_advance(const void* coeffs, const void* knots,
   if (first_launch > 0 && sharded && !reduced_sums) return CDE_ERR_NULL;
   const int grid = cde::adj_grid(B);
   if (first_launch == 0) {
-    if (hipMemsetAsync(base, 0, 2 * cde::ADJ_CTRL_STRIDE, s) != hipSuccess) return CDE_ERR_LAUNCH;     // phase 0
-    if (first_interval &&
-        (hipMemsetAsync(base + L.carry, 0, 256, s) != hipSuccess ||
-         hipMemsetAsync(base + L.G, 0, L.att - L.G, s) != hipSuccess))           // G, G_local, the prev buffers
-      return CDE_ERR_LAUNCH;
+    cde::zero_async(base, 2 * cde::ADJ_CTRL_STRIDE, s);                                                // phase 0
+    if (first_interval) {
+      cde::zero_async(base + L.carry, 256, s);
+      cde::zero_async(base + L.G, L.att - L.G, s);                                // G, G_local, the prev buffers
+    }
   }
   cde::AdjReduceArgs r = adj_reduce_args(base, L, B, rtol, atol, sharded);
 #define CDE_ADJ(D, A)                                                                                                \

@@ -485,13 +485,12 @@ extern "C" int cde_dopri5_adjoint_mlp_advance(const void* coeffs, const void* kn
   g.com.trace_all = (double*)(base + L.trace_all);
   g.com.carry = (double*)(base + L.carry);
   if (first_launch == 0) {
-    if (hipMemsetAsync(base, 0, 2 * ADJ_CTRL_STRIDE, s) != hipSuccess) return CDE_ERR_LAUNCH;     // phase 0
+    zero_async(base, 2 * ADJ_CTRL_STRIDE, s);                                                     // phase 0
     if (first_interval) {
       // vjp_t, the running totals and the factor rows (padding rows must hold zeros; the "1" columns are set below)
-      if (hipMemsetAsync(base + L.carry, 0, 256, s) != hipSuccess ||
-          hipMemsetAsync(base + L.G, 0, L.slopes - L.G, s) != hipSuccess ||
-          hipMemsetAsync(base + L.U, 0, L.trace - L.U, s) != hipSuccess)
-        return CDE_ERR_LAUNCH;
+      zero_async(base + L.carry, 256, s);
+      zero_async(base + L.G, L.slopes - L.G, s);
+      zero_async(base + L.U, L.trace - L.U, s);
       const int64_t rows = (int64_t)MADJ_SLOTS * L.rows_per_stage;
       madj_ones_kernel<<<(unsigned)((rows + 255) / 256), 256, 0, s>>>(g.U, g.Z, rows);
       const int rc = launch_mlp_adjoint_images(W1, bias1, width, W2, bias2, C, H, (float*)(base + L.image), s);

@@ -1341,7 +1341,7 @@ extern "C" int cde_logsig_windows_backward(const void* grad_out, const void* x, 
   if (!grad_out || !x || !rows || !scale || !words || !grad_x || !workspace) return CDE_ERR_NULL;
   if (dtype != CDE_F32 && dtype != CDE_F64) return CDE_ERR_DTYPE;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(grad_x, 0, (size_t)(B * L * C) * (dtype == CDE_F64 ? 8 : 4), s) != hipSuccess) return CDE_ERR_LAUNCH;
+  cde::zero_async(grad_x, (size_t)(B * L * C) * (dtype == CDE_F64 ? 8 : 4), s);
   const unsigned grid = (unsigned)((B * n_windows + 63) / 64), grid2 = (unsigned)((B * n_words + 255) / 256);
 #define CDE_LSB(T, MAXC, MAXD)                                                                                         \
   do {                                                                                                                 \

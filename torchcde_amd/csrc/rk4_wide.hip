@@ -527,7 +527,7 @@ int launch_adjoint_wide(const void* coeffs, const void* knots, int64_t n_interva
   float* Zbuf = (float*)(base + L.off_Z);
   const unsigned blocks = (unsigned)((B + 15) / 16);
   const unsigned seed_blocks = (unsigned)((B * H + 255) / 256);
-  if (hipMemsetAsync(acc, 0, (size_t)L.HP * L.CT * (L.HP + 1) * sizeof(float), s) != hipSuccess) return CDE_ERR_LAUNCH;
+  zero_async(acc, (size_t)L.HP * L.CT * (L.HP + 1) * sizeof(float), s);
   wide_seed_kernel<<<seed_blocks, 256, 0, s>>>(y_state, a_state, (const float*)z_saved, (const float*)grad_out,
                                                n_out - 1, n_out, B, (int)H, 1);
 #define CDE_SWEEP(D, A, NWV, NBV)                                                                                    \
