@@ -235,8 +235,20 @@ def other_configs(cde, device, reps=3):
         z = z0.detach().requires_grad_(True)
         cde.cdeint(X, func, z, X.interval, **kw)[:, -1].sum().backward()
 
+    front = sys.modules["torchcde_amd.cdeint"]
+
+    def dopri_adjoint_seminorm():
+        z = z0.detach().requires_grad_(True)
+        cde.cdeint(X, func, z, X.interval, adjoint_options=dict(norm="seminorm", jump_t=X.grid_points), **kw)[:, -1].sum().backward()
+
     out["config4_shard_dopri5_forward_ms"] = timed(dopri_forward)
+    # the reference's default adjoint (torchdiffeq's MIXED norm: the parameter-gradient blocks drive the step size -- in
+    # float32 their error estimate sits at the noise floor of the batch sums, hence the rejected attempts) and the same call
+    # with adjoint_options=dict(norm="seminorm")
     out["config4_shard_dopri5_forward_adjoint_ms"] = timed(dopri_adjoint)
+    out["config4_shard_dopri5_adjoint_attempts"] = {k: v for k, v in front.last_dopri5_adjoint_stats.items()
+                                                    if k in ("n_accept", "n_reject")}
+    out["config4_shard_dopri5_forward_adjoint_seminorm_ms"] = timed(dopri_adjoint_seminorm)
 
     class TwoLayer(torch.nn.Module):
         def __init__(self, hidden, channels):
@@ -267,6 +279,45 @@ def other_configs(cde, device, reps=3):
     out["config5_logsig_transform_ms"] = timed(transform)
     out["config5_two_layer_forward_adjoint_ms"] = timed(solve)
     out["config5_series_per_s"] = B / ((out["config5_logsig_transform_ms"] + out["config5_two_layer_forward_adjoint_ms"]) * 1e-3)
+
+    # config 5 as the reference's example RUNS it (example/logsignature_example.py builds the same CDEFunc and calls cdeint
+    # without a method: dopri5 + adjoint): K4 forward, K4am backward -- one run each after a warm-up
+    def solve_default(extra):
+        z = z8.detach().requires_grad_(True)
+        Xl = state["X"]
+        cde.cdeint(Xl, field, z, Xl.interval, **extra)[:, -1].sum().backward()
+
+    def once(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3
+
+    solve_default({})
+    out["config5_default_method_forward_adjoint_ms"] = once(lambda: solve_default({}))
+    out["config5_default_method_attempts"] = {"forward": dict(front.last_dopri5_stats),
+                                              "backward": {k: v for k, v in front.last_dopri5_adjoint_stats.items()
+                                                           if k in ("n_accept", "n_reject")}}
+    out["config5_default_method_seminorm_forward_adjoint_ms"] = once(lambda: solve_default(dict(adjoint_options=dict(norm="seminorm"))))
+
+    # the example model's own training call (example/time_series_classification.py:83-86: cdeint(X, CDEFunc, z0, X.interval),
+    # 4096 series of the headline workload; round 2: 1.0 s forward + 34 s backward step-wise)
+    torch.manual_seed(0)
+    model = TwoLayer(H, C).to(device)
+    xs = make_series(4096, L, C, seed=0).to(device)
+    Xs = cde.CubicSpline(cde.hermite_cubic_coefficients_with_backward_differences(xs))
+    zs0 = torch.randn(4096, H, generator=torch.Generator().manual_seed(0)).to(device)
+    for tag, extra in (("", {}), ("_seminorm", dict(adjoint_options=dict(norm="seminorm")))):
+        zs = zs0.detach().requires_grad_(True)
+        cde.cdeint(Xs, model, zs, Xs.interval, **extra)        # warm-up of the forward kernels
+        fwd_ms = once(lambda: cde.cdeint(Xs, model, zs, Xs.interval, **extra))
+        res = cde.cdeint(Xs, model, zs, Xs.interval, **extra)
+        assert type(res.grad_fn).__name__ == "_FusedMlpDopri5Backward"
+        out["example_model_default_call%s_forward_ms" % tag] = fwd_ms
+        out["example_model_default_call%s_backward_ms" % tag] = once(lambda: res[:, -1].sum().backward())
+        out["example_model_default_call%s_backward_attempts" % tag] = {
+            k: v for k, v in front.last_dopri5_adjoint_stats.items() if k in ("n_accept", "n_reject")}
     return out
 
 
