@@ -59,8 +59,12 @@ enum {
                               else: the generic kernels */
   CDE_VARIANT_GENERIC = 1, /* VALU kernel: any H, C, f32 or f64                             */
   CDE_VARIANT_MFMA = 2,    /* fail with CDE_ERR_UNSUPPORTED unless the MFMA kernel applies   */
-  CDE_VARIANT_SPLIT = 3    /* MFMA, one workgroup (4 waves) per 16 series: the latency-oriented kernels for small
+  CDE_VARIANT_SPLIT = 3,   /* MFMA, one workgroup (4 waves) per 16 series: the latency-oriented kernels for small
                               per-GPU batches (strong scaling); AUTO picks them when B <= CDE_SPLIT_MAX_BATCH */
+  CDE_VARIANT_BF16X3 = 4   /* opt-in: the weight GEMMs on the bf16 matrix pipe at float32 accuracy (every operand split
+                              into three bf16 pieces, six piece products per block, f32 accumulate; csrc/rk4_bf16x3.hip).
+                              f32, H <= 32, C <= 8, identity activation, rk4 forward and adjoint (no control gradients);
+                              CDE_ERR_UNSUPPORTED otherwise.  Never chosen by AUTO. */
 };
 #define CDE_SPLIT_MAX_BATCH 16384
 

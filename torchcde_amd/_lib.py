@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libcde_mi355x.so")
 SOURCES = ["interp_kernels.hip", "rk4_generic.hip", "rk4_mfma.hip", "rk4_split.hip", "rk4_wide.hip", "rk4_mlp_adjoint.hip",
-           "dopri5.hip", "dopri5_adjoint.hip", "dopri5_mlp_adjoint.hip", "mlp_grad_reduce.hip", "api.hip"]
+           "rk4_bf16x3.hip", "dopri5.hip", "dopri5_adjoint.hip", "dopri5_mlp_adjoint.hip", "mlp_grad_reduce.hip", "api.hip"]
 HEADERS = [os.path.join(_CSRC, "cde_common.h"), os.path.join(_CSRC, "cde_mfma.h"), os.path.join(_CSRC, "cde_split.h"),
            os.path.join(_CSRC, "cde_dopri.h"), os.path.join(_CSRC, "cde_dopri_adj.h"), os.path.join(_CSRC, "cde_mlp_adj.h"),
            os.path.join(_HERE, "..", "include", "cde_mi355x.h")]
@@ -29,7 +29,7 @@ F32, F64 = 0, 1
 PATH_LINEAR, PATH_CUBIC = 1, 3
 EVAL_VALUE, EVAL_DERIVATIVE = 0, 1
 ACT_NONE, ACT_TANH = 0, 1
-VARIANT_AUTO, VARIANT_GENERIC, VARIANT_MFMA, VARIANT_SPLIT = 0, 1, 2, 3
+VARIANT_AUTO, VARIANT_GENERIC, VARIANT_MFMA, VARIANT_SPLIT, VARIANT_BF16X3 = 0, 1, 2, 3, 4
 
 _lib = None
 

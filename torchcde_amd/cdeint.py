@@ -889,7 +889,7 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
     ``torchcde.cdeint`` (solver.py:144-194).  ``variant=`` (extra keyword, one of
     "auto" | "generic" | "mfma" | "split") selects the kernel and exists for testing."""
     variant = {"auto": _lib.VARIANT_AUTO, "generic": _lib.VARIANT_GENERIC, "mfma": _lib.VARIANT_MFMA,
-               "split": _lib.VARIANT_SPLIT}[kwargs.pop("variant", "auto")]
+               "split": _lib.VARIANT_SPLIT, "bf16x3": _lib.VARIANT_BF16X3}[kwargs.pop("variant", "auto")]
     # tolerance defaults of solver.py:195-203 (only adaptive methods read them)
     kwargs.setdefault("atol", 1e-6)
     kwargs.setdefault("rtol", 1e-4)

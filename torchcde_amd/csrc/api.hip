@@ -55,6 +55,18 @@ int launch_adjoint_wide(const void*, const void*, int64_t, int, const void*, con
                         const void*, int64_t, const int64_t*, int64_t, void*, void*, void*, int64_t, int64_t, int64_t,
                         const int64_t*, const void*, void*, hipStream_t);
 
+// from rk4_bf16x3.hip
+template <typename TT>
+int launch_forward_bf16x3(const void*, const void*, int64_t, int, const void*, const void*, const void*, const void*, int64_t,
+                          const void*, int64_t, void*, int64_t, int64_t, int64_t, const int64_t*, const void*, hipStream_t);
+template <typename TT>
+int launch_adjoint_bf16x3(const void*, const void*, int64_t, int, const void*, const void*, const void*, const void*,
+                          const void*, const int64_t*, int64_t, void*, void*, void*, int64_t, int64_t, int64_t,
+                          const int64_t*, const void*, float*, hipStream_t);
+static bool bf16x3_applicable(int64_t C, int64_t H, int dtype, int act) {
+  return dtype == CDE_F32 && act == CDE_ACT_NONE && H >= 1 && H <= 32 && C >= 1 && C <= 8;
+}
+
 // from rk4_mlp_adjoint.hip
 size_t mlp_adjoint_image_bytes();
 int launch_mlp_adjoint_images(const void*, const void*, int64_t, const void*, const void*, int64_t, int64_t, float*,
@@ -126,6 +138,11 @@ static int forward_typed(const void* coeffs, const void* knots, int64_t n_interv
                          int variant, int64_t* stage_index, void* stage_frac, hipStream_t s) {
   int rc = fill_stage_table<T, TT>(knots, n_intervals, grid, n_grid - 1, 0, stage_index, stage_frac, s);
   if (rc != CDE_OK) return rc;
+  if (variant == CDE_VARIANT_BF16X3) {
+    if (!bf16x3_applicable(C, H, dtype, act)) return CDE_ERR_UNSUPPORTED;
+    return launch_forward_bf16x3<TT>(coeffs, knots, n_intervals, degree, W, bias, z0, grid, n_grid, t_out, n_out, z_out, B, C,
+                                     H, stage_index, stage_frac, s);
+  }
   const bool use_mfma = pick_mfma(variant, C, H, dtype, act, false, &rc);
   if (rc != CDE_OK) return rc;
   if (use_mfma && pick_split(variant, B, false, act))
@@ -148,6 +165,20 @@ static int adjoint_typed(const void* coeffs, const void* knots, int64_t n_interv
                          void* grad_z0, void* grad_W, void* grad_b, int64_t B, int64_t C, int64_t H, int dtype,
                          int variant, void* workspace, size_t workspace_bytes, void* grad_coeffs, hipStream_t s) {
   int rc;
+  if (variant == CDE_VARIANT_BF16X3) {
+    if (!bf16x3_applicable(C, H, dtype, act) || grad_coeffs) return CDE_ERR_UNSUPPORTED;
+    const int64_t n_steps_b = n_sgrid - 1;
+    const size_t off_frac_b = align256((size_t)(4 * n_steps_b) * sizeof(int64_t));
+    const size_t off_part_b = off_frac_b + align256((size_t)(4 * n_steps_b) * sizeof(T));
+    if (workspace_bytes < off_part_b + mfma_adjoint_partial_bytes(B)) return CDE_ERR_WORKSPACE;
+    int64_t* sidx = (int64_t*)workspace;
+    void* sfrac = (unsigned char*)workspace + off_frac_b;
+    rc = fill_stage_table<T, TT>(knots, n_intervals, sgrid, n_steps_b, 1, sidx, sfrac, s);
+    if (rc != CDE_OK) return rc;
+    return launch_adjoint_bf16x3<TT>(coeffs, knots, n_intervals, degree, W, bias, z_saved, grad_out, sgrid, seg_off, n_out,
+                                     grad_z0, grad_W, grad_b, B, C, H, sidx, sfrac,
+                                     (float*)((unsigned char*)workspace + off_part_b), s);
+  }
   const bool use_mfma = pick_mfma(variant, C, H, dtype, act, true, &rc);
   if (rc != CDE_OK) return rc;
   if (grad_coeffs && !use_mfma) return CDE_ERR_UNSUPPORTED;      // control gradients: MFMA kernels only
@@ -188,6 +219,7 @@ static int adjoint_typed(const void* coeffs, const void* knots, int64_t n_interv
 extern "C" int cde_rk4_supported(int64_t C, int64_t H, int dtype, int act, int adjoint, int variant) {
   if (C < 1 || H < 1 || (dtype != CDE_F32 && dtype != CDE_F64)) return 0;
   if (act != CDE_ACT_NONE && act != CDE_ACT_TANH) return 0;
+  if (variant == CDE_VARIANT_BF16X3) return cde::bf16x3_applicable(C, H, dtype, act) ? 1 : 0;
   int rc;
   const bool mfma = cde::pick_mfma(variant, C, H, dtype, act, adjoint != 0, &rc);
   if (rc != CDE_OK) return 0;
@@ -250,6 +282,7 @@ extern "C" size_t cde_rk4_adjoint_workspace_bytes(int64_t B, int64_t C, int64_t 
   const size_t elem = dtype == CDE_F64 ? 8 : 4;
   const int64_t n_steps = n_sgrid > 1 ? n_sgrid - 1 : 0;
   size_t bytes = cde::align256((size_t)(4 * n_steps) * sizeof(int64_t)) + cde::align256((size_t)(4 * n_steps) * elem);
+  if (variant == CDE_VARIANT_BF16X3) return bytes + cde::mfma_adjoint_partial_bytes(B);
   int rc;
   const bool use_mfma = cde::pick_mfma(variant, C, H, dtype, CDE_ACT_NONE, true, &rc);
   // AUTO may resolve to either kernel depending on the activation: reserve the larger need
