@@ -158,6 +158,36 @@ def strong_scaling_proxy(cde, x, func, z0, full_ms):
     return out
 
 
+def bf16x3_variant(cde, X, func, z0, steps=10):
+    """The same headline step through variant="bf16x3" (csrc/rk4_bf16x3.hip: the weight GEMMs on the bf16 matrix pipe, every
+    float32 operand split into three bf16 pieces -- float32 accuracy, same parity bars; NOT the reported `value`, which
+    stays on the exact-f32 kernels): ms per forward solve and per forward + adjoint step, wall clock over `steps`."""
+    kw = dict(method="rk4", options={"step_size": 1.0}, variant="bf16x3")
+    params = list(func.parameters())
+
+    def fwd():
+        with torch.no_grad():
+            cde.cdeint(X, func, z0, X.interval, **kw)
+
+    def both():
+        z = z0.detach().requires_grad_(True)
+        for p in params:
+            p.grad = None
+        cde.cdeint(X, func, z, X.interval, **kw)[:, -1].sum().backward()
+    out = {}
+    for name, fn in (("forward_ms", fwd), ("forward_adjoint_ms", both)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        out[name] = (time.perf_counter() - t0) / steps * 1e3
+    out["series_per_s"] = z0.size(0) / (out["forward_adjoint_ms"] * 1e-3)
+    return out
+
+
 def other_fields(cde, X, z0, device, reps=3):
     """Same workload with the non-linear vector fields of the reference's examples (outside the timed region, not part
     of `value`): Linear -> tanh (example/irregular_data.py) and Linear -> relu -> Linear -> tanh, width 128
@@ -677,6 +707,7 @@ def main():
         if world == 1:
             result["extra"]["strong_scaling_proxy_1gpu"] = strong_scaling_proxy(cde, x, func, z0, elapsed / args.steps * 1e3)
         if world == 1:
+            result["extra"]["bf16x3_variant"] = bf16x3_variant(cde, X, func, z0)
             result["extra"]["other_fields"] = other_fields(cde, X, z0, device)
             result["extra"]["other_configs"] = other_configs(cde, device)
         if world == 1 and args.cpu_sample > 0:

@@ -887,7 +887,8 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
 
     Arguments, return value (shape ``(..., len(t), hidden_channels)``) and errors as reference
     ``torchcde.cdeint`` (solver.py:144-194).  ``variant=`` (extra keyword, one of
-    "auto" | "generic" | "mfma" | "split") selects the kernel and exists for testing."""
+    "auto" | "generic" | "mfma" | "split" | "bf16x3") selects the kernel family: "bf16x3" runs the rk4 solve's weight
+    GEMMs on the bf16 matrix pipe at float32 accuracy (csrc/rk4_bf16x3.hip), the others exist for testing."""
     variant = {"auto": _lib.VARIANT_AUTO, "generic": _lib.VARIANT_GENERIC, "mfma": _lib.VARIANT_MFMA,
                "split": _lib.VARIANT_SPLIT, "bf16x3": _lib.VARIANT_BF16X3}[kwargs.pop("variant", "auto")]
     # tolerance defaults of solver.py:195-203 (only adaptive methods read them)
@@ -956,6 +957,11 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         elif not _lib.load().cde_rk4_supported(C, H, _lib.dtype_enum(z0.dtype), field.act, int(bool(adjoint)), variant):
             field = None              # beyond the fused kernels' tiles (LDS / lane limits): step-wise, not a late error
 
+    if variant == _lib.VARIANT_BF16X3 and (field is None or field.act != _lib.ACT_NONE or kwargs.get("method") != "rk4"
+                                           or z0.dtype != torch.float32 or H > 32 or C > 8):
+        # an explicit request for a specific kernel family is never redirected
+        raise NotImplementedError("torchcde_amd: variant='bf16x3' covers method='rk4' with the one-layer identity-activation "
+                                  "field Linear(H, H*C), float32, H <= 32, C <= 8.")
     if adjoint and "adjoint_params" not in kwargs:
         for buffer in X.buffers():
             if buffer.requires_grad:
