@@ -372,6 +372,7 @@ typedef struct {
   int32_t phase; /* 4 == done */
   int32_t on_jump, refresh, pad;
   int32_t slot, stored; /* kernel-internal: which state slot holds the start of the pending step, what the attempt stored */
+  int32_t hint_lo, hint_hi; /* kernel-internal: knot intervals of the pending attempt's first / last stage time */
 } cde_dopri5_status;
 size_t cde_dopri5_workspace_bytes(int64_t B, int64_t C, int64_t H, int dtype);
 /* The solve's step sequence: the workspace holds, at byte offset cde_dopri5_trace_offset(...), up to

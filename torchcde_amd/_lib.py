@@ -12,13 +12,18 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(_HERE, "libcde_mi355x.so")
+# CDE_PHASE_TRACE=1: the debug build whose attempt kernels stamp their phase boundaries (csrc/cde_common.h "phase trace",
+# scripts/phase_trace.py).  A different file, so the product library is never the instrumented one.
+PHASE_TRACE = os.environ.get("CDE_PHASE_TRACE", "") == "1"
+SO_PATH = os.path.join(_HERE, "libcde_mi355x_trace.so" if PHASE_TRACE else "libcde_mi355x.so")
 SOURCES = ["interp_kernels.hip", "rk4_generic.hip", "rk4_mfma.hip", "rk4_split.hip", "rk4_wide.hip", "rk4_mlp_adjoint.hip",
            "rk4_bf16x3.hip", "dopri5.hip", "dopri5_adjoint.hip", "dopri5_mlp_adjoint.hip", "mlp_grad_reduce.hip", "api.hip"]
 HEADERS = [os.path.join(_CSRC, "cde_common.h"), os.path.join(_CSRC, "cde_mfma.h"), os.path.join(_CSRC, "cde_split.h"),
            os.path.join(_CSRC, "cde_dopri.h"), os.path.join(_CSRC, "cde_dopri_adj.h"), os.path.join(_CSRC, "cde_mlp_adj.h"),
            os.path.join(_HERE, "..", "include", "cde_mi355x.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC"]
+if PHASE_TRACE:
+    HIPCC_FLAGS.append("-DCDE_PHASE_TRACE")
 # per-file additions.  rk4_split.hip: keep MFMA accumulators in VGPRs -- its tiles are consumed by VALU code right
 # away, and on gfx950 every v_accvgpr_read costs matrix-pipe time (f32 MFMA and VALU do not overlap within a wave).
 EXTRA_FLAGS = {"rk4_split.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
@@ -149,7 +154,7 @@ class DopriStatus(ctypes.Structure):
                 ("i_out", ctypes.c_int64), ("i_jump", ctypes.c_int64), ("n_accept", ctypes.c_int64),
                 ("n_reject", ctypes.c_int64), ("phase", ctypes.c_int32), ("on_jump", ctypes.c_int32),
                 ("refresh", ctypes.c_int32), ("pad", ctypes.c_int32), ("slot", ctypes.c_int32),
-                ("stored", ctypes.c_int32)]
+                ("stored", ctypes.c_int32), ("hint_lo", ctypes.c_int32), ("hint_hi", ctypes.c_int32)]
 
 
 def load():

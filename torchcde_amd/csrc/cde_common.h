@@ -67,6 +67,37 @@ __device__ __forceinline__ int64_t locate_around(const T* __restrict__ knots, in
   return locate(knots, n_intervals, t, frac);
 }
 
+// locate_around in two halves, for kernels that know the hint long before they know the query: the four knots around
+// `hint` are REQUESTED early (knot_window), the comparisons happen when t is known (locate_window: same result as locate()
+// in every case -- it falls back to the search when t is in none of the three intervals).
+template <typename T>
+struct KnotWindow { T k[4]; int64_t lo, hi; bool valid; };
+template <typename T>
+__device__ __forceinline__ KnotWindow<T> knot_window(const T* __restrict__ knots, int64_t n_intervals, int64_t hint) {
+  KnotWindow<T> w;
+  w.valid = hint >= 0 && hint < n_intervals;
+  const int64_t h = w.valid ? hint : 0;
+  w.lo = h > 0 ? h - 1 : 0;
+  w.hi = h < n_intervals - 1 ? h + 1 : n_intervals - 1;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) w.k[j] = knots[w.lo + j <= n_intervals ? w.lo + j : n_intervals];
+  return w;
+}
+template <typename T>
+__device__ __forceinline__ int64_t locate_window(const KnotWindow<T>& w, const T* __restrict__ knots, int64_t n_intervals, T t, T& frac) {
+  if (w.valid) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int64_t cand = w.lo + j;
+      if (cand > w.hi) break;
+      const bool above = cand == 0 || !(w.k[j] >= t);
+      const bool below = cand == n_intervals - 1 ? !(w.k[j] >= t) || cand == 0 : w.k[j + 1] >= t;
+      if (above && below) { frac = t - w.k[j]; return cand; }
+    }
+  }
+  return locate(knots, n_intervals, t, frac);
+}
+
 // ---------------------------------------------------------------- RK4 3/8-rule stage clock
 // torchdiffeq rk4_alt_step_func: stage times t0, t0 + dt*(1/3), t0 + dt*(2/3), t1 formed in the
 // grid's dtype (python floats 1/3, 2/3 rounded to that dtype), then cast to the state dtype.
@@ -122,5 +153,32 @@ static inline int zero_async(void* p, size_t bytes, hipStream_t s) {
   zero_words_kernel<<<(unsigned)blocks, 256, 0, s>>>((unsigned*)p, n);
   return CDE_OK;
 }
+
+// ------------------------------------------------------------------------------------------ phase trace (debug builds)
+// CDE_PHASE_TRACE=1 builds libcde_mi355x_trace.so (torchcde_amd/_lib.py): the attempt kernels stamp the 100 MHz
+// wall clock (s_memrealtime: one time base for the whole chip) at their phase boundaries, wave 0 of every workgroup
+// writes its stamps to a ring indexed by the attempt number, and scripts/phase_trace.py turns the ring into the
+// per-phase split of an attempt (launch gap, prologue, stages, drain).  The product build compiles none of it.
+#ifdef CDE_PHASE_TRACE
+constexpr int TRACE_SLOTS = 40, TRACE_BLOCKS = 512, TRACE_RING = 32;   // slots 20..39: a second wave's stamps (CDE_STAMP_FLUSH2)
+struct PhaseStamps { unsigned long long t[TRACE_SLOTS]; };
+#define CDE_STAMP_DECL ::cde::PhaseStamps stamps_ = {}
+#define CDE_STAMP(slot) do { __builtin_amdgcn_sched_barrier(0); stamps_.t[slot] = wall_clock64(); \
+                             __builtin_amdgcn_sched_barrier(0); } while (0)
+#define CDE_STAMP_FLUSH(buf, attempt) do { if (threadIdx.x == 0 && blockIdx.x < ::cde::TRACE_BLOCKS) { \
+    unsigned long long* dst_ = (buf) + ((size_t)((attempt) % ::cde::TRACE_RING) * ::cde::TRACE_BLOCKS + blockIdx.x) * ::cde::TRACE_SLOTS; \
+    for (int s_ = 0; s_ < 20; ++s_) dst_[s_] = stamps_.t[s_]; } } while (0)
+// a second stamping wave (its lane 0 is thread `tid2`) owns slots 20..39
+#define CDE_STAMP_FLUSH2(buf, attempt, tid2) do { if (threadIdx.x == (tid2) && blockIdx.x < ::cde::TRACE_BLOCKS) { \
+    unsigned long long* dst_ = (buf) + ((size_t)((attempt) % ::cde::TRACE_RING) * ::cde::TRACE_BLOCKS + blockIdx.x) * ::cde::TRACE_SLOTS; \
+    for (int s_ = 20; s_ < ::cde::TRACE_SLOTS; ++s_) dst_[s_] = stamps_.t[s_]; } } while (0)
+#define CDE_STAMP_IF(cond, slot) do { if (cond) CDE_STAMP(slot); } while (0)
+#else
+#define CDE_STAMP_FLUSH2(buf, attempt, tid2) do {} while (0)
+#define CDE_STAMP_IF(cond, slot) do {} while (0)
+#define CDE_STAMP_DECL do {} while (0)
+#define CDE_STAMP(slot) do {} while (0)
+#define CDE_STAMP_FLUSH(buf, attempt) do {} while (0)
+#endif
 
 }  // namespace cde

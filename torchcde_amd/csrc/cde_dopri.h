@@ -17,7 +17,10 @@ struct DopriCtrl {
   int32_t pad;
   int32_t slot;                 // MFMA attempt kernel: which of the two (y, k) state slots holds the step's start
   int32_t stored;               // ... and what the pending attempt left in the other one: bit 0 k6, bit 1 the midpoint
+  int32_t hint_lo, hint_hi;     // ... and the knot intervals of the pending attempt's first and last stage times: the next
+                                // launch requests the control rows of its two likely intervals BEFORE it knows the decision
 };
+static_assert(sizeof(DopriCtrl) == 112, "cde_dopri5_status (include/cde_mi355x.h) and _lib.DopriStatus mirror this layout");
 
 // wave-uniform copies: the controller's outputs derive from LDS reads (the block sums), so the compiler keeps them --
 // and everything computed from them -- in vector registers; read back through lane 0 they live in scalar registers

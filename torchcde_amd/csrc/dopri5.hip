@@ -376,17 +376,32 @@ __device__ __forceinline__ double sq4(const f32x4& v) {
   return (double)(v[0] * v[0]) + (double)(v[1] * v[1]) + (double)(v[2] * v[2]) + (double)(v[3] * v[3]);
 }
 
+#ifdef CDE_PHASE_TRACE
+__device__ unsigned long long k4_phase_trace[TRACE_RING * TRACE_BLOCKS * TRACE_SLOTS];
+#endif
+
 template <int DEGREE, int ACT, bool MLP = false, int CT = MC>
 __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g, int parity) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using T = float;
   const int tid = threadIdx.x;
   const int p = parity, q2 = parity ^ 1;
+  CDE_STAMP_DECL;
+  CDE_STAMP(0);
+  // Everything a launch needs before it can decide the pending attempt is requested at once, ahead of the first wait:
+  // the previous launch's partial sums (their address depends on the launch parity only), the controller block, the
+  // weight image and the knots.  (profiles/r03_phase_k4.log: taken one after the other these dependent round trips were
+  // 5.7 us of a 40 us attempt.)
+  const double* Pp = g.partial + (int64_t)p * g.n_blocks_alloc * 2;
+  double sums[2] = {0.0, 0.0};
+  if (!g.ext_sums)
+    for (int64_t b = tid; b < (int64_t)gridDim.x; b += blockDim.x) { sums[0] += Pp[2 * b]; sums[1] += Pp[2 * b + 1]; }
   DopriCtrl c = g.ctrl[p];
   if (c.phase == 4) {
     if (blockIdx.x == 0 && tid == 0) g.ctrl[q2] = c;
     return;
   }
+  CDE_STAMP(1);
   // weight images: built once per solve (w16_image_kernel / wy16_image_kernel).  Product form: one coalesced
   // 16-byte load per group and lane into registers; activation form: copied to LDS (field_act16 reads it there).
   constexpr bool PRODUCT = ACT == CDE_ACT_NONE && !MLP;
@@ -396,11 +411,6 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   float4 wA[PRODUCT ? W16_GROUPS : 1], wB[PRODUCT ? W16_GROUPS : 1];
   const Dims dims{(int)g.H, (int)g.C};
   const int Hr = dims.H;
-  if constexpr (PRODUCT) {
-    const float4* img = reinterpret_cast<const float4*>(g.w16) + (tid & 63);
-#pragma unroll
-    for (int grp = 0; grp < W16_GROUPS; ++grp) { wA[grp] = img[grp * 64]; wB[grp] = img[(W16_GROUPS + grp) * 64]; }
-  }
   double* red = reinterpret_cast<double*>(lds);                    // 2 * 512 doubles
   // The knot search of every stage time is a chain of dependent loads: from global memory that is ~7 x 0.3 us per
   // stage (it dominated this kernel); the knots are copied to LDS once per launch instead.
@@ -414,7 +424,6 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
     float4* dst = reinterpret_cast<float4*>(img_lds);
     for (int i = tid; i < IMG_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
   }
-  __syncthreads();
   const int64_t BH = g.B * g.H;
   // State: two (y, k) slots and one midpoint array.  Slot `c.slot` holds the start of the pending attempt (y0, k0 = f
   // at t0), the other slot what the attempt produced (y1, and k6 = f at t1 when that is ever read: a step clipped
@@ -424,7 +433,6 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   float* const Ys[2] = {g.state, g.state + BH};
   float* const Ks[2] = {g.state + 2 * BH, g.state + 3 * BH};
   float* const Mid = g.state + 4 * BH;
-  const double* Pp = g.partial + (int64_t)p * g.n_blocks_alloc * 2;
   double* Pq = g.partial + (int64_t)q2 * g.n_blocks_alloc * 2;
   const T rtol = (T)g.rtol, atol = (T)g.atol;
 
@@ -446,13 +454,49 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
     if (pending_stored & 1) { k0a = load_units4<STRIDE>(Ks[cand] + e, u0, Hr); k0b = load_units4<STRIDE>(Ks[cand] + e, u1, Hr); }
   }
 
-  double sums[2] = {0.0, 0.0};
+  // The control rows of the two intervals the next attempt is likely to start in (the pending attempt's own start
+  // interval if it is rejected or stays inside it, the one it ended in -- or the next, after a jump -- if it is
+  // accepted) are TOUCHED now: one dword per lane, first and last of each row, pulls their lines from HBM into this
+  // XCD's L2 while the sums are reduced and the controller runs.  The row load proper can only be issued once the
+  // controller has decided; it used to be an HBM round trip in front of the first stage (profiles/r03_phase_k4.log:
+  // stage 1 took 8.0 us, the others 3.5), now it hits the L2.  (Holding both candidate rows in registers instead
+  // spilled: the weight image already fills the register file.)
+  float touched = 0.f;
+  if (phase_in == 3) {
+    const int hint_a = uni(c.hint_lo), hint_b = uni(c.hint_hi == c.hint_lo ? c.hint_lo + 1 : c.hint_hi);
+    const int cand = q < 2 ? hint_a : hint_b;
+    if (cand >= 0 && cand < g.n_intervals) {
+      constexpr int PARTS = DEGREE == CDE_PATH_CUBIC ? 3 : 2;
+      const float* rowp = DEGREE == CDE_PATH_CUBIC ? g.coeffs + ((sc * g.n_intervals + cand) * 4 + 1) * dims.C
+                                                   : g.coeffs + (sc * (g.n_intervals + 1) + cand) * dims.C;
+      touched = *reinterpret_cast<const volatile float*>(rowp + ((q & 1) ? PARTS * dims.C - 1 : 0));
+    }
+  }
+
+  // pending sums of the whole batch: fixed order (xor tree in each wave, then the waves in index order), so the decision
+  // is identical in every workgroup and run to run.  One barrier serves the knots, the weight image and the sums.
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sums[k] += __shfl_xor(sums[k], off, 64);
+  if (lane == 0) { red[wave] = sums[0]; red[8 + wave] = sums[1]; }
+  __syncthreads();
+  CDE_STAMP(2);
+  // (the register image of the weights is requested here, not at entry: it fills the register file, and its L2 latency
+  // hides behind the controller just as well)
+  if constexpr (PRODUCT) {
+    const float4* img = reinterpret_cast<const float4*>(g.w16) + (tid & 63);
+#pragma unroll
+    for (int grp = 0; grp < W16_GROUPS; ++grp) { wA[grp] = img[grp * 64]; wB[grp] = img[(W16_GROUPS + grp) * 64]; }
+  }
   if (phase_in != 0 && g.ext_sums) {                              // one controller for all shards of the batch
     sums[0] = g.ext_sums[0]; sums[1] = g.ext_sums[1];
-  } else if (phase_in != 0) {
-    for (int64_t b = tid; b < (int64_t)gridDim.x; b += blockDim.x) { sums[0] += Pp[2 * b]; sums[1] += Pp[2 * b + 1]; }
-    block_total<2>(sums, red);
+  } else {
+    sums[0] = sums[1] = 0.0;
+#pragma unroll
+    for (int w8 = 0; w8 < 8; ++w8) { sums[0] += red[w8]; sums[1] += red[8 + w8]; }
   }
+  CDE_STAMP(3);
   const DopriPlan<T> plan = dopri_controller<T>(g, c, sums[0], sums[1]);
   // The controller's outputs derive from LDS reads (the block sums), so the compiler would keep them -- and every
   // stage time, interval index and slot pointer computed from them -- in vector registers; read back through lane 0
@@ -473,7 +517,10 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
     c.slot = slot; c.stored = stored;
     g.ctrl[q2] = c;
   }
-
+#ifdef CDE_PHASE_TRACE
+  const int attempt_no = uni((int)(c.n_accept + c.n_reject));
+#endif
+  CDE_STAMP(4);
   const float4* wy = reinterpret_cast<const float4*>(img_lds) + lane;
   const float4* by = reinterpret_cast<const float4*>(img_lds + WY_FLOATS) + q;
   auto field = [&](const f32x4& za, const f32x4& zb, const float (&dXv)[CT], f32x4& fa, f32x4& fb) {
@@ -485,9 +532,10 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   };
 
   // control derivative at a (wave-uniform) time; the row is re-fetched only when the interval changes
-  int64_t row_idx = -1;
+  int64_t row_idx = -1, first_idx = -1;
   Row<DEGREE, CT> row;
   float dX_lin[CT];                                   // piecewise-linear control: the slope of the interval in use
+  asm volatile("" ::"v"(touched));                    // (the touch loads are waited for here at the latest)
   auto slope_at = [&](T ts, float (&dX)[CT]) {
     T frac;
     // the stages of an attempt almost always share their interval (always, with jump_t on the knots): two comparisons
@@ -495,6 +543,7 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
     const int64_t idx = locate_near(kn, g.n_intervals, ts, row_idx, frac);
     if (idx != row_idx) {
       row = load_row<DEGREE, CT>(g.coeffs, sc, g.n_intervals, idx, dims.C);
+      if (first_idx < 0) first_idx = idx;
       row_idx = idx;
       // the 8 IEEE divisions of a linear slope once per interval, not once per stage (with jump_t on the knots all
       // stages of an attempt share the interval: the divisions were a fifth of this kernel's VALU instructions)
@@ -549,6 +598,7 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   }
 
   float dX[CT];
+  CDE_STAMP(5);
   if (mode == 0) {
     slope_at((T)t_hi, dX);
     field(ya, yb, dX, k0a, k0b);
@@ -595,6 +645,7 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
       zia = ya + ia; zib = yb + ib;
       slope_at(ti, dX);
       field(zia, zib, dX, ka[i + 1], kb[i + 1]);
+      CDE_STAMP(6 + i);
     }
     f32x4 ea = {0.f, 0.f, 0.f, 0.f}, eb = ea;
 #pragma unroll
@@ -622,8 +673,14 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
       if (valid) { store_units4<STRIDE>(Mid + e, u0, Hr, ya + ma); store_units4<STRIDE>(Mid + e, u1, Hr, yb + mb); }
     }
   }
+  CDE_STAMP(12);
   block_total<2>(acc, red);
+  CDE_STAMP(13);
   if (tid == 0) { Pq[2 * blockIdx.x] = acc[0]; Pq[2 * blockIdx.x + 1] = acc[1]; }
+  if (blockIdx.x == 0 && tid == 0) {                               // (the rest of the block was written before the stages)
+    g.ctrl[q2].hint_lo = (int32_t)first_idx; g.ctrl[q2].hint_hi = (int32_t)row_idx;
+  }
+  CDE_STAMP_FLUSH(k4_phase_trace, attempt_no);
 }
 
 // ------------------------------------------------------------------------------------------ wide attempt kernel
@@ -1005,6 +1062,14 @@ static inline int64_t dopri_blocks_any(int64_t B, int64_t H) {          // parti
 }
 
 }  // namespace cde
+
+#ifdef CDE_PHASE_TRACE
+// debug builds only (cde_common.h, "phase trace"): the stamp ring of dopri5_attempt_mfma, [ring][workgroup][slot]
+extern "C" int cde_debug_k4_phase_trace(void* host_out, size_t bytes) {
+  if (bytes > sizeof(unsigned long long) * cde::TRACE_RING * cde::TRACE_BLOCKS * cde::TRACE_SLOTS) return CDE_ERR_SHAPE;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(cde::k4_phase_trace), bytes) == hipSuccess ? CDE_OK : CDE_ERR_LAUNCH;
+}
+#endif
 
 // ================================================================================================ C ABI
 extern "C" size_t cde_dopri5_trace_offset(int64_t B, int64_t C, int64_t H, int dtype) {

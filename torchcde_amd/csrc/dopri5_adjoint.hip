@@ -61,21 +61,55 @@ __device__ __forceinline__ AdjCtrl* adj_ctrl(unsigned char* base, int which) {
   return reinterpret_cast<AdjCtrl*>(base + which * ADJ_CTRL_STRIDE);
 }
 
+#ifdef CDE_PHASE_TRACE
+__device__ unsigned long long k4a_phase_trace[TRACE_RING * TRACE_BLOCKS * TRACE_SLOTS];
+#endif
+
 template <int DEGREE, int ACT>
 __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g, int parity) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int p = parity, p2 = parity ^ 1;
+  CDE_STAMP_DECL;
+  CDE_STAMP(0);
+  // Everything the launch needs before it can decide the pending attempt is requested at once, ahead of the first wait
+  // (profiles/r03_phase_k4a.log: one after the other, these round trips were 19 us of a 131 us attempt): the pending
+  // sums of the previous attempt launch and of its R kernel (addresses depend on the launch parity only), the controller
+  // block, then -- once that is here -- the knots around the previous attempt's interval, the chain waves' weights and a
+  // touch of the control rows the first tile is likely to need.
+  const double* Pp = g.partial + (int64_t)p * ADJ_MAX_WG * ADJ_NS;
+  const double* Qp = g.pq + (int64_t)p * ADJ_RBLOCKS * 4;
+  double sum[ADJ_NS + 4];
+#pragma unroll
+  for (int i = 0; i < ADJ_NS + 4; ++i) sum[i] = 0.0;
+  if (!g.ext_sums) {
+    for (int64_t b = tid; b < (int64_t)gridDim.x; b += blockDim.x) {
+#pragma unroll
+      for (int i = 0; i < ADJ_NS; ++i) sum[i] += Pp[ADJ_NS * b + i];
+    }
+  }
+  for (int b = tid; b < ADJ_RBLOCKS; b += blockDim.x) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sum[ADJ_NS + i] += Qp[4 * b + i];
+  }
   AdjCtrl k = *adj_ctrl(g.ctrl, p);
   DopriCtrl& c = k.c;
   if (c.phase == 4) {
     if (blockIdx.x == 0 && tid == 0) { k.commit = 0; k.mode = 3; *adj_ctrl(g.ctrl, p2) = k; }
     return;
   }
+  CDE_STAMP(1);
   const int Hr = g.dims.H, Cr = g.dims.C;
   const int lane = tid & 63, wave = tid >> 6;
   const int w = wave & 3;
   const bool helper = __builtin_amdgcn_readfirstlane(wave) >= 4;
+  // The chain waves are the critical path of a stage (two dependent products, the activation and the LDS exchange
+  // between them); a helper wave shares its SIMD -- and the matrix pipe -- with one of them and is ready the moment the
+  // stage barrier opens.  With equal priorities its 32 (64 with the E image) MFMAs went first and the chain wave's
+  // product queued behind them: every helper MFMA was on the critical path (the E image cost exactly its own MFMA
+  // time per stage).  Priority 3 for the chain waves: helper MFMAs fill the pipe only while the chain wave is busy
+  // with VALU / LDS work.
+  if (!helper) __builtin_amdgcn_s_setprio(3);
   const int n = lane & 15, q = lane >> 4;
   float* zbuf = lds;
   float* ztb = lds + 2 * SPL_ZBUF;
@@ -87,37 +121,46 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
   const int64_t BH = g.B * g.dims.H;
   const float* Sp = g.state + (int64_t)p * 4 * BH;
   float* Sq = g.state + (int64_t)p2 * 4 * BH;
-  const double* Pp = g.partial + (int64_t)p * ADJ_MAX_WG * ADJ_NS;
   double* Pq = g.partial + (int64_t)p2 * ADJ_MAX_WG * ADJ_NS;
   const float rtol = (float)g.com.rtol, atol = (float)g.com.atol;
+  const int phase_in = c.phase;
+
+  // the four knots around the previous attempt's first stage time (reversed time: the field lives at t = -s)
+  const KnotWindow<float> window = knot_window(g.knots, g.n_intervals, phase_in == 0 ? (int64_t)-1 : (int64_t)c.slot);
+  // chain waves: weights into registers (L2 hits, but 80 scattered loads per lane whose latency used to sit between the
+  // controller and the first stage)
+  float wy[4][8], wv[2][16];
+  f32x4 by[4];
+  if (!helper) {
+    spl_load_wy(g.W, g.bias, w, n, q, g.dims, wy, by);
+    spl_load_wv(g.W, w, n, q, g.dims, wv);
+  }
+  // helper wave 0: one dword of the first and the last 16 bytes of the control rows the first tile will most likely read
+  // (the previous attempt's interval, or the one before it in reversed time) pulls their lines from HBM into this XCD's L2
+  // while the sums are reduced and the controller runs
+  float touched = 0.f;
+  if (helper && w == 0 && phase_in == 3 && (int64_t)blockIdx.x < g.n_tiles) {
+    const int64_t series = (int64_t)blockIdx.x * 16 + n;
+    const int64_t sc = series < g.B ? series : g.B - 1;
+    const int cand = c.slot - (q >> 1);
+    if (cand >= 0 && cand < g.n_intervals) {
+      const float* rowp = DEGREE == CDE_PATH_CUBIC ? g.coeffs + ((sc * g.n_intervals + cand) * 4 + 1) * Cr
+                                                   : g.coeffs + (sc * (g.n_intervals + 1) + cand) * Cr;
+      touched = *reinterpret_cast<const volatile float*>(rowp + ((q & 1) ? (DEGREE == CDE_PATH_CUBIC ? 3 : 2) * Cr - 1 : 0));
+    }
+  }
 
   // ---- pending global sums (fixed order: the decision is identical in every workgroup and run to run): the state
   // sums of the previous attempt launch and the parameter sums its R kernel left
-  double sum[ADJ_NS + 4];
-#pragma unroll
-  for (int i = 0; i < ADJ_NS + 4; ++i) sum[i] = 0.0;
-  if (c.phase != 0) {
-    if (g.ext_sums) {
-#pragma unroll
-      for (int i = 0; i < ADJ_NS; ++i) sum[i] = g.ext_sums[i];
-    } else {
-      for (int64_t b = tid; b < (int64_t)gridDim.x; b += blockDim.x) {
-#pragma unroll
-        for (int i = 0; i < ADJ_NS; ++i) sum[i] += Pp[ADJ_NS * b + i];
-      }
-    }
-    const double* Qp = g.pq + (int64_t)p * ADJ_RBLOCKS * 4;
-    for (int b = tid; b < ADJ_RBLOCKS; b += blockDim.x) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) sum[ADJ_NS + i] += Qp[4 * b + i];
-    }
+  if (phase_in != 0) {
     block_total<ADJ_NS + 4>(sum, red);
     if (g.ext_sums) {
 #pragma unroll
-      for (int i = 0; i < ADJ_NS; ++i) sum[i] = g.ext_sums[i];      // (block_total summed 512 copies of them)
+      for (int i = 0; i < ADJ_NS; ++i) sum[i] = g.ext_sums[i];
     }
   }
-  const int phase_in = c.phase;
+  CDE_STAMP(2);
+  asm volatile("" ::"v"(touched));
   const AdjPlan plan = adj_controller(g.com, k, sum, sum + ADJ_NS);
   const int mode = plan.mode;
   // mode 3 repeats the accepted step from ITS start state (the dense output at the interval end needs its slopes)
@@ -140,13 +183,22 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
     // the field lives at t = -s.  Consecutive steps sit in the same or in neighbouring intervals: the interval of the
     // previous launch's stage 0 (kept in the controller block) turns the search's eight dependent global loads -- paid
     // by every launch before anything else can start -- into four independent ones
-    const int idx = (int)locate_around(g.knots, g.n_intervals, -ts, phase_in == 0 ? (int64_t)-1 : (int64_t)c.slot, frac);
+    const int idx = (int)locate_window(window, g.knots, g.n_intervals, -ts, frac);
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
       sidx[j] = __builtin_amdgcn_readlane(idx, j);
       sfrac[j] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(frac), j));
     }
   }
+  // the controller block of the next launch (written now: 36 registers the stages do not have to carry)
+  if (blockIdx.x == 0 && tid == 0) {
+    c.phase = mode == 0 ? 1 : mode == 1 ? 2 : mode == 2 ? 3 : 4;
+    c.slot = sidx[0];                                              // search hint for the next launch's stage times
+    *adj_ctrl(g.ctrl, p2) = k;
+  }
+#ifdef CDE_PHASE_TRACE
+  const int attempt_no = uni((int)(c.n_accept + c.n_reject));
+#endif
   // bc[i][j]: weight of slope j in the state handed to stage i.  Everything here is wave-uniform but derives from
   // memory / LDS reads, so the compiler would hold it in vector registers (70 of them): read back through lane 0
   float bc[7][6];
@@ -166,6 +218,7 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
 
   int par = 0, gpar = 0, dbuf = 0;
   double acc[ADJ_NS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  CDE_STAMP(3);
 
   if (helper) {
     // ------------------------------------------------------------------------------------------ helper wave
@@ -217,17 +270,29 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
       }
     };
     if ((int64_t)blockIdx.x < g.n_tiles) { feed_request(blockIdx.x); feed_store(0); }
+#ifdef CDE_PHASE_TRACE
+    int htile = -1;
+#endif
     for (int64_t tile = blockIdx.x; tile < g.n_tiles; tile += gridDim.x) {
+#ifdef CDE_PHASE_TRACE
+      ++htile;
+#endif
       const bool has_next = tile + gridDim.x < g.n_tiles;
       if (has_next) feed_request(tile + gridDim.x);
       spl_barrier();
       f32x2 zr[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};      // z of the stage whose g tile is next
       // one stage's contribution to the images: g^T (w z) for each functional with a non-zero weight on that stage
+#ifdef CDE_PHASE_TRACE
+      int hstage = -1;
+#endif
       auto dw_round = [&](int gp, float a_w, float e_w) {
         if (a_w == 0.f && e_w == 0.f) return;
         float4 ga4[4];
 #pragma unroll
         for (int Tm = 0; Tm < 4; ++Tm) ga4[Tm] = *reinterpret_cast<const float4*>(gr + gp * 4 * SPL_GT + Tm * 16 * SPL_TROW);
+#ifdef CDE_PHASE_TRACE
+        if (htile == 1 && hstage == 3) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); CDE_STAMP(21); }
+#endif
         float rs[4];
 #pragma unroll
         for (int Tm = 0; Tm < 4; ++Tm) rs[Tm] = (ga4[Tm].x + ga4[Tm].y) + (ga4[Tm].z + ga4[Tm].w);
@@ -251,12 +316,21 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
         if (i < ns) {
+#ifdef CDE_PHASE_TRACE
+          hstage = i;
+#endif
+          CDE_STAMP_IF(htile == 1 && i == 3, 20);
           const float4 zt0 = *reinterpret_cast<const float4*>(ztr + par * SPL_ZT);
           const float4 zt1 = *reinterpret_cast<const float4*>(ztr + par * SPL_ZT + 16 * SPL_TROW);
           if (i >= 1) dw_round(gpar ^ 1, wS[i - 1], img_e ? wE[i - 1] : 0.f);      // stage i-1's tile
+#ifdef CDE_PHASE_TRACE
+          if (htile == 1 && i == 3) { asm volatile("s_nop 0" : "+v"(accA[3][1]), "+v"(accE[3][1])); CDE_STAMP(22); }
+#endif
           zr[0] = f32x2{zt0.x, zt0.y}; zr[1] = f32x2{zt0.z, zt0.w};
           zr[2] = f32x2{zt1.x, zt1.y}; zr[3] = f32x2{zt1.z, zt1.w};
+          CDE_STAMP_IF(htile == 1 && i == 3, 23);
           spl_barrier();
+          CDE_STAMP_IF(htile == 1 && i == 3, 24);
           par ^= 1; gpar ^= 1;
         }
       }
@@ -282,10 +356,6 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
     }
   } else {
     // ------------------------------------------------------------------------------------------ chain wave
-    float wy[4][8], wv[2][16];
-    f32x4 by[4];
-    spl_load_wy(g.W, g.bias, w, n, q, g.dims, wy, by);
-    spl_load_wv(g.W, w, n, q, g.dims, wv);
     const int ua = 8 * w + q, ub = ua + 4;
     const int pos = spl_pos(n);
     float* zw = zbuf + n * SPL_ZROW + q * 8 + 2 * w;
@@ -323,6 +393,10 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
     float st_next[4] = {0.f, 0.f, 0.f, 0.f};
     if ((int64_t)blockIdx.x < g.n_tiles) state_request(blockIdx.x, st_next);
     float vtS = 0.f, vtE = 0.f;                                   // this lane's share of the vjp_t functionals
+    CDE_STAMP(4);
+#ifdef CDE_PHASE_TRACE
+    int tile_no = 0;
+#endif
     for (int64_t tile = blockIdx.x; tile < g.n_tiles; tile += gridDim.x) {
       const int64_t series = tile * 16 + n;
       const bool valid = series < g.B;
@@ -345,6 +419,7 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
         if (i < ns) {
+          CDE_STAMP_IF(tile_no == 1 && i == 3, 15);
           const float4 z03 = *reinterpret_cast<const float4*>(zr + par * SPL_ZBUF);
           const float4 z47 = *reinterpret_cast<const float4*>(zr + par * SPL_ZBUF + 4);
           const float4 d03 = *reinterpret_cast<const float4*>(dxr + (dbuf * 7 + i) * SPL_DX);
@@ -367,6 +442,9 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
             yt[2] = mfma16(wy[2][s], zs[s], yt[2]);
             yt[3] = mfma16(wy[3][s], zs[s], yt[3]);
           }
+#ifdef CDE_PHASE_TRACE
+          if (tile_no == 1 && i == 3) { asm volatile("s_nop 0" : "+v"(yt[0]), "+v"(yt[1]), "+v"(yt[2]), "+v"(yt[3])); CDE_STAMP(16); }
+#endif
           f32x2 gq[4][2];
           f32x2 fpa = {0.f, 0.f}, fpb = {0.f, 0.f};
           f32x2 hpa = {0.f, 0.f}, hpb = {0.f, 0.f};                // the same contraction with d2X/dt2: d f / dt
@@ -410,6 +488,7 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
             ysa = y0a + sa; ysb = y0b + sb;
             publish(par ^ 1, ysa, ysb);
           }
+          CDE_STAMP_IF(tile_no == 1 && i == 3, 17);
           f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
 #pragma unroll
           for (int sp = 0; sp < 16; ++sp) {
@@ -417,12 +496,16 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
             v0 = mfma16(wv[0][sp], gv, v0);
             v1 = mfma16(wv[1][sp], gv, v1);
           }
+#ifdef CDE_PHASE_TRACE
+          if (tile_no == 1 && i == 3) { asm volatile("s_nop 0" : "+v"(v0), "+v"(v1)); CDE_STAMP(18); }
+#endif
           float* vwp = vw + (par ^ 1) * SPL_VA;
           *reinterpret_cast<float2*>(vwp) = make_float2(v0[0], v0[1]);
           *reinterpret_cast<float2*>(vwp + 64 * SPL_VROW) = make_float2(v0[2], v0[3]);
           *reinterpret_cast<float2*>(vwp + 2 * 64 * SPL_VROW) = make_float2(v1[0], v1[1]);
           *reinterpret_cast<float2*>(vwp + 3 * 64 * SPL_VROW) = make_float2(v1[2], v1[3]);
           spl_barrier();
+          CDE_STAMP_IF(tile_no == 1 && i == 3, 19);
           par ^= 1; gpar ^= 1;
         }
       }
@@ -482,20 +565,23 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
         }
       }
       dbuf ^= 1;
+#ifdef CDE_PHASE_TRACE
+      if (tile_no < 8) { __builtin_amdgcn_sched_barrier(0); stamps_.t[5 + tile_no] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); }
+      ++tile_no;
+#endif
     }
     acc[4] = (double)vtS; acc[5] = (double)vtE;
   }
+  CDE_STAMP(13);
   // ---- publish this launch's partial sums and the controller state for the next launch
   block_total<ADJ_NS>(acc, red);
+  CDE_STAMP(14);
   if (tid == 0) {
 #pragma unroll
     for (int i = 0; i < ADJ_NS; ++i) Pq[ADJ_NS * blockIdx.x + i] = acc[i];
   }
-  if (blockIdx.x == 0 && tid == 0) {
-    c.phase = mode == 0 ? 1 : mode == 1 ? 2 : mode == 2 ? 3 : 4;
-    c.slot = sidx[0];                                              // search hint for the next launch's stage times
-    *adj_ctrl(g.ctrl, p2) = k;
-  }
+  CDE_STAMP_FLUSH(k4a_phase_trace, attempt_no);
+  CDE_STAMP_FLUSH2(k4a_phase_trace, attempt_no, 256);
 }
 
 // ------------------------------------------------------------------------------------------ the R kernel
@@ -621,6 +707,14 @@ static inline size_t a256(size_t x) { return (x + 255) / 256 * 256; }
 static inline int adj_grid(int64_t B) { const int64_t t = (B + 15) / 16; return (int)(t < ADJ_MAX_WG ? t : ADJ_MAX_WG); }
 
 }  // namespace cde
+
+#ifdef CDE_PHASE_TRACE
+// debug builds only (cde_common.h, "phase trace"): the stamp ring of dopri5_adjoint_attempt, [ring][workgroup][slot]
+extern "C" int cde_debug_k4a_phase_trace(void* host_out, size_t bytes) {
+  if (bytes > sizeof(unsigned long long) * cde::TRACE_RING * cde::TRACE_BLOCKS * cde::TRACE_SLOTS) return CDE_ERR_SHAPE;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(cde::k4a_phase_trace), bytes) == hipSuccess ? CDE_OK : CDE_ERR_LAUNCH;
+}
+#endif
 
 // ================================================================================================ C ABI
 // workspace: [ctrl x2][state sums][parameter sums][carry][state 2x4xBxH][G][G_local][prev A, D (x2, global + local)]
