@@ -32,6 +32,12 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+__device__ __forceinline__ void swap32(float& x, float& y) {      // x[lanes 32..63] <-> y[lanes 0..31]
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  x = __uint_as_float(r[0]);
+  y = __uint_as_float(r[1]);
+}
+
 // ============================================================================================ forward
 // K2.  One wave owns 16 series; lane l = (n = l & 15, q = l >> 4) keeps hidden units 8q..8q+7 of series n.
 // v_mfma_f32_16x16x4_f32 (32-cycle issue, 40-cycle dependent latency): two M-tiles (hidden 32 = 2 x 16
@@ -404,6 +410,280 @@ __global__ __launch_bounds__(256, 1) void rk4_adjoint_mfma(
   }
 }
 
+// ============================================================================================ adjoint, shared Jacobian
+// K3j.  The vector field of the headline configuration is AFFINE in z: f(z) = (W z + b) dX, so its Jacobian
+//     J = df/dz = sum_c dX_c W_c          (W_c[h][k] = W[(h, c), k]; H x H per series and stage time)
+// serves both products the adjoint needs: f = J z + (b dX) and a^T df/dz = a^T J.  K3 evaluates them as two GEMMs
+// against W ((z (x) dX) and (a (x) dX) as the B operands: 2 x 16384 flop per series and stage); here ONE GEMM of the
+// same size forms J -- M = (h, k) = 1024 rows, K = the 8 channels, N = the series, i.e. 4 MFMAs per row h that leave
+// J[h][k], k = the lane's own 16 units, in the lane -- and the two H x H matrix-vector products run on the vector
+// pipe straight from the MFMA result (16 packed FMAs per row h, two half-lane exchanges per unit pair per stage).
+// Per stage and 32 series: 132 + 128 MFMAs instead of 260 + 128.  The reassociation moves roundings, not the
+// algorithm: same stages, same quadrature, same dL/dW product (tests: the same tolerances as K3 against the oracle).
+constexpr int WJ_ROWS = MH + 1;                          // 32 rows of J + the bias rows
+constexpr int WJ_FLOATS = WJ_ROWS * 64 * 4;
+// A operand of row `h`, K step s (channels 2s, 2s + 1), lane l: MFMA row i = l & 31 is unit k = rho(i), so that register
+// r of half-lane `half` receives k = 2r + half -- the layout the state lives in.  Row 32: bias, MFMA row i = unit rho(i).
+__device__ __forceinline__ float wj_image(const float* __restrict__ W, const float* __restrict__ bias, int h, int s, int l,
+                                          Dims d) {
+  const int k = rho(l & 31), c = 2 * s + (l >> 5);
+  if (c >= d.C || k >= d.H) return 0.f;
+  if (h < MH) return h < d.H ? W[(h * d.C + c) * d.H + k] : 0.f;
+  return bias[k * d.C + c];
+}
+
+template <typename TT, int DEGREE>
+__global__ __launch_bounds__(256, 1) void rk4_adjoint_jacobian(
+    const float* __restrict__ coeffs, const float* __restrict__ knots, int64_t n_intervals,
+    const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ z_saved,
+    const float* __restrict__ grad_out, const TT* __restrict__ sgrid, const int64_t* __restrict__ seg_off,
+    int64_t n_out, float* __restrict__ grad_z0, float* __restrict__ partial, int64_t B,
+    const int64_t* __restrict__ stage_index, const float* __restrict__ stage_frac, Dims dims) {
+  const int Hr = dims.H, Cr = dims.C;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  for (int e = threadIdx.x; e < WJ_FLOATS; e += 256) lds[e] = wj_image(W, bias, e >> 8, e & 3, (e >> 2) & 63, dims);
+  __syncthreads();
+  const float4* wj = reinterpret_cast<const float4*>(lds);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 31, half = lane >> 5;
+  float* scr_y = lds + WJ_FLOATS + wave * SCR_FLOATS;
+
+  const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  float* my_partial = partial + tile * PARTIAL_FLOATS;
+  if (tile * 32 >= B) return;   // host sizes `partial` by the number of live tiles only
+  const int64_t series = tile * 32 + n;
+  const bool valid = series < B;
+  const int64_t sc = valid ? series : B - 1;
+
+  f32x16 accW[MC];
+  f32x2 gbp[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};   // dL/db partials, channel pairs
+#pragma unroll
+  for (int c = 0; c < MC; ++c) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accW[c][r] = 0.f;
+  }
+
+  f32x16 y0, a0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int u = 2 * r + half;
+    const bool on = u < Hr;
+    y0[r] = on ? z_saved[(sc * n_out + (n_out - 1)) * Hr + u] : 0.f;
+    a0[r] = (valid && on) ? grad_out[(sc * n_out + (n_out - 1)) * Hr + u] : 0.f;   // a == 0 stays 0: padded lanes add nothing to dL/dW
+  }
+
+  // Per-wave LDS scratch for the (series -> MFMA K index) transpose of the dL/dW product, laid out so that
+  // the reader side is 16-byte vector loads:
+  //   scr_zt[(par*32 + u)*20 + s] = z_u of series 2s+par      (row stride 20 floats = 80 B: b128-aligned and
+  //   scr_at[(par*32 + u)*20 + s] = a_u of series 2s+par       conflict-free for the 16-lane b128 groups)
+  //   scr_dw[series*8 + c]        = (quadrature weight * ds) * dX_c of that series
+  // Instruction economy matters more than placement here: a single wave hides nothing behind its own f32
+  // MFMAs (scripts/ubench/mfma_issue.hip), so every product is a packed v_pk_mul_f32, operands of the two
+  // chains come straight from registers, and LDS is touched with b128 only.
+  float* scr_zt = scr_y;                    // 64 rows x 20
+  float* scr_at = scr_y + 64 * 20;          // 64 rows x 20
+  float* scr_dw = scr_y + 2 * 64 * 20;      // 32 x 8
+
+  for (int64_t p = 0; p + 1 < n_out; ++p) {
+    const int64_t i_out = n_out - 1 - p;
+    const int64_t k_begin = seg_off[p], k_end = seg_off[p + 1] - 1;   // steps k_begin .. k_end-1
+    if (k_end > k_begin) {
+      int64_t idx = stage_index[4 * k_begin];
+      float frac = stage_frac[4 * k_begin];
+      Row<DEGREE> row = load_row<DEGREE>(coeffs, sc, n_intervals, idx, Cr);
+      for (int64_t k = k_begin; k < k_end; ++k) {
+        const float ds = (float)(sgrid[k + 1] - sgrid[k]);
+        f32x16 ky1, ky2, ka1, ka2, yst = y0, ast = a0;
+#pragma unroll
+        for (int stage = 0; stage < 4; ++stage) {
+          float dX[MC];
+          const float width = DEGREE == CDE_PATH_LINEAR ? knots[idx + 1] - knots[idx] : 1.f;
+          control_slope<DEGREE>(row, frac, width, dX);
+          // prefetch the next stage's table entry and (if the interval changes) its control row
+          const int64_t e_next = 4 * k + stage + 1;
+          const bool more = e_next < 4 * k_end;
+          const int64_t nidx = more ? stage_index[e_next] : idx;
+          const float nfrac = more ? stage_frac[e_next] : frac;
+          if (nidx != idx) row = load_row<DEGREE>(coeffs, sc, n_intervals, nidx, Cr);
+
+          const f32x2 d01 = {dX[0], dX[1]}, d23 = {dX[2], dX[3]}, d45 = {dX[4], dX[5]}, d67 = {dX[6], dX[7]};
+          // ---- stage state -> scratch (transposed), weighted control derivative
+          {
+            const float wq = ((stage == 0 || stage == 3) ? 0.125f : 0.375f) * ds;   // 3/8-rule quadrature weight
+            float* wz = scr_zt + ((n & 1) * 32 + half) * 20 + (n >> 1);              // + 2r*20
+            float* wa = scr_at + ((n & 1) * 32 + half) * 20 + (n >> 1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { wz[r * 40] = yst[r]; wa[r * 40] = ast[r]; }
+            const f32x2 w0 = (half ? d45 : d01) * wq, w1 = (half ? d67 : d23) * wq;
+            *reinterpret_cast<float4*>(scr_dw + n * 8 + 4 * half) = make_float4(w0[0], w0[1], w1[0], w1[1]);
+            wave_lds_sync();
+          }
+
+          // ---- J = sum_c dX_c W_c one row (hidden unit h) at a time: 4 MFMAs leave J[h][k] of this lane's series in
+          // the lane, k = the 16 units it owns; f_h += J[h][.] . z and va += a_h J[h][.] follow on the vector pipe.
+          f32x16 f, va;
+          {
+            const float bs0 = half ? dX[1] : dX[0], bs1 = half ? dX[3] : dX[2], bs2 = half ? dX[5] : dX[4], bs3 = half ? dX[7] : dX[6];
+            f32x2 va2[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) va2[j] = f32x2{0.f, 0.f};
+            int opaque = 0;                               // the image reads are loop invariant: without this the
+            asm volatile("" : "+v"(opaque));              // compiler hoists all 33 out of the solve (132 registers)
+            const float4* wp = wj + lane + opaque;
+            // One row of J = 4 dependent MFMAs into VECTOR registers.  Written as asm because the compiler gives MFMA
+            // results of this kernel accumulator registers (the 128 of dL/dW have to live there) and would then move
+            // every J value back with a v_accvgpr_read: 16 extra instructions per row, each one costing the wave
+            // matrix-pipe time.  Hazards: the rows are issued one ahead of their use -- J of row h is read only after
+            // the 4 MFMAs of row h + 1 have ISSUED, and those queue behind row h in the same in-order pipe (each waits
+            // for its predecessor's accumulator), so row h has long been written; the empty asm on J after the next
+            // issue pins that order.  The last issue of a stage (bias rows) is followed by explicit wait states.
+            auto issue = [&](f32x16& J, const float4& a) {
+              __builtin_amdgcn_sched_barrier(0);           // everything that still reads the old J stays above
+              asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %5, 0\n\t"
+                           "v_mfma_f32_32x32x2_f32 %0, %2, %6, %0\n\t"
+                           "v_mfma_f32_32x32x2_f32 %0, %3, %7, %0\n\t"
+                           "v_mfma_f32_32x32x2_f32 %0, %4, %8, %0"
+                           : "=&v"(J) : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(bs0), "v"(bs1), "v"(bs2), "v"(bs3));
+              __builtin_amdgcn_sched_barrier(0);
+            };
+            // the two uses of a row: this half-lane's share of f_h = J[h][.] . z, and va += a_h J[h][.]
+            auto consume = [&](const f32x16& J, float ah) {
+              const f32x2 ah2 = {ah, ah};
+              f32x2 p2 = {0.f, 0.f}, q2 = {0.f, 0.f};
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const f32x2 m = {J[2 * j], J[2 * j + 1]};
+                if (j & 1) q2 = __builtin_elementwise_fma(m, f32x2{yst[2 * j], yst[2 * j + 1]}, q2);
+                else p2 = __builtin_elementwise_fma(m, f32x2{yst[2 * j], yst[2 * j + 1]}, p2);
+                va2[j] = __builtin_elementwise_fma(m, ah2, va2[j]);
+              }
+              // (va is only read after the last row: left alone, the optimiser sinks all 256 of these FMAs below the
+              // last row and keeps every J alive in scratch until then)
+#pragma unroll
+              for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(va2[j]));
+              p2 = p2 + q2;
+              return p2[0] + p2[1];
+            };
+            f32x16 Je, Jo;                                 // rows 2r / 2r + 1 in flight
+            float4 a_cur = wp[0], a_nxt = wp[64];
+            issue(Je, a_cur);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              a_cur = wp[(2 * r + 2) * 64];                // image of row 2r + 2 (r = 15: the bias rows)
+              issue(Jo, a_nxt);
+              asm volatile("" : "+v"(Je));
+              // a of units 2r, 2r + 1 in both half-lanes (the lower half-lanes own unit 2r, the upper ones 2r + 1)
+              float ae = ast[r], ao = ast[r];
+              swap32(ae, ao);
+              float X = consume(Je, ae);
+              if (r < 15) a_nxt = wp[(2 * r + 3) * 64];
+              issue(Je, a_cur);
+              asm volatile("" : "+v"(Jo));
+              float Y = consume(Jo, ao);
+              swap32(X, Y);                                // ... and each half-lane collects the f of the unit it owns
+              f[r] = X + Y;
+            }
+            // Je: (b dX)_h for the units this lane owns.  16-pass MFMA result -> VALU read: 20 wait states
+            asm volatile("s_nop 15\n\ts_nop 7" : "+v"(Je));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              f[r] += Je[r];
+              va[r] = va2[r >> 1][r & 1];
+            }
+          }
+
+          // ---- dL/dW tile c: D[h][k] += sum_series (w ds a_h dX_c)[series] * z_k[series]; this lane feeds MFMA
+          // K index `half` of K-step s2, i.e. series 2*s2 + half, row h = n, column k = n.
+          {
+            const float4* zt4 = reinterpret_cast<const float4*>(scr_zt + (half * 32 + n) * 20);
+            const float4* at4 = reinterpret_cast<const float4*>(scr_at + (half * 32 + n) * 20);
+            const float4* dw4 = reinterpret_cast<const float4*>(scr_dw + half * 8);      // + s2*4 (16 floats per s2)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              const float4 zq = zt4[g4], aq = at4[g4];                       // K-steps 4*g4 .. 4*g4+3
+              const f32x2 ap0 = {aq.x, aq.y}, ap1 = {aq.z, aq.w};
+              const float zs[4] = {zq.x, zq.y, zq.z, zq.w};
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const int s2 = 4 * g4 + i;
+                const float4 e0 = dw4[s2 * 4], e1 = dw4[s2 * 4 + 1];
+                const f32x2 e01 = {e0.x, e0.y}, e23 = {e0.z, e0.w}, e45 = {e1.x, e1.y}, e67 = {e1.z, e1.w};
+                const f32x2 asrc = i < 2 ? ap0 : ap1;
+                f32x2 v01, v23, v45, v67;
+                if (i & 1) {
+                  v01 = pk_mul_hi(e01, asrc); v23 = pk_mul_hi(e23, asrc); v45 = pk_mul_hi(e45, asrc); v67 = pk_mul_hi(e67, asrc);
+                  pk_fma_hi(gbp[0], e01, asrc); pk_fma_hi(gbp[1], e23, asrc); pk_fma_hi(gbp[2], e45, asrc); pk_fma_hi(gbp[3], e67, asrc);
+                } else {
+                  v01 = pk_mul_lo(e01, asrc); v23 = pk_mul_lo(e23, asrc); v45 = pk_mul_lo(e45, asrc); v67 = pk_mul_lo(e67, asrc);
+                  pk_fma_lo(gbp[0], e01, asrc); pk_fma_lo(gbp[1], e23, asrc); pk_fma_lo(gbp[2], e45, asrc); pk_fma_lo(gbp[3], e67, asrc);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const float zb = zs[i];
+                accW[0] = mfma(v01[0], zb, accW[0]); accW[1] = mfma(v01[1], zb, accW[1]);
+                accW[2] = mfma(v23[0], zb, accW[2]); accW[3] = mfma(v23[1], zb, accW[3]);
+                accW[4] = mfma(v45[0], zb, accW[4]); accW[5] = mfma(v45[1], zb, accW[5]);
+                accW[6] = mfma(v67[0], zb, accW[6]); accW[7] = mfma(v67[1], zb, accW[7]);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+          }
+          wave_lds_sync();   // scratch reads retired before the next stage overwrites it
+
+          // ---- reverse-time dynamics: dy/ds = -f, da/ds = +a^T df/dz.  3/8 rule in two slots per variable:
+          // after stage 2 slot 1 holds k1 + 3*(k2+k3) (same association as torchdiffeq).
+          const f32x16 ky = -f, ka = va;
+          const float third = (float)(1.0 / 3.0);
+          if (stage == 0) {
+            ky1 = ky; ka1 = ka;
+            yst = y0 + ds * ky1 * third;
+            ast = a0 + ds * ka1 * third;
+          } else if (stage == 1) {
+            ky2 = ky; ka2 = ka;
+            yst = y0 + ds * (ky2 - ky1 * third);
+            ast = a0 + ds * (ka2 - ka1 * third);
+          } else if (stage == 2) {
+            yst = y0 + ds * (ky1 - ky2 + ky);
+            ast = a0 + ds * (ka1 - ka2 + ka);
+            ky1 = ky1 + 3.f * (ky2 + ky);
+            ka1 = ka1 + 3.f * (ka2 + ka);
+          } else {
+            yst = y0 + (ky1 + ky) * ds * 0.125f;
+            ast = a0 + (ka1 + ka) * ds * 0.125f;
+          }
+          idx = nidx; frac = nfrac;
+        }
+        y0 = yst; a0 = ast;
+      }
+    }
+    // torchdiffeq adjoint: re-seed y from the stored forward value, add the incoming gradient
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int u = 2 * r + half;
+      if (u < Hr) {
+        y0[r] = z_saved[(sc * n_out + (i_out - 1)) * Hr + u];
+        if (valid) a0[r] += grad_out[(sc * n_out + (i_out - 1)) * Hr + u];
+      }
+    }
+  }
+  if (valid) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) if (2 * r + half < Hr) grad_z0[series * Hr + 2 * r + half] = a0[r];
+  }
+  // per-wave partial parameter gradients (summed in tile order by reduce_mfma_partials)
+#pragma unroll
+  for (int c = 0; c < MC; ++c) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int h = (r & 3) + 8 * (r >> 2) + 4 * half;
+      my_partial[(h * MC + c) * MH + n] = accW[c][r];
+    }
+    // gb partial of lane (h = n, half): add the two halves through a lane exchange
+    const float mine_gb = gbp[c >> 1][c & 1];
+    const float other = __shfl_xor(mine_gb, 32, 64);
+    if (half == 0) my_partial[MH * MC * MH + n * MC + c] = mine_gb + other;
+  }
+}
+
 // ============================================================================================ adjoint, fields with an activation
 // K3a.  f = reshape(act(W z + b)) dX.  Same ownership as K3 (one wave = 32 series, lane (n, half) keeps hidden
 // units 2r + half), but the GEMMs are the pre-activation ones, processed in 8 row tiles of 4 hidden units x 8
@@ -437,11 +717,6 @@ __device__ __forceinline__ float wv32_image(const float* __restrict__ W, int T, 
   return (h < d.H && c < d.C && k < d.H) ? W[(h * d.C + c) * d.H + k] : 0.f;
 }
 
-__device__ __forceinline__ void swap32(float& x, float& y) {      // x[lanes 32..63] <-> y[lanes 0..31]
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-  x = __uint_as_float(r[0]);
-  y = __uint_as_float(r[1]);
-}
 
 //
 // DCOEFF: also produce dL/d(control coefficients) (adjoint_params containing the coefficient tensor, reference
@@ -816,6 +1091,13 @@ int launch_forward_mlp(const void* coeffs, const void* knots, int64_t n_interval
   return check_launch();
 }
 
+// which of the two adjoint kernels of the affine field runs: K3j (shared Jacobian) unless CDE_K3_FORM=product asks for K3
+// (the tests run both against the oracle; scripts compare their timings)
+static bool k3_form_jacobian() {
+  const char* e = getenv("CDE_K3_FORM");
+  return !(e && e[0] == 'p');
+}
+
 template <typename TT>
 int launch_adjoint_mfma(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
                         const void* bias, int act, const void* z_saved, const void* grad_out, const void* sgrid,
@@ -851,6 +1133,9 @@ int launch_adjoint_mfma(const void* coeffs, const void* knots, int64_t n_interva
       if (degree == CDE_PATH_CUBIC) CDE_ADJ_DX((rk4_adjoint_act_mfma<TT, CDE_PATH_CUBIC, CDE_ACT_TANH, true>));
       else CDE_ADJ_DX((rk4_adjoint_act_mfma<TT, CDE_PATH_LINEAR, CDE_ACT_TANH, true>));
     } else return CDE_ERR_UNSUPPORTED;
+  } else if (act == CDE_ACT_NONE && k3_form_jacobian()) {
+    if (degree == CDE_PATH_CUBIC) CDE_ADJ((rk4_adjoint_jacobian<TT, CDE_PATH_CUBIC>), WJ_FLOATS + 4 * SCR_FLOATS);
+    else CDE_ADJ((rk4_adjoint_jacobian<TT, CDE_PATH_LINEAR>), WJ_FLOATS + 4 * SCR_FLOATS);
   } else if (act == CDE_ACT_NONE) {
     if (degree == CDE_PATH_CUBIC) CDE_ADJ((rk4_adjoint_mfma<TT, CDE_PATH_CUBIC>), W1_FLOATS + W2_FLOATS + 4 * SCR_FLOATS);
     else CDE_ADJ((rk4_adjoint_mfma<TT, CDE_PATH_LINEAR>), W1_FLOATS + W2_FLOATS + 4 * SCR_FLOATS);
