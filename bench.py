@@ -40,6 +40,11 @@ N_EVAL = 4 * (L - 1)
 FLOP_FWD = N_EVAL * (2 * H * (H * C) + 2 * H * C)                                     # 8.58 MFLOP
 FLOP_ADJ = N_EVAL * ((2 * H * H * C + 2 * H * C) + 2 * H * C + 2 * H * C * H + 2 * H * C * H + H * C)   # 25.6 MFLOP
 PEAK_F32_MFMA_TFLOPS = 157.3
+# What K3j (csrc/rk4_mfma.hip, the default adjoint kernel of the affine field) EXECUTES per evaluation: the shared Jacobian
+# J = sum_c dX_c W_c replaces the two GEMMs f = W (z (x) dX), a^T df/dz = W^T (a (x) dX) of the count above by one GEMM of
+# the same size plus two H x H matrix-vector products on the vector pipe.  Matrix pipe: J (+ bias rows) and dL/dW.
+FLOP_ADJ_K3J_MFMA = N_EVAL * ((2 * H * H * C + 2 * H * C) + 2 * H * C * H)            # 16.9 MFLOP
+FLOP_ADJ_K3J_VALU = N_EVAL * (2 * 2 * H * H + H * C)                                   # 2.2 MFLOP
 PEAK_HBM_GBS = 8000.0
 # HBM bytes per launch of the dominant kernel from rocprofv3 counter passes (see roofline.traffic_source); keyed by the
 # per-GPU batch the pass was run at, None where no pass exists
@@ -663,7 +668,17 @@ def main():
         value = total_series / elapsed
         achieved = B * FLOP_ADJ / (adj_avg * 1e-3) / 1e12 if adj_avg > 0 else 0.0
         split = B <= 16384                      # CDE_SPLIT_MAX_BATCH: workgroup-per-tile kernels below, K2/K3 above
-        kernel = "rk4_adjoint_split8 (K3s)" if split else "rk4_adjoint_mfma (K3)"
+        jacobian = not split and not os.environ.get("CDE_K3_FORM", "").startswith("p")
+        kernel = "rk4_adjoint_split8 (K3s)" if split else "rk4_adjoint_jacobian (K3j)" if jacobian else "rk4_adjoint_mfma (K3)"
+        executed = None
+        if jacobian and adj_avg > 0:
+            mfma_tf = B * FLOP_ADJ_K3J_MFMA / (adj_avg * 1e-3) / 1e12
+            executed = {"mfma_flop_per_launch": B * FLOP_ADJ_K3J_MFMA, "valu_flop_per_launch": B * FLOP_ADJ_K3J_VALU,
+                        "mfma_tflops": mfma_tf, "mfma_frac_of_peak": mfma_tf / PEAK_F32_MFMA_TFLOPS,
+                        "note": "`achieved` counts the ALGORITHMIC flop of the reference formulation (SURVEY 8(d): 50,432 per "
+                                "series and stage, three GEMMs); K3j executes 33,280 of them on the matrix pipe and 4,352 on "
+                                "the vector pipe (f and a^T df/dz share the Jacobian J = sum_c dX_c W_c), so `frac` can "
+                                "exceed what the matrix pipe alone would allow; mfma_frac_of_peak is the executed share"}
         traffic = ADJOINT_HBM_BYTES_PER_LAUNCH.get(B)
         result = {
             "metric": "series/sec (fwd+adjoint) for cdeint RK4, batch=32k L=128 C=8 H=32",
@@ -690,7 +705,7 @@ def main():
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                          "traffic_source": TRAFFIC_SOURCE.get(B),
                          "kernel": kernel, "kernel_ms": adj_avg,
-                         "algorithmic_flop_per_launch": B * FLOP_ADJ},
+                         "algorithmic_flop_per_launch": B * FLOP_ADJ, "executed": executed},
             "extra": {
                 "forward_kernel_ms": fwd_avg,
                 "forward_tflops": B * FLOP_FWD / (fwd_avg * 1e-3) / 1e12 if fwd_avg > 0 else None,
