@@ -187,7 +187,25 @@ __global__ __launch_bounds__(256, 2) void rk4_forward_split(
 // at B = 4096 against 0.87 ms here); the helper's MFMA chain runs in exactly those gaps.
 constexpr int SPL8_LDS_FLOATS = 2 * SPL_ZBUF + 2 * SPL_ZT + 2 * SPL_VA + 2 * SPL_DX + 2 * 4 * SPL_GT;
 
-template <typename TT, int DEGREE, int ACT>
+// JF (affine field only): the chain waves evaluate f and a^T df/dz through the shared Jacobian J = sum_c dX_c W_c (see K3j,
+// rk4_mfma.hip) instead of the two products Y = W z and va = W_w^T g.  Wave w forms the 8 rows of J it owns,
+//     tile (hi, kh), MFMA row i = 4 q' + r  <->  J[h = 8w + hi][k = 4 (4 kh + r) + q'],      K = the 8 channels (2 steps)
+// = 32 MFMAs (as many as Y alone), and lane (n, q) then holds J[h][k] for the very units k = 4 s + q whose z it already has
+// in registers as the Y product's B operand (s = 4 kh + r).  f_h = J[h][.] . z is completed over the four lane quarters by
+// two half-/row-swap rounds; a's slope sum_h a_h J[h][k] lands in the (tile kh, register r) pattern of the old va tiles, so
+// the cross-wave exchange through vab is unchanged.  64 MFMAs per SIMD and stage instead of 96.
+__device__ __forceinline__ void swap32s(float& x, float& y) {      // x[lanes 32..63] <-> y[lanes 0..31]
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  x = __uint_as_float(r[0]);
+  y = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap16s(float& x, float& y) {      // x[odd 16-lane rows] <-> y[even 16-lane rows]
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  x = __uint_as_float(r[0]);
+  y = __uint_as_float(r[1]);
+}
+
+template <typename TT, int DEGREE, int ACT, bool JF = false>
 __global__ __launch_bounds__(512, 1) void rk4_adjoint_split8(
     const float* __restrict__ coeffs, const float* __restrict__ knots, int64_t n_intervals,
     const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ z_saved,
@@ -294,11 +312,32 @@ __global__ __launch_bounds__(512, 1) void rk4_adjoint_split8(
   }
 
   // -------------------------------------------------------------------------------------------- chain wave
+  static_assert(!JF || ACT == CDE_ACT_NONE, "the Jacobian form needs a field that is affine in z");
   float wy[4][8], wv[2][16];
   f32x4 by[4];
-  spl_load_wy(W, bias, w, n, q, dims, wy, by);
-  spl_load_wv(W, w, n, q, dims, wv);
+  float wj[JF ? 16 : 1][2];                                        // JF: A image of J, [tile = 2 hi + kh][K step]
+  f32x2 bja[4], bjb[4];                                            //     bias rows of the lane's two units, channel pairs
   const int ua = 8 * w + q, ub = ua + 4;
+  if constexpr (JF) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int h = 8 * w + (t >> 1), k = 4 * (4 * (t & 1) + (n & 3)) + (n >> 2);
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const int c = 4 * st + q;
+        wj[t][st] = (h < Hr && c < Cr && k < Hr) ? W[(h * Cr + c) * Hr + k] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      auto bv = [&](int u, int c) { return (u < Hr && c < Cr) ? bias[u * Cr + c] : 0.f; };
+      bja[j] = f32x2{bv(ua, 2 * j), bv(ua, 2 * j + 1)};
+      bjb[j] = f32x2{bv(ub, 2 * j), bv(ub, 2 * j + 1)};
+    }
+  } else {
+    spl_load_wy(W, bias, w, n, q, dims, wy, by);
+    spl_load_wv(W, w, n, q, dims, wv);
+  }
   const int pos = spl_pos(n);
   auto saved = [&](int64_t j, int u) { return u < Hr ? z_saved[(sc * n_out + j) * Hr + u] : 0.f; };
   auto gout = [&](int64_t j, int u) { return (valid && u < Hr) ? grad_out[(sc * n_out + j) * Hr + u] : 0.f; };
@@ -360,6 +399,70 @@ __global__ __launch_bounds__(512, 1) void rk4_adjoint_split8(
           }
           const float zs[8] = {z03.x, z03.y, z03.z, z03.w, z47.x, z47.y, z47.z, z47.w};
           const float dX[MC] = {d03.x, d03.y, d03.z, d03.w, d47.x, d47.y, d47.z, d47.w};
+          f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;                // a's slope, partial over this wave's 8 units
+          float kya, kyb;
+          float* gwp = gw_ + gpar * 4 * SPL_GT;
+          if constexpr (JF) {
+            // ---- g = a (x) dX for the helper waves' dL/dW product (the lane's two units, all channels)
+#pragma unroll
+            for (int T = 0; T < 4; ++T) {
+              const float aown = (T >> 1) ? asb : asa;
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                const f32x2 gq2 = f32x2{dX[4 * (T & 1) + 2 * j], dX[4 * (T & 1) + 2 * j + 1]} * aown;
+                gwp[(T * 16 + 2 * j) * SPL_TROW] = gq2[0];
+                gwp[(T * 16 + 2 * j + 1) * SPL_TROW] = gq2[1];
+              }
+            }
+            // ---- a of the wave's 8 units in every lane quarter: a8[hi] = a_(8w + hi) of this lane's series
+            float a8[8];
+            {
+              float ea = asa, oa = asa, eb = asb, ob = asb;
+              swap16s(ea, oa);                                     // ea: unit q & ~1, oa: unit q | 1 (of this half)
+              swap16s(eb, ob);
+              float e0 = ea, e2 = ea, o1 = oa, o3 = oa, e4 = eb, e6 = eb, o5 = ob, o7 = ob;
+              swap32s(e0, e2); swap32s(o1, o3); swap32s(e4, e6); swap32s(o5, o7);
+              a8[0] = e0; a8[1] = o1; a8[2] = e2; a8[3] = o3; a8[4] = e4; a8[5] = o5; a8[6] = e6; a8[7] = o7;
+            }
+            // ---- J one unit at a time: two tiles (k halves) of 2 K steps each; f_h partial and a's slope from the result
+            const float bq0 = q == 0 ? dX[0] : q == 1 ? dX[1] : q == 2 ? dX[2] : dX[3];
+            const float bq1 = q == 0 ? dX[4] : q == 1 ? dX[5] : q == 2 ? dX[6] : dX[7];
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            const f32x2 z01 = {zs[0], zs[1]}, z23 = {zs[2], zs[3]}, z45 = {zs[4], zs[5]}, z67 = {zs[6], zs[7]};
+            f32x2 va01 = {0.f, 0.f}, va23 = va01, vb01 = va01, vb23 = va01;
+            float p[8];
+#pragma unroll
+            for (int hi = 0; hi < 8; ++hi) {
+              f32x4 j0 = mfma16(wj[2 * hi][0], bq0, zero);
+              f32x4 j1 = mfma16(wj[2 * hi + 1][0], bq0, zero);
+              j0 = mfma16(wj[2 * hi][1], bq1, j0);
+              j1 = mfma16(wj[2 * hi + 1][1], bq1, j1);
+              const f32x2 ah = {a8[hi], a8[hi]};
+              f32x2 pp = f32x2{j0[0], j0[1]} * z01;
+              pp = __builtin_elementwise_fma(f32x2{j0[2], j0[3]}, z23, pp);
+              pp = __builtin_elementwise_fma(f32x2{j1[0], j1[1]}, z45, pp);
+              pp = __builtin_elementwise_fma(f32x2{j1[2], j1[3]}, z67, pp);
+              p[hi] = pp[0] + pp[1];
+              va01 = __builtin_elementwise_fma(f32x2{j0[0], j0[1]}, ah, va01);
+              va23 = __builtin_elementwise_fma(f32x2{j0[2], j0[3]}, ah, va23);
+              vb01 = __builtin_elementwise_fma(f32x2{j1[0], j1[1]}, ah, vb01);
+              vb23 = __builtin_elementwise_fma(f32x2{j1[2], j1[3]}, ah, vb23);
+            }
+            v0 = f32x4{va01[0], va01[1], va23[0], va23[1]};
+            v1 = f32x4{vb01[0], vb01[1], vb23[0], vb23[1]};
+            // ---- f of the lane's two units: sum the four quarters' shares (units 0,1,4,5 meet in the lower half-wave,
+            // 2,3,6,7 in the upper one; then even / odd units in the even / odd 16-lane rows)
+            swap32s(p[0], p[2]); swap32s(p[1], p[3]); swap32s(p[4], p[6]); swap32s(p[5], p[7]);
+            float s0 = p[0] + p[2], s1 = p[1] + p[3], s4 = p[4] + p[6], s5 = p[5] + p[7];
+            swap16s(s0, s1); swap16s(s4, s5);
+            f32x2 fb2 = bja[0] * f32x2{dX[0], dX[1]}, fb3 = bjb[0] * f32x2{dX[0], dX[1]};
+#pragma unroll
+            for (int j = 1; j < 4; ++j) {
+              fb2 = __builtin_elementwise_fma(bja[j], f32x2{dX[2 * j], dX[2 * j + 1]}, fb2);
+              fb3 = __builtin_elementwise_fma(bjb[j], f32x2{dX[2 * j], dX[2 * j + 1]}, fb3);
+            }
+            kya = -((s0 + s1) + (fb2[0] + fb2[1])); kyb = -((s4 + s5) + (fb3[0] + fb3[1]));      // reverse time: dy/ds = -f
+          } else {
           // ---- Y tiles of this wave's 8 hidden units
           f32x4 yt[4] = {by[0], by[1], by[2], by[3]};
 #pragma unroll
@@ -372,7 +475,6 @@ __global__ __launch_bounds__(512, 1) void rk4_adjoint_split8(
           // ---- activation, f, g = dL/dY (pairs = neighbouring channels of one unit: packed, no shuffles)
           f32x2 gq[4][2];
           f32x2 fpa = {0.f, 0.f}, fpb = {0.f, 0.f};
-          float* gwp = gw_ + gpar * 4 * SPL_GT;
 #pragma unroll
           for (int T = 0; T < 4; ++T) {
             const float aown = (T >> 1) ? asb : asa;
@@ -387,7 +489,15 @@ __global__ __launch_bounds__(512, 1) void rk4_adjoint_split8(
               gwp[(T * 16 + 2 * j + 1) * SPL_TROW] = gq[T][j][1];
             }
           }
-          const float kya = -(fpa[0] + fpa[1]), kyb = -(fpb[0] + fpb[1]);          // reverse time: dy/ds = -f
+            kya = -(fpa[0] + fpa[1]); kyb = -(fpb[0] + fpb[1]);          // reverse time: dy/ds = -f
+          // ---- va partial over this wave's 64 (h, c) rows, all 32 output units (K step 8P + c)
+#pragma unroll
+          for (int sp = 0; sp < 16; ++sp) {
+            const float gv = gq[2 * (sp >> 3) + ((sp >> 2) & 1)][(sp >> 1) & 1][sp & 1];     // g[P = sp >> 3][c = sp & 7]
+            v0 = mfma16(wv[0][sp], gv, v0);
+            v1 = mfma16(wv[1][sp], gv, v1);
+          }
+          }
           float nya, nyb;
           if (stage == 0) {
             ky1a = kya; ky1b = kyb;
@@ -403,14 +513,6 @@ __global__ __launch_bounds__(512, 1) void rk4_adjoint_split8(
           }
           publish(par ^ 1, nya, nyb);
           ysa = nya; ysb = nyb;
-          // ---- va partial over this wave's 64 (h, c) rows, all 32 output units (K step 8P + c)
-          f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
-#pragma unroll
-          for (int sp = 0; sp < 16; ++sp) {
-            const float gv = gq[2 * (sp >> 3) + ((sp >> 2) & 1)][(sp >> 1) & 1][sp & 1];     // g[P = sp >> 3][c = sp & 7]
-            v0 = mfma16(wv[0][sp], gv, v0);
-            v1 = mfma16(wv[1][sp], gv, v1);
-          }
           // register r of tile T -> destination wave 2T + (r >> 1), its unit j = r & 1
           float* vwp = vw + (par ^ 1) * SPL_VA;
           *reinterpret_cast<float2*>(vwp) = make_float2(v0[0], v0[1]);
@@ -476,19 +578,23 @@ int launch_adjoint_split(const void* coeffs, const void* knots, int64_t n_interv
   const unsigned blocks = (unsigned)((B + 15) / 16);
   const size_t lds = (size_t)SPL8_LDS_FLOATS * sizeof(float);
   if (degree != CDE_PATH_CUBIC && degree != CDE_PATH_LINEAR) return CDE_ERR_UNSUPPORTED;
-#define CDE_ADJ(D, A)                                                                                                \
+#define CDE_ADJ(D, A, J)                                                                                             \
   do {                                                                                                               \
-    (void)hipFuncSetAttribute((const void*)rk4_adjoint_split8<TT, D, A>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+    (void)hipFuncSetAttribute((const void*)rk4_adjoint_split8<TT, D, A, J>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)lds);                                                                             \
-    rk4_adjoint_split8<TT, D, A><<<blocks, 512, lds, s>>>(                                                           \
+    rk4_adjoint_split8<TT, D, A, J><<<blocks, 512, lds, s>>>(                                                        \
         (const float*)coeffs, (const float*)knots, n_intervals, (const float*)W, (const float*)bias,                 \
         (const float*)z_saved, (const float*)grad_out, (const TT*)sgrid, seg_off, n_out, (float*)grad_z0, partial,   \
         B, stage_index, (const float*)stage_frac, dims);                                                             \
   } while (0)
-  if (act == CDE_ACT_NONE) {
-    if (degree == CDE_PATH_CUBIC) CDE_ADJ(CDE_PATH_CUBIC, CDE_ACT_NONE); else CDE_ADJ(CDE_PATH_LINEAR, CDE_ACT_NONE);
+  const char* form = getenv("CDE_K3_FORM");                          // "product": the two-GEMM chain waves (tests, comparisons)
+  const bool jacobian = !(form && form[0] == 'p');
+  if (act == CDE_ACT_NONE && jacobian) {
+    if (degree == CDE_PATH_CUBIC) CDE_ADJ(CDE_PATH_CUBIC, CDE_ACT_NONE, true); else CDE_ADJ(CDE_PATH_LINEAR, CDE_ACT_NONE, true);
+  } else if (act == CDE_ACT_NONE) {
+    if (degree == CDE_PATH_CUBIC) CDE_ADJ(CDE_PATH_CUBIC, CDE_ACT_NONE, false); else CDE_ADJ(CDE_PATH_LINEAR, CDE_ACT_NONE, false);
   } else if (act == CDE_ACT_TANH) {
-    if (degree == CDE_PATH_CUBIC) CDE_ADJ(CDE_PATH_CUBIC, CDE_ACT_TANH); else CDE_ADJ(CDE_PATH_LINEAR, CDE_ACT_TANH);
+    if (degree == CDE_PATH_CUBIC) CDE_ADJ(CDE_PATH_CUBIC, CDE_ACT_TANH, false); else CDE_ADJ(CDE_PATH_LINEAR, CDE_ACT_TANH, false);
   } else return CDE_ERR_UNSUPPORTED;
 #undef CDE_ADJ
   int rc = check_launch();
