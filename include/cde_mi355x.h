@@ -327,6 +327,10 @@ int cde_rk4_adjoint_mlp_sweep(const void* coeffs, const void* knots, int64_t n_i
  * parameter gradients in registers; it streams 2.3 KB of per-stage factors per series to the workspace (chunks of RK
  * steps, at most 4 GB at a time; CDE_WIDE_SCRATCH_BYTES in the environment overrides the bound) and a split-K MFMA
  * reduction adds each chunk up.  That chunk loop runs on the host and takes its segment bounds from `seg_off_host`.
+ * Affine fields (act == CDE_ACT_NONE) on the 32 x 8 tiles: f and a^T df/dz are evaluated from the shared Jacobian
+ * J = sum_c dX_c W_c (one GEMM instead of two, K3j / the chain waves of the SPLIT variant) -- a reassociation of the same
+ * sums, same tolerances against the reference.  CDE_K3_FORM=product in the environment selects the two-GEMM kernels
+ * (read at every call; for tests and comparisons).
  * No entry point of this library synchronises a stream or copies device memory to the host: every call only queues
  * work on `stream` and can be captured into a hipGraph (tests: test_solver_calls_are_graph_capturable).
  * ------------------------------------------------------------------------------------------- */
