@@ -55,6 +55,11 @@ int launch_adjoint_wide(const void*, const void*, int64_t, int, const void*, con
                         const void*, int64_t, const int64_t*, int64_t, void*, void*, void*, int64_t, int64_t, int64_t,
                         const int64_t*, const void*, void*, hipStream_t);
 
+// from rk4_mfma.hip
+template <typename TT>
+int launch_adjoint_jacobian_bx(const void*, const void*, int64_t, int, const void*, const void*, const void*, const void*,
+                               const void*, const int64_t*, int64_t, void*, void*, void*, int64_t, int64_t, int64_t,
+                               const int64_t*, const void*, float*, hipStream_t);
 // from rk4_bf16x3.hip
 template <typename TT>
 int launch_forward_bf16x3(const void*, const void*, int64_t, int, const void*, const void*, const void*, const void*, int64_t,
@@ -175,6 +180,13 @@ static int adjoint_typed(const void* coeffs, const void* knots, int64_t n_interv
     void* sfrac = (unsigned char*)workspace + off_frac_b;
     rc = fill_stage_table<T, TT>(knots, n_intervals, sgrid, n_steps_b, 1, sidx, sfrac, s);
     if (rc != CDE_OK) return rc;
+    // the reverse sweep: K3j with its J rows on the bf16 pipe (rk4_mfma.hip); CDE_K3_FORM=product keeps K3b (three GEMMs,
+    // two of them on the bf16 pipe)
+    const char* form = getenv("CDE_K3_FORM");
+    if (!(form && form[0] == 'p'))
+      return launch_adjoint_jacobian_bx<TT>(coeffs, knots, n_intervals, degree, W, bias, z_saved, grad_out, sgrid, seg_off,
+                                            n_out, grad_z0, grad_W, grad_b, B, C, H, sidx, sfrac,
+                                            (float*)((unsigned char*)workspace + off_part_b), s);
     return launch_adjoint_bf16x3<TT>(coeffs, knots, n_intervals, degree, W, bias, z_saved, grad_out, sgrid, seg_off, n_out,
                                      grad_z0, grad_W, grad_b, B, C, H, sidx, sfrac,
                                      (float*)((unsigned char*)workspace + off_part_b), s);

@@ -432,7 +432,37 @@ __device__ __forceinline__ float wj_image(const float* __restrict__ W, const flo
   return bias[k * d.C + c];
 }
 
-template <typename TT, int DEGREE>
+// BX (variant "bf16x3"): J's GEMM on the bf16 matrix pipe at float32 accuracy.  Every float32 operand is split into three
+// bf16 pieces (x = x1 + x2 + x3) and the product takes the six piece products with i + j <= 4 (csrc/rk4_bf16x3.hip).  J's
+// GEMM has K = 8 channels, a bf16 MFMA K = 16: the second half of K carries a second PIECE of dX, so three
+// v_mfma_f32_32x32x16_bf16 (8 passes each) replace the four 16-pass f32 MFMAs of a row:
+//     W1 (d1 | d2)  +  W2 (d1 | d2)  +  (W1 | W3) (d3 | d1)          (A | B: lower | upper half of the K index)
+// The weight pieces are split once per launch into the LDS image, dX's eight values once per stage.
+using bf16x8j = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4j = __attribute__((ext_vector_type(4))) unsigned;
+constexpr int WJB_U4 = WJ_ROWS * 3 * 64;                 // 16-byte entries: [row][MFMA][lane]
+constexpr int WJB_FLOATS = WJB_U4 * 4;
+__device__ __forceinline__ void split3j(float x, __bf16& a, __bf16& b, __bf16& c) {
+  a = (__bf16)x;
+  const float r1 = x - (float)a;
+  b = (__bf16)r1;
+  c = (__bf16)(r1 - (float)b);
+}
+__device__ __forceinline__ u32x4j wjb_image(const float* __restrict__ W, const float* __restrict__ bias, int h, int m, int l, Dims d) {
+  const int k = rho(l & 31), upper = l >> 5;
+  bf16x8j out;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    float w = 0.f;
+    if (c < d.C && k < d.H) w = h < MH ? (h < d.H ? W[(h * d.C + c) * d.H + k] : 0.f) : bias[k * d.C + c];
+    __bf16 p1, p2, p3;
+    split3j(w, p1, p2, p3);
+    out[c] = m == 0 ? p1 : m == 1 ? p2 : (upper ? p3 : p1);
+  }
+  return __builtin_bit_cast(u32x4j, out);
+}
+
+template <typename TT, int DEGREE, bool BX = false>
 __global__ __launch_bounds__(256, 1) void rk4_adjoint_jacobian(
     const float* __restrict__ coeffs, const float* __restrict__ knots, int64_t n_intervals,
     const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ z_saved,
@@ -441,12 +471,17 @@ __global__ __launch_bounds__(256, 1) void rk4_adjoint_jacobian(
     const int64_t* __restrict__ stage_index, const float* __restrict__ stage_frac, Dims dims) {
   const int Hr = dims.H, Cr = dims.C;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  for (int e = threadIdx.x; e < WJ_FLOATS; e += 256) lds[e] = wj_image(W, bias, e >> 8, e & 3, (e >> 2) & 63, dims);
+  if constexpr (BX) {
+    u32x4j* img = reinterpret_cast<u32x4j*>(lds);
+    for (int e = threadIdx.x; e < WJB_U4; e += 256) img[e] = wjb_image(W, bias, e / 192, (e >> 6) % 3, e & 63, dims);
+  } else {
+    for (int e = threadIdx.x; e < WJ_FLOATS; e += 256) lds[e] = wj_image(W, bias, e >> 8, e & 3, (e >> 2) & 63, dims);
+  }
   __syncthreads();
   const float4* wj = reinterpret_cast<const float4*>(lds);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 31, half = lane >> 5;
-  float* scr_y = lds + WJ_FLOATS + wave * SCR_FLOATS;
+  float* scr_y = lds + (BX ? WJB_FLOATS : WJ_FLOATS) + wave * SCR_FLOATS;
 
   const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
   float* my_partial = partial + tile * PARTIAL_FLOATS;
@@ -537,13 +572,45 @@ __global__ __launch_bounds__(256, 1) void rk4_adjoint_jacobian(
             // the 4 MFMAs of row h + 1 have ISSUED, and those queue behind row h in the same in-order pipe (each waits
             // for its predecessor's accumulator), so row h has long been written; the empty asm on J after the next
             // issue pins that order.  The last issue of a stage (bias rows) is followed by explicit wait states.
-            auto issue = [&](f32x16& J, const float4& a) {
+            // (BX) B operands: the three bf16 pieces of this lane's 8 channel values; lower half-lanes feed d1 (rows 1, 2)
+            // and d3 (row 3), upper ones d2 and d1
+            u32x4j b01 = {0u, 0u, 0u, 0u}, b2 = b01;
+            if constexpr (BX) {
+              bf16x8j q01, q2;
+#pragma unroll
+              for (int c = 0; c < 8; ++c) {
+                __bf16 p1, p2, p3;
+                split3j(dX[c], p1, p2, p3);
+                q01[c] = half ? p2 : p1;
+                q2[c] = half ? p1 : p3;
+              }
+              b01 = __builtin_bit_cast(u32x4j, q01);
+              b2 = __builtin_bit_cast(u32x4j, q2);
+            }
+            const u32x4j* wpb = reinterpret_cast<const u32x4j*>(wj) + lane + opaque;
+            struct RowImage { float4 a; u32x4j m0, m1, m2; };
+            auto image = [&](int h) {
+              RowImage r;
+              if constexpr (BX) { r.m0 = wpb[(3 * h) * 64]; r.m1 = wpb[(3 * h + 1) * 64]; r.m2 = wpb[(3 * h + 2) * 64]; }
+              else r.a = wp[h * 64];
+              return r;
+            };
+            auto issue = [&](f32x16& J, const RowImage& a) {
               __builtin_amdgcn_sched_barrier(0);           // everything that still reads the old J stays above
-              asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %5, 0\n\t"
-                           "v_mfma_f32_32x32x2_f32 %0, %2, %6, %0\n\t"
-                           "v_mfma_f32_32x32x2_f32 %0, %3, %7, %0\n\t"
-                           "v_mfma_f32_32x32x2_f32 %0, %4, %8, %0"
-                           : "=&v"(J) : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(bs0), "v"(bs1), "v"(bs2), "v"(bs3));
+              if constexpr (BX) {
+                asm volatile("s_nop 1\n\t"                                     // (operands may be fresh VALU results)
+                             "v_mfma_f32_32x32x16_bf16 %0, %3, %5, 0\n\t"      // smallest terms first
+                             "v_mfma_f32_32x32x16_bf16 %0, %2, %4, %0\n\t"
+                             "v_mfma_f32_32x32x16_bf16 %0, %1, %4, %0"
+                             : "=&v"(J) : "v"(a.m0), "v"(a.m1), "v"(a.m2), "v"(b01), "v"(b2));
+              } else {
+                asm volatile("s_nop 1\n\t"                                     // (operands may be fresh VALU results)
+                             "v_mfma_f32_32x32x2_f32 %0, %1, %5, 0\n\t"
+                             "v_mfma_f32_32x32x2_f32 %0, %2, %6, %0\n\t"
+                             "v_mfma_f32_32x32x2_f32 %0, %3, %7, %0\n\t"
+                             "v_mfma_f32_32x32x2_f32 %0, %4, %8, %0"
+                             : "=&v"(J) : "v"(a.a.x), "v"(a.a.y), "v"(a.a.z), "v"(a.a.w), "v"(bs0), "v"(bs1), "v"(bs2), "v"(bs3));
+              }
               __builtin_amdgcn_sched_barrier(0);
             };
             // the two uses of a row: this half-lane's share of f_h = J[h][.] . z, and va += a_h J[h][.]
@@ -565,18 +632,18 @@ __global__ __launch_bounds__(256, 1) void rk4_adjoint_jacobian(
               return p2[0] + p2[1];
             };
             f32x16 Je, Jo;                                 // rows 2r / 2r + 1 in flight
-            float4 a_cur = wp[0], a_nxt = wp[64];
+            RowImage a_cur = image(0), a_nxt = image(1);
             issue(Je, a_cur);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              a_cur = wp[(2 * r + 2) * 64];                // image of row 2r + 2 (r = 15: the bias rows)
+              a_cur = image(2 * r + 2);                    // image of row 2r + 2 (r = 15: the bias rows)
               issue(Jo, a_nxt);
               asm volatile("" : "+v"(Je));
               // a of units 2r, 2r + 1 in both half-lanes (the lower half-lanes own unit 2r, the upper ones 2r + 1)
               float ae = ast[r], ao = ast[r];
               swap32(ae, ao);
               float X = consume(Je, ae);
-              if (r < 15) a_nxt = wp[(2 * r + 3) * 64];
+              if (r < 15) a_nxt = image(2 * r + 3);
               issue(Je, a_cur);
               asm volatile("" : "+v"(Jo));
               float Y = consume(Jo, ao);
@@ -1149,6 +1216,40 @@ int launch_adjoint_mfma(const void* coeffs, const void* knots, int64_t n_interva
   if (rc != CDE_OK) return rc;
   return launch_reduce_partials(partial, (B + 31) / 32, grad_W, grad_b, (int)H, (int)C, s);
 }
+
+// variant "bf16x3": K3j with its J rows on the bf16 pipe (three-piece operands)
+template <typename TT>
+int launch_adjoint_jacobian_bx(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
+                               const void* bias, const void* z_saved, const void* grad_out, const void* sgrid,
+                               const int64_t* seg_off, int64_t n_out, void* grad_z0, void* grad_W, void* grad_b, int64_t B,
+                               int64_t C, int64_t H, const int64_t* stage_index, const void* stage_frac, float* partial,
+                               hipStream_t s) {
+  const Dims dims{(int)H, (int)C};
+  const unsigned blocks = (unsigned)((B + 127) / 128);
+  const size_t lds = (size_t)(WJB_FLOATS + 4 * SCR_FLOATS) * sizeof(float);
+#define CDE_ADJ_BX(D)                                                                                                \
+  do {                                                                                                               \
+    (void)hipFuncSetAttribute((const void*)rk4_adjoint_jacobian<TT, D, true>,                                        \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
+    rk4_adjoint_jacobian<TT, D, true><<<blocks, 256, lds, s>>>(                                                      \
+        (const float*)coeffs, (const float*)knots, n_intervals, (const float*)W, (const float*)bias,                 \
+        (const float*)z_saved, (const float*)grad_out, (const TT*)sgrid, seg_off, n_out, (float*)grad_z0, partial,   \
+        B, stage_index, (const float*)stage_frac, dims);                                                             \
+  } while (0)
+  if (degree == CDE_PATH_CUBIC) CDE_ADJ_BX(CDE_PATH_CUBIC);
+  else if (degree == CDE_PATH_LINEAR) CDE_ADJ_BX(CDE_PATH_LINEAR);
+  else return CDE_ERR_UNSUPPORTED;
+#undef CDE_ADJ_BX
+  const int rc = check_launch();
+  if (rc != CDE_OK) return rc;
+  return launch_reduce_partials(partial, (B + 31) / 32, grad_W, grad_b, (int)H, (int)C, s);
+}
+template int launch_adjoint_jacobian_bx<float>(const void*, const void*, int64_t, int, const void*, const void*, const void*,
+                                               const void*, const void*, const int64_t*, int64_t, void*, void*, void*,
+                                               int64_t, int64_t, int64_t, const int64_t*, const void*, float*, hipStream_t);
+template int launch_adjoint_jacobian_bx<double>(const void*, const void*, int64_t, int, const void*, const void*, const void*,
+                                                const void*, const void*, const int64_t*, int64_t, void*, void*, void*,
+                                                int64_t, int64_t, int64_t, const int64_t*, const void*, float*, hipStream_t);
 
 template int launch_forward_mfma<float>(const void*, const void*, int64_t, int, const void*, const void*, int,
                                         const void*, const void*, int64_t, const void*, int64_t, void*, int64_t, int64_t,
