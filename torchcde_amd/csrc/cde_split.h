@@ -147,6 +147,40 @@ struct Wide {
   static constexpr int GC = HP * CT;                             // columns of a G row
 };
 
+// half-wave / 16-lane-row exchanges (shared-Jacobian chain waves: rk4_split.hip, dopri5_adjoint.hip)
+__device__ __forceinline__ void swap32s(float& x, float& y) {      // x[lanes 32..63] <-> y[lanes 0..31]
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  x = __uint_as_float(r[0]);
+  y = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap16s(float& x, float& y) {      // x[odd 16-lane rows] <-> y[even 16-lane rows]
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  x = __uint_as_float(r[0]);
+  y = __uint_as_float(r[1]);
+}
+
+// A image of the Jacobian rows wave w owns (shared-Jacobian form, affine fields): tile t = 2 hi + kh, MFMA row i = 4 q' + r
+// <-> J[h = 8w + hi][k = 4 (4 kh + r) + q'], K step st <-> channel 4 st + q; and the bias rows of the lane's two units
+__device__ __forceinline__ void spl_load_wj(const float* __restrict__ W, const float* __restrict__ bias, int w, int n, int q,
+                                            Dims d, float (&wj)[16][2], f32x2 (&bja)[4], f32x2 (&bjb)[4]) {
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int h = 8 * w + (t >> 1), k = 4 * (4 * (t & 1) + (n & 3)) + (n >> 2);
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const int c = 4 * st + q;
+      wj[t][st] = (h < d.H && c < d.C && k < d.H) ? W[(h * d.C + c) * d.H + k] : 0.f;
+    }
+  }
+  const int ua = 8 * w + q, ub = ua + 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    auto bv = [&](int u, int c) { return (u < d.H && c < d.C) ? bias[u * d.C + c] : 0.f; };
+    bja[j] = f32x2{bv(ua, 2 * j), bv(ua, 2 * j + 1)};
+    bjb[j] = f32x2{bv(ub, 2 * j), bv(ub, 2 * j + 1)};
+  }
+}
+
 // workgroup barrier that waits for this wave's LDS traffic only (no vmcnt: global loads stay in flight)
 __device__ __forceinline__ void spl_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");

@@ -129,11 +129,21 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
   const KnotWindow<float> window = knot_window(g.knots, g.n_intervals, phase_in == 0 ? (int64_t)-1 : (int64_t)c.slot);
   // chain waves: weights into registers (L2 hits, but 80 scattered loads per lane whose latency used to sit between the
   // controller and the first stage)
+  // JC (affine field, piecewise-linear control): the chain waves work from the Jacobian J = sum_c dX_c W_c of THEIR rows
+  // (the shared-Jacobian form of rk4_split.hip) -- and dX is constant inside a knot interval, so J is formed once per
+  // tile and interval (32 MFMAs) and every further stage in that interval costs the chain wave no MFMA at all: with
+  // jump_t on the knots (steps never cross one) that is every stage but the first of a tile.
+  constexpr bool JC = DEGREE == CDE_PATH_LINEAR && ACT == CDE_ACT_NONE;
   float wy[4][8], wv[2][16];
   f32x4 by[4];
+  float wj[JC ? 16 : 1][2];
+  f32x2 bja[4], bjb[4];
   if (!helper) {
-    spl_load_wy(g.W, g.bias, w, n, q, g.dims, wy, by);
-    spl_load_wv(g.W, w, n, q, g.dims, wv);
+    if constexpr (JC) spl_load_wj(g.W, g.bias, w, n, q, g.dims, wj, bja, bjb);
+    else {
+      spl_load_wy(g.W, g.bias, w, n, q, g.dims, wy, by);
+      spl_load_wv(g.W, w, n, q, g.dims, wv);
+    }
   }
   // helper wave 0: one dword of the first and the last 16 bytes of the control rows the first tile will most likely read
   // (the previous attempt's interval, or the one before it in reversed time) pulls their lines from HBM into this XCD's L2
@@ -416,6 +426,9 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
       spl_barrier();
       float kya[7], kyb[7], kaa[7], kab[7];
       float ysa = y0a, ysb = y0b, asa = a0a, asb = a0b;          // state handed to the current stage
+      f32x4 Jr[JC ? 16 : 1];                                     // JC: this wave's Jacobian rows for the tile's series ...
+      int jc_idx = -1;                                           // ... valid for this knot interval
+      float cba = 0.f, cbb = 0.f;
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
         if (i < ns) {
@@ -434,6 +447,81 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
           }
           const float zs[8] = {z03.x, z03.y, z03.z, z03.w, z47.x, z47.y, z47.z, z47.w};
           const float dX[MC] = {d03.x, d03.y, d03.z, d03.w, d47.x, d47.y, d47.z, d47.w};
+          f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+          if constexpr (JC) {
+            float* gwp = gw_ + gpar * 4 * SPL_GT;
+            // ---- g = a (x) dX for the helper waves' images (the lane's two units, all channels)
+#pragma unroll
+            for (int T = 0; T < 4; ++T) {
+              const float aown = (T >> 1) ? asb : asa;
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                const f32x2 gq2 = f32x2{dX[4 * (T & 1) + 2 * j], dX[4 * (T & 1) + 2 * j + 1]} * aown;
+                gwp[(T * 16 + 2 * j) * SPL_TROW] = gq2[0];
+                gwp[(T * 16 + 2 * j + 1) * SPL_TROW] = gq2[1];
+              }
+            }
+            // ---- the Jacobian rows of this wave for the tile's series: new only when the knot interval changed
+            if (sidx[i] != jc_idx) {
+              jc_idx = sidx[i];
+              const float bq0 = q == 0 ? dX[0] : q == 1 ? dX[1] : q == 2 ? dX[2] : dX[3];
+              const float bq1 = q == 0 ? dX[4] : q == 1 ? dX[5] : q == 2 ? dX[6] : dX[7];
+              const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+              for (int t = 0; t < 16; ++t) {
+                f32x4 jt = mfma16(wj[t][0], bq0, zero);
+                Jr[t] = mfma16(wj[t][1], bq1, jt);
+              }
+              f32x2 fb2 = bja[0] * f32x2{dX[0], dX[1]}, fb3 = bjb[0] * f32x2{dX[0], dX[1]};
+#pragma unroll
+              for (int j = 1; j < 4; ++j) {
+                fb2 = __builtin_elementwise_fma(bja[j], f32x2{dX[2 * j], dX[2 * j + 1]}, fb2);
+                fb3 = __builtin_elementwise_fma(bjb[j], f32x2{dX[2 * j], dX[2 * j + 1]}, fb3);
+              }
+              cba = fb2[0] + fb2[1]; cbb = fb3[0] + fb3[1];        // (b dX) of the lane's two units
+            }
+            // ---- a of the wave's 8 units in every lane quarter
+            float a8[8];
+            {
+              float ea = asa, oa = asa, eb = asb, ob = asb;
+              swap16s(ea, oa);
+              swap16s(eb, ob);
+              float e0 = ea, e2 = ea, o1 = oa, o3 = oa, e4 = eb, e6 = eb, o5 = ob, o7 = ob;
+              swap32s(e0, e2); swap32s(o1, o3); swap32s(e4, e6); swap32s(o5, o7);
+              a8[0] = e0; a8[1] = o1; a8[2] = e2; a8[3] = o3; a8[4] = e4; a8[5] = o5; a8[6] = e6; a8[7] = o7;
+            }
+            // ---- f_h = J[h][.] . z (this quarter's share) and a's slope sum_h a_h J[h][.], from the cached rows
+            const f32x2 z01 = {zs[0], zs[1]}, z23 = {zs[2], zs[3]}, z45 = {zs[4], zs[5]}, z67 = {zs[6], zs[7]};
+            f32x2 va01 = {0.f, 0.f}, va23 = va01, vb01 = va01, vb23 = va01;
+            float p[8];
+#pragma unroll
+            for (int hi = 0; hi < 8; ++hi) {
+              const f32x4 j0 = Jr[2 * hi], j1 = Jr[2 * hi + 1];
+              const f32x2 ah = {a8[hi], a8[hi]};
+              f32x2 pp = f32x2{j0[0], j0[1]} * z01;
+              pp = __builtin_elementwise_fma(f32x2{j0[2], j0[3]}, z23, pp);
+              pp = __builtin_elementwise_fma(f32x2{j1[0], j1[1]}, z45, pp);
+              pp = __builtin_elementwise_fma(f32x2{j1[2], j1[3]}, z67, pp);
+              p[hi] = pp[0] + pp[1];
+              va01 = __builtin_elementwise_fma(f32x2{j0[0], j0[1]}, ah, va01);
+              va23 = __builtin_elementwise_fma(f32x2{j0[2], j0[3]}, ah, va23);
+              vb01 = __builtin_elementwise_fma(f32x2{j1[0], j1[1]}, ah, vb01);
+              vb23 = __builtin_elementwise_fma(f32x2{j1[2], j1[3]}, ah, vb23);
+            }
+            v0 = f32x4{va01[0], va01[1], va23[0], va23[1]};
+            v1 = f32x4{vb01[0], vb01[1], vb23[0], vb23[1]};
+            swap32s(p[0], p[2]); swap32s(p[1], p[3]); swap32s(p[4], p[6]); swap32s(p[5], p[7]);
+            float s0 = p[0] + p[2], s1 = p[1] + p[3], s4 = p[4] + p[6], s5 = p[5] + p[7];
+            swap16s(s0, s1); swap16s(s4, s5);
+            kya[i] = -((s0 + s1) + cba); kyb[i] = -((s4 + s5) + cbb);          // reverse time: dy/ds = -f
+            if (i + 1 < ns) {
+              float sa = 0.f, sb = 0.f;
+#pragma unroll
+              for (int j = 0; j <= i; ++j) { sa = __builtin_fmaf(bc[i + 1][j], kya[j], sa); sb = __builtin_fmaf(bc[i + 1][j], kyb[j], sb); }
+              ysa = y0a + sa; ysb = y0b + sb;
+              publish(par ^ 1, ysa, ysb);
+            }
+          } else {
           f32x4 yt[4] = {by[0], by[1], by[2], by[3]};
 #pragma unroll
           for (int s = 0; s < 8; ++s) {
@@ -489,7 +577,6 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
             publish(par ^ 1, ysa, ysb);
           }
           CDE_STAMP_IF(tile_no == 1 && i == 3, 17);
-          f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
 #pragma unroll
           for (int sp = 0; sp < 16; ++sp) {
             const float gv = gq[2 * (sp >> 3) + ((sp >> 2) & 1)][(sp >> 1) & 1][sp & 1];
@@ -499,6 +586,7 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
 #ifdef CDE_PHASE_TRACE
           if (tile_no == 1 && i == 3) { asm volatile("s_nop 0" : "+v"(v0), "+v"(v1)); CDE_STAMP(18); }
 #endif
+          }
           float* vwp = vw + (par ^ 1) * SPL_VA;
           *reinterpret_cast<float2*>(vwp) = make_float2(v0[0], v0[1]);
           *reinterpret_cast<float2*>(vwp + 64 * SPL_VROW) = make_float2(v0[2], v0[3]);

@@ -194,16 +194,6 @@ constexpr int SPL8_LDS_FLOATS = 2 * SPL_ZBUF + 2 * SPL_ZT + 2 * SPL_VA + 2 * SPL
 // in registers as the Y product's B operand (s = 4 kh + r).  f_h = J[h][.] . z is completed over the four lane quarters by
 // two half-/row-swap rounds; a's slope sum_h a_h J[h][k] lands in the (tile kh, register r) pattern of the old va tiles, so
 // the cross-wave exchange through vab is unchanged.  64 MFMAs per SIMD and stage instead of 96.
-__device__ __forceinline__ void swap32s(float& x, float& y) {      // x[lanes 32..63] <-> y[lanes 0..31]
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-  x = __uint_as_float(r[0]);
-  y = __uint_as_float(r[1]);
-}
-__device__ __forceinline__ void swap16s(float& x, float& y) {      // x[odd 16-lane rows] <-> y[even 16-lane rows]
-  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-  x = __uint_as_float(r[0]);
-  y = __uint_as_float(r[1]);
-}
 
 template <typename TT, int DEGREE, int ACT, bool JF = false>
 __global__ __launch_bounds__(512, 1) void rk4_adjoint_split8(
