@@ -38,6 +38,7 @@ NAMES = {
 
 
 def read_ring(which):
+    _lib.build()                                      # the instrumented library (a no-op when it is up to date)
     lib = _lib.load()
     fn = getattr(lib, "cde_debug_%s_phase_trace" % which)
     fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]
@@ -103,6 +104,7 @@ def report_stage(ring, n_blocks):
 
 
 def main():
+    _lib.build()
     which = sys.argv[1] if len(sys.argv) > 1 else "k4"
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
     dev = torch.device("cuda", 0)
