@@ -30,13 +30,44 @@ __device__ __forceinline__ void stream_store4(float* p, float a, float b, float 
 //     Z  [36]   z | 1 | 0 0 0                      G1 [128]  dL/dY1
 // (the "1" columns are written once by the host; dW2 | db2 = G2^T U, dW1 | db1 = G1^T Z).  The body is K3m's (same
 // MFMA order, same LDS reads); TGRAD adds kt = a . (F(z) d2X/dt2), the slope of vjp_t (cde_dopri_adj.h).
-template <int ACT, int CT, bool TGRAD>
+// SPLIT (K4am on small batches): the four waves of a workgroup evaluate the SAME 16 series.  Everything cheap is done by
+// all of them redundantly and bit-identically (layer 1, dL/dY1, va, the RK bookkeeping around this call); the expensive
+// middle -- layer 2, its activation, dL/dY2 and gu += W2^T dL/dY2 -- is split by unit group: wave `pw` takes the groups
+// P with P / (NP / 4) == pw, streams their G2 rows, and the four partial gu (and the f / kt entries each wave produced)
+// are added up in a fixed wave order through a small LDS window `xbuf` (4 waves x 64 lanes x 9 floats, five rounds), so
+// every wave continues with the same numbers.  384 instead of 1152 MFMAs per wave and evaluation.
+//     xchg: all-reduce 8 (+1) floats per lane over the workgroup's four waves
+__device__ __forceinline__ void mlp_split_allreduce(float* xbuf, int pw, int lane, f32x4& a, f32x4& b, float* extra) {
+  float* slot = xbuf + (pw * 64 + lane) * 9;
+  slot[0] = a[0]; slot[1] = a[1]; slot[2] = a[2]; slot[3] = a[3];
+  slot[4] = b[0]; slot[5] = b[1]; slot[6] = b[2]; slot[7] = b[3];
+  if (extra) slot[8] = *extra;
+  __syncthreads();
+  float s[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) s[i] = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {                                     // the same order in every wave
+    const float* src = xbuf + (w * 64 + lane) * 9;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] += src[i];
+    if (extra) s[8] += src[8];
+  }
+  a = f32x4{s[0], s[1], s[2], s[3]};
+  b = f32x4{s[4], s[5], s[6], s[7]};
+  if (extra) *extra = s[8];
+  __syncthreads();                                                  // the window is free again
+}
+
+template <int ACT, int CT, bool TGRAD, bool SPLIT = false>
 __device__ __forceinline__ void mlp_adjoint_eval(const float* lds_base, const float4* w1t_base, int lane, int n, int q,
                                                  int w2y_off, const int (&w2g_off)[4], const float (&zs)[8],
                                                  const float (&as)[8], const float (&dX)[CT], const float (&d2X)[CT],
                                                  bool stream, float* urow, float* zrow, float* g2row, float* g1row, int Hr,
-                                                 f32x4& fa, f32x4& fb, f32x4& va, f32x4& vb, float& kt) {
+                                                 f32x4& fa, f32x4& fb, f32x4& va, f32x4& vb, float& kt, int pw = 0,
+                                                 float* xbuf = nullptr) {
   constexpr int NB = CT / 4, NP = 16 / NB;      // channel blocks per unit group, unit groups (of 4 hidden units)
+  const bool writer = !SPLIT || pw == 0;        // the wave that streams the factor rows every wave holds (U, Z, G1)
   int opaque = 0;                                                // keeps the LDS reads inside the evaluation
   asm volatile("" : "+v"(opaque));
   const float4* w1 = reinterpret_cast<const float4*>(lds_base) + lane + opaque;
@@ -67,7 +98,7 @@ __device__ __forceinline__ void mlp_adjoint_eval(const float* lds_base, const fl
       mask |= (y1[r] > 0.f ? 1u : 0u) << (8 * TP + 4 + r);
     }
   }
-  if (stream) {
+  if (stream && writer) {
 #pragma unroll
     for (int T1 = 0; T1 < 8; ++T1) stream_store4(urow + 16 * T1, u[4 * T1], u[4 * T1 + 1], u[4 * T1 + 2], u[4 * T1 + 3]);
 #pragma unroll
@@ -83,6 +114,7 @@ __device__ __forceinline__ void mlp_adjoint_eval(const float* lds_base, const fl
   kt = 0.f;
 #pragma unroll
   for (int P = 0; P < NP; ++P) {                                 // unit group P: 4 hidden units x CT channels = NB tiles
+    if (SPLIT && P / (NP / 4) != pw) continue;                   // (wave-uniform: another wave's group)
     f32x4 y[NB];
     const float* tp_[NB];
 #pragma unroll
@@ -138,11 +170,19 @@ __device__ __forceinline__ void mlp_adjoint_eval(const float* lds_base, const fl
   }
 
   __builtin_amdgcn_sched_barrier(0);
+  if constexpr (SPLIT) {
+    // ---- the four waves' shares of gu, f and kt meet: afterwards every wave holds the complete values
+    mlp_split_allreduce(xbuf, pw, lane, gu[0], gu[1], nullptr);
+    mlp_split_allreduce(xbuf, pw, lane, gu[2], gu[3], nullptr);
+    mlp_split_allreduce(xbuf, pw, lane, gu[4], gu[5], nullptr);
+    mlp_split_allreduce(xbuf, pw, lane, gu[6], gu[7], nullptr);
+    mlp_split_allreduce(xbuf, pw, lane, fa, fb, &kt);
+  }
   // ---- dL/dY1 = gu * relu'(pre1);  va = W1^T dL/dY1
   float g1[32];
 #pragma unroll
   for (int s2 = 0; s2 < 32; ++s2) g1[s2] = (mask >> s2) & 1u ? gu[s2 >> 2][s2 & 3] : 0.f;
-  if (stream) {
+  if (stream && writer) {
 #pragma unroll
     for (int T1 = 0; T1 < 8; ++T1)
       stream_store4(g1row + 16 * T1, g1[4 * T1], g1[4 * T1 + 1], g1[4 * T1 + 2], g1[4 * T1 + 3]);

@@ -33,6 +33,7 @@ constexpr int MADJ_P2 = 256 * 129, MADJ_P1 = 128 * 33;          // elements of a
 constexpr int MADJ_ELEMS = MADJ_P2 + MADJ_P1;
 constexpr int MADJ_RBLOCKS = (MADJ_ELEMS + 31) / 32;
 constexpr int MADJ_MAX_SPS = 40;                 // slabs per stage of the factor reduction
+constexpr int64_t MADJ_SPLIT_MAX_TILES = 384;    // batches up to 6144 series: four waves per tile (K4am's split form)
 constexpr int MADJ_NSUM = ADJ_NS + 2 * ADJ_MAX_PT;
 __host__ __device__ constexpr int madj_slot(int stage) { return stage == 0 ? 0 : stage - 1; }      // stage 1 is never stored
 
@@ -53,8 +54,13 @@ struct MlpAdjArgs {
   int n_wg_max;
 };
 
-template <int DEGREE, int ACT, int CT, int NWAVE>
+// SPLIT (small batches: fewer tiles than SIMDs): the workgroup's four waves share ONE tile and split the middle of every
+// evaluation between them (cde_mlp_adj.h: mlp_adjoint_eval<..., SPLIT>); each wave keeps its own copy of the slope ring,
+// wave 0 alone stores state, streams the shared factor rows and contributes to the error sums.
+constexpr int MADJ_XBUF_FLOATS = 4 * 64 * 9;
+template <int DEGREE, int ACT, int CT, int NWAVE, bool SPLIT = false>
 __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adjoint_attempt(MlpAdjArgs g, int parity) {
+  static_assert(!SPLIT || NWAVE == 4, "the split form is four waves per tile");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int p = parity, p2 = parity ^ 1;
@@ -70,6 +76,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
     for (int i = tid; i < ADJ_LDS_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
   }
   double* red = reinterpret_cast<double*>(lds + ADJ_LDS_FLOATS);
+  float* xbuf = lds + ADJ_LDS_FLOATS + 2 * MADJ_NSUM * 8;          // (behind the 16 x 8 doubles of `red`)
   const int Hr = g.dims.H, Cr = g.dims.C;
   const int lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, q = lane >> 4;
@@ -142,7 +149,9 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
   }
 
   double acc[ADJ_NS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  const int64_t tile = (int64_t)blockIdx.x * NWAVE + wave;
+  const int64_t tile = SPLIT ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * NWAVE + wave;
+  const int pw = SPLIT ? wave : 0;
+  const bool writer = !SPLIT || wave == 0;
   if (tile < g.n_tiles) {
     const int64_t series = tile * 16 + n;
     const bool valid = series < g.B;
@@ -159,11 +168,11 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
     f32x4 y0a = load_units4<4>(ysrc + sc * Hr, ua, Hr), y0b = load_units4<4>(ysrc + sc * Hr, ub, Hr);
     f32x4 a0a = load_units4<4>(asrc + sc * Hr, ua, Hr), a0b = load_units4<4>(asrc + sc * Hr, ub, Hr);
     if (!valid) { a0a = f32x4{0.f, 0.f, 0.f, 0.f}; a0b = a0a; }   // a == 0 stays 0: padded lanes contribute nothing
-    if (valid && mode != 3) {
+    if (valid && mode != 3 && writer) {
       store_units4<4>(Sq + 0 * BH + series * Hr, ua, Hr, y0a); store_units4<4>(Sq + 0 * BH + series * Hr, ub, Hr, y0b);
       store_units4<4>(Sq + 1 * BH + series * Hr, ua, Hr, a0a); store_units4<4>(Sq + 1 * BH + series * Hr, ub, Hr, a0b);
     }
-    float4* ring = reinterpret_cast<float4*>(g.slopes) + (tile * 7 * 4) * 64 + lane;      // [stage][4][64 lanes]
+    float4* ring = reinterpret_cast<float4*>(g.slopes) + ((SPLIT ? tile * 4 + pw : tile) * 7 * 4) * 64 + lane;      // [stage][4][64 lanes]
     float vtS = 0.f, vtE = 0.f;
 
 #pragma unroll
@@ -202,9 +211,10 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
       const int64_t out_row = (int64_t)(mode <= 1 ? i : madj_slot(i)) * g.rows_per_stage + series;
       f32x4 fa, fb, va, vb;
       float kt;
-      mlp_adjoint_eval<ACT, CT, DEGREE == CDE_PATH_CUBIC>(
+      mlp_adjoint_eval<ACT, CT, DEGREE == CDE_PATH_CUBIC, SPLIT>(
           lds, w1t_base, lane, n, q, w2y_off, w2g_off, zs, as, dX, d2X, stream, g.U + out_row * U_COLS + 4 * q,
-          g.Z + out_row * Z_COLS, g.G2 + out_row * G2_COLS + CT * q, g.G1 + out_row * G1_COLS + 4 * q, Hr, fa, fb, va, vb, kt);
+          g.Z + out_row * Z_COLS, g.G2 + out_row * G2_COLS + CT * q, g.G1 + out_row * G1_COLS + 4 * q, Hr, fa, fb, va, vb, kt,
+          pw, xbuf);
       if (DEGREE == CDE_PATH_CUBIC) { vtS = __builtin_fmaf(wS[i], kt, vtS); vtE = __builtin_fmaf(wE[i], kt, vtE); }
       // ---- reverse-time slopes dy/ds = -f, da/ds = +a^T df/dz into the ring
       ring[(i * 4 + 0) * 64] = make_float4(-fa[0], -fa[1], -fa[2], -fa[3]);
@@ -221,14 +231,14 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
     if (mode == 0) {
       const f32x4 sya = atol + abs4f(y0a) * rtol, syb = atol + abs4f(y0b) * rtol;       // Hairer's scale
       const f32x4 saa = atol + abs4f(a0a) * rtol, sab = atol + abs4f(a0b) * rtol;
-      if (valid) {
+      if (valid && writer) {
         acc[0] = sq4f(y0a / sya) + sq4f(y0b / syb); acc[1] = sq4f(a0a / saa) + sq4f(a0b / sab);
         acc[2] = sq4f(slope(0, 0) / sya) + sq4f(slope(0, 1) / syb); acc[3] = sq4f(slope(0, 2) / saa) + sq4f(slope(0, 3) / sab);
       }
     } else if (mode == 1) {
       const f32x4 sya = atol + abs4f(y0a) * rtol, syb = atol + abs4f(y0b) * rtol;
       const f32x4 saa = atol + abs4f(a0a) * rtol, sab = atol + abs4f(a0b) * rtol;
-      if (valid) {
+      if (valid && writer) {
         acc[0] = sq4f((slope(1, 0) - slope(0, 0)) / sya) + sq4f((slope(1, 1) - slope(0, 1)) / syb);
         acc[1] = sq4f((slope(1, 2) - slope(0, 2)) / saa) + sq4f((slope(1, 3) - slope(0, 3)) / sab);
       }
@@ -253,7 +263,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
       if (mode == 2) {
         const f32x4 tya = atol + rtol * max4f(abs4f(y0a), abs4f(y1a)), tyb = atol + rtol * max4f(abs4f(y0b), abs4f(y1b));
         const f32x4 taa = atol + rtol * max4f(abs4f(a0a), abs4f(a1a)), tab = atol + rtol * max4f(abs4f(a0b), abs4f(a1b));
-        if (valid) {
+        if (valid && writer) {
           acc[0] = sq4f(ey[0] / tya) + sq4f(ey[1] / tyb); acc[1] = sq4f(ea[0] / taa) + sq4f(ea[1] / tab);
           store_units4<4>(Sq + 2 * BH + series * Hr, ua, Hr, y1a); store_units4<4>(Sq + 2 * BH + series * Hr, ub, Hr, y1b);
           store_units4<4>(Sq + 3 * BH + series * Hr, ua, Hr, a1a); store_units4<4>(Sq + 3 * BH + series * Hr, ub, Hr, a1b);
@@ -273,13 +283,13 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
           xp = xp * x_end; total = total + xp * ca;
           return total;
         };
-        if (valid) {
+        if (valid && writer) {
           store_units4<4>(g.a_out + series * Hr, ua, Hr, dense(a0a, a1a, slope(0, 2), slope(6, 2), ma[0]));
           store_units4<4>(g.a_out + series * Hr, ub, Hr, dense(a0b, a1b, slope(0, 3), slope(6, 3), ma[1]));
         }
       }
     }
-    acc[4] = (double)vtS; acc[5] = (double)vtE;
+    if (writer) { acc[4] = (double)vtS; acc[5] = (double)vtE; }
   }
   // ---- publish this launch's partial sums
   block_total<ADJ_NS>(acc, red);
@@ -393,6 +403,7 @@ namespace {
 struct MadjLayout {
   int64_t n_tiles, rows_per_stage, rows_per_slab;
   int sps, nwave, n_wg;
+  bool split;
   size_t partial, pq, carry, image, state, G, prev, slopes, part2, part1, U, G2, G1, Z, trace, trace_all, total;
 };
 MadjLayout madj_layout(int64_t B, int64_t H) {
@@ -400,7 +411,9 @@ MadjLayout madj_layout(int64_t B, int64_t H) {
   MadjLayout L;
   L.n_tiles = (B + 15) / 16;
   L.nwave = L.n_tiles > 1024 ? 8 : 4;              // 16384 series fill the GPU's 1024 SIMDs with one wave each
-  L.n_wg = (int)((L.n_tiles + L.nwave - 1) / L.nwave);
+  // up to MADJ_SPLIT_MAX_TILES tiles (one per CU and a half): four waves per tile, the evaluation's middle split four ways
+  L.split = L.n_tiles <= MADJ_SPLIT_MAX_TILES && !getenv("CDE_K4AM_NO_SPLIT");
+  L.n_wg = L.split ? (int)L.n_tiles : (int)((L.n_tiles + L.nwave - 1) / L.nwave);
   int64_t sps = (B + 63) / 64;
   L.sps = (int)(sps < 1 ? 1 : sps > MADJ_MAX_SPS ? MADJ_MAX_SPS : sps);
   L.rows_per_slab = ((B + L.sps - 1) / L.sps + 15) / 16 * 16;
@@ -414,7 +427,7 @@ MadjLayout madj_layout(int64_t B, int64_t H) {
   L.G = L.state + m256((size_t)2 * 4 * B * H * sizeof(float));
   L.prev = L.G + m256((size_t)MADJ_ELEMS * sizeof(float));
   L.slopes = L.prev + m256((size_t)2 * MADJ_ELEMS * sizeof(float));
-  L.part2 = L.slopes + m256((size_t)L.n_tiles * 7 * 4 * 64 * 16);
+  L.part2 = L.slopes + m256((size_t)L.n_tiles * (L.split ? 4 : 1) * 7 * 4 * 64 * 16);
   L.part1 = L.part2 + m256((size_t)MADJ_SLOTS * L.sps * MADJ_P2 * sizeof(float));
   L.U = L.part1 + m256((size_t)MADJ_SLOTS * L.sps * MADJ_P1 * sizeof(float));
   L.G2 = L.U + m256(rows * U_COLS * sizeof(float));
@@ -502,14 +515,15 @@ extern "C" int cde_dopri5_adjoint_mlp_advance(const void* coeffs, const void* kn
   r.G = (float*)(base + L.G); r.prevS = (float*)(base + L.prev); r.pq = g.pq;
   r.partial = g.partial; r.n_wg = L.n_wg; r.n_wg_max = L.n_wg; r.carry = g.com.carry;
   r.rtol = (float)rtol; r.atol = (float)atol;
-  const size_t lds_bytes = (size_t)ADJ_LDS_FLOATS * sizeof(float) + (size_t)MADJ_NSUM * 8 * sizeof(double);
-#define CDE_MADJ_LAUNCH(D, A, CTV, NWV)                                                                              \
+  const size_t lds_bytes = (size_t)ADJ_LDS_FLOATS * sizeof(float) + (size_t)MADJ_NSUM * 8 * sizeof(double) +
+                           (L.split ? (size_t)MADJ_XBUF_FLOATS * sizeof(float) : 0);
+#define CDE_MADJ_LAUNCH(D, A, CTV, NWV, SPL)                                                                         \
   do {                                                                                                               \
-    (void)hipFuncSetAttribute((const void*)dopri5_mlp_adjoint_attempt<D, A, CTV, NWV>,                               \
+    (void)hipFuncSetAttribute((const void*)dopri5_mlp_adjoint_attempt<D, A, CTV, NWV, SPL>,                          \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                           \
     for (int64_t i = 0; i < n_launches; ++i) {                                                                       \
       const int parity = (int)((first_launch + i) & 1);                                                              \
-      dopri5_mlp_adjoint_attempt<D, A, CTV, NWV><<<L.n_wg, 64 * NWV, lds_bytes, s>>>(g, parity);                     \
+      dopri5_mlp_adjoint_attempt<D, A, CTV, NWV, SPL><<<L.n_wg, 64 * NWV, lds_bytes, s>>>(g, parity);                \
       const int rc = launch_mlp_adjoint_factor_reduce(g.G2, g.U, g.G1, g.Z, L.rows_per_stage, L.sps, L.rows_per_slab, \
                                                       (float*)(base + L.part2), (float*)(base + L.part1), base, parity, s); \
       if (rc != CDE_OK) return rc;                                                                                   \
@@ -518,7 +532,9 @@ extern "C" int cde_dopri5_adjoint_mlp_advance(const void* coeffs, const void* kn
   } while (0)
 #define CDE_MADJ_W(D, A, CTV)                                                                                        \
   do {                                                                                                               \
-    if (L.nwave == 8) CDE_MADJ_LAUNCH(D, A, CTV, 8); else CDE_MADJ_LAUNCH(D, A, CTV, 4);                             \
+    if (L.split) CDE_MADJ_LAUNCH(D, A, CTV, 4, true);                                                                \
+    else if (L.nwave == 8) CDE_MADJ_LAUNCH(D, A, CTV, 8, false);                                                     \
+    else CDE_MADJ_LAUNCH(D, A, CTV, 4, false);                                                                       \
   } while (0)
 #define CDE_MADJ(D, A)                                                                                               \
   do {                                                                                                               \
