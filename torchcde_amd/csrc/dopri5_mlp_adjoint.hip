@@ -33,7 +33,7 @@ constexpr int MADJ_P2 = 256 * 129, MADJ_P1 = 128 * 33;          // elements of a
 constexpr int MADJ_ELEMS = MADJ_P2 + MADJ_P1;
 constexpr int MADJ_RBLOCKS = (MADJ_ELEMS + 31) / 32;
 constexpr int MADJ_MAX_SPS = 40;                 // slabs per stage of the factor reduction
-constexpr int64_t MADJ_SPLIT_MAX_TILES = 384;    // batches up to 6144 series: four waves per tile (K4am's split form)
+constexpr int64_t MADJ_SPLIT_MAX_TILES = 256;    // batches up to 4096 series (one tile per CU): four waves per tile (K4am's split form)
 constexpr int MADJ_NSUM = ADJ_NS + 2 * ADJ_MAX_PT;
 __host__ __device__ constexpr int madj_slot(int stage) { return stage == 0 ? 0 : stage - 1; }      // stage 1 is never stored
 
@@ -411,7 +411,8 @@ MadjLayout madj_layout(int64_t B, int64_t H) {
   MadjLayout L;
   L.n_tiles = (B + 15) / 16;
   L.nwave = L.n_tiles > 1024 ? 8 : 4;              // 16384 series fill the GPU's 1024 SIMDs with one wave each
-  // up to MADJ_SPLIT_MAX_TILES tiles (one per CU and a half): four waves per tile, the evaluation's middle split four ways
+  // up to MADJ_SPLIT_MAX_TILES tiles (one workgroup per CU in a single round): four waves per tile, the evaluation's middle
+  // split four ways
   L.split = L.n_tiles <= MADJ_SPLIT_MAX_TILES && !getenv("CDE_K4AM_NO_SPLIT");
   L.n_wg = L.split ? (int)L.n_tiles : (int)((L.n_tiles + L.nwave - 1) / L.nwave);
   int64_t sps = (B + 63) / 64;
