@@ -415,8 +415,8 @@ MadjLayout madj_layout(int64_t B, int64_t H) {
   // split four ways
   L.split = L.n_tiles <= MADJ_SPLIT_MAX_TILES && !getenv("CDE_K4AM_NO_SPLIT");
   L.n_wg = L.split ? (int)L.n_tiles : (int)((L.n_tiles + L.nwave - 1) / L.nwave);
-  int64_t sps = (B + 63) / 64;
-  L.sps = (int)(sps < 1 ? 1 : sps > MADJ_MAX_SPS ? MADJ_MAX_SPS : sps);
+  int64_t sps = (B + 63) / 64;                     // (measured at 4096 series: 40 slabs 193 us per attempt, 16: 209, 6: 284;
+  L.sps = (int)(sps < 4 ? 4 : sps > MADJ_MAX_SPS ? MADJ_MAX_SPS : sps);        //  at 64 series: 4 slabs 138, 1: 146)
   L.rows_per_slab = ((B + L.sps - 1) / L.sps + 15) / 16 * 16;
   L.rows_per_stage = L.rows_per_slab * L.sps;
   const size_t rows = (size_t)MADJ_SLOTS * L.rows_per_stage;
