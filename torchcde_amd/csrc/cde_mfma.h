@@ -390,9 +390,12 @@ __device__ __forceinline__ void stage_mlp16(const float* __restrict__ W1, const 
 // img = staged images + nothing else; lane (n, q): za/zb = units q, 4+q, .., 28+q of series n.
 // CT = 8: 8 unit groups P of 2 tiles (4 units x 8 channels each); CT = 16: 4 unit groups of 4 tiles (4 units x 16
 // channels; units 16.. do not exist: zb is zero in, fb zero out).  Tile index T = (CT/4) P + tb in both cases.
-template <int ACT, int CT = MC>
+// SPLIT (small batches, dopri5 forward): the 8 waves of a workgroup evaluate the SAME 16 series -- layer 1 redundantly and
+// bit-identically, unit group P of layer 2 by wave P alone -- and gather the NP values of f through `xwin` (LDS, 8 x 64
+// floats): 128 instead of 576 MFMAs per wave and evaluation.
+template <int ACT, int CT = MC, bool SPLIT = false>
 __device__ __forceinline__ void field_mlp16(const float* img, int lane, int q, const f32x4& za, const f32x4& zb,
-                                            const float (&dX)[CT], f32x4& fa, f32x4& fb) {
+                                            const float (&dX)[CT], f32x4& fa, f32x4& fb, int pw = 0, float* xwin = nullptr) {
   constexpr int NB = CT / 4, NP = 16 / NB;
   int opaque = 0;                             // as in field_act16: keeps the LDS reads inside the call
   asm volatile("" : "+v"(opaque));
@@ -420,6 +423,7 @@ __device__ __forceinline__ void field_mlp16(const float* img, int lane, int q, c
   fb = fa;
 #pragma unroll
   for (int P = 0; P < NP; ++P) {
+    if (SPLIT && P != pw) continue;                          // (wave-uniform: another wave's unit group)
     f32x4 y[NB];
 #pragma unroll
     for (int tb = 0; tb < NB; ++tb) {
@@ -452,6 +456,17 @@ __device__ __forceinline__ void field_mlp16(const float* img, int lane, int q, c
     }
     if (P < 4) fa[P] = f; else fb[P - 4] = f;
     __builtin_amdgcn_sched_barrier(0);
+  }
+  if constexpr (SPLIT) {
+    // wave P holds f of unit group P (waves beyond NP hold nothing): everybody collects all of them
+    float mine = 0.f;
+#pragma unroll
+    for (int P = 0; P < NP; ++P) if (P == pw) mine = P < 4 ? fa[P] : fb[P - 4];
+    xwin[pw * 64 + lane] = mine;
+    __syncthreads();
+#pragma unroll
+    for (int P = 0; P < NP; ++P) { const float v = xwin[P * 64 + lane]; if (P < 4) fa[P] = v; else fb[P - 4] = v; }
+    __syncthreads();
   }
 }
 

@@ -380,8 +380,13 @@ __device__ __forceinline__ double sq4(const f32x4& v) {
 __device__ unsigned long long k4_phase_trace[TRACE_RING * TRACE_BLOCKS * TRACE_SLOTS];
 #endif
 
-template <int DEGREE, int ACT, bool MLP = false, int CT = MC>
+// SPLIT (two-layer field, at most one tile per CU): the workgroup's 8 waves share ONE 16-series tile and split layer 2 of
+// every evaluation by unit group (cde_mfma.h: field_mlp16<..., SPLIT>); all of them carry the state, wave 0 alone stores
+// it, writes outputs and contributes to the error sums.
+constexpr int DOPRI_XWIN_FLOATS = 8 * 64;
+template <int DEGREE, int ACT, bool MLP = false, int CT = MC, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g, int parity) {
+  static_assert(!SPLIT || MLP, "the split form exists for the two-layer field");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using T = float;
   const int tid = threadIdx.x;
@@ -419,6 +424,7 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   if (knots_in_lds) for (int64_t i = tid; i <= g.n_intervals; i += blockDim.x) knots_lds[i] = g.knots[i];
   const float* kn = knots_in_lds ? knots_lds : g.knots;
   float* img_lds = knots_lds + (knots_in_lds ? (g.n_intervals + 4) / 4 * 4 : 0);          // 16-byte aligned
+  float* xwin = img_lds + IMG_FLOATS;                                 // (SPLIT only: 8 x 64 floats behind the image)
   if constexpr (!PRODUCT) {
     const float4* src = reinterpret_cast<const float4*>(g.w16);
     float4* dst = reinterpret_cast<float4*>(img_lds);
@@ -438,9 +444,10 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
 
   const int lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, q = lane >> 4;
-  const int64_t series = ((int64_t)blockIdx.x * 8 + wave) * 16 + n;
-  const bool valid = series < g.B;
-  const int64_t sc = valid ? series : g.B - 1;
+  const int64_t series = SPLIT ? (int64_t)blockIdx.x * 16 + n : ((int64_t)blockIdx.x * 8 + wave) * 16 + n;
+  const bool in_range = series < g.B;
+  const bool valid = in_range && (!SPLIT || wave == 0);               // who stores / counts (every wave LOADS its series)
+  const int64_t sc = in_range ? series : g.B - 1;
   const int64_t e = sc * Hr;                                          // this series' row in the state arrays
   // this lane's 8 hidden units in two groups of 4: product form 8q..8q+7, activation form q, 4+q, .., 28+q
   const int u0 = PRODUCT ? 8 * q : q, u1 = PRODUCT ? 8 * q + 4 : 16 + q;
@@ -524,7 +531,7 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   const float4* wy = reinterpret_cast<const float4*>(img_lds) + lane;
   const float4* by = reinterpret_cast<const float4*>(img_lds + WY_FLOATS) + q;
   auto field = [&](const f32x4& za, const f32x4& zb, const float (&dXv)[CT], f32x4& fa, f32x4& fb) {
-    if constexpr (MLP) field_mlp16<ACT, CT>(img_lds, lane, q, za, zb, dXv, fa, fb);
+    if constexpr (MLP) field_mlp16<ACT, CT, SPLIT>(img_lds, lane, q, za, zb, dXv, fa, fb, wave, xwin);
     else if constexpr (CT == MC) {
       if constexpr (PRODUCT) field16(wA, wB, za, zb, dXv, q, fa, fb);
       else field_act16<ACT>(wy, by, za, zb, dXv, fa, fb);
@@ -1171,12 +1178,24 @@ static int dopri5_advance_impl(const void* coeffs, const void* knots, int64_t n_
       const size_t lds = 2 * 512 * sizeof(double) +
                          (n_knots <= cde::DOPRI_MAX_LDS_KNOTS_MLP ? (size_t)((n_knots + 3) / 4 * 4) * sizeof(float) : 0) +
                          cde::DOPRI_IMAGE_BYTES;
+      // up to 256 tiles (one workgroup per CU): the 8 waves of a workgroup share a tile
+      const int64_t tiles = (B + 15) / 16;
+      const bool split = tiles <= 256 && !ext_sums && B_global == 0 && !getenv("CDE_K4M_NO_SPLIT");
+      const size_t lds_split = lds + (size_t)cde::DOPRI_XWIN_FLOATS * sizeof(float);
 #define CDE_MLP_CT(D, A, CTV)                                                                                      \
   do {                                                                                                             \
-    (void)hipFuncSetAttribute((const void*)cde::dopri5_attempt_mfma<D, A, true, CTV>,                              \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
-    for (int64_t i = 0; i < n_launches; ++i)                                                                       \
-      cde::dopri5_attempt_mfma<D, A, true, CTV><<<grid, 512, lds, s>>>(g, (int)((first_launch + i) & 1));          \
+    if (split) {                                                                                                   \
+      (void)hipFuncSetAttribute((const void*)cde::dopri5_attempt_mfma<D, A, true, CTV, true>,                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split);                       \
+      for (int64_t i = 0; i < n_launches; ++i)                                                                     \
+        cde::dopri5_attempt_mfma<D, A, true, CTV, true><<<(unsigned)tiles, 512, lds_split, s>>>(                   \
+            g, (int)((first_launch + i) & 1));                                                                     \
+    } else {                                                                                                       \
+      (void)hipFuncSetAttribute((const void*)cde::dopri5_attempt_mfma<D, A, true, CTV>,                            \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                             \
+      for (int64_t i = 0; i < n_launches; ++i)                                                                     \
+        cde::dopri5_attempt_mfma<D, A, true, CTV><<<grid, 512, lds, s>>>(g, (int)((first_launch + i) & 1));        \
+    }                                                                                                              \
   } while (0)
 #define CDE_MLP(D, A)                                                                                              \
   do {                                                                                                             \
