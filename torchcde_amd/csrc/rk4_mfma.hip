@@ -59,7 +59,9 @@ __device__ __forceinline__ void swap32(float& x, float& y) {      // x[lanes 32.
 template <int ACT, bool MLP> constexpr int fwd_block_threads() { return 512; }
 template <int ACT, bool MLP> constexpr int fwd_waves_per_simd() { return 2; }
 
-template <typename TT, int DEGREE, int ACT, bool MLP = false, int CT = MC>
+// SPLIT (two-layer field, at most one tile per CU): the workgroup's 8 waves carry ONE tile together and split layer 2 of
+// every evaluation by unit group (cde_mfma.h: field_mlp16<..., SPLIT>); wave 0 alone writes the outputs.
+template <typename TT, int DEGREE, int ACT, bool MLP = false, int CT = MC, bool SPLIT = false>
 __global__ __launch_bounds__((fwd_block_threads<ACT, MLP>()), (fwd_waves_per_simd<ACT, MLP>())) void rk4_forward_mfma(
     const float* __restrict__ coeffs, const float* __restrict__ knots, int64_t n_intervals,
     const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ z0,
@@ -78,15 +80,18 @@ __global__ __launch_bounds__((fwd_block_threads<ACT, MLP>()), (fwd_waves_per_sim
   const int Hr = dims.H, Cr = dims.C;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, q = lane >> 4;
-  const int64_t tile = (int64_t)blockIdx.x * (fwd_block_threads<ACT, MLP>() / 64) + wave;
+  static_assert(!SPLIT || MLP, "the split form exists for the two-layer field");
+  const int64_t tile = SPLIT ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * (fwd_block_threads<ACT, MLP>() / 64) + wave;
   if (tile * 16 >= B) return;
   // Waves w and w+4 of a 512-thread workgroup share a SIMD and do identical work: left alone they run in
   // lockstep and both sit in their MFMA-free RK tail at the same time.  Half a stage of head start for one of
-  // them keeps the matrix pipe fed by the other.
-  if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_sleep(FWD_STAGGER_SLEEP);
+  // them keeps the matrix pipe fed by the other.  (Not in the split form: its waves meet at barriers.)
+  if (!SPLIT && __builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_sleep(FWD_STAGGER_SLEEP);
   const int64_t series = tile * 16 + n;
-  const bool valid = series < B;
-  const int64_t sc = valid ? series : B - 1;
+  const bool in_range = series < B;
+  const bool valid = in_range && (!SPLIT || wave == 0);           // who writes (every wave of a split tile LOADS its series)
+  const int64_t sc = in_range ? series : B - 1;
+  float* xwin = lds + MLP16_LDS_FLOATS;                           // (SPLIT only: 8 x 64 floats behind the images)
 
   // this lane's 8 hidden units in two groups of 4 (zero beyond the real hidden size)
   const int ua = PRODUCT ? 8 * q : q, ub = PRODUCT ? 8 * q + 4 : 16 + q;
@@ -131,7 +136,7 @@ __global__ __launch_bounds__((fwd_block_threads<ACT, MLP>()), (fwd_waves_per_sim
 
       f32x4 fa, fb;
       if constexpr (PRODUCT) { if constexpr (CT == MC) field16(wA, wB, za, zb, dX, q, fa, fb); }
-      else if constexpr (MLP) field_mlp16<ACT, CT>(lds, lane, q, za, zb, dX, fa, fb);
+      else if constexpr (MLP) field_mlp16<ACT, CT, SPLIT>(lds, lane, q, za, zb, dX, fa, fb, wave, xwin);
       else { if constexpr (CT == MC) field_act16<ACT>(wy, by, za, zb, dX, fa, fb); }
       if constexpr (!PRODUCT) {
         __builtin_amdgcn_sched_barrier(0);
@@ -1135,14 +1140,27 @@ int launch_forward_mlp(const void* coeffs, const void* knots, int64_t n_interval
   const unsigned blocks = (unsigned)((B + 127) / 128);
   const size_t lds = (size_t)MLP16_LDS_FLOATS * sizeof(float);
   const bool wide = C > MC;                 // 16 channels x 16 hidden units on the same 16 tiles
+  // up to 256 tiles (one workgroup per CU): the 8 waves of a workgroup share a tile (K2m's split form)
+  const int64_t tiles = (B + 15) / 16;
+  const bool split = tiles <= 256 && !getenv("CDE_K2M_NO_SPLIT");
+  const size_t lds_split = lds + 8 * 64 * sizeof(float);
 #define CDE_FWD_CT(D, A, CTV)                                                                                       \
   do {                                                                                                              \
-    (void)hipFuncSetAttribute((const void*)rk4_forward_mfma<TT, D, A, true, CTV>,                                   \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
-    rk4_forward_mfma<TT, D, A, true, CTV><<<blocks, 512, lds, s>>>(                                                 \
-        (const float*)coeffs, (const float*)knots, n_intervals, (const float*)W2, (const float*)bias2,              \
-        (const float*)z0, (const TT*)grid, n_grid, (const TT*)t_out, n_out, (float*)z_out, B, stage_index,          \
-        (const float*)stage_frac, dims, (const float*)W1, (const float*)bias1, (int)width);                         \
+    if (split) {                                                                                                    \
+      (void)hipFuncSetAttribute((const void*)rk4_forward_mfma<TT, D, A, true, CTV, true>,                           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split);                        \
+      rk4_forward_mfma<TT, D, A, true, CTV, true><<<(unsigned)tiles, 512, lds_split, s>>>(                          \
+          (const float*)coeffs, (const float*)knots, n_intervals, (const float*)W2, (const float*)bias2,            \
+          (const float*)z0, (const TT*)grid, n_grid, (const TT*)t_out, n_out, (float*)z_out, B, stage_index,        \
+          (const float*)stage_frac, dims, (const float*)W1, (const float*)bias1, (int)width);                       \
+    } else {                                                                                                        \
+      (void)hipFuncSetAttribute((const void*)rk4_forward_mfma<TT, D, A, true, CTV>,                                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
+      rk4_forward_mfma<TT, D, A, true, CTV><<<blocks, 512, lds, s>>>(                                               \
+          (const float*)coeffs, (const float*)knots, n_intervals, (const float*)W2, (const float*)bias2,            \
+          (const float*)z0, (const TT*)grid, n_grid, (const TT*)t_out, n_out, (float*)z_out, B, stage_index,        \
+          (const float*)stage_frac, dims, (const float*)W1, (const float*)bias1, (int)width);                       \
+    }                                                                                                               \
   } while (0)
 #define CDE_FWD(D, A)                                                                                               \
   do {                                                                                                              \
