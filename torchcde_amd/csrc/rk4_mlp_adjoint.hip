@@ -68,8 +68,12 @@ __global__ void mlp_adj_image_kernel(const float* __restrict__ W1, const float* 
 // DCOEFF: also accumulate dL/d(control coefficients) into `grad_coeffs` (zeroed by the caller, layout of `coeffs`),
 // as K3a does: d(a.f)/d(dX_c) = sum_h a_h act(Y2)_hc, here summed in-lane over the lane's 8 hidden units and then
 // over the four lane quarters with two shuffles; quarter q carries channels 2q, 2q+1 to the coefficient row.
-template <typename TT, int DEGREE, int ACT, bool DCOEFF = false, int CT = MC>
-__global__ __launch_bounds__(512, 2) void rk4_adjoint_mlp_sweep(
+// SPLIT (at most one tile per CU): a 256-thread workgroup whose four waves carry ONE tile through the sweep -- layer 1,
+// dL/dY1, va and the RK bookkeeping redundantly and bit-identically, the unit groups of layer 2 / dL/dY2 / gu split four
+// ways, partial sums added in a fixed wave order through a 9 KB LDS window (cde_mlp_adj.h: mlp_split_allreduce, as in
+// K4am's split form); wave 0 stores state, the shared factor rows and the control gradients.
+template <typename TT, int DEGREE, int ACT, bool DCOEFF = false, int CT = MC, bool SPLIT = false>
+__global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2) void rk4_adjoint_mlp_sweep(
     const float* __restrict__ coeffs, const float* __restrict__ knots, int64_t n_intervals,
     const float* __restrict__ img, float* __restrict__ y_state, float* __restrict__ a_state,
     const TT* __restrict__ sgrid, int64_t k_begin, int64_t k_end, const int64_t* __restrict__ stage_index,
@@ -87,11 +91,14 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_mlp_sweep(
   const int Hr = dims.H, Cr = dims.C;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, q = lane >> 4;
-  const int64_t tile = (int64_t)blockIdx.x * 8 + wave;
+  const int64_t tile = SPLIT ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * 8 + wave;
   if (tile * 16 >= B) return;
+  const int pw = SPLIT ? wave : 0;
+  float* xbuf = lds + ADJ_LDS_FLOATS;                                // (SPLIT only: 4 x 64 x 9 floats behind the images)
   const int64_t series = tile * 16 + n;
-  const bool valid = series < B;
-  const int64_t sc = valid ? series : B - 1;
+  const bool in_range = series < B;
+  const bool valid = in_range && (!SPLIT || wave == 0);              // who stores what every wave of a split tile holds
+  const int64_t sc = in_range ? series : B - 1;
   const float4* w1t_base = reinterpret_cast<const float4*>(img + ADJ_LDS_FLOATS) + lane;
   // lane offsets into the plain W2 copy (see the header): Y2 rows (h&3 = n>>2, c&3 = n&3), gu rows (h&3 = q, c&3 = cl)
   const int w2y_off = ((n >> 3) * 8 + w2p_residue(n >> 2, n & 3)) * W2P_STRIDE + 4 * q;
@@ -102,7 +109,7 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_mlp_sweep(
   const int ua = q, ub = 16 + q;                                     // this lane's units: q, 4+q, .., 28+q
   f32x4 ya = load_units4<4>(y_state + sc * Hr, ua, Hr), yb = load_units4<4>(y_state + sc * Hr, ub, Hr);
   f32x4 aa = load_units4<4>(a_state + sc * Hr, ua, Hr), ab = load_units4<4>(a_state + sc * Hr, ub, Hr);
-  if (!valid) { aa = f32x4{0.f, 0.f, 0.f, 0.f}; ab = aa; }          // a == 0 stays 0: padded lanes contribute nothing
+  if (!in_range) { aa = f32x4{0.f, 0.f, 0.f, 0.f}; ab = aa; }       // a == 0 stays 0: padded lanes contribute nothing
 
   int64_t idx = stage_index[4 * k_begin];
   float frac = stage_frac[4 * k_begin];
@@ -197,6 +204,7 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_mlp_sweep(
       float gdx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // d(a.f)/d(dX_c), this lane's hidden units (DCOEFF)
 #pragma unroll
       for (int P = 0; P < NP; ++P) {                                 // unit group P: 4 hidden units x CT channels = NB tiles
+        if (SPLIT && P / (NP / 4) != pw) continue;                   // (wave-uniform: another wave's group)
         f32x4 y[NB];
         const float* tp_[NB];
 #pragma unroll
@@ -236,7 +244,7 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_mlp_sweep(
           }
         }
         if (P < 4) fa[P] = f; else fb[P - 4] = f;
-        if (valid) {
+        if (SPLIT ? in_range : valid) {                              // (split: the rows of a unit group by the wave that owns it)
           float* grow = G2 + out_row * G2_COLS + 4 * CT * P + CT * q;     // rows (h = 4P+q, c = 0..CT-1) of the padded layout
 #pragma unroll
           for (int c4 = 0; c4 < CT; c4 += 4)
@@ -252,6 +260,20 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_mlp_sweep(
       }
 
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (SPLIT) {
+        // the four waves' shares of gu, f (and of d(a.f)/d(dX)) meet: afterwards every wave holds the complete values
+        mlp_split_allreduce(xbuf, pw, lane, gu[0], gu[1], nullptr);
+        mlp_split_allreduce(xbuf, pw, lane, gu[2], gu[3], nullptr);
+        mlp_split_allreduce(xbuf, pw, lane, gu[4], gu[5], nullptr);
+        mlp_split_allreduce(xbuf, pw, lane, gu[6], gu[7], nullptr);
+        mlp_split_allreduce(xbuf, pw, lane, fa, fb, nullptr);
+        if constexpr (DCOEFF) {
+          f32x4 g03 = {gdx[0], gdx[1], gdx[2], gdx[3]}, g47 = {gdx[4], gdx[5], gdx[6], gdx[7]};
+          mlp_split_allreduce(xbuf, pw, lane, g03, g47, nullptr);
+          gdx[0] = g03[0]; gdx[1] = g03[1]; gdx[2] = g03[2]; gdx[3] = g03[3];
+          gdx[4] = g47[0]; gdx[5] = g47[1]; gdx[6] = g47[2]; gdx[7] = g47[3];
+        }
+      }
       if constexpr (DCOEFF) {
         float mine[2];
 #pragma unroll
@@ -346,26 +368,30 @@ int launch_mlp_adjoint_sweep(const void* coeffs, const void* knots, int64_t n_in
                              void* G1, void* Z, int64_t B, int64_t C, int64_t H, void* grad_coeffs, hipStream_t s) {
   if (k_end <= k_begin) return CDE_OK;
   const Dims dims{(int)H, (int)C};
-  const unsigned blocks = (unsigned)((B + 127) / 128);
-  const size_t lds = (size_t)ADJ_LDS_FLOATS * sizeof(float);
+  // up to 256 tiles (one workgroup per CU): four waves per tile (the split form)
+  const int64_t tiles = (B + 15) / 16;
+  const bool split = tiles <= 256 && !getenv("CDE_K3M_NO_SPLIT");
+  const unsigned blocks = split ? (unsigned)tiles : (unsigned)((B + 127) / 128);
+  const unsigned threads = split ? 256 : 512;
+  const size_t lds = (size_t)ADJ_LDS_FLOATS * sizeof(float) + (split ? (size_t)4 * 64 * 9 * sizeof(float) : 0);
+#define CDE_SWEEP_L(D, A, X, CTV, SPL, GC)                                                                         \
+  do {                                                                                                             \
+    (void)hipFuncSetAttribute((const void*)rk4_adjoint_mlp_sweep<TT, D, A, X, CTV, SPL>,                           \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
+    rk4_adjoint_mlp_sweep<TT, D, A, X, CTV, SPL><<<blocks, threads, lds, s>>>(                                     \
+        (const float*)coeffs, (const float*)knots, n_intervals, img, (float*)y_state, (float*)a_state,             \
+        (const TT*)sgrid, k_begin, k_end, stage_index, (const float*)stage_frac, (float*)U, (float*)G2, (float*)G1, \
+        (float*)Z, B, dims, GC);                                                                                   \
+  } while (0)
 #define CDE_SWEEP_X(D, A, X)                                                                                       \
   do {                                                                                                             \
     if (C > MC) {                              /* 16 channels x 16 units; control gradients: 8-channel layout only */ \
       if (X) return CDE_ERR_UNSUPPORTED;                                                                           \
-      (void)hipFuncSetAttribute((const void*)rk4_adjoint_mlp_sweep<TT, D, A, false, 16>,                           \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                             \
-      rk4_adjoint_mlp_sweep<TT, D, A, false, 16><<<blocks, 512, lds, s>>>(                                         \
-          (const float*)coeffs, (const float*)knots, n_intervals, img, (float*)y_state, (float*)a_state,           \
-          (const TT*)sgrid, k_begin, k_end, stage_index, (const float*)stage_frac, (float*)U, (float*)G2,          \
-          (float*)G1, (float*)Z, B, dims, nullptr);                                                                \
+      if (split) CDE_SWEEP_L(D, A, false, 16, true, nullptr); else CDE_SWEEP_L(D, A, false, 16, false, nullptr);   \
       break;                                                                                                       \
     }                                                                                                              \
-    (void)hipFuncSetAttribute((const void*)rk4_adjoint_mlp_sweep<TT, D, A, X>,                                     \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
-    rk4_adjoint_mlp_sweep<TT, D, A, X><<<blocks, 512, lds, s>>>(                                                   \
-        (const float*)coeffs, (const float*)knots, n_intervals, img, (float*)y_state, (float*)a_state,             \
-        (const TT*)sgrid, k_begin, k_end, stage_index, (const float*)stage_frac, (float*)U, (float*)G2, (float*)G1, \
-        (float*)Z, B, dims, (float*)grad_coeffs);                                                                  \
+    if (split) CDE_SWEEP_L(D, A, X, MC, true, (float*)grad_coeffs);                                                \
+    else CDE_SWEEP_L(D, A, X, MC, false, (float*)grad_coeffs);                                                     \
   } while (0)
 #define CDE_SWEEP(D, A)                                                                                            \
   do {                                                                                                             \
@@ -379,6 +405,7 @@ int launch_mlp_adjoint_sweep(const void* coeffs, const void* knots, int64_t n_in
   } else return CDE_ERR_UNSUPPORTED;
 #undef CDE_SWEEP
 #undef CDE_SWEEP_X
+#undef CDE_SWEEP_L
   return check_launch();
 }
 
