@@ -14,7 +14,7 @@ from helpers import TwoLayerField, make_series  # noqa: E402
 
 dev = "cuda"
 kw = dict(method="rk4", options=dict(step_size=1.0))
-for B in (64, 1024, 4096):
+for B in (64, 4096, 8192, 12288):
     x = make_series(B, 128, 8, seed=0).to(dev)
     X = cde.CubicSpline(cde.hermite_cubic_coefficients_with_backward_differences(x))
     f = TwoLayerField(32, 8, 128, seed=0).to(dev)

@@ -1140,9 +1140,10 @@ int launch_forward_mlp(const void* coeffs, const void* knots, int64_t n_interval
   const unsigned blocks = (unsigned)((B + 127) / 128);
   const size_t lds = (size_t)MLP16_LDS_FLOATS * sizeof(float);
   const bool wide = C > MC;                 // 16 channels x 16 hidden units on the same 16 tiles
-  // up to 256 tiles (one workgroup per CU): the 8 waves of a workgroup share a tile (K2m's split form)
+  // up to 768 tiles (three rounds of one workgroup per CU still beat 8 tiles per workgroup on a quarter of the CUs): the 8
+  // waves of a workgroup share a tile (K2m's split form)
   const int64_t tiles = (B + 15) / 16;
-  const bool split = tiles <= 256 && !getenv("CDE_K2M_NO_SPLIT");
+  const bool split = tiles <= 768 && !getenv("CDE_K2M_NO_SPLIT");
   const size_t lds_split = lds + 8 * 64 * sizeof(float);
 #define CDE_FWD_CT(D, A, CTV)                                                                                       \
   do {                                                                                                              \

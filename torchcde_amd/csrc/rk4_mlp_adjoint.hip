@@ -368,9 +368,10 @@ int launch_mlp_adjoint_sweep(const void* coeffs, const void* knots, int64_t n_in
                              void* G1, void* Z, int64_t B, int64_t C, int64_t H, void* grad_coeffs, hipStream_t s) {
   if (k_end <= k_begin) return CDE_OK;
   const Dims dims{(int)H, (int)C};
-  // up to 256 tiles (one workgroup per CU): four waves per tile (the split form)
+  // up to 512 tiles (two rounds of one workgroup per CU; the 8-wave form would use a quarter of the CUs there): four
+  // waves per tile (the split form)
   const int64_t tiles = (B + 15) / 16;
-  const bool split = tiles <= 256 && !getenv("CDE_K3M_NO_SPLIT");
+  const bool split = tiles <= 512 && !getenv("CDE_K3M_NO_SPLIT");
   const unsigned blocks = split ? (unsigned)tiles : (unsigned)((B + 127) / 128);
   const unsigned threads = split ? 256 : 512;
   const size_t lds = (size_t)ADJ_LDS_FLOATS * sizeof(float) + (split ? (size_t)4 * 64 * 9 * sizeof(float) : 0);
