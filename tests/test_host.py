@@ -53,6 +53,21 @@ def test_ctypes_signatures_match_the_header_prototypes():
         assert {"int": ctypes.c_int, "size_t": ctypes.c_size_t, "const char*": ctypes.c_char_p}[ret] is restype, name
 
 
+def test_status_struct_mirror_matches_the_header():
+    """cde_dopri5_status (include/cde_mi355x.h) against its ctypes mirror: same fields in the same order with the same
+    widths -- the host reads the controller block of the adaptive kernels through it (112 bytes since the two interval
+    hints were appended)."""
+    header = open(os.path.join(ROOT, "include", "cde_mi355x.h")).read()
+    body = re.search(r"typedef struct \{(.*?)\} cde_dopri5_status;", header, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for ctype, names in re.findall(r"(double|int64_t|int32_t)\s+([^;]+);", body):
+        fields += [(n.strip(), ctype) for n in names.split(",")]
+    widths = {"double": ctypes.c_double, "int64_t": ctypes.c_int64, "int32_t": ctypes.c_int32}
+    assert [(n, widths[t]) for n, t in fields] == list(_lib.DopriStatus._fields_)
+    assert ctypes.sizeof(_lib.DopriStatus) == 112
+
+
 def test_argument_errors_come_back_as_codes_without_a_gpu():
     lib = torchcde_amd.load()
     null = ctypes.c_void_p(0)
