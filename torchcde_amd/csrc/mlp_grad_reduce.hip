@@ -44,11 +44,11 @@ __device__ __forceinline__ void ring_barrier() {           // LDS traffic of thi
 }
 
 template <int MT, int NV, int NG>
-__global__ __launch_bounds__(256, 2) void mlp_grad_partial_kernel(const float* __restrict__ G, const float* __restrict__ X,
-                                                                  int64_t rows, int64_t rows_per_slab, int xc,
-                                                                  float* __restrict__ partial, int gc,
-                                                                  const unsigned char* __restrict__ gate = nullptr,
-                                                                  int gate_parity = 0, int slabs_per_stage = 0) {
+__device__ __forceinline__ void mlp_grad_partial_body(const float* __restrict__ G, const float* __restrict__ X,
+                                                      int64_t rows, int64_t rows_per_slab, int xc,
+                                                      float* __restrict__ partial, int gc,
+                                                      const unsigned char* __restrict__ gate, int gate_parity,
+                                                      int slabs_per_stage, const int block_x, const int block_y) {
   constexpr int M = 4 * MT * 16, NT = NG * NV, N = NT * 16, R = GRAD_TILE_ROWS;
   if (gate) {
     // K4am (dopri5_mlp_adjoint.hip): one block of rows per stored stage, `slabs_per_stage` slabs each; the attempt launch
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, 2) void mlp_grad_partial_kernel(const float* _
     const AdjCtrl* k = reinterpret_cast<const AdjCtrl*>(gate + (gate_parity ^ 1) * ADJ_CTRL_STRIDE);
     if (k->c.phase == 4 && k->commit == 0) return;
     const int n_slots = k->mode == 0 ? 1 : k->mode == 1 ? 2 : 6;
-    if ((int)blockIdx.x >= n_slots * slabs_per_stage) return;
+    if (block_x >= n_slots * slabs_per_stage) return;
   }
   constexpr int TILE = R * (M + N);                          // floats per ring buffer: [G rows | X rows]
   // wave-wide loads (256 floats each) per tile and wave; every wave issues the same number (idle slots load into a
@@ -68,10 +68,10 @@ __global__ __launch_bounds__(256, 2) void mlp_grad_partial_kernel(const float* _
   using BV = typename VecOf<NV>::type;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* dummy = lds + GRAD_RING * TILE;
-  const int m0 = blockIdx.y * M;
+  const int m0 = block_y * M;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
-  const int64_t lo = (int64_t)blockIdx.x * rows_per_slab;
+  const int64_t lo = (int64_t)block_x * rows_per_slab;
   int64_t hi = lo + rows_per_slab;
   hi = hi < rows ? hi : rows;
   f32x4 acc[MT][NT];
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void mlp_grad_partial_kernel(const float* _
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // nothing may still be landing in LDS when the workgroup ends
   // partial[slab][m][N + 1]: D fragment of tile (tm, tn): lane (j = i, q = kq), register r = row 4q + r of the tile
-  float* out = partial + ((int64_t)blockIdx.x * gc + m0) * (N + 1);
+  float* out = partial + ((int64_t)block_x * gc + m0) * (N + 1);
 #pragma unroll
   for (int tm = 0; tm < MT; ++tm) {
 #pragma unroll
@@ -185,6 +185,32 @@ __global__ __launch_bounds__(256) void mlp_grad_finish_kernel(const float* __res
 
 constexpr int GRAD_SLABS = 512;
 
+template <int MT, int NV, int NG>
+__global__ __launch_bounds__(256, 2) void mlp_grad_partial_kernel(const float* __restrict__ G, const float* __restrict__ X,
+                                                                  int64_t rows, int64_t rows_per_slab, int xc,
+                                                                  float* __restrict__ partial, int gc,
+                                                                  const unsigned char* __restrict__ gate = nullptr,
+                                                                  int gate_parity = 0, int slabs_per_stage = 0) {
+  mlp_grad_partial_body<MT, NV, NG>(G, X, rows, rows_per_slab, xc, partial, gc, gate, gate_parity, slabs_per_stage,
+                                    (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// K4am: both layers' factor rows of one attempt in ONE launch (blockIdx.y = 0: [dW2 | db2] = G2^T U on the 256 x 132 tiles,
+// 1: [dW1 | db1] = G1^T Z on the 128 x 36 ones) -- a launch boundary less per attempted step
+__global__ __launch_bounds__(256, 2) void mlp_grad_partial_pair_kernel(const float* __restrict__ G2, const float* __restrict__ U,
+                                                                       const float* __restrict__ G1, const float* __restrict__ Z,
+                                                                       int64_t rows, int64_t rows_per_slab,
+                                                                       float* __restrict__ part2, float* __restrict__ part1,
+                                                                       const unsigned char* __restrict__ gate, int gate_parity,
+                                                                       int slabs_per_stage) {
+  if (blockIdx.y == 0)
+    mlp_grad_partial_body<4, 4, 2>(G2, U, rows, rows_per_slab, 132, part2, 256, gate, gate_parity, slabs_per_stage,
+                                   (int)blockIdx.x, 0);
+  else
+    mlp_grad_partial_body<2, 2, 1>(G1, Z, rows, rows_per_slab, 36, part1, 128, gate, gate_parity, slabs_per_stage,
+                                   (int)blockIdx.x, 0);
+}
+
 #define CDE_GRAD_PARTIAL(MTV, NVV, NGV, GRID, ...)                                                                 \
   do {                                                                                                             \
     const size_t lds_bytes = cde::grad_partial_lds_bytes<MTV, NVV, NGV>();                                         \
@@ -216,9 +242,12 @@ int launch_mlp_adjoint_factor_reduce(const float* G2, const float* U, const floa
                                      int sps, int64_t rows_per_slab, float* part2, float* part1, const unsigned char* ctrl,
                                      int parity, hipStream_t s) {
   const int64_t rows = 6 * rows_per_stage;
-  const dim3 grid((unsigned)(6 * sps));
-  CDE_GRAD_PARTIAL(4, 4, 2, grid, G2, U, rows, rows_per_slab, 132, part2, 256, ctrl, parity, sps);
-  CDE_GRAD_PARTIAL(2, 2, 1, grid, G1, Z, rows, rows_per_slab, 36, part1, 128, ctrl, parity, sps);
+  const dim3 grid((unsigned)(6 * sps), 2);
+  const size_t a = grad_partial_lds_bytes<4, 4, 2>(), b = grad_partial_lds_bytes<2, 2, 1>();
+  const size_t lds_bytes = a > b ? a : b;
+  (void)hipFuncSetAttribute((const void*)mlp_grad_partial_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_bytes);
+  mlp_grad_partial_pair_kernel<<<grid, 256, lds_bytes, s>>>(G2, U, G1, Z, rows, rows_per_slab, part2, part1, ctrl, parity, sps);
   return check_launch();
 }
 
