@@ -341,6 +341,37 @@ __device__ __forceinline__ void field_act16(const float4* wy, const float4* by, 
   }
 }
 
+// The split form (dopri5 forward on small batches): the 8 waves of a workgroup evaluate the SAME 16 series, wave `pw` the
+// unit group P = pw alone (16 MFMAs instead of 128), and gather the 8 values of f through `xwin` (LDS, 8 x 64 floats).
+template <int ACT>
+__device__ __forceinline__ void field_act16_split(const float4* wy, const float4* by, const f32x4& za, const f32x4& zb,
+                                                  const float (&dX)[MC], f32x4& fa, f32x4& fb, int pw, float* xwin,
+                                                  int lane) {
+  const float zs[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
+  int opaque = 0;
+  asm volatile("" : "+v"(opaque));
+  wy += opaque + 4 * pw * 64;
+  by += opaque + 8 * pw;
+  const float4 g00 = wy[0], g01 = wy[64], g10 = wy[128], g11 = wy[192];
+  const float4 b0 = by[0], b1 = by[4];
+  f32x4 y0 = {b0.x, b0.y, b0.z, b0.w}, y1 = {b1.x, b1.y, b1.z, b1.w};
+  const float a0[8] = {g00.x, g00.y, g00.z, g00.w, g01.x, g01.y, g01.z, g01.w};
+  const float a1[8] = {g10.x, g10.y, g10.z, g10.w, g11.x, g11.y, g11.z, g11.w};
+#pragma unroll
+  for (int s = 0; s < 8; ++s) { y0 = mfma16(a0[s], zs[s], y0); y1 = mfma16(a1[s], zs[s], y1); }
+  const f32x2 t01 = activate2<ACT>(y0[0], y0[1]), t23 = activate2<ACT>(y0[2], y0[3]);
+  const f32x2 t45 = activate2<ACT>(y1[0], y1[1]), t67 = activate2<ACT>(y1[2], y1[3]);
+  float f = t01[0] * dX[0];
+  f = __builtin_fmaf(t01[1], dX[1], f); f = __builtin_fmaf(t23[0], dX[2], f); f = __builtin_fmaf(t23[1], dX[3], f);
+  f = __builtin_fmaf(t45[0], dX[4], f); f = __builtin_fmaf(t45[1], dX[5], f);
+  f = __builtin_fmaf(t67[0], dX[6], f); f = __builtin_fmaf(t67[1], dX[7], f);
+  xwin[pw * 64 + lane] = f;
+  __syncthreads();
+#pragma unroll
+  for (int P = 0; P < 8; ++P) { const float v = xwin[P * 64 + lane]; if (P < 4) fa[P] = v; else fb[P - 4] = v; }
+  __syncthreads();
+}
+
 // ============================================================================ two-layer fields
 // f(z) = reshape_{HxC}(act(W2 relu(W1 z + b1) + b2)) dX   (reference example/time_series_classification.py:20-51:
 // Linear(H, width) -> relu -> Linear(width, H*C) -> tanh, width = 128).  Same tiling as field_act16 with a hidden

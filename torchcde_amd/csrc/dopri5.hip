@@ -386,7 +386,7 @@ __device__ unsigned long long k4_phase_trace[TRACE_RING * TRACE_BLOCKS * TRACE_S
 constexpr int DOPRI_XWIN_FLOATS = 8 * 64;
 template <int DEGREE, int ACT, bool MLP = false, int CT = MC, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g, int parity) {
-  static_assert(!SPLIT || MLP, "the split form exists for the two-layer field");
+  static_assert(!SPLIT || MLP || ACT != CDE_ACT_NONE, "the split form exists for the pre-activation tilings");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using T = float;
   const int tid = threadIdx.x;
@@ -534,6 +534,7 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
     if constexpr (MLP) field_mlp16<ACT, CT, SPLIT>(img_lds, lane, q, za, zb, dXv, fa, fb, wave, xwin);
     else if constexpr (CT == MC) {
       if constexpr (PRODUCT) field16(wA, wB, za, zb, dXv, q, fa, fb);
+      else if constexpr (SPLIT) field_act16_split<ACT>(wy, by, za, zb, dXv, fa, fb, wave, xwin, lane);
       else field_act16<ACT>(wy, by, za, zb, dXv, fa, fb);
     }
   };
@@ -1219,13 +1220,22 @@ static int dopri5_advance_impl(const void* coeffs, const void* knots, int64_t n_
     const size_t lds = 2 * 512 * sizeof(double) +
                        (n_knots <= cde::DOPRI_MAX_LDS_KNOTS ? (size_t)((n_knots + 3) / 4 * 4) * sizeof(float) : 0) +
                        (act == CDE_ACT_NONE ? 0 : cde::ACT16_LDS_FLOATS * sizeof(float));
+    // tanh fields on small batches (at most one tile per CU): the 8 waves of a workgroup share a tile, one unit group each
+    const int64_t tiles_act = (B + 15) / 16;
+    const bool split_act = act != CDE_ACT_NONE && tiles_act <= 256 && !ext_sums && B_global == 0 && !getenv("CDE_K4_NO_SPLIT");
+    const size_t lds_split = lds + (size_t)cde::DOPRI_XWIN_FLOATS * sizeof(float);
     for (int64_t i = 0; i < n_launches; ++i) {
       const int par = (int)((first_launch + i) & 1);
       if (act == CDE_ACT_NONE) {
         if (degree == CDE_PATH_CUBIC) cde::dopri5_attempt_mfma<CDE_PATH_CUBIC, CDE_ACT_NONE><<<grid, 512, lds, s>>>(g, par);
         else cde::dopri5_attempt_mfma<CDE_PATH_LINEAR, CDE_ACT_NONE><<<grid, 512, lds, s>>>(g, par);
       } else {
-        if (degree == CDE_PATH_CUBIC) cde::dopri5_attempt_mfma<CDE_PATH_CUBIC, CDE_ACT_TANH><<<grid, 512, lds, s>>>(g, par);
+        if (split_act) {                        // at most one tile per CU: the 8 waves of a workgroup share it
+          if (degree == CDE_PATH_CUBIC)
+            cde::dopri5_attempt_mfma<CDE_PATH_CUBIC, CDE_ACT_TANH, false, cde::MC, true><<<(unsigned)tiles_act, 512, lds_split, s>>>(g, par);
+          else
+            cde::dopri5_attempt_mfma<CDE_PATH_LINEAR, CDE_ACT_TANH, false, cde::MC, true><<<(unsigned)tiles_act, 512, lds_split, s>>>(g, par);
+        } else if (degree == CDE_PATH_CUBIC) cde::dopri5_attempt_mfma<CDE_PATH_CUBIC, CDE_ACT_TANH><<<grid, 512, lds, s>>>(g, par);
         else cde::dopri5_attempt_mfma<CDE_PATH_LINEAR, CDE_ACT_TANH><<<grid, 512, lds, s>>>(g, par);
       }
     }
