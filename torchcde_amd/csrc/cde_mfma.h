@@ -211,6 +211,53 @@ __device__ __forceinline__ void field16(const float4 (&wA)[W16_GROUPS], const fl
   fb = mfma16(wB[16].y, b1, fb);
 }
 
+// The split form of field16 (dopri5 forward on small batches): the 8 waves of a workgroup evaluate the SAME 16 series; wave
+// `pw` takes the K steps of the lane's pw-th hidden unit (groups 2 pw, 2 pw + 1 of both tile images: 16 of the 132
+// MFMAs; wave 0 also the two bias steps) and the 8 partial sums meet in `xwin` (LDS, 8 x 64 x 9 floats), added in wave
+// order so that every wave continues with the same numbers.  g0 / g1: the wave's two groups of tile A, h0 / h1 of tile
+// B, ba / bb: the bias groups.
+__device__ __forceinline__ void field16_split(const float4& g0, const float4& g1, const float4& h0, const float4& h1,
+                                              const float4& ba, const float4& bb, const f32x4& za, const f32x4& zb,
+                                              const float (&dX)[MC], int q, f32x4& fa, f32x4& fb, int pw, float* xwin,
+                                              int lane) {
+  fa = f32x4{0.f, 0.f, 0.f, 0.f};
+  fb = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float zall[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
+  float zm = zall[0];
+#pragma unroll
+  for (int m = 1; m < 8; ++m) zm = pw == m ? zall[m] : zm;         // (wave-uniform select: the lane's pw-th unit)
+  const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+  const float gb[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float p = dX[c] * zm;
+    fa = mfma16(ga[c], p, fa);
+    fb = mfma16(gb[c], p, fb);
+  }
+  if (pw == 0) {                                                   // bias: step 64 feeds channel kq, step 65 channel 4 + kq
+    const float b0 = q == 0 ? dX[0] : q == 1 ? dX[1] : q == 2 ? dX[2] : dX[3];
+    const float b1 = q == 0 ? dX[4] : q == 1 ? dX[5] : q == 2 ? dX[6] : dX[7];
+    fa = mfma16(ba.x, b0, fa);
+    fb = mfma16(bb.x, b0, fb);
+    fa = mfma16(ba.y, b1, fa);
+    fb = mfma16(bb.y, b1, fb);
+  }
+  float* slot = xwin + (pw * 64 + lane) * 9;
+  slot[0] = fa[0]; slot[1] = fa[1]; slot[2] = fa[2]; slot[3] = fa[3];
+  slot[4] = fb[0]; slot[5] = fb[1]; slot[6] = fb[2]; slot[7] = fb[3];
+  __syncthreads();
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    const float* src = xwin + (w * 64 + lane) * 9;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] += src[i];
+  }
+  fa = f32x4{s[0], s[1], s[2], s[3]};
+  fb = f32x4{s[4], s[5], s[6], s[7]};
+  __syncthreads();
+}
+
 // stage the two 16x16x4 weight images in LDS (blockDim threads), then pull this lane's copy into registers
 __device__ __forceinline__ void load_w16(const float* __restrict__ W, const float* __restrict__ bias, float* lds,
                                          float4 (&wA)[W16_GROUPS], float4 (&wB)[W16_GROUPS], Dims d) {

@@ -386,7 +386,7 @@ __device__ unsigned long long k4_phase_trace[TRACE_RING * TRACE_BLOCKS * TRACE_S
 constexpr int DOPRI_XWIN_FLOATS = 8 * 64;
 template <int DEGREE, int ACT, bool MLP = false, int CT = MC, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g, int parity) {
-  static_assert(!SPLIT || MLP || ACT != CDE_ACT_NONE, "the split form exists for the pre-activation tilings");
+  static_assert(CT == MC || MLP, "16-channel tiles: two-layer fields only");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using T = float;
   const int tid = threadIdx.x;
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   if (knots_in_lds) for (int64_t i = tid; i <= g.n_intervals; i += blockDim.x) knots_lds[i] = g.knots[i];
   const float* kn = knots_in_lds ? knots_lds : g.knots;
   float* img_lds = knots_lds + (knots_in_lds ? (g.n_intervals + 4) / 4 * 4 : 0);          // 16-byte aligned
-  float* xwin = img_lds + IMG_FLOATS;                                 // (SPLIT only: 8 x 64 floats behind the image)
+  float* xwin = PRODUCT ? img_lds : img_lds + IMG_FLOATS;             // (SPLIT only: the exchange window behind the image)
   if constexpr (!PRODUCT) {
     const float4* src = reinterpret_cast<const float4*>(g.w16);
     float4* dst = reinterpret_cast<float4*>(img_lds);
@@ -491,7 +491,14 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   CDE_STAMP(2);
   // (the register image of the weights is requested here, not at entry: it fills the register file, and its L2 latency
   // hides behind the controller just as well)
-  if constexpr (PRODUCT) {
+  float4 sg0, sg1, sh0, sh1, sba, sbb;                               // (PRODUCT && SPLIT: this wave's groups only)
+  if constexpr (PRODUCT && SPLIT) {
+    const float4* img = reinterpret_cast<const float4*>(g.w16) + (tid & 63);
+    const int pw_ = uni((int)(tid >> 6));
+    sg0 = img[(2 * pw_) * 64]; sg1 = img[(2 * pw_ + 1) * 64];
+    sh0 = img[(W16_GROUPS + 2 * pw_) * 64]; sh1 = img[(W16_GROUPS + 2 * pw_ + 1) * 64];
+    sba = img[16 * 64]; sbb = img[(W16_GROUPS + 16) * 64];
+  } else if constexpr (PRODUCT) {
     const float4* img = reinterpret_cast<const float4*>(g.w16) + (tid & 63);
 #pragma unroll
     for (int grp = 0; grp < W16_GROUPS; ++grp) { wA[grp] = img[grp * 64]; wB[grp] = img[(W16_GROUPS + grp) * 64]; }
@@ -533,7 +540,8 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   auto field = [&](const f32x4& za, const f32x4& zb, const float (&dXv)[CT], f32x4& fa, f32x4& fb) {
     if constexpr (MLP) field_mlp16<ACT, CT, SPLIT>(img_lds, lane, q, za, zb, dXv, fa, fb, wave, xwin);
     else if constexpr (CT == MC) {
-      if constexpr (PRODUCT) field16(wA, wB, za, zb, dXv, q, fa, fb);
+      if constexpr (PRODUCT && SPLIT) field16_split(sg0, sg1, sh0, sh1, sba, sbb, za, zb, dXv, q, fa, fb, wave, xwin, lane);
+      else if constexpr (PRODUCT) field16(wA, wB, za, zb, dXv, q, fa, fb);
       else if constexpr (SPLIT) field_act16_split<ACT>(wy, by, za, zb, dXv, fa, fb, wave, xwin, lane);
       else field_act16<ACT>(wy, by, za, zb, dXv, fa, fb);
     }
@@ -1220,14 +1228,20 @@ static int dopri5_advance_impl(const void* coeffs, const void* knots, int64_t n_
     const size_t lds = 2 * 512 * sizeof(double) +
                        (n_knots <= cde::DOPRI_MAX_LDS_KNOTS ? (size_t)((n_knots + 3) / 4 * 4) * sizeof(float) : 0) +
                        (act == CDE_ACT_NONE ? 0 : cde::ACT16_LDS_FLOATS * sizeof(float));
-    // tanh fields on small batches (at most one tile per CU): the 8 waves of a workgroup share a tile, one unit group each
+    // small batches (at most one tile per CU): the 8 waves of a workgroup share a tile -- tanh fields one unit group each,
+    // identity fields one K group each
     const int64_t tiles_act = (B + 15) / 16;
-    const bool split_act = act != CDE_ACT_NONE && tiles_act <= 256 && !ext_sums && B_global == 0 && !getenv("CDE_K4_NO_SPLIT");
-    const size_t lds_split = lds + (size_t)cde::DOPRI_XWIN_FLOATS * sizeof(float);
+    const bool split_act = tiles_act <= 256 && !ext_sums && B_global == 0 && !getenv("CDE_K4_NO_SPLIT");
+    const size_t lds_split = lds + (size_t)8 * 64 * 9 * sizeof(float);
     for (int64_t i = 0; i < n_launches; ++i) {
       const int par = (int)((first_launch + i) & 1);
       if (act == CDE_ACT_NONE) {
-        if (degree == CDE_PATH_CUBIC) cde::dopri5_attempt_mfma<CDE_PATH_CUBIC, CDE_ACT_NONE><<<grid, 512, lds, s>>>(g, par);
+        if (split_act) {
+          if (degree == CDE_PATH_CUBIC)
+            cde::dopri5_attempt_mfma<CDE_PATH_CUBIC, CDE_ACT_NONE, false, cde::MC, true><<<(unsigned)tiles_act, 512, lds_split, s>>>(g, par);
+          else
+            cde::dopri5_attempt_mfma<CDE_PATH_LINEAR, CDE_ACT_NONE, false, cde::MC, true><<<(unsigned)tiles_act, 512, lds_split, s>>>(g, par);
+        } else if (degree == CDE_PATH_CUBIC) cde::dopri5_attempt_mfma<CDE_PATH_CUBIC, CDE_ACT_NONE><<<grid, 512, lds, s>>>(g, par);
         else cde::dopri5_attempt_mfma<CDE_PATH_LINEAR, CDE_ACT_NONE><<<grid, 512, lds, s>>>(g, par);
       } else {
         if (split_act) {                        // at most one tile per CU: the 8 waves of a workgroup share it
