@@ -1233,26 +1233,29 @@ static int dopri5_advance_impl(const void* coeffs, const void* knots, int64_t n_
     const int64_t tiles_act = (B + 15) / 16;
     const bool split_act = tiles_act <= 256 && !ext_sums && B_global == 0 && !getenv("CDE_K4_NO_SPLIT");
     const size_t lds_split = lds + (size_t)8 * 64 * 9 * sizeof(float);
-    for (int64_t i = 0; i < n_launches; ++i) {
-      const int par = (int)((first_launch + i) & 1);
-      if (act == CDE_ACT_NONE) {
-        if (split_act) {
-          if (degree == CDE_PATH_CUBIC)
-            cde::dopri5_attempt_mfma<CDE_PATH_CUBIC, CDE_ACT_NONE, false, cde::MC, true><<<(unsigned)tiles_act, 512, lds_split, s>>>(g, par);
-          else
-            cde::dopri5_attempt_mfma<CDE_PATH_LINEAR, CDE_ACT_NONE, false, cde::MC, true><<<(unsigned)tiles_act, 512, lds_split, s>>>(g, par);
-        } else if (degree == CDE_PATH_CUBIC) cde::dopri5_attempt_mfma<CDE_PATH_CUBIC, CDE_ACT_NONE><<<grid, 512, lds, s>>>(g, par);
-        else cde::dopri5_attempt_mfma<CDE_PATH_LINEAR, CDE_ACT_NONE><<<grid, 512, lds, s>>>(g, par);
-      } else {
-        if (split_act) {                        // at most one tile per CU: the 8 waves of a workgroup share it
-          if (degree == CDE_PATH_CUBIC)
-            cde::dopri5_attempt_mfma<CDE_PATH_CUBIC, CDE_ACT_TANH, false, cde::MC, true><<<(unsigned)tiles_act, 512, lds_split, s>>>(g, par);
-          else
-            cde::dopri5_attempt_mfma<CDE_PATH_LINEAR, CDE_ACT_TANH, false, cde::MC, true><<<(unsigned)tiles_act, 512, lds_split, s>>>(g, par);
-        } else if (degree == CDE_PATH_CUBIC) cde::dopri5_attempt_mfma<CDE_PATH_CUBIC, CDE_ACT_TANH><<<grid, 512, lds, s>>>(g, par);
-        else cde::dopri5_attempt_mfma<CDE_PATH_LINEAR, CDE_ACT_TANH><<<grid, 512, lds, s>>>(g, par);
-      }
+    // every form may ask for more than the 64 KB a kernel gets by default (knot buffer up to 32 KB + the 33.8 KB tanh
+    // image + the split forms' 18 KB exchange window): the limit is raised per instantiation, as for the other families
+#define CDE_K4_ONE(D, A)                                                                                           \
+  do {                                                                                                             \
+    if (split_act) {                                                                                               \
+      (void)hipFuncSetAttribute((const void*)cde::dopri5_attempt_mfma<D, A, false, cde::MC, true>,                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split);                       \
+      for (int64_t i = 0; i < n_launches; ++i)                                                                     \
+        cde::dopri5_attempt_mfma<D, A, false, cde::MC, true><<<(unsigned)tiles_act, 512, lds_split, s>>>(          \
+            g, (int)((first_launch + i) & 1));                                                                     \
+    } else {                                                                                                       \
+      (void)hipFuncSetAttribute((const void*)cde::dopri5_attempt_mfma<D, A>,                                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                             \
+      for (int64_t i = 0; i < n_launches; ++i)                                                                     \
+        cde::dopri5_attempt_mfma<D, A><<<grid, 512, lds, s>>>(g, (int)((first_launch + i) & 1));                   \
+    }                                                                                                              \
+  } while (0)
+    if (act == CDE_ACT_NONE) {
+      if (degree == CDE_PATH_CUBIC) CDE_K4_ONE(CDE_PATH_CUBIC, CDE_ACT_NONE); else CDE_K4_ONE(CDE_PATH_LINEAR, CDE_ACT_NONE);
+    } else {
+      if (degree == CDE_PATH_CUBIC) CDE_K4_ONE(CDE_PATH_CUBIC, CDE_ACT_TANH); else CDE_K4_ONE(CDE_PATH_LINEAR, CDE_ACT_TANH);
     }
+#undef CDE_K4_ONE
     return cde::check_launch();
   }
   if (dtype == CDE_F32) CDE_DOPRI(float);

@@ -410,7 +410,10 @@ MadjLayout madj_layout(int64_t B, int64_t H) {
   using namespace cde;
   MadjLayout L;
   L.n_tiles = (B + 15) / 16;
-  L.nwave = L.n_tiles > 1024 ? 8 : 4;              // 16384 series fill the GPU's 1024 SIMDs with one wave each
+  // 16384 series fill the GPU's 1024 SIMDs with one wave each; CDE_K4AM_WAVES=8 runs the large-batch form on any batch
+  // (tests: the 8-wave kernel at a size the CPU oracle can follow)
+  const char* force_waves = getenv("CDE_K4AM_WAVES");
+  L.nwave = (L.n_tiles > 1024 || (force_waves && force_waves[0] == '8')) ? 8 : 4;
   // up to MADJ_SPLIT_MAX_TILES tiles (one workgroup per CU in a single round): four waves per tile, the evaluation's middle
   // split four ways
   L.split = L.n_tiles <= MADJ_SPLIT_MAX_TILES && !getenv("CDE_K4AM_NO_SPLIT");
