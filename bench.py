@@ -46,9 +46,28 @@ PEAK_F32_MFMA_TFLOPS = 157.3
 FLOP_ADJ_K3J_MFMA = N_EVAL * ((2 * H * H * C + 2 * H * C) + 2 * H * C * H)            # 16.9 MFLOP
 FLOP_ADJ_K3J_VALU = N_EVAL * (2 * 2 * H * H + H * C)                                   # 2.2 MFLOP
 PEAK_HBM_GBS = 8000.0
-# HBM bytes per launch of the dominant kernel from rocprofv3 counter passes (see roofline.traffic_source); keyed by the
-# per-GPU batch the pass was run at, None where no pass exists
-ADJOINT_HBM_BYTES_PER_LAUNCH = {32768: int(2 * 268.9e6 + 37.9e6), 4096: int(2 * 33.87e6 + 8.96e6)}
+
+
+def adjoint_hbm_traffic(kernel_substring):
+    """HBM bytes per launch of the dominant kernel, read from the newest profiles/r*_pmc_summary.csv that holds a row for it
+    (separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes, scripts/pmc_passes.sh + scripts/pmc_summary.py;
+    FETCH_SIZE doubled: gfx950 tallies the 128-byte requests of 16 B/lane reads at 64 bytes, MI355X_MICROARCH.md "HBM").
+    Returns (bytes or None, source string or None)."""
+    import csv
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv")), reverse=True):
+        try:
+            with open(path, newline="") as fh:
+                for row in csv.DictReader(fh):
+                    if kernel_substring in row.get("kernel", "") and row.get("fetch_KB_raw") and row.get("write_KB_raw"):
+                        fetch, write = float(row["fetch_KB_raw"]) * 1e3, float(row["write_KB_raw"]) * 1e3
+                        return int(2 * fetch + write), (
+                            "profiles/%s, row %s: 2 x %.1f MB FETCH_SIZE (gfx950 half-count correction for 16 B/lane reads) + "
+                            "%.1f MB WRITE_SIZE, separate --pmc passes" % (os.path.basename(path), row["kernel"], fetch / 1e6,
+                                                                          write / 1e6))
+        except (OSError, ValueError):
+            continue
+    return None, None
 
 
 def make_workload(device, seed, n=None, first=0, count=None):
@@ -120,16 +139,6 @@ def cpu_baseline(max_sample, budget_s=20.0):
                       "(min %.2f s), the fastest of {8,16,32,64} threads (%d cores available); container-side figure "
                       "with the reference's own CubicSpline/_VectorField classes: profiles/r02_cpu_reference_container"
                       ".json" % (sample, B, L, times[1], times[0], avail)}
-
-
-TRAFFIC_SOURCE = {
-    32768: "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload (profiles/r02_k3_traffic_summary.csv, same "
-           "as r01): 2 x 268.9 MB fetched (gfx950 half-count correction for 16 B/lane reads) + 37.9 MB written; "
-           "algorithmic bytes: 32768 x 12,704 B = 416 MB (whole 128 B rows: 550 MB)",
-    4096: "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of rk4_adjoint_split8 at 4096 series "
-          "(profiles/r02_split_pmc_summary.csv): 2 x 33.9 MB fetched + 9.0 MB written (8.7 MB of it the 256 per-tile "
-          "parameter-gradient partials); algorithmic bytes: 4096 x 12,704 B = 52 MB",
-}
 
 
 def strong_scaling_proxy(cde, x, func, z0, full_ms):
@@ -666,20 +675,23 @@ def main():
     if rank == 0:
         total_series = B * world * args.steps
         value = total_series / elapsed
-        achieved = B * FLOP_ADJ / (adj_avg * 1e-3) / 1e12 if adj_avg > 0 else 0.0
         split = B <= 16384                      # CDE_SPLIT_MAX_BATCH: workgroup-per-tile kernels below, K2/K3 above
-        jacobian = not split and not os.environ.get("CDE_K3_FORM", "").startswith("p")
-        kernel = "rk4_adjoint_split8 (K3s)" if split else "rk4_adjoint_jacobian (K3j)" if jacobian else "rk4_adjoint_mfma (K3)"
-        executed = None
-        if jacobian and adj_avg > 0:
-            mfma_tf = B * FLOP_ADJ_K3J_MFMA / (adj_avg * 1e-3) / 1e12
-            executed = {"mfma_flop_per_launch": B * FLOP_ADJ_K3J_MFMA, "valu_flop_per_launch": B * FLOP_ADJ_K3J_VALU,
-                        "mfma_tflops": mfma_tf, "mfma_frac_of_peak": mfma_tf / PEAK_F32_MFMA_TFLOPS,
-                        "note": "`achieved` counts the ALGORITHMIC flop of the reference formulation (SURVEY 8(d): 50,432 per "
-                                "series and stage, three GEMMs); K3j executes 33,280 of them on the matrix pipe and 4,352 on "
-                                "the vector pipe (f and a^T df/dz share the Jacobian J = sum_c dX_c W_c), so `frac` can "
-                                "exceed what the matrix pipe alone would allow; mfma_frac_of_peak is the executed share"}
-        traffic = ADJOINT_HBM_BYTES_PER_LAUNCH.get(B)
+        jacobian = not os.environ.get("CDE_K3_FORM", "").startswith("p")
+        kernel = ("rk4_adjoint_split8" if split else "rk4_adjoint_jacobian" if jacobian else "rk4_adjoint_mfma")
+        # `achieved` = the flop the kernel's formulation EXECUTES per launch / its average duration.  The default kernels of
+        # the affine field take f AND a^T df/dz from the shared Jacobian J = sum_c dX_c W_c: per series and evaluation
+        # 33,280 flop on the matrix pipe (J with its bias rows, dL/dW) + 4,352 on the vector pipe (two H x H matrix-vector
+        # products, dL/db) = 37,632 -- not the 50,432 of the reference's three-GEMM formulation, which is kept
+        # beside it as `reference_formulation_*` (the rate a kernel of that formulation would need for the same duration).
+        flop_exec = B * (FLOP_ADJ_K3J_MFMA + FLOP_ADJ_K3J_VALU) if jacobian else B * FLOP_ADJ
+        flop_mfma = B * FLOP_ADJ_K3J_MFMA if jacobian else B * (FLOP_ADJ - N_EVAL * (H * C + 4 * H * C))
+        sec = adj_avg * 1e-3
+        achieved = flop_exec / sec / 1e12 if adj_avg > 0 else 0.0
+        mfma_tf = flop_mfma / sec / 1e12 if adj_avg > 0 else 0.0
+        ref_tf = B * FLOP_ADJ / sec / 1e12 if adj_avg > 0 else 0.0
+        traffic, traffic_source = adjoint_hbm_traffic(kernel)
+        if B != (4096 if split else 32768):
+            traffic, traffic_source = None, None          # the counter passes were run at 32768 series (K3j / K3) and 4096 (K3s)
         result = {
             "metric": "series/sec (fwd+adjoint) for cdeint RK4, batch=32k L=128 C=8 H=32",
             "value": value,
@@ -703,9 +715,15 @@ def main():
                                                                   "33 KB gradient all-reduce per step" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                         "traffic_source": TRAFFIC_SOURCE.get(B),
-                         "kernel": kernel, "kernel_ms": adj_avg,
-                         "algorithmic_flop_per_launch": B * FLOP_ADJ, "executed": executed},
+                         "mfma_frac": mfma_tf / PEAK_F32_MFMA_TFLOPS, "mfma_tflops": mfma_tf,
+                         "kernel": kernel + {"rk4_adjoint_split8": " (K3s)", "rk4_adjoint_jacobian": " (K3j)",
+                                             "rk4_adjoint_mfma": " (K3)"}[kernel],
+                         "kernel_ms": adj_avg, "executed_flop_per_launch": flop_exec,
+                         "formulation": ("shared Jacobian: 33,280 MFMA + 4,352 VALU flop per series and evaluation" if jacobian
+                                         else "three GEMMs: 50,432 flop per series and evaluation (SURVEY 8(d))"),
+                         "reference_formulation_flop": B * FLOP_ADJ, "reference_formulation_tflops": ref_tf,
+                         "traffic_source": traffic_source,
+                         "algorithmic_bytes_per_launch": B * 12704},
             "extra": {
                 "forward_kernel_ms": fwd_avg,
                 "forward_tflops": B * FLOP_FWD / (fwd_avg * 1e-3) / 1e12 if fwd_avg > 0 else None,
