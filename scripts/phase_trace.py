@@ -34,6 +34,9 @@ NAMES = {
     "k4a": ["entry", "ctrl loaded", "pending sums reduced", "controller + scalars", "weights in registers / first state requested",
             "tile 1 (7 stages)", "tile 2", "tile 3", "tile 4", "tile 5", "tile 6", "tile 7", "tile 8", "helper images stored (join)",
             "workgroup sum"],
+    "k4am": ["entry", "LDS images + pending sums reduced", "controller + scalars", "state / W1^T / first row in registers",
+             "stage 1", "stage 2", "stage 3", "stage 4", "stage 5", "stage 6", "stage 7", "error sums + state stores",
+             "workgroup sum"],
 }
 
 
@@ -103,10 +106,42 @@ def report_stage(ring, n_blocks):
         print("    %-70s %6.2f" % (name, med(slot)))
 
 
+def report_eval(ring, n_blocks):
+    """K4am: inside the evaluation of stage 4 (slots 13..16 since slot 6 = end of stage 3)."""
+    us = 0.01
+    rows = [r for r in range(RING) if (ring[r, :n_blocks, 13] > 0).all() and (ring[r, :n_blocks, 16] > 0).all()]
+    if not rows:
+        return
+    t = ring[rows][:, :n_blocks, :]
+    print("  inside the evaluation of stage 4, wave 0 (median over workgroups and attempts):")
+    for name, a, b in (("stage combination + control -> layer 1 done", 6, 13), ("layer 2 / activation / dL/dY2 / gu (this wave's groups)", 13, 14),
+                       ("all-reduce of gu, f, kt over the four waves", 14, 15), ("dL/dY1, va = W1^T dL/dY1", 15, 16),
+                       ("slopes stored, end of stage", 16, 7)):
+        print("    %-62s %6.2f" % (name, us * np.median(t[:, :, b] - t[:, :, a])))
+
+
+def main_k4am(B):
+    from helpers import TwoLayerField
+    dev = torch.device("cuda", 0)
+    x = make_series(B, 128, 8, seed=0).to(dev)
+    X = cde.CubicSpline(cde.hermite_cubic_coefficients_with_backward_differences(x))
+    func = TwoLayerField(32, 8, 128, seed=0).to(dev)
+    z = torch.randn(B, 32, generator=torch.Generator().manual_seed(0)).to(dev).requires_grad_(True)
+    out = cde.cdeint(X, func, z, X.interval, adjoint_options=dict(norm="seminorm"))
+    out[:, -1].sum().backward()
+    torch.cuda.synchronize()
+    n_blocks = min(BLOCKS, (B + 15) // 16)
+    ring = read_ring("k4am")
+    report("k4am", ring, n_blocks)
+    report_eval(ring, n_blocks)
+
+
 def main():
     _lib.build()
     which = sys.argv[1] if len(sys.argv) > 1 else "k4"
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
+    if which == "k4am":
+        return main_k4am(B)
     dev = torch.device("cuda", 0)
     x = make_series(B, 128, 8, seed=0).to(dev)
     X = cde.LinearInterpolation(cde.linear_interpolation_coeffs(x))

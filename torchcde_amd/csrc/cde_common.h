@@ -5,6 +5,7 @@
 // stage combinations, output interpolation) the kernels reproduce that sequence literally;
 // fused multiply-adds appear only where written explicitly (dot products, MFMA).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -155,6 +156,19 @@ static inline int zero_async(void* p, size_t bytes, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------ phase trace (debug builds)
+// A runtime stage number as a compile-time constant: `fn(std::integral_constant<int, i>{})` for i in 0..6.  Lets a ROLLED
+// stage loop (small enough for the instruction cache) index register-resident arrays and Butcher rows statically.
+#define CDE_STATIC_STAGE(i, fn)                                                                                       \
+  switch (i) {                                                                                                        \
+    case 0: fn(std::integral_constant<int, 0>{}); break;                                                              \
+    case 1: fn(std::integral_constant<int, 1>{}); break;                                                              \
+    case 2: fn(std::integral_constant<int, 2>{}); break;                                                              \
+    case 3: fn(std::integral_constant<int, 3>{}); break;                                                              \
+    case 4: fn(std::integral_constant<int, 4>{}); break;                                                              \
+    case 5: fn(std::integral_constant<int, 5>{}); break;                                                              \
+    default: fn(std::integral_constant<int, 6>{}); break;                                                             \
+  }
+
 // CDE_PHASE_TRACE=1 builds libcde_mi355x_trace.so (torchcde_amd/_lib.py): the attempt kernels stamp the 100 MHz
 // wall clock (s_memrealtime: one time base for the whole chip) at their phase boundaries, wave 0 of every workgroup
 // writes its stamps to a ring indexed by the attempt number, and scripts/phase_trace.py turns the ring into the

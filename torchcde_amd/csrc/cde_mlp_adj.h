@@ -65,7 +65,14 @@ __device__ __forceinline__ void mlp_adjoint_eval(const float* lds_base, const fl
                                                  const float (&as)[8], const float (&dX)[CT], const float (&d2X)[CT],
                                                  bool stream, float* urow, float* zrow, float* g2row, float* g1row, int Hr,
                                                  f32x4& fa, f32x4& fb, f32x4& va, f32x4& vb, float& kt, int pw = 0,
-                                                 float* xbuf = nullptr) {
+                                                 float* xbuf = nullptr, const float4* w1t_regs = nullptr,
+                                                 bool stamp_on = false, unsigned long long* stamp = nullptr) {
+#ifdef CDE_PHASE_TRACE
+#define CDE_EVAL_STAMP(slot, ...) do { if (stamp_on) { asm volatile("s_nop 0" : __VA_ARGS__); __builtin_amdgcn_sched_barrier(0); \
+                                       stamp[slot] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define CDE_EVAL_STAMP(slot, ...) do { (void)stamp; (void)stamp_on; } while (0)
+#endif
   constexpr int NB = CT / 4, NP = 16 / NB;      // channel blocks per unit group, unit groups (of 4 hidden units)
   const bool writer = !SPLIT || pw == 0;        // the wave that streams the factor rows every wave holds (U, Z, G1)
   int opaque = 0;                                                // keeps the LDS reads inside the evaluation
@@ -77,6 +84,8 @@ __device__ __forceinline__ void mlp_adjoint_eval(const float* lds_base, const fl
   const float* w2y = w2p + w2y_off;
   const float* w2g[4] = {w2p + w2g_off[0], w2p + w2g_off[1], w2p + w2g_off[2], w2p + w2g_off[3]};
   const float4* w1t = w1t_base + opaque;                         // L2-resident image: same trick against LICM
+  // (SPLIT: one wave per SIMD owns the whole register file, so the caller keeps the 16 float4 of the W1^T image in
+  //  registers for the launch -- `w1t_regs`, indexed by compile-time constants only -- instead of 16 L2 loads per call)
 
   // ---- layer 1: u = relu(W1 z + b1); `mask` bit s2 = (pre-activation of the lane's s2-th hidden unit > 0)
   float u[32];
@@ -105,6 +114,7 @@ __device__ __forceinline__ void mlp_adjoint_eval(const float* lds_base, const fl
     for (int m = 0; m < 8; ++m) if (4 * m + q < Hr) zrow[4 * m + q] = zs[m];
   }
 
+  CDE_EVAL_STAMP(0, "+v"(u[0]), "+v"(u[31]));
   __builtin_amdgcn_sched_barrier(0);
   // ---- layer 2, activation, contraction, dL/dY2, and gu += W2^T dL/dY2, one tile pair at a time
   f32x4 gu[8];
@@ -112,9 +122,12 @@ __device__ __forceinline__ void mlp_adjoint_eval(const float* lds_base, const fl
   for (int T1 = 0; T1 < 8; ++T1) gu[T1] = f32x4{0.f, 0.f, 0.f, 0.f};
   fa = f32x4{0.f, 0.f, 0.f, 0.f}; fb = fa;
   kt = 0.f;
+  // SPLIT: a REAL loop over the wave's unit groups (round 4; the rolled stage loop of the caller then is ~10 KB of code).
+  // Every address below is affine in P; only as[P] and the slot of f need a select chain on the (wave-uniform) P.
+  auto group = [&](int P) {                                      // unit group P: 4 hidden units x CT channels = NB tiles
+    float as_P = as[0];
 #pragma unroll
-  for (int P = 0; P < NP; ++P) {                                 // unit group P: 4 hidden units x CT channels = NB tiles
-    if (SPLIT && P / (NP / 4) != pw) continue;                   // (wave-uniform: another wave's group)
+    for (int kk = 1; kk < NP; ++kk) as_P = P == kk ? as[kk] : as_P;
     f32x4 y[NB];
     const float* tp_[NB];
 #pragma unroll
@@ -150,11 +163,12 @@ __device__ __forceinline__ void mlp_adjoint_eval(const float* lds_base, const fl
         f = c == 0 ? t * dX[0] : __builtin_fmaf(t, dX[c], f);
         if (TGRAD) h2 = __builtin_fmaf(t, d2X[c], h2);
         const float slope = ACT == CDE_ACT_TANH ? __builtin_fmaf(-t, t, 1.f) : 1.f;
-        g2[c] = as[P] * (dX[c] * slope);
+        g2[c] = as_P * (dX[c] * slope);
       }
     }
-    if (P < 4) fa[P] = f; else fb[P - 4] = f;
-    if (TGRAD) kt = __builtin_fmaf(as[P], h2, kt);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { fa[kk] = P == kk ? f : fa[kk]; fb[kk] = P == 4 + kk ? f : fb[kk]; }
+    if (TGRAD) kt = __builtin_fmaf(as_P, h2, kt);
     if (stream) {
       float* grow = g2row + 4 * CT * P;                          // rows (h = 4P+q, c = 0..CT-1) of the padded layout
 #pragma unroll
@@ -167,8 +181,17 @@ __device__ __forceinline__ void mlp_adjoint_eval(const float* lds_base, const fl
       for (int T1 = 0; T1 < 8; ++T1) gu[T1] = mfma16(rowp[16 * T1], g2[c], gu[T1]);
     }
     __builtin_amdgcn_sched_barrier(0);
+  };
+  if constexpr (SPLIT) {
+    const int P_first = pw * (NP / 4);
+#pragma clang loop unroll(disable)
+    for (int P = P_first; P < P_first + NP / 4; ++P) group(P);
+  } else {
+#pragma unroll
+    for (int P = 0; P < NP; ++P) group(P);
   }
 
+  CDE_EVAL_STAMP(1, "+v"(gu[0]), "+v"(gu[7]));
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (SPLIT) {
     // ---- the four waves' shares of gu, f and kt meet: afterwards every wave holds the complete values
@@ -178,6 +201,7 @@ __device__ __forceinline__ void mlp_adjoint_eval(const float* lds_base, const fl
     mlp_split_allreduce(xbuf, pw, lane, gu[6], gu[7], nullptr);
     mlp_split_allreduce(xbuf, pw, lane, fa, fb, &kt);
   }
+  CDE_EVAL_STAMP(2, "+v"(gu[0]), "+v"(gu[7]));
   // ---- dL/dY1 = gu * relu'(pre1);  va = W1^T dL/dY1
   float g1[32];
 #pragma unroll
@@ -190,13 +214,163 @@ __device__ __forceinline__ void mlp_adjoint_eval(const float* lds_base, const fl
   va = f32x4{0.f, 0.f, 0.f, 0.f}; vb = va;
 #pragma unroll
   for (int T1 = 0; T1 < 8; ++T1) {
-    const float4 a0 = w1t[T1 * 64], a1 = w1t[(8 + T1) * 64];
+    const float4 a0 = SPLIT ? w1t_regs[T1] : w1t[T1 * 64], a1 = SPLIT ? w1t_regs[8 + T1] : w1t[(8 + T1) * 64];
     va = mfma16(a0.x, g1[4 * T1], va);     vb = mfma16(a1.x, g1[4 * T1], vb);
     va = mfma16(a0.y, g1[4 * T1 + 1], va); vb = mfma16(a1.y, g1[4 * T1 + 1], vb);
     va = mfma16(a0.z, g1[4 * T1 + 2], va); vb = mfma16(a1.z, g1[4 * T1 + 2], vb);
     va = mfma16(a0.w, g1[4 * T1 + 3], va); vb = mfma16(a1.w, g1[4 * T1 + 3], vb);
   }
+  CDE_EVAL_STAMP(3, "+v"(va), "+v"(vb));
   __builtin_amdgcn_sched_barrier(0);
+#undef CDE_EVAL_STAMP
+}
+
+// SPLIT8 (round 4; CT = 8): the EIGHT waves of a workgroup (two per SIMD) evaluate the same 16 series and split EVERYTHING:
+// wave w owns hidden-layer tile T1 = w (units 16w .. 16w+15) and unit group P = w (hidden units 4w .. 4w+3 of z).
+//   layer 1   8 MFMAs  -> u for its 16 units                  -> all-gather of u            (xb, 8 KB, one barrier)
+//   layer 2  64 MFMAs  -> Y2 of its group, activation, f_h, dL/dY2 (g2)  -> all-gather of g2   (xa, 16 KB, one barrier)
+//   gu       64 MFMAs  -> (W2^T dL/dY2) for ITS 16 units over all 256 rows: complete, nothing to reduce
+//   va        8 MFMAs  -> W1^T dL/dY1 over its 16 units: a partial of all 32 outputs -> all-reduce (xa / xb, two barriers)
+// and of the adjoint state a wave carries only ITS unit (a_{4w+q}): the a half of the slope ring is 7 registers, not 56.
+// 144 MFMAs per wave and evaluation instead of 384 (four waves) / 1152 (one), a quarter of the vector work per wave, and the
+// second wave of each SIMD fills the issue slots the first one leaves (a single wave overlaps nothing with its own MFMAs:
+// profiles/r01_mfma_issue_ubench.txt; profiles/r04_phase_k4am_*.log: the four-wave form spent 14 us per evaluation on
+// 5.1 us of MFMA work).  Every wave ends with the same f, va, kt (fixed summation order), so the RK bookkeeping around
+// the call stays redundant and bit-identical.  The W1 / W1^T tiles a wave needs are 4 float4 in registers; the 16 KB the
+// W1 image occupied in LDS is the exchange window `xa`.
+template <int ACT, bool TGRAD>
+__device__ __forceinline__ void mlp_adjoint_eval_split8(const float* lds_base, float* xa, float* xb, int lane, int q, int w,
+                                                        const float4 (&w1r)[2], float4 b1r, const float4 (&w1tr)[2],
+                                                        int w2y_off, const int (&w2g_off)[4], const float (&zs)[8],
+                                                        float as_w, const float (&dX)[8], const float (&d2X)[8],
+                                                        bool stream, float* urow, float* zrow, float* g2row, float* g1row,
+                                                        int Hr, f32x4& fa, f32x4& fb, float& va_w, float& kt,
+                                                        bool stamp_on = false, unsigned long long* stamp = nullptr) {
+#ifdef CDE_PHASE_TRACE
+#define CDE_EVAL_STAMP(slot, ...) do { if (stamp_on) { asm volatile("s_nop 0" : __VA_ARGS__); __builtin_amdgcn_sched_barrier(0); \
+                                       stamp[slot] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define CDE_EVAL_STAMP(slot, ...) do { (void)stamp; (void)stamp_on; } while (0)
+#endif
+  constexpr int CT = 8;
+  const float* w2p = lds_base + W1M_FLOATS + B1M_FLOATS;
+  const float4* bb2 = reinterpret_cast<const float4*>(lds_base + W1M_FLOATS + B1M_FLOATS + W2P_FLOATS) + q;
+  // ---- layer 1, tile T1 = w: u = relu(W1 z + b1) for hidden-layer units 16w + 4q + r
+  f32x4 y1 = {b1r.x, b1r.y, b1r.z, b1r.w}, y1b = {0.f, 0.f, 0.f, 0.f};
+  {
+    const float a0[8] = {w1r[0].x, w1r[0].y, w1r[0].z, w1r[0].w, w1r[1].x, w1r[1].y, w1r[1].z, w1r[1].w};
+#pragma unroll
+    for (int s = 0; s < 8; s += 2) { y1 = mfma16(a0[s], zs[s], y1); y1b = mfma16(a0[s + 1], zs[s + 1], y1b); }
+  }
+  y1 = y1 + y1b;
+  float uo[4];
+  unsigned mask = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { uo[r] = fmaxf(y1[r], 0.f); mask |= (y1[r] > 0.f ? 1u : 0u) << r; }
+  *reinterpret_cast<float4*>(xb + (w * 64 + lane) * 4) = make_float4(uo[0], uo[1], uo[2], uo[3]);
+  if (stream) {
+    stream_store4(urow + 16 * w, uo[0], uo[1], uo[2], uo[3]);
+    if (w == 0) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) if (4 * m + q < Hr) zrow[4 * m + q] = zs[m];
+    }
+  }
+  __syncthreads();                                               // u of all 128 units is in xb
+  CDE_EVAL_STAMP(0, "+v"(uo[0]));
+
+  // ---- layer 2 for unit group P = w (tiles 2w, 2w+1), activation, contraction with dX, dL/dY2
+  f32x4 y[2];
+  const float* tp_[2];
+#pragma unroll
+  for (int tb = 0; tb < 2; ++tb) {
+    const float4 c0 = bb2[4 * (2 * w + tb)];
+    y[tb] = f32x4{c0.x, c0.y, c0.z, c0.w};
+    tp_[tb] = w2p + w2y_off + 2 * (2 * w + tb) * 8 * W2P_STRIDE;
+  }
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const float4 u4 = *reinterpret_cast<const float4*>(xb + (g * 64 + lane) * 4);
+    const float4 a0 = *reinterpret_cast<const float4*>(tp_[0] + 16 * g), a1 = *reinterpret_cast<const float4*>(tp_[1] + 16 * g);
+    y[0] = mfma16(a0.x, u4.x, y[0]); y[1] = mfma16(a1.x, u4.x, y[1]);
+    y[0] = mfma16(a0.y, u4.y, y[0]); y[1] = mfma16(a1.y, u4.y, y[1]);
+    y[0] = mfma16(a0.z, u4.z, y[0]); y[1] = mfma16(a1.z, u4.z, y[1]);
+    y[0] = mfma16(a0.w, u4.w, y[0]); y[1] = mfma16(a1.w, u4.w, y[1]);
+  }
+  float g2[CT];
+  float f = 0.f, h2 = 0.f;
+#pragma unroll
+  for (int tb = 0; tb < 2; ++tb) {
+    const f32x2 t01 = activate2<ACT>(y[tb][0], y[tb][1]), t23 = activate2<ACT>(y[tb][2], y[tb][3]);
+    const float tv[4] = {t01[0], t01[1], t23[0], t23[1]};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = 4 * tb + r;
+      const float t = tv[r];
+      f = c == 0 ? t * dX[0] : __builtin_fmaf(t, dX[c], f);
+      if (TGRAD) h2 = __builtin_fmaf(t, d2X[c], h2);
+      const float slope = ACT == CDE_ACT_TANH ? __builtin_fmaf(-t, t, 1.f) : 1.f;
+      g2[c] = as_w * (dX[c] * slope);
+    }
+  }
+  const float kt_part = TGRAD ? as_w * h2 : 0.f;
+  *reinterpret_cast<float4*>(xa + ((2 * w + 0) * 64 + lane) * 4) = make_float4(g2[0], g2[1], g2[2], g2[3]);
+  *reinterpret_cast<float4*>(xa + ((2 * w + 1) * 64 + lane) * 4) = make_float4(g2[4], g2[5], g2[6], g2[7]);
+  if (stream) {
+    float* grow = g2row + 4 * CT * w;                            // rows (h = 4w+q, c = 0..7) of the padded layout
+    stream_store4(grow, g2[0], g2[1], g2[2], g2[3]);
+    stream_store4(grow + 4, g2[4], g2[5], g2[6], g2[7]);
+  }
+  __syncthreads();                                               // dL/dY2 of all 256 rows is in xa
+  CDE_EVAL_STAMP(1, "+v"(g2[0]));
+
+  // ---- gu = W2^T dL/dY2 for this wave's 16 hidden-layer units, over all 256 rows: K step (P', c)
+  f32x4 gua = {0.f, 0.f, 0.f, 0.f}, gub = gua;
+#pragma unroll
+  for (int Pp = 0; Pp < 8; ++Pp) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const float4 g4 = *reinterpret_cast<const float4*>(xa + ((2 * Pp + half) * 64 + lane) * 4);
+      const float* rowbase = w2p + 2 * (2 * Pp + half) * 8 * W2P_STRIDE + 16 * w;
+      gua = mfma16(rowbase[w2g_off[0]], g4.x, gua);
+      gub = mfma16(rowbase[w2g_off[1]], g4.y, gub);
+      gua = mfma16(rowbase[w2g_off[2]], g4.z, gua);
+      gub = mfma16(rowbase[w2g_off[3]], g4.w, gub);
+    }
+  }
+  const f32x4 gu = gua + gub;
+  // ---- dL/dY1 = gu * relu'(pre1) for its units; its share of va = W1^T dL/dY1
+  float g1[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) g1[r] = (mask >> r) & 1u ? gu[r] : 0.f;
+  if (stream) stream_store4(g1row + 16 * w, g1[0], g1[1], g1[2], g1[3]);
+  f32x4 pa = {0.f, 0.f, 0.f, 0.f}, pb = pa;
+  pa = mfma16(w1tr[0].x, g1[0], pa); pb = mfma16(w1tr[1].x, g1[0], pb);
+  pa = mfma16(w1tr[0].y, g1[1], pa); pb = mfma16(w1tr[1].y, g1[1], pb);
+  pa = mfma16(w1tr[0].z, g1[2], pa); pb = mfma16(w1tr[1].z, g1[2], pb);
+  pa = mfma16(w1tr[0].w, g1[3], pa); pb = mfma16(w1tr[1].w, g1[3], pb);
+  __syncthreads();                                               // every wave is done reading u (xb) and dL/dY2 (xa)
+  CDE_EVAL_STAMP(2, "+v"(pa), "+v"(pb));
+  *reinterpret_cast<float4*>(xa + ((2 * w + 0) * 64 + lane) * 4) = make_float4(pa[0], pa[1], pa[2], pa[3]);
+  *reinterpret_cast<float4*>(xa + ((2 * w + 1) * 64 + lane) * 4) = make_float4(pb[0], pb[1], pb[2], pb[3]);
+  *reinterpret_cast<float2*>(xb + (w * 64 + lane) * 2) = make_float2(f, kt_part);
+  __syncthreads();
+  // this wave's component of va (hidden unit 4w + q: entry w & 3 of half w >> 2), all of f, kt: fixed order over the waves
+  va_w = 0.f;
+  kt = 0.f;
+  float fs[8];
+  const float* mine = xa + ((w >> 2) * 64 + lane) * 4 + (w & 3);
+#pragma unroll
+  for (int ww = 0; ww < 8; ++ww) {
+    const float2 fk = *reinterpret_cast<const float2*>(xb + (ww * 64 + lane) * 2);
+    va_w += mine[2 * ww * 64 * 4];
+    fs[ww] = fk.x;
+    kt += fk.y;
+  }
+  fa = f32x4{fs[0], fs[1], fs[2], fs[3]};
+  fb = f32x4{fs[4], fs[5], fs[6], fs[7]};
+  __syncthreads();                                               // the windows are free for the next evaluation
+  CDE_EVAL_STAMP(3, "+v"(va_w));
+#undef CDE_EVAL_STAMP
 }
 
 // host side of the images (rk4_mlp_adjoint.hip)

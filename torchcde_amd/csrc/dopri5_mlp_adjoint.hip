@@ -52,24 +52,33 @@ struct MlpAdjArgs {
   float* U; float* G2; float* G1; float* Z;      // factor rows [slot][rows_per_stage]
   AdjCommon com;
   int n_wg_max;
+  int dbg;                          // CDE_K4AM_DBG (timing experiments only): bit 0 = no factor stores
 };
 
 // SPLIT (small batches: fewer tiles than SIMDs): the workgroup's four waves share ONE tile and split the middle of every
 // evaluation between them (cde_mlp_adj.h: mlp_adjoint_eval<..., SPLIT>); each wave keeps its own copy of the slope ring,
 // wave 0 alone stores state, streams the shared factor rows and contributes to the error sums.
 constexpr int MADJ_XBUF_FLOATS = 4 * 64 * 9;
+#ifdef CDE_PHASE_TRACE
+__device__ unsigned long long k4am_phase_trace[TRACE_RING * TRACE_BLOCKS * TRACE_SLOTS];
+#endif
 template <int DEGREE, int ACT, int CT, int NWAVE, bool SPLIT = false>
 __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adjoint_attempt(MlpAdjArgs g, int parity) {
-  static_assert(!SPLIT || NWAVE == 4, "the split form is four waves per tile");
+  static_assert(!SPLIT || NWAVE == 4, "this kernel's split form is four waves per tile (eight: dopri5_mlp_adjoint_attempt_s8)");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int p = parity, p2 = parity ^ 1;
+  CDE_STAMP_DECL;
+  CDE_STAMP(0);
   AdjCtrl k = *reinterpret_cast<const AdjCtrl*>(g.ctrl + p * ADJ_CTRL_STRIDE);
   DopriCtrl& c = k.c;
   if (c.phase == 4) {
     if (blockIdx.x == 0 && tid == 0) { k.commit = 0; k.mode = 3; *reinterpret_cast<AdjCtrl*>(g.ctrl + p2 * ADJ_CTRL_STRIDE) = k; }
     return;
   }
+#ifdef CDE_PHASE_TRACE
+  const int attempt_no = uni((int)(c.n_accept + c.n_reject));
+#endif
   {
     const float4* src = reinterpret_cast<const float4*>(g.img);
     float4* dst = reinterpret_cast<float4*>(lds);
@@ -103,6 +112,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
     }
   }
   block_total<MADJ_NSUM>(sum, red);                                // (also the barrier after the LDS image copy)
+  CDE_STAMP(1);
   const int phase_in = c.phase;
   const AdjPlan plan = adj_controller(g.com, k, sum, sum + ADJ_NS);
   const int mode = uni(plan.mode);
@@ -141,6 +151,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
 #pragma unroll
   for (int j = 0; j < 7; ++j) { wS[j] = uni(wS[j]); wE[j] = uni(wE[j]); }
   const float x_end = uni(plan.x_end);
+  CDE_STAMP(2);
 
   if (blockIdx.x == 0 && tid == 0) {                               // the controller block for the next launch / the R kernel
     c.phase = mode == 0 ? 1 : mode == 1 ? 2 : mode == 2 ? 3 : 4;
@@ -172,62 +183,150 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
       store_units4<4>(Sq + 0 * BH + series * Hr, ua, Hr, y0a); store_units4<4>(Sq + 0 * BH + series * Hr, ub, Hr, y0b);
       store_units4<4>(Sq + 1 * BH + series * Hr, ua, Hr, a0a); store_units4<4>(Sq + 1 * BH + series * Hr, ub, Hr, a0b);
     }
-    float4* ring = reinterpret_cast<float4*>(g.slopes) + ((SPLIT ? tile * 4 + pw : tile) * 7 * 4) * 64 + lane;      // [stage][4][64 lanes]
-    float vtS = 0.f, vtE = 0.f;
-
+    // the 7 x 16 stage slopes of a lane: a per-wave ring in global memory (L2-resident) when two waves share a SIMD; in the
+    // SPLIT form a wave has the SIMD's whole register file and keeps them in registers (every index below is a compile-time
+    // constant after unrolling) -- no L2 round trip per stage, and no global load left in the stage loop that would have to
+    // wait, through the in-order vmcnt, for the factor stores of the previous stage
+    float4* ring = reinterpret_cast<float4*>(g.slopes) + (tile * 7 * 4) * 64 + lane;      // [stage][4][64 lanes]
+    float4 rreg[SPLIT ? 28 : 1];
+    auto ring_get = [&](int j, int v) -> float4 { if constexpr (SPLIT) return rreg[j * 4 + v]; else return ring[(j * 4 + v) * 64]; };
+    auto ring_put = [&](int j, int v, float4 x) { if constexpr (SPLIT) rreg[j * 4 + v] = x; else ring[(j * 4 + v) * 64] = x; };
+    float4 w1tr[SPLIT ? 16 : 1];
+    if constexpr (SPLIT) {
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      if (i >= ns) continue;
-      // ---- the state handed to stage i: y0 + sum_j bc[i][j] k_j (slopes back from the ring)
-      f32x4 za = y0a, zb = y0b, sa = a0a, sb = a0b;
-      if (i > 0) {
+      for (int T1 = 0; T1 < 8; ++T1) { w1tr[T1] = w1t_base[T1 * 64]; w1tr[8 + T1] = w1t_base[(8 + T1) * 64]; }
+    }
+    float vtS = 0.f, vtE = 0.f;
+    // the control row of a stage is requested one stage ahead (SPLIT): its latency hides behind the previous evaluation
+    Row<DEGREE, CT> row_next;
+    if constexpr (SPLIT) row_next = load_row<DEGREE, CT>(g.coeffs, sc, g.n_intervals, sidx[0], Cr);
+#ifdef CDE_PHASE_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    CDE_STAMP(3);
+
+    // ---- one stage, given the state handed to it and its scalars: control, evaluation, slopes (returned in fa .. vb)
+#ifdef CDE_PHASE_TRACE
+    unsigned long long est[4] = {0, 0, 0, 0};
+#endif
+    auto stage = [&](int i, const f32x4& za, const f32x4& zb, const f32x4& sa, const f32x4& sb, const Row<DEGREE, CT>& row,
+                     int idx_i, float frac_i, float wS_i, float wE_i, f32x4& fa, f32x4& fb, f32x4& va, f32x4& vb) {
+      float dX[CT], d2X[CT];
+      {
+        const float width = DEGREE == CDE_PATH_LINEAR ? g.knots[idx_i + 1] - g.knots[idx_i] : 1.f;
+        control_slope<DEGREE, CT>(row, frac_i, width, dX);
+        const float* f = reinterpret_cast<const float*>(row.v);
+#pragma unroll
+        for (int cc = 0; cc < CT; ++cc)
+          d2X[cc] = DEGREE == CDE_PATH_CUBIC ? f[CT + cc] + 2.f * f[2 * CT + cc] * frac_i : 0.f;
+      }
+      const float zs[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
+      const float as[8] = {sa[0], sa[1], sa[2], sa[3], sb[0], sb[1], sb[2], sb[3]};
+      const bool stream = valid && (wS_i != 0.f || wE_i != 0.f) && !(g.dbg & 1);
+      const int64_t out_row = (int64_t)(mode <= 1 ? i : madj_slot(i)) * g.rows_per_stage + series;
+      float kt;
+      {
+        mlp_adjoint_eval<ACT, CT, DEGREE == CDE_PATH_CUBIC, SPLIT>(
+            lds, w1t_base, lane, n, q, w2y_off, w2g_off, zs, as, dX, d2X, stream, g.U + out_row * U_COLS + 4 * q,
+            g.Z + out_row * Z_COLS, g.G2 + out_row * G2_COLS + CT * q, g.G1 + out_row * G1_COLS + 4 * q, Hr, fa, fb, va, vb, kt,
+            pw, xbuf, w1tr
+#ifdef CDE_PHASE_TRACE
+            , i == 3, est
+#endif
+            );
+      }
+      if (DEGREE == CDE_PATH_CUBIC) { vtS = __builtin_fmaf(wS_i, kt, vtS); vtE = __builtin_fmaf(wE_i, kt, vtE); }
+    };
+
+    if constexpr (!SPLIT) {
+      // one wave per tile: fully unrolled (the slope ring lives in global memory, every index is static)
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        if (i >= ns) continue;
+        f32x4 za = y0a, zb = y0b, sa = a0a, sb = a0b;
+        if (i > 0) {
+          f32x4 ia = {0.f, 0.f, 0.f, 0.f}, ib = ia, ja = ia, jb = ia;
+#pragma unroll
+          for (int j = 0; j < i; ++j) {
+            const float wgt = bc[i][j];
+            const float4 k0 = ring_get(j, 0), k1 = ring_get(j, 1), k2 = ring_get(j, 2), k3 = ring_get(j, 3);
+            const f32x4 wv4 = {wgt, wgt, wgt, wgt};
+            ia = __builtin_elementwise_fma(f32x4{k0.x, k0.y, k0.z, k0.w}, wv4, ia);
+            ib = __builtin_elementwise_fma(f32x4{k1.x, k1.y, k1.z, k1.w}, wv4, ib);
+            ja = __builtin_elementwise_fma(f32x4{k2.x, k2.y, k2.z, k2.w}, wv4, ja);
+            jb = __builtin_elementwise_fma(f32x4{k3.x, k3.y, k3.z, k3.w}, wv4, jb);
+          }
+          za = y0a + ia; zb = y0b + ib; sa = a0a + ja; sb = a0b + jb;
+        }
+        const Row<DEGREE, CT> row = load_row<DEGREE, CT>(g.coeffs, sc, g.n_intervals, sidx[i], Cr);
+        f32x4 fa, fb, va, vb;
+        stage(i, za, zb, sa, sb, row, sidx[i], sfrac[i], wS[i], wE[i], fa, fb, va, vb);
+        ring_put(i, 0, make_float4(-fa[0], -fa[1], -fa[2], -fa[3]));
+        ring_put(i, 1, make_float4(-fb[0], -fb[1], -fb[2], -fb[3]));
+        ring_put(i, 2, make_float4(va[0], va[1], va[2], va[3]));
+        ring_put(i, 3, make_float4(vb[0], vb[1], vb[2], vb[3]));
+        CDE_STAMP(4 + i);
+      }
+    } else {
+      // Waves sharing a tile (round 4): a REAL loop.  The slope ring lives in registers, which only static indices can
+      // address, so the stage number enters through (wave-uniform) select chains instead: the Butcher row of stage i as six
+      // weights (zero for the slopes stage i does not use -- the ring starts out as zeros), the new slopes into slot i by
+      // 16 x 7 conditional moves.  The loop body is one evaluation: ~10 KB of code instead of the 200 KB of seven inlined
+      // evaluations, and the unit-group loop inside the four-wave evaluation is a real loop as well.
+#pragma unroll
+      for (int e = 0; e < 28; ++e) rreg[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma clang loop unroll(disable)
+      for (int i = 0; i < ns; ++i) {
+        int idx_i = sidx[0], idx_n = sidx[1];
+        float frac_i = sfrac[0], wS_i = wS[0], wE_i = wE[0];
+        float wj[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 1; kk < 7; ++kk) {
+          const bool at = i == kk;
+          idx_i = at ? sidx[kk] : idx_i; frac_i = at ? sfrac[kk] : frac_i; wS_i = at ? wS[kk] : wS_i; wE_i = at ? wE[kk] : wE_i;
+          if (kk < 6) idx_n = at ? sidx[kk + 1] : idx_n;
+#pragma unroll
+          for (int j = 0; j < 6; ++j) wj[j] = at ? bc[kk][j] : wj[j];
+        }
         f32x4 ia = {0.f, 0.f, 0.f, 0.f}, ib = ia, ja = ia, jb = ia;
 #pragma unroll
-        for (int j = 0; j < i; ++j) {
-          const float wgt = bc[i][j];
-          const float4 k0 = ring[(j * 4 + 0) * 64], k1 = ring[(j * 4 + 1) * 64], k2 = ring[(j * 4 + 2) * 64], k3 = ring[(j * 4 + 3) * 64];
-          const f32x4 wv4 = {wgt, wgt, wgt, wgt};
+        for (int j = 0; j < 6; ++j) {
+          const float4 k0 = rreg[4 * j], k1 = rreg[4 * j + 1], k2 = rreg[4 * j + 2], k3 = rreg[4 * j + 3];
+          const f32x4 wv4 = {wj[j], wj[j], wj[j], wj[j]};
           ia = __builtin_elementwise_fma(f32x4{k0.x, k0.y, k0.z, k0.w}, wv4, ia);
           ib = __builtin_elementwise_fma(f32x4{k1.x, k1.y, k1.z, k1.w}, wv4, ib);
           ja = __builtin_elementwise_fma(f32x4{k2.x, k2.y, k2.z, k2.w}, wv4, ja);
           jb = __builtin_elementwise_fma(f32x4{k3.x, k3.y, k3.z, k3.w}, wv4, jb);
         }
-        za = y0a + ia; zb = y0b + ib; sa = a0a + ja; sb = a0b + jb;
-      }
-      // ---- the control at the stage time (and, for vjp_t, its second derivative)
-      float dX[CT], d2X[CT];
-      {
-        const Row<DEGREE, CT> row = load_row<DEGREE, CT>(g.coeffs, sc, g.n_intervals, sidx[i], Cr);
-        const float width = DEGREE == CDE_PATH_LINEAR ? g.knots[sidx[i] + 1] - g.knots[sidx[i]] : 1.f;
-        control_slope<DEGREE, CT>(row, sfrac[i], width, dX);
-        const float* f = reinterpret_cast<const float*>(row.v);
+        const f32x4 za = y0a + ia, zb = y0b + ib, sa = a0a + ja, sb = a0b + jb;
+        const Row<DEGREE, CT> row = row_next;
+        if (i + 1 < ns) row_next = load_row<DEGREE, CT>(g.coeffs, sc, g.n_intervals, idx_n, Cr);
+        f32x4 fa, fb, va, vb;
+        stage(i, za, zb, sa, sb, row, idx_i, frac_i, wS_i, wE_i, fa, fb, va, vb);
+        const float4 n0 = make_float4(-fa[0], -fa[1], -fa[2], -fa[3]), n1 = make_float4(-fb[0], -fb[1], -fb[2], -fb[3]);
+        const float4 n2 = make_float4(va[0], va[1], va[2], va[3]), n3 = make_float4(vb[0], vb[1], vb[2], vb[3]);
+        auto pick = [](bool c, const float4& x, const float4& y) { return make_float4(c ? x.x : y.x, c ? x.y : y.y, c ? x.z : y.z, c ? x.w : y.w); };
 #pragma unroll
-        for (int cc = 0; cc < CT; ++cc)
-          d2X[cc] = DEGREE == CDE_PATH_CUBIC ? f[CT + cc] + 2.f * f[2 * CT + cc] * sfrac[i] : 0.f;
+        for (int kk = 0; kk < 7; ++kk) {
+          const bool at = i == kk;
+          rreg[4 * kk] = pick(at, n0, rreg[4 * kk]); rreg[4 * kk + 1] = pick(at, n1, rreg[4 * kk + 1]);
+          rreg[4 * kk + 2] = pick(at, n2, rreg[4 * kk + 2]); rreg[4 * kk + 3] = pick(at, n3, rreg[4 * kk + 3]);
+        }
+#ifdef CDE_PHASE_TRACE
+#pragma unroll
+        for (int kk = 0; kk < 7; ++kk) if (i == kk) CDE_STAMP(4 + kk);
+#endif
       }
-      const float zs[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
-      const float as[8] = {sa[0], sa[1], sa[2], sa[3], sb[0], sb[1], sb[2], sb[3]};
-      const bool stream = valid && (wS[i] != 0.f || wE[i] != 0.f);
-      const int64_t out_row = (int64_t)(mode <= 1 ? i : madj_slot(i)) * g.rows_per_stage + series;
-      f32x4 fa, fb, va, vb;
-      float kt;
-      mlp_adjoint_eval<ACT, CT, DEGREE == CDE_PATH_CUBIC, SPLIT>(
-          lds, w1t_base, lane, n, q, w2y_off, w2g_off, zs, as, dX, d2X, stream, g.U + out_row * U_COLS + 4 * q,
-          g.Z + out_row * Z_COLS, g.G2 + out_row * G2_COLS + CT * q, g.G1 + out_row * G1_COLS + 4 * q, Hr, fa, fb, va, vb, kt,
-          pw, xbuf);
-      if (DEGREE == CDE_PATH_CUBIC) { vtS = __builtin_fmaf(wS[i], kt, vtS); vtE = __builtin_fmaf(wE[i], kt, vtE); }
-      // ---- reverse-time slopes dy/ds = -f, da/ds = +a^T df/dz into the ring
-      ring[(i * 4 + 0) * 64] = make_float4(-fa[0], -fa[1], -fa[2], -fa[3]);
-      ring[(i * 4 + 1) * 64] = make_float4(-fb[0], -fb[1], -fb[2], -fb[3]);
-      ring[(i * 4 + 2) * 64] = make_float4(va[0], va[1], va[2], va[3]);
-      ring[(i * 4 + 3) * 64] = make_float4(vb[0], vb[1], vb[2], vb[3]);
     }
+#ifdef CDE_PHASE_TRACE
+    stamps_.t[13] = est[0]; stamps_.t[14] = est[1]; stamps_.t[15] = est[2]; stamps_.t[16] = est[3];
+#endif
 
     // ---- what this launch owes the controller (one more pass over the slopes)
     auto sq4f = [](const f32x4& v) { return (double)(v[0] * v[0]) + (double)(v[1] * v[1]) + (double)(v[2] * v[2]) + (double)(v[3] * v[3]); };
     auto abs4f = [](const f32x4& v) { return f32x4{fabsf(v[0]), fabsf(v[1]), fabsf(v[2]), fabsf(v[3])}; };
     auto max4f = [](const f32x4& a, const f32x4& b) { return f32x4{fmaxf(a[0], b[0]), fmaxf(a[1], b[1]), fmaxf(a[2], b[2]), fmaxf(a[3], b[3])}; };
-    auto slope = [&](int j, int v) { const float4 t = ring[(j * 4 + v) * 64]; return f32x4{t.x, t.y, t.z, t.w}; };
+    auto slope = [&](int j, int v) { const float4 t = ring_get(j, v); return f32x4{t.x, t.y, t.z, t.w}; };
     if (mode == 0) {
       const f32x4 sya = atol + abs4f(y0a) * rtol, syb = atol + abs4f(y0b) * rtol;       // Hairer's scale
       const f32x4 saa = atol + abs4f(a0a) * rtol, sab = atol + abs4f(a0b) * rtol;
@@ -291,12 +390,306 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
     }
     if (writer) { acc[4] = (double)vtS; acc[5] = (double)vtE; }
   }
+  CDE_STAMP(11);
   // ---- publish this launch's partial sums
+  block_total<ADJ_NS>(acc, red);
+  CDE_STAMP(12);
+  CDE_STAMP_FLUSH(k4am_phase_trace, attempt_no);
+  if (tid == 0) {
+#pragma unroll
+    for (int i = 0; i < ADJ_NS; ++i) Pq[ADJ_NS * blockIdx.x + i] = acc[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------ eight waves per tile (round 4)
+// The attempt kernel for SMALL batches (at most one 16-series tile per CU, i.e. up to 4096 series; CT = 8) -- the range the
+// reference's examples train in (batch_size = 32: example/time_series_classification.py:149).  Same controller, same
+// launch protocol and workspace as dopri5_mlp_adjoint_attempt; what differs is who does what inside a workgroup:
+//   * the EIGHT waves (two per SIMD) share one tile and split every evaluation eight ways (cde_mlp_adj.h:
+//     mlp_adjoint_eval_split8: 144 MFMAs per wave instead of 384 with four waves, a quarter of the vector work);
+//   * the stage loop is a real loop around ONE evaluation body (~10 KB of code; the four-wave form had seven inlined
+//     evaluations, 200 KB), the slope ring lives in registers, and of the adjoint state a wave carries only its own
+//     component a_{4w+q} -- 56 + 7 ring registers instead of 112, which is what lets two waves share a SIMD without spills;
+//   * wave 0 owns y (state stores, error sums), every wave its component of a.
+// profiles/r04_phase_k4am_*.log: the four-wave form spent 14 us per evaluation on 5.1 us of MFMA work -- one wave per SIMD
+// issues one instruction every ~5 cycles and overlaps nothing with its own MFMAs.
+template <int DEGREE, int ACT>
+__global__ __launch_bounds__(512, 2) void dopri5_mlp_adjoint_attempt_s8(MlpAdjArgs g, int parity) {
+  constexpr int CT = 8;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int p = parity, p2 = parity ^ 1;
+  CDE_STAMP_DECL;
+  CDE_STAMP(0);
+  AdjCtrl k = *reinterpret_cast<const AdjCtrl*>(g.ctrl + p * ADJ_CTRL_STRIDE);
+  DopriCtrl& c = k.c;
+  if (c.phase == 4) {
+    if (blockIdx.x == 0 && tid == 0) { k.commit = 0; k.mode = 3; *reinterpret_cast<AdjCtrl*>(g.ctrl + p2 * ADJ_CTRL_STRIDE) = k; }
+    return;
+  }
+#ifdef CDE_PHASE_TRACE
+  const int attempt_no = uni((int)(c.n_accept + c.n_reject));
+#endif
+  {
+    const float4* src = reinterpret_cast<const float4*>(g.img);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    for (int i = tid; i < ADJ_LDS_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
+  }
+  double* red = reinterpret_cast<double*>(lds + ADJ_LDS_FLOATS);
+  float* xb = lds + ADJ_LDS_FLOATS + 2 * MADJ_NSUM * 8;            // exchange window B (9 KB), behind `red`
+  float* xa = lds;                                                 // exchange window A: the W1 image's 16 KB, once it is in registers
+  const int Hr = g.dims.H, Cr = g.dims.C;
+  const int lane = tid & 63, w = tid >> 6;
+  const int n = lane & 15, q = lane >> 4;
+  const int64_t BH = g.B * Hr;
+  const float* Sp = g.state + (int64_t)p * 4 * BH;
+  float* Sq = g.state + (int64_t)p2 * 4 * BH;
+  const double* Pp = g.partial + (int64_t)p * g.n_wg_max * ADJ_NS;
+  double* Pq = g.partial + (int64_t)p2 * g.n_wg_max * ADJ_NS;
+  const float rtol = (float)g.com.rtol, atol = (float)g.com.atol;
+
+  // ---- pending sums, controller, stage scalars: as in dopri5_mlp_adjoint_attempt
+  double sum[MADJ_NSUM];
+#pragma unroll
+  for (int i = 0; i < MADJ_NSUM; ++i) sum[i] = 0.0;
+  if (c.phase != 0) {
+    for (int64_t b = tid; b < (int64_t)gridDim.x; b += blockDim.x) {
+#pragma unroll
+      for (int i = 0; i < ADJ_NS; ++i) sum[i] += Pp[ADJ_NS * b + i];
+    }
+    const double* Qp = g.pq + (int64_t)p * MADJ_RBLOCKS * 8;
+    for (int b = tid; b < MADJ_RBLOCKS; b += blockDim.x) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sum[ADJ_NS + i] += Qp[8 * b + i];
+    }
+  }
+  block_total<MADJ_NSUM>(sum, red);                                // (also the barrier after the LDS image copy)
+  CDE_STAMP(1);
+  const int phase_in = c.phase;
+  const AdjPlan plan = adj_controller(g.com, k, sum, sum + ADJ_NS);
+  const int mode = uni(plan.mode);
+  const bool commit = phase_in == 3 && plan.accept && mode != 3;
+  const int ns = mode == 0 ? 1 : mode == 1 ? 2 : 7;
+  const float t0f = uni((float)plan.t0), dtf = uni((float)plan.dt), t1f = uni((float)plan.t1);
+  int sidx[7];
+  float sfrac[7];
+  {
+    float ts = 0.f;
+    const int i = lane & 7;
+    if (mode == 0) ts = (float)c.t_hi;
+    else if (mode == 1) ts = i == 0 ? (float)c.t_hi : (float)(c.t_hi + (double)plan.h0);
+    else if (i == 0) ts = plan.kind0 == 0 ? t0f : next_toward(t0f, plan.kind0 > 0 ? 1.f : -1.f);
+    else if (i <= 4) ts = t0f + (float)DP_ALPHA[i - 1] * dtf;
+    else ts = next_toward(t1f, -1.f);
+    float frac;
+    const int idx = (int)locate_around(g.knots, g.n_intervals, -ts, phase_in == 0 ? (int64_t)-1 : (int64_t)c.slot, frac);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      sidx[j] = __builtin_amdgcn_readlane(idx, j);
+      sfrac[j] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(frac), j));
+    }
+  }
+  float bc[7][6];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) bc[i][j] = (i >= 1 && j < i) ? uni((float)DP_BETA[i - 1][j] * dtf) : 0.f;
+  }
+  if (mode == 1) bc[1][0] = uni(plan.h0);
+  float wS[7], wE[7];
+  adj_stage_weights(mode, dtf, plan.x_end, wS, wE);
+#pragma unroll
+  for (int j = 0; j < 7; ++j) { wS[j] = uni(wS[j]); wE[j] = uni(wE[j]); }
+  const float x_end = uni(plan.x_end);
+  CDE_STAMP(2);
+  if (blockIdx.x == 0 && tid == 0) {
+    c.phase = mode == 0 ? 1 : mode == 1 ? 2 : mode == 2 ? 3 : 4;
+    c.slot = sidx[0];
+    *reinterpret_cast<AdjCtrl*>(g.ctrl + p2 * ADJ_CTRL_STRIDE) = k;
+  }
+
+  double acc[ADJ_NS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  const int64_t tile = blockIdx.x;                                 // (the grid is exactly the tiles)
+  const int64_t series = tile * 16 + n;
+  const bool valid = series < g.B;
+  const int64_t sc = valid ? series : g.B - 1;
+  const bool writer = w == 0;
+  const int hw = 4 * w + q;                                        // the hidden unit whose adjoint component this lane carries
+  const bool own = valid && hw < Hr;
+  // the tiles of W1 / b1 (LDS image) and W1^T (L2) for hidden-layer units 16w .. 16w+15
+  float4 w1r[2], w1tr[2], b1r;
+  {
+    const float4* w1img = reinterpret_cast<const float4*>(lds) + lane;
+    w1r[0] = w1img[(2 * w) * 64]; w1r[1] = w1img[(2 * w + 1) * 64];
+    b1r = (reinterpret_cast<const float4*>(lds + W1M_FLOATS) + q)[4 * w];
+    const float4* w1t_base = reinterpret_cast<const float4*>(g.img + ADJ_LDS_FLOATS) + lane;
+    w1tr[0] = w1t_base[w * 64]; w1tr[1] = w1t_base[(8 + w) * 64];
+  }
+  const int w2y_off = ((n >> 3) * 8 + w2p_residue(n >> 2, n & 3)) * W2P_STRIDE + 4 * q;
+  int w2g_off[4];
+#pragma unroll
+  for (int cl = 0; cl < 4; ++cl) w2g_off[cl] = ((q >> 1) * 8 + w2p_residue(q, cl)) * W2P_STRIDE + n;
+  const int ua = q, ub = 16 + q;
+  const float* ysrc = phase_in == 0 ? g.y_init : Sp + (commit ? 2 : 0) * BH;
+  const float* asrc = phase_in == 0 ? g.a_init : Sp + (commit ? 3 : 1) * BH;
+  const f32x4 y0a = load_units4<4>(ysrc + sc * Hr, ua, Hr), y0b = load_units4<4>(ysrc + sc * Hr, ub, Hr);
+  const float a0 = own ? asrc[sc * Hr + hw] : 0.f;                 // a == 0 stays 0: padded lanes / units contribute nothing
+  if (mode != 3) {
+    if (valid && writer) {
+      store_units4<4>(Sq + 0 * BH + series * Hr, ua, Hr, y0a); store_units4<4>(Sq + 0 * BH + series * Hr, ub, Hr, y0b);
+    }
+    if (own) Sq[1 * BH + series * Hr + hw] = a0;
+  }
+  // the slope ring: dy/ds of all 8 units of this lane (2 float4 per stage), da/ds of the wave's own unit
+  float4 ry[14];
+  float ra[7];
+#pragma unroll
+  for (int e = 0; e < 14; ++e) ry[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int e = 0; e < 7; ++e) ra[e] = 0.f;
+  float vtS = 0.f, vtE = 0.f;
+#ifdef CDE_PHASE_TRACE
+  unsigned long long est[4] = {0, 0, 0, 0};
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  CDE_STAMP(3);
+
+#pragma clang loop unroll(disable)
+  for (int i = 0; i < ns; ++i) {
+    // the scalars of stage i and its Butcher row (zero for the slopes it does not use), by wave-uniform select chains
+    int idx_i = sidx[0];
+    float frac_i = sfrac[0], wS_i = wS[0], wE_i = wE[0];
+    float wj[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 1; kk < 7; ++kk) {
+      const bool at = i == kk;
+      idx_i = at ? sidx[kk] : idx_i; frac_i = at ? sfrac[kk] : frac_i; wS_i = at ? wS[kk] : wS_i; wE_i = at ? wE[kk] : wE_i;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) wj[j] = at ? bc[kk][j] : wj[j];
+    }
+    f32x4 ia = {0.f, 0.f, 0.f, 0.f}, ib = ia;
+    float ja = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const float4 k0 = ry[2 * j], k1 = ry[2 * j + 1];
+      const f32x4 wv4 = {wj[j], wj[j], wj[j], wj[j]};
+      ia = __builtin_elementwise_fma(f32x4{k0.x, k0.y, k0.z, k0.w}, wv4, ia);
+      ib = __builtin_elementwise_fma(f32x4{k1.x, k1.y, k1.z, k1.w}, wv4, ib);
+      ja = __builtin_fmaf(ra[j], wj[j], ja);
+    }
+    const f32x4 za = y0a + ia, zb = y0b + ib;
+    const float as_w = a0 + ja;
+    float dX[CT], d2X[CT];
+    {
+      const Row<DEGREE, CT> row = load_row<DEGREE, CT>(g.coeffs, sc, g.n_intervals, idx_i, Cr);
+      const float width = DEGREE == CDE_PATH_LINEAR ? g.knots[idx_i + 1] - g.knots[idx_i] : 1.f;
+      control_slope<DEGREE, CT>(row, frac_i, width, dX);
+      const float* f = reinterpret_cast<const float*>(row.v);
+#pragma unroll
+      for (int cc = 0; cc < CT; ++cc)
+        d2X[cc] = DEGREE == CDE_PATH_CUBIC ? f[CT + cc] + 2.f * f[2 * CT + cc] * frac_i : 0.f;
+    }
+    const float zs[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
+    const bool stream = valid && (wS_i != 0.f || wE_i != 0.f) && !(g.dbg & 1);
+    const int64_t out_row = (int64_t)(mode <= 1 ? i : madj_slot(i)) * g.rows_per_stage + series;
+    f32x4 fa, fb;
+    float va_w, kt;
+    mlp_adjoint_eval_split8<ACT, DEGREE == CDE_PATH_CUBIC>(
+        lds, xa, xb, lane, q, w, w1r, b1r, w1tr, w2y_off, w2g_off, zs, as_w, dX, d2X, stream, g.U + out_row * U_COLS + 4 * q,
+        g.Z + out_row * Z_COLS, g.G2 + out_row * G2_COLS + CT * q, g.G1 + out_row * G1_COLS + 4 * q, Hr, fa, fb, va_w, kt
+#ifdef CDE_PHASE_TRACE
+        , i == 3, est
+#endif
+        );
+    if (DEGREE == CDE_PATH_CUBIC) { vtS = __builtin_fmaf(wS_i, kt, vtS); vtE = __builtin_fmaf(wE_i, kt, vtE); }
+    // reverse-time slopes dy/ds = -f, da/ds = +a^T df/dz into slot i of the ring
+#pragma unroll
+    for (int kk = 0; kk < 7; ++kk) {
+      const bool at = i == kk;
+      ry[2 * kk] = make_float4(at ? -fa[0] : ry[2 * kk].x, at ? -fa[1] : ry[2 * kk].y, at ? -fa[2] : ry[2 * kk].z, at ? -fa[3] : ry[2 * kk].w);
+      ry[2 * kk + 1] = make_float4(at ? -fb[0] : ry[2 * kk + 1].x, at ? -fb[1] : ry[2 * kk + 1].y, at ? -fb[2] : ry[2 * kk + 1].z,
+                                   at ? -fb[3] : ry[2 * kk + 1].w);
+      ra[kk] = at ? va_w : ra[kk];
+    }
+#ifdef CDE_PHASE_TRACE
+#pragma unroll
+    for (int kk = 0; kk < 7; ++kk) if (i == kk) CDE_STAMP(4 + kk);
+#endif
+  }
+#ifdef CDE_PHASE_TRACE
+  stamps_.t[13] = est[0]; stamps_.t[14] = est[1]; stamps_.t[15] = est[2]; stamps_.t[16] = est[3];
+#endif
+
+  // ---- what this launch owes the controller: wave 0 the y block, every wave its component of a
+  auto sq4f = [](const f32x4& v) { return (double)(v[0] * v[0]) + (double)(v[1] * v[1]) + (double)(v[2] * v[2]) + (double)(v[3] * v[3]); };
+  auto abs4f = [](const f32x4& v) { return f32x4{fabsf(v[0]), fabsf(v[1]), fabsf(v[2]), fabsf(v[3])}; };
+  auto max4f = [](const f32x4& a, const f32x4& b) { return f32x4{fmaxf(a[0], b[0]), fmaxf(a[1], b[1]), fmaxf(a[2], b[2]), fmaxf(a[3], b[3])}; };
+  auto ys = [&](int j, int v) { const float4 t = ry[2 * j + v]; return f32x4{t.x, t.y, t.z, t.w}; };
+  auto sq1 = [](float v) { return (double)(v * v); };
+  const bool yw = valid && writer;
+  if (mode == 0) {
+    const f32x4 sya = atol + abs4f(y0a) * rtol, syb = atol + abs4f(y0b) * rtol;       // Hairer's scale
+    const float sa = atol + fabsf(a0) * rtol;
+    if (yw) { acc[0] = sq4f(y0a / sya) + sq4f(y0b / syb); acc[2] = sq4f(ys(0, 0) / sya) + sq4f(ys(0, 1) / syb); }
+    if (valid) { acc[1] = sq1(a0 / sa); acc[3] = sq1(ra[0] / sa); }
+  } else if (mode == 1) {
+    const f32x4 sya = atol + abs4f(y0a) * rtol, syb = atol + abs4f(y0b) * rtol;
+    const float sa = atol + fabsf(a0) * rtol;
+    if (yw) acc[0] = sq4f((ys(1, 0) - ys(0, 0)) / sya) + sq4f((ys(1, 1) - ys(0, 1)) / syb);
+    if (valid) acc[1] = sq1((ra[1] - ra[0]) / sa);
+  } else {
+    f32x4 iy[2], ey[2];
+    float ia2 = 0.f, ea = 0.f, ma = 0.f;
+#pragma unroll
+    for (int v = 0; v < 2; ++v) { iy[v] = f32x4{0.f, 0.f, 0.f, 0.f}; ey[v] = iy[v]; }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const float ws = j < 6 ? bc[6][j] : 0.f, we = wE[j], wm = dtf * (float)DP_CMID[j];
+      const f32x4 ws4 = {ws, ws, ws, ws}, we4 = {we, we, we, we};
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        const f32x4 ky = ys(j, v);
+        iy[v] = __builtin_elementwise_fma(ky, ws4, iy[v]);
+        ey[v] = __builtin_elementwise_fma(ky, we4, ey[v]);
+      }
+      ia2 = __builtin_fmaf(ra[j], ws, ia2); ea = __builtin_fmaf(ra[j], we, ea); ma = __builtin_fmaf(ra[j], wm, ma);
+    }
+    const f32x4 y1a = y0a + iy[0], y1b = y0b + iy[1];
+    const float a1 = a0 + ia2;
+    if (mode == 2) {
+      const f32x4 tya = atol + rtol * max4f(abs4f(y0a), abs4f(y1a)), tyb = atol + rtol * max4f(abs4f(y0b), abs4f(y1b));
+      const float ta = atol + rtol * fmaxf(fabsf(a0), fabsf(a1));
+      if (yw) {
+        acc[0] = sq4f(ey[0] / tya) + sq4f(ey[1] / tyb);
+        store_units4<4>(Sq + 2 * BH + series * Hr, ua, Hr, y1a); store_units4<4>(Sq + 2 * BH + series * Hr, ub, Hr, y1b);
+      }
+      if (valid) acc[1] = sq1(ea / ta);
+      if (own) Sq[3 * BH + series * Hr + hw] = a1;
+    } else if (own) {
+      // mode 3: a(s1) by torchdiffeq's dense output (_interp_fit / _interp_evaluate, the oracle's expression order)
+      const float f0 = ra[0], f1 = ra[6];
+      const float ym = a0 + ma;
+      const float ca = 2.f * dtf * (f1 - f0) - 8.f * (a1 + a0) + 16.f * ym;
+      const float cb = dtf * (5.f * f0 - 3.f * f1) + 18.f * a0 + 14.f * a1 - 32.f * ym;
+      const float cc = dtf * (f1 - 4.f * f0) - 11.f * a0 - 5.f * a1 + 16.f * ym;
+      const float cd = dtf * f0;
+      float total = a0 + x_end * cd;
+      float xp = x_end;
+      xp = xp * x_end; total = total + xp * cc;
+      xp = xp * x_end; total = total + xp * cb;
+      xp = xp * x_end; total = total + xp * ca;
+      g.a_out[series * Hr + hw] = total;
+    }
+  }
+  if (writer) { acc[4] = (double)vtS; acc[5] = (double)vtE; }
+  CDE_STAMP(11);
   block_total<ADJ_NS>(acc, red);
   if (tid == 0) {
 #pragma unroll
     for (int i = 0; i < ADJ_NS; ++i) Pq[ADJ_NS * blockIdx.x + i] = acc[i];
   }
+  CDE_STAMP(12);
+  CDE_STAMP_FLUSH(k4am_phase_trace, attempt_no);
 }
 
 // ------------------------------------------------------------------------------------------ the R kernel of this family
@@ -398,15 +791,23 @@ static inline size_t m256(size_t x) { return (x + 255) / 256 * 256; }
 
 }  // namespace cde
 
+#ifdef CDE_PHASE_TRACE
+// debug builds only (cde_common.h, "phase trace"): the stamp ring of dopri5_mlp_adjoint_attempt, [ring][workgroup][slot]
+extern "C" int cde_debug_k4am_phase_trace(void* host_out, size_t bytes) {
+  if (bytes > sizeof(unsigned long long) * cde::TRACE_RING * cde::TRACE_BLOCKS * cde::TRACE_SLOTS) return CDE_ERR_SHAPE;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(cde::k4am_phase_trace), bytes) == hipSuccess ? CDE_OK : CDE_ERR_LAUNCH;
+}
+#endif
+
 // ================================================================================================ C ABI
 namespace {
 struct MadjLayout {
   int64_t n_tiles, rows_per_stage, rows_per_slab;
   int sps, nwave, n_wg;
-  bool split;
+  bool split, split8;
   size_t partial, pq, carry, image, state, G, prev, slopes, part2, part1, U, G2, G1, Z, trace, trace_all, total;
 };
-MadjLayout madj_layout(int64_t B, int64_t H) {
+MadjLayout madj_layout(int64_t B, int64_t H, int64_t C) {
   using namespace cde;
   MadjLayout L;
   L.n_tiles = (B + 15) / 16;
@@ -417,6 +818,8 @@ MadjLayout madj_layout(int64_t B, int64_t H) {
   // up to MADJ_SPLIT_MAX_TILES tiles (one workgroup per CU in a single round): four waves per tile, the evaluation's middle
   // split four ways
   L.split = L.n_tiles <= MADJ_SPLIT_MAX_TILES && !getenv("CDE_K4AM_NO_SPLIT");
+  // ... eight (two per SIMD, everything split eight ways: mlp_adjoint_eval_split8) when the control fits the 32 x 8 tiling
+  L.split8 = L.split && C <= MC && !getenv("CDE_K4AM_SPLIT4");
   L.n_wg = L.split ? (int)L.n_tiles : (int)((L.n_tiles + L.nwave - 1) / L.nwave);
   int64_t sps = (B + 63) / 64;                     // (measured at 4096 series: 40 slabs 193 us per attempt, 16: 209, 6: 284;
   L.sps = (int)(sps < 4 ? 4 : sps > MADJ_MAX_SPS ? MADJ_MAX_SPS : sps);        //  at 64 series: 4 slabs 138, 1: 146)
@@ -431,7 +834,7 @@ MadjLayout madj_layout(int64_t B, int64_t H) {
   L.G = L.state + m256((size_t)2 * 4 * B * H * sizeof(float));
   L.prev = L.G + m256((size_t)MADJ_ELEMS * sizeof(float));
   L.slopes = L.prev + m256((size_t)2 * MADJ_ELEMS * sizeof(float));
-  L.part2 = L.slopes + m256((size_t)L.n_tiles * (L.split ? 4 : 1) * 7 * 4 * 64 * 16);
+  L.part2 = L.slopes + m256((size_t)L.n_tiles * 7 * 4 * 64 * 16);
   L.part1 = L.part2 + m256((size_t)MADJ_SLOTS * L.sps * MADJ_P2 * sizeof(float));
   L.U = L.part1 + m256((size_t)MADJ_SLOTS * L.sps * MADJ_P1 * sizeof(float));
   L.G2 = L.U + m256(rows * U_COLS * sizeof(float));
@@ -445,18 +848,15 @@ MadjLayout madj_layout(int64_t B, int64_t H) {
 }  // namespace
 
 extern "C" size_t cde_dopri5_adjoint_mlp_workspace_bytes(int64_t B, int64_t C, int64_t H) {
-  (void)C;
-  return B < 1 || H < 1 ? 0 : madj_layout(B, H).total;
+  return B < 1 || H < 1 ? 0 : madj_layout(B, H, C).total;
 }
 extern "C" size_t cde_dopri5_adjoint_mlp_trace_offset(int64_t B, int64_t C, int64_t H, int which) {
-  (void)C;
-  const MadjLayout L = madj_layout(B, H);
+  const MadjLayout L = madj_layout(B, H, C);
   return which == 0 ? L.trace : L.trace_all;
 }
 // where the running totals live: layer 2 as [256][129] (row = padded (h, c), bias in column 128), then layer 1 as [128][33]
 extern "C" size_t cde_dopri5_adjoint_mlp_gradient_offset(int64_t B, int64_t C, int64_t H) {
-  (void)C;
-  return madj_layout(B, H).G;
+  return madj_layout(B, H, C).G;
 }
 
 extern "C" int cde_dopri5_adjoint_mlp_advance(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
@@ -479,7 +879,7 @@ extern "C" int cde_dopri5_adjoint_mlp_advance(const void* coeffs, const void* kn
   if (workspace_bytes < cde_dopri5_adjoint_mlp_workspace_bytes(B, C, H)) return CDE_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   unsigned char* base = (unsigned char*)workspace;
-  const MadjLayout L = madj_layout(B, H);
+  const MadjLayout L = madj_layout(B, H, C);
   MlpAdjArgs g;
   g.coeffs = (const float*)coeffs; g.knots = (const float*)knots; g.n_intervals = n_intervals;
   g.img = (const float*)(base + L.image);
@@ -492,6 +892,7 @@ extern "C" int cde_dopri5_adjoint_mlp_advance(const void* coeffs, const void* kn
   g.slopes = (float*)(base + L.slopes);
   g.U = (float*)(base + L.U); g.G2 = (float*)(base + L.G2); g.G1 = (float*)(base + L.G1); g.Z = (float*)(base + L.Z);
   g.n_wg_max = L.n_wg;
+  { const char* d = getenv("CDE_K4AM_DBG"); g.dbg = d ? atoi(d) : 0; }
   g.com.s0 = s0; g.com.s1 = s1; g.com.jump_s = jump_s; g.com.n_jump = n_jump;
   g.com.rtol = rtol; g.com.atol = atol; g.com.safety = safety; g.com.ifactor = ifactor; g.com.dfactor = dfactor;
   g.com.n_state = B * H;
@@ -534,6 +935,19 @@ extern "C" int cde_dopri5_adjoint_mlp_advance(const void* coeffs, const void* kn
       mlp_adjoint_reduce_kernel<<<MADJ_RBLOCKS, 256, 0, s>>>(r, parity);                                             \
     }                                                                                                                \
   } while (0)
+#define CDE_MADJ_LAUNCH_S8(D, A)                                                                                     \
+  do {                                                                                                               \
+    (void)hipFuncSetAttribute((const void*)dopri5_mlp_adjoint_attempt_s8<D, A>,                                      \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                           \
+    for (int64_t i = 0; i < n_launches; ++i) {                                                                       \
+      const int parity = (int)((first_launch + i) & 1);                                                              \
+      dopri5_mlp_adjoint_attempt_s8<D, A><<<L.n_wg, 512, lds_bytes, s>>>(g, parity);                                 \
+      const int rc = launch_mlp_adjoint_factor_reduce(g.G2, g.U, g.G1, g.Z, L.rows_per_stage, L.sps, L.rows_per_slab, \
+                                                      (float*)(base + L.part2), (float*)(base + L.part1), base, parity, s); \
+      if (rc != CDE_OK) return rc;                                                                                   \
+      mlp_adjoint_reduce_kernel<<<MADJ_RBLOCKS, 256, 0, s>>>(r, parity);                                             \
+    }                                                                                                                \
+  } while (0)
 #define CDE_MADJ_W(D, A, CTV)                                                                                        \
   do {                                                                                                               \
     if (L.split) CDE_MADJ_LAUNCH(D, A, CTV, 4, true);                                                                \
@@ -542,7 +956,9 @@ extern "C" int cde_dopri5_adjoint_mlp_advance(const void* coeffs, const void* kn
   } while (0)
 #define CDE_MADJ(D, A)                                                                                               \
   do {                                                                                                               \
-    if (C > MC) CDE_MADJ_W(D, A, 16); else CDE_MADJ_W(D, A, 8);                                                      \
+    if (C > MC) CDE_MADJ_W(D, A, 16);                                                                                \
+    else if (L.split8) CDE_MADJ_LAUNCH_S8(D, A);                                                                     \
+    else CDE_MADJ_W(D, A, 8);                                                                                        \
   } while (0)
   if (act == CDE_ACT_NONE) {
     if (degree == CDE_PATH_CUBIC) CDE_MADJ(CDE_PATH_CUBIC, CDE_ACT_NONE); else CDE_MADJ(CDE_PATH_LINEAR, CDE_ACT_NONE);
@@ -552,5 +968,6 @@ extern "C" int cde_dopri5_adjoint_mlp_advance(const void* coeffs, const void* kn
 #undef CDE_MADJ
 #undef CDE_MADJ_W
 #undef CDE_MADJ_LAUNCH
+#undef CDE_MADJ_LAUNCH_S8
   return check_launch();
 }
