@@ -21,7 +21,10 @@ __device__ __forceinline__ void stream_store4(float* p, float a, float b, float 
   // written once, read once by the GEMM much later: keep it out of the way of the L2-resident weight images
   __builtin_nontemporal_store(f32x4{a, b, c, d}, reinterpret_cast<f32x4*>(p));
 }
-
+__device__ __forceinline__ void plain_store4(float* p, float a, float b, float c, float d) {
+  // small batches (mlp_adjoint_eval_split8): the rows are read back a few microseconds later by the fused reduction -- from L2
+  *reinterpret_cast<f32x4*>(p) = f32x4{a, b, c, d};
+}
 
 // One evaluation of the augmented dynamics of the two-layer field for the 16 series of a wave (lane (n, q) owns hidden
 // units q, 4+q, .., 28+q of z and a): f = F(z) dX, va = a^T dF/dz dX, and -- when `stream` -- the UNWEIGHTED factors of
@@ -269,7 +272,7 @@ __device__ __forceinline__ void mlp_adjoint_eval_split8(const float* lds_base, f
   for (int r = 0; r < 4; ++r) { uo[r] = fmaxf(y1[r], 0.f); mask |= (y1[r] > 0.f ? 1u : 0u) << r; }
   *reinterpret_cast<float4*>(xb + (w * 64 + lane) * 4) = make_float4(uo[0], uo[1], uo[2], uo[3]);
   if (stream) {
-    stream_store4(urow + 16 * w, uo[0], uo[1], uo[2], uo[3]);
+    plain_store4(urow + 16 * w, uo[0], uo[1], uo[2], uo[3]);
     if (w == 0) {
 #pragma unroll
       for (int m = 0; m < 8; ++m) if (4 * m + q < Hr) zrow[4 * m + q] = zs[m];
@@ -317,8 +320,8 @@ __device__ __forceinline__ void mlp_adjoint_eval_split8(const float* lds_base, f
   *reinterpret_cast<float4*>(xa + ((2 * w + 1) * 64 + lane) * 4) = make_float4(g2[4], g2[5], g2[6], g2[7]);
   if (stream) {
     float* grow = g2row + 4 * CT * w;                            // rows (h = 4w+q, c = 0..7) of the padded layout
-    stream_store4(grow, g2[0], g2[1], g2[2], g2[3]);
-    stream_store4(grow + 4, g2[4], g2[5], g2[6], g2[7]);
+    plain_store4(grow, g2[0], g2[1], g2[2], g2[3]);
+    plain_store4(grow + 4, g2[4], g2[5], g2[6], g2[7]);
   }
   __syncthreads();                                               // dL/dY2 of all 256 rows is in xa
   CDE_EVAL_STAMP(1, "+v"(g2[0]));
@@ -342,7 +345,7 @@ __device__ __forceinline__ void mlp_adjoint_eval_split8(const float* lds_base, f
   float g1[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) g1[r] = (mask >> r) & 1u ? gu[r] : 0.f;
-  if (stream) stream_store4(g1row + 16 * w, g1[0], g1[1], g1[2], g1[3]);
+  if (stream) plain_store4(g1row + 16 * w, g1[0], g1[1], g1[2], g1[3]);
   f32x4 pa = {0.f, 0.f, 0.f, 0.f}, pb = pa;
   pa = mfma16(w1tr[0].x, g1[0], pa); pb = mfma16(w1tr[1].x, g1[0], pb);
   pa = mfma16(w1tr[0].y, g1[1], pa); pb = mfma16(w1tr[1].y, g1[1], pb);

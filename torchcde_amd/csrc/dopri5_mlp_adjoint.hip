@@ -52,6 +52,7 @@ struct MlpAdjArgs {
   float* U; float* G2; float* G1; float* Z;      // factor rows [slot][rows_per_stage]
   AdjCommon com;
   int n_wg_max;
+  int n_pq;                         // blocks of parameter sums the R kernel of this batch size leaves in `pq`
   int dbg;                          // CDE_K4AM_DBG (timing experiments only): bit 0 = no factor stores
 };
 
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
       for (int i = 0; i < ADJ_NS; ++i) sum[i] += Pp[ADJ_NS * b + i];
     }
     const double* Qp = g.pq + (int64_t)p * MADJ_RBLOCKS * 8;
-    for (int b = tid; b < MADJ_RBLOCKS; b += blockDim.x) {
+    for (int b = tid; b < g.n_pq; b += blockDim.x) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) sum[ADJ_NS + i] += Qp[8 * b + i];
     }
@@ -421,6 +422,24 @@ __global__ __launch_bounds__(512, 2) void dopri5_mlp_adjoint_attempt_s8(MlpAdjAr
   const int p = parity, p2 = parity ^ 1;
   CDE_STAMP_DECL;
   CDE_STAMP(0);
+  // the pending sums are requested together with the controller block, not after it (both were written by the previous
+  // launches, on other XCDs: each dependent round trip through the memory side costs ~2 us); before the first attempt
+  // of an interval they are ignored
+  double sum[MADJ_NSUM];
+#pragma unroll
+  for (int i = 0; i < MADJ_NSUM; ++i) sum[i] = 0.0;
+  {
+    const double* Pp0 = g.partial + (int64_t)p * g.n_wg_max * ADJ_NS;
+    for (int64_t b = tid; b < (int64_t)gridDim.x; b += blockDim.x) {
+#pragma unroll
+      for (int i = 0; i < ADJ_NS; ++i) sum[i] += Pp0[ADJ_NS * b + i];
+    }
+    const double* Qp = g.pq + (int64_t)p * MADJ_RBLOCKS * 8;
+    for (int b = tid; b < g.n_pq; b += blockDim.x) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sum[ADJ_NS + i] += Qp[8 * b + i];
+    }
+  }
   AdjCtrl k = *reinterpret_cast<const AdjCtrl*>(g.ctrl + p * ADJ_CTRL_STRIDE);
   DopriCtrl& c = k.c;
   if (c.phase == 4) {
@@ -430,40 +449,53 @@ __global__ __launch_bounds__(512, 2) void dopri5_mlp_adjoint_attempt_s8(MlpAdjAr
 #ifdef CDE_PHASE_TRACE
   const int attempt_no = uni((int)(c.n_accept + c.n_reject));
 #endif
+  const int lane = tid & 63, w = tid >> 6;
+  // Everything that does not depend on the controller's decision is requested before the first wait: the LDS image
+  // (b1 | W2 | b2; straight into LDS, 1 KB per wave-wide load -- the W1 part is not needed there, its tile goes to
+  // registers), this wave's W1 / W1^T tiles, and BOTH candidates of the start state (committed or attempted).
+  for (int chunk = W1M_FLOATS / 256 + w; chunk * 256 < ADJ_LDS_FLOATS; chunk += 8) {
+    if (chunk * 256 + lane * 4 < ADJ_LDS_FLOATS)
+      __builtin_amdgcn_global_load_lds(g.img + chunk * 256 + lane * 4, lds + chunk * 256, 16, 0, 0);
+  }
+  float4 w1r[2], w1tr[2];
   {
-    const float4* src = reinterpret_cast<const float4*>(g.img);
-    float4* dst = reinterpret_cast<float4*>(lds);
-    for (int i = tid; i < ADJ_LDS_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
+    const float4* w1img = reinterpret_cast<const float4*>(g.img) + lane;
+    w1r[0] = w1img[(2 * w) * 64]; w1r[1] = w1img[(2 * w + 1) * 64];
+    const float4* w1t_base = reinterpret_cast<const float4*>(g.img + ADJ_LDS_FLOATS) + lane;
+    w1tr[0] = w1t_base[w * 64]; w1tr[1] = w1t_base[(8 + w) * 64];
   }
   double* red = reinterpret_cast<double*>(lds + ADJ_LDS_FLOATS);
   float* xb = lds + ADJ_LDS_FLOATS + 2 * MADJ_NSUM * 8;            // exchange window B (9 KB), behind `red`
   float* xa = lds;                                                 // exchange window A: the W1 image's 16 KB, once it is in registers
   const int Hr = g.dims.H, Cr = g.dims.C;
-  const int lane = tid & 63, w = tid >> 6;
   const int n = lane & 15, q = lane >> 4;
   const int64_t BH = g.B * Hr;
   const float* Sp = g.state + (int64_t)p * 4 * BH;
   float* Sq = g.state + (int64_t)p2 * 4 * BH;
-  const double* Pp = g.partial + (int64_t)p * g.n_wg_max * ADJ_NS;
   double* Pq = g.partial + (int64_t)p2 * g.n_wg_max * ADJ_NS;
   const float rtol = (float)g.com.rtol, atol = (float)g.com.atol;
+  const int64_t tile = blockIdx.x;                                 // (the grid is exactly the tiles)
+  const int64_t series = tile * 16 + n;
+  const bool valid = series < g.B;
+  const int64_t sc = valid ? series : g.B - 1;
+  const int hw = 4 * w + q;                                        // the hidden unit whose adjoint component this lane carries
+  const bool own = valid && hw < Hr;
+  const int ua = q, ub = 16 + q;
+  const bool fresh = c.phase == 0;
+  const float* yc0 = fresh ? g.y_init : Sp + 0 * BH;               // start state if the pending attempt is not committed ..
+  const float* ac0 = fresh ? g.a_init : Sp + 1 * BH;
+  const f32x4 yk0a = load_units4<4>(yc0 + sc * Hr, ua, Hr), yk0b = load_units4<4>(yc0 + sc * Hr, ub, Hr);
+  const f32x4 yk1a = load_units4<4>((fresh ? yc0 : Sp + 2 * BH) + sc * Hr, ua, Hr);           // .. and if it is
+  const f32x4 yk1b = load_units4<4>((fresh ? yc0 : Sp + 2 * BH) + sc * Hr, ub, Hr);
+  const float ak0 = own ? ac0[sc * Hr + hw] : 0.f, ak1 = own ? (fresh ? ac0 : Sp + 3 * BH)[sc * Hr + hw] : 0.f;
 
   // ---- pending sums, controller, stage scalars: as in dopri5_mlp_adjoint_attempt
-  double sum[MADJ_NSUM];
+  if (c.phase == 0) {
 #pragma unroll
-  for (int i = 0; i < MADJ_NSUM; ++i) sum[i] = 0.0;
-  if (c.phase != 0) {
-    for (int64_t b = tid; b < (int64_t)gridDim.x; b += blockDim.x) {
-#pragma unroll
-      for (int i = 0; i < ADJ_NS; ++i) sum[i] += Pp[ADJ_NS * b + i];
-    }
-    const double* Qp = g.pq + (int64_t)p * MADJ_RBLOCKS * 8;
-    for (int b = tid; b < MADJ_RBLOCKS; b += blockDim.x) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) sum[ADJ_NS + i] += Qp[8 * b + i];
-    }
+    for (int i = 0; i < MADJ_NSUM; ++i) sum[i] = 0.0;
   }
-  block_total<MADJ_NSUM>(sum, red);                                // (also the barrier after the LDS image copy)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's part of the LDS image has landed ..
+  block_total<MADJ_NSUM>(sum, red);                                // .. and, past its barriers, everybody's
   CDE_STAMP(1);
   const int phase_in = c.phase;
   const AdjPlan plan = adj_controller(g.com, k, sum, sum + ADJ_NS);
@@ -509,31 +541,14 @@ __global__ __launch_bounds__(512, 2) void dopri5_mlp_adjoint_attempt_s8(MlpAdjAr
   }
 
   double acc[ADJ_NS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  const int64_t tile = blockIdx.x;                                 // (the grid is exactly the tiles)
-  const int64_t series = tile * 16 + n;
-  const bool valid = series < g.B;
-  const int64_t sc = valid ? series : g.B - 1;
   const bool writer = w == 0;
-  const int hw = 4 * w + q;                                        // the hidden unit whose adjoint component this lane carries
-  const bool own = valid && hw < Hr;
-  // the tiles of W1 / b1 (LDS image) and W1^T (L2) for hidden-layer units 16w .. 16w+15
-  float4 w1r[2], w1tr[2], b1r;
-  {
-    const float4* w1img = reinterpret_cast<const float4*>(lds) + lane;
-    w1r[0] = w1img[(2 * w) * 64]; w1r[1] = w1img[(2 * w + 1) * 64];
-    b1r = (reinterpret_cast<const float4*>(lds + W1M_FLOATS) + q)[4 * w];
-    const float4* w1t_base = reinterpret_cast<const float4*>(g.img + ADJ_LDS_FLOATS) + lane;
-    w1tr[0] = w1t_base[w * 64]; w1tr[1] = w1t_base[(8 + w) * 64];
-  }
+  const float4 b1r = (reinterpret_cast<const float4*>(lds + W1M_FLOATS) + q)[4 * w];
   const int w2y_off = ((n >> 3) * 8 + w2p_residue(n >> 2, n & 3)) * W2P_STRIDE + 4 * q;
   int w2g_off[4];
 #pragma unroll
   for (int cl = 0; cl < 4; ++cl) w2g_off[cl] = ((q >> 1) * 8 + w2p_residue(q, cl)) * W2P_STRIDE + n;
-  const int ua = q, ub = 16 + q;
-  const float* ysrc = phase_in == 0 ? g.y_init : Sp + (commit ? 2 : 0) * BH;
-  const float* asrc = phase_in == 0 ? g.a_init : Sp + (commit ? 3 : 1) * BH;
-  const f32x4 y0a = load_units4<4>(ysrc + sc * Hr, ua, Hr), y0b = load_units4<4>(ysrc + sc * Hr, ub, Hr);
-  const float a0 = own ? asrc[sc * Hr + hw] : 0.f;                 // a == 0 stays 0: padded lanes / units contribute nothing
+  const f32x4 y0a = commit ? yk1a : yk0a, y0b = commit ? yk1b : yk0b;
+  const float a0 = commit ? ak1 : ak0;                             // a == 0 stays 0: padded lanes / units contribute nothing
   if (mode != 3) {
     if (valid && writer) {
       store_units4<4>(Sq + 0 * BH + series * Hr, ua, Hr, y0a); store_units4<4>(Sq + 0 * BH + series * Hr, ub, Hr, y0b);
@@ -776,6 +791,127 @@ __global__ __launch_bounds__(256) void mlp_adjoint_reduce_kernel(MlpReduceArgs r
   }
 }
 
+// ------------------------------------------------------------------------------------------ small batches: reduction + R in one
+// Up to MADJ_SMALL_MAX_ROWS series (at 256 the two forms take the same time) the factor rows of an attempt are few: the split-K reduction (6 x sps
+// slab partials through memory) and the R kernel (1165 blocks over those partials) are two launches of fixed latency --
+// 12 + 6 us plus two launch gaps per attempted step at 32 series (profiles/r04_k4am_32_seminorm_kernel_stats_before.csv), a
+// fifth of the step.  Here ONE launch does both: a wave owns a 16 x 16 tile of [dW2 | db2] (144 tiles) or [dW1 | db1] (24),
+// forms the stage images K_s = G_s^T X_s of its tile for the stored stages straight from the factor rows (K = the series,
+// v_mfma_f32_16x16x4_f32, operands by plain loads: the rows are L2-resident), and goes on with the R kernel's work on the
+// four elements each lane then holds: S = sum wS[s] K_s, E = sum wE[s] K_s, commit, norm sums.  42 blocks of parameter
+// sums instead of 1165 for the next launch's prologue.
+constexpr int64_t MADJ_SMALL_MAX_ROWS = 128;
+constexpr int MADJ_SMALL_TILES = 16 * 9 + 8 * 3, MADJ_SMALL_BLOCKS = MADJ_SMALL_TILES / 4;
+
+struct MlpSmallArgs {
+  MlpReduceArgs r;
+  const float* G2; const float* U; const float* G1; const float* Z;
+  int64_t rows_per_stage, B;
+};
+
+__global__ __launch_bounds__(256) void mlp_adjoint_small_reduce_kernel(MlpSmallArgs a, int parity) {
+  __shared__ double red[4][8];
+  const MlpReduceArgs& r = a.r;
+  const int p2 = parity ^ 1;
+  const AdjCtrl k = *reinterpret_cast<const AdjCtrl*>(r.ctrl + p2 * ADJ_CTRL_STRIDE);
+  if (k.c.phase == 4 && k.commit == 0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int t = blockIdx.x * 4 + wave;
+  const bool layer2 = t < 16 * 9;
+  const int tt = layer2 ? t : t - 16 * 9;
+  const int mt = layer2 ? tt / 9 : tt / 3, nt = layer2 ? tt % 9 : tt % 3;
+  const int gc = layer2 ? G2_COLS : G1_COLS, xc = layer2 ? U_COLS : Z_COLS, ncols = layer2 ? 129 : 33;
+  const float* G = layer2 ? a.G2 : a.G1;
+  const float* X = layer2 ? a.U : a.Z;
+  const int n_slots = k.mode == 0 ? 1 : k.mode == 1 ? 2 : MADJ_SLOTS;
+  const int col_load = min(16 * nt + i, xc - 1);                  // (columns past the row: any valid address, the result is dropped)
+  const int ksteps = (int)((a.B + 31) / 32) * 8;                   // rows past B hold zeros (rows_per_stage >= 4 * ksteps)
+  f32x4 acc[MADJ_SLOTS];
+#pragma unroll
+  for (int s = 0; s < MADJ_SLOTS; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // the operands of four K steps (16 series) of every stored stage at a time, the next group requested before this one is
+  // used: the kernel is a chain of memory round trips (the rows were streamed out by the attempt kernel), so as many loads
+  // as the registers hold are kept in flight -- at 32 series all of them at once
+  const float* gp = G + (int64_t)kq * gc + 16 * mt + i;
+  const float* xp = X + (int64_t)kq * xc + col_load;
+  const int64_t gs = a.rows_per_stage * gc, xs = a.rows_per_stage * xc;
+  float av[2][MADJ_SLOTS][4], bv[2][MADJ_SLOTS][4];
+  auto request = [&](int buf, int k0) {
+#pragma unroll
+    for (int s = 0; s < MADJ_SLOTS; ++s) {
+      if (s >= n_slots) continue;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        av[buf][s][u] = gp[s * gs + (int64_t)(k0 + u) * 4 * gc];
+        bv[buf][s][u] = xp[s * xs + (int64_t)(k0 + u) * 4 * xc];
+      }
+    }
+  };
+  auto consume = [&](int buf) {
+#pragma unroll
+    for (int s = 0; s < MADJ_SLOTS; ++s) {
+      if (s >= n_slots) continue;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[s] = mfma16(av[buf][s][u], bv[buf][s][u], acc[s]);
+    }
+  };
+  request(0, 0);
+  for (int k0 = 0; k0 < ksteps; k0 += 8) {                          // (ksteps is a multiple of 8)
+    request(1, k0 + 4);
+    consume(0);
+    if (k0 + 8 < ksteps) request(0, k0 + 8);
+    consume(1);
+  }
+  if (k.mode == 3 && t == 0 && lane == 0) {
+    double vt = 0.0;
+    for (int b = 0; b < r.n_wg; ++b) vt += r.partial[((int64_t)p2 * r.n_wg_max + b) * ADJ_NS + 4];
+    r.carry[0] = (double)((float)k.T + (float)vt);
+  }
+  float wS[7], wE[7];
+  adj_stage_weights(k.mode, (float)k.c.dt_try, (float)k.x_end, wS, wE);
+  double qv[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  const int col = 16 * nt + i;                                     // D fragment: lane (n = i, q = kq), register rr <-> row 4 kq + rr
+  if (col < ncols) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      float S = 0.f, E = 0.f;
+#pragma unroll
+      for (int slot = 0; slot < MADJ_SLOTS; ++slot) {
+        if (slot >= n_slots) continue;
+        const int stage = k.mode <= 1 ? slot : (slot == 0 ? 0 : slot + 1);
+        float ws = wS[0], we = wE[0];
+#pragma unroll
+        for (int j = 1; j < 7; ++j) { ws = stage == j ? wS[j] : ws; we = stage == j ? wE[j] : we; }
+        S = __builtin_fmaf(ws, acc[slot][rr], S);
+        E = __builtin_fmaf(we, acc[slot][rr], E);
+      }
+      const int m = 16 * mt + 4 * kq + rr;
+      const int e = layer2 ? m * 129 + col : MADJ_P2 + m * 33 + col;
+      const int tensor = layer2 ? (col == 128 ? 3 : 2) : (col == 32 ? 1 : 0);      // 0 W1, 1 b1, 2 W2, 3 b2 (torch's order)
+      double q0 = 0.0, q1 = 0.0;
+      const float gn = adj_param_element(k, r.rtol, r.atol, r.G[e], r.prevS[p2 * MADJ_ELEMS + e], S, E, q0, q1);
+      if (k.commit) r.G[e] = gn;
+      r.prevS[parity * MADJ_ELEMS + e] = S;
+#pragma unroll
+      for (int tz = 0; tz < 4; ++tz) if (tensor == tz) { qv[2 * tz] += q0; qv[2 * tz + 1] += q1; }
+    }
+  }
+  if (k.mode == 3) return;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) qv[j] += __shfl_xor(qv[j], off, 64);
+  }
+  if (lane == 0)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[wave][j] = qv[j];
+  __syncthreads();
+  if (threadIdx.x < 8)
+    r.pq[((int64_t)p2 * MADJ_RBLOCKS + blockIdx.x) * 8 + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 // the "1" columns of the U and Z rows (bias gradients = column sums of G): written once per backward pass
 __global__ __launch_bounds__(256) void madj_ones_kernel(float* __restrict__ U, float* __restrict__ Z, int64_t rows) {
   const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -804,7 +940,7 @@ namespace {
 struct MadjLayout {
   int64_t n_tiles, rows_per_stage, rows_per_slab;
   int sps, nwave, n_wg;
-  bool split, split8;
+  bool split, split8, small;
   size_t partial, pq, carry, image, state, G, prev, slopes, part2, part1, U, G2, G1, Z, trace, trace_all, total;
 };
 MadjLayout madj_layout(int64_t B, int64_t H, int64_t C) {
@@ -820,6 +956,8 @@ MadjLayout madj_layout(int64_t B, int64_t H, int64_t C) {
   L.split = L.n_tiles <= MADJ_SPLIT_MAX_TILES && !getenv("CDE_K4AM_NO_SPLIT");
   // ... eight (two per SIMD, everything split eight ways: mlp_adjoint_eval_split8) when the control fits the 32 x 8 tiling
   L.split8 = L.split && C <= MC && !getenv("CDE_K4AM_SPLIT4");
+  // a few hundred rows per attempt: factor reduction + R in one launch (mlp_adjoint_small_reduce_kernel)
+  L.small = B <= MADJ_SMALL_MAX_ROWS && !getenv("CDE_K4AM_NO_SMALL_REDUCE");
   L.n_wg = L.split ? (int)L.n_tiles : (int)((L.n_tiles + L.nwave - 1) / L.nwave);
   int64_t sps = (B + 63) / 64;                     // (measured at 4096 series: 40 slabs 193 us per attempt, 16: 209, 6: 284;
   L.sps = (int)(sps < 4 ? 4 : sps > MADJ_MAX_SPS ? MADJ_MAX_SPS : sps);        //  at 64 series: 4 slabs 138, 1: 146)
@@ -893,6 +1031,7 @@ extern "C" int cde_dopri5_adjoint_mlp_advance(const void* coeffs, const void* kn
   g.U = (float*)(base + L.U); g.G2 = (float*)(base + L.G2); g.G1 = (float*)(base + L.G1); g.Z = (float*)(base + L.Z);
   g.n_wg_max = L.n_wg;
   { const char* d = getenv("CDE_K4AM_DBG"); g.dbg = d ? atoi(d) : 0; }
+  g.n_pq = L.small ? MADJ_SMALL_BLOCKS : MADJ_RBLOCKS;
   g.com.s0 = s0; g.com.s1 = s1; g.com.jump_s = jump_s; g.com.n_jump = n_jump;
   g.com.rtol = rtol; g.com.atol = atol; g.com.safety = safety; g.com.ifactor = ifactor; g.com.dfactor = dfactor;
   g.com.n_state = B * H;
@@ -920,6 +1059,20 @@ extern "C" int cde_dopri5_adjoint_mlp_advance(const void* coeffs, const void* kn
   r.G = (float*)(base + L.G); r.prevS = (float*)(base + L.prev); r.pq = g.pq;
   r.partial = g.partial; r.n_wg = L.n_wg; r.n_wg_max = L.n_wg; r.carry = g.com.carry;
   r.rtol = (float)rtol; r.atol = (float)atol;
+  MlpSmallArgs sm;
+  sm.r = r; sm.G2 = g.G2; sm.U = g.U; sm.G1 = g.G1; sm.Z = g.Z; sm.rows_per_stage = L.rows_per_stage; sm.B = B;
+  // after an attempt launch: the split-K reduction of its factor rows + the R kernel, or (small batches) both in one launch
+  auto after_attempt = [&](int parity) -> int {
+    if (L.small) {
+      mlp_adjoint_small_reduce_kernel<<<MADJ_SMALL_BLOCKS, 256, 0, s>>>(sm, parity);
+      return CDE_OK;
+    }
+    const int rc = launch_mlp_adjoint_factor_reduce(g.G2, g.U, g.G1, g.Z, L.rows_per_stage, L.sps, L.rows_per_slab,
+                                                    (float*)(base + L.part2), (float*)(base + L.part1), base, parity, s);
+    if (rc != CDE_OK) return rc;
+    mlp_adjoint_reduce_kernel<<<MADJ_RBLOCKS, 256, 0, s>>>(r, parity);
+    return CDE_OK;
+  };
   const size_t lds_bytes = (size_t)ADJ_LDS_FLOATS * sizeof(float) + (size_t)MADJ_NSUM * 8 * sizeof(double) +
                            (L.split ? (size_t)MADJ_XBUF_FLOATS * sizeof(float) : 0);
 #define CDE_MADJ_LAUNCH(D, A, CTV, NWV, SPL)                                                                         \
@@ -929,10 +1082,8 @@ extern "C" int cde_dopri5_adjoint_mlp_advance(const void* coeffs, const void* kn
     for (int64_t i = 0; i < n_launches; ++i) {                                                                       \
       const int parity = (int)((first_launch + i) & 1);                                                              \
       dopri5_mlp_adjoint_attempt<D, A, CTV, NWV, SPL><<<L.n_wg, 64 * NWV, lds_bytes, s>>>(g, parity);                \
-      const int rc = launch_mlp_adjoint_factor_reduce(g.G2, g.U, g.G1, g.Z, L.rows_per_stage, L.sps, L.rows_per_slab, \
-                                                      (float*)(base + L.part2), (float*)(base + L.part1), base, parity, s); \
+      const int rc = after_attempt(parity);                                                                          \
       if (rc != CDE_OK) return rc;                                                                                   \
-      mlp_adjoint_reduce_kernel<<<MADJ_RBLOCKS, 256, 0, s>>>(r, parity);                                             \
     }                                                                                                                \
   } while (0)
 #define CDE_MADJ_LAUNCH_S8(D, A)                                                                                     \
@@ -942,10 +1093,8 @@ extern "C" int cde_dopri5_adjoint_mlp_advance(const void* coeffs, const void* kn
     for (int64_t i = 0; i < n_launches; ++i) {                                                                       \
       const int parity = (int)((first_launch + i) & 1);                                                              \
       dopri5_mlp_adjoint_attempt_s8<D, A><<<L.n_wg, 512, lds_bytes, s>>>(g, parity);                                 \
-      const int rc = launch_mlp_adjoint_factor_reduce(g.G2, g.U, g.G1, g.Z, L.rows_per_stage, L.sps, L.rows_per_slab, \
-                                                      (float*)(base + L.part2), (float*)(base + L.part1), base, parity, s); \
+      const int rc = after_attempt(parity);                                                                          \
       if (rc != CDE_OK) return rc;                                                                                   \
-      mlp_adjoint_reduce_kernel<<<MADJ_RBLOCKS, 256, 0, s>>>(r, parity);                                             \
     }                                                                                                                \
   } while (0)
 #define CDE_MADJ_W(D, A, CTV)                                                                                        \
