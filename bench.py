@@ -589,7 +589,7 @@ def main():
                 dist.init_process_group(backend="nccl")
 
     import torchcde_amd as cde
-    from torchcde_amd.cdeint import _Plan
+    front_events = sys.modules["torchcde_amd.cdeint"]      # its `event_log` attribute is this thread's
     from torchcde_amd.distributed import allreduce_gradients
     cde.load()
     if args.config != 3:
@@ -646,7 +646,7 @@ def main():
     torch.cuda.synchronize()
     _log("timing %d steps" % args.steps)
 
-    _Plan.event_log = []                                   # HIP events around the K2 / K3 C-ABI calls
+    front_events.event_log = []                                   # HIP events around the K2 / K3 C-ABI calls
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -659,7 +659,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    log, _Plan.event_log = _Plan.event_log, None
+    log, front_events.event_log = front_events.event_log, None
 
     if distributed:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)

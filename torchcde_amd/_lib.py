@@ -85,6 +85,7 @@ _SIGNATURES = {
     "cde_error_string": (ctypes.c_char_p, [_i]),
     "cde_hermite_bdiff_coeffs": (_i, [_p, _p, _p, _i64, _i64, _i64, _i, _p]),
     "cde_hermite_bdiff_coeffs_checked": (_i, [_p, _p, _p, _i64, _i64, _i64, _i, _p, _p]),
+    "cde_hermite_bdiff_coeffs_nonblocking": (_i, [_p, _p, _p, _p, _i64, _i64, _i64, _i, _p, _i, _p]),
     "cde_linear_fill_missing": (_i, [_p, _p, _p, _i64, _i64, _i64, _i, _p]),
     "cde_linear_fill_missing_backward": (_i, [_p, _p, _p, _p, _i64, _i64, _i64, _i, _p]),
     "cde_interpret_t": (_i, [_p, _i64, _p, _i64, _p, _p, _i, _p]),

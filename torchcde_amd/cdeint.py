@@ -19,6 +19,9 @@ Native scope (round 1):
     with the native control-derivative and contraction kernels under every vector-field evaluation
 """
 import ctypes
+import sys
+import threading
+import types
 import warnings
 import weakref
 
@@ -40,6 +43,28 @@ _GRAD_WARNING = ("One of the inputs to the control path X requires gradients but
                  "adjoint_params = tuple(func.parameters()) + (coeffs,)\n"
                  "cdeint(X=X, func=func, ..., adjoint_params=adjoint_params)\n"
                  "```")
+
+
+# ------------------------------------------------------------------------------------------ per-thread call state
+class _CallState:
+    """What a caller may ask about / configure for ITS OWN cdeint calls: the step statistics of its most recent adaptive
+    solve and fused adaptive backward, whether the step traces are fetched as well (tests), and the list bench.py hands
+    in to receive HIP events around the K2 / K3 C-ABI calls.  One per calling thread (like dispatch.last()); a plan
+    remembers the state of the thread that built it, because autograd runs its backward on an engine thread."""
+    __slots__ = ("dopri5", "dopri5_adjoint", "record", "event_log")
+
+    def __init__(self):
+        self.dopri5, self.dopri5_adjoint, self.record, self.event_log = {}, {}, False, None
+
+
+_tls = threading.local()
+
+
+def _state():
+    st = getattr(_tls, "state", None)
+    if st is None:
+        st = _tls.state = _CallState()
+    return st
 
 
 # ------------------------------------------------------------------------------------------ time grids
@@ -70,6 +95,23 @@ def _parse_fixed_options(options, what):
     if options:
         raise NotImplementedError("torchcde_amd: unsupported %s options %s" % (what, sorted(options)))
     return step_size
+
+
+def _strip_noops(opts, fixed):
+    """Options as the fused paths see them: keys whose value is None are absent (torchdiffeq's `options.get(key)`
+    semantics), and for the fixed-grid methods so are torchdiffeq's defaults spelled out -- interp='linear',
+    perturb=False -- and `norm`, which only adaptive solvers read.  ADVICE round 3: the dispatch test and the plans used
+    to judge these differently (a fused call went step-wise over interp='linear'; safety=None raised a TypeError)."""
+    if not isinstance(opts, dict):
+        return opts
+    out = {k: v for k, v in opts.items() if v is not None}
+    if fixed:
+        if out.get("interp") == "linear":
+            del out["interp"]
+        if out.get("perturb") is False:
+            del out["perturb"]
+        out.pop("norm", None)
+    return out
 
 
 _host_copies = {}      # id(time tensor) -> (weakref, version, host copy): avoids a D2H sync per call
@@ -178,19 +220,17 @@ def _plan_time_gradients(plan, z_saved, grad_out, weight, bias, grad_x, t, want_
 class _Plan:
     """Everything one cdeint call needs besides the differentiable tensors."""
 
-    # bench.py sets this to a list to receive ("forward" | "adjoint", start_event, end_event) around the
-    # C-ABI calls, recorded on the stream the kernels are launched on.
-    event_log = None
-
-    @staticmethod
-    def _mark():
-        if _Plan.event_log is None:
+    # bench.py sets `torchcde_amd.cdeint.event_log` (of its thread) to a list to receive ("forward" | "adjoint",
+    # start_event, end_event) around the C-ABI calls, recorded on the stream the kernels are launched on.
+    def _mark(self):
+        if self.owner.event_log is None:
             return None
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         return ev
 
     def __init__(self, path, field, batch, H, C, t, step_size, adjoint_step_size, adjoint, variant):
+        self.owner = _state()
         coeffs, knots, _ = path._native_inputs()
         self.coeffs, self.knots = coeffs, knots
         self.path = path
@@ -229,7 +269,7 @@ class _Plan:
             self.variant, _lib.ptr(self.stage_index), _lib.ptr(self.stage_frac), _lib.stream_ptr(self.device)),
             "cde_rk4_forward_linear")
         if begin is not None:
-            _Plan.event_log.append(("forward", begin, self._mark()))
+            self.owner.event_log.append(("forward", begin, self._mark()))
         return out
 
     # backward: K3
@@ -269,7 +309,7 @@ class _Plan:
                 _lib.dtype_enum(self.time_dtype), self.variant, _lib.ptr(workspace), workspace.numel(),
                 _lib.stream_ptr(self.device)), "cde_rk4_adjoint_linear")
         if begin is not None:
-            _Plan.event_log.append(("adjoint", begin, self._mark()))
+            self.owner.event_log.append(("adjoint", begin, self._mark()))
         return grad_z0, grad_w, grad_b, grad_x
 
 
@@ -459,9 +499,11 @@ class _FusedRK4(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------ dopri5 (K4)
 last_dispatch = dispatch.last      # () -> (Choice(path, reason), Request) of this thread's most recent cdeint call
-last_dopri5_stats = {}     # {"n_accept", "n_reject", "launches"} of the most recent adaptive solve (for tests / logging)
-last_dopri5_adjoint_stats = {}   # the same for the most recent fused adaptive backward (summed over the output intervals)
-record_dopri5_steps = False   # tests: also fetch the accepted (t0, t1, on_jump) steps into last_dopri5_stats["steps"]
+# Module attributes served from the calling thread's _CallState (see the module class at the end of this file):
+#   last_dopri5_stats          {"n_accept", "n_reject", "launches"} of the most recent adaptive solve (tests / logging)
+#   last_dopri5_adjoint_stats  the same for the most recent fused adaptive backward (summed over the output intervals)
+#   record_dopri5_steps        tests: also fetch the accepted (t0, t1, on_jump) steps into last_dopri5_stats["steps"]
+#   event_log                  bench.py: a list that receives the HIP events around the rk4 C-ABI calls
 _DOPRI_CHUNK = 48          # attempt kernels queued between two looks at the done flag
 _WORKSPACE_HEAD = 1 << 20  # bytes at the start of an adaptive workspace that hold the controller blocks and partial sums
 
@@ -469,6 +511,8 @@ _WORKSPACE_HEAD = 1 << 20  # bytes at the start of an adaptive workspace that ho
 class _Dopri5Plan:
     def __init__(self, path, field, batch, H, C, t, rtol, atol, options, variant=_lib.VARIANT_AUTO,
                  adjoint_rtol=None, adjoint_atol=None, adjoint_options=None):
+        self.owner = _state()
+        self.record = self.owner.record
         self.variant = variant
         self.adjoint_rtol = float(rtol if adjoint_rtol is None else adjoint_rtol)
         self.adjoint_atol = float(atol if adjoint_atol is None else adjoint_atol)
@@ -549,9 +593,10 @@ class _Dopri5Plan:
                 break
             if launched > 2_000_000:
                 raise RuntimeError("torchcde_amd: dopri5 did not reach t[-1] after %d attempted steps" % launched)
+        last_dopri5_stats = self.owner.dopri5            # (updated in place: callers may hold the dict itself)
         last_dopri5_stats.clear()
         last_dopri5_stats.update(n_accept=status.n_accept, n_reject=status.n_reject, launches=launched)
-        if record_dopri5_steps:
+        if self.record:
             off = lib.cde_dopri5_trace_offset(self.B, self.C, self.H, dt)
             n = min(status.n_accept, 4096)
             last_dopri5_stats["steps"] = workspace[off:off + 24 * n].view(torch.float64).view(n, 3).cpu()
@@ -625,7 +670,7 @@ class _Dopri5Plan:
             stats["n_accept"] += status.n_accept
             stats["n_reject"] += status.n_reject
             stats["launches"] += launched
-            if record_dopri5_steps:
+            if self.record:
                 off = lib.cde_dopri5_adjoint_trace_offset(B, C, H)
                 n = min(status.n_accept, 4096)
                 steps.append(workspace[off:off + 24 * n].view(torch.float64).view(n, 3).cpu())
@@ -635,9 +680,10 @@ class _Dopri5Plan:
             a = a_out + grad_out[:, i - 1]
         _lib.check(lib.cde_dopri5_adjoint_finish(_lib.ptr(workspace), workspace.numel(), _lib.ptr(grad_w), _lib.ptr(grad_b),
                                                  B, C, H, int(shared is not None), stream), "cde_dopri5_adjoint_finish")
+        last_dopri5_adjoint_stats = self.owner.dopri5_adjoint
         last_dopri5_adjoint_stats.clear()
         last_dopri5_adjoint_stats.update(stats)
-        if record_dopri5_steps:
+        if self.record:
             last_dopri5_adjoint_stats["steps"] = steps           # one (n, 3) tensor per output interval, last first
             last_dopri5_adjoint_stats["attempts"] = attempts     # (t0, t1, on_jump, accepted, ratio) of EVERY attempt
         return a, grad_w, grad_b
@@ -686,7 +732,7 @@ class _Dopri5Plan:
             stats["n_accept"] += status.n_accept
             stats["n_reject"] += status.n_reject
             stats["launches"] += launched
-            if record_dopri5_steps:
+            if self.record:
                 off = lib.cde_dopri5_adjoint_mlp_trace_offset(B, C, H, 0)
                 n = min(status.n_accept, 4096)
                 steps.append(workspace[off:off + 24 * n].view(torch.float64).view(n, 3).cpu())
@@ -702,9 +748,10 @@ class _Dopri5Plan:
         grad_b2 = acc2[:, 128].reshape(units, channels)[:H, :C].reshape(H * C)
         grad_w1 = acc1[:width, :H].contiguous()
         grad_b1 = acc1[:width, 32].contiguous()
+        last_dopri5_adjoint_stats = self.owner.dopri5_adjoint
         last_dopri5_adjoint_stats.clear()
         last_dopri5_adjoint_stats.update(stats)
-        if record_dopri5_steps:
+        if self.record:
             last_dopri5_adjoint_stats["steps"] = steps
             last_dopri5_adjoint_stats["attempts"] = attempts
         return a, grad_w1, grad_b1, grad_w2, grad_b2
@@ -753,9 +800,10 @@ class _Dopri5Plan:
             if launched > 2_000_000:
                 raise RuntimeError("torchcde_amd: dopri5 did not reach t[-1] after %d attempted steps (t = %g, dt = %g)"
                                    % (launched, status.t_hi, status.dt))
+        last_dopri5_stats = self.owner.dopri5            # (updated in place: callers may hold the dict itself)
         last_dopri5_stats.clear()
         last_dopri5_stats.update(n_accept=status.n_accept, n_reject=status.n_reject, launches=launched)
-        if record_dopri5_steps:
+        if self.record:
             off = lib.cde_dopri5_trace_offset(self.B, self.C, self.H, dt)
             n = min(status.n_accept, 4096)            # CDE_DOPRI5_TRACE_STEPS
             last_dopri5_stats["steps"] = workspace[off:off + 24 * n].view(torch.float64).view(n, 3).cpu()
@@ -1014,17 +1062,21 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
             params_kind = "foreign"             # knot-time gradients of a two-layer solve: step-wise
 
     fixed_keys, adaptive_keys = {"step_size"}, {"jump_t", "safety", "ifactor", "dfactor"}
+    # ONE normalised view of the options for the fused paths (the step-wise path gets them verbatim, like torchdiffeq):
+    # None values and torchdiffeq's own defaults spelled out are the same request as leaving the key away
+    fused_options = _strip_noops(options, fixed=method != "dopri5")
+    fused_adj_opts = _strip_noops(adj_opts, fixed=method != "dopri5")
 
     def within(opts, allowed):
-        return opts is None or (isinstance(opts, dict) and set(k for k, v in opts.items() if v is not None) <= allowed)
+        return opts is None or (isinstance(opts, dict) and set(opts) <= allowed)
 
     if method == "dopri5":
-        options_ok = within(options, adaptive_keys)
-        adjoint_options_ok = adj_opts is None or (within(adj_opts, adaptive_keys | {"norm"})
-                                                  and adj_opts.get("norm", "seminorm") == "seminorm")
+        options_ok = within(fused_options, adaptive_keys)
+        adjoint_options_ok = fused_adj_opts is None or (within(fused_adj_opts, adaptive_keys | {"norm"})
+                                                        and fused_adj_opts.get("norm", "seminorm") == "seminorm")
     else:
-        options_ok = within(options, fixed_keys)
-        adjoint_options_ok = within(adj_opts, fixed_keys)
+        options_ok = within(fused_options, fixed_keys)
+        adjoint_options_ok = within(fused_adj_opts, fixed_keys)
     from .distributed import step_control
     request = dispatch.Request(
         prod=False, kind=None if known is None else known.kind, tiles_ok=known is not None, mfma_shape=mfma_shape,
@@ -1061,8 +1113,8 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
 
     # ---- two-layer fields
     if choice.path == "mlp_rk4_adjoint":
-        step = _parse_fixed_options(options, "solver")
-        adj_step = step if adj_opts is None else _parse_fixed_options(adj_opts, "adjoint")
+        step = _parse_fixed_options(fused_options, "solver")
+        adj_step = step if fused_adj_opts is None else _parse_fixed_options(fused_adj_opts, "adjoint")
         plan = _MlpPlan(X, mlp, batch, H, C, t, step, adj_step)
         want_x = bool(control_wants)
         control_inputs = X._control_buffers() if want_x else ()
@@ -1070,10 +1122,10 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
                                   want_x, *control_inputs)
     if choice.path == "mlp_rk4_forward":
         with torch.no_grad():
-            return _MlpPlan(X, mlp, batch, H, C, t, _parse_fixed_options(options, "solver")).run(z0)
+            return _MlpPlan(X, mlp, batch, H, C, t, _parse_fixed_options(fused_options, "solver")).run(z0)
     if choice.path in ("mlp_dopri5_forward", "mlp_dopri5_adjoint"):
-        plan = _Dopri5Plan(X, mlp, batch, H, C, t, kwargs["rtol"], kwargs["atol"], options, variant,
-                           kwargs.get("adjoint_rtol"), kwargs.get("adjoint_atol"), adj_opts)
+        plan = _Dopri5Plan(X, mlp, batch, H, C, t, kwargs["rtol"], kwargs["atol"], fused_options, variant,
+                           kwargs.get("adjoint_rtol"), kwargs.get("adjoint_atol"), fused_adj_opts)
         if choice.path == "mlp_dopri5_forward":
             with torch.no_grad():
                 return plan.run(z0, mlp.weight, mlp.bias).reshape(*batch, plan.n_out, H)
@@ -1083,8 +1135,8 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
     # ---- one-layer fields
     weight, bias = field.weight, field.bias
     if choice.path in ("dopri5_forward", "dopri5_adjoint"):
-        plan = _Dopri5Plan(X, field, batch, H, C, t, kwargs["rtol"], kwargs["atol"], options, variant,
-                           kwargs.get("adjoint_rtol"), kwargs.get("adjoint_atol"), adj_opts)
+        plan = _Dopri5Plan(X, field, batch, H, C, t, kwargs["rtol"], kwargs["atol"], fused_options, variant,
+                           kwargs.get("adjoint_rtol"), kwargs.get("adjoint_atol"), fused_adj_opts)
         if choice.path == "dopri5_forward":
             # nothing is to be differentiated (`adjoint_params=()` with weights that still require grad, no_grad ...): no
             # autograd node -- one here would reach K4a without its eligibility checks
@@ -1093,8 +1145,8 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         wants = (True, True) if given_params is None else (any(p is weight for p in given_params),
                                                            any(p is bias for p in given_params))
         return _FusedDopri5.apply(z0, weight, bias, plan, wants)
-    step_size = _parse_fixed_options(options, "solver")
-    adjoint_step = step_size if adj_opts is None else _parse_fixed_options(adj_opts, "adjoint")
+    step_size = _parse_fixed_options(fused_options, "solver")
+    adjoint_step = step_size if fused_adj_opts is None else _parse_fixed_options(fused_adj_opts, "adjoint")
     want_w = want_b = True
     want_x = want_knots = False
     if given_params is not None and adjoint:
@@ -1115,3 +1167,17 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
     control_inputs = X._control_buffers() if want_x else ()
     return _FusedRK4.apply(z0, weight, bias, plan, (want_w, want_b, want_x), t if wants_t else None,
                            X._t if want_knots else None, *control_inputs)
+
+
+# ------------------------------------------------------------------------------------------ per-thread module attributes
+class _Module(types.ModuleType):
+    """`torchcde_amd.cdeint.last_dopri5_stats` etc. read and write the CALLING THREAD's state (_CallState): two threads
+    solving at once do not see each other's statistics, and one thread recording step traces does not switch it on for
+    the other."""
+    last_dopri5_stats = property(lambda self: _state().dopri5)
+    last_dopri5_adjoint_stats = property(lambda self: _state().dopri5_adjoint)
+    record_dopri5_steps = property(lambda self: _state().record, lambda self, value: setattr(_state(), "record", bool(value)))
+    event_log = property(lambda self: _state().event_log, lambda self, value: setattr(_state(), "event_log", value))
+
+
+sys.modules[__name__].__class__ = _Module

@@ -25,13 +25,18 @@ struct Vec {
 // Stores: the 64 lanes of a wave own 64 consecutive (interval, channel group) entries = one contiguous span of
 // 256*V output values, but lane by lane the four kinds of a row sit 4C values apart.  The tile goes through a
 // per-wave LDS buffer and leaves as four fully coalesced stores (64 lanes x 16 B contiguous each).
-// CHECK: OR "some input value is NaN" into *nan_flag (the reference scans x for NaNs before fitting,
-// interpolation_linear.py:169; here the scan rides on the loads the fit does anyway).
+// CHECK: raise *nan_flag to `mark` (atomic max) when some input value is NaN (the reference scans x for NaNs before
+// fitting, interpolation_linear.py:169; here the scan rides on the loads the fit does anyway).  mark = 1 on a zeroed
+// flag is the plain "OR 1"; a call counter as `mark` needs no zero-fill between calls.
+// gate: when non-null the launch does nothing unless *gate == gate_value (the on-device "repair" pass of
+// cde_hermite_bdiff_coeffs_nonblocking: it runs only if the checked pass of the same call raised the flag).
 template <typename T, int V, bool CHECK>
 __global__ __launch_bounds__(256) void hermite_bdiff_kernel(const T* __restrict__ x, const T* __restrict__ t,
                                                             T* __restrict__ out, int64_t B, int64_t L, int64_t C,
-                                                            int* __restrict__ nan_flag) {
+                                                            int* __restrict__ nan_flag, int mark = 1,
+                                                            const int* __restrict__ gate = nullptr, int gate_value = 0) {
   __shared__ __attribute__((aligned(16))) T stage[V > 1 ? 4 * 256 * V : 1];
+  if (gate && *gate != gate_value) return;
   const int64_t groups = C / V;                       // lanes per interval row
   const int64_t total = B * (L - 1) * groups;
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -49,7 +54,7 @@ __global__ __launch_bounds__(256) void hermite_bdiff_kernel(const T* __restrict_
     bool bad = false;
 #pragma unroll
     for (int k = 0; k < V; ++k) bad = bad || (lo.v[k] != lo.v[k]) || (hi.v[k] != hi.v[k]);
-    if (__builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(nan_flag, 1);
+    if (__builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) atomicMax(nan_flag, mark);
   }
   const bool unit = h == (T)1;
   Vec<T, V> rise, secant;
@@ -132,13 +137,14 @@ __global__ __launch_bounds__(256) void hermite_bdiff_kernel(const T* __restrict_
 
 template <typename T>
 static int launch_hermite(const void* x, const void* t, void* out, int64_t B, int64_t L, int64_t C, int* nan_flag,
-                          hipStream_t s) {
+                          hipStream_t s, int mark = 1, const int* gate = nullptr, int gate_value = 0) {
   constexpr int VMAX = 16 / sizeof(T);
   if (B * (L - 1) * C == 0) return CDE_OK;
   const bool aligned = ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0);
   auto grid_for = [](int64_t n) { return (unsigned)((n + 255) / 256); };
 #define CDE_K1(V, CHECK, N)                                                                                         \
-  hermite_bdiff_kernel<T, V, CHECK><<<grid_for(N), 256, 0, s>>>((const T*)x, (const T*)t, (T*)out, B, L, C, nan_flag)
+  hermite_bdiff_kernel<T, V, CHECK><<<grid_for(N), 256, 0, s>>>((const T*)x, (const T*)t, (T*)out, B, L, C, nan_flag, mark, \
+                                                               gate, gate_value)
   if (aligned && C % VMAX == 0) {
     if (nan_flag) CDE_K1(VMAX, true, B * (L - 1) * (C / VMAX)); else CDE_K1(VMAX, false, B * (L - 1) * (C / VMAX));
   } else {
@@ -214,7 +220,9 @@ __global__ __launch_bounds__(256) void hermite_bdiff_backward_dt_kernel(const T*
 // land in the same cache lines.  (The reference does this with Python loops per scalar path: ~47 series/s.)
 template <typename T>
 __global__ __launch_bounds__(256) void linear_fill_kernel(const T* __restrict__ x, const T* __restrict__ t,
-                                                          T* __restrict__ out, int64_t B, int64_t L, int64_t C) {
+                                                          T* __restrict__ out, int64_t B, int64_t L, int64_t C,
+                                                          const int* __restrict__ gate = nullptr, int gate_value = 0) {
+  if (gate && *gate != gate_value) return;             // (see hermite_bdiff_kernel)
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= B * C) return;
   const int64_t b = e / C, c = e - b * C;
@@ -1164,6 +1172,34 @@ extern "C" int cde_hermite_bdiff_coeffs_checked(const void* x, const void* t, vo
   hipStream_t s = (hipStream_t)stream;
   if (dtype == CDE_F32) return cde::launch_hermite<float>(x, t, coeffs, B, L, C, nan_flag, s);
   if (dtype == CDE_F64) return cde::launch_hermite<double>(x, t, coeffs, B, L, C, nan_flag, s);
+  return CDE_ERR_DTYPE;
+}
+
+// K1 without a host round trip: the checked fit, then -- gated ON THE DEVICE by the flag the first launch may have raised
+// to `generation` -- the missing-value fill of x into `scratch` and the fit of the filled series over `coeffs`.
+extern "C" int cde_hermite_bdiff_coeffs_nonblocking(const void* x, const void* t, void* coeffs, void* scratch, int64_t B,
+                                                    int64_t L, int64_t C, int dtype, int* nan_flag, int generation,
+                                                    void* stream) {
+  if (B < 0 || L < 2 || C < 1 || generation < 1) return CDE_ERR_SHAPE;
+  if (B == 0) return CDE_OK;
+  if (!x || !t || !coeffs || !scratch || !nan_flag) return CDE_ERR_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((B * C + 255) / 256);
+  int rc;
+  if (dtype == CDE_F32) {
+    rc = cde::launch_hermite<float>(x, t, coeffs, B, L, C, nan_flag, s, generation);
+    if (rc != CDE_OK) return rc;
+    cde::linear_fill_kernel<float><<<grid, 256, 0, s>>>((const float*)x, (const float*)t, (float*)scratch, B, L, C, nan_flag,
+                                                        generation);
+    return cde::launch_hermite<float>(scratch, t, coeffs, B, L, C, nullptr, s, 1, nan_flag, generation);
+  }
+  if (dtype == CDE_F64) {
+    rc = cde::launch_hermite<double>(x, t, coeffs, B, L, C, nan_flag, s, generation);
+    if (rc != CDE_OK) return rc;
+    cde::linear_fill_kernel<double><<<grid, 256, 0, s>>>((const double*)x, (const double*)t, (double*)scratch, B, L, C,
+                                                         nan_flag, generation);
+    return cde::launch_hermite<double>(scratch, t, coeffs, B, L, C, nullptr, s, 1, nan_flag, generation);
+  }
   return CDE_ERR_DTYPE;
 }
 

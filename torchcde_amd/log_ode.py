@@ -39,7 +39,8 @@ def _plan(t, given, window_length, L, C_in, depth, version, dtype, device):
     to be merged in, the per-window scale and the Lyndon-word table -- as device tensors.  The reference's loop
     (`value <= t[pointer]` or `value.allclose(t[pointer])`, pointer never moving back) is evaluated for all window ends
     at once with the same elementwise arithmetic (`torch.isclose` is allclose's formula)."""
-    th = t.detach().cpu()
+    from .cdeint import _to_host          # id + version guarded host copy: steady-state calls do not synchronise
+    th = _to_host(t)
     # keyed on the VALUES of the times (as cdeint._grids_for does), never on an address: allocators recycle blocks, and a
     # different `t` of the same length at a recycled address must not be handed the previous plan
     key = ((th.numpy().tobytes(), str(th.dtype)) if given else None, float(window_length), L, C_in, depth, version, dtype,
