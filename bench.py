@@ -143,10 +143,14 @@ def cpu_baseline(max_sample, budget_s=20.0):
 
 def strong_scaling_proxy(cde, x, func, z0, full_ms):
     """What ONE GPU of an N-GPU strong-scaling run does, measured on this GPU: forward + adjoint on 32768/N series
-    (N = 2, 4, 8) against the full batch.  Wall clock over 20 steps after 3 warm-ups; no communication (the real run
-    adds one 33 KB all-reduce)."""
+    (N = 2, 4, 8) against the full batch.  Wall clock over 20 steps after 3 warm-ups.  The real run adds one 33 KB
+    gradient all-reduce per step: its cost is measured here on a ONE-RANK RCCL group (the call path and launch of
+    `allreduce_gradients`, not the 8-rank ring latency -- no multi-GPU node is available to this run) and added to the
+    shard time for `speedup_at_N_gpus_incl_allreduce`."""
     out = {"batch_32768_ms": full_ms}
     params = list(func.parameters())
+    allreduce_ms = measured_allreduce_ms(params)
+    out["allreduce_33KB_1rank_rccl_ms"] = allreduce_ms
     for n_gpus in (2, 4, 8):
         b = 32768 // n_gpus
         if b > x.size(0):
@@ -169,7 +173,46 @@ def strong_scaling_proxy(cde, x, func, z0, full_ms):
         ms = (time.perf_counter() - t0) / 20 * 1e3
         out["batch_%d_ms" % b] = ms
         out["speedup_at_%d_gpus_compute_only" % n_gpus] = full_ms / ms
+        if allreduce_ms is not None:
+            out["speedup_at_%d_gpus_incl_allreduce" % n_gpus] = full_ms / (ms + allreduce_ms)
     return out
+
+
+def measured_allreduce_ms(params):
+    """`distributed.allreduce_gradients` of the 8,448 parameter gradients on a one-rank RCCL process group, ms per call
+    (stream time over 50 calls after 5 warm-ups); None when no group can be formed here."""
+    import socket
+    import torch.distributed as dist
+    from torchcde_amd.distributed import allreduce_gradients
+    created = False
+    try:
+        if not dist.is_initialized():
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                port = sock.getsockname()[1]
+            dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+            created = True
+        for p in params:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        for _ in range(5):
+            allreduce_gradients(params)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev[0].record()
+        for _ in range(50):
+            allreduce_gradients(params)
+        ev[1].record()
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / 50 * 1e3
+        return max(ev[0].elapsed_time(ev[1]) / 50, wall)          # the larger of stream time and host time per call
+    except Exception as err:                                      # no RCCL here: the proxy stays compute-only
+        _log("all-reduce timing skipped: %r" % (err,))
+        return None
+    finally:
+        if created:
+            dist.destroy_process_group()
 
 
 def bf16x3_variant(cde, X, func, z0, steps=10):
@@ -352,6 +395,20 @@ def other_configs(cde, device, reps=3):
     xs = make_series(4096, L, C, seed=0).to(device)
     Xs = cde.CubicSpline(cde.hermite_cubic_coefficients_with_backward_differences(xs))
     zs0 = torch.randn(4096, H, generator=torch.Generator().manual_seed(0)).to(device)
+    # ... and at the examples' own batch size (batch_size=32, example/time_series_classification.py:149): the eight-waves-
+    # per-tile attempt kernel with the factor reduction + R step in one launch
+    zb0 = zs0[:32].contiguous()
+    Xb = cde.CubicSpline(cde.hermite_cubic_coefficients_with_backward_differences(xs[:32].contiguous()))
+    for tag, extra in (("", {}), ("_seminorm", dict(adjoint_options=dict(norm="seminorm")))):
+        zb = zb0.detach().requires_grad_(True)
+        cde.cdeint(Xb, model, zb, Xb.interval, **extra)
+        fwd_ms = once(lambda: cde.cdeint(Xb, model, zb, Xb.interval, **extra))
+        res = cde.cdeint(Xb, model, zb, Xb.interval, **extra)
+        out["example_model_batch32_default_call%s_forward_ms" % tag] = fwd_ms
+        out["example_model_batch32_default_call%s_backward_ms" % tag] = once(lambda: res[:, -1].sum().backward())
+        st = front.last_dopri5_adjoint_stats
+        out["example_model_batch32_default_call%s_us_per_attempt" % tag] = (
+            out["example_model_batch32_default_call%s_backward_ms" % tag] * 1e3 / max(st.get("n_accept", 0) + st.get("n_reject", 0), 1))
     for tag, extra in (("", {}), ("_seminorm", dict(adjoint_options=dict(norm="seminorm")))):
         zs = zs0.detach().requires_grad_(True)
         cde.cdeint(Xs, model, zs, Xs.interval, **extra)        # warm-up of the forward kernels

@@ -571,14 +571,20 @@ __global__ __launch_bounds__(512, 2) void dopri5_mlp_adjoint_attempt_s8(MlpAdjAr
 
 #pragma clang loop unroll(disable)
   for (int i = 0; i < ns; ++i) {
-    // the scalars of stage i and its Butcher row (zero for the slopes it does not use), by wave-uniform select chains
+    // the control row of stage i first: its (L2) latency runs under the select chains and the stage combination below
     int idx_i = sidx[0];
-    float frac_i = sfrac[0], wS_i = wS[0], wE_i = wE[0];
+    float frac_i = sfrac[0];
+#pragma unroll
+    for (int kk = 1; kk < 7; ++kk) { idx_i = i == kk ? sidx[kk] : idx_i; frac_i = i == kk ? sfrac[kk] : frac_i; }
+    const Row<DEGREE, CT> row = load_row<DEGREE, CT>(g.coeffs, sc, g.n_intervals, idx_i, Cr);
+    const float width = DEGREE == CDE_PATH_LINEAR ? g.knots[idx_i + 1] - g.knots[idx_i] : 1.f;
+    // the other scalars of stage i and its Butcher row (zero for the slopes it does not use), by wave-uniform select chains
+    float wS_i = wS[0], wE_i = wE[0];
     float wj[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 1; kk < 7; ++kk) {
       const bool at = i == kk;
-      idx_i = at ? sidx[kk] : idx_i; frac_i = at ? sfrac[kk] : frac_i; wS_i = at ? wS[kk] : wS_i; wE_i = at ? wE[kk] : wE_i;
+      wS_i = at ? wS[kk] : wS_i; wE_i = at ? wE[kk] : wE_i;
 #pragma unroll
       for (int j = 0; j < 6; ++j) wj[j] = at ? bc[kk][j] : wj[j];
     }
@@ -596,8 +602,6 @@ __global__ __launch_bounds__(512, 2) void dopri5_mlp_adjoint_attempt_s8(MlpAdjAr
     const float as_w = a0 + ja;
     float dX[CT], d2X[CT];
     {
-      const Row<DEGREE, CT> row = load_row<DEGREE, CT>(g.coeffs, sc, g.n_intervals, idx_i, Cr);
-      const float width = DEGREE == CDE_PATH_LINEAR ? g.knots[idx_i + 1] - g.knots[idx_i] : 1.f;
       control_slope<DEGREE, CT>(row, frac_i, width, dX);
       const float* f = reinterpret_cast<const float*>(row.v);
 #pragma unroll
