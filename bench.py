@@ -3,7 +3,7 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python bench.py --config 4 [--controller local|shared] [--adjoint] [--gpus N]     BASELINE configs[3] (see run_adaptive_config)
-    python bench.py --config 5 [--method dopri5|rk4] [--gpus N]                       BASELINE configs[4] (see run_logode_config)
+    python bench.py --config 5 [--method dopri5|rk4] [--controller local|shared] [--gpus N]   BASELINE configs[4] (see run_logode_config)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -525,6 +525,12 @@ def run_logode_config(args, cde, device, rank, world, distributed, share_gpu):
         solver["adjoint_options"] = dict(norm="seminorm")
     times = {"transform": 0.0}
 
+    import contextlib
+    from torchcde_amd.distributed import shared_step_control
+    shared = args.controller == "shared" and args.method != "rk4"
+    if shared and not distributed:
+        raise SystemExit("--controller shared needs a process group (N > 1, or CDE_BENCH_FORCE_DIST=1 on one GPU)")
+
     def step():
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         ev[0].record()
@@ -533,7 +539,9 @@ def run_logode_config(args, cde, device, rank, world, distributed, share_gpu):
         z = z8.detach().requires_grad_(True)
         for p in params:
             p.grad = None
-        cde.cdeint(Xl, field, z, Xl.interval, **solver)[:, -1].sum().backward()
+        # --controller shared: ONE step controller for the whole sharded batch (K4 / K4am with the two-layer field, round 4)
+        with (shared_step_control(n * world) if shared else contextlib.nullcontext()):
+            cde.cdeint(Xl, field, z, Xl.interval, **solver)[:, -1].sum().backward()
         if distributed:
             allreduce_gradients(params)
         return ev
@@ -573,7 +581,8 @@ def run_logode_config(args, cde, device, rank, world, distributed, share_gpu):
                                    "Linear(8,128)-relu-Linear(128,112)-tanh field, method %s, adjoint=True; %d series in total"
                                    % ("dopri5 (the reference example's default call)" if args.method != "rk4" else "rk4 step 1",
                                       n * world),
-                       "method": args.method, "adjoint_norm": args.norm, "batch_per_gpu": n, "global_batch": n * world,
+                       "method": args.method, "adjoint_norm": args.norm, "controller": "shared" if shared else "local",
+                       "batch_per_gpu": n, "global_batch": n * world,
                        "parallelism": "batch-sharded x%d, one gradient all-reduce per step" % world},
             "extra": extra}))
 
@@ -585,7 +594,7 @@ def main():
                     help="3 (default): the headline metric, BASELINE configs[2]; 4: configs[3] (sharded adaptive dopri5 solve); "
                          "5: configs[4] (log-ODE pipeline)")
     ap.add_argument("--controller", choices=("local", "shared"), default="local",
-                    help="--config 4: one step controller per rank, or ONE for the whole sharded batch (all-reduce per attempt)")
+                    help="--config 4 / 5: one step controller per rank, or ONE for the whole sharded batch (all-reduce per attempt)")
     ap.add_argument("--adjoint", action="store_true", help="--config 4: also time the default adjoint backward")
     ap.add_argument("--method", choices=("dopri5", "rk4"), default="dopri5", help="--config 5: the solver")
     ap.add_argument("--norm", choices=("mixed", "seminorm"), default="mixed",

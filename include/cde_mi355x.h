@@ -475,6 +475,34 @@ int cde_dopri5_adjoint_mlp_advance(const void* coeffs, const void* knots, int64_
                                    int first_interval, void* workspace, size_t workspace_bytes, int64_t first_launch,
                                    int64_t n_launches, void* stream);
 
+/* K4am under ONE step controller for a batch sharded over GPUs (round 4): the protocol of the one-layer kernels above.
+ * Per attempted step n every shard runs
+ *   cde_dopri5_adjoint_mlp_advance_sharded(first_launch = n, reduced_sums = the buffer below (NULL for n == 0), B_global)
+ *       -- ONE attempt launch, no reduction
+ *   cde_dopri5_adjoint_mlp_pending_sums(total_launches = n + 1) -> cde_dopri5_adjoint_mlp_reduced_count() doubles on the
+ *       device: 8 state sums, then this shard's S (increment) and E (error) images of the four parameter tensors in the
+ *       gradient layout (2 x 37,248 values)
+ *   an all-reduce (sum) of that buffer over the shards
+ *   cde_dopri5_adjoint_mlp_apply_reduced(total_launches = n + 1, the reduced buffer): commit + parameter norms on the
+ *       GLOBAL images (every shard keeps the global running total for the norm and its OWN total, which is what
+ *       cde_dopri5_adjoint_mlp_gradient_offset() points at: the caller all-reduces gradients as for any data-parallel step)
+ * and all shards take the same decisions.  Replaces, for a sharded batch, the same reference call as K4am
+ * (example/time_series_classification.py:83-86 over solver.py:199-203,226). */
+size_t cde_dopri5_adjoint_mlp_reduced_count(void);
+int cde_dopri5_adjoint_mlp_advance_sharded(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
+                                           const void* W1, const void* bias1, int64_t width, const void* W2,
+                                           const void* bias2, int act, const void* y_init, const void* a_init, double s0,
+                                           double s1, const double* jump_s, int64_t n_jump, double rtol, double atol,
+                                           double safety, double ifactor, double dfactor, int norm_kind, void* a_out,
+                                           int64_t B, int64_t C, int64_t H, int dtype, int first_interval, void* workspace,
+                                           size_t workspace_bytes, int64_t first_launch, const double* reduced_sums,
+                                           int64_t B_global, void* stream);
+int cde_dopri5_adjoint_mlp_pending_sums(void* workspace, size_t workspace_bytes, int64_t B, int64_t C, int64_t H,
+                                        int64_t total_launches, double* sums, void* stream);
+int cde_dopri5_adjoint_mlp_apply_reduced(void* workspace, size_t workspace_bytes, int64_t B, int64_t C, int64_t H,
+                                         double rtol, double atol, int64_t total_launches, const double* reduced,
+                                         void* stream);
+
 /* Sharded batches under ONE step controller -- torchdiffeq's semantics for the whole batch when the batch lives on
  * several GPUs.  Per attempted step every shard (1) calls cde_dopri5_pending_sums(total_launches so far) -> 2 doubles on
  * the device, (2) all-reduces them (sum) with the other shards, (3) runs ONE launch through cde_dopri5_advance_sharded
@@ -498,6 +526,16 @@ int cde_dopri5_advance_mlp(const void* coeffs, const void* knots, int64_t n_inte
                            double rtol, double atol, double safety, double ifactor, double dfactor, void* z_out,
                            int64_t B, int64_t C, int64_t H, int dtype, void* workspace, size_t workspace_bytes,
                            int64_t first_launch, int64_t n_launches, void* stream);
+/* ... and under ONE controller for a sharded batch (round 4): cde_dopri5_pending_sums / cde_dopri5_advance_sharded for the
+ * two-layer field (one launch per all-reduce of the 2 pending sums). */
+int cde_dopri5_pending_sums_mlp(const void* workspace, size_t workspace_bytes, int64_t B, int64_t C, int64_t H, int dtype,
+                                int64_t total_launches, double* sums, void* stream);
+int cde_dopri5_advance_mlp_sharded(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W1,
+                                   const void* bias1, int64_t width, const void* W2, const void* bias2, int act,
+                                   const void* z0, const double* t_out, int64_t n_out, const double* jump_t, int64_t n_jump,
+                                   double rtol, double atol, double safety, double ifactor, double dfactor, void* z_out,
+                                   int64_t B, int64_t C, int64_t H, int dtype, void* workspace, size_t workspace_bytes,
+                                   int64_t first_launch, const double* reduced_sums, int64_t B_global, void* stream);
 
 #ifdef __cplusplus
 }

@@ -177,6 +177,65 @@ class _ProtocolLib:
         self.log.append(("finish", sharded))
         return 0
 
+    # --- the same protocol for the two-layer field (round 4): K4 / K4am under one controller
+    MLP_REDUCED = 8 + 2 * 24
+
+    def cde_dopri5_adjoint_mlp_workspace_bytes(self, B, C, H):
+        return 4096 + 4 * (256 * 129 + 128 * 33) + 4096
+
+    def cde_dopri5_adjoint_mlp_gradient_offset(self, B, C, H):
+        return 4096
+
+    def cde_dopri5_adjoint_mlp_reduced_count(self):
+        return self.MLP_REDUCED
+
+    def cde_dopri5_pending_sums_mlp(self, ws, ws_bytes, B, C, H, dt, launched, sums, stream):
+        out = self._doubles(sums, 2)
+        out[0], out[1] = (self.rank + 1) * (launched + 1), 10.0 * (self.rank + 1)
+        self.log.append(("mlp_fwd_pending", launched))
+        return 0
+
+    def cde_dopri5_advance_mlp_sharded(self, *a):
+        width, ws, launched, sums, global_batch = a[6], a[25], a[27], a[28], a[29]
+        got = self._doubles(sums, 2)
+        total_ranks = sum(range(1, self.world + 1))
+        assert width == 8 and global_batch == 11
+        assert got[0] == total_ranks * (launched + 1) and got[1] == 10.0 * total_ranks, (self.rank, launched, got[0], got[1])
+        self.log.append(("mlp_fwd_launch", launched))
+        from torchcde_amd import _lib
+        done = launched + 1 >= self.N_ATTEMPTS
+        self._status(ws, launched + 1, self.ct.sizeof(_lib.DopriStatus), 4 if done else 3, min(launched + 1, self.N_ATTEMPTS))
+        return 0
+
+    def cde_dopri5_adjoint_mlp_advance_sharded(self, *a):
+        width, ws, first, sums, global_batch = a[6], a[28], a[30], a[31], a[32]
+        assert width == 8 and global_batch == 11
+        if first == 0:
+            assert sums is None or not getattr(sums, "value", sums), "the first launch of an interval has nothing pending"
+        else:
+            got = self._doubles(sums, self.MLP_REDUCED)
+            assert got[0] == sum(range(1, self.world + 1)) * first, (first, got[0])
+            assert got[8] == 100.0 * sum(range(1, self.world + 1)) and got[self.MLP_REDUCED - 1] == got[8]
+        self.log.append(("mlp_bwd_launch", first))
+        done = first + 1 >= self.N_ATTEMPTS
+        self._status(ws, first + 1, 256, 4 if done else 3, min(first + 1, self.N_ATTEMPTS))
+        return 0
+
+    def cde_dopri5_adjoint_mlp_pending_sums(self, ws, ws_bytes, B, C, H, total, sums, stream):
+        out = self._doubles(sums, self.MLP_REDUCED)
+        for i in range(8):
+            out[i] = (self.rank + 1) * total
+        for i in range(8, self.MLP_REDUCED):
+            out[i] = 100.0 * (self.rank + 1)
+        self.log.append(("mlp_bwd_pending", total))
+        return 0
+
+    def cde_dopri5_adjoint_mlp_apply_reduced(self, ws, ws_bytes, B, C, H, rtol, atol, total, reduced, stream):
+        got = self._doubles(reduced, self.MLP_REDUCED)
+        assert got[0] == sum(range(1, self.world + 1)) * total
+        self.log.append(("mlp_bwd_apply", total))
+        return 0
+
 
 def _shared_worker(rank, world, port, tmp):
     sys.path.insert(0, ROOT)
@@ -207,6 +266,17 @@ def _shared_worker(rank, world, port, tmp):
     assert front.last_dopri5_stats["n_accept"] == fake.N_ATTEMPTS
     plan.run_adjoint(out, torch.ones(n, 2, 4), w, b)
     assert front.last_dopri5_adjoint_stats["launches"] % front._DOPRI_CHUNK == 0
+    # ... and the two-layer field (K4 / K4am): the same order of calls, with its own entry points
+    hidden = types.SimpleNamespace(weight=torch.zeros(8, 4), bias=torch.zeros(8))
+    field2 = types.SimpleNamespace(act=_lib.ACT_TANH, kind="mlp2", hidden=hidden)
+    with shared_step_control(11):
+        plan2 = front._Dopri5Plan(path, field2, (n,), 4, 3, t, 1e-4, 1e-6, None)
+    w2, b2 = torch.zeros(12, 8), torch.zeros(12)
+    out2 = plan2.run(torch.zeros(n, 4), w2, b2)
+    assert front.last_dopri5_stats["n_accept"] == fake.N_ATTEMPTS
+    grads = plan2.run_adjoint_mlp(out2, torch.ones(n, 2, 4), hidden.weight, hidden.bias, w2, b2)
+    assert grads[1].shape == (8, 4) and grads[3].shape == (12, 8)
+    assert front.last_dopri5_adjoint_stats["launches"] % front._DOPRI_CHUNK == 0
     torch.save(fake.log, tmp + ".%d" % rank)
     dist.barrier()
     dist.destroy_process_group()
@@ -229,4 +299,9 @@ def test_shared_step_control_protocol_on_two_gloo_ranks(tmp_path):
     assert kinds[first_fwd:first_fwd + 2 * n] == ["fwd_pending", "fwd_launch"] * n        # pending -> reduce -> launch
     first_bwd = kinds.index("bwd_launch")
     assert kinds[first_bwd:first_bwd + 3 * n] == ["bwd_launch", "bwd_pending", "bwd_apply"] * n
-    assert kinds[-1] == "finish"
+    assert "finish" in kinds
+    # the two-layer field: pending -> reduce -> launch forward; launch -> pending -> reduce -> apply backward
+    first_fwd = kinds.index("mlp_fwd_pending")
+    assert kinds[first_fwd:first_fwd + 2 * n] == ["mlp_fwd_pending", "mlp_fwd_launch"] * n
+    first_bwd = kinds.index("mlp_bwd_launch")
+    assert kinds[first_bwd:first_bwd + 3 * n] == ["mlp_bwd_launch", "mlp_bwd_pending", "mlp_bwd_apply"] * n

@@ -789,7 +789,7 @@ def test_dispatch_table_is_exhaustively_consistent():
                     if c.path == "dopri5_adjoint":
                         assert f["mfma_shape"] and not f["wants_t"] and not f["wants_control"]
                     if c.path == "mlp_dopri5_adjoint":
-                        assert not f["shared"] and not f["wants_t"] and not f["wants_control"]
+                        assert not f["wants_t"] and not f["wants_control"]
                     if kind == "mlp2":
                         assert not f["variant_generic"]
                         assert not f["wants_t"] and (not f["wants_control"] or (f["narrow_control"] and method == "rk4"))
@@ -812,11 +812,11 @@ def test_dispatch_table_is_exhaustively_consistent():
     assert ask(wants_grad=False).path == "dopri5_forward"                       # BASELINE configs[3]
     assert ask(kind="mlp2", mfma_shape=False, method="rk4").path == "mlp_rk4_adjoint"      # BASELINE configs[4] with rk4
     assert ask(shared=True).path == "dopri5_adjoint"                            # one controller over the shards
+    assert ask(kind="mlp2", mfma_shape=False, shared=True).path == "mlp_dopri5_adjoint"    # ... for the examples' model too
     assert ask(method="rk4", wants_control=True, params="own").path == "rk4"    # README.md:251-270
     for kw, word in ((dict(kind=None), "recognised"), (dict(method="midpoint"), "midpoint"),
                      (dict(adjoint=False), "adjoint=False"), (dict(options_ok=False), "options"),
                      (dict(mfma_shape=False), "32 x 8"), (dict(wants_t=True), "time"),
-                     (dict(kind="mlp2", mfma_shape=False, shared=True), "shared_step_control"),
                      (dict(kind="mlp2", mfma_shape=False, method="rk4", wants_control=True, narrow_control=False), "8 channels"),
                      (dict(t_ok=False), "increasing"), (dict(params="foreign"), "adjoint_params"),
                      (dict(prod=True), "prod"), (dict(tiles_ok=False, mfma_shape=False), "tiles")):

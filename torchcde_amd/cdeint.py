@@ -566,7 +566,7 @@ class _Dopri5Plan:
                 jb = torch.sort(_to_host(torch.as_tensor(jump_b)).to(torch.float64).reshape(-1)).values
                 self.jump_s, self.n_jump_s = (-jb).flip(0).contiguous().to(self.device), jb.numel()
 
-    def _run_shared(self, lib, shared, out, z0c, w, b, dt, workspace):
+    def _run_shared(self, lib, shared, out, z0c, w, b, dt, workspace, w1=None, b1=None):
         """One controller for all shards: per attempted step the pending error sums are all-reduced before the launch
         that consumes them (torchcde_amd.distributed.shared_step_control)."""
         reduce, global_batch = shared
@@ -576,16 +576,28 @@ class _Dopri5Plan:
         launched = 0
         while True:
             for _ in range(_DOPRI_CHUNK):
-                _lib.check(lib.cde_dopri5_pending_sums(_lib.ptr(workspace), workspace.numel(), self.B, self.C, self.H, dt,
-                                                       self.variant, self.act, launched, _lib.ptr(sums), stream),
-                           "cde_dopri5_pending_sums")
-                reduce(sums)
-                _lib.check(lib.cde_dopri5_advance_sharded(
-                    _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w), _lib.ptr(b),
-                    self.act, _lib.ptr(z0c), _lib.ptr(self.t_out), self.n_out, _lib.ptr(self.jump_t), self.n_jump,
-                    self.rtol, self.atol, self.safety, self.ifactor, self.dfactor, _lib.ptr(out), self.B, self.C, self.H,
-                    dt, self.variant, _lib.ptr(workspace), workspace.numel(), launched, _lib.ptr(sums), global_batch,
-                    stream), "cde_dopri5_advance_sharded")
+                if self.hidden is None:
+                    _lib.check(lib.cde_dopri5_pending_sums(_lib.ptr(workspace), workspace.numel(), self.B, self.C, self.H, dt,
+                                                           self.variant, self.act, launched, _lib.ptr(sums), stream),
+                               "cde_dopri5_pending_sums")
+                    reduce(sums)
+                    _lib.check(lib.cde_dopri5_advance_sharded(
+                        _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w), _lib.ptr(b),
+                        self.act, _lib.ptr(z0c), _lib.ptr(self.t_out), self.n_out, _lib.ptr(self.jump_t), self.n_jump,
+                        self.rtol, self.atol, self.safety, self.ifactor, self.dfactor, _lib.ptr(out), self.B, self.C, self.H,
+                        dt, self.variant, _lib.ptr(workspace), workspace.numel(), launched, _lib.ptr(sums), global_batch,
+                        stream), "cde_dopri5_advance_sharded")
+                else:                                                  # the two-layer field (round 4)
+                    _lib.check(lib.cde_dopri5_pending_sums_mlp(_lib.ptr(workspace), workspace.numel(), self.B, self.C, self.H,
+                                                               dt, launched, _lib.ptr(sums), stream),
+                               "cde_dopri5_pending_sums_mlp")
+                    reduce(sums)
+                    _lib.check(lib.cde_dopri5_advance_mlp_sharded(
+                        _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w1), _lib.ptr(b1),
+                        w1.size(0), _lib.ptr(w), _lib.ptr(b), self.act, _lib.ptr(z0c), _lib.ptr(self.t_out), self.n_out,
+                        _lib.ptr(self.jump_t), self.n_jump, self.rtol, self.atol, self.safety, self.ifactor, self.dfactor,
+                        _lib.ptr(out), self.B, self.C, self.H, dt, _lib.ptr(workspace), workspace.numel(), launched,
+                        _lib.ptr(sums), global_batch, stream), "cde_dopri5_advance_mlp_sharded")
                 launched += 1
             raw = workspace[(launched & 1) * size:(launched & 1) * size + size].cpu().numpy().tobytes()
             status = _lib.DopriStatus.from_buffer_copy(raw)
@@ -707,6 +719,10 @@ class _Dopri5Plan:
         stride = lib.cde_dopri5_adjoint_status_stride()
         a_out = torch.empty(B, H, dtype=torch.float32, device=dev)
         stream = _lib.stream_ptr(dev)
+        shared = self.shared
+        reduced = None
+        if shared is not None:
+            reduced = torch.zeros(lib.cde_dopri5_adjoint_mlp_reduced_count(), dtype=torch.float64, device=dev)
         stats = dict(n_accept=0, n_reject=0, launches=0)
         steps, attempts = [], []
         for i in range(self.n_out - 1, 0, -1):
@@ -714,14 +730,36 @@ class _Dopri5Plan:
             s0, s1 = -float(self.t_host[i]), -float(self.t_host[i - 1])
             launched = 0
             while True:
-                _lib.check(lib.cde_dopri5_adjoint_mlp_advance(
-                    _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w1), _lib.ptr(b1),
-                    width, _lib.ptr(w2), _lib.ptr(b2), self.act, _lib.ptr(y), _lib.ptr(a), s0, s1, _lib.ptr(self.jump_s),
-                    self.n_jump_s, self.adjoint_rtol, self.adjoint_atol, self.adj_safety, self.adj_ifactor,
-                    self.adj_dfactor, self.adj_norm_kind, _lib.ptr(a_out), B, C, H, _lib.dtype_enum(torch.float32),
-                    int(i == self.n_out - 1), _lib.ptr(workspace), workspace.numel(), launched, _DOPRI_CHUNK, stream),
-                    "cde_dopri5_adjoint_mlp_advance")
-                launched += _DOPRI_CHUNK
+                if shared is None:
+                    _lib.check(lib.cde_dopri5_adjoint_mlp_advance(
+                        _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w1), _lib.ptr(b1),
+                        width, _lib.ptr(w2), _lib.ptr(b2), self.act, _lib.ptr(y), _lib.ptr(a), s0, s1, _lib.ptr(self.jump_s),
+                        self.n_jump_s, self.adjoint_rtol, self.adjoint_atol, self.adj_safety, self.adj_ifactor,
+                        self.adj_dfactor, self.adj_norm_kind, _lib.ptr(a_out), B, C, H, _lib.dtype_enum(torch.float32),
+                        int(i == self.n_out - 1), _lib.ptr(workspace), workspace.numel(), launched, _DOPRI_CHUNK, stream),
+                        "cde_dopri5_adjoint_mlp_advance")
+                    launched += _DOPRI_CHUNK
+                else:
+                    # one controller for all shards (round 4): per attempted step ONE attempt launch, then this shard's
+                    # state sums + S / E gradient images are all-reduced and every shard commits / measures the
+                    # parameter blocks on the same (global) numbers
+                    for _ in range(_DOPRI_CHUNK):
+                        _lib.check(lib.cde_dopri5_adjoint_mlp_advance_sharded(
+                            _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w1),
+                            _lib.ptr(b1), width, _lib.ptr(w2), _lib.ptr(b2), self.act, _lib.ptr(y), _lib.ptr(a), s0, s1,
+                            _lib.ptr(self.jump_s), self.n_jump_s, self.adjoint_rtol, self.adjoint_atol, self.adj_safety,
+                            self.adj_ifactor, self.adj_dfactor, self.adj_norm_kind, _lib.ptr(a_out), B, C, H,
+                            _lib.dtype_enum(torch.float32), int(i == self.n_out - 1), _lib.ptr(workspace), workspace.numel(),
+                            launched, _lib.ptr(reduced) if launched else None, shared[1], stream),
+                            "cde_dopri5_adjoint_mlp_advance_sharded")
+                        launched += 1
+                        _lib.check(lib.cde_dopri5_adjoint_mlp_pending_sums(_lib.ptr(workspace), workspace.numel(), B, C, H,
+                                                                           launched, _lib.ptr(reduced), stream),
+                                   "cde_dopri5_adjoint_mlp_pending_sums")
+                        shared[0](reduced)
+                        _lib.check(lib.cde_dopri5_adjoint_mlp_apply_reduced(
+                            _lib.ptr(workspace), workspace.numel(), B, C, H, self.adjoint_rtol, self.adjoint_atol, launched,
+                            _lib.ptr(reduced), stream), "cde_dopri5_adjoint_mlp_apply_reduced")
                 at = (launched & 1) * stride
                 status = _lib.DopriStatus.from_buffer_copy(workspace[at:at + size].cpu().numpy().tobytes())
                 if status.phase == 4:
@@ -775,7 +813,7 @@ class _Dopri5Plan:
         shared = self.shared
         if shared is not None:
             if self.hidden is not None:
-                raise NotImplementedError("torchcde_amd: shared_step_control covers the one-layer fields (K4 / K4a).")
+                return self._run_shared(lib, shared, out, z0c, w, b, dt, workspace, w1, b1)
             return self._run_shared(lib, shared, out, z0c, w, b, dt, workspace)
         while True:
             if self.hidden is None:

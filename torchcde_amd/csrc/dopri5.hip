@@ -1320,3 +1320,33 @@ extern "C" int cde_dopri5_advance_mlp(const void* coeffs, const void* knots, int
                              jump_t, n_jump, rtol, atol, safety, ifactor, dfactor, z_out, B, C, H, dtype,
                              CDE_VARIANT_AUTO, workspace, workspace_bytes, first_launch, n_launches, stream);
 }
+
+// The same two calls for the two-layer field (round 4): one controller across the shards of a sharded batch for the
+// call every example of the reference makes (cde_dopri5_advance_mlp's arguments + the reduced sums / global batch).
+extern "C" int cde_dopri5_pending_sums_mlp(const void* workspace, size_t workspace_bytes, int64_t B, int64_t C, int64_t H,
+                                           int dtype, int64_t total_launches, double* sums, void* stream) {
+  if (B < 1 || C < 1 || H < 1) return CDE_ERR_SHAPE;
+  if (!workspace || !sums) return CDE_ERR_NULL;
+  if (workspace_bytes < cde_dopri5_workspace_bytes(B, C, H, dtype)) return CDE_ERR_WORKSPACE;
+  const int64_t stride = cde::dopri_blocks_any(B, H);
+  const int64_t live = (B + 127) / 128;                 // the grid of the (never split, when sharded) two-layer attempt kernel
+  const double* partial = (const double*)((const unsigned char*)workspace + cde::al256(2 * sizeof(cde::DopriCtrl))) +
+                          (total_launches & 1) * stride * 2;
+  cde::dopri_pending_sums_kernel<<<1, 64, 0, (hipStream_t)stream>>>(partial, live, 2, sums);
+  return cde::check_launch();
+}
+
+extern "C" int cde_dopri5_advance_mlp_sharded(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
+                                              const void* W1, const void* bias1, int64_t width, const void* W2,
+                                              const void* bias2, int act, const void* z0, const double* t_out,
+                                              int64_t n_out, const double* jump_t, int64_t n_jump, double rtol, double atol,
+                                              double safety, double ifactor, double dfactor, void* z_out, int64_t B,
+                                              int64_t C, int64_t H, int dtype, void* workspace, size_t workspace_bytes,
+                                              int64_t first_launch, const double* reduced_sums, int64_t B_global,
+                                              void* stream) {
+  if (!W1) return CDE_ERR_NULL;
+  if (!reduced_sums || B_global < B) return reduced_sums ? CDE_ERR_SHAPE : CDE_ERR_NULL;
+  return dopri5_advance_impl(coeffs, knots, n_intervals, degree, W1, bias1, width, W2, bias2, act, z0, t_out, n_out,
+                             jump_t, n_jump, rtol, atol, safety, ifactor, dfactor, z_out, B, C, H, dtype,
+                             CDE_VARIANT_AUTO, workspace, workspace_bytes, first_launch, 1, stream, reduced_sums, B_global);
+}

@@ -52,6 +52,7 @@ struct MlpAdjArgs {
   float* U; float* G2; float* G1; float* Z;      // factor rows [slot][rows_per_stage]
   AdjCommon com;
   int n_wg_max;
+  const double* ext_sums;           // sharded batch: the ADJ_NS state sums of the pending attempt, added up over ALL shards
   int n_pq;                         // blocks of parameter sums the R kernel of this batch size leaves in `pq`
   int dbg;                          // CDE_K4AM_DBG (timing experiments only): bit 0 = no factor stores
 };
@@ -111,6 +112,10 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
 #pragma unroll
       for (int i = 0; i < 8; ++i) sum[ADJ_NS + i] += Qp[8 * b + i];
     }
+  }
+  if (g.ext_sums && c.phase != 0) {                                // one controller for all shards: the reduced state sums
+#pragma unroll
+    for (int i = 0; i < ADJ_NS; ++i) sum[i] = tid == 0 ? g.ext_sums[i] : 0.0;
   }
   block_total<MADJ_NSUM>(sum, red);                                // (also the barrier after the LDS image copy)
   CDE_STAMP(1);
@@ -493,6 +498,9 @@ __global__ __launch_bounds__(512, 2) void dopri5_mlp_adjoint_attempt_s8(MlpAdjAr
   if (c.phase == 0) {
 #pragma unroll
     for (int i = 0; i < MADJ_NSUM; ++i) sum[i] = 0.0;
+  } else if (g.ext_sums) {                                         // one controller for all shards: the reduced state sums
+#pragma unroll
+    for (int i = 0; i < ADJ_NS; ++i) sum[i] = tid == 0 ? g.ext_sums[i] : 0.0;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's part of the LDS image has landed ..
   block_total<MADJ_NSUM>(sum, red);                                // .. and, past its barriers, everybody's
@@ -716,22 +724,29 @@ __global__ __launch_bounds__(512, 2) void dopri5_mlp_adjoint_attempt_s8(MlpAdjAr
 // columns = hidden-layer unit, last column = the bias), then layer 1 [128][33].  K_s[e] = sum over the slabs of stage s
 // (fixed order); S = sum_s wS[s] K_s, E = sum_s wE[s] K_s with the weights of cde_dopri_adj.h rebuilt from the controller
 // block; then the commit / norm logic of adj_param_element, per-block sums per parameter tensor (W1, b1, W2, b2).
+//   stage 0 (fused) : S, E from the slab partials -> commit -> norms          (unsharded: one launch per attempt)
+//   stage 1         : S, E only, into `sums_out` (doubles)                    (sharded: the host all-reduces them ...)
+//   stage 2         : commit + norms from `sums_in`                           (... every rank then holds the same images)
 struct MlpReduceArgs {
   unsigned char* ctrl;
   const float* part2; const float* part1;   // slab partials [slot][sps][M][N + 1]
   int sps;
-  float* G;                 // [MADJ_ELEMS] running totals (layer 2 block, then layer 1 block)
-  float* prevS;             // [2][MADJ_ELEMS]
+  float* G;                 // [MADJ_ELEMS] running totals (layer 2 block, then layer 1 block): what the caller gets back
+  float* prevS;             // [2][MADJ_ELEMS]: the S sums of a launch, kept for the commit one launch later
+  float* Gn;                // sharded: the running totals of the GLOBAL batch (the norm needs those); else nullptr
+  float* prevSn;            // sharded: the global S sums
   double* pq;               // [2][MADJ_RBLOCKS][8]
   const double* partial; int n_wg; int n_wg_max;
   double* carry;
+  double* sums_out;         // stage 1: [2][MADJ_ELEMS] doubles (S, E)
+  const double* sums_in;    // stage 2: the reduced buffer (ADJ_NS state sums, then the S and E images)
   float rtol, atol;
 };
 
 // Launch shape: 32 elements per block x 8 lanes; lane s < 6 adds the slabs of stored stage s (independent loads, eight
 // in flight: one thread walking all 6 x 40 slabs was a 240-deep chain of L2 latencies), the stage images of an element
 // meet in LDS and are weighted in stage order.
-__global__ __launch_bounds__(256) void mlp_adjoint_reduce_kernel(MlpReduceArgs r, int parity) {
+__global__ __launch_bounds__(256) void mlp_adjoint_reduce_kernel(MlpReduceArgs r, int parity, int stage = 0) {
   __shared__ float ks[8][33];
   __shared__ double red[8][32];
   const int p2 = parity ^ 1;
@@ -741,7 +756,7 @@ __global__ __launch_bounds__(256) void mlp_adjoint_reduce_kernel(MlpReduceArgs r
   const int e = blockIdx.x * 32 + el;
   const int n_slots = k.mode == 0 ? 1 : k.mode == 1 ? 2 : MADJ_SLOTS;
   const bool layer2 = e < MADJ_P2;
-  {
+  if (stage != 2) {
     float sum = 0.f;
     if (e < MADJ_ELEMS && sl < n_slots) {
       const float* base = (layer2 ? r.part2 + e : r.part1 + (e - MADJ_P2)) + (int64_t)sl * r.sps * (layer2 ? MADJ_P2 : MADJ_P1);
@@ -759,29 +774,51 @@ __global__ __launch_bounds__(256) void mlp_adjoint_reduce_kernel(MlpReduceArgs r
   __syncthreads();
   double qv[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   if (sl == 0) {
-    if (k.mode == 3 && e == 0) {
+    if (stage != 1 && k.mode == 3 && e == 0) {
       double vt = 0.0;
-      for (int b = 0; b < r.n_wg; ++b) vt += r.partial[((int64_t)p2 * r.n_wg_max + b) * ADJ_NS + 4];
+      if (stage == 2) vt = r.sums_in[4];
+      else
+        for (int b = 0; b < r.n_wg; ++b) vt += r.partial[((int64_t)p2 * r.n_wg_max + b) * ADJ_NS + 4];
       r.carry[0] = (double)((float)k.T + (float)vt);
     }
     if (e < MADJ_ELEMS) {
-      float wS[7], wE[7];
-      adj_stage_weights(k.mode, (float)k.c.dt_try, (float)k.x_end, wS, wE);
       float S = 0.f, E = 0.f;
-      for (int slot = 0; slot < n_slots; ++slot) {
-        const int stage = k.mode <= 1 ? slot : (slot == 0 ? 0 : slot + 1);
-        S = __builtin_fmaf(wS[stage], ks[slot][el], S);
-        E = __builtin_fmaf(wE[stage], ks[slot][el], E);
+      if (stage == 2) {
+        S = (float)r.sums_in[ADJ_NS + e]; E = (float)r.sums_in[ADJ_NS + MADJ_ELEMS + e];
+      } else {
+        float wS[7], wE[7];
+        adj_stage_weights(k.mode, (float)k.c.dt_try, (float)k.x_end, wS, wE);
+        for (int slot = 0; slot < n_slots; ++slot) {
+          const int stg = k.mode <= 1 ? slot : (slot == 0 ? 0 : slot + 1);
+          S = __builtin_fmaf(wS[stg], ks[slot][el], S);
+          E = __builtin_fmaf(wE[stg], ks[slot][el], E);
+        }
       }
-      const int col = layer2 ? e % 129 : (e - MADJ_P2) % 33;
-      const int tensor = layer2 ? (col == 128 ? 3 : 2) : (col == 32 ? 1 : 0);      // 0 W1, 1 b1, 2 W2, 3 b2 (torch's order)
-      double q0 = 0.0, q1 = 0.0;
-      const float gn = adj_param_element(k, r.rtol, r.atol, r.G[e], r.prevS[p2 * MADJ_ELEMS + e], S, E, q0, q1);
-      if (k.commit) r.G[e] = gn;
-      r.prevS[parity * MADJ_ELEMS + e] = S;
-      qv[2 * tensor] = q0; qv[2 * tensor + 1] = q1;
+      if (stage == 1) {
+        r.sums_out[e] = (double)S; r.sums_out[MADJ_ELEMS + e] = (double)E;
+        r.prevS[parity * MADJ_ELEMS + e] = S;                     // this shard's own increment, for its own running total
+      } else {
+        const int col = layer2 ? e % 129 : (e - MADJ_P2) % 33;
+        const int tensor = layer2 ? (col == 128 ? 3 : 2) : (col == 32 ? 1 : 0);      // 0 W1, 1 b1, 2 W2, 3 b2 (torch's order)
+        double q0 = 0.0, q1 = 0.0;
+        if (stage == 2) {
+          // norms and commit on the GLOBAL images; the shard's own running total takes its own (local) increments
+          const float gn = adj_param_element(k, r.rtol, r.atol, r.Gn[e], r.prevSn[p2 * MADJ_ELEMS + e], S, E, q0, q1);
+          if (k.commit) {
+            r.Gn[e] = gn;
+            r.G[e] += k.commit == 1 ? r.prevS[p2 * MADJ_ELEMS + e] : r.prevS[parity * MADJ_ELEMS + e];
+          }
+          r.prevSn[parity * MADJ_ELEMS + e] = S;
+        } else {
+          const float gn = adj_param_element(k, r.rtol, r.atol, r.G[e], r.prevS[p2 * MADJ_ELEMS + e], S, E, q0, q1);
+          if (k.commit) r.G[e] = gn;
+          r.prevS[parity * MADJ_ELEMS + e] = S;
+        }
+        qv[2 * tensor] = q0; qv[2 * tensor + 1] = q1;
+      }
     }
   }
+  if (stage == 1) return;
   if (k.mode == 3) return;
   if (sl == 0)
 #pragma unroll
@@ -945,7 +982,7 @@ struct MadjLayout {
   int64_t n_tiles, rows_per_stage, rows_per_slab;
   int sps, nwave, n_wg;
   bool split, split8, small;
-  size_t partial, pq, carry, image, state, G, prev, slopes, part2, part1, U, G2, G1, Z, trace, trace_all, total;
+  size_t partial, pq, carry, image, state, G, prev, Gn, prevn, slopes, part2, part1, U, G2, G1, Z, trace, trace_all, total;
 };
 MadjLayout madj_layout(int64_t B, int64_t H, int64_t C) {
   using namespace cde;
@@ -975,7 +1012,9 @@ MadjLayout madj_layout(int64_t B, int64_t H, int64_t C) {
   L.state = L.image + m256(mlp_adjoint_image_bytes());
   L.G = L.state + m256((size_t)2 * 4 * B * H * sizeof(float));
   L.prev = L.G + m256((size_t)MADJ_ELEMS * sizeof(float));
-  L.slopes = L.prev + m256((size_t)2 * MADJ_ELEMS * sizeof(float));
+  L.Gn = L.prev + m256((size_t)2 * MADJ_ELEMS * sizeof(float));        // sharded: the GLOBAL running totals and S sums
+  L.prevn = L.Gn + m256((size_t)MADJ_ELEMS * sizeof(float));
+  L.slopes = L.prevn + m256((size_t)2 * MADJ_ELEMS * sizeof(float));
   L.part2 = L.slopes + m256((size_t)L.n_tiles * 7 * 4 * 64 * 16);
   L.part1 = L.part2 + m256((size_t)MADJ_SLOTS * L.sps * MADJ_P2 * sizeof(float));
   L.U = L.part1 + m256((size_t)MADJ_SLOTS * L.sps * MADJ_P1 * sizeof(float));
@@ -1001,15 +1040,32 @@ extern "C" size_t cde_dopri5_adjoint_mlp_gradient_offset(int64_t B, int64_t C, i
   return madj_layout(B, H, C).G;
 }
 
-extern "C" int cde_dopri5_adjoint_mlp_advance(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
-                                              const void* W1, const void* bias1, int64_t width, const void* W2,
-                                              const void* bias2, int act, const void* y_init, const void* a_init,
-                                              double s0, double s1, const double* jump_s, int64_t n_jump, double rtol,
-                                              double atol, double safety, double ifactor, double dfactor, int norm_kind,
-                                              void* a_out, int64_t B, int64_t C, int64_t H, int dtype, int first_interval,
-                                              void* workspace, size_t workspace_bytes, int64_t first_launch,
-                                              int64_t n_launches, void* stream) {
+namespace {
+cde::MlpReduceArgs madj_reduce_args(unsigned char* base, const MadjLayout& L, double rtol, double atol, bool sharded) {
+  cde::MlpReduceArgs q;
+  q.ctrl = base; q.part2 = (const float*)(base + L.part2); q.part1 = (const float*)(base + L.part1); q.sps = L.sps;
+  q.G = (float*)(base + L.G); q.prevS = (float*)(base + L.prev);
+  q.Gn = sharded ? (float*)(base + L.Gn) : nullptr; q.prevSn = sharded ? (float*)(base + L.prevn) : nullptr;
+  q.pq = (double*)(base + L.pq);
+  q.partial = (double*)(base + L.partial); q.n_wg = L.n_wg; q.n_wg_max = L.n_wg; q.carry = (double*)(base + L.carry);
+  q.sums_out = nullptr; q.sums_in = nullptr;
+  q.rtol = (float)rtol; q.atol = (float)atol;
+  return q;
+}
+}  // namespace
+
+static int dopri5_adjoint_mlp_advance_impl(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
+                                           const void* W1, const void* bias1, int64_t width, const void* W2,
+                                           const void* bias2, int act, const void* y_init, const void* a_init,
+                                           double s0, double s1, const double* jump_s, int64_t n_jump, double rtol,
+                                           double atol, double safety, double ifactor, double dfactor, int norm_kind,
+                                           void* a_out, int64_t B, int64_t C, int64_t H, int dtype, int first_interval,
+                                           void* workspace, size_t workspace_bytes, int64_t first_launch,
+                                           int64_t n_launches, void* stream, const double* reduced_sums, int64_t B_global) {
   using namespace cde;
+  const bool sharded = reduced_sums != nullptr || B_global > 0;
+  if (sharded && (n_launches != 1 || B_global < B)) return CDE_ERR_SHAPE;        // sharded: one launch per all-reduce
+  if (first_launch > 0 && sharded && !reduced_sums) return CDE_ERR_NULL;
   if (B < 1 || C < 1 || H < 1 || width < 1 || n_intervals < 1 || n_launches < 0 || n_jump < 0 || !(s0 < s1)) return CDE_ERR_SHAPE;
   if (dtype != CDE_F32) return dtype == CDE_F64 ? CDE_ERR_UNSUPPORTED : CDE_ERR_DTYPE;
   if (!mlp_shape_ok(C, H, width)) return CDE_ERR_UNSUPPORTED;
@@ -1035,10 +1091,11 @@ extern "C" int cde_dopri5_adjoint_mlp_advance(const void* coeffs, const void* kn
   g.U = (float*)(base + L.U); g.G2 = (float*)(base + L.G2); g.G1 = (float*)(base + L.G1); g.Z = (float*)(base + L.Z);
   g.n_wg_max = L.n_wg;
   { const char* d = getenv("CDE_K4AM_DBG"); g.dbg = d ? atoi(d) : 0; }
-  g.n_pq = L.small ? MADJ_SMALL_BLOCKS : MADJ_RBLOCKS;
+  g.n_pq = L.small && !sharded ? MADJ_SMALL_BLOCKS : MADJ_RBLOCKS;
   g.com.s0 = s0; g.com.s1 = s1; g.com.jump_s = jump_s; g.com.n_jump = n_jump;
   g.com.rtol = rtol; g.com.atol = atol; g.com.safety = safety; g.com.ifactor = ifactor; g.com.dfactor = dfactor;
-  g.com.n_state = B * H;
+  g.com.n_state = (B_global > 0 ? B_global : B) * H;
+  g.ext_sums = reduced_sums;
   g.com.n_pt = 4;
   g.com.n_param[0] = width * H; g.com.n_param[1] = width; g.com.n_param[2] = H * C * width; g.com.n_param[3] = H * C;
   g.com.norm_kind = norm_kind;
@@ -1058,15 +1115,12 @@ extern "C" int cde_dopri5_adjoint_mlp_advance(const void* coeffs, const void* kn
       if (rc != CDE_OK) return rc;
     }
   }
-  MlpReduceArgs r;
-  r.ctrl = base; r.part2 = (const float*)(base + L.part2); r.part1 = (const float*)(base + L.part1); r.sps = L.sps;
-  r.G = (float*)(base + L.G); r.prevS = (float*)(base + L.prev); r.pq = g.pq;
-  r.partial = g.partial; r.n_wg = L.n_wg; r.n_wg_max = L.n_wg; r.carry = g.com.carry;
-  r.rtol = (float)rtol; r.atol = (float)atol;
+  MlpReduceArgs r = madj_reduce_args(base, L, rtol, atol, sharded);
   MlpSmallArgs sm;
   sm.r = r; sm.G2 = g.G2; sm.U = g.U; sm.G1 = g.G1; sm.Z = g.Z; sm.rows_per_stage = L.rows_per_stage; sm.B = B;
   // after an attempt launch: the split-K reduction of its factor rows + the R kernel, or (small batches) both in one launch
   auto after_attempt = [&](int parity) -> int {
+    if (sharded) return CDE_OK;          // the caller goes on with cde_dopri5_adjoint_mlp_pending_sums / _apply_reduced
     if (L.small) {
       mlp_adjoint_small_reduce_kernel<<<MADJ_SMALL_BLOCKS, 256, 0, s>>>(sm, parity);
       return CDE_OK;
@@ -1122,5 +1176,92 @@ extern "C" int cde_dopri5_adjoint_mlp_advance(const void* coeffs, const void* kn
 #undef CDE_MADJ_W
 #undef CDE_MADJ_LAUNCH
 #undef CDE_MADJ_LAUNCH_S8
+  return check_launch();
+}
+
+extern "C" int cde_dopri5_adjoint_mlp_advance(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
+                                              const void* W1, const void* bias1, int64_t width, const void* W2,
+                                              const void* bias2, int act, const void* y_init, const void* a_init,
+                                              double s0, double s1, const double* jump_s, int64_t n_jump, double rtol,
+                                              double atol, double safety, double ifactor, double dfactor, int norm_kind,
+                                              void* a_out, int64_t B, int64_t C, int64_t H, int dtype, int first_interval,
+                                              void* workspace, size_t workspace_bytes, int64_t first_launch,
+                                              int64_t n_launches, void* stream) {
+  return dopri5_adjoint_mlp_advance_impl(coeffs, knots, n_intervals, degree, W1, bias1, width, W2, bias2, act, y_init, a_init,
+                                         s0, s1, jump_s, n_jump, rtol, atol, safety, ifactor, dfactor, norm_kind, a_out, B, C,
+                                         H, dtype, first_interval, workspace, workspace_bytes, first_launch, n_launches,
+                                         stream, nullptr, 0);
+}
+
+// ---- one step controller for a batch sharded over GPUs, two-layer field (round 4; the one-layer protocol of
+// dopri5_adjoint.hip, see cde_mi355x.h).  Per attempted step n every shard runs
+//   cde_dopri5_adjoint_mlp_advance_sharded   ONE attempt launch (n > 0: with the reduced buffer of step n - 1)
+//   cde_dopri5_adjoint_mlp_pending_sums      its 8 state sums + its S and E gradient images -> `sums` (doubles)
+//   [all-reduce `sums` over the shards]
+//   cde_dopri5_adjoint_mlp_apply_reduced     commit + parameter norms on the reduced images
+extern "C" size_t cde_dopri5_adjoint_mlp_reduced_count(void) { return (size_t)cde::ADJ_NS + 2 * (size_t)cde::MADJ_ELEMS; }
+
+extern "C" int cde_dopri5_adjoint_mlp_advance_sharded(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
+                                                      const void* W1, const void* bias1, int64_t width, const void* W2,
+                                                      const void* bias2, int act, const void* y_init, const void* a_init,
+                                                      double s0, double s1, const double* jump_s, int64_t n_jump,
+                                                      double rtol, double atol, double safety, double ifactor,
+                                                      double dfactor, int norm_kind, void* a_out, int64_t B, int64_t C,
+                                                      int64_t H, int dtype, int first_interval, void* workspace,
+                                                      size_t workspace_bytes, int64_t first_launch,
+                                                      const double* reduced_sums, int64_t B_global, void* stream) {
+  if (B_global < B) return CDE_ERR_SHAPE;
+  return dopri5_adjoint_mlp_advance_impl(coeffs, knots, n_intervals, degree, W1, bias1, width, W2, bias2, act, y_init, a_init,
+                                         s0, s1, jump_s, n_jump, rtol, atol, safety, ifactor, dfactor, norm_kind, a_out, B, C,
+                                         H, dtype, first_interval, workspace, workspace_bytes, first_launch, 1, stream,
+                                         reduced_sums, B_global);
+}
+
+namespace cde {
+__global__ __launch_bounds__(64) void madj_state_sums_kernel(const double* __restrict__ partial, int n_wg,
+                                                             double* __restrict__ out) {
+  const int i = threadIdx.x;
+  if (i >= ADJ_NS) return;
+  double s = 0.0;
+  for (int b = 0; b < n_wg; ++b) s += partial[ADJ_NS * b + i];
+  out[i] = s;
+}
+}  // namespace cde
+
+extern "C" int cde_dopri5_adjoint_mlp_pending_sums(void* workspace, size_t workspace_bytes, int64_t B, int64_t C, int64_t H,
+                                                   int64_t total_launches, double* sums, void* stream) {
+  using namespace cde;
+  if (B < 1 || C < 1 || H < 1 || total_launches < 1) return CDE_ERR_SHAPE;
+  if (!workspace || !sums) return CDE_ERR_NULL;
+  if (workspace_bytes < cde_dopri5_adjoint_mlp_workspace_bytes(B, C, H)) return CDE_ERR_WORKSPACE;
+  unsigned char* base = (unsigned char*)workspace;
+  const MadjLayout L = madj_layout(B, H, C);
+  hipStream_t s = (hipStream_t)stream;
+  const int parity = (int)((total_launches - 1) & 1);               // the launch whose sums are pending
+  const double* partial = (const double*)(base + L.partial) + (int64_t)(parity ^ 1) * L.n_wg * ADJ_NS;
+  madj_state_sums_kernel<<<1, 64, 0, s>>>(partial, L.n_wg, sums);
+  const int rc = launch_mlp_adjoint_factor_reduce((const float*)(base + L.G2), (const float*)(base + L.U),
+                                                  (const float*)(base + L.G1), (const float*)(base + L.Z), L.rows_per_stage,
+                                                  L.sps, L.rows_per_slab, (float*)(base + L.part2), (float*)(base + L.part1),
+                                                  base, parity, s);
+  if (rc != CDE_OK) return rc;
+  MlpReduceArgs r = madj_reduce_args(base, L, 0.0, 0.0, true);
+  r.sums_out = sums + ADJ_NS;
+  mlp_adjoint_reduce_kernel<<<MADJ_RBLOCKS, 256, 0, s>>>(r, parity, 1);
+  return check_launch();
+}
+
+extern "C" int cde_dopri5_adjoint_mlp_apply_reduced(void* workspace, size_t workspace_bytes, int64_t B, int64_t C, int64_t H,
+                                                    double rtol, double atol, int64_t total_launches, const double* reduced,
+                                                    void* stream) {
+  using namespace cde;
+  if (B < 1 || C < 1 || H < 1 || total_launches < 1) return CDE_ERR_SHAPE;
+  if (!workspace || !reduced) return CDE_ERR_NULL;
+  if (workspace_bytes < cde_dopri5_adjoint_mlp_workspace_bytes(B, C, H)) return CDE_ERR_WORKSPACE;
+  unsigned char* base = (unsigned char*)workspace;
+  const MadjLayout L = madj_layout(B, H, C);
+  MlpReduceArgs r = madj_reduce_args(base, L, rtol, atol, true);
+  r.sums_in = reduced;
+  mlp_adjoint_reduce_kernel<<<MADJ_RBLOCKS, 256, 0, (hipStream_t)stream>>>(r, (int)((total_launches - 1) & 1), 2);
   return check_launch();
 }

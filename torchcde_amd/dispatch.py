@@ -78,8 +78,6 @@ def select_path(q):
         if q.variant_generic:
             return _stepwise("variant='generic' was requested (the step-wise reference path)")
         if not q.wants_grad:
-            if q.method == "dopri5" and q.shared:
-                return _stepwise("shared_step_control covers the one-layer fields only")
             return Choice("mlp_rk4_forward" if q.method == "rk4" else "mlp_dopri5_forward", "")
         if q.wants_t:
             return _stepwise("gradients w.r.t. the output times of a two-layer field")
@@ -91,8 +89,6 @@ def select_path(q):
             return Choice("mlp_rk4_adjoint", "")
         if q.method == "rk4":
             return Choice("mlp_rk4_adjoint", "")
-        if q.shared:
-            return _stepwise("shared_step_control covers the one-layer fields only")
         return Choice("mlp_dopri5_adjoint", "")
     # one-layer (affine) fields
     if (q.wants_t or q.wants_control) and not q.mfma_shape:
