@@ -32,7 +32,7 @@ constexpr int MADJ_SLOTS = 6;                    // stages whose factors are kep
 constexpr int MADJ_P2 = 256 * 129, MADJ_P1 = 128 * 33;          // elements of a layer-2 / layer-1 slab partial (bias column last)
 constexpr int MADJ_ELEMS = MADJ_P2 + MADJ_P1;
 constexpr int MADJ_RBLOCKS = (MADJ_ELEMS + 31) / 32;
-constexpr int MADJ_MAX_SPS = 40;                 // slabs per stage of the factor reduction
+constexpr int MADJ_MAX_SPS = 40;                 // slabs per stage of the factor reduction (80: 121 -> 133 us per attempt at 4096 series)
 constexpr int64_t MADJ_SPLIT_MAX_TILES = 256;    // batches up to 4096 series (one tile per CU): four waves per tile (K4am's split form)
 constexpr int MADJ_NSUM = ADJ_NS + 2 * ADJ_MAX_PT;
 __host__ __device__ constexpr int madj_slot(int stage) { return stage == 0 ? 0 : stage - 1; }      // stage 1 is never stored
