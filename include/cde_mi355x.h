@@ -441,7 +441,8 @@ int cde_dopri5_adjoint_advance(const void* coeffs, const void* knots, int64_t n_
  *       8 state sums, then the A / E / D gradient images of the attempt
  *   an all-reduce (sum) of that buffer over the shards
  *   cde_dopri5_adjoint_apply_reduced(total_launches = n + 1, the reduced buffer): commit + parameter norms
- * and all shards take the unsharded batch's decisions.  cde_dopri5_adjoint_finish(sharded = 1) returns THIS shard's
+ * and all shards take THE SAME decisions (those of the unsharded batch up to the summation order of the float images:
+ * shards are added as doubles, an unsharded solve adds its workgroups' float images).  cde_dopri5_adjoint_finish(sharded = 1) returns THIS shard's
  * share of dL/dW, dL/db (the caller all-reduces gradients as for any data-parallel step). */
 size_t cde_dopri5_adjoint_reduced_count(void);
 int cde_dopri5_adjoint_pending_sums(void* workspace, size_t workspace_bytes, int64_t B, int64_t C, int64_t H,
@@ -463,6 +464,9 @@ int cde_dopri5_adjoint_finish(const void* workspace, size_t workspace_bytes, voi
  *           columns 0..width-1 = dL/dW2, column 128 = dL/db2;   then layer 1 as float [128][33]: row = hidden-layer
  *           unit, columns 0..H-1 = dL/dW1, column 32 = dL/db1.
  * cde_dopri5_adjoint_mlp_trace_offset(which = 0 accepted steps | 1 every attempt) as for K4a.
+ * Workspace footprint: the attempt streams the gradient factors of its six weighted stages, (132 + 256 + 128 + 36) floats
+ * per series and stage = 13.2 KB per series (434 MB at 32768 series), plus 6 x 40 slab partials of 37,248 floats (36 MB);
+ * the factor rows are zeroed once per backward pass (first_interval), not per attempt.
  * ------------------------------------------------------------------------------------------- */
 size_t cde_dopri5_adjoint_mlp_workspace_bytes(int64_t B, int64_t C, int64_t H);
 size_t cde_dopri5_adjoint_mlp_trace_offset(int64_t B, int64_t C, int64_t H, int which);

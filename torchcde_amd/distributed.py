@@ -17,7 +17,8 @@ import torch.distributed as dist
 # torchdiffeq's dopri5 has ONE step controller for the whole batch (the error norm is an RMS over all series).  When
 # the batch is sharded over ranks, every rank running its own controller gives valid but different step sequences.
 # Inside `shared_step_control()` the fused adaptive solves (forward K4 and backward K4a) instead all-reduce the two
-# (four) error sums of every attempted step, so that all shards take exactly the step sequence of the unsharded batch.
+# (four) error sums of every attempted step, so that all shards take the same step sequence (the unsharded batch's, up to
+# the summation order of float32 partial sums).
 _local = threading.local()    # .control = (reduce(tensor) -> None, global number of series); read when a solve is planned
 
 
