@@ -86,6 +86,31 @@ def _log(msg):
     print("[bench] " + msg, file=sys.stderr, flush=True)
 
 
+# The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner through C stdio when its
+# first communicator comes up), so file descriptor 1 points at stderr for the whole run and the result line is written to
+# the saved descriptor at the very end.
+_REAL_STDOUT = None
+
+
+def capture_stdout():
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)                    # whatever C code buffered for "stdout" goes to stderr now
+    except OSError:
+        pass
+    fd = 1 if _REAL_STDOUT is None else _REAL_STDOUT
+    os.write(fd, (line + "\n").encode())
+
+
 def cpu_baseline(max_sample, budget_s=20.0):
     """The oracle (torch-CPU restatement of the reference path) on a bounded sample of the same workload, timed per
     BASELINE.md section 3: 1 warm-up + 3 timed runs of the same sample, min and median reported, `value` = median.
@@ -190,7 +215,9 @@ def measured_allreduce_ms(params):
             with socket.socket() as sock:
                 sock.bind(("127.0.0.1", 0))
                 port = sock.getsockname()[1]
-            dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+            import datetime
+            dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                                    timeout=datetime.timedelta(seconds=60))
             created = True
         for p in params:
             if p.grad is None:
@@ -484,7 +511,7 @@ def run_adaptive_config(args, cde, device, rank, world, distributed, share_gpu):
     if rank == 0:
         fwd, bwd = dict(front.last_dopri5_stats), dict(front.last_dopri5_adjoint_stats) if args.adjoint else {}
         attempts = fwd.get("launches", 0) + bwd.get("launches", 0)
-        print(json.dumps({
+        emit(json.dumps({
             "metric": "series/sec, dopri5 adaptive cdeint %s, 32768 series per GPU, L=128 C=8 H=32 (BASELINE configs[3])"
                       % ("forward + adjoint" if args.adjoint else "forward"),
             "value": n * world * args.steps / elapsed, "unit": "series/s", "n_gpus": world, "steps": args.steps,
@@ -570,7 +597,7 @@ def run_logode_config(args, cde, device, rank, world, distributed, share_gpu):
             extra["forward_steps"] = dict(front.last_dopri5_stats)
             extra["backward_steps"] = {k: v for k, v in front.last_dopri5_adjoint_stats.items()
                                        if k in ("n_accept", "n_reject", "launches")}
-        print(json.dumps({
+        emit(json.dumps({
             "metric": "series/sec, log-ODE pipeline (depth-3 logsignature windows + two-layer field, %s, fwd+adjoint), "
                       "32768 x 512 x 3 per GPU (BASELINE configs[4])" % args.method,
             "value": n * world * args.steps / elapsed, "unit": "series/s", "n_gpus": world, "steps": args.steps,
@@ -616,6 +643,7 @@ def main():
                                   "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
                                   "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
 
+    capture_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -811,7 +839,7 @@ def main():
             result["extra"]["other_configs"] = other_configs(cde, device)
         if world == 1 and args.cpu_sample > 0:
             result["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, B))
-        print(json.dumps(result))
+        emit(json.dumps(result))
     if distributed:
         dist.destroy_process_group()
 
