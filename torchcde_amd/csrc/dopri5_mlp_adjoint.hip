@@ -54,7 +54,7 @@ struct MlpAdjArgs {
   int n_wg_max;
   const double* ext_sums;           // sharded batch: the ADJ_NS state sums of the pending attempt, added up over ALL shards
   int n_pq;                         // blocks of parameter sums the R kernel of this batch size leaves in `pq`
-  int dbg;                          // CDE_K4AM_DBG (timing experiments only): bit 0 = no factor stores
+  int dbg;                          // instrumented (CDE_PHASE_TRACE) builds only: CDE_K4AM_DBG bit 0 = no factor stores
 };
 
 // SPLIT (small batches: fewer tiles than SIMDs): the workgroup's four waves share ONE tile and split the middle of every
@@ -1090,7 +1090,10 @@ static int dopri5_adjoint_mlp_advance_impl(const void* coeffs, const void* knots
   g.slopes = (float*)(base + L.slopes);
   g.U = (float*)(base + L.U); g.G2 = (float*)(base + L.G2); g.G1 = (float*)(base + L.G1); g.Z = (float*)(base + L.Z);
   g.n_wg_max = L.n_wg;
-  { const char* d = getenv("CDE_K4AM_DBG"); g.dbg = d ? atoi(d) : 0; }
+  g.dbg = 0;
+#ifdef CDE_PHASE_TRACE
+  { const char* d = getenv("CDE_K4AM_DBG"); g.dbg = d ? atoi(d) : 0; }      // timing experiments (wrong gradients!)
+#endif
   g.n_pq = L.small && !sharded ? MADJ_SMALL_BLOCKS : MADJ_RBLOCKS;
   g.com.s0 = s0; g.com.s1 = s1; g.com.jump_s = jump_s; g.com.n_jump = n_jump;
   g.com.rtol = rtol; g.com.atol = atol; g.com.safety = safety; g.com.ifactor = ifactor; g.com.dfactor = dfactor;
