@@ -8,10 +8,11 @@
 #   <tag>_phase_k4am_{32,4096}.log              where an attempt's time goes (instrumented library)
 #   <tag>_k4am_pmc_summary.csv                  MFMA-busy / wait / instruction counters of the K4am kernels at 4096 series
 #   <tag>_fuzz_seed61.log                       AUTO kernels vs generic / step-wise on drawn configurations
+#   <tag>_multigpu_harness_rccl_1rank.log       bench.py --config 5 / --config 4 --adjoint, local vs shared controller, one RCCL rank
 # Usage on the GPU box:  bash scripts/collect_profiles.sh r04 [steps...]     (default: all steps)
 set -u
 TAG=${1:-r04}
-STEPS=${2:-"tests bench stats k4am phase pmc fuzz"}
+STEPS=${2:-"tests bench stats k4am phase pmc fuzz dist"}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
@@ -42,6 +43,15 @@ PY
             CDE_PHASE_TRACE=1 timeout 300 python scripts/phase_trace.py k4am 4096 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_phase_k4am_4096.log; head -6 $OUT/${TAG}_phase_k4am_4096.log) ;;
     pmc) PMC_OUT=/tmp timeout 500 bash $ROOT/scripts/pmc_passes.sh ${TAG}k4am scripts/prof_default_mlp.py "mfma waves" "4096 seminorm" > /dev/null 2>&1
          timeout 60 python $ROOT/scripts/pmc_summary.py /tmp/pmc_${TAG}k4am $OUT/${TAG}_k4am_pmc_summary.csv; cat $OUT/${TAG}_k4am_pmc_summary.csv | cut -c1-220 ;;
+    dist) (cd $ROOT && { for mode in local shared; do CDE_BENCH_FORCE_DIST=1 timeout 300 python bench.py --config 5 --controller $mode --steps 3 --warmup 1 2>/dev/null; done
+                        for mode in local shared; do CDE_BENCH_FORCE_DIST=1 timeout 300 python bench.py --config 4 --adjoint --norm seminorm --controller $mode --steps 5 --warmup 2 2>/dev/null; done; } > $OUT/${TAG}_multigpu_harness_rccl_1rank.log
+           python - <<PY
+import json
+for line in open("$OUT/${TAG}_multigpu_harness_rccl_1rank.log"):
+    d = json.loads(line)
+    print(d["config"].get("controller"), d["metric"][:60], round(d["ms_per_step"], 1), "ms/step")
+PY
+) ;;
     fuzz) (cd $ROOT && timeout 600 python tests/tools/fuzz_variants.py --cases 100 --seed 61 2>&1 | tail -6 > $OUT/${TAG}_fuzz_seed61.log; cat $OUT/${TAG}_fuzz_seed61.log) ;;
   esac
 done
