@@ -452,6 +452,15 @@ int cde_dopri5_adjoint_apply_reduced(void* workspace, size_t workspace_bytes, in
                                      void* stream);
 int cde_dopri5_adjoint_finish(const void* workspace, size_t workspace_bytes, void* grad_W, void* grad_b, int64_t B,
                               int64_t C, int64_t H, int sharded, void* stream);
+/* The same protocol under norm_kind = 1 ("seminorm"; round 4): the parameter blocks take no part in the decision, so only
+ * the 8 state sums travel.  Per attempted step: cde_dopri5_adjoint_advance as above (it then also runs the R kernel on
+ * THIS shard's images), cde_dopri5_adjoint_state_sums -> 8 doubles, all-reduce, cde_dopri5_adjoint_apply_state_sums (vjp_t
+ * at an interval end from the reduced sums).  64 bytes per attempted step instead of 147 KB; the gradients stay per shard:
+ * cde_dopri5_adjoint_finish(sharded = 0). */
+int cde_dopri5_adjoint_state_sums(void* workspace, size_t workspace_bytes, int64_t B, int64_t C, int64_t H,
+                                  int64_t total_launches, double* sums, void* stream);
+int cde_dopri5_adjoint_apply_state_sums(void* workspace, size_t workspace_bytes, int64_t B, int64_t C, int64_t H,
+                                        int64_t total_launches, const double* reduced, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K4am  K4a for the two-layer field Linear(H, width) -> relu -> Linear(width, H*C) -> tanh | identity of the reference's
@@ -506,6 +515,13 @@ int cde_dopri5_adjoint_mlp_pending_sums(void* workspace, size_t workspace_bytes,
 int cde_dopri5_adjoint_mlp_apply_reduced(void* workspace, size_t workspace_bytes, int64_t B, int64_t C, int64_t H,
                                          double rtol, double atol, int64_t total_launches, const double* reduced,
                                          void* stream);
+/* ... and under norm_kind = 1 ("seminorm"), as for the one-layer kernels: cde_dopri5_adjoint_mlp_advance_sharded (which then
+ * also runs this shard's own factor reduction and R step), cde_dopri5_adjoint_mlp_state_sums -> 8 doubles, all-reduce,
+ * cde_dopri5_adjoint_mlp_apply_state_sums.  64 bytes per attempted step instead of 596 KB. */
+int cde_dopri5_adjoint_mlp_state_sums(void* workspace, size_t workspace_bytes, int64_t B, int64_t C, int64_t H,
+                                      int64_t total_launches, double* sums, void* stream);
+int cde_dopri5_adjoint_mlp_apply_state_sums(void* workspace, size_t workspace_bytes, int64_t B, int64_t C, int64_t H,
+                                            int64_t total_launches, const double* reduced, void* stream);
 
 /* Sharded batches under ONE step controller -- torchdiffeq's semantics for the whole batch when the batch lives on
  * several GPUs.  Per attempted step every shard (1) calls cde_dopri5_pending_sums(total_launches so far) -> 2 doubles on

@@ -44,12 +44,13 @@ PY
     pmc) PMC_OUT=/tmp timeout 500 bash $ROOT/scripts/pmc_passes.sh ${TAG}k4am scripts/prof_default_mlp.py "mfma waves" "4096 seminorm" > /dev/null 2>&1
          timeout 60 python $ROOT/scripts/pmc_summary.py /tmp/pmc_${TAG}k4am $OUT/${TAG}_k4am_pmc_summary.csv; cat $OUT/${TAG}_k4am_pmc_summary.csv | cut -c1-220 ;;
     dist) (cd $ROOT && { for mode in local shared; do CDE_BENCH_FORCE_DIST=1 timeout 300 python bench.py --config 5 --controller $mode --steps 3 --warmup 1 2>/dev/null; done
+                        for mode in local shared; do CDE_BENCH_FORCE_DIST=1 timeout 300 python bench.py --config 5 --norm seminorm --controller $mode --steps 3 --warmup 1 2>/dev/null; done
                         for mode in local shared; do CDE_BENCH_FORCE_DIST=1 timeout 300 python bench.py --config 4 --adjoint --norm seminorm --controller $mode --steps 5 --warmup 2 2>/dev/null; done; } > $OUT/${TAG}_multigpu_harness_rccl_1rank.log
            python - <<PY
 import json
 for line in open("$OUT/${TAG}_multigpu_harness_rccl_1rank.log"):
     d = json.loads(line)
-    print(d["config"].get("controller"), d["metric"][:60], round(d["ms_per_step"], 1), "ms/step")
+    print(d["config"].get("controller"), d["config"].get("adjoint_norm"), d["metric"][:60], round(d["ms_per_step"], 1), "ms/step")
 PY
 ) ;;
     fuzz) (cd $ROOT && timeout 600 python tests/tools/fuzz_variants.py --cases 100 --seed 61 2>&1 | tail -6 > $OUT/${TAG}_fuzz_seed61.log; cat $OUT/${TAG}_fuzz_seed61.log) ;;

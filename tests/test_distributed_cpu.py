@@ -148,6 +148,8 @@ class _ProtocolLib:
         assert count == 1 and global_batch == 11
         if first == 0:
             assert sums is None or not getattr(sums, "value", sums), "the first launch of an interval has nothing pending"
+        elif self.seminorm:
+            assert self._doubles(sums, 8)[0] == sum(range(1, self.world + 1)) * first
         else:
             got = self._doubles(sums, 8 + 32)
             assert got[0] == sum(range(1, self.world + 1)) * first, (first, got[0])       # the PREVIOUS launch's sums
@@ -173,9 +175,27 @@ class _ProtocolLib:
         return 0
 
     def cde_dopri5_adjoint_finish(self, ws, ws_bytes, gw, gb, B, C, H, sharded, stream):
-        assert sharded == 1
+        assert sharded == (0 if self.seminorm else 1)       # "seminorm": the gradient images stayed local
         self.log.append(("finish", sharded))
         return 0
+
+    # --- "seminorm": only the 8 state sums travel (both kernel families share the stand-in)
+    seminorm = False
+
+    def cde_dopri5_adjoint_state_sums(self, ws, ws_bytes, B, C, H, total, sums, stream):
+        out = self._doubles(sums, 8)
+        for i in range(8):
+            out[i] = (self.rank + 1) * total
+        self.log.append(("semi_pending", total))
+        return 0
+
+    def cde_dopri5_adjoint_apply_state_sums(self, ws, ws_bytes, B, C, H, total, reduced, stream):
+        assert self._doubles(reduced, 8)[4] == sum(range(1, self.world + 1)) * total
+        self.log.append(("semi_apply", total))
+        return 0
+
+    cde_dopri5_adjoint_mlp_state_sums = cde_dopri5_adjoint_state_sums
+    cde_dopri5_adjoint_mlp_apply_state_sums = cde_dopri5_adjoint_apply_state_sums
 
     # --- the same protocol for the two-layer field (round 4): K4 / K4am under one controller
     MLP_REDUCED = 8 + 2 * 24
@@ -212,6 +232,8 @@ class _ProtocolLib:
         assert width == 8 and global_batch == 11
         if first == 0:
             assert sums is None or not getattr(sums, "value", sums), "the first launch of an interval has nothing pending"
+        elif self.seminorm:
+            assert self._doubles(sums, 8)[0] == sum(range(1, self.world + 1)) * first
         else:
             got = self._doubles(sums, self.MLP_REDUCED)
             assert got[0] == sum(range(1, self.world + 1)) * first, (first, got[0])
@@ -277,6 +299,13 @@ def _shared_worker(rank, world, port, tmp):
     grads = plan2.run_adjoint_mlp(out2, torch.ones(n, 2, 4), hidden.weight, hidden.bias, w2, b2)
     assert grads[1].shape == (8, 4) and grads[3].shape == (12, 8)
     assert front.last_dopri5_adjoint_stats["launches"] % front._DOPRI_CHUNK == 0
+    # ... and both again with adjoint_options=dict(norm="seminorm"): 8 doubles per attempted step, images local
+    fake.seminorm = True
+    with shared_step_control(11):
+        plan3 = front._Dopri5Plan(path, field, (n,), 4, 3, t, 1e-4, 1e-6, None, adjoint_options=dict(norm="seminorm"))
+        plan4 = front._Dopri5Plan(path, field2, (n,), 4, 3, t, 1e-4, 1e-6, None, adjoint_options=dict(norm="seminorm"))
+    plan3.run_adjoint(out, torch.ones(n, 2, 4), w, b)
+    plan4.run_adjoint_mlp(out2, torch.ones(n, 2, 4), hidden.weight, hidden.bias, w2, b2)
     torch.save(fake.log, tmp + ".%d" % rank)
     dist.barrier()
     dist.destroy_process_group()
@@ -305,3 +334,8 @@ def test_shared_step_control_protocol_on_two_gloo_ranks(tmp_path):
     assert kinds[first_fwd:first_fwd + 2 * n] == ["mlp_fwd_pending", "mlp_fwd_launch"] * n
     first_bwd = kinds.index("mlp_bwd_launch")
     assert kinds[first_bwd:first_bwd + 3 * n] == ["mlp_bwd_launch", "mlp_bwd_pending", "mlp_bwd_apply"] * n
+    # "seminorm": launch -> 8 state sums -> reduce -> apply, for the one-layer and then the two-layer plan
+    first = kinds.index("semi_pending") - 1
+    assert kinds[first:first + 3 * n] == ["bwd_launch", "semi_pending", "semi_apply"] * n
+    second = len(kinds) - 1 - kinds[::-1].index("mlp_bwd_launch") - 3 * (n - 1)
+    assert kinds[second:second + 3 * n] == ["mlp_bwd_launch", "semi_pending", "semi_apply"] * n

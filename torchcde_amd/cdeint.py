@@ -637,8 +637,10 @@ class _Dopri5Plan:
         a_out = torch.empty(B, H, dtype=torch.float32, device=dev)
         shared = self.shared
         reduced = None
+        # "seminorm": the parameter blocks are not part of the decision -- only the 8 state sums travel between the shards
+        state_only = shared is not None and self.adj_norm_kind == 1
         if shared is not None:
-            reduced = torch.zeros(lib.cde_dopri5_adjoint_reduced_count(), dtype=torch.float64, device=dev)
+            reduced = torch.zeros(8 if state_only else lib.cde_dopri5_adjoint_reduced_count(), dtype=torch.float64, device=dev)
         stream = _lib.stream_ptr(dev)
         stats = dict(n_accept=0, n_reject=0, launches=0)
         steps, attempts = [], []
@@ -664,6 +666,15 @@ class _Dopri5Plan:
                     for _ in range(_DOPRI_CHUNK):
                         advance(launched, 1, _lib.ptr(reduced) if launched else None, shared[1])
                         launched += 1
+                        if state_only:
+                            _lib.check(lib.cde_dopri5_adjoint_state_sums(_lib.ptr(workspace), workspace.numel(), B, C, H,
+                                                                         launched, _lib.ptr(reduced), stream),
+                                       "cde_dopri5_adjoint_state_sums")
+                            shared[0](reduced)
+                            _lib.check(lib.cde_dopri5_adjoint_apply_state_sums(_lib.ptr(workspace), workspace.numel(), B, C,
+                                                                               H, launched, _lib.ptr(reduced), stream),
+                                       "cde_dopri5_adjoint_apply_state_sums")
+                            continue
                         _lib.check(lib.cde_dopri5_adjoint_pending_sums(_lib.ptr(workspace), workspace.numel(), B, C, H,
                                                                        launched, _lib.ptr(reduced), stream),
                                    "cde_dopri5_adjoint_pending_sums")
@@ -691,7 +702,8 @@ class _Dopri5Plan:
                 attempts.append(workspace[off:off + 40 * n].view(torch.float64).view(n, 5).cpu())
             a = a_out + grad_out[:, i - 1]
         _lib.check(lib.cde_dopri5_adjoint_finish(_lib.ptr(workspace), workspace.numel(), _lib.ptr(grad_w), _lib.ptr(grad_b),
-                                                 B, C, H, int(shared is not None), stream), "cde_dopri5_adjoint_finish")
+                                                 B, C, H, int(shared is not None and not state_only), stream),
+                   "cde_dopri5_adjoint_finish")
         last_dopri5_adjoint_stats = self.owner.dopri5_adjoint
         last_dopri5_adjoint_stats.clear()
         last_dopri5_adjoint_stats.update(stats)
@@ -721,8 +733,10 @@ class _Dopri5Plan:
         stream = _lib.stream_ptr(dev)
         shared = self.shared
         reduced = None
+        state_only = shared is not None and self.adj_norm_kind == 1      # "seminorm": only the 8 state sums travel
         if shared is not None:
-            reduced = torch.zeros(lib.cde_dopri5_adjoint_mlp_reduced_count(), dtype=torch.float64, device=dev)
+            reduced = torch.zeros(8 if state_only else lib.cde_dopri5_adjoint_mlp_reduced_count(), dtype=torch.float64,
+                                  device=dev)
         stats = dict(n_accept=0, n_reject=0, launches=0)
         steps, attempts = [], []
         for i in range(self.n_out - 1, 0, -1):
@@ -753,6 +767,15 @@ class _Dopri5Plan:
                             launched, _lib.ptr(reduced) if launched else None, shared[1], stream),
                             "cde_dopri5_adjoint_mlp_advance_sharded")
                         launched += 1
+                        if state_only:
+                            _lib.check(lib.cde_dopri5_adjoint_mlp_state_sums(_lib.ptr(workspace), workspace.numel(), B, C, H,
+                                                                             launched, _lib.ptr(reduced), stream),
+                                       "cde_dopri5_adjoint_mlp_state_sums")
+                            shared[0](reduced)
+                            _lib.check(lib.cde_dopri5_adjoint_mlp_apply_state_sums(
+                                _lib.ptr(workspace), workspace.numel(), B, C, H, launched, _lib.ptr(reduced), stream),
+                                "cde_dopri5_adjoint_mlp_apply_state_sums")
+                            continue
                         _lib.check(lib.cde_dopri5_adjoint_mlp_pending_sums(_lib.ptr(workspace), workspace.numel(), B, C, H,
                                                                            launched, _lib.ptr(reduced), stream),
                                    "cde_dopri5_adjoint_mlp_pending_sums")

@@ -911,7 +911,11 @@ extern "C" int cde_dopri5_adjoint_advance(const void* coeffs, const void* knots,
       cde::zero_async(base + L.G, L.att - L.G, s);                                // G, G_local, the prev buffers
     }
   }
-  cde::AdjReduceArgs r = adj_reduce_args(base, L, B, rtol, atol, sharded);
+  // sharded under "seminorm": the parameter blocks take no part in the decision, so only the 8 state sums travel between the
+  // shards (cde_dopri5_adjoint_state_sums / _apply_state_sums) and the gradient images stay LOCAL -- reduced, committed and
+  // returned per shard like an unsharded solve's (the caller all-reduces gradients once, as for any data-parallel step)
+  const bool images_local = sharded && norm_kind == 1;
+  cde::AdjReduceArgs r = adj_reduce_args(base, L, B, rtol, atol, sharded && !images_local);
 #define CDE_ADJ(D, A)                                                                                                \
   do {                                                                                                               \
     (void)hipFuncSetAttribute((const void*)cde::dopri5_adjoint_attempt<D, A>,                                        \
@@ -919,7 +923,7 @@ extern "C" int cde_dopri5_adjoint_advance(const void* coeffs, const void* knots,
     for (int64_t i = 0; i < n_launches; ++i) {                                                                       \
       const int parity = (int)((first_launch + i) & 1);                                                              \
       cde::dopri5_adjoint_attempt<D, A><<<grid, 512, cde::ADJ_LDS_BYTES, s>>>(g, parity);                            \
-      if (!sharded) cde::adjoint_reduce_kernel<<<cde::ADJ_RBLOCKS, 256, 0, s>>>(r, parity, 0);                       \
+      if (!sharded || images_local) cde::adjoint_reduce_kernel<<<cde::ADJ_RBLOCKS, 256, 0, s>>>(r, parity, 0);       \
     }                                                                                                                \
   } while (0)
   if (act == CDE_ACT_NONE) {
@@ -957,6 +961,41 @@ extern "C" int cde_dopri5_adjoint_pending_sums(void* workspace, size_t workspace
   cde::AdjReduceArgs r = adj_reduce_args(base, L, B, 0.0, 0.0, true);
   r.sums_out = sums + cde::ADJ_NS;
   cde::adjoint_reduce_kernel<<<cde::ADJ_RBLOCKS, 256, 0, s>>>(r, parity, 1);
+  return cde::check_launch();
+}
+
+// The "seminorm" form of the two calls: only the ADJ_NS state sums are pending on the other shards (the attempt's launch
+// already ran the R kernel on this shard's own images); after the all-reduce the one number the R kernel took from LOCAL
+// sums -- vjp_t at the end of an interval -- is redone from the reduced ones.
+__global__ void dopri_adjoint_carry_kernel(const unsigned char* __restrict__ ctrl, int p2, const double* __restrict__ reduced,
+                                           double* __restrict__ carry) {
+  const cde::AdjCtrl k = *reinterpret_cast<const cde::AdjCtrl*>(ctrl + p2 * cde::ADJ_CTRL_STRIDE);
+  if (k.c.phase == 4 && k.commit == 0) return;
+  if (k.mode == 3) carry[0] = (double)((float)k.T + (float)reduced[4]);
+}
+
+extern "C" int cde_dopri5_adjoint_state_sums(void* workspace, size_t workspace_bytes, int64_t B, int64_t C, int64_t H,
+                                             int64_t total_launches, double* sums, void* stream) {
+  if (B < 1 || C < 1 || H < 1 || total_launches < 1) return CDE_ERR_SHAPE;
+  if (!workspace || !sums) return CDE_ERR_NULL;
+  if (workspace_bytes < cde_dopri5_adjoint_workspace_bytes(B, C, H)) return CDE_ERR_WORKSPACE;
+  unsigned char* base = (unsigned char*)workspace;
+  const AdjLayout L = adj_layout(B, H);
+  const int parity = (int)((total_launches - 1) & 1);
+  const double* partial = (const double*)(base + L.partial) + (int64_t)(parity ^ 1) * cde::ADJ_MAX_WG * cde::ADJ_NS;
+  dopri_adjoint_pending_sums_kernel<<<1, 64, 0, (hipStream_t)stream>>>(partial, cde::adj_grid(B), sums);
+  return cde::check_launch();
+}
+
+extern "C" int cde_dopri5_adjoint_apply_state_sums(void* workspace, size_t workspace_bytes, int64_t B, int64_t C, int64_t H,
+                                                   int64_t total_launches, const double* reduced, void* stream) {
+  if (B < 1 || C < 1 || H < 1 || total_launches < 1) return CDE_ERR_SHAPE;
+  if (!workspace || !reduced) return CDE_ERR_NULL;
+  if (workspace_bytes < cde_dopri5_adjoint_workspace_bytes(B, C, H)) return CDE_ERR_WORKSPACE;
+  unsigned char* base = (unsigned char*)workspace;
+  const AdjLayout L = adj_layout(B, H);
+  const int parity = (int)((total_launches - 1) & 1);
+  dopri_adjoint_carry_kernel<<<1, 1, 0, (hipStream_t)stream>>>(base, parity ^ 1, reduced, (double*)(base + L.carry));
   return cde::check_launch();
 }
 

@@ -1094,7 +1094,7 @@ static int dopri5_adjoint_mlp_advance_impl(const void* coeffs, const void* knots
 #ifdef CDE_PHASE_TRACE
   { const char* d = getenv("CDE_K4AM_DBG"); g.dbg = d ? atoi(d) : 0; }      // timing experiments (wrong gradients!)
 #endif
-  g.n_pq = L.small && !sharded ? MADJ_SMALL_BLOCKS : MADJ_RBLOCKS;
+  g.n_pq = L.small && (!sharded || norm_kind == 1) ? MADJ_SMALL_BLOCKS : MADJ_RBLOCKS;
   g.com.s0 = s0; g.com.s1 = s1; g.com.jump_s = jump_s; g.com.n_jump = n_jump;
   g.com.rtol = rtol; g.com.atol = atol; g.com.safety = safety; g.com.ifactor = ifactor; g.com.dfactor = dfactor;
   g.com.n_state = (B_global > 0 ? B_global : B) * H;
@@ -1118,13 +1118,16 @@ static int dopri5_adjoint_mlp_advance_impl(const void* coeffs, const void* knots
       if (rc != CDE_OK) return rc;
     }
   }
-  MlpReduceArgs r = madj_reduce_args(base, L, rtol, atol, sharded);
+  // sharded under "seminorm": only the 8 state sums travel between the shards (cde_dopri5_adjoint_mlp_state_sums /
+  // _apply_state_sums); the gradient images are reduced, committed and returned per shard like an unsharded solve's
+  const bool images_local = sharded && norm_kind == 1;
+  MlpReduceArgs r = madj_reduce_args(base, L, rtol, atol, sharded && !images_local);
   MlpSmallArgs sm;
   sm.r = r; sm.G2 = g.G2; sm.U = g.U; sm.G1 = g.G1; sm.Z = g.Z; sm.rows_per_stage = L.rows_per_stage; sm.B = B;
   // after an attempt launch: the split-K reduction of its factor rows + the R kernel, or (small batches) both in one launch
   auto after_attempt = [&](int parity) -> int {
-    if (sharded) return CDE_OK;          // the caller goes on with cde_dopri5_adjoint_mlp_pending_sums / _apply_reduced
-    if (L.small) {
+    if (sharded && !images_local) return CDE_OK;   // the caller goes on with cde_dopri5_adjoint_mlp_pending_sums / _apply_reduced
+    if (L.small && !(sharded && !images_local)) {
       mlp_adjoint_small_reduce_kernel<<<MADJ_SMALL_BLOCKS, 256, 0, s>>>(sm, parity);
       return CDE_OK;
     }
@@ -1266,5 +1269,44 @@ extern "C" int cde_dopri5_adjoint_mlp_apply_reduced(void* workspace, size_t work
   MlpReduceArgs r = madj_reduce_args(base, L, rtol, atol, true);
   r.sums_in = reduced;
   mlp_adjoint_reduce_kernel<<<MADJ_RBLOCKS, 256, 0, (hipStream_t)stream>>>(r, (int)((total_launches - 1) & 1), 2);
+  return check_launch();
+}
+
+// The "seminorm" form: only the ADJ_NS state sums are pending on the other shards; after the all-reduce vjp_t at the end of
+// an interval is redone from the reduced sums (see dopri5_adjoint.hip: cde_dopri5_adjoint_state_sums).
+namespace cde {
+__global__ void madj_carry_kernel(const unsigned char* __restrict__ ctrl, int p2, const double* __restrict__ reduced,
+                                  double* __restrict__ carry) {
+  const AdjCtrl k = *reinterpret_cast<const AdjCtrl*>(ctrl + p2 * ADJ_CTRL_STRIDE);
+  if (k.c.phase == 4 && k.commit == 0) return;
+  if (k.mode == 3) carry[0] = (double)((float)k.T + (float)reduced[4]);
+}
+}  // namespace cde
+
+extern "C" int cde_dopri5_adjoint_mlp_state_sums(void* workspace, size_t workspace_bytes, int64_t B, int64_t C, int64_t H,
+                                                 int64_t total_launches, double* sums, void* stream) {
+  using namespace cde;
+  if (B < 1 || C < 1 || H < 1 || total_launches < 1) return CDE_ERR_SHAPE;
+  if (!workspace || !sums) return CDE_ERR_NULL;
+  if (workspace_bytes < cde_dopri5_adjoint_mlp_workspace_bytes(B, C, H)) return CDE_ERR_WORKSPACE;
+  unsigned char* base = (unsigned char*)workspace;
+  const MadjLayout L = madj_layout(B, H, C);
+  const int parity = (int)((total_launches - 1) & 1);
+  const double* partial = (const double*)(base + L.partial) + (int64_t)(parity ^ 1) * L.n_wg * ADJ_NS;
+  madj_state_sums_kernel<<<1, 64, 0, (hipStream_t)stream>>>(partial, L.n_wg, sums);
+  return check_launch();
+}
+
+extern "C" int cde_dopri5_adjoint_mlp_apply_state_sums(void* workspace, size_t workspace_bytes, int64_t B, int64_t C,
+                                                       int64_t H, int64_t total_launches, const double* reduced,
+                                                       void* stream) {
+  using namespace cde;
+  if (B < 1 || C < 1 || H < 1 || total_launches < 1) return CDE_ERR_SHAPE;
+  if (!workspace || !reduced) return CDE_ERR_NULL;
+  if (workspace_bytes < cde_dopri5_adjoint_mlp_workspace_bytes(B, C, H)) return CDE_ERR_WORKSPACE;
+  unsigned char* base = (unsigned char*)workspace;
+  const MadjLayout L = madj_layout(B, H, C);
+  const int parity = (int)((total_launches - 1) & 1);
+  madj_carry_kernel<<<1, 1, 0, (hipStream_t)stream>>>(base, parity ^ 1, reduced, (double*)(base + L.carry));
   return check_launch();
 }
