@@ -1,6 +1,7 @@
 """The training call of the reference's example model (example/time_series_classification.py: two-layer field,
 cdeint without `method`: dopri5 forward + adjoint).  Fused since round 3 (K4 forward, K4am backward); `stepwise` as a
-third argument forces the host-driven path of round 2.  python scripts/bench_default_call.py [B] [seminorm|mixed] [stepwise]"""
+third argument forces the host-driven path of round 2.
+    python scripts/bench_default_call.py [B] [seminorm|mixed] [stepwise|fused] [C] [H]     (C, H: e.g. 14 8 = config 5's shape)"""
 import sys, time, torch
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import torchcde_amd as cde
@@ -9,7 +10,9 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 extra = dict(adjoint_options=dict(norm="seminorm")) if len(sys.argv) > 2 and sys.argv[2] == "seminorm" else {}
 if len(sys.argv) > 3 and sys.argv[3] == "stepwise":
     extra["variant"] = "generic"
-L, C, H = 128, 8, 32
+L = 128
+C = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+H = int(sys.argv[5]) if len(sys.argv) > 5 else 32
 dev = torch.device("cuda", 0)
 class TwoLayer(torch.nn.Module):
     def __init__(self):
