@@ -473,8 +473,63 @@ __device__ __forceinline__ void stage_mlp16(const float* __restrict__ W1, const 
 // floats): 128 instead of 576 MFMAs per wave and evaluation.
 template <int ACT, int CT = MC, bool SPLIT = false>
 __device__ __forceinline__ void field_mlp16(const float* img, int lane, int q, const f32x4& za, const f32x4& zb,
-                                            const float (&dX)[CT], f32x4& fa, f32x4& fb, int pw = 0, float* xwin = nullptr) {
+                                            const float (&dX)[CT], f32x4& fa, f32x4& fb, int pw = 0, float* xwin = nullptr,
+                                            float* xu = nullptr) {
   constexpr int NB = CT / 4, NP = 16 / NB;
+  if constexpr (SPLIT && CT == MC) {
+    // Eight waves, 8-channel tiles (round 4): layer 1 is split as well -- wave pw computes hidden-layer tile pw (8 MFMAs
+    // instead of 64 redundant ones), the 8 x 16 units meet in `xu` (8 KB of LDS, one barrier) and are read from there as
+    // layer 2's B operands; layer 2 of unit group pw as before.  72 instead of 128 MFMAs per wave and evaluation.
+    const float4* w1 = reinterpret_cast<const float4*>(img) + lane;
+    const float4* bb1 = reinterpret_cast<const float4*>(img + W1M_FLOATS) + q;
+    const float4* w2 = reinterpret_cast<const float4*>(img + W1M_FLOATS + B1M_FLOATS) + lane;
+    const float4* bb2 = reinterpret_cast<const float4*>(img + W1M_FLOATS + B1M_FLOATS + W2M_FLOATS) + q;
+    const float zs[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
+    {
+      const float4 c0 = bb1[4 * pw];
+      f32x4 y0 = {c0.x, c0.y, c0.z, c0.w};
+      const float4 g0 = w1[(2 * pw) * 64], g1 = w1[(2 * pw + 1) * 64];
+      const float a0[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+      for (int s = 0; s < 8; ++s) y0 = mfma16(a0[s], zs[s], y0);      // one chain, bias first: the bits of the unsplit form
+      *reinterpret_cast<float4*>(xu + (pw * 64 + lane) * 4) =
+          make_float4(fmaxf(y0[0], 0.f), fmaxf(y0[1], 0.f), fmaxf(y0[2], 0.f), fmaxf(y0[3], 0.f));
+    }
+    __syncthreads();
+    f32x4 y[2];
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+      const float4 c0 = bb2[4 * (2 * pw + tb)];
+      y[tb] = f32x4{c0.x, c0.y, c0.z, c0.w};
+    }
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const float4 u4 = *reinterpret_cast<const float4*>(xu + (g * 64 + lane) * 4);
+      const float4 a0 = w2[(8 * (2 * pw) + g) * 64], a1 = w2[(8 * (2 * pw + 1) + g) * 64];
+      y[0] = mfma16(a0.x, u4.x, y[0]); y[1] = mfma16(a1.x, u4.x, y[1]);
+      y[0] = mfma16(a0.y, u4.y, y[0]); y[1] = mfma16(a1.y, u4.y, y[1]);
+      y[0] = mfma16(a0.z, u4.z, y[0]); y[1] = mfma16(a1.z, u4.z, y[1]);
+      y[0] = mfma16(a0.w, u4.w, y[0]); y[1] = mfma16(a1.w, u4.w, y[1]);
+    }
+    float f = 0.f;
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+      const f32x2 t01 = activate2<ACT>(y[tb][0], y[tb][1]), t23 = activate2<ACT>(y[tb][2], y[tb][3]);
+      f = (tb == 0) ? t01[0] * dX[0] : __builtin_fmaf(t01[0], dX[4 * tb], f);
+      f = __builtin_fmaf(t01[1], dX[4 * tb + 1], f);
+      f = __builtin_fmaf(t23[0], dX[4 * tb + 2], f);
+      f = __builtin_fmaf(t23[1], dX[4 * tb + 3], f);
+    }
+    xwin[pw * 64 + lane] = f;
+    __syncthreads();                                           // (also: every wave is done reading `xu`)
+    float fs[8];
+#pragma unroll
+    for (int P = 0; P < 8; ++P) fs[P] = xwin[P * 64 + lane];
+    fa = f32x4{fs[0], fs[1], fs[2], fs[3]};
+    fb = f32x4{fs[4], fs[5], fs[6], fs[7]};
+    __syncthreads();
+    return;
+  }
   int opaque = 0;                             // as in field_act16: keeps the LDS reads inside the call
   asm volatile("" : "+v"(opaque));
   const float4* w1 = reinterpret_cast<const float4*>(img) + lane + opaque;

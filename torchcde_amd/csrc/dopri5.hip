@@ -510,6 +510,9 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
 #pragma unroll
     for (int w8 = 0; w8 < 8; ++w8) { sums[0] += red[w8]; sums[1] += red[8 + w8]; }
   }
+  // (two-layer field, eight waves per tile: the 8 KB of `red` are the evaluations' u window from here on -- nobody may
+  //  still be reading the block sums)
+  if constexpr (MLP && SPLIT && CT == MC) __syncthreads();
   CDE_STAMP(3);
   const DopriPlan<T> plan = dopri_controller<T>(g, c, sums[0], sums[1]);
   // The controller's outputs derive from LDS reads (the block sums), so the compiler would keep them -- and every
@@ -538,7 +541,7 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   const float4* wy = reinterpret_cast<const float4*>(img_lds) + lane;
   const float4* by = reinterpret_cast<const float4*>(img_lds + WY_FLOATS) + q;
   auto field = [&](const f32x4& za, const f32x4& zb, const float (&dXv)[CT], f32x4& fa, f32x4& fb) {
-    if constexpr (MLP) field_mlp16<ACT, CT, SPLIT>(img_lds, lane, q, za, zb, dXv, fa, fb, wave, xwin);
+    if constexpr (MLP) field_mlp16<ACT, CT, SPLIT>(img_lds, lane, q, za, zb, dXv, fa, fb, wave, xwin, reinterpret_cast<float*>(red));
     else if constexpr (CT == MC) {
       if constexpr (PRODUCT && SPLIT) field16_split(sg0, sg1, sh0, sh1, sba, sbb, za, zb, dXv, q, fa, fb, wave, xwin, lane);
       else if constexpr (PRODUCT) field16(wA, wB, za, zb, dXv, q, fa, fb);

@@ -136,7 +136,7 @@ __global__ __launch_bounds__((fwd_block_threads<ACT, MLP>()), (fwd_waves_per_sim
 
       f32x4 fa, fb;
       if constexpr (PRODUCT) { if constexpr (CT == MC) field16(wA, wB, za, zb, dX, q, fa, fb); }
-      else if constexpr (MLP) field_mlp16<ACT, CT, SPLIT>(lds, lane, q, za, zb, dX, fa, fb, wave, xwin);
+      else if constexpr (MLP) field_mlp16<ACT, CT, SPLIT>(lds, lane, q, za, zb, dX, fa, fb, wave, xwin, xwin + 8 * 64);
       else { if constexpr (CT == MC) field_act16<ACT>(wy, by, za, zb, dX, fa, fb); }
       if constexpr (!PRODUCT) {
         __builtin_amdgcn_sched_barrier(0);
@@ -1144,7 +1144,7 @@ int launch_forward_mlp(const void* coeffs, const void* knots, int64_t n_interval
   // waves of a workgroup share a tile (K2m's split form)
   const int64_t tiles = (B + 15) / 16;
   const bool split = tiles <= 768 && !getenv("CDE_K2M_NO_SPLIT");
-  const size_t lds_split = lds + 8 * 64 * sizeof(float);
+  const size_t lds_split = lds + (8 * 64 + 8 * 64 * 4) * sizeof(float);     // f window + (8-channel tiles) the u window
 #define CDE_FWD_CT(D, A, CTV)                                                                                       \
   do {                                                                                                              \
     if (split) {                                                                                                    \
