@@ -241,14 +241,17 @@ __device__ __forceinline__ void mlp_adjoint_eval(const float* lds_base, const fl
 // 5.1 us of MFMA work).  Every wave ends with the same f, va, kt (fixed summation order), so the RK bookkeeping around
 // the call stays redundant and bit-identical.  The W1 / W1^T tiles a wave needs are 4 float4 in registers; the 16 KB the
 // W1 image occupied in LDS is the exchange window `xa`.
-template <int ACT, bool TGRAD>
+// NTSTORE / wq: the fixed-grid sweep (rk4_mlp_adjoint.hip) streams quadrature-WEIGHTED dL/dY rows that are read back only
+// after a whole chunk of steps (non-temporal stores); the adaptive kernel streams unweighted rows read microseconds later.
+template <int ACT, bool TGRAD, bool NTSTORE = false>
 __device__ __forceinline__ void mlp_adjoint_eval_split8(const float* lds_base, float* xa, float* xb, int lane, int q, int w,
                                                         const float4 (&w1r)[2], float4 b1r, const float4 (&w1tr)[2],
                                                         int w2y_off, const int (&w2g_off)[4], const float (&zs)[8],
                                                         float as_w, const float (&dX)[8], const float (&d2X)[8],
                                                         bool stream, float* urow, float* zrow, float* g2row, float* g1row,
                                                         int Hr, f32x4& fa, f32x4& fb, float& va_w, float& kt,
-                                                        bool stamp_on = false, unsigned long long* stamp = nullptr) {
+                                                        bool stamp_on = false, unsigned long long* stamp = nullptr,
+                                                        float wq = 1.f) {
 #ifdef CDE_PHASE_TRACE
 #define CDE_EVAL_STAMP(slot, ...) do { if (stamp_on) { asm volatile("s_nop 0" : __VA_ARGS__); __builtin_amdgcn_sched_barrier(0); \
                                        stamp[slot] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } } while (0)
@@ -256,23 +259,28 @@ __device__ __forceinline__ void mlp_adjoint_eval_split8(const float* lds_base, f
 #define CDE_EVAL_STAMP(slot, ...) do { (void)stamp; (void)stamp_on; } while (0)
 #endif
   constexpr int CT = 8;
+  auto store4 = [](float* p, float a, float b, float c, float d) {
+    if constexpr (NTSTORE) stream_store4(p, a, b, c, d); else plain_store4(p, a, b, c, d);
+  };
   const float* w2p = lds_base + W1M_FLOATS + B1M_FLOATS;
   const float4* bb2 = reinterpret_cast<const float4*>(lds_base + W1M_FLOATS + B1M_FLOATS + W2P_FLOATS) + q;
   // ---- layer 1, tile T1 = w: u = relu(W1 z + b1) for hidden-layer units 16w + 4q + r
-  f32x4 y1 = {b1r.x, b1r.y, b1r.z, b1r.w}, y1b = {0.f, 0.f, 0.f, 0.f};
+  // (ONE accumulator chain, bias first, K steps in order: the bits of every other form of this layer -- forward kernels
+  //  included -- so that the relu mask of the backward pass is the forward pass's: with a different summation order a
+  //  pre-activation within an ulp of zero flips its mask and that series' gradient jumps)
+  f32x4 y1 = {b1r.x, b1r.y, b1r.z, b1r.w};
   {
     const float a0[8] = {w1r[0].x, w1r[0].y, w1r[0].z, w1r[0].w, w1r[1].x, w1r[1].y, w1r[1].z, w1r[1].w};
 #pragma unroll
-    for (int s = 0; s < 8; s += 2) { y1 = mfma16(a0[s], zs[s], y1); y1b = mfma16(a0[s + 1], zs[s + 1], y1b); }
+    for (int s = 0; s < 8; ++s) y1 = mfma16(a0[s], zs[s], y1);
   }
-  y1 = y1 + y1b;
   float uo[4];
   unsigned mask = 0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) { uo[r] = fmaxf(y1[r], 0.f); mask |= (y1[r] > 0.f ? 1u : 0u) << r; }
   *reinterpret_cast<float4*>(xb + (w * 64 + lane) * 4) = make_float4(uo[0], uo[1], uo[2], uo[3]);
   if (stream) {
-    plain_store4(urow + 16 * w, uo[0], uo[1], uo[2], uo[3]);
+    store4(urow + 16 * w, uo[0], uo[1], uo[2], uo[3]);
     if (w == 0) {
 #pragma unroll
       for (int m = 0; m < 8; ++m) if (4 * m + q < Hr) zrow[4 * m + q] = zs[m];
@@ -320,8 +328,8 @@ __device__ __forceinline__ void mlp_adjoint_eval_split8(const float* lds_base, f
   *reinterpret_cast<float4*>(xa + ((2 * w + 1) * 64 + lane) * 4) = make_float4(g2[4], g2[5], g2[6], g2[7]);
   if (stream) {
     float* grow = g2row + 4 * CT * w;                            // rows (h = 4w+q, c = 0..7) of the padded layout
-    plain_store4(grow, g2[0], g2[1], g2[2], g2[3]);
-    plain_store4(grow + 4, g2[4], g2[5], g2[6], g2[7]);
+    store4(grow, g2[0] * wq, g2[1] * wq, g2[2] * wq, g2[3] * wq);
+    store4(grow + 4, g2[4] * wq, g2[5] * wq, g2[6] * wq, g2[7] * wq);
   }
   __syncthreads();                                               // dL/dY2 of all 256 rows is in xa
   CDE_EVAL_STAMP(1, "+v"(g2[0]));
@@ -345,7 +353,7 @@ __device__ __forceinline__ void mlp_adjoint_eval_split8(const float* lds_base, f
   float g1[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) g1[r] = (mask >> r) & 1u ? gu[r] : 0.f;
-  if (stream) plain_store4(g1row + 16 * w, g1[0], g1[1], g1[2], g1[3]);
+  if (stream) store4(g1row + 16 * w, g1[0] * wq, g1[1] * wq, g1[2] * wq, g1[3] * wq);
   f32x4 pa = {0.f, 0.f, 0.f, 0.f}, pb = pa;
   pa = mfma16(w1tr[0].x, g1[0], pa); pb = mfma16(w1tr[1].x, g1[0], pb);
   pa = mfma16(w1tr[0].y, g1[1], pa); pb = mfma16(w1tr[1].y, g1[1], pb);

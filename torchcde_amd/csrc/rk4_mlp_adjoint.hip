@@ -350,6 +350,115 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2) void rk4_adjoint_
   }
 }
 
+// ------------------------------------------------------------------------------------------ eight waves per tile (round 4)
+// The sweep for SMALL batches (at most two 16-series tiles per CU; 8-channel tiles, no control gradients) on the
+// decomposition of K4am's small-batch kernel (dopri5_mlp_adjoint.hip: dopri5_mlp_adjoint_attempt_s8, cde_mlp_adj.h:
+// mlp_adjoint_eval_split8): the eight waves of a workgroup share one tile and split every evaluation eight ways -- 144 MFMAs
+// per wave instead of 384 in the four-wave form, two waves per SIMD -- every wave carries all of z but only ITS component of
+// a (hidden unit 4w + q), wave 0 streams z / stores y, every wave its part of the factor rows and its component of a.
+template <typename TT, int DEGREE, int ACT>
+__global__ __launch_bounds__(512, 2) void rk4_adjoint_mlp_sweep_s8(
+    const float* __restrict__ coeffs, const float* __restrict__ knots, int64_t n_intervals,
+    const float* __restrict__ img, float* __restrict__ y_state, float* __restrict__ a_state,
+    const TT* __restrict__ sgrid, int64_t k_begin, int64_t k_end, const int64_t* __restrict__ stage_index,
+    const float* __restrict__ stage_frac, float* __restrict__ U, float* __restrict__ G2, float* __restrict__ G1,
+    float* __restrict__ Z, int64_t B, Dims dims) {
+  constexpr int CT = MC;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // the LDS image without its W1 part (b1 | W2 | b2), straight into LDS; this wave's W1 / W1^T tiles into registers
+  for (int chunk = W1M_FLOATS / 256 + w; chunk * 256 < ADJ_LDS_FLOATS; chunk += 8) {
+    if (chunk * 256 + lane * 4 < ADJ_LDS_FLOATS)
+      __builtin_amdgcn_global_load_lds(img + chunk * 256 + lane * 4, lds + chunk * 256, 16, 0, 0);
+  }
+  float4 w1r[2], w1tr[2];
+  {
+    const float4* w1img = reinterpret_cast<const float4*>(img) + lane;
+    w1r[0] = w1img[(2 * w) * 64]; w1r[1] = w1img[(2 * w + 1) * 64];
+    const float4* w1t_base = reinterpret_cast<const float4*>(img + ADJ_LDS_FLOATS) + lane;
+    w1tr[0] = w1t_base[w * 64]; w1tr[1] = w1t_base[(8 + w) * 64];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const float4 b1r = (reinterpret_cast<const float4*>(lds + W1M_FLOATS) + (lane >> 4))[4 * w];
+  float* xa = lds;                                                 // exchange windows: the W1 image's 16 KB ..
+  float* xb = lds + ADJ_LDS_FLOATS;                                // .. and 9 KB behind the image
+  const int Hr = dims.H, Cr = dims.C;
+  const int n = lane & 15, q = lane >> 4;
+  const int64_t tile = blockIdx.x;
+  const int64_t series = tile * 16 + n;
+  const bool in_range = series < B;
+  const int64_t sc = in_range ? series : B - 1;
+  const int hw = 4 * w + q;
+  const bool own = in_range && hw < Hr;
+  const int w2y_off = ((n >> 3) * 8 + w2p_residue(n >> 2, n & 3)) * W2P_STRIDE + 4 * q;
+  int w2g_off[4];
+#pragma unroll
+  for (int cl = 0; cl < 4; ++cl) w2g_off[cl] = ((q >> 1) * 8 + w2p_residue(q, cl)) * W2P_STRIDE + n;
+  const int ua = q, ub = 16 + q;
+  f32x4 ya = load_units4<4>(y_state + sc * Hr, ua, Hr), yb = load_units4<4>(y_state + sc * Hr, ub, Hr);
+  float aw = own ? a_state[sc * Hr + hw] : 0.f;                    // a == 0 stays 0: padded lanes / units contribute nothing
+  int64_t idx = stage_index[4 * k_begin];
+  float frac = stage_frac[4 * k_begin];
+  const float zero8[CT] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  for (int64_t k = k_begin; k < k_end; ++k) {
+    const float ds = (float)(sgrid[k + 1] - sgrid[k]);
+    f32x4 ky1a = {0.f, 0.f, 0.f, 0.f}, ky1b = ky1a, ky2a = ky1a, ky2b = ky1a;
+    float ka1 = 0.f, ka2 = 0.f;
+    f32x4 za = ya, zb = yb;
+    float sw = aw;
+#pragma clang loop unroll(disable)
+    for (int stage = 0; stage < 4; ++stage) {
+      const Row<DEGREE, CT> row = load_row<DEGREE, CT>(coeffs, sc, n_intervals, idx, Cr);
+      float dX[CT];
+      const float width = DEGREE == CDE_PATH_LINEAR ? knots[idx + 1] - knots[idx] : 1.f;
+      control_slope<DEGREE, CT>(row, frac, width, dX);
+      const int64_t e_next = 4 * k + stage + 1;
+      const bool more = e_next < 4 * k_end;
+      const int64_t nidx = more ? stage_index[e_next] : idx;
+      const float nfrac = more ? stage_frac[e_next] : frac;
+      const float wq = ((stage == 0 || stage == 3) ? 0.125f : 0.375f) * ds;     // 3/8-rule quadrature weight
+      const int64_t out_row = ((k - k_begin) * 4 + stage) * B + series;          // (stage, series)
+      const float zs[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
+      f32x4 fa, fb;
+      float va_w, kt;
+      mlp_adjoint_eval_split8<ACT, false, true>(lds, xa, xb, lane, q, w, w1r, b1r, w1tr, w2y_off, w2g_off, zs, sw, dX, zero8,
+                                                in_range, U + out_row * U_COLS + 4 * q, Z + out_row * Z_COLS,
+                                                G2 + out_row * G2_COLS + CT * q, G1 + out_row * G1_COLS + 4 * q, Hr, fa, fb,
+                                                va_w, kt, false, nullptr, wq);
+      // ---- reverse-time dynamics: dz/ds = -f, da/ds = +a^T df/dz; torchdiffeq 3/8 rule, association preserved
+      const f32x4 kya = -fa, kyb = -fb;
+      const float ka = va_w;
+      const float third = (float)(1.0 / 3.0);
+      if (stage == 0) {
+        ky1a = kya; ky1b = kyb; ka1 = ka;
+        za = ya + ds * ky1a * third; zb = yb + ds * ky1b * third;
+        sw = aw + ds * ka1 * third;
+      } else if (stage == 1) {
+        ky2a = kya; ky2b = kyb; ka2 = ka;
+        za = ya + ds * (ky2a - ky1a * third); zb = yb + ds * (ky2b - ky1b * third);
+        sw = aw + ds * (ka2 - ka1 * third);
+      } else if (stage == 2) {
+        za = ya + ds * (ky1a - ky2a + kya); zb = yb + ds * (ky1b - ky2b + kyb);
+        sw = aw + ds * (ka1 - ka2 + ka);
+        ky1a = ky1a + 3.f * (ky2a + kya); ky1b = ky1b + 3.f * (ky2b + kyb);
+        ka1 = ka1 + 3.f * (ka2 + ka);
+      } else {
+        za = ya + (ky1a + kya) * ds * 0.125f; zb = yb + (ky1b + kyb) * ds * 0.125f;
+        sw = aw + (ka1 + ka) * ds * 0.125f;
+      }
+      idx = nidx; frac = nfrac;
+    }
+    ya = za; yb = zb; aw = sw;
+  }
+  if (in_range && w == 0) {
+    store_units4<4>(y_state + series * Hr, ua, Hr, ya);
+    store_units4<4>(y_state + series * Hr, ub, Hr, yb);
+  }
+  if (own) a_state[series * Hr + hw] = aw;
+}
+
 // ------------------------------------------------------------------------------------------ host side
 size_t mlp_adjoint_image_bytes() { return (size_t)MLP_ADJ_IMAGE_FLOATS * sizeof(float); }
 
@@ -361,6 +470,8 @@ int launch_mlp_adjoint_images(const void* W1, const void* b1, int64_t width, con
   return check_launch();
 }
 
+constexpr int64_t K3M_S8_MAX_TILES = 1536;    // 24576 series (measured: 12288: 34.4 -> 20.9 ms, 24576: 44.1 -> 41.9, 32768: 47.6 vs 52.2)
+
 template <typename TT>
 int launch_mlp_adjoint_sweep(const void* coeffs, const void* knots, int64_t n_intervals, int degree, int act,
                              const float* img, void* y_state, void* a_state, const void* sgrid, int64_t k_begin,
@@ -371,10 +482,35 @@ int launch_mlp_adjoint_sweep(const void* coeffs, const void* knots, int64_t n_in
   // up to 512 tiles (two rounds of one workgroup per CU; the 8-wave form would use a quarter of the CUs there): four
   // waves per tile (the split form)
   const int64_t tiles = (B + 15) / 16;
-  const bool split = tiles <= 512 && !getenv("CDE_K3M_NO_SPLIT");
+  // (the eight-wave form of 8-channel tiles runs ~7 ms per round of 256 tiles: it beats the one-wave-per-tile form up to
+  //  CDE_K3M_S8_TILES tiles; measured crossover in profiles/NOTES.md)
+  const char* s8_env = getenv("CDE_K3M_S8_TILES");
+  const int64_t s8_tiles = s8_env ? atoll(s8_env) : K3M_S8_MAX_TILES;
+  const bool s8_shape = C <= MC && !grad_coeffs && !getenv("CDE_K3M_SPLIT4");
+  const bool split = tiles <= (s8_shape ? (s8_tiles > 512 ? s8_tiles : 512) : 512) && !getenv("CDE_K3M_NO_SPLIT");
   const unsigned blocks = split ? (unsigned)tiles : (unsigned)((B + 127) / 128);
   const unsigned threads = split ? 256 : 512;
   const size_t lds = (size_t)ADJ_LDS_FLOATS * sizeof(float) + (split ? (size_t)4 * 64 * 9 * sizeof(float) : 0);
+  // ... eight waves per tile (everything split eight ways) for 8-channel tiles without control gradients
+  if (split && s8_shape && tiles <= (s8_tiles > 512 ? s8_tiles : 512)) {
+#define CDE_SWEEP8(D, A)                                                                                           \
+  do {                                                                                                             \
+    (void)hipFuncSetAttribute((const void*)rk4_adjoint_mlp_sweep_s8<TT, D, A>,                                     \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
+    rk4_adjoint_mlp_sweep_s8<TT, D, A><<<blocks, 512, lds, s>>>(                                                   \
+        (const float*)coeffs, (const float*)knots, n_intervals, img, (float*)y_state, (float*)a_state,             \
+        (const TT*)sgrid, k_begin, k_end, stage_index, (const float*)stage_frac, (float*)U, (float*)G2, (float*)G1, \
+        (float*)Z, B, dims);                                                                                       \
+  } while (0)
+    if (degree != CDE_PATH_CUBIC && degree != CDE_PATH_LINEAR) return CDE_ERR_UNSUPPORTED;
+    if (act == CDE_ACT_NONE) {
+      if (degree == CDE_PATH_CUBIC) CDE_SWEEP8(CDE_PATH_CUBIC, CDE_ACT_NONE); else CDE_SWEEP8(CDE_PATH_LINEAR, CDE_ACT_NONE);
+    } else if (act == CDE_ACT_TANH) {
+      if (degree == CDE_PATH_CUBIC) CDE_SWEEP8(CDE_PATH_CUBIC, CDE_ACT_TANH); else CDE_SWEEP8(CDE_PATH_LINEAR, CDE_ACT_TANH);
+    } else return CDE_ERR_UNSUPPORTED;
+#undef CDE_SWEEP8
+    return check_launch();
+  }
 #define CDE_SWEEP_L(D, A, X, CTV, SPL, GC)                                                                         \
   do {                                                                                                             \
     (void)hipFuncSetAttribute((const void*)rk4_adjoint_mlp_sweep<TT, D, A, X, CTV, SPL>,                           \
