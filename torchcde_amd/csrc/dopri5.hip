@@ -384,6 +384,7 @@ __device__ unsigned long long k4_phase_trace[TRACE_RING * TRACE_BLOCKS * TRACE_S
 // every evaluation by unit group (cde_mfma.h: field_mlp16<..., SPLIT>); all of them carry the state, wave 0 alone stores
 // it, writes outputs and contributes to the error sums.
 constexpr int DOPRI_XWIN_FLOATS = 8 * 64;
+constexpr int64_t DOPRI_MLP_SPLIT_TILES = 768;   // two-layer field, 8-channel tiles: the eight waves of a workgroup share a tile (forward 8192 series: 105 -> 51 ms, 16384: tie)
 template <int DEGREE, int ACT, bool MLP = false, int CT = MC, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g, int parity) {
   static_assert(CT == MC || MLP, "16-channel tiles: two-layer fields only");
@@ -1192,7 +1193,9 @@ static int dopri5_advance_impl(const void* coeffs, const void* knots, int64_t n_
                          cde::DOPRI_IMAGE_BYTES;
       // up to 256 tiles (one workgroup per CU): the 8 waves of a workgroup share a tile
       const int64_t tiles = (B + 15) / 16;
-      const bool split = tiles <= 256 && !ext_sums && B_global == 0 && !getenv("CDE_K4M_NO_SPLIT");
+      const char* split_env = getenv("CDE_K4M_SPLIT_TILES");                    // (measurements)
+      const int64_t split_tiles = split_env ? atoll(split_env) : (C > cde::MC ? 256 : cde::DOPRI_MLP_SPLIT_TILES);
+      const bool split = tiles <= split_tiles && !ext_sums && B_global == 0 && !getenv("CDE_K4M_NO_SPLIT");
       const size_t lds_split = lds + (size_t)cde::DOPRI_XWIN_FLOATS * sizeof(float);
 #define CDE_MLP_CT(D, A, CTV)                                                                                      \
   do {                                                                                                             \

@@ -33,6 +33,7 @@ constexpr int MADJ_P2 = 256 * 129, MADJ_P1 = 128 * 33;          // elements of a
 constexpr int MADJ_ELEMS = MADJ_P2 + MADJ_P1;
 constexpr int MADJ_RBLOCKS = (MADJ_ELEMS + 31) / 32;
 constexpr int MADJ_MAX_SPS = 40;                 // slabs per stage of the factor reduction (80: 121 -> 133 us per attempt at 4096 series)
+constexpr int64_t MADJ_S8_MAX_TILES = 768;       // eight waves per tile (8-channel tiles), several rounds: see madj_layout
 constexpr int64_t MADJ_SPLIT_MAX_TILES = 256;    // batches up to 4096 series (one tile per CU): four waves per tile (K4am's split form)
 constexpr int MADJ_NSUM = ADJ_NS + 2 * ADJ_MAX_PT;
 __host__ __device__ constexpr int madj_slot(int stage) { return stage == 0 ? 0 : stage - 1; }      // stage 1 is never stored
@@ -994,7 +995,14 @@ MadjLayout madj_layout(int64_t B, int64_t H, int64_t C) {
   L.nwave = (L.n_tiles > 1024 || (force_waves && force_waves[0] == '8')) ? 8 : 4;
   // up to MADJ_SPLIT_MAX_TILES tiles (one workgroup per CU in a single round): four waves per tile, the evaluation's middle
   // split four ways
-  L.split = L.n_tiles <= MADJ_SPLIT_MAX_TILES && !getenv("CDE_K4AM_NO_SPLIT");
+  // (8-channel tiles: the eight-wave form takes ~75 us per round of 256 tiles, the one-wave-per-tile forms 260-420 us
+  //  whatever the batch -- measured per attempted step: 8192 series 320 -> 210 us, 12288: 341 -> 303, 16384: 360 vs 394;
+  //  CDE_K4AM_S8_TILES overrides the threshold, for measurements)
+  const char* s8_env = getenv("CDE_K4AM_S8_TILES");
+  const int64_t s8_tiles = s8_env ? atoll(s8_env) : MADJ_S8_MAX_TILES;
+  const bool s8_shape = C <= MC && !getenv("CDE_K4AM_SPLIT4");
+  L.split = L.n_tiles <= (s8_shape && s8_tiles > MADJ_SPLIT_MAX_TILES ? s8_tiles : MADJ_SPLIT_MAX_TILES) &&
+            !getenv("CDE_K4AM_NO_SPLIT");
   // ... eight (two per SIMD, everything split eight ways: mlp_adjoint_eval_split8) when the control fits the 32 x 8 tiling
   L.split8 = L.split && C <= MC && !getenv("CDE_K4AM_SPLIT4");
   // a few hundred rows per attempt: factor reduction + R in one launch (mlp_adjoint_small_reduce_kernel)
