@@ -446,6 +446,29 @@ def other_configs(cde, device, reps=3):
         out["example_model_default_call%s_backward_ms" % tag] = once(lambda: res[:, -1].sum().backward())
         out["example_model_default_call%s_backward_attempts" % tag] = {
             k: v for k, v in front.last_dopri5_adjoint_stats.items() if k in ("n_accept", "n_reject")}
+    # ... at 8192 series: the shared-tile forms of K4 / K4am over two rounds of workgroups (up to 12288 series)
+    x8 = make_series(8192, L, C, seed=0).to(device)
+    X8 = cde.CubicSpline(cde.hermite_cubic_coefficients_with_backward_differences(x8))
+    z8 = torch.randn(8192, H, generator=torch.Generator().manual_seed(0)).to(device).requires_grad_(True)
+    semi = dict(adjoint_options=dict(norm="seminorm"))
+    cde.cdeint(X8, model, z8, X8.interval, **semi)
+    out["example_model_8192_default_call_seminorm_forward_ms"] = once(lambda: cde.cdeint(X8, model, z8, X8.interval, **semi))
+    res = cde.cdeint(X8, model, z8, X8.interval, **semi)
+    out["example_model_8192_default_call_seminorm_backward_ms"] = once(lambda: res[:, -1].sum().backward())
+    st = front.last_dopri5_adjoint_stats
+    out["example_model_8192_default_call_seminorm_us_per_attempt"] = (
+        out["example_model_8192_default_call_seminorm_backward_ms"] * 1e3 / max(st.get("n_accept", 0) + st.get("n_reject", 0), 1))
+    # ... and the same model under rk4 (K2m + K3m, the eight-wave sweep below 24576 series): forward + adjoint
+    for nb, Xr, zr in ((64, None, None), (4096, Xs, zs0)):
+        if Xr is None:
+            Xr = cde.CubicSpline(cde.hermite_cubic_coefficients_with_backward_differences(xs[:nb].contiguous()))
+            zr = zs0[:nb].contiguous()
+
+        def rk4_step():
+            z = zr.detach().requires_grad_(True)
+            cde.cdeint(Xr, model, z, Xr.interval, method="rk4", options=dict(step_size=1.0))[:, -1].sum().backward()
+        rk4_step()
+        out["example_model_rk4_forward_adjoint_%d_series_ms" % nb] = min(once(rk4_step) for _ in range(3))
     return out
 
 

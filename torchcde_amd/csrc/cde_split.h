@@ -79,6 +79,8 @@ struct Feed {
   float frac1, frac2;
   float cur[3], raw[3];
   bool pending;                        // raw holds the coefficients of idx1, not yet installed in cur (uniform)
+  int ahead, idx_max;                  // rows between an installed interval and the one whose cache line is touched (signed)
+  float touched;
 
   __device__ __forceinline__ void init(const float* coeffs, const float* knots_, const int64_t* si, const float* sf,
                                        int64_t n_intervals, int64_t sc, int Cr, int c) {
@@ -88,6 +90,19 @@ struct Feed {
     part = Cr;
     if (DEGREE == CDE_PATH_CUBIC) { stride = 4 * Cr; base = coeffs + sc * n_intervals * 4 * Cr + Cr + cc; }
     else { stride = Cr; base = coeffs + sc * (n_intervals + 1) * Cr + cc; }
+    idx_max = (int)(DEGREE == CDE_PATH_CUBIC ? n_intervals - 1 : n_intervals);
+    ahead = 0;
+  }
+  // Every coefficient row is read exactly once, so the row of a NEW interval comes from HBM (~1 us) although it is needed
+  // one stage (~0.5 us) after the stage table names it: a third of that wait was exposed every time the interval changed.
+  // When a row is installed, one dword of the row the sweep will most likely need after it (the next 128-byte line in the
+  // sweep's direction) is requested and never looked at: by the time request() names it, it sits in this XCD's L2.
+  // (a plain load whose value is "used" by an empty asm at the NEXT install: the compiler waits for it there and nowhere
+  //  else; a volatile access would also turn the stage table's scalar loads into vector loads)
+  __device__ __forceinline__ void touch(int idx) {
+    int at = idx + ahead;
+    at = at < 0 ? 0 : (at > idx_max ? idx_max : at);
+    touched = base[(int64_t)at * stride];
   }
   __device__ __forceinline__ int index_at(int e) const { return (int)sidx[e < e_last ? e : e_last]; }
   __device__ __forceinline__ float frac_at(int e) const { return sfrac[e < e_last ? e : e_last]; }
@@ -112,6 +127,11 @@ struct Feed {
     const float frac0 = frac_at(e0);
     request(idx0);
     install();
+    {
+      const int rows_per_line = DEGREE == CDE_PATH_CUBIC ? 1 : (32 / part > 1 ? 32 / part : 1);
+      ahead = index_at(last) >= idx0 ? rows_per_line : -rows_per_line;
+      touch(idx0);
+    }
     const float v0 = value(frac0);
     idx1 = index_at(e0 + 1); frac1 = frac_at(e0 + 1);
     idx2 = index_at(e0 + 2); frac2 = frac_at(e0 + 2);
@@ -123,10 +143,16 @@ struct Feed {
   __device__ __forceinline__ float advance(int e) {
     const int idx3 = index_at(e + 3);
     const float frac3 = frac_at(e + 3);
-    // opaque to the optimiser: otherwise it merges this install into the request of the previous stage (same
-    // condition) and the load is waited for right where it was issued
-    asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]));
-    if (pending) install();
+    // `pending` opaque to the optimiser: otherwise it merges this install into the request of the previous stage (same
+    // condition) and the load is waited for right where it was issued.  The wait (s_waitcnt vmcnt) sits INSIDE the branch:
+    // stages that install nothing wait for nothing, so the line touched below has until the next install to arrive.
+    int inst = __builtin_amdgcn_readfirstlane(pending ? 1 : 0);
+    asm volatile("" : "+s"(inst));
+    if (inst) {
+      asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]) : "v"(touched));
+      install();
+      touch(idx1);
+    }
     const float v = value(frac1);
     pending = idx2 != idx1;
     if (pending) request(idx2);
@@ -178,6 +204,21 @@ __device__ __forceinline__ void spl_load_wj(const float* __restrict__ W, const f
     auto bv = [&](int u, int c) { return (u < d.H && c < d.C) ? bias[u * d.C + c] : 0.f; };
     bja[j] = f32x2{bv(ua, 2 * j), bv(ua, 2 * j + 1)};
     bjb[j] = f32x2{bv(ub, 2 * j), bv(ub, 2 * j + 1)};
+  }
+}
+
+// The stage table (interval index + fraction per stage, a few KB) is read through the scalar cache, one entry per stage, by
+// every workgroup in the same stage at the same time: the first reader of a 64-byte line on an XCD waits for HBM (~1 us,
+// every 8th stage) and the others with it.  Pull the sweep's part of the table into L2 before the first stage.
+__device__ __forceinline__ void touch_stage_table(const int64_t* __restrict__ sidx, const float* __restrict__ sfrac,
+                                                  int64_t first, int64_t count) {
+  for (int64_t i = (int64_t)threadIdx.x * 8; i < count; i += (int64_t)blockDim.x * 8) {
+    const int lo = (int)sidx[first + i];
+    asm volatile("" ::"v"(lo));
+  }
+  for (int64_t i = (int64_t)threadIdx.x * 16; i < count; i += (int64_t)blockDim.x * 16) {
+    const float v = sfrac[first + i];
+    asm volatile("" ::"v"(v));
   }
 }
 

@@ -82,6 +82,7 @@ __global__ __launch_bounds__(256, 2) void rk4_forward_split(
   store(0, ya, yb);
   const int64_t n_steps = n_grid - 1;
   if (n_steps <= 0) return;
+  touch_stage_table(stage_index, stage_frac, 0, 4 * n_steps);
 
   float* zw = zbuf + n * SPL_ZROW + q * 8 + 2 * w;          // writer: global K steps 2w, 2w + 1 of quarter q
   const float* zr = zbuf + n * SPL_ZROW + q * 8;            // reader: quarter q
@@ -108,6 +109,7 @@ __global__ __launch_bounds__(256, 2) void rk4_forward_split(
   __syncthreads();
 
   int64_t jout = 1;
+  TT t_due = n_out > 1 ? t_out[1] : (TT)0;                    // the next output time: reloaded when an output is written only
   for (int64_t k = 0; k < n_steps; ++k) {
     const TT t0 = grid[k], t1 = grid[k + 1];
     const float dt = (float)(t1 - t0);
@@ -162,8 +164,8 @@ __global__ __launch_bounds__(256, 2) void rk4_forward_split(
       par ^= 1;
     }
     const float y1a = za, y1b = zb;
-    while (jout < n_out && t1 >= t_out[jout]) {
-      const TT tj = t_out[jout];
+    while (jout < n_out && t1 >= t_due) {
+      const TT tj = t_due;
       if (tj == t0) store(jout, ya, yb);
       else if (tj == t1) store(jout, y1a, y1b);
       else {
@@ -171,6 +173,7 @@ __global__ __launch_bounds__(256, 2) void rk4_forward_split(
         store(jout, ya + slope * (y1a - ya), yb + slope * (y1b - yb));
       }
       ++jout;
+      if (jout < n_out) t_due = t_out[jout];
     }
     ya = y1a; yb = y1b;
   }
@@ -218,6 +221,7 @@ __global__ __launch_bounds__(512, 1) void rk4_adjoint_split8(
   const int64_t sc = valid ? series : B - 1;
   const float third = (float)(1.0 / 3.0);
   int par = 0, gpar = 0;                                           // parity of the state buffers / of the g^T tile
+  if (n_out >= 2) touch_stage_table(stage_index, stage_frac, 0, 4 * (seg_off[n_out - 1] - 1));
 
   if (helper) {
     // ------------------------------------------------------------------------------------------ helper wave
