@@ -34,6 +34,11 @@ struct AdjCtrl {
                                 // totals, 2 add THIS launch's image (mode 3: the dense output at the interval end)
   int32_t mode;                 // what this launch computes: 0 f0 norms, 1 f1 norm, 2 attempt, 3 dense output at s1
   int32_t kind0;                // stage-0 time perturbation of the pending attempt (mode 3 repeats that attempt)
+  // K4am, eight-wave form (first-same-as-last, as torchdiffeq keeps f0 / f1): where the pending attempt's FIRST stage lives
+  // -- factor-row block and slope stash `src0` (0: evaluated by that launch; 5 / 6: the last stage of the step accepted
+  // before it) -- and where its LAST stage went (`six`: 5 or 6, never `src0`).  The other forms set (0, 5): every stage
+  // evaluated, the last one in block 5.
+  int32_t src0, six;
 };
 static_assert(sizeof(AdjCtrl) <= ADJ_CTRL_STRIDE, "controller block outgrew its slot");
 

@@ -29,6 +29,8 @@
 namespace cde {
 
 constexpr int MADJ_SLOTS = 6;                    // stages whose factors are kept: 0, 2, 3, 4, 5, 6
+constexpr int MADJ_FSLOTS = 7;                   // factor-row blocks: 0 first stage, 1..4 stages 2..5, 5 and 6 the last stage
+                                                 // (alternating: the accepted step's last stage IS the next step's first)
 constexpr int MADJ_P2 = 256 * 129, MADJ_P1 = 128 * 33;          // elements of a layer-2 / layer-1 slab partial (bias column last)
 constexpr int MADJ_ELEMS = MADJ_P2 + MADJ_P1;
 constexpr int MADJ_RBLOCKS = (MADJ_ELEMS + 31) / 32;
@@ -50,7 +52,8 @@ struct MlpAdjArgs {
   double* partial;                  // [2][n_wg_max][ADJ_NS]
   double* pq;                       // [2][MADJ_RBLOCKS][8]
   float* slopes;                    // [n_tiles][7][4][64] float4: the stage slopes of every lane
-  float* U; float* G2; float* G1; float* Z;      // factor rows [slot][rows_per_stage]
+  float* U; float* G2; float* G1; float* Z;      // factor rows [block][rows_per_stage], MADJ_FSLOTS blocks
+  float* stash_y; float* stash_a; float* stash_t;  // [3][B*H], [3][B*H], [3][B*4]: slopes of a first / last stage (blocks 0, 5, 6)
   AdjCommon com;
   int n_wg_max;
   const double* ext_sums;           // sharded batch: the ADJ_NS state sums of the pending attempt, added up over ALL shards
@@ -163,6 +166,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
   if (blockIdx.x == 0 && tid == 0) {                               // the controller block for the next launch / the R kernel
     c.phase = mode == 0 ? 1 : mode == 1 ? 2 : mode == 2 ? 3 : 4;
     c.slot = sidx[0];                                              // search hint for the next launch's stage times
+    k.src0 = 0; k.six = 5;                                         // every stage evaluated here, the last one in block 5
     *reinterpret_cast<AdjCtrl*>(g.ctrl + p2 * ADJ_CTRL_STRIDE) = k;
   }
 
@@ -494,6 +498,16 @@ __global__ __launch_bounds__(512, 2) void dopri5_mlp_adjoint_attempt_s8(MlpAdjAr
   const f32x4 yk1a = load_units4<4>((fresh ? yc0 : Sp + 2 * BH) + sc * Hr, ua, Hr);           // .. and if it is
   const f32x4 yk1b = load_units4<4>((fresh ? yc0 : Sp + 2 * BH) + sc * Hr, ub, Hr);
   const float ak0 = own ? ac0[sc * Hr + hw] : 0.f, ak1 = own ? (fresh ? ac0 : Sp + 3 * BH)[sc * Hr + hw] : 0.f;
+  // ... and both candidates of the FIRST STAGE's slopes (first-same-as-last): the pending attempt's own first stage if it is
+  // rejected (same start state, same stage time: torchdiffeq keeps f0), its last stage if it is accepted (f1 becomes f0)
+  const int in_src0 = uni((int)k.src0), in_six = uni((int)k.six);
+  auto stash_of = [](int blk) { return blk == 0 ? 0 : blk - 4; };  // blocks 0, 5, 6 -> the stash's three planes
+  const int64_t at_r = (int64_t)stash_of(in_src0) * g.B + sc, at_a = (int64_t)stash_of(fresh ? 0 : in_six) * g.B + sc;
+  const f32x4 kr_a = load_units4<4>(g.stash_y + at_r * Hr, ua, Hr), kr_b = load_units4<4>(g.stash_y + at_r * Hr, ub, Hr);
+  const f32x4 ka_a = load_units4<4>(g.stash_y + at_a * Hr, ua, Hr), ka_b = load_units4<4>(g.stash_y + at_a * Hr, ub, Hr);
+  const float sr_a = own ? g.stash_a[at_r * Hr + hw] : 0.f, sa_a = own ? g.stash_a[at_a * Hr + hw] : 0.f;
+  // (padded lanes repeat the last series' y, with a == 0: their share of vjp_t's slope is zero, not that series')
+  const float kt_r = valid ? g.stash_t[at_r * 4 + q] : 0.f, kt_a = valid ? g.stash_t[at_a * 4 + q] : 0.f;
 
   // ---- pending sums, controller, stage scalars: as in dopri5_mlp_adjoint_attempt
   if (c.phase == 0) {
@@ -543,6 +557,13 @@ __global__ __launch_bounds__(512, 2) void dopri5_mlp_adjoint_attempt_s8(MlpAdjAr
   for (int j = 0; j < 7; ++j) { wS[j] = uni(wS[j]); wE[j] = uni(wE[j]); }
   const float x_end = uni(plan.x_end);
   CDE_STAMP(2);
+  // first-same-as-last: an attempt that follows an attempt (phase 3) starts where that one started (rejected) or ended
+  // (accepted) -- unless the accepted step ended on a jump: f is then evaluated just AFTER the jump, as torchdiffeq does
+  const bool reuse = phase_in == 3 && mode == 2 && !(plan.accept && c.refresh) && !(g.dbg & 2) &&
+                     !((g.dbg & 4) && plan.accept) && !((g.dbg & 8) && !plan.accept);
+  const int src0 = reuse ? (plan.accept ? in_six : in_src0) : 0;
+  const int six = reuse ? (plan.accept ? 11 - in_six : in_six) : 5;                  // 11 - 5 = 6, 11 - 6 = 5
+  k.src0 = src0; k.six = six;
   if (blockIdx.x == 0 && tid == 0) {
     c.phase = mode == 0 ? 1 : mode == 1 ? 2 : mode == 2 ? 3 : 4;
     c.slot = sidx[0];
@@ -572,6 +593,16 @@ __global__ __launch_bounds__(512, 2) void dopri5_mlp_adjoint_attempt_s8(MlpAdjAr
 #pragma unroll
   for (int e = 0; e < 7; ++e) ra[e] = 0.f;
   float vtS = 0.f, vtE = 0.f;
+  if (reuse) {
+    const f32x4 k0a = plan.accept ? ka_a : kr_a, k0b = plan.accept ? ka_b : kr_b;
+    ry[0] = make_float4(k0a[0], k0a[1], k0a[2], k0a[3]);
+    ry[1] = make_float4(k0b[0], k0b[1], k0b[2], k0b[3]);
+    ra[0] = plan.accept ? sa_a : sr_a;
+    if (DEGREE == CDE_PATH_CUBIC) {
+      const float kt0 = plan.accept ? kt_a : kt_r;
+      vtS = __builtin_fmaf(wS[0], kt0, vtS); vtE = __builtin_fmaf(wE[0], kt0, vtE);
+    }
+  }
 #ifdef CDE_PHASE_TRACE
   unsigned long long est[4] = {0, 0, 0, 0};
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -579,7 +610,7 @@ __global__ __launch_bounds__(512, 2) void dopri5_mlp_adjoint_attempt_s8(MlpAdjAr
   CDE_STAMP(3);
 
 #pragma clang loop unroll(disable)
-  for (int i = 0; i < ns; ++i) {
+  for (int i = reuse ? 1 : 0; i < ns; ++i) {
     // the control row of stage i first: its (L2) latency runs under the select chains and the stage combination below
     int idx_i = sidx[0];
     float frac_i = sfrac[0];
@@ -618,8 +649,9 @@ __global__ __launch_bounds__(512, 2) void dopri5_mlp_adjoint_attempt_s8(MlpAdjAr
         d2X[cc] = DEGREE == CDE_PATH_CUBIC ? f[CT + cc] + 2.f * f[2 * CT + cc] * frac_i : 0.f;
     }
     const float zs[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
-    const bool stream = valid && (wS_i != 0.f || wE_i != 0.f) && !(g.dbg & 1);
-    const int64_t out_row = (int64_t)(mode <= 1 ? i : madj_slot(i)) * g.rows_per_stage + series;
+    const bool keeps = mode == 2 && (i == 0 || i == 6);            // a first / last stage: the next attempt may start from it
+    const bool stream = valid && (wS_i != 0.f || wE_i != 0.f || keeps) && !(g.dbg & 1);
+    const int64_t out_row = (int64_t)(mode <= 1 ? i : i == 6 ? six : madj_slot(i)) * g.rows_per_stage + series;
     f32x4 fa, fb;
     float va_w, kt;
     mlp_adjoint_eval_split8<ACT, DEGREE == CDE_PATH_CUBIC>(
@@ -630,6 +662,14 @@ __global__ __launch_bounds__(512, 2) void dopri5_mlp_adjoint_attempt_s8(MlpAdjAr
 #endif
         );
     if (DEGREE == CDE_PATH_CUBIC) { vtS = __builtin_fmaf(wS_i, kt, vtS); vtE = __builtin_fmaf(wE_i, kt, vtE); }
+    if (keeps) {                                                   // (the values the ring gets below)
+      const int64_t at = (int64_t)(i == 0 ? 0 : stash_of(six)) * g.B + series;
+      if (valid && writer) {
+        store_units4<4>(g.stash_y + at * Hr, ua, Hr, -fa); store_units4<4>(g.stash_y + at * Hr, ub, Hr, -fb);
+        g.stash_t[at * 4 + q] = kt;
+      }
+      if (own) g.stash_a[at * Hr + hw] = va_w;
+    }
     // reverse-time slopes dy/ds = -f, da/ds = +a^T df/dz into slot i of the ring
 #pragma unroll
     for (int kk = 0; kk < 7; ++kk) {
@@ -878,15 +918,18 @@ __global__ __launch_bounds__(256) void mlp_adjoint_small_reduce_kernel(MlpSmallA
   const float* gp = G + (int64_t)kq * gc + 16 * mt + i;
   const float* xp = X + (int64_t)kq * xc + col_load;
   const int64_t gs = a.rows_per_stage * gc, xs = a.rows_per_stage * xc;
+  // (the first and the last stage of an attempt live where the controller block says: AdjCtrl::src0 / six)
+  const int blk0 = k.mode <= 1 ? 0 : k.src0, blk5 = k.mode <= 1 ? 5 : k.six;
   float av[2][MADJ_SLOTS][4], bv[2][MADJ_SLOTS][4];
   auto request = [&](int buf, int k0) {
 #pragma unroll
     for (int s = 0; s < MADJ_SLOTS; ++s) {
       if (s >= n_slots) continue;
+      const int blk = s == 0 ? blk0 : s == 5 ? blk5 : s;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        av[buf][s][u] = gp[s * gs + (int64_t)(k0 + u) * 4 * gc];
-        bv[buf][s][u] = xp[s * xs + (int64_t)(k0 + u) * 4 * xc];
+        av[buf][s][u] = gp[blk * gs + (int64_t)(k0 + u) * 4 * gc];
+        bv[buf][s][u] = xp[blk * xs + (int64_t)(k0 + u) * 4 * xc];
       }
     }
   };
@@ -983,7 +1026,7 @@ struct MadjLayout {
   int64_t n_tiles, rows_per_stage, rows_per_slab;
   int sps, nwave, n_wg;
   bool split, split8, small;
-  size_t partial, pq, carry, image, state, G, prev, Gn, prevn, slopes, part2, part1, U, G2, G1, Z, trace, trace_all, total;
+  size_t partial, pq, carry, image, state, G, prev, Gn, prevn, slopes, stash, part2, part1, U, G2, G1, Z, trace, trace_all, total;
 };
 MadjLayout madj_layout(int64_t B, int64_t H, int64_t C) {
   using namespace cde;
@@ -1009,10 +1052,12 @@ MadjLayout madj_layout(int64_t B, int64_t H, int64_t C) {
   L.small = B <= MADJ_SMALL_MAX_ROWS && !getenv("CDE_K4AM_NO_SMALL_REDUCE");
   L.n_wg = L.split ? (int)L.n_tiles : (int)((L.n_tiles + L.nwave - 1) / L.nwave);
   int64_t sps = (B + 63) / 64;                     // (measured at 4096 series: 40 slabs 193 us per attempt, 16: 209, 6: 284;
-  L.sps = (int)(sps < 4 ? 4 : sps > MADJ_MAX_SPS ? MADJ_MAX_SPS : sps);        //  at 64 series: 4 slabs 138, 1: 146)
+  const char* sps_env = getenv("CDE_K4AM_SPS");                                  // (measurements)
+  const int64_t sps_max = sps_env && atoll(sps_env) >= 4 && atoll(sps_env) <= MADJ_MAX_SPS ? atoll(sps_env) : MADJ_MAX_SPS;
+  L.sps = (int)(sps < 4 ? 4 : sps > sps_max ? sps_max : sps);        //  at 64 series: 4 slabs 138, 1: 146)
   L.rows_per_slab = ((B + L.sps - 1) / L.sps + 15) / 16 * 16;
   L.rows_per_stage = L.rows_per_slab * L.sps;
-  const size_t rows = (size_t)MADJ_SLOTS * L.rows_per_stage;
+  const size_t rows = (size_t)MADJ_FSLOTS * L.rows_per_stage;
   L.partial = m256(2 * ADJ_CTRL_STRIDE);
   L.pq = L.partial + m256((size_t)2 * L.n_wg * ADJ_NS * sizeof(double));
   L.carry = L.pq + m256((size_t)2 * MADJ_RBLOCKS * 8 * sizeof(double));
@@ -1023,7 +1068,8 @@ MadjLayout madj_layout(int64_t B, int64_t H, int64_t C) {
   L.Gn = L.prev + m256((size_t)2 * MADJ_ELEMS * sizeof(float));        // sharded: the GLOBAL running totals and S sums
   L.prevn = L.Gn + m256((size_t)MADJ_ELEMS * sizeof(float));
   L.slopes = L.prevn + m256((size_t)2 * MADJ_ELEMS * sizeof(float));
-  L.part2 = L.slopes + m256((size_t)L.n_tiles * 7 * 4 * 64 * 16);
+  L.stash = L.slopes + m256((size_t)L.n_tiles * 7 * 4 * 64 * 16);
+  L.part2 = L.stash + m256((size_t)3 * B * (2 * H + 4) * sizeof(float));
   L.part1 = L.part2 + m256((size_t)MADJ_SLOTS * L.sps * MADJ_P2 * sizeof(float));
   L.U = L.part1 + m256((size_t)MADJ_SLOTS * L.sps * MADJ_P1 * sizeof(float));
   L.G2 = L.U + m256(rows * U_COLS * sizeof(float));
@@ -1097,10 +1143,11 @@ static int dopri5_adjoint_mlp_advance_impl(const void* coeffs, const void* knots
   g.y_init = (const float*)y_init; g.a_init = (const float*)a_init; g.a_out = (float*)a_out;
   g.slopes = (float*)(base + L.slopes);
   g.U = (float*)(base + L.U); g.G2 = (float*)(base + L.G2); g.G1 = (float*)(base + L.G1); g.Z = (float*)(base + L.Z);
+  g.stash_y = (float*)(base + L.stash); g.stash_a = g.stash_y + 3 * B * H; g.stash_t = g.stash_a + 3 * B * H;
   g.n_wg_max = L.n_wg;
-  g.dbg = 0;
+  { const char* e = getenv("CDE_K4AM_NO_FSAL"); g.dbg = !e ? 0 : e[0] == 'a' ? 4 : e[0] == 'r' ? 8 : 2; }                      // bit 1: evaluate every first stage (tests compare the two)
 #ifdef CDE_PHASE_TRACE
-  { const char* d = getenv("CDE_K4AM_DBG"); g.dbg = d ? atoi(d) : 0; }      // timing experiments (wrong gradients!)
+  { const char* d = getenv("CDE_K4AM_DBG"); g.dbg |= d ? atoi(d) & 1 : 0; }      // timing experiments (wrong gradients!)
 #endif
   g.n_pq = L.small && (!sharded || norm_kind == 1) ? MADJ_SMALL_BLOCKS : MADJ_RBLOCKS;
   g.com.s0 = s0; g.com.s1 = s1; g.com.jump_s = jump_s; g.com.n_jump = n_jump;
@@ -1120,7 +1167,7 @@ static int dopri5_adjoint_mlp_advance_impl(const void* coeffs, const void* knots
       zero_async(base + L.carry, 256, s);
       zero_async(base + L.G, L.slopes - L.G, s);
       zero_async(base + L.U, L.trace - L.U, s);
-      const int64_t rows = (int64_t)MADJ_SLOTS * L.rows_per_stage;
+      const int64_t rows = (int64_t)MADJ_FSLOTS * L.rows_per_stage;
       madj_ones_kernel<<<(unsigned)((rows + 255) / 256), 256, 0, s>>>(g.U, g.Z, rows);
       const int rc = launch_mlp_adjoint_images(W1, bias1, width, W2, bias2, C, H, (float*)(base + L.image), s);
       if (rc != CDE_OK) return rc;

@@ -50,6 +50,7 @@ __device__ __forceinline__ void mlp_grad_partial_body(const float* __restrict__ 
                                                       const unsigned char* __restrict__ gate, int gate_parity,
                                                       int slabs_per_stage, const int block_x, const int block_y) {
   constexpr int M = 4 * MT * 16, NT = NG * NV, N = NT * 16, R = GRAD_TILE_ROWS;
+  int64_t lo = (int64_t)block_x * rows_per_slab;
   if (gate) {
     // K4am (dopri5_mlp_adjoint.hip): one block of rows per stored stage, `slabs_per_stage` slabs each; the attempt launch
     // just before this one left, in the controller block, what it computed -- nothing once the interval is finished,
@@ -58,6 +59,11 @@ __device__ __forceinline__ void mlp_grad_partial_body(const float* __restrict__ 
     if (k->c.phase == 4 && k->commit == 0) return;
     const int n_slots = k->mode == 0 ? 1 : k->mode == 1 ? 2 : 6;
     if (block_x >= n_slots * slabs_per_stage) return;
+    // the rows of an attempt's first and last stage live in the block the controller names (AdjCtrl::src0 / six: the last
+    // stage of an accepted step is the first stage of the next one and is not evaluated again)
+    const int slot = block_x / slabs_per_stage;
+    const int blk = k->mode <= 1 ? slot : slot == 0 ? k->src0 : slot == 5 ? k->six : slot;
+    lo = ((int64_t)blk * slabs_per_stage + (block_x - slot * slabs_per_stage)) * rows_per_slab;
   }
   constexpr int TILE = R * (M + N);                          // floats per ring buffer: [G rows | X rows]
   // wave-wide loads (256 floats each) per tile and wave; every wave issues the same number (idle slots load into a
@@ -71,7 +77,6 @@ __device__ __forceinline__ void mlp_grad_partial_body(const float* __restrict__ 
   const int m0 = block_y * M;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
-  const int64_t lo = (int64_t)block_x * rows_per_slab;
   int64_t hi = lo + rows_per_slab;
   hi = hi < rows ? hi : rows;
   f32x4 acc[MT][NT];
@@ -195,17 +200,19 @@ __global__ __launch_bounds__(256, 2) void mlp_grad_partial_kernel(const float* _
                                     (int)blockIdx.x, (int)blockIdx.y);
 }
 
-// K4am: both layers' factor rows of one attempt in ONE launch (blockIdx.y = 0: [dW2 | db2] = G2^T U on the 256 x 132 tiles,
-// 1: [dW1 | db1] = G1^T Z on the 128 x 36 ones) -- a launch boundary less per attempted step
+// K4am: both layers' factor rows of one attempt in ONE launch (blockIdx.y = 0, 1: the two row halves of [dW2 | db2] = G2^T U,
+// 2: [dW1 | db1] = G1^T Z on the 128 x 36 tiles) -- a launch boundary less per attempted step
 __global__ __launch_bounds__(256, 2) void mlp_grad_partial_pair_kernel(const float* __restrict__ G2, const float* __restrict__ U,
                                                                        const float* __restrict__ G1, const float* __restrict__ Z,
                                                                        int64_t rows, int64_t rows_per_slab,
                                                                        float* __restrict__ part2, float* __restrict__ part1,
                                                                        const unsigned char* __restrict__ gate, int gate_parity,
                                                                        int slabs_per_stage) {
-  if (blockIdx.y == 0)
-    mlp_grad_partial_body<4, 4, 2>(G2, U, rows, rows_per_slab, 132, part2, 256, gate, gate_parity, slabs_per_stage,
-                                   (int)blockIdx.x, 0);
+  // (layer 2 in two halves of 128 rows: two workgroups per CU instead of one -- a single wave per SIMD overlaps neither its
+  //  LDS reads nor its partial stores with its own MFMAs, the second workgroup's waves run in exactly those gaps)
+  if (blockIdx.y < 2)
+    mlp_grad_partial_body<2, 4, 2>(G2, U, rows, rows_per_slab, 132, part2, 256, gate, gate_parity, slabs_per_stage,
+                                   (int)blockIdx.x, (int)blockIdx.y);
   else
     mlp_grad_partial_body<2, 2, 1>(G1, Z, rows, rows_per_slab, 36, part1, 128, gate, gate_parity, slabs_per_stage,
                                    (int)blockIdx.x, 0);
@@ -241,9 +248,9 @@ int launch_wide_grad_reduce(const float* G, const float* Z, int64_t rows, int M,
 int launch_mlp_adjoint_factor_reduce(const float* G2, const float* U, const float* G1, const float* Z, int64_t rows_per_stage,
                                      int sps, int64_t rows_per_slab, float* part2, float* part1, const unsigned char* ctrl,
                                      int parity, hipStream_t s) {
-  const int64_t rows = 6 * rows_per_stage;
-  const dim3 grid((unsigned)(6 * sps), 2);
-  const size_t a = grad_partial_lds_bytes<4, 4, 2>(), b = grad_partial_lds_bytes<2, 2, 1>();
+  const int64_t rows = 7 * rows_per_stage;                     // (MADJ_FSLOTS blocks of rows; 6 of them are read per attempt)
+  const dim3 grid((unsigned)(6 * sps), 3);
+  const size_t a = grad_partial_lds_bytes<2, 4, 2>(), b = grad_partial_lds_bytes<2, 2, 1>();
   const size_t lds_bytes = a > b ? a : b;
   (void)hipFuncSetAttribute((const void*)mlp_grad_partial_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds_bytes);
