@@ -38,8 +38,10 @@ struct AdjCtrl {
   // -- factor-row block and slope stash `src0` (0: evaluated by that launch; 5 / 6: the last stage of the step accepted
   // before it) -- and where its LAST stage went (`six`: 5 or 6, never `src0`).  The other forms set (0, 5): every stage
   // evaluated, the last one in block 5.
-  int32_t src0, six;
+  int32_t src0, six;            // (six & 15: the block; six & ADJ_FRESH0: this launch evaluated its first stage -- its factor
+                                //  rows and its stage image are new; a separate word would cost the attempt kernels a register)
 };
+constexpr int ADJ_FRESH0 = 16;
 static_assert(sizeof(AdjCtrl) <= ADJ_CTRL_STRIDE, "controller block outgrew its slot");
 
 struct AdjCommon {

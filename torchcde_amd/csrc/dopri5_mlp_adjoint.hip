@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
   if (blockIdx.x == 0 && tid == 0) {                               // the controller block for the next launch / the R kernel
     c.phase = mode == 0 ? 1 : mode == 1 ? 2 : mode == 2 ? 3 : 4;
     c.slot = sidx[0];                                              // search hint for the next launch's stage times
-    k.src0 = 0; k.six = 5;                                         // every stage evaluated here, the last one in block 5
+    k.src0 = 0; k.six = 5 | ADJ_FRESH0;                            // every stage evaluated here, the last one in block 5
     *reinterpret_cast<AdjCtrl*>(g.ctrl + p2 * ADJ_CTRL_STRIDE) = k;
   }
 
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(512, 2) void dopri5_mlp_adjoint_attempt_s8(MlpAdjAr
   const float ak0 = own ? ac0[sc * Hr + hw] : 0.f, ak1 = own ? (fresh ? ac0 : Sp + 3 * BH)[sc * Hr + hw] : 0.f;
   // ... and both candidates of the FIRST STAGE's slopes (first-same-as-last): the pending attempt's own first stage if it is
   // rejected (same start state, same stage time: torchdiffeq keeps f0), its last stage if it is accepted (f1 becomes f0)
-  const int in_src0 = uni((int)k.src0), in_six = uni((int)k.six);
+  const int in_src0 = uni((int)k.src0), in_six = uni((int)k.six) & 15;
   auto stash_of = [](int blk) { return blk == 0 ? 0 : blk - 4; };  // blocks 0, 5, 6 -> the stash's three planes
   const int64_t at_r = (int64_t)stash_of(in_src0) * g.B + sc, at_a = (int64_t)stash_of(fresh ? 0 : in_six) * g.B + sc;
   const f32x4 kr_a = load_units4<4>(g.stash_y + at_r * Hr, ua, Hr), kr_b = load_units4<4>(g.stash_y + at_r * Hr, ub, Hr);
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(512, 2) void dopri5_mlp_adjoint_attempt_s8(MlpAdjAr
                      !((g.dbg & 4) && plan.accept) && !((g.dbg & 8) && !plan.accept);
   const int src0 = reuse ? (plan.accept ? in_six : in_src0) : 0;
   const int six = reuse ? (plan.accept ? 11 - in_six : in_six) : 5;                  // 11 - 5 = 6, 11 - 6 = 5
-  k.src0 = src0; k.six = six;
+  k.src0 = src0; k.six = six | (reuse ? 0 : ADJ_FRESH0);
   if (blockIdx.x == 0 && tid == 0) {
     c.phase = mode == 0 ? 1 : mode == 1 ? 2 : mode == 2 ? 3 : 4;
     c.slot = sidx[0];
@@ -772,6 +772,8 @@ struct MlpReduceArgs {
   unsigned char* ctrl;
   const float* part2; const float* part1;   // slab partials [slot][sps][M][N + 1]
   int sps;
+  float* kst;               // [3][MADJ_ELEMS]: the stage image K_s of a first / last stage (blocks 0, 5, 6), kept because the
+                            // next attempt's first stage is one of them (AdjCtrl::src0) and is not reduced again
   float* G;                 // [MADJ_ELEMS] running totals (layer 2 block, then layer 1 block): what the caller gets back
   float* prevS;             // [2][MADJ_ELEMS]: the S sums of a launch, kept for the commit one launch later
   float* Gn;                // sharded: the running totals of the GLOBAL batch (the norm needs those); else nullptr
@@ -800,14 +802,20 @@ __global__ __launch_bounds__(256) void mlp_adjoint_reduce_kernel(MlpReduceArgs r
   if (stage != 2) {
     float sum = 0.f;
     if (e < MADJ_ELEMS && sl < n_slots) {
-      const float* base = (layer2 ? r.part2 + e : r.part1 + (e - MADJ_P2)) + (int64_t)sl * r.sps * (layer2 ? MADJ_P2 : MADJ_P1);
-      const int64_t stride = layer2 ? MADJ_P2 : MADJ_P1;
-      for (int b0 = 0; b0 < r.sps; b0 += 8) {
-        float v[8];
+      auto plane = [](int blk) { return blk == 0 ? 0 : blk - 4; };
+      if (k.mode == 2 && sl == 0 && !(k.six & ADJ_FRESH0)) sum = r.kst[(int64_t)plane(k.src0) * MADJ_ELEMS + e];
+      else {
+        const float* base = (layer2 ? r.part2 + e : r.part1 + (e - MADJ_P2)) + (int64_t)sl * r.sps * (layer2 ? MADJ_P2 : MADJ_P1);
+        const int64_t stride = layer2 ? MADJ_P2 : MADJ_P1;
+        for (int b0 = 0; b0 < r.sps; b0 += 8) {
+          float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = b0 + u < r.sps ? base[(int64_t)(b0 + u) * stride] : 0.f;
+          for (int u = 0; u < 8; ++u) v[u] = b0 + u < r.sps ? base[(int64_t)(b0 + u) * stride] : 0.f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) sum += v[u];
+          for (int u = 0; u < 8; ++u) sum += v[u];
+        }
+        if (k.mode == 2 && sl == 0) r.kst[e] = sum;
+        if (k.mode == 2 && sl == 5) r.kst[(int64_t)plane(k.six & 15) * MADJ_ELEMS + e] = sum;
       }
     }
     ks[sl][el] = sum;
@@ -919,7 +927,7 @@ __global__ __launch_bounds__(256) void mlp_adjoint_small_reduce_kernel(MlpSmallA
   const float* xp = X + (int64_t)kq * xc + col_load;
   const int64_t gs = a.rows_per_stage * gc, xs = a.rows_per_stage * xc;
   // (the first and the last stage of an attempt live where the controller block says: AdjCtrl::src0 / six)
-  const int blk0 = k.mode <= 1 ? 0 : k.src0, blk5 = k.mode <= 1 ? 5 : k.six;
+  const int blk0 = k.mode <= 1 ? 0 : k.src0, blk5 = k.mode <= 1 ? 5 : (k.six & 15);
   float av[2][MADJ_SLOTS][4], bv[2][MADJ_SLOTS][4];
   auto request = [&](int buf, int k0) {
 #pragma unroll
@@ -1026,7 +1034,7 @@ struct MadjLayout {
   int64_t n_tiles, rows_per_stage, rows_per_slab;
   int sps, nwave, n_wg;
   bool split, split8, small;
-  size_t partial, pq, carry, image, state, G, prev, Gn, prevn, slopes, stash, part2, part1, U, G2, G1, Z, trace, trace_all, total;
+  size_t partial, pq, carry, image, state, G, prev, Gn, prevn, slopes, stash, kst, part2, part1, U, G2, G1, Z, trace, trace_all, total;
 };
 MadjLayout madj_layout(int64_t B, int64_t H, int64_t C) {
   using namespace cde;
@@ -1069,7 +1077,8 @@ MadjLayout madj_layout(int64_t B, int64_t H, int64_t C) {
   L.prevn = L.Gn + m256((size_t)MADJ_ELEMS * sizeof(float));
   L.slopes = L.prevn + m256((size_t)2 * MADJ_ELEMS * sizeof(float));
   L.stash = L.slopes + m256((size_t)L.n_tiles * 7 * 4 * 64 * 16);
-  L.part2 = L.stash + m256((size_t)3 * B * (2 * H + 4) * sizeof(float));
+  L.kst = L.stash + m256((size_t)3 * B * (2 * H + 4) * sizeof(float));
+  L.part2 = L.kst + m256((size_t)3 * MADJ_ELEMS * sizeof(float));
   L.part1 = L.part2 + m256((size_t)MADJ_SLOTS * L.sps * MADJ_P2 * sizeof(float));
   L.U = L.part1 + m256((size_t)MADJ_SLOTS * L.sps * MADJ_P1 * sizeof(float));
   L.G2 = L.U + m256(rows * U_COLS * sizeof(float));
@@ -1098,6 +1107,7 @@ namespace {
 cde::MlpReduceArgs madj_reduce_args(unsigned char* base, const MadjLayout& L, double rtol, double atol, bool sharded) {
   cde::MlpReduceArgs q;
   q.ctrl = base; q.part2 = (const float*)(base + L.part2); q.part1 = (const float*)(base + L.part1); q.sps = L.sps;
+  q.kst = (float*)(base + L.kst);
   q.G = (float*)(base + L.G); q.prevS = (float*)(base + L.prev);
   q.Gn = sharded ? (float*)(base + L.Gn) : nullptr; q.prevSn = sharded ? (float*)(base + L.prevn) : nullptr;
   q.pq = (double*)(base + L.pq);

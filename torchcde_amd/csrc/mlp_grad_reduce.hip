@@ -62,8 +62,8 @@ __device__ __forceinline__ void mlp_grad_partial_body(const float* __restrict__ 
     // the rows of an attempt's first and last stage live in the block the controller names (AdjCtrl::src0 / six: the last
     // stage of an accepted step is the first stage of the next one and is not evaluated again)
     const int slot = block_x / slabs_per_stage;
-    if (k->mode == 2 && slot == 0 && !k->fresh0) return;        // its image was formed when that stage was evaluated (R kernel: kst)
-    const int blk = k->mode <= 1 ? slot : slot == 0 ? k->src0 : slot == 5 ? k->six : slot;
+    if (k->mode == 2 && slot == 0 && !(k->six & ADJ_FRESH0)) return;        // its image was formed when that stage was evaluated (R kernel: kst)
+    const int blk = k->mode <= 1 ? slot : slot == 0 ? k->src0 : slot == 5 ? (k->six & 15) : slot;
     lo = ((int64_t)blk * slabs_per_stage + (block_x - slot * slabs_per_stage)) * rows_per_slab;
   }
   constexpr int TILE = R * (M + N);                          // floats per ring buffer: [G rows | X rows]
