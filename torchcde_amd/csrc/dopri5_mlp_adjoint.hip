@@ -163,10 +163,17 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
   const float x_end = uni(plan.x_end);
   CDE_STAMP(2);
 
+  // First same as last (one wave per tile; the shared-tile form below evaluates every stage): an attempt that follows an
+  // attempt starts where that one started (rejected) or ended (accepted, not on a jump) -- the slopes of that stage are in the
+  // lane's ring already (slot 0, or slot 6: copied to slot 0), its factor rows in the block the controller names.
+  const int in_src0 = uni((int)k.src0), in_six = uni((int)k.six) & 15;
+  const bool reuse = !SPLIT && phase_in == 3 && mode == 2 && !(plan.accept && c.refresh) && !(g.dbg & 2);
+  const int src0 = reuse ? (plan.accept ? in_six : in_src0) : 0;
+  const int six = reuse ? (plan.accept ? 11 - in_six : in_six) : 5;
   if (blockIdx.x == 0 && tid == 0) {                               // the controller block for the next launch / the R kernel
     c.phase = mode == 0 ? 1 : mode == 1 ? 2 : mode == 2 ? 3 : 4;
     c.slot = sidx[0];                                              // search hint for the next launch's stage times
-    k.src0 = 0; k.six = 5 | ADJ_FRESH0;                            // every stage evaluated here, the last one in block 5
+    k.src0 = src0; k.six = six | (reuse ? 0 : ADJ_FRESH0);
     *reinterpret_cast<AdjCtrl*>(g.ctrl + p2 * ADJ_CTRL_STRIDE) = k;
   }
 
@@ -233,8 +240,9 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
       }
       const float zs[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
       const float as[8] = {sa[0], sa[1], sa[2], sa[3], sb[0], sb[1], sb[2], sb[3]};
-      const bool stream = valid && (wS_i != 0.f || wE_i != 0.f) && !(g.dbg & 1);
-      const int64_t out_row = (int64_t)(mode <= 1 ? i : madj_slot(i)) * g.rows_per_stage + series;
+      const bool keeps = !SPLIT && mode == 2 && (i == 0 || i == 6);  // a first / last stage: the next attempt may start from it
+      const bool stream = valid && (wS_i != 0.f || wE_i != 0.f || keeps) && !(g.dbg & 1);
+      const int64_t out_row = (int64_t)(mode <= 1 ? i : i == 6 ? six : madj_slot(i)) * g.rows_per_stage + series;
       float kt;
       {
         mlp_adjoint_eval<ACT, CT, DEGREE == CDE_PATH_CUBIC, SPLIT>(
@@ -247,13 +255,24 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
             );
       }
       if (DEGREE == CDE_PATH_CUBIC) { vtS = __builtin_fmaf(wS_i, kt, vtS); vtE = __builtin_fmaf(wE_i, kt, vtE); }
+      if (keeps && valid && DEGREE == CDE_PATH_CUBIC) g.stash_t[((int64_t)(i == 0 ? 0 : 1) * g.B + series) * 4 + q] = kt;
     };
 
     if constexpr (!SPLIT) {
+      if (reuse) {
+        // the first stage's slopes: slot 0 of the ring (after an accepted step: that step's last stage, slot 6)
+        float kt0 = valid ? g.stash_t[((int64_t)(plan.accept ? 1 : 0) * g.B + sc) * 4 + q] : 0.f;
+        if (plan.accept) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) ring_put(0, v, ring_get(6, v));
+          if (valid && DEGREE == CDE_PATH_CUBIC) g.stash_t[((int64_t)0 * g.B + series) * 4 + q] = kt0;
+        }
+        if (DEGREE == CDE_PATH_CUBIC) { vtS = __builtin_fmaf(wS[0], kt0, vtS); vtE = __builtin_fmaf(wE[0], kt0, vtE); }
+      }
       // one wave per tile: fully unrolled (the slope ring lives in global memory, every index is static)
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
-        if (i >= ns) continue;
+        if (i >= ns || (i == 0 && reuse)) continue;
         f32x4 za = y0a, zb = y0b, sa = a0a, sb = a0b;
         if (i > 0) {
           f32x4 ia = {0.f, 0.f, 0.f, 0.f}, ib = ia, ja = ia, jb = ia;
