@@ -474,8 +474,11 @@ int cde_dopri5_adjoint_apply_state_sums(void* workspace, size_t workspace_bytes,
  *           unit, columns 0..H-1 = dL/dW1, column 32 = dL/db1.
  * cde_dopri5_adjoint_mlp_trace_offset(which = 0 accepted steps | 1 every attempt) as for K4a.
  * Workspace footprint: the attempt streams the gradient factors of its six weighted stages, (132 + 256 + 128 + 36) floats
- * per series and stage = 13.2 KB per series (434 MB at 32768 series), plus 6 x 40 slab partials of 37,248 floats (36 MB);
- * the factor rows are zeroed once per backward pass (first_interval), not per attempt.
+ * per series and stage, into SEVEN blocks of rows (the last stage alternates between two: an accepted step's last stage is
+ * the next step's first -- torchdiffeq's first-same-as-last -- and is neither evaluated nor reduced again) = 15.5 KB per
+ * series (507 MB at 32768 series), plus 6 x 40 slab partials of 37,248 floats (36 MB), three kept stage images and
+ * 3 x (2 H + 4) floats per series of kept slopes; the factor rows are zeroed once per backward pass (first_interval), not
+ * per attempt.  CDE_K4AM_NO_FSAL=1 in the environment evaluates every first stage (tests compare the two: identical bits).
  * ------------------------------------------------------------------------------------------- */
 size_t cde_dopri5_adjoint_mlp_workspace_bytes(int64_t B, int64_t C, int64_t H);
 size_t cde_dopri5_adjoint_mlp_trace_offset(int64_t B, int64_t C, int64_t H, int which);
