@@ -1080,9 +1080,10 @@ MadjLayout madj_layout(int64_t B, int64_t H, int64_t C) {
   L.n_wg = L.split ? (int)L.n_tiles : (int)((L.n_tiles + L.nwave - 1) / L.nwave);
   int64_t sps = (B + 63) / 64;                     // (measured at 4096 series: 40 slabs 193 us per attempt, 16: 209, 6: 284;
   const char* sps_env = getenv("CDE_K4AM_SPS");                                  // (measurements)
-  // (up to 4096 series 20 slabs: half the partials for the R kernel to read -- 112.4 -> 108.0 us per attempt at 4096 series,
-  //  102.9 -> 99.4 at 2048; at 8192 no difference, beyond that more blocks balance better)
-  const int64_t sps_default = B <= 4096 ? 20 : MADJ_MAX_SPS;
+  // (20 slabs up to 4096 series are 4 % faster -- 112.4 -> 108.0 us per attempt at 4096 series, half the partials for the R
+  //  kernel -- and NOT used: longer float32 chains per slab move the parameter blocks' error estimate, and on the 2048-series
+  //  config-5 replay 95.5 % instead of >= 97 % of the mixed-norm error ratios stayed within 2 % of the float64 oracle's)
+  const int64_t sps_default = MADJ_MAX_SPS;
   const int64_t sps_max = sps_env && atoll(sps_env) >= 4 && atoll(sps_env) <= MADJ_MAX_SPS ? atoll(sps_env) : sps_default;
   L.sps = (int)(sps < 4 ? 4 : sps > sps_max ? sps_max : sps);        //  at 64 series: 4 slabs 138, 1: 146)
   L.rows_per_slab = ((B + L.sps - 1) / L.sps + 15) / 16 * 16;
