@@ -163,11 +163,12 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
   const float x_end = uni(plan.x_end);
   CDE_STAMP(2);
 
-  // First same as last (one wave per tile; the shared-tile form below evaluates every stage): an attempt that follows an
-  // attempt starts where that one started (rejected) or ended (accepted, not on a jump) -- the slopes of that stage are in the
-  // lane's ring already (slot 0, or slot 6: copied to slot 0), its factor rows in the block the controller names.
+  // First same as last: an attempt that follows an attempt starts where that one started (rejected) or ended (accepted, not
+  // on a jump).  One wave per tile: the slopes of that stage are in the lane's ring in memory already (slot 0, or slot 6:
+  // copied to slot 0); waves sharing a tile (ring in registers): from the three-plane stash of the eight-wave kernel.  The
+  // stage's factor rows are in the block the controller names.
   const int in_src0 = uni((int)k.src0), in_six = uni((int)k.six) & 15;
-  const bool reuse = !SPLIT && phase_in == 3 && mode == 2 && !(plan.accept && c.refresh) && !(g.dbg & 2);
+  const bool reuse = phase_in == 3 && mode == 2 && !(plan.accept && c.refresh) && !(g.dbg & 2);
   const int src0 = reuse ? (plan.accept ? in_six : in_src0) : 0;
   const int six = reuse ? (plan.accept ? 11 - in_six : in_six) : 5;
   if (blockIdx.x == 0 && tid == 0) {                               // the controller block for the next launch / the R kernel
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
       }
       const float zs[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
       const float as[8] = {sa[0], sa[1], sa[2], sa[3], sb[0], sb[1], sb[2], sb[3]};
-      const bool keeps = !SPLIT && mode == 2 && (i == 0 || i == 6);  // a first / last stage: the next attempt may start from it
+      const bool keeps = mode == 2 && (i == 0 || i == 6);            // a first / last stage: the next attempt may start from it
       const bool stream = valid && (wS_i != 0.f || wE_i != 0.f || keeps) && !(g.dbg & 1);
       const int64_t out_row = (int64_t)(mode <= 1 ? i : i == 6 ? six : madj_slot(i)) * g.rows_per_stage + series;
       float kt;
@@ -255,7 +256,14 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
             );
       }
       if (DEGREE == CDE_PATH_CUBIC) { vtS = __builtin_fmaf(wS_i, kt, vtS); vtE = __builtin_fmaf(wE_i, kt, vtE); }
-      if (keeps && valid && DEGREE == CDE_PATH_CUBIC) g.stash_t[((int64_t)(i == 0 ? 0 : 1) * g.B + series) * 4 + q] = kt;
+      if constexpr (!SPLIT) {
+        if (keeps && valid && DEGREE == CDE_PATH_CUBIC) g.stash_t[((int64_t)(i == 0 ? 0 : 1) * g.B + series) * 4 + q] = kt;
+      } else if (keeps && valid && writer) {                       // planes 0 / 1 / 2 <-> blocks 0 / 5 / 6
+        const int64_t at = (int64_t)(i == 0 ? 0 : six - 4) * g.B + series;
+        store_units4<4>(g.stash_y + at * Hr, ua, Hr, -fa); store_units4<4>(g.stash_y + at * Hr, ub, Hr, -fb);
+        store_units4<4>(g.stash_a + at * Hr, ua, Hr, va); store_units4<4>(g.stash_a + at * Hr, ub, Hr, vb);
+        g.stash_t[at * 4 + q] = kt;
+      }
     };
 
     if constexpr (!SPLIT) {
@@ -305,8 +313,21 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
       // evaluations, and the unit-group loop inside the four-wave evaluation is a real loop as well.
 #pragma unroll
       for (int e = 0; e < 28; ++e) rreg[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (reuse) {
+        const int64_t at = (int64_t)(src0 == 0 ? 0 : src0 - 4) * g.B + sc;
+        const f32x4 k0 = load_units4<4>(g.stash_y + at * Hr, ua, Hr), k1 = load_units4<4>(g.stash_y + at * Hr, ub, Hr);
+        f32x4 k2 = load_units4<4>(g.stash_a + at * Hr, ua, Hr), k3 = load_units4<4>(g.stash_a + at * Hr, ub, Hr);
+        if (!valid) { k2 = f32x4{0.f, 0.f, 0.f, 0.f}; k3 = k2; }  // (padded lanes: a == 0, so are its slope and vjp_t's)
+        rreg[0] = make_float4(k0[0], k0[1], k0[2], k0[3]); rreg[1] = make_float4(k1[0], k1[1], k1[2], k1[3]);
+        rreg[2] = make_float4(k2[0], k2[1], k2[2], k2[3]); rreg[3] = make_float4(k3[0], k3[1], k3[2], k3[3]);
+        if (DEGREE == CDE_PATH_CUBIC) {
+          const float kt0 = valid ? g.stash_t[at * 4 + q] : 0.f;
+          vtS = __builtin_fmaf(wS[0], kt0, vtS); vtE = __builtin_fmaf(wE[0], kt0, vtE);
+        }
+        row_next = load_row<DEGREE, CT>(g.coeffs, sc, g.n_intervals, sidx[1], Cr);      // the first evaluated stage is stage 1
+      }
 #pragma clang loop unroll(disable)
-      for (int i = 0; i < ns; ++i) {
+      for (int i = reuse ? 1 : 0; i < ns; ++i) {
         int idx_i = sidx[0], idx_n = sidx[1];
         float frac_i = sfrac[0], wS_i = wS[0], wE_i = wE[0];
         float wj[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
