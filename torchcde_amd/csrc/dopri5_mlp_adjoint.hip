@@ -22,7 +22,12 @@
 //     `mlp_adjoint_reduce_kernel` -- the R kernel of this family -- forms S = sum_s wS[s] K_s and E = sum_s wE[s] K_s per
 //     element (adj_stage_weights), owns the running totals, commits the accepted attempt's increment and leaves the
 //     per-block sums of (E / tol)^2 of the four parameter tensors for the next launch's controller.
-// Four launches per attempted step (attempt, factor reduction of each layer, R), no host round trip.
+//   * FIRST SAME AS LAST (round 4), as torchdiffeq keeps f0 after a rejection and passes f1 on after an accepted step: an
+//     attempt that follows an attempt does not evaluate its first stage -- its slopes are kept (ring slot / stash plane), its
+//     factor rows stay where they were written (seven blocks of rows: the last stage alternates between blocks 5 and 6,
+//     AdjCtrl::src0 / six say which is which) and its image is kept by the R kernel.  Same inputs bit for bit, so traces and
+//     gradients are identical with CDE_K4AM_NO_FSAL=1 (tests).
+// Three launches per attempted step (attempt, factor reduction of both layers, R; up to 128 series: two), no host round trip.
 #include "cde_dopri_adj.h"
 #include "cde_mlp_adj.h"
 
