@@ -412,8 +412,13 @@ int cde_dopri5_advance(const void* coeffs, const void* knots, int64_t n_interval
  * calls cde_dopri5_adjoint_advance with first_launch = 0, n, 2n, ... until the cde_dopri5_status at the head of the
  * workspace (block index total_launches & 1, the two blocks cde_dopri5_adjoint_status_stride() bytes apart) reports
  * phase == 4; a_out (B, H) then holds dL/dz(t_{i-1}) before the incoming gradient of that output time is added.
- * first_interval != 0 zeroes the running parameter gradients and vjp_t; after the last interval
+ * first_interval bit 0 zeroes the running parameter gradients and vjp_t; after the last interval
  * cde_dopri5_adjoint_finish writes grad_W (H*C, H) and grad_b (H*C).
+ * Output times that require a gradient (torchdiffeq's time_vjps, reference test/test_tricks.py:21-49): vjp_t is one double
+ * at byte cde_dopri5_adjoint_carry_offset() of the workspace, carried from interval to interval.  torchdiffeq starts interval
+ * i at vjp_t - f(t_i, y_i) . dL/dy_i: the caller subtracts that (float32 arithmetic) before the first call of every
+ * interval -- with first_interval bit 1 set on the first one, which then keeps the caller's value instead of zeroing it --
+ * and reads dL/dt_0 there after the last interval (dL/dt_i = f(t_i, y_i) . dL/dy_i for i >= 1).
  * The accepted steps of the CURRENT interval are traced like K4's, at cde_dopri5_adjoint_trace_offset(...); EVERY decided
  * attempt (at most 16384), rejected ones included, at cde_dopri5_adjoint_attempt_trace_offset(...) as 5 doubles
  * (t0, t1, clipped onto a jump, accepted, error ratio) -- the tests replay them through the oracle.
@@ -428,6 +433,7 @@ size_t cde_dopri5_adjoint_workspace_bytes(int64_t B, int64_t C, int64_t H);
 size_t cde_dopri5_adjoint_trace_offset(int64_t B, int64_t C, int64_t H);
 size_t cde_dopri5_adjoint_attempt_trace_offset(int64_t B, int64_t C, int64_t H);
 size_t cde_dopri5_adjoint_status_stride(void);
+size_t cde_dopri5_adjoint_carry_offset(int64_t B, int64_t C, int64_t H);
 int cde_dopri5_adjoint_advance(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
                                const void* bias, int act, const void* y_init, const void* a_init, double s0, double s1,
                                const double* jump_s, int64_t n_jump, double rtol, double atol, double safety,

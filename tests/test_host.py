@@ -787,14 +787,15 @@ def test_dispatch_table_is_exhaustively_consistent():
                     if f["wants_grad"]:
                         assert f["adjoint"] and f["adjoint_method_ok"] and f["adjoint_options_ok"] and params != "foreign"
                     if c.path == "dopri5_adjoint":
-                        assert f["mfma_shape"] and not f["wants_t"] and not f["wants_control"]
+                        # (output-time gradients: K4a carries vjp_t; not with one controller across shards)
+                        assert f["mfma_shape"] and not f["wants_control"] and not (f["wants_t"] and f["shared"])
                     if c.path == "mlp_dopri5_adjoint":
                         assert not f["wants_t"] and not f["wants_control"]
                     if kind == "mlp2":
                         assert not f["variant_generic"]
                         assert not f["wants_t"] and (not f["wants_control"] or (f["narrow_control"] and method == "rk4"))
                     if kind == "affine" and (f["wants_t"] or f["wants_control"]):
-                        assert f["mfma_shape"] and method == "rk4"
+                        assert f["mfma_shape"] and (method == "rk4" or not f["wants_control"])
     assert n > 100000 and set(seen) == set(D.FUSED_PATHS) | {D.STEPWISE}       # every path is reachable
 
     def ask(**kw):
@@ -814,9 +815,11 @@ def test_dispatch_table_is_exhaustively_consistent():
     assert ask(shared=True).path == "dopri5_adjoint"                            # one controller over the shards
     assert ask(kind="mlp2", mfma_shape=False, shared=True).path == "mlp_dopri5_adjoint"    # ... for the examples' model too
     assert ask(method="rk4", wants_control=True, params="own").path == "rk4"    # README.md:251-270
+    assert ask(wants_t=True).path == "dopri5_adjoint"                           # output-time gradients: K4a carries vjp_t
     for kw, word in ((dict(kind=None), "recognised"), (dict(method="midpoint"), "midpoint"),
                      (dict(adjoint=False), "adjoint=False"), (dict(options_ok=False), "options"),
-                     (dict(mfma_shape=False), "32 x 8"), (dict(wants_t=True), "time"),
+                     (dict(mfma_shape=False), "32 x 8"), (dict(wants_t=True, shared=True), "time"),
+                     (dict(wants_control=True, params="own"), "control"),
                      (dict(kind="mlp2", mfma_shape=False, method="rk4", wants_control=True, narrow_control=False), "8 channels"),
                      (dict(t_ok=False), "increasing"), (dict(params="foreign"), "adjoint_params"),
                      (dict(prod=True), "prod"), (dict(tiles_ok=False, mfma_shape=False), "tiles")):

@@ -531,6 +531,7 @@ class _Dopri5Plan:
             raise NotImplementedError("torchcde_amd: unsupported dopri5 options %s" % sorted(options))
         coeffs, knots, _ = path._native_inputs()
         self.coeffs, self.knots = coeffs, knots
+        self.path = path
         self.n_intervals, self.degree, self.act = path._n_intervals(), path._degree, field.act
         self.hidden = field.hidden if field.kind == "mlp2" else None      # two-layer field: its first Linear
         self.batch, self.B, self.H, self.C = batch, coeffs.size(0), H, C
@@ -614,10 +615,13 @@ class _Dopri5Plan:
             last_dopri5_stats["steps"] = workspace[off:off + 24 * n].view(torch.float64).view(n, 3).cpu()
         return out
 
-    def run_adjoint(self, z_saved, grad_out, weight, bias):
+    def run_adjoint(self, z_saved, grad_out, weight, bias, want_t=False):
         """K4a: torchdiffeq's odeint_adjoint backward for the adaptive solve -- default mixed norm (or "seminorm"), dense
         output at the interval ends -- one attempt kernel + one reduction kernel per attempted step
-        (csrc/dopri5_adjoint.hip), output intervals from the last to the first."""
+        (csrc/dopri5_adjoint.hip), output intervals from the last to the first.
+        want_t: the output times require a gradient (torchdiffeq's time_vjps): dL/dt_i = f(t_i, z_i) . dL/dz_i for i >= 1
+        (one field evaluation per output time, here); vjp_t -- which K4a integrates and measures in its error norm anyway --
+        starts every interval at its carried value minus that term, and is dL/dt_0 after the last one."""
         lib = _lib.load()
         B, H, C, dev = self.B, self.H, self.C, self.device
         z_saved = z_saved.detach().reshape(B, self.n_out, H)
@@ -628,7 +632,7 @@ class _Dopri5Plan:
         grad_w, grad_b = flat[:n_w].view(H * C, H), flat[n_w:]
         a = grad_out[:, -1].contiguous()
         if self.n_out == 1:
-            return a, grad_w, grad_b
+            return (a, grad_w, grad_b, torch.zeros(1, dtype=torch.float32, device=dev)) if want_t else (a, grad_w, grad_b)
         nbytes = lib.cde_dopri5_adjoint_workspace_bytes(B, C, H)
         workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         workspace[:_WORKSPACE_HEAD].zero_()     # controller blocks + partial sums: defined before the first launch reads them
@@ -644,9 +648,24 @@ class _Dopri5Plan:
         stream = _lib.stream_ptr(dev)
         stats = dict(n_accept=0, n_reject=0, launches=0)
         steps, attempts = [], []
+        time_terms = [None] * self.n_out
+        carry = None
+        if want_t:
+            off = lib.cde_dopri5_adjoint_carry_offset(B, C, H)
+            carry = workspace[off:off + 8].view(torch.float64)        # vjp_t, carried across the intervals on the device
+            carry.zero_()
         for i in range(self.n_out - 1, 0, -1):
             y = z_saved[:, i].contiguous()
             s0, s1 = -float(self.t_host[i]), -float(self.t_host[i - 1])
+            if want_t:
+                # torchdiffeq: func_eval = func(t[i], y[i]); dLd_cur_t = func_eval . grad_y[i]; aug_state[0] -= dLd_cur_t
+                pre = torch.nn.functional.linear(y, w, b)
+                if self.act == _lib.ACT_TANH:
+                    pre = pre.tanh()
+                dX = self.path.derivative(self.t_out[i]).reshape(B, C)
+                f_i = (pre.view(B, H, C) * dX.unsqueeze(1)).sum(-1)
+                time_terms[i] = (f_i * grad_out[:, i]).sum()
+                carry.copy_((carry.to(torch.float32) - time_terms[i]).to(torch.float64))
             launched = 0
             while True:
                 def advance(first, count, sums_ptr, global_batch):
@@ -655,8 +674,8 @@ class _Dopri5Plan:
                         _lib.ptr(b), self.act, _lib.ptr(y), _lib.ptr(a), s0, s1, _lib.ptr(self.jump_s), self.n_jump_s,
                         self.adjoint_rtol, self.adjoint_atol, self.adj_safety, self.adj_ifactor, self.adj_dfactor,
                         self.adj_norm_kind, _lib.ptr(a_out), B, C, H, _lib.dtype_enum(torch.float32),
-                        int(i == self.n_out - 1), _lib.ptr(workspace), workspace.numel(), first, count, sums_ptr,
-                        global_batch, stream), "cde_dopri5_adjoint_advance")
+                        int(i == self.n_out - 1) | (2 if want_t else 0), _lib.ptr(workspace), workspace.numel(), first,
+                        count, sums_ptr, global_batch, stream), "cde_dopri5_adjoint_advance")
                 if shared is None:
                     advance(launched, _DOPRI_CHUNK, None, 0)
                     launched += _DOPRI_CHUNK
@@ -710,6 +729,9 @@ class _Dopri5Plan:
         if self.record:
             last_dopri5_adjoint_stats["steps"] = steps           # one (n, 3) tensor per output interval, last first
             last_dopri5_adjoint_stats["attempts"] = attempts     # (t0, t1, on_jump, accepted, ratio) of EVERY attempt
+        if want_t:
+            time_terms[0] = carry.to(torch.float32).reshape(())       # time_vjps[0] = the carried vjp_t
+            return a, grad_w, grad_b, torch.stack(time_terms)
         return a, grad_w, grad_b
 
     def run_adjoint_mlp(self, z_saved, grad_out, w1, b1, w2, b2):
@@ -873,9 +895,10 @@ class _Dopri5Plan:
 
 class _FusedDopri5(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, z0, weight, bias, plan, wants):
+    def forward(ctx, z0, weight, bias, plan, wants, t=None):
         out = plan.run(z0, weight, bias)
         ctx.plan, ctx.wants = plan, wants
+        ctx.t_like = t
         ctx.save_for_backward(out, weight, bias)
         return out.reshape(*plan.batch, plan.n_out, plan.H)
 
@@ -883,11 +906,16 @@ class _FusedDopri5(torch.autograd.Function):
     def backward(ctx, grad_out):
         plan = ctx.plan
         out, weight, bias = ctx.saved_tensors
-        grad_z0, grad_w, grad_b = plan.run_adjoint(out, grad_out, weight, bias)
+        want_t = ctx.t_like is not None and ctx.needs_input_grad[5]
+        res = plan.run_adjoint(out, grad_out, weight, bias, want_t=want_t)
+        grad_z0, grad_w, grad_b = res[:3]
+        grad_t = None
+        if want_t:                                # on `t`'s own device: cdeint accepts a CPU `t` next to GPU data
+            grad_t = res[3].to(device=ctx.t_like.device, dtype=ctx.t_like.dtype)
         want_w, want_b = ctx.wants
         return (grad_z0.reshape(*plan.batch, plan.H) if ctx.needs_input_grad[0] else None,
                 grad_w.view_as(weight) if (ctx.needs_input_grad[1] and want_w) else None,
-                grad_b.view_as(bias) if (ctx.needs_input_grad[2] and want_b) else None, None, None)
+                grad_b.view_as(bias) if (ctx.needs_input_grad[2] and want_b) else None, None, None, grad_t)
 
 
 class _FusedMlpDopri5(torch.autograd.Function):
@@ -1205,7 +1233,7 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
                 return plan.run(z0, weight, bias).reshape(*batch, plan.n_out, H)
         wants = (True, True) if given_params is None else (any(p is weight for p in given_params),
                                                            any(p is bias for p in given_params))
-        return _FusedDopri5.apply(z0, weight, bias, plan, wants)
+        return _FusedDopri5.apply(z0, weight, bias, plan, wants, t if wants_t else None)
     step_size = _parse_fixed_options(fused_options, "solver")
     adjoint_step = step_size if fused_adj_opts is None else _parse_fixed_options(fused_adj_opts, "adjoint")
     want_w = want_b = True

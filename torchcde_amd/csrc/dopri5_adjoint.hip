@@ -842,6 +842,10 @@ extern "C" size_t cde_dopri5_adjoint_attempt_trace_offset(int64_t B, int64_t C, 
   return adj_layout(B, H).trace_all;
 }
 extern "C" size_t cde_dopri5_adjoint_status_stride(void) { return cde::ADJ_CTRL_STRIDE; }
+extern "C" size_t cde_dopri5_adjoint_carry_offset(int64_t B, int64_t C, int64_t H) {
+  (void)C;
+  return adj_layout(B, H).carry;
+}
 extern "C" size_t cde_dopri5_adjoint_reduced_count(void) { return (size_t)cde::ADJ_NS + 2 * (size_t)cde::ADJ_IMAGE_FLOATS; }
 
 static cde::AdjReduceArgs adj_reduce_args(unsigned char* base, const AdjLayout& L, int64_t B, double rtol, double atol,
@@ -906,8 +910,10 @@ extern "C" int cde_dopri5_adjoint_advance(const void* coeffs, const void* knots,
   const int grid = cde::adj_grid(B);
   if (first_launch == 0) {
     cde::zero_async(base, 2 * cde::ADJ_CTRL_STRIDE, s);                                                // phase 0
-    if (first_interval) {
-      cde::zero_async(base + L.carry, 256, s);
+    if (first_interval & 1) {
+      // (bit 1: the caller has set vjp_t itself -- output times that require a gradient: torchdiffeq starts every interval
+      //  at vjp_t - f(t_i, y_i) . dL/dy_i, cde_dopri5_adjoint_carry_offset)
+      if (!(first_interval & 2)) cde::zero_async(base + L.carry, 256, s);
       cde::zero_async(base + L.G, L.att - L.G, s);                                // G, G_local, the prev buffers
     }
   }

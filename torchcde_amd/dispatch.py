@@ -97,8 +97,10 @@ def select_path(q):
         return Choice("rk4", "")
     if not q.wants_grad:
         return Choice("dopri5_forward", "")
-    if q.wants_t or q.wants_control:
-        return _stepwise("time / control gradients through the adaptive backward")
+    if q.wants_control:
+        return _stepwise("control gradients through the adaptive backward")
+    if q.wants_t and q.shared:
+        return _stepwise("output-time gradients through the adaptive backward with a shared step controller")
     if not q.mfma_shape:
         return _stepwise("the adaptive backward exists for the 32 x 8 MFMA tiles only (float32, H <= 32, C <= 8)")
     return Choice("dopri5_adjoint", "")
