@@ -489,6 +489,8 @@ int cde_dopri5_adjoint_apply_state_sums(void* workspace, size_t workspace_bytes,
 size_t cde_dopri5_adjoint_mlp_workspace_bytes(int64_t B, int64_t C, int64_t H);
 size_t cde_dopri5_adjoint_mlp_trace_offset(int64_t B, int64_t C, int64_t H, int which);
 size_t cde_dopri5_adjoint_mlp_gradient_offset(int64_t B, int64_t C, int64_t H);
+/* vjp_t of the two-layer solve (output-time gradients; first_interval bit 1): as cde_dopri5_adjoint_carry_offset */
+size_t cde_dopri5_adjoint_mlp_carry_offset(int64_t B, int64_t C, int64_t H);
 int cde_dopri5_adjoint_mlp_advance(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W1,
                                    const void* bias1, int64_t width, const void* W2, const void* bias2, int act,
                                    const void* y_init, const void* a_init, double s0, double s1, const double* jump_s,

@@ -790,10 +790,11 @@ def test_dispatch_table_is_exhaustively_consistent():
                         # (output-time gradients: K4a carries vjp_t; not with one controller across shards)
                         assert f["mfma_shape"] and not f["wants_control"] and not (f["wants_t"] and f["shared"])
                     if c.path == "mlp_dopri5_adjoint":
-                        assert not f["wants_t"] and not f["wants_control"]
+                        assert not f["wants_control"] and not (f["wants_t"] and f["shared"])
                     if kind == "mlp2":
                         assert not f["variant_generic"]
-                        assert not f["wants_t"] and (not f["wants_control"] or (f["narrow_control"] and method == "rk4"))
+                        assert not f["wants_t"] or c.path == "mlp_dopri5_adjoint"
+                        assert not f["wants_control"] or (f["narrow_control"] and method == "rk4")
                     if kind == "affine" and (f["wants_t"] or f["wants_control"]):
                         assert f["mfma_shape"] and (method == "rk4" or not f["wants_control"])
     assert n > 100000 and set(seen) == set(D.FUSED_PATHS) | {D.STEPWISE}       # every path is reachable

@@ -138,6 +138,7 @@ _SIGNATURES = {
                                             _d, _p, _i64, _i64, _i64, _i, _p, _sz, _i64, _p, _i64, _p]),
     "cde_dopri5_adjoint_status_stride": (_sz, []),
     "cde_dopri5_adjoint_carry_offset": (_sz, [_i64, _i64, _i64]),
+    "cde_dopri5_adjoint_mlp_carry_offset": (_sz, [_i64, _i64, _i64]),
     "cde_dopri5_adjoint_attempt_trace_offset": (_sz, [_i64, _i64, _i64]),
     "cde_dopri5_adjoint_reduced_count": (_sz, []),
     "cde_dopri5_adjoint_advance": (_i, [_p, _p, _i64, _i, _p, _p, _i, _p, _p, _d, _d, _p, _i64, _d, _d, _d, _d, _d, _i, _p,

@@ -734,9 +734,10 @@ class _Dopri5Plan:
             return a, grad_w, grad_b, torch.stack(time_terms)
         return a, grad_w, grad_b
 
-    def run_adjoint_mlp(self, z_saved, grad_out, w1, b1, w2, b2):
+    def run_adjoint_mlp(self, z_saved, grad_out, w1, b1, w2, b2, want_t=False):
         """K4am: the same backward for the two-layer field (csrc/dopri5_mlp_adjoint.hip): per attempted step the attempt
-        kernel, the split-K reduction of its gradient factors and the commit / norm kernel, queued by one C-ABI call."""
+        kernel, the split-K reduction of its gradient factors and the commit / norm kernel, queued by one C-ABI call.
+        want_t: output-time gradients, as in run_adjoint."""
         lib = _lib.load()
         B, H, C, dev = self.B, self.H, self.C, self.device
         z_saved = z_saved.detach().reshape(B, self.n_out, H)
@@ -745,7 +746,8 @@ class _Dopri5Plan:
         width = w1.size(0)
         a = grad_out[:, -1].contiguous()
         if self.n_out == 1:
-            return a, torch.zeros_like(w1), torch.zeros_like(b1), torch.zeros_like(w2), torch.zeros_like(b2)
+            zeros = (a, torch.zeros_like(w1), torch.zeros_like(b1), torch.zeros_like(w2), torch.zeros_like(b2))
+            return zeros + (torch.zeros(1, dtype=torch.float32, device=dev),) if want_t else zeros
         nbytes = lib.cde_dopri5_adjoint_mlp_workspace_bytes(B, C, H)
         workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         workspace[:_WORKSPACE_HEAD].zero_()
@@ -761,9 +763,22 @@ class _Dopri5Plan:
                                   device=dev)
         stats = dict(n_accept=0, n_reject=0, launches=0)
         steps, attempts = [], []
+        time_terms = [None] * self.n_out
+        carry = None
+        if want_t:
+            off = lib.cde_dopri5_adjoint_mlp_carry_offset(B, C, H)
+            carry = workspace[off:off + 8].view(torch.float64)
+            carry.zero_()
         for i in range(self.n_out - 1, 0, -1):
             y = z_saved[:, i].contiguous()
             s0, s1 = -float(self.t_host[i]), -float(self.t_host[i - 1])
+            if want_t:                                                # torchdiffeq: aug_state[0] -= func(t[i], y[i]) . grad_y[i]
+                pre = torch.nn.functional.linear(torch.nn.functional.linear(y, w1, b1).relu(), w2, b2)
+                if self.act == _lib.ACT_TANH:
+                    pre = pre.tanh()
+                dX = self.path.derivative(self.t_out[i]).reshape(B, C)
+                time_terms[i] = ((pre.view(B, H, C) * dX.unsqueeze(1)).sum(-1) * grad_out[:, i]).sum()
+                carry.copy_((carry.to(torch.float32) - time_terms[i]).to(torch.float64))
             launched = 0
             while True:
                 if shared is None:
@@ -772,8 +787,8 @@ class _Dopri5Plan:
                         width, _lib.ptr(w2), _lib.ptr(b2), self.act, _lib.ptr(y), _lib.ptr(a), s0, s1, _lib.ptr(self.jump_s),
                         self.n_jump_s, self.adjoint_rtol, self.adjoint_atol, self.adj_safety, self.adj_ifactor,
                         self.adj_dfactor, self.adj_norm_kind, _lib.ptr(a_out), B, C, H, _lib.dtype_enum(torch.float32),
-                        int(i == self.n_out - 1), _lib.ptr(workspace), workspace.numel(), launched, _DOPRI_CHUNK, stream),
-                        "cde_dopri5_adjoint_mlp_advance")
+                        int(i == self.n_out - 1) | (2 if want_t else 0), _lib.ptr(workspace), workspace.numel(), launched,
+                        _DOPRI_CHUNK, stream), "cde_dopri5_adjoint_mlp_advance")
                     launched += _DOPRI_CHUNK
                 else:
                     # one controller for all shards (round 4): per attempted step ONE attempt launch, then this shard's
@@ -837,6 +852,9 @@ class _Dopri5Plan:
         if self.record:
             last_dopri5_adjoint_stats["steps"] = steps
             last_dopri5_adjoint_stats["attempts"] = attempts
+        if want_t:
+            time_terms[0] = carry.to(torch.float32).reshape(())
+            return a, grad_w1, grad_b1, grad_w2, grad_b2, torch.stack(time_terms)
         return a, grad_w1, grad_b1, grad_w2, grad_b2
 
     def run(self, z0, weight, bias):
@@ -923,9 +941,10 @@ class _FusedMlpDopri5(torch.autograd.Function):
     (K4 with the two-layer field) and torchdiffeq's adaptive adjoint backward (K4am)."""
 
     @staticmethod
-    def forward(ctx, z0, w1, b1, w2, b2, plan):
+    def forward(ctx, z0, w1, b1, w2, b2, plan, t=None):
         out = plan.run(z0, w2, b2)
         ctx.plan = plan
+        ctx.t_like = t
         ctx.save_for_backward(out, w1, b1, w2, b2)
         return out.reshape(*plan.batch, plan.n_out, plan.H)
 
@@ -933,10 +952,13 @@ class _FusedMlpDopri5(torch.autograd.Function):
     def backward(ctx, grad_out):
         out, w1, b1, w2, b2 = ctx.saved_tensors
         plan = ctx.plan
-        grad_z0, gw1, gb1, gw2, gb2 = plan.run_adjoint_mlp(out, grad_out, w1, b1, w2, b2)
         need = ctx.needs_input_grad
+        want_t = ctx.t_like is not None and need[6]
+        res = plan.run_adjoint_mlp(out, grad_out, w1, b1, w2, b2, want_t=want_t)
+        grad_z0, gw1, gb1, gw2, gb2 = res[:5]
+        grad_t = res[5].to(device=ctx.t_like.device, dtype=ctx.t_like.dtype) if want_t else None
         return (grad_z0.reshape(*plan.batch, plan.H) if need[0] else None, gw1 if need[1] else None,
-                gb1 if need[2] else None, gw2 if need[3] else None, gb2 if need[4] else None, None)
+                gb1 if need[2] else None, gw2 if need[3] else None, gb2 if need[4] else None, None, grad_t)
 
 
 # ------------------------------------------------------------------------------------------ front end
@@ -1219,7 +1241,8 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
             with torch.no_grad():
                 return plan.run(z0, mlp.weight, mlp.bias).reshape(*batch, plan.n_out, H)
         # the reference examples' own training call (no method: dopri5 + adjoint): K4 forward, K4am backward
-        return _FusedMlpDopri5.apply(z0, mlp.hidden.weight, mlp.hidden.bias, mlp.output.weight, mlp.output.bias, plan)
+        return _FusedMlpDopri5.apply(z0, mlp.hidden.weight, mlp.hidden.bias, mlp.output.weight, mlp.output.bias, plan,
+                                     t if wants_t else None)
 
     # ---- one-layer fields
     weight, bias = field.weight, field.bias

@@ -1147,6 +1147,7 @@ extern "C" size_t cde_dopri5_adjoint_mlp_trace_offset(int64_t B, int64_t C, int6
   const MadjLayout L = madj_layout(B, H, C);
   return which == 0 ? L.trace : L.trace_all;
 }
+extern "C" size_t cde_dopri5_adjoint_mlp_carry_offset(int64_t B, int64_t C, int64_t H) { return madj_layout(B, H, C).carry; }
 // where the running totals live: layer 2 as [256][129] (row = padded (h, c), bias in column 128), then layer 1 as [128][33]
 extern "C" size_t cde_dopri5_adjoint_mlp_gradient_offset(int64_t B, int64_t C, int64_t H) {
   return madj_layout(B, H, C).G;
@@ -1221,9 +1222,10 @@ static int dopri5_adjoint_mlp_advance_impl(const void* coeffs, const void* knots
   g.com.carry = (double*)(base + L.carry);
   if (first_launch == 0) {
     zero_async(base, 2 * ADJ_CTRL_STRIDE, s);                                                     // phase 0
-    if (first_interval) {
+    if (first_interval & 1) {
       // vjp_t, the running totals and the factor rows (padding rows must hold zeros; the "1" columns are set below)
-      zero_async(base + L.carry, 256, s);
+      // (bit 1: the caller has set vjp_t itself -- output-time gradients, as for K4a: cde_dopri5_adjoint_mlp_carry_offset)
+      if (!(first_interval & 2)) zero_async(base + L.carry, 256, s);
       zero_async(base + L.G, L.slopes - L.G, s);
       zero_async(base + L.U, L.trace - L.U, s);
       const int64_t rows = (int64_t)MADJ_FSLOTS * L.rows_per_stage;

@@ -79,7 +79,7 @@ def select_path(q):
             return _stepwise("variant='generic' was requested (the step-wise reference path)")
         if not q.wants_grad:
             return Choice("mlp_rk4_forward" if q.method == "rk4" else "mlp_dopri5_forward", "")
-        if q.wants_t:
+        if q.wants_t and (q.method != "dopri5" or q.wants_control or q.shared):
             return _stepwise("gradients w.r.t. the output times of a two-layer field")
         if q.wants_control:
             if q.method == "dopri5":
