@@ -793,7 +793,7 @@ def test_dispatch_table_is_exhaustively_consistent():
                         assert not f["wants_control"] and not (f["wants_t"] and f["shared"])
                     if kind == "mlp2":
                         assert not f["variant_generic"]
-                        assert not f["wants_t"] or c.path == "mlp_dopri5_adjoint"
+                        assert not f["wants_t"] or c.path == "mlp_dopri5_adjoint" or (method == "rk4" and f["narrow_control"])
                         assert not f["wants_control"] or (f["narrow_control"] and method == "rk4")
                     if kind == "affine" and (f["wants_t"] or f["wants_control"]):
                         assert f["mfma_shape"] and (method == "rk4" or not f["wants_control"])

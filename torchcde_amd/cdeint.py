@@ -324,6 +324,7 @@ class _MlpPlan:
         self.coeffs, self.knots = coeffs, knots
         self.n_intervals, self.degree = path._n_intervals(), path._degree
         self.field, self.batch, self.B, self.H, self.C = field, batch, coeffs.size(0), H, C
+        self.path = path
         self.device = coeffs.device
         self.grids = _grids_for(_to_host(t), step_size, step_size if adjoint_step_size is None else adjoint_step_size,
                                 self.device)
@@ -418,12 +419,37 @@ class _MlpPlan:
         grad_b1 = acc1[:width, 32].contiguous()
         return a.reshape(*self.batch, H), grad_w1, grad_b1, grad_w2, grad_b2, grad_x
 
+    def time_gradients(self, z_saved, grad_out, weights, grad_x, t):
+        """Output-time gradients from what the sweep produced (as _plan_time_gradients for the one-layer fields):
+        dL/dt_i = f(t_i, z_i) . dL/dz_i for i >= 1, dL/dt_0 = int a^T F(z) d2X/dt2 dt - sum_i dL/dt_i; the integral is a
+        contraction of the control gradient with the cubic's (2c, 3d) rows and vanishes for a piecewise-linear control."""
+        B, H, C, f = self.B, self.H, self.C, self.field
+        w1, b1, w2, b2 = self._weights(weights)
+        zs = z_saved.detach().reshape(B, self.n_out, H)
+        go = grad_out.detach().reshape(B, self.n_out, H)
+        if self.degree == _lib.PATH_CUBIC:
+            co = self.coeffs
+            integral = (co[..., 2 * C:3 * C] * grad_x[..., C:2 * C] + 2 * co[..., 3 * C:] * grad_x[..., 2 * C:3 * C]).sum()
+        else:
+            integral = torch.zeros((), dtype=torch.float32, device=self.device)
+        vals = [None] * self.n_out
+        total = torch.zeros((), dtype=torch.float32, device=self.device)
+        for i in range(1, self.n_out):
+            pre = torch.nn.functional.linear(torch.nn.functional.linear(zs[:, i], w1, b1).relu(), w2, b2)
+            if f.act == _lib.ACT_TANH:
+                pre = pre.tanh()
+            dX = self.path.derivative(self.grids.t_out[i]).reshape(B, C)
+            vals[i] = ((pre.view(B, H, C) * dX.unsqueeze(1)).sum(-1) * go[:, i]).sum()
+            total = total + vals[i]
+        vals[0] = integral - total
+        return torch.stack(vals).to(device=t.device, dtype=t.dtype) if self.n_out > 1 else torch.zeros_like(t)
+
 
 class _FusedMlpRK4(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, z0, w1, b1, w2, b2, plan, want_x, *control):
+    def forward(ctx, z0, w1, b1, w2, b2, plan, want_x, t, *control):
         out = plan.run(z0)
-        ctx.plan, ctx.want_x = plan, want_x
+        ctx.plan, ctx.want_x, ctx.t_like = plan, want_x, t
         ctx.save_for_backward(out, w1, b1, w2, b2)
         return out
 
@@ -431,16 +457,20 @@ class _FusedMlpRK4(torch.autograd.Function):
     def backward(ctx, grad_out):
         out, *weights = ctx.saved_tensors
         plan = ctx.plan
-        grad_z0, gw1, gb1, gw2, gb2, grad_x = plan.run_adjoint(out, grad_out, ctx.want_x, weights)
         need = ctx.needs_input_grad
+        want_t = ctx.t_like is not None and need[7]
+        # (output-time gradients of a cubic control need the control gradient the sweep can accumulate: _plan_time_gradients)
+        need_gx = ctx.want_x or (want_t and plan.degree == _lib.PATH_CUBIC)
+        grad_z0, gw1, gb1, gw2, gb2, grad_x = plan.run_adjoint(out, grad_out, need_gx, weights)
+        grad_t = plan.time_gradients(out, grad_out, weights, grad_x, ctx.t_like) if want_t else None
         control_grads = ()
         if ctx.want_x:
             C = plan.C
             gx = grad_x.reshape(*plan.batch, grad_x.size(-2), grad_x.size(-1))
             pieces = (gx[..., C:2 * C], gx[..., 2 * C:3 * C], gx[..., 3 * C:]) if plan.degree == _lib.PATH_CUBIC else (gx,)
-            control_grads = tuple(g if n else None for g, n in zip(pieces, need[7:]))
+            control_grads = tuple(g if n else None for g, n in zip(pieces, need[8:]))
         return (grad_z0 if need[0] else None, gw1 if need[1] else None, gb1 if need[2] else None,
-                gw2 if need[3] else None, gb2 if need[4] else None, None, None) + control_grads
+                gw2 if need[3] else None, gb2 if need[4] else None, None, None, grad_t) + control_grads
 
 
 def _mlp_fusable(field, H, C, z0, packed):
@@ -1230,7 +1260,7 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         want_x = bool(control_wants)
         control_inputs = X._control_buffers() if want_x else ()
         return _FusedMlpRK4.apply(z0, mlp.hidden.weight, mlp.hidden.bias, mlp.output.weight, mlp.output.bias, plan,
-                                  want_x, *control_inputs)
+                                  want_x, t if wants_t else None, *control_inputs)
     if choice.path == "mlp_rk4_forward":
         with torch.no_grad():
             return _MlpPlan(X, mlp, batch, H, C, t, _parse_fixed_options(fused_options, "solver")).run(z0)

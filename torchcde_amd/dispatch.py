@@ -79,8 +79,10 @@ def select_path(q):
             return _stepwise("variant='generic' was requested (the step-wise reference path)")
         if not q.wants_grad:
             return Choice("mlp_rk4_forward" if q.method == "rk4" else "mlp_dopri5_forward", "")
-        if q.wants_t and (q.method != "dopri5" or q.wants_control or q.shared):
-            return _stepwise("gradients w.r.t. the output times of a two-layer field")
+        if q.wants_t and q.method == "dopri5" and (q.wants_control or q.shared):
+            return _stepwise("gradients w.r.t. the output times of a two-layer field next to control gradients / a shared controller")
+        if q.wants_t and q.method == "rk4" and not q.narrow_control:
+            return _stepwise("gradients w.r.t. the output times of a two-layer field with more than 8 channels")
         if q.wants_control:
             if q.method == "dopri5":
                 return _stepwise("control gradients through the adaptive backward of a two-layer field")
