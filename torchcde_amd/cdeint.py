@@ -459,10 +459,15 @@ class _FusedMlpRK4(torch.autograd.Function):
         plan = ctx.plan
         need = ctx.needs_input_grad
         want_t = ctx.t_like is not None and need[7]
-        # (output-time gradients of a cubic control need the control gradient the sweep can accumulate: _plan_time_gradients)
-        need_gx = ctx.want_x or (want_t and plan.degree == _lib.PATH_CUBIC)
-        grad_z0, gw1, gb1, gw2, gb2, grad_x = plan.run_adjoint(out, grad_out, need_gx, weights)
-        grad_t = plan.time_gradients(out, grad_out, weights, grad_x, ctx.t_like) if want_t else None
+        grad_z0, gw1, gb1, gw2, gb2, grad_x = plan.run_adjoint(out, grad_out, ctx.want_x, weights)
+        grad_t = None
+        if want_t:
+            if grad_x is None and plan.degree == _lib.PATH_CUBIC:
+                # the time terms of a cubic control come out of the control-gradient sweep: run IN ADDITION, so that the
+                # other gradients are bitwise the same whether or not `t` requires grad (the reference's "detach trick"
+                # invariance, test/test_tricks.py:111-131), as _FusedRK4 does
+                grad_x = plan.run_adjoint(out, grad_out, True, weights)[5]
+            grad_t = plan.time_gradients(out, grad_out, weights, grad_x, ctx.t_like)
         control_grads = ()
         if ctx.want_x:
             C = plan.C
