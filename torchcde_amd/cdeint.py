@@ -419,19 +419,33 @@ class _MlpPlan:
         grad_b1 = acc1[:width, 32].contiguous()
         return a.reshape(*self.batch, H), grad_w1, grad_b1, grad_w2, grad_b2, grad_x
 
-    def time_gradients(self, z_saved, grad_out, weights, grad_x, t):
-        """Output-time gradients from what the sweep produced (as _plan_time_gradients for the one-layer fields):
+    def time_gradients(self, z_saved, grad_out, weights, grad_x, t, want_t=True, want_knots=False):
+        """Time gradients from what the sweep produced (as _plan_time_gradients for the one-layer fields):
         dL/dt_i = f(t_i, z_i) . dL/dz_i for i >= 1, dL/dt_0 = int a^T F(z) d2X/dt2 dt - sum_i dL/dt_i; the integral is a
-        contraction of the control gradient with the cubic's (2c, 3d) rows and vanishes for a piecewise-linear control."""
+        contraction of the control gradient with the cubic's (2c, 3d) rows and vanishes for a piecewise-linear control;
+        dL/d knot_j = - its part over interval j (cubic), or through the widths of a piecewise-linear control."""
         B, H, C, f = self.B, self.H, self.C, self.field
         w1, b1, w2, b2 = self._weights(weights)
         zs = z_saved.detach().reshape(B, self.n_out, H)
         go = grad_out.detach().reshape(B, self.n_out, H)
+        co = self.coeffs
         if self.degree == _lib.PATH_CUBIC:
-            co = self.coeffs
-            integral = (co[..., 2 * C:3 * C] * grad_x[..., C:2 * C] + 2 * co[..., 3 * C:] * grad_x[..., 2 * C:3 * C]).sum()
+            per_interval = (co[..., 2 * C:3 * C] * grad_x[..., C:2 * C]
+                            + 2 * co[..., 3 * C:] * grad_x[..., 2 * C:3 * C]).sum(-1).sum(0)
         else:
-            integral = torch.zeros((), dtype=torch.float32, device=self.device)
+            per_interval = torch.zeros(co.size(1) - 1, dtype=torch.float32, device=self.device)
+        integral = per_interval.sum()
+        grad_knots = None
+        if want_knots and self.degree == _lib.PATH_CUBIC:
+            grad_knots = torch.cat([-per_interval, per_interval.new_zeros(1)])
+        elif want_knots:
+            knots, values = self.knots.double(), co.double()
+            slopes = (values[:, 1:] - values[:, :-1]) / (knots[1:] - knots[:-1]).unsqueeze(-1)
+            dh = (grad_x.double().cumsum(1)[:, :-1] * slopes).sum((0, 2))            # dL/dh_j
+            zero = dh.new_zeros(1)
+            grad_knots = (torch.cat([zero, dh]) - torch.cat([dh, zero])).to(co.dtype)
+        if not want_t:
+            return None, grad_knots
         vals = [None] * self.n_out
         total = torch.zeros((), dtype=torch.float32, device=self.device)
         for i in range(1, self.n_out):
@@ -442,14 +456,15 @@ class _MlpPlan:
             vals[i] = ((pre.view(B, H, C) * dX.unsqueeze(1)).sum(-1) * go[:, i]).sum()
             total = total + vals[i]
         vals[0] = integral - total
-        return torch.stack(vals).to(device=t.device, dtype=t.dtype) if self.n_out > 1 else torch.zeros_like(t)
+        grad_t = torch.stack(vals).to(device=t.device, dtype=t.dtype) if self.n_out > 1 else torch.zeros_like(t)
+        return grad_t, grad_knots
 
 
 class _FusedMlpRK4(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, z0, w1, b1, w2, b2, plan, want_x, t, *control):
+    def forward(ctx, z0, w1, b1, w2, b2, plan, want_x, t, knots, *control):
         out = plan.run(z0)
-        ctx.plan, ctx.want_x, ctx.t_like = plan, want_x, t
+        ctx.plan, ctx.want_x, ctx.t_like, ctx.has_knots = plan, want_x, t, knots is not None
         ctx.save_for_backward(out, w1, b1, w2, b2)
         return out
 
@@ -459,23 +474,24 @@ class _FusedMlpRK4(torch.autograd.Function):
         plan = ctx.plan
         need = ctx.needs_input_grad
         want_t = ctx.t_like is not None and need[7]
+        want_knots = ctx.has_knots and need[8]
         grad_z0, gw1, gb1, gw2, gb2, grad_x = plan.run_adjoint(out, grad_out, ctx.want_x, weights)
-        grad_t = None
-        if want_t:
-            if grad_x is None and plan.degree == _lib.PATH_CUBIC:
-                # the time terms of a cubic control come out of the control-gradient sweep: run IN ADDITION, so that the
-                # other gradients are bitwise the same whether or not `t` requires grad (the reference's "detach trick"
-                # invariance, test/test_tricks.py:111-131), as _FusedRK4 does
+        grad_t = grad_knots = None
+        if want_t or want_knots:
+            if grad_x is None and (plan.degree == _lib.PATH_CUBIC or want_knots):
+                # the time terms come out of the control-gradient sweep: run IN ADDITION, so that the other gradients are
+                # bitwise the same whether or not a time requires grad (the reference's "detach trick" invariance,
+                # test/test_tricks.py:111-131), as _FusedRK4 does
                 grad_x = plan.run_adjoint(out, grad_out, True, weights)[5]
-            grad_t = plan.time_gradients(out, grad_out, weights, grad_x, ctx.t_like)
+            grad_t, grad_knots = plan.time_gradients(out, grad_out, weights, grad_x, ctx.t_like, want_t, want_knots)
         control_grads = ()
         if ctx.want_x:
             C = plan.C
             gx = grad_x.reshape(*plan.batch, grad_x.size(-2), grad_x.size(-1))
             pieces = (gx[..., C:2 * C], gx[..., 2 * C:3 * C], gx[..., 3 * C:]) if plan.degree == _lib.PATH_CUBIC else (gx,)
-            control_grads = tuple(g if n else None for g, n in zip(pieces, need[8:]))
+            control_grads = tuple(g if n else None for g, n in zip(pieces, need[9:]))
         return (grad_z0 if need[0] else None, gw1 if need[1] else None, gb1 if need[2] else None,
-                gw2 if need[3] else None, gb2 if need[4] else None, None, None, grad_t) + control_grads
+                gw2 if need[3] else None, gb2 if need[4] else None, None, None, grad_t, grad_knots) + control_grads
 
 
 def _mlp_fusable(field, H, C, z0, packed):
@@ -1204,8 +1220,8 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         extra_ok = all(isinstance(p, torch.Tensor) and p.untyped_storage().data_ptr() in control_ids for p in extra)
         complete = field is not None or all(any(p is o for p in given_params) for o in own)    # K3m / K4am: all four or none
         params_kind = "own" if (extra_ok and complete) else "foreign"
-        if field is None and any(p is X._t for p in extra):
-            params_kind = "foreign"             # knot-time gradients of a two-layer solve: step-wise
+        if field is None and any(p is X._t for p in extra) and not (method == "rk4" and C <= 8):
+            params_kind = "foreign"             # knot-time gradients of a two-layer solve: rk4 up to 8 channels, else step-wise
 
     fixed_keys, adaptive_keys = {"step_size"}, {"jump_t", "safety", "ifactor", "dfactor"}
     # ONE normalised view of the options for the fused paths (the step-wise path gets them verbatim, like torchdiffeq):
@@ -1262,10 +1278,14 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         step = _parse_fixed_options(fused_options, "solver")
         adj_step = step if fused_adj_opts is None else _parse_fixed_options(fused_adj_opts, "adjoint")
         plan = _MlpPlan(X, mlp, batch, H, C, t, step, adj_step)
-        want_x = bool(control_wants)
+        want_knots = bool(grad_mode and given_params is not None and any(p is X._t and p.requires_grad for p in given_params))
+        # (the coefficient tensor the path was built from: dL/dcoeffs flows back through the path's buffer views)
+        want_x = bool(grad_mode and given_params is not None and any(
+            isinstance(p, torch.Tensor) and p.requires_grad and p is not X._t
+            and p.untyped_storage().data_ptr() in control_ids for p in given_params))
         control_inputs = X._control_buffers() if want_x else ()
         return _FusedMlpRK4.apply(z0, mlp.hidden.weight, mlp.hidden.bias, mlp.output.weight, mlp.output.bias, plan,
-                                  want_x, t if wants_t else None, *control_inputs)
+                                  want_x, t if wants_t else None, X._t if want_knots else None, *control_inputs)
     if choice.path == "mlp_rk4_forward":
         with torch.no_grad():
             return _MlpPlan(X, mlp, batch, H, C, t, _parse_fixed_options(fused_options, "solver")).run(z0)
