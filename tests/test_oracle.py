@@ -293,6 +293,56 @@ def test_adjoint_matches_backprop_through_solver():
         assert gaps[1] < 1e-4 and gaps[1] < gaps[0] / 6, gaps
 
 
+def test_adjoint_output_time_gradients_against_the_exact_flow():
+    """The restated odeint_adjoint's time_vjps (what the GPU tests hold the fused output-time gradients to).  For a loss
+    sum_i w_i . z(t_i) of the exact flow: dL/dt_i = w_i . f(t_i, z_i) for i >= 1 (what torchdiffeq computes verbatim), and
+    dL/dt_0 = -a(t_0+) . f(t_0, z_0) -- torchdiffeq gets it as the integral of a . df/dt minus the other terms, an identity
+    of the exact adjoint flow.  Tightly resolved dopri5 must satisfy both, and central differences of solves without any
+    adjoint.  Fixed-step rk4 evaluates the same integral by its own quadrature: df/dt = F(z) d2X/dt2 jumps at the knots of a
+    Hermite cubic, so its dL/dt_0 carries an O(step) error that depends on where the stage times fall relative to the knots
+    (the reference's behaviour, restated -- and what the fused rk4 path reproduces step for step)."""
+    gen = torch.Generator().manual_seed(12)
+    B, L, C, H = 3, 9, 3, 5
+    x = make_series(B, L, C, torch.float64, seed=6)
+    X = interp.CubicPath(interp.hermite_bdiff_coeffs(x))
+    func = LinearField(H, C, torch.float64, scale=0.3, tanh=True, seed=5)
+    z0 = torch.randn(B, H, generator=gen, dtype=torch.float64)
+    w = torch.rand(B, 3, H, generator=gen, dtype=torch.float64) + 0.5
+    t_out = torch.tensor([0.4, 3.3, 7.6], dtype=torch.float64)
+
+    def solve(kw):
+        t = t_out.clone().requires_grad_(True)
+        z = z0.clone().requires_grad_(True)
+        out = cde.cdeint(X, func, z, t, adjoint=True, **kw)
+        (out * w).sum().backward()
+        f = [(func(t_out[i], out[:, i].detach()) * X.derivative(t_out[i]).unsqueeze(-2)).sum(-1) for i in range(3)]
+        exact0 = -float(((z.grad - w[:, 0]) * f[0]).sum())
+        return t.grad.detach(), [float((w[:, i] * f[i]).sum()) for i in range(3)], exact0
+
+    tight = dict(method="dopri5", rtol=1e-10, atol=1e-12)
+    grad_t, direct, exact0 = solve(tight)
+    assert abs(float(grad_t[0]) - exact0) <= 1e-7
+    assert abs(float(grad_t[1]) - direct[1]) <= 1e-9 and abs(float(grad_t[2]) - direct[2]) <= 1e-9
+
+    def loss(times):
+        with torch.no_grad():
+            return float((cde.cdeint(X, func, z0, times, adjoint=False, **tight) * w).sum())
+    eps = 1e-4
+    for i in range(3):
+        hi, lo = t_out.clone(), t_out.clone()
+        hi[i] += eps
+        lo[i] -= eps
+        fd = (loss(hi) - loss(lo)) / (2 * eps)
+        assert abs(float(grad_t[i]) - fd) <= (5e-4 if i == 0 else 1e-6), (i, float(grad_t[i]), fd)   # (t_0 moves the step grid)
+
+    errors = []
+    for step in (0.04, 0.01):
+        grad_r, direct_r, _ = solve(dict(method="rk4", options=dict(step_size=step)))
+        assert abs(float(grad_r[1]) - direct_r[1]) <= 1e-12 and abs(float(grad_r[2]) - direct_r[2]) <= 1e-12
+        errors.append(abs(float(grad_r[0]) - exact0))
+    assert max(errors) < 2e-2, errors        # (observed 4e-3 and 6e-3: whichever side of a knot a stage time falls on)
+
+
 def test_gradcheck_direct_float64():
     gen = torch.Generator().manual_seed(8)
     x = make_series(2, 6, 2, torch.float64, seed=1)
