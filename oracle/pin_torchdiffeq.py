@@ -19,6 +19,9 @@ float32/float64, half steps with outputs off the grid, irregular knots, dopri5 -
     ``func``: 6 evaluations per attempt + initial-step evaluations) and the outputs / gradients to 1e-6 relative
     (bitwise is reported too, but torchdiffeq versions differ in in-place vs. out-of-place stage sums)
 
+  * every adjoint problem once more with output times that require a gradient: ``time_vjps`` (what the fused output-time
+    gradients are held to) next to the other gradients
+
 and it prints the torchdiffeq version it pinned against.  Until it has been run somewhere, DESIGN.md section 2 keeps
 the words "parity unpinned" for the solver half.
 """
@@ -51,7 +54,7 @@ def _field(case):
     return golden_field(case)
 
 
-def _solve(odeint_mod, cde_cdeint, X, func, case, adjoint, extra=None, probe_calls=0):
+def _solve(odeint_mod, cde_cdeint, X, func, case, adjoint, extra=None, probe_calls=0, time_grad=False):
     z0 = case["z0"].clone().requires_grad_(True)
     func.zero_grad()
     kwargs = dict(extra or {})
@@ -60,15 +63,16 @@ def _solve(odeint_mod, cde_cdeint, X, func, case, adjoint, extra=None, probe_cal
     if case["options"] is not None:
         kwargs["options"] = dict(case["options"])
     counted = _Counting(func)
-    out = cde_cdeint(X=X, func=counted, z0=z0, t=case["t_out"], adjoint=adjoint, **kwargs)
+    t_out = case["t_out"].clone().requires_grad_(True) if time_grad else case["t_out"]
+    out = cde_cdeint(X=X, func=counted, z0=z0, t=t_out, adjoint=adjoint, **kwargs)
     weight = torch.linspace(0.5, 1.5, out.numel(), dtype=out.dtype).view_as(out)
     # `probe_calls`: evaluations the front end itself makes before the integrator runs (the reference's compatibility
     # probe func(t[0], z0), solver.py:47-53) -- not part of the step sequence
     forward_calls = counted.calls - probe_calls
     (out * weight).sum().backward()
     return dict(out=out.detach(), gz0=z0.grad.clone(), gW=func.linear.weight.grad.clone(),
-                gb=func.linear.bias.grad.clone(), forward_calls=forward_calls, calls=counted.calls - probe_calls,
-                times=list(counted.times[probe_calls:]))
+                gb=func.linear.bias.grad.clone(), gt=t_out.grad.clone() if time_grad else torch.zeros(()),
+                forward_calls=forward_calls, calls=counted.calls - probe_calls, times=list(counted.times[probe_calls:]))
 
 
 def main():
@@ -170,6 +174,21 @@ def main():
             print("%-32s %-8s %s  close=%s evaluations %d/%d stage times equal=%s  (%s)"
                   % (case["name"], "adjoint", "ok  " if ok else "FAIL", close, got["calls"], want["calls"],
                      got["times"] == want["times"], sorted(list(extra) + (["jump_t"] if trial["options"] else []))))
+
+    # output times that require a gradient (torchdiffeq's time_vjps; reference test/test_tricks.py:21-49): what the fused
+    # output-time gradients of K3 / K4a / K4am are held to
+    for case in cases:
+        X = oracle_interp.CubicPath(case["coeffs"], case["knots"])
+        want = _solve(torchdiffeq, reference_cdeint, X, _field(case), case, True, probe_calls=probe, time_grad=True)
+        got = _solve(oracle_ode, oracle_cdeint, X, _field(case), case, True, time_grad=True)
+        fixed = case["method"] in ("rk4", "midpoint", "euler")
+        keys = ("out", "gz0", "gW", "gb", "gt")
+        bitwise = all(torch.equal(got[k], want[k]) for k in keys)
+        close = all(torch.allclose(got[k], want[k], rtol=1e-6, atol=1e-9) for k in keys)
+        ok = bitwise if fixed else (close and got["times"] == want["times"])
+        failures += not ok
+        print("%-32s %-8s %s  bitwise=%s close=%s stage times equal=%s  (t requires grad)"
+              % (case["name"], "adjoint", "ok  " if ok else "FAIL", bitwise, close, got["times"] == want["times"]))
 
     if opts.write and not failures and not opts.self_test:
         for record in rewritten:
