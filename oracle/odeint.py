@@ -207,7 +207,7 @@ class _Dopri5:
         self.accepted = []           # (t0, t1, on_jump) of every accepted step (test infrastructure: the GPU trace's twin)
         # TEST INFRASTRUCTURE, not a torchdiffeq option: a list / (n, 3) tensor of accepted (t0, t1, on_jump) steps.  The
         # controller is bypassed and exactly these steps are taken -- used to check a SAMPLE of a large batch against
-        # the step sequence the batch-global controller chose for the WHOLE batch (tests/test_gpu_parity.py, config 4).
+        # the step sequence the batch-global controller chose for the WHOLE batch (tests/test_gpu_01_atsize.py, config 4).
         self.replay_steps = None if replay_steps is None else torch.as_tensor(replay_steps, dtype=tdtype).reshape(-1, 3)
         # TEST INFRASTRUCTURE as well: EVERY attempt another solver made -- rows (t0, t1, on_jump, accepted, ...), rejected
         # ones included -- is re-made from the state THIS solver has at t0; the error ratio this solver computes for it is
@@ -220,7 +220,7 @@ class _Dopri5:
         self.ratios, self.first_dt = [], None
         # TEST INFRASTRUCTURE: called as attempt_probe(y0, y1, y1_err) (flat states) for every re-made attempt.  A batch-global
         # error norm cannot be formed on a CHUNK of a large batch; the probe lets a test collect each chunk's share of the
-        # norm's sums and assemble the whole batch's error ratio (tests/test_gpu_parity.py, the at-size adaptive tests).
+        # norm's sums and assemble the whole batch's error ratio (tests/test_gpu_01_atsize.py).
         self.attempt_probe = attempt_probe
 
     # -- initial step (Hairer), order argument = self.order - 1

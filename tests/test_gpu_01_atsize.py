@@ -1,0 +1,614 @@
+"""GPU parity tests through the C ABI -- Rows a11 / a12 / d / f4 AT THE SIZES bench.py TIMES: the adaptive backward (K4a, K4am) first, then configs 2-5.
+
+Tolerances and helpers: tests/gpu_common.py.  Collection order is the file order (01 first): the tests with the least driver history run first, so a failure elsewhere cannot hide them.
+"""
+import os
+
+import pytest
+import torch
+
+from gpu_common import (_expect_dispatch, oracle_cde, oracle_interp, LinearField, _TwoLayerField, make_series, DEV, _close, _oracle_solution, _front, _oracle_solver_log, _oracle_threads, _chunked_oracle_replay)
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config4_shard_default_training_call_at_size_against_the_oracle(native):
+    """VERDICT round 3, item 1a.  BASELINE configs[3], one GPU's shard AT ITS CONFIGURED SIZE through the reference's
+    training call (solver.py:195-203,226: dopri5 + adjoint): 32768 series, L = 128, LinearInterpolation, jump_t = the knots
+    forward and backward, adjoint_options norm="seminorm" -- exactly what bench.py times as
+    config4_shard_dopri5_forward_adjoint_seminorm_ms.  K4a here runs 256 workgroups x 8 tiles with the cached Jacobian rows,
+    the 576-block R kernel over 256 images.  The float64 oracle replays the kernels' forward steps and EVERY backward
+    attempt in eight 4096-series chunks:
+      * all 32768 trajectories (rtol 1e-4), all of dL/dz0, dL/dW, dL/db (rtol 1e-3);
+      * the batch-global error ratio of every backward attempt, assembled from the chunks' shares of torchdiffeq's
+        seminorm max(|e_t|/tol, rms_y, rms_a), against the ratio the kernel's controller computed (2 % + 0.01)."""
+    front = _front()
+    B, L, C, H = 32768, 128, 8, 32
+    x = make_series(B, L, C, seed=0)
+    z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(0))
+    func = LinearField(H, C, scale=0.25, seed=0).to(DEV)
+    X = native.LinearInterpolation(native.linear_interpolation_coeffs(x.to(DEV)))
+    zd = z0.to(DEV).requires_grad_(True)
+    front.record_dopri5_steps = True
+    try:
+        out = native.cdeint(X, func, zd, X.interval, method="dopri5", rtol=1e-4, atol=1e-6, options=dict(jump_t=X.grid_points),
+                            adjoint_options=dict(norm="seminorm", jump_t=X.grid_points))
+        _expect_dispatch("affine_dopri5", out)
+        fwd = dict(front.last_dopri5_stats)
+        out[:, -1].sum().backward()
+        bwd = dict(front.last_dopri5_adjoint_stats)
+    finally:
+        front.record_dopri5_steps = False
+    assert fwd["n_accept"] >= L - 1 and bwd["n_accept"] >= L - 1 and len(bwd["attempts"]) == 1
+    attempts = bwd["attempts"][0]
+    assert len(attempts) == bwd["n_accept"] + bwd["n_reject"]
+    knots = torch.arange(L, dtype=torch.float64)
+    ref, gz, f64, shares = _chunked_oracle_replay(
+        lambda: LinearField(H, C, torch.float64, scale=0.25, seed=0),
+        lambda lo, hi: oracle_interp.LinearPath(x[lo:hi].double()), z0, knots[[0, -1]], fwd["steps"], bwd["attempts"],
+        4096, dict(norm="seminorm"), probe_dims=H)
+    _close(out, ref, 1e-4, 1e-5)
+    _close(zd.grad, gz, 1e-3, 1e-4 * gz.abs().max().item())
+    gw, gb = f64.linear.weight.grad, f64.linear.bias.grad
+    _close(func.linear.weight.grad, gw, 1e-3, 1e-4 * gw.abs().max().item())
+    _close(func.linear.bias.grad, gb, 1e-3, 1e-4 * gb.abs().max().item())
+    # the whole batch's error ratio per attempt: vjp_t is a sum over series (its error and tolerance add up over the
+    # chunks), the state blocks are mean squares over all B*H elements
+    total = torch.stack(shares).sum(0)                                         # (attempts, 5)
+    e_t = total[:, 0].abs() / (1e-6 + 1e-4 * torch.max(total[:, 1].abs(), total[:, 2].abs()))
+    theirs = torch.stack([e_t, (total[:, 3] / (B * H)).sqrt(), (total[:, 4] / (B * H)).sqrt()]).max(0).values
+    mine = attempts[:, 4]
+    dev = (mine - theirs).abs() - (0.02 * theirs + 0.01)
+    assert dev.max() <= 0, "attempt %d: kernel ratio %.5g, oracle %.5g" % (dev.argmax(), mine[dev.argmax()], theirs[dev.argmax()])
+    assert torch.equal(attempts[:, 3] != 0, mine <= 1)
+
+
+def test_config4_default_mixed_norm_4096_series_against_the_oracle(native):
+    """VERDICT round 3, item 1b.  The same call WITHOUT adjoint_options -- torchdiffeq's default MIXED adjoint norm over
+    (vjp_t, y, a, dL/dW, dL/db), the setting under which the backward takes thousands of attempts -- on a 4096-series
+    shard (256 tiles: the workgroup-per-tile range of K4a, every attempt followed by the R kernel's commit / norm over the
+    parameter blocks).  One oracle chunk holds the whole batch, so its mixed-norm error ratios ARE the batch's: every
+    ACCEPTED attempt and the rejected ones among the first 400 attempts are re-made by the float64 oracle from its own
+    state (ratios 2 % + 0.01, decisions where the ratio is clear of 1); trajectories and all gradients rtol 1e-3."""
+    front = _front()
+    B, L, C, H = 4096, 128, 8, 32
+    x = make_series(B, L, C, seed=0)
+    z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(0))
+    func = LinearField(H, C, scale=0.25, seed=0).to(DEV)
+    X = native.LinearInterpolation(native.linear_interpolation_coeffs(x.to(DEV)))
+    zd = z0.to(DEV).requires_grad_(True)
+    front.record_dopri5_steps = True
+    try:
+        out = native.cdeint(X, func, zd, X.interval, method="dopri5", rtol=1e-4, atol=1e-6, options=dict(jump_t=X.grid_points))
+        fwd = dict(front.last_dopri5_stats)
+        out[:, -1].sum().backward()
+        bwd = dict(front.last_dopri5_adjoint_stats)
+    finally:
+        front.record_dopri5_steps = False
+    attempts = bwd["attempts"][0]
+    n_all = bwd["n_accept"] + bwd["n_reject"]
+    assert len(attempts) == n_all <= 16384, "attempt trace overflowed: %d" % n_all
+    keep = (attempts[:, 3] != 0) | (torch.arange(len(attempts)) < 400)
+    kept = attempts[keep]
+    knots = torch.arange(L, dtype=torch.float64)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(_oracle_threads())
+    try:
+        f64 = LinearField(H, C, torch.float64, scale=0.25, seed=0)
+        Xo = oracle_interp.LinearPath(x.double())
+        zo = z0.double().requires_grad_(True)
+        with _oracle_solver_log() as solvers:
+            ref = oracle_cde.cdeint(Xo, f64, zo, knots[[0, -1]], adjoint=True, method="dopri5", rtol=1e-4, atol=1e-6,
+                                    options=dict(replay_steps=fwd["steps"]), adjoint_options=dict(replay_attempts=[kept.clone()]))
+            ref[:, -1].sum().backward()
+    finally:
+        torch.set_num_threads(threads)
+    theirs = torch.tensor(solvers[1].ratios, dtype=torch.float64)
+    mine, accepted = kept[:, 4], kept[:, 3] != 0
+    assert len(theirs) == len(mine)
+    inside = (mine - theirs).abs() <= 0.02 * theirs + 0.01
+    assert inside.double().mean() >= 0.995, "%d of %d error ratios leave the band (worst: kernel %.5g oracle %.5g)" % (
+        (~inside).sum(), len(inside), mine[(mine - theirs).abs().argmax()], theirs[(mine - theirs).abs().argmax()])
+    clear = inside & ((theirs - 1).abs() > 0.03)
+    assert torch.equal(accepted[clear], (theirs <= 1)[clear])
+    first = float(attempts[0, 1] - attempts[0, 0])
+    assert abs(first - float(solvers[1].first_dt)) <= 1e-3 * float(solvers[1].first_dt)
+    _close(out, ref, 1e-4, 1e-5)
+    _close(zd.grad, zo.grad, 1e-3, 1e-4 * zo.grad.abs().max().item())
+    gw, gb = f64.linear.weight.grad, f64.linear.bias.grad
+    _close(func.linear.weight.grad, gw, 1e-3, 1e-4 * gw.abs().max().item())
+    _close(func.linear.bias.grad, gb, 1e-3, 1e-4 * gb.abs().max().item())
+
+
+@pytest.mark.parametrize("n_sub,form", [(2048, "split"), (8192, "eight_waves")])
+def test_config5_as_the_reference_calls_it_against_the_oracle(native, monkeypatch, n_sub, form):
+    """VERDICT round 3, item 1c.  Config 5 AS THE REFERENCE RUNS IT (example/logsignature_example.py:21-23: cdeint(X, func,
+    z0, X.interval) with no method -- dopri5, adjoint, default mixed norm over (vjp_t, y, a, dW1, db1, dW2, db2)), on a
+    sub-batch of the 32768 x 512 x 3 -> 65 x 14 logsignature control bench.py uses, hidden size 8, width 128:
+      * 2048 series: the split forms (four / eight waves share a tile) of K4 and K4am;
+      * 8192 series with CDE_K4AM_WAVES=8: the one-wave-per-tile forward kernel and the 8-wave K4am form with its
+        multi-slab factor reduction -- the kernels the 32768-series bench line runs.
+    The float64 oracle replays the kernels' forward steps and their accepted backward steps (2048: every attempt, so its
+    mixed-norm error ratios are the batch's and are compared as well); trajectories rtol 1e-4, dL/dz0 and all FOUR
+    parameter gradients 2e-3."""
+    from oracle import logsig as oracle_logsig
+    if form == "eight_waves":
+        monkeypatch.setenv("CDE_K4AM_WAVES", "8")
+    front = _front()
+    B, L, C, H, width = 32768, 512, 3, 8, 128
+    gen = torch.Generator().manual_seed(1)
+    raw = (torch.randn(B, L, C, generator=gen) * 0.1).cumsum(1)
+    raw[..., 0] = torch.linspace(0, 1, L)
+    z8 = torch.randn(B, H, generator=gen)
+    raw, z8 = raw[:n_sub], z8[:n_sub]
+    logsig = native.logsig_windows(raw.to(DEV), 3, 8.0)
+    assert logsig.shape == (n_sub, 65, 14)
+    X = native.LinearInterpolation(native.linear_interpolation_coeffs(logsig))
+    func = _TwoLayerField(H, 14, width, seed=0).to(DEV)
+    zd = z8.to(DEV).requires_grad_(True)
+    front.record_dopri5_steps = True
+    try:
+        out = native.cdeint(X, func, zd, X.interval)                              # the example's call
+        _expect_dispatch("two_layer_dopri5", out)
+        fwd = dict(front.last_dopri5_stats)
+        out[:, -1].sum().backward()
+        bwd = dict(front.last_dopri5_adjoint_stats)
+    finally:
+        front.record_dopri5_steps = False
+    attempts = bwd["attempts"][0]
+    assert len(attempts) == bwd["n_accept"] + bwd["n_reject"] <= 16384
+    every = n_sub <= 2048
+    kept = attempts if every else attempts[attempts[:, 3] != 0]
+    threads = torch.get_num_threads()
+    torch.set_num_threads(_oracle_threads())
+    try:
+        ref_logsig = oracle_logsig.logsig_windows(raw.double(), 3, 8.0)
+        f64 = _TwoLayerField(H, 14, width, torch.float64, seed=0)
+        Xo = oracle_interp.LinearPath(ref_logsig)
+        zo = z8.double().requires_grad_(True)
+        with _oracle_solver_log() as solvers:
+            ref = oracle_cde.cdeint(Xo, f64, zo, Xo.interval, adjoint=True, method="dopri5",
+                                    options=dict(replay_steps=fwd["steps"]), adjoint_options=dict(replay_attempts=[kept.clone()]))
+            ref[:, -1].sum().backward()
+    finally:
+        torch.set_num_threads(threads)
+    _close(logsig, ref_logsig, 1e-4, 1e-5)
+    if every:
+        theirs = torch.tensor(solvers[1].ratios, dtype=torch.float64)
+        mine, accepted = kept[:, 4], kept[:, 3] != 0
+        inside = (mine - theirs).abs() <= 0.02 * theirs + 0.01
+        assert inside.double().mean() >= 0.97, "only %.1f %% of the error ratios match" % (100 * inside.double().mean())
+        clear = inside & ((theirs - 1).abs() > 0.03)
+        assert torch.equal(accepted[clear], (theirs <= 1)[clear])
+        first = float(attempts[0, 1] - attempts[0, 0])
+        assert abs(first - float(solvers[1].first_dt)) <= 1e-3 * float(solvers[1].first_dt)
+    _close(out, ref, 1e-4, 2e-5)
+    _close(zd.grad, zo.grad, 2e-3, 1e-3 * zo.grad.abs().max().item())
+    for (name, got), want in zip(func.named_parameters(), f64.parameters()):
+        _close(got.grad, want.grad, 2e-3, 2e-3 * want.grad.abs().max().item())
+
+
+def test_two_layer_default_call_over_several_rounds_of_shared_tiles(native):
+    """The shared-tile forms of the two-layer adaptive kernels BEYOND one round of workgroups: 6000 series of the example
+    model's shape (8 channels, hidden 32, width 128) are 375 tiles -- the forward kernel (eight waves share a tile, up to
+    DOPRI_MLP_SPLIT_TILES = 768) and dopri5_mlp_adjoint_attempt_s8 (up to MADJ_S8_MAX_TILES = 768) run them as 375
+    workgroups on 256 CUs, with the 42-block fused reduction replaced by the split-K factor reduction + R kernel (> 128
+    series).  The float64 oracle replays the kernels' forward steps and every backward attempt (seminorm) in three
+    2000-series chunks: trajectories rtol 1e-4, dL/dz0 and the four parameter gradients 2e-3; the whole batch's error
+    ratio per attempt is assembled from the chunks' shares."""
+    front = _front()
+    B, L, C, H, width = 6000, 17, 8, 32, 128
+    x = make_series(B, L, C, seed=11)
+    z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(11))
+    func = _TwoLayerField(H, C, width, seed=5).to(DEV)
+    X = native.LinearInterpolation(native.linear_interpolation_coeffs(x.to(DEV)))
+    zd = z0.to(DEV).requires_grad_(True)
+    adj = dict(norm="seminorm")
+    front.record_dopri5_steps = True
+    try:
+        out = native.cdeint(X, func, zd, X.interval, adjoint_options=adj, rtol=1e-4, atol=1e-6)
+        _expect_dispatch("two_layer_dopri5", out)
+        fwd = dict(front.last_dopri5_stats)
+        out[:, -1].sum().backward()
+        bwd = dict(front.last_dopri5_adjoint_stats)
+    finally:
+        front.record_dopri5_steps = False
+    attempts = bwd["attempts"][0]
+    assert len(attempts) == bwd["n_accept"] + bwd["n_reject"] <= 16384
+    outs, gz, f64, shares = _chunked_oracle_replay(
+        lambda: _TwoLayerField(H, C, width, torch.float64, seed=5),
+        lambda lo, hi: oracle_interp.LinearPath(x[lo:hi].double()),
+        z0, torch.tensor([0., L - 1.]), fwd["steps"], [attempts], 2000, adj, probe_dims=H)
+    total = torch.stack(shares).sum(0)                                         # (attempts, 5): see the config-4 test above
+    e_t = total[:, 0].abs() / (1e-6 + 1e-4 * torch.max(total[:, 1].abs(), total[:, 2].abs()))
+    theirs = torch.stack([e_t, (total[:, 3] / (B * H)).sqrt(), (total[:, 4] / (B * H)).sqrt()]).max(0).values
+    mine, accepted = attempts[:, 4], attempts[:, 3] != 0
+    inside = (mine - theirs).abs() <= 0.02 * theirs + 0.01
+    assert inside.double().mean() >= 0.97, "only %.1f %% of the error ratios match" % (100 * inside.double().mean())
+    clear = inside & ((theirs - 1).abs() > 0.03)
+    assert torch.equal(accepted[clear], (theirs <= 1)[clear])
+    _close(out, outs, 1e-4, 2e-5)
+    # a relu field is only piecewise smooth: a series whose float32 and float64 states sit on different sides of a kink at
+    # some stage sees a visibly different gradient -- per series, 99.5 % within 2e-3, every one within 1e-2
+    worst = ((zd.grad.double().cpu() - gz).abs() / (1e-3 * gz.abs().max() + 2e-3 * gz.abs())).max(1).values
+    assert (worst <= 1).double().mean() >= 0.995 and worst.max() <= 5, "dL/dz0: %d series beyond tolerance, worst %.3g x" % (
+        (worst > 1).sum(), worst.max())
+    for (name, got), want in zip(func.named_parameters(), f64.parameters()):
+        _close(got.grad, want.grad, 2e-3, 2e-3 * want.grad.abs().max().item())
+
+
+def test_config3_full_batch_against_the_oracle(native):
+    """BASELINE configs[2] at its configured size, EVERY number against the float64 oracle: all 32768 trajectories, all
+    of dL/dz0, and the parameter gradients dL/dW, dL/db (sums over the whole batch -- the 1,024-tile partial reduction
+    of K3 and the 256-tile one of the split kernels at B = 4096 are thereby oracle-checked at size).  The oracle runs
+    in eight 4096-series chunks (cache friendly: ~20 s on 16 threads)."""
+    B, L, C, H = 32768, 128, 8, 32
+    x = make_series(B, L, C, seed=0)
+    z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(0))
+    kw = dict(method="rk4", options=dict(step_size=1.0))
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, max(1, (os.cpu_count() or 1))))
+    try:
+        f64 = LinearField(H, C, torch.float64, scale=0.25, seed=0)
+        ref_out, ref_gz = [], []
+        for lo in range(0, B, 4096):
+            Xo = oracle_interp.CubicPath(oracle_interp.hermite_bdiff_coeffs(x[lo:lo + 4096].double()))
+            zo = z0[lo:lo + 4096].double().requires_grad_(True)
+            o = oracle_cde.cdeint(Xo, f64, zo, Xo.interval, adjoint=True, **kw)
+            o[:, -1].sum().backward()                       # parameter gradients accumulate over the chunks
+            ref_out.append(o.detach())
+            ref_gz.append(zo.grad)
+        ref_out, ref_gz = torch.cat(ref_out), torch.cat(ref_gz)
+        ref_gw, ref_gb = f64.linear.weight.grad, f64.linear.bias.grad
+    finally:
+        torch.set_num_threads(threads)
+
+    coeffs = native.hermite_cubic_coefficients_with_backward_differences(x.to(DEV))
+    X = native.CubicSpline(coeffs)
+    func = LinearField(H, C, scale=0.25, seed=0).to(DEV)
+    z = z0.to(DEV).requires_grad_(True)
+    out = native.cdeint(X, func, z, X.interval, **kw)                      # K2 + K3
+    out[:, -1].sum().backward()
+    _close(out, ref_out, 1e-4, 1e-5)
+    _close(z.grad, ref_gz, 1e-3, 1e-5)
+    _close(func.linear.weight.grad, ref_gw, 1e-3, 1e-4 * ref_gw.abs().max().item())
+    _close(func.linear.bias.grad, ref_gb, 1e-3, 1e-4 * ref_gb.abs().max().item())
+
+    # the same job as 8 GPUs would run it (strong scaling): 4096-series shards on the workgroup-per-tile kernels,
+    # parameter gradients summed over the shards (what the all-reduce does)
+    gw = torch.zeros_like(func.linear.weight)
+    gb = torch.zeros_like(func.linear.bias)
+    for lo in range(0, B, 4096):
+        f = LinearField(H, C, scale=0.25, seed=0).to(DEV)
+        zz = z0[lo:lo + 4096].to(DEV).requires_grad_(True)
+        o = native.cdeint(native.CubicSpline(coeffs[lo:lo + 4096].contiguous()), f, zz, X.interval, **kw)
+        o[:, -1].sum().backward()
+        _close(o, ref_out[lo:lo + 4096], 1e-4, 1e-5)
+        _close(zz.grad, ref_gz[lo:lo + 4096], 1e-3, 1e-5)
+        gw += f.linear.weight.grad
+        gb += f.linear.bias.grad
+    _close(gw, ref_gw, 1e-3, 1e-4 * ref_gw.abs().max().item())
+    _close(gb, ref_gb, 1e-3, 1e-4 * ref_gb.abs().max().item())
+
+
+def test_config4_shard_dopri5_with_the_batch_step_sequence(native):
+    """BASELINE configs[3], one GPU's shard at its configured size: 32768 series, L = 128, LinearInterpolation control,
+    dopri5 with the reference's default tolerances and jump_t at the knots.  torchdiffeq's controller is batch-global,
+    so a SAMPLE of the batch cannot be re-solved on its own: the kernel exports the accepted (t0, t1) sequence of the
+    whole batch and the float64 oracle replays exactly those steps on 256 sampled series."""
+    import sys
+    front = sys.modules["torchcde_amd.cdeint"]            # the module (the package attribute of that name is the function)
+    B, L, C, H = 32768, 128, 8, 32
+    x = make_series(B, L, C, seed=4)
+    z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(4))
+    func = LinearField(H, C, scale=0.25, seed=0)
+    X = native.LinearInterpolation(native.linear_interpolation_coeffs(x.to(DEV)))
+    t_out = torch.tensor([0., 40.5, 127.])
+    front.record_dopri5_steps = True
+    try:
+        with torch.no_grad():
+            out = native.cdeint(X, func.to(DEV), z0.to(DEV), t_out.to(DEV), options=dict(jump_t=X.grid_points))   # default method
+        stats = dict(front.last_dopri5_stats)
+    finally:
+        front.record_dopri5_steps = False
+    steps = stats["steps"]
+    assert out.shape == (B, 3, H) and torch.isfinite(out).all()
+    assert steps.shape == (stats["n_accept"], 3) and stats["n_accept"] >= L - 1
+    assert steps[0, 0] == 0 and steps[-1, 1] >= 127 and torch.equal(steps[1:, 0], steps[:-1, 1])      # contiguous
+    knots = torch.arange(L, dtype=torch.float64)
+    assert all(bool((steps[:, 1] == k).any()) for k in knots[1:])                                     # lands on every knot
+    sample = torch.arange(0, B, 128)
+    f64 = LinearField(H, C, torch.float64, scale=0.25, seed=0)
+    Xo = oracle_interp.LinearPath(x[sample].double())
+    with torch.no_grad():
+        ref = oracle_cde.cdeint(Xo, f64, z0[sample].double(), t_out.double(), adjoint=False, method="dopri5",
+                                options=dict(jump_t=Xo.grid_points, replay_steps=steps))
+    _close(out[sample.to(DEV)], ref, 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize("H", [8, 32])
+def test_config5_log_ode_pipeline_at_size(native, H):
+    """BASELINE configs[4] at its configured size on one GPU: 32768 series, L = 512, 3 channels -> depth-3
+    logsignatures over windows of 8 (65 x 14), LinearInterpolation, two-layer field (width 128), rk4, adjoint.
+    Sampled series against the float64 oracle (logsignature transform, trajectory, dL/dz0); parameter gradients
+    through additivity over two half batches and, on a 2048-series sub-batch, all four against the float64 oracle.
+    H = 8 is the reference example's hidden size (example/logsignature_example.py:22): the 14-channel control then
+    fits the 16 x 16 tiles of the fused two-layer kernels; H = 32 with 14 channels is solved step by step."""
+    from oracle import logsig as oracle_logsig
+    B, L, C, width = 32768, 512, 3, 128
+    gen = torch.Generator().manual_seed(77)
+    x = (torch.randn(B, L, C, generator=gen) * 0.1).cumsum(1)
+    x[..., 0] = torch.linspace(0, 1, L)
+    z0 = torch.randn(B, H, generator=gen) * 0.5
+    logsig = native.logsig_windows(x.to(DEV), 3, 8.0)
+    assert logsig.shape == (B, 65, 14)
+    sample = torch.arange(0, B, 1024)
+    ref_logsig = oracle_logsig.logsig_windows(x[sample].double(), 3, 8.0)
+    _close(logsig[sample.to(DEV)], ref_logsig, 1e-4, 1e-5)
+    coeffs = native.linear_interpolation_coeffs(logsig)
+    X = native.LinearInterpolation(coeffs)
+    kw = dict(method="rk4", options=dict(step_size=1.0))
+
+    def solve(lo, hi):
+        f = _TwoLayerField(H, 14, width, seed=15).to(DEV)
+        z = z0[lo:hi].to(DEV).requires_grad_(True)
+        Xs = X if (lo, hi) == (0, B) else native.LinearInterpolation(coeffs[lo:hi].contiguous())
+        o = native.cdeint(Xs, f, z, X.interval, **kw)
+        _expect_dispatch("two_layer_rk4" if H <= 16 else "two_layer_beyond_tiles", o)
+        o[:, -1].sum().backward()
+        return o.detach(), z.grad, [p.grad.clone() for p in f.parameters()]
+
+    out, gz, gp = solve(0, B)
+    assert out.shape == (B, 2, H) and torch.isfinite(out).all()
+    fo = _TwoLayerField(H, 14, width, torch.float64, seed=15)
+    Xo = oracle_interp.LinearPath(ref_logsig)
+    zo = z0[sample].double().requires_grad_(True)
+    ref = oracle_cde.cdeint(Xo, fo, zo, Xo.interval, adjoint=True, **kw)
+    ref[:, -1].sum().backward()
+    _close(out[sample.to(DEV)], ref, 1e-4, 2e-5)
+    _close(gz[sample.to(DEV)], zo.grad, 2e-3, 2e-3 * zo.grad.abs().max().item())
+    # parameter gradients are sums over series: two half batches add up to the full batch ...
+    _, _, ga = solve(0, B // 2)
+    _, _, gb2 = solve(B // 2, B)
+    for full, a, b in zip(gp, ga, gb2):
+        _close(a + b, full, 1e-3, 1e-3 * full.abs().max().item())
+    # ... and (not only the kernel against itself) all FOUR parameter gradients of a contiguous
+    # 2048-series sub-batch against the float64 oracle on the same series
+    n_sub = 2048
+    _, _, g_sub = solve(0, n_sub)
+    sub_logsig = oracle_logsig.logsig_windows(x[:n_sub].double(), 3, 8.0)
+    fs = _TwoLayerField(H, 14, width, torch.float64, seed=15)
+    Xs = oracle_interp.LinearPath(sub_logsig)
+    zs = z0[:n_sub].double().requires_grad_(True)
+    oracle_cde.cdeint(Xs, fs, zs, Xs.interval, adjoint=True, **kw)[:, -1].sum().backward()
+    for (name, want), got in zip(fs.named_parameters(), g_sub):
+        _close(got, want.grad, 2e-3, 2e-3 * want.grad.abs().max().item())
+
+
+def test_full_size_properties_config2_config3(native):
+    """BASELINE configs 2/3 (B=32768, L=128, C=8, H=32, fp32, RK4 step 1): size-independent properties.
+      * series independence: reversing the batch reverses the result bit-for-bit
+      * affine structure: z_T is an affine map of z0 for the affine field, RK4 preserves that
+      * MFMA kernel == generic kernel == float64 oracle on a sample of series (trajectory + grad_z0)
+      * parameter gradients of the two kernels agree"""
+    B, L, C, H = 32768, 128, 8, 32
+    x = make_series(B, L, C, seed=0).to(DEV)
+    coeffs = native.hermite_cubic_coefficients_with_backward_differences(x)
+    X = native.CubicSpline(coeffs)
+    func = LinearField(H, C, scale=0.25, seed=0).to(DEV)
+    z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(0)).to(DEV)
+    kw = dict(method="rk4", options=dict(step_size=1.0))
+
+    z = z0.clone().requires_grad_(True)
+    out = native.cdeint(X, func, z, X.interval, **kw)
+    assert out.shape == (B, 2, H) and torch.isfinite(out).all()
+    assert torch.equal(out[:, 0], z0)
+    out[:, -1].sum().backward()
+    gW, gb, gz = func.linear.weight.grad.clone(), func.linear.bias.grad.clone(), z.grad.clone()
+
+    # series independence (bit-exact)
+    Xr = native.CubicSpline(coeffs.flip(0).contiguous())
+    out_r = native.cdeint(Xr, func, z0.flip(0).contiguous(), X.interval, **kw)
+    assert torch.equal(out_r.flip(0), out.detach())
+
+    # affine in z0: z(a) + z(b) - 2 z((a+b)/2) = 0
+    zb = torch.randn(B, H, generator=torch.Generator().manual_seed(1)).to(DEV)
+    mid = native.cdeint(X, func, 0.5 * (z0 + zb), X.interval, **kw)[:, -1]
+    other = native.cdeint(X, func, zb, X.interval, **kw)[:, -1]
+    resid = (out.detach()[:, -1] + other - 2 * mid).abs().max().item()
+    assert resid < 1e-4 * max(1.0, out.detach().abs().max().item()), resid
+
+    # sample vs float64 oracle and vs the generic kernel
+    sample = torch.arange(0, B, 2048, device=DEV)
+    Xs = native.CubicSpline(coeffs[sample].contiguous())
+    zs = z0[sample].clone().requires_grad_(True)
+    func_g = LinearField(H, C, scale=0.25, seed=0).to(DEV)
+    out_g = native.cdeint(Xs, func_g, zs, X.interval, variant="generic", **kw)
+    _close(out.detach()[sample], out_g, 1e-4, 1e-5)
+    out_g[:, -1].sum().backward()
+    _close(gz[sample], zs.grad, 1e-3, 1e-5)
+    lw = torch.cat([torch.zeros(len(sample), 1, H), torch.ones(len(sample), 1, H)], 1)
+    ref_out, ref_gz, _, _ = _oracle_solution(coeffs[sample].cpu(), None, LinearField(H, C, scale=0.25, seed=0),
+                                             z0[sample].cpu(), X.interval.cpu(), 1.0, lw)
+    _close(out.detach()[sample], ref_out, 1e-4, 1e-5)
+    _close(gz[sample], ref_gz, 1e-3, 1e-5)
+    # calibration: how far is the CPU float32 path (the reference's own arithmetic) from float64?
+    cpu32 = oracle_cde.cdeint(oracle_interp.CubicPath(coeffs[sample].cpu()), LinearField(H, C, scale=0.25, seed=0),
+                              z0[sample].cpu(), X.interval.cpu(), adjoint=False, method="rk4",
+                              options=dict(step_size=1.0))
+    err_cpu32 = (cpu32.double() - ref_out).abs().max().item()
+    err_kernel = (out.detach()[sample].double().cpu() - ref_out).abs().max().item()
+    assert err_kernel <= 4 * err_cpu32 + 1e-6, (err_kernel, err_cpu32)
+
+    # parameter gradients: MFMA kernel vs generic kernel on a 4096-series slab
+    slab = slice(0, 4096)
+    res = []
+    for variant in ("mfma", "generic"):
+        f = LinearField(H, C, scale=0.25, seed=0).to(DEV)
+        zz = z0[slab].clone().requires_grad_(True)
+        o = native.cdeint(native.CubicSpline(coeffs[slab].contiguous()), f, zz, X.interval, variant=variant, **kw)
+        o[:, -1].sum().backward()
+        res.append((f.linear.weight.grad.clone(), f.linear.bias.grad.clone()))
+    _close(res[0][0], res[1][0], 1e-3, 1e-4 * res[1][0].abs().max().item())
+    _close(res[0][1], res[1][1], 1e-3, 1e-4 * res[1][1].abs().max().item())
+    assert torch.isfinite(gW).all() and torch.isfinite(gb).all()
+
+
+def test_full_size_properties_nonlinear_fields(native):
+    """The same B=32768, L=128 workload with the examples' vector fields (tanh field; two-layer field, width 128):
+      * series independence: reversing the batch reverses trajectories and dL/dz0 bit-for-bit (all per-series
+        arithmetic is order independent); parameter gradients agree to rounding (their reduction order changes)
+      * a sample of series against the float64 oracle (trajectory and dL/dz0, self-calibrated on the CPU float32 run)
+      * the two tanh kernels (MFMA tiles vs VALU) agree on a slab."""
+    B, L, C, H = 32768, 128, 8, 32
+    x = make_series(B, L, C, seed=0).to(DEV)
+    coeffs = native.hermite_cubic_coefficients_with_backward_differences(x)
+    X = native.CubicSpline(coeffs)
+    Xr = native.CubicSpline(coeffs.flip(0).contiguous())
+    z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(0)).to(DEV)
+    kw = dict(method="rk4", options=dict(step_size=1.0))
+    sample = torch.arange(0, B, 4096)
+    fields = {"tanh": lambda dtype: LinearField(H, C, dtype, scale=0.5, tanh=True, seed=2),
+              "two_layer": lambda dtype: _TwoLayerField(H, C, 128, dtype, seed=2)}
+    for name, make in fields.items():
+        func, func_r = make(torch.float32).to(DEV), make(torch.float32).to(DEV)
+        z = z0.clone().requires_grad_(True)
+        out = native.cdeint(X, func, z, X.interval, **kw)
+        _expect_dispatch("affine_rk4" if name == "tanh" else "two_layer_rk4", out)
+        out[:, -1].square().sum().backward()
+        zr = z0.flip(0).contiguous().requires_grad_(True)
+        out_r = native.cdeint(Xr, func_r, zr, X.interval, **kw)
+        out_r[:, -1].square().sum().backward()
+        assert torch.isfinite(out).all() and torch.equal(out_r.detach().flip(0), out.detach()), name
+        assert torch.equal(zr.grad.flip(0), z.grad), name
+        for p, pr in zip(func.parameters(), func_r.parameters()):
+            _close(pr.grad, p.grad, 1e-3, 1e-4 * p.grad.abs().max().item())
+        # sample vs float64 (and CPU float32 for calibration)
+        f64, f32 = make(torch.float64), make(torch.float32)
+        cs = coeffs[sample.to(DEV)].cpu()
+        z64 = z0[sample.to(DEV)].cpu().double().requires_grad_(True)
+        ref = oracle_cde.cdeint(oracle_interp.CubicPath(cs.double()), f64, z64, X.interval.cpu().double(), adjoint=True, **kw)
+        ref[:, -1].square().sum().backward()
+        z32 = z0[sample.to(DEV)].cpu().requires_grad_(True)
+        cpu32 = oracle_cde.cdeint(oracle_interp.CubicPath(cs), f32, z32, X.interval.cpu(), adjoint=True, **kw)
+        cpu32[:, -1].square().sum().backward()
+        got, got_g = out.detach()[sample.to(DEV)].double().cpu(), z.grad[sample.to(DEV)].double().cpu()
+        err, err32 = (got - ref.detach()).abs().max().item(), (cpu32.detach().double() - ref.detach()).abs().max().item()
+        assert err <= 4 * err32 + 1e-5, (name, err, err32)
+        gerr, gerr32 = (got_g - z64.grad).abs().max().item(), (z32.grad.double() - z64.grad).abs().max().item()
+        assert gerr <= 4 * gerr32 + 1e-3 * z64.grad.abs().max().item(), (name, gerr, gerr32)
+    # tanh: MFMA tiles vs VALU kernel on a 2048-series slab
+    slab = slice(0, 2048)
+    Xs = native.CubicSpline(coeffs[slab].contiguous())
+    f = fields["tanh"](torch.float32).to(DEV)
+    with torch.no_grad():
+        a = native.cdeint(Xs, f, z0[slab], X.interval, variant="mfma", **kw)
+        b = native.cdeint(Xs, f, z0[slab], X.interval, variant="generic", **kw)
+    _close(a, b, 1e-4, 1e-5)
+
+
+def test_affine_field_adjoint_forms_at_benchmark_size(native, monkeypatch):
+    """The headline workload (32768 x 128 x 8, H = 32) through both reverse-sweep forms of the affine field, every SIMD of
+    the chip busy: finite, run-to-run bit-identical (K3j's Jacobian rows are hand-scheduled asm MFMAs: a hazard would
+    show up here, as it did for the bf16 rows before they got their wait states), and the two forms within 1e-5 of each
+    other's scale (the oracle comparison at this size is test_config3_full_batch_against_the_oracle)."""
+    B, L, C, H = 32768, 128, 8, 32
+    x = make_series(B, L, C, seed=0).to(DEV)
+    X = native.CubicSpline(native.hermite_cubic_coefficients_with_backward_differences(x))
+    z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(0)).to(DEV)
+    res = {}
+    for form in ("jacobian", "jacobian", "jacobian", "product"):
+        monkeypatch.setenv("CDE_K3_FORM", form)
+        f = LinearField(H, C, scale=0.25, seed=0).to(DEV)
+        z = z0.clone().requires_grad_(True)
+        out = native.cdeint(X, f, z, X.interval, method="rk4", options=dict(step_size=1.0), variant="mfma")
+        out[:, -1].sum().backward()
+        res.setdefault(form, []).append((z.grad, f.linear.weight.grad, f.linear.bias.grad))
+    for t in res["jacobian"][0]:
+        assert torch.isfinite(t).all()
+    for other in res["jacobian"][1:]:
+        for a_, b_ in zip(res["jacobian"][0], other):
+            assert torch.equal(a_, b_)
+    for a_, b_ in zip(res["jacobian"][0], res["product"][0]):
+        _close(a_, b_, 1e-5, 1e-5 * b_.abs().max().item())
+
+
+def test_bf16x3_variant_at_benchmark_size_and_unsupported_requests(native):
+    """The headline workload (32768 x 128 x 8, H = 32) through variant="bf16x3" against the exact-f32 kernels: all
+    trajectories, dL/dz0 and the parameter gradients to 1e-5 of their scale (both are float32 computations of the same
+    thing); run-to-run bit-identical; and the requests the variant does not cover are refused, not silently redirected."""
+    B, L, C, H = 32768, 128, 8, 32
+    x = make_series(B, L, C, seed=0).to(DEV)
+    X = native.CubicSpline(native.hermite_cubic_coefficients_with_backward_differences(x))
+    z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(0)).to(DEV)
+    res = {}
+    for variant in ("mfma", "bf16x3", "bf16x3"):
+        f = LinearField(H, C, scale=0.25, seed=0).to(DEV)
+        z = z0.clone().requires_grad_(True)
+        out = native.cdeint(X, f, z, X.interval, method="rk4", options=dict(step_size=1.0), variant=variant)
+        out[:, -1].sum().backward()
+        res.setdefault(variant, []).append((out.detach(), z.grad, f.linear.weight.grad, f.linear.bias.grad))
+    for a, b in zip(*res["bf16x3"]):
+        assert torch.equal(a, b)
+    for a, b in zip(res["bf16x3"][0], res["mfma"][0]):
+        _close(a, b, 1e-5, 1e-5 * b.abs().max().item())
+    tanh = LinearField(H, C, scale=0.25, tanh=True, seed=0).to(DEV)
+    with pytest.raises(NotImplementedError, match="bf16x3"):
+        native.cdeint(X, tanh, z0, X.interval, method="rk4", options=dict(step_size=1.0), variant="bf16x3")
+    with pytest.raises(NotImplementedError, match="bf16x3"):
+        native.cdeint(X, LinearField(H, C, scale=0.25, seed=0).to(DEV), z0, X.interval, variant="bf16x3")      # dopri5
+
+
+def test_tanh_field_small_batch_with_thousands_of_knots(native):
+    """the split forms of the one-layer adaptive kernel ask for knot buffer + tanh image + exchange
+    window = up to ~83 KB of LDS with 1280-5888 knots at B <= 4096 -- above the 64 KB a kernel gets unless the limit is
+    raised.  A tanh field on 3000- and 5600-knot controls, 48 series, against the generic attempt kernel."""
+    for L in (3000, 5600):
+        gen = torch.Generator().manual_seed(L)
+        x = (torch.randn(48, L, 6, generator=gen) * 0.02).cumsum(-2).to(DEV)
+        X = native.LinearInterpolation(native.linear_interpolation_coeffs(x))
+        t_out = torch.tensor([float(L - 400), float(L - 1)], dtype=torch.float64, device=DEV)
+        func = LinearField(32, 6, scale=0.05, tanh=True, seed=3).to(DEV)
+        z0 = torch.randn(48, 32, generator=gen).to(DEV)
+        res = {}
+        for variant in ("auto", "generic"):
+            with torch.no_grad():
+                res[variant] = native.cdeint(X, func, z0, t_out, variant=variant, rtol=1e-5, atol=1e-7,
+                                             options=dict(jump_t=X.grid_points))
+        _close(res["auto"], res["generic"], 5e-3, 5e-3 * res["generic"].abs().max().item())
+
+
+def test_two_layer_rk4_sweep_forms_agree_beyond_one_round_of_tiles(native, monkeypatch):
+    """Round 4: the rk4 adjoint sweep of the two-layer field runs eight waves per 16-series tile (rk4_adjoint_mlp_sweep_s8,
+    every evaluation split eight ways, the adjoint state distributed over the waves) up to 1536 tiles.  9000 series are 563
+    tiles -- more than two rounds of workgroups, a ragged last tile -- checked against the one-wave-per-tile form
+    (CDE_K3M_NO_SPLIT=1; itself checked against the float64 oracle at 32768 series) and, on a sample, against the oracle."""
+    B, L, C, H, width = 9000, 20, 8, 32, 128
+    x = make_series(B, L, C, seed=21)
+    z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(21))
+    X = native.CubicSpline(native.hermite_cubic_coefficients_with_backward_differences(x.to(DEV)))
+    kw = dict(method="rk4", options=dict(step_size=1.0))
+
+    def run():
+        f = _TwoLayerField(H, C, width, seed=4).to(DEV)
+        z = z0.to(DEV).requires_grad_(True)
+        out = native.cdeint(X, f, z, X.interval, **kw)
+        _expect_dispatch("two_layer_rk4", out)
+        out[:, -1].square().sum().backward()
+        return out.detach(), z.grad, [p.grad.clone() for p in f.parameters()]
+
+    out8, gz8, gp8 = run()
+    monkeypatch.setenv("CDE_K3M_NO_SPLIT", "1")
+    out1, gz1, gp1 = run()
+    _close(out8, out1, 1e-5, 1e-6)
+    _close(gz8, gz1, 1e-4, 1e-5 * gz1.abs().max().item())
+    for a, b in zip(gp8, gp1):
+        _close(a, b, 2e-4, 2e-4 * b.abs().max().item())
+    sample = torch.arange(0, B, 250)
+    f64 = _TwoLayerField(H, C, width, torch.float64, seed=4)
+    Xo = oracle_interp.CubicPath(oracle_interp.hermite_bdiff_coeffs(x[sample].double()))
+    zo = z0[sample].double().requires_grad_(True)
+    ref = oracle_cde.cdeint(Xo, f64, zo, Xo.interval, adjoint=True, **kw)
+    ref[:, -1].square().sum().backward()
+    _close(out8[sample.to(DEV)], ref, 1e-4, 1e-5)
+    _close(gz8[sample.to(DEV)], zo.grad, 2e-3, 1e-3 * zo.grad.abs().max().item())

@@ -1,0 +1,518 @@
+"""GPU parity tests through the C ABI -- Row a12: torchdiffeq.odeint_adjoint(method="dopri5") -- K4a (one-layer fields) and K4am (the examples' two-layer field).
+
+Tolerances and helpers: tests/gpu_common.py.  Collection order is the file order (01 first): the tests with the least driver history run first, so a failure elsewhere cannot hide them.
+"""
+import os
+
+import pytest
+import torch
+
+from gpu_common import (_expect_dispatch, oracle_cde, oracle_interp, LinearField, _TwoLayerField, make_series, DEV, _close, _front, _oracle_solver_log)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kind", ["two_layer", "two_layer_wide", "default_call"])
+def test_edge_cases_two_layer_and_adaptive_backward(native, kind):
+    """Single interval / single series / single output time for the two-layer kernels (32 x 8 and 16 x 16 tilings: K2m,
+    K3m + reduction) and for the reference's default call (dopri5 forward K4 + adaptive backward K4a)."""
+    gen = torch.Generator().manual_seed(len(kind))
+    H, C = {"two_layer": (12, 5), "two_layer_wide": (9, 13), "default_call": (32, 8)}[kind]
+    for B, L in ((1, 2), (19, 2), (2, 4)):
+        x = torch.randn(B, L, C, generator=gen)
+        coeffs = oracle_interp.hermite_bdiff_coeffs(x)
+        z0 = torch.randn(B, H, generator=gen)
+        if kind == "default_call":
+            func, f64 = LinearField(H, C, scale=0.3, seed=3).to(DEV), LinearField(H, C, torch.float64, scale=0.3, seed=3)
+            kw = dict(rtol=1e-6, atol=1e-8)
+            okw = dict(method="dopri5", adjoint_options=dict(norm="seminorm"), **kw)
+            expect = "affine_dopri5"
+        else:
+            func, f64 = _TwoLayerField(H, C, 48, seed=3).to(DEV), _TwoLayerField(H, C, 48, torch.float64, seed=3)
+            kw = dict(method="rk4", options=dict(step_size=0.5))
+            okw = kw
+            expect = "two_layer_rk4"
+        X, Xo = native.CubicSpline(coeffs.to(DEV)), oracle_interp.CubicPath(coeffs.double())
+        for t_out in (torch.tensor([0., float(L - 1)]), torch.tensor([0., 0.3, float(L - 1)]), torch.tensor([0.])):
+            zr = z0.double().requires_grad_(True)
+            f64.zero_grad()
+            ref = oracle_cde.cdeint(Xo, f64, zr, t_out.double(), adjoint=True, **okw)
+            ref.sum().backward()
+            z = z0.to(DEV).requires_grad_(True)
+            func.zero_grad()
+            out = native.cdeint(X, func, z, t_out.to(DEV), **kw)
+            _expect_dispatch(expect, out)
+            out.sum().backward()
+            _close(out, ref, 1e-3, 1e-4)
+            _close(z.grad, zr.grad, 5e-3, 5e-3 * max(1.0, zr.grad.abs().max().item()))
+            for pd, po in zip(func.parameters(), f64.parameters()):
+                want = torch.zeros_like(po) if po.grad is None else po.grad
+                got = torch.zeros_like(pd) if pd.grad is None else pd.grad
+                _close(got, want, 5e-3, 5e-3 * max(1e-3, want.abs().max().item()))
+
+
+def test_two_layer_backward_uses_the_weights_of_its_forward(native):
+    """An in-place parameter update between forward and backward must trip autograd's version check (the weights are
+    saved tensors), not silently differentiate the new values."""
+    B, L, C, H = 33, 8, 8, 32
+    X = native.CubicSpline(native.hermite_cubic_coefficients_with_backward_differences(make_series(B, L, C, seed=2).to(DEV)))
+    func = _TwoLayerField(H, C, 64, seed=4).to(DEV)
+    z = torch.randn(B, H, device=DEV, requires_grad=True)
+    out = native.cdeint(X, func, z, X.interval, method="rk4", options=dict(step_size=1.0))
+    with torch.no_grad():
+        func.linear2.weight.mul_(1.5)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        out[:, -1].sum().backward()
+
+
+@pytest.mark.parametrize("act,degree", [(False, 1), (True, 3)])
+def test_dopri5_adjoint_fused_replayed_through_the_oracle(native, act, degree):
+    """The reference's DEFAULT training call -- cdeint(X, func, z0, t) with no method, adjoint=True -- runs fused in both
+    directions.  The kernels export the accepted steps of the forward solve and of the backward sweep; the float64
+    oracle (torchdiffeq's odeint_adjoint restated) takes exactly those steps, so trajectories and ALL gradients must
+    agree to float32 round-off, not merely to the solver tolerance."""
+    front = _front()
+    B, L, C, H = 203, 14, 8, 32
+    x = make_series(B, L, C, seed=61)
+    z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(61))
+    func = LinearField(H, C, scale=0.3, tanh=act, seed=6).to(DEV)
+    if degree == 1:
+        X = native.LinearInterpolation(native.linear_interpolation_coeffs(x.to(DEV)))
+        Xo = oracle_interp.LinearPath(x.double())
+    else:
+        X = native.CubicSpline(native.hermite_cubic_coefficients_with_backward_differences(x.to(DEV)))
+        Xo = oracle_interp.CubicPath(oracle_interp.hermite_bdiff_coeffs(x.double()))
+    zd = z0.to(DEV).requires_grad_(True)
+    front.record_dopri5_steps = True
+    try:
+        out = native.cdeint(X, func, zd, X.interval, options=dict(jump_t=X.grid_points))       # dopri5 + adjoint
+        fwd_steps = front.last_dopri5_stats["steps"]
+        out[:, -1].square().sum().backward()
+        bwd = dict(front.last_dopri5_adjoint_stats)
+    finally:
+        front.record_dopri5_steps = False
+    assert bwd["n_accept"] >= L - 1 and len(bwd["steps"]) == 1
+    bwd_steps = bwd["steps"][0]
+    assert bwd_steps[0, 0] == -(L - 1) and bwd_steps[-1, 1] == 0 and torch.equal(bwd_steps[1:, 0], bwd_steps[:-1, 1])
+
+    f64 = LinearField(H, C, torch.float64, scale=0.3, tanh=act, seed=6)
+    zo = z0.double().requires_grad_(True)
+    ref = oracle_cde.cdeint(Xo, f64, zo, Xo.interval, adjoint=True, method="dopri5",
+                            options=dict(jump_t=Xo.grid_points, replay_steps=fwd_steps),
+                            adjoint_options=dict(jump_t=Xo.grid_points, replay_steps=bwd_steps))
+    ref[:, -1].square().sum().backward()
+    _close(out, ref, 1e-4, 1e-5)
+    _close(zd.grad, zo.grad, 1e-3, 1e-4 * zo.grad.abs().max().item())
+    _close(func.linear.weight.grad, f64.linear.weight.grad, 1e-3, 1e-4 * f64.linear.weight.grad.abs().max().item())
+    _close(func.linear.bias.grad, f64.linear.bias.grad, 1e-3, 1e-4 * f64.linear.bias.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("case", ["cubic_tanh_multi_out", "linear_jumps", "cubic_seminorm", "cubic_identity_loose",
+                                  "linear_padded_crossing_knots"])
+def test_dopri5_adjoint_takes_torchdiffeqs_decisions(native, case):
+    """K4a must BE torchdiffeq's backward, not a relative of it -- default MIXED adjoint norm over
+    (vjp_t, y, a, dL/dW, dL/db) (or "seminorm"), the interval ends passed and interpolated.
+    Adaptive step sequences are chaotic in the last bits (the float32 and the float64 oracle already differ in their
+    reject counts), so the controller is pinned ATTEMPT BY ATTEMPT instead: the kernel traces every backward attempt it
+    made -- (t0, t1, clipped onto a jump, accepted, error ratio), rejected ones included -- and the float64 oracle
+    (oracle/odeint.py: the restated odeint_adjoint incl. its always-alive vjp_t) re-makes each of them from ITS state at
+    t0 under torchdiffeq's norm:
+      * the error ratio of every attempt agrees (2 % + a float32 noise floor of 0.01), so the accept / reject decision is
+        the oracle's whenever its ratio is not within 3 % of 1;
+      * the initial step of every output interval (Hairer's rule on the augmented state, parameter blocks included) is
+        the oracle's (1e-3);
+      * between attempts the step size follows torchdiffeq's update from the traced ratio (safety 0.9, ifactor 10,
+        dfactor 0.2, exponent 1/5), exactly;
+      * the last step of an interval passes its end unless a jump time sits there, and all gradients -- which include the
+        dense-output evaluation of (a, dL/dW, dL/db) at the interval ends -- agree with the oracle's to float32 round-off.
+    With jump times on the knots of a linear control the sequence is not chaotic, and the float32 oracle's OWN controller
+    must then take the same number of accepted and rejected steps."""
+    front = _front()
+    cfg = {"cubic_tanh_multi_out": dict(B=70, L=10, C=5, H=24, tanh=True, degree=3, t_out=[0., 3.6, 9.], jumps=False,
+                                        kw=dict(rtol=1e-5, atol=1e-7), adj={}),
+           "linear_jumps": dict(B=130, L=9, C=8, H=32, tanh=False, degree=1, t_out=None, jumps=True,
+                                kw=dict(rtol=1e-4, atol=1e-6), adj={}),
+           "cubic_seminorm": dict(B=50, L=8, C=6, H=20, tanh=True, degree=3, t_out=None, jumps=False,
+                                  kw=dict(rtol=1e-4, atol=1e-6), adj=dict(adjoint_options=dict(norm="seminorm"))),
+           "cubic_identity_loose": dict(B=64, L=12, C=8, H=32, tanh=False, degree=3, t_out=[0., 11.], jumps=False,
+                                        kw=dict(rtol=1e-3, atol=1e-5), adj={}),
+           # affine field + piecewise-linear control: K4a's chain waves work from cached Jacobian rows; no jump_t, so the
+           # steps cross knots and the rows are re-formed inside an attempt; zero-padded shape, two output intervals
+           "linear_padded_crossing_knots": dict(B=90, L=12, C=5, H=20, tanh=False, degree=1, t_out=[0., 4.5, 11.],
+                                                jumps=False, kw=dict(rtol=1e-4, atol=1e-6),
+                                                adj=dict(adjoint_options=dict(norm="seminorm")))}[case]
+    B, L, C, H, kw = cfg["B"], cfg["L"], cfg["C"], cfg["H"], cfg["kw"]
+    x = make_series(B, L, C, seed=len(case))
+    z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(len(case)))
+    t_out = None if cfg["t_out"] is None else torch.tensor(cfg["t_out"])
+    n_t = 2 if t_out is None else t_out.numel()
+    lw = torch.rand(B, n_t, H, generator=torch.Generator().manual_seed(3)) + 0.5
+    func = LinearField(H, C, scale=0.3, tanh=cfg["tanh"], seed=7).to(DEV)
+    X = (native.CubicSpline(native.hermite_cubic_coefficients_with_backward_differences(x.to(DEV))) if cfg["degree"] == 3
+         else native.LinearInterpolation(native.linear_interpolation_coeffs(x.to(DEV))))
+    zd = z0.to(DEV).requires_grad_(True)
+    times = X.interval if t_out is None else t_out.to(DEV)
+    opts = dict(options=dict(jump_t=X.grid_points)) if cfg["jumps"] else {}
+    front.record_dopri5_steps = True
+    try:
+        out = native.cdeint(X, func, zd, times, **opts, **cfg["adj"], **kw)
+        _expect_dispatch("affine_dopri5", out)
+        fwd = dict(front.last_dopri5_stats)
+        (out * lw.to(DEV)).sum().backward()
+        bwd = dict(front.last_dopri5_adjoint_stats)
+    finally:
+        front.record_dopri5_steps = False
+    assert len(bwd["attempts"]) == n_t - 1
+
+    def oracle_run(dtype, replay):
+        f = LinearField(H, C, dtype, scale=0.3, tanh=cfg["tanh"], seed=7)
+        Xo = (oracle_interp.CubicPath(oracle_interp.hermite_bdiff_coeffs(x.to(dtype))) if cfg["degree"] == 3
+              else oracle_interp.LinearPath(x.to(dtype)))
+        zo = z0.to(dtype).requires_grad_(True)
+        to = Xo.interval if t_out is None else t_out.to(dtype)
+        call = dict(kw)
+        if replay:
+            adj_opts = dict(cfg["adj"].get("adjoint_options", {}))
+            adj_opts["replay_attempts"] = [a.clone() for a in bwd["attempts"]]
+            call.update(options=dict(replay_steps=fwd["steps"]), adjoint_options=adj_opts)
+        else:
+            call.update(cfg["adj"])
+            if cfg["jumps"]:
+                call["options"] = dict(jump_t=Xo.grid_points)
+        with _oracle_solver_log() as log:
+            ref = oracle_cde.cdeint(Xo, f, zo, to, adjoint=True, method="dopri5", **call)
+            (ref * lw.to(dtype)).sum().backward()
+        return ref.detach(), zo.grad, f.linear.weight.grad, f.linear.bias.grad, log
+
+    ref, gz, gw, gb, solvers = oracle_run(torch.float64, replay=True)
+    assert len(solvers) == n_t
+    s_end = [-float(times[i - 1]) for i in range(n_t - 1, 0, -1)]               # reversed-time end of every interval
+    for attempts, solver, end in zip(bwd["attempts"], solvers[1:], s_end):
+        mine, theirs = attempts[:, 4], torch.tensor(solver.ratios, dtype=torch.float64)
+        accepted = attempts[:, 3] != 0
+        assert len(mine) == len(theirs) > 0
+        dev = (mine - theirs).abs() - (0.02 * theirs + 0.01)
+        assert dev.max() <= 0, "error ratio of attempt %d: kernel %.5g, oracle %.5g" % (
+            dev.argmax(), mine[dev.argmax()], theirs[dev.argmax()])
+        clear = (theirs - 1).abs() > 0.03
+        assert torch.equal(accepted[clear], (theirs <= 1)[clear])               # the oracle's decisions
+        assert torch.equal(accepted, mine <= 1)
+        first = float(attempts[0, 1] - attempts[0, 0])
+        assert abs(first - float(solver.first_dt)) <= 1e-3 * float(solver.first_dt)      # Hairer's initial step
+        # torchdiffeq's step-size update between consecutive attempts
+        for n in range(len(mine) - 1):
+            ratio, dt = float(mine[n]), float(attempts[n, 1] - attempts[n, 0])
+            factor = 10.0 if ratio == 0 else min(10.0, max(0.9 / ratio ** 0.2, 1.0 if ratio < 1 else 0.2))
+            if attempts[n + 1, 2] == 0:                                         # (a step clipped onto a jump is shorter)
+                nxt = float(attempts[n + 1, 1] - attempts[n + 1, 0])
+                assert abs(nxt - dt * factor) <= 1e-6 * dt * factor + 1e-12, (n, nxt, dt * factor)
+        last = attempts[accepted][-1]
+        assert last[1] >= end and (cfg["jumps"] or last[1] > end)               # the end is PASSED, not clipped onto
+        assert attempts[accepted][:-1, 1].max() < end if accepted.sum() > 1 else True
+    _close(out, ref, 1e-4, 2e-5)
+    for got, want in ((zd.grad, gz), (func.linear.weight.grad, gw), (func.linear.bias.grad, gb)):
+        _close(got, want, 1e-3, 1e-4 * want.abs().max().item())
+    if cfg["jumps"]:
+        own = oracle_run(torch.float32, replay=False)[4]
+        assert (fwd["n_accept"], fwd["n_reject"]) == (own[0].n_accept, own[0].n_reject)
+        assert (bwd["n_accept"], bwd["n_reject"]) == (sum(s.n_accept for s in own[1:]), sum(s.n_reject for s in own[1:]))
+        # (the sequences themselves drift apart after a few steps: error ratios of ~1e-4 sit at float32's noise floor and
+        # enter the next step size through ratio^(-1/5); the first steps, driven by the parameter blocks, agree)
+        for mine, theirs in zip(bwd["steps"], own[1:]):
+            _close(mine[:3, :2], torch.tensor(theirs.accepted, dtype=torch.float64)[:3, :2], 2e-3, 1e-6)
+
+
+@pytest.mark.parametrize("case", ["cubic_tanh_three_times", "linear_jumps_interval"])
+def test_dopri5_adjoint_output_time_gradients(native, case):
+    """output times that require a gradient through the ADAPTIVE backward, fused
+    (reference test/test_tricks.py:21-49 asks for t_.grad with method='dopri5'; torchdiffeq: time_vjps).  K4a integrates
+    vjp_t anyway -- it is the first block of the mixed norm -- so the host only starts every interval at the carried value
+    minus f(t_i, z_i) . dL/dz_i (cde_dopri5_adjoint_carry_offset, first_interval bit 1) and reads dL/dt_0 at the end.
+    That starting value enters the error norm's tolerance, so the float64 oracle re-makes every attempt here as well
+    (ratios 2 % + 0.01, decisions) before trajectories, dL/dz0, dL/dW, dL/db and dL/dt are compared."""
+    front = _front()
+    cfg = {"cubic_tanh_three_times": dict(B=70, L=10, C=5, H=24, tanh=True, degree=3, t_out=[0., 3.6, 9.], jumps=False),
+           "linear_jumps_interval": dict(B=130, L=9, C=8, H=32, tanh=False, degree=1, t_out=[0., 8.], jumps=True)}[case]
+    B, L, C, H, kw = cfg["B"], cfg["L"], cfg["C"], cfg["H"], dict(rtol=1e-4, atol=1e-6)
+    x = make_series(B, L, C, seed=len(case))
+    z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(len(case)))
+    t_out = torch.tensor(cfg["t_out"])
+    n_t = t_out.numel()
+    lw = torch.rand(B, n_t, H, generator=torch.Generator().manual_seed(3)) + 0.5
+    func = LinearField(H, C, scale=0.3, tanh=cfg["tanh"], seed=7).to(DEV)
+    X = (native.CubicSpline(native.hermite_cubic_coefficients_with_backward_differences(x.to(DEV))) if cfg["degree"] == 3
+         else native.LinearInterpolation(native.linear_interpolation_coeffs(x.to(DEV))))
+    zd = z0.to(DEV).requires_grad_(True)
+    td = t_out.to(DEV).requires_grad_(True)
+    opts = dict(options=dict(jump_t=X.grid_points)) if cfg["jumps"] else {}
+    front.record_dopri5_steps = True
+    try:
+        out = native.cdeint(X, func, zd, td, **opts, **kw)
+        _expect_dispatch("affine_dopri5_times", out)                          # no step-wise path
+        fwd = dict(front.last_dopri5_stats)
+        (out * lw.to(DEV)).sum().backward()
+        bwd = dict(front.last_dopri5_adjoint_stats)
+    finally:
+        front.record_dopri5_steps = False
+    assert len(bwd["attempts"]) == n_t - 1 and td.grad is not None and td.grad.shape == (n_t,)
+
+    f64 = LinearField(H, C, torch.float64, scale=0.3, tanh=cfg["tanh"], seed=7)
+    Xo = (oracle_interp.CubicPath(oracle_interp.hermite_bdiff_coeffs(x.double())) if cfg["degree"] == 3
+          else oracle_interp.LinearPath(x.double()))
+    zo = z0.double().requires_grad_(True)
+    to = t_out.double().requires_grad_(True)
+    with _oracle_solver_log() as solvers:
+        ref = oracle_cde.cdeint(Xo, f64, zo, to, adjoint=True, method="dopri5", options=dict(replay_steps=fwd["steps"]),
+                                adjoint_options=dict(replay_attempts=[a.clone() for a in bwd["attempts"]]), **kw)
+        (ref * lw.double()).sum().backward()
+    for attempts, solver in zip(bwd["attempts"], solvers[1:]):
+        mine, theirs = attempts[:, 4], torch.tensor(solver.ratios, dtype=torch.float64)
+        assert len(mine) == len(theirs) > 0
+        dev = (mine - theirs).abs() - (0.02 * theirs + 0.01)
+        assert dev.max() <= 0, "error ratio of attempt %d: kernel %.5g, oracle %.5g" % (
+            dev.argmax(), mine[dev.argmax()], theirs[dev.argmax()])
+        clear = (theirs - 1).abs() > 0.03
+        assert torch.equal((attempts[:, 3] != 0)[clear], (theirs <= 1)[clear])
+    _close(out, ref, 1e-4, 2e-5)
+    for got, want in ((zd.grad, zo.grad), (func.linear.weight.grad, f64.linear.weight.grad),
+                      (func.linear.bias.grad, f64.linear.bias.grad), (td.grad, to.grad)):
+        _close(got, want, 1e-3, 1e-4 * want.abs().max().item())
+
+
+def test_two_layer_dopri5_adjoint_output_time_gradients(native):
+    """The same for the examples' two-layer model (K4am carries vjp_t like K4a): three output times, default mixed norm;
+    every backward attempt re-made by the float64 oracle (relu kinks: 97 % within the band, as in the test below), then
+    trajectories, dL/dz0, the four parameter gradients and dL/dt."""
+    front = _front()
+    B, L, C, H, width, kw = 70, 8, 8, 32, 128, dict(rtol=1e-4, atol=1e-6)
+    x = make_series(B, L, C, seed=21)
+    z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(21))
+    t_out = torch.tensor([0., 2.7, 7.])
+    lw = torch.rand(B, 3, H, generator=torch.Generator().manual_seed(3)) + 0.5
+    func = _TwoLayerField(H, C, width, seed=3).to(DEV)
+    X = native.CubicSpline(native.hermite_cubic_coefficients_with_backward_differences(x.to(DEV)))
+    zd = z0.to(DEV).requires_grad_(True)
+    td = t_out.to(DEV).requires_grad_(True)
+    front.record_dopri5_steps = True
+    try:
+        out = native.cdeint(X, func, zd, td, **kw)
+        _expect_dispatch("two_layer_dopri5_times", out)
+        fwd = dict(front.last_dopri5_stats)
+        (out * lw.to(DEV)).sum().backward()
+        bwd = dict(front.last_dopri5_adjoint_stats)
+    finally:
+        front.record_dopri5_steps = False
+    assert len(bwd["attempts"]) == 2 and td.grad is not None
+    f64 = _TwoLayerField(H, C, width, torch.float64, seed=3)
+    Xo = oracle_interp.CubicPath(oracle_interp.hermite_bdiff_coeffs(x.double()))
+    zo = z0.double().requires_grad_(True)
+    to = t_out.double().requires_grad_(True)
+    with _oracle_solver_log() as solvers:
+        ref = oracle_cde.cdeint(Xo, f64, zo, to, adjoint=True, method="dopri5", options=dict(replay_steps=fwd["steps"]),
+                                adjoint_options=dict(replay_attempts=[a.clone() for a in bwd["attempts"]]), **kw)
+        (ref * lw.double()).sum().backward()
+    for attempts, solver in zip(bwd["attempts"], solvers[1:]):
+        mine, theirs = attempts[:, 4], torch.tensor(solver.ratios, dtype=torch.float64)
+        inside = (mine - theirs).abs() <= 0.02 * theirs + 0.01
+        assert inside.double().mean() >= 0.97, "only %.1f %% of the error ratios match" % (100 * inside.double().mean())
+        clear = inside & ((theirs - 1).abs() > 0.03)
+        assert torch.equal((attempts[:, 3] != 0)[clear], (theirs <= 1)[clear])
+    _close(out, ref, 1e-4, 2e-5)
+    _close(zd.grad, zo.grad, 2e-3, 1e-3 * zo.grad.abs().max().item())
+    _close(td.grad, to.grad, 2e-3, 1e-3 * to.grad.abs().max().item())
+    for (name, got), want in zip(func.named_parameters(), f64.parameters()):
+        _close(got.grad, want.grad, 2e-3, 2e-3 * want.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("form", ["split", "four_waves", "one_wave_per_tile"])
+@pytest.mark.parametrize("case", ["example_model", "config5_shape_seminorm", "multi_out_jumps"])
+def test_two_layer_default_call_runs_fused_with_torchdiffeqs_decisions(native, monkeypatch, case, form):
+    """(`form`: the workgroup shapes of the two-layer adaptive kernels -- the waves of a workgroup sharing one tile, the
+    default up to 4096 series (backward: eight waves per tile, dopri5_mlp_adjoint_attempt_s8; `four_waves`: round 3's
+    form, still what 16-channel tiles run), and one wave per tile, CDE_K4M_NO_SPLIT=1 / CDE_K4AM_NO_SPLIT=1: what larger
+    batches run.)
+    VERDICT round 2, item 2 (K4am).  The call every example of the reference makes to train its model --
+    cdeint(X, CDEFunc, z0, X.interval): no method, so dopri5, adjoint=True (example/time_series_classification.py:30-51,
+    :83-86; solver.py:144,199-203) -- takes NO step-wise path any more: forward K4 with the two-layer field, backward
+    K4am (csrc/dopri5_mlp_adjoint.hip), asserted on grad_fn.  Same checks as for K4a above: every backward attempt,
+    rejected ones included, is re-made by the float64 oracle from its own state at t0 under torchdiffeq's default mixed
+    norm over (vjp_t, y, a, dW1, db1, dW2, db2) (or "seminorm"): error ratios, hence decisions; the initial step of every
+    interval; and -- the oracle having taken exactly the kernel's forward and backward steps -- the trajectories, dL/dz0
+    and all FOUR parameter gradients.  A relu field is only piecewise smooth: where the float32 and float64 states sit on
+    different sides of a kink at some stage, an attempt's error estimate differs visibly, so up to 3 % of the attempts
+    may leave the 2 % + 0.01 band (observed: 3 of 583 on the multi-output case, none elsewhere)."""
+    if form == "four_waves":
+        if case == "config5_shape_seminorm":
+            pytest.skip("16-channel tiles always take the four-wave form")
+        monkeypatch.setenv("CDE_K4AM_SPLIT4", "1")          # backward: four waves per tile instead of eight (round 3's split form)
+    if form == "one_wave_per_tile":
+        monkeypatch.setenv("CDE_K4AM_NO_SMALL_REDUCE", "1")  # the split-K factor reduction + R kernel of larger batches
+        monkeypatch.setenv("CDE_K4AM_NO_SPLIT", "1")        # backward: K4am
+        monkeypatch.setenv("CDE_K4M_NO_SPLIT", "1")         # forward: K4 with the two-layer field
+    front = _front()
+    cfg = {"example_model": dict(B=70, L=7, C=8, H=32, width=128, tanh=True, degree=3, t_out=None, jumps=False, adj={}),
+           # config 5's solve: 14 logsignature channels, hidden size 8 (example/logsignature_example.py:21-23), 16 x 16 tiles
+           "config5_shape_seminorm": dict(B=40, L=8, C=14, H=8, width=128, tanh=True, degree=1, t_out=None, jumps=False,
+                                          adj=dict(adjoint_options=dict(norm="seminorm"))),
+           "multi_out_jumps": dict(B=150, L=9, C=4, H=16, width=64, tanh=True, degree=1, t_out=[0., 3.5, 8.], jumps=True,
+                                   adj={})}[case]
+    B, L, C, H, kw = cfg["B"], cfg["L"], cfg["C"], cfg["H"], dict(rtol=1e-4, atol=1e-6)
+    x = make_series(B, L, C, seed=len(case))
+    z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(len(case)))
+    t_out = None if cfg["t_out"] is None else torch.tensor(cfg["t_out"])
+    n_t = 2 if t_out is None else t_out.numel()
+    lw = torch.rand(B, n_t, H, generator=torch.Generator().manual_seed(3)) + 0.5
+    func = _TwoLayerField(H, C, cfg["width"], seed=3, final_tanh=cfg["tanh"]).to(DEV)
+    X = (native.CubicSpline(native.hermite_cubic_coefficients_with_backward_differences(x.to(DEV))) if cfg["degree"] == 3
+         else native.LinearInterpolation(native.linear_interpolation_coeffs(x.to(DEV))))
+    zd = z0.to(DEV).requires_grad_(True)
+    times = X.interval if t_out is None else t_out.to(DEV)
+    opts = dict(options=dict(jump_t=X.grid_points)) if cfg["jumps"] else {}
+    front.record_dopri5_steps = True
+    try:
+        out = native.cdeint(X, func, zd, times, **opts, **cfg["adj"], **kw)
+        _expect_dispatch("two_layer_dopri5", out)                             # no step-wise path
+        fwd = dict(front.last_dopri5_stats)
+        (out * lw.to(DEV)).sum().backward()
+        bwd = dict(front.last_dopri5_adjoint_stats)
+    finally:
+        front.record_dopri5_steps = False
+    assert len(bwd["attempts"]) == n_t - 1 and bwd["n_accept"] > 0
+
+    f64 = _TwoLayerField(H, C, cfg["width"], torch.float64, seed=3, final_tanh=cfg["tanh"])
+    Xo = (oracle_interp.CubicPath(oracle_interp.hermite_bdiff_coeffs(x.double())) if cfg["degree"] == 3
+          else oracle_interp.LinearPath(x.double()))
+    zo = z0.double().requires_grad_(True)
+    adj_opts = dict(cfg["adj"].get("adjoint_options", {}))
+    adj_opts["replay_attempts"] = [a.clone() for a in bwd["attempts"]]
+    with _oracle_solver_log() as solvers:
+        ref = oracle_cde.cdeint(Xo, f64, zo, Xo.interval if t_out is None else t_out.double(), adjoint=True, method="dopri5",
+                                options=dict(replay_steps=fwd["steps"]), adjoint_options=adj_opts, **kw)
+        (ref * lw.double()).sum().backward()
+    assert len(solvers) == n_t
+    for attempts, solver in zip(bwd["attempts"], solvers[1:]):
+        mine, theirs = attempts[:, 4], torch.tensor(solver.ratios, dtype=torch.float64)
+        accepted = attempts[:, 3] != 0
+        inside = (mine - theirs).abs() <= 0.02 * theirs + 0.01
+        assert inside.double().mean() >= 0.97, "only %.1f %% of the attempts' error ratios match the oracle's" % (
+            100 * inside.double().mean())
+        clear = inside & ((theirs - 1).abs() > 0.03)
+        assert torch.equal(accepted[clear], (theirs <= 1)[clear])
+        assert torch.equal(accepted, mine <= 1)
+        # (later intervals start from float32 running totals of the parameter gradients: Hairer's d0 / d1 feel that)
+        first = float(attempts[0, 1] - attempts[0, 0])
+        assert abs(first - float(solver.first_dt)) <= (1e-3 if solver is solvers[1] else 2e-2) * float(solver.first_dt)
+    _close(out, ref, 1e-4, 2e-5)
+    _close(zd.grad, zo.grad, 2e-3, 1e-3 * zo.grad.abs().max().item())
+    for (name, got), want in zip(func.named_parameters(), f64.parameters()):
+        assert got.grad is not None, name
+        _close(got.grad, want.grad, 2e-3, 2e-3 * want.grad.abs().max().item())
+
+
+def test_dopri5_adjoint_with_torchdiffeq_seminorm_option(native):
+    """adjoint_options=dict(norm="seminorm") is torchdiffeq's adjoint norm without the parameter blocks (K4a: norm_kind 1):
+    the call stays on the fused path, takes the backward WITHOUT the forward's jump times (explicit
+    adjoint_options replace the forward options, torchdiffeq odeint_adjoint), and agrees with the step-wise path and
+    with the float64 oracle given the same string."""
+    front = _front()
+    B, L, C, H = 90, 11, 6, 20
+    x = make_series(B, L, C, seed=91)
+    z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(91))
+    tol = dict(rtol=1e-6, atol=1e-8)
+    f64 = LinearField(H, C, torch.float64, scale=0.3, seed=4)
+    Xo = oracle_interp.LinearPath(x.double())
+    zo = z0.double().requires_grad_(True)
+    ref = oracle_cde.cdeint(Xo, f64, zo, Xo.interval, adjoint=True, method="dopri5", options=dict(jump_t=Xo.grid_points),
+                            adjoint_options=dict(norm="seminorm"), **tol)
+    ref[:, -1].square().sum().backward()
+    res = {}
+    for variant in ("auto", "generic"):
+        func = LinearField(H, C, scale=0.3, seed=4).to(DEV)
+        X = native.LinearInterpolation(native.linear_interpolation_coeffs(x.to(DEV)))
+        z = z0.to(DEV).requires_grad_(True)
+        front.last_dopri5_adjoint_stats.clear()
+        out = native.cdeint(X, func, z, X.interval, options=dict(jump_t=X.grid_points),
+                            adjoint_options=dict(norm="seminorm"), variant=variant, **tol)
+        _expect_dispatch("affine_dopri5" if variant == "auto" else "affine_dopri5_generic", out)
+        out[:, -1].square().sum().backward()
+        if variant == "auto":
+            assert front.last_dopri5_adjoint_stats["n_accept"] > 0
+        res[variant] = (out.detach(), z.grad, func.linear.weight.grad, func.linear.bias.grad)
+        _close(out, ref, 1e-3, 5e-4)
+        _close(z.grad, zo.grad, 5e-3, 5e-3 * zo.grad.abs().max().item())
+        _close(func.linear.weight.grad, f64.linear.weight.grad, 5e-3, 5e-3 * f64.linear.weight.grad.abs().max().item())
+    for a, b in zip(res["auto"], res["generic"]):
+        _close(a, b, 5e-3, 5e-3 * b.abs().max().item())
+
+
+def test_dopri5_adjoint_fused_equals_stepwise_reference_semantics_and_is_deterministic(native):
+    """Against the step-wise path (torchdiffeq's default mixed adjoint norm, overshoot + interpolation) on the same
+    device: tolerance-level agreement; and two fused runs are bit-identical (fixed-order reductions)."""
+    B, L, C, H = 300, 12, 8, 32
+    x = make_series(B, L, C, seed=64).to(DEV)
+    X = native.LinearInterpolation(native.linear_interpolation_coeffs(x))
+    z0 = torch.randn(B, H, device=DEV)
+    res = {}
+    for variant in ("auto", "auto", "generic"):
+        func = LinearField(H, C, scale=0.25, seed=8).to(DEV)
+        z = z0.clone().requires_grad_(True)
+        out = native.cdeint(X, func, z, X.interval, options=dict(jump_t=X.grid_points), rtol=1e-5, atol=1e-7,
+                            variant=variant)
+        out[:, -1].sum().backward()
+        res.setdefault(variant, []).append((out.detach(), z.grad, func.linear.weight.grad, func.linear.bias.grad))
+    for a, b in zip(*res["auto"]):
+        assert torch.equal(a, b)
+    for a, b in zip(res["auto"][0], res["generic"][0]):
+        _close(a, b, 2e-3, 2e-3 * b.abs().max().item())
+
+
+@pytest.mark.parametrize("B,degree,jumps,C,form", [
+    (70, 3, False, 8, "shared_tile"), (300, 1, True, 8, "shared_tile"), (300, 3, False, 8, "shared_tile"),
+    (4500, 3, False, 8, "shared_tile"),
+    # four waves share a tile (16-channel tiles up to 4096 series; 8-channel tiles with CDE_K4AM_SPLIT4): ring in registers
+    (300, 3, False, 14, "shared_tile"), (70, 1, True, 14, "shared_tile"), (300, 3, False, 8, "four_waves"),
+    # one wave per tile (what batches above 12288 series and 16-channel tiles above 4096 run): four and eight waves per workgroup
+    (70, 3, False, 8, "one_wave"), (300, 1, True, 14, "one_wave"), (300, 3, False, 14, "one_wave_8")])
+def test_two_layer_backward_first_same_as_last_is_bit_identical(native, monkeypatch, B, degree, jumps, C, form):
+    """The eight-wave K4am attempt kernel does not evaluate the first stage of an attempt that follows an attempt: after a
+    rejection it is the rejected attempt's own first stage (same state, same time), after an accepted step that step's last
+    stage (torchdiffeq keeps f0 / passes f1 on the same way: oracle/odeint.py _Dopri5) -- slopes from a stash, factor rows
+    from the block the controller names (AdjCtrl::src0 / six).  The re-evaluation it replaces has the same inputs bit for
+    bit, so with CDE_K4AM_NO_FSAL=1 (every first stage evaluated) the attempt trace, the trajectories and every gradient
+    must be IDENTICAL: 70 series (fused reduction), 300 (split-K reduction + R kernel; with jump_t on the knots the step
+    after a jump does evaluate its first stage), 4500 (two rounds of workgroups).  The one-wave-per-tile form keeps its
+    slopes in a per-lane ring in memory: slot 0 stays, or slot 6 is copied to it."""
+    front = _front()
+    if form == "four_waves":
+        monkeypatch.setenv("CDE_K4AM_SPLIT4", "1")
+    elif form != "shared_tile":
+        monkeypatch.setenv("CDE_K4AM_NO_SPLIT", "1")
+    if form == "one_wave_8":
+        monkeypatch.setenv("CDE_K4AM_WAVES", "8")
+    L, H, width = 9, (32 if C <= 8 else 16), 128
+    x = make_series(B, L, C, seed=B)
+    z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(B))
+    X = (native.CubicSpline(native.hermite_cubic_coefficients_with_backward_differences(x.to(DEV))) if degree == 3
+         else native.LinearInterpolation(native.linear_interpolation_coeffs(x.to(DEV))))
+    opts = dict(options=dict(jump_t=X.grid_points)) if jumps else {}
+    res = {}
+    for form in ("reuse", "evaluate"):
+        if form == "evaluate":
+            monkeypatch.setenv("CDE_K4AM_NO_FSAL", "1")
+        func = _TwoLayerField(H, C, width, seed=3).to(DEV)
+        zd = z0.to(DEV).requires_grad_(True)
+        front.record_dopri5_steps = True
+        try:
+            out = native.cdeint(X, func, zd, X.interval, rtol=1e-4, atol=1e-6, **opts)
+            _expect_dispatch("two_layer_dopri5", out)
+            out[:, -1].sum().backward()
+            bwd = dict(front.last_dopri5_adjoint_stats)
+        finally:
+            front.record_dopri5_steps = False
+        res[form] = (out.detach().cpu(), zd.grad.cpu(), [p.grad.cpu().clone() for p in func.parameters()], bwd["attempts"][0].clone())
+    a, b = res["reuse"], res["evaluate"]
+    assert a[3].shape == b[3].shape and torch.equal(a[3], b[3]), "the attempt sequences differ"
+    assert (a[3][:, 3] == 0).any() and (a[3][:, 3] != 0).any()                 # rejected and accepted attempts both occur
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for got, want in zip(a[2], b[2]):
+        assert torch.equal(got, want)

@@ -59,7 +59,6 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return SO_PATH
     # one hipcc process per translation unit, in parallel (the MFMA kernels dominate: ~35 s), then one link step
-    import tempfile
     from concurrent.futures import ThreadPoolExecutor
     compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"]
 
@@ -70,12 +69,34 @@ def build(force=False, verbose=False):
         if proc.returncode != 0:
             raise RuntimeError("hipcc failed:\n" + proc.stdout)
 
-    with tempfile.TemporaryDirectory(prefix="cde_build_") as tmp:
-        objects = [os.path.join(tmp, os.path.splitext(src)[0] + ".o") for src in SOURCES]
-        with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
-            list(pool.map(run, [[_hipcc()] + compile_flags + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(_CSRC, src), "-o", obj]
-                                for src, obj in zip(SOURCES, objects)]))
-        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objects + ["-o", SO_PATH])
+    # objects are cached under torchcde_amd/.build/ keyed by (source, headers, flags): editing one kernel file recompiles
+    # that file only (the cache is neither tracked nor shipped to the GPU box; the linked .so is what travels)
+    import hashlib
+    cache = os.path.join(_HERE, ".build")
+    os.makedirs(cache, exist_ok=True)
+    header_blob = b"".join(open(h, "rb").read() for h in HEADERS if os.path.exists(h))
+    objects, jobs = [], []
+    for src in SOURCES:
+        flags = compile_flags + EXTRA_FLAGS.get(src, [])
+        key = hashlib.sha256(open(os.path.join(_CSRC, src), "rb").read() + header_blob + " ".join(flags).encode()).hexdigest()[:20]
+        obj = os.path.join(cache, "%s.%s.o" % (os.path.splitext(src)[0], key))
+        objects.append(obj)
+        if force or not os.path.exists(obj):
+            jobs.append((src, obj, [_hipcc()] + flags + ["-c", os.path.join(_CSRC, src), "-o", obj + ".tmp"]))
+
+    def compile_one(job):
+        src, obj, cmd = job
+        run(cmd)
+        os.replace(obj + ".tmp", obj)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as pool:
+            list(pool.map(compile_one, jobs))
+    run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objects + ["-o", SO_PATH])
+    keep = set(objects)
+    for name in os.listdir(cache):                  # drop objects of older source versions
+        if os.path.join(cache, name) not in keep:
+            os.remove(os.path.join(cache, name))
     return SO_PATH
 
 

@@ -141,7 +141,7 @@ __device__ __forceinline__ double tanh_t(double x) { return tanh(x); }
 inline int check_launch() { return hipGetLastError() == hipSuccess ? CDE_OK : CDE_ERR_LAUNCH; }
 
 // Zero-fill as a KERNEL, never hipMemsetAsync: captured into a hipGraph, the memset node of this ROCm zeroes its target on
-// the first replay only (found by tests/test_gpu_parity.py::test_solver_calls_are_graph_capturable: the second replay of
+// the first replay only (found by tests/test_gpu_08_frontend.py::test_solver_calls_are_graph_capturable: the second replay of
 // the wide adjoint added to the first one's sums).  `bytes` must be a multiple of 4.
 static __global__ __launch_bounds__(256) void zero_words_kernel(unsigned* __restrict__ p, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0u;

@@ -440,10 +440,20 @@ def hermite_cubic_coefficients_with_backward_differences(x, t=None):
     scratch = torch.empty_like(src)                     # where the filled series would go (caching allocator: no sync)
     lib = _lib.load()
     stream = _lib.stream_ptr(x.device)
-    flag, generation = _nan_flag(x.device, stream)
-    _lib.check(lib.cde_hermite_bdiff_coeffs_nonblocking(_lib.ptr(src), _lib.ptr(knots), _lib.ptr(out), _lib.ptr(scratch), B, L,
-                                                        C, _lib.dtype_enum(x.dtype), _lib.ptr(flag), generation, stream),
-               "cde_hermite_bdiff_coeffs_nonblocking")
+    args = (_lib.ptr(src), _lib.ptr(knots), _lib.ptr(out), _lib.ptr(scratch), B, L, C, _lib.dtype_enum(x.dtype))
+    if torch.cuda.is_current_stream_capturing():
+        # a captured call is replayed with its arguments baked in, so a call number would be stale from the second replay
+        # on: the graph gets a flag word of its own (from the graph's pool) that a captured fill kernel zeroes first
+        flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+        _lib.check(lib.cde_hermite_bdiff_coeffs_nonblocking(*args, _lib.ptr(flag), 1, stream), "cde_hermite_bdiff_coeffs_nonblocking")
+        return out
+    # the call number is drawn AND the three launches are queued under one lock: numbers then rise in stream order, which
+    # is what the flag protocol assumes (two threads sharing a stream could queue call 5 after call 6; 5's
+    # atomicMax then did nothing, its gate failed and its gaps stayed NaN)
+    with _NAN_FLAGS_LOCK:
+        flag, generation = _nan_flag(x.device, stream)
+        rc = lib.cde_hermite_bdiff_coeffs_nonblocking(*args, _lib.ptr(flag), generation, stream)
+    _lib.check(rc, "cde_hermite_bdiff_coeffs_nonblocking")
     return out
 
 
@@ -453,16 +463,16 @@ _NAN_FLAGS_LOCK = threading.Lock()
 
 def _nan_flag(device, stream):
     """The device int K1 raises when its input holds NaNs, one per (device, stream), and the number of this call on it
-    (cde_hermite_bdiff_coeffs_nonblocking: the flag is compared with the call's number, so it is never zeroed again)."""
+    (cde_hermite_bdiff_coeffs_nonblocking: the flag is compared with the call's number, so it is never zeroed again).
+    The caller holds _NAN_FLAGS_LOCK until its launches are queued."""
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device(),
            getattr(stream, "value", stream))
-    with _NAN_FLAGS_LOCK:
-        entry = _NAN_FLAGS.get(key)
-        if entry is None or entry[1] >= 2 ** 31 - 2:
-            entry = [torch.zeros(1, dtype=torch.int32, device=device), 0]
-            _NAN_FLAGS[key] = entry
-        entry[1] += 1
-        return entry[0], entry[1]
+    entry = _NAN_FLAGS.get(key)
+    if entry is None or entry[1] >= 2 ** 31 - 2:
+        entry = [torch.zeros(1, dtype=torch.int32, device=device), 0]
+        _NAN_FLAGS[key] = entry
+    entry[1] += 1
+    return entry[0], entry[1]
 
 
 # --------------------------------------------------------------------------------------- path modules
