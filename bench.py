@@ -272,6 +272,41 @@ def bf16x3_variant(cde, X, func, z0, steps=10):
     return out
 
 
+def backprop_mode(cde, X, func, z0, steps=10):
+    """The same workload through cdeint(..., adjoint=False) (reference solver.py:144; README.md:103 "the faster mode"):
+    K2 storing its stage states + K3d, the reverse-mode sweep of csrc/rk4_backprop.hip -- the gradient of the DISCRETE
+    solve.  NOT the reported `value` (BASELINE's metric is forward + adjoint).  ms per forward + backward step, wall clock
+    over `steps`, and the two kernels' own durations from HIP events on the launching stream."""
+    import torchcde_amd.cdeint as front
+    kw = dict(method="rk4", options={"step_size": 1.0}, adjoint=False)
+    params = list(func.parameters())
+
+    def both():
+        z = z0.detach().requires_grad_(True)
+        for p in params:
+            p.grad = None
+        cde.cdeint(X, func, z, X.interval, **kw)[:, -1].sum().backward()
+    for _ in range(3):
+        both()
+    torch.cuda.synchronize()
+    front.event_log = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        both()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / steps * 1e3
+    log, front.event_log = front.event_log, None
+    fwd = [a.elapsed_time(b) for kind, a, b in log if kind == "forward"]
+    bwd = [a.elapsed_time(b) for kind, a, b in log if kind == "backprop"]
+    B = z0.size(0)
+    bwd_ms = sum(bwd) / max(len(bwd), 1)
+    flop = B * N_EVAL * (2 * 2 * H * H * C + 2 * H * H + 2 * H * C)       # J's GEMM + dL/dW on the matrix pipe, J^T kb + dL/db
+    return {"forward_backward_ms": wall, "series_per_s": B / (wall * 1e-3),
+            "forward_with_stage_stores_kernel_ms": sum(fwd) / max(len(fwd), 1), "backward_kernel_ms": bwd_ms,
+            "backward_executed_tflops": flop / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else None,
+            "stage_state_bytes": B * (N_EVAL) * 32 * 4}
+
+
 def other_fields(cde, X, z0, device, reps=3):
     """Same workload with the non-linear vector fields of the reference's examples (outside the timed region, not part
     of `value`): Linear -> tanh (example/irregular_data.py) and Linear -> relu -> Linear -> tanh, width 128
@@ -858,6 +893,7 @@ def main():
             result["extra"]["strong_scaling_proxy_1gpu"] = strong_scaling_proxy(cde, x, func, z0, elapsed / args.steps * 1e3)
         if world == 1:
             result["extra"]["bf16x3_variant"] = bf16x3_variant(cde, X, func, z0)
+            result["extra"]["backprop_mode_adjoint_false"] = backprop_mode(cde, X, func, z0)
             result["extra"]["other_fields"] = other_fields(cde, X, z0, device)
             result["extra"]["other_configs"] = other_configs(cde, device)
         if world == 1 and args.cpu_sample > 0:

@@ -364,6 +364,42 @@ int cde_rk4_adjoint_linear_dcontrol(const void* coeffs, const void* knots, int64
                                     size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * K3d  The backward pass of cdeint(..., method='rk4', adjoint=False) for the affine field (reference solver.py:144,
+ * 226-227: torchdiffeq.odeint differentiated by autograd through the solver's own operations -- the EXACT gradient of
+ * the discrete 3/8-rule map, README.md:103; not the continuous adjoint of K3).  Two calls:
+ *   cde_rk4_forward_linear_stages   K2, which also stores the state handed to each of the 4 * (n_grid - 1) field
+ *       evaluations:  stages (B, n_grid - 1, 4, 32) f32 -- row (series, step, stage) holds the 32 (zero padded) hidden
+ *       units in the order u -> (u & 1) * 16 + (u >> 1) (evens, then odds: the lane order of the 32 x 32 MFMA tiles).
+ *       All other arguments as cde_rk4_forward_linear (the affine field with act == CDE_ACT_NONE is implied).
+ *   cde_rk4_backprop_linear   reverse-mode sweep over the stored stages, one Jacobian GEMM + one matrix-vector
+ *       product + the dL/dW product per stage (csrc/rk4_backprop.hip):
+ *         grad_out (B, n_out, H)      dL/dz_out
+ *         step_dt  (n_steps) f32      float32(grid[k+1] - grid[k]), the step sizes the forward kernel used
+ *         node_ptr (n_steps + 2) int64, node_out / node_weight (node_ptr[n_steps + 1]) int64 / f32:  CSR lists -- grid node
+ *                  m receives  sum_e node_weight[e] * grad_out[:, node_out[e]]  for e in [node_ptr[m], node_ptr[m+1]):
+ *                  the transpose of torchdiffeq's linear output interpolation (an output at a grid point is one entry
+ *                  of weight 1, an output inside a step two entries on the step's end nodes)
+ *         stage_index / stage_frac    the table cde_rk4_forward_linear_stages filled
+ *         grad_z0 (B, H), grad_W (H*C, H), grad_b (H*C)   out
+ *         workspace  cde_rk4_backprop_workspace_bytes(B) bytes: per-wave partial parameter gradients, reduced in a
+ *                    fixed order (deterministic)
+ * f32, H <= 32, C <= 8 (cde_rk4_backprop_supported); anything else CDE_ERR_UNSUPPORTED (the Python host then
+ * differentiates the step-wise solve).
+ * ------------------------------------------------------------------------------------------- */
+int cde_rk4_backprop_supported(int64_t C, int64_t H, int dtype, int act);
+int cde_rk4_forward_linear_stages(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
+                                  const void* bias, const void* z0, const void* grid, int64_t n_grid, const void* t_out,
+                                  int64_t n_out, void* z_out, void* stages, int64_t B, int64_t C, int64_t H, int dtype,
+                                  int time_dtype, int64_t* stage_index, void* stage_frac, void* stream);
+size_t cde_rk4_backprop_workspace_bytes(int64_t B);
+int cde_rk4_backprop_linear(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
+                            const void* stages, const void* grad_out, int64_t n_out, const float* step_dt,
+                            int64_t n_steps, const int64_t* node_ptr, const int64_t* node_out, const float* node_weight,
+                            void* grad_z0, void* grad_W, void* grad_b, int64_t B, int64_t C, int64_t H, int dtype,
+                            const int64_t* stage_index, const void* stage_frac, void* workspace, size_t workspace_bytes,
+                            void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K4  Adaptive Dormand-Prince 5(4) solve (torchdiffeq's default method, what cdeint runs when the
  * caller passes no `method`: reference solver.py:226-227, README.md:174) for the affine family.
  * Replaces torchdiffeq.odeint(method='dopri5', rtol, atol, options={'jump_t': ...}) including the

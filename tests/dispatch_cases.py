@@ -18,11 +18,11 @@ from torchcde_amd import dispatch
 BASE = dispatch.Request(
     prod=False, kind="affine", tiles_ok=True, mfma_shape=True, method="rk4", adjoint=True, wants_grad=True, wants_t=False,
     wants_control=False, params="default", adjoint_method_ok=True, options_ok=True, adjoint_options_ok=True, t_ok=True,
-    variant_generic=False, shared=False, narrow_control=True)
+    variant_generic=False, shared=False, narrow_control=True, backprop_ok=True)
 
 _MLP = dict(kind="mlp2", mfma_shape=False)
 _BOOLS = {"mfma_shape": (False, True), "narrow_control": (False, True), "variant_generic": (False, True),
-          "wants_t": (False, True), "shared": (False, True)}
+          "wants_t": (False, True), "shared": (False, True), "backprop_ok": (False, True)}
 
 CASES = {
     # ------------------------------------------------------------------ one-layer (affine / tanh) fields
@@ -34,6 +34,10 @@ CASES = {
     "affine_dopri5_generic":     (dict(method="dopri5", variant_generic=True, mfma_shape=False), "stepwise", ()),
     "affine_dopri5_wide":        (dict(method="dopri5", mfma_shape=False), "stepwise", ("narrow_control",)),
     "affine_dopri5_control":     (dict(method="dopri5", wants_control=True, params="own"), "stepwise", ("wants_t",)),
+    # ------------------------------------------------------------------ adjoint=False: reverse mode through the solver's steps
+    "affine_rk4_backprop":       (dict(adjoint=False), "rk4_backprop", ("narrow_control",)),
+    "affine_backprop_beyond_the_kernel": (dict(adjoint=False, backprop_ok=False), "stepwise",
+                                          ("mfma_shape", "variant_generic", "narrow_control")),
     # ------------------------------------------------------------------ the examples' two-layer field
     "two_layer_rk4":             (dict(_MLP), "mlp_rk4_adjoint", ("narrow_control",)),
     "two_layer_rk4_control":     (dict(_MLP, wants_control=True, params="own"), "mlp_rk4_adjoint", ("wants_t",)),
@@ -50,21 +54,28 @@ CASES = {
                                                      "stepwise", ("variant_generic",)),
 }
 
-GRAD_FN = {"rk4": "_FusedRK4Backward", "dopri5_adjoint": "_FusedDopri5Backward", "mlp_rk4_adjoint": "_FusedMlpRK4Backward",
+GRAD_FN = {"rk4_backprop": "_FusedRK4BackpropBackward", "rk4": "_FusedRK4Backward", "dopri5_adjoint": "_FusedDopri5Backward", "mlp_rk4_adjoint": "_FusedMlpRK4Backward",
            "mlp_dopri5_adjoint": "_FusedMlpDopri5Backward"}
+
+
+def _free(name):
+    """The row's free fields; `backprop_ok` only matters to adjoint=False requests, so every adjoint=True row leaves it free."""
+    fields, _, free = CASES[name]
+    return tuple(free) + (("backprop_ok",) if BASE._replace(**fields).adjoint and "backprop_ok" not in fields else ())
 
 
 def requests_of(name):
     """Every Request the row stands for (the free fields enumerated)."""
-    fields, _, free = CASES[name]
-    base = BASE._replace(**fields)
+    fields, _, _ = CASES[name]
+    base, free = BASE._replace(**fields), _free(name)
     for values in itertools.product(*(_BOOLS[f] for f in free)):
         yield base._replace(**dict(zip(free, values)))
 
 
 def expect_dispatch(front, name, out=None):
     """GPU side: the calling thread's last cdeint call WAS the request the row describes and took the row's path."""
-    fields, path, free = CASES[name]
+    fields, path, _ = CASES[name]
+    free = _free(name)
     choice, request = front.last_dispatch()
     want = BASE._replace(**fields)._replace(**{f: getattr(request, f) for f in free})
     if request != want:

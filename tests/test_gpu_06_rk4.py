@@ -7,7 +7,7 @@ import os
 import pytest
 import torch
 
-from gpu_common import (_expect_dispatch, oracle_cde, oracle_interp, LinearField, _TwoLayerField, make_series, DEV, _close, _run_native, _oracle_solution)
+from gpu_common import (_front, _expect_dispatch, oracle_cde, oracle_interp, LinearField, _TwoLayerField, make_series, DEV, _close, _run_native, _oracle_solution)
 
 pytestmark = pytest.mark.gpu
 
@@ -638,3 +638,76 @@ def test_tile_kernels_agree_with_the_wave_kernels_on_random_shapes(native):
             res[variant] = (out.detach(), z.grad, func.linear.weight.grad, func.linear.bias.grad)
         for a, b in zip(res["split"], res["mfma"]):
             _close(a, b, 2e-4, 2e-5 * max(1.0, b.abs().max().item()))
+
+
+@pytest.mark.parametrize("B,L,C,H,degree,step,times", [
+    (75, 12, 8, 32, 3, 1.0, [0., 11.]),                       # the benchmark's shape, ragged batch (75 = 2 tiles + 11)
+    (75, 12, 8, 32, 1, 1.0, [0., 4.5, 11.]),                  # piecewise-linear control, an output inside a step
+    (203, 9, 5, 20, 3, 0.75, [0., 1.5, 2.0, 2.25, 6.9, 8.]),  # zero-padded shape, outputs on / between grid points, short last step
+    (1, 4, 3, 7, 3, 0.5, [1., 2.6]),                          # one series, interval inside the data range
+    (40, 6, 8, 32, 3, 1.0, [2.]),                             # a single output time: nothing to integrate
+])
+def test_rk4_backprop_mode_fused_against_autograd_through_the_oracle(native, B, L, C, H, degree, step, times):
+    """cdeint(..., method='rk4', adjoint=False) for the README's affine field (reference solver.py:144,226-227 with
+    adjoint=False: torchdiffeq.odeint under autograd; README.md:103) runs fused: K2 storing every stage state
+    (cde_rk4_forward_linear_stages) and the reverse-mode sweep K3d (cde_rk4_backprop_linear, csrc/rk4_backprop.hip).  The
+    gradient is that of the DISCRETE solve -- compared with autograd through the float64 oracle's odeint (rtol 1e-3 of the
+    largest entry; trajectories rtol 1e-4 / atol 1e-6), and, since both exist, told apart from the continuous adjoint."""
+    x = make_series(B, L, C, seed=7 + B)
+    z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(8))
+    t_out = torch.tensor(times)
+    lw = torch.rand(B, t_out.numel(), H, generator=torch.Generator().manual_seed(9)) + 0.5
+    kw = dict(method="rk4", options=dict(step_size=step), adjoint=False)
+    f64 = LinearField(H, C, torch.float64, scale=0.3, seed=3)
+    Xo = (oracle_interp.CubicPath(oracle_interp.hermite_bdiff_coeffs(x.double())) if degree == 3
+          else oracle_interp.LinearPath(x.double()))
+    zo = z0.double().requires_grad_(True)
+    ref = oracle_cde.cdeint(Xo, f64, zo, t_out.double(), **kw)
+    (ref * lw.double()).sum().backward()
+    func = LinearField(H, C, scale=0.3, seed=3).to(DEV)
+    X = (native.CubicSpline(native.hermite_cubic_coefficients_with_backward_differences(x.to(DEV))) if degree == 3
+         else native.LinearInterpolation(native.linear_interpolation_coeffs(x.to(DEV))))
+    z = z0.to(DEV).requires_grad_(True)
+    out = native.cdeint(X, func, z, t_out.to(DEV), **kw)
+    _expect_dispatch("affine_rk4_backprop", out)
+    (out * lw.to(DEV)).sum().backward()
+    _close(out, ref, 1e-4, 1e-6)
+    gw, gb = f64.linear.weight.grad, f64.linear.bias.grad
+    if gw is None:                                     # a single output time: the solve does not touch the parameters
+        gw, gb = torch.zeros_like(f64.linear.weight), torch.zeros_like(f64.linear.bias)
+    _close(z.grad, zo.grad, 1e-3, 1e-3 * zo.grad.abs().max().item())
+    _close(func.linear.weight.grad, gw, 1e-3, 1e-3 * max(gw.abs().max().item(), 1e-12))
+    _close(func.linear.bias.grad, gb, 1e-3, 1e-3 * max(gb.abs().max().item(), 1e-12))
+    # the forward values are K2's own, bit for bit (same kernel body, the stage stores aside)
+    with torch.no_grad():
+        plain = native.cdeint(X, func, z0.to(DEV), t_out.to(DEV), method="rk4", options=dict(step_size=step), variant="mfma")
+    assert torch.equal(out.detach(), plain)
+    # run to run deterministic (fixed-order reduction of the per-wave partials)
+    func2 = LinearField(H, C, scale=0.3, seed=3).to(DEV)
+    z2 = z0.to(DEV).requires_grad_(True)
+    (native.cdeint(X, func2, z2, t_out.to(DEV), **kw) * lw.to(DEV)).sum().backward()
+    assert torch.equal(z2.grad, z.grad) and torch.equal(func2.linear.weight.grad, func.linear.weight.grad)
+
+
+def test_rk4_backprop_mode_requests_the_kernel_does_not_take(native):
+    """adjoint=False with a tanh field, float64, a control that requires a gradient, or output times that do: still the
+    step-wise path (the table row says why), still correct against the oracle."""
+    B, L, C, H = 9, 7, 4, 6
+    x = make_series(B, L, C, seed=3)
+    z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(4))
+    kw = dict(method="rk4", options=dict(step_size=1.0), adjoint=False)
+    for tanh, dtype, want_t in ((True, torch.float32, False), (False, torch.float64, False), (False, torch.float32, True)):
+        f64 = LinearField(H, C, torch.float64, scale=0.3, tanh=tanh, seed=3)
+        Xo = oracle_interp.CubicPath(oracle_interp.hermite_bdiff_coeffs(x.double()))
+        zo = z0.double().requires_grad_(True)
+        ref = oracle_cde.cdeint(Xo, f64, zo, Xo.interval, **kw)
+        ref[:, -1].square().sum().backward()
+        func = LinearField(H, C, dtype, scale=0.3, tanh=tanh, seed=3).to(DEV)
+        X = native.CubicSpline(oracle_interp.hermite_bdiff_coeffs(x.to(dtype)).to(DEV))
+        z = z0.to(DEV, dtype).requires_grad_(True)
+        t = X.interval.clone().requires_grad_(want_t)
+        out = native.cdeint(X, func, z, t, **kw)
+        assert _front().last_dispatch()[0].path == "stepwise"
+        out[:, -1].square().sum().backward()
+        tol = 1e-8 if dtype == torch.float64 else 2e-3
+        _close(z.grad, zo.grad, tol, tol * zo.grad.abs().max().item())

@@ -759,7 +759,7 @@ def test_dispatch_table_is_exhaustively_consistent():
     import itertools
     from torchcde_amd import dispatch as D
     flags = ["prod", "tiles_ok", "mfma_shape", "adjoint", "wants_grad", "wants_t", "wants_control", "adjoint_method_ok",
-             "options_ok", "adjoint_options_ok", "t_ok", "variant_generic", "shared", "narrow_control"]
+             "options_ok", "adjoint_options_ok", "t_ok", "variant_generic", "shared", "narrow_control", "backprop_ok"]
     seen = collections_counter = {}
     n = 0
     for kind in (None, "affine", "mlp2"):
@@ -771,6 +771,8 @@ def test_dispatch_table_is_exhaustively_consistent():
                         continue                                 # contradictory requests are never built by cdeint
                     if f["mfma_shape"] and (kind != "affine" or not f["tiles_ok"] or f["variant_generic"]):
                         continue
+                    if f["backprop_ok"] and not f["mfma_shape"]:
+                        continue                                 # the reverse-mode sweep lives on the 32 x 8 tiles
                     q = D.Request(kind=kind, method=method, params=params, **f)
                     c = D.select_path(q)
                     n += 1
@@ -784,6 +786,11 @@ def test_dispatch_table_is_exhaustively_consistent():
                     assert method == ("rk4" if "rk4" in c.path else "dopri5")
                     assert c.path.startswith("mlp_") == (kind == "mlp2")
                     assert ("forward" in c.path) <= (not f["wants_grad"])    # forward-only kernels: nothing to differentiate
+                    if c.path == "rk4_backprop":
+                        # adjoint=False: reverse mode through the steps -- the affine identity field, no time / control gradients
+                        assert f["wants_grad"] and not f["adjoint"] and f["backprop_ok"] and f["mfma_shape"] and kind == "affine"
+                        assert not f["wants_t"]
+                        continue
                     if f["wants_grad"]:
                         assert f["adjoint"] and f["adjoint_method_ok"] and f["adjoint_options_ok"] and params != "foreign"
                     if c.path == "dopri5_adjoint":
@@ -803,7 +810,7 @@ def test_dispatch_table_is_exhaustively_consistent():
         base = dict(prod=False, kind="affine", tiles_ok=True, mfma_shape=True, method="dopri5", adjoint=True,
                     wants_grad=True, wants_t=False, wants_control=False, params="default", adjoint_method_ok=True,
                     options_ok=True, adjoint_options_ok=True, t_ok=True, variant_generic=False, shared=False,
-                    narrow_control=True)
+                    narrow_control=True, backprop_ok=True)
         base.update(kw)
         return D.select_path(D.Request(**base))
     # the rows a user meets
@@ -817,8 +824,9 @@ def test_dispatch_table_is_exhaustively_consistent():
     assert ask(kind="mlp2", mfma_shape=False, shared=True).path == "mlp_dopri5_adjoint"    # ... for the examples' model too
     assert ask(method="rk4", wants_control=True, params="own").path == "rk4"    # README.md:251-270
     assert ask(wants_t=True).path == "dopri5_adjoint"                           # output-time gradients: K4a carries vjp_t
+    assert ask(method="rk4", adjoint=False).path == "rk4_backprop"              # README.md:103: backprop through the solver
     for kw, word in ((dict(kind=None), "recognised"), (dict(method="midpoint"), "midpoint"),
-                     (dict(adjoint=False), "adjoint=False"), (dict(options_ok=False), "options"),
+                     (dict(adjoint=False), "adjoint=False"), (dict(method="rk4", adjoint=False, backprop_ok=False), "adjoint=False"), (dict(options_ok=False), "options"),
                      (dict(mfma_shape=False), "32 x 8"), (dict(wants_t=True, shared=True), "time"),
                      (dict(wants_control=True, params="own"), "control"),
                      (dict(kind="mlp2", mfma_shape=False, method="rk4", wants_control=True, narrow_control=False), "8 channels"),
@@ -842,7 +850,7 @@ def test_every_dispatch_expectation_of_the_gpu_tests_holds_on_the_cpu():
             got = D.select_path(q)
             assert got.path == path, "row %r, request %r: select_path says %r (%s)" % (name, q, got.path, got.reason)
             n += 1
-        assert n == 2 ** len(free)
+        assert n == 2 ** len(DC._free(name))
     assert set(DC.GRAD_FN) == {p for p in D.FUSED_PATHS if "forward" not in p}
     # every row a GPU test names exists, and every row is used by some GPU test
     here = os.path.dirname(os.path.abspath(__file__))
@@ -891,3 +899,82 @@ def test_option_noops_and_per_thread_call_state():
     finally:
         front.record_dopri5_steps = False
         front.event_log = None
+
+
+def test_reverse_mode_recurrences_of_the_rk4_backprop_kernel_equal_autograd_through_the_oracle():
+    """csrc/rk4_backprop.hip (adjoint=False under rk4) restated in float64 torch ops: the stage states of torchdiffeq's 3/8
+    rule stored on the way forward, then per step and stage  v = J^T kb,  yb += v,  the kb updates of the file header, the
+    dL/dW / dL/db products -- and the host's transpose of the fixed-grid output interpolation (`_Grids.backprop_lists`:
+    outputs at grid points, inside a step, at the ends; a last step shorter than step_size).  Against autograd through the
+    oracle's odeint (what the reference's adjoint=False call differentiates)."""
+    from torchcde_amd.cdeint import _Grids
+    from oracle import cde as oracle_cde, interp as oracle_interp
+    from helpers import make_series
+    B, L, C, H = 5, 9, 3, 4
+    dt64 = torch.float64
+    x = make_series(B, L, C, dt64, seed=41)
+    for t_out, step in ((torch.tensor([0., 8.], dtype=dt64), 1.0),
+                        (torch.tensor([0., 1.5, 2.0, 2.25, 6.9, 8.], dtype=dt64), 0.75),
+                        (torch.tensor([1., 7.3], dtype=dt64), 2.0)):
+        func = LinearField(H, C, dt64, scale=0.4, seed=2)
+        X = oracle_interp.CubicPath(oracle_interp.hermite_bdiff_coeffs(x))
+        z0 = torch.randn(B, H, dtype=dt64, generator=torch.Generator().manual_seed(3)).requires_grad_(True)
+        lw = torch.rand(B, t_out.numel(), H, dtype=dt64, generator=torch.Generator().manual_seed(4)) + 0.5
+        ref = oracle_cde.cdeint(X, func, z0, t_out, adjoint=False, method="rk4", options=dict(step_size=step))
+        (ref * lw).sum().backward()
+        W, b = func.linear.weight.detach().view(H, C, H), func.linear.bias.detach().view(H, C)
+        grids = _Grids(t_out, step, None, torch.device("cpu"))
+        step_dt, node_ptr, node_out, node_w, n_steps = grids.backprop_lists()
+        grid = grids.grid
+        assert step_dt.dtype == torch.float32 and n_steps == grid.numel() - 1
+        third = 1.0 / 3.0
+
+        def jac(t):                                       # J(t) = sum_c dX_c W_c, beta = b dX
+            dX = X.derivative(t)                          # (B, C)
+            return torch.einsum("bc,hck->bhk", dX, W), torch.einsum("bc,hc->bh", dX, b), dX
+
+        stages, y = [], z0.detach().clone()
+        for k in range(n_steps):
+            t0, t1 = grid[k], grid[k + 1]
+            dt = t1 - t0
+            times = (t0, t0 + dt * third, t0 + dt * 2 * third, t1)
+            f = lambda t, s: torch.einsum("bhk,bk->bh", jac(t)[0], s) + jac(t)[1]
+            s1 = y; k1 = f(times[0], s1)
+            s2 = y + dt * k1 * third; k2 = f(times[1], s2)
+            s3 = y + dt * (k2 - k1 * third); k3 = f(times[2], s3)
+            s4 = y + dt * (k1 - k2 + k3); k4 = f(times[3], s4)
+            stages.append((times, (s1, s2, s3, s4)))
+            y = y + (k1 + 3 * (k2 + k3) + k4) * dt * 0.125
+        go = lw                                           # dL/dz_out
+
+        def outputs_at(m):
+            g = torch.zeros(B, H, dtype=dt64)
+            for e in range(int(node_ptr[m]), int(node_ptr[m + 1])):
+                g = g + float(node_w[e]) * go[:, int(node_out[e])]
+            return g
+
+        gy = outputs_at(n_steps)
+        gW, gb = torch.zeros(H, C, H, dtype=dt64), torch.zeros(H, C, dtype=dt64)
+        for k in range(n_steps - 1, -1, -1):
+            dt = float(step_dt[k].double())
+            times, ss = stages[k]
+            c8 = dt * 0.125
+            kb = [gy * c8, gy * (3 * c8), gy * (3 * c8), gy * c8]       # kb1 .. kb4
+            yb = gy.clone()
+            for i in (3, 2, 1, 0):
+                J, _, dX = jac(times[i])
+                v = torch.einsum("bh,bhk->bk", kb[i], J)
+                gW += torch.einsum("bh,bc,bk->hck", kb[i], dX, ss[i])
+                gb += torch.einsum("bh,bc->hc", kb[i], dX)
+                yb = yb + v
+                if i == 3:
+                    kb[0] = kb[0] + dt * v; kb[1] = kb[1] - dt * v; kb[2] = kb[2] + dt * v
+                elif i == 2:
+                    kb[1] = kb[1] + dt * v; kb[0] = kb[0] - dt * third * v
+                elif i == 1:
+                    kb[0] = kb[0] + dt * third * v
+            gy = yb + outputs_at(k)
+        # (the output-interpolation weights are rounded to float32 like the kernel's slope: 1e-7 relative)
+        assert torch.allclose(gy, z0.grad, rtol=1e-6, atol=1e-9)
+        assert torch.allclose(gW.reshape(H * C, H), func.linear.weight.grad, rtol=1e-6, atol=1e-9)
+        assert torch.allclose(gb.reshape(H * C), func.linear.bias.grad, rtol=1e-6, atol=1e-9)

@@ -17,7 +17,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 PHASE_TRACE = os.environ.get("CDE_PHASE_TRACE", "") == "1"
 SO_PATH = os.path.join(_HERE, "libcde_mi355x_trace.so" if PHASE_TRACE else "libcde_mi355x.so")
 SOURCES = ["interp_kernels.hip", "rk4_generic.hip", "rk4_mfma.hip", "rk4_split.hip", "rk4_wide.hip", "rk4_mlp_adjoint.hip",
-           "rk4_bf16x3.hip", "dopri5.hip", "dopri5_adjoint.hip", "dopri5_mlp_adjoint.hip", "mlp_grad_reduce.hip", "api.hip"]
+           "rk4_bf16x3.hip", "rk4_backprop.hip", "dopri5.hip", "dopri5_adjoint.hip", "dopri5_mlp_adjoint.hip", "mlp_grad_reduce.hip", "api.hip"]
 HEADERS = [os.path.join(_CSRC, "cde_common.h"), os.path.join(_CSRC, "cde_mfma.h"), os.path.join(_CSRC, "cde_split.h"),
            os.path.join(_CSRC, "cde_dopri.h"), os.path.join(_CSRC, "cde_dopri_adj.h"), os.path.join(_CSRC, "cde_mlp_adj.h"),
            os.path.join(_HERE, "..", "include", "cde_mi355x.h")]
@@ -131,6 +131,12 @@ _SIGNATURES = {
     "cde_rk4_forward_mlp": (_i, [_p, _p, _i64, _i, _p, _p, _i64, _p, _p, _i, _p, _p, _i64, _p, _i64, _p, _i64, _i64, _i64,
                                  _i, _i, _p, _p, _p]),
     "cde_rk4_adjoint_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i, _i]),
+    "cde_rk4_backprop_supported": (_i, [_i64, _i64, _i, _i]),
+    "cde_rk4_forward_linear_stages": (_i, [_p, _p, _i64, _i, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i, _i,
+                                           _p, _p, _p]),
+    "cde_rk4_backprop_workspace_bytes": (_sz, [_i64]),
+    "cde_rk4_backprop_linear": (_i, [_p, _p, _i64, _i, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i,
+                                     _p, _p, _p, _sz, _p]),
     "cde_dopri5_workspace_bytes": (_sz, [_i64, _i64, _i64, _i]),
     "cde_dopri5_trace_offset": (_sz, [_i64, _i64, _i64, _i]),
     "cde_dopri5_advance": (_i, [_p, _p, _i64, _i, _p, _p, _i, _p, _p, _i64, _p, _i64, _d, _d, _d, _d, _d, _p, _i64, _i64,

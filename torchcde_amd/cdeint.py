@@ -156,6 +156,44 @@ class _Grids:
         self.seg_off = torch.tensor(offsets, dtype=torch.int64).to(device)
         self.seg_off_host = offsets
         self.seg_off_c = (ctypes.c_int64 * len(offsets))(*offsets)      # host copy handed to the C ABI (wide shapes)
+        self._t_host, self._step_size, self._device = t_host, step_size, device
+        self._backprop = None
+
+    def backprop_lists(self):
+        """What the discrete backward (adjoint=False, cde_rk4_backprop_linear) needs besides the stored stages: the step
+        sizes as the forward kernel rounds them, and per grid node the (output index, weight) pairs of torchdiffeq's linear
+        output interpolation transposed (fixed-grid solvers: out = y0 + (t - t0) / (t1 - t0) * (y1 - y0), end points
+        returned as they are) -- the same walk over (grid, t_out) the forward kernel makes."""
+        if self._backprop is None:
+            grid, t_out = _fixed_grid(self._t_host, self._step_size), self._t_host
+            n_steps = grid.numel() - 1
+            nodes = [[] for _ in range(n_steps + 1)]
+            nodes[0].append((0, 1.0))
+            jout = 1
+            for k in range(n_steps):
+                t0, t1 = grid[k], grid[k + 1]
+                while jout < self.n_out and bool(t1 >= t_out[jout]):
+                    tj = t_out[jout]
+                    if bool(tj == t0):
+                        nodes[k].append((jout, 1.0))
+                    elif bool(tj == t1):
+                        nodes[k + 1].append((jout, 1.0))
+                    else:
+                        slope = ((tj - t0) / (t1 - t0)).to(torch.float32)
+                        nodes[k].append((jout, float(torch.ones((), dtype=torch.float32) - slope)))
+                        nodes[k + 1].append((jout, float(slope)))
+                    jout += 1
+            ptr, outs, weights = [0], [], []
+            for entries in nodes:
+                outs += [j for j, _ in entries]
+                weights += [w for _, w in entries]
+                ptr.append(len(outs))
+            dev = self._device
+            self._backprop = (
+                (grid[1:] - grid[:-1]).to(torch.float32).to(dev) if n_steps > 0 else torch.zeros(1, dtype=torch.float32, device=dev),
+                torch.tensor(ptr, dtype=torch.int64).to(dev), torch.tensor(outs, dtype=torch.int64).to(dev),
+                torch.tensor(weights, dtype=torch.float32).to(dev), n_steps)
+        return self._backprop
 
 
 def _grids_for(t_host, step_size, adjoint_step_size, device):
@@ -271,6 +309,50 @@ class _Plan:
         if begin is not None:
             self.owner.event_log.append(("forward", begin, self._mark()))
         return out
+
+    # adjoint=False: K2 that also stores every stage state, and the reverse-mode sweep over them (K3d)
+    def run_forward_stages(self, z0, weight, bias):
+        lib = _lib.load()
+        out = torch.empty(self.B, self.n_out, self.H, dtype=self.dtype, device=self.device)
+        n_steps = max(self.grid.numel() - 1, 0)
+        self.stage_index = torch.empty(max(4 * n_steps, 1), dtype=torch.int64, device=self.device)
+        self.stage_frac = torch.empty(max(4 * n_steps, 1), dtype=self.dtype, device=self.device)
+        stages = torch.empty(self.B, max(n_steps, 1), 4, 32, dtype=torch.float32, device=self.device)
+        z0c = z0.detach().reshape(self.B, self.H).contiguous()
+        w = weight.detach().contiguous()
+        b = bias.detach().contiguous()
+        begin = self._mark()
+        _lib.check(lib.cde_rk4_forward_linear_stages(
+            _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w), _lib.ptr(b),
+            _lib.ptr(z0c), _lib.ptr(self.grid), self.grid.numel(), _lib.ptr(self.t_out), self.n_out, _lib.ptr(out),
+            _lib.ptr(stages), self.B, self.C, self.H, _lib.dtype_enum(self.dtype), _lib.dtype_enum(self.time_dtype),
+            _lib.ptr(self.stage_index), _lib.ptr(self.stage_frac), _lib.stream_ptr(self.device)),
+            "cde_rk4_forward_linear_stages")
+        if begin is not None:
+            self.owner.event_log.append(("forward", begin, self._mark()))
+        return out, stages
+
+    def run_backprop(self, stages, grad_out, weight):
+        lib = _lib.load()
+        step_dt, node_ptr, node_out, node_weight, n_steps = self.grids.backprop_lists()
+        nbytes = lib.cde_rk4_backprop_workspace_bytes(self.B)
+        workspace = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+        grad_z0 = torch.empty(self.B, self.H, dtype=self.dtype, device=self.device)
+        n_w = self.H * self.C * self.H
+        flat = torch.empty(n_w + self.H * self.C, dtype=self.dtype, device=self.device)     # one buffer: see run_adjoint
+        grad_w, grad_b = flat[:n_w].view(self.H * self.C, self.H), flat[n_w:]
+        go = grad_out.detach().reshape(self.B, self.n_out, self.H).contiguous()
+        w = weight.detach().contiguous()
+        begin = self._mark()
+        _lib.check(lib.cde_rk4_backprop_linear(
+            _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w), _lib.ptr(stages),
+            _lib.ptr(go), self.n_out, _lib.ptr(step_dt), n_steps, _lib.ptr(node_ptr), _lib.ptr(node_out),
+            _lib.ptr(node_weight), _lib.ptr(grad_z0), _lib.ptr(grad_w), _lib.ptr(grad_b), self.B, self.C, self.H,
+            _lib.dtype_enum(self.dtype), _lib.ptr(self.stage_index), _lib.ptr(self.stage_frac), _lib.ptr(workspace),
+            workspace.numel(), _lib.stream_ptr(self.device)), "cde_rk4_backprop_linear")
+        if begin is not None:
+            self.owner.event_log.append(("backprop", begin, self._mark()))
+        return grad_z0, grad_w, grad_b
 
     # backward: K3
     def run_adjoint(self, z_saved, grad_out, weight, bias, want_control=False):
@@ -546,6 +628,29 @@ class _FusedRK4(torch.autograd.Function):
                 grad_w.view_as(weight) if (ctx.needs_input_grad[1] and want_w) else None,
                 grad_b.view_as(bias) if (ctx.needs_input_grad[2] and want_b) else None,
                 None, None, grad_t, grad_knots) + control_grads
+
+
+class _FusedRK4Backprop(torch.autograd.Function):
+    """cdeint(..., method='rk4', adjoint=False) for the affine field: torchdiffeq.odeint under autograd (reference
+    solver.py:226-227 with adjoint=False) -- the forward kernel stores the state handed to every field evaluation, the
+    backward is reverse-mode differentiation of the 3/8-rule steps themselves (csrc/rk4_backprop.hip), i.e. the gradient
+    of the discrete solve, as `loss.backward()` through torchdiffeq's own operations gives it."""
+
+    @staticmethod
+    def forward(ctx, z0, weight, bias, plan):
+        out, stages = plan.run_forward_stages(z0, weight, bias)
+        ctx.plan = plan
+        ctx.save_for_backward(weight, stages)
+        return out.reshape(*plan.batch, plan.n_out, plan.H)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        plan = ctx.plan
+        weight, stages = ctx.saved_tensors
+        grad_z0, grad_w, grad_b = plan.run_backprop(stages, grad_out, weight)
+        return (grad_z0.reshape(*plan.batch, plan.H) if ctx.needs_input_grad[0] else None,
+                grad_w.view_as(weight) if ctx.needs_input_grad[1] else None,
+                grad_b if ctx.needs_input_grad[2] else None, None)
 
 
 # ------------------------------------------------------------------------------------------ dopri5 (K4)
@@ -1246,7 +1351,9 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         wants_control=bool(control_wants), params=params_kind,
         adjoint_method_ok=adjoint_method in (None, method), options_ok=options_ok,
         adjoint_options_ok=adjoint_options_ok, t_ok=bool(increasing) or not t_is_vector,
-        variant_generic=variant == _lib.VARIANT_GENERIC, shared=step_control() is not None, narrow_control=C <= 8)
+        variant_generic=variant == _lib.VARIANT_GENERIC, shared=step_control() is not None, narrow_control=C <= 8,
+        backprop_ok=bool(mfma_shape and field.act == _lib.ACT_NONE and variant in (_lib.VARIANT_AUTO, _lib.VARIANT_MFMA)
+                         and not any(b.requires_grad for b in X.buffers())))
     if recognised_kind is not None and known is None:
         # the probe recognised the formula but the shape / dtype is beyond the tiles: say so in the record and the warning
         request = request._replace(kind=recognised_kind, tiles_ok=False)
@@ -1301,6 +1408,9 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
 
     # ---- one-layer fields
     weight, bias = field.weight, field.bias
+    if choice.path == "rk4_backprop":
+        plan = _Plan(X, field, batch, H, C, t, _parse_fixed_options(fused_options, "solver"), None, False, variant)
+        return _FusedRK4Backprop.apply(z0, weight, bias, plan)
     if choice.path in ("dopri5_forward", "dopri5_adjoint"):
         plan = _Dopri5Plan(X, field, batch, H, C, t, kwargs["rtol"], kwargs["atol"], fused_options, variant,
                            kwargs.get("adjoint_rtol"), kwargs.get("adjoint_atol"), fused_adj_opts)

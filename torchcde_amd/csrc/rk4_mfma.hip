@@ -61,17 +61,21 @@ template <int ACT, bool MLP> constexpr int fwd_waves_per_simd() { return 2; }
 
 // SPLIT (two-layer field, at most one tile per CU): the workgroup's 8 waves carry ONE tile together and split layer 2 of
 // every evaluation by unit group (cde_mfma.h: field_mlp16<..., SPLIT>); wave 0 alone writes the outputs.
-template <typename TT, int DEGREE, int ACT, bool MLP = false, int CT = MC, bool SPLIT = false>
+// SAVE (affine field, the backward pass of adjoint=False: rk4_backprop.hip): the state handed to EVERY field evaluation
+// is also written to `stages` (B, n_steps, 4, 32), the 32 units in K3's lane order (evens, then odds: a lane's units
+// 8q .. 8q+7 are two 16-byte stores) -- what reverse-mode autograd would keep of torchdiffeq's rk4 step.
+template <typename TT, int DEGREE, int ACT, bool MLP = false, int CT = MC, bool SPLIT = false, bool SAVE = false>
 __global__ __launch_bounds__((fwd_block_threads<ACT, MLP>()), (fwd_waves_per_simd<ACT, MLP>())) void rk4_forward_mfma(
     const float* __restrict__ coeffs, const float* __restrict__ knots, int64_t n_intervals,
     const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ z0,
     const TT* __restrict__ grid, int64_t n_grid, const TT* __restrict__ t_out, int64_t n_out,
     float* __restrict__ z_out, int64_t B, const int64_t* __restrict__ stage_index,
     const float* __restrict__ stage_frac, Dims dims, const float* __restrict__ W1 = nullptr,
-    const float* __restrict__ bias1 = nullptr, int width = 0) {
+    const float* __restrict__ bias1 = nullptr, int width = 0, float* __restrict__ stages = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // the A-operand image is loop invariant: staged once through LDS, then it lives in registers
   constexpr bool PRODUCT = ACT == CDE_ACT_NONE && !MLP;
+  static_assert(!SAVE || (PRODUCT && CT == MC), "stage states are stored by the affine field's kernel only");
   constexpr int STRIDE = PRODUCT ? 1 : 4;          // distance between a lane's consecutive hidden units
   float4 wA[PRODUCT ? W16_GROUPS : 1], wB[PRODUCT ? W16_GROUPS : 1];
   if constexpr (PRODUCT) load_w16(W, bias, lds, wA, wB, dims);
@@ -133,6 +137,13 @@ __global__ __launch_bounds__((fwd_block_threads<ACT, MLP>()), (fwd_waves_per_sim
       // this wave / the MFMA phase of the other waves on the SIMD)
       Row<DEGREE, CT> nrow = row;
       if constexpr (PRODUCT) { if (nidx != idx) nrow = load_row<DEGREE, CT>(coeffs, sc, n_intervals, nidx, Cr); }
+      if constexpr (SAVE) {
+        if (valid) {
+          float* srow = stages + ((series * n_steps + k) * 4 + stage) * 32;
+          *reinterpret_cast<float4*>(srow + 4 * q) = make_float4(za[0], za[2], zb[0], zb[2]);            // units 8q, 8q+2, ..
+          *reinterpret_cast<float4*>(srow + 16 + 4 * q) = make_float4(za[1], za[3], zb[1], zb[3]);       // units 8q+1, 8q+3, ..
+        }
+      }
 
       f32x4 fa, fb;
       if constexpr (PRODUCT) { if constexpr (CT == MC) field16(wA, wB, za, zb, dX, q, fa, fb); }
@@ -1176,6 +1187,33 @@ int launch_forward_mlp(const void* coeffs, const void* knots, int64_t n_interval
 #undef CDE_FWD_CT
   return check_launch();
 }
+
+// K2 with the stage states stored (adjoint=False backward: rk4_backprop.hip).  Affine field, f32, H <= 32, C <= 8.
+template <typename TT>
+int launch_forward_mfma_stages(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
+                               const void* bias, const void* z0, const void* grid, int64_t n_grid, const void* t_out,
+                               int64_t n_out, void* z_out, void* stages, int64_t B, int64_t C, int64_t H,
+                               const int64_t* stage_index, const void* stage_frac, hipStream_t s) {
+  const Dims dims{(int)H, (int)C};
+  constexpr int threads = fwd_block_threads<CDE_ACT_NONE, false>();
+#define CDE_FWD_S(D)                                                                                                  \
+  rk4_forward_mfma<TT, D, CDE_ACT_NONE, false, MC, false, true>                                                       \
+      <<<(unsigned)((B + threads / 4 - 1) / (threads / 4)), threads, W16_FLOATS * sizeof(float), s>>>(                \
+          (const float*)coeffs, (const float*)knots, n_intervals, (const float*)W, (const float*)bias,                \
+          (const float*)z0, (const TT*)grid, n_grid, (const TT*)t_out, n_out, (float*)z_out, B, stage_index,          \
+          (const float*)stage_frac, dims, nullptr, nullptr, 0, (float*)stages)
+  if (degree == CDE_PATH_CUBIC) CDE_FWD_S(CDE_PATH_CUBIC);
+  else if (degree == CDE_PATH_LINEAR) CDE_FWD_S(CDE_PATH_LINEAR);
+  else return CDE_ERR_UNSUPPORTED;
+#undef CDE_FWD_S
+  return check_launch();
+}
+template int launch_forward_mfma_stages<float>(const void*, const void*, int64_t, int, const void*, const void*, const void*,
+                                               const void*, int64_t, const void*, int64_t, void*, void*, int64_t, int64_t,
+                                               int64_t, const int64_t*, const void*, hipStream_t);
+template int launch_forward_mfma_stages<double>(const void*, const void*, int64_t, int, const void*, const void*, const void*,
+                                                const void*, int64_t, const void*, int64_t, void*, void*, int64_t, int64_t,
+                                                int64_t, const int64_t*, const void*, hipStream_t);
 
 // which of the two adjoint kernels of the affine field runs: K3j (shared Jacobian) unless CDE_K3_FORM=product asks for K3
 // (the tests run both against the oracle; scripts compare their timings)

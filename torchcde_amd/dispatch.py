@@ -32,6 +32,8 @@ Request = collections.namedtuple("Request", [
     "variant_generic",   # variant="generic" (tests: the independent kernels / the step-wise reference path)
     "shared",            # torchcde_amd.distributed.shared_step_control is active
     "narrow_control",    # the control has at most 8 channels (control gradients of a two-layer field)
+    "backprop_ok",       # the fused reverse-mode sweep applies (adjoint=False): identity-activation affine field on the 32 x 8
+                         # tiles, float32, no control tensor that requires a gradient
 ])
 
 Choice = collections.namedtuple("Choice", ["path", "reason"])
@@ -44,6 +46,7 @@ FUSED_PATHS = (
     "mlp_rk4_adjoint",        # K2m + K3m + factor reduction (optionally with control gradients)
     "mlp_dopri5_forward",     # K4 with the two-layer field
     "mlp_dopri5_adjoint",     # K4 + K4am: the reference examples' training call with their own model
+    "rk4_backprop",           # adjoint=False: K2 storing its stage states + K3d, reverse mode through the solver's steps
 )
 STEPWISE = "stepwise"
 
@@ -65,7 +68,10 @@ def select_path(q):
     if q.method not in ("rk4", "dopri5"):
         return _stepwise("method %r has no fused kernel (rk4 and dopri5 have)" % (q.method,))
     if q.wants_grad and not q.adjoint:
-        return _stepwise("adjoint=False with gradients: backpropagation through the solver's own operations")
+        if q.kind == "affine" and q.backprop_ok and q.method == "rk4" and q.options_ok and not q.wants_t:
+            return Choice("rk4_backprop", "")
+        return _stepwise("adjoint=False with gradients: backpropagation through the solver's own operations (fused for "
+                         "the identity-activation affine field under rk4 only)")
     if not q.options_ok:
         return _stepwise("solver options outside the fused kernels' set")
     if q.wants_grad and not q.adjoint_method_ok:
