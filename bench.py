@@ -277,7 +277,7 @@ def backprop_mode(cde, X, func, z0, steps=10):
     K2 storing its stage states + K3d, the reverse-mode sweep of csrc/rk4_backprop.hip -- the gradient of the DISCRETE
     solve.  NOT the reported `value` (BASELINE's metric is forward + adjoint).  ms per forward + backward step, wall clock
     over `steps`, and the two kernels' own durations from HIP events on the launching stream."""
-    import torchcde_amd.cdeint as front
+    front = sys.modules["torchcde_amd.cdeint"]            # its `event_log` attribute is this thread's
     kw = dict(method="rk4", options={"step_size": 1.0}, adjoint=False)
     params = list(func.parameters())
 
@@ -829,7 +829,9 @@ def main():
         value = total_series / elapsed
         split = B <= 16384                      # CDE_SPLIT_MAX_BATCH: workgroup-per-tile kernels below, K2/K3 above
         jacobian = not os.environ.get("CDE_K3_FORM", "").startswith("p")
-        kernel = ("rk4_adjoint_split8" if split else "rk4_adjoint_jacobian" if jacobian else "rk4_adjoint_mfma")
+        pair = jacobian and os.environ.get("CDE_K3_WAVES", "2") != "1"        # K3p: chain + helper wave per tile (the default)
+        kernel = ("rk4_adjoint_split8" if split else "rk4_adjoint_jacobian_pair" if pair else
+                  "rk4_adjoint_jacobian" if jacobian else "rk4_adjoint_mfma")
         # `achieved` = the flop the kernel's formulation EXECUTES per launch / its average duration.  The default kernels of
         # the affine field take f AND a^T df/dz from the shared Jacobian J = sum_c dX_c W_c: per series and evaluation
         # 33,280 flop on the matrix pipe (J with its bias rows, dL/dW) + 4,352 on the vector pipe (two H x H matrix-vector
@@ -869,7 +871,7 @@ def main():
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                          "mfma_frac": mfma_tf / PEAK_F32_MFMA_TFLOPS, "mfma_tflops": mfma_tf,
                          "kernel": kernel + {"rk4_adjoint_split8": " (K3s)", "rk4_adjoint_jacobian": " (K3j)",
-                                             "rk4_adjoint_mfma": " (K3)"}[kernel],
+                                             "rk4_adjoint_jacobian_pair": " (K3p)", "rk4_adjoint_mfma": " (K3)"}[kernel],
                          "kernel_ms": adj_avg, "executed_flop_per_launch": flop_exec,
                          "formulation": ("shared Jacobian: 33,280 MFMA + 4,352 VALU flop per series and evaluation" if jacobian
                                          else "three GEMMs: 50,432 flop per series and evaluation (SURVEY 8(d))"),

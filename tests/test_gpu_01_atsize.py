@@ -546,7 +546,7 @@ def test_full_size_properties_nonlinear_fields(native):
 
 def test_affine_field_adjoint_forms_at_benchmark_size(native, monkeypatch):
     """The headline workload (32768 x 128 x 8, H = 32) through both reverse-sweep forms of the affine field, every SIMD of
-    the chip busy: finite, run-to-run bit-identical (K3j's Jacobian rows are hand-scheduled asm MFMAs: a hazard would
+    the chip busy: finite, run-to-run bit-identical (the Jacobian rows of K3j / K3p are hand-scheduled asm MFMAs: a hazard would
     show up here, as it did for the bf16 rows before they got their wait states), and the two forms within 1e-5 of each
     other's scale (the oracle comparison at this size is test_config3_full_batch_against_the_oracle)."""
     B, L, C, H = 32768, 128, 8, 32
@@ -554,8 +554,10 @@ def test_affine_field_adjoint_forms_at_benchmark_size(native, monkeypatch):
     X = native.CubicSpline(native.hermite_cubic_coefficients_with_backward_differences(x))
     z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(0)).to(DEV)
     res = {}
-    for form in ("jacobian", "jacobian", "jacobian", "product"):
-        monkeypatch.setenv("CDE_K3_FORM", form)
+    for form in ("jacobian", "jacobian", "jacobian", "one_wave", "product"):
+        # "jacobian": K3p, a chain wave + a helper wave per tile (the default); "one_wave": K3j (CDE_K3_WAVES=1), bitwise the same
+        monkeypatch.setenv("CDE_K3_FORM", "product" if form == "product" else "jacobian")
+        monkeypatch.setenv("CDE_K3_WAVES", "1" if form == "one_wave" else "2")
         f = LinearField(H, C, scale=0.25, seed=0).to(DEV)
         z = z0.clone().requires_grad_(True)
         out = native.cdeint(X, f, z, X.interval, method="rk4", options=dict(step_size=1.0), variant="mfma")
@@ -566,6 +568,8 @@ def test_affine_field_adjoint_forms_at_benchmark_size(native, monkeypatch):
     for other in res["jacobian"][1:]:
         for a_, b_ in zip(res["jacobian"][0], other):
             assert torch.equal(a_, b_)
+    for a_, b_ in zip(res["jacobian"][0], res["one_wave"][0]):
+        assert torch.equal(a_, b_)
     for a_, b_ in zip(res["jacobian"][0], res["product"][0]):
         _close(a_, b_, 1e-5, 1e-5 * b_.abs().max().item())
 

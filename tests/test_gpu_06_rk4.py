@@ -102,6 +102,18 @@ def test_affine_field_adjoint_in_both_forms(native, monkeypatch, H, C, degree, v
     for a_, b_ in zip(got["jacobian"], got["product"]):
         assert not torch.equal(a_, b_)                     # (two different kernels did run)
         _close(a_, b_, 1e-4, 1e-5 * b_.abs().max().item())
+    if variant == "mfma":
+        # the Jacobian form itself comes as one wave per tile (K3j, CDE_K3_WAVES=1) and, the default since round 5, as a
+        # chain wave + a helper wave per tile on one SIMD (K3p, csrc/rk4_adjoint_pair.hip): the same operations in the
+        # same order -- bit for bit
+        monkeypatch.setenv("CDE_K3_FORM", "jacobian")
+        monkeypatch.setenv("CDE_K3_WAVES", "1")
+        dfunc = LinearField(H, C, torch.float32, scale=0.25, seed=5).to(DEV)
+        z = z0.to(DEV).requires_grad_(True)
+        out = native.cdeint(X, dfunc, z, t_out.to(DEV), method="rk4", options=dict(step_size=1.0), variant=variant)
+        (out * lw.to(DEV)).sum().backward()
+        for a_, b_ in zip(got["jacobian"], (z.grad, dfunc.linear.weight.grad, dfunc.linear.bias.grad)):
+            assert torch.equal(a_, b_)
 
 
 @pytest.mark.parametrize("H,C,degree", [(32, 8, 3), (32, 8, 1), (20, 5, 3)])

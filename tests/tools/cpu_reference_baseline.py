@@ -3,7 +3,7 @@
 torchcde.solver._VectorField imported unmodified from /root/reference, the reference's own
 hermite_cubic_coefficients_with_backward_differences, driven by the oracle's restatement of torchdiffeq (registered as
 the `torchdiffeq` module: the real package is not installable here).  Runs only where /root/reference exists (the
-build container, not the GPU box); writes profiles/r02_cpu_reference_container.json.
+build container, not the GPU box); writes profiles/r05_cpu_reference_container.json.
 
     python tests/tools/cpu_reference_baseline.py [series=4096] [threads=all]
 """
@@ -63,6 +63,6 @@ for name, fn in (("fit", lambda: fit()[0]), ("forward", lambda: solve(coeffs, Fa
     res[name + "_s_median"] = statistics.median(times)
     res[name + "_series_per_s_median"] = n / statistics.median(times)
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-with open(os.path.join(ROOT, "profiles", "r02_cpu_reference_container.json"), "w") as fh:
+with open(os.path.join(ROOT, "profiles", "r05_cpu_reference_container.json"), "w") as fh:
     json.dump(res, fh, indent=1)
 print(json.dumps(res))

@@ -17,7 +17,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 PHASE_TRACE = os.environ.get("CDE_PHASE_TRACE", "") == "1"
 SO_PATH = os.path.join(_HERE, "libcde_mi355x_trace.so" if PHASE_TRACE else "libcde_mi355x.so")
 SOURCES = ["interp_kernels.hip", "rk4_generic.hip", "rk4_mfma.hip", "rk4_split.hip", "rk4_wide.hip", "rk4_mlp_adjoint.hip",
-           "rk4_bf16x3.hip", "rk4_backprop.hip", "dopri5.hip", "dopri5_adjoint.hip", "dopri5_mlp_adjoint.hip", "mlp_grad_reduce.hip", "api.hip"]
+           "rk4_bf16x3.hip", "rk4_backprop.hip", "rk4_adjoint_pair.hip", "dopri5.hip", "dopri5_adjoint.hip", "dopri5_mlp_adjoint.hip", "mlp_grad_reduce.hip", "api.hip"]
 HEADERS = [os.path.join(_CSRC, "cde_common.h"), os.path.join(_CSRC, "cde_mfma.h"), os.path.join(_CSRC, "cde_split.h"),
            os.path.join(_CSRC, "cde_dopri.h"), os.path.join(_CSRC, "cde_dopri_adj.h"), os.path.join(_CSRC, "cde_mlp_adj.h"),
            os.path.join(_HERE, "..", "include", "cde_mi355x.h")]
@@ -28,6 +28,7 @@ if PHASE_TRACE:
 # away, and on gfx950 every v_accvgpr_read costs matrix-pipe time (f32 MFMA and VALU do not overlap within a wave).
 EXTRA_FLAGS = {"rk4_split.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                "rk4_wide.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+               "rk4_adjoint_pair.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                "dopri5_adjoint.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 F32, F64 = 0, 1

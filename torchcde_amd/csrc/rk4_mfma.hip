@@ -1222,6 +1222,18 @@ static bool k3_form_jacobian() {
   return !(e && e[0] == 'p');
 }
 
+// K3p (rk4_adjoint_pair.hip): K3j as a chain wave + a helper wave per tile, two waves per SIMD.  CDE_K3_WAVES=1 / 2 in the
+// environment picks the form (tests run both; bitwise the same results)
+template <typename TT>
+int launch_adjoint_jacobian_pair(const void*, const void*, int64_t, int, const void*, const void*, const void*, const void*,
+                                 const void*, const int64_t*, int64_t, void*, void*, void*, int64_t, int64_t, int64_t,
+                                 const int64_t*, const void*, float*, hipStream_t);
+constexpr bool K3_PAIR_DEFAULT = true;       // 5.26 -> 5.01 ms on the headline workload (profiles/r05_k3_pair_b.log)
+static bool k3_form_pair() {
+  const char* e = getenv("CDE_K3_WAVES");
+  return e ? e[0] == '2' : K3_PAIR_DEFAULT;
+}
+
 template <typename TT>
 int launch_adjoint_mfma(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
                         const void* bias, int act, const void* z_saved, const void* grad_out, const void* sgrid,
@@ -1257,6 +1269,9 @@ int launch_adjoint_mfma(const void* coeffs, const void* knots, int64_t n_interva
       if (degree == CDE_PATH_CUBIC) CDE_ADJ_DX((rk4_adjoint_act_mfma<TT, CDE_PATH_CUBIC, CDE_ACT_TANH, true>));
       else CDE_ADJ_DX((rk4_adjoint_act_mfma<TT, CDE_PATH_LINEAR, CDE_ACT_TANH, true>));
     } else return CDE_ERR_UNSUPPORTED;
+  } else if (act == CDE_ACT_NONE && k3_form_jacobian() && k3_form_pair()) {
+    return launch_adjoint_jacobian_pair<TT>(coeffs, knots, n_intervals, degree, W, bias, z_saved, grad_out, sgrid, seg_off,
+                                            n_out, grad_z0, grad_W, grad_b, B, C, H, stage_index, stage_frac, partial, s);
   } else if (act == CDE_ACT_NONE && k3_form_jacobian()) {
     if (degree == CDE_PATH_CUBIC) CDE_ADJ((rk4_adjoint_jacobian<TT, CDE_PATH_CUBIC>), WJ_FLOATS + 4 * SCR_FLOATS);
     else CDE_ADJ((rk4_adjoint_jacobian<TT, CDE_PATH_LINEAR>), WJ_FLOATS + 4 * SCR_FLOATS);
