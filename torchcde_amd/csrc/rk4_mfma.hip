@@ -1072,8 +1072,29 @@ __global__ __launch_bounds__(256, 1) void rk4_adjoint_act_mfma(
   }
 }
 
-// sum per-wave partials in tile order (deterministic)
-__global__ __launch_bounds__(256) void reduce_mfma_partials(const float* __restrict__ partial, int64_t n_tiles,
+// Sum the per-wave partials in a FIXED order (run-to-run deterministic: reference test/test_tricks.py:111-131 compares
+// gradients bitwise), in two passes: pass 1 adds up groups of consecutive tiles -- one lane per entry of the padded
+// (32, 8, 32) + (32, 8) layout and group, the group's sum written over its first tile (a lane only ever touches its own
+// entry) -- pass 2 adds the at most 16 group sums in group order, one lane per REAL gradient entry.  (Round 4: one pass
+// with 33 workgroups walking all 1,024 tiles took 83 us at 32768 series -- 0.4 TB/s; pass 1 now runs 33 x 16 workgroups.)
+constexpr int REDUCE_GROUPS = 16;
+__global__ __launch_bounds__(256) void reduce_mfma_partials_groups(float* __restrict__ partial, int64_t n_tiles, int64_t group) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t t0 = (int64_t)blockIdx.y * group;
+  if (e >= PARTIAL_FLOATS || t0 >= n_tiles) return;
+  const int64_t t1 = t0 + group < n_tiles ? t0 + group : n_tiles;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int64_t t = t0;
+  for (; t + 3 < t1; t += 4) {
+    s0 += partial[(t + 0) * PARTIAL_FLOATS + e];
+    s1 += partial[(t + 1) * PARTIAL_FLOATS + e];
+    s2 += partial[(t + 2) * PARTIAL_FLOATS + e];
+    s3 += partial[(t + 3) * PARTIAL_FLOATS + e];
+  }
+  for (; t < t1; ++t) s0 += partial[t * PARTIAL_FLOATS + e];
+  partial[t0 * PARTIAL_FLOATS + e] = (s0 + s1) + (s2 + s3);
+}
+__global__ __launch_bounds__(256) void reduce_mfma_partials(const float* __restrict__ partial, int64_t n_tiles, int64_t group,
                                                             float* __restrict__ grad_W, float* __restrict__ grad_b,
                                                             Dims d) {
   // one lane per REAL gradient entry; `e` is its position in the padded (32, 8, 32) + (32, 8) partial layout
@@ -1083,16 +1104,8 @@ __global__ __launch_bounds__(256) void reduce_mfma_partials(const float* __restr
   int64_t e;
   if (id < n_w) { const int64_t k = id % d.H, hc = id / d.H, c = hc % d.C, h = hc / d.C; e = (h * MC + c) * MH + k; }
   else { const int64_t hc = id - n_w, c = hc % d.C, h = hc / d.C; e = (int64_t)MH * MC * MH + h * MC + c; }
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int64_t t = 0;
-  for (; t + 3 < n_tiles; t += 4) {
-    s0 += partial[(t + 0) * PARTIAL_FLOATS + e];
-    s1 += partial[(t + 1) * PARTIAL_FLOATS + e];
-    s2 += partial[(t + 2) * PARTIAL_FLOATS + e];
-    s3 += partial[(t + 3) * PARTIAL_FLOATS + e];
-  }
-  for (; t < n_tiles; ++t) s0 += partial[t * PARTIAL_FLOATS + e];
-  const float sum = (s0 + s1) + (s2 + s3);
+  float sum = 0.f;
+  for (int64_t t = 0; t < n_tiles; t += group) sum += partial[t * PARTIAL_FLOATS + e];
   if (id < n_w) grad_W[id] = sum; else grad_b[id - n_w] = sum;
 }
 
@@ -1103,7 +1116,13 @@ bool mlp_shape_ok(int64_t C, int64_t H, int64_t width) {
 }
 
 int launch_reduce_partials(const float* partial, int64_t n_tiles, void* grad_W, void* grad_b, int H, int C, hipStream_t s) {
-  reduce_mfma_partials<<<(unsigned)((H * C * H + H * C + 255) / 256), 256, 0, s>>>(partial, n_tiles, (float*)grad_W,
+  // (`partial` is the caller's scratch: pass 1 overwrites the first tile of every group with the group's sum)
+  const int64_t group = (n_tiles + REDUCE_GROUPS - 1) / REDUCE_GROUPS > 0 ? (n_tiles + REDUCE_GROUPS - 1) / REDUCE_GROUPS : 1;
+  const unsigned n_groups = (unsigned)((n_tiles + group - 1) / group);
+  if (n_tiles > 0)
+    reduce_mfma_partials_groups<<<dim3((unsigned)((PARTIAL_FLOATS + 255) / 256), n_groups), 256, 0, s>>>(
+        const_cast<float*>(partial), n_tiles, group);
+  reduce_mfma_partials<<<(unsigned)((H * C * H + H * C + 255) / 256), 256, 0, s>>>(partial, n_tiles, group, (float*)grad_W,
                                                                                  (float*)grad_b, Dims{H, C});
   return check_launch();
 }
