@@ -68,6 +68,17 @@ enum {
 };
 #define CDE_SPLIT_MAX_BATCH 16384
 
+/* Environment knobs (tests and measurements only; the library keeps no state of its own, so they are read at the call
+ * that queues the launch -- hold them fixed for the duration of a solve):
+ *   CDE_K3_FORM=product | jacobian      reverse sweep of the affine field: two GEMMs against W, or the shared Jacobian (default)
+ *   CDE_K3_WAVES=1 | 2                  its Jacobian form as one wave per tile (K3j) or as chain + helper wave (K3p, default)
+ *   CDE_K2M_NO_SPLIT, CDE_K3M_NO_SPLIT, CDE_K3M_SPLIT4, CDE_K4_NO_SPLIT, CDE_K4M_NO_SPLIT, CDE_K4AM_NO_SPLIT,
+ *   CDE_K4AM_SPLIT4, CDE_K4AM_WAVES=8, CDE_K4AM_NO_SMALL_REDUCE     select the other workgroup shape of a kernel family
+ *   CDE_K4AM_NO_FSAL                    evaluate every first stage (bit-identical results; tests compare the two)
+ *   CDE_K3M_S8_TILES, CDE_K4AM_S8_TILES, CDE_K4M_SPLIT_TILES, CDE_K4AM_SPS   thresholds; clamped to the measured limits (an
+ *                                       override can only LOWER them)
+ *   CDE_WIDE_SCRATCH_BYTES              chunk budget of the wide-shape sweep
+ * None of them changes what is computed beyond summation order; every form is tested against the oracle. */
 int cde_abi_version(void);
 const char* cde_error_string(int code);
 

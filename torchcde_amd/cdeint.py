@@ -810,17 +810,21 @@ class _Dopri5Plan:
             off = lib.cde_dopri5_adjoint_carry_offset(B, C, H)
             carry = workspace[off:off + 8].view(torch.float64)        # vjp_t, carried across the intervals on the device
             carry.zero_()
+        if want_t:
+            # torchdiffeq: func_eval = func(t[i], y[i]); dLd_cur_t = func_eval . grad_y[i]; aug_state[0] -= dLd_cur_t -- the
+            # field at ALL output times in one batched evaluation before the loop
+            pre = torch.nn.functional.linear(z_saved[:, 1:], w, b)                            # (B, T - 1, H * C)
+            if self.act == _lib.ACT_TANH:
+                pre = pre.tanh()
+            dX = self.path.derivative(self.t_out[1:]).reshape(B, self.n_out - 1, C)
+            f_all = (pre.view(B, self.n_out - 1, H, C) * dX.unsqueeze(2)).sum(-1)
+            terms = (f_all * grad_out[:, 1:]).sum((0, 2))
+            for i in range(1, self.n_out):
+                time_terms[i] = terms[i - 1]
         for i in range(self.n_out - 1, 0, -1):
             y = z_saved[:, i].contiguous()
             s0, s1 = -float(self.t_host[i]), -float(self.t_host[i - 1])
             if want_t:
-                # torchdiffeq: func_eval = func(t[i], y[i]); dLd_cur_t = func_eval . grad_y[i]; aug_state[0] -= dLd_cur_t
-                pre = torch.nn.functional.linear(y, w, b)
-                if self.act == _lib.ACT_TANH:
-                    pre = pre.tanh()
-                dX = self.path.derivative(self.t_out[i]).reshape(B, C)
-                f_i = (pre.view(B, H, C) * dX.unsqueeze(1)).sum(-1)
-                time_terms[i] = (f_i * grad_out[:, i]).sum()
                 carry.copy_((carry.to(torch.float32) - time_terms[i]).to(torch.float64))
             launched = 0
             while True:
@@ -925,15 +929,18 @@ class _Dopri5Plan:
             off = lib.cde_dopri5_adjoint_mlp_carry_offset(B, C, H)
             carry = workspace[off:off + 8].view(torch.float64)
             carry.zero_()
+        if want_t:                              # torchdiffeq: aug_state[0] -= func(t[i], y[i]) . grad_y[i], all output times at once
+            pre = torch.nn.functional.linear(torch.nn.functional.linear(z_saved[:, 1:], w1, b1).relu(), w2, b2)
+            if self.act == _lib.ACT_TANH:
+                pre = pre.tanh()
+            dX = self.path.derivative(self.t_out[1:]).reshape(B, self.n_out - 1, C)
+            terms = ((pre.view(B, self.n_out - 1, H, C) * dX.unsqueeze(2)).sum(-1) * grad_out[:, 1:]).sum((0, 2))
+            for i in range(1, self.n_out):
+                time_terms[i] = terms[i - 1]
         for i in range(self.n_out - 1, 0, -1):
             y = z_saved[:, i].contiguous()
             s0, s1 = -float(self.t_host[i]), -float(self.t_host[i - 1])
-            if want_t:                                                # torchdiffeq: aug_state[0] -= func(t[i], y[i]) . grad_y[i]
-                pre = torch.nn.functional.linear(torch.nn.functional.linear(y, w1, b1).relu(), w2, b2)
-                if self.act == _lib.ACT_TANH:
-                    pre = pre.tanh()
-                dX = self.path.derivative(self.t_out[i]).reshape(B, C)
-                time_terms[i] = ((pre.view(B, H, C) * dX.unsqueeze(1)).sum(-1) * grad_out[:, i]).sum()
+            if want_t:
                 carry.copy_((carry.to(torch.float32) - time_terms[i]).to(torch.float64))
             launched = 0
             while True:

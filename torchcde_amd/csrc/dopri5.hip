@@ -1194,7 +1194,9 @@ static int dopri5_advance_impl(const void* coeffs, const void* knots, int64_t n_
       // up to 256 tiles (one workgroup per CU): the 8 waves of a workgroup share a tile
       const int64_t tiles = (B + 15) / 16;
       const char* split_env = getenv("CDE_K4M_SPLIT_TILES");                    // (measurements)
-      const int64_t split_tiles = split_env ? atoll(split_env) : (C > cde::MC ? 256 : cde::DOPRI_MLP_SPLIT_TILES);
+      // (an override can only LOWER the threshold: the split form was measured and tested up to these tile counts)
+      const int64_t split_max = C > cde::MC ? 256 : cde::DOPRI_MLP_SPLIT_TILES;
+      const int64_t split_tiles = split_env ? (atoll(split_env) < split_max ? (atoll(split_env) > 0 ? atoll(split_env) : 0) : split_max) : split_max;
       const bool split = tiles <= split_tiles && !ext_sums && B_global == 0 && !getenv("CDE_K4M_NO_SPLIT");
       const size_t lds_split = lds + (size_t)cde::DOPRI_XWIN_FLOATS * sizeof(float);
 #define CDE_MLP_CT(D, A, CTV)                                                                                      \

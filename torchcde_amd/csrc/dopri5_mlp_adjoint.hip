@@ -1095,7 +1095,8 @@ MadjLayout madj_layout(int64_t B, int64_t H, int64_t C) {
   //  whatever the batch -- measured per attempted step: 8192 series 320 -> 210 us, 12288: 341 -> 303, 16384: 360 vs 394;
   //  CDE_K4AM_S8_TILES overrides the threshold, for measurements)
   const char* s8_env = getenv("CDE_K4AM_S8_TILES");
-  const int64_t s8_tiles = s8_env ? atoll(s8_env) : MADJ_S8_MAX_TILES;
+  const int64_t s8_req = s8_env ? atoll(s8_env) : MADJ_S8_MAX_TILES;      // (an override can only LOWER the measured limit)
+  const int64_t s8_tiles = s8_req < 0 ? 0 : s8_req > MADJ_S8_MAX_TILES ? MADJ_S8_MAX_TILES : s8_req;
   const bool s8_shape = C <= MC && !getenv("CDE_K4AM_SPLIT4");
   L.split = L.n_tiles <= (s8_shape && s8_tiles > MADJ_SPLIT_MAX_TILES ? s8_tiles : MADJ_SPLIT_MAX_TILES) &&
             !getenv("CDE_K4AM_NO_SPLIT");
