@@ -17,7 +17,7 @@ def main(d, out=None):
         q = ("select kernel_name, counter_name, avg(value), count(*), avg(end-start) from counters_collection "
              "where kernel_name like '%cde::%' group by kernel_name, counter_name")
         for kern, ctr, val, n, dur in con.execute(q):
-            short = kern.split("(")[0].replace("void ", "")
+            short = kern.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
             rows.setdefault(short, {})[ctr] = val
             rows[short].setdefault("dur_ns_" + name, dur)
     lines = []
