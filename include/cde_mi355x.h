@@ -68,6 +68,10 @@ enum {
 };
 #define CDE_SPLIT_MAX_BATCH 16384
 
+/* torchdiffeq's fixed-grid methods: rk4 is the 3/8 rule (rk4_alt_step_func), midpoint
+ * y1 = y0 + dt f(t0 + dt/2, y0 + f(t0, y0) dt/2), euler y1 = y0 + dt f(t0, y0) */
+enum { CDE_METHOD_RK4 = 0, CDE_METHOD_MIDPOINT = 1, CDE_METHOD_EULER = 2 };
+
 /* Environment knobs (tests and measurements only; the library keeps no state of its own, so they are read at the call
  * that queues the launch -- hold them fixed for the duration of a solve):
  *   CDE_K3_FORM=product | jacobian      reverse sweep of the affine field: two GEMMs against W, or the shared Jacobian (default)
@@ -373,6 +377,27 @@ int cde_rk4_adjoint_linear_dcontrol(const void* coeffs, const void* knots, int64
                                     int64_t n_out, void* grad_z0, void* grad_W, void* grad_b, void* grad_coeffs,
                                     int64_t B, int64_t C, int64_t H, int dtype, int time_dtype, void* workspace,
                                     size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * torchdiffeq's other fixed-grid methods, `midpoint` and `euler` (reference test/test_cdeint.py:49-63 solves with
+ * method='midpoint'; solver.py:226-227 forwards `method` verbatim), for the affine field with act == CDE_ACT_NONE on the
+ * 32 x 8 tiles (f32, H <= 32, C <= 8: cde_fixed_supported; otherwise CDE_ERR_UNSUPPORTED and the Python host steps the
+ * solve itself).  K2 / K3p with two stages / one stage per step; the continuous adjoint integrates the augmented state
+ * with the same method in reversed time (parameter gradients: quadrature weights (0, ds) / (ds)).  Arguments as
+ * cde_rk4_forward_linear / cde_rk4_adjoint_linear without `act`, `variant`, `seg_off_host`; the stage table keeps four
+ * slots per step (a method uses the first two / one); workspace of cde_fixed_adjoint_workspace_bytes(B, n_sgrid).
+ * ------------------------------------------------------------------------------------------- */
+int cde_fixed_supported(int method, int64_t C, int64_t H, int dtype, int act);
+int cde_fixed_forward_linear(int method, const void* coeffs, const void* knots, int64_t n_intervals, int degree,
+                             const void* W, const void* bias, const void* z0, const void* grid, int64_t n_grid,
+                             const void* t_out, int64_t n_out, void* z_out, int64_t B, int64_t C, int64_t H, int dtype,
+                             int time_dtype, int64_t* stage_index, void* stage_frac, void* stream);
+size_t cde_fixed_adjoint_workspace_bytes(int64_t B, int64_t n_sgrid);
+int cde_fixed_adjoint_linear(int method, const void* coeffs, const void* knots, int64_t n_intervals, int degree,
+                             const void* W, const void* bias, const void* z_saved, const void* grad_out, const void* sgrid,
+                             int64_t n_sgrid, const int64_t* seg_off, int64_t n_out, void* grad_z0, void* grad_W,
+                             void* grad_b, int64_t B, int64_t C, int64_t H, int dtype, int time_dtype, void* workspace,
+                             size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K3d  The backward pass of cdeint(..., method='rk4', adjoint=False) for the affine field (reference solver.py:144,

@@ -38,6 +38,11 @@ CASES = {
     "affine_rk4_backprop":       (dict(adjoint=False), "rk4_backprop", ("narrow_control",)),
     "affine_backprop_beyond_the_kernel": (dict(adjoint=False, backprop_ok=False), "stepwise",
                                           ("mfma_shape", "variant_generic", "narrow_control")),
+    # ------------------------------------------------------------------ torchdiffeq's other fixed-grid methods
+    "affine_midpoint":           (dict(method="midpoint"), "fixed_grid", ("narrow_control",)),
+    "affine_euler":              (dict(method="euler"), "fixed_grid", ("narrow_control",)),
+    "affine_midpoint_forward":   (dict(method="midpoint", wants_grad=False), "fixed_grid", ()),
+    "midpoint_beyond_the_kernel": (dict(method="midpoint", backprop_ok=False), "stepwise", ("mfma_shape", "variant_generic")),
     # ------------------------------------------------------------------ the examples' two-layer field
     "two_layer_rk4":             (dict(_MLP), "mlp_rk4_adjoint", ("narrow_control",)),
     "two_layer_rk4_control":     (dict(_MLP, wants_control=True, params="own"), "mlp_rk4_adjoint", ("wants_t",)),
@@ -54,14 +59,16 @@ CASES = {
                                                      "stepwise", ("variant_generic",)),
 }
 
-GRAD_FN = {"rk4_backprop": "_FusedRK4BackpropBackward", "rk4": "_FusedRK4Backward", "dopri5_adjoint": "_FusedDopri5Backward", "mlp_rk4_adjoint": "_FusedMlpRK4Backward",
+GRAD_FN = {"rk4_backprop": "_FusedRK4BackpropBackward", "rk4": "_FusedRK4Backward", "fixed_grid": "_FusedRK4Backward", "dopri5_adjoint": "_FusedDopri5Backward", "mlp_rk4_adjoint": "_FusedMlpRK4Backward",
            "mlp_dopri5_adjoint": "_FusedMlpDopri5Backward"}
 
 
 def _free(name):
-    """The row's free fields; `backprop_ok` only matters to adjoint=False requests, so every adjoint=True row leaves it free."""
+    """The row's free fields; `backprop_ok` only matters to adjoint=False and midpoint / euler requests: other rows leave it free."""
     fields, _, free = CASES[name]
-    return tuple(free) + (("backprop_ok",) if BASE._replace(**fields).adjoint and "backprop_ok" not in fields else ())
+    row = BASE._replace(**fields)
+    matters = not row.adjoint or row.method in ("midpoint", "euler") or "backprop_ok" in fields
+    return tuple(free) + (() if matters else ("backprop_ok",))
 
 
 def requests_of(name):

@@ -723,3 +723,73 @@ def test_rk4_backprop_mode_requests_the_kernel_does_not_take(native):
         out[:, -1].square().sum().backward()
         tol = 1e-8 if dtype == torch.float64 else 2e-3
         _close(z.grad, zo.grad, tol, tol * zo.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("method", ["midpoint", "euler"])
+@pytest.mark.parametrize("B,L,C,H,degree,step,times", [
+    (75, 12, 8, 32, 3, 1.0, [0., 11.]),                       # the benchmark's shape, ragged batch
+    (203, 9, 5, 20, 1, 0.75, [0., 1.5, 2.0, 2.25, 6.9, 8.]),  # zero-padded shape, linear control, outputs on / between grid points
+    (1, 4, 3, 7, 3, 0.5, [1., 2.6]),                          # one series, a last step shorter than step_size
+])
+def test_midpoint_and_euler_fused_against_the_oracle(native, method, B, L, C, H, degree, step, times):
+    """torchdiffeq's other fixed-grid methods (reference test/test_cdeint.py:49-63 solves with method='midpoint';
+    solver.py:226-227 forwards `method`): K2 / K3p with two stages / one stage per step (cde_fixed_forward_linear,
+    cde_fixed_adjoint_linear).  Forward and continuous-adjoint gradients against the float64 oracle's odeint_adjoint with the
+    same method (trajectories rtol 1e-4 / atol 1e-6, gradients rtol 1e-3 of the largest entry)."""
+    x = make_series(B, L, C, seed=17 + B)
+    z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(18))
+    t_out = torch.tensor(times)
+    lw = torch.rand(B, t_out.numel(), H, generator=torch.Generator().manual_seed(19)) + 0.5
+    kw = dict(method=method, options=dict(step_size=step))
+    f64 = LinearField(H, C, torch.float64, scale=0.3, seed=3)
+    Xo = (oracle_interp.CubicPath(oracle_interp.hermite_bdiff_coeffs(x.double())) if degree == 3
+          else oracle_interp.LinearPath(x.double()))
+    zo = z0.double().requires_grad_(True)
+    ref = oracle_cde.cdeint(Xo, f64, zo, t_out.double(), adjoint=True, **kw)
+    (ref * lw.double()).sum().backward()
+    func = LinearField(H, C, scale=0.3, seed=3).to(DEV)
+    X = (native.CubicSpline(native.hermite_cubic_coefficients_with_backward_differences(x.to(DEV))) if degree == 3
+         else native.LinearInterpolation(native.linear_interpolation_coeffs(x.to(DEV))))
+    z = z0.to(DEV).requires_grad_(True)
+    out = native.cdeint(X, func, z, t_out.to(DEV), **kw)
+    _expect_dispatch("affine_midpoint" if method == "midpoint" else "affine_euler", out)
+    (out * lw.to(DEV)).sum().backward()
+    _close(out, ref, 1e-4, 1e-6)
+    gw, gb = f64.linear.weight.grad, f64.linear.bias.grad
+    _close(z.grad, zo.grad, 1e-3, 1e-3 * zo.grad.abs().max().item())
+    _close(func.linear.weight.grad, gw, 1e-3, 1e-3 * gw.abs().max().item())
+    _close(func.linear.bias.grad, gb, 1e-3, 1e-3 * gb.abs().max().item())
+    # nothing to differentiate: the same kernel, the same bits; and the step-wise path (the user's module itself) agrees
+    with torch.no_grad():
+        plain = native.cdeint(X, func, z0.to(DEV), t_out.to(DEV), **kw)
+        if method == "midpoint":
+            _expect_dispatch("affine_midpoint_forward")
+        stepwise = native.cdeint(X, func, z0.to(DEV), t_out.to(DEV), variant="generic", **kw)
+        assert _front().last_dispatch()[0].path == "stepwise"
+    assert torch.equal(plain, out.detach())
+    _close(plain, stepwise, 1e-4, 1e-5)
+
+
+def test_reference_backend_test_scenario_with_midpoint(native):
+    """reference test/test_cdeint.py:49-63 (`test_backend`): natural cubic control of a (1, 10, 2) path, hidden size 3,
+    method='midpoint', step_size 1 over X.interval -- there with a plain function f(t, z) = -z (solved step by step here as
+    well: not a module of the fused families), here also with the README's affine field of that shape, fused, against
+    the oracle."""
+    x = torch.randn(1, 10, 2, generator=torch.Generator().manual_seed(5))
+    z0 = torch.randn(1, 3, generator=torch.Generator().manual_seed(6))
+    kw = dict(method="midpoint", options=dict(step_size=1.0))
+    X = native.CubicSpline(native.natural_cubic_coeffs(x.to(DEV)))
+    Xo = oracle_interp.CubicPath(oracle_interp.natural_cubic_coeffs(x.double()))
+
+    def func(t, z):
+        return -z.unsqueeze(-1).expand(1, 3, 2)
+
+    out = native.cdeint(X, func, z0.to(DEV), X.interval, adjoint=False, **kw)
+    ref = oracle_cde.cdeint(Xo, func, z0.double(), Xo.interval, adjoint=False, **kw)
+    _close(out, ref, 1e-5, 1e-6)
+    f32, f64 = LinearField(3, 2, scale=0.5, seed=1).to(DEV), LinearField(3, 2, torch.float64, scale=0.5, seed=1)
+    with torch.no_grad():
+        out = native.cdeint(X, f32, z0.to(DEV), X.interval, **kw)
+        assert _front().last_dispatch()[0].path == "fixed_grid"
+        ref = oracle_cde.cdeint(Xo, f64, z0.double(), Xo.interval, adjoint=False, **kw)
+    _close(out, ref, 1e-4, 1e-6)

@@ -377,6 +377,10 @@ def test_dispatch_is_queryable_and_warns_once_when_a_known_field_goes_stepwise(n
         with torch.no_grad():
             native.cdeint(X, func, z0, X.interval, options=dict(max_num_steps=10000))
             native.cdeint(X, func, z0, X.interval, method="midpoint", options=dict(step_size=0.5))
+        assert front.last_dispatch()[0] == ("fixed_grid", "")                  # midpoint / euler are fused since round 5 ...
+        # ... for adjoint=True: backpropagating through a midpoint solve is still the step-wise path, and says so
+        native.cdeint(X, func, z0.clone().requires_grad_(True), X.interval, method="midpoint", adjoint=False,
+                      options=dict(step_size=0.5))
         assert "midpoint" in front.last_dispatch()[0].reason
     told = [str(w.message) for w in caught if "step-wise" in str(w.message)]
     assert len(told) == 2 and "Field" in told[0] and "options" in told[0] and "midpoint" in told[1]      # once per reason

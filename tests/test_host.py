@@ -783,6 +783,13 @@ def test_dispatch_table_is_exhaustively_consistent():
                         continue
                     # ---- what every fused path may assume
                     assert not f["prod"] and kind is not None and f["tiles_ok"] and f["t_ok"] and f["options_ok"]
+                    if c.path == "fixed_grid":
+                        # midpoint / euler: the plain affine field, no time / control gradients, gradients through adjoint=True only
+                        assert method == "midpoint" and kind == "affine" and f["backprop_ok"] and f["mfma_shape"]
+                        assert not f["wants_t"] and not f["wants_control"]
+                        assert not f["wants_grad"] or (f["adjoint"] and f["adjoint_method_ok"] and f["adjoint_options_ok"]
+                                                       and params != "foreign")
+                        continue
                     assert method == ("rk4" if "rk4" in c.path else "dopri5")
                     assert c.path.startswith("mlp_") == (kind == "mlp2")
                     assert ("forward" in c.path) <= (not f["wants_grad"])    # forward-only kernels: nothing to differentiate
@@ -825,7 +832,10 @@ def test_dispatch_table_is_exhaustively_consistent():
     assert ask(method="rk4", wants_control=True, params="own").path == "rk4"    # README.md:251-270
     assert ask(wants_t=True).path == "dopri5_adjoint"                           # output-time gradients: K4a carries vjp_t
     assert ask(method="rk4", adjoint=False).path == "rk4_backprop"              # README.md:103: backprop through the solver
-    for kw, word in ((dict(kind=None), "recognised"), (dict(method="midpoint"), "midpoint"),
+    assert ask(method="midpoint").path == "fixed_grid"                          # test/test_cdeint.py:49-63
+    assert ask(method="euler", wants_grad=False).path == "fixed_grid"
+    for kw, word in ((dict(kind=None), "recognised"), (dict(method="midpoint", kind="mlp2", mfma_shape=False), "midpoint"),
+                     (dict(method="euler", adjoint=False), "euler"), (dict(method="heun3"), "heun3"),
                      (dict(adjoint=False), "adjoint=False"), (dict(method="rk4", adjoint=False, backprop_ok=False), "adjoint=False"), (dict(options_ok=False), "options"),
                      (dict(mfma_shape=False), "32 x 8"), (dict(wants_t=True, shared=True), "time"),
                      (dict(wants_control=True, params="own"), "control"),

@@ -36,6 +36,8 @@ PATH_LINEAR, PATH_CUBIC = 1, 3
 EVAL_VALUE, EVAL_DERIVATIVE = 0, 1
 ACT_NONE, ACT_TANH = 0, 1
 VARIANT_AUTO, VARIANT_GENERIC, VARIANT_MFMA, VARIANT_SPLIT, VARIANT_BF16X3 = 0, 1, 2, 3, 4
+METHOD_RK4, METHOD_MIDPOINT, METHOD_EULER = 0, 1, 2
+FIXED_METHODS = {"rk4": METHOD_RK4, "midpoint": METHOD_MIDPOINT, "euler": METHOD_EULER}
 
 _lib = None
 
@@ -132,6 +134,12 @@ _SIGNATURES = {
     "cde_rk4_forward_mlp": (_i, [_p, _p, _i64, _i, _p, _p, _i64, _p, _p, _i, _p, _p, _i64, _p, _i64, _p, _i64, _i64, _i64,
                                  _i, _i, _p, _p, _p]),
     "cde_rk4_adjoint_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i, _i]),
+    "cde_fixed_supported": (_i, [_i, _i64, _i64, _i, _i]),
+    "cde_fixed_forward_linear": (_i, [_i, _p, _p, _i64, _i, _p, _p, _p, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i, _i, _p, _p,
+                                      _p]),
+    "cde_fixed_adjoint_workspace_bytes": (_sz, [_i64, _i64]),
+    "cde_fixed_adjoint_linear": (_i, [_i, _p, _p, _i64, _i, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i64,
+                                      _i, _i, _p, _sz, _p]),
     "cde_rk4_backprop_supported": (_i, [_i64, _i64, _i, _i]),
     "cde_rk4_forward_linear_stages": (_i, [_p, _p, _i64, _i, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i, _i,
                                            _p, _p, _p]),

@@ -267,8 +267,9 @@ class _Plan:
         ev.record()
         return ev
 
-    def __init__(self, path, field, batch, H, C, t, step_size, adjoint_step_size, adjoint, variant):
+    def __init__(self, path, field, batch, H, C, t, step_size, adjoint_step_size, adjoint, variant, method=_lib.METHOD_RK4):
         self.owner = _state()
+        self.method = method             # _lib.METHOD_*: rk4 (3/8 rule), or midpoint / euler on the same kernels
         coeffs, knots, _ = path._native_inputs()
         self.coeffs, self.knots = coeffs, knots
         self.path = path
@@ -300,12 +301,20 @@ class _Plan:
         w = weight.detach().contiguous()
         b = bias.detach().contiguous()
         begin = self._mark()
-        _lib.check(lib.cde_rk4_forward_linear(
-            _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w), _lib.ptr(b),
-            self.act, _lib.ptr(z0c), _lib.ptr(self.grid), self.grid.numel(), _lib.ptr(self.t_out), self.n_out,
-            _lib.ptr(out), self.B, self.C, self.H, _lib.dtype_enum(self.dtype), _lib.dtype_enum(self.time_dtype),
-            self.variant, _lib.ptr(self.stage_index), _lib.ptr(self.stage_frac), _lib.stream_ptr(self.device)),
-            "cde_rk4_forward_linear")
+        if self.method != _lib.METHOD_RK4:
+            _lib.check(lib.cde_fixed_forward_linear(
+                self.method, _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w),
+                _lib.ptr(b), _lib.ptr(z0c), _lib.ptr(self.grid), self.grid.numel(), _lib.ptr(self.t_out), self.n_out,
+                _lib.ptr(out), self.B, self.C, self.H, _lib.dtype_enum(self.dtype), _lib.dtype_enum(self.time_dtype),
+                _lib.ptr(self.stage_index), _lib.ptr(self.stage_frac), _lib.stream_ptr(self.device)),
+                "cde_fixed_forward_linear")
+        else:
+            _lib.check(lib.cde_rk4_forward_linear(
+                _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w), _lib.ptr(b),
+                self.act, _lib.ptr(z0c), _lib.ptr(self.grid), self.grid.numel(), _lib.ptr(self.t_out), self.n_out,
+                _lib.ptr(out), self.B, self.C, self.H, _lib.dtype_enum(self.dtype), _lib.dtype_enum(self.time_dtype),
+                self.variant, _lib.ptr(self.stage_index), _lib.ptr(self.stage_frac), _lib.stream_ptr(self.device)),
+                "cde_rk4_forward_linear")
         if begin is not None:
             self.owner.event_log.append(("forward", begin, self._mark()))
         return out
@@ -360,7 +369,9 @@ class _Plan:
         sgrid, seg_off, n_sgrid = self.grids.sgrid, self.grids.seg_off, self.grids.n_sgrid
         dt = _lib.dtype_enum(self.dtype)
         variant = _lib.VARIANT_MFMA if want_control else self.variant
-        nbytes = lib.cde_rk4_adjoint_workspace_bytes(self.B, self.C, self.H, n_sgrid, dt, variant)
+        fixed = self.method != _lib.METHOD_RK4
+        nbytes = (lib.cde_fixed_adjoint_workspace_bytes(self.B, n_sgrid) if fixed else
+                  lib.cde_rk4_adjoint_workspace_bytes(self.B, self.C, self.H, n_sgrid, dt, variant))
         workspace = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
         grad_z0 = torch.empty(self.B, self.H, dtype=self.dtype, device=self.device)
         # weight and bias gradients are two views of ONE flat buffer: a data-parallel caller can all-reduce that
@@ -374,7 +385,14 @@ class _Plan:
         b = bias.detach().contiguous()
         begin = self._mark()
         grad_x = None
-        if want_control:
+        if fixed:
+            _lib.check(lib.cde_fixed_adjoint_linear(
+                self.method, _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w),
+                _lib.ptr(b), _lib.ptr(zs), _lib.ptr(go), _lib.ptr(sgrid), n_sgrid, _lib.ptr(seg_off), self.n_out,
+                _lib.ptr(grad_z0), _lib.ptr(grad_w), _lib.ptr(grad_b), self.B, self.C, self.H, dt,
+                _lib.dtype_enum(self.time_dtype), _lib.ptr(workspace), workspace.numel(), _lib.stream_ptr(self.device)),
+                "cde_fixed_adjoint_linear")
+        elif want_control:
             grad_x = torch.zeros_like(self.coeffs)          # (B, rows, width) like the packed coefficients
             _lib.check(lib.cde_rk4_adjoint_linear_dcontrol(
                 _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w), _lib.ptr(b),
@@ -1447,7 +1465,8 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
                 want_x = want_x or (p.requires_grad and grad_mode)
         want_w = any(p is weight for p in given_params)
         want_b = any(p is bias for p in given_params)
-    plan = _Plan(X, field, batch, H, C, t, step_size, adjoint_step, adjoint, variant)
+    plan = _Plan(X, field, batch, H, C, t, step_size, adjoint_step, adjoint, variant,
+                 _lib.FIXED_METHODS[method] if choice.path == "fixed_grid" else _lib.METHOD_RK4)
     control_inputs = X._control_buffers() if want_x else ()
     return _FusedRK4.apply(z0, weight, bias, plan, (want_w, want_b, want_x), t if wants_t else None,
                            X._t if want_knots else None, *control_inputs)

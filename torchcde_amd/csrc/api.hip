@@ -60,6 +60,15 @@ template <typename TT>
 int launch_adjoint_jacobian_bx(const void*, const void*, int64_t, int, const void*, const void*, const void*, const void*,
                                const void*, const int64_t*, int64_t, void*, void*, void*, int64_t, int64_t, int64_t,
                                const int64_t*, const void*, float*, hipStream_t);
+// midpoint / euler: K2 and K3p with two stages / one stage per step (rk4_mfma.hip, rk4_adjoint_pair.hip)
+template <typename TT>
+int launch_forward_mfma_method(int, const void*, const void*, int64_t, int, const void*, const void*, const void*, const void*,
+                               int64_t, const void*, int64_t, void*, int64_t, int64_t, int64_t, const int64_t*, const void*,
+                               hipStream_t);
+template <typename TT>
+int launch_adjoint_jacobian_pair(const void*, const void*, int64_t, int, const void*, const void*, const void*, const void*,
+                                 const void*, const int64_t*, int64_t, void*, void*, void*, int64_t, int64_t, int64_t,
+                                 const int64_t*, const void*, float*, hipStream_t, int method);
 // K2 with the stage states stored (rk4_mfma.hip) and the reverse-mode sweep over them (rk4_backprop.hip): adjoint=False
 template <typename TT>
 int launch_forward_mfma_stages(const void*, const void*, int64_t, int, const void*, const void*, const void*, const void*,
@@ -94,15 +103,21 @@ int launch_mlp_adjoint_sweep(const void*, const void*, int64_t, int, int, const 
 // and fractional part at the stage time -- what CubicSpline._interpret_t (interpolation_cubic.py:
 // 315-322) returns when torchdiffeq's rk4 evaluates the vector field there.  One lane per entry.
 // `negate`: the reverse sweep integrates in s = -t and evaluates the field at t = -s.
+// `method` (CDE_METHOD_*): rk4's 3/8-rule times; midpoint: t0, t0 + 0.5 dt (torchdiffeq's `half_dt = 0.5 * dt`); euler: t0.
+// The table keeps four slots per step whatever the method (unused slots repeat t0).
 template <typename T, typename TT>
 __global__ void stage_table_kernel(const T* __restrict__ knots, int64_t n_intervals, const TT* __restrict__ grid,
                                    int64_t n_steps, int negate, int64_t* __restrict__ index_out,
-                                   T* __restrict__ frac_out) {
+                                   T* __restrict__ frac_out, int method) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= 4 * n_steps) return;
   const int64_t k = e >> 2;
   const StageClock<TT> clk(grid[k], grid[k + 1]);
-  T ts = (T)clk.time((int)(e & 3));
+  const int stage = (int)(e & 3);
+  TT tt = clk.time(stage);
+  if (method == CDE_METHOD_MIDPOINT) tt = stage == 1 ? clk.t0 + (TT)0.5 * clk.dt : clk.t0;
+  else if (method == CDE_METHOD_EULER) tt = clk.t0;
+  T ts = (T)tt;
   if (negate) ts = -ts;
   T frac;
   index_out[e] = locate(knots, n_intervals, ts, frac);
@@ -111,10 +126,10 @@ __global__ void stage_table_kernel(const T* __restrict__ knots, int64_t n_interv
 
 template <typename T, typename TT>
 static int fill_stage_table(const void* knots, int64_t n_intervals, const void* grid, int64_t n_steps, int negate,
-                            int64_t* index_out, void* frac_out, hipStream_t s) {
+                            int64_t* index_out, void* frac_out, hipStream_t s, int method = CDE_METHOD_RK4) {
   if (n_steps <= 0) return CDE_OK;
   stage_table_kernel<T, TT><<<(unsigned)((4 * n_steps + 255) / 256), 256, 0, s>>>(
-      (const T*)knots, n_intervals, (const TT*)grid, n_steps, negate, index_out, (T*)frac_out);
+      (const T*)knots, n_intervals, (const TT*)grid, n_steps, negate, index_out, (T*)frac_out, method);
   return check_launch();
 }
 
@@ -369,6 +384,82 @@ extern "C" int cde_rk4_adjoint_linear_dcontrol(const void* coeffs, const void* k
   return adjoint_linear_impl(coeffs, knots, n_intervals, degree, W, bias, act, z_saved, grad_out, sgrid, n_sgrid, seg_off,
                              nullptr, n_out, grad_z0, grad_W, grad_b, grad_coeffs, B, C, H, dtype, time_dtype, CDE_VARIANT_MFMA,
                              workspace, workspace_bytes, stream);
+}
+
+// ---------------------------------------------------------------------------------------------- midpoint / euler
+extern "C" int cde_fixed_supported(int method, int64_t C, int64_t H, int dtype, int act) {
+  if (method != CDE_METHOD_MIDPOINT && method != CDE_METHOD_EULER) return 0;
+  return (dtype == CDE_F32 && act == CDE_ACT_NONE && cde::mfma_applicable(C, H, dtype, act, true)) ? 1 : 0;
+}
+
+extern "C" int cde_fixed_forward_linear(int method, const void* coeffs, const void* knots, int64_t n_intervals, int degree,
+                                        const void* W, const void* bias, const void* z0, const void* grid, int64_t n_grid,
+                                        const void* t_out, int64_t n_out, void* z_out, int64_t B, int64_t C, int64_t H,
+                                        int dtype, int time_dtype, int64_t* stage_index, void* stage_frac, void* stream) {
+  if (B < 0 || C < 1 || H < 1 || n_intervals < 1 || n_grid < 1 || n_out < 1) return CDE_ERR_SHAPE;
+  if (dtype != CDE_F32) return dtype == CDE_F64 ? CDE_ERR_UNSUPPORTED : CDE_ERR_DTYPE;
+  if (!cde_fixed_supported(method, C, H, dtype, CDE_ACT_NONE)) return CDE_ERR_UNSUPPORTED;
+  if (B == 0) return CDE_OK;
+  if (!coeffs || !knots || !W || !bias || !z0 || !grid || !t_out || !z_out) return CDE_ERR_NULL;
+  if (n_grid > 1 && (!stage_index || !stage_frac)) return CDE_ERR_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if (time_dtype == CDE_F32) {
+    rc = cde::fill_stage_table<float, float>(knots, n_intervals, grid, n_grid - 1, 0, stage_index, stage_frac, s, method);
+    if (rc != CDE_OK) return rc;
+    return cde::launch_forward_mfma_method<float>(method, coeffs, knots, n_intervals, degree, W, bias, z0, grid, n_grid, t_out,
+                                                  n_out, z_out, B, C, H, stage_index, stage_frac, s);
+  }
+  if (time_dtype == CDE_F64) {
+    rc = cde::fill_stage_table<float, double>(knots, n_intervals, grid, n_grid - 1, 0, stage_index, stage_frac, s, method);
+    if (rc != CDE_OK) return rc;
+    return cde::launch_forward_mfma_method<double>(method, coeffs, knots, n_intervals, degree, W, bias, z0, grid, n_grid,
+                                                   t_out, n_out, z_out, B, C, H, stage_index, stage_frac, s);
+  }
+  return CDE_ERR_DTYPE;
+}
+
+// workspace: [stage_index: 4*(n_sgrid-1) int64][stage_frac: 4*(n_sgrid-1) f32][per-wave partial parameter gradients]
+extern "C" size_t cde_fixed_adjoint_workspace_bytes(int64_t B, int64_t n_sgrid) {
+  const int64_t n_steps = n_sgrid > 1 ? n_sgrid - 1 : 0;
+  return cde::align256((size_t)(4 * n_steps) * sizeof(int64_t)) + cde::align256((size_t)(4 * n_steps) * sizeof(float)) +
+         (B > 0 ? cde::mfma_adjoint_partial_bytes(B) : 0);
+}
+
+extern "C" int cde_fixed_adjoint_linear(int method, const void* coeffs, const void* knots, int64_t n_intervals, int degree,
+                                        const void* W, const void* bias, const void* z_saved, const void* grad_out,
+                                        const void* sgrid, int64_t n_sgrid, const int64_t* seg_off, int64_t n_out,
+                                        void* grad_z0, void* grad_W, void* grad_b, int64_t B, int64_t C, int64_t H, int dtype,
+                                        int time_dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  if (B < 1 || C < 1 || H < 1 || n_intervals < 1 || n_out < 1 || n_sgrid < 0) return CDE_ERR_SHAPE;
+  if (dtype != CDE_F32) return dtype == CDE_F64 ? CDE_ERR_UNSUPPORTED : CDE_ERR_DTYPE;
+  if (!cde_fixed_supported(method, C, H, dtype, CDE_ACT_NONE)) return CDE_ERR_UNSUPPORTED;
+  if (!coeffs || !knots || !W || !bias || !z_saved || !grad_out || !grad_z0 || !grad_W || !grad_b || !workspace)
+    return CDE_ERR_NULL;
+  if (n_out > 1 && (!sgrid || !seg_off)) return CDE_ERR_NULL;
+  if (workspace_bytes < cde_fixed_adjoint_workspace_bytes(B, n_sgrid)) return CDE_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n_steps = n_sgrid > 1 ? n_sgrid - 1 : 0;
+  unsigned char* base = (unsigned char*)workspace;
+  int64_t* stage_index = (int64_t*)base;
+  void* stage_frac = base + cde::align256((size_t)(4 * n_steps) * sizeof(int64_t));
+  float* partial = (float*)((unsigned char*)stage_frac + cde::align256((size_t)(4 * n_steps) * sizeof(float)));
+  int rc;
+  if (time_dtype == CDE_F32) {
+    rc = cde::fill_stage_table<float, float>(knots, n_intervals, sgrid, n_steps, 1, stage_index, stage_frac, s, method);
+    if (rc != CDE_OK) return rc;
+    return cde::launch_adjoint_jacobian_pair<float>(coeffs, knots, n_intervals, degree, W, bias, z_saved, grad_out, sgrid,
+                                                    seg_off, n_out, grad_z0, grad_W, grad_b, B, C, H, stage_index, stage_frac,
+                                                    partial, s, method);
+  }
+  if (time_dtype == CDE_F64) {
+    rc = cde::fill_stage_table<float, double>(knots, n_intervals, sgrid, n_steps, 1, stage_index, stage_frac, s, method);
+    if (rc != CDE_OK) return rc;
+    return cde::launch_adjoint_jacobian_pair<double>(coeffs, knots, n_intervals, degree, W, bias, z_saved, grad_out, sgrid,
+                                                     seg_off, n_out, grad_z0, grad_W, grad_b, B, C, H, stage_index, stage_frac,
+                                                     partial, s, method);
+  }
+  return CDE_ERR_DTYPE;
 }
 
 // ---------------------------------------------------------------------------------------------- K3d (adjoint=False)

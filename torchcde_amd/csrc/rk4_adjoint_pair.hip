@@ -59,7 +59,9 @@ __device__ __forceinline__ float kp_wj_image(const float* __restrict__ W, const 
 // the stage barrier: this wave's LDS traffic done, then all eight waves meet
 __device__ __forceinline__ void kp_stage_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <typename TT, int DEGREE>
+// METHOD (CDE_METHOD_*): the 3/8 rule, or torchdiffeq's midpoint / euler on the same augmented system -- two stages / one
+// stage per step, quadrature weights (0, ds) / (ds) for the parameter gradients (a zero-weight stage costs the helper nothing).
+template <typename TT, int DEGREE, int METHOD = CDE_METHOD_RK4>
 __global__ __launch_bounds__(512, 2) void rk4_adjoint_jacobian_pair(
     const float* __restrict__ coeffs, const float* __restrict__ knots, int64_t n_intervals,
     const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ z_saved,
@@ -67,6 +69,7 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_jacobian_pair(
     int64_t n_out, float* __restrict__ grad_z0, float* __restrict__ partial, int64_t B,
     const int64_t* __restrict__ stage_index, const float* __restrict__ stage_frac, Dims dims, int flags) {
   const int Hr = dims.H, Cr = dims.C;
+  constexpr int NS = METHOD == CDE_METHOD_RK4 ? 4 : METHOD == CDE_METHOD_MIDPOINT ? 2 : 1;     // stages per step
   extern __shared__ __attribute__((aligned(16))) float lds[];
   for (int e = threadIdx.x; e < KP_WJ_FLOATS; e += 512) lds[e] = kp_wj_image(W, bias, e >> 8, e & 3, (e >> 2) & 63, dims);
   const float4* wj = reinterpret_cast<const float4*>(lds);
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_jacobian_pair(
     int64_t n_stages = 0;
     for (int64_t p = 0; p + 1 < n_out; ++p) {
       const int64_t k_begin = seg_off[p], k_end = seg_off[p + 1] - 1;
-      if (k_end > k_begin) n_stages += 4 * (k_end - k_begin);
+      if (k_end > k_begin) n_stages += NS * (k_end - k_begin);
     }
     if (flags & 2) __builtin_amdgcn_s_setprio(3);
     // A cursor over those entries runs THREE stages ahead of the dL/dW work: the control derivative of stage st + 2 is
@@ -109,8 +112,9 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_jacobian_pair(
     // waited for where it was issued.
     int64_t cur_p = -1, cur_e = 0, cur_end = 0;
     bool cur_ok = false;
-    auto advance = [&]() {
-      if (cur_ok && cur_e + 1 < cur_end) { ++cur_e; return; }
+    auto advance = [&]() {                     // (the table keeps four slots per step; a method uses the first NS of them)
+      if (cur_ok && (cur_e & 3) + 1 < NS) { ++cur_e; return; }
+      if (cur_ok && (cur_e | 3) + 1 < cur_end) { cur_e = (cur_e | 3) + 1; return; }
       cur_ok = false;
       for (int64_t p = cur_p + 1; p + 1 < n_out; ++p) {
         const int64_t k_begin = seg_off[p], k_end = seg_off[p + 1] - 1;
@@ -130,7 +134,9 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_jacobian_pair(
         const int64_t k = cur_e >> 2;
         const int stage = (int)(cur_e & 3);
         const float ds = (float)(sgrid[k + 1] - sgrid[k]);
-        p_wq = ((stage == 0 || stage == 3) ? 0.125f : 0.375f) * ds;             // 3/8-rule quadrature weight
+        if constexpr (METHOD == CDE_METHOD_RK4) p_wq = ((stage == 0 || stage == 3) ? 0.125f : 0.375f) * ds;   // 3/8-rule quadrature weight
+        else if constexpr (METHOD == CDE_METHOD_MIDPOINT) p_wq = stage == 1 ? ds : 0.f;                        // the midpoint evaluation alone
+        else p_wq = ds;
       }
       advance();
       if (cur_ok) idx_ahead = stage_index[cur_e];
@@ -150,11 +156,14 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_jacobian_pair(
     fetch(); publish(1);
     fetch();                                                        // stage 2: in flight
     __syncthreads();                                                // (also: the weight image is staged)
-    int par = 0, rs = 0;                                            // (z, a) buffer and ring slot of stage st
+    int par = 0, rs = 0, cs = 0;                                    // (z, a) buffer, ring slot and stage-in-step of stage st
     for (int64_t st = 0; st < n_stages; ++st) {
       kp_stage_barrier();                                           // barrier `st`: buffer `par` holds (z, a) of stage `st`
       publish(rs >= 1 ? rs - 1 : 2);                                // stage st + 2 -> slot (st + 2) % 3
       fetch();                                                      // stage st + 3: requested, used next iteration
+      const bool weighted = METHOD != CDE_METHOD_MIDPOINT || cs == 1;      // midpoint: the first evaluation carries no weight
+      cs = cs + 1 == NS ? 0 : cs + 1;
+      if (weighted) {
       // dL/dW tile c: D[h][k] += sum_series (w ds a_h dX_c)[series] * z_k[series]; this lane feeds MFMA K index `half`
       // of K-step s2, i.e. series 2*s2 + half, row h = n, column k = n.  Operands of K-step s2 + 1 are requested from LDS
       // before the MFMAs of K-step s2 are issued (their issue blocks this wave for as long as they take).
@@ -187,6 +196,7 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_jacobian_pair(
         accW[4] = mfma(v45[0], zb, accW[4]); accW[5] = mfma(v45[1], zb, accW[5]);
         accW[6] = mfma(v67[0], zb, accW[6]); accW[7] = mfma(v67[1], zb, accW[7]);
         __builtin_amdgcn_sched_barrier(0);
+      }
       }
       par ^= 1;
       rs = rs == 2 ? 0 : rs + 1;
@@ -228,7 +238,7 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_jacobian_pair(
       const float ds = (float)(sgrid[k + 1] - sgrid[k]);
       f32x16 ky1, ky2, ka1, ka2, yst = y0, ast = a0;
 #pragma unroll
-      for (int stage = 0; stage < 4; ++stage) {
+      for (int stage = 0; stage < NS; ++stage) {
         // ---- this stage's control derivative (the helper wave left it two stages ago), the stage state -> this stage's
         // buffer (transposed); then the stage barrier
         float bs0, bs1, bs2, bs3;
@@ -312,7 +322,14 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_jacobian_pair(
         // ---- reverse-time dynamics: dy/ds = -f, da/ds = +a^T df/dz.  3/8 rule in two slots per variable
         const f32x16 ky = -f, ka = va;
         const float third = (float)(1.0 / 3.0);
-        if (stage == 0) {
+        if constexpr (METHOD == CDE_METHOD_EULER) {                    // y1 = y0 + ds * k
+          yst = y0 + ds * ky;
+          ast = a0 + ds * ka;
+        } else if constexpr (METHOD == CDE_METHOD_MIDPOINT) {          // mid = y0 + k1 * half_ds; y1 = y0 + ds * k(mid)
+          const float half_ds = 0.5f * ds;
+          if (stage == 0) { yst = y0 + ky * half_ds; ast = a0 + ka * half_ds; }
+          else { yst = y0 + ds * ky; ast = a0 + ds * ka; }
+        } else if (stage == 0) {
           ky1 = ky; ka1 = ka;
           yst = y0 + ds * ky1 * third;
           ast = a0 + ds * ka1 * third;
@@ -355,24 +372,31 @@ int launch_adjoint_jacobian_pair(const void* coeffs, const void* knots, int64_t 
                                  const void* bias, const void* z_saved, const void* grad_out, const void* sgrid,
                                  const int64_t* seg_off, int64_t n_out, void* grad_z0, void* grad_W, void* grad_b, int64_t B,
                                  int64_t C, int64_t H, const int64_t* stage_index, const void* stage_frac, float* partial,
-                                 hipStream_t s) {
+                                 hipStream_t s, int method) {
   const Dims dims{(int)H, (int)C};
   const unsigned blocks = (unsigned)((B + 127) / 128);
   const size_t lds = (size_t)KP_LDS_FLOATS * sizeof(float);
   // bit 0: priority 3 for the chain waves, bit 1: for the helper waves (CDE_K3P_FLAGS, read once: experiments)
   static const int flags = [] { const char* e = getenv("CDE_K3P_FLAGS"); return e ? atoi(e) : 1; }();
-#define CDE_ADJ_P(D)                                                                                                 \
+#define CDE_ADJ_P(D, M)                                                                                              \
   do {                                                                                                               \
-    (void)hipFuncSetAttribute((const void*)rk4_adjoint_jacobian_pair<TT, D>,                                         \
+    (void)hipFuncSetAttribute((const void*)rk4_adjoint_jacobian_pair<TT, D, M>,                                      \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
-    rk4_adjoint_jacobian_pair<TT, D><<<blocks, 512, lds, s>>>(                                                       \
+    rk4_adjoint_jacobian_pair<TT, D, M><<<blocks, 512, lds, s>>>(                                                    \
         (const float*)coeffs, (const float*)knots, n_intervals, (const float*)W, (const float*)bias,                 \
         (const float*)z_saved, (const float*)grad_out, (const TT*)sgrid, seg_off, n_out, (float*)grad_z0, partial,   \
         B, stage_index, (const float*)stage_frac, dims, flags);                                                      \
   } while (0)
-  if (degree == CDE_PATH_CUBIC) CDE_ADJ_P(CDE_PATH_CUBIC);
-  else if (degree == CDE_PATH_LINEAR) CDE_ADJ_P(CDE_PATH_LINEAR);
+#define CDE_ADJ_PD(M)                                                                                                \
+  do {                                                                                                               \
+    if (degree == CDE_PATH_CUBIC) CDE_ADJ_P(CDE_PATH_CUBIC, M); else CDE_ADJ_P(CDE_PATH_LINEAR, M);                   \
+  } while (0)
+  if (degree != CDE_PATH_CUBIC && degree != CDE_PATH_LINEAR) return CDE_ERR_UNSUPPORTED;
+  if (method == CDE_METHOD_RK4) CDE_ADJ_PD(CDE_METHOD_RK4);
+  else if (method == CDE_METHOD_MIDPOINT) CDE_ADJ_PD(CDE_METHOD_MIDPOINT);
+  else if (method == CDE_METHOD_EULER) CDE_ADJ_PD(CDE_METHOD_EULER);
   else return CDE_ERR_UNSUPPORTED;
+#undef CDE_ADJ_PD
 #undef CDE_ADJ_P
   const int rc = check_launch();
   if (rc != CDE_OK) return rc;
@@ -380,9 +404,9 @@ int launch_adjoint_jacobian_pair(const void* coeffs, const void* knots, int64_t 
 }
 template int launch_adjoint_jacobian_pair<float>(const void*, const void*, int64_t, int, const void*, const void*, const void*,
                                                  const void*, const void*, const int64_t*, int64_t, void*, void*, void*,
-                                                 int64_t, int64_t, int64_t, const int64_t*, const void*, float*, hipStream_t);
+                                                 int64_t, int64_t, int64_t, const int64_t*, const void*, float*, hipStream_t, int);
 template int launch_adjoint_jacobian_pair<double>(const void*, const void*, int64_t, int, const void*, const void*, const void*,
                                                   const void*, const void*, const int64_t*, int64_t, void*, void*, void*,
-                                                  int64_t, int64_t, int64_t, const int64_t*, const void*, float*, hipStream_t);
+                                                  int64_t, int64_t, int64_t, const int64_t*, const void*, float*, hipStream_t, int);
 
 }  // namespace cde

@@ -64,7 +64,10 @@ template <int ACT, bool MLP> constexpr int fwd_waves_per_simd() { return 2; }
 // SAVE (affine field, the backward pass of adjoint=False: rk4_backprop.hip): the state handed to EVERY field evaluation
 // is also written to `stages` (B, n_steps, 4, 32), the 32 units in K3's lane order (evens, then odds: a lane's units
 // 8q .. 8q+7 are two 16-byte stores) -- what reverse-mode autograd would keep of torchdiffeq's rk4 step.
-template <typename TT, int DEGREE, int ACT, bool MLP = false, int CT = MC, bool SPLIT = false, bool SAVE = false>
+// METHOD (CDE_METHOD_*): the same skeleton for torchdiffeq's other fixed-grid methods (reference test/test_cdeint.py:49-63
+// runs `midpoint`) -- two stages (midpoint) or one (euler) per step instead of the four of the 3/8 rule.
+template <typename TT, int DEGREE, int ACT, bool MLP = false, int CT = MC, bool SPLIT = false, bool SAVE = false,
+          int METHOD = CDE_METHOD_RK4>
 __global__ __launch_bounds__((fwd_block_threads<ACT, MLP>()), (fwd_waves_per_simd<ACT, MLP>())) void rk4_forward_mfma(
     const float* __restrict__ coeffs, const float* __restrict__ knots, int64_t n_intervals,
     const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ z0,
@@ -76,6 +79,8 @@ __global__ __launch_bounds__((fwd_block_threads<ACT, MLP>()), (fwd_waves_per_sim
   // the A-operand image is loop invariant: staged once through LDS, then it lives in registers
   constexpr bool PRODUCT = ACT == CDE_ACT_NONE && !MLP;
   static_assert(!SAVE || (PRODUCT && CT == MC), "stage states are stored by the affine field's kernel only");
+  static_assert(METHOD == CDE_METHOD_RK4 || !SAVE, "stage states are stored for the 3/8 rule only");
+  constexpr int NS = METHOD == CDE_METHOD_RK4 ? 4 : METHOD == CDE_METHOD_MIDPOINT ? 2 : 1;     // stages per step
   constexpr int STRIDE = PRODUCT ? 1 : 4;          // distance between a lane's consecutive hidden units
   float4 wA[PRODUCT ? W16_GROUPS : 1], wB[PRODUCT ? W16_GROUPS : 1];
   if constexpr (PRODUCT) load_w16(W, bias, lds, wA, wB, dims);
@@ -119,16 +124,20 @@ __global__ __launch_bounds__((fwd_block_threads<ACT, MLP>()), (fwd_waves_per_sim
   Row<DEGREE, CT> row = load_row<DEGREE, CT>(coeffs, sc, n_intervals, idx, Cr);
 
   for (int64_t k = 0; k < n_steps; ++k) {
-    const TT t0 = grid[k], t1 = grid[k + 1];
+    TT t0 = grid[k];
+    const TT t1 = grid[k + 1];
+    // (euler instantiations: with both grid points in scalar registers this compiler emits v_add_f32 with two SGPR operands,
+    //  "violates constant bus restriction" on gfx950 -- one of them is pinned to a vector register)
+    if constexpr (METHOD == CDE_METHOD_EULER) asm volatile("" : "+v"(t0));
     const float dt = (float)(t1 - t0);
     f32x4 k1a, k1b, k2a, k2b, pqa, pqb, za = ya, zb = yb;
 #pragma unroll
-    for (int stage = 0; stage < 4; ++stage) {
+    for (int stage = 0; stage < NS; ++stage) {
       float dX[CT];
       const float width = DEGREE == CDE_PATH_LINEAR ? knots[idx + 1] - knots[idx] : 1.f;
       control_slope<DEGREE, CT>(row, frac, width, dX);
       // prefetch the next stage's table entry and (if the interval changes) its control row
-      const int64_t e_next = 4 * k + stage + 1;
+      const int64_t e_next = stage + 1 < NS ? 4 * k + stage + 1 : 4 * (k + 1);
       const bool more = e_next < 4 * n_steps;
       const int64_t nidx = more ? stage_index[e_next] : idx;
       const float nfrac = more ? stage_frac[e_next] : frac;
@@ -156,7 +165,13 @@ __global__ __launch_bounds__((fwd_block_threads<ACT, MLP>()), (fwd_waves_per_sim
 
       // torchdiffeq rk4_alt_step_func (3/8 rule), association order preserved
       const float third = (float)(1.0 / 3.0);
-      if (stage == 0) {
+      if constexpr (METHOD == CDE_METHOD_EULER) {                       // y1 = y0 + dt * f(t0, y0)
+        za = ya + dt * fa; zb = yb + dt * fb;
+      } else if constexpr (METHOD == CDE_METHOD_MIDPOINT) {             // y_mid = y0 + f(t0, y0) * half_dt; y1 = y0 + dt * f(t0 + half_dt, y_mid)
+        const float half_dt = 0.5f * dt;
+        if (stage == 0) { za = ya + fa * half_dt; zb = yb + fb * half_dt; }
+        else { za = ya + dt * fa; zb = yb + dt * fb; }
+      } else if (stage == 0) {
         k1a = fa; k1b = fb;
         za = ya + dt * k1a * third; zb = yb + dt * k1b * third;
       } else if (stage == 1) {
@@ -1234,6 +1249,36 @@ template int launch_forward_mfma_stages<double>(const void*, const void*, int64_
                                                 const void*, int64_t, const void*, int64_t, void*, void*, int64_t, int64_t,
                                                 int64_t, const int64_t*, const void*, hipStream_t);
 
+// midpoint / euler through the same kernel (affine field, f32, H <= 32, C <= 8)
+template <typename TT>
+int launch_forward_mfma_method(int method, const void* coeffs, const void* knots, int64_t n_intervals, int degree,
+                               const void* W, const void* bias, const void* z0, const void* grid, int64_t n_grid,
+                               const void* t_out, int64_t n_out, void* z_out, int64_t B, int64_t C, int64_t H,
+                               const int64_t* stage_index, const void* stage_frac, hipStream_t s) {
+  const Dims dims{(int)H, (int)C};
+  constexpr int threads = fwd_block_threads<CDE_ACT_NONE, false>();
+#define CDE_FWD_M(D, M)                                                                                               \
+  rk4_forward_mfma<TT, D, CDE_ACT_NONE, false, MC, false, false, M>                                                   \
+      <<<(unsigned)((B + threads / 4 - 1) / (threads / 4)), threads, W16_FLOATS * sizeof(float), s>>>(                \
+          (const float*)coeffs, (const float*)knots, n_intervals, (const float*)W, (const float*)bias,                \
+          (const float*)z0, (const TT*)grid, n_grid, (const TT*)t_out, n_out, (float*)z_out, B, stage_index,          \
+          (const float*)stage_frac, dims)
+  if (degree != CDE_PATH_CUBIC && degree != CDE_PATH_LINEAR) return CDE_ERR_UNSUPPORTED;
+  if (method == CDE_METHOD_MIDPOINT) {
+    if (degree == CDE_PATH_CUBIC) CDE_FWD_M(CDE_PATH_CUBIC, CDE_METHOD_MIDPOINT); else CDE_FWD_M(CDE_PATH_LINEAR, CDE_METHOD_MIDPOINT);
+  } else if (method == CDE_METHOD_EULER) {
+    if (degree == CDE_PATH_CUBIC) CDE_FWD_M(CDE_PATH_CUBIC, CDE_METHOD_EULER); else CDE_FWD_M(CDE_PATH_LINEAR, CDE_METHOD_EULER);
+  } else return CDE_ERR_UNSUPPORTED;
+#undef CDE_FWD_M
+  return check_launch();
+}
+template int launch_forward_mfma_method<float>(int, const void*, const void*, int64_t, int, const void*, const void*, const void*,
+                                               const void*, int64_t, const void*, int64_t, void*, int64_t, int64_t, int64_t,
+                                               const int64_t*, const void*, hipStream_t);
+template int launch_forward_mfma_method<double>(int, const void*, const void*, int64_t, int, const void*, const void*, const void*,
+                                                const void*, int64_t, const void*, int64_t, void*, int64_t, int64_t, int64_t,
+                                                const int64_t*, const void*, hipStream_t);
+
 // which of the two adjoint kernels of the affine field runs: K3j (shared Jacobian) unless CDE_K3_FORM=product asks for K3
 // (the tests run both against the oracle; scripts compare their timings)
 static bool k3_form_jacobian() {
@@ -1246,7 +1291,7 @@ static bool k3_form_jacobian() {
 template <typename TT>
 int launch_adjoint_jacobian_pair(const void*, const void*, int64_t, int, const void*, const void*, const void*, const void*,
                                  const void*, const int64_t*, int64_t, void*, void*, void*, int64_t, int64_t, int64_t,
-                                 const int64_t*, const void*, float*, hipStream_t);
+                                 const int64_t*, const void*, float*, hipStream_t, int method);
 constexpr bool K3_PAIR_DEFAULT = true;       // 5.26 -> 5.01 ms on the headline workload (profiles/r05_k3_pair_b.log)
 static bool k3_form_pair() {
   const char* e = getenv("CDE_K3_WAVES");
@@ -1290,7 +1335,8 @@ int launch_adjoint_mfma(const void* coeffs, const void* knots, int64_t n_interva
     } else return CDE_ERR_UNSUPPORTED;
   } else if (act == CDE_ACT_NONE && k3_form_jacobian() && k3_form_pair()) {
     return launch_adjoint_jacobian_pair<TT>(coeffs, knots, n_intervals, degree, W, bias, z_saved, grad_out, sgrid, seg_off,
-                                            n_out, grad_z0, grad_W, grad_b, B, C, H, stage_index, stage_frac, partial, s);
+                                            n_out, grad_z0, grad_W, grad_b, B, C, H, stage_index, stage_frac, partial, s,
+                                            CDE_METHOD_RK4);
   } else if (act == CDE_ACT_NONE && k3_form_jacobian()) {
     if (degree == CDE_PATH_CUBIC) CDE_ADJ((rk4_adjoint_jacobian<TT, CDE_PATH_CUBIC>), WJ_FLOATS + 4 * SCR_FLOATS);
     else CDE_ADJ((rk4_adjoint_jacobian<TT, CDE_PATH_LINEAR>), WJ_FLOATS + 4 * SCR_FLOATS);

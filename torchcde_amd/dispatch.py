@@ -32,8 +32,9 @@ Request = collections.namedtuple("Request", [
     "variant_generic",   # variant="generic" (tests: the independent kernels / the step-wise reference path)
     "shared",            # torchcde_amd.distributed.shared_step_control is active
     "narrow_control",    # the control has at most 8 channels (control gradients of a two-layer field)
-    "backprop_ok",       # the fused reverse-mode sweep applies (adjoint=False): identity-activation affine field on the 32 x 8
-                         # tiles, float32, no control tensor that requires a gradient
+    "backprop_ok",       # the plain benchmark field: identity-activation affine field on the 32 x 8 tiles, float32, no control
+                         # tensor that requires a gradient -- what the reverse-mode sweep (adjoint=False) and the midpoint /
+                         # euler forms of K2 / K3p take
 ])
 
 Choice = collections.namedtuple("Choice", ["path", "reason"])
@@ -47,6 +48,7 @@ FUSED_PATHS = (
     "mlp_dopri5_forward",     # K4 with the two-layer field
     "mlp_dopri5_adjoint",     # K4 + K4am: the reference examples' training call with their own model
     "rk4_backprop",           # adjoint=False: K2 storing its stage states + K3d, reverse mode through the solver's steps
+    "fixed_grid",             # method='midpoint' / 'euler': K2 / K3p with two stages / one stage per step
 )
 STEPWISE = "stepwise"
 
@@ -65,8 +67,15 @@ def select_path(q):
         return _stepwise("the field's shape or dtype is beyond the fused kernels' tiles")
     if not q.t_ok:
         return _stepwise("the output times are not strictly increasing")
+    if q.method in ("midpoint", "euler"):
+        # torchdiffeq's other fixed-grid methods (reference test/test_cdeint.py:49-63): K2 / K3p with two stages / one per step
+        grads_ok = not q.wants_grad or (q.adjoint and q.adjoint_method_ok and q.adjoint_options_ok and q.params != "foreign")
+        if q.kind == "affine" and q.backprop_ok and q.options_ok and not q.wants_t and not q.wants_control and grads_ok:
+            return Choice("fixed_grid", "")
+        return _stepwise("method %r is fused for the identity-activation affine field on the 32 x 8 tiles only (float32, "
+                         "adjoint=True, no time / control gradients)" % (q.method,))
     if q.method not in ("rk4", "dopri5"):
-        return _stepwise("method %r has no fused kernel (rk4 and dopri5 have)" % (q.method,))
+        return _stepwise("method %r has no fused kernel (rk4, midpoint, euler and dopri5 have)" % (q.method,))
     if q.wants_grad and not q.adjoint:
         if q.kind == "affine" and q.backprop_ok and q.method == "rk4" and q.options_ok and not q.wants_t:
             return Choice("rk4_backprop", "")
