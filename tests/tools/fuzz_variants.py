@@ -39,7 +39,7 @@ def draw(rng):
     return dict(kind=kind, H=H, C=C, width=rng.choice([8, 32, 100, 128]), final_tanh=rng.random() < 0.6,
                 B=rng.choice([1, 2, 15, 16, 17, 33, 100, 257]), L=rng.choice([2, 3, 5, 12, 30]),
                 degree=rng.choice([1, 3]), irregular=rng.random() < 0.5, extra_dim=rng.random() < 0.2,
-                mode=rng.choice(["rk4", "rk4", "dopri5_forward", "default_call"]),
+                mode=rng.choice(["rk4", "rk4", "dopri5_forward", "default_call", "midpoint", "euler", "rk4_backprop"]),
                 step=rng.choice([1.0, 0.5, 0.37]), n_out=rng.choice([2, 3, 5]), seed=rng.randrange(10 ** 6))
 
 
@@ -68,6 +68,11 @@ def run(cfg, variant, dev):
     spacing = (hi - lo) / (L - 1)
     if cfg["mode"] == "rk4":
         out = cde.cdeint(X, func, z0, t_out, method="rk4", options=dict(step_size=cfg["step"] * spacing), variant=variant)
+    elif cfg["mode"] in ("midpoint", "euler"):        # round 5: K2 / K3p with two stages / one per step (affine field on the tiles)
+        out = cde.cdeint(X, func, z0, t_out, method=cfg["mode"], options=dict(step_size=cfg["step"] * spacing), variant=variant)
+    elif cfg["mode"] == "rk4_backprop":               # round 5: adjoint=False, reverse mode through the steps (K3d) vs autograd
+        out = cde.cdeint(X, func, z0, t_out, method="rk4", adjoint=False, options=dict(step_size=cfg["step"] * spacing),
+                         variant=variant)
     elif cfg["mode"] == "dopri5_forward":
         opts = dict(jump_t=X.grid_points) if cfg["degree"] == 1 else {}
         with torch.no_grad():
@@ -93,7 +98,7 @@ def main():
         cfg = draw(rng)
         try:
             got, want = run(cfg, "auto", dev), run(cfg, "generic", dev)
-            tol = 2e-3 if cfg["mode"] == "rk4" else 2e-2
+            tol = 2e-3 if cfg["mode"] in ("rk4", "midpoint", "euler", "rk4_backprop") else 2e-2
             for k, (g, r) in enumerate(zip(got, want)):
                 scale = max(r.abs().max().item(), 1e-3)
                 err = (g - r).abs().max().item()
