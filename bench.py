@@ -329,14 +329,16 @@ def other_fields(cde, X, z0, device, reps=3):
     out = {}
     for name, func in fields.items():
         start = starts.get(name, z0)
-        for mode in ("forward", "forward_adjoint"):
+        # (adjoint=False -- reverse mode through the solver's steps, README.md:103 -- is fused for the two-layer field too)
+        for mode in ("forward", "forward_adjoint") + (("forward_backprop_adjoint_false",) if name == "two_layer" else ()):
             def once():
                 if mode == "forward":
                     with torch.no_grad():
                         cde.cdeint(X, func, start, X.interval, method="rk4", options={"step_size": 1.0})
                 else:
                     z = start.detach().requires_grad_(True)
-                    cde.cdeint(X, func, z, X.interval, method="rk4", options={"step_size": 1.0})[:, -1].sum().backward()
+                    cde.cdeint(X, func, z, X.interval, method="rk4", options={"step_size": 1.0},
+                               adjoint=mode == "forward_adjoint")[:, -1].sum().backward()
             once()
             torch.cuda.synchronize()
             best = float("inf")

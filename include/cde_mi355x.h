@@ -435,6 +435,27 @@ int cde_rk4_backprop_linear(const void* coeffs, const void* knots, int64_t n_int
                             const int64_t* stage_index, const void* stage_frac, void* workspace, size_t workspace_bytes,
                             void* stream);
 
+/* K3d for the two-layer field of the reference's examples (adjoint=False, method='rk4'): cde_rk4_forward_mlp_stages is
+ * cde_rk4_forward_mlp (one wave per tile at any batch) that also stores `stages` (B, n_grid - 1, 4, 32), the 32 zero-padded
+ * hidden units in plain order; cde_rk4_backprop_mlp_prepare fills the workspace of cde_rk4_adjoint_mlp_workspace_bytes(n_grid)
+ * with the stage table of the FORWARD grid and the weight images; cde_rk4_backprop_mlp_sweep walks the steps
+ * k_end-1 .. k_begin backwards (stage 4 first) in reverse mode: `g_state` (B, H) holds dL/dy of grid node k_end on entry and
+ * of node k_begin on return (the caller adds the output gradients that land on a node between two calls), and the
+ * unweighted gradient factors of the 4 (k_end - k_begin) evaluations are streamed to U / G2 / G1 / Z exactly as
+ * cde_rk4_adjoint_mlp_sweep streams them (rows ((k_end-1-k) * 4 + (3-stage)) * B + series), for cde_mlp_grad_reduce. */
+int cde_rk4_forward_mlp_stages(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W1,
+                               const void* bias1, int64_t width, const void* W2, const void* bias2, int act,
+                               const void* z0, const void* grid, int64_t n_grid, const void* t_out, int64_t n_out,
+                               void* z_out, void* stages, int64_t B, int64_t C, int64_t H, int dtype, int time_dtype,
+                               int64_t* stage_index, void* stage_frac, void* stream);
+int cde_rk4_backprop_mlp_prepare(const void* knots, int64_t n_intervals, const void* grid, int64_t n_grid, const void* W1,
+                                 const void* bias1, int64_t width, const void* W2, const void* bias2, int64_t C, int64_t H,
+                                 int dtype, int time_dtype, void* workspace, size_t workspace_bytes, void* stream);
+int cde_rk4_backprop_mlp_sweep(const void* coeffs, const void* knots, int64_t n_intervals, int degree, int act,
+                               const void* stages, void* g_state, const void* grid, int64_t n_grid, int64_t k_begin,
+                               int64_t k_end, void* U, void* G2, void* G1, void* Z, int64_t B, int64_t C, int64_t H,
+                               int dtype, int time_dtype, const void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K4  Adaptive Dormand-Prince 5(4) solve (torchdiffeq's default method, what cdeint runs when the
  * caller passes no `method`: reference solver.py:226-227, README.md:174) for the affine family.

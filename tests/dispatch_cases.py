@@ -38,6 +38,7 @@ CASES = {
     "affine_rk4_backprop":       (dict(adjoint=False), "rk4_backprop", ("narrow_control",)),
     "affine_backprop_beyond_the_kernel": (dict(adjoint=False, backprop_ok=False), "stepwise",
                                           ("mfma_shape", "variant_generic", "narrow_control")),
+    "two_layer_rk4_backprop":    (dict(_MLP, adjoint=False), "mlp_rk4_backprop", ("narrow_control",)),
     # ------------------------------------------------------------------ torchdiffeq's other fixed-grid methods
     "affine_midpoint":           (dict(method="midpoint"), "fixed_grid", ("narrow_control",)),
     "affine_euler":              (dict(method="euler"), "fixed_grid", ("narrow_control",)),
@@ -59,7 +60,7 @@ CASES = {
                                                      "stepwise", ("variant_generic",)),
 }
 
-GRAD_FN = {"rk4_backprop": "_FusedRK4BackpropBackward", "rk4": "_FusedRK4Backward", "fixed_grid": "_FusedRK4Backward", "dopri5_adjoint": "_FusedDopri5Backward", "mlp_rk4_adjoint": "_FusedMlpRK4Backward",
+GRAD_FN = {"rk4_backprop": "_FusedRK4BackpropBackward", "rk4": "_FusedRK4Backward", "fixed_grid": "_FusedRK4Backward", "mlp_rk4_backprop": "_FusedMlpRK4BackpropBackward", "dopri5_adjoint": "_FusedDopri5Backward", "mlp_rk4_adjoint": "_FusedMlpRK4Backward",
            "mlp_dopri5_adjoint": "_FusedMlpDopri5Backward"}
 
 

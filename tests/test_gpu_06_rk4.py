@@ -793,3 +793,61 @@ def test_reference_backend_test_scenario_with_midpoint(native):
         assert _front().last_dispatch()[0].path == "fixed_grid"
         ref = oracle_cde.cdeint(Xo, f64, z0.double(), Xo.interval, adjoint=False, **kw)
     _close(out, ref, 1e-4, 1e-6)
+
+
+@pytest.mark.parametrize("H,C,width,degree,final_tanh,chunk_bytes", [
+    (32, 8, 128, 3, True, None), (32, 8, 128, 1, True, 3 * 4 * 203 * 552 * 4),   # (second: three steps per sweep launch)
+    (8, 14, 100, 3, True, None), (16, 16, 64, 1, False, None), (12, 5, 48, 3, False, 2 * 4 * 203 * 552 * 4)])
+def test_two_layer_backprop_mode_fused_against_autograd_through_the_oracle(native, H, C, width, degree, final_tanh, chunk_bytes):
+    """cdeint(..., method='rk4', adjoint=False) with the examples' two-layer model (example/time_series_classification.py:
+    20-51; README.md:103's "faster mode"): K2m stores every stage state, K3m's sweep runs as reverse mode through the steps
+    (cde_rk4_forward_mlp_stages, cde_rk4_backprop_mlp_sweep) in chunks that end on the grid nodes an output gradient lands
+    on.  Against autograd through the float64 oracle's odeint; the relu makes the gradient discontinuous in z, so the bar is
+    1e-3 of the largest entry or 4x what float32 costs the CPU oracle (as for the continuous adjoint above)."""
+    import sys
+    cdeint_mod = sys.modules["torchcde_amd.cdeint"]
+    B, L = 203, 12
+    x = make_series(B, L, C, torch.float32, seed=71)
+    coeffs = oracle_interp.hermite_bdiff_coeffs(x) if degree == 3 else x
+    gen = torch.Generator().manual_seed(72)
+    z0 = torch.randn(B, H, generator=gen)
+    t_out = torch.tensor([0., 2.0, 4.5, 11.])
+    lw = torch.rand(B, 4, H, generator=gen) + 0.5
+    kw = dict(method="rk4", options=dict(step_size=1.0), adjoint=False)
+    res = {}
+    for dtype in (torch.float64, torch.float32):
+        f = _TwoLayerField(H, C, width, dtype, seed=5, final_tanh=final_tanh)
+        path = (oracle_interp.CubicPath if degree == 3 else oracle_interp.LinearPath)(coeffs.to(dtype))
+        zc = z0.to(dtype).clone().requires_grad_(True)
+        out = oracle_cde.cdeint(path, f, zc, t_out.to(dtype), **kw)
+        (out * lw.to(dtype)).sum().backward()
+        res[dtype] = [out.detach(), zc.grad] + [p.grad for p in f.parameters()]
+
+    def bar(want, cpu32):
+        return max(1e-3 * want.abs().max().item(), 4 * (cpu32.double() - want).abs().max().item())
+
+    dfunc = _TwoLayerField(H, C, width, seed=5, final_tanh=final_tanh).to(DEV)
+    X = (native.CubicSpline if degree == 3 else native.LinearInterpolation)(coeffs.to(DEV))
+    z = z0.to(DEV).requires_grad_(True)
+    budget = cdeint_mod._MlpPlan.scratch_budget
+    try:
+        if chunk_bytes is not None:
+            cdeint_mod._MlpPlan.scratch_budget = chunk_bytes
+        out = native.cdeint(X, dfunc, z, t_out.to(DEV), **kw)
+        _expect_dispatch("two_layer_rk4_backprop", out)
+        (out * lw.to(DEV)).sum().backward()
+    finally:
+        cdeint_mod._MlpPlan.scratch_budget = budget
+    got = [out.detach(), z.grad] + [p.grad for p in dfunc.parameters()]
+    _close(got[0], res[torch.float64][0], 1e-4, 5e-6)
+    for g_, want, cpu32 in zip(got[1:], res[torch.float64][1:], res[torch.float32][1:]):
+        _close(g_, want, 1e-3, bar(want, cpu32))
+    # the forward values are K2m's own (one wave per tile), bit for bit
+    with torch.no_grad():
+        import os
+        os.environ["CDE_K2M_NO_SPLIT"] = "1"
+        try:
+            plain = native.cdeint(X, dfunc, z0.to(DEV), t_out.to(DEV), method="rk4", options=dict(step_size=1.0))
+        finally:
+            del os.environ["CDE_K2M_NO_SPLIT"]
+    assert torch.equal(plain, out.detach())

@@ -771,8 +771,8 @@ def test_dispatch_table_is_exhaustively_consistent():
                         continue                                 # contradictory requests are never built by cdeint
                     if f["mfma_shape"] and (kind != "affine" or not f["tiles_ok"] or f["variant_generic"]):
                         continue
-                    if f["backprop_ok"] and not f["mfma_shape"]:
-                        continue                                 # the reverse-mode sweep lives on the 32 x 8 tiles
+                    if f["backprop_ok"] and not (f["mfma_shape"] or (kind == "mlp2" and f["tiles_ok"] and not f["variant_generic"])):
+                        continue                                 # the reverse-mode sweeps live on the MFMA tiles
                     q = D.Request(kind=kind, method=method, params=params, **f)
                     c = D.select_path(q)
                     n += 1
@@ -793,10 +793,10 @@ def test_dispatch_table_is_exhaustively_consistent():
                     assert method == ("rk4" if "rk4" in c.path else "dopri5")
                     assert c.path.startswith("mlp_") == (kind == "mlp2")
                     assert ("forward" in c.path) <= (not f["wants_grad"])    # forward-only kernels: nothing to differentiate
-                    if c.path == "rk4_backprop":
-                        # adjoint=False: reverse mode through the steps -- the affine identity field, no time / control gradients
-                        assert f["wants_grad"] and not f["adjoint"] and f["backprop_ok"] and f["mfma_shape"] and kind == "affine"
-                        assert not f["wants_t"]
+                    if c.path in ("rk4_backprop", "mlp_rk4_backprop"):
+                        # adjoint=False: reverse mode through the steps -- no time / control gradients
+                        assert f["wants_grad"] and not f["adjoint"] and f["backprop_ok"] and not f["wants_t"]
+                        assert f["mfma_shape"] == (kind == "affine")
                         continue
                     if f["wants_grad"]:
                         assert f["adjoint"] and f["adjoint_method_ok"] and f["adjoint_options_ok"] and params != "foreign"
@@ -832,6 +832,7 @@ def test_dispatch_table_is_exhaustively_consistent():
     assert ask(method="rk4", wants_control=True, params="own").path == "rk4"    # README.md:251-270
     assert ask(wants_t=True).path == "dopri5_adjoint"                           # output-time gradients: K4a carries vjp_t
     assert ask(method="rk4", adjoint=False).path == "rk4_backprop"              # README.md:103: backprop through the solver
+    assert ask(kind="mlp2", mfma_shape=False, method="rk4", adjoint=False).path == "mlp_rk4_backprop"
     assert ask(method="midpoint").path == "fixed_grid"                          # test/test_cdeint.py:49-63
     assert ask(method="euler", wants_grad=False).path == "fixed_grid"
     for kw, word in ((dict(kind=None), "recognised"), (dict(method="midpoint", kind="mlp2", mfma_shape=False), "midpoint"),

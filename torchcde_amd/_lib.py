@@ -140,6 +140,11 @@ _SIGNATURES = {
     "cde_fixed_adjoint_workspace_bytes": (_sz, [_i64, _i64]),
     "cde_fixed_adjoint_linear": (_i, [_i, _p, _p, _i64, _i, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i64,
                                       _i, _i, _p, _sz, _p]),
+    "cde_rk4_forward_mlp_stages": (_i, [_p, _p, _i64, _i, _p, _p, _i64, _p, _p, _i, _p, _p, _i64, _p, _i64, _p, _p, _i64, _i64,
+                                        _i64, _i, _i, _p, _p, _p]),
+    "cde_rk4_backprop_mlp_prepare": (_i, [_p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _i64, _i64, _i, _i, _p, _sz, _p]),
+    "cde_rk4_backprop_mlp_sweep": (_i, [_p, _p, _i64, _i, _i, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64,
+                                        _i, _i, _p, _sz, _p]),
     "cde_rk4_backprop_supported": (_i, [_i64, _i64, _i, _i]),
     "cde_rk4_forward_linear_stages": (_i, [_p, _p, _i64, _i, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i, _i,
                                            _p, _p, _p]),

@@ -189,6 +189,7 @@ class _Grids:
                 weights += [w for _, w in entries]
                 ptr.append(len(outs))
             dev = self._device
+            self.backprop_nodes = nodes                    # host copy: the two-layer sweep runs in chunks that end on these nodes
             self._backprop = (
                 (grid[1:] - grid[:-1]).to(torch.float32).to(dev) if n_steps > 0 else torch.zeros(1, dtype=torch.float32, device=dev),
                 torch.tensor(ptr, dtype=torch.int64).to(dev), torch.tensor(outs, dtype=torch.int64).to(dev),
@@ -519,6 +520,95 @@ class _MlpPlan:
         grad_b1 = acc1[:width, 32].contiguous()
         return a.reshape(*self.batch, H), grad_w1, grad_b1, grad_w2, grad_b2, grad_x
 
+    # adjoint=False: K2m that also stores every stage state, and K3m's sweep as reverse mode through the steps
+    def run_with_stages(self, z0):
+        lib = _lib.load()
+        g, f = self.grids, self.field
+        out = torch.empty(self.B, g.n_out, self.H, dtype=torch.float32, device=self.device)
+        n_steps = max(g.grid.numel() - 1, 0)
+        stage_index = torch.empty(max(4 * n_steps, 1), dtype=torch.int64, device=self.device)
+        stage_frac = torch.empty(max(4 * n_steps, 1), dtype=torch.float32, device=self.device)
+        stages = torch.empty(self.B, max(n_steps, 1), 4, 32, dtype=torch.float32, device=self.device)
+        z0c = z0.detach().reshape(self.B, self.H).contiguous()
+        w1, b1, w2, b2 = self._weights()
+        _lib.check(lib.cde_rk4_forward_mlp_stages(
+            _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w1), _lib.ptr(b1),
+            w1.size(0), _lib.ptr(w2), _lib.ptr(b2), f.act, _lib.ptr(z0c), _lib.ptr(g.grid), g.grid.numel(),
+            _lib.ptr(g.t_out), g.n_out, _lib.ptr(out), _lib.ptr(stages), self.B, self.C, self.H,
+            _lib.dtype_enum(torch.float32), _lib.dtype_enum(g.time_dtype), _lib.ptr(stage_index), _lib.ptr(stage_frac),
+            _lib.stream_ptr(self.device)), "cde_rk4_forward_mlp_stages")
+        return out.reshape(*self.batch, g.n_out, self.H), stages
+
+    def run_backprop(self, stages, grad_out, weights):
+        """Reverse mode through the 3/8-rule steps (the gradient `loss.backward()` through torchdiffeq's own operations
+        gives, reference solver.py:144 with adjoint=False): the sweep walks the forward grid backwards in chunks of steps
+        that end on the grid nodes an output gradient lands on (the transpose of torchdiffeq's linear output
+        interpolation, `_Grids.backprop_lists`); each chunk's factor rows go through the same split-K reduction as the
+        continuous adjoint's."""
+        lib = _lib.load()
+        g, f = self.grids, self.field
+        B, H, C = self.B, self.H, self.C
+        dev, f32 = self.device, _lib.dtype_enum(torch.float32)
+        w1, b1, w2, b2 = self._weights(weights)
+        width = w1.size(0)
+        _, _, _, _, n_steps = g.backprop_lists()
+        nodes = g.backprop_nodes
+        n_grid = n_steps + 1
+        go = grad_out.detach().reshape(B, self.n_out, H).to(torch.float32)
+        gy = torch.zeros(B, H, dtype=torch.float32, device=dev)
+
+        def land(m):                                                # output gradients that land on grid node m
+            for j, wgt in nodes[m]:
+                gy.add_(go[:, j], alpha=wgt)
+        land(n_steps)
+        acc2 = torch.zeros(256, 132, dtype=torch.float32, device=dev)
+        acc1 = torch.zeros(128, 36, dtype=torch.float32, device=dev)
+        if n_steps > 0:
+            stream = _lib.stream_ptr(dev)
+            tdt = _lib.dtype_enum(g.time_dtype)
+            nbytes = lib.cde_rk4_adjoint_mlp_workspace_bytes(n_grid)
+            workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _lib.check(lib.cde_rk4_backprop_mlp_prepare(
+                _lib.ptr(self.knots), self.n_intervals, _lib.ptr(g.grid), n_grid, _lib.ptr(w1), _lib.ptr(b1), width,
+                _lib.ptr(w2), _lib.ptr(b2), C, H, f32, tdt, _lib.ptr(workspace), nbytes, stream),
+                "cde_rk4_backprop_mlp_prepare")
+            row_bytes = (132 + 256 + 128 + 36) * 4
+            chunk = max(1, min(n_steps, self.scratch_budget // (row_bytes * 4 * B)))
+            rows = chunk * 4 * B
+            U = torch.zeros(rows, 132, dtype=torch.float32, device=dev)
+            U[:, 128] = 1
+            Z = torch.zeros(rows, 36, dtype=torch.float32, device=dev)
+            Z[:, 32] = 1
+            G2 = torch.empty(rows, 256, dtype=torch.float32, device=dev)
+            G1 = torch.empty(rows, 128, dtype=torch.float32, device=dev)
+            reduce_ws = torch.empty(lib.cde_mlp_grad_reduce_workspace_bytes(), dtype=torch.uint8, device=dev)
+            k_hi = n_steps
+            while k_hi > 0:
+                k_lo = max(0, k_hi - chunk)
+                for m in range(k_hi - 1, k_lo, -1):                 # stop on the highest node below k_hi that receives a gradient
+                    if nodes[m]:
+                        k_lo = m
+                        break
+                _lib.check(lib.cde_rk4_backprop_mlp_sweep(
+                    _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, f.act, _lib.ptr(stages),
+                    _lib.ptr(gy), _lib.ptr(g.grid), n_grid, k_lo, k_hi, _lib.ptr(U), _lib.ptr(G2), _lib.ptr(G1), _lib.ptr(Z),
+                    B, C, H, f32, tdt, _lib.ptr(workspace), nbytes, stream), "cde_rk4_backprop_mlp_sweep")
+                n = 4 * (k_hi - k_lo) * B
+                _lib.check(lib.cde_mlp_grad_reduce(_lib.ptr(G2), _lib.ptr(U), n, 2, _lib.ptr(acc2), _lib.ptr(reduce_ws),
+                                                   reduce_ws.numel(), stream), "cde_mlp_grad_reduce")
+                _lib.check(lib.cde_mlp_grad_reduce(_lib.ptr(G1), _lib.ptr(Z), n, 1, _lib.ptr(acc1), _lib.ptr(reduce_ws),
+                                                   reduce_ws.numel(), stream), "cde_mlp_grad_reduce")
+                land(k_lo)
+                k_hi = k_lo
+        else:
+            pass                                                    # a single output time: node 0 is node n_steps, landed above
+        units, channels = (32, 8) if C <= 8 else (16, 16)        # padded (hidden unit, channel) layout of the G2 rows
+        grad_w2 = acc2[:, :width].reshape(units, channels, width)[:H, :C].reshape(H * C, width)
+        grad_b2 = acc2[:, 128].reshape(units, channels)[:H, :C].reshape(H * C)
+        grad_w1 = acc1[:width, :H].contiguous()
+        grad_b1 = acc1[:width, 32].contiguous()
+        return gy.reshape(*self.batch, H), grad_w1, grad_b1, grad_w2, grad_b2
+
     def time_gradients(self, z_saved, grad_out, weights, grad_x, t, want_t=True, want_knots=False):
         """Time gradients from what the sweep produced (as _plan_time_gradients for the one-layer fields):
         dL/dt_i = f(t_i, z_i) . dL/dz_i for i >= 1, dL/dt_0 = int a^T F(z) d2X/dt2 dt - sum_i dL/dt_i; the integral is a
@@ -646,6 +736,25 @@ class _FusedRK4(torch.autograd.Function):
                 grad_w.view_as(weight) if (ctx.needs_input_grad[1] and want_w) else None,
                 grad_b.view_as(bias) if (ctx.needs_input_grad[2] and want_b) else None,
                 None, None, grad_t, grad_knots) + control_grads
+
+
+class _FusedMlpRK4Backprop(torch.autograd.Function):
+    """cdeint(..., method='rk4', adjoint=False) for the examples' two-layer field: as _FusedRK4Backprop, on K2m / K3m."""
+
+    @staticmethod
+    def forward(ctx, z0, w1, b1, w2, b2, plan):
+        out, stages = plan.run_with_stages(z0)
+        ctx.plan = plan
+        ctx.save_for_backward(stages, w1, b1, w2, b2)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        stages, *weights = ctx.saved_tensors
+        grad_z0, g1w, g1b, g2w, g2b = ctx.plan.run_backprop(stages, grad_out, weights)
+        need = ctx.needs_input_grad
+        return (grad_z0 if need[0] else None, g1w if need[1] else None, g1b if need[2] else None,
+                g2w if need[3] else None, g2b if need[4] else None, None)
 
 
 class _FusedRK4Backprop(torch.autograd.Function):
@@ -1377,7 +1486,8 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         adjoint_method_ok=adjoint_method in (None, method), options_ok=options_ok,
         adjoint_options_ok=adjoint_options_ok, t_ok=bool(increasing) or not t_is_vector,
         variant_generic=variant == _lib.VARIANT_GENERIC, shared=step_control() is not None, narrow_control=C <= 8,
-        backprop_ok=bool(mfma_shape and field.act == _lib.ACT_NONE and variant in (_lib.VARIANT_AUTO, _lib.VARIANT_MFMA)
+        backprop_ok=bool(((mfma_shape and field.act == _lib.ACT_NONE and variant in (_lib.VARIANT_AUTO, _lib.VARIANT_MFMA))
+                          or (mlp is not None and variant == _lib.VARIANT_AUTO))
                          and not any(b.requires_grad for b in X.buffers())))
     if recognised_kind is not None and known is None:
         # the probe recognised the formula but the shape / dtype is beyond the tiles: say so in the record and the warning
@@ -1418,6 +1528,9 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         control_inputs = X._control_buffers() if want_x else ()
         return _FusedMlpRK4.apply(z0, mlp.hidden.weight, mlp.hidden.bias, mlp.output.weight, mlp.output.bias, plan,
                                   want_x, t if wants_t else None, X._t if want_knots else None, *control_inputs)
+    if choice.path == "mlp_rk4_backprop":
+        plan = _MlpPlan(X, mlp, batch, H, C, t, _parse_fixed_options(fused_options, "solver"))
+        return _FusedMlpRK4Backprop.apply(z0, mlp.hidden.weight, mlp.hidden.bias, mlp.output.weight, mlp.output.bias, plan)
     if choice.path == "mlp_rk4_forward":
         with torch.no_grad():
             return _MlpPlan(X, mlp, batch, H, C, t, _parse_fixed_options(fused_options, "solver")).run(z0)

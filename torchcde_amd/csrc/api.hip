@@ -99,6 +99,16 @@ int launch_mlp_adjoint_sweep(const void*, const void*, int64_t, int, int, const 
                              int64_t, int64_t, const int64_t*, const void*, void*, void*, void*, void*, int64_t,
                              int64_t, int64_t, void*, hipStream_t);
 
+// adjoint=False for the two-layer field: K2m storing its stage states, K3m's sweep as reverse mode through the steps
+template <typename TT>
+int launch_forward_mlp_stages(const void*, const void*, int64_t, int, const void*, const void*, int64_t, const void*,
+                              const void*, int, const void*, const void*, int64_t, const void*, int64_t, void*, void*, int64_t,
+                              int64_t, int64_t, const int64_t*, const void*, hipStream_t);
+template <typename TT>
+int launch_mlp_backprop_sweep(const void*, const void*, int64_t, int, int, const float*, const void*, int64_t, void*,
+                              const void*, int64_t, int64_t, const int64_t*, const void*, void*, void*, void*, void*, int64_t,
+                              int64_t, int64_t, hipStream_t);
+
 // Stage table: for solver step k over [grid[k], grid[k+1]] and RK stage j, the control interval
 // and fractional part at the stage time -- what CubicSpline._interpret_t (interpolation_cubic.py:
 // 315-322) returns when torchdiffeq's rk4 evaluates the vector field there.  One lane per entry.
@@ -551,6 +561,84 @@ extern "C" int cde_rk4_adjoint_mlp_prepare(const void* knots, int64_t n_interval
   else return CDE_ERR_DTYPE;
   if (rc != CDE_OK) return rc;
   return cde::launch_mlp_adjoint_images(W1, bias1, width, W2, bias2, C, H, (float*)(base + mlp_ws_image_offset(n_steps)), s);
+}
+
+// ---------------------------------------------------------------------------------------------- K3m, reverse mode (adjoint=False)
+extern "C" int cde_rk4_forward_mlp_stages(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
+                                          const void* W1, const void* bias1, int64_t width, const void* W2,
+                                          const void* bias2, int act, const void* z0, const void* grid, int64_t n_grid,
+                                          const void* t_out, int64_t n_out, void* z_out, void* stages, int64_t B, int64_t C,
+                                          int64_t H, int dtype, int time_dtype, int64_t* stage_index, void* stage_frac,
+                                          void* stream) {
+  if (B < 0 || C < 1 || H < 1 || width < 1 || n_intervals < 1 || n_grid < 1 || n_out < 1) return CDE_ERR_SHAPE;
+  if (dtype != CDE_F32) return dtype == CDE_F64 ? CDE_ERR_UNSUPPORTED : CDE_ERR_DTYPE;
+  if (B == 0) return CDE_OK;
+  if (!coeffs || !knots || !W1 || !bias1 || !W2 || !bias2 || !z0 || !grid || !t_out || !z_out) return CDE_ERR_NULL;
+  if (n_grid > 1 && (!stage_index || !stage_frac || !stages)) return CDE_ERR_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if (time_dtype == CDE_F32) {
+    rc = cde::fill_stage_table<float, float>(knots, n_intervals, grid, n_grid - 1, 0, stage_index, stage_frac, s);
+    if (rc != CDE_OK) return rc;
+    return cde::launch_forward_mlp_stages<float>(coeffs, knots, n_intervals, degree, W1, bias1, width, W2, bias2, act, z0,
+                                                 grid, n_grid, t_out, n_out, z_out, stages, B, C, H, stage_index, stage_frac, s);
+  }
+  if (time_dtype == CDE_F64) {
+    rc = cde::fill_stage_table<float, double>(knots, n_intervals, grid, n_grid - 1, 0, stage_index, stage_frac, s);
+    if (rc != CDE_OK) return rc;
+    return cde::launch_forward_mlp_stages<double>(coeffs, knots, n_intervals, degree, W1, bias1, width, W2, bias2, act, z0,
+                                                  grid, n_grid, t_out, n_out, z_out, stages, B, C, H, stage_index, stage_frac, s);
+  }
+  return CDE_ERR_DTYPE;
+}
+
+extern "C" int cde_rk4_backprop_mlp_prepare(const void* knots, int64_t n_intervals, const void* grid, int64_t n_grid,
+                                            const void* W1, const void* bias1, int64_t width, const void* W2,
+                                            const void* bias2, int64_t C, int64_t H, int dtype, int time_dtype,
+                                            void* workspace, size_t workspace_bytes, void* stream) {
+  if (C < 1 || H < 1 || width < 1 || n_intervals < 1 || n_grid < 0) return CDE_ERR_SHAPE;
+  if (dtype != CDE_F32) return dtype == CDE_F64 ? CDE_ERR_UNSUPPORTED : CDE_ERR_DTYPE;
+  if (!cde::mlp_shape_ok(C, H, width)) return CDE_ERR_UNSUPPORTED;
+  if (!knots || !W1 || !bias1 || !W2 || !bias2 || !workspace || (n_grid > 1 && !grid)) return CDE_ERR_NULL;
+  if (workspace_bytes < cde_rk4_adjoint_mlp_workspace_bytes(n_grid)) return CDE_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n_steps = n_grid > 1 ? n_grid - 1 : 0;
+  unsigned char* base = (unsigned char*)workspace;
+  int rc;
+  if (time_dtype == CDE_F32)
+    rc = cde::fill_stage_table<float, float>(knots, n_intervals, grid, n_steps, 0, (int64_t*)base,
+                                             base + mlp_ws_frac_offset(n_steps), s);
+  else if (time_dtype == CDE_F64)
+    rc = cde::fill_stage_table<float, double>(knots, n_intervals, grid, n_steps, 0, (int64_t*)base,
+                                              base + mlp_ws_frac_offset(n_steps), s);
+  else return CDE_ERR_DTYPE;
+  if (rc != CDE_OK) return rc;
+  return cde::launch_mlp_adjoint_images(W1, bias1, width, W2, bias2, C, H, (float*)(base + mlp_ws_image_offset(n_steps)), s);
+}
+
+extern "C" int cde_rk4_backprop_mlp_sweep(const void* coeffs, const void* knots, int64_t n_intervals, int degree, int act,
+                                          const void* stages, void* g_state, const void* grid, int64_t n_grid,
+                                          int64_t k_begin, int64_t k_end, void* U, void* G2, void* G1, void* Z, int64_t B,
+                                          int64_t C, int64_t H, int dtype, int time_dtype, const void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+  if (B < 1 || C < 1 || H < 1 || n_intervals < 1 || k_begin < 0 || k_end < k_begin || k_end > n_grid - 1) return CDE_ERR_SHAPE;
+  if (dtype != CDE_F32) return dtype == CDE_F64 ? CDE_ERR_UNSUPPORTED : CDE_ERR_DTYPE;
+  if (!cde::mlp_shape_ok(C, H, 1)) return CDE_ERR_UNSUPPORTED;
+  if (!coeffs || !knots || !stages || !g_state || !grid || !U || !G2 || !G1 || !Z || !workspace) return CDE_ERR_NULL;
+  if (workspace_bytes < cde_rk4_adjoint_mlp_workspace_bytes(n_grid)) return CDE_ERR_WORKSPACE;
+  const int64_t n_steps = n_grid - 1;
+  const unsigned char* base = (const unsigned char*)workspace;
+  const int64_t* stage_index = (const int64_t*)base;
+  const void* stage_frac = base + mlp_ws_frac_offset(n_steps);
+  const float* img = (const float*)(base + mlp_ws_image_offset(n_steps));
+  hipStream_t s = (hipStream_t)stream;
+  if (time_dtype == CDE_F32)
+    return cde::launch_mlp_backprop_sweep<float>(coeffs, knots, n_intervals, degree, act, img, stages, n_steps, g_state, grid,
+                                                 k_begin, k_end, stage_index, stage_frac, U, G2, G1, Z, B, C, H, s);
+  if (time_dtype == CDE_F64)
+    return cde::launch_mlp_backprop_sweep<double>(coeffs, knots, n_intervals, degree, act, img, stages, n_steps, g_state, grid,
+                                                  k_begin, k_end, stage_index, stage_frac, U, G2, G1, Z, B, C, H, s);
+  return CDE_ERR_DTYPE;
 }
 
 extern "C" int cde_rk4_adjoint_mlp_sweep(const void* coeffs, const void* knots, int64_t n_intervals, int degree, int act,

@@ -78,7 +78,7 @@ __global__ __launch_bounds__((fwd_block_threads<ACT, MLP>()), (fwd_waves_per_sim
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // the A-operand image is loop invariant: staged once through LDS, then it lives in registers
   constexpr bool PRODUCT = ACT == CDE_ACT_NONE && !MLP;
-  static_assert(!SAVE || (PRODUCT && CT == MC), "stage states are stored by the affine field's kernel only");
+  static_assert(!SAVE || (PRODUCT && CT == MC) || (MLP && !SPLIT), "stage states: the affine field's kernel, the two-layer field's one-wave form");
   static_assert(METHOD == CDE_METHOD_RK4 || !SAVE, "stage states are stored for the 3/8 rule only");
   constexpr int NS = METHOD == CDE_METHOD_RK4 ? 4 : METHOD == CDE_METHOD_MIDPOINT ? 2 : 1;     // stages per step
   constexpr int STRIDE = PRODUCT ? 1 : 4;          // distance between a lane's consecutive hidden units
@@ -149,8 +149,13 @@ __global__ __launch_bounds__((fwd_block_threads<ACT, MLP>()), (fwd_waves_per_sim
       if constexpr (SAVE) {
         if (valid) {
           float* srow = stages + ((series * n_steps + k) * 4 + stage) * 32;
-          *reinterpret_cast<float4*>(srow + 4 * q) = make_float4(za[0], za[2], zb[0], zb[2]);            // units 8q, 8q+2, ..
-          *reinterpret_cast<float4*>(srow + 16 + 4 * q) = make_float4(za[1], za[3], zb[1], zb[3]);       // units 8q+1, 8q+3, ..
+          if constexpr (PRODUCT) {           // K3's lane order: evens, then odds
+            *reinterpret_cast<float4*>(srow + 4 * q) = make_float4(za[0], za[2], zb[0], zb[2]);          // units 8q, 8q+2, ..
+            *reinterpret_cast<float4*>(srow + 16 + 4 * q) = make_float4(za[1], za[3], zb[1], zb[3]);     // units 8q+1, 8q+3, ..
+          } else {                           // two-layer field: plain unit order (the lane owns units q, 4+q, .., 28+q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { srow[q + 4 * i] = za[i]; srow[16 + q + 4 * i] = zb[i]; }
+          }
         }
       }
 
@@ -1248,6 +1253,50 @@ template int launch_forward_mfma_stages<float>(const void*, const void*, int64_t
 template int launch_forward_mfma_stages<double>(const void*, const void*, int64_t, int, const void*, const void*, const void*,
                                                 const void*, int64_t, const void*, int64_t, void*, void*, int64_t, int64_t,
                                                 int64_t, const int64_t*, const void*, hipStream_t);
+
+// K2m with the stage states stored (adjoint=False backward of the two-layer field): the one-wave-per-tile form at any batch
+template <typename TT>
+int launch_forward_mlp_stages(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W1,
+                              const void* bias1, int64_t width, const void* W2, const void* bias2, int act, const void* z0,
+                              const void* grid, int64_t n_grid, const void* t_out, int64_t n_out, void* z_out, void* stages,
+                              int64_t B, int64_t C, int64_t H, const int64_t* stage_index, const void* stage_frac,
+                              hipStream_t s) {
+  if (!mlp_shape_ok(C, H, width)) return CDE_ERR_UNSUPPORTED;
+  if (degree != CDE_PATH_CUBIC && degree != CDE_PATH_LINEAR) return CDE_ERR_UNSUPPORTED;
+  if (act != CDE_ACT_NONE && act != CDE_ACT_TANH) return CDE_ERR_UNSUPPORTED;
+  const Dims dims{(int)H, (int)C};
+  const unsigned blocks = (unsigned)((B + 127) / 128);
+  const size_t lds = (size_t)MLP16_LDS_FLOATS * sizeof(float);
+#define CDE_FWD_MS(D, A, CTV)                                                                                       \
+  do {                                                                                                              \
+    (void)hipFuncSetAttribute((const void*)rk4_forward_mfma<TT, D, A, true, CTV, false, true>,                      \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
+    rk4_forward_mfma<TT, D, A, true, CTV, false, true><<<blocks, 512, lds, s>>>(                                    \
+        (const float*)coeffs, (const float*)knots, n_intervals, (const float*)W2, (const float*)bias2,              \
+        (const float*)z0, (const TT*)grid, n_grid, (const TT*)t_out, n_out, (float*)z_out, B, stage_index,          \
+        (const float*)stage_frac, dims, (const float*)W1, (const float*)bias1, (int)width, (float*)stages);         \
+  } while (0)
+#define CDE_FWD_MSD(D, A)                                                                                           \
+  do {                                                                                                              \
+    if (C > MC) CDE_FWD_MS(D, A, 16); else CDE_FWD_MS(D, A, MC);                                                    \
+  } while (0)
+  if (act == CDE_ACT_NONE) {
+    if (degree == CDE_PATH_CUBIC) CDE_FWD_MSD(CDE_PATH_CUBIC, CDE_ACT_NONE); else CDE_FWD_MSD(CDE_PATH_LINEAR, CDE_ACT_NONE);
+  } else {
+    if (degree == CDE_PATH_CUBIC) CDE_FWD_MSD(CDE_PATH_CUBIC, CDE_ACT_TANH); else CDE_FWD_MSD(CDE_PATH_LINEAR, CDE_ACT_TANH);
+  }
+#undef CDE_FWD_MSD
+#undef CDE_FWD_MS
+  return check_launch();
+}
+template int launch_forward_mlp_stages<float>(const void*, const void*, int64_t, int, const void*, const void*, int64_t,
+                                              const void*, const void*, int, const void*, const void*, int64_t, const void*,
+                                              int64_t, void*, void*, int64_t, int64_t, int64_t, const int64_t*, const void*,
+                                              hipStream_t);
+template int launch_forward_mlp_stages<double>(const void*, const void*, int64_t, int, const void*, const void*, int64_t,
+                                               const void*, const void*, int, const void*, const void*, int64_t, const void*,
+                                               int64_t, void*, void*, int64_t, int64_t, int64_t, const int64_t*, const void*,
+                                               hipStream_t);
 
 // midpoint / euler through the same kernel (affine field, f32, H <= 32, C <= 8)
 template <typename TT>

@@ -72,13 +72,21 @@ __global__ void mlp_adj_image_kernel(const float* __restrict__ W1, const float* 
 // dL/dY1, va and the RK bookkeeping redundantly and bit-identically, the unit groups of layer 2 / dL/dY2 / gu split four
 // ways, partial sums added in a fixed wave order through a 9 KB LDS window (cde_mlp_adj.h: mlp_split_allreduce, as in
 // K4am's split form); wave 0 stores state, the shared factor rows and the control gradients.
-template <typename TT, int DEGREE, int ACT, bool DCOEFF = false, int CT = MC, bool SPLIT = false>
+// BACKPROP (round 5; adjoint=False under rk4, reference solver.py:144 + README.md:103): the same evaluation, but as
+// reverse-mode differentiation of the 3/8-rule steps themselves (see rk4_backprop.hip for the recurrences): the steps
+// k_end-1 .. k_begin of the FORWARD grid are walked backwards, stage 4 first; the stage states come from `stages`
+// (B, n_steps_total, 4, 32: what rk4_forward_mfma<.., MLP, .., SAVE> stored), the vector the Jacobian-transpose is
+// applied to is kb_i (in place of a), factor rows are streamed unweighted (kb_i carries dt/8, 3dt/8), nothing is
+// re-integrated: `a_state` holds dL/dy of the grid node above the chunk on entry and of the node below it on return.
+template <typename TT, int DEGREE, int ACT, bool DCOEFF = false, int CT = MC, bool SPLIT = false, bool BACKPROP = false>
 __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2) void rk4_adjoint_mlp_sweep(
     const float* __restrict__ coeffs, const float* __restrict__ knots, int64_t n_intervals,
     const float* __restrict__ img, float* __restrict__ y_state, float* __restrict__ a_state,
     const TT* __restrict__ sgrid, int64_t k_begin, int64_t k_end, const int64_t* __restrict__ stage_index,
     const float* __restrict__ stage_frac, float* __restrict__ U, float* __restrict__ G2, float* __restrict__ G1,
-    float* __restrict__ Z, int64_t B, Dims dims, float* __restrict__ grad_coeffs = nullptr) {
+    float* __restrict__ Z, int64_t B, Dims dims, float* __restrict__ grad_coeffs = nullptr,
+    const float* __restrict__ stages = nullptr, int64_t n_steps_total = 0) {
+  static_assert(!BACKPROP || (!DCOEFF && !SPLIT), "the reverse-mode form: one wave per tile, no control gradients");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   {
     const float4* src = reinterpret_cast<const float4*>(img);
@@ -107,12 +115,14 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2) void rk4_adjoint_
   for (int cl = 0; cl < 4; ++cl) w2g_off[cl] = ((q >> 1) * 8 + w2p_residue(q, cl)) * W2P_STRIDE + n;
 
   const int ua = q, ub = 16 + q;                                     // this lane's units: q, 4+q, .., 28+q
-  f32x4 ya = load_units4<4>(y_state + sc * Hr, ua, Hr), yb = load_units4<4>(y_state + sc * Hr, ub, Hr);
+  f32x4 ya = {0.f, 0.f, 0.f, 0.f}, yb = ya;
+  if constexpr (!BACKPROP) { ya = load_units4<4>(y_state + sc * Hr, ua, Hr); yb = load_units4<4>(y_state + sc * Hr, ub, Hr); }
   f32x4 aa = load_units4<4>(a_state + sc * Hr, ua, Hr), ab = load_units4<4>(a_state + sc * Hr, ub, Hr);
   if (!in_range) { aa = f32x4{0.f, 0.f, 0.f, 0.f}; ab = aa; }       // a == 0 stays 0: padded lanes contribute nothing
 
-  int64_t idx = stage_index[4 * k_begin];
-  float frac = stage_frac[4 * k_begin];
+  const int64_t e_first = BACKPROP ? 4 * k_end - 1 : 4 * k_begin;
+  int64_t idx = stage_index[e_first];
+  float frac = stage_frac[e_first];
   Row<DEGREE, CT> row = load_row<DEGREE, CT>(coeffs, sc, n_intervals, idx, Cr);
 
   // dL/d(coefficient row in use) for channels 2q, 2q+1: cubic (b, 2c, 3d), linear (left knot, right knot)
@@ -136,23 +146,38 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2) void rk4_adjoint_
     }
   };
 
-  for (int64_t k = k_begin; k < k_end; ++k) {
+  for (int64_t kk = 0; kk < k_end - k_begin; ++kk) {
+    const int64_t k = BACKPROP ? k_end - 1 - kk : k_begin + kk;
     const float ds = (float)(sgrid[k + 1] - sgrid[k]);
     f32x4 ky1a, ky1b, ky2a, ky2b, ka1a, ka1b, ka2a, ka2b;
     f32x4 za = ya, zb = yb, sa = aa, sb = ab;                        // stage values of z and a
+    // BACKPROP: aa / ab = dL/dy1 of this step; kb1 .. kb3 as in rk4_backprop.hip, sa / sb = the kb of the stage at hand
+    f32x4 kb1a, kb1b, kb2a, kb2b, kb3a, kb3b, yba, ybb;
+    if constexpr (BACKPROP) {
+      const float c8 = ds * 0.125f;
+      kb1a = aa * c8; kb1b = ab * c8; kb2a = aa * (3.f * c8); kb2b = ab * (3.f * c8); kb3a = kb2a; kb3b = kb2b;
+      sa = kb1a; sb = kb1b;                                          // kb4 == kb1's initial value
+      yba = aa; ybb = ab;
+    }
 #pragma unroll
-    for (int stage = 0; stage < 4; ++stage) {
+    for (int si = 0; si < 4; ++si) {
+      const int stage = BACKPROP ? 3 - si : si;
       float dX[CT];
       const float width = DEGREE == CDE_PATH_LINEAR ? knots[idx + 1] - knots[idx] : 1.f;
       control_slope<DEGREE, CT>(row, frac, width, dX);
-      const int64_t e_next = 4 * k + stage + 1;
-      const bool more = e_next < 4 * k_end;
+      const int64_t e_next = BACKPROP ? 4 * k + stage - 1 : 4 * k + stage + 1;
+      const bool more = BACKPROP ? e_next >= 4 * k_begin : e_next < 4 * k_end;
       const int64_t nidx = more ? stage_index[e_next] : idx;
       const float nfrac = more ? stage_frac[e_next] : frac;
       // `row` is dead from here to the end of the tile loop: the next stage's row is (re)loaded only then, so its 24
       // registers are free while the register pressure peaks (reloading costs 6 KB of L2 traffic per wave and stage)
-      const float wq = ((stage == 0 || stage == 3) ? 0.125f : 0.375f) * ds;     // 3/8-rule quadrature weight
-      const int64_t out_row = ((k - k_begin) * 4 + stage) * B + series;          // (stage, series)
+      const float wq = BACKPROP ? 1.f : ((stage == 0 || stage == 3) ? 0.125f : 0.375f) * ds;     // 3/8-rule quadrature weight
+      const int64_t out_row = (kk * 4 + si) * B + series;                        // (stage, series)
+      if constexpr (BACKPROP) {                                      // the state the forward pass handed to this evaluation
+        const float* srow = stages + ((sc * n_steps_total + k) * 4 + stage) * 32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { za[i] = srow[q + 4 * i]; zb[i] = srow[16 + q + 4 * i]; }
+      }
 
       int opaque = 0;                                                // keeps the LDS reads inside the stage
       asm volatile("" : "+v"(opaque));
@@ -319,7 +344,26 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2) void rk4_adjoint_
       // ---- reverse-time dynamics: dz/ds = -f, da/ds = +a^T df/dz; torchdiffeq 3/8 rule, association preserved
       const f32x4 kya = -fa, kyb = -fb, kaa = va, kab = vb;
       const float third = (float)(1.0 / 3.0);
-      if (stage == 0) {
+      if constexpr (BACKPROP) {
+        // reverse mode through the step (rk4_backprop.hip): va / vb = J_i^T kb_i
+        const float dt3 = ds * third;
+        yba = yba + va; ybb = ybb + vb;
+        if (stage == 3) {
+          kb1a = kb1a + ds * va; kb1b = kb1b + ds * vb;
+          kb2a = kb2a - ds * va; kb2b = kb2b - ds * vb;
+          kb3a = kb3a + ds * va; kb3b = kb3b + ds * vb;
+          sa = kb3a; sb = kb3b;
+        } else if (stage == 2) {
+          kb2a = kb2a + ds * va; kb2b = kb2b + ds * vb;
+          kb1a = kb1a - dt3 * va; kb1b = kb1b - dt3 * vb;
+          sa = kb2a; sb = kb2b;
+        } else if (stage == 1) {
+          kb1a = kb1a + dt3 * va; kb1b = kb1b + dt3 * vb;
+          sa = kb1a; sb = kb1b;
+        } else {
+          sa = yba; sb = ybb;                                        // dL/dy0: what the step hands down
+        }
+      } else if (stage == 0) {
         ky1a = kya; ky1b = kyb; ka1a = kaa; ka1b = kab;
         za = ya + ds * ky1a * third; zb = yb + ds * ky1b * third;
         sa = aa + ds * ka1a * third; sb = ab + ds * ka1b * third;
@@ -343,8 +387,10 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2) void rk4_adjoint_
   }
   flush_control_grad(idx);                     // end of this chunk of steps
   if (valid) {
-    store_units4<4>(y_state + series * Hr, ua, Hr, ya);
-    store_units4<4>(y_state + series * Hr, ub, Hr, yb);
+    if constexpr (!BACKPROP) {
+      store_units4<4>(y_state + series * Hr, ua, Hr, ya);
+      store_units4<4>(y_state + series * Hr, ub, Hr, yb);
+    }
     store_units4<4>(a_state + series * Hr, ua, Hr, aa);
     store_units4<4>(a_state + series * Hr, ub, Hr, ab);
   }
@@ -546,6 +592,46 @@ int launch_mlp_adjoint_sweep(const void* coeffs, const void* knots, int64_t n_in
 #undef CDE_SWEEP_L
   return check_launch();
 }
+
+// the reverse-mode form (adjoint=False): one wave per tile, steps k_end-1 .. k_begin of the forward grid
+template <typename TT>
+int launch_mlp_backprop_sweep(const void* coeffs, const void* knots, int64_t n_intervals, int degree, int act,
+                              const float* img, const void* stages, int64_t n_steps_total, void* g_state, const void* grid,
+                              int64_t k_begin, int64_t k_end, const int64_t* stage_index, const void* stage_frac, void* U,
+                              void* G2, void* G1, void* Z, int64_t B, int64_t C, int64_t H, hipStream_t s) {
+  if (k_end <= k_begin) return CDE_OK;
+  const Dims dims{(int)H, (int)C};
+  const unsigned blocks = (unsigned)((B + 127) / 128);
+  const size_t lds = (size_t)ADJ_LDS_FLOATS * sizeof(float);
+#define CDE_BP_L(D, A, CTV)                                                                                        \
+  do {                                                                                                             \
+    (void)hipFuncSetAttribute((const void*)rk4_adjoint_mlp_sweep<TT, D, A, false, CTV, false, true>,               \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
+    rk4_adjoint_mlp_sweep<TT, D, A, false, CTV, false, true><<<blocks, 512, lds, s>>>(                             \
+        (const float*)coeffs, (const float*)knots, n_intervals, img, nullptr, (float*)g_state, (const TT*)grid,    \
+        k_begin, k_end, stage_index, (const float*)stage_frac, (float*)U, (float*)G2, (float*)G1, (float*)Z, B,    \
+        dims, nullptr, (const float*)stages, n_steps_total);                                                       \
+  } while (0)
+#define CDE_BP(D, A)                                                                                               \
+  do {                                                                                                             \
+    if (C > MC) CDE_BP_L(D, A, 16); else CDE_BP_L(D, A, MC);                                                       \
+  } while (0)
+  if (degree != CDE_PATH_CUBIC && degree != CDE_PATH_LINEAR) return CDE_ERR_UNSUPPORTED;
+  if (act == CDE_ACT_NONE) {
+    if (degree == CDE_PATH_CUBIC) CDE_BP(CDE_PATH_CUBIC, CDE_ACT_NONE); else CDE_BP(CDE_PATH_LINEAR, CDE_ACT_NONE);
+  } else if (act == CDE_ACT_TANH) {
+    if (degree == CDE_PATH_CUBIC) CDE_BP(CDE_PATH_CUBIC, CDE_ACT_TANH); else CDE_BP(CDE_PATH_LINEAR, CDE_ACT_TANH);
+  } else return CDE_ERR_UNSUPPORTED;
+#undef CDE_BP
+#undef CDE_BP_L
+  return check_launch();
+}
+template int launch_mlp_backprop_sweep<float>(const void*, const void*, int64_t, int, int, const float*, const void*, int64_t,
+                                              void*, const void*, int64_t, int64_t, const int64_t*, const void*, void*, void*,
+                                              void*, void*, int64_t, int64_t, int64_t, hipStream_t);
+template int launch_mlp_backprop_sweep<double>(const void*, const void*, int64_t, int, int, const float*, const void*, int64_t,
+                                               void*, const void*, int64_t, int64_t, const int64_t*, const void*, void*, void*,
+                                               void*, void*, int64_t, int64_t, int64_t, hipStream_t);
 
 template int launch_mlp_adjoint_sweep<float>(const void*, const void*, int64_t, int, int, const float*, void*, void*,
                                              const void*, int64_t, int64_t, const int64_t*, const void*, void*, void*,

@@ -32,9 +32,9 @@ Request = collections.namedtuple("Request", [
     "variant_generic",   # variant="generic" (tests: the independent kernels / the step-wise reference path)
     "shared",            # torchcde_amd.distributed.shared_step_control is active
     "narrow_control",    # the control has at most 8 channels (control gradients of a two-layer field)
-    "backprop_ok",       # the plain benchmark field: identity-activation affine field on the 32 x 8 tiles, float32, no control
-                         # tensor that requires a gradient -- what the reverse-mode sweep (adjoint=False) and the midpoint /
-                         # euler forms of K2 / K3p take
+    "backprop_ok",       # affine: the plain benchmark field (identity activation, 32 x 8 tiles, float32); mlp2: the field fits
+                         # the two-layer tiles; and no control tensor requires a gradient -- what the reverse-mode sweeps
+                         # (adjoint=False) and, for the affine field, the midpoint / euler forms of K2 / K3p take
 ])
 
 Choice = collections.namedtuple("Choice", ["path", "reason"])
@@ -49,6 +49,7 @@ FUSED_PATHS = (
     "mlp_dopri5_adjoint",     # K4 + K4am: the reference examples' training call with their own model
     "rk4_backprop",           # adjoint=False: K2 storing its stage states + K3d, reverse mode through the solver's steps
     "fixed_grid",             # method='midpoint' / 'euler': K2 / K3p with two stages / one stage per step
+    "mlp_rk4_backprop",       # adjoint=False for the two-layer field: K2m storing its stage states + K3m's sweep in reverse mode
 )
 STEPWISE = "stepwise"
 
@@ -77,10 +78,10 @@ def select_path(q):
     if q.method not in ("rk4", "dopri5"):
         return _stepwise("method %r has no fused kernel (rk4, midpoint, euler and dopri5 have)" % (q.method,))
     if q.wants_grad and not q.adjoint:
-        if q.kind == "affine" and q.backprop_ok and q.method == "rk4" and q.options_ok and not q.wants_t:
-            return Choice("rk4_backprop", "")
-        return _stepwise("adjoint=False with gradients: backpropagation through the solver's own operations (fused for "
-                         "the identity-activation affine field under rk4 only)")
+        if q.backprop_ok and q.method == "rk4" and q.options_ok and not q.wants_t:
+            return Choice("rk4_backprop" if q.kind == "affine" else "mlp_rk4_backprop", "")
+        return _stepwise("adjoint=False with gradients: backpropagation through the solver's own operations (fused under rk4 "
+                         "for the identity-activation affine field on the 32 x 8 tiles and for the two-layer field)")
     if not q.options_ok:
         return _stepwise("solver options outside the fused kernels' set")
     if q.wants_grad and not q.adjoint_method_ok:
