@@ -405,10 +405,11 @@ int cde_fixed_adjoint_linear(int method, const void* coeffs, const void* knots, 
  * the discrete 3/8-rule map, README.md:103; not the continuous adjoint of K3).  Two calls:
  *   cde_rk4_forward_linear_stages   K2, which also stores the state handed to each of the 4 * (n_grid - 1) field
  *       evaluations:  stages (B, n_grid - 1, 4, 32) f32 -- row (series, step, stage) holds the 32 (zero padded) hidden
- *       units in the order u -> (u & 1) * 16 + (u >> 1) (evens, then odds: the lane order of the 32 x 32 MFMA tiles).
- *       All other arguments as cde_rk4_forward_linear (the affine field with act == CDE_ACT_NONE is implied).
- *   cde_rk4_backprop_linear   reverse-mode sweep over the stored stages, one Jacobian GEMM + one matrix-vector
- *       product + the dL/dW product per stage (csrc/rk4_backprop.hip):
+ *       units; act == CDE_ACT_NONE: in the order u -> (u & 1) * 16 + (u >> 1) (evens, then odds: the lane order of the
+ *       32 x 32 MFMA tiles), act == CDE_ACT_TANH: in plain order.  All other arguments as cde_rk4_forward_linear.
+ *   cde_rk4_backprop_linear   reverse-mode sweep over the stored stages (csrc/rk4_backprop.hip): identity activation -- one
+ *       Jacobian GEMM + one matrix-vector product + the dL/dW product per stage; tanh -- the pre-activation GEMM, its
+ *       transpose and the dL/dW product (K3a's stage), same `act` as the forward call:
  *         grad_out (B, n_out, H)      dL/dz_out
  *         step_dt  (n_steps) f32      float32(grid[k+1] - grid[k]), the step sizes the forward kernel used
  *         node_ptr (n_steps + 2) int64, node_out / node_weight (node_ptr[n_steps + 1]) int64 / f32:  CSR lists -- grid node
@@ -424,12 +425,13 @@ int cde_fixed_adjoint_linear(int method, const void* coeffs, const void* knots, 
  * ------------------------------------------------------------------------------------------- */
 int cde_rk4_backprop_supported(int64_t C, int64_t H, int dtype, int act);
 int cde_rk4_forward_linear_stages(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
-                                  const void* bias, const void* z0, const void* grid, int64_t n_grid, const void* t_out,
-                                  int64_t n_out, void* z_out, void* stages, int64_t B, int64_t C, int64_t H, int dtype,
-                                  int time_dtype, int64_t* stage_index, void* stage_frac, void* stream);
+                                  const void* bias, int act, const void* z0, const void* grid, int64_t n_grid,
+                                  const void* t_out, int64_t n_out, void* z_out, void* stages, int64_t B, int64_t C, int64_t H,
+                                  int dtype, int time_dtype, int64_t* stage_index, void* stage_frac, void* stream);
 size_t cde_rk4_backprop_workspace_bytes(int64_t B);
 int cde_rk4_backprop_linear(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
-                            const void* stages, const void* grad_out, int64_t n_out, const float* step_dt,
+                            const void* bias, int act, const void* stages, const void* grad_out, int64_t n_out,
+                            const float* step_dt,
                             int64_t n_steps, const int64_t* node_ptr, const int64_t* node_out, const float* node_weight,
                             void* grad_z0, void* grad_W, void* grad_b, int64_t B, int64_t C, int64_t H, int dtype,
                             const int64_t* stage_index, const void* stage_frac, void* workspace, size_t workspace_bytes,

@@ -18,11 +18,11 @@ from torchcde_amd import dispatch
 BASE = dispatch.Request(
     prod=False, kind="affine", tiles_ok=True, mfma_shape=True, method="rk4", adjoint=True, wants_grad=True, wants_t=False,
     wants_control=False, params="default", adjoint_method_ok=True, options_ok=True, adjoint_options_ok=True, t_ok=True,
-    variant_generic=False, shared=False, narrow_control=True, backprop_ok=True)
+    variant_generic=False, shared=False, narrow_control=True, backprop_ok=True, identity=True)
 
-_MLP = dict(kind="mlp2", mfma_shape=False)
+_MLP = dict(kind="mlp2", mfma_shape=False, identity=False)
 _BOOLS = {"mfma_shape": (False, True), "narrow_control": (False, True), "variant_generic": (False, True),
-          "wants_t": (False, True), "shared": (False, True), "backprop_ok": (False, True)}
+          "wants_t": (False, True), "shared": (False, True), "backprop_ok": (False, True), "identity": (False, True)}
 
 CASES = {
     # ------------------------------------------------------------------ one-layer (affine / tanh) fields
@@ -35,7 +35,7 @@ CASES = {
     "affine_dopri5_wide":        (dict(method="dopri5", mfma_shape=False), "stepwise", ("narrow_control",)),
     "affine_dopri5_control":     (dict(method="dopri5", wants_control=True, params="own"), "stepwise", ("wants_t",)),
     # ------------------------------------------------------------------ adjoint=False: reverse mode through the solver's steps
-    "affine_rk4_backprop":       (dict(adjoint=False), "rk4_backprop", ("narrow_control",)),
+    "affine_rk4_backprop":       (dict(adjoint=False), "rk4_backprop", ("narrow_control",)),          # (identity or tanh)
     "affine_backprop_beyond_the_kernel": (dict(adjoint=False, backprop_ok=False), "stepwise",
                                           ("mfma_shape", "variant_generic", "narrow_control")),
     "two_layer_rk4_backprop":    (dict(_MLP, adjoint=False), "mlp_rk4_backprop", ("narrow_control",)),
@@ -44,6 +44,7 @@ CASES = {
     "affine_euler":              (dict(method="euler"), "fixed_grid", ("narrow_control",)),
     "affine_midpoint_forward":   (dict(method="midpoint", wants_grad=False), "fixed_grid", ()),
     "midpoint_beyond_the_kernel": (dict(method="midpoint", backprop_ok=False), "stepwise", ("mfma_shape", "variant_generic")),
+    "midpoint_tanh":             (dict(method="midpoint", identity=False), "stepwise", ()),
     # ------------------------------------------------------------------ the examples' two-layer field
     "two_layer_rk4":             (dict(_MLP), "mlp_rk4_adjoint", ("narrow_control",)),
     "two_layer_rk4_control":     (dict(_MLP, wants_control=True, params="own"), "mlp_rk4_adjoint", ("wants_t",)),
@@ -69,7 +70,10 @@ def _free(name):
     fields, _, free = CASES[name]
     row = BASE._replace(**fields)
     matters = not row.adjoint or row.method in ("midpoint", "euler") or "backprop_ok" in fields
-    return tuple(free) + (() if matters else ("backprop_ok",))
+    extra = () if matters else ("backprop_ok",)
+    if row.kind == "affine" and row.method not in ("midpoint", "euler") and "identity" not in fields:
+        extra += ("identity",)              # identity / tanh: the same row everywhere except under midpoint / euler
+    return tuple(free) + extra
 
 
 def requests_of(name):

@@ -702,13 +702,13 @@ def test_rk4_backprop_mode_fused_against_autograd_through_the_oracle(native, B, 
 
 
 def test_rk4_backprop_mode_requests_the_kernel_does_not_take(native):
-    """adjoint=False with a tanh field, float64, a control that requires a gradient, or output times that do: still the
-    step-wise path (the table row says why), still correct against the oracle."""
+    """adjoint=False in float64 or with output times that require a gradient: still the step-wise path (the table row says
+    why), still correct against the oracle."""
     B, L, C, H = 9, 7, 4, 6
     x = make_series(B, L, C, seed=3)
     z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(4))
     kw = dict(method="rk4", options=dict(step_size=1.0), adjoint=False)
-    for tanh, dtype, want_t in ((True, torch.float32, False), (False, torch.float64, False), (False, torch.float32, True)):
+    for tanh, dtype, want_t in ((True, torch.float64, False), (False, torch.float64, False), (False, torch.float32, True)):
         f64 = LinearField(H, C, torch.float64, scale=0.3, tanh=tanh, seed=3)
         Xo = oracle_interp.CubicPath(oracle_interp.hermite_bdiff_coeffs(x.double()))
         zo = z0.double().requires_grad_(True)
@@ -851,3 +851,34 @@ def test_two_layer_backprop_mode_fused_against_autograd_through_the_oracle(nativ
         finally:
             del os.environ["CDE_K2M_NO_SPLIT"]
     assert torch.equal(plain, out.detach())
+
+
+@pytest.mark.parametrize("B,L,C,H,degree,step,times", [
+    (75, 12, 8, 32, 3, 1.0, [0., 4.5, 11.]), (203, 9, 5, 20, 1, 0.75, [0., 1.5, 2.0, 2.25, 6.9, 8.]), (1, 4, 3, 7, 3, 0.5, [1., 2.6])])
+def test_rk4_backprop_mode_tanh_field_fused_against_autograd_through_the_oracle(native, B, L, C, H, degree, step, times):
+    """adjoint=False under rk4 for the tanh field of example/irregular_data.py:36-46: K2 (pre-activation tiling) stores its
+    stage states in plain unit order, rk4_backprop_act runs K3a's stage -- pre-activation GEMM, tanh', its transpose, the
+    dL/dW product -- in reverse mode.  Against autograd through the float64 oracle."""
+    x = make_series(B, L, C, seed=27 + B)
+    z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(28))
+    t_out = torch.tensor(times)
+    lw = torch.rand(B, t_out.numel(), H, generator=torch.Generator().manual_seed(29)) + 0.5
+    kw = dict(method="rk4", options=dict(step_size=step), adjoint=False)
+    f64 = LinearField(H, C, torch.float64, scale=0.5, tanh=True, seed=3)
+    Xo = (oracle_interp.CubicPath(oracle_interp.hermite_bdiff_coeffs(x.double())) if degree == 3
+          else oracle_interp.LinearPath(x.double()))
+    zo = z0.double().requires_grad_(True)
+    ref = oracle_cde.cdeint(Xo, f64, zo, t_out.double(), **kw)
+    (ref * lw.double()).sum().backward()
+    func = LinearField(H, C, scale=0.5, tanh=True, seed=3).to(DEV)
+    X = (native.CubicSpline(native.hermite_cubic_coefficients_with_backward_differences(x.to(DEV))) if degree == 3
+         else native.LinearInterpolation(native.linear_interpolation_coeffs(x.to(DEV))))
+    z = z0.to(DEV).requires_grad_(True)
+    out = native.cdeint(X, func, z, t_out.to(DEV), **kw)
+    _expect_dispatch("affine_rk4_backprop", out)
+    (out * lw.to(DEV)).sum().backward()
+    _close(out, ref, 1e-4, 2e-6)
+    gw, gb = f64.linear.weight.grad, f64.linear.bias.grad
+    _close(z.grad, zo.grad, 1e-3, 1e-3 * zo.grad.abs().max().item())
+    _close(func.linear.weight.grad, gw, 1e-3, 1e-3 * gw.abs().max().item())
+    _close(func.linear.bias.grad, gb, 1e-3, 1e-3 * gb.abs().max().item())

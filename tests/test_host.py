@@ -759,7 +759,7 @@ def test_dispatch_table_is_exhaustively_consistent():
     import itertools
     from torchcde_amd import dispatch as D
     flags = ["prod", "tiles_ok", "mfma_shape", "adjoint", "wants_grad", "wants_t", "wants_control", "adjoint_method_ok",
-             "options_ok", "adjoint_options_ok", "t_ok", "variant_generic", "shared", "narrow_control", "backprop_ok"]
+             "options_ok", "adjoint_options_ok", "t_ok", "variant_generic", "shared", "narrow_control", "backprop_ok", "identity"]
     seen = collections_counter = {}
     n = 0
     for kind in (None, "affine", "mlp2"):
@@ -773,6 +773,8 @@ def test_dispatch_table_is_exhaustively_consistent():
                         continue
                     if f["backprop_ok"] and not (f["mfma_shape"] or (kind == "mlp2" and f["tiles_ok"] and not f["variant_generic"])):
                         continue                                 # the reverse-mode sweeps live on the MFMA tiles
+                    if f["identity"] and kind != "affine":
+                        continue
                     q = D.Request(kind=kind, method=method, params=params, **f)
                     c = D.select_path(q)
                     n += 1
@@ -785,7 +787,7 @@ def test_dispatch_table_is_exhaustively_consistent():
                     assert not f["prod"] and kind is not None and f["tiles_ok"] and f["t_ok"] and f["options_ok"]
                     if c.path == "fixed_grid":
                         # midpoint / euler: the plain affine field, no time / control gradients, gradients through adjoint=True only
-                        assert method == "midpoint" and kind == "affine" and f["backprop_ok"] and f["mfma_shape"]
+                        assert method == "midpoint" and kind == "affine" and f["backprop_ok"] and f["mfma_shape"] and f["identity"]
                         assert not f["wants_t"] and not f["wants_control"]
                         assert not f["wants_grad"] or (f["adjoint"] and f["adjoint_method_ok"] and f["adjoint_options_ok"]
                                                        and params != "foreign")
@@ -817,7 +819,7 @@ def test_dispatch_table_is_exhaustively_consistent():
         base = dict(prod=False, kind="affine", tiles_ok=True, mfma_shape=True, method="dopri5", adjoint=True,
                     wants_grad=True, wants_t=False, wants_control=False, params="default", adjoint_method_ok=True,
                     options_ok=True, adjoint_options_ok=True, t_ok=True, variant_generic=False, shared=False,
-                    narrow_control=True, backprop_ok=True)
+                    narrow_control=True, backprop_ok=True, identity=True)
         base.update(kw)
         return D.select_path(D.Request(**base))
     # the rows a user meets

@@ -333,7 +333,7 @@ class _Plan:
         b = bias.detach().contiguous()
         begin = self._mark()
         _lib.check(lib.cde_rk4_forward_linear_stages(
-            _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w), _lib.ptr(b),
+            _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w), _lib.ptr(b), self.act,
             _lib.ptr(z0c), _lib.ptr(self.grid), self.grid.numel(), _lib.ptr(self.t_out), self.n_out, _lib.ptr(out),
             _lib.ptr(stages), self.B, self.C, self.H, _lib.dtype_enum(self.dtype), _lib.dtype_enum(self.time_dtype),
             _lib.ptr(self.stage_index), _lib.ptr(self.stage_frac), _lib.stream_ptr(self.device)),
@@ -342,7 +342,7 @@ class _Plan:
             self.owner.event_log.append(("forward", begin, self._mark()))
         return out, stages
 
-    def run_backprop(self, stages, grad_out, weight):
+    def run_backprop(self, stages, grad_out, weight, bias):
         lib = _lib.load()
         step_dt, node_ptr, node_out, node_weight, n_steps = self.grids.backprop_lists()
         nbytes = lib.cde_rk4_backprop_workspace_bytes(self.B)
@@ -353,10 +353,11 @@ class _Plan:
         grad_w, grad_b = flat[:n_w].view(self.H * self.C, self.H), flat[n_w:]
         go = grad_out.detach().reshape(self.B, self.n_out, self.H).contiguous()
         w = weight.detach().contiguous()
+        bvec = bias.detach().contiguous()
         begin = self._mark()
         _lib.check(lib.cde_rk4_backprop_linear(
-            _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w), _lib.ptr(stages),
-            _lib.ptr(go), self.n_out, _lib.ptr(step_dt), n_steps, _lib.ptr(node_ptr), _lib.ptr(node_out),
+            _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w), _lib.ptr(bvec), self.act,
+            _lib.ptr(stages), _lib.ptr(go), self.n_out, _lib.ptr(step_dt), n_steps, _lib.ptr(node_ptr), _lib.ptr(node_out),
             _lib.ptr(node_weight), _lib.ptr(grad_z0), _lib.ptr(grad_w), _lib.ptr(grad_b), self.B, self.C, self.H,
             _lib.dtype_enum(self.dtype), _lib.ptr(self.stage_index), _lib.ptr(self.stage_frac), _lib.ptr(workspace),
             workspace.numel(), _lib.stream_ptr(self.device)), "cde_rk4_backprop_linear")
@@ -767,14 +768,14 @@ class _FusedRK4Backprop(torch.autograd.Function):
     def forward(ctx, z0, weight, bias, plan):
         out, stages = plan.run_forward_stages(z0, weight, bias)
         ctx.plan = plan
-        ctx.save_for_backward(weight, stages)
+        ctx.save_for_backward(weight, bias, stages)
         return out.reshape(*plan.batch, plan.n_out, plan.H)
 
     @staticmethod
     def backward(ctx, grad_out):
         plan = ctx.plan
-        weight, stages = ctx.saved_tensors
-        grad_z0, grad_w, grad_b = plan.run_backprop(stages, grad_out, weight)
+        weight, bias, stages = ctx.saved_tensors
+        grad_z0, grad_w, grad_b = plan.run_backprop(stages, grad_out, weight, bias)
         return (grad_z0.reshape(*plan.batch, plan.H) if ctx.needs_input_grad[0] else None,
                 grad_w.view_as(weight) if ctx.needs_input_grad[1] else None,
                 grad_b if ctx.needs_input_grad[2] else None, None)
@@ -1486,9 +1487,10 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         adjoint_method_ok=adjoint_method in (None, method), options_ok=options_ok,
         adjoint_options_ok=adjoint_options_ok, t_ok=bool(increasing) or not t_is_vector,
         variant_generic=variant == _lib.VARIANT_GENERIC, shared=step_control() is not None, narrow_control=C <= 8,
-        backprop_ok=bool(((mfma_shape and field.act == _lib.ACT_NONE and variant in (_lib.VARIANT_AUTO, _lib.VARIANT_MFMA))
+        backprop_ok=bool(((mfma_shape and variant in (_lib.VARIANT_AUTO, _lib.VARIANT_MFMA))
                           or (mlp is not None and variant == _lib.VARIANT_AUTO))
-                         and not any(b.requires_grad for b in X.buffers())))
+                         and not any(b.requires_grad for b in X.buffers())),
+        identity=bool(field is not None and field.act == _lib.ACT_NONE))
     if recognised_kind is not None and known is None:
         # the probe recognised the formula but the shape / dtype is beyond the tiles: say so in the record and the warning
         request = request._replace(kind=recognised_kind, tiles_ok=False)

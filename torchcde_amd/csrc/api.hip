@@ -71,13 +71,13 @@ int launch_adjoint_jacobian_pair(const void*, const void*, int64_t, int, const v
                                  const int64_t*, const void*, float*, hipStream_t, int method);
 // K2 with the stage states stored (rk4_mfma.hip) and the reverse-mode sweep over them (rk4_backprop.hip): adjoint=False
 template <typename TT>
-int launch_forward_mfma_stages(const void*, const void*, int64_t, int, const void*, const void*, const void*, const void*,
+int launch_forward_mfma_stages(const void*, const void*, int64_t, int, const void*, const void*, int, const void*, const void*,
                                int64_t, const void*, int64_t, void*, void*, int64_t, int64_t, int64_t, const int64_t*,
                                const void*, hipStream_t);
 size_t backprop_workspace_bytes(int64_t B);
-int launch_backprop_jacobian(const void*, const void*, int64_t, int, const void*, const void*, const void*, int64_t,
-                             const float*, int64_t, const int64_t*, const int64_t*, const float*, void*, void*, void*, int64_t,
-                             int64_t, int64_t, const int64_t*, const float*, float*, hipStream_t);
+int launch_backprop_jacobian(const void*, const void*, int64_t, int, const void*, const void*, int, const void*, const void*,
+                             int64_t, const float*, int64_t, const int64_t*, const int64_t*, const float*, void*, void*, void*,
+                             int64_t, int64_t, int64_t, const int64_t*, const float*, float*, hipStream_t);
 // from rk4_bf16x3.hip
 template <typename TT>
 int launch_forward_bf16x3(const void*, const void*, int64_t, int, const void*, const void*, const void*, const void*, int64_t,
@@ -474,17 +474,17 @@ extern "C" int cde_fixed_adjoint_linear(int method, const void* coeffs, const vo
 
 // ---------------------------------------------------------------------------------------------- K3d (adjoint=False)
 extern "C" int cde_rk4_backprop_supported(int64_t C, int64_t H, int dtype, int act) {
-  return (dtype == CDE_F32 && act == CDE_ACT_NONE && cde::mfma_applicable(C, H, dtype, act, true)) ? 1 : 0;
+  return (dtype == CDE_F32 && (act == CDE_ACT_NONE || act == CDE_ACT_TANH) && cde::mfma_applicable(C, H, dtype, act, true)) ? 1 : 0;
 }
 
 extern "C" int cde_rk4_forward_linear_stages(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
-                                             const void* W, const void* bias, const void* z0, const void* grid,
+                                             const void* W, const void* bias, int act, const void* z0, const void* grid,
                                              int64_t n_grid, const void* t_out, int64_t n_out, void* z_out, void* stages,
                                              int64_t B, int64_t C, int64_t H, int dtype, int time_dtype,
                                              int64_t* stage_index, void* stage_frac, void* stream) {
   if (B < 0 || C < 1 || H < 1 || n_intervals < 1 || n_grid < 1 || n_out < 1) return CDE_ERR_SHAPE;
   if (dtype != CDE_F32) return dtype == CDE_F64 ? CDE_ERR_UNSUPPORTED : CDE_ERR_DTYPE;
-  if (!cde_rk4_backprop_supported(C, H, dtype, CDE_ACT_NONE)) return CDE_ERR_UNSUPPORTED;
+  if (!cde_rk4_backprop_supported(C, H, dtype, act)) return CDE_ERR_UNSUPPORTED;
   if (B == 0) return CDE_OK;
   if (!coeffs || !knots || !W || !bias || !z0 || !grid || !t_out || !z_out) return CDE_ERR_NULL;
   if (n_grid > 1 && (!stage_index || !stage_frac || !stages)) return CDE_ERR_NULL;
@@ -493,13 +493,13 @@ extern "C" int cde_rk4_forward_linear_stages(const void* coeffs, const void* kno
   if (time_dtype == CDE_F32) {
     rc = cde::fill_stage_table<float, float>(knots, n_intervals, grid, n_grid - 1, 0, stage_index, stage_frac, s);
     if (rc != CDE_OK) return rc;
-    return cde::launch_forward_mfma_stages<float>(coeffs, knots, n_intervals, degree, W, bias, z0, grid, n_grid, t_out, n_out,
-                                                  z_out, stages, B, C, H, stage_index, stage_frac, s);
+    return cde::launch_forward_mfma_stages<float>(coeffs, knots, n_intervals, degree, W, bias, act, z0, grid, n_grid, t_out,
+                                                  n_out, z_out, stages, B, C, H, stage_index, stage_frac, s);
   }
   if (time_dtype == CDE_F64) {
     rc = cde::fill_stage_table<float, double>(knots, n_intervals, grid, n_grid - 1, 0, stage_index, stage_frac, s);
     if (rc != CDE_OK) return rc;
-    return cde::launch_forward_mfma_stages<double>(coeffs, knots, n_intervals, degree, W, bias, z0, grid, n_grid, t_out,
+    return cde::launch_forward_mfma_stages<double>(coeffs, knots, n_intervals, degree, W, bias, act, z0, grid, n_grid, t_out,
                                                    n_out, z_out, stages, B, C, H, stage_index, stage_frac, s);
   }
   return CDE_ERR_DTYPE;
@@ -508,7 +508,8 @@ extern "C" int cde_rk4_forward_linear_stages(const void* coeffs, const void* kno
 extern "C" size_t cde_rk4_backprop_workspace_bytes(int64_t B) { return B > 0 ? cde::backprop_workspace_bytes(B) : 0; }
 
 extern "C" int cde_rk4_backprop_linear(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
-                                       const void* W, const void* stages, const void* grad_out, int64_t n_out,
+                                       const void* W, const void* bias, int act, const void* stages, const void* grad_out,
+                                       int64_t n_out,
                                        const float* step_dt, int64_t n_steps, const int64_t* node_ptr,
                                        const int64_t* node_out, const float* node_weight, void* grad_z0, void* grad_W,
                                        void* grad_b, int64_t B, int64_t C, int64_t H, int dtype,
@@ -516,13 +517,13 @@ extern "C" int cde_rk4_backprop_linear(const void* coeffs, const void* knots, in
                                        size_t workspace_bytes, void* stream) {
   if (B < 1 || C < 1 || H < 1 || n_intervals < 1 || n_out < 1 || n_steps < 0) return CDE_ERR_SHAPE;
   if (dtype != CDE_F32) return dtype == CDE_F64 ? CDE_ERR_UNSUPPORTED : CDE_ERR_DTYPE;
-  if (!cde_rk4_backprop_supported(C, H, dtype, CDE_ACT_NONE)) return CDE_ERR_UNSUPPORTED;
-  if (!coeffs || !knots || !W || !grad_out || !node_ptr || !node_out || !node_weight || !grad_z0 || !grad_W || !grad_b ||
+  if (!cde_rk4_backprop_supported(C, H, dtype, act)) return CDE_ERR_UNSUPPORTED;
+  if (!coeffs || !knots || !W || !bias || !grad_out || !node_ptr || !node_out || !node_weight || !grad_z0 || !grad_W || !grad_b ||
       !workspace)
     return CDE_ERR_NULL;
   if (n_steps > 0 && (!stages || !step_dt || !stage_index || !stage_frac)) return CDE_ERR_NULL;
   if (workspace_bytes < cde_rk4_backprop_workspace_bytes(B)) return CDE_ERR_WORKSPACE;
-  return cde::launch_backprop_jacobian(coeffs, knots, n_intervals, degree, W, stages, grad_out, n_out, step_dt, n_steps,
+  return cde::launch_backprop_jacobian(coeffs, knots, n_intervals, degree, W, bias, act, stages, grad_out, n_out, step_dt, n_steps,
                                        node_ptr, node_out, node_weight, grad_z0, grad_W, grad_b, B, C, H, stage_index,
                                        (const float*)stage_frac, (float*)workspace, (hipStream_t)stream);
 }

@@ -56,6 +56,249 @@ __device__ __forceinline__ float bp_wj_image(const float* __restrict__ W, int h,
   return (c < d.C && k < d.H && h < d.H) ? W[(h * d.C + c) * d.H + k] : 0.f;
 }
 
+// ---- the tanh field, f = reshape(tanh(W z + b)) dX (example/irregular_data.py:36-46): no shared Jacobian -- the activation
+// sits between the GEMM and the contraction -- so a stage is K3a's (rk4_mfma.hip: rk4_adjoint_act_mfma): per tile T of four
+// hidden units the pre-activation Y_T = W_T s_i + b_T (16 MFMAs), g = kb_h dX_c (1 - tanh^2) in-lane, v += W_T^T g
+// (16 MFMAs), dL/dW_T += g^T s_i with the batch as MFMA K through a transposed scratch tile (16 MFMAs).
+constexpr int BP_WV32_FLOATS = 8 * 16 * 64;          // one 32x32x2 image: 8 tiles x 16 K steps x 64 lanes
+constexpr int BP_BY32_FLOATS = 8 * 2 * 16;           // bias image [tile][half][register]
+constexpr int BP_SCRA_FLOATS = 2 * 64 * 20;          // per wave: z^T and one transposed g tile
+constexpr int BP_ACT_LDS_FLOATS = 2 * BP_WV32_FLOATS + BP_BY32_FLOATS + 4 * BP_SCRA_FLOATS;
+__device__ __forceinline__ float bp_wy32_image(const float* __restrict__ W, int T, int s, int l, Dims d) {
+  const int i = l & 31, hk = l >> 5;
+  const int h = 4 * T + (i >> 3), c = i & 7, k = 2 * s + hk;
+  return (h < d.H && c < d.C && k < d.H) ? W[(h * d.C + c) * d.H + k] : 0.f;
+}
+__device__ __forceinline__ float bp_wv32_image(const float* __restrict__ W, int T, int r, int l, Dims d) {
+  const int k = rho(l & 31), hk = l >> 5;
+  const int h = 4 * T + (r >> 2), c = (r & 3) + 4 * hk;
+  return (h < d.H && c < d.C && k < d.H) ? W[(h * d.C + c) * d.H + k] : 0.f;
+}
+
+template <int DEGREE>
+__global__ __launch_bounds__(256, 1) void rk4_backprop_act(
+    const float* __restrict__ coeffs, const float* __restrict__ knots, int64_t n_intervals,
+    const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ stages,
+    const float* __restrict__ grad_out, int64_t n_out, const float* __restrict__ step_dt, int64_t n_steps,
+    const int64_t* __restrict__ node_ptr, const int64_t* __restrict__ node_out, const float* __restrict__ node_weight,
+    float* __restrict__ grad_z0, float* __restrict__ partial, int64_t B, const int64_t* __restrict__ stage_index,
+    const float* __restrict__ stage_frac, Dims dims) {
+  constexpr int ACT = CDE_ACT_TANH;
+  const int Hr = dims.H, Cr = dims.C;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* wyf = lds;
+  float* wvf = lds + BP_WV32_FLOATS;
+  float* byf = lds + 2 * BP_WV32_FLOATS;
+  for (int e = threadIdx.x; e < BP_WV32_FLOATS; e += 256) {
+    const int j = e & 3, l = (e >> 2) & 63, g = e >> 8;             // g = 4T + (step >> 2)
+    wyf[e] = bp_wy32_image(W, g >> 2, 4 * (g & 3) + j, l, dims);
+    wvf[e] = bp_wv32_image(W, g >> 2, 4 * (g & 3) + j, l, dims);
+  }
+  for (int e = threadIdx.x; e < BP_BY32_FLOATS; e += 256) {
+    const int r = e & 15, hf = (e >> 4) & 1, T = e >> 5;
+    const int h = 4 * T + (r >> 2), c = (r & 3) + 4 * hf;
+    byf[e] = (h < Hr && c < Cr) ? bias[h * Cr + c] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 31, half = lane >> 5;
+  const float4* wy = reinterpret_cast<const float4*>(wyf) + lane;
+  const float4* wv = reinterpret_cast<const float4*>(wvf) + lane;
+  const float4* by = reinterpret_cast<const float4*>(byf) + 4 * half;
+  float* scr_zt = lds + 2 * BP_WV32_FLOATS + BP_BY32_FLOATS + wave * BP_SCRA_FLOATS;   // 64 rows x 20
+  float* scr_g = scr_zt + 64 * 20;                                                     // 64 rows x 20
+
+  const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  float* my_partial = partial + tile * BP_PARTIAL_FLOATS;
+  if (tile * 32 >= B) return;
+  const int64_t series = tile * 32 + n;
+  const bool valid = series < B;
+  const int64_t sc = valid ? series : B - 1;
+
+  f32x16 accW[8];
+  float gb[8];
+#pragma unroll
+  for (int T = 0; T < 8; ++T) {
+    gb[T] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accW[T][r] = 0.f;
+  }
+  auto add_outputs = [&](int64_t m, f32x16& g) {
+    for (int64_t e = node_ptr[m]; e < node_ptr[m + 1]; ++e) {
+      const int64_t j = node_out[e];
+      const float wgt = node_weight[e];
+      if (valid) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int u = 2 * r + half;
+          if (u < Hr) g[r] = __builtin_fmaf(wgt, grad_out[(sc * n_out + j) * Hr + u], g[r]);
+        }
+      }
+    }
+  };
+  f32x16 gy;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) gy[r] = 0.f;
+  add_outputs(n_steps, gy);
+
+  if (n_steps > 0) {
+    int64_t idx = stage_index[4 * n_steps - 1];
+    float frac = stage_frac[4 * n_steps - 1];
+    Row<DEGREE> row = load_row<DEGREE>(coeffs, sc, n_intervals, idx, Cr);
+    const float* srow = stages + (sc * n_steps * 4) * 32;                   // + (4 k + stage) * 32: plain unit order
+    for (int64_t k = n_steps - 1; k >= 0; --k) {
+      const float dt = step_dt[k];
+      const float third = (float)(1.0 / 3.0);
+      const float c8 = dt * 0.125f, dt3 = dt * third;
+      f32x16 kb1 = gy * c8, kb2 = gy * (3.f * c8), kb3 = kb2, kbc = kb1;
+      f32x16 yb = gy;
+#pragma unroll
+      for (int stage = 3; stage >= 0; --stage) {
+        float dX[MC];
+        const float width = DEGREE == CDE_PATH_LINEAR ? knots[idx + 1] - knots[idx] : 1.f;
+        control_slope<DEGREE>(row, frac, width, dX);
+        f32x16 sst;                                   // the stored stage state: units 2r + half of the plain-order row
+        {
+          const float* sp = srow + (4 * k + stage) * 32 + half;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sst[r] = sp[2 * r];
+        }
+        const int64_t e_next = 4 * k + stage - 1;
+        const bool more = e_next >= 0;
+        const int64_t nidx = more ? stage_index[e_next] : idx;
+        const float nfrac = more ? stage_frac[e_next] : frac;
+        if (nidx != idx) row = load_row<DEGREE>(coeffs, sc, n_intervals, nidx, Cr);
+        const float dh[4] = {half ? dX[4] : dX[0], half ? dX[5] : dX[1], half ? dX[6] : dX[2], half ? dX[7] : dX[3]};
+
+        // z^T for the dL/dW products: scr_zt[(par*32 + u)*20 + s] = s_i's unit u of series 2s+par
+        {
+          float* wz = scr_zt + ((n & 1) * 32 + half) * 20 + (n >> 1);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) wz[r * 40] = sst[r];
+          bp_wave_lds_sync();
+        }
+        float zB[16];
+        {
+          const float4* zt4 = reinterpret_cast<const float4*>(scr_zt + (half * 32 + n) * 20);
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 v4 = zt4[g4];
+            zB[4 * g4] = v4.x; zB[4 * g4 + 1] = v4.y; zB[4 * g4 + 2] = v4.z; zB[4 * g4 + 3] = v4.w;
+          }
+        }
+        f32x16 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int opaque = 0;
+        asm volatile("" : "+v"(opaque));          // keeps the image reads inside the stage (no hoisting)
+        const float4* wys = wy + opaque;
+        const float4* wvs = wv + opaque;
+        const float4* bys = by + opaque;
+#pragma unroll
+        for (int T = 0; T < 8; ++T) {
+          // ---- Y tile
+          f32x16 y;
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 b4 = bys[T * 8 + g4];
+            y[4 * g4] = b4.x; y[4 * g4 + 1] = b4.y; y[4 * g4 + 2] = b4.z; y[4 * g4 + 3] = b4.w;
+          }
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 a4 = wys[(4 * T + g4) * 64];
+            y = mfma(a4.x, sst[4 * g4], y);
+            y = mfma(a4.y, sst[4 * g4 + 1], y);
+            y = mfma(a4.z, sst[4 * g4 + 2], y);
+            y = mfma(a4.w, sst[4 * g4 + 3], y);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          // ---- activation, dL/dY: kb of units 4T..4T+3 in every lane (swap32 of two copies broadcasts both halves' values)
+          float ae0 = kbc[2 * T], ao0 = kbc[2 * T], ae1 = kbc[2 * T + 1], ao1 = kbc[2 * T + 1];
+          bp_swap32(ae0, ao0);
+          bp_swap32(ae1, ao1);
+          const float a4u[4] = {ae0, ao0, ae1, ao1};
+          float g[16];
+#pragma unroll
+          for (int hl = 0; hl < 4; ++hl) {
+            const f32x2 tp[2] = {activate2<ACT>(y[4 * hl], y[4 * hl + 1]), activate2<ACT>(y[4 * hl + 2], y[4 * hl + 3])};
+#pragma unroll
+            for (int cl = 0; cl < 4; ++cl) {
+              const float t = tp[cl >> 1][cl & 1];
+              g[4 * hl + cl] = a4u[hl] * (dh[cl] * __builtin_fmaf(-t, t, 1.f));
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          // ---- v += W_T^T g
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 a4 = wvs[(4 * T + g4) * 64];
+            v = mfma(a4.x, g[4 * g4], v);
+            v = mfma(a4.y, g[4 * g4 + 1], v);
+            v = mfma(a4.z, g[4 * g4 + 2], v);
+            v = mfma(a4.w, g[4 * g4 + 3], v);
+          }
+          // ---- dW_T += g^T s_i through the transposed scratch tile
+          {
+            float* wg = scr_g + ((n & 1) * 32 + 4 * half) * 20 + (n >> 1);     // + row(r) * 20, row = (r&3) + 8*(r>>2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wg[((r & 3) + 8 * (r >> 2)) * 20] = g[r];
+            bp_wave_lds_sync();
+            const float4* g4p = reinterpret_cast<const float4*>(scr_g + (half * 32 + n) * 20);
+            float gA[16];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              const float4 v4 = g4p[g4];
+              gA[4 * g4] = v4.x; gA[4 * g4 + 1] = v4.y; gA[4 * g4 + 2] = v4.z; gA[4 * g4 + 3] = v4.w;
+            }
+            bp_wave_lds_sync();                    // reads retired before the next tile overwrites the scratch
+            float rs = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) {
+              accW[T] = mfma(gA[s2], zB[s2], accW[T]);
+              rs += gA[s2];
+            }
+            gb[T] += rs;
+          }
+          __builtin_amdgcn_sched_barrier(0);       // one tile at a time: bounds the live registers
+        }
+
+        // ---- reverse-mode bookkeeping of the 3/8 rule (see the file header)
+        yb = yb + v;
+        if (stage == 3) {
+          kb1 = kb1 + dt * v;
+          kb2 = kb2 - dt * v;
+          kb3 = kb3 + dt * v;
+          kbc = kb3;
+        } else if (stage == 2) {
+          kb2 = kb2 + dt * v;
+          kb1 = kb1 - dt3 * v;
+          kbc = kb2;
+        } else if (stage == 1) {
+          kb1 = kb1 + dt3 * v;
+          kbc = kb1;
+        }
+        idx = nidx; frac = nfrac;
+      }
+      gy = yb;
+      add_outputs(k, gy);
+    }
+  }
+  if (valid) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) if (2 * r + half < Hr) grad_z0[series * Hr + 2 * r + half] = gy[r];
+  }
+  // per-wave partials in the K3 layout: tile T register r of lane (n, half) is dW[h = 4T + (r>>2)][c = (r&3) + 4 half][k = n]
+#pragma unroll
+  for (int T = 0; T < 8; ++T) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int h = 4 * T + (r >> 2), c = (r & 3) + 4 * half;
+      my_partial[(h * MC + c) * MH + n] = accW[T][r];
+    }
+    // row sums: lane (i = n, half) summed row i = (h = 4T + (n>>3), c = n&7) over the series of its parity
+    const float other = __shfl_xor(gb[T], 32, 64);
+    if (half == 0) my_partial[MH * MC * MH + 32 * T + n] = gb[T] + other;
+  }
+}
+
 template <int DEGREE>
 __global__ __launch_bounds__(256, 1) void rk4_backprop_jacobian(
     const float* __restrict__ coeffs, const float* __restrict__ knots, int64_t n_intervals,
@@ -293,12 +536,33 @@ __global__ __launch_bounds__(256, 1) void rk4_backprop_jacobian(
 size_t backprop_workspace_bytes(int64_t B) { return mfma_adjoint_partial_bytes(B); }
 
 int launch_backprop_jacobian(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
-                             const void* stages, const void* grad_out, int64_t n_out, const float* step_dt, int64_t n_steps,
+                             const void* bias, int act, const void* stages, const void* grad_out, int64_t n_out,
+                             const float* step_dt, int64_t n_steps,
                              const int64_t* node_ptr, const int64_t* node_out, const float* node_weight, void* grad_z0,
                              void* grad_W, void* grad_b, int64_t B, int64_t C, int64_t H, const int64_t* stage_index,
                              const float* stage_frac, float* partial, hipStream_t s) {
   const Dims dims{(int)H, (int)C};
   const unsigned blocks = (unsigned)((B + 127) / 128);
+  if (act == CDE_ACT_TANH) {
+    const size_t lds_act = (size_t)BP_ACT_LDS_FLOATS * sizeof(float);
+#define CDE_BPA(D)                                                                                                   \
+  do {                                                                                                               \
+    (void)hipFuncSetAttribute((const void*)rk4_backprop_act<D>, hipFuncAttributeMaxDynamicSharedMemorySize,          \
+                              (int)lds_act);                                                                         \
+    rk4_backprop_act<D><<<blocks, 256, lds_act, s>>>(                                                                \
+        (const float*)coeffs, (const float*)knots, n_intervals, (const float*)W, (const float*)bias,                 \
+        (const float*)stages, (const float*)grad_out, n_out, step_dt, n_steps, node_ptr, node_out, node_weight,      \
+        (float*)grad_z0, partial, B, stage_index, stage_frac, dims);                                                 \
+  } while (0)
+    if (degree == CDE_PATH_CUBIC) CDE_BPA(CDE_PATH_CUBIC);
+    else if (degree == CDE_PATH_LINEAR) CDE_BPA(CDE_PATH_LINEAR);
+    else return CDE_ERR_UNSUPPORTED;
+#undef CDE_BPA
+    const int rca = check_launch();
+    if (rca != CDE_OK) return rca;
+    return launch_reduce_partials(partial, (B + 31) / 32, grad_W, grad_b, (int)H, (int)C, s);
+  }
+  if (act != CDE_ACT_NONE) return CDE_ERR_UNSUPPORTED;
   const size_t lds = (size_t)(BP_WJ_FLOATS + 4 * SCR_FLOATS) * sizeof(float);
 #define CDE_BP(D)                                                                                                    \
   do {                                                                                                               \

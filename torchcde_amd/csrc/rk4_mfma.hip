@@ -78,7 +78,7 @@ __global__ __launch_bounds__((fwd_block_threads<ACT, MLP>()), (fwd_waves_per_sim
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // the A-operand image is loop invariant: staged once through LDS, then it lives in registers
   constexpr bool PRODUCT = ACT == CDE_ACT_NONE && !MLP;
-  static_assert(!SAVE || (PRODUCT && CT == MC) || (MLP && !SPLIT), "stage states: the affine field's kernel, the two-layer field's one-wave form");
+  static_assert(!SAVE || (!MLP && CT == MC) || (MLP && !SPLIT), "stage states: the one-layer fields' kernel, the two-layer field's one-wave form");
   static_assert(METHOD == CDE_METHOD_RK4 || !SAVE, "stage states are stored for the 3/8 rule only");
   constexpr int NS = METHOD == CDE_METHOD_RK4 ? 4 : METHOD == CDE_METHOD_MIDPOINT ? 2 : 1;     // stages per step
   constexpr int STRIDE = PRODUCT ? 1 : 4;          // distance between a lane's consecutive hidden units
@@ -152,7 +152,7 @@ __global__ __launch_bounds__((fwd_block_threads<ACT, MLP>()), (fwd_waves_per_sim
           if constexpr (PRODUCT) {           // K3's lane order: evens, then odds
             *reinterpret_cast<float4*>(srow + 4 * q) = make_float4(za[0], za[2], zb[0], zb[2]);          // units 8q, 8q+2, ..
             *reinterpret_cast<float4*>(srow + 16 + 4 * q) = make_float4(za[1], za[3], zb[1], zb[3]);     // units 8q+1, 8q+3, ..
-          } else {                           // two-layer field: plain unit order (the lane owns units q, 4+q, .., 28+q)
+          } else {                           // tanh / two-layer field: plain unit order (the lane owns units q, 4+q, .., 28+q)
 #pragma unroll
             for (int i = 0; i < 4; ++i) { srow[q + 4 * i] = za[i]; srow[16 + q + 4 * i] = zb[i]; }
           }
@@ -1230,29 +1230,33 @@ int launch_forward_mlp(const void* coeffs, const void* knots, int64_t n_interval
 // K2 with the stage states stored (adjoint=False backward: rk4_backprop.hip).  Affine field, f32, H <= 32, C <= 8.
 template <typename TT>
 int launch_forward_mfma_stages(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
-                               const void* bias, const void* z0, const void* grid, int64_t n_grid, const void* t_out,
+                               const void* bias, int act, const void* z0, const void* grid, int64_t n_grid, const void* t_out,
                                int64_t n_out, void* z_out, void* stages, int64_t B, int64_t C, int64_t H,
                                const int64_t* stage_index, const void* stage_frac, hipStream_t s) {
   const Dims dims{(int)H, (int)C};
   constexpr int threads = fwd_block_threads<CDE_ACT_NONE, false>();
-#define CDE_FWD_S(D)                                                                                                  \
-  rk4_forward_mfma<TT, D, CDE_ACT_NONE, false, MC, false, true>                                                       \
-      <<<(unsigned)((B + threads / 4 - 1) / (threads / 4)), threads, W16_FLOATS * sizeof(float), s>>>(                \
+#define CDE_FWD_S(D, A)                                                                                               \
+  rk4_forward_mfma<TT, D, A, false, MC, false, true>                                                                  \
+      <<<(unsigned)((B + threads / 4 - 1) / (threads / 4)), threads,                                                  \
+         (A == CDE_ACT_NONE ? W16_FLOATS : ACT16_LDS_FLOATS) * sizeof(float), s>>>(                                   \
           (const float*)coeffs, (const float*)knots, n_intervals, (const float*)W, (const float*)bias,                \
           (const float*)z0, (const TT*)grid, n_grid, (const TT*)t_out, n_out, (float*)z_out, B, stage_index,          \
           (const float*)stage_frac, dims, nullptr, nullptr, 0, (float*)stages)
-  if (degree == CDE_PATH_CUBIC) CDE_FWD_S(CDE_PATH_CUBIC);
-  else if (degree == CDE_PATH_LINEAR) CDE_FWD_S(CDE_PATH_LINEAR);
-  else return CDE_ERR_UNSUPPORTED;
+  if (degree != CDE_PATH_CUBIC && degree != CDE_PATH_LINEAR) return CDE_ERR_UNSUPPORTED;
+  if (act == CDE_ACT_NONE) {
+    if (degree == CDE_PATH_CUBIC) CDE_FWD_S(CDE_PATH_CUBIC, CDE_ACT_NONE); else CDE_FWD_S(CDE_PATH_LINEAR, CDE_ACT_NONE);
+  } else if (act == CDE_ACT_TANH) {
+    if (degree == CDE_PATH_CUBIC) CDE_FWD_S(CDE_PATH_CUBIC, CDE_ACT_TANH); else CDE_FWD_S(CDE_PATH_LINEAR, CDE_ACT_TANH);
+  } else return CDE_ERR_UNSUPPORTED;
 #undef CDE_FWD_S
   return check_launch();
 }
-template int launch_forward_mfma_stages<float>(const void*, const void*, int64_t, int, const void*, const void*, const void*,
-                                               const void*, int64_t, const void*, int64_t, void*, void*, int64_t, int64_t,
-                                               int64_t, const int64_t*, const void*, hipStream_t);
-template int launch_forward_mfma_stages<double>(const void*, const void*, int64_t, int, const void*, const void*, const void*,
-                                                const void*, int64_t, const void*, int64_t, void*, void*, int64_t, int64_t,
-                                                int64_t, const int64_t*, const void*, hipStream_t);
+template int launch_forward_mfma_stages<float>(const void*, const void*, int64_t, int, const void*, const void*, int,
+                                               const void*, const void*, int64_t, const void*, int64_t, void*, void*, int64_t,
+                                               int64_t, int64_t, const int64_t*, const void*, hipStream_t);
+template int launch_forward_mfma_stages<double>(const void*, const void*, int64_t, int, const void*, const void*, int,
+                                                const void*, const void*, int64_t, const void*, int64_t, void*, void*, int64_t,
+                                                int64_t, int64_t, const int64_t*, const void*, hipStream_t);
 
 // K2m with the stage states stored (adjoint=False backward of the two-layer field): the one-wave-per-tile form at any batch
 template <typename TT>

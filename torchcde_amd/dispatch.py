@@ -32,9 +32,10 @@ Request = collections.namedtuple("Request", [
     "variant_generic",   # variant="generic" (tests: the independent kernels / the step-wise reference path)
     "shared",            # torchcde_amd.distributed.shared_step_control is active
     "narrow_control",    # the control has at most 8 channels (control gradients of a two-layer field)
-    "backprop_ok",       # affine: the plain benchmark field (identity activation, 32 x 8 tiles, float32); mlp2: the field fits
-                         # the two-layer tiles; and no control tensor requires a gradient -- what the reverse-mode sweeps
-                         # (adjoint=False) and, for the affine field, the midpoint / euler forms of K2 / K3p take
+    "backprop_ok",       # affine: the field sits on the 32 x 8 tiles (float32, identity or tanh); mlp2: it fits the two-layer
+                         # tiles; and no control tensor requires a gradient -- what the reverse-mode sweeps (adjoint=False) take
+    "identity",          # affine field without an activation (the README's): with backprop_ok, what the midpoint / euler forms
+                         # of K2 / K3p take
 ])
 
 Choice = collections.namedtuple("Choice", ["path", "reason"])
@@ -71,7 +72,8 @@ def select_path(q):
     if q.method in ("midpoint", "euler"):
         # torchdiffeq's other fixed-grid methods (reference test/test_cdeint.py:49-63): K2 / K3p with two stages / one per step
         grads_ok = not q.wants_grad or (q.adjoint and q.adjoint_method_ok and q.adjoint_options_ok and q.params != "foreign")
-        if q.kind == "affine" and q.backprop_ok and q.options_ok and not q.wants_t and not q.wants_control and grads_ok:
+        if (q.kind == "affine" and q.identity and q.backprop_ok and q.options_ok and not q.wants_t and not q.wants_control
+                and grads_ok):
             return Choice("fixed_grid", "")
         return _stepwise("method %r is fused for the identity-activation affine field on the 32 x 8 tiles only (float32, "
                          "adjoint=True, no time / control gradients)" % (q.method,))
@@ -81,7 +83,7 @@ def select_path(q):
         if q.backprop_ok and q.method == "rk4" and q.options_ok and not q.wants_t:
             return Choice("rk4_backprop" if q.kind == "affine" else "mlp_rk4_backprop", "")
         return _stepwise("adjoint=False with gradients: backpropagation through the solver's own operations (fused under rk4 "
-                         "for the identity-activation affine field on the 32 x 8 tiles and for the two-layer field)")
+                         "for the one-layer fields on the 32 x 8 tiles and for the two-layer field)")
     if not q.options_ok:
         return _stepwise("solver options outside the fused kernels' set")
     if q.wants_grad and not q.adjoint_method_ok:
