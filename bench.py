@@ -162,7 +162,7 @@ def cpu_baseline(max_sample, budget_s=20.0):
             "sample": "oracle (torch-CPU restatement of reference CubicSpline + _VectorField + torchdiffeq rk4/"
                       "adjoint) on %d of the %d series, L=%d, fwd+adjoint: 1 warm-up + 3 timed runs, median %.2f s "
                       "(min %.2f s), the fastest of {8,16,32,64} threads (%d cores available); container-side figure "
-                      "with the reference's own CubicSpline/_VectorField classes: profiles/r02_cpu_reference_container"
+                      "with the reference's own CubicSpline/_VectorField classes: profiles/r05_cpu_reference_container"
                       ".json" % (sample, B, L, times[1], times[0], avail)}
 
 
