@@ -936,8 +936,8 @@ class _Dopri5Plan:
         carry = None
         if want_t:
             off = lib.cde_dopri5_adjoint_carry_offset(B, C, H)
+            workspace[off:off + 256].zero_()                          # the whole carry block (the kernel leaves it alone: bit 1)
             carry = workspace[off:off + 8].view(torch.float64)        # vjp_t, carried across the intervals on the device
-            carry.zero_()
         if want_t:
             # torchdiffeq: func_eval = func(t[i], y[i]); dLd_cur_t = func_eval . grad_y[i]; aug_state[0] -= dLd_cur_t -- the
             # field at ALL output times in one batched evaluation before the loop
@@ -1055,8 +1055,8 @@ class _Dopri5Plan:
         carry = None
         if want_t:
             off = lib.cde_dopri5_adjoint_mlp_carry_offset(B, C, H)
+            workspace[off:off + 256].zero_()
             carry = workspace[off:off + 8].view(torch.float64)
-            carry.zero_()
         if want_t:                              # torchdiffeq: aug_state[0] -= func(t[i], y[i]) . grad_y[i], all output times at once
             pre = torch.nn.functional.linear(torch.nn.functional.linear(z_saved[:, 1:], w1, b1).relu(), w2, b2)
             if self.act == _lib.ACT_TANH:
