@@ -5,7 +5,9 @@
 // exact derivative of the discrete 3/8-rule map, NOT the continuous adjoint K3j integrates: here it is computed the way
 // reverse-mode autograd would, from the stage states the forward kernel stored (rk4_forward_mfma<..., SAVE>: the state
 // handed to every one of the 4 x n_steps field evaluations, 128 B per series and evaluation), for the affine field
-// f(t, z) = J(t) z + beta(t),  J = sum_c dX_c(t) W_c  (the README's Linear(H, H*C); f32, H <= 32, C <= 8).
+// f(t, z) = J(t) z + beta(t),  J = sum_c dX_c(t) W_c  (the README's Linear(H, H*C); f32, H <= 32, C <= 8) -- and, on K3a's
+// product-form stage instead of the shared Jacobian, for its tanh variant (rk4_backprop_act below; the two-layer field's
+// reverse-mode sweep is K3m's own kernel with a BACKPROP flag, rk4_mlp_adjoint.hip).
 //
 // One RK step y1 = y0 + (k1 + 3 (k2 + k3) + k4) dt / 8 with
 //     k1 = f(t0, s1 = y0)              k2 = f(t0 + dt/3, s2 = y0 + dt k1 / 3)
