@@ -362,6 +362,19 @@ __global__ __launch_bounds__(256, 1) void rk4_backprop_jacobian(
     float frac = stage_frac[4 * n_steps - 1];
     Row<DEGREE> row = load_row<DEGREE>(coeffs, sc, n_intervals, idx, Cr);
     const float* srow = stages + (sc * n_steps * 4) * 32 + half * 16;          // + (4 k + stage) * 32
+    // the stage state the forward pass stored (this lane's 16 units: four 16-byte loads), requested ONE STAGE AHEAD: the
+    // rows stream from HBM (2.1 GB per sweep at the benchmark size) and nothing else of a stage can start before them
+    auto load_state = [&](int64_t e) {
+      f32x16 v16;
+      const float4* sp = reinterpret_cast<const float4*>(srow + e * 32);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 v = sp[i];
+        v16[4 * i] = v.x; v16[4 * i + 1] = v.y; v16[4 * i + 2] = v.z; v16[4 * i + 3] = v.w;
+      }
+      return v16;
+    };
+    f32x16 snext = load_state(4 * n_steps - 1);
     for (int64_t k = n_steps - 1; k >= 0; --k) {
       const float dt = step_dt[k];
       const float third = (float)(1.0 / 3.0);
@@ -373,19 +386,12 @@ __global__ __launch_bounds__(256, 1) void rk4_backprop_jacobian(
         float dX[MC];
         const float width = DEGREE == CDE_PATH_LINEAR ? knots[idx + 1] - knots[idx] : 1.f;
         control_slope<DEGREE>(row, frac, width, dX);
-        // the stage state the forward pass stored (this lane's 16 units: four 16-byte loads)
-        f32x16 sst;
-        {
-          const float4* sp = reinterpret_cast<const float4*>(srow + (4 * k + stage) * 32);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float4 v = sp[i];
-            sst[4 * i] = v.x; sst[4 * i + 1] = v.y; sst[4 * i + 2] = v.z; sst[4 * i + 3] = v.w;
-          }
-        }
-        // prefetch the table entry of the stage processed next (one entry down) and, if the interval changes, its row
+        const f32x16 sst = snext;
+        // prefetch the table entry of the stage processed next (one entry down), its stored state and, if the interval
+        // changes, its row
         const int64_t e_next = 4 * k + stage - 1;
         const bool more = e_next >= 0;
+        if (more) snext = load_state(e_next);
         const int64_t nidx = more ? stage_index[e_next] : idx;
         const float nfrac = more ? stage_frac[e_next] : frac;
         if (nidx != idx) row = load_row<DEGREE>(coeffs, sc, n_intervals, nidx, Cr);
