@@ -76,6 +76,7 @@ enum { CDE_METHOD_RK4 = 0, CDE_METHOD_MIDPOINT = 1, CDE_METHOD_EULER = 2 };
  * that queues the launch -- hold them fixed for the duration of a solve):
  *   CDE_K3_FORM=product | jacobian      reverse sweep of the affine field: two GEMMs against W, or the shared Jacobian (default)
  *   CDE_K3_WAVES=1 | 2                  its Jacobian form as one wave per tile (K3j) or as chain + helper wave (K3p, default)
+ *   CDE_K3D_WAVES=1 | 2                 the same two forms of the adjoint=False sweep K3d (identity activation)
  *   CDE_K2M_NO_SPLIT, CDE_K3M_NO_SPLIT, CDE_K3M_SPLIT4, CDE_K4_NO_SPLIT, CDE_K4M_NO_SPLIT, CDE_K4AM_NO_SPLIT,
  *   CDE_K4AM_SPLIT4, CDE_K4AM_WAVES=8, CDE_K4AM_NO_SMALL_REDUCE     select the other workgroup shape of a kernel family
  *   CDE_K4AM_NO_FSAL                    evaluate every first stage (bit-identical results; tests compare the two)

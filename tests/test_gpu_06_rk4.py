@@ -694,11 +694,18 @@ def test_rk4_backprop_mode_fused_against_autograd_through_the_oracle(native, B, 
     with torch.no_grad():
         plain = native.cdeint(X, func, z0.to(DEV), t_out.to(DEV), method="rk4", options=dict(step_size=step), variant="mfma")
     assert torch.equal(out.detach(), plain)
-    # run to run deterministic (fixed-order reduction of the per-wave partials)
-    func2 = LinearField(H, C, scale=0.3, seed=3).to(DEV)
-    z2 = z0.to(DEV).requires_grad_(True)
-    (native.cdeint(X, func2, z2, t_out.to(DEV), **kw) * lw.to(DEV)).sum().backward()
-    assert torch.equal(z2.grad, z.grad) and torch.equal(func2.linear.weight.grad, func.linear.weight.grad)
+    # run to run deterministic (fixed-order reduction of the per-wave partials); and the sweep's two forms -- a chain wave + a
+    # helper wave per tile (the default, rk4_adjoint_pair.hip) and one wave per tile (CDE_K3D_WAVES=1) -- agree bit for bit
+    for waves in ("2", "1"):
+        os.environ["CDE_K3D_WAVES"] = waves
+        try:
+            func2 = LinearField(H, C, scale=0.3, seed=3).to(DEV)
+            z2 = z0.to(DEV).requires_grad_(True)
+            (native.cdeint(X, func2, z2, t_out.to(DEV), **kw) * lw.to(DEV)).sum().backward()
+        finally:
+            del os.environ["CDE_K3D_WAVES"]
+        assert torch.equal(z2.grad, z.grad) and torch.equal(func2.linear.weight.grad, func.linear.weight.grad)
+        assert torch.equal(func2.linear.bias.grad, func.linear.bias.grad)
 
 
 def test_rk4_backprop_mode_requests_the_kernel_does_not_take(native):

@@ -365,7 +365,292 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_jacobian_pair(
   }
 }
 
+
+// ------------------------------------------------------------------------------------------ K3d as a pair (adjoint=False)
+// rk4_backprop.hip's reverse-mode sweep (identity-activation affine field) with the same cut: the chain wave reads the stored
+// stage state s_i, forms the 32 Jacobian rows, v_i = J_i^T kb_i on the vector pipe and the kb bookkeeping; the helper wave
+// runs dL/dW += (kb_i (x) dX_i)^T s_i one stage behind and the control derivative two stages ahead (the FORWARD stage table,
+// walked backwards; one ring: the products carry no quadrature weight).  Same arithmetic as rk4_backprop_jacobian.
+template <int DEGREE>
+__global__ __launch_bounds__(512, 2) void rk4_backprop_jacobian_pair(
+    const float* __restrict__ coeffs, const float* __restrict__ knots, int64_t n_intervals,
+    const float* __restrict__ W, const float* __restrict__ stages, const float* __restrict__ grad_out, int64_t n_out,
+    const float* __restrict__ step_dt, int64_t n_steps, const int64_t* __restrict__ node_ptr,
+    const int64_t* __restrict__ node_out, const float* __restrict__ node_weight, float* __restrict__ grad_z0,
+    float* __restrict__ partial, int64_t B, const int64_t* __restrict__ stage_index,
+    const float* __restrict__ stage_frac, Dims dims) {
+  const int Hr = dims.H, Cr = dims.C;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  for (int e = threadIdx.x; e < KP_WJ_FLOATS; e += 512) lds[e] = kp_wj_image(W, W, e >> 8, e & 3, (e >> 2) & 63, dims);   // (row 32 unused)
+  const float4* wj = reinterpret_cast<const float4*>(lds);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int slot = wave & 3;
+  const bool helper = wave >= 4;
+  const int n = lane & 31, half = lane >> 5;
+  float* tile_lds = lds + KP_WJ_FLOATS + slot * KP_TILE_FLOATS;
+  float* ring_dx = tile_lds + 2 * KP_ZA_FLOATS;                      // + (stage counter % 3) * 256: dX_c of series n at [n*8 + c]
+  const int64_t tile = (int64_t)blockIdx.x * 4 + slot;
+  const bool live = tile * 32 < B;
+  const int64_t series = tile * 32 + n;
+  const bool valid = series < B;
+  const int64_t sc = valid ? series : B - 1;
+  const int64_t n_stages = 4 * n_steps;
+
+  if (helper) {
+    f32x16 accW[MC];
+    f32x2 gbp[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+#pragma unroll
+    for (int c = 0; c < MC; ++c) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accW[c][r] = 0.f;
+    }
+    // cursor over the forward table's entries, last first; the interval index of the entry after the fetched one is requested
+    // one iteration before its row (as in the adjoint's helper)
+    int64_t cur_e = n_stages;                                       // entry whose data `fetch` takes next is cur_e - 1
+    Row<DEGREE> row;
+    int64_t row_idx = -1, idx_ahead = -1;
+    float p_frac = 0.f, p_width = 1.f;
+    bool p_ok = false;
+    auto fetch = [&]() {
+      --cur_e;
+      p_ok = cur_e >= 0;
+      if (p_ok) {
+        if (idx_ahead != row_idx) { row = load_row<DEGREE>(coeffs, sc, n_intervals, idx_ahead, Cr); row_idx = idx_ahead; }
+        p_frac = stage_frac[cur_e];
+        if (DEGREE == CDE_PATH_LINEAR) p_width = knots[idx_ahead + 1] - knots[idx_ahead];
+      }
+      if (cur_e >= 1) idx_ahead = stage_index[cur_e - 1];
+    };
+    auto publish = [&](int which) {
+      if (!p_ok) return;
+      float dX[MC];
+      control_slope<DEGREE>(row, p_frac, p_width, dX);
+      const f32x2 d0 = half ? f32x2{dX[4], dX[5]} : f32x2{dX[0], dX[1]}, d1 = half ? f32x2{dX[6], dX[7]} : f32x2{dX[2], dX[3]};
+      *reinterpret_cast<float4*>(ring_dx + which * 256 + n * 8 + 4 * half) = make_float4(d0[0], d0[1], d1[0], d1[1]);
+    };
+    if (n_stages > 0) idx_ahead = stage_index[n_stages - 1];
+    fetch(); publish(0);
+    fetch(); publish(1);
+    fetch();
+    __syncthreads();
+    int par = 0, rs = 0;
+    for (int64_t st = 0; st < n_stages; ++st) {
+      kp_stage_barrier();
+      // dL/dW of stage st first (its ring slot is rs), THEN stage st + 2's derivative into slot (st + 2) % 3 -- one ring
+      // serves the chain wave and this wave, so the slot this stage reads must not be the one written: (st + 2) % 3 != st % 3
+      publish(rs >= 1 ? rs - 1 : 2);
+      fetch();
+      const float* base = tile_lds + par * KP_ZA_FLOATS;
+      const float4* zt4 = reinterpret_cast<const float4*>(base + (half * 32 + n) * 20);
+      const float4* at4 = reinterpret_cast<const float4*>(base + 64 * 20 + (half * 32 + n) * 20);
+      const float4* dw4 = reinterpret_cast<const float4*>(ring_dx + rs * 256 + half * 8);
+      float4 zq = zt4[0], aq = at4[0], e0 = dw4[0], e1 = dw4[1];
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) {
+        const int i = s2 & 3;
+        const f32x2 e01 = {e0.x, e0.y}, e23 = {e0.z, e0.w}, e45 = {e1.x, e1.y}, e67 = {e1.z, e1.w};
+        const f32x2 asrc = i < 2 ? f32x2{aq.x, aq.y} : f32x2{aq.z, aq.w};
+        const float zb = i == 0 ? zq.x : i == 1 ? zq.y : i == 2 ? zq.z : zq.w;
+        f32x2 v01, v23, v45, v67;
+        if (i & 1) {
+          v01 = pk_mul_hi(e01, asrc); v23 = pk_mul_hi(e23, asrc); v45 = pk_mul_hi(e45, asrc); v67 = pk_mul_hi(e67, asrc);
+          pk_fma_hi(gbp[0], e01, asrc); pk_fma_hi(gbp[1], e23, asrc); pk_fma_hi(gbp[2], e45, asrc); pk_fma_hi(gbp[3], e67, asrc);
+        } else {
+          v01 = pk_mul_lo(e01, asrc); v23 = pk_mul_lo(e23, asrc); v45 = pk_mul_lo(e45, asrc); v67 = pk_mul_lo(e67, asrc);
+          pk_fma_lo(gbp[0], e01, asrc); pk_fma_lo(gbp[1], e23, asrc); pk_fma_lo(gbp[2], e45, asrc); pk_fma_lo(gbp[3], e67, asrc);
+        }
+        if (s2 < 15) {
+          e0 = dw4[(s2 + 1) * 4]; e1 = dw4[(s2 + 1) * 4 + 1];
+          if (i == 3) { zq = zt4[(s2 + 1) >> 2]; aq = at4[(s2 + 1) >> 2]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        accW[0] = mfma(v01[0], zb, accW[0]); accW[1] = mfma(v01[1], zb, accW[1]);
+        accW[2] = mfma(v23[0], zb, accW[2]); accW[3] = mfma(v23[1], zb, accW[3]);
+        accW[4] = mfma(v45[0], zb, accW[4]); accW[5] = mfma(v45[1], zb, accW[5]);
+        accW[6] = mfma(v67[0], zb, accW[6]); accW[7] = mfma(v67[1], zb, accW[7]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      par ^= 1;
+      rs = rs == 2 ? 0 : rs + 1;
+    }
+    if (live) {
+      float* my_partial = partial + tile * KP_PARTIAL_FLOATS;
+#pragma unroll
+      for (int c = 0; c < MC; ++c) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int h = (r & 3) + 8 * (r >> 2) + 4 * half;
+          my_partial[(h * MC + c) * MH + n] = accW[c][r];
+        }
+        const float mine_gb = gbp[c >> 1][c & 1];
+        const float other = __shfl_xor(mine_gb, 32, 64);
+        if (half == 0) my_partial[MH * MC * MH + n * MC + c] = mine_gb + other;
+      }
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------------------------------- chain wave
+  __builtin_amdgcn_s_setprio(3);
+  auto add_outputs = [&](int64_t m, f32x16& g) {
+    for (int64_t e = node_ptr[m]; e < node_ptr[m + 1]; ++e) {
+      const int64_t j = node_out[e];
+      const float wgt = node_weight[e];
+      if (valid) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int u = 2 * r + half;
+          if (u < Hr) g[r] = __builtin_fmaf(wgt, grad_out[(sc * n_out + j) * Hr + u], g[r]);
+        }
+      }
+    }
+  };
+  f32x16 gy;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) gy[r] = 0.f;
+  add_outputs(n_steps, gy);
+  const float* srow = stages + (sc * n_steps * 4) * 32 + half * 16;
+  auto load_state = [&](int64_t e) {
+    f32x16 v16;
+    const float4* sp = reinterpret_cast<const float4*>(srow + e * 32);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 v = sp[i];
+      v16[4 * i] = v.x; v16[4 * i + 1] = v.y; v16[4 * i + 2] = v.z; v16[4 * i + 3] = v.w;
+    }
+    return v16;
+  };
+  f32x16 snext = gy;
+  if (n_steps > 0) snext = load_state(4 * n_steps - 1);
+  __syncthreads();
+  int par = 0, rs = 0;
+  for (int64_t k = n_steps - 1; k >= 0; --k) {
+    const float dt = step_dt[k];
+    const float third = (float)(1.0 / 3.0);
+    const float c8 = dt * 0.125f, dt3 = dt * third;
+    f32x16 kb1 = gy * c8, kb2 = gy * (3.f * c8), kb3 = kb2, kbc = kb1;
+    f32x16 yb = gy;
+#pragma unroll
+    for (int stage = 3; stage >= 0; --stage) {
+      const f32x16 sst = snext;
+      const int64_t e_next = 4 * k + stage - 1;
+      if (e_next >= 0) snext = load_state(e_next);
+      float bs0, bs1, bs2, bs3;
+      {
+        const float4 dA = *reinterpret_cast<const float4*>(ring_dx + rs * 256 + n * 8);
+        const float4 dB = *reinterpret_cast<const float4*>(ring_dx + rs * 256 + n * 8 + 4);
+        bs0 = half ? dA.y : dA.x; bs1 = half ? dA.w : dA.z; bs2 = half ? dB.y : dB.x; bs3 = half ? dB.w : dB.z;
+        float* base = tile_lds + par * KP_ZA_FLOATS;
+        float* wz = base + ((n & 1) * 32 + half) * 20 + (n >> 1);
+        float* wa = base + 64 * 20 + ((n & 1) * 32 + half) * 20 + (n >> 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { wz[r * 40] = sst[r]; wa[r * 40] = kbc[r]; }
+        kp_stage_barrier();
+        par ^= 1;
+        rs = rs == 2 ? 0 : rs + 1;
+      }
+      f32x16 v;
+      {
+        f32x2 v2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v2[j] = f32x2{0.f, 0.f};
+        int opaque = 0;
+        asm volatile("" : "+v"(opaque));
+        const float4* wp = wj + lane + opaque;
+        auto issue = [&](f32x16& J, const float4& a) {
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_nop 1\n\t"
+                       "v_mfma_f32_32x32x2_f32 %0, %1, %5, 0\n\t"
+                       "v_mfma_f32_32x32x2_f32 %0, %2, %6, %0\n\t"
+                       "v_mfma_f32_32x32x2_f32 %0, %3, %7, %0\n\t"
+                       "v_mfma_f32_32x32x2_f32 %0, %4, %8, %0"
+                       : "=&v"(J) : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(bs0), "v"(bs1), "v"(bs2), "v"(bs3));
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        auto consume = [&](const f32x16& J, float ah) {
+          const f32x2 ah2 = {ah, ah};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v2[j] = __builtin_elementwise_fma(f32x2{J[2 * j], J[2 * j + 1]}, ah2, v2[j]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(v2[j]));
+        };
+        f32x16 Je, Jo;
+        float4 a_cur = wp[0], a_nxt = wp[64];
+        issue(Je, a_cur);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (r < 15) a_cur = wp[(2 * r + 2) * 64];
+          issue(Jo, a_nxt);
+          asm volatile("" : "+v"(Je));
+          float ae = kbc[r], ao = kbc[r];
+          kp_swap32(ae, ao);
+          consume(Je, ae);
+          if (r < 15) {
+            a_nxt = wp[(2 * r + 3) * 64];
+            issue(Je, a_cur);
+            asm volatile("" : "+v"(Jo));
+          } else {
+            asm volatile("s_nop 15\n\ts_nop 7" : "+v"(Jo));
+          }
+          consume(Jo, ao);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = v2[r >> 1][r & 1];
+      }
+      yb = yb + v;
+      if (stage == 3) {
+        kb1 = kb1 + dt * v;
+        kb2 = kb2 - dt * v;
+        kb3 = kb3 + dt * v;
+        kbc = kb3;
+      } else if (stage == 2) {
+        kb2 = kb2 + dt * v;
+        kb1 = kb1 - dt3 * v;
+        kbc = kb2;
+      } else if (stage == 1) {
+        kb1 = kb1 + dt3 * v;
+        kbc = kb1;
+      }
+    }
+    gy = yb;
+    add_outputs(k, gy);
+  }
+  if (valid) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) if (2 * r + half < Hr) grad_z0[series * Hr + 2 * r + half] = gy[r];
+  }
+}
+
 }  // namespace
+
+// K3d's pair form (identity activation); CDE_K3D_WAVES=1 keeps the one-wave kernel of rk4_backprop.hip
+int launch_backprop_jacobian_pair(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
+                                  const void* stages, const void* grad_out, int64_t n_out, const float* step_dt,
+                                  int64_t n_steps, const int64_t* node_ptr, const int64_t* node_out, const float* node_weight,
+                                  void* grad_z0, void* grad_W, void* grad_b, int64_t B, int64_t C, int64_t H,
+                                  const int64_t* stage_index, const float* stage_frac, float* partial, hipStream_t s) {
+  const Dims dims{(int)H, (int)C};
+  const unsigned blocks = (unsigned)((B + 127) / 128);
+  const size_t lds = (size_t)KP_LDS_FLOATS * sizeof(float);
+#define CDE_BPP(D)                                                                                                   \
+  do {                                                                                                               \
+    (void)hipFuncSetAttribute((const void*)rk4_backprop_jacobian_pair<D>, hipFuncAttributeMaxDynamicSharedMemorySize,\
+                              (int)lds);                                                                             \
+    rk4_backprop_jacobian_pair<D><<<blocks, 512, lds, s>>>(                                                          \
+        (const float*)coeffs, (const float*)knots, n_intervals, (const float*)W, (const float*)stages,               \
+        (const float*)grad_out, n_out, step_dt, n_steps, node_ptr, node_out, node_weight, (float*)grad_z0, partial,  \
+        B, stage_index, stage_frac, dims);                                                                           \
+  } while (0)
+  if (degree == CDE_PATH_CUBIC) CDE_BPP(CDE_PATH_CUBIC);
+  else if (degree == CDE_PATH_LINEAR) CDE_BPP(CDE_PATH_LINEAR);
+  else return CDE_ERR_UNSUPPORTED;
+#undef CDE_BPP
+  const int rc = check_launch();
+  if (rc != CDE_OK) return rc;
+  return launch_reduce_partials(partial, (B + 31) / 32, grad_W, grad_b, (int)H, (int)C, s);
+}
+
 
 template <typename TT>
 int launch_adjoint_jacobian_pair(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
