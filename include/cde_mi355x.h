@@ -437,6 +437,17 @@ int cde_rk4_backprop_linear(const void* coeffs, const void* knots, int64_t n_int
                             void* grad_z0, void* grad_W, void* grad_b, int64_t B, int64_t C, int64_t H, int dtype,
                             const int64_t* stage_index, const void* stage_frac, void* workspace, size_t workspace_bytes,
                             void* stream);
+/* ... with the gradient w.r.t. the control's coefficient tensor as well: under adjoint=False autograd reaches the control
+ * through X.derivative at every stage (reference solver.py:117-135; test/test_tricks.py:21-49 parametrises adjoint=False).
+ * `grad_coeffs`: layout of `coeffs` (cubic (B, n_intervals, 4C): the b, 2c, 3d columns receive gradients; linear
+ * (B, n_intervals + 1, C): the knot values), ZEROED by the caller, accumulated.  Both activations run the product-form stage
+ * (the cotangent of dX_c is sum_h kb_h act(Y)_hc, a sum over rows a lane of that stage holds). */
+int cde_rk4_backprop_linear_dcontrol(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
+                                     const void* bias, int act, const void* stages, const void* grad_out, int64_t n_out,
+                                     const float* step_dt, int64_t n_steps, const int64_t* node_ptr, const int64_t* node_out,
+                                     const float* node_weight, void* grad_z0, void* grad_W, void* grad_b, void* grad_coeffs,
+                                     int64_t B, int64_t C, int64_t H, int dtype, const int64_t* stage_index,
+                                     const void* stage_frac, void* workspace, size_t workspace_bytes, void* stream);
 
 /* K3d for the two-layer field of the reference's examples (adjoint=False, method='rk4'): cde_rk4_forward_mlp_stages is
  * cde_rk4_forward_mlp (one wave per tile at any batch) that also stores `stages` (B, n_grid - 1, 4, 32), the 32 zero-padded
@@ -458,6 +469,13 @@ int cde_rk4_backprop_mlp_sweep(const void* coeffs, const void* knots, int64_t n_
                                const void* stages, void* g_state, const void* grid, int64_t n_grid, int64_t k_begin,
                                int64_t k_end, void* U, void* G2, void* G1, void* Z, int64_t B, int64_t C, int64_t H,
                                int dtype, int time_dtype, const void* workspace, size_t workspace_bytes, void* stream);
+/* ... with the gradient w.r.t. the control's coefficient tensor (C <= 8, else CDE_ERR_UNSUPPORTED; `grad_coeffs` as for
+ * cde_rk4_backprop_linear_dcontrol: zeroed by the caller before the first chunk, accumulated by every chunk's call) */
+int cde_rk4_backprop_mlp_sweep_dcontrol(const void* coeffs, const void* knots, int64_t n_intervals, int degree, int act,
+                                        const void* stages, void* g_state, const void* grid, int64_t n_grid, int64_t k_begin,
+                                        int64_t k_end, void* U, void* G2, void* G1, void* Z, void* grad_coeffs, int64_t B,
+                                        int64_t C, int64_t H, int dtype, int time_dtype, const void* workspace,
+                                        size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K4  Adaptive Dormand-Prince 5(4) solve (torchdiffeq's default method, what cdeint runs when the

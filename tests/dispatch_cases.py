@@ -39,6 +39,9 @@ CASES = {
     "affine_backprop_beyond_the_kernel": (dict(adjoint=False, backprop_ok=False), "stepwise",
                                           ("mfma_shape", "variant_generic", "narrow_control")),
     "two_layer_rk4_backprop":    (dict(_MLP, adjoint=False), "mlp_rk4_backprop", ("narrow_control",)),
+    "affine_rk4_backprop_control": (dict(adjoint=False, wants_control=True), "rk4_backprop", ("narrow_control",)),
+    "two_layer_rk4_backprop_control": (dict(_MLP, adjoint=False, wants_control=True), "mlp_rk4_backprop", ()),
+    "two_layer_backprop_wide_control": (dict(_MLP, adjoint=False, wants_control=True, narrow_control=False), "stepwise", ()),
     # ------------------------------------------------------------------ torchdiffeq's other fixed-grid methods
     "affine_midpoint":           (dict(method="midpoint"), "fixed_grid", ("narrow_control",)),
     "affine_euler":              (dict(method="euler"), "fixed_grid", ("narrow_control",)),

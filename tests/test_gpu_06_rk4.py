@@ -3,6 +3,7 @@
 Tolerances and helpers: tests/gpu_common.py.  Collection order is the file order (01 first): the tests with the least driver history run first, so a failure elsewhere cannot hide them.
 """
 import os
+import warnings
 
 import pytest
 import torch
@@ -730,6 +731,122 @@ def test_rk4_backprop_mode_requests_the_kernel_does_not_take(native):
         out[:, -1].square().sum().backward()
         tol = 1e-8 if dtype == torch.float64 else 2e-3
         _close(z.grad, zo.grad, tol, tol * zo.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("kind", ["identity", "tanh", "two_layer"])
+@pytest.mark.parametrize("degree,knot_grad", [(3, True), (1, True), (3, False)])
+def test_rk4_backprop_mode_reaches_the_control_tensors(native, kind, degree, knot_grad):
+    """adjoint=False differentiates the solver's own operations, so autograd reaches every control tensor that requires a
+    gradient through X.derivative at each stage (reference solver.py:117-135; test/test_tricks.py:21-49 and :52-106 run it
+    with adjoint=False; no adjoint_params are involved).  For the recognised fields the gradient w.r.t. the coefficient tensor
+    comes out of the fused reverse-mode sweep (cde_rk4_backprop_linear_dcontrol / cde_rk4_backprop_mlp_sweep_dcontrol: the
+    cotangent of dX_c at a stage is sum_h kb_h act(Y)_hc, chained to the row in use) and the knot-time gradient follows from
+    it on the host.  Irregular knots, steps that cross knots, outputs on and between grid points, a ragged batch; against
+    autograd through the float64 oracle (1e-3 of the largest entry, or 4x what float32 costs the CPU oracle for the relu
+    field)."""
+    B, L, C, H, width = 75, 9, 5, 20, 48
+    gen = torch.Generator().manual_seed(311)
+    x = make_series(B, L, C, seed=312)
+    t32 = (torch.arange(L, dtype=torch.float32) + 0.3 * torch.rand(L, generator=gen)).contiguous()
+    z0 = torch.randn(B, H, generator=gen)
+    t_out = torch.tensor([float(t32[0]), 1.7, 2.5, 6.1, float(t32[-1])])
+    lw = torch.rand(B, t_out.numel(), H, generator=gen) + 0.5
+    kw = dict(method="rk4", options=dict(step_size=0.5), adjoint=False)
+    c32 = oracle_interp.hermite_bdiff_coeffs(x, t32) if degree == 3 else x
+
+    def field(dtype):
+        if kind == "two_layer":
+            return _TwoLayerField(H, C, width, dtype, seed=5, final_tanh=True)
+        return LinearField(H, C, dtype, scale=0.4, tanh=kind == "tanh", seed=3)
+
+    res = {}
+    for dtype in (torch.float64, torch.float32):
+        f = field(dtype)
+        co = c32.to(dtype).clone().requires_grad_(True)
+        kn = t32.to(dtype).clone().requires_grad_(knot_grad)
+        path = (oracle_interp.CubicPath if degree == 3 else oracle_interp.LinearPath)(co, kn)
+        zc = z0.to(dtype).clone().requires_grad_(True)
+        out = oracle_cde.cdeint(path, f, zc, t_out.to(dtype), **kw)
+        (out * lw.to(dtype)).sum().backward()
+        res[dtype] = [out.detach(), zc.grad, co.grad, kn.grad if knot_grad else None] + [p.grad for p in f.parameters()]
+
+    def bar(want, cpu32):
+        return max(1e-3 * want.abs().max().item(), 4 * (cpu32.double() - want).abs().max().item() if kind == "two_layer" else 0.0)
+
+    func = field(torch.float32).to(DEV)
+    cd = c32.to(DEV).clone().requires_grad_(True)
+    kd = t32.to(DEV).clone().requires_grad_(knot_grad)
+    X = (native.CubicSpline if degree == 3 else native.LinearInterpolation)(cd, kd)
+    z = z0.to(DEV).requires_grad_(True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                      # in particular: no step-wise warning
+        out = native.cdeint(X, func, z, t_out.to(DEV), **kw)
+    _expect_dispatch("two_layer_rk4_backprop_control" if kind == "two_layer" else "affine_rk4_backprop_control", out)
+    (out * lw.to(DEV)).sum().backward()
+    got = [out.detach(), z.grad, cd.grad, kd.grad if knot_grad else None] + [p.grad for p in func.parameters()]
+    _close(got[0], res[torch.float64][0], 1e-4, 5e-6)
+    names = ["z0", "coeffs", "knots"] + [n for n, _ in func.named_parameters()]
+    for name, g_, want, cpu32 in zip(names, got[1:], res[torch.float64][1:], res[torch.float32][1:]):
+        if want is None:
+            assert g_ is None, name
+            continue
+        assert g_ is not None, name
+        _close(g_, want, 1e-3, bar(want, cpu32))
+    if degree == 3:
+        assert not bool(cd.grad[..., :C].any())             # the spline's `a` columns never enter the derivative
+    # the other gradients do not depend on whether the control requires one: bit for bit the same sweep results as without
+    func2 = field(torch.float32).to(DEV)
+    z2 = z0.to(DEV).requires_grad_(True)
+    X2 = (native.CubicSpline if degree == 3 else native.LinearInterpolation)(c32.to(DEV), t32.to(DEV))
+    out2 = native.cdeint(X2, func2, z2, t_out.to(DEV), **kw)
+    (out2 * lw.to(DEV)).sum().backward()
+    assert torch.equal(out2, out.detach())
+    if kind != "identity":                                   # (the identity field's plain sweep is the shared-Jacobian kernel)
+        assert torch.equal(z2.grad, z.grad)
+        for p2, p1 in zip(func2.parameters(), func.parameters()):
+            assert torch.equal(p2.grad, p1.grad)
+    else:
+        _close(z2.grad, z.grad, 1e-4, 1e-5 * z.grad.abs().max().item())
+
+
+def test_stacked_cdes_backprop_mode_fused(native):
+    """reference test/test_tricks.py:52-106 with adjoint=False on recognised fields: the output of one CDE is the control of
+    the next (linear interpolation of the first solution), the loss sits on the second -- both solves and both backward
+    passes run fused, the gradient reaches the first CDE's parameters and initial state through the second's control
+    gradient.  Against autograd through the float64 oracle."""
+    B, L, C, H1, H2 = 40, 24, 3, 6, 8
+    gen = torch.Generator().manual_seed(41)
+    x = make_series(B, L, C, seed=42)
+    z01, z02 = torch.randn(B, H1, generator=gen), torch.randn(B, H2, generator=gen)
+    t2 = torch.linspace(0, L - 1, 12)
+    kw = dict(method="rk4", options=dict(step_size=1.0), adjoint=False)
+
+    def run(dtype, dev, interp, Cubic, Linear, solve, hermite):
+        f1 = LinearField(H1, C, dtype, scale=0.4, tanh=True, seed=3).to(dev)
+        f2 = LinearField(H2, H1, dtype, scale=0.4, seed=4).to(dev)
+        za = z01.to(dev, dtype).clone().requires_grad_(True)
+        zb = z02.to(dev, dtype).clone().requires_grad_(True)
+        X1 = Cubic(hermite(x.to(dev, dtype)))
+        y1 = solve(X1, f1, za, t2.to(dev, dtype), **kw)                       # (B, 12, H1): the second CDE's data
+        X2 = Linear(interp(y1, t2.to(dev, dtype)), t2.to(dev, dtype))
+        y2 = solve(X2, f2, zb, X2.interval, **kw)
+        y2[:, -1].square().sum().backward()
+        return [y2.detach().cpu(), za.grad.cpu(), zb.grad.cpu()] + [p.grad.cpu() for p in list(f1.parameters()) + list(f2.parameters())]
+
+    want = run(torch.float64, "cpu", oracle_interp.linear_coeffs, oracle_interp.CubicPath, oracle_interp.LinearPath,
+               oracle_cde.cdeint, oracle_interp.hermite_bdiff_coeffs)
+    paths = []
+
+    def solve(X, f, z, t, **k):
+        out = native.cdeint(X, f, z, t, **k)
+        paths.append(_front().last_dispatch()[0].path)
+        return out
+    got = run(torch.float32, DEV, native.linear_interpolation_coeffs, native.CubicSpline, native.LinearInterpolation, solve,
+              native.hermite_cubic_coefficients_with_backward_differences)
+    assert paths == ["rk4_backprop", "rk4_backprop"]
+    _close(got[0], want[0], 1e-4, 1e-5)
+    for g_, w_ in zip(got[1:], want[1:]):
+        _close(g_, w_, 2e-3, 2e-3 * w_.abs().max().item())
 
 
 @pytest.mark.parametrize("method", ["midpoint", "euler"])

@@ -796,9 +796,11 @@ def test_dispatch_table_is_exhaustively_consistent():
                     assert c.path.startswith("mlp_") == (kind == "mlp2")
                     assert ("forward" in c.path) <= (not f["wants_grad"])    # forward-only kernels: nothing to differentiate
                     if c.path in ("rk4_backprop", "mlp_rk4_backprop"):
-                        # adjoint=False: reverse mode through the steps -- no time / control gradients
+                        # adjoint=False: reverse mode through the steps -- no output-time gradients; control gradients on the
+                        # 8-channel tiles
                         assert f["wants_grad"] and not f["adjoint"] and f["backprop_ok"] and not f["wants_t"]
                         assert f["mfma_shape"] == (kind == "affine")
+                        assert not f["wants_control"] or kind == "affine" or f["narrow_control"]
                         continue
                     if f["wants_grad"]:
                         assert f["adjoint"] and f["adjoint_method_ok"] and f["adjoint_options_ok"] and params != "foreign"
@@ -835,6 +837,8 @@ def test_dispatch_table_is_exhaustively_consistent():
     assert ask(wants_t=True).path == "dopri5_adjoint"                           # output-time gradients: K4a carries vjp_t
     assert ask(method="rk4", adjoint=False).path == "rk4_backprop"              # README.md:103: backprop through the solver
     assert ask(kind="mlp2", mfma_shape=False, method="rk4", adjoint=False).path == "mlp_rk4_backprop"
+    assert ask(method="rk4", adjoint=False, wants_control=True).path == "rk4_backprop"      # test/test_tricks.py:21-49, adjoint=False
+    assert ask(kind="mlp2", mfma_shape=False, method="rk4", adjoint=False, wants_control=True).path == "mlp_rk4_backprop"
     assert ask(method="midpoint").path == "fixed_grid"                          # test/test_cdeint.py:49-63
     assert ask(method="euler", wants_grad=False).path == "fixed_grid"
     for kw, word in ((dict(kind=None), "recognised"), (dict(method="midpoint", kind="mlp2", mfma_shape=False), "midpoint"),
@@ -843,6 +847,8 @@ def test_dispatch_table_is_exhaustively_consistent():
                      (dict(mfma_shape=False), "32 x 8"), (dict(wants_t=True, shared=True), "time"),
                      (dict(wants_control=True, params="own"), "control"),
                      (dict(kind="mlp2", mfma_shape=False, method="rk4", wants_control=True, narrow_control=False), "8 channels"),
+                     (dict(kind="mlp2", mfma_shape=False, method="rk4", adjoint=False, wants_control=True, narrow_control=False),
+                      "8 channels"),
                      (dict(t_ok=False), "increasing"), (dict(params="foreign"), "adjoint_params"),
                      (dict(prod=True), "prod"), (dict(tiles_ok=False, mfma_shape=False), "tiles")):
         verdict = ask(**kw)
@@ -930,7 +936,11 @@ def test_reverse_mode_recurrences_of_the_rk4_backprop_kernel_equal_autograd_thro
                         (torch.tensor([0., 1.5, 2.0, 2.25, 6.9, 8.], dtype=dt64), 0.75),
                         (torch.tensor([1., 7.3], dtype=dt64), 2.0)):
         func = LinearField(H, C, dt64, scale=0.4, seed=2)
-        X = oracle_interp.CubicPath(oracle_interp.hermite_bdiff_coeffs(x))
+        # the control's tensors require gradients too (autograd reaches them through X.derivative at every stage): the
+        # coefficient tensor and the knot times are leaves here
+        coeffs = oracle_interp.hermite_bdiff_coeffs(x).requires_grad_(True)
+        knots = torch.arange(L, dtype=dt64).requires_grad_(True)
+        X = oracle_interp.CubicPath(coeffs, knots)
         z0 = torch.randn(B, H, dtype=dt64, generator=torch.Generator().manual_seed(3)).requires_grad_(True)
         lw = torch.rand(B, t_out.numel(), H, dtype=dt64, generator=torch.Generator().manual_seed(4)) + 0.5
         ref = oracle_cde.cdeint(X, func, z0, t_out, adjoint=False, method="rk4", options=dict(step_size=step))
@@ -968,6 +978,7 @@ def test_reverse_mode_recurrences_of_the_rk4_backprop_kernel_equal_autograd_thro
 
         gy = outputs_at(n_steps)
         gW, gb = torch.zeros(H, C, H, dtype=dt64), torch.zeros(H, C, dtype=dt64)
+        gx = torch.zeros_like(coeffs)                    # dL/d(packed coefficients): the b, 2c, 3d columns of the row in use
         for k in range(n_steps - 1, -1, -1):
             dt = float(step_dt[k].double())
             times, ss = stages[k]
@@ -979,6 +990,14 @@ def test_reverse_mode_recurrences_of_the_rk4_backprop_kernel_equal_autograd_thro
                 v = torch.einsum("bh,bhk->bk", kb[i], J)
                 gW += torch.einsum("bh,bc,bk->hck", kb[i], dX, ss[i])
                 gb += torch.einsum("bh,bc->hc", kb[i], dX)
+                # the cotangent of dX_c: sum_h kb_h F(s_i)_hc with F = reshape(W s + b); chained to the row (1, frac, frac^2)
+                F = torch.einsum("hck,bk->bhc", W, ss[i]) + b
+                gdx = torch.einsum("bh,bhc->bc", kb[i], F)
+                frac, index = X._interpret_t(times[i])
+                frac, index = float(frac.detach()), int(index)
+                gx[:, index, C:2 * C] += gdx
+                gx[:, index, 2 * C:3 * C] += gdx * frac
+                gx[:, index, 3 * C:] += gdx * frac * frac
                 yb = yb + v
                 if i == 3:
                     kb[0] = kb[0] + dt * v; kb[1] = kb[1] - dt * v; kb[2] = kb[2] + dt * v
@@ -991,3 +1010,9 @@ def test_reverse_mode_recurrences_of_the_rk4_backprop_kernel_equal_autograd_thro
         assert torch.allclose(gy, z0.grad, rtol=1e-6, atol=1e-9)
         assert torch.allclose(gW.reshape(H * C, H), func.linear.weight.grad, rtol=1e-6, atol=1e-9)
         assert torch.allclose(gb.reshape(H * C), func.linear.bias.grad, rtol=1e-6, atol=1e-9)
+        with torch.no_grad():
+            assert torch.allclose(gx, coeffs.grad, rtol=1e-6, atol=1e-9)
+            # the knot times: frac = t - knot_j, so dL/d knot_j = - sum over the stages in interval j of gdx . d2X/dt2 -- which is
+            # a contraction of the coefficient gradient itself (cdeint.py: _plan_time_gradients)
+            per_interval = (coeffs[..., 2 * C:3 * C] * gx[..., C:2 * C] + 2 * coeffs[..., 3 * C:] * gx[..., 2 * C:3 * C]).sum((0, 2))
+            assert torch.allclose(torch.cat([-per_interval, per_interval.new_zeros(1)]), knots.grad, rtol=1e-6, atol=1e-9)

@@ -145,12 +145,16 @@ _SIGNATURES = {
     "cde_rk4_backprop_mlp_prepare": (_i, [_p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _i64, _i64, _i, _i, _p, _sz, _p]),
     "cde_rk4_backprop_mlp_sweep": (_i, [_p, _p, _i64, _i, _i, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i64,
                                         _i, _i, _p, _sz, _p]),
+    "cde_rk4_backprop_mlp_sweep_dcontrol": (_i, [_p, _p, _i64, _i, _i, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _i64,
+                                                 _i64, _i64, _i, _i, _p, _sz, _p]),
     "cde_rk4_backprop_supported": (_i, [_i64, _i64, _i, _i]),
     "cde_rk4_forward_linear_stages": (_i, [_p, _p, _i64, _i, _p, _p, _i, _p, _p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i,
                                            _i, _p, _p, _p]),
     "cde_rk4_backprop_workspace_bytes": (_sz, [_i64]),
     "cde_rk4_backprop_linear": (_i, [_p, _p, _i64, _i, _p, _p, _i, _p, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64,
                                      _i64, _i, _p, _p, _p, _sz, _p]),
+    "cde_rk4_backprop_linear_dcontrol": (_i, [_p, _p, _i64, _i, _p, _p, _i, _p, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p,
+                                              _i64, _i64, _i64, _i, _p, _p, _p, _sz, _p]),
     "cde_dopri5_workspace_bytes": (_sz, [_i64, _i64, _i64, _i]),
     "cde_dopri5_trace_offset": (_sz, [_i64, _i64, _i64, _i]),
     "cde_dopri5_advance": (_i, [_p, _p, _i64, _i, _p, _p, _i, _p, _p, _i64, _p, _i64, _d, _d, _d, _d, _d, _p, _i64, _i64,

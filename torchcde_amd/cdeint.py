@@ -342,7 +342,7 @@ class _Plan:
             self.owner.event_log.append(("forward", begin, self._mark()))
         return out, stages
 
-    def run_backprop(self, stages, grad_out, weight, bias):
+    def run_backprop(self, stages, grad_out, weight, bias, want_control=False):
         lib = _lib.load()
         step_dt, node_ptr, node_out, node_weight, n_steps = self.grids.backprop_lists()
         nbytes = lib.cde_rk4_backprop_workspace_bytes(self.B)
@@ -355,15 +355,27 @@ class _Plan:
         w = weight.detach().contiguous()
         bvec = bias.detach().contiguous()
         begin = self._mark()
-        _lib.check(lib.cde_rk4_backprop_linear(
-            _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w), _lib.ptr(bvec), self.act,
-            _lib.ptr(stages), _lib.ptr(go), self.n_out, _lib.ptr(step_dt), n_steps, _lib.ptr(node_ptr), _lib.ptr(node_out),
-            _lib.ptr(node_weight), _lib.ptr(grad_z0), _lib.ptr(grad_w), _lib.ptr(grad_b), self.B, self.C, self.H,
-            _lib.dtype_enum(self.dtype), _lib.ptr(self.stage_index), _lib.ptr(self.stage_frac), _lib.ptr(workspace),
-            workspace.numel(), _lib.stream_ptr(self.device)), "cde_rk4_backprop_linear")
+        grad_x = None
+        if want_control:
+            # the control's tensors require a gradient (autograd reaches them through X.derivative at every stage)
+            grad_x = torch.zeros_like(self.coeffs)          # (B, rows, width) like the packed coefficients
+            _lib.check(lib.cde_rk4_backprop_linear_dcontrol(
+                _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w), _lib.ptr(bvec),
+                self.act, _lib.ptr(stages), _lib.ptr(go), self.n_out, _lib.ptr(step_dt), n_steps, _lib.ptr(node_ptr),
+                _lib.ptr(node_out), _lib.ptr(node_weight), _lib.ptr(grad_z0), _lib.ptr(grad_w), _lib.ptr(grad_b),
+                _lib.ptr(grad_x), self.B, self.C, self.H, _lib.dtype_enum(self.dtype), _lib.ptr(self.stage_index),
+                _lib.ptr(self.stage_frac), _lib.ptr(workspace), workspace.numel(), _lib.stream_ptr(self.device)),
+                "cde_rk4_backprop_linear_dcontrol")
+        else:
+            _lib.check(lib.cde_rk4_backprop_linear(
+                _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w), _lib.ptr(bvec),
+                self.act, _lib.ptr(stages), _lib.ptr(go), self.n_out, _lib.ptr(step_dt), n_steps, _lib.ptr(node_ptr),
+                _lib.ptr(node_out), _lib.ptr(node_weight), _lib.ptr(grad_z0), _lib.ptr(grad_w), _lib.ptr(grad_b), self.B,
+                self.C, self.H, _lib.dtype_enum(self.dtype), _lib.ptr(self.stage_index), _lib.ptr(self.stage_frac),
+                _lib.ptr(workspace), workspace.numel(), _lib.stream_ptr(self.device)), "cde_rk4_backprop_linear")
         if begin is not None:
             self.owner.event_log.append(("backprop", begin, self._mark()))
-        return grad_z0, grad_w, grad_b
+        return grad_z0, grad_w, grad_b, grad_x
 
     # backward: K3
     def run_adjoint(self, z_saved, grad_out, weight, bias, want_control=False):
@@ -540,7 +552,7 @@ class _MlpPlan:
             _lib.stream_ptr(self.device)), "cde_rk4_forward_mlp_stages")
         return out.reshape(*self.batch, g.n_out, self.H), stages
 
-    def run_backprop(self, stages, grad_out, weights):
+    def run_backprop(self, stages, grad_out, weights, want_control=False):
         """Reverse mode through the 3/8-rule steps (the gradient `loss.backward()` through torchdiffeq's own operations
         gives, reference solver.py:144 with adjoint=False): the sweep walks the forward grid backwards in chunks of steps
         that end on the grid nodes an output gradient lands on (the transpose of torchdiffeq's linear output
@@ -564,6 +576,7 @@ class _MlpPlan:
         land(n_steps)
         acc2 = torch.zeros(256, 132, dtype=torch.float32, device=dev)
         acc1 = torch.zeros(128, 36, dtype=torch.float32, device=dev)
+        grad_x = torch.zeros_like(self.coeffs) if want_control else None     # accumulated by the sweep launches
         if n_steps > 0:
             stream = _lib.stream_ptr(dev)
             tdt = _lib.dtype_enum(g.time_dtype)
@@ -590,10 +603,17 @@ class _MlpPlan:
                     if nodes[m]:
                         k_lo = m
                         break
-                _lib.check(lib.cde_rk4_backprop_mlp_sweep(
-                    _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, f.act, _lib.ptr(stages),
-                    _lib.ptr(gy), _lib.ptr(g.grid), n_grid, k_lo, k_hi, _lib.ptr(U), _lib.ptr(G2), _lib.ptr(G1), _lib.ptr(Z),
-                    B, C, H, f32, tdt, _lib.ptr(workspace), nbytes, stream), "cde_rk4_backprop_mlp_sweep")
+                if want_control:
+                    _lib.check(lib.cde_rk4_backprop_mlp_sweep_dcontrol(
+                        _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, f.act, _lib.ptr(stages),
+                        _lib.ptr(gy), _lib.ptr(g.grid), n_grid, k_lo, k_hi, _lib.ptr(U), _lib.ptr(G2), _lib.ptr(G1),
+                        _lib.ptr(Z), _lib.ptr(grad_x), B, C, H, f32, tdt, _lib.ptr(workspace), nbytes, stream),
+                        "cde_rk4_backprop_mlp_sweep_dcontrol")
+                else:
+                    _lib.check(lib.cde_rk4_backprop_mlp_sweep(
+                        _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, f.act, _lib.ptr(stages),
+                        _lib.ptr(gy), _lib.ptr(g.grid), n_grid, k_lo, k_hi, _lib.ptr(U), _lib.ptr(G2), _lib.ptr(G1),
+                        _lib.ptr(Z), B, C, H, f32, tdt, _lib.ptr(workspace), nbytes, stream), "cde_rk4_backprop_mlp_sweep")
                 n = 4 * (k_hi - k_lo) * B
                 _lib.check(lib.cde_mlp_grad_reduce(_lib.ptr(G2), _lib.ptr(U), n, 2, _lib.ptr(acc2), _lib.ptr(reduce_ws),
                                                    reduce_ws.numel(), stream), "cde_mlp_grad_reduce")
@@ -608,7 +628,7 @@ class _MlpPlan:
         grad_b2 = acc2[:, 128].reshape(units, channels)[:H, :C].reshape(H * C)
         grad_w1 = acc1[:width, :H].contiguous()
         grad_b1 = acc1[:width, 32].contiguous()
-        return gy.reshape(*self.batch, H), grad_w1, grad_b1, grad_w2, grad_b2
+        return gy.reshape(*self.batch, H), grad_w1, grad_b1, grad_w2, grad_b2, grad_x
 
     def time_gradients(self, z_saved, grad_out, weights, grad_x, t, want_t=True, want_knots=False):
         """Time gradients from what the sweep produced (as _plan_time_gradients for the one-layer fields):
@@ -616,9 +636,6 @@ class _MlpPlan:
         contraction of the control gradient with the cubic's (2c, 3d) rows and vanishes for a piecewise-linear control;
         dL/d knot_j = - its part over interval j (cubic), or through the widths of a piecewise-linear control."""
         B, H, C, f = self.B, self.H, self.C, self.field
-        w1, b1, w2, b2 = self._weights(weights)
-        zs = z_saved.detach().reshape(B, self.n_out, H)
-        go = grad_out.detach().reshape(B, self.n_out, H)
         co = self.coeffs
         if self.degree == _lib.PATH_CUBIC:
             per_interval = (co[..., 2 * C:3 * C] * grad_x[..., C:2 * C]
@@ -637,6 +654,9 @@ class _MlpPlan:
             grad_knots = (torch.cat([zero, dh]) - torch.cat([dh, zero])).to(co.dtype)
         if not want_t:
             return None, grad_knots
+        w1, b1, w2, b2 = self._weights(weights)
+        zs = z_saved.detach().reshape(B, self.n_out, H)
+        go = grad_out.detach().reshape(B, self.n_out, H)
         vals = [None] * self.n_out
         total = torch.zeros((), dtype=torch.float32, device=self.device)
         for i in range(1, self.n_out):
@@ -739,23 +759,40 @@ class _FusedRK4(torch.autograd.Function):
                 None, None, grad_t, grad_knots) + control_grads
 
 
+def _control_gradients(plan, grad_x, want_x, want_knots, need, knot_gradient):
+    """(dL/d knot times, *dL/d the path's buffer views) of a reverse-mode sweep: the sweep leaves dL/d(packed coefficients)
+    in `grad_x`; the knot times follow from it by the chain rule of `frac = t - t_j` / of the widths (plan.time_gradients)."""
+    grad_knots = knot_gradient() if want_knots else None
+    if not want_x:
+        return (grad_knots,)
+    C = plan.C
+    gx = grad_x.reshape(*plan.batch, grad_x.size(-2), grad_x.size(-1))
+    pieces = (gx[..., C:2 * C], gx[..., 2 * C:3 * C], gx[..., 3 * C:]) if plan.degree == _lib.PATH_CUBIC else (gx,)
+    return (grad_knots,) + tuple(g if n else None for g, n in zip(pieces, need))
+
+
 class _FusedMlpRK4Backprop(torch.autograd.Function):
     """cdeint(..., method='rk4', adjoint=False) for the examples' two-layer field: as _FusedRK4Backprop, on K2m / K3m."""
 
     @staticmethod
-    def forward(ctx, z0, w1, b1, w2, b2, plan):
+    def forward(ctx, z0, w1, b1, w2, b2, plan, want_x, knots, *control):
+        # `control` / `knots`: the path's differentiable buffer views / its knot times when autograd must reach them (with
+        # adjoint=False it does so through X.derivative at every stage) -- only their gradient slots are used
         out, stages = plan.run_with_stages(z0)
-        ctx.plan = plan
+        ctx.plan, ctx.want_x, ctx.has_knots = plan, want_x, knots is not None
         ctx.save_for_backward(stages, w1, b1, w2, b2)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         stages, *weights = ctx.saved_tensors
-        grad_z0, g1w, g1b, g2w, g2b = ctx.plan.run_backprop(stages, grad_out, weights)
-        need = ctx.needs_input_grad
+        plan, need = ctx.plan, ctx.needs_input_grad
+        want_knots = ctx.has_knots and need[7]
+        grad_z0, g1w, g1b, g2w, g2b, grad_x = plan.run_backprop(stages, grad_out, weights, ctx.want_x or want_knots)
         return (grad_z0 if need[0] else None, g1w if need[1] else None, g1b if need[2] else None,
-                g2w if need[3] else None, g2b if need[4] else None, None)
+                g2w if need[3] else None, g2b if need[4] else None, None, None) + _control_gradients(
+                    plan, grad_x, ctx.want_x, want_knots, need[8:], lambda: plan.time_gradients(
+                        None, None, weights, grad_x, None, False, True)[1])
 
 
 class _FusedRK4Backprop(torch.autograd.Function):
@@ -765,20 +802,24 @@ class _FusedRK4Backprop(torch.autograd.Function):
     of the discrete solve, as `loss.backward()` through torchdiffeq's own operations gives it."""
 
     @staticmethod
-    def forward(ctx, z0, weight, bias, plan):
+    def forward(ctx, z0, weight, bias, plan, want_x, knots, *control):
+        # `control` / `knots`: as for _FusedMlpRK4Backprop
         out, stages = plan.run_forward_stages(z0, weight, bias)
-        ctx.plan = plan
+        ctx.plan, ctx.want_x, ctx.has_knots = plan, want_x, knots is not None
         ctx.save_for_backward(weight, bias, stages)
         return out.reshape(*plan.batch, plan.n_out, plan.H)
 
     @staticmethod
     def backward(ctx, grad_out):
-        plan = ctx.plan
+        plan, need = ctx.plan, ctx.needs_input_grad
         weight, bias, stages = ctx.saved_tensors
-        grad_z0, grad_w, grad_b = plan.run_backprop(stages, grad_out, weight, bias)
-        return (grad_z0.reshape(*plan.batch, plan.H) if ctx.needs_input_grad[0] else None,
-                grad_w.view_as(weight) if ctx.needs_input_grad[1] else None,
-                grad_b if ctx.needs_input_grad[2] else None, None)
+        want_knots = ctx.has_knots and need[5]
+        grad_z0, grad_w, grad_b, grad_x = plan.run_backprop(stages, grad_out, weight, bias, ctx.want_x or want_knots)
+        return (grad_z0.reshape(*plan.batch, plan.H) if need[0] else None,
+                grad_w.view_as(weight) if need[1] else None,
+                grad_b if need[2] else None, None, None) + _control_gradients(
+                    plan, grad_x, ctx.want_x, want_knots, need[6:], lambda: plan.time_gradients(
+                        None, None, weight, bias, grad_x, None, False, True)[1])
 
 
 # ------------------------------------------------------------------------------------------ dopri5 (K4)
@@ -1441,6 +1482,9 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
     control_wants = grad_mode and adjoint and given_params is not None and any(
         isinstance(p, torch.Tensor) and p.requires_grad and p.untyped_storage().data_ptr() in control_ids
         for p in given_params)
+    if not adjoint:
+        # autograd through the solver's own operations reaches every control tensor that requires a gradient
+        control_wants = grad_mode and any(b.requires_grad for b in X.buffers())
     mfma_shape = (field is not None and z0.dtype == torch.float32 and H <= 32 and C <= 8
                   and variant != _lib.VARIANT_GENERIC)
     adj_opts = kwargs.get("adjoint_options")
@@ -1487,9 +1531,8 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         adjoint_method_ok=adjoint_method in (None, method), options_ok=options_ok,
         adjoint_options_ok=adjoint_options_ok, t_ok=bool(increasing) or not t_is_vector,
         variant_generic=variant == _lib.VARIANT_GENERIC, shared=step_control() is not None, narrow_control=C <= 8,
-        backprop_ok=bool(((mfma_shape and variant in (_lib.VARIANT_AUTO, _lib.VARIANT_MFMA))
-                          or (mlp is not None and variant == _lib.VARIANT_AUTO))
-                         and not any(b.requires_grad for b in X.buffers())),
+        backprop_ok=bool((mfma_shape and variant in (_lib.VARIANT_AUTO, _lib.VARIANT_MFMA))
+                         or (mlp is not None and variant == _lib.VARIANT_AUTO)),
         identity=bool(field is not None and field.act == _lib.ACT_NONE))
     if recognised_kind is not None and known is None:
         # the probe recognised the formula but the shape / dtype is beyond the tiles: say so in the record and the warning
@@ -1530,9 +1573,15 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         control_inputs = X._control_buffers() if want_x else ()
         return _FusedMlpRK4.apply(z0, mlp.hidden.weight, mlp.hidden.bias, mlp.output.weight, mlp.output.bias, plan,
                                   want_x, t if wants_t else None, X._t if want_knots else None, *control_inputs)
+    if choice.path in ("rk4_backprop", "mlp_rk4_backprop"):
+        # adjoint=False: the control tensors autograd must reach (their gradients come out of the same reverse-mode sweep)
+        want_x = bool(grad_mode and any(b.requires_grad for b in X._control_buffers()))
+        knots_in = X._t if (grad_mode and X._t.requires_grad) else None
+        control_inputs = X._control_buffers() if want_x else ()
     if choice.path == "mlp_rk4_backprop":
         plan = _MlpPlan(X, mlp, batch, H, C, t, _parse_fixed_options(fused_options, "solver"))
-        return _FusedMlpRK4Backprop.apply(z0, mlp.hidden.weight, mlp.hidden.bias, mlp.output.weight, mlp.output.bias, plan)
+        return _FusedMlpRK4Backprop.apply(z0, mlp.hidden.weight, mlp.hidden.bias, mlp.output.weight, mlp.output.bias, plan,
+                                          want_x, knots_in, *control_inputs)
     if choice.path == "mlp_rk4_forward":
         with torch.no_grad():
             return _MlpPlan(X, mlp, batch, H, C, t, _parse_fixed_options(fused_options, "solver")).run(z0)
@@ -1550,7 +1599,7 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
     weight, bias = field.weight, field.bias
     if choice.path == "rk4_backprop":
         plan = _Plan(X, field, batch, H, C, t, _parse_fixed_options(fused_options, "solver"), None, False, variant)
-        return _FusedRK4Backprop.apply(z0, weight, bias, plan)
+        return _FusedRK4Backprop.apply(z0, weight, bias, plan, want_x, knots_in, *control_inputs)
     if choice.path in ("dopri5_forward", "dopri5_adjoint"):
         plan = _Dopri5Plan(X, field, batch, H, C, t, kwargs["rtol"], kwargs["atol"], fused_options, variant,
                            kwargs.get("adjoint_rtol"), kwargs.get("adjoint_atol"), fused_adj_opts)

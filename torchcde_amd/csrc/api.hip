@@ -77,7 +77,7 @@ int launch_forward_mfma_stages(const void*, const void*, int64_t, int, const voi
 size_t backprop_workspace_bytes(int64_t B);
 int launch_backprop_jacobian(const void*, const void*, int64_t, int, const void*, const void*, int, const void*, const void*,
                              int64_t, const float*, int64_t, const int64_t*, const int64_t*, const float*, void*, void*, void*,
-                             int64_t, int64_t, int64_t, const int64_t*, const float*, float*, hipStream_t);
+                             int64_t, int64_t, int64_t, const int64_t*, const float*, float*, void* grad_coeffs, hipStream_t);
 // from rk4_bf16x3.hip
 template <typename TT>
 int launch_forward_bf16x3(const void*, const void*, int64_t, int, const void*, const void*, const void*, const void*, int64_t,
@@ -107,7 +107,7 @@ int launch_forward_mlp_stages(const void*, const void*, int64_t, int, const void
 template <typename TT>
 int launch_mlp_backprop_sweep(const void*, const void*, int64_t, int, int, const float*, const void*, int64_t, void*,
                               const void*, int64_t, int64_t, const int64_t*, const void*, void*, void*, void*, void*, int64_t,
-                              int64_t, int64_t, hipStream_t);
+                              int64_t, int64_t, void* grad_coeffs, hipStream_t);
 
 // Stage table: for solver step k over [grid[k], grid[k+1]] and RK stage j, the control interval
 // and fractional part at the stage time -- what CubicSpline._interpret_t (interpolation_cubic.py:
@@ -507,12 +507,12 @@ extern "C" int cde_rk4_forward_linear_stages(const void* coeffs, const void* kno
 
 extern "C" size_t cde_rk4_backprop_workspace_bytes(int64_t B) { return B > 0 ? cde::backprop_workspace_bytes(B) : 0; }
 
-extern "C" int cde_rk4_backprop_linear(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
+static int rk4_backprop_linear_impl(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
                                        const void* W, const void* bias, int act, const void* stages, const void* grad_out,
                                        int64_t n_out,
                                        const float* step_dt, int64_t n_steps, const int64_t* node_ptr,
                                        const int64_t* node_out, const float* node_weight, void* grad_z0, void* grad_W,
-                                       void* grad_b, int64_t B, int64_t C, int64_t H, int dtype,
+                                       void* grad_b, void* grad_coeffs, int64_t B, int64_t C, int64_t H, int dtype,
                                        const int64_t* stage_index, const void* stage_frac, void* workspace,
                                        size_t workspace_bytes, void* stream) {
   if (B < 1 || C < 1 || H < 1 || n_intervals < 1 || n_out < 1 || n_steps < 0) return CDE_ERR_SHAPE;
@@ -525,7 +525,36 @@ extern "C" int cde_rk4_backprop_linear(const void* coeffs, const void* knots, in
   if (workspace_bytes < cde_rk4_backprop_workspace_bytes(B)) return CDE_ERR_WORKSPACE;
   return cde::launch_backprop_jacobian(coeffs, knots, n_intervals, degree, W, bias, act, stages, grad_out, n_out, step_dt, n_steps,
                                        node_ptr, node_out, node_weight, grad_z0, grad_W, grad_b, B, C, H, stage_index,
-                                       (const float*)stage_frac, (float*)workspace, (hipStream_t)stream);
+                                       (const float*)stage_frac, (float*)workspace, grad_coeffs, (hipStream_t)stream);
+}
+
+extern "C" int cde_rk4_backprop_linear(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
+                                       const void* W, const void* bias, int act, const void* stages, const void* grad_out,
+                                       int64_t n_out,
+                                       const float* step_dt, int64_t n_steps, const int64_t* node_ptr,
+                                       const int64_t* node_out, const float* node_weight, void* grad_z0, void* grad_W,
+                                       void* grad_b, int64_t B, int64_t C, int64_t H, int dtype,
+                                       const int64_t* stage_index, const void* stage_frac, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+  return rk4_backprop_linear_impl(coeffs, knots, n_intervals, degree, W, bias, act, stages, grad_out, n_out, step_dt, n_steps,
+                                  node_ptr, node_out, node_weight, grad_z0, grad_W, grad_b, nullptr, B, C, H, dtype,
+                                  stage_index, stage_frac, workspace, workspace_bytes, stream);
+}
+
+// ... and with the gradient w.r.t. the control's coefficient tensor (`grad_coeffs`: layout of `coeffs`, ZEROED by the caller,
+// accumulated): under adjoint=False autograd reaches the control through X.derivative at every stage.
+extern "C" int cde_rk4_backprop_linear_dcontrol(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
+                                                const void* W, const void* bias, int act, const void* stages,
+                                                const void* grad_out, int64_t n_out, const float* step_dt, int64_t n_steps,
+                                                const int64_t* node_ptr, const int64_t* node_out, const float* node_weight,
+                                                void* grad_z0, void* grad_W, void* grad_b, void* grad_coeffs, int64_t B,
+                                                int64_t C, int64_t H, int dtype, const int64_t* stage_index,
+                                                const void* stage_frac, void* workspace, size_t workspace_bytes,
+                                                void* stream) {
+  if (!grad_coeffs) return CDE_ERR_NULL;
+  return rk4_backprop_linear_impl(coeffs, knots, n_intervals, degree, W, bias, act, stages, grad_out, n_out, step_dt, n_steps,
+                                  node_ptr, node_out, node_weight, grad_z0, grad_W, grad_b, grad_coeffs, B, C, H, dtype,
+                                  stage_index, stage_frac, workspace, workspace_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------- K3m
@@ -617,11 +646,13 @@ extern "C" int cde_rk4_backprop_mlp_prepare(const void* knots, int64_t n_interva
   return cde::launch_mlp_adjoint_images(W1, bias1, width, W2, bias2, C, H, (float*)(base + mlp_ws_image_offset(n_steps)), s);
 }
 
-extern "C" int cde_rk4_backprop_mlp_sweep(const void* coeffs, const void* knots, int64_t n_intervals, int degree, int act,
+static int rk4_backprop_mlp_sweep_impl(const void* coeffs, const void* knots, int64_t n_intervals, int degree, int act,
                                           const void* stages, void* g_state, const void* grid, int64_t n_grid,
-                                          int64_t k_begin, int64_t k_end, void* U, void* G2, void* G1, void* Z, int64_t B,
+                                          int64_t k_begin, int64_t k_end, void* U, void* G2, void* G1, void* Z,
+                                          void* grad_coeffs, int64_t B,
                                           int64_t C, int64_t H, int dtype, int time_dtype, const void* workspace,
                                           size_t workspace_bytes, void* stream) {
+  if (grad_coeffs && C > 8) return CDE_ERR_UNSUPPORTED;            // control gradients: the 8-channel tiles only
   if (B < 1 || C < 1 || H < 1 || n_intervals < 1 || k_begin < 0 || k_end < k_begin || k_end > n_grid - 1) return CDE_ERR_SHAPE;
   if (dtype != CDE_F32) return dtype == CDE_F64 ? CDE_ERR_UNSUPPORTED : CDE_ERR_DTYPE;
   if (!cde::mlp_shape_ok(C, H, 1)) return CDE_ERR_UNSUPPORTED;
@@ -635,11 +666,33 @@ extern "C" int cde_rk4_backprop_mlp_sweep(const void* coeffs, const void* knots,
   hipStream_t s = (hipStream_t)stream;
   if (time_dtype == CDE_F32)
     return cde::launch_mlp_backprop_sweep<float>(coeffs, knots, n_intervals, degree, act, img, stages, n_steps, g_state, grid,
-                                                 k_begin, k_end, stage_index, stage_frac, U, G2, G1, Z, B, C, H, s);
+                                                 k_begin, k_end, stage_index, stage_frac, U, G2, G1, Z, B, C, H, grad_coeffs, s);
   if (time_dtype == CDE_F64)
     return cde::launch_mlp_backprop_sweep<double>(coeffs, knots, n_intervals, degree, act, img, stages, n_steps, g_state, grid,
-                                                  k_begin, k_end, stage_index, stage_frac, U, G2, G1, Z, B, C, H, s);
+                                                  k_begin, k_end, stage_index, stage_frac, U, G2, G1, Z, B, C, H, grad_coeffs, s);
   return CDE_ERR_DTYPE;
+}
+
+extern "C" int cde_rk4_backprop_mlp_sweep(const void* coeffs, const void* knots, int64_t n_intervals, int degree, int act,
+                                          const void* stages, void* g_state, const void* grid, int64_t n_grid,
+                                          int64_t k_begin, int64_t k_end, void* U, void* G2, void* G1, void* Z, int64_t B,
+                                          int64_t C, int64_t H, int dtype, int time_dtype, const void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+  return rk4_backprop_mlp_sweep_impl(coeffs, knots, n_intervals, degree, act, stages, g_state, grid, n_grid, k_begin, k_end, U,
+                                     G2, G1, Z, nullptr, B, C, H, dtype, time_dtype, workspace, workspace_bytes, stream);
+}
+
+// ... and with the gradient w.r.t. the control's coefficient tensor (C <= 8; `grad_coeffs` zeroed by the caller before the
+// first chunk, accumulated by every chunk's launch)
+extern "C" int cde_rk4_backprop_mlp_sweep_dcontrol(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
+                                                   int act, const void* stages, void* g_state, const void* grid,
+                                                   int64_t n_grid, int64_t k_begin, int64_t k_end, void* U, void* G2, void* G1,
+                                                   void* Z, void* grad_coeffs, int64_t B, int64_t C, int64_t H, int dtype,
+                                                   int time_dtype, const void* workspace, size_t workspace_bytes,
+                                                   void* stream) {
+  if (!grad_coeffs) return CDE_ERR_NULL;
+  return rk4_backprop_mlp_sweep_impl(coeffs, knots, n_intervals, degree, act, stages, g_state, grid, n_grid, k_begin, k_end, U,
+                                     G2, G1, Z, grad_coeffs, B, C, H, dtype, time_dtype, workspace, workspace_bytes, stream);
 }
 
 extern "C" int cde_rk4_adjoint_mlp_sweep(const void* coeffs, const void* knots, int64_t n_intervals, int degree, int act,

@@ -82,15 +82,20 @@ __device__ __forceinline__ float bp_wv32_image(const float* __restrict__ W, int 
   return (h < d.H && c < d.C && k < d.H) ? W[(h * d.C + c) * d.H + k] : 0.f;
 }
 
-template <int DEGREE>
+// DCOEFF: the control tensors require a gradient as well (under adjoint=False autograd reaches them through X.derivative at
+// every stage, reference solver.py:117-135): the cotangent of dX_c at a stage is sum_h kb_h act(Y)_hc -- a sum over rows the
+// lane holds, as in K3a -- chained to the coefficient row in use (cubic: 1, frac, frac^2 for b, 2c, 3d; linear: -+1/width on
+// the two knot values) and added to `grad_coeffs` (zeroed by the caller, layout of `coeffs`) whenever the row changes; one
+// lane owns a (series, channel): no atomics, run-to-run deterministic.  Both activations (the identity field's control
+// gradients take this product-form stage too: the shared-Jacobian stage never forms act(Y)).
+template <int DEGREE, int ACT, bool DCOEFF>
 __global__ __launch_bounds__(256, 1) void rk4_backprop_act(
     const float* __restrict__ coeffs, const float* __restrict__ knots, int64_t n_intervals,
     const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ stages,
     const float* __restrict__ grad_out, int64_t n_out, const float* __restrict__ step_dt, int64_t n_steps,
     const int64_t* __restrict__ node_ptr, const int64_t* __restrict__ node_out, const float* __restrict__ node_weight,
     float* __restrict__ grad_z0, float* __restrict__ partial, int64_t B, const int64_t* __restrict__ stage_index,
-    const float* __restrict__ stage_frac, Dims dims) {
-  constexpr int ACT = CDE_ACT_TANH;
+    const float* __restrict__ stage_frac, Dims dims, float* __restrict__ grad_coeffs) {
   const int Hr = dims.H, Cr = dims.C;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* wyf = lds;
@@ -148,6 +153,27 @@ __global__ __launch_bounds__(256, 1) void rk4_backprop_act(
   for (int r = 0; r < 16; ++r) gy[r] = 0.f;
   add_outputs(n_steps, gy);
 
+  // dL/d(coefficient row in use), this lane's 4 channels: cubic (b, 2c, 3d), linear (left knot, right knot)
+  float gc0[4] = {0.f, 0.f, 0.f, 0.f}, gc1[4] = {0.f, 0.f, 0.f, 0.f}, gc2[4] = {0.f, 0.f, 0.f, 0.f};
+  auto flush_control_grad = [&](int64_t at) {
+    if constexpr (DCOEFF) {
+#pragma unroll
+      for (int cl = 0; cl < 4; ++cl) {
+        const int c = cl + 4 * half;
+        if (valid && c < Cr) {
+          if (DEGREE == CDE_PATH_CUBIC) {
+            float* g = grad_coeffs + (series * n_intervals + at) * 4 * Cr;
+            g[Cr + c] += gc0[cl]; g[2 * Cr + c] += gc1[cl]; g[3 * Cr + c] += gc2[cl];
+          } else {
+            float* g = grad_coeffs + (series * (n_intervals + 1) + at) * Cr;
+            g[c] += gc0[cl]; g[Cr + c] += gc1[cl];
+          }
+        }
+        gc0[cl] = 0.f; gc1[cl] = 0.f; gc2[cl] = 0.f;
+      }
+    }
+  };
+
   if (n_steps > 0) {
     int64_t idx = stage_index[4 * n_steps - 1];
     float frac = stage_frac[4 * n_steps - 1];
@@ -164,11 +190,18 @@ __global__ __launch_bounds__(256, 1) void rk4_backprop_act(
         float dX[MC];
         const float width = DEGREE == CDE_PATH_LINEAR ? knots[idx + 1] - knots[idx] : 1.f;
         control_slope<DEGREE>(row, frac, width, dX);
-        f32x16 sst;                                   // the stored stage state: units 2r + half of the plain-order row
-        {
+        f32x16 sst;                                   // the stored stage state: units 2r + half
+        if constexpr (ACT == CDE_ACT_TANH) {          // (the tanh forward stores its rows in plain unit order ...
           const float* sp = srow + (4 * k + stage) * 32 + half;
 #pragma unroll
           for (int r = 0; r < 16; ++r) sst[r] = sp[2 * r];
+        } else {                                      //  ... the product-form forward of the identity field evens, then odds)
+          const float4* sp = reinterpret_cast<const float4*>(srow + (4 * k + stage) * 32 + 16 * half);
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 v4 = sp[g4];
+            sst[4 * g4] = v4.x; sst[4 * g4 + 1] = v4.y; sst[4 * g4 + 2] = v4.z; sst[4 * g4 + 3] = v4.w;
+          }
         }
         const int64_t e_next = 4 * k + stage - 1;
         const bool more = e_next >= 0;
@@ -194,6 +227,7 @@ __global__ __launch_bounds__(256, 1) void rk4_backprop_act(
           }
         }
         f32x16 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float gdx[4] = {0.f, 0.f, 0.f, 0.f};        // cotangent of dX_c, this lane's 4 channels (DCOEFF)
         int opaque = 0;
         asm volatile("" : "+v"(opaque));          // keeps the image reads inside the stage (no hoisting)
         const float4* wys = wy + opaque;
@@ -229,7 +263,8 @@ __global__ __launch_bounds__(256, 1) void rk4_backprop_act(
 #pragma unroll
             for (int cl = 0; cl < 4; ++cl) {
               const float t = tp[cl >> 1][cl & 1];
-              g[4 * hl + cl] = a4u[hl] * (dh[cl] * __builtin_fmaf(-t, t, 1.f));
+              g[4 * hl + cl] = a4u[hl] * (dh[cl] * (ACT == CDE_ACT_TANH ? __builtin_fmaf(-t, t, 1.f) : 1.f));
+              if constexpr (DCOEFF) gdx[cl] = __builtin_fmaf(a4u[hl], t, gdx[cl]);
             }
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -267,6 +302,15 @@ __global__ __launch_bounds__(256, 1) void rk4_backprop_act(
           __builtin_amdgcn_sched_barrier(0);       // one tile at a time: bounds the live registers
         }
 
+        if constexpr (DCOEFF) {
+#pragma unroll
+          for (int cl = 0; cl < 4; ++cl) {
+            const float w = gdx[cl];                // (kb_i carries the step's dt / 8, 3 dt / 8: no quadrature weight here)
+            if (DEGREE == CDE_PATH_CUBIC) { gc0[cl] += w; gc1[cl] += w * frac; gc2[cl] += w * frac * frac; }
+            else { gc0[cl] -= w / width; gc1[cl] += w / width; }
+          }
+          if (nidx != idx) flush_control_grad(idx);
+        }
         // ---- reverse-mode bookkeeping of the 3/8 rule (see the file header)
         yb = yb + v;
         if (stage == 3) {
@@ -287,6 +331,7 @@ __global__ __launch_bounds__(256, 1) void rk4_backprop_act(
       gy = yb;
       add_outputs(k, gy);
     }
+    flush_control_grad(idx);
   }
   if (valid) {
 #pragma unroll
@@ -553,29 +598,35 @@ int launch_backprop_jacobian(const void* coeffs, const void* knots, int64_t n_in
                              const float* step_dt, int64_t n_steps,
                              const int64_t* node_ptr, const int64_t* node_out, const float* node_weight, void* grad_z0,
                              void* grad_W, void* grad_b, int64_t B, int64_t C, int64_t H, const int64_t* stage_index,
-                             const float* stage_frac, float* partial, hipStream_t s) {
+                             const float* stage_frac, float* partial, void* grad_coeffs, hipStream_t s) {
   const Dims dims{(int)H, (int)C};
   const unsigned blocks = (unsigned)((B + 127) / 128);
-  if (act == CDE_ACT_TANH) {
+  if (act != CDE_ACT_NONE && act != CDE_ACT_TANH) return CDE_ERR_UNSUPPORTED;
+  if (act == CDE_ACT_TANH || grad_coeffs) {
     const size_t lds_act = (size_t)BP_ACT_LDS_FLOATS * sizeof(float);
-#define CDE_BPA(D)                                                                                                   \
+#define CDE_BPA(D, A, X)                                                                                             \
   do {                                                                                                               \
-    (void)hipFuncSetAttribute((const void*)rk4_backprop_act<D>, hipFuncAttributeMaxDynamicSharedMemorySize,          \
+    (void)hipFuncSetAttribute((const void*)rk4_backprop_act<D, A, X>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                               (int)lds_act);                                                                         \
-    rk4_backprop_act<D><<<blocks, 256, lds_act, s>>>(                                                                \
+    rk4_backprop_act<D, A, X><<<blocks, 256, lds_act, s>>>(                                                          \
         (const float*)coeffs, (const float*)knots, n_intervals, (const float*)W, (const float*)bias,                 \
         (const float*)stages, (const float*)grad_out, n_out, step_dt, n_steps, node_ptr, node_out, node_weight,      \
-        (float*)grad_z0, partial, B, stage_index, stage_frac, dims);                                                 \
+        (float*)grad_z0, partial, B, stage_index, stage_frac, dims, (float*)grad_coeffs);                            \
   } while (0)
-    if (degree == CDE_PATH_CUBIC) CDE_BPA(CDE_PATH_CUBIC);
-    else if (degree == CDE_PATH_LINEAR) CDE_BPA(CDE_PATH_LINEAR);
+#define CDE_BPA_D(D)                                                                                                 \
+  do {                                                                                                               \
+    if (grad_coeffs) { if (act == CDE_ACT_TANH) CDE_BPA(D, CDE_ACT_TANH, true); else CDE_BPA(D, CDE_ACT_NONE, true); } \
+    else CDE_BPA(D, CDE_ACT_TANH, false);                                                                            \
+  } while (0)
+    if (degree == CDE_PATH_CUBIC) CDE_BPA_D(CDE_PATH_CUBIC);
+    else if (degree == CDE_PATH_LINEAR) CDE_BPA_D(CDE_PATH_LINEAR);
     else return CDE_ERR_UNSUPPORTED;
+#undef CDE_BPA_D
 #undef CDE_BPA
     const int rca = check_launch();
     if (rca != CDE_OK) return rca;
     return launch_reduce_partials(partial, (B + 31) / 32, grad_W, grad_b, (int)H, (int)C, s);
   }
-  if (act != CDE_ACT_NONE) return CDE_ERR_UNSUPPORTED;
   {
     const char* e = getenv("CDE_K3D_WAVES");          // 1: this file's one-wave kernel, 2: the pair form (tests compare the two)
     if (e ? e[0] == '2' : K3D_PAIR_DEFAULT)

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2) void rk4_adjoint_
     const float* __restrict__ stage_frac, float* __restrict__ U, float* __restrict__ G2, float* __restrict__ G1,
     float* __restrict__ Z, int64_t B, Dims dims, float* __restrict__ grad_coeffs = nullptr,
     const float* __restrict__ stages = nullptr, int64_t n_steps_total = 0) {
-  static_assert(!BACKPROP || (!DCOEFF && !SPLIT), "the reverse-mode form: one wave per tile, no control gradients");
+  static_assert(!BACKPROP || !SPLIT, "the reverse-mode form: one wave per tile");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   {
     const float4* src = reinterpret_cast<const float4*>(img);
@@ -598,23 +598,27 @@ template <typename TT>
 int launch_mlp_backprop_sweep(const void* coeffs, const void* knots, int64_t n_intervals, int degree, int act,
                               const float* img, const void* stages, int64_t n_steps_total, void* g_state, const void* grid,
                               int64_t k_begin, int64_t k_end, const int64_t* stage_index, const void* stage_frac, void* U,
-                              void* G2, void* G1, void* Z, int64_t B, int64_t C, int64_t H, hipStream_t s) {
+                              void* G2, void* G1, void* Z, int64_t B, int64_t C, int64_t H, void* grad_coeffs,
+                              hipStream_t s) {
   if (k_end <= k_begin) return CDE_OK;
+  if (grad_coeffs && C > MC) return CDE_ERR_UNSUPPORTED;
   const Dims dims{(int)H, (int)C};
   const unsigned blocks = (unsigned)((B + 127) / 128);
   const size_t lds = (size_t)ADJ_LDS_FLOATS * sizeof(float);
-#define CDE_BP_L(D, A, CTV)                                                                                        \
+#define CDE_BP_L(D, A, X, CTV)                                                                                     \
   do {                                                                                                             \
-    (void)hipFuncSetAttribute((const void*)rk4_adjoint_mlp_sweep<TT, D, A, false, CTV, false, true>,               \
+    (void)hipFuncSetAttribute((const void*)rk4_adjoint_mlp_sweep<TT, D, A, X, CTV, false, true>,                   \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
-    rk4_adjoint_mlp_sweep<TT, D, A, false, CTV, false, true><<<blocks, 512, lds, s>>>(                             \
+    rk4_adjoint_mlp_sweep<TT, D, A, X, CTV, false, true><<<blocks, 512, lds, s>>>(                                 \
         (const float*)coeffs, (const float*)knots, n_intervals, img, nullptr, (float*)g_state, (const TT*)grid,    \
         k_begin, k_end, stage_index, (const float*)stage_frac, (float*)U, (float*)G2, (float*)G1, (float*)Z, B,    \
-        dims, nullptr, (const float*)stages, n_steps_total);                                                       \
+        dims, (float*)grad_coeffs, (const float*)stages, n_steps_total);                                           \
   } while (0)
 #define CDE_BP(D, A)                                                                                               \
   do {                                                                                                             \
-    if (C > MC) CDE_BP_L(D, A, 16); else CDE_BP_L(D, A, MC);                                                       \
+    if (C > MC) CDE_BP_L(D, A, false, 16);                                                                         \
+    else if (grad_coeffs) CDE_BP_L(D, A, true, MC);                                                                \
+    else CDE_BP_L(D, A, false, MC);                                                                                \
   } while (0)
   if (degree != CDE_PATH_CUBIC && degree != CDE_PATH_LINEAR) return CDE_ERR_UNSUPPORTED;
   if (act == CDE_ACT_NONE) {
@@ -628,10 +632,10 @@ int launch_mlp_backprop_sweep(const void* coeffs, const void* knots, int64_t n_i
 }
 template int launch_mlp_backprop_sweep<float>(const void*, const void*, int64_t, int, int, const float*, const void*, int64_t,
                                               void*, const void*, int64_t, int64_t, const int64_t*, const void*, void*, void*,
-                                              void*, void*, int64_t, int64_t, int64_t, hipStream_t);
+                                              void*, void*, int64_t, int64_t, int64_t, void*, hipStream_t);
 template int launch_mlp_backprop_sweep<double>(const void*, const void*, int64_t, int, int, const float*, const void*, int64_t,
                                                void*, const void*, int64_t, int64_t, const int64_t*, const void*, void*, void*,
-                                               void*, void*, int64_t, int64_t, int64_t, hipStream_t);
+                                               void*, void*, int64_t, int64_t, int64_t, void*, hipStream_t);
 
 template int launch_mlp_adjoint_sweep<float>(const void*, const void*, int64_t, int, int, const float*, void*, void*,
                                              const void*, int64_t, int64_t, const int64_t*, const void*, void*, void*,

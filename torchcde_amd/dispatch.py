@@ -22,7 +22,8 @@ Request = collections.namedtuple("Request", [
     "adjoint",           # cdeint's adjoint flag
     "wants_grad",        # something requires a gradient through the solve
     "wants_t",           # ... the output times do
-    "wants_control",     # ... the control's coefficient / knot tensors do (through adjoint_params)
+    "wants_control",     # ... the control's coefficient / knot tensors do (through adjoint_params; adjoint=False: any of them
+                         #     that requires a gradient -- autograd reaches it through X.derivative)
     "params",            # adjoint_params: "default" | "own" (the field's parameters, all of them for mlp2, plus control
                          #                 tensors) | "foreign" (anything else)
     "adjoint_method_ok", # adjoint_method absent or equal to the forward method
@@ -33,7 +34,7 @@ Request = collections.namedtuple("Request", [
     "shared",            # torchcde_amd.distributed.shared_step_control is active
     "narrow_control",    # the control has at most 8 channels (control gradients of a two-layer field)
     "backprop_ok",       # affine: the field sits on the 32 x 8 tiles (float32, identity or tanh); mlp2: it fits the two-layer
-                         # tiles; and no control tensor requires a gradient -- what the reverse-mode sweeps (adjoint=False) take
+                         # tiles -- what the reverse-mode sweeps (adjoint=False) take
     "identity",          # affine field without an activation (the README's): with backprop_ok, what the midpoint / euler forms
                          # of K2 / K3p take
 ])
@@ -81,6 +82,8 @@ def select_path(q):
         return _stepwise("method %r has no fused kernel (rk4, midpoint, euler and dopri5 have)" % (q.method,))
     if q.wants_grad and not q.adjoint:
         if q.backprop_ok and q.method == "rk4" and q.options_ok and not q.wants_t:
+            if q.kind == "mlp2" and q.wants_control and not q.narrow_control:
+                return _stepwise("adjoint=False with control gradients of a two-layer field with more than 8 channels")
             return Choice("rk4_backprop" if q.kind == "affine" else "mlp_rk4_backprop", "")
         return _stepwise("adjoint=False with gradients: backpropagation through the solver's own operations (fused under rk4 "
                          "for the one-layer fields on the 32 x 8 tiles and for the two-layer field)")
