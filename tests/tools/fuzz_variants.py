@@ -39,7 +39,8 @@ def draw(rng):
     return dict(kind=kind, H=H, C=C, width=rng.choice([8, 32, 100, 128]), final_tanh=rng.random() < 0.6,
                 B=rng.choice([1, 2, 15, 16, 17, 33, 100, 257]), L=rng.choice([2, 3, 5, 12, 30]),
                 degree=rng.choice([1, 3]), irregular=rng.random() < 0.5, extra_dim=rng.random() < 0.2,
-                mode=rng.choice(["rk4", "rk4", "dopri5_forward", "default_call", "midpoint", "euler", "rk4_backprop"]),
+                mode=rng.choice(["rk4", "rk4", "dopri5_forward", "default_call", "midpoint", "euler", "rk4_backprop",
+                                 "rk4_backprop_control"]),
                 step=rng.choice([1.0, 0.5, 0.37]), n_out=rng.choice([2, 3, 5]), seed=rng.randrange(10 ** 6))
 
 
@@ -54,6 +55,8 @@ def run(cfg, variant, dev):
     B, L, C, H = cfg["B"], cfg["L"], cfg["C"], cfg["H"]
     lead = (2, B) if cfg["extra_dim"] else (B,)
     x = (torch.randn(*lead, L, C, generator=gen) * 0.3).cumsum(-2).to(dev)
+    if cfg["mode"] == "rk4_backprop_control":         # the data require a gradient: fit -> control -> solve (adjoint=False) -> loss
+        x.requires_grad_(True)
     t = ((torch.rand(L, generator=gen) + 0.4).cumsum(0) if cfg["irregular"] else torch.arange(L, dtype=torch.float32)).to(dev)
     if cfg["degree"] == 3:
         X = cde.CubicSpline(cde.hermite_cubic_coefficients_with_backward_differences(x, t), t)
@@ -70,7 +73,7 @@ def run(cfg, variant, dev):
         out = cde.cdeint(X, func, z0, t_out, method="rk4", options=dict(step_size=cfg["step"] * spacing), variant=variant)
     elif cfg["mode"] in ("midpoint", "euler"):        # round 5: K2 / K3p with two stages / one per step (affine field on the tiles)
         out = cde.cdeint(X, func, z0, t_out, method=cfg["mode"], options=dict(step_size=cfg["step"] * spacing), variant=variant)
-    elif cfg["mode"] == "rk4_backprop":               # round 5: adjoint=False, reverse mode through the steps (K3d) vs autograd
+    elif cfg["mode"] in ("rk4_backprop", "rk4_backprop_control"):   # round 5: adjoint=False, reverse mode through the steps (K3d) vs autograd
         out = cde.cdeint(X, func, z0, t_out, method="rk4", adjoint=False, options=dict(step_size=cfg["step"] * spacing),
                          variant=variant)
     elif cfg["mode"] == "dopri5_forward":
@@ -83,7 +86,7 @@ def run(cfg, variant, dev):
         out = cde.cdeint(X, func, z0, t_out, rtol=1e-6, atol=1e-8, options=opts,
                          adjoint_options=dict(norm="seminorm", **opts), variant=variant)
     (out * w).sum().backward()
-    return [out.detach(), z0.grad] + [p.grad for p in func.parameters()]
+    return [out.detach(), z0.grad] + [p.grad for p in func.parameters()] + ([x.grad] if x.requires_grad else [])
 
 
 def main():
@@ -98,7 +101,7 @@ def main():
         cfg = draw(rng)
         try:
             got, want = run(cfg, "auto", dev), run(cfg, "generic", dev)
-            tol = 2e-3 if cfg["mode"] in ("rk4", "midpoint", "euler", "rk4_backprop") else 2e-2
+            tol = 2e-3 if cfg["mode"] in ("rk4", "midpoint", "euler", "rk4_backprop", "rk4_backprop_control") else 2e-2
             for k, (g, r) in enumerate(zip(got, want)):
                 scale = max(r.abs().max().item(), 1e-3)
                 err = (g - r).abs().max().item()
