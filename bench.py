@@ -23,6 +23,7 @@ which keep every SIMD busy down to 16 series per CU.  ``--scaling weak`` keeps 3
 ranks on 127.0.0.1.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -286,7 +287,8 @@ def backprop_mode(cde, X, func, z0, steps=10):
         for p in params:
             p.grad = None
         cde.cdeint(X, func, z, X.interval, **kw)[:, -1].sum().backward()
-    for _ in range(3):
+    gc.collect()                       # a full collection of a torch process takes ~50 ms: not inside a 66 ms timed region,
+    for _ in range(5):                 # and before the warm-up (the GPU idles meanwhile and drops its clocks)
         both()
     torch.cuda.synchronize()
     front.event_log = []
@@ -300,6 +302,9 @@ def backprop_mode(cde, X, func, z0, steps=10):
     bwd = [a.elapsed_time(b) for kind, a, b in log if kind == "backprop"]
     B = z0.size(0)
     bwd_ms = sum(bwd) / max(len(bwd), 1)
+    if os.environ.get("CDE_BENCH_DEBUG"):
+        _log("backprop_mode: wall %.3f fwd %s bwd %s dispatch %s" % (wall, [round(v, 2) for v in fwd], [round(v, 2) for v in bwd],
+                                                                   front.last_dispatch()))
     flop = B * N_EVAL * (2 * 2 * H * H * C + 2 * H * H + 2 * H * C)       # J's GEMM + dL/dW on the matrix pipe, J^T kb + dL/db
     return {"forward_backward_ms": wall, "series_per_s": B / (wall * 1e-3),
             "forward_with_stage_stores_kernel_ms": sum(fwd) / max(len(fwd), 1), "backward_kernel_ms": bwd_ms,
@@ -795,6 +800,12 @@ def main():
         return out
 
     _log("hermite fit %.3f ms; warm-up" % fit_ms)
+    # the interpreter's own full collection (~50 ms in a torch process) is not part of the step being timed: run it now, BEFORE
+    # the warm-up (the GPU idles meanwhile and needs the warm-up steps to come back to its clocks)
+    gc.collect()
+    gc.freeze()                                  # (what survives is permanent: later collections only look at new objects)
+    for _ in range(int(os.environ.get("CDE_BENCH_PREWARM", "5"))):   # untimed, before the contract's W warm-up steps: back to full clocks
+        step()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
