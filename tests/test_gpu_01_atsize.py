@@ -49,6 +49,51 @@ def test_config3_backprop_mode_full_batch_against_the_oracle(native):
     _close(func.linear.bias.grad, ref_gb, 1e-3, 1e-4 * ref_gb.abs().max().item())
 
 
+def test_config3_backprop_mode_control_gradients_at_size(native):
+    """The same solve with a coefficient tensor that requires a gradient (adjoint=False: autograd reaches the control through
+    X.derivative at every stage, reference solver.py:117-135; test/test_tricks.py:21-106) AT THE CONFIGURED SIZE: all
+    32768 x 127 x 32 entries of dL/d(coeffs) come out of the fused reverse-mode sweep (cde_rk4_backprop_linear_dcontrol).
+    Checked (a) against autograd through the float64 oracle on four 256-series slices spread over the batch (first and last
+    tiles included): the coefficient gradient and dL/dz0 of those series; (b) for the whole batch dL/dz0, dL/dW, dL/db against
+    the plain adjoint=False run above (K3d's shared-Jacobian kernel, itself checked against the oracle at this size)."""
+    B, L, C, H = 32768, 128, 8, 32
+    x = make_series(B, L, C, seed=0)
+    z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(0))
+    kw = dict(method="rk4", options=dict(step_size=1.0), adjoint=False)
+    c32 = oracle_interp.hermite_bdiff_coeffs(x)
+    func = LinearField(H, C, scale=0.25, seed=0).to(DEV)
+    cd = c32.to(DEV).requires_grad_(True)
+    z = z0.to(DEV).requires_grad_(True)
+    out = native.cdeint(native.CubicSpline(cd), func, z, torch.tensor([0., L - 1.], device=DEV), **kw)
+    _expect_dispatch("affine_rk4_backprop_control", out)
+    out[:, -1].sum().backward()
+    assert cd.grad.shape == cd.shape and bool(torch.isfinite(cd.grad).all()) and not bool(cd.grad[..., :C].any())
+    threads = torch.get_num_threads()
+    torch.set_num_threads(_oracle_threads())
+    try:
+        f64 = LinearField(H, C, torch.float64, scale=0.25, seed=0)
+        for lo in (0, 11000, 21333, B - 256):
+            co = c32[lo:lo + 256].double().requires_grad_(True)
+            zo = z0[lo:lo + 256].double().requires_grad_(True)
+            Xo = oracle_interp.CubicPath(co)
+            o = oracle_cde.cdeint(Xo, f64, zo, Xo.interval, **kw)
+            o[:, -1].sum().backward()
+            _close(out[lo:lo + 256], o.detach(), 1e-4, 1e-5)
+            _close(z.grad[lo:lo + 256], zo.grad, 1e-3, 1e-5)
+            _close(cd.grad[lo:lo + 256], co.grad, 1e-3, 1e-4 * co.grad.abs().max().item())
+    finally:
+        torch.set_num_threads(threads)
+    func2 = LinearField(H, C, scale=0.25, seed=0).to(DEV)
+    z2 = z0.to(DEV).requires_grad_(True)
+    out2 = native.cdeint(native.CubicSpline(c32.to(DEV)), func2, z2, torch.tensor([0., L - 1.], device=DEV), **kw)
+    _expect_dispatch("affine_rk4_backprop", out2)
+    out2[:, -1].sum().backward()
+    assert torch.equal(out2, out.detach())
+    _close(z.grad, z2.grad, 1e-4, 5e-6 * z2.grad.abs().max().item())       # (two float32 kernels: 9e-6 apart at most)
+    for a, b in ((func.linear.weight.grad, func2.linear.weight.grad), (func.linear.bias.grad, func2.linear.bias.grad)):
+        _close(a, b, 1e-4, 1e-5 * b.abs().max().item())
+
+
 def test_config4_shard_default_training_call_at_size_against_the_oracle(native):
     """VERDICT round 3, item 1a.  BASELINE configs[3], one GPU's shard AT ITS CONFIGURED SIZE through the reference's
     training call (solver.py:195-203,226: dopri5 + adjoint): 32768 series, L = 128, LinearInterpolation, jump_t = the knots
