@@ -312,7 +312,7 @@ int cde_mlp_grad_reduce(const void* G, const void* X, int64_t rows, int layer, v
  *                                 gradient between output intervals, as torchdiffeq does); `grad_coeffs` is NULL or a
  *                                 caller-zeroed buffer shaped like `coeffs` that accumulates dL/dcoeffs over the calls
  *                                 (as cde_rk4_adjoint_linear_dcontrol)
- * f32, width <= 128, (H <= 32, C <= 8) or (H <= 16, C <= 16) as K2m; `grad_coeffs` only with C <= 8.  G2's
+ * f32, width <= 128, (H <= 32, C <= 8) or (H <= 16, C <= 16) as K2m; `grad_coeffs` on both tile layouts (C > 8: the one-wave-per-tile form at every batch size).  G2's
  * columns are (hidden unit)*8 + channel for C <= 8 and (hidden unit)*16 + channel for 8 < C <= 16.
  * ------------------------------------------------------------------------------------------- */
 size_t cde_rk4_adjoint_mlp_workspace_bytes(int64_t n_sgrid);
@@ -469,8 +469,8 @@ int cde_rk4_backprop_mlp_sweep(const void* coeffs, const void* knots, int64_t n_
                                const void* stages, void* g_state, const void* grid, int64_t n_grid, int64_t k_begin,
                                int64_t k_end, void* U, void* G2, void* G1, void* Z, int64_t B, int64_t C, int64_t H,
                                int dtype, int time_dtype, const void* workspace, size_t workspace_bytes, void* stream);
-/* ... with the gradient w.r.t. the control's coefficient tensor (C <= 8, else CDE_ERR_UNSUPPORTED; `grad_coeffs` as for
- * cde_rk4_backprop_linear_dcontrol: zeroed by the caller before the first chunk, accumulated by every chunk's call) */
+/* ... with the gradient w.r.t. the control's coefficient tensor (`grad_coeffs` as for cde_rk4_backprop_linear_dcontrol: zeroed by
+ * the caller before the first chunk, accumulated by every chunk's call) */
 int cde_rk4_backprop_mlp_sweep_dcontrol(const void* coeffs, const void* knots, int64_t n_intervals, int degree, int act,
                                         const void* stages, void* g_state, const void* grid, int64_t n_grid, int64_t k_begin,
                                         int64_t k_end, void* U, void* G2, void* G1, void* Z, void* grad_coeffs, int64_t B,

@@ -40,8 +40,7 @@ CASES = {
                                           ("mfma_shape", "variant_generic", "narrow_control")),
     "two_layer_rk4_backprop":    (dict(_MLP, adjoint=False), "mlp_rk4_backprop", ("narrow_control",)),
     "affine_rk4_backprop_control": (dict(adjoint=False, wants_control=True), "rk4_backprop", ("narrow_control",)),
-    "two_layer_rk4_backprop_control": (dict(_MLP, adjoint=False, wants_control=True), "mlp_rk4_backprop", ()),
-    "two_layer_backprop_wide_control": (dict(_MLP, adjoint=False, wants_control=True, narrow_control=False), "stepwise", ()),
+    "two_layer_rk4_backprop_control": (dict(_MLP, adjoint=False, wants_control=True), "mlp_rk4_backprop", ("narrow_control",)),
     # ------------------------------------------------------------------ torchdiffeq's other fixed-grid methods
     "affine_midpoint":           (dict(method="midpoint"), "fixed_grid", ("narrow_control",)),
     "affine_euler":              (dict(method="euler"), "fixed_grid", ("narrow_control",)),
@@ -50,8 +49,8 @@ CASES = {
     "midpoint_tanh":             (dict(method="midpoint", identity=False), "stepwise", ()),
     # ------------------------------------------------------------------ the examples' two-layer field
     "two_layer_rk4":             (dict(_MLP), "mlp_rk4_adjoint", ("narrow_control",)),
-    "two_layer_rk4_control":     (dict(_MLP, wants_control=True, params="own"), "mlp_rk4_adjoint", ("wants_t",)),
-    "two_layer_rk4_times":       (dict(_MLP, wants_t=True), "mlp_rk4_adjoint", ()),
+    "two_layer_rk4_control":     (dict(_MLP, wants_control=True, params="own"), "mlp_rk4_adjoint", ("wants_t", "narrow_control")),
+    "two_layer_rk4_times":       (dict(_MLP, wants_t=True), "mlp_rk4_adjoint", ("narrow_control",)),
     "two_layer_dopri5":          (dict(_MLP, method="dopri5"), "mlp_dopri5_adjoint", ("narrow_control", "shared")),
     "two_layer_dopri5_times":    (dict(_MLP, method="dopri5", wants_t=True), "mlp_dopri5_adjoint", ("narrow_control",)),
     "two_layer_beyond_tiles":    (dict(_MLP, tiles_ok=False), "stepwise", ("narrow_control",)),

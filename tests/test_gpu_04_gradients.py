@@ -75,7 +75,8 @@ def test_data_gradient_through_fit_and_solve(native):
     _close(xd.grad, x64.grad, 1e-3, 1e-3 * x64.grad.abs().max().item())
 
 
-@pytest.mark.parametrize("H,C,width,degree", [(32, 8, 128, 3), (12, 5, 40, 1)])
+@pytest.mark.parametrize("H,C,width,degree", [(32, 8, 128, 3), (12, 5, 40, 1),
+                                              (16, 14, 100, 3), (16, 16, 64, 1)])    # (the 16 x 16 tile layout: config 5's shape)
 def test_two_layer_field_gradient_wrt_control_coefficients(native, H, C, width, degree):
     """adjoint_params = the four layer parameters + the coefficient tensor, two-layer field: dL/dcoeffs accumulated by
     the K3m sweep (several chunk launches: state and partial row gradients carried across them) vs the float64 oracle."""
@@ -396,13 +397,14 @@ def test_control_gradients_are_not_dropped_with_a_frozen_field(native):
         _close(got["dopri5"], got["rk4"], 0.1, 1e-2 * got["rk4"].abs().max().item())
 
 
+@pytest.mark.parametrize("H,C,width", [(32, 8, 128), (16, 14, 100)])
 @pytest.mark.parametrize("degree", [3, 1])
-def test_two_layer_rk4_output_time_gradients(native, degree):
+def test_two_layer_rk4_output_time_gradients(native, degree, H, C, width):
     """Output-time gradients of the examples' two-layer model under rk4, fused (K2m + K3m): dL/dt_i = f . dL/dz_i on the
     host, dL/dt_0 from the control gradient the sweep accumulates (cubic control) or without it (piecewise-linear: no
-    d2X/dt2 term) -- against the float64 oracle's odeint_adjoint (torchdiffeq's time_vjps restated)."""
-    x, knots, coeffs, z0, t_out, lw = _time_grad_case(torch.float32, B=45)
-    H, C, width = 32, 8, 128
+    d2X/dt2 term) -- against the float64 oracle's odeint_adjoint (torchdiffeq's time_vjps restated).  Both tile layouts
+    (32 units x 8 channels; 16 x 16 with the 14 channels of config 5's logsignature control)."""
+    x, knots, coeffs, z0, t_out, lw = _time_grad_case(torch.float32, B=45, C=C, H=H)
     f64 = _TwoLayerField(H, C, width, torch.float64, seed=4)
     Xo = (oracle_interp.CubicPath(coeffs.double(), knots.double()) if degree == 3
           else oracle_interp.LinearPath(x.double(), knots.double()))
@@ -433,13 +435,13 @@ def test_two_layer_rk4_output_time_gradients(native, degree):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("H,C,width", [(32, 8, 128), (16, 14, 100)])
 @pytest.mark.parametrize("degree", [3, 1])
-def test_two_layer_rk4_knot_time_and_control_gradients(native, degree):
+def test_two_layer_rk4_knot_time_and_control_gradients(native, degree, H, C, width):
     """reference test/test_tricks.py:21-49 with the examples' two-layer model under rk4: adjoint_params = the model's
     parameters + the control's tensors -- knot times, and (piecewise-linear control) the knot values -- with output times
-    that require a gradient as well; nothing runs step-wise.  Against the float64 oracle's odeint_adjoint."""
-    x, knots, coeffs, z0, t_out, lw = _time_grad_case(torch.float32, B=45)
-    H, C, width = 32, 8, 128
+    that require a gradient as well; nothing runs step-wise.  Against the float64 oracle's odeint_adjoint.  Both tile layouts."""
+    x, knots, coeffs, z0, t_out, lw = _time_grad_case(torch.float32, B=45, C=C, H=H)
     f64 = _TwoLayerField(H, C, width, torch.float64, seed=4)
     kn = knots.double().requires_grad_(True)
     xo = x.double().requires_grad_(True)

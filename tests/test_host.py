@@ -796,11 +796,9 @@ def test_dispatch_table_is_exhaustively_consistent():
                     assert c.path.startswith("mlp_") == (kind == "mlp2")
                     assert ("forward" in c.path) <= (not f["wants_grad"])    # forward-only kernels: nothing to differentiate
                     if c.path in ("rk4_backprop", "mlp_rk4_backprop"):
-                        # adjoint=False: reverse mode through the steps -- no output-time gradients; control gradients on the
-                        # 8-channel tiles
+                        # adjoint=False: reverse mode through the steps -- no output-time gradients
                         assert f["wants_grad"] and not f["adjoint"] and f["backprop_ok"] and not f["wants_t"]
                         assert f["mfma_shape"] == (kind == "affine")
-                        assert not f["wants_control"] or kind == "affine" or f["narrow_control"]
                         continue
                     if f["wants_grad"]:
                         assert f["adjoint"] and f["adjoint_method_ok"] and f["adjoint_options_ok"] and params != "foreign"
@@ -811,8 +809,8 @@ def test_dispatch_table_is_exhaustively_consistent():
                         assert not f["wants_control"] and not (f["wants_t"] and f["shared"])
                     if kind == "mlp2":
                         assert not f["variant_generic"]
-                        assert not f["wants_t"] or c.path == "mlp_dopri5_adjoint" or (method == "rk4" and f["narrow_control"])
-                        assert not f["wants_control"] or (f["narrow_control"] and method == "rk4")
+                        assert not f["wants_t"] or c.path == "mlp_dopri5_adjoint" or method == "rk4"
+                        assert not f["wants_control"] or method == "rk4"
                     if kind == "affine" and (f["wants_t"] or f["wants_control"]):
                         assert f["mfma_shape"] and (method == "rk4" or not f["wants_control"])
     assert n > 100000 and set(seen) == set(D.FUSED_PATHS) | {D.STEPWISE}       # every path is reachable
@@ -839,6 +837,9 @@ def test_dispatch_table_is_exhaustively_consistent():
     assert ask(kind="mlp2", mfma_shape=False, method="rk4", adjoint=False).path == "mlp_rk4_backprop"
     assert ask(method="rk4", adjoint=False, wants_control=True).path == "rk4_backprop"      # test/test_tricks.py:21-49, adjoint=False
     assert ask(kind="mlp2", mfma_shape=False, method="rk4", adjoint=False, wants_control=True).path == "mlp_rk4_backprop"
+    # the logsignature-shaped two-layer field (16 units x 14 channels): time and control gradients on its tile layout too
+    assert ask(kind="mlp2", mfma_shape=False, method="rk4", wants_control=True, params="own", narrow_control=False).path == "mlp_rk4_adjoint"
+    assert ask(kind="mlp2", mfma_shape=False, method="rk4", wants_t=True, narrow_control=False).path == "mlp_rk4_adjoint"
     assert ask(method="midpoint").path == "fixed_grid"                          # test/test_cdeint.py:49-63
     assert ask(method="euler", wants_grad=False).path == "fixed_grid"
     for kw, word in ((dict(kind=None), "recognised"), (dict(method="midpoint", kind="mlp2", mfma_shape=False), "midpoint"),
@@ -846,9 +847,6 @@ def test_dispatch_table_is_exhaustively_consistent():
                      (dict(adjoint=False), "adjoint=False"), (dict(method="rk4", adjoint=False, backprop_ok=False), "adjoint=False"), (dict(options_ok=False), "options"),
                      (dict(mfma_shape=False), "32 x 8"), (dict(wants_t=True, shared=True), "time"),
                      (dict(wants_control=True, params="own"), "control"),
-                     (dict(kind="mlp2", mfma_shape=False, method="rk4", wants_control=True, narrow_control=False), "8 channels"),
-                     (dict(kind="mlp2", mfma_shape=False, method="rk4", adjoint=False, wants_control=True, narrow_control=False),
-                      "8 channels"),
                      (dict(t_ok=False), "increasing"), (dict(params="foreign"), "adjoint_params"),
                      (dict(prod=True), "prod"), (dict(tiles_ok=False, mfma_shape=False), "tiles")):
         verdict = ask(**kw)

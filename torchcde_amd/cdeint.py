@@ -1504,8 +1504,8 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         extra_ok = all(isinstance(p, torch.Tensor) and p.untyped_storage().data_ptr() in control_ids for p in extra)
         complete = field is not None or all(any(p is o for p in given_params) for o in own)    # K3m / K4am: all four or none
         params_kind = "own" if (extra_ok and complete) else "foreign"
-        if field is None and any(p is X._t for p in extra) and not (method == "rk4" and C <= 8):
-            params_kind = "foreign"             # knot-time gradients of a two-layer solve: rk4 up to 8 channels, else step-wise
+        if field is None and any(p is X._t for p in extra) and method != "rk4":
+            params_kind = "foreign"             # knot-time gradients of a two-layer solve: under rk4, else step-wise
 
     fixed_keys, adaptive_keys = {"step_size"}, {"jump_t", "safety", "ifactor", "dfactor"}
     # ONE normalised view of the options for the fused paths (the step-wise path gets them verbatim, like torchdiffeq):

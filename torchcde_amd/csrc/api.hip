@@ -652,7 +652,6 @@ static int rk4_backprop_mlp_sweep_impl(const void* coeffs, const void* knots, in
                                           void* grad_coeffs, int64_t B,
                                           int64_t C, int64_t H, int dtype, int time_dtype, const void* workspace,
                                           size_t workspace_bytes, void* stream) {
-  if (grad_coeffs && C > 8) return CDE_ERR_UNSUPPORTED;            // control gradients: the 8-channel tiles only
   if (B < 1 || C < 1 || H < 1 || n_intervals < 1 || k_begin < 0 || k_end < k_begin || k_end > n_grid - 1) return CDE_ERR_SHAPE;
   if (dtype != CDE_F32) return dtype == CDE_F64 ? CDE_ERR_UNSUPPORTED : CDE_ERR_DTYPE;
   if (!cde::mlp_shape_ok(C, H, 1)) return CDE_ERR_UNSUPPORTED;
@@ -682,8 +681,8 @@ extern "C" int cde_rk4_backprop_mlp_sweep(const void* coeffs, const void* knots,
                                      G2, G1, Z, nullptr, B, C, H, dtype, time_dtype, workspace, workspace_bytes, stream);
 }
 
-// ... and with the gradient w.r.t. the control's coefficient tensor (C <= 8; `grad_coeffs` zeroed by the caller before the
-// first chunk, accumulated by every chunk's launch)
+// ... and with the gradient w.r.t. the control's coefficient tensor (`grad_coeffs` zeroed by the caller before the first chunk,
+// accumulated by every chunk's launch)
 extern "C" int cde_rk4_backprop_mlp_sweep_dcontrol(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
                                                    int act, const void* stages, void* g_state, const void* grid,
                                                    int64_t n_grid, int64_t k_begin, int64_t k_end, void* U, void* G2, void* G1,

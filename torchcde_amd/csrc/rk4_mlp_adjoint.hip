@@ -66,8 +66,9 @@ __global__ void mlp_adj_image_kernel(const float* __restrict__ W1, const float* 
 }
 
 // DCOEFF: also accumulate dL/d(control coefficients) into `grad_coeffs` (zeroed by the caller, layout of `coeffs`),
-// as K3a does: d(a.f)/d(dX_c) = sum_h a_h act(Y2)_hc, here summed in-lane over the lane's 8 hidden units and then
-// over the four lane quarters with two shuffles; quarter q carries channels 2q, 2q+1 to the coefficient row.
+// as K3a does: d(a.f)/d(dX_c) = sum_h a_h act(Y2)_hc, here summed in-lane over the lane's hidden units and then
+// over the four lane quarters with two shuffles; quarter q carries channels (CT/4) q .. (CT/4) q + CT/4 - 1 to the
+// coefficient row (the 16-channel layout, round 5: the one-wave-per-tile form only).
 // SPLIT (at most one tile per CU): a 256-thread workgroup whose four waves carry ONE tile through the sweep -- layer 1,
 // dL/dY1, va and the RK bookkeeping redundantly and bit-identically, the unit groups of layer 2 / dL/dY2 / gu split four
 // ways, partial sums added in a fixed wave order through a 9 KB LDS window (cde_mlp_adj.h: mlp_split_allreduce, as in
@@ -95,7 +96,8 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2) void rk4_adjoint_
   }
   __syncthreads();
   constexpr int NB = CT / 4, NP = 16 / NB;      // channel blocks per unit group, unit groups (of 4 hidden units)
-  static_assert(!(DCOEFF && CT != MC), "control gradients: 8-channel layout only");
+  constexpr int NJ = CT / 4;                    // control gradients: channels NJ q .. NJ q + NJ - 1 go to the coefficient row with quarter q
+  static_assert(!(DCOEFF && CT != MC && SPLIT), "control gradients of the 16-channel layout: one wave per tile");
   const int Hr = dims.H, Cr = dims.C;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, q = lane >> 4;
@@ -125,13 +127,15 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2) void rk4_adjoint_
   float frac = stage_frac[e_first];
   Row<DEGREE, CT> row = load_row<DEGREE, CT>(coeffs, sc, n_intervals, idx, Cr);
 
-  // dL/d(coefficient row in use) for channels 2q, 2q+1: cubic (b, 2c, 3d), linear (left knot, right knot)
-  float gc0[2] = {0.f, 0.f}, gc1[2] = {0.f, 0.f}, gc2[2] = {0.f, 0.f};
+  // dL/d(coefficient row in use) for channels NJ q .. NJ q + NJ - 1: cubic (b, 2c, 3d), linear (left knot, right knot)
+  float gc0[NJ], gc1[NJ], gc2[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) { gc0[j] = 0.f; gc1[j] = 0.f; gc2[j] = 0.f; }
   auto flush_control_grad = [&](int64_t at) {
     if constexpr (DCOEFF) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int c = 2 * q + j;
+      for (int j = 0; j < NJ; ++j) {
+        const int c = NJ * q + j;
         if (valid && c < Cr) {
           if (DEGREE == CDE_PATH_CUBIC) {
             float* g = grad_coeffs + (series * n_intervals + at) * 4 * Cr;
@@ -226,7 +230,9 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2) void rk4_adjoint_
 #pragma unroll
       for (int T1 = 0; T1 < 8; ++T1) gu[T1] = f32x4{0.f, 0.f, 0.f, 0.f};
       f32x4 fa = {0.f, 0.f, 0.f, 0.f}, fb = fa;
-      float gdx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // d(a.f)/d(dX_c), this lane's hidden units (DCOEFF)
+      float gdx[CT];                                                 // d(a.f)/d(dX_c), this lane's hidden units (DCOEFF)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) gdx[c] = 0.f;
 #pragma unroll
       for (int P = 0; P < NP; ++P) {                                 // unit group P: 4 hidden units x CT channels = NB tiles
         if (SPLIT && P / (NP / 4) != pw) continue;                   // (wave-uniform: another wave's group)
@@ -292,7 +298,7 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2) void rk4_adjoint_
         mlp_split_allreduce(xbuf, pw, lane, gu[4], gu[5], nullptr);
         mlp_split_allreduce(xbuf, pw, lane, gu[6], gu[7], nullptr);
         mlp_split_allreduce(xbuf, pw, lane, fa, fb, nullptr);
-        if constexpr (DCOEFF) {
+        if constexpr (DCOEFF && CT == MC) {
           f32x4 g03 = {gdx[0], gdx[1], gdx[2], gdx[3]}, g47 = {gdx[4], gdx[5], gdx[6], gdx[7]};
           mlp_split_allreduce(xbuf, pw, lane, g03, g47, nullptr);
           gdx[0] = g03[0]; gdx[1] = g03[1]; gdx[2] = g03[2]; gdx[3] = g03[3];
@@ -300,14 +306,14 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2) void rk4_adjoint_
         }
       }
       if constexpr (DCOEFF) {
-        float mine[2];
+        float mine[NJ];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          // sum over the four lane quarters (lanes n, n+16, n+32, n+48), then quarter q keeps channels 2q, 2q+1
+        for (int j = 0; j < NJ; ++j) {
+          // sum over the four lane quarters (lanes n, n+16, n+32, n+48), then quarter q keeps channels NJ q .. NJ q + NJ - 1
           float v[4];
 #pragma unroll
           for (int qq = 0; qq < 4; ++qq) {
-            float x = gdx[2 * qq + j];
+            float x = gdx[NJ * qq + j];
             x += __shfl_xor(x, 16, 64);
             x += __shfl_xor(x, 32, 64);
             v[qq] = x;
@@ -534,7 +540,9 @@ int launch_mlp_adjoint_sweep(const void* coeffs, const void* knots, int64_t n_in
   const int64_t s8_req = s8_env ? atoll(s8_env) : K3M_S8_MAX_TILES;       // (an override can only LOWER the measured limit)
   const int64_t s8_tiles = s8_req < 0 ? 0 : s8_req > K3M_S8_MAX_TILES ? K3M_S8_MAX_TILES : s8_req;
   const bool s8_shape = C <= MC && !grad_coeffs && !getenv("CDE_K3M_SPLIT4");
-  const bool split = tiles <= (s8_shape ? (s8_tiles > 512 ? s8_tiles : 512) : 512) && !getenv("CDE_K3M_NO_SPLIT");
+  // (control gradients of the 16-channel layout: the one-wave-per-tile form at every batch size)
+  const bool split = tiles <= (s8_shape ? (s8_tiles > 512 ? s8_tiles : 512) : 512) && !getenv("CDE_K3M_NO_SPLIT") &&
+                     !(grad_coeffs && C > MC);
   const unsigned blocks = split ? (unsigned)tiles : (unsigned)((B + 127) / 128);
   const unsigned threads = split ? 256 : 512;
   const size_t lds = (size_t)ADJ_LDS_FLOATS * sizeof(float) + (split ? (size_t)4 * 64 * 9 * sizeof(float) : 0);
@@ -569,9 +577,10 @@ int launch_mlp_adjoint_sweep(const void* coeffs, const void* knots, int64_t n_in
   } while (0)
 #define CDE_SWEEP_X(D, A, X)                                                                                       \
   do {                                                                                                             \
-    if (C > MC) {                              /* 16 channels x 16 units; control gradients: 8-channel layout only */ \
-      if (X) return CDE_ERR_UNSUPPORTED;                                                                           \
-      if (split) CDE_SWEEP_L(D, A, false, 16, true, nullptr); else CDE_SWEEP_L(D, A, false, 16, false, nullptr);   \
+    if (C > MC) {                              /* 16 channels x 16 units */                                        \
+      if (X) CDE_SWEEP_L(D, A, X, 16, false, (float*)grad_coeffs);                                                 \
+      else if (split) CDE_SWEEP_L(D, A, false, 16, true, nullptr);                                                 \
+      else CDE_SWEEP_L(D, A, false, 16, false, nullptr);                                                           \
       break;                                                                                                       \
     }                                                                                                              \
     if (split) CDE_SWEEP_L(D, A, X, MC, true, (float*)grad_coeffs);                                                \
@@ -601,7 +610,6 @@ int launch_mlp_backprop_sweep(const void* coeffs, const void* knots, int64_t n_i
                               void* G2, void* G1, void* Z, int64_t B, int64_t C, int64_t H, void* grad_coeffs,
                               hipStream_t s) {
   if (k_end <= k_begin) return CDE_OK;
-  if (grad_coeffs && C > MC) return CDE_ERR_UNSUPPORTED;
   const Dims dims{(int)H, (int)C};
   const unsigned blocks = (unsigned)((B + 127) / 128);
   const size_t lds = (size_t)ADJ_LDS_FLOATS * sizeof(float);
@@ -616,7 +624,7 @@ int launch_mlp_backprop_sweep(const void* coeffs, const void* knots, int64_t n_i
   } while (0)
 #define CDE_BP(D, A)                                                                                               \
   do {                                                                                                             \
-    if (C > MC) CDE_BP_L(D, A, false, 16);                                                                         \
+    if (C > MC) { if (grad_coeffs) CDE_BP_L(D, A, true, 16); else CDE_BP_L(D, A, false, 16); }                     \
     else if (grad_coeffs) CDE_BP_L(D, A, true, MC);                                                                \
     else CDE_BP_L(D, A, false, MC);                                                                                \
   } while (0)

@@ -32,7 +32,8 @@ Request = collections.namedtuple("Request", [
     "t_ok",              # t is strictly increasing
     "variant_generic",   # variant="generic" (tests: the independent kernels / the step-wise reference path)
     "shared",            # torchcde_amd.distributed.shared_step_control is active
-    "narrow_control",    # the control has at most 8 channels (control gradients of a two-layer field)
+    "narrow_control",    # the control has at most 8 channels (recorded; since round 5 no row depends on it: the two-layer sweeps
+                         # accumulate control gradients on both of their tile layouts)
     "backprop_ok",       # affine: the field sits on the 32 x 8 tiles (float32, identity or tanh); mlp2: it fits the two-layer
                          # tiles -- what the reverse-mode sweeps (adjoint=False) take
     "identity",          # affine field without an activation (the README's): with backprop_ok, what the midpoint / euler forms
@@ -82,8 +83,6 @@ def select_path(q):
         return _stepwise("method %r has no fused kernel (rk4, midpoint, euler and dopri5 have)" % (q.method,))
     if q.wants_grad and not q.adjoint:
         if q.backprop_ok and q.method == "rk4" and q.options_ok and not q.wants_t:
-            if q.kind == "mlp2" and q.wants_control and not q.narrow_control:
-                return _stepwise("adjoint=False with control gradients of a two-layer field with more than 8 channels")
             return Choice("rk4_backprop" if q.kind == "affine" else "mlp_rk4_backprop", "")
         return _stepwise("adjoint=False with gradients: backpropagation through the solver's own operations (fused under rk4 "
                          "for the one-layer fields on the 32 x 8 tiles and for the two-layer field)")
@@ -102,13 +101,9 @@ def select_path(q):
             return Choice("mlp_rk4_forward" if q.method == "rk4" else "mlp_dopri5_forward", "")
         if q.wants_t and q.method == "dopri5" and (q.wants_control or q.shared):
             return _stepwise("gradients w.r.t. the output times of a two-layer field next to control gradients / a shared controller")
-        if q.wants_t and q.method == "rk4" and not q.narrow_control:
-            return _stepwise("gradients w.r.t. the output times of a two-layer field with more than 8 channels")
         if q.wants_control:
             if q.method == "dopri5":
                 return _stepwise("control gradients through the adaptive backward of a two-layer field")
-            if not q.narrow_control:
-                return _stepwise("control gradients of a two-layer field with more than 8 channels")
             return Choice("mlp_rk4_adjoint", "")
         if q.method == "rk4":
             return Choice("mlp_rk4_adjoint", "")
