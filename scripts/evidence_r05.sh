@@ -4,7 +4,7 @@
 set -u
 cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out
-timeout 300 python scripts/achieved_parity.py 2>/dev/null > $OUT/r05_achieved_parity.json; head -c 600 $OUT/r05_achieved_parity.json; echo
+timeout 300 python tests/tools/achieved_parity.py 2>/dev/null > $OUT/r05_achieved_parity.json; head -c 600 $OUT/r05_achieved_parity.json; echo
 timeout 600 python bench.py > $OUT/r05_bench_n1.json 2> /tmp/bench.err || tail -5 /tmp/bench.err
 python - <<PY
 import json

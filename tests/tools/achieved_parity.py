@@ -1,14 +1,14 @@
 """The parity figures ACHIEVED at the benchmark size (SURVEY 8(d) asks for allclose(rtol 1e-4, atol 1e-6) on trajectories and
 rtol 1e-3 on gradients; VERDICT round 4: "state the achieved figure"): BASELINE configs[2] -- 32768 series, L = 128, C = 8,
 H = 32, rk4 step 1 -- K2 forward + K3p adjoint (and adjoint=False: K2 + K3d) against the float64 oracle, every element.
-    python scripts/achieved_parity.py > profiles/r05_achieved_parity.json"""
+    python tests/tools/achieved_parity.py > profiles/r05_achieved_parity.json"""
 import json
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torchcde_amd as cde  # noqa: E402

@@ -5,14 +5,14 @@ The oracle (oracle/odeint.py, torchdiffeq's odeint_adjoint restated) runs the re
 AND float64, under the default mixed norm and under "seminorm", and prints the accepted / rejected step counts of the
 backward solve.  If the rejections were a float32 noise-floor effect the float64 run would not show them; it does.
 
-    python scripts/probe_mixed_norm_rejections.py > profiles/r04_mixed_norm_rejections_probe.log
+    python tests/tools/probe_mixed_norm_rejections.py > profiles/r04_mixed_norm_rejections_probe.log
 """
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import LinearField, make_series          # noqa: E402
