@@ -804,7 +804,8 @@ def main():
     # the warm-up (the GPU idles meanwhile and needs the warm-up steps to come back to its clocks)
     gc.collect()
     gc.freeze()                                  # (what survives is permanent: later collections only look at new objects)
-    for _ in range(int(os.environ.get("CDE_BENCH_PREWARM", "5"))):   # untimed, before the contract's W warm-up steps: back to full clocks
+    prewarm = int(os.environ.get("CDE_BENCH_PREWARM", "5"))
+    for _ in range(prewarm):   # untimed, before the contract's W warm-up steps: back to full clocks
         step()
     for _ in range(args.warmup):
         step()
@@ -841,8 +842,8 @@ def main():
         total_series = B * world * args.steps
         value = total_series / elapsed
         split = B <= 16384                      # CDE_SPLIT_MAX_BATCH: workgroup-per-tile kernels below, K2/K3 above
-        jacobian = not os.environ.get("CDE_K3_FORM", "").startswith("p")
-        pair = jacobian and os.environ.get("CDE_K3_WAVES", "2") != "1"        # K3p: chain + helper wave per tile (the default)
+        jacobian = cde.get_option("k3_form") != 1
+        pair = jacobian and cde.get_option("k3_waves") != 1                    # K3p: chain + helper wave per tile (the default)
         kernel = ("rk4_adjoint_split8" if split else "rk4_adjoint_jacobian_pair" if pair else
                   "rk4_adjoint_jacobian" if jacobian else "rk4_adjoint_mfma")
         # `achieved` = the flop the kernel's formulation EXECUTES per launch / its average duration.  The default kernels of
@@ -892,6 +893,9 @@ def main():
                          "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": B * 12704},
             "extra": {
+                # methodology since round 5 (disclosed here so that lines of different rounds can be compared): `prewarm`
+                # untimed steps BEFORE the contract's --warmup steps, and one gc.collect() + gc.freeze() before them
+                "untimed_prewarm_steps_before_warmup": prewarm, "gc_frozen_before_timing": True,
                 "forward_kernel_ms": fwd_avg,
                 "forward_tflops": B * FLOP_FWD / (fwd_avg * 1e-3) / 1e12 if fwd_avg > 0 else None,
                 "forward_only_series_per_s": B / (fwd_avg * 1e-3) if fwd_avg > 0 else None,

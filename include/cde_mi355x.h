@@ -8,7 +8,8 @@
  *   - all pointers are DEVICE pointers into caller-owned, contiguous, row-major buffers
  *     (the Python host passes torch.Tensor.data_ptr()); nothing is allocated or freed here;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call is
- *     asynchronous on that stream, keeps no global state and is safe to capture in a hipGraph;
+ *     asynchronous on that stream, keeps no state between calls (the one exception is the explicit tuning table
+ *     below, which only cde_set_option() writes) and is safe to capture in a hipGraph;
  *   - `dtype` / `time_dtype` are CDE_F32 or CDE_F64.  `dtype` is the arithmetic type of the
  *     state z, the control coefficients and the knots; `time_dtype` is the type the solver's
  *     time grid is stepped in (torchdiffeq keeps the grid in `t.dtype` and casts each stage
@@ -26,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CDE_ABI_VERSION 2
+#define CDE_ABI_VERSION 3
 
 enum { CDE_F32 = 0, CDE_F64 = 1 };
 
@@ -72,18 +73,42 @@ enum {
  * y1 = y0 + dt f(t0 + dt/2, y0 + f(t0, y0) dt/2), euler y1 = y0 + dt f(t0, y0) */
 enum { CDE_METHOD_RK4 = 0, CDE_METHOD_MIDPOINT = 1, CDE_METHOD_EULER = 2 };
 
-/* Environment knobs (tests and measurements only; the library keeps no state of its own, so they are read at the call
- * that queues the launch -- hold them fixed for the duration of a solve):
- *   CDE_K3_FORM=product | jacobian      reverse sweep of the affine field: two GEMMs against W, or the shared Jacobian (default)
- *   CDE_K3_WAVES=1 | 2                  its Jacobian form as one wave per tile (K3j) or as chain + helper wave (K3p, default)
- *   CDE_K3D_WAVES=1 | 2                 the same two forms of the adjoint=False sweep K3d (identity activation)
- *   CDE_K2M_NO_SPLIT, CDE_K3M_NO_SPLIT, CDE_K3M_SPLIT4, CDE_K4_NO_SPLIT, CDE_K4M_NO_SPLIT, CDE_K4AM_NO_SPLIT,
- *   CDE_K4AM_SPLIT4, CDE_K4AM_WAVES=8, CDE_K4AM_NO_SMALL_REDUCE     select the other workgroup shape of a kernel family
- *   CDE_K4AM_NO_FSAL                    evaluate every first stage (bit-identical results; tests compare the two)
- *   CDE_K3M_S8_TILES, CDE_K4AM_S8_TILES, CDE_K4M_SPLIT_TILES, CDE_K4AM_SPS   thresholds; clamped to the measured limits (an
- *                                       override can only LOWER them)
- *   CDE_WIDE_SCRATCH_BYTES              chunk budget of the wide-shape sweep
- * None of them changes what is computed beyond summation order; every form is tested against the oracle. */
+/* Tuning table (tests and measurements only).  Kernel-form selectors and thresholds are NOT read from the environment:
+ * they live in one process-wide table of atomics that only cde_set_option() writes (defaults = the production choice;
+ * 0 everywhere unless stated).  This table is the library's only state of its own; set an option BEFORE the workspace
+ * query of the solve it should apply to and hold it fixed until that solve's last launch is queued (the layout
+ * functions and the launchers read it).  None of the options changes what is computed beyond summation order; every
+ * form is tested against the oracle.  The host mirror is `torchcde_amd.tuning(...)` (a context manager). */
+enum {
+  CDE_OPT_K3_FORM = 0,          /* reverse sweep of the affine field: 0 shared Jacobian (default), 1 two GEMMs against W */
+  CDE_OPT_K3_WAVES = 1,         /* its Jacobian form: 0 default (= 2), 1 one wave per tile (K3j), 2 chain + helper wave (K3p) */
+  CDE_OPT_K3D_WAVES = 2,        /* the same two forms of the adjoint=False sweep K3d (identity activation) */
+  CDE_OPT_K2M_NO_SPLIT = 3,     /* 1: K2m one wave per tile at every batch size */
+  CDE_OPT_K3M_NO_SPLIT = 4,     /* 1: K3m one wave per tile at every batch size */
+  CDE_OPT_K3M_SPLIT4 = 5,       /* 1: K3m's shared-tile form with four instead of eight waves */
+  CDE_OPT_K3M_S8_TILES = 6,     /* -1 default; otherwise the tile count up to which K3m's eight-wave form runs (can only LOWER it) */
+  CDE_OPT_K4_NO_SPLIT = 7,      /* 1: K4 (one-layer fields) one wave per tile at every batch size */
+  CDE_OPT_K4M_NO_SPLIT = 8,     /* 1: K4 (two-layer field) one wave per tile at every batch size */
+  CDE_OPT_K4M_SPLIT_TILES = 9,  /* -1 default; otherwise its shared-tile threshold (can only LOWER it) */
+  CDE_OPT_K4AM_WAVES = 10,      /* 0 default; 8: the large-batch workgroup shape of K4am on any batch */
+  CDE_OPT_K4AM_S8_TILES = 11,   /* -1 default; otherwise the tile count up to which K4am's eight-wave form runs (can only LOWER it) */
+  CDE_OPT_K4AM_SPLIT4 = 12,     /* 1: K4am's shared-tile form with four instead of eight waves */
+  CDE_OPT_K4AM_NO_SPLIT = 13,   /* 1: K4am one wave per tile at every batch size */
+  CDE_OPT_K4AM_NO_SMALL_REDUCE = 14, /* 1: the split-K factor reduction + R kernel also for <= 128 series */
+  CDE_OPT_K4AM_SPS = 15,        /* 0 default; 4 .. 40: slabs per stage of the factor reduction */
+  CDE_OPT_K4AM_NO_FSAL = 16,    /* 0 default; 1 evaluate every first stage (bit-identical results), 2 after accepted
+                                   steps only, 3 after rejected steps only */
+  CDE_OPT_WIDE_SCRATCH_BYTES = 17, /* 0 default (4 GB); otherwise the chunk budget of the wide-shape sweep in bytes */
+  CDE_OPT_SPLIT_FORM = 18,      /* small-batch rk4 kernels of the 32 x 8 affine / tanh field: 0 default (quad kernels where
+                                   they apply), 1 the workgroup-per-tile kernels K2s / K3s */
+  CDE_OPT_COUNT = 19
+};
+/* Set / read one entry of the tuning table.  cde_set_option returns CDE_ERR_SHAPE for an unknown key; cde_get_option
+ * returns INT64_MIN for one.  cde_reset_options() restores every default. */
+int cde_set_option(int key, int64_t value);
+int64_t cde_get_option(int key);
+int cde_reset_options(void);
+
 int cde_abi_version(void);
 const char* cde_error_string(int code);
 

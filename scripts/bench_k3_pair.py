@@ -23,7 +23,7 @@ z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(0)).to(dev)
 X = cde.CubicSpline(cde.hermite_cubic_coefficients_with_backward_differences(x))
 res = {}
 for waves in ("1", "2"):
-    os.environ["CDE_K3_WAVES"] = waves
+    cde.set_option("k3_waves", int(waves))
     func = LinearField(H, C, scale=0.25, seed=0).to(dev)
 
     def step():

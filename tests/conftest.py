@@ -35,3 +35,13 @@ def native():
     torchcde_amd.load()
     assert torch.cuda.is_available(), "gpu-marked test running without a GPU"
     return torchcde_amd
+
+
+@pytest.fixture(autouse=True)
+def _default_tuning():
+    """Tests switch kernel forms through the library's tuning table (torchcde_amd.set_option); every test starts and
+    ends with the production defaults."""
+    yield
+    import torchcde_amd._lib as lib
+    if lib._lib is not None:
+        lib._lib.cde_reset_options()

@@ -208,14 +208,14 @@ def test_config5_as_the_reference_calls_it_against_the_oracle(native, monkeypatc
     z0, X.interval) with no method -- dopri5, adjoint, default mixed norm over (vjp_t, y, a, dW1, db1, dW2, db2)), on a
     sub-batch of the 32768 x 512 x 3 -> 65 x 14 logsignature control bench.py uses, hidden size 8, width 128:
       * 2048 series: the split forms (four / eight waves share a tile) of K4 and K4am;
-      * 8192 series with CDE_K4AM_WAVES=8: the one-wave-per-tile forward kernel and the 8-wave K4am form with its
+      * 8192 series with tuning option k4am_waves = 8: the one-wave-per-tile forward kernel and the 8-wave K4am form with its
         multi-slab factor reduction -- the kernels the 32768-series bench line runs.
     The float64 oracle replays the kernels' forward steps and their accepted backward steps (2048: every attempt, so its
     mixed-norm error ratios are the batch's and are compared as well); trajectories rtol 1e-4, dL/dz0 and all FOUR
     parameter gradients 2e-3."""
     from oracle import logsig as oracle_logsig
     if form == "eight_waves":
-        monkeypatch.setenv("CDE_K4AM_WAVES", "8")
+        native.set_option("k4am_waves", 8)
     front = _front()
     B, L, C, H, width = 32768, 512, 3, 8, 128
     gen = torch.Generator().manual_seed(1)
@@ -600,9 +600,9 @@ def test_affine_field_adjoint_forms_at_benchmark_size(native, monkeypatch):
     z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(0)).to(DEV)
     res = {}
     for form in ("jacobian", "jacobian", "jacobian", "one_wave", "product"):
-        # "jacobian": K3p, a chain wave + a helper wave per tile (the default); "one_wave": K3j (CDE_K3_WAVES=1), bitwise the same
-        monkeypatch.setenv("CDE_K3_FORM", "product" if form == "product" else "jacobian")
-        monkeypatch.setenv("CDE_K3_WAVES", "1" if form == "one_wave" else "2")
+        # "jacobian": K3p, a chain wave + a helper wave per tile (the default); "one_wave": K3j (tuning option k3_waves = 1), bitwise the same
+        native.set_option("k3_form", "product" if form == "product" else "jacobian")
+        native.set_option("k3_waves", 1 if form == "one_wave" else 2)
         f = LinearField(H, C, scale=0.25, seed=0).to(DEV)
         z = z0.clone().requires_grad_(True)
         out = native.cdeint(X, f, z, X.interval, method="rk4", options=dict(step_size=1.0), variant="mfma")
@@ -668,7 +668,7 @@ def test_two_layer_rk4_sweep_forms_agree_beyond_one_round_of_tiles(native, monke
     """Round 4: the rk4 adjoint sweep of the two-layer field runs eight waves per 16-series tile (rk4_adjoint_mlp_sweep_s8,
     every evaluation split eight ways, the adjoint state distributed over the waves) up to 1536 tiles.  9000 series are 563
     tiles -- more than two rounds of workgroups, a ragged last tile -- checked against the one-wave-per-tile form
-    (CDE_K3M_NO_SPLIT=1; itself checked against the float64 oracle at 32768 series) and, on a sample, against the oracle."""
+    (tuning option k3m_no_split = 1; itself checked against the float64 oracle at 32768 series) and, on a sample, against the oracle."""
     B, L, C, H, width = 9000, 20, 8, 32, 128
     x = make_series(B, L, C, seed=21)
     z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(21))
@@ -684,7 +684,7 @@ def test_two_layer_rk4_sweep_forms_agree_beyond_one_round_of_tiles(native, monke
         return out.detach(), z.grad, [p.grad.clone() for p in f.parameters()]
 
     out8, gz8, gp8 = run()
-    monkeypatch.setenv("CDE_K3M_NO_SPLIT", "1")
+    native.set_option("k3m_no_split", 1)
     out1, gz1, gp1 = run()
     _close(out8, out1, 1e-5, 1e-6)
     _close(gz8, gz1, 1e-4, 1e-5 * gz1.abs().max().item())

@@ -329,7 +329,7 @@ def test_two_layer_dopri5_adjoint_output_time_gradients(native):
 def test_two_layer_default_call_runs_fused_with_torchdiffeqs_decisions(native, monkeypatch, case, form):
     """(`form`: the workgroup shapes of the two-layer adaptive kernels -- the waves of a workgroup sharing one tile, the
     default up to 4096 series (backward: eight waves per tile, dopri5_mlp_adjoint_attempt_s8; `four_waves`: round 3's
-    form, still what 16-channel tiles run), and one wave per tile, CDE_K4M_NO_SPLIT=1 / CDE_K4AM_NO_SPLIT=1: what larger
+    form, still what 16-channel tiles run), and one wave per tile, tuning option k4m_no_split = 1 / tuning option k4am_no_split = 1: what larger
     batches run.)
     VERDICT round 2, item 2 (K4am).  The call every example of the reference makes to train its model --
     cdeint(X, CDEFunc, z0, X.interval): no method, so dopri5, adjoint=True (example/time_series_classification.py:30-51,
@@ -344,11 +344,11 @@ def test_two_layer_default_call_runs_fused_with_torchdiffeqs_decisions(native, m
     if form == "four_waves":
         if case == "config5_shape_seminorm":
             pytest.skip("16-channel tiles always take the four-wave form")
-        monkeypatch.setenv("CDE_K4AM_SPLIT4", "1")          # backward: four waves per tile instead of eight (round 3's split form)
+        native.set_option("k4am_split4", 1)          # backward: four waves per tile instead of eight (round 3's split form)
     if form == "one_wave_per_tile":
-        monkeypatch.setenv("CDE_K4AM_NO_SMALL_REDUCE", "1")  # the split-K factor reduction + R kernel of larger batches
-        monkeypatch.setenv("CDE_K4AM_NO_SPLIT", "1")        # backward: K4am
-        monkeypatch.setenv("CDE_K4M_NO_SPLIT", "1")         # forward: K4 with the two-layer field
+        native.set_option("k4am_no_small_reduce", 1)  # the split-K factor reduction + R kernel of larger batches
+        native.set_option("k4am_no_split", 1)        # backward: K4am
+        native.set_option("k4m_no_split", 1)         # forward: K4 with the two-layer field
     front = _front()
     cfg = {"example_model": dict(B=70, L=7, C=8, H=32, width=128, tanh=True, degree=3, t_out=None, jumps=False, adj={}),
            # config 5's solve: 14 logsignature channels, hidden size 8 (example/logsignature_example.py:21-23), 16 x 16 tiles
@@ -469,7 +469,7 @@ def test_dopri5_adjoint_fused_equals_stepwise_reference_semantics_and_is_determi
 @pytest.mark.parametrize("B,degree,jumps,C,form", [
     (70, 3, False, 8, "shared_tile"), (300, 1, True, 8, "shared_tile"), (300, 3, False, 8, "shared_tile"),
     (4500, 3, False, 8, "shared_tile"),
-    # four waves share a tile (16-channel tiles up to 4096 series; 8-channel tiles with CDE_K4AM_SPLIT4): ring in registers
+    # four waves share a tile (16-channel tiles up to 4096 series; 8-channel tiles with tuning option k4am_split4): ring in registers
     (300, 3, False, 14, "shared_tile"), (70, 1, True, 14, "shared_tile"), (300, 3, False, 8, "four_waves"),
     # one wave per tile (what batches above 12288 series and 16-channel tiles above 4096 run): four and eight waves per workgroup
     (70, 3, False, 8, "one_wave"), (300, 1, True, 14, "one_wave"), (300, 3, False, 14, "one_wave_8")])
@@ -478,17 +478,17 @@ def test_two_layer_backward_first_same_as_last_is_bit_identical(native, monkeypa
     rejection it is the rejected attempt's own first stage (same state, same time), after an accepted step that step's last
     stage (torchdiffeq keeps f0 / passes f1 on the same way: oracle/odeint.py _Dopri5) -- slopes from a stash, factor rows
     from the block the controller names (AdjCtrl::src0 / six).  The re-evaluation it replaces has the same inputs bit for
-    bit, so with CDE_K4AM_NO_FSAL=1 (every first stage evaluated) the attempt trace, the trajectories and every gradient
+    bit, so with tuning option k4am_no_fsal = 1 (every first stage evaluated) the attempt trace, the trajectories and every gradient
     must be IDENTICAL: 70 series (fused reduction), 300 (split-K reduction + R kernel; with jump_t on the knots the step
     after a jump does evaluate its first stage), 4500 (two rounds of workgroups).  The one-wave-per-tile form keeps its
     slopes in a per-lane ring in memory: slot 0 stays, or slot 6 is copied to it."""
     front = _front()
     if form == "four_waves":
-        monkeypatch.setenv("CDE_K4AM_SPLIT4", "1")
+        native.set_option("k4am_split4", 1)
     elif form != "shared_tile":
-        monkeypatch.setenv("CDE_K4AM_NO_SPLIT", "1")
+        native.set_option("k4am_no_split", 1)
     if form == "one_wave_8":
-        monkeypatch.setenv("CDE_K4AM_WAVES", "8")
+        native.set_option("k4am_waves", 8)
     L, H, width = 9, (32 if C <= 8 else 16), 128
     x = make_series(B, L, C, seed=B)
     z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(B))
@@ -498,7 +498,7 @@ def test_two_layer_backward_first_same_as_last_is_bit_identical(native, monkeypa
     res = {}
     for form in ("reuse", "evaluate"):
         if form == "evaluate":
-            monkeypatch.setenv("CDE_K4AM_NO_FSAL", "1")
+            native.set_option("k4am_no_fsal", 1)
         func = _TwoLayerField(H, C, width, seed=3).to(DEV)
         zd = z0.to(DEV).requires_grad_(True)
         front.record_dopri5_steps = True

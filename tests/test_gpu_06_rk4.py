@@ -68,7 +68,7 @@ def test_cdeint_vs_float64_oracle_ragged_batch(native, variant, act):
 def test_affine_field_adjoint_in_both_forms(native, monkeypatch, H, C, degree, variant):
     """The reverse sweep of the affine field has two forms: the shared Jacobian (default: f and a^T df/dz from
     J = sum_c dX_c W_c, one GEMM + two matrix-vector products on the vector pipe -- K3j, and the chain waves of the
-    workgroup-per-tile kernel K3s) and the product form (CDE_K3_FORM=product: two GEMMs against W).  Both against the
+    workgroup-per-tile kernel K3s) and the product form (tuning option k3_form = product: two GEMMs against W).  Both against the
     float64 oracle on a ragged batch with several output times and zero-padded shapes, and against each other (a
     reassociation: rounding-level differences only)."""
     B, L = 203, 24
@@ -90,7 +90,7 @@ def test_affine_field_adjoint_in_both_forms(native, monkeypatch, H, C, degree, v
     X = native.CubicSpline(coeffs.to(DEV)) if degree == 3 else native.LinearInterpolation(x.to(DEV))
     got = {}
     for form in ("jacobian", "product"):
-        monkeypatch.setenv("CDE_K3_FORM", form)
+        native.set_option("k3_form", form)
         dfunc = LinearField(H, C, torch.float32, scale=0.25, seed=5).to(DEV)
         z = z0.to(DEV).requires_grad_(True)
         out = native.cdeint(X, dfunc, z, t_out.to(DEV), method="rk4", options=dict(step_size=1.0), variant=variant)
@@ -104,11 +104,11 @@ def test_affine_field_adjoint_in_both_forms(native, monkeypatch, H, C, degree, v
         assert not torch.equal(a_, b_)                     # (two different kernels did run)
         _close(a_, b_, 1e-4, 1e-5 * b_.abs().max().item())
     if variant == "mfma":
-        # the Jacobian form itself comes as one wave per tile (K3j, CDE_K3_WAVES=1) and, the default since round 5, as a
+        # the Jacobian form itself comes as one wave per tile (K3j, tuning option k3_waves = 1) and, the default since round 5, as a
         # chain wave + a helper wave per tile on one SIMD (K3p, csrc/rk4_adjoint_pair.hip): the same operations in the
         # same order -- bit for bit
-        monkeypatch.setenv("CDE_K3_FORM", "jacobian")
-        monkeypatch.setenv("CDE_K3_WAVES", "1")
+        native.set_option("k3_form", "jacobian")
+        native.set_option("k3_waves", 1)
         dfunc = LinearField(H, C, torch.float32, scale=0.25, seed=5).to(DEV)
         z = z0.to(DEV).requires_grad_(True)
         out = native.cdeint(X, dfunc, z, t_out.to(DEV), method="rk4", options=dict(step_size=1.0), variant=variant)
@@ -291,7 +291,7 @@ def test_wide_tile_kernels(native, monkeypatch, H, C, act, degree, chunk):
     times (two reverse segments), zero-padded shapes; `chunk=1` squeezes the factor scratch so that every RK step is its
     own sweep launch (state carried through HBM between launches)."""
     if chunk is not None:
-        monkeypatch.setenv("CDE_WIDE_SCRATCH_BYTES", "1")
+        native.set_option("wide_scratch_bytes", 1)
     B, L = 75, 12
     x = make_series(B, L, C, torch.float32, seed=150 + H)
     coeffs = oracle_interp.hermite_bdiff_coeffs(x) if degree == 3 else x
@@ -457,7 +457,7 @@ def test_wide_tile_kernels_larger_batch_several_chunks(native, monkeypatch):
     above): trajectories, dL/dz0 and the parameter gradients (sums over 3001 series x 128 stages) at float32 round-off."""
     B, L, C, H = 3001, 33, 8, 64
     row_bytes = (64 * 8 + 64) * 4
-    monkeypatch.setenv("CDE_WIDE_SCRATCH_BYTES", str(5 * 4 * 3008 * row_bytes))
+    native.set_option("wide_scratch_bytes", 5 * 4 * 3008 * row_bytes)
     x = make_series(B, L, C, torch.float32, seed=77).to(DEV)
     X = native.CubicSpline(native.hermite_cubic_coefficients_with_backward_differences(x))
     z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(78)).to(DEV)
@@ -696,15 +696,15 @@ def test_rk4_backprop_mode_fused_against_autograd_through_the_oracle(native, B, 
         plain = native.cdeint(X, func, z0.to(DEV), t_out.to(DEV), method="rk4", options=dict(step_size=step), variant="mfma")
     assert torch.equal(out.detach(), plain)
     # run to run deterministic (fixed-order reduction of the per-wave partials); and the sweep's two forms -- a chain wave + a
-    # helper wave per tile (the default, rk4_adjoint_pair.hip) and one wave per tile (CDE_K3D_WAVES=1) -- agree bit for bit
-    for waves in ("2", "1"):
-        os.environ["CDE_K3D_WAVES"] = waves
+    # helper wave per tile (the default, rk4_adjoint_pair.hip) and one wave per tile (tuning option k3d_waves = 1) -- agree bit for bit
+    for waves in (2, 1):
+        native.set_option("k3d_waves", waves)
         try:
             func2 = LinearField(H, C, scale=0.3, seed=3).to(DEV)
             z2 = z0.to(DEV).requires_grad_(True)
             (native.cdeint(X, func2, z2, t_out.to(DEV), **kw) * lw.to(DEV)).sum().backward()
         finally:
-            del os.environ["CDE_K3D_WAVES"]
+            native.set_option("k3d_waves", 0)
         assert torch.equal(z2.grad, z.grad) and torch.equal(func2.linear.weight.grad, func.linear.weight.grad)
         assert torch.equal(func2.linear.bias.grad, func.linear.bias.grad)
 
@@ -976,12 +976,11 @@ def test_two_layer_backprop_mode_fused_against_autograd_through_the_oracle(nativ
         _close(g_, want, 1e-3, bar(want, cpu32))
     # the forward values are K2m's own (one wave per tile), bit for bit
     with torch.no_grad():
-        import os
-        os.environ["CDE_K2M_NO_SPLIT"] = "1"
+        native.set_option("k2m_no_split", 1)
         try:
             plain = native.cdeint(X, dfunc, z0.to(DEV), t_out.to(DEV), method="rk4", options=dict(step_size=1.0))
         finally:
-            del os.environ["CDE_K2M_NO_SPLIT"]
+            native.set_option("k2m_no_split", 0)
     assert torch.equal(plain, out.detach())
 
 

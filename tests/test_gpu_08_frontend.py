@@ -391,3 +391,136 @@ def test_dispatch_is_queryable_and_warns_once_when_a_known_field_goes_stepwise(n
     with pytest.raises(AssertionError, match="max_num_steps"):
         with torch.no_grad():
             native.cdeint(X, func, z0, X.interval, options=dict(max_num_steps=2))
+
+
+class _SineControl(torch.nn.Module):
+    """A user-defined control: X_c(t) = amp_c sin(w_c t + phase_c) per series -- nothing but a `derivative` method, which is all
+    reference solver.py:45-46 asks of X (no coefficients, no grid points, not one of the package's path classes)."""
+
+    def __init__(self, B, C, dtype, seed=0):
+        super().__init__()
+        gen = torch.Generator().manual_seed(seed)
+        self.amp = torch.nn.Parameter(torch.rand(B, C, generator=gen, dtype=dtype) + 0.5)
+        self.register_buffer("freq", torch.rand(B, C, generator=gen, dtype=dtype) * 2 + 0.5)
+        self.register_buffer("phase", torch.rand(B, C, generator=gen, dtype=dtype) * 6)
+
+    def derivative(self, t):
+        return self.amp * self.freq * torch.cos(self.freq * t + self.phase)
+
+
+@pytest.mark.parametrize("method,adjoint", [("rk4", True), ("rk4", False), ("dopri5", True)])
+def test_user_defined_control_with_only_a_derivative_method(native, method, adjoint):
+    """reference solver.py:45-46: cdeint needs nothing of X but `derivative`.  A control module of the user's own runs
+    step-wise on the GPU (its derivative called at every evaluation, the product in cde_contract) and matches the oracle's
+    cdeint over the same control: trajectories, dL/dz0, the field's parameters and the CONTROL's own parameter (passed in
+    adjoint_params, README.md:251-270's pattern; under adjoint=False autograd reaches it by itself)."""
+    B, C, H = 5, 3, 6
+    dtype = torch.float64
+    t = torch.tensor([0.0, 0.7, 1.9], dtype=dtype)
+    z0 = torch.randn(B, H, dtype=dtype, generator=torch.Generator().manual_seed(5))
+    kw = dict(method=method, adjoint=adjoint)
+    if method == "rk4":
+        kw["options"] = dict(step_size=0.1)
+    else:
+        kw.update(rtol=1e-8, atol=1e-10)
+    res = {}
+    for where in ("oracle", "native"):
+        dev = "cpu" if where == "oracle" else DEV
+        X = _SineControl(B, C, dtype, seed=2).to(dev)
+        f = _Mlp(C, H, 16, dtype, seed=4).to(dev)
+        z = z0.to(dev).requires_grad_(True)
+        extra = dict(adjoint_params=tuple(f.parameters()) + (X.amp,)) if adjoint else {}
+        solve = oracle_cde.cdeint if where == "oracle" else native.cdeint
+        out = solve(X, f, z, t.to(dev), **kw, **extra)
+        assert out.shape == (B, 3, H)
+        out[:, 1:].pow(2).sum().backward()
+        res[where] = [out.detach().cpu(), z.grad.cpu(), X.amp.grad.cpu()] + [p.grad.cpu() for p in f.parameters()]
+    assert _front().last_dispatch()[0].path == "stepwise"
+    tight = method == "rk4"
+    for got, want in zip(res["native"], res["oracle"]):
+        _close(got, want, 1e-9 if tight else 1e-5, (1e-11 if tight else 1e-7) * max(1.0, want.abs().max().item()))
+    # the reference's own complaints about a control that does not fit (solver.py:7-33, :56-57)
+    class NoDerivative(torch.nn.Module):
+        pass
+    with pytest.raises(ValueError, match="X must have a 'derivative' method"):
+        native.cdeint(NoDerivative(), _Mlp(C, H, 16, dtype, seed=4).to(DEV), z0.to(DEV), t.to(DEV))
+    with pytest.raises(ValueError, match="same number of batch dimensions as z0"):
+        native.cdeint(_SineControl(B + 1, C, dtype).to(DEV), _Mlp(C, H, 16, dtype, seed=4).to(DEV), z0.to(DEV), t.to(DEV))
+    with pytest.raises(ValueError, match="same number of input channels as X.derivative"):
+        native.cdeint(_SineControl(B, C + 1, dtype).to(DEV), _Mlp(C, H, 16, dtype, seed=4).to(DEV), z0.to(DEV), t.to(DEV))
+
+
+class _ExampleNeuralCDE(torch.nn.Module):
+    """The model of reference example/time_series_classification.py:54-94 restated over any implementation of the torchcde
+    API (`api` = torchcde_amd on the GPU, the oracle's classes on the CPU): initial = Linear(C, H) on X.evaluate(X.interval[0]),
+    z_T = cdeint(X, func, z0, X.interval) with NO method (dopri5 + adjoint, solver.py:195-203,226), readout = Linear(H, 1)."""
+
+    def __init__(self, api, C, H, dtype, seed):
+        super().__init__()
+        self.api = api
+        from helpers import TwoLayerField
+        self.func = TwoLayerField(H, C, 128, dtype, seed=seed)
+        gen = torch.Generator().manual_seed(seed + 1)
+        self.initial = torch.nn.Linear(C, H).to(dtype)
+        self.readout = torch.nn.Linear(H, 1).to(dtype)
+        with torch.no_grad():
+            for lin in (self.initial, self.readout):
+                bound = 1 / lin.in_features ** 0.5
+                lin.weight.copy_((torch.rand(lin.weight.shape, generator=gen, dtype=torch.float64) * 2 - 1) * bound)
+                lin.bias.copy_((torch.rand(lin.bias.shape, generator=gen, dtype=torch.float64) * 2 - 1) * bound)
+
+    def forward(self, coeffs):
+        X = self.api["spline"](coeffs)
+        z0 = self.initial(X.evaluate(X.interval[0]))
+        z_T = self.api["cdeint"](X=X, z0=z0, func=self.func, t=X.interval)
+        return self.readout(z_T[:, 1]).squeeze(-1)
+
+
+def test_example_neural_cde_trains_like_the_reference_model(native):
+    """SURVEY section 2 row 12 / example/time_series_classification.py:54-147: the example's NeuralCDE on top of this package
+    -- spirals (t, x, y) -> hermite coefficients -> CubicSpline -> X.evaluate(X.interval[0]) -> initial -> DEFAULT cdeint
+    (dopri5 + adjoint, fused: K4 + K4am) -> readout -> BCE-with-logits -> Adam.step(), three steps at the example's batch size
+    (32) -- against the same model over the oracle in float64.  Both take tolerance-level adaptive solutions with their own
+    step sequences (rtol 1e-4), so the losses and predictions are compared at 2e-3, the first step's gradients at 2 %."""
+    B, L, C, H = 32, 40, 3, 8
+    gen = torch.Generator().manual_seed(11)
+    t = torch.linspace(0.0, 4 * 3.141592653589793, L)
+    start = torch.rand(B, generator=gen) * 2 * 3.141592653589793
+    sign = torch.where(torch.arange(B) % 2 == 0, 1.0, -1.0)
+    ang = start[:, None] + sign[:, None] * t[None]
+    x = torch.stack([t.expand(B, L), torch.cos(ang) / (1 + 0.5 * t), torch.sin(ang) / (1 + 0.5 * t)], dim=2)
+    x[..., 1:] += 0.01 * torch.randn(B, L, 2, generator=gen)
+    y = (sign > 0).float()
+
+    apis = {"oracle": dict(spline=oracle_interp.CubicPath, cdeint=oracle_cde.cdeint, fit=oracle_interp.hermite_bdiff_coeffs),
+            "native": dict(spline=native.CubicSpline, cdeint=native.cdeint,
+                           fit=native.hermite_cubic_coefficients_with_backward_differences)}
+    log = {}
+    for where, api in apis.items():
+        dev, dtype = ("cpu", torch.float64) if where == "oracle" else (DEV, torch.float32)
+        model = _ExampleNeuralCDE(api, C, H, dtype, seed=21).to(dev)
+        coeffs = api["fit"](x.to(dev, dtype))
+        target = y.to(dev, dtype)
+        opt = torch.optim.Adam(model.parameters())
+        losses, first_grads = [], None
+        for step in range(3):
+            pred = model(coeffs)
+            loss = torch.nn.functional.binary_cross_entropy_with_logits(pred, target)
+            opt.zero_grad()
+            loss.backward()
+            if where == "native" and step == 0:
+                _expect_dispatch("two_layer_dopri5", None)
+            if first_grads is None:
+                first_grads = [p.grad.detach().double().cpu().clone() for p in model.parameters()]
+            opt.step()
+            losses.append(loss.item())
+        with torch.no_grad():
+            final = model(coeffs).double().cpu()
+        log[where] = (losses, first_grads, final)
+    (lo, go, fo), (ln, gn, fn) = log["oracle"], log["native"]
+    assert ln[2] < ln[0]                                  # it trains
+    for a, b in zip(ln, lo):
+        assert abs(a - b) <= 2e-3 * abs(b), (ln, lo)
+    _close(fn, fo, 2e-3, 2e-3)
+    for a, b in zip(gn, go):
+        _close(a, b, 2e-2, 2e-2 * b.abs().max().item())

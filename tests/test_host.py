@@ -29,9 +29,39 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     raw = ctypes.CDLL(_lib.SO_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert lib.cde_abi_version() == 2
+    assert lib.cde_abi_version() == 3
     assert lib.cde_error_string(0) == b"ok"
     assert b"workspace" in lib.cde_error_string(-5)
+
+
+def test_tuning_table_is_explicit_and_restores_its_defaults():
+    """The library reads no environment variable: kernel-form selectors live in one table that only cde_set_option writes
+    (include/cde_mi355x.h, CDE_OPT_*).  Names and keys of the host mirror against the header's enum, defaults, the
+    context manager's restore, and the source itself (getenv appears only inside the trace build's #ifdef)."""
+    lib = torchcde_amd.load()
+    header = open(os.path.join(ROOT, "include", "cde_mi355x.h")).read()
+    enum = dict((name.lower(), int(val)) for name, val in re.findall(r"CDE_OPT_([A-Z0-9_]+) = (\d+)", header))
+    count = enum.pop("count")
+    assert enum == {name: key for name, (key, _) in _lib.OPTIONS.items()} and count == len(enum)
+    lib.cde_reset_options()
+    defaults = {name: torchcde_amd.get_option(name) for name in _lib.OPTIONS}
+    assert defaults["k3_form"] == 0 and defaults["k3m_s8_tiles"] == -1 and defaults["wide_scratch_bytes"] == 0
+    with torchcde_amd.tuning(k3_form="product", k3_waves=1, k4am_no_fsal=True, wide_scratch_bytes=12345):
+        assert torchcde_amd.get_option("k3_form") == 1 and torchcde_amd.get_option("k3_waves") == 1
+        assert torchcde_amd.get_option("k4am_no_fsal") == 1 and torchcde_amd.get_option("wide_scratch_bytes") == 12345
+    assert {name: torchcde_amd.get_option(name) for name in _lib.OPTIONS} == defaults
+    assert lib.cde_set_option(count, 1) != 0 and lib.cde_get_option(-1) == -2 ** 63
+    with pytest.raises(KeyError):
+        torchcde_amd.tuning(no_such_option=1)
+    csrc = os.path.join(ROOT, "torchcde_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        guarded = False
+        for line in open(os.path.join(csrc, name)):
+            if line.startswith("#ifdef CDE_PHASE_TRACE"):
+                guarded = True
+            elif line.startswith("#else") or line.startswith("#endif"):
+                guarded = False
+            assert "getenv" not in line or guarded, (name, line)
 
 
 def test_ctypes_signatures_match_the_header_prototypes():
@@ -39,7 +69,7 @@ def test_ctypes_signatures_match_the_header_prototypes():
     parameters, pointers bound as c_void_p, integers / doubles / size_t as such, same return type."""
     header = open(os.path.join(ROOT, "include", "cde_mi355x.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
-    protos = re.findall(r"\b(int|size_t|const char\*)\s+(cde_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", header, flags=re.S)
+    protos = re.findall(r"\b(int64_t|int|size_t|const char\*)\s+(cde_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", header, flags=re.S)
     assert len(protos) == len(_lib.EXPORTED_SYMBOLS)
     kinds = {ctypes.c_void_p: "ptr", ctypes.c_int: "int", ctypes.c_int64: "int64_t", ctypes.c_size_t: "size_t",
              ctypes.c_double: "double"}
@@ -50,7 +80,8 @@ def test_ctypes_signatures_match_the_header_prototypes():
         for text, ctype in zip(params, argtypes):
             want = "ptr" if "*" in text else text.split()[-2] if len(text.split()) > 1 else text
             assert kinds[ctype] == want, (name, text, ctype)
-        assert {"int": ctypes.c_int, "size_t": ctypes.c_size_t, "const char*": ctypes.c_char_p}[ret] is restype, name
+        assert {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "size_t": ctypes.c_size_t,
+                "const char*": ctypes.c_char_p}[ret] is restype, name
 
 
 def test_status_struct_mirror_matches_the_header():

@@ -5,7 +5,7 @@ Drop-in names (reference ``torchcde/__init__.py:1-7``): ``hermite_cubic_coeffici
 ``InterpolationBase``, ``TupleControl``, ``logsig_windows`` / ``logsignature_windows``, ``cdeint``.  Everything numerical runs in hand-written HIP kernels (gfx950) loaded from
 ``libcde_mi355x.so`` through the C ABI of ``include/cde_mi355x.h``; there is no eager or CPU fallback.
 """
-from ._lib import build, load, SO_PATH
+from ._lib import build, load, SO_PATH, set_option, get_option, tuning
 from .paths import (InterpolationBase, CubicSpline, NaturalCubicSpline, LinearInterpolation,
                     hermite_cubic_coefficients_with_backward_differences, linear_interpolation_coeffs,
                     natural_cubic_coeffs, natural_cubic_spline_coeffs)

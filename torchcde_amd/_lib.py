@@ -39,7 +39,66 @@ VARIANT_AUTO, VARIANT_GENERIC, VARIANT_MFMA, VARIANT_SPLIT, VARIANT_BF16X3 = 0, 
 METHOD_RK4, METHOD_MIDPOINT, METHOD_EULER = 0, 1, 2
 FIXED_METHODS = {"rk4": METHOD_RK4, "midpoint": METHOD_MIDPOINT, "euler": METHOD_EULER}
 
+ABI_VERSION = 3                     # == CDE_ABI_VERSION of include/cde_mi355x.h
 _lib = None
+
+# The library's tuning table (include/cde_mi355x.h, CDE_OPT_*): name -> (key, accepted spellings).  Tests and measurement
+# scripts switch kernel forms with `with torchcde_amd.tuning(k3_form="product"): ...`; nothing is read from the environment.
+OPTIONS = {
+    "k3_form": (0, {"jacobian": 0, "product": 1}),
+    "k3_waves": (1, {"default": 0, 1: 1, 2: 2}),
+    "k3d_waves": (2, {"default": 0, 1: 1, 2: 2}),
+    "k2m_no_split": (3, None), "k3m_no_split": (4, None), "k3m_split4": (5, None), "k3m_s8_tiles": (6, None),
+    "k4_no_split": (7, None), "k4m_no_split": (8, None), "k4m_split_tiles": (9, None), "k4am_waves": (10, None),
+    "k4am_s8_tiles": (11, None), "k4am_split4": (12, None), "k4am_no_split": (13, None),
+    "k4am_no_small_reduce": (14, None), "k4am_sps": (15, None),
+    "k4am_no_fsal": (16, {False: 0, True: 1, "accepted": 2, "rejected": 3}),
+    "wide_scratch_bytes": (17, None),
+    "split_form": (18, {"default": 0, "quad": 0, "workgroup": 1}),
+}
+
+
+def _option_value(name, value):
+    key, spellings = OPTIONS[name]
+    if spellings is not None and not isinstance(value, bool) and value in spellings:
+        return key, spellings[value]
+    if spellings is not None and isinstance(value, bool) and value in spellings:
+        return key, spellings[value]
+    return key, int(value)
+
+
+def set_option(name, value):
+    key, v = _option_value(name, value)
+    check(load().cde_set_option(key, v), "cde_set_option(%s)" % name)
+
+
+def get_option(name):
+    return int(load().cde_get_option(OPTIONS[name][0]))
+
+
+class tuning:
+    """Context manager over the library's tuning table: `with tuning(k3_form="product", k3_waves=1): ...` sets the
+    named options and restores the previous values on exit.  Process-wide (autograd runs backward on its own thread),
+    so hold it around the whole solve, backward pass included."""
+
+    def __init__(self, **options):
+        for name in options:
+            if name not in OPTIONS:
+                raise KeyError("torchcde_amd.tuning: unknown option %r (known: %s)" % (name, ", ".join(sorted(OPTIONS))))
+        self._new = options
+        self._old = {}
+
+    def __enter__(self):
+        for name, value in self._new.items():
+            self._old[name] = get_option(name)
+            set_option(name, value)
+        return self
+
+    def __exit__(self, *exc):
+        lib = load()
+        for name, value in self._old.items():
+            check(lib.cde_set_option(OPTIONS[name][0], value), "cde_set_option(%s)" % name)
+        return False
 
 
 def _hipcc():
@@ -61,8 +120,7 @@ def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 into torchcde_amd/libcde_mi355x.so (cross-compiles without a GPU)."""
     if not force and not _stale():
         return SO_PATH
-    # one hipcc process per translation unit, in parallel (the MFMA kernels dominate: ~35 s), then one link step
-    from concurrent.futures import ThreadPoolExecutor
+    # one hipcc process per translation unit, in parallel (the MFMA kernels dominate), then one link step
     compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"]
 
     def run(cmd):
@@ -73,32 +131,62 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed:\n" + proc.stdout)
 
     # objects are cached under torchcde_amd/.build/ keyed by (source, headers, flags): editing one kernel file recompiles
-    # that file only (the cache is neither tracked nor shipped to the GPU box; the linked .so is what travels)
+    # that file only (the cache is neither tracked nor shipped to the GPU box; the linked .so is what travels).  Several
+    # processes may get here at once (the ranks of a launcher over a stale library): one file lock around the whole build,
+    # per-process temporary names, and the library itself is linked beside its final name and renamed into place.
+    import fcntl
     import hashlib
     cache = os.path.join(_HERE, ".build")
     os.makedirs(cache, exist_ok=True)
-    header_blob = b"".join(open(h, "rb").read() for h in HEADERS if os.path.exists(h))
+    lock = open(os.path.join(cache, ".lock"), "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        if not force and not _stale():            # another process built it while this one waited for the lock
+            return SO_PATH
+        return _build_locked(force, verbose, run, compile_flags, cache, hashlib)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(force, verbose, run, compile_flags, cache, hashlib):
+    tag = ".tmp%d" % os.getpid()
+    import re
+
+    def closure(path, seen):                      # the file and every "quoted" header it includes, transitively
+        path = os.path.normpath(path)
+        if path in seen or not os.path.exists(path):
+            return
+        seen[path] = open(path, "rb").read()
+        for inc in re.findall(rb'^\s*#\s*include\s+"([^"]+)"', seen[path], flags=re.M):
+            closure(os.path.join(os.path.dirname(path), inc.decode()), seen)
+
     objects, jobs = [], []
     for src in SOURCES:
         flags = compile_flags + EXTRA_FLAGS.get(src, [])
-        key = hashlib.sha256(open(os.path.join(_CSRC, src), "rb").read() + header_blob + " ".join(flags).encode()).hexdigest()[:20]
+        seen = {}
+        closure(os.path.join(_CSRC, src), seen)
+        blob = b"".join(seen[k] for k in sorted(seen))
+        key = hashlib.sha256(blob + " ".join(flags).encode()).hexdigest()[:20]
         obj = os.path.join(cache, "%s.%s.o" % (os.path.splitext(src)[0], key))
         objects.append(obj)
         if force or not os.path.exists(obj):
-            jobs.append((src, obj, [_hipcc()] + flags + ["-c", os.path.join(_CSRC, src), "-o", obj + ".tmp"]))
+            jobs.append((src, obj, [_hipcc()] + flags + ["-c", os.path.join(_CSRC, src), "-o", obj + tag]))
 
     def compile_one(job):
         src, obj, cmd = job
         run(cmd)
-        os.replace(obj + ".tmp", obj)
+        os.replace(obj + tag, obj)
 
     if jobs:
+        from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as pool:
             list(pool.map(compile_one, jobs))
-    run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objects + ["-o", SO_PATH])
+    run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objects + ["-o", SO_PATH + tag])
+    os.replace(SO_PATH + tag, SO_PATH)
     keep = set(objects)
-    for name in os.listdir(cache):                  # drop objects of older source versions
-        if os.path.join(cache, name) not in keep:
+    for name in os.listdir(cache):                  # drop objects of older source versions (never a lock or a temporary)
+        if name.endswith(".o") and os.path.join(cache, name) not in keep:
             os.remove(os.path.join(cache, name))
     return SO_PATH
 
@@ -107,6 +195,9 @@ _p, _i, _i64, _sz, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_
 _SIGNATURES = {
     "cde_abi_version": (_i, []),
     "cde_error_string": (ctypes.c_char_p, [_i]),
+    "cde_set_option": (_i, [_i, _i64]),
+    "cde_get_option": (_i64, [_i]),
+    "cde_reset_options": (_i, []),
     "cde_hermite_bdiff_coeffs": (_i, [_p, _p, _p, _i64, _i64, _i64, _i, _p]),
     "cde_hermite_bdiff_coeffs_checked": (_i, [_p, _p, _p, _i64, _i64, _i64, _i, _p, _p]),
     "cde_hermite_bdiff_coeffs_nonblocking": (_i, [_p, _p, _p, _p, _i64, _i64, _i64, _i, _p, _i, _p]),
@@ -227,11 +318,21 @@ def load():
                 "torchcde_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU/eager fallback." % SO_PATH)
         lib = ctypes.CDLL(SO_PATH)
+        # the version first: an older library would otherwise fail with a bare AttributeError on a symbol it lacks
+        try:
+            lib.cde_abi_version.restype, lib.cde_abi_version.argtypes = _i, []
+            version = lib.cde_abi_version()
+        except AttributeError:
+            version = None
+        if version != ABI_VERSION:
+            raise RuntimeError("torchcde_amd: %s has ABI version %s, this package needs %d -- rebuild it "
+                               "(python -c 'import __graft_entry__ as g; g.build()')" % (SO_PATH, version, ABI_VERSION))
         for name, (res, args) in _SIGNATURES.items():
-            fn = getattr(lib, name)
+            try:
+                fn = getattr(lib, name)
+            except AttributeError:
+                raise RuntimeError("torchcde_amd: %s does not export %s (ABI mismatch) -- rebuild it" % (SO_PATH, name))
             fn.restype, fn.argtypes = res, args
-        if lib.cde_abi_version() != 2:
-            raise RuntimeError("torchcde_amd: ABI version mismatch in %s" % SO_PATH)
         _lib = lib
     return _lib
 

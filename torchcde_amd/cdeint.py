@@ -26,6 +26,7 @@ import warnings
 import weakref
 
 import torch
+from torch.autograd.function import once_differentiable as _once_differentiable
 
 from . import _lib, dispatch
 from .fields import probe
@@ -680,6 +681,7 @@ class _FusedMlpRK4(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_once_differentiable
     def backward(ctx, grad_out):
         out, *weights = ctx.saved_tensors
         plan = ctx.plan
@@ -726,6 +728,7 @@ class _FusedRK4(torch.autograd.Function):
         return out.reshape(*plan.batch, plan.n_out, plan.H)
 
     @staticmethod
+    @_once_differentiable
     def backward(ctx, grad_out):
         plan = ctx.plan
         if not plan.adjoint:
@@ -784,6 +787,7 @@ class _FusedMlpRK4Backprop(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_once_differentiable
     def backward(ctx, grad_out):
         stages, *weights = ctx.saved_tensors
         plan, need = ctx.plan, ctx.needs_input_grad
@@ -810,6 +814,7 @@ class _FusedRK4Backprop(torch.autograd.Function):
         return out.reshape(*plan.batch, plan.n_out, plan.H)
 
     @staticmethod
+    @_once_differentiable
     def backward(ctx, grad_out):
         plan, need = ctx.plan, ctx.needs_input_grad
         weight, bias, stages = ctx.saved_tensors
@@ -1253,6 +1258,7 @@ class _FusedDopri5(torch.autograd.Function):
         return out.reshape(*plan.batch, plan.n_out, plan.H)
 
     @staticmethod
+    @_once_differentiable
     def backward(ctx, grad_out):
         plan = ctx.plan
         out, weight, bias = ctx.saved_tensors
@@ -1281,6 +1287,7 @@ class _FusedMlpDopri5(torch.autograd.Function):
         return out.reshape(*plan.batch, plan.n_out, plan.H)
 
     @staticmethod
+    @_once_differentiable
     def backward(ctx, grad_out):
         out, w1, b1, w2, b2 = ctx.saved_tensors
         plan = ctx.plan
@@ -1373,6 +1380,47 @@ def _cdeint_tuple(X, func, z0, t, adjoint, backend, kwargs):
     return tuple(out.split(sizes, dim=-1))
 
 
+def _cdeint_foreign_control(X, func, z0, t, adjoint, kwargs):
+    """A control that is not one of this package's paths (reference solver.py:45-46: anything with a `derivative` method,
+    typically an nn.Module of the user's): the reference's compatibility checks and messages (solver.py:44-67), then the
+    step-wise solver -- X.derivative(t) is called as it is (under autograd when its parameters or the times need a
+    gradient), the vector field times dX/dt runs in cde_contract."""
+    _lib.require_gpu(z0, "z0")
+    probe_t = t[0].to(z0.device) if isinstance(t, torch.Tensor) else t
+    is_prod = hasattr(func, "prod")
+    with torch.no_grad():
+        dX = X.derivative(probe_t.detach() if isinstance(probe_t, torch.Tensor) else probe_t)
+        system = func.prod(probe_t, z0, dX) if is_prod else func(probe_t, z0)
+    if not isinstance(dX, torch.Tensor):
+        raise ValueError("z0 is a tensor and so X.derivative must return a tensor as well.")
+    if is_prod:
+        if not isinstance(system, torch.Tensor):
+            raise ValueError("z0 is a tensor and so func.prod must return a tensor as well.")
+        if tuple(dX.shape[:-1]) != tuple(z0.shape[:-1]):
+            _shape_errors(tuple(dX.shape), tuple(z0.shape) + (dX.size(-1),), z0)
+        if system.shape != z0.shape:
+            raise ValueError("func.prod did not return a tensor with the same shape as z0. func.prod returned shape {} "
+                             "whilst z0 has shape {}.".format(tuple(system.shape), tuple(z0.shape)))
+    else:
+        if not isinstance(system, torch.Tensor):
+            raise ValueError("z0 is a tensor and so func must return a tensor as well.")
+        _shape_errors(tuple(dX.shape), tuple(system.shape), z0)
+    _lib.require_gpu(dX, "X.derivative(t)")
+    buffers = tuple(X.buffers()) if isinstance(X, torch.nn.Module) else ()
+    if adjoint and "adjoint_params" not in kwargs:
+        for buffer in buffers:
+            if buffer.requires_grad:
+                warnings.warn(_GRAD_WARNING)
+    from . import stepwise
+    dispatch.record(dispatch.Choice(dispatch.STEPWISE, "the control is not one of this package's paths: X.derivative is "
+                                                       "called at every evaluation"), None)
+    kw = dict(kwargs)
+    field = stepwise.ForeignControlField(X, func)
+    return stepwise.solve(X, func, z0, t, adjoint, kw.pop("method", None) or "dopri5", kw.pop("options", None),
+                          kw["rtol"], kw["atol"], kw.get("adjoint_method"), kw.get("adjoint_options"),
+                          kw.get("adjoint_rtol"), kw.get("adjoint_atol"), kw.get("adjoint_params"), field=field)
+
+
 def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
     r"""Solve  z_t = z_{t_0} + \int_{t_0}^t f(s, z_s) dX_s  on the MI355X.
 
@@ -1400,7 +1448,9 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
     if backend != "torchdiffeq":
         raise ValueError(f"Unrecognised backend={backend}")
     if not isinstance(X, _NativePath):
-        raise NotImplementedError("torchcde_amd: X must be a torchcde_amd.CubicSpline or LinearInterpolation.")
+        # solver.py:45-46 asks X for nothing but a `derivative` method: a user-defined control is solved step by step on the
+        # GPU with X.derivative(t) itself under every evaluation (cde_contract for the matrix-vector product)
+        return _cdeint_foreign_control(X, func, z0, t, adjoint, kwargs)
     stepwise_kwargs = dict(kwargs)      # what the step-wise path would receive (the reference forwards these verbatim)
     _lib.require_gpu(z0, "z0")
     packed = X._packed()

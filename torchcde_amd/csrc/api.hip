@@ -214,10 +214,9 @@ static int adjoint_typed(const void* coeffs, const void* knots, int64_t n_interv
     void* sfrac = (unsigned char*)workspace + off_frac_b;
     rc = fill_stage_table<T, TT>(knots, n_intervals, sgrid, n_steps_b, 1, sidx, sfrac, s);
     if (rc != CDE_OK) return rc;
-    // the reverse sweep: K3j with its J rows on the bf16 pipe (rk4_mfma.hip); CDE_K3_FORM=product keeps K3b (three GEMMs,
+    // the reverse sweep: K3j with its J rows on the bf16 pipe (rk4_mfma.hip); CDE_OPT_K3_FORM = 1 keeps K3b (three GEMMs,
     // two of them on the bf16 pipe)
-    const char* form = getenv("CDE_K3_FORM");
-    if (!(form && form[0] == 'p'))
+    if (cde::option(CDE_OPT_K3_FORM) != 1)
       return launch_adjoint_jacobian_bx<TT>(coeffs, knots, n_intervals, degree, W, bias, z_saved, grad_out, sgrid, seg_off,
                                             n_out, grad_z0, grad_W, grad_b, B, C, H, sidx, sfrac,
                                             (float*)((unsigned char*)workspace + off_part_b), s);

@@ -138,6 +138,10 @@ __device__ __forceinline__ double fma_t(double a, double b, double c) { return _
 __device__ __forceinline__ float tanh_t(float x) { return tanhf(x); }
 __device__ __forceinline__ double tanh_t(double x) { return tanh(x); }
 
+// The tuning table (include/cde_mi355x.h, CDE_OPT_*): written by cde_set_option only, read by the layout functions and the
+// launchers.  Defined in interp_kernels.hip.
+int64_t option(int key);
+
 inline int check_launch() { return hipGetLastError() == hipSuccess ? CDE_OK : CDE_ERR_LAUNCH; }
 
 // Zero-fill as a KERNEL, never hipMemsetAsync: captured into a hipGraph, the memset node of this ROCm zeroes its target on

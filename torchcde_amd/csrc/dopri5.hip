@@ -1193,11 +1193,11 @@ static int dopri5_advance_impl(const void* coeffs, const void* knots, int64_t n_
                          cde::DOPRI_IMAGE_BYTES;
       // up to 256 tiles (one workgroup per CU): the 8 waves of a workgroup share a tile
       const int64_t tiles = (B + 15) / 16;
-      const char* split_env = getenv("CDE_K4M_SPLIT_TILES");                    // (measurements)
+      const int64_t split_req = cde::option(CDE_OPT_K4M_SPLIT_TILES);           // (measurements; -1: the default)
       // (an override can only LOWER the threshold: the split form was measured and tested up to these tile counts)
       const int64_t split_max = C > cde::MC ? 256 : cde::DOPRI_MLP_SPLIT_TILES;
-      const int64_t split_tiles = split_env ? (atoll(split_env) < split_max ? (atoll(split_env) > 0 ? atoll(split_env) : 0) : split_max) : split_max;
-      const bool split = tiles <= split_tiles && !ext_sums && B_global == 0 && !getenv("CDE_K4M_NO_SPLIT");
+      const int64_t split_tiles = split_req >= 0 && split_req < split_max ? split_req : split_max;
+      const bool split = tiles <= split_tiles && !ext_sums && B_global == 0 && !cde::option(CDE_OPT_K4M_NO_SPLIT);
       const size_t lds_split = lds + (size_t)cde::DOPRI_XWIN_FLOATS * sizeof(float);
 #define CDE_MLP_CT(D, A, CTV)                                                                                      \
   do {                                                                                                             \
@@ -1239,7 +1239,7 @@ static int dopri5_advance_impl(const void* coeffs, const void* knots, int64_t n_
     // small batches (at most one tile per CU): the 8 waves of a workgroup share a tile -- tanh fields one unit group each,
     // identity fields one K group each
     const int64_t tiles_act = (B + 15) / 16;
-    const bool split_act = tiles_act <= 256 && !ext_sums && B_global == 0 && !getenv("CDE_K4_NO_SPLIT");
+    const bool split_act = tiles_act <= 256 && !ext_sums && B_global == 0 && !cde::option(CDE_OPT_K4_NO_SPLIT);
     const size_t lds_split = lds + (size_t)8 * 64 * 9 * sizeof(float);
     // every form may ask for more than the 64 KB a kernel gets by default (knot buffer up to 32 KB + the 33.8 KB tanh
     // image + the split forms' 18 KB exchange window): the limit is raised per instantiation, as for the other families

@@ -1085,33 +1085,31 @@ MadjLayout madj_layout(int64_t B, int64_t H, int64_t C) {
   using namespace cde;
   MadjLayout L;
   L.n_tiles = (B + 15) / 16;
-  // 16384 series fill the GPU's 1024 SIMDs with one wave each; CDE_K4AM_WAVES=8 runs the large-batch form on any batch
+  // 16384 series fill the GPU's 1024 SIMDs with one wave each; CDE_OPT_K4AM_WAVES = 8 runs the large-batch form on any batch
   // (tests: the 8-wave kernel at a size the CPU oracle can follow)
-  const char* force_waves = getenv("CDE_K4AM_WAVES");
-  L.nwave = (L.n_tiles > 1024 || (force_waves && force_waves[0] == '8')) ? 8 : 4;
+  L.nwave = (L.n_tiles > 1024 || option(CDE_OPT_K4AM_WAVES) == 8) ? 8 : 4;
   // up to MADJ_SPLIT_MAX_TILES tiles (one workgroup per CU in a single round): four waves per tile, the evaluation's middle
   // split four ways
   // (8-channel tiles: the eight-wave form takes ~75 us per round of 256 tiles, the one-wave-per-tile forms 260-420 us
   //  whatever the batch -- measured per attempted step: 8192 series 320 -> 210 us, 12288: 341 -> 303, 16384: 360 vs 394;
-  //  CDE_K4AM_S8_TILES overrides the threshold, for measurements)
-  const char* s8_env = getenv("CDE_K4AM_S8_TILES");
-  const int64_t s8_req = s8_env ? atoll(s8_env) : MADJ_S8_MAX_TILES;      // (an override can only LOWER the measured limit)
-  const int64_t s8_tiles = s8_req < 0 ? 0 : s8_req > MADJ_S8_MAX_TILES ? MADJ_S8_MAX_TILES : s8_req;
-  const bool s8_shape = C <= MC && !getenv("CDE_K4AM_SPLIT4");
+  //  CDE_OPT_K4AM_S8_TILES overrides the threshold, for measurements)
+  const int64_t s8_req = option(CDE_OPT_K4AM_S8_TILES);                   // (-1: the default; an override can only LOWER the measured limit)
+  const int64_t s8_tiles = s8_req < 0 || s8_req > MADJ_S8_MAX_TILES ? MADJ_S8_MAX_TILES : s8_req;
+  const bool s8_shape = C <= MC && !option(CDE_OPT_K4AM_SPLIT4);
   L.split = L.n_tiles <= (s8_shape && s8_tiles > MADJ_SPLIT_MAX_TILES ? s8_tiles : MADJ_SPLIT_MAX_TILES) &&
-            !getenv("CDE_K4AM_NO_SPLIT");
+            !option(CDE_OPT_K4AM_NO_SPLIT);
   // ... eight (two per SIMD, everything split eight ways: mlp_adjoint_eval_split8) when the control fits the 32 x 8 tiling
-  L.split8 = L.split && C <= MC && !getenv("CDE_K4AM_SPLIT4");
+  L.split8 = L.split && C <= MC && !option(CDE_OPT_K4AM_SPLIT4);
   // a few hundred rows per attempt: factor reduction + R in one launch (mlp_adjoint_small_reduce_kernel)
-  L.small = B <= MADJ_SMALL_MAX_ROWS && !getenv("CDE_K4AM_NO_SMALL_REDUCE");
+  L.small = B <= MADJ_SMALL_MAX_ROWS && !option(CDE_OPT_K4AM_NO_SMALL_REDUCE);
   L.n_wg = L.split ? (int)L.n_tiles : (int)((L.n_tiles + L.nwave - 1) / L.nwave);
   int64_t sps = (B + 63) / 64;                     // (measured at 4096 series: 40 slabs 193 us per attempt, 16: 209, 6: 284;
-  const char* sps_env = getenv("CDE_K4AM_SPS");                                  // (measurements)
+  const int64_t sps_req = option(CDE_OPT_K4AM_SPS);                              // (measurements; 0: the default)
   // (20 slabs up to 4096 series are 4 % faster -- 112.4 -> 108.0 us per attempt at 4096 series, half the partials for the R
   //  kernel -- and NOT used: longer float32 chains per slab move the parameter blocks' error estimate, and on the 2048-series
   //  config-5 replay 95.5 % instead of >= 97 % of the mixed-norm error ratios stayed within 2 % of the float64 oracle's)
   const int64_t sps_default = MADJ_MAX_SPS;
-  const int64_t sps_max = sps_env && atoll(sps_env) >= 4 && atoll(sps_env) <= MADJ_MAX_SPS ? atoll(sps_env) : sps_default;
+  const int64_t sps_max = sps_req >= 4 && sps_req <= MADJ_MAX_SPS ? sps_req : sps_default;
   L.sps = (int)(sps < 4 ? 4 : sps > sps_max ? sps_max : sps);        //  at 64 series: 4 slabs 138, 1: 146)
   L.rows_per_slab = ((B + L.sps - 1) / L.sps + 15) / 16 * 16;
   L.rows_per_stage = L.rows_per_slab * L.sps;
@@ -1206,7 +1204,7 @@ static int dopri5_adjoint_mlp_advance_impl(const void* coeffs, const void* knots
   g.U = (float*)(base + L.U); g.G2 = (float*)(base + L.G2); g.G1 = (float*)(base + L.G1); g.Z = (float*)(base + L.Z);
   g.stash_y = (float*)(base + L.stash); g.stash_a = g.stash_y + 3 * B * H; g.stash_t = g.stash_a + 3 * B * H;
   g.n_wg_max = L.n_wg;
-  { const char* e = getenv("CDE_K4AM_NO_FSAL"); g.dbg = !e ? 0 : e[0] == 'a' ? 4 : e[0] == 'r' ? 8 : 2; }                      // bit 1: evaluate every first stage (tests compare the two)
+  { const int64_t e = option(CDE_OPT_K4AM_NO_FSAL); g.dbg = e == 1 ? 2 : e == 2 ? 4 : e == 3 ? 8 : 0; }   // bit 1: evaluate every first stage (tests compare the two); 4 / 8: after accepted / rejected steps only
 #ifdef CDE_PHASE_TRACE
   { const char* d = getenv("CDE_K4AM_DBG"); g.dbg |= d ? atoi(d) & 1 : 0; }      // timing experiments (wrong gradients!)
 #endif

@@ -1512,6 +1512,33 @@ extern "C" int cde_contract(const void* F, const void* dX, void* out, int64_t B,
 
 extern "C" int cde_abi_version(void) { return CDE_ABI_VERSION; }
 
+// ---------------------------------------------------------------------------------------------- tuning table
+#include <atomic>
+namespace cde {
+static constexpr int64_t OPTION_DEFAULTS[CDE_OPT_COUNT] = {
+    /* K3_FORM */ 0, /* K3_WAVES */ 0, /* K3D_WAVES */ 0, /* K2M_NO_SPLIT */ 0, /* K3M_NO_SPLIT */ 0, /* K3M_SPLIT4 */ 0,
+    /* K3M_S8_TILES */ -1, /* K4_NO_SPLIT */ 0, /* K4M_NO_SPLIT */ 0, /* K4M_SPLIT_TILES */ -1, /* K4AM_WAVES */ 0,
+    /* K4AM_S8_TILES */ -1, /* K4AM_SPLIT4 */ 0, /* K4AM_NO_SPLIT */ 0, /* K4AM_NO_SMALL_REDUCE */ 0, /* K4AM_SPS */ 0,
+    /* K4AM_NO_FSAL */ 0, /* WIDE_SCRATCH_BYTES */ 0, /* SPLIT_FORM */ 0};
+static std::atomic<int64_t> g_options[CDE_OPT_COUNT] = {
+    {0}, {0}, {0}, {0}, {0}, {0}, {-1}, {0}, {0}, {-1}, {0}, {-1}, {0}, {0}, {0}, {0}, {0}, {0}, {0}};
+int64_t option(int key) { return g_options[key].load(std::memory_order_relaxed); }
+}  // namespace cde
+
+extern "C" int cde_set_option(int key, int64_t value) {
+  if (key < 0 || key >= CDE_OPT_COUNT) return CDE_ERR_SHAPE;
+  cde::g_options[key].store(value, std::memory_order_relaxed);
+  return CDE_OK;
+}
+extern "C" int64_t cde_get_option(int key) {
+  if (key < 0 || key >= CDE_OPT_COUNT) return INT64_MIN;
+  return cde::option(key);
+}
+extern "C" int cde_reset_options(void) {
+  for (int k = 0; k < CDE_OPT_COUNT; ++k) cde::g_options[k].store(cde::OPTION_DEFAULTS[k], std::memory_order_relaxed);
+  return CDE_OK;
+}
+
 extern "C" const char* cde_error_string(int code) {
   switch (code) {
     case CDE_OK: return "ok";

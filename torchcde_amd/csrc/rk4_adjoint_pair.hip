@@ -661,8 +661,12 @@ int launch_adjoint_jacobian_pair(const void* coeffs, const void* knots, int64_t 
   const Dims dims{(int)H, (int)C};
   const unsigned blocks = (unsigned)((B + 127) / 128);
   const size_t lds = (size_t)KP_LDS_FLOATS * sizeof(float);
-  // bit 0: priority 3 for the chain waves, bit 1: for the helper waves (CDE_K3P_FLAGS, read once: experiments)
+  // bit 0: priority 3 for the chain waves, bit 1: for the helper waves (the trace build reads CDE_K3P_FLAGS once: experiments)
+#ifdef CDE_PHASE_TRACE
   static const int flags = [] { const char* e = getenv("CDE_K3P_FLAGS"); return e ? atoi(e) : 1; }();
+#else
+  constexpr int flags = 1;
+#endif
 #define CDE_ADJ_P(D, M)                                                                                              \
   do {                                                                                                               \
     (void)hipFuncSetAttribute((const void*)rk4_adjoint_jacobian_pair<TT, D, M>,                                      \

@@ -628,8 +628,8 @@ int launch_backprop_jacobian(const void* coeffs, const void* knots, int64_t n_in
     return launch_reduce_partials(partial, (B + 31) / 32, grad_W, grad_b, (int)H, (int)C, s);
   }
   {
-    const char* e = getenv("CDE_K3D_WAVES");          // 1: this file's one-wave kernel, 2: the pair form (tests compare the two)
-    if (e ? e[0] == '2' : K3D_PAIR_DEFAULT)
+    const int64_t e = option(CDE_OPT_K3D_WAVES);      // 1: this file's one-wave kernel, 2: the pair form (tests compare the two)
+    if (e ? e == 2 : K3D_PAIR_DEFAULT)
       return launch_backprop_jacobian_pair(coeffs, knots, n_intervals, degree, W, stages, grad_out, n_out, step_dt, n_steps,
                                            node_ptr, node_out, node_weight, grad_z0, grad_W, grad_b, B, C, H, stage_index,
                                            stage_frac, partial, s);

@@ -1193,7 +1193,7 @@ int launch_forward_mlp(const void* coeffs, const void* knots, int64_t n_interval
   // up to 768 tiles (three rounds of one workgroup per CU still beat 8 tiles per workgroup on a quarter of the CUs): the 8
   // waves of a workgroup share a tile (K2m's split form)
   const int64_t tiles = (B + 15) / 16;
-  const bool split = tiles <= 768 && !getenv("CDE_K2M_NO_SPLIT");
+  const bool split = tiles <= 768 && !option(CDE_OPT_K2M_NO_SPLIT);
   const size_t lds_split = lds + (8 * 64 + 8 * 64 * 4) * sizeof(float);     // f window + (8-channel tiles) the u window
 #define CDE_FWD_CT(D, A, CTV)                                                                                       \
   do {                                                                                                              \
@@ -1332,23 +1332,21 @@ template int launch_forward_mfma_method<double>(int, const void*, const void*, i
                                                 const void*, int64_t, const void*, int64_t, void*, int64_t, int64_t, int64_t,
                                                 const int64_t*, const void*, hipStream_t);
 
-// which of the two adjoint kernels of the affine field runs: K3j (shared Jacobian) unless CDE_K3_FORM=product asks for K3
+// which of the two adjoint kernels of the affine field runs: K3j (shared Jacobian) unless CDE_OPT_K3_FORM = 1 asks for K3
 // (the tests run both against the oracle; scripts compare their timings)
 static bool k3_form_jacobian() {
-  const char* e = getenv("CDE_K3_FORM");
-  return !(e && e[0] == 'p');
+  return option(CDE_OPT_K3_FORM) != 1;
 }
 
-// K3p (rk4_adjoint_pair.hip): K3j as a chain wave + a helper wave per tile, two waves per SIMD.  CDE_K3_WAVES=1 / 2 in the
-// environment picks the form (tests run both; bitwise the same results)
+// K3p (rk4_adjoint_pair.hip): K3j as a chain wave + a helper wave per tile, two waves per SIMD.  CDE_OPT_K3_WAVES = 1 / 2 picks the form (tests run both; bitwise the same results)
 template <typename TT>
 int launch_adjoint_jacobian_pair(const void*, const void*, int64_t, int, const void*, const void*, const void*, const void*,
                                  const void*, const int64_t*, int64_t, void*, void*, void*, int64_t, int64_t, int64_t,
                                  const int64_t*, const void*, float*, hipStream_t, int method);
 constexpr bool K3_PAIR_DEFAULT = true;       // 5.26 -> 5.01 ms on the headline workload (profiles/r05_k3_pair_b.log)
 static bool k3_form_pair() {
-  const char* e = getenv("CDE_K3_WAVES");
-  return e ? e[0] == '2' : K3_PAIR_DEFAULT;
+  const int64_t e = option(CDE_OPT_K3_WAVES);
+  return e ? e == 2 : K3_PAIR_DEFAULT;
 }
 
 template <typename TT>

@@ -535,13 +535,12 @@ int launch_mlp_adjoint_sweep(const void* coeffs, const void* knots, int64_t n_in
   // waves per tile (the split form)
   const int64_t tiles = (B + 15) / 16;
   // (the eight-wave form of 8-channel tiles runs ~7 ms per round of 256 tiles: it beats the one-wave-per-tile form up to
-  //  CDE_K3M_S8_TILES tiles; measured crossover in profiles/NOTES.md)
-  const char* s8_env = getenv("CDE_K3M_S8_TILES");
-  const int64_t s8_req = s8_env ? atoll(s8_env) : K3M_S8_MAX_TILES;       // (an override can only LOWER the measured limit)
-  const int64_t s8_tiles = s8_req < 0 ? 0 : s8_req > K3M_S8_MAX_TILES ? K3M_S8_MAX_TILES : s8_req;
-  const bool s8_shape = C <= MC && !grad_coeffs && !getenv("CDE_K3M_SPLIT4");
+  //  CDE_OPT_K3M_S8_TILES tiles; measured crossover in profiles/NOTES.md)
+  const int64_t s8_req = option(CDE_OPT_K3M_S8_TILES);                    // (-1: the default; an override can only LOWER the measured limit)
+  const int64_t s8_tiles = s8_req < 0 || s8_req > K3M_S8_MAX_TILES ? K3M_S8_MAX_TILES : s8_req;
+  const bool s8_shape = C <= MC && !grad_coeffs && !option(CDE_OPT_K3M_SPLIT4);
   // (control gradients of the 16-channel layout: the one-wave-per-tile form at every batch size)
-  const bool split = tiles <= (s8_shape ? (s8_tiles > 512 ? s8_tiles : 512) : 512) && !getenv("CDE_K3M_NO_SPLIT") &&
+  const bool split = tiles <= (s8_shape ? (s8_tiles > 512 ? s8_tiles : 512) : 512) && !option(CDE_OPT_K3M_NO_SPLIT) &&
                      !(grad_coeffs && C > MC);
   const unsigned blocks = split ? (unsigned)tiles : (unsigned)((B + 127) / 128);
   const unsigned threads = split ? 256 : 512;

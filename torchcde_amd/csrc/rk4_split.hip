@@ -581,8 +581,7 @@ int launch_adjoint_split(const void* coeffs, const void* knots, int64_t n_interv
         (const float*)z_saved, (const float*)grad_out, (const TT*)sgrid, seg_off, n_out, (float*)grad_z0, partial,   \
         B, stage_index, (const float*)stage_frac, dims);                                                             \
   } while (0)
-  const char* form = getenv("CDE_K3_FORM");                          // "product": the two-GEMM chain waves (tests, comparisons)
-  const bool jacobian = !(form && form[0] == 'p');
+  const bool jacobian = option(CDE_OPT_K3_FORM) != 1;                // 1: the two-GEMM chain waves (tests, comparisons)
   if (act == CDE_ACT_NONE && jacobian) {
     if (degree == CDE_PATH_CUBIC) CDE_ADJ(CDE_PATH_CUBIC, CDE_ACT_NONE, true); else CDE_ADJ(CDE_PATH_LINEAR, CDE_ACT_NONE, true);
   } else if (act == CDE_ACT_NONE) {

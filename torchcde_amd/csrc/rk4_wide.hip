@@ -477,9 +477,8 @@ struct WideLayout {
 };
 static inline size_t w256(size_t x) { return (x + 255) / 256 * 256; }
 constexpr size_t WIDE_SCRATCH_BYTES = (size_t)4 << 30;                // factor chunk: at most 4 GB (288 GB of HBM per GPU)
-static size_t wide_scratch_bytes() {                                  // CDE_WIDE_SCRATCH_BYTES overrides (tests: tiny chunks)
-  const char* e = getenv("CDE_WIDE_SCRATCH_BYTES");
-  const long long v = e ? atoll(e) : 0;
+static size_t wide_scratch_bytes() {                                  // CDE_OPT_WIDE_SCRATCH_BYTES overrides (tests: tiny chunks)
+  const int64_t v = option(CDE_OPT_WIDE_SCRATCH_BYTES);
   return v > 0 ? (size_t)v : WIDE_SCRATCH_BYTES;
 }
 

@@ -72,6 +72,24 @@ class ControlledField:
             return _Contract.apply(self.func(t, z), d2X)
 
 
+class ForeignControlField(ControlledField):
+    """The same for a control that is not one of this package's paths (reference solver.py:45-46, :117-135): X.derivative is
+    the user's code, so it is called under the ambient autograd mode with the time it is given -- gradients reach X's own
+    parameters when they are among `adjoint_params`, and the time through X when the control depends on it smoothly."""
+
+    def __call__(self, t, z):
+        dX = self.X.derivative(t)
+        if hasattr(self.func, "prod"):
+            return self.func.prod(t, z, dX)
+        return _Contract.apply(self.func(t, z), dX)
+
+    def time_partial(self, t, z):
+        # nothing to add: X.derivative ran on the very time tensor the adjoint differentiates, so autograd has already
+        # seen the dependence of f on t through the control (ControlledField adds it by hand because the native
+        # derivative kernel is opaque to autograd)
+        return torch.zeros_like(z)
+
+
 def _explicit_dynamics(field, params):
     """The augmented dynamics of the continuous adjoint in closed form for a RECOGNISED vector field (fields.py: the
     probe established bitwise that func is act(Linear(z)) or act(Linear(relu(Linear(z)))) viewed (..., H, C)):
