@@ -606,6 +606,25 @@ int cde_dopri5_adjoint_state_sums(void* workspace, size_t workspace_bytes, int64
                                   int64_t total_launches, double* sums, void* stream);
 int cde_dopri5_adjoint_apply_state_sums(void* workspace, size_t workspace_bytes, int64_t B, int64_t C, int64_t H,
                                         int64_t total_launches, const double* reduced, void* stream);
+/* K4a with CONTROL gradients (round 6): adjoint_params = the field's parameters + the coefficient tensor the path was built
+ * from (reference solver.py:207-222, README.md:251-270; test/test_tricks.py:21-49 with method='dopri5').  torchdiffeq then
+ * integrates dL/dcoeffs as one more block of the augmented state and measures it in the mixed norm like dL/dW, dL/db: the
+ * attempt kernel leaves, per series and stage, d(a.f)/d(dX_c) = sum_h a_h act(Y)_hc; a third small launch per attempted
+ * step (one thread per (series, channel)) chains it to the coefficient rows the stages touch (cubic: 1, frac, frac^2 on
+ * b, 2c, 3d; linear: -+1/width on the two knot values), commits accepted steps into `grad_coeffs` -- the block's running
+ * total -- and leaves the block's norm sums for the next launch's controller.
+ *   grad_coeffs    layout of `coeffs`, zeroed by the caller before the first interval; the same tensor for every interval
+ *   control_numel  element count of the tensor named in adjoint_params (the block's rms runs over all of them)
+ * Workspace: cde_dopri5_adjoint_dcontrol_workspace_bytes (the plain layout is a prefix: the trace / carry / status offsets
+ * above hold).  One controller per solve (no sharded form); everything else as cde_dopri5_adjoint_advance. */
+size_t cde_dopri5_adjoint_dcontrol_workspace_bytes(int64_t B, int64_t C, int64_t H);
+int cde_dopri5_adjoint_advance_dcontrol(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
+                                        const void* W, const void* bias, int act, const void* y_init, const void* a_init,
+                                        double s0, double s1, const double* jump_s, int64_t n_jump, double rtol,
+                                        double atol, double safety, double ifactor, double dfactor, int norm_kind,
+                                        void* a_out, int64_t B, int64_t C, int64_t H, int dtype, int first_interval,
+                                        void* workspace, size_t workspace_bytes, int64_t first_launch, int64_t n_launches,
+                                        void* grad_coeffs, int64_t control_numel, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K4am  K4a for the two-layer field Linear(H, width) -> relu -> Linear(width, H*C) -> tanh | identity of the reference's

@@ -18,7 +18,7 @@ from torchcde_amd import dispatch
 BASE = dispatch.Request(
     prod=False, kind="affine", tiles_ok=True, mfma_shape=True, method="rk4", adjoint=True, wants_grad=True, wants_t=False,
     wants_control=False, params="default", adjoint_method_ok=True, options_ok=True, adjoint_options_ok=True, t_ok=True,
-    variant_generic=False, shared=False, narrow_control=True, backprop_ok=True, identity=True)
+    variant_generic=False, shared=False, narrow_control=True, backprop_ok=True, identity=True, control_block=False)
 
 _MLP = dict(kind="mlp2", mfma_shape=False, identity=False)
 _BOOLS = {"mfma_shape": (False, True), "narrow_control": (False, True), "variant_generic": (False, True),
@@ -34,6 +34,9 @@ CASES = {
     "affine_dopri5_generic":     (dict(method="dopri5", variant_generic=True, mfma_shape=False), "stepwise", ()),
     "affine_dopri5_wide":        (dict(method="dopri5", mfma_shape=False), "stepwise", ("narrow_control",)),
     "affine_dopri5_control":     (dict(method="dopri5", wants_control=True, params="own"), "stepwise", ("wants_t",)),
+    # (round 6) ... unless the control tensors are exactly the coefficient tensor the path was built from: K4a carries that block
+    "affine_dopri5_control_block": (dict(method="dopri5", wants_control=True, params="own", control_block=True), "dopri5_adjoint",
+                                    ("wants_t",)),
     # ------------------------------------------------------------------ adjoint=False: reverse mode through the solver's steps
     "affine_rk4_backprop":       (dict(adjoint=False), "rk4_backprop", ("narrow_control",)),          # (identity or tanh)
     "affine_backprop_beyond_the_kernel": (dict(adjoint=False, backprop_ok=False), "stepwise",

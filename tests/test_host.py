@@ -784,13 +784,14 @@ def test_log_ode_plan_cache_is_keyed_on_the_values_of_t_not_on_its_address():
 
 def test_dispatch_table_is_exhaustively_consistent():
     """torchcde_amd/dispatch.py: the field kind x method x gradient request -> path table that replaced round 2's
-    if-lattice.  ALL combinations of its inputs are enumerated (3 kinds x 3 methods x 2^13 flags x 3 parameter kinds,
+    if-lattice.  ALL combinations of its inputs are enumerated (3 kinds x 3 methods x 2^17 flags x 3 parameter kinds,
     pruned of contradictory ones) and every verdict is checked against the invariants the kernels rely on; then the rows a
     user meets are spelled out one by one."""
     import itertools
     from torchcde_amd import dispatch as D
     flags = ["prod", "tiles_ok", "mfma_shape", "adjoint", "wants_grad", "wants_t", "wants_control", "adjoint_method_ok",
-             "options_ok", "adjoint_options_ok", "t_ok", "variant_generic", "shared", "narrow_control", "backprop_ok", "identity"]
+             "options_ok", "adjoint_options_ok", "t_ok", "variant_generic", "shared", "narrow_control", "backprop_ok", "identity",
+             "control_block"]
     seen = collections_counter = {}
     n = 0
     for kind in (None, "affine", "mlp2"):
@@ -806,6 +807,8 @@ def test_dispatch_table_is_exhaustively_consistent():
                         continue                                 # the reverse-mode sweeps live on the MFMA tiles
                     if f["identity"] and kind != "affine":
                         continue
+                    if f["control_block"] and not (f["wants_control"] and f["adjoint"] and params == "own"):
+                        continue                                 # the one extra entry of adjoint_params: the coefficient tensor
                     q = D.Request(kind=kind, method=method, params=params, **f)
                     c = D.select_path(q)
                     n += 1
@@ -835,7 +838,9 @@ def test_dispatch_table_is_exhaustively_consistent():
                         assert f["adjoint"] and f["adjoint_method_ok"] and f["adjoint_options_ok"] and params != "foreign"
                     if c.path == "dopri5_adjoint":
                         # (output-time gradients: K4a carries vjp_t; not with one controller across shards)
-                        assert f["mfma_shape"] and not f["wants_control"] and not (f["wants_t"] and f["shared"])
+                        # (control gradients: the coefficient tensor as ONE block of the adjoint norm, one controller per solve)
+                        assert f["mfma_shape"] and not (f["wants_t"] and f["shared"])
+                        assert not f["wants_control"] or (f["control_block"] and not f["shared"])
                     if c.path == "mlp_dopri5_adjoint":
                         assert not f["wants_control"] and not (f["wants_t"] and f["shared"])
                     if kind == "mlp2":
@@ -843,14 +848,14 @@ def test_dispatch_table_is_exhaustively_consistent():
                         assert not f["wants_t"] or c.path == "mlp_dopri5_adjoint" or method == "rk4"
                         assert not f["wants_control"] or method == "rk4"
                     if kind == "affine" and (f["wants_t"] or f["wants_control"]):
-                        assert f["mfma_shape"] and (method == "rk4" or not f["wants_control"])
+                        assert f["mfma_shape"] and (method == "rk4" or not f["wants_control"] or f["control_block"])
     assert n > 100000 and set(seen) == set(D.FUSED_PATHS) | {D.STEPWISE}       # every path is reachable
 
     def ask(**kw):
         base = dict(prod=False, kind="affine", tiles_ok=True, mfma_shape=True, method="dopri5", adjoint=True,
                     wants_grad=True, wants_t=False, wants_control=False, params="default", adjoint_method_ok=True,
                     options_ok=True, adjoint_options_ok=True, t_ok=True, variant_generic=False, shared=False,
-                    narrow_control=True, backprop_ok=True, identity=True)
+                    narrow_control=True, backprop_ok=True, identity=True, control_block=False)
         base.update(kw)
         return D.select_path(D.Request(**base))
     # the rows a user meets
@@ -864,6 +869,10 @@ def test_dispatch_table_is_exhaustively_consistent():
     assert ask(kind="mlp2", mfma_shape=False, shared=True).path == "mlp_dopri5_adjoint"    # ... for the examples' model too
     assert ask(method="rk4", wants_control=True, params="own").path == "rk4"    # README.md:251-270
     assert ask(wants_t=True).path == "dopri5_adjoint"                           # output-time gradients: K4a carries vjp_t
+    # README.md:251-270 with the default method: adjoint_params = parameters + (coeffs,) -- one more block of K4a's norm
+    assert ask(wants_control=True, params="own", control_block=True).path == "dopri5_adjoint"
+    assert ask(wants_control=True, params="own", control_block=True, wants_t=True).path == "dopri5_adjoint"
+    assert ask(wants_control=True, params="own", control_block=True, shared=True).path == D.STEPWISE
     assert ask(method="rk4", adjoint=False).path == "rk4_backprop"              # README.md:103: backprop through the solver
     assert ask(kind="mlp2", mfma_shape=False, method="rk4", adjoint=False).path == "mlp_rk4_backprop"
     assert ask(method="rk4", adjoint=False, wants_control=True).path == "rk4_backprop"      # test/test_tricks.py:21-49, adjoint=False

@@ -945,13 +945,16 @@ class _Dopri5Plan:
             last_dopri5_stats["steps"] = workspace[off:off + 24 * n].view(torch.float64).view(n, 3).cpu()
         return out
 
-    def run_adjoint(self, z_saved, grad_out, weight, bias, want_t=False):
+    def run_adjoint(self, z_saved, grad_out, weight, bias, want_t=False, want_control=False):
         """K4a: torchdiffeq's odeint_adjoint backward for the adaptive solve -- default mixed norm (or "seminorm"), dense
         output at the interval ends -- one attempt kernel + one reduction kernel per attempted step
         (csrc/dopri5_adjoint.hip), output intervals from the last to the first.
         want_t: the output times require a gradient (torchdiffeq's time_vjps): dL/dt_i = f(t_i, z_i) . dL/dz_i for i >= 1
         (one field evaluation per output time, here); vjp_t -- which K4a integrates and measures in its error norm anyway --
-        starts every interval at its carried value minus that term, and is dL/dt_0 after the last one."""
+        starts every interval at its carried value minus that term, and is dL/dt_0 after the last one.
+        want_control: adjoint_params names the coefficient tensor (self.control_numel elements): dL/dcoeffs, packed layout,
+        is appended to the result -- one more block of the mixed norm, accumulated on the device
+        (cde_dopri5_adjoint_advance_dcontrol)."""
         lib = _lib.load()
         B, H, C, dev = self.B, self.H, self.C, self.device
         z_saved = z_saved.detach().reshape(B, self.n_out, H)
@@ -961,9 +964,13 @@ class _Dopri5Plan:
         flat = torch.zeros(n_w + H * C, dtype=torch.float32, device=dev)       # one buffer: a single all-reduce upstream
         grad_w, grad_b = flat[:n_w].view(H * C, H), flat[n_w:]
         a = grad_out[:, -1].contiguous()
+        grad_x = torch.zeros_like(self.coeffs) if want_control else None
+        tail = (grad_x,) if want_control else ()
         if self.n_out == 1:
-            return (a, grad_w, grad_b, torch.zeros(1, dtype=torch.float32, device=dev)) if want_t else (a, grad_w, grad_b)
-        nbytes = lib.cde_dopri5_adjoint_workspace_bytes(B, C, H)
+            return ((a, grad_w, grad_b, torch.zeros(1, dtype=torch.float32, device=dev)) if want_t else (a, grad_w, grad_b)) + tail
+        if want_control and self.shared is not None:
+            raise NotImplementedError("torchcde_amd: control gradients through the adaptive backward have no shared-controller form")
+        nbytes = (lib.cde_dopri5_adjoint_dcontrol_workspace_bytes if want_control else lib.cde_dopri5_adjoint_workspace_bytes)(B, C, H)
         workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         workspace[:_WORKSPACE_HEAD].zero_()     # controller blocks + partial sums: defined before the first launch reads them
         size = ctypes.sizeof(_lib.DopriStatus)
@@ -1003,13 +1010,18 @@ class _Dopri5Plan:
             launched = 0
             while True:
                 def advance(first, count, sums_ptr, global_batch):
-                    _lib.check(lib.cde_dopri5_adjoint_advance(
-                        _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w),
-                        _lib.ptr(b), self.act, _lib.ptr(y), _lib.ptr(a), s0, s1, _lib.ptr(self.jump_s), self.n_jump_s,
-                        self.adjoint_rtol, self.adjoint_atol, self.adj_safety, self.adj_ifactor, self.adj_dfactor,
-                        self.adj_norm_kind, _lib.ptr(a_out), B, C, H, _lib.dtype_enum(torch.float32),
-                        int(i == self.n_out - 1) | (2 if want_t else 0), _lib.ptr(workspace), workspace.numel(), first,
-                        count, sums_ptr, global_batch, stream), "cde_dopri5_adjoint_advance")
+                    head = (_lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w),
+                            _lib.ptr(b), self.act, _lib.ptr(y), _lib.ptr(a), s0, s1, _lib.ptr(self.jump_s), self.n_jump_s,
+                            self.adjoint_rtol, self.adjoint_atol, self.adj_safety, self.adj_ifactor, self.adj_dfactor,
+                            self.adj_norm_kind, _lib.ptr(a_out), B, C, H, _lib.dtype_enum(torch.float32),
+                            int(i == self.n_out - 1) | (2 if want_t else 0), _lib.ptr(workspace), workspace.numel(), first,
+                            count)
+                    if want_control:
+                        _lib.check(lib.cde_dopri5_adjoint_advance_dcontrol(*head, _lib.ptr(grad_x), int(self.control_numel),
+                                                                           stream), "cde_dopri5_adjoint_advance_dcontrol")
+                    else:
+                        _lib.check(lib.cde_dopri5_adjoint_advance(*head, sums_ptr, global_batch, stream),
+                                   "cde_dopri5_adjoint_advance")
                 if shared is None:
                     advance(launched, _DOPRI_CHUNK, None, 0)
                     launched += _DOPRI_CHUNK
@@ -1065,8 +1077,8 @@ class _Dopri5Plan:
             last_dopri5_adjoint_stats["attempts"] = attempts     # (t0, t1, on_jump, accepted, ratio) of EVERY attempt
         if want_t:
             time_terms[0] = carry.to(torch.float32).reshape(())       # time_vjps[0] = the carried vjp_t
-            return a, grad_w, grad_b, torch.stack(time_terms)
-        return a, grad_w, grad_b
+            return (a, grad_w, grad_b, torch.stack(time_terms)) + tail
+        return (a, grad_w, grad_b) + tail
 
     def run_adjoint_mlp(self, z_saved, grad_out, w1, b1, w2, b2, want_t=False):
         """K4am: the same backward for the two-layer field (csrc/dopri5_mlp_adjoint.hip): per attempted step the attempt
@@ -1250,10 +1262,13 @@ class _Dopri5Plan:
 
 class _FusedDopri5(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, z0, weight, bias, plan, wants, t=None):
+    def forward(ctx, z0, weight, bias, plan, wants, t=None, *control):
+        # `control`: the path's buffers the control derivative reads, present (and differentiable inputs) only when the
+        # coefficient tensor is among adjoint_params -- K4a then integrates dL/dcoeffs as one more block of the adjoint state
         out = plan.run(z0, weight, bias)
         ctx.plan, ctx.wants = plan, wants
         ctx.t_like = t
+        ctx.want_x = len(control) > 0
         ctx.save_for_backward(out, weight, bias)
         return out.reshape(*plan.batch, plan.n_out, plan.H)
 
@@ -1263,15 +1278,18 @@ class _FusedDopri5(torch.autograd.Function):
         plan = ctx.plan
         out, weight, bias = ctx.saved_tensors
         want_t = ctx.t_like is not None and ctx.needs_input_grad[5]
-        res = plan.run_adjoint(out, grad_out, weight, bias, want_t=want_t)
+        res = plan.run_adjoint(out, grad_out, weight, bias, want_t=want_t, want_control=ctx.want_x)
         grad_z0, grad_w, grad_b = res[:3]
         grad_t = None
         if want_t:                                # on `t`'s own device: cdeint accepts a CPU `t` next to GPU data
             grad_t = res[3].to(device=ctx.t_like.device, dtype=ctx.t_like.dtype)
         want_w, want_b = ctx.wants
+        control_grads = ()
+        if ctx.want_x:
+            control_grads = _control_gradients(plan, res[-1], True, False, ctx.needs_input_grad[6:], None)[1:]
         return (grad_z0.reshape(*plan.batch, plan.H) if ctx.needs_input_grad[0] else None,
                 grad_w.view_as(weight) if (ctx.needs_input_grad[1] and want_w) else None,
-                grad_b.view_as(bias) if (ctx.needs_input_grad[2] and want_b) else None, None, None, grad_t)
+                grad_b.view_as(bias) if (ctx.needs_input_grad[2] and want_b) else None, None, None, grad_t) + control_grads
 
 
 class _FusedMlpDopri5(torch.autograd.Function):
@@ -1557,6 +1575,16 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         if field is None and any(p is X._t for p in extra) and method != "rk4":
             params_kind = "foreign"             # knot-time gradients of a two-layer solve: under rk4, else step-wise
 
+    # the adaptive backward measures every entry of adjoint_params as a block of its error norm: control gradients are fused
+    # there when the ONE extra entry is the packed coefficient tensor the path reads (its buffers are views of it)
+    control_block = None
+    if given_params is not None and known is not None and params_kind == "own":
+        extra = [p for p in given_params if not any(p is o for o in own)]
+        if (len(extra) == 1 and extra[0] is not X._t and extra[0].requires_grad and extra[0].is_contiguous()
+                and extra[0].numel() == packed.numel() and extra[0].dtype == packed.dtype
+                and extra[0].untyped_storage().data_ptr() == packed.untyped_storage().data_ptr()):
+            control_block = extra[0]
+
     fixed_keys, adaptive_keys = {"step_size"}, {"jump_t", "safety", "ifactor", "dfactor"}
     # ONE normalised view of the options for the fused paths (the step-wise path gets them verbatim, like torchdiffeq):
     # None values and torchdiffeq's own defaults spelled out are the same request as leaving the key away
@@ -1583,7 +1611,8 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         variant_generic=variant == _lib.VARIANT_GENERIC, shared=step_control() is not None, narrow_control=C <= 8,
         backprop_ok=bool((mfma_shape and variant in (_lib.VARIANT_AUTO, _lib.VARIANT_MFMA))
                          or (mlp is not None and variant == _lib.VARIANT_AUTO)),
-        identity=bool(field is not None and field.act == _lib.ACT_NONE))
+        identity=bool(field is not None and field.act == _lib.ACT_NONE),
+        control_block=control_block is not None)
     if recognised_kind is not None and known is None:
         # the probe recognised the formula but the shape / dtype is beyond the tiles: say so in the record and the warning
         request = request._replace(kind=recognised_kind, tiles_ok=False)
@@ -1660,7 +1689,11 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
                 return plan.run(z0, weight, bias).reshape(*batch, plan.n_out, H)
         wants = (True, True) if given_params is None else (any(p is weight for p in given_params),
                                                            any(p is bias for p in given_params))
-        return _FusedDopri5.apply(z0, weight, bias, plan, wants, t if wants_t else None)
+        # control gradients: dL/dcoeffs flows back to the caller's tensor through the path's buffer views
+        want_x = bool(control_wants and control_block is not None)
+        control_inputs = X._control_buffers() if want_x else ()
+        plan.control_numel = control_block.numel() if want_x else 0
+        return _FusedDopri5.apply(z0, weight, bias, plan, wants, t if wants_t else None, *control_inputs)
     step_size = _parse_fixed_options(fused_options, "solver")
     adjoint_step = step_size if fused_adj_opts is None else _parse_fixed_options(fused_adj_opts, "adjoint")
     want_w = want_b = True

@@ -41,6 +41,24 @@ constexpr int ADJ_MAX_WG = 256;
 constexpr int ADJ_LDS_FLOATS = 2 * SPL_ZBUF + 2 * SPL_ZT + 2 * SPL_VA + 2 * 2 * 7 * SPL_DX + 2 * 4 * SPL_GT;
 constexpr size_t ADJ_LDS_BYTES = (size_t)ADJ_LDS_FLOATS * sizeof(float) + 4 * 512 * sizeof(double);
 constexpr int ADJ_RBLOCKS = ADJ_IMAGE_FLOATS / 16;               // blocks of the R kernel: 16 image slots each
+// DCTRL (control gradients: adjoint_params holds the coefficient tensor the path was built from, reference solver.py:207-222,
+// README.md:251-270).  torchdiffeq then integrates one more block of the augmented state -- dL/dcoeffs, the size of the
+// coefficient tensor -- and measures it in the mixed norm like the parameter blocks.  Its integrand is local to a series:
+// per stage gx_c = sum_h a_h act(Y)_hc = d(a.f)/d(dX_c), chained to the coefficient row in use (cubic: 1, frac, frac^2 on
+// b, 2c, 3d; linear: -+1/width on the two knot values).  The chain waves (product form only: the cached-Jacobian chain
+// never forms act(Y)) leave their two units' shares of gx in an LDS tile, helper waves 0 / 1 add the 16 shares of a
+// (series, channel) one stage behind and store the seven UNWEIGHTED values of the attempt; `adjoint_control_kernel` (one
+// thread per (series, channel), right after the R kernel) applies the stage weights of the launch's record, commits to the
+// gradient tensor itself -- which is the running total G of this block -- and leaves the block's norm sums.
+constexpr int ADJ_GX_TILE = 16 * 16 * 8;                         // [chain wave * 4 + lane quarter][series][channel]
+constexpr int ADJ_GX_ROW = 64;                                   // floats per series in the pending buffer: [channel][8 stages]
+struct AdjStageRec {                                             // what a launch computed, for the control kernel (uniform)
+  int32_t mode, ns;
+  int32_t sidx[7];
+  float sfrac[7], wS[7], wE[7];
+};
+constexpr int ADJ_REC_STRIDE = 128;
+static_assert(sizeof(AdjStageRec) <= ADJ_REC_STRIDE, "stage record outgrew its slot");
 
 struct DopriAdjArgs {
   const float* coeffs; const float* knots; int64_t n_intervals;
@@ -55,6 +73,11 @@ struct DopriAdjArgs {
   float* att;                       // [ADJ_MAX_WG][2][ADJ_IMAGE_FLOATS]: this launch's S and E images
   AdjCommon com;
   const double* ext_sums;           // sharded batch: the ADJ_NS pending sums added up over all shards (else nullptr)
+  // DCTRL
+  float* gx;                        // [2][B][ADJ_GX_ROW]: the launch's per-stage d(a.f)/d(dX_c), unweighted
+  unsigned char* rec;               // [2] AdjStageRec, ADJ_REC_STRIDE bytes apart
+  const double* cq;                 // [2][n_cblocks][2]: the control kernel's norm sums
+  int n_cblocks;
 };
 
 __device__ __forceinline__ AdjCtrl* adj_ctrl(unsigned char* base, int which) {
@@ -65,7 +88,7 @@ __device__ __forceinline__ AdjCtrl* adj_ctrl(unsigned char* base, int which) {
 __device__ unsigned long long k4a_phase_trace[TRACE_RING * TRACE_BLOCKS * TRACE_SLOTS];
 #endif
 
-template <int DEGREE, int ACT>
+template <int DEGREE, int ACT, bool DCTRL = false>
 __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g, int parity) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
@@ -79,9 +102,10 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
   // touch of the control rows the first tile is likely to need.
   const double* Pp = g.partial + (int64_t)p * ADJ_MAX_WG * ADJ_NS;
   const double* Qp = g.pq + (int64_t)p * ADJ_RBLOCKS * 4;
-  double sum[ADJ_NS + 4];
+  constexpr int NQ = DCTRL ? 8 : 4;                                 // norm slots of the parameter blocks: W, b (, coefficients)
+  double sum[ADJ_NS + NQ];
 #pragma unroll
-  for (int i = 0; i < ADJ_NS + 4; ++i) sum[i] = 0.0;
+  for (int i = 0; i < ADJ_NS + NQ; ++i) sum[i] = 0.0;
   if (!g.ext_sums) {
     for (int64_t b = tid; b < (int64_t)gridDim.x; b += blockDim.x) {
 #pragma unroll
@@ -91,6 +115,10 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
   for (int b = tid; b < ADJ_RBLOCKS; b += blockDim.x) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) sum[ADJ_NS + i] += Qp[4 * b + i];
+  }
+  if constexpr (DCTRL) {
+    const double* Cp = g.cq + (int64_t)p * g.n_cblocks * 2;
+    for (int b = tid; b < g.n_cblocks; b += blockDim.x) { sum[ADJ_NS + 4] += Cp[2 * b]; sum[ADJ_NS + 5] += Cp[2 * b + 1]; }
   }
   AdjCtrl k = *adj_ctrl(g.ctrl, p);
   DopriCtrl& c = k.c;
@@ -118,6 +146,7 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
   float* d2b = dxb + 2 * 7 * SPL_DX;                               // the same for d2X/dt2 (cubic controls: vjp_t)
   float* gT = d2b + 2 * 7 * SPL_DX + w * SPL_GT;                   // + (parity) * 4 * SPL_GT
   double* red = reinterpret_cast<double*>(lds + ADJ_LDS_FLOATS);
+  float* gxb = lds + ADJ_LDS_FLOATS + 4096;                         // DCTRL: [2][ADJ_GX_TILE], behind the 16 KB of `red`
   const int64_t BH = g.B * g.dims.H;
   const float* Sp = g.state + (int64_t)p * 4 * BH;
   float* Sq = g.state + (int64_t)p2 * 4 * BH;
@@ -133,7 +162,7 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
   // (the shared-Jacobian form of rk4_split.hip) -- and dX is constant inside a knot interval, so J is formed once per
   // tile and interval (32 MFMAs) and every further stage in that interval costs the chain wave no MFMA at all: with
   // jump_t on the knots (steps never cross one) that is every stage but the first of a tile.
-  constexpr bool JC = DEGREE == CDE_PATH_LINEAR && ACT == CDE_ACT_NONE;
+  constexpr bool JC = DEGREE == CDE_PATH_LINEAR && ACT == CDE_ACT_NONE && !DCTRL;
   float wy[4][8], wv[2][16];
   f32x4 by[4];
   float wj[JC ? 16 : 1][2];
@@ -163,7 +192,7 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
   // ---- pending global sums (fixed order: the decision is identical in every workgroup and run to run): the state
   // sums of the previous attempt launch and the parameter sums its R kernel left
   if (phase_in != 0) {
-    block_total<ADJ_NS + 4>(sum, red);
+    block_total<ADJ_NS + NQ>(sum, red);
     if (g.ext_sums) {
 #pragma unroll
       for (int i = 0; i < ADJ_NS; ++i) sum[i] = g.ext_sums[i];
@@ -225,6 +254,15 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
 #pragma unroll
   for (int j = 0; j < 7; ++j) { wS[j] = uni(wS[j]); wE[j] = uni(wE[j]); }
   const bool img_e = mode == 2 && g.com.norm_kind == 0;            // the E image: only when the parameter blocks are in the norm
+  if constexpr (DCTRL) {
+    if (blockIdx.x == 0 && tid == 0) {
+      AdjStageRec rc;
+      rc.mode = mode; rc.ns = ns;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) { rc.sidx[j] = sidx[j]; rc.sfrac[j] = sfrac[j]; rc.wS[j] = wS[j]; rc.wE[j] = wE[j]; }
+      *reinterpret_cast<AdjStageRec*>(g.rec + p * ADJ_REC_STRIDE) = rc;
+    }
+  }
 
   int par = 0, gpar = 0, dbuf = 0;
   double acc[ADJ_NS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -280,6 +318,16 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
       }
     };
     if ((int64_t)blockIdx.x < g.n_tiles) { feed_request(blockIdx.x); feed_store(0); }
+    // DCTRL: helper waves 0 / 1 own (series 8w + (lane >> 3), channel lane & 7): the 16 chain-wave shares of a stage, in a
+    // fixed order, one stage behind like the g tile
+    const bool sums_gx = DCTRL && w < 2;
+    const int gx_at = (8 * w + (lane >> 3)) * 8 + (lane & 7);
+    auto gx_sum = [&](int gp) {
+      float t = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) t += gxb[gp * ADJ_GX_TILE + kk * 128 + gx_at];
+      return t;
+    };
 #ifdef CDE_PHASE_TRACE
     int htile = -1;
 #endif
@@ -291,6 +339,7 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
       if (has_next) feed_request(tile + gridDim.x);
       spl_barrier();
       f32x2 zr[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};      // z of the stage whose g tile is next
+      float gxs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       // one stage's contribution to the images: g^T (w z) for each functional with a non-zero weight on that stage
 #ifdef CDE_PHASE_TRACE
       int hstage = -1;
@@ -333,6 +382,7 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
           const float4 zt0 = *reinterpret_cast<const float4*>(ztr + par * SPL_ZT);
           const float4 zt1 = *reinterpret_cast<const float4*>(ztr + par * SPL_ZT + 16 * SPL_TROW);
           if (i >= 1) dw_round(gpar ^ 1, wS[i - 1], img_e ? wE[i - 1] : 0.f);      // stage i-1's tile
+          if constexpr (DCTRL) { if (i >= 1 && sums_gx) gxs[i - 1] = gx_sum(gpar ^ 1); }
 #ifdef CDE_PHASE_TRACE
           if (htile == 1 && i == 3) { asm volatile("s_nop 0" : "+v"(accA[3][1]), "+v"(accE[3][1])); CDE_STAMP(22); }
 #endif
@@ -348,6 +398,18 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
       if (ns == 1) dw_round(gpar ^ 1, wS[0], 0.f);
       else if (ns == 2) dw_round(gpar ^ 1, wS[1], 0.f);
       else dw_round(gpar ^ 1, wS[6], img_e ? wE[6] : 0.f);
+      if constexpr (DCTRL) {
+        if (sums_gx) {
+          const float last = gx_sum(gpar ^ 1);
+          if (ns == 1) gxs[0] = last; else if (ns == 2) gxs[1] = last; else gxs[6] = last;
+          const int64_t series = tile * 16 + 8 * w + (lane >> 3);
+          if (series < g.B) {
+            float* dst = g.gx + ((int64_t)p * g.B + series) * ADJ_GX_ROW + (lane & 7) * 8;
+            *reinterpret_cast<float4*>(dst) = make_float4(gxs[0], gxs[1], gxs[2], gxs[3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(gxs[4], gxs[5], gxs[6], 0.f);
+          }
+        }
+      }
       if (has_next) feed_store(dbuf ^ 1);
       dbuf ^= 1;
     }
@@ -544,6 +606,7 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
             d2X[4] = e47.x; d2X[5] = e47.y; d2X[6] = e47.z; d2X[7] = e47.w;
           }
           float* gwp = gw_ + gpar * 4 * SPL_GT;
+          f32x2 gx2[4];                                            // DCTRL: a_ua act(Y)_(ua, c) + a_ub act(Y)_(ub, c), channel pairs
 #pragma unroll
           for (int T = 0; T < 4; ++T) {
             const float aown = (T >> 1) ? asb : asa;
@@ -551,6 +614,10 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
             for (int j = 0; j < 2; ++j) {
               const f32x2 dx = {dX[4 * (T & 1) + 2 * j], dX[4 * (T & 1) + 2 * j + 1]};
               const f32x2 t = activate2<ACT>(yt[T][2 * j], yt[T][2 * j + 1]);
+              if constexpr (DCTRL) {
+                if (T >> 1) gx2[(T & 1) * 2 + j] = __builtin_elementwise_fma(t, f32x2{aown, aown}, gx2[(T & 1) * 2 + j]);
+                else gx2[(T & 1) * 2 + j] = t * aown;
+              }
               if (T >> 1) fpb = __builtin_elementwise_fma(t, dx, fpb); else fpa = __builtin_elementwise_fma(t, dx, fpa);
               if (DEGREE == CDE_PATH_CUBIC) {
                 const f32x2 d2 = {d2X[4 * (T & 1) + 2 * j], d2X[4 * (T & 1) + 2 * j + 1]};
@@ -561,6 +628,11 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
               gwp[(T * 16 + 2 * j) * SPL_TROW] = gq[T][j][0];
               gwp[(T * 16 + 2 * j + 1) * SPL_TROW] = gq[T][j][1];
             }
+          }
+          if constexpr (DCTRL) {
+            float* gxw = gxb + gpar * ADJ_GX_TILE + ((w * 4 + q) * 16 + n) * 8;
+            *reinterpret_cast<float4*>(gxw) = make_float4(gx2[0][0], gx2[0][1], gx2[1][0], gx2[1][1]);
+            *reinterpret_cast<float4*>(gxw + 4) = make_float4(gx2[2][0], gx2[2][1], gx2[3][0], gx2[3][1]);
           }
           kya[i] = -(fpa[0] + fpa[1]); kyb[i] = -(fpb[0] + fpb[1]);          // reverse time: dy/ds = -f
           // d vjp_t / ds = + a . (df/dt) with the stage value of a (padded lanes carry a == 0)
@@ -772,6 +844,134 @@ __global__ __launch_bounds__(256) void adjoint_reduce_kernel(AdjReduceArgs r, in
   }
 }
 
+// ------------------------------------------------------------------------------------------ the control kernel (DCTRL)
+// One thread per (series, channel), launched after the R kernel of every attempt launch.  The gradient tensor `G` (layout of
+// the coefficient tensor, zeroed by the caller) IS the running total of the block; per launch the thread
+//   1. commits what the controller decided: the previous attempt's increment (commit 1: its record and pending values are
+//      still in the other parity's slots) or this launch's dense-output functional (commit 2, mode 3);
+//   2. adds this launch's contribution to the block's two norm slots -- over the entries the launch's stages touch (elsewhere
+//      its S and E are zero), and in mode 0 over the whole tensor (Hairer's d0 = |G / scale|) -- with the float arithmetic
+//      of adj_param_element.
+// Entries: cubic (row, j) <- sum over the stages in that row of w gx frac^j (b, 2c, 3d: interpolation_cubic.py:334-335);
+// linear knot value e <- sum of +- w gx / width over the stages whose interval ends / starts there
+// (interpolation_linear.py:186-191, :222-225).
+struct AdjControlArgs {
+  unsigned char* ctrl; const unsigned char* rec; const float* gx; float* G; const float* knots; double* cq;
+  int64_t B, n_intervals;
+  int C, degree, norm_kind;
+  float rtol, atol;
+};
+
+template <int DEGREE>
+__device__ __forceinline__ void control_entry(const AdjStageRec& rc, const float (&gxv)[8], const float* __restrict__ knots,
+                                              int e, int j, float& S, float& E) {
+  S = 0.f; E = 0.f;
+#pragma unroll
+  for (int s = 0; s < 7; ++s) {
+    if (s < rc.ns) {
+      float chain = 0.f;
+      if (DEGREE == CDE_PATH_CUBIC) {
+        if (rc.sidx[s] == e) chain = j == 0 ? 1.f : j == 1 ? rc.sfrac[s] : rc.sfrac[s] * rc.sfrac[s];
+      } else {
+        const float width = knots[rc.sidx[s] + 1] - knots[rc.sidx[s]];
+        if (rc.sidx[s] == e) chain = -1.f / width; else if (rc.sidx[s] + 1 == e) chain = 1.f / width;
+      }
+      const float v = gxv[s] * chain;
+      S = __builtin_fmaf(rc.wS[s], v, S);
+      E = __builtin_fmaf(rc.wE[s], v, E);
+    }
+  }
+}
+
+template <int DEGREE>
+__global__ __launch_bounds__(256) void adjoint_control_kernel(AdjControlArgs r, int parity) {
+  __shared__ double red[2][4];
+  const int p2 = parity ^ 1;
+  const AdjCtrl k = *adj_ctrl(r.ctrl, p2);                          // written by the attempt launch just before this one
+  if (k.c.phase == 4 && k.commit == 0) return;
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t series = id >> 3;
+  const int c = (int)(id & 7);
+  const bool on = series < r.B && c < r.C;
+  constexpr int NJ = DEGREE == CDE_PATH_CUBIC ? 3 : 1;
+  double q0 = 0.0, q1 = 0.0;
+  if (on) {
+    const AdjStageRec cur = *reinterpret_cast<const AdjStageRec*>(r.rec + parity * ADJ_REC_STRIDE);
+    auto pending = [&](int which, float (&v)[8]) {
+      const float* src = r.gx + ((int64_t)which * r.B + series) * ADJ_GX_ROW + c * 8;
+      const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+      v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+    };
+    auto element = [&](int e, int j) -> float* {
+      return DEGREE == CDE_PATH_CUBIC ? r.G + ((series * r.n_intervals + e) * 4 + 1 + j) * r.C + c
+                                      : r.G + (series * (r.n_intervals + 1) + e) * r.C + c;
+    };
+    auto span = [&](const AdjStageRec& rc, int& lo, int& hi) {
+      lo = rc.sidx[0]; hi = rc.sidx[0];
+      for (int s = 1; s < rc.ns; ++s) { lo = rc.sidx[s] < lo ? rc.sidx[s] : lo; hi = rc.sidx[s] > hi ? rc.sidx[s] : hi; }
+      if (DEGREE == CDE_PATH_LINEAR) hi += 1;
+    };
+    float gxc[8];
+    pending(parity, gxc);
+    // ---- 1. commit
+    if (k.commit == 1) {
+      const AdjStageRec prev = *reinterpret_cast<const AdjStageRec*>(r.rec + p2 * ADJ_REC_STRIDE);
+      float gxp[8];
+      pending(p2, gxp);
+      int lo, hi;
+      span(prev, lo, hi);
+      for (int e = lo; e <= hi; ++e)
+        for (int j = 0; j < NJ; ++j) {
+          float S, E;
+          control_entry<DEGREE>(prev, gxp, r.knots, e, j, S, E);
+          *element(e, j) += S;
+        }
+    } else if (k.commit == 2) {
+      int lo, hi;
+      span(cur, lo, hi);
+      for (int e = lo; e <= hi; ++e)
+        for (int j = 0; j < NJ; ++j) {
+          float S, E;
+          control_entry<DEGREE>(cur, gxc, r.knots, e, j, S, E);
+          *element(e, j) += S;
+        }
+    }
+    // ---- 2. this launch's share of the block's norm slots
+    if (r.norm_kind == 0 && k.mode != 3) {
+      if (k.mode == 0) {
+        const int n_e = (int)(DEGREE == CDE_PATH_CUBIC ? r.n_intervals : r.n_intervals + 1);
+        for (int e = 0; e < n_e; ++e)
+          for (int j = 0; j < NJ; ++j) {
+            const float g = *element(e, j), sc = r.atol + fabsf(g) * r.rtol, u = g / sc;
+            q0 += (double)(u * u);
+          }
+      }
+      int lo, hi;
+      span(cur, lo, hi);
+      for (int e = lo; e <= hi; ++e)
+        for (int j = 0; j < NJ; ++j) {
+          float S, E;
+          control_entry<DEGREE>(cur, gxc, r.knots, e, j, S, E);
+          const float g = *element(e, j);
+          if (k.mode == 0) { const float sc = r.atol + fabsf(g) * r.rtol, v = S / sc; q1 += (double)(v * v); }
+          else if (k.mode == 1) { const float sc = r.atol + fabsf(g) * r.rtol, v = S / sc; q0 += (double)(v * v); }
+          else { const float tol = r.atol + r.rtol * fmaxf(fabsf(g), fabsf(g + S)), v = E / tol; q0 += (double)(v * v); }
+        }
+    }
+  }
+  if (r.norm_kind != 0 || k.mode == 3) return;
+  // the block's sums (fixed order)
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { q0 += __shfl_xor(q0, off, 64); q1 += __shfl_xor(q1, off, 64); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = q0; red[1][threadIdx.x >> 6] = q1; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const int i = threadIdx.x;
+    // slot p2: where the NEXT attempt launch (parity p2) looks for the sums pending on it, like the R kernel's
+    r.cq[((int64_t)p2 * gridDim.x + blockIdx.x) * 2 + i] = (red[i][0] + red[i][1]) + (red[i][2] + red[i][3]);
+  }
+}
+
 // dL/dW, dL/db from the running total in image layout.  Image of helper wave w, lane (n = l & 15, q = l >> 4): register
 // (Tm*2 + Tn)*4 + r = dW[h = 8w + 4(Tm>>1) + q][c = 4(Tm&1) + r][k = 16 Tn + n]; register 32 + Tm of the q == 0 lane =
 // the bias gradient of h = 8w + 4(Tm>>1) + (n>>2), c = 4(Tm&1) + (n&3).
@@ -810,6 +1010,8 @@ extern "C" int cde_debug_k4a_phase_trace(void* host_out, size_t bytes) {
 namespace {
 struct AdjLayout {
   size_t partial, pq, carry, state, G, G_local, prev, att, trace, trace_all, total;
+  size_t rec, cq, gx, total_dcontrol;
+  int n_cblocks;
 };
 AdjLayout adj_layout(int64_t B, int64_t H) {
   using namespace cde;
@@ -825,6 +1027,12 @@ AdjLayout adj_layout(int64_t B, int64_t H) {
   L.trace = L.att + a256((size_t)ADJ_MAX_WG * 2 * ADJ_IMAGE_FLOATS * sizeof(float));
   L.trace_all = L.trace + a256((size_t)CDE_DOPRI5_TRACE_STEPS * 3 * sizeof(double));
   L.total = L.trace_all + a256((size_t)ADJ_TRACE_ATTEMPTS * 5 * sizeof(double));
+  // control gradients (cde_dopri5_adjoint_advance_dcontrol): behind everything else, so the plain layout is a prefix
+  L.n_cblocks = (int)((B * 8 + 255) / 256);
+  L.rec = L.total;
+  L.cq = L.rec + a256(2 * ADJ_REC_STRIDE);
+  L.gx = L.cq + a256((size_t)2 * L.n_cblocks * 2 * sizeof(double));
+  L.total_dcontrol = L.gx + a256((size_t)2 * B * ADJ_GX_ROW * sizeof(float));
   return L;
 }
 }  // namespace
@@ -865,14 +1073,18 @@ static cde::AdjReduceArgs adj_reduce_args(unsigned char* base, const AdjLayout& 
   return r;
 }
 
-extern "C" int cde_dopri5_adjoint_advance(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
-                                          const void* W, const void* bias, int act, const void* y_init,
-                                          const void* a_init, double s0, double s1, const double* jump_s, int64_t n_jump,
-                                          double rtol, double atol, double safety, double ifactor, double dfactor,
-                                          int norm_kind, void* a_out, int64_t B, int64_t C, int64_t H, int dtype,
-                                          int first_interval, void* workspace, size_t workspace_bytes,
-                                          int64_t first_launch, int64_t n_launches, const double* reduced_sums,
-                                          int64_t B_global, void* stream) {
+extern "C" size_t cde_dopri5_adjoint_dcontrol_workspace_bytes(int64_t B, int64_t C, int64_t H) {
+  (void)C;
+  return adj_layout(B, H).total_dcontrol;
+}
+
+static int adjoint_advance(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W,
+                           const void* bias, int act, const void* y_init, const void* a_init, double s0, double s1,
+                           const double* jump_s, int64_t n_jump, double rtol, double atol, double safety, double ifactor,
+                           double dfactor, int norm_kind, void* a_out, int64_t B, int64_t C, int64_t H, int dtype,
+                           int first_interval, void* workspace, size_t workspace_bytes, int64_t first_launch,
+                           int64_t n_launches, const double* reduced_sums, int64_t B_global, void* grad_coeffs,
+                           int64_t control_numel, void* stream) {
   if (B < 1 || C < 1 || H < 1 || n_intervals < 1 || n_launches < 0 || n_jump < 0 || !(s0 < s1)) return CDE_ERR_SHAPE;
   if (dtype != CDE_F32) return dtype == CDE_F64 ? CDE_ERR_UNSUPPORTED : CDE_ERR_DTYPE;
   if (H > cde::MH || C > cde::MC) return CDE_ERR_UNSUPPORTED;
@@ -881,11 +1093,14 @@ extern "C" int cde_dopri5_adjoint_advance(const void* coeffs, const void* knots,
   if (norm_kind != 0 && norm_kind != 1) return CDE_ERR_UNSUPPORTED;
   if (!coeffs || !knots || !W || !bias || !y_init || !a_init || !a_out || !workspace) return CDE_ERR_NULL;
   if (n_jump > 0 && !jump_s) return CDE_ERR_NULL;
-  if (workspace_bytes < cde_dopri5_adjoint_workspace_bytes(B, C, H)) return CDE_ERR_WORKSPACE;
+  const bool dctrl = grad_coeffs != nullptr;
+  if (workspace_bytes < (dctrl ? cde_dopri5_adjoint_dcontrol_workspace_bytes(B, C, H) : cde_dopri5_adjoint_workspace_bytes(B, C, H)))
+    return CDE_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   unsigned char* base = (unsigned char*)workspace;
   const AdjLayout L = adj_layout(B, H);
   const bool sharded = reduced_sums != nullptr || B_global > 0;
+  if (dctrl && (sharded || control_numel < 1)) return CDE_ERR_UNSUPPORTED;          // control gradients: one controller per solve
   cde::DopriAdjArgs g;
   g.coeffs = (const float*)coeffs; g.knots = (const float*)knots; g.n_intervals = n_intervals;
   g.W = (const float*)W; g.bias = (const float*)bias; g.dims = cde::Dims{(int)H, (int)C};
@@ -899,7 +1114,9 @@ extern "C" int cde_dopri5_adjoint_advance(const void* coeffs, const void* knots,
   g.com.s0 = s0; g.com.s1 = s1; g.com.jump_s = jump_s; g.com.n_jump = n_jump;
   g.com.rtol = rtol; g.com.atol = atol; g.com.safety = safety; g.com.ifactor = ifactor; g.com.dfactor = dfactor;
   g.com.n_state = (B_global > 0 ? B_global : B) * H;
-  g.com.n_pt = 2; g.com.n_param[0] = H * C * H; g.com.n_param[1] = H * C; g.com.n_param[2] = g.com.n_param[3] = 1;
+  g.com.n_pt = dctrl ? 3 : 2; g.com.n_param[0] = H * C * H; g.com.n_param[1] = H * C;
+  g.com.n_param[2] = dctrl ? control_numel : 1; g.com.n_param[3] = 1;
+  g.gx = (float*)(base + L.gx); g.rec = base + L.rec; g.cq = (const double*)(base + L.cq); g.n_cblocks = L.n_cblocks;
   g.com.norm_kind = norm_kind;
   g.com.trace = (double*)(base + L.trace);
   g.com.trace_all = (double*)(base + L.trace_all);
@@ -916,20 +1133,30 @@ extern "C" int cde_dopri5_adjoint_advance(const void* coeffs, const void* knots,
       if (!(first_interval & 2)) cde::zero_async(base + L.carry, 256, s);
       cde::zero_async(base + L.G, L.att - L.G, s);                                // G, G_local, the prev buffers
     }
+    if (dctrl) cde::zero_async(base + L.rec, L.gx - L.rec, s);                    // stage records, control norm sums
   }
   // sharded under "seminorm": the parameter blocks take no part in the decision, so only the 8 state sums travel between the
   // shards (cde_dopri5_adjoint_state_sums / _apply_state_sums) and the gradient images stay LOCAL -- reduced, committed and
   // returned per shard like an unsharded solve's (the caller all-reduces gradients once, as for any data-parallel step)
   const bool images_local = sharded && norm_kind == 1;
   cde::AdjReduceArgs r = adj_reduce_args(base, L, B, rtol, atol, sharded && !images_local);
+  cde::AdjControlArgs cr;
+  cr.ctrl = base; cr.rec = base + L.rec; cr.gx = (const float*)(base + L.gx); cr.G = (float*)grad_coeffs;
+  cr.knots = (const float*)knots; cr.cq = (double*)(base + L.cq); cr.B = B; cr.n_intervals = n_intervals;
+  cr.C = (int)C; cr.degree = degree; cr.norm_kind = norm_kind; cr.rtol = (float)rtol; cr.atol = (float)atol;
+  const size_t lds_dc = cde::ADJ_LDS_BYTES + (size_t)2 * cde::ADJ_GX_TILE * sizeof(float);
 #define CDE_ADJ(D, A)                                                                                                \
   do {                                                                                                               \
     (void)hipFuncSetAttribute((const void*)cde::dopri5_adjoint_attempt<D, A>,                                        \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)cde::ADJ_LDS_BYTES);                  \
+    (void)hipFuncSetAttribute((const void*)cde::dopri5_adjoint_attempt<D, A, true>,                                  \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dc);                              \
     for (int64_t i = 0; i < n_launches; ++i) {                                                                       \
       const int parity = (int)((first_launch + i) & 1);                                                              \
-      cde::dopri5_adjoint_attempt<D, A><<<grid, 512, cde::ADJ_LDS_BYTES, s>>>(g, parity);                            \
+      if (dctrl) cde::dopri5_adjoint_attempt<D, A, true><<<grid, 512, lds_dc, s>>>(g, parity);                       \
+      else cde::dopri5_adjoint_attempt<D, A><<<grid, 512, cde::ADJ_LDS_BYTES, s>>>(g, parity);                       \
       if (!sharded || images_local) cde::adjoint_reduce_kernel<<<cde::ADJ_RBLOCKS, 256, 0, s>>>(r, parity, 0);       \
+      if (dctrl) cde::adjoint_control_kernel<D><<<L.n_cblocks, 256, 0, s>>>(cr, parity);                             \
     }                                                                                                                \
   } while (0)
   if (act == CDE_ACT_NONE) {
@@ -939,6 +1166,38 @@ extern "C" int cde_dopri5_adjoint_advance(const void* coeffs, const void* knots,
   }
 #undef CDE_ADJ
   return cde::check_launch();
+}
+
+extern "C" int cde_dopri5_adjoint_advance(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
+                                          const void* W, const void* bias, int act, const void* y_init,
+                                          const void* a_init, double s0, double s1, const double* jump_s, int64_t n_jump,
+                                          double rtol, double atol, double safety, double ifactor, double dfactor,
+                                          int norm_kind, void* a_out, int64_t B, int64_t C, int64_t H, int dtype,
+                                          int first_interval, void* workspace, size_t workspace_bytes,
+                                          int64_t first_launch, int64_t n_launches, const double* reduced_sums,
+                                          int64_t B_global, void* stream) {
+  return adjoint_advance(coeffs, knots, n_intervals, degree, W, bias, act, y_init, a_init, s0, s1, jump_s, n_jump, rtol, atol,
+                         safety, ifactor, dfactor, norm_kind, a_out, B, C, H, dtype, first_interval, workspace,
+                         workspace_bytes, first_launch, n_launches, reduced_sums, B_global, nullptr, 0, stream);
+}
+
+// The same with adjoint_params naming the coefficient tensor the path was built from (reference solver.py:207-222,
+// README.md:251-270): `grad_coeffs` (layout of `coeffs`, zeroed by the caller before the first interval, the same tensor
+// for every interval of a backward pass) receives dL/dcoeffs and is the running total of that block of torchdiffeq's
+// mixed norm; `control_numel` = the element count of the tensor the caller passed in adjoint_params (the block's rms
+// runs over all of them).  One controller per solve: no sharded form.
+extern "C" int cde_dopri5_adjoint_advance_dcontrol(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
+                                                   const void* W, const void* bias, int act, const void* y_init,
+                                                   const void* a_init, double s0, double s1, const double* jump_s,
+                                                   int64_t n_jump, double rtol, double atol, double safety, double ifactor,
+                                                   double dfactor, int norm_kind, void* a_out, int64_t B, int64_t C,
+                                                   int64_t H, int dtype, int first_interval, void* workspace,
+                                                   size_t workspace_bytes, int64_t first_launch, int64_t n_launches,
+                                                   void* grad_coeffs, int64_t control_numel, void* stream) {
+  if (!grad_coeffs) return CDE_ERR_NULL;
+  return adjoint_advance(coeffs, knots, n_intervals, degree, W, bias, act, y_init, a_init, s0, s1, jump_s, n_jump, rtol, atol,
+                         safety, ifactor, dfactor, norm_kind, a_out, B, C, H, dtype, first_interval, workspace,
+                         workspace_bytes, first_launch, n_launches, nullptr, 0, grad_coeffs, control_numel, stream);
 }
 
 // sharded batches (one controller for all shards), after the single attempt launch `total_launches - 1`: this shard's
