@@ -615,6 +615,10 @@ int cde_dopri5_adjoint_apply_state_sums(void* workspace, size_t workspace_bytes,
  * total -- and leaves the block's norm sums for the next launch's controller.
  *   grad_coeffs    layout of `coeffs`, zeroed by the caller before the first interval; the same tensor for every interval
  *   control_numel  element count of the tensor named in adjoint_params (the block's rms runs over all of them)
+ *   grad_knots     NULL, or (n_intervals + 1) floats zeroed by the caller: the knot times are in adjoint_params as well
+ *                  (test/test_tricks.py:21-49 passes (coeffs, t)) -- a fourth block of the norm.  f depends on knot j through
+ *                  frac = t - t_j (cubic) or through the widths of the slopes (linear); per stage ONE batch sum drives the
+ *                  block (sum over the series of a . F d2X/dt2, or of a . f), which the attempt kernel leaves per workgroup
  * Workspace: cde_dopri5_adjoint_dcontrol_workspace_bytes (the plain layout is a prefix: the trace / carry / status offsets
  * above hold).  One controller per solve (no sharded form); everything else as cde_dopri5_adjoint_advance. */
 size_t cde_dopri5_adjoint_dcontrol_workspace_bytes(int64_t B, int64_t C, int64_t H);
@@ -624,7 +628,7 @@ int cde_dopri5_adjoint_advance_dcontrol(const void* coeffs, const void* knots, i
                                         double atol, double safety, double ifactor, double dfactor, int norm_kind,
                                         void* a_out, int64_t B, int64_t C, int64_t H, int dtype, int first_interval,
                                         void* workspace, size_t workspace_bytes, int64_t first_launch, int64_t n_launches,
-                                        void* grad_coeffs, int64_t control_numel, void* stream);
+                                        void* grad_coeffs, int64_t control_numel, void* grad_knots, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K4am  K4a for the two-layer field Linear(H, width) -> relu -> Linear(width, H*C) -> tanh | identity of the reference's

@@ -281,7 +281,7 @@ _SIGNATURES = {
                                         _i64, _i64, _i64, _i, _i, _p, _sz, _i64, _i64, _p, _i64, _p]),
     "cde_dopri5_adjoint_dcontrol_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "cde_dopri5_adjoint_advance_dcontrol": (_i, [_p, _p, _i64, _i, _p, _p, _i, _p, _p, _d, _d, _p, _i64, _d, _d, _d, _d, _d, _i,
-                                                 _p, _i64, _i64, _i64, _i, _i, _p, _sz, _i64, _i64, _p, _i64, _p]),
+                                                 _p, _i64, _i64, _i64, _i, _i, _p, _sz, _i64, _i64, _p, _i64, _p, _p]),
     "cde_dopri5_adjoint_pending_sums": (_i, [_p, _sz, _i64, _i64, _i64, _i64, _p, _p]),
     "cde_dopri5_adjoint_apply_reduced": (_i, [_p, _sz, _i64, _i64, _i64, _d, _d, _i64, _p, _p]),
     "cde_dopri5_pending_sums": (_i, [_p, _sz, _i64, _i64, _i64, _i, _i, _i, _i64, _p, _p]),

@@ -945,7 +945,7 @@ class _Dopri5Plan:
             last_dopri5_stats["steps"] = workspace[off:off + 24 * n].view(torch.float64).view(n, 3).cpu()
         return out
 
-    def run_adjoint(self, z_saved, grad_out, weight, bias, want_t=False, want_control=False):
+    def run_adjoint(self, z_saved, grad_out, weight, bias, want_t=False, want_control=False, want_knots=False):
         """K4a: torchdiffeq's odeint_adjoint backward for the adaptive solve -- default mixed norm (or "seminorm"), dense
         output at the interval ends -- one attempt kernel + one reduction kernel per attempted step
         (csrc/dopri5_adjoint.hip), output intervals from the last to the first.
@@ -953,8 +953,8 @@ class _Dopri5Plan:
         (one field evaluation per output time, here); vjp_t -- which K4a integrates and measures in its error norm anyway --
         starts every interval at its carried value minus that term, and is dL/dt_0 after the last one.
         want_control: adjoint_params names the coefficient tensor (self.control_numel elements): dL/dcoeffs, packed layout,
-        is appended to the result -- one more block of the mixed norm, accumulated on the device
-        (cde_dopri5_adjoint_advance_dcontrol)."""
+        and (want_knots: the knot times are there too; else None) dL/d knots are appended to the result -- more blocks of
+        the mixed norm, accumulated on the device (cde_dopri5_adjoint_advance_dcontrol)."""
         lib = _lib.load()
         B, H, C, dev = self.B, self.H, self.C, self.device
         z_saved = z_saved.detach().reshape(B, self.n_out, H)
@@ -965,7 +965,8 @@ class _Dopri5Plan:
         grad_w, grad_b = flat[:n_w].view(H * C, H), flat[n_w:]
         a = grad_out[:, -1].contiguous()
         grad_x = torch.zeros_like(self.coeffs) if want_control else None
-        tail = (grad_x,) if want_control else ()
+        grad_k = torch.zeros_like(self.knots) if (want_control and want_knots) else None
+        tail = (grad_x, grad_k) if want_control else ()
         if self.n_out == 1:
             return ((a, grad_w, grad_b, torch.zeros(1, dtype=torch.float32, device=dev)) if want_t else (a, grad_w, grad_b)) + tail
         if want_control and self.shared is not None:
@@ -1018,7 +1019,8 @@ class _Dopri5Plan:
                             count)
                     if want_control:
                         _lib.check(lib.cde_dopri5_adjoint_advance_dcontrol(*head, _lib.ptr(grad_x), int(self.control_numel),
-                                                                           stream), "cde_dopri5_adjoint_advance_dcontrol")
+                                                                           _lib.ptr(grad_k), stream),
+                                   "cde_dopri5_adjoint_advance_dcontrol")
                     else:
                         _lib.check(lib.cde_dopri5_adjoint_advance(*head, sums_ptr, global_batch, stream),
                                    "cde_dopri5_adjoint_advance")
@@ -1262,13 +1264,16 @@ class _Dopri5Plan:
 
 class _FusedDopri5(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, z0, weight, bias, plan, wants, t=None, *control):
+    def forward(ctx, z0, weight, bias, plan, wants, t=None, knots=None, *control):
         # `control`: the path's buffers the control derivative reads, present (and differentiable inputs) only when the
         # coefficient tensor is among adjoint_params -- K4a then integrates dL/dcoeffs as one more block of the adjoint state
+        # (`knots`: the path's knot times when they are in adjoint_params too: a fourth block)
         out = plan.run(z0, weight, bias)
         ctx.plan, ctx.wants = plan, wants
         ctx.t_like = t
         ctx.want_x = len(control) > 0
+        ctx.want_knots = knots is not None
+        ctx.knots_like = knots
         ctx.save_for_backward(out, weight, bias)
         return out.reshape(*plan.batch, plan.n_out, plan.H)
 
@@ -1278,18 +1283,23 @@ class _FusedDopri5(torch.autograd.Function):
         plan = ctx.plan
         out, weight, bias = ctx.saved_tensors
         want_t = ctx.t_like is not None and ctx.needs_input_grad[5]
-        res = plan.run_adjoint(out, grad_out, weight, bias, want_t=want_t, want_control=ctx.want_x)
+        want_knots = ctx.want_knots and ctx.needs_input_grad[6]
+        res = plan.run_adjoint(out, grad_out, weight, bias, want_t=want_t, want_control=ctx.want_x, want_knots=want_knots)
         grad_z0, grad_w, grad_b = res[:3]
         grad_t = None
         if want_t:                                # on `t`'s own device: cdeint accepts a CPU `t` next to GPU data
             grad_t = res[3].to(device=ctx.t_like.device, dtype=ctx.t_like.dtype)
         want_w, want_b = ctx.wants
-        control_grads = ()
+        control_grads, grad_knots = (), None
         if ctx.want_x:
-            control_grads = _control_gradients(plan, res[-1], True, False, ctx.needs_input_grad[6:], None)[1:]
+            grad_x, grad_knots = res[-2], res[-1]
+            if grad_knots is not None:
+                grad_knots = grad_knots.to(device=ctx.knots_like.device, dtype=ctx.knots_like.dtype)
+            control_grads = _control_gradients(plan, grad_x, True, False, ctx.needs_input_grad[7:], None)[1:]
         return (grad_z0.reshape(*plan.batch, plan.H) if ctx.needs_input_grad[0] else None,
                 grad_w.view_as(weight) if (ctx.needs_input_grad[1] and want_w) else None,
-                grad_b.view_as(bias) if (ctx.needs_input_grad[2] and want_b) else None, None, None, grad_t) + control_grads
+                grad_b.view_as(bias) if (ctx.needs_input_grad[2] and want_b) else None, None, None, grad_t,
+                grad_knots) + control_grads
 
 
 class _FusedMlpDopri5(torch.autograd.Function):
@@ -1580,10 +1590,11 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
     control_block = None
     if given_params is not None and known is not None and params_kind == "own":
         extra = [p for p in given_params if not any(p is o for o in own)]
-        if (len(extra) == 1 and extra[0] is not X._t and extra[0].requires_grad and extra[0].is_contiguous()
-                and extra[0].numel() == packed.numel() and extra[0].dtype == packed.dtype
-                and extra[0].untyped_storage().data_ptr() == packed.untyped_storage().data_ptr()):
-            control_block = extra[0]
+        tensors = [p for p in extra if p is not X._t]
+        if (len(tensors) == 1 and len(extra) <= 2 and tensors[0].requires_grad and tensors[0].is_contiguous()
+                and tensors[0].numel() == packed.numel() and tensors[0].dtype == packed.dtype
+                and tensors[0].untyped_storage().data_ptr() == packed.untyped_storage().data_ptr()):
+            control_block = tensors[0]          # (+ optionally the knot times X._t: a fourth block)
 
     fixed_keys, adaptive_keys = {"step_size"}, {"jump_t", "safety", "ifactor", "dfactor"}
     # ONE normalised view of the options for the fused paths (the step-wise path gets them verbatim, like torchdiffeq):
@@ -1693,7 +1704,8 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         want_x = bool(control_wants and control_block is not None)
         control_inputs = X._control_buffers() if want_x else ()
         plan.control_numel = control_block.numel() if want_x else 0
-        return _FusedDopri5.apply(z0, weight, bias, plan, wants, t if wants_t else None, *control_inputs)
+        knots_in = X._t if (want_x and any(p is X._t and p.requires_grad for p in given_params)) else None
+        return _FusedDopri5.apply(z0, weight, bias, plan, wants, t if wants_t else None, knots_in, *control_inputs)
     step_size = _parse_fixed_options(fused_options, "solver")
     adjoint_step = step_size if fused_adj_opts is None else _parse_fixed_options(fused_adj_opts, "adjoint")
     want_w = want_b = True

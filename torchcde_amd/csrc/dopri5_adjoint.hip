@@ -76,8 +76,11 @@ struct DopriAdjArgs {
   // DCTRL
   float* gx;                        // [2][B][ADJ_GX_ROW]: the launch's per-stage d(a.f)/d(dX_c), unweighted
   unsigned char* rec;               // [2] AdjStageRec, ADJ_REC_STRIDE bytes apart
-  const double* cq;                 // [2][n_cblocks][2]: the control kernel's norm sums
+  const double* cq;                 // [2][n_cblocks + 1][2]: the control kernel's norm sums (last entry: the knot block)
   int n_cblocks;
+  double* ktp;                      // [2][ADJ_MAX_WG][8]: per-workgroup sums over the series of the per-stage time term
+                                    // (cubic: a . F d2X/dt2; linear: a . f) -- what the knot-time block is made of
+  int with_knots;                   // the knot times are a block of the norm too (n_pt == 4)
 };
 
 __device__ __forceinline__ AdjCtrl* adj_ctrl(unsigned char* base, int which) {
@@ -117,8 +120,9 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
     for (int i = 0; i < 4; ++i) sum[ADJ_NS + i] += Qp[4 * b + i];
   }
   if constexpr (DCTRL) {
-    const double* Cp = g.cq + (int64_t)p * g.n_cblocks * 2;
+    const double* Cp = g.cq + (int64_t)p * (g.n_cblocks + 1) * 2;
     for (int b = tid; b < g.n_cblocks; b += blockDim.x) { sum[ADJ_NS + 4] += Cp[2 * b]; sum[ADJ_NS + 5] += Cp[2 * b + 1]; }
+    if (tid == 0) { sum[ADJ_NS + 6] = Cp[2 * g.n_cblocks]; sum[ADJ_NS + 7] = Cp[2 * g.n_cblocks + 1]; }     // the knot block
   }
   AdjCtrl k = *adj_ctrl(g.ctrl, p);
   DopriCtrl& c = k.c;
@@ -266,6 +270,7 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
 
   int par = 0, gpar = 0, dbuf = 0;
   double acc[ADJ_NS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  double ktd[DCTRL ? 7 : 1] = {};                                  // DCTRL with knots: the per-stage time term, summed over the series
   CDE_STAMP(3);
 
   if (helper) {
@@ -465,6 +470,7 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
     float st_next[4] = {0.f, 0.f, 0.f, 0.f};
     if ((int64_t)blockIdx.x < g.n_tiles) state_request(blockIdx.x, st_next);
     float vtS = 0.f, vtE = 0.f;                                   // this lane's share of the vjp_t functionals
+    float ktv[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};           // DCTRL: ... and of the unweighted per-stage time term
     CDE_STAMP(4);
 #ifdef CDE_PHASE_TRACE
     int tile_no = 0;
@@ -639,6 +645,10 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
           if (DEGREE == CDE_PATH_CUBIC) {
             const float kt = asa * (hpa[0] + hpa[1]) + asb * (hpb[0] + hpb[1]);
             vtS = __builtin_fmaf(wS[i], kt, vtS); vtE = __builtin_fmaf(wE[i], kt, vtE);
+            if constexpr (DCTRL) ktv[i] += kt;
+          } else if constexpr (DCTRL) {
+            // piecewise-linear control: the knot times act through the widths; per stage sum_c gx_c dX_c = a . f
+            ktv[i] += asa * (fpa[0] + fpa[1]) + asb * (fpb[0] + fpb[1]);
           }
           if (i + 1 < ns) {
             // y path: the state of the next stage does not wait for anything else
@@ -731,6 +741,12 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
 #endif
     }
     acc[4] = (double)vtS; acc[5] = (double)vtE;
+    if constexpr (DCTRL) {
+      if (g.with_knots) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) ktd[j] = (double)ktv[j];
+      }
+    }
   }
   CDE_STAMP(13);
   // ---- publish this launch's partial sums and the controller state for the next launch
@@ -739,6 +755,16 @@ __global__ __launch_bounds__(512, 1) void dopri5_adjoint_attempt(DopriAdjArgs g,
   if (tid == 0) {
 #pragma unroll
     for (int i = 0; i < ADJ_NS; ++i) Pq[ADJ_NS * blockIdx.x + i] = acc[i];
+  }
+  if constexpr (DCTRL) {
+    if (g.with_knots) {
+      block_total<7>(ktd, red);
+      if (tid == 0) {
+        double* dst = g.ktp + ((int64_t)p * ADJ_MAX_WG + blockIdx.x) * 8;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) dst[j] = ktd[j];
+      }
+    }
   }
   CDE_STAMP_FLUSH(k4a_phase_trace, attempt_no);
   CDE_STAMP_FLUSH2(k4a_phase_trace, attempt_no, 256);
@@ -860,7 +886,36 @@ struct AdjControlArgs {
   int64_t B, n_intervals;
   int C, degree, norm_kind;
   float rtol, atol;
+  // the knot-time block (nullptr: not requested): G_knots (n_intervals + 1 floats, zeroed by the caller) is its running total
+  float* G_knots; const double* ktp; int n_wg;
 };
+
+// The knot times as a block (adjoint_params = (.., coeffs, t), reference test/test_tricks.py:21-49).  f depends on knot j
+// through frac = t - t_j (cubic: df/dt_j = -F d2X/dt2 for the stages in interval j, interpolation_cubic.py:315-336) or through
+// the widths of the slopes (linear: d slope_j / d h_j = -slope_j / h_j, interpolation_linear.py:186-191), so per stage ONE
+// batch sum drives it: KT(s) = sum over the series of a . F d2X/dt2 (cubic) or of a . f (linear), left per workgroup by the
+// attempt kernel.  Entry e of the launch described by `rc`:
+//   cubic :  - sum_{s: idx(s) == e} w(s) KT(s)
+//   linear:  + sum_{s: idx(s) == e} w(s) KT(s) / h_e  -  sum_{s: idx(s) + 1 == e} w(s) KT(s) / h_{e-1}
+template <int DEGREE>
+__device__ __forceinline__ void knot_entry(const AdjStageRec& rc, const double (&KT)[7], const float* __restrict__ knots, int e,
+                                           float& S, float& E) {
+  S = 0.f; E = 0.f;
+#pragma unroll
+  for (int s = 0; s < 7; ++s) {
+    if (s < rc.ns) {
+      float chain = 0.f;
+      if (DEGREE == CDE_PATH_CUBIC) { if (rc.sidx[s] == e) chain = -1.f; }
+      else {
+        const float width = knots[rc.sidx[s] + 1] - knots[rc.sidx[s]];
+        if (rc.sidx[s] == e) chain = 1.f / width; else if (rc.sidx[s] + 1 == e) chain = -1.f / width;
+      }
+      const float v = (float)KT[s] * chain;
+      S = __builtin_fmaf(rc.wS[s], v, S);
+      E = __builtin_fmaf(rc.wE[s], v, E);
+    }
+  }
+}
 
 template <int DEGREE>
 __device__ __forceinline__ void control_entry(const AdjStageRec& rc, const float (&gxv)[8], const float* __restrict__ knots,
@@ -959,6 +1014,68 @@ __global__ __launch_bounds__(256) void adjoint_control_kernel(AdjControlArgs r, 
         }
     }
   }
+  // ---- the knot-time block: one wave of block 0 (batch sums of the per-stage time term -> entries -> commit -> norm slots)
+  if (r.G_knots && blockIdx.x == 0 && threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    auto stage_sums = [&](int which, double (&KT)[7]) {
+#pragma unroll
+      for (int s = 0; s < 7; ++s) {
+        double t = 0.0;
+        for (int b = lane; b < r.n_wg; b += 64) t += r.ktp[((int64_t)which * ADJ_MAX_WG + b) * 8 + s];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
+        KT[s] = t;
+      }
+    };
+    const AdjStageRec cur = *reinterpret_cast<const AdjStageRec*>(r.rec + parity * ADJ_REC_STRIDE);
+    double KTc[7];
+    stage_sums(parity, KTc);
+    auto span = [&](const AdjStageRec& rc, int& lo, int& hi) {
+      lo = rc.sidx[0]; hi = rc.sidx[0];
+      for (int s = 1; s < rc.ns; ++s) { lo = rc.sidx[s] < lo ? rc.sidx[s] : lo; hi = rc.sidx[s] > hi ? rc.sidx[s] : hi; }
+      if (DEGREE == CDE_PATH_LINEAR) hi += 1;
+    };
+    if (k.commit == 1) {
+      const AdjStageRec prev = *reinterpret_cast<const AdjStageRec*>(r.rec + p2 * ADJ_REC_STRIDE);
+      double KTp[7];
+      stage_sums(p2, KTp);
+      int lo, hi;
+      span(prev, lo, hi);
+      if (lane == 0)
+        for (int e = lo; e <= hi; ++e) { float S, E; knot_entry<DEGREE>(prev, KTp, r.knots, e, S, E); r.G_knots[e] += S; }
+    } else if (k.commit == 2) {
+      int lo, hi;
+      span(cur, lo, hi);
+      if (lane == 0)
+        for (int e = lo; e <= hi; ++e) { float S, E; knot_entry<DEGREE>(cur, KTc, r.knots, e, S, E); r.G_knots[e] += S; }
+    }
+    if (r.norm_kind == 0 && k.mode != 3) {
+      double k0 = 0.0, k1 = 0.0;
+      if (k.mode == 0) {
+        const int n_e = (int)r.n_intervals + 1;
+        for (int e = lane; e < n_e; e += 64) {
+          const float g = r.G_knots[e], sc = r.atol + fabsf(g) * r.rtol, u = g / sc;
+          k0 += (double)(u * u);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) k0 += __shfl_xor(k0, off, 64);
+      }
+      if (lane == 0) {
+        int lo, hi;
+        span(cur, lo, hi);
+        for (int e = lo; e <= hi; ++e) {
+          float S, E;
+          knot_entry<DEGREE>(cur, KTc, r.knots, e, S, E);
+          const float g = r.G_knots[e];
+          if (k.mode == 0) { const float sc = r.atol + fabsf(g) * r.rtol, v = S / sc; k1 += (double)(v * v); }
+          else if (k.mode == 1) { const float sc = r.atol + fabsf(g) * r.rtol, v = S / sc; k0 += (double)(v * v); }
+          else { const float tol = r.atol + r.rtol * fmaxf(fabsf(g), fabsf(g + S)), v = E / tol; k0 += (double)(v * v); }
+        }
+        r.cq[((int64_t)p2 * (gridDim.x + 1) + gridDim.x) * 2] = k0;
+        r.cq[((int64_t)p2 * (gridDim.x + 1) + gridDim.x) * 2 + 1] = k1;
+      }
+    }
+  }
   if (r.norm_kind != 0 || k.mode == 3) return;
   // the block's sums (fixed order)
 #pragma unroll
@@ -968,7 +1085,7 @@ __global__ __launch_bounds__(256) void adjoint_control_kernel(AdjControlArgs r, 
   if (threadIdx.x < 2) {
     const int i = threadIdx.x;
     // slot p2: where the NEXT attempt launch (parity p2) looks for the sums pending on it, like the R kernel's
-    r.cq[((int64_t)p2 * gridDim.x + blockIdx.x) * 2 + i] = (red[i][0] + red[i][1]) + (red[i][2] + red[i][3]);
+    r.cq[((int64_t)p2 * (gridDim.x + 1) + blockIdx.x) * 2 + i] = (red[i][0] + red[i][1]) + (red[i][2] + red[i][3]);
   }
 }
 
@@ -1010,7 +1127,7 @@ extern "C" int cde_debug_k4a_phase_trace(void* host_out, size_t bytes) {
 namespace {
 struct AdjLayout {
   size_t partial, pq, carry, state, G, G_local, prev, att, trace, trace_all, total;
-  size_t rec, cq, gx, total_dcontrol;
+  size_t rec, cq, ktp, gx, total_dcontrol;
   int n_cblocks;
 };
 AdjLayout adj_layout(int64_t B, int64_t H) {
@@ -1031,7 +1148,8 @@ AdjLayout adj_layout(int64_t B, int64_t H) {
   L.n_cblocks = (int)((B * 8 + 255) / 256);
   L.rec = L.total;
   L.cq = L.rec + a256(2 * ADJ_REC_STRIDE);
-  L.gx = L.cq + a256((size_t)2 * L.n_cblocks * 2 * sizeof(double));
+  L.ktp = L.cq + a256((size_t)2 * (L.n_cblocks + 1) * 2 * sizeof(double));
+  L.gx = L.ktp + a256((size_t)2 * ADJ_MAX_WG * 8 * sizeof(double));
   L.total_dcontrol = L.gx + a256((size_t)2 * B * ADJ_GX_ROW * sizeof(float));
   return L;
 }
@@ -1084,7 +1202,7 @@ static int adjoint_advance(const void* coeffs, const void* knots, int64_t n_inte
                            double dfactor, int norm_kind, void* a_out, int64_t B, int64_t C, int64_t H, int dtype,
                            int first_interval, void* workspace, size_t workspace_bytes, int64_t first_launch,
                            int64_t n_launches, const double* reduced_sums, int64_t B_global, void* grad_coeffs,
-                           int64_t control_numel, void* stream) {
+                           int64_t control_numel, void* grad_knots, void* stream) {
   if (B < 1 || C < 1 || H < 1 || n_intervals < 1 || n_launches < 0 || n_jump < 0 || !(s0 < s1)) return CDE_ERR_SHAPE;
   if (dtype != CDE_F32) return dtype == CDE_F64 ? CDE_ERR_UNSUPPORTED : CDE_ERR_DTYPE;
   if (H > cde::MH || C > cde::MC) return CDE_ERR_UNSUPPORTED;
@@ -1114,9 +1232,11 @@ static int adjoint_advance(const void* coeffs, const void* knots, int64_t n_inte
   g.com.s0 = s0; g.com.s1 = s1; g.com.jump_s = jump_s; g.com.n_jump = n_jump;
   g.com.rtol = rtol; g.com.atol = atol; g.com.safety = safety; g.com.ifactor = ifactor; g.com.dfactor = dfactor;
   g.com.n_state = (B_global > 0 ? B_global : B) * H;
-  g.com.n_pt = dctrl ? 3 : 2; g.com.n_param[0] = H * C * H; g.com.n_param[1] = H * C;
-  g.com.n_param[2] = dctrl ? control_numel : 1; g.com.n_param[3] = 1;
+  if (grad_knots && !dctrl) return CDE_ERR_UNSUPPORTED;
+  g.com.n_pt = dctrl ? (grad_knots ? 4 : 3) : 2; g.com.n_param[0] = H * C * H; g.com.n_param[1] = H * C;
+  g.com.n_param[2] = dctrl ? control_numel : 1; g.com.n_param[3] = grad_knots ? n_intervals + 1 : 1;
   g.gx = (float*)(base + L.gx); g.rec = base + L.rec; g.cq = (const double*)(base + L.cq); g.n_cblocks = L.n_cblocks;
+  g.ktp = (double*)(base + L.ktp); g.with_knots = grad_knots ? 1 : 0;
   g.com.norm_kind = norm_kind;
   g.com.trace = (double*)(base + L.trace);
   g.com.trace_all = (double*)(base + L.trace_all);
@@ -1144,6 +1264,7 @@ static int adjoint_advance(const void* coeffs, const void* knots, int64_t n_inte
   cr.ctrl = base; cr.rec = base + L.rec; cr.gx = (const float*)(base + L.gx); cr.G = (float*)grad_coeffs;
   cr.knots = (const float*)knots; cr.cq = (double*)(base + L.cq); cr.B = B; cr.n_intervals = n_intervals;
   cr.C = (int)C; cr.degree = degree; cr.norm_kind = norm_kind; cr.rtol = (float)rtol; cr.atol = (float)atol;
+  cr.G_knots = (float*)grad_knots; cr.ktp = (const double*)(base + L.ktp); cr.n_wg = grid;
   const size_t lds_dc = cde::ADJ_LDS_BYTES + (size_t)2 * cde::ADJ_GX_TILE * sizeof(float);
 #define CDE_ADJ(D, A)                                                                                                \
   do {                                                                                                               \
@@ -1178,7 +1299,7 @@ extern "C" int cde_dopri5_adjoint_advance(const void* coeffs, const void* knots,
                                           int64_t B_global, void* stream) {
   return adjoint_advance(coeffs, knots, n_intervals, degree, W, bias, act, y_init, a_init, s0, s1, jump_s, n_jump, rtol, atol,
                          safety, ifactor, dfactor, norm_kind, a_out, B, C, H, dtype, first_interval, workspace,
-                         workspace_bytes, first_launch, n_launches, reduced_sums, B_global, nullptr, 0, stream);
+                         workspace_bytes, first_launch, n_launches, reduced_sums, B_global, nullptr, 0, nullptr, stream);
 }
 
 // The same with adjoint_params naming the coefficient tensor the path was built from (reference solver.py:207-222,
@@ -1193,11 +1314,12 @@ extern "C" int cde_dopri5_adjoint_advance_dcontrol(const void* coeffs, const voi
                                                    double dfactor, int norm_kind, void* a_out, int64_t B, int64_t C,
                                                    int64_t H, int dtype, int first_interval, void* workspace,
                                                    size_t workspace_bytes, int64_t first_launch, int64_t n_launches,
-                                                   void* grad_coeffs, int64_t control_numel, void* stream) {
+                                                   void* grad_coeffs, int64_t control_numel, void* grad_knots,
+                                                   void* stream) {
   if (!grad_coeffs) return CDE_ERR_NULL;
   return adjoint_advance(coeffs, knots, n_intervals, degree, W, bias, act, y_init, a_init, s0, s1, jump_s, n_jump, rtol, atol,
                          safety, ifactor, dfactor, norm_kind, a_out, B, C, H, dtype, first_interval, workspace,
-                         workspace_bytes, first_launch, n_launches, nullptr, 0, grad_coeffs, control_numel, stream);
+                         workspace_bytes, first_launch, n_launches, nullptr, 0, grad_coeffs, control_numel, grad_knots, stream);
 }
 
 // sharded batches (one controller for all shards), after the single attempt launch `total_launches - 1`: this shard's

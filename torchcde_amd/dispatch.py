@@ -38,9 +38,9 @@ Request = collections.namedtuple("Request", [
                          # tiles -- what the reverse-mode sweeps (adjoint=False) take
     "identity",          # affine field without an activation (the README's): with backprop_ok, what the midpoint / euler forms
                          # of K2 / K3p take
-    "control_block",     # the control tensors named in adjoint_params are exactly ONE tensor: the packed coefficient tensor the
-                         # path was built from (README.md:251-270) -- one block of torchdiffeq's adjoint error norm, which the
-                         # adaptive backward K4a carries since round 6 (not the knot times)
+    "control_block",     # the control tensors named in adjoint_params are the packed coefficient tensor the path was built from
+                         # (README.md:251-270), optionally with the knot times (test/test_tricks.py:21-49) -- blocks of
+                         # torchdiffeq's adjoint error norm which the adaptive backward K4a carries since round 6
 ])
 
 Choice = collections.namedtuple("Choice", ["path", "reason"])
@@ -120,7 +120,8 @@ def select_path(q):
         return Choice("dopri5_forward", "")
     if q.wants_control and not (q.control_block and q.mfma_shape and not q.shared):
         return _stepwise("control gradients through the adaptive backward: fused for the coefficient tensor the path was built "
-                         "from as the one extra entry of adjoint_params (no knot times, no shared step controller)")
+                         "from (optionally with its knot times) as the extra entries of adjoint_params, one-layer fields on the "
+                         "32 x 8 tiles, no shared step controller")
     if q.wants_t and q.shared:
         return _stepwise("output-time gradients through the adaptive backward with a shared step controller")
     if not q.mfma_shape:
