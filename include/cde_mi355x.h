@@ -661,6 +661,22 @@ int cde_dopri5_adjoint_mlp_advance(const void* coeffs, const void* knots, int64_
                                    int first_interval, void* workspace, size_t workspace_bytes, int64_t first_launch,
                                    int64_t n_launches, void* stream);
 
+/* K4am with control gradients (round 6): as cde_dopri5_adjoint_advance_dcontrol, for the two-layer field -- the
+ * coefficient tensor (and optionally the knot times) as a fifth (and sixth) block of the adjoint state.  The evaluation
+ * (cde_mlp_adj.h) also leaves d(a.f)/d(dX_c) = sum_h a_h act(Y2)_hc per stage; a first stage that is reused (first same as
+ * last) takes its pending values from the previous launch's slot.  Eight-channel tiles run the four-wave / one-wave forms
+ * of the attempt kernel (not the eight-wave one); the layout of cde_dopri5_adjoint_mlp_workspace_bytes is a prefix of
+ * cde_dopri5_adjoint_mlp_dcontrol_workspace_bytes (the trace / carry / gradient offsets hold). */
+size_t cde_dopri5_adjoint_mlp_dcontrol_workspace_bytes(int64_t B, int64_t C, int64_t H);
+int cde_dopri5_adjoint_mlp_advance_dcontrol(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
+                                            const void* W1, const void* bias1, int64_t width, const void* W2,
+                                            const void* bias2, int act, const void* y_init, const void* a_init, double s0,
+                                            double s1, const double* jump_s, int64_t n_jump, double rtol, double atol,
+                                            double safety, double ifactor, double dfactor, int norm_kind, void* a_out,
+                                            int64_t B, int64_t C, int64_t H, int dtype, int first_interval, void* workspace,
+                                            size_t workspace_bytes, int64_t first_launch, int64_t n_launches,
+                                            void* grad_coeffs, int64_t control_numel, void* grad_knots, void* stream);
+
 /* K4am under ONE step controller for a batch sharded over GPUs (round 4): the protocol of the one-layer kernels above.
  * Per attempted step n every shard runs
  *   cde_dopri5_adjoint_mlp_advance_sharded(first_launch = n, reduced_sums = the buffer below (NULL for n == 0), B_global)

@@ -59,6 +59,8 @@ CASES = {
     "two_layer_beyond_tiles":    (dict(_MLP, tiles_ok=False), "stepwise", ("narrow_control",)),
     "two_layer_dopri5_control":  (dict(_MLP, method="dopri5", wants_control=True, params="own"), "stepwise",
                                   ("narrow_control", "wants_t")),
+    "two_layer_dopri5_control_block": (dict(_MLP, method="dopri5", wants_control=True, params="own", control_block=True),
+                                       "mlp_dopri5_adjoint", ("narrow_control", "wants_t")),
     # ------------------------------------------------------------------ requests that stay step-wise for every field
     "adjoint_options_beyond_the_kernels": (dict(method="dopri5", adjoint_options_ok=False, wants_t=True), "stepwise",
                                            ("mfma_shape", "variant_generic")),

@@ -842,11 +842,12 @@ def test_dispatch_table_is_exhaustively_consistent():
                         assert f["mfma_shape"] and not (f["wants_t"] and f["shared"])
                         assert not f["wants_control"] or (f["control_block"] and not f["shared"])
                     if c.path == "mlp_dopri5_adjoint":
-                        assert not f["wants_control"] and not (f["wants_t"] and f["shared"])
+                        assert not (f["wants_t"] and f["shared"])
+                        assert not f["wants_control"] or (f["control_block"] and not f["shared"])
                     if kind == "mlp2":
                         assert not f["variant_generic"]
                         assert not f["wants_t"] or c.path == "mlp_dopri5_adjoint" or method == "rk4"
-                        assert not f["wants_control"] or method == "rk4"
+                        assert not f["wants_control"] or method == "rk4" or f["control_block"]
                     if kind == "affine" and (f["wants_t"] or f["wants_control"]):
                         assert f["mfma_shape"] and (method == "rk4" or not f["wants_control"] or f["control_block"])
     assert n > 100000 and set(seen) == set(D.FUSED_PATHS) | {D.STEPWISE}       # every path is reachable
@@ -873,6 +874,7 @@ def test_dispatch_table_is_exhaustively_consistent():
     assert ask(wants_control=True, params="own", control_block=True).path == "dopri5_adjoint"
     assert ask(wants_control=True, params="own", control_block=True, wants_t=True).path == "dopri5_adjoint"
     assert ask(wants_control=True, params="own", control_block=True, shared=True).path == D.STEPWISE
+    assert ask(kind="mlp2", mfma_shape=False, wants_control=True, params="own", control_block=True).path == "mlp_dopri5_adjoint"
     assert ask(method="rk4", adjoint=False).path == "rk4_backprop"              # README.md:103: backprop through the solver
     assert ask(kind="mlp2", mfma_shape=False, method="rk4", adjoint=False).path == "mlp_rk4_backprop"
     assert ask(method="rk4", adjoint=False, wants_control=True).path == "rk4_backprop"      # test/test_tricks.py:21-49, adjoint=False

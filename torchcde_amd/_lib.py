@@ -19,7 +19,8 @@ SO_PATH = os.path.join(_HERE, "libcde_mi355x_trace.so" if PHASE_TRACE else "libc
 SOURCES = ["interp_kernels.hip", "rk4_generic.hip", "rk4_mfma.hip", "rk4_split.hip", "rk4_wide.hip", "rk4_mlp_adjoint.hip",
            "rk4_bf16x3.hip", "rk4_backprop.hip", "rk4_adjoint_pair.hip", "dopri5.hip", "dopri5_adjoint.hip", "dopri5_mlp_adjoint.hip", "mlp_grad_reduce.hip", "api.hip"]
 HEADERS = [os.path.join(_CSRC, "cde_common.h"), os.path.join(_CSRC, "cde_mfma.h"), os.path.join(_CSRC, "cde_split.h"),
-           os.path.join(_CSRC, "cde_dopri.h"), os.path.join(_CSRC, "cde_dopri_adj.h"), os.path.join(_CSRC, "cde_mlp_adj.h"),
+           os.path.join(_CSRC, "cde_dopri.h"), os.path.join(_CSRC, "cde_dopri_adj.h"), os.path.join(_CSRC, "cde_dopri_ctl.h"),
+           os.path.join(_CSRC, "cde_mlp_adj.h"),
            os.path.join(_HERE, "..", "include", "cde_mi355x.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC"]
 if PHASE_TRACE:
@@ -261,6 +262,10 @@ _SIGNATURES = {
                                             _d, _d, _i, _p, _i64, _i64, _i64, _i, _i, _p, _sz, _i64, _i64, _p]),
     "cde_dopri5_adjoint_state_sums": (_i, [_p, _sz, _i64, _i64, _i64, _i64, _p, _p]),
     "cde_dopri5_adjoint_apply_state_sums": (_i, [_p, _sz, _i64, _i64, _i64, _i64, _p, _p]),
+    "cde_dopri5_adjoint_mlp_dcontrol_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "cde_dopri5_adjoint_mlp_advance_dcontrol": (_i, [_p, _p, _i64, _i, _p, _p, _i64, _p, _p, _i, _p, _p, _d, _d, _p, _i64, _d, _d,
+                                                     _d, _d, _d, _i, _p, _i64, _i64, _i64, _i, _i, _p, _sz, _i64, _i64, _p, _i64,
+                                                     _p, _p]),
     "cde_dopri5_adjoint_mlp_state_sums": (_i, [_p, _sz, _i64, _i64, _i64, _i64, _p, _p]),
     "cde_dopri5_adjoint_mlp_apply_state_sums": (_i, [_p, _sz, _i64, _i64, _i64, _i64, _p, _p]),
     "cde_dopri5_adjoint_mlp_reduced_count": (_sz, []),

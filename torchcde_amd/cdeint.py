@@ -1082,7 +1082,7 @@ class _Dopri5Plan:
             return (a, grad_w, grad_b, torch.stack(time_terms)) + tail
         return (a, grad_w, grad_b) + tail
 
-    def run_adjoint_mlp(self, z_saved, grad_out, w1, b1, w2, b2, want_t=False):
+    def run_adjoint_mlp(self, z_saved, grad_out, w1, b1, w2, b2, want_t=False, want_control=False, want_knots=False):
         """K4am: the same backward for the two-layer field (csrc/dopri5_mlp_adjoint.hip): per attempted step the attempt
         kernel, the split-K reduction of its gradient factors and the commit / norm kernel, queued by one C-ABI call.
         want_t: output-time gradients, as in run_adjoint."""
@@ -1093,10 +1093,17 @@ class _Dopri5Plan:
         w1, b1, w2, b2 = (p.detach().contiguous() for p in (w1, b1, w2, b2))
         width = w1.size(0)
         a = grad_out[:, -1].contiguous()
+        # control gradients (as run_adjoint): dL/dcoeffs (packed layout) and, when the knot times are in adjoint_params too,
+        # dL/d knots (else None) are appended to the result
+        grad_x = torch.zeros_like(self.coeffs) if want_control else None
+        grad_k = torch.zeros_like(self.knots) if (want_control and want_knots) else None
+        tail = (grad_x, grad_k) if want_control else ()
         if self.n_out == 1:
             zeros = (a, torch.zeros_like(w1), torch.zeros_like(b1), torch.zeros_like(w2), torch.zeros_like(b2))
-            return zeros + (torch.zeros(1, dtype=torch.float32, device=dev),) if want_t else zeros
-        nbytes = lib.cde_dopri5_adjoint_mlp_workspace_bytes(B, C, H)
+            return (zeros + (torch.zeros(1, dtype=torch.float32, device=dev),) if want_t else zeros) + tail
+        if want_control and self.shared is not None:
+            raise NotImplementedError("torchcde_amd: control gradients through the adaptive backward have no shared-controller form")
+        nbytes = (lib.cde_dopri5_adjoint_mlp_dcontrol_workspace_bytes if want_control else lib.cde_dopri5_adjoint_mlp_workspace_bytes)(B, C, H)
         workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         workspace[:_WORKSPACE_HEAD].zero_()
         size = ctypes.sizeof(_lib.DopriStatus)
@@ -1133,13 +1140,18 @@ class _Dopri5Plan:
             launched = 0
             while True:
                 if shared is None:
-                    _lib.check(lib.cde_dopri5_adjoint_mlp_advance(
-                        _lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w1), _lib.ptr(b1),
-                        width, _lib.ptr(w2), _lib.ptr(b2), self.act, _lib.ptr(y), _lib.ptr(a), s0, s1, _lib.ptr(self.jump_s),
-                        self.n_jump_s, self.adjoint_rtol, self.adjoint_atol, self.adj_safety, self.adj_ifactor,
-                        self.adj_dfactor, self.adj_norm_kind, _lib.ptr(a_out), B, C, H, _lib.dtype_enum(torch.float32),
-                        int(i == self.n_out - 1) | (2 if want_t else 0), _lib.ptr(workspace), workspace.numel(), launched,
-                        _DOPRI_CHUNK, stream), "cde_dopri5_adjoint_mlp_advance")
+                    head = (_lib.ptr(self.coeffs), _lib.ptr(self.knots), self.n_intervals, self.degree, _lib.ptr(w1), _lib.ptr(b1),
+                            width, _lib.ptr(w2), _lib.ptr(b2), self.act, _lib.ptr(y), _lib.ptr(a), s0, s1, _lib.ptr(self.jump_s),
+                            self.n_jump_s, self.adjoint_rtol, self.adjoint_atol, self.adj_safety, self.adj_ifactor,
+                            self.adj_dfactor, self.adj_norm_kind, _lib.ptr(a_out), B, C, H, _lib.dtype_enum(torch.float32),
+                            int(i == self.n_out - 1) | (2 if want_t else 0), _lib.ptr(workspace), workspace.numel(), launched,
+                            _DOPRI_CHUNK)
+                    if want_control:
+                        _lib.check(lib.cde_dopri5_adjoint_mlp_advance_dcontrol(*head, _lib.ptr(grad_x), int(self.control_numel),
+                                                                               _lib.ptr(grad_k), stream),
+                                   "cde_dopri5_adjoint_mlp_advance_dcontrol")
+                    else:
+                        _lib.check(lib.cde_dopri5_adjoint_mlp_advance(*head, stream), "cde_dopri5_adjoint_mlp_advance")
                     launched += _DOPRI_CHUNK
                 else:
                     # one controller for all shards (round 4): per attempted step ONE attempt launch, then this shard's
@@ -1205,8 +1217,8 @@ class _Dopri5Plan:
             last_dopri5_adjoint_stats["attempts"] = attempts
         if want_t:
             time_terms[0] = carry.to(torch.float32).reshape(())
-            return a, grad_w1, grad_b1, grad_w2, grad_b2, torch.stack(time_terms)
-        return a, grad_w1, grad_b1, grad_w2, grad_b2
+            return (a, grad_w1, grad_b1, grad_w2, grad_b2, torch.stack(time_terms)) + tail
+        return (a, grad_w1, grad_b1, grad_w2, grad_b2) + tail
 
     def run(self, z0, weight, bias):
         lib = _lib.load()
@@ -1307,10 +1319,13 @@ class _FusedMlpDopri5(torch.autograd.Function):
     (K4 with the two-layer field) and torchdiffeq's adaptive adjoint backward (K4am)."""
 
     @staticmethod
-    def forward(ctx, z0, w1, b1, w2, b2, plan, t=None):
+    def forward(ctx, z0, w1, b1, w2, b2, plan, t=None, knots=None, *control):
+        # (`control` / `knots`: as in _FusedDopri5 -- the path's buffers / knot times when adjoint_params names them)
         out = plan.run(z0, w2, b2)
         ctx.plan = plan
         ctx.t_like = t
+        ctx.want_x = len(control) > 0
+        ctx.knots_like = knots
         ctx.save_for_backward(out, w1, b1, w2, b2)
         return out.reshape(*plan.batch, plan.n_out, plan.H)
 
@@ -1321,11 +1336,20 @@ class _FusedMlpDopri5(torch.autograd.Function):
         plan = ctx.plan
         need = ctx.needs_input_grad
         want_t = ctx.t_like is not None and need[6]
-        res = plan.run_adjoint_mlp(out, grad_out, w1, b1, w2, b2, want_t=want_t)
+        want_knots = ctx.knots_like is not None and need[7]
+        res = plan.run_adjoint_mlp(out, grad_out, w1, b1, w2, b2, want_t=want_t, want_control=ctx.want_x,
+                                   want_knots=want_knots)
         grad_z0, gw1, gb1, gw2, gb2 = res[:5]
         grad_t = res[5].to(device=ctx.t_like.device, dtype=ctx.t_like.dtype) if want_t else None
+        control_grads, grad_knots = (), None
+        if ctx.want_x:
+            grad_x, grad_knots = res[-2], res[-1]
+            if grad_knots is not None:
+                grad_knots = grad_knots.to(device=ctx.knots_like.device, dtype=ctx.knots_like.dtype)
+            control_grads = _control_gradients(plan, grad_x, True, False, need[8:], None)[1:]
         return (grad_z0.reshape(*plan.batch, plan.H) if need[0] else None, gw1 if need[1] else None,
-                gb1 if need[2] else None, gw2 if need[3] else None, gb2 if need[4] else None, None, grad_t)
+                gb1 if need[2] else None, gw2 if need[3] else None, gb2 if need[4] else None, None, grad_t,
+                grad_knots) + control_grads
 
 
 # ------------------------------------------------------------------------------------------ front end
@@ -1582,8 +1606,9 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         extra_ok = all(isinstance(p, torch.Tensor) and p.untyped_storage().data_ptr() in control_ids for p in extra)
         complete = field is not None or all(any(p is o for p in given_params) for o in own)    # K3m / K4am: all four or none
         params_kind = "own" if (extra_ok and complete) else "foreign"
-        if field is None and any(p is X._t for p in extra) and method != "rk4":
-            params_kind = "foreign"             # knot-time gradients of a two-layer solve: under rk4, else step-wise
+        if field is None and any(p is X._t for p in extra) and method not in ("rk4", "dopri5"):
+            params_kind = "foreign"             # knot-time gradients of a two-layer solve: under rk4 and (with the coefficient
+                                                # tensor: control_block) dopri5, else step-wise
 
     # the adaptive backward measures every entry of adjoint_params as a block of its error norm: control gradients are fused
     # there when the ONE extra entry is the packed coefficient tensor the path reads (its buffers are views of it)
@@ -1682,8 +1707,12 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
             with torch.no_grad():
                 return plan.run(z0, mlp.weight, mlp.bias).reshape(*batch, plan.n_out, H)
         # the reference examples' own training call (no method: dopri5 + adjoint): K4 forward, K4am backward
+        want_x = bool(control_wants and control_block is not None)
+        control_inputs = X._control_buffers() if want_x else ()
+        plan.control_numel = control_block.numel() if want_x else 0
+        knots_in = X._t if (want_x and any(p is X._t and p.requires_grad for p in given_params)) else None
         return _FusedMlpDopri5.apply(z0, mlp.hidden.weight, mlp.hidden.bias, mlp.output.weight, mlp.output.bias, plan,
-                                     t if wants_t else None)
+                                     t if wants_t else None, knots_in, *control_inputs)
 
     # ---- one-layer fields
     weight, bias = field.weight, field.bias

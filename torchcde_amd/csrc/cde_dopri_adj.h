@@ -20,7 +20,8 @@
 namespace cde {
 
 constexpr int ADJ_NS = 8;                // pending state sums per launch (see adj_controller)
-constexpr int ADJ_MAX_PT = 4;            // parameter tensors in the mixed norm: W, b (one-layer) or W1, b1, W2, b2
+constexpr int ADJ_MAX_PT = 6;            // tensors in the mixed norm: W, b (one-layer) or W1, b1, W2, b2 -- and, when they are
+                                         // among adjoint_params, the control's coefficient tensor and its knot times
 constexpr int ADJ_CTRL_STRIDE = 256;     // bytes between the two controller blocks at the head of the workspace
 constexpr int ADJ_MAX_RBLOCKS = 256;     // blocks of the R kernel (partial parameter sums per launch)
 constexpr int ADJ_TRACE_ATTEMPTS = 16384;  // rows of the attempt trace: (t0, t1, clipped onto a jump, accepted, error ratio)

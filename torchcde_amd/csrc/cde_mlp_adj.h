@@ -62,14 +62,17 @@ __device__ __forceinline__ void mlp_split_allreduce(float* xbuf, int pw, int lan
   __syncthreads();                                                  // the window is free again
 }
 
-template <int ACT, int CT, bool TGRAD, bool SPLIT = false>
+// DCTRL (control gradients through K4am, round 6): also gxo[c] = sum_h a_h act(Y2)_hc = d(a.f)/d(dX_c) of the lane's SERIES,
+// complete in every lane (the lane's own hidden units, the other waves' unit groups in the SPLIT form, the four lane quarters).
+template <int ACT, int CT, bool TGRAD, bool SPLIT = false, bool DCTRL = false>
 __device__ __forceinline__ void mlp_adjoint_eval(const float* lds_base, const float4* w1t_base, int lane, int n, int q,
                                                  int w2y_off, const int (&w2g_off)[4], const float (&zs)[8],
                                                  const float (&as)[8], const float (&dX)[CT], const float (&d2X)[CT],
                                                  bool stream, float* urow, float* zrow, float* g2row, float* g1row, int Hr,
                                                  f32x4& fa, f32x4& fb, f32x4& va, f32x4& vb, float& kt, int pw = 0,
                                                  float* xbuf = nullptr, const float4* w1t_regs = nullptr,
-                                                 bool stamp_on = false, unsigned long long* stamp = nullptr) {
+                                                 bool stamp_on = false, unsigned long long* stamp = nullptr,
+                                                 float* gxo = nullptr) {
 #ifdef CDE_PHASE_TRACE
 #define CDE_EVAL_STAMP(slot, ...) do { if (stamp_on) { asm volatile("s_nop 0" : __VA_ARGS__); __builtin_amdgcn_sched_barrier(0); \
                                        stamp[slot] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } } while (0)
@@ -125,6 +128,9 @@ __device__ __forceinline__ void mlp_adjoint_eval(const float* lds_base, const fl
   for (int T1 = 0; T1 < 8; ++T1) gu[T1] = f32x4{0.f, 0.f, 0.f, 0.f};
   fa = f32x4{0.f, 0.f, 0.f, 0.f}; fb = fa;
   kt = 0.f;
+  float gxl[DCTRL ? CT : 1];
+#pragma unroll
+  for (int c = 0; c < (DCTRL ? CT : 1); ++c) gxl[c] = 0.f;
   // SPLIT: a REAL loop over the wave's unit groups (round 4; the rolled stage loop of the caller then is ~10 KB of code).
   // Every address below is affine in P; only as[P] and the slot of f need a select chain on the (wave-uniform) P.
   auto group = [&](int P) {                                      // unit group P: 4 hidden units x CT channels = NB tiles
@@ -165,6 +171,7 @@ __device__ __forceinline__ void mlp_adjoint_eval(const float* lds_base, const fl
         const float t = tv[r];
         f = c == 0 ? t * dX[0] : __builtin_fmaf(t, dX[c], f);
         if (TGRAD) h2 = __builtin_fmaf(t, d2X[c], h2);
+        if constexpr (DCTRL) gxl[c] = __builtin_fmaf(as_P, t, gxl[c]);
         const float slope = ACT == CDE_ACT_TANH ? __builtin_fmaf(-t, t, 1.f) : 1.f;
         g2[c] = as_P * (dX[c] * slope);
       }
@@ -203,6 +210,25 @@ __device__ __forceinline__ void mlp_adjoint_eval(const float* lds_base, const fl
     mlp_split_allreduce(xbuf, pw, lane, gu[4], gu[5], nullptr);
     mlp_split_allreduce(xbuf, pw, lane, gu[6], gu[7], nullptr);
     mlp_split_allreduce(xbuf, pw, lane, fa, fb, &kt);
+    if constexpr (DCTRL) {
+#pragma unroll
+      for (int c8 = 0; c8 < CT; c8 += 8) {
+        f32x4 lo = {gxl[c8], gxl[c8 + 1], gxl[c8 + 2], gxl[c8 + 3]}, hi = {gxl[c8 + 4], gxl[c8 + 5], gxl[c8 + 6], gxl[c8 + 7]};
+        mlp_split_allreduce(xbuf, pw, lane, lo, hi, nullptr);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { gxl[c8 + r] = lo[r]; gxl[c8 + 4 + r] = hi[r]; }
+      }
+    }
+  }
+  if constexpr (DCTRL) {
+    // the four lane quarters hold different hidden units of the same series: fixed-order sum, the result in every lane
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      float v = gxl[c];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      gxo[c] = v;
+    }
   }
   CDE_EVAL_STAMP(2, "+v"(gu[0]), "+v"(gu[7]));
   // ---- dL/dY1 = gu * relu'(pre1);  va = W1^T dL/dY1

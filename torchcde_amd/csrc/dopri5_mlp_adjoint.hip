@@ -29,6 +29,7 @@
 //     gradients are identical with CDE_K4AM_NO_FSAL=1 (tests).
 // Three launches per attempted step (attempt, factor reduction of both layers, R; up to 128 series: two), no host round trip.
 #include "cde_dopri_adj.h"
+#include "cde_dopri_ctl.h"
 #include "cde_mlp_adj.h"
 
 namespace cde {
@@ -64,6 +65,13 @@ struct MlpAdjArgs {
   const double* ext_sums;           // sharded batch: the ADJ_NS state sums of the pending attempt, added up over ALL shards
   int n_pq;                         // blocks of parameter sums the R kernel of this batch size leaves in `pq`
   int dbg;                          // instrumented (CDE_PHASE_TRACE) builds only: CDE_K4AM_DBG bit 0 = no factor stores
+  // DCTRL (control gradients: cde_dopri_ctl.h) -- dopri5_mlp_adjoint_attempt<.., DCTRL = true> only
+  float* gx;                        // [2][B][CT][8]: the launch's per-stage d(a.f)/d(dX_c), unweighted
+  unsigned char* rec;               // [2] AdjStageRec
+  const double* cq;                 // [2][n_cblocks + 1][2]: the control kernel's norm sums (last entry: the knot block)
+  int n_cblocks;
+  double* ktp;                      // [2][n_wg_max][8]: per-workgroup sums of the per-stage time term
+  int with_knots;
 };
 
 // SPLIT (small batches: fewer tiles than SIMDs): the workgroup's four waves share ONE tile and split the middle of every
@@ -73,7 +81,7 @@ constexpr int MADJ_XBUF_FLOATS = 4 * 64 * 9;
 #ifdef CDE_PHASE_TRACE
 __device__ unsigned long long k4am_phase_trace[TRACE_RING * TRACE_BLOCKS * TRACE_SLOTS];
 #endif
-template <int DEGREE, int ACT, int CT, int NWAVE, bool SPLIT = false>
+template <int DEGREE, int ACT, int CT, int NWAVE, bool SPLIT = false, bool DCTRL = false>
 __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adjoint_attempt(MlpAdjArgs g, int parity) {
   static_assert(!SPLIT || NWAVE == 4, "this kernel's split form is four waves per tile (eight: dopri5_mlp_adjoint_attempt_s8)");
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -121,6 +129,11 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
 #pragma unroll
       for (int i = 0; i < 8; ++i) sum[ADJ_NS + i] += Qp[8 * b + i];
     }
+    if constexpr (DCTRL) {                                         // the control kernel's sums: coefficient block, knot block
+      const double* Cp = g.cq + (int64_t)p * (g.n_cblocks + 1) * 2;
+      for (int b = tid; b < g.n_cblocks; b += blockDim.x) { sum[ADJ_NS + 8] += Cp[2 * b]; sum[ADJ_NS + 9] += Cp[2 * b + 1]; }
+      if (tid == 0) { sum[ADJ_NS + 10] = Cp[2 * g.n_cblocks]; sum[ADJ_NS + 11] = Cp[2 * g.n_cblocks + 1]; }
+    }
   }
   if (g.ext_sums && c.phase != 0) {                                // one controller for all shards: the reduced state sums
 #pragma unroll
@@ -167,6 +180,15 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
   for (int j = 0; j < 7; ++j) { wS[j] = uni(wS[j]); wE[j] = uni(wE[j]); }
   const float x_end = uni(plan.x_end);
   CDE_STAMP(2);
+  if constexpr (DCTRL) {
+    if (blockIdx.x == 0 && tid == 0) {
+      AdjStageRec rc;
+      rc.mode = mode; rc.ns = ns;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) { rc.sidx[j] = sidx[j]; rc.sfrac[j] = sfrac[j]; rc.wS[j] = wS[j]; rc.wE[j] = wE[j]; }
+      *reinterpret_cast<AdjStageRec*>(g.rec + p * ADJ_REC_STRIDE) = rc;
+    }
+  }
 
   // First same as last: an attempt that follows an attempt starts where that one started (rejected) or ended (accepted, not
   // on a jump).  One wave per tile: the slopes of that stage are in the lane's ring in memory already (slot 0, or slot 6:
@@ -184,6 +206,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
   }
 
   double acc[ADJ_NS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  double ktd[DCTRL ? 7 : 1] = {};                                  // DCTRL: the per-stage time term of this wave's series
   const int64_t tile = SPLIT ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * NWAVE + wave;
   const int pw = SPLIT ? wave : 0;
   const bool writer = !SPLIT || wave == 0;
@@ -221,6 +244,10 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
       for (int T1 = 0; T1 < 8; ++T1) { w1tr[T1] = w1t_base[T1 * 64]; w1tr[8 + T1] = w1t_base[(8 + T1) * 64]; }
     }
     float vtS = 0.f, vtE = 0.f;
+    float ktv[DCTRL ? 7 : 1] = {};
+    // DCTRL: this series' row of the pending buffer -- lane (n, q) stores channels q, 4 + q, ..
+    float* gx_mine = DCTRL ? g.gx + (((int64_t)p * g.B + sc) * CT) * 8 : nullptr;
+    const float* gx_prev = DCTRL ? g.gx + (((int64_t)p2 * g.B + sc) * CT) * 8 : nullptr;
     // the control row of a stage is requested one stage ahead (SPLIT): its latency hides behind the previous evaluation
     Row<DEGREE, CT> row_next;
     if constexpr (SPLIT) row_next = load_row<DEGREE, CT>(g.coeffs, sc, g.n_intervals, sidx[0], Cr);
@@ -250,17 +277,35 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
       const bool stream = valid && (wS_i != 0.f || wE_i != 0.f || keeps) && !(g.dbg & 1);
       const int64_t out_row = (int64_t)(mode <= 1 ? i : i == 6 ? six : madj_slot(i)) * g.rows_per_stage + series;
       float kt;
+      float gxo[DCTRL ? CT : 1];
       {
-        mlp_adjoint_eval<ACT, CT, DEGREE == CDE_PATH_CUBIC, SPLIT>(
+        mlp_adjoint_eval<ACT, CT, DEGREE == CDE_PATH_CUBIC, SPLIT, DCTRL>(
             lds, w1t_base, lane, n, q, w2y_off, w2g_off, zs, as, dX, d2X, stream, g.U + out_row * U_COLS + 4 * q,
             g.Z + out_row * Z_COLS, g.G2 + out_row * G2_COLS + CT * q, g.G1 + out_row * G1_COLS + 4 * q, Hr, fa, fb, va, vb, kt,
-            pw, xbuf, w1tr
+            pw, xbuf, w1tr,
 #ifdef CDE_PHASE_TRACE
-            , i == 3, est
+            i == 3, est,
+#else
+            false, nullptr,
 #endif
-            );
+            gxo);
       }
       if (DEGREE == CDE_PATH_CUBIC) { vtS = __builtin_fmaf(wS_i, kt, vtS); vtE = __builtin_fmaf(wE_i, kt, vtE); }
+      if constexpr (DCTRL) {
+        // the pending values of this stage: slot i of the series' row (channel c by lane quarter c & 3), and the time term
+        if (valid && writer) {
+#pragma unroll
+          for (int c = 0; c < CT; ++c) if ((c & 3) == q) gx_mine[c * 8 + i] = gxo[c];
+        }
+        float term = kt;                                             // cubic: a . F d2X/dt2 (this lane's share)
+        if (DEGREE != CDE_PATH_CUBIC) {                              // linear: a . f (the knot times act through the widths)
+          term = 0.f;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) term = __builtin_fmaf(as[m], fa[m], __builtin_fmaf(as[4 + m], fb[m], term));
+        }
+#pragma unroll
+        for (int kk = 0; kk < 7; ++kk) ktv[kk] += i == kk ? term : 0.f;
+      }
       if constexpr (!SPLIT) {
         if (keeps && valid && DEGREE == CDE_PATH_CUBIC) g.stash_t[((int64_t)(i == 0 ? 0 : 1) * g.B + series) * 4 + q] = kt;
       } else if (keeps && valid && writer) {                       // planes 0 / 1 / 2 <-> blocks 0 / 5 / 6
@@ -281,6 +326,21 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
           if (valid && DEGREE == CDE_PATH_CUBIC) g.stash_t[((int64_t)0 * g.B + series) * 4 + q] = kt0;
         }
         if (DEGREE == CDE_PATH_CUBIC) { vtS = __builtin_fmaf(wS[0], kt0, vtS); vtE = __builtin_fmaf(wE[0], kt0, vtE); }
+        if constexpr (DCTRL) {
+          // the reused stage's pending values: the previous launch's slot 0 (rejected) or 6 (accepted); its time term from the
+          // stash (cubic) or from the kept slopes (linear: a . f, with a = the step's start value)
+          if (valid) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c) if ((c & 3) == q) gx_mine[c * 8] = gx_prev[c * 8 + (plan.accept ? 6 : 0)];
+          }
+          float term = kt0;
+          if (DEGREE != CDE_PATH_CUBIC) {
+            const float4 k0 = ring_get(0, 0), k1 = ring_get(0, 1);
+            term = -((a0a[0] * k0.x + a0a[1] * k0.y + a0a[2] * k0.z + a0a[3] * k0.w) +
+                     (a0b[0] * k1.x + a0b[1] * k1.y + a0b[2] * k1.z + a0b[3] * k1.w));
+          }
+          ktv[0] += term;
+        }
       }
       // one wave per tile: fully unrolled (the slope ring lives in global memory, every index is static)
 #pragma unroll
@@ -328,6 +388,16 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
         if (DEGREE == CDE_PATH_CUBIC) {
           const float kt0 = valid ? g.stash_t[at * 4 + q] : 0.f;
           vtS = __builtin_fmaf(wS[0], kt0, vtS); vtE = __builtin_fmaf(wE[0], kt0, vtE);
+          if constexpr (DCTRL) ktv[0] += kt0;
+        } else if constexpr (DCTRL) {
+          ktv[0] -= (a0a[0] * k0[0] + a0a[1] * k0[1] + a0a[2] * k0[2] + a0a[3] * k0[3]) +
+                    (a0b[0] * k1[0] + a0b[1] * k1[1] + a0b[2] * k1[2] + a0b[3] * k1[3]);
+        }
+        if constexpr (DCTRL) {
+          if (valid && writer) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c) if ((c & 3) == q) gx_mine[c * 8] = gx_prev[c * 8 + (plan.accept ? 6 : 0)];
+          }
         }
         row_next = load_row<DEGREE, CT>(g.coeffs, sc, g.n_intervals, sidx[1], Cr);      // the first evaluated stage is stage 1
       }
@@ -445,6 +515,12 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
       }
     }
     if (writer) { acc[4] = (double)vtS; acc[5] = (double)vtE; }
+    if constexpr (DCTRL) {
+      if (writer) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) ktd[j] = (double)ktv[j];
+      }
+    }
   }
   CDE_STAMP(11);
   // ---- publish this launch's partial sums
@@ -454,6 +530,16 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
   if (tid == 0) {
 #pragma unroll
     for (int i = 0; i < ADJ_NS; ++i) Pq[ADJ_NS * blockIdx.x + i] = acc[i];
+  }
+  if constexpr (DCTRL) {
+    if (g.with_knots) {
+      block_total<7>(ktd, red);
+      if (tid == 0) {
+        double* dst = g.ktp + ((int64_t)p * g.n_wg_max + blockIdx.x) * 8;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) dst[j] = ktd[j];
+      }
+    }
   }
 }
 
@@ -1080,6 +1166,8 @@ struct MadjLayout {
   int sps, nwave, n_wg;
   bool split, split8, small;
   size_t partial, pq, carry, image, state, G, prev, Gn, prevn, slopes, stash, kst, part2, part1, U, G2, G1, Z, trace, trace_all, total;
+  size_t rec, cq, ktp, gx, total_dcontrol;                         // control gradients: behind everything else
+  int n_cblocks, ct;
 };
 MadjLayout madj_layout(int64_t B, int64_t H, int64_t C) {
   using namespace cde;
@@ -1135,12 +1223,23 @@ MadjLayout madj_layout(int64_t B, int64_t H, int64_t C) {
   L.trace = L.Z + m256(rows * Z_COLS * sizeof(float));
   L.trace_all = L.trace + m256((size_t)CDE_DOPRI5_TRACE_STEPS * 3 * sizeof(double));
   L.total = L.trace_all + m256((size_t)ADJ_TRACE_ATTEMPTS * 5 * sizeof(double));
+  // control gradients (cde_dopri5_adjoint_mlp_advance_dcontrol): the plain layout is a prefix
+  L.ct = C > MC ? 16 : 8;
+  L.n_cblocks = (int)((B * L.ct + 255) / 256);
+  L.rec = L.total;
+  L.cq = L.rec + m256(2 * ADJ_REC_STRIDE);
+  L.ktp = L.cq + m256((size_t)2 * (L.n_cblocks + 1) * 2 * sizeof(double));
+  L.gx = L.ktp + m256((size_t)2 * L.n_wg * 8 * sizeof(double));
+  L.total_dcontrol = L.gx + m256((size_t)2 * B * L.ct * 8 * sizeof(float));
   return L;
 }
 }  // namespace
 
 extern "C" size_t cde_dopri5_adjoint_mlp_workspace_bytes(int64_t B, int64_t C, int64_t H) {
   return B < 1 || H < 1 ? 0 : madj_layout(B, H, C).total;
+}
+extern "C" size_t cde_dopri5_adjoint_mlp_dcontrol_workspace_bytes(int64_t B, int64_t C, int64_t H) {
+  return B < 1 || H < 1 ? 0 : madj_layout(B, H, C).total_dcontrol;
 }
 extern "C" size_t cde_dopri5_adjoint_mlp_trace_offset(int64_t B, int64_t C, int64_t H, int which) {
   const MadjLayout L = madj_layout(B, H, C);
@@ -1174,9 +1273,14 @@ static int dopri5_adjoint_mlp_advance_impl(const void* coeffs, const void* knots
                                            double atol, double safety, double ifactor, double dfactor, int norm_kind,
                                            void* a_out, int64_t B, int64_t C, int64_t H, int dtype, int first_interval,
                                            void* workspace, size_t workspace_bytes, int64_t first_launch,
-                                           int64_t n_launches, void* stream, const double* reduced_sums, int64_t B_global) {
+                                           int64_t n_launches, void* stream, const double* reduced_sums, int64_t B_global,
+                                           void* grad_coeffs = nullptr, int64_t control_numel = 0,
+                                           void* grad_knots = nullptr) {
   using namespace cde;
   const bool sharded = reduced_sums != nullptr || B_global > 0;
+  const bool dctrl = grad_coeffs != nullptr;
+  if (dctrl && (sharded || control_numel < 1)) return CDE_ERR_UNSUPPORTED;     // control gradients: one controller per solve
+  if (grad_knots && !dctrl) return CDE_ERR_UNSUPPORTED;
   if (sharded && (n_launches != 1 || B_global < B)) return CDE_ERR_SHAPE;        // sharded: one launch per all-reduce
   if (first_launch > 0 && sharded && !reduced_sums) return CDE_ERR_NULL;
   if (B < 1 || C < 1 || H < 1 || width < 1 || n_intervals < 1 || n_launches < 0 || n_jump < 0 || !(s0 < s1)) return CDE_ERR_SHAPE;
@@ -1187,10 +1291,12 @@ static int dopri5_adjoint_mlp_advance_impl(const void* coeffs, const void* knots
   if (norm_kind != 0 && norm_kind != 1) return CDE_ERR_UNSUPPORTED;
   if (!coeffs || !knots || !W1 || !bias1 || !W2 || !bias2 || !y_init || !a_init || !a_out || !workspace) return CDE_ERR_NULL;
   if (n_jump > 0 && !jump_s) return CDE_ERR_NULL;
-  if (workspace_bytes < cde_dopri5_adjoint_mlp_workspace_bytes(B, C, H)) return CDE_ERR_WORKSPACE;
+  if (workspace_bytes < (dctrl ? cde_dopri5_adjoint_mlp_dcontrol_workspace_bytes(B, C, H) : cde_dopri5_adjoint_mlp_workspace_bytes(B, C, H)))
+    return CDE_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   unsigned char* base = (unsigned char*)workspace;
   const MadjLayout L = madj_layout(B, H, C);
+  if (dctrl && grad_knots && L.n_wg > ADJ_KT_MAX_WG * 64) return CDE_ERR_UNSUPPORTED;
   MlpAdjArgs g;
   g.coeffs = (const float*)coeffs; g.knots = (const float*)knots; g.n_intervals = n_intervals;
   g.img = (const float*)(base + L.image);
@@ -1213,8 +1319,11 @@ static int dopri5_adjoint_mlp_advance_impl(const void* coeffs, const void* knots
   g.com.rtol = rtol; g.com.atol = atol; g.com.safety = safety; g.com.ifactor = ifactor; g.com.dfactor = dfactor;
   g.com.n_state = (B_global > 0 ? B_global : B) * H;
   g.ext_sums = reduced_sums;
-  g.com.n_pt = 4;
+  g.com.n_pt = dctrl ? (grad_knots ? 6 : 5) : 4;
   g.com.n_param[0] = width * H; g.com.n_param[1] = width; g.com.n_param[2] = H * C * width; g.com.n_param[3] = H * C;
+  g.com.n_param[4] = dctrl ? control_numel : 1; g.com.n_param[5] = grad_knots ? n_intervals + 1 : 1;
+  g.gx = (float*)(base + L.gx); g.rec = base + L.rec; g.cq = (const double*)(base + L.cq); g.n_cblocks = L.n_cblocks;
+  g.ktp = (double*)(base + L.ktp); g.with_knots = grad_knots ? 1 : 0;
   g.com.norm_kind = norm_kind;
   g.com.trace = (double*)(base + L.trace);
   g.com.trace_all = (double*)(base + L.trace_all);
@@ -1232,11 +1341,23 @@ static int dopri5_adjoint_mlp_advance_impl(const void* coeffs, const void* knots
       const int rc = launch_mlp_adjoint_images(W1, bias1, width, W2, bias2, C, H, (float*)(base + L.image), s);
       if (rc != CDE_OK) return rc;
     }
+    if (dctrl) zero_async(base + L.rec, L.gx - L.rec, s);                         // stage records, control norm sums, time terms
   }
+  AdjControlArgs cr;
+  cr.ctrl = base; cr.rec = base + L.rec; cr.gx = (const float*)(base + L.gx); cr.G = (float*)grad_coeffs;
+  cr.knots = (const float*)knots; cr.cq = (double*)(base + L.cq); cr.B = B; cr.n_intervals = n_intervals;
+  cr.C = (int)C; cr.degree = degree; cr.norm_kind = norm_kind; cr.rtol = (float)rtol; cr.atol = (float)atol;
+  cr.G_knots = (float*)grad_knots; cr.ktp = (const double*)(base + L.ktp); cr.n_wg = L.n_wg; cr.kt_stride = L.n_wg;
+  if (dctrl && L.split8 && L.n_tiles > MADJ_SPLIT_MAX_TILES) cr.n_wg = (int)((L.n_tiles + 3) / 4);
   // sharded under "seminorm": only the 8 state sums travel between the shards (cde_dopri5_adjoint_mlp_state_sums /
   // _apply_state_sums); the gradient images are reduced, committed and returned per shard like an unsharded solve's
   const bool images_local = sharded && norm_kind == 1;
   MlpReduceArgs r = madj_reduce_args(base, L, rtol, atol, sharded && !images_local);
+  // control gradients on eight-channel tiles take the four-wave form where the eight-wave form would run -- up to the 256 tiles
+  // that form is used (and tested) on; beyond that one wave per tile, on fewer workgroups than the layout provides for
+  const bool dctrl_one_wave = dctrl && L.split8 && L.n_tiles > MADJ_SPLIT_MAX_TILES;
+  const int grid = dctrl_one_wave ? (int)((L.n_tiles + 3) / 4) : L.n_wg;
+  r.n_wg = grid;
   MlpSmallArgs sm;
   sm.r = r; sm.G2 = g.G2; sm.U = g.U; sm.G1 = g.G1; sm.Z = g.Z; sm.rows_per_stage = L.rows_per_stage; sm.B = B;
   // after an attempt launch: the split-K reduction of its factor rows + the R kernel, or (small batches) both in one launch
@@ -1252,17 +1373,32 @@ static int dopri5_adjoint_mlp_advance_impl(const void* coeffs, const void* knots
     mlp_adjoint_reduce_kernel<<<MADJ_RBLOCKS, 256, 0, s>>>(r, parity);
     return CDE_OK;
   };
+  // ... and (control gradients) the kernel that owns the coefficient / knot-time blocks (cde_dopri_ctl.h)
+  auto control_after = [&](int parity) {
+    if (!dctrl) return;
+    if (degree == CDE_PATH_CUBIC) {
+      if (C > MC) adjoint_control_kernel<CDE_PATH_CUBIC, 16><<<L.n_cblocks, 256, 0, s>>>(cr, parity);
+      else adjoint_control_kernel<CDE_PATH_CUBIC, 8><<<L.n_cblocks, 256, 0, s>>>(cr, parity);
+    } else {
+      if (C > MC) adjoint_control_kernel<CDE_PATH_LINEAR, 16><<<L.n_cblocks, 256, 0, s>>>(cr, parity);
+      else adjoint_control_kernel<CDE_PATH_LINEAR, 8><<<L.n_cblocks, 256, 0, s>>>(cr, parity);
+    }
+  };
   const size_t lds_bytes = (size_t)ADJ_LDS_FLOATS * sizeof(float) + (size_t)MADJ_NSUM * 8 * sizeof(double) +
                            (L.split ? (size_t)MADJ_XBUF_FLOATS * sizeof(float) : 0);
 #define CDE_MADJ_LAUNCH(D, A, CTV, NWV, SPL)                                                                         \
   do {                                                                                                               \
     (void)hipFuncSetAttribute((const void*)dopri5_mlp_adjoint_attempt<D, A, CTV, NWV, SPL>,                          \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                           \
+    (void)hipFuncSetAttribute((const void*)dopri5_mlp_adjoint_attempt<D, A, CTV, NWV, SPL, true>,                    \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                           \
     for (int64_t i = 0; i < n_launches; ++i) {                                                                       \
       const int parity = (int)((first_launch + i) & 1);                                                              \
-      dopri5_mlp_adjoint_attempt<D, A, CTV, NWV, SPL><<<L.n_wg, 64 * NWV, lds_bytes, s>>>(g, parity);                \
+      if (dctrl) dopri5_mlp_adjoint_attempt<D, A, CTV, NWV, SPL, true><<<grid, 64 * NWV, lds_bytes, s>>>(g, parity);   \
+      else dopri5_mlp_adjoint_attempt<D, A, CTV, NWV, SPL><<<L.n_wg, 64 * NWV, lds_bytes, s>>>(g, parity);           \
       const int rc = after_attempt(parity);                                                                          \
       if (rc != CDE_OK) return rc;                                                                                   \
+      control_after(parity);                                                                                         \
     }                                                                                                                \
   } while (0)
 #define CDE_MADJ_LAUNCH_S8(D, A)                                                                                     \
@@ -1278,14 +1414,15 @@ static int dopri5_adjoint_mlp_advance_impl(const void* coeffs, const void* knots
   } while (0)
 #define CDE_MADJ_W(D, A, CTV)                                                                                        \
   do {                                                                                                               \
-    if (L.split) CDE_MADJ_LAUNCH(D, A, CTV, 4, true);                                                                \
+    if (dctrl_one_wave) CDE_MADJ_LAUNCH(D, A, CTV, 4, false);                                                        \
+    else if (L.split) CDE_MADJ_LAUNCH(D, A, CTV, 4, true);                                                           \
     else if (L.nwave == 8) CDE_MADJ_LAUNCH(D, A, CTV, 8, false);                                                     \
     else CDE_MADJ_LAUNCH(D, A, CTV, 4, false);                                                                       \
   } while (0)
 #define CDE_MADJ(D, A)                                                                                               \
   do {                                                                                                               \
     if (C > MC) CDE_MADJ_W(D, A, 16);                                                                                \
-    else if (L.split8) CDE_MADJ_LAUNCH_S8(D, A);                                                                     \
+    else if (L.split8 && !dctrl) CDE_MADJ_LAUNCH_S8(D, A);       /* (control gradients: the four-wave form) */          \
     else CDE_MADJ_W(D, A, 8);                                                                                        \
   } while (0)
   if (act == CDE_ACT_NONE) {
@@ -1312,6 +1449,25 @@ extern "C" int cde_dopri5_adjoint_mlp_advance(const void* coeffs, const void* kn
                                          s0, s1, jump_s, n_jump, rtol, atol, safety, ifactor, dfactor, norm_kind, a_out, B, C,
                                          H, dtype, first_interval, workspace, workspace_bytes, first_launch, n_launches,
                                          stream, nullptr, 0);
+}
+
+// K4am with control gradients (round 6; cde_mi355x.h): the coefficient tensor -- and optionally the knot times -- as further
+// blocks of the adjoint state.  Eight-channel tiles then run the four-wave / one-wave forms (not the eight-wave one).
+extern "C" int cde_dopri5_adjoint_mlp_advance_dcontrol(const void* coeffs, const void* knots, int64_t n_intervals, int degree,
+                                                       const void* W1, const void* bias1, int64_t width, const void* W2,
+                                                       const void* bias2, int act, const void* y_init, const void* a_init,
+                                                       double s0, double s1, const double* jump_s, int64_t n_jump,
+                                                       double rtol, double atol, double safety, double ifactor,
+                                                       double dfactor, int norm_kind, void* a_out, int64_t B, int64_t C,
+                                                       int64_t H, int dtype, int first_interval, void* workspace,
+                                                       size_t workspace_bytes, int64_t first_launch, int64_t n_launches,
+                                                       void* grad_coeffs, int64_t control_numel, void* grad_knots,
+                                                       void* stream) {
+  if (!grad_coeffs) return CDE_ERR_NULL;
+  return dopri5_adjoint_mlp_advance_impl(coeffs, knots, n_intervals, degree, W1, bias1, width, W2, bias2, act, y_init, a_init,
+                                         s0, s1, jump_s, n_jump, rtol, atol, safety, ifactor, dfactor, norm_kind, a_out, B, C,
+                                         H, dtype, first_interval, workspace, workspace_bytes, first_launch, n_launches,
+                                         stream, nullptr, 0, grad_coeffs, control_numel, grad_knots);
 }
 
 // ---- one step controller for a batch sharded over GPUs, two-layer field (round 4; the one-layer protocol of

@@ -436,7 +436,8 @@ __global__ __launch_bounds__(512, 1) void rk4_adjoint_split8(
               pp = __builtin_elementwise_fma(f32x2{j0[2], j0[3]}, z23, pp);
               pp = __builtin_elementwise_fma(f32x2{j1[0], j1[1]}, z45, pp);
               pp = __builtin_elementwise_fma(f32x2{j1[2], j1[3]}, z67, pp);
-              p[hi] = pp[0] + pp[1];
+              asm("" : "+v"(pp));                                    // keeps the chain packed (LLVM scalarises a packed chain
+              p[hi] = pp[0] + pp[1];                                 //  whose lanes are consumed separately: 8 instead of 4 per row)
               va01 = __builtin_elementwise_fma(f32x2{j0[0], j0[1]}, ah, va01);
               va23 = __builtin_elementwise_fma(f32x2{j0[2], j0[3]}, ah, va23);
               vb01 = __builtin_elementwise_fma(f32x2{j1[0], j1[1]}, ah, vb01);

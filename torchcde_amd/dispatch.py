@@ -102,11 +102,15 @@ def select_path(q):
             return _stepwise("variant='generic' was requested (the step-wise reference path)")
         if not q.wants_grad:
             return Choice("mlp_rk4_forward" if q.method == "rk4" else "mlp_dopri5_forward", "")
-        if q.wants_t and q.method == "dopri5" and (q.wants_control or q.shared):
-            return _stepwise("gradients w.r.t. the output times of a two-layer field next to control gradients / a shared controller")
+        if q.wants_t and q.method == "dopri5" and q.shared:
+            return _stepwise("gradients w.r.t. the output times of a two-layer field next to a shared controller")
         if q.wants_control:
             if q.method == "dopri5":
-                return _stepwise("control gradients through the adaptive backward of a two-layer field")
+                if q.control_block and not q.shared:
+                    return Choice("mlp_dopri5_adjoint", "")
+                return _stepwise("control gradients through the adaptive backward: fused for the coefficient tensor the path "
+                                 "was built from (optionally with its knot times) as the extra entries of adjoint_params, no "
+                                 "shared step controller")
             return Choice("mlp_rk4_adjoint", "")
         if q.method == "rk4":
             return Choice("mlp_rk4_adjoint", "")
