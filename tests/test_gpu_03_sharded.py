@@ -12,12 +12,18 @@ from gpu_common import (LinearField, _TwoLayerField, make_series, DEV, _close, _
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("times", [False, True])
 @pytest.mark.parametrize("norm", ["mixed", "seminorm"])
-def test_sharded_dopri5_with_one_shared_controller(native, norm):
+def test_sharded_dopri5_with_one_shared_controller(native, norm, times):
     """SURVEY 8(e) caveat / BASELINE configs[3]: a batch sharded over GPUs must take the step sequence of the UNSHARDED
     batch (torchdiffeq's controller is batch-global).  Two shards are driven in lock step on this one GPU -- two host
     threads whose `reduce` adds their pending sums, exactly what the RCCL all-reduce does between ranks -- and must
-    reproduce the unsharded solve: same accepted steps, same trajectories, same gradients (forward K4 and backward K4a)."""
+    reproduce the unsharded solve: same accepted steps, same trajectories, same gradients (forward K4 and backward K4a).
+    `times` (round 6): the output times require a gradient as well.  vjp_t is a quantity of the WHOLE batch (it is in the
+    error norm), so the shards add up the terms it starts every interval from and every shard returns the global dL/dt --
+    bitwise the same on both.  Those terms are then summed in another order than the unsharded batch sums them, the starting
+    value of vjp_t differs in its last bit and with it, possibly, a borderline decision: step counts within 5 %, values at
+    solver tolerance."""
     import threading
     from torchcde_amd.distributed import shared_step_control
     from torchcde_amd.cdeint import _Dopri5Plan
@@ -44,7 +50,9 @@ def test_sharded_dopri5_with_one_shared_controller(native, norm):
         whole = plan_for(slice(0, B))
         out_ref = whole.run(z0, field.weight, field.bias)
         steps_ref = front.last_dopri5_stats["steps"]
-        gz_ref, gw_ref, gb_ref = whole.run_adjoint(out_ref, g_out, field.weight, field.bias)
+        # (output times that require a gradient, round 6: vjp_t is a quantity of the whole batch -- the shards add up the terms
+        #  it starts every interval from and every shard returns the global dL/dt)
+        gz_ref, gw_ref, gb_ref, *gt_ref = whole.run_adjoint(out_ref, g_out, field.weight, field.bias, want_t=times)
         bsteps_ref = front.last_dopri5_adjoint_stats["steps"][0]
     finally:
         front.record_dopri5_steps = False
@@ -71,8 +79,9 @@ def test_sharded_dopri5_with_one_shared_controller(native, norm):
                 plan = plan_for(sl)
             out = plan.run(z0[sl].contiguous(), field.weight, field.bias)
             n_fwd = front.last_dopri5_stats["n_accept"]
-            gz, gw, gb = plan.run_adjoint(out, g_out[sl].contiguous(), field.weight, field.bias)
-            results[rank] = (out, gz, gw.clone(), gb.clone(), n_fwd, front.last_dopri5_adjoint_stats["n_accept"])
+            gz, gw, gb, *gt = plan.run_adjoint(out, g_out[sl].contiguous(), field.weight, field.bias, want_t=times)
+            results[rank] = (out, gz, gw.clone(), gb.clone(), n_fwd, front.last_dopri5_adjoint_stats["n_accept"],
+                             gt[0].clone() if times else None)
         except Exception as exc:                        # noqa: BLE001
             errors.append(exc)
             barrier.abort()
@@ -86,19 +95,29 @@ def test_sharded_dopri5_with_one_shared_controller(native, norm):
     out = torch.cat([results[0][0], results[1][0]])
     gz = torch.cat([results[0][1], results[1][1]])
     assert results[0][4] == results[1][4] == steps_ref.size(0)                    # the unsharded step sequence
-    assert results[0][5] == results[1][5] == bsteps_ref.size(0)
+    assert results[0][5] == results[1][5]
+    tol = 1e-4
+    if times:
+        assert abs(results[0][5] - bsteps_ref.size(0)) <= max(1, 0.05 * bsteps_ref.size(0))
+        tol = 1e-2
+    else:
+        assert results[0][5] == bsteps_ref.size(0)
     _close(out, out_ref, 1e-5, 1e-6)
-    _close(gz, gz_ref, 1e-4, 1e-5 * gz_ref.abs().max().item())
-    _close(results[0][2] + results[1][2], gw_ref, 1e-4, 1e-4 * gw_ref.abs().max().item())
-    _close(results[0][3] + results[1][3], gb_ref, 1e-4, 1e-4 * gb_ref.abs().max().item())
+    _close(gz, gz_ref, tol, 0.1 * tol * gz_ref.abs().max().item())
+    _close(results[0][2] + results[1][2], gw_ref, tol, tol * gw_ref.abs().max().item())
+    _close(results[0][3] + results[1][3], gb_ref, tol, tol * gb_ref.abs().max().item())
+    if times:
+        assert torch.equal(results[0][6], results[1][6])                          # dL/dt: the same global value on both shards
+        _close(results[0][6], gt_ref[0], tol, tol * gt_ref[0].abs().max().item())
     # and without the shared controller the halves really do step differently (the test would be vacuous otherwise)
     lone = plan_for(slice(0, B // 2))
     lone.run(z0[:B // 2].contiguous(), field.weight, field.bias)
     assert front.last_dopri5_stats["n_accept"] != steps_ref.size(0) or True
 
 
+@pytest.mark.parametrize("times", [False, True])
 @pytest.mark.parametrize("norm", ["seminorm", "mixed"])
-def test_sharded_two_layer_default_call_with_one_shared_controller(native, norm):
+def test_sharded_two_layer_default_call_with_one_shared_controller(native, norm, times):
     """VERDICT round 3, missing #3: one controller across GPUs for the TWO-LAYER field -- the call every example of the
     reference makes (example/time_series_classification.py:83-86, logsignature_example.py:21-23), sharded.  As for the
     one-layer kernels above: two shards in lock step on this GPU (two host threads whose `reduce` adds their buffers, what
@@ -136,7 +155,7 @@ def test_sharded_two_layer_default_call_with_one_shared_controller(native, norm)
     whole = plan_for(slice(0, B))
     out_ref = whole.run(z0, mlp.weight, mlp.bias)
     n_fwd_ref = front.last_dopri5_stats["n_accept"]
-    ref = whole.run_adjoint_mlp(out_ref, g_out, *weights)
+    ref = whole.run_adjoint_mlp(out_ref, g_out, *weights, want_t=times)
     ref = tuple(t.clone() for t in ref)
     n_bwd_ref = (front.last_dopri5_adjoint_stats["n_accept"], front.last_dopri5_adjoint_stats["n_reject"])
 
@@ -161,7 +180,7 @@ def test_sharded_two_layer_default_call_with_one_shared_controller(native, norm)
                 plan = plan_for(sl)
             out = plan.run(z0[sl].contiguous(), mlp.weight, mlp.bias)
             n_fwd = front.last_dopri5_stats["n_accept"]
-            grads = plan.run_adjoint_mlp(out, g_out[sl].contiguous(), *weights)
+            grads = plan.run_adjoint_mlp(out, g_out[sl].contiguous(), *weights, want_t=times)
             st = front.last_dopri5_adjoint_stats
             results[rank] = (out, tuple(t.clone() for t in grads), n_fwd, (st["n_accept"], st["n_reject"]))
         except Exception as exc:                        # noqa: BLE001
@@ -176,7 +195,7 @@ def test_sharded_two_layer_default_call_with_one_shared_controller(native, norm)
     assert not errors, errors
     assert results[0][2] == results[1][2] == n_fwd_ref                            # the unsharded step sequence, forward ..
     assert results[0][3] == results[1][3]                                         # .. both shards the same backward ..
-    if norm == "seminorm":
+    if norm == "seminorm" and not times:
         assert results[0][3] == n_bwd_ref                                         # .. which is the unsharded one
         tol = 1e-4
     else:
@@ -186,3 +205,6 @@ def test_sharded_two_layer_default_call_with_one_shared_controller(native, norm)
     _close(torch.cat([results[0][1][0], results[1][1][0]]), ref[0], tol, tol * ref[0].abs().max().item())
     for i in range(1, 5):                                                          # dW1, db1, dW2, db2: shard sums
         _close(results[0][1][i] + results[1][1][i], ref[i], tol, tol * ref[i].abs().max().item())
+    if times:                                                                      # (round 6, as for the one-layer kernels)
+        assert torch.equal(results[0][1][5], results[1][1][5])                     # dL/dt: the global value on both shards
+        _close(results[0][1][5], ref[5], tol, tol * ref[5].abs().max().item())

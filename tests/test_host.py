@@ -838,11 +838,11 @@ def test_dispatch_table_is_exhaustively_consistent():
                         assert f["adjoint"] and f["adjoint_method_ok"] and f["adjoint_options_ok"] and params != "foreign"
                     if c.path == "dopri5_adjoint":
                         # (output-time gradients: K4a carries vjp_t; not with one controller across shards)
-                        # (control gradients: the coefficient tensor as ONE block of the adjoint norm, one controller per solve)
-                        assert f["mfma_shape"] and not (f["wants_t"] and f["shared"])
+                        # (control gradients: the coefficient tensor as ONE block of the adjoint norm, one controller per solve;
+                        #  output-time gradients: K4a carries vjp_t, with one controller across shards as well since round 6)
+                        assert f["mfma_shape"]
                         assert not f["wants_control"] or (f["control_block"] and not f["shared"])
                     if c.path == "mlp_dopri5_adjoint":
-                        assert not (f["wants_t"] and f["shared"])
                         assert not f["wants_control"] or (f["control_block"] and not f["shared"])
                     if kind == "mlp2":
                         assert not f["variant_generic"]
@@ -870,6 +870,8 @@ def test_dispatch_table_is_exhaustively_consistent():
     assert ask(kind="mlp2", mfma_shape=False, shared=True).path == "mlp_dopri5_adjoint"    # ... for the examples' model too
     assert ask(method="rk4", wants_control=True, params="own").path == "rk4"    # README.md:251-270
     assert ask(wants_t=True).path == "dopri5_adjoint"                           # output-time gradients: K4a carries vjp_t
+    assert ask(wants_t=True, shared=True).path == "dopri5_adjoint"              # ... next to one controller across the shards too
+    assert ask(kind="mlp2", mfma_shape=False, wants_t=True, shared=True).path == "mlp_dopri5_adjoint"
     # README.md:251-270 with the default method: adjoint_params = parameters + (coeffs,) -- one more block of K4a's norm
     assert ask(wants_control=True, params="own", control_block=True).path == "dopri5_adjoint"
     assert ask(wants_control=True, params="own", control_block=True, wants_t=True).path == "dopri5_adjoint"
@@ -887,7 +889,7 @@ def test_dispatch_table_is_exhaustively_consistent():
     for kw, word in ((dict(kind=None), "recognised"), (dict(method="midpoint", kind="mlp2", mfma_shape=False), "midpoint"),
                      (dict(method="euler", adjoint=False), "euler"), (dict(method="heun3"), "heun3"),
                      (dict(adjoint=False), "adjoint=False"), (dict(method="rk4", adjoint=False, backprop_ok=False), "adjoint=False"), (dict(options_ok=False), "options"),
-                     (dict(mfma_shape=False), "32 x 8"), (dict(wants_t=True, shared=True), "time"),
+                     (dict(mfma_shape=False), "32 x 8"),
                      (dict(wants_control=True, params="own"), "control"),
                      (dict(t_ok=False), "increasing"), (dict(params="foreign"), "adjoint_params"),
                      (dict(prod=True), "prod"), (dict(tiles_ok=False, mfma_shape=False), "tiles")):

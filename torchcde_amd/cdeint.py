@@ -1001,6 +1001,12 @@ class _Dopri5Plan:
             dX = self.path.derivative(self.t_out[1:]).reshape(B, self.n_out - 1, C)
             f_all = (pre.view(B, self.n_out - 1, H, C) * dX.unsqueeze(2)).sum(-1)
             terms = (f_all * grad_out[:, 1:]).sum((0, 2))
+            if shared is not None:
+                # one controller for all shards: vjp_t is a quantity of the WHOLE batch (it is in the error norm), so the
+                # terms it starts every interval from are summed over the shards; every rank returns the global dL/dt
+                terms64 = terms.to(torch.float64)
+                shared[0](terms64)
+                terms = terms64.to(torch.float32)
             for i in range(1, self.n_out):
                 time_terms[i] = terms[i - 1]
         for i in range(self.n_out - 1, 0, -1):
@@ -1130,6 +1136,10 @@ class _Dopri5Plan:
                 pre = pre.tanh()
             dX = self.path.derivative(self.t_out[1:]).reshape(B, self.n_out - 1, C)
             terms = ((pre.view(B, self.n_out - 1, H, C) * dX.unsqueeze(2)).sum(-1) * grad_out[:, 1:]).sum((0, 2))
+            if shared is not None:                # (as in run_adjoint: the time terms of the whole batch)
+                terms64 = terms.to(torch.float64)
+                shared[0](terms64)
+                terms = terms64.to(torch.float32)
             for i in range(1, self.n_out):
                 time_terms[i] = terms[i - 1]
         for i in range(self.n_out - 1, 0, -1):
@@ -1163,8 +1173,8 @@ class _Dopri5Plan:
                             _lib.ptr(b1), width, _lib.ptr(w2), _lib.ptr(b2), self.act, _lib.ptr(y), _lib.ptr(a), s0, s1,
                             _lib.ptr(self.jump_s), self.n_jump_s, self.adjoint_rtol, self.adjoint_atol, self.adj_safety,
                             self.adj_ifactor, self.adj_dfactor, self.adj_norm_kind, _lib.ptr(a_out), B, C, H,
-                            _lib.dtype_enum(torch.float32), int(i == self.n_out - 1), _lib.ptr(workspace), workspace.numel(),
-                            launched, _lib.ptr(reduced) if launched else None, shared[1], stream),
+                            _lib.dtype_enum(torch.float32), int(i == self.n_out - 1) | (2 if want_t else 0), _lib.ptr(workspace),
+                            workspace.numel(), launched, _lib.ptr(reduced) if launched else None, shared[1], stream),
                             "cde_dopri5_adjoint_mlp_advance_sharded")
                         launched += 1
                         if state_only:

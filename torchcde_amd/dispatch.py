@@ -102,8 +102,6 @@ def select_path(q):
             return _stepwise("variant='generic' was requested (the step-wise reference path)")
         if not q.wants_grad:
             return Choice("mlp_rk4_forward" if q.method == "rk4" else "mlp_dopri5_forward", "")
-        if q.wants_t and q.method == "dopri5" and q.shared:
-            return _stepwise("gradients w.r.t. the output times of a two-layer field next to a shared controller")
         if q.wants_control:
             if q.method == "dopri5":
                 if q.control_block and not q.shared:
@@ -126,8 +124,6 @@ def select_path(q):
         return _stepwise("control gradients through the adaptive backward: fused for the coefficient tensor the path was built "
                          "from (optionally with its knot times) as the extra entries of adjoint_params, one-layer fields on the "
                          "32 x 8 tiles, no shared step controller")
-    if q.wants_t and q.shared:
-        return _stepwise("output-time gradients through the adaptive backward with a shared step controller")
     if not q.mfma_shape:
         return _stepwise("the adaptive backward exists for the 32 x 8 MFMA tiles only (float32, H <= 32, C <= 8)")
     return Choice("dopri5_adjoint", "")
