@@ -22,7 +22,8 @@ BASE = dispatch.Request(
 
 _MLP = dict(kind="mlp2", mfma_shape=False, identity=False)
 _BOOLS = {"mfma_shape": (False, True), "narrow_control": (False, True), "variant_generic": (False, True),
-          "wants_t": (False, True), "shared": (False, True), "backprop_ok": (False, True), "identity": (False, True)}
+          "wants_t": (False, True), "shared": (False, True), "backprop_ok": (False, True), "identity": (False, True),
+          "control_block": (False, True)}
 
 CASES = {
     # ------------------------------------------------------------------ one-layer (affine / tanh) fields
@@ -80,6 +81,8 @@ def _free(name):
     extra = () if matters else ("backprop_ok",)
     if row.kind == "affine" and row.method not in ("midpoint", "euler") and "identity" not in fields:
         extra += ("identity",)              # identity / tanh: the same row everywhere except under midpoint / euler
+    if row.wants_control and row.adjoint and row.params == "own" and row.method != "dopri5" and "control_block" not in fields:
+        extra += ("control_block",)         # which control tensors adjoint_params names only matters to the adaptive backward
     return tuple(free) + extra
 
 
