@@ -58,6 +58,8 @@ CASES = {
     "two_layer_dopri5":          (dict(_MLP, method="dopri5"), "mlp_dopri5_adjoint", ("narrow_control", "shared")),
     "two_layer_dopri5_times":    (dict(_MLP, method="dopri5", wants_t=True), "mlp_dopri5_adjoint", ("narrow_control",)),
     "two_layer_beyond_tiles":    (dict(_MLP, tiles_ok=False), "stepwise", ("narrow_control",)),
+    # 32 units x 16 channels (round 6): nothing to differentiate -> the forward kernels read the upper half from the raw tensors
+    "two_layer_rk4_forward_upper_half": (dict(_MLP, wants_grad=False, narrow_control=False), "mlp_rk4_forward", ()),
     "two_layer_dopri5_control":  (dict(_MLP, method="dopri5", wants_control=True, params="own"), "stepwise",
                                   ("narrow_control", "wants_t")),
     "two_layer_dopri5_control_block": (dict(_MLP, method="dopri5", wants_control=True, params="own", control_block=True),

@@ -146,10 +146,15 @@ def test_tanh_field_forward_on_mfma_tiles(native, H, C, degree):
 
 
 @pytest.mark.parametrize("H,C,width,degree,final_tanh", [(32, 8, 128, 3, True), (16, 4, 64, 1, True), (8, 3, 100, 3, False),
-                                                         (16, 14, 128, 3, True), (12, 16, 64, 1, False)])   # 16 x 16 tiles
+                                                         (16, 14, 128, 3, True), (12, 16, 64, 1, False),    # 16 x 16 tiles
+                                                         # 32 units x 16 channels (round 6): the upper unit groups from the raw tensors
+                                                         (32, 14, 128, 3, True), (20, 9, 64, 1, False), (32, 16, 128, 1, True)])
 def test_two_layer_field_forward_fused(native, H, C, width, degree, final_tanh):
     """Linear -> relu -> Linear -> tanh fields: the fused forward kernel (K2m) vs the float64 oracle and vs the
-    step-wise path running the user module itself."""
+    step-wise path running the user module itself.  The last three shapes: config 5 at hidden size 32 (14 logsignature
+    channels, reference example/logsignature_example.py:13-98 with a wider state) -- twice the 16 tiles of the kernels' LDS
+    images; unit groups 4..7 are read straight from the output layer's tensors (csrc/cde_mfma.h: MlpHi), in the shared-tile
+    form (this batch) and, bit for bit the same, with one wave per tile."""
     from torchcde_amd import fields
     B, L = 203, 24
     x = make_series(B, L, C, torch.float32, seed=61)
@@ -168,11 +173,21 @@ def test_two_layer_field_forward_fused(native, H, C, width, degree, final_tanh):
     assert found is not None and found.kind == "mlp2"
     with torch.no_grad():
         fused = native.cdeint(X, dfunc, z0.to(DEV), t_out.to(DEV), method="rk4", options=dict(step_size=1.0))
+        if H > 16 and C > 8:
+            _expect_dispatch("two_layer_rk4_forward_upper_half")
         stepwise = native.cdeint(X, dfunc, z0.to(DEV), t_out.to(DEV), method="rk4", options=dict(step_size=1.0),
                                  variant="generic")
     _close(fused, ref, 1e-4, 5e-6)
     _close(fused, stepwise, 1e-4, 5e-6)
     assert not torch.equal(fused, stepwise)          # two different code paths did run
+    if H > 16 and C > 8:
+        with torch.no_grad():
+            native.set_option("k2m_no_split", 1)
+            try:
+                one_wave = native.cdeint(X, dfunc, z0.to(DEV), t_out.to(DEV), method="rk4", options=dict(step_size=1.0))
+            finally:
+                native.set_option("k2m_no_split", 0)
+        assert torch.equal(one_wave, fused)
     # the reference's default method: adaptive dopri5 (fused attempt kernel vs the host-driven controller vs float64)
     from torchcde_amd.cdeint import last_dopri5_stats
     kw = dict(method="dopri5", options=dict(jump_t=X.grid_points)) if degree == 1 else {}

@@ -707,11 +707,24 @@ class _FusedMlpRK4(torch.autograd.Function):
                 gw2 if need[3] else None, gb2 if need[4] else None, None, None, grad_t, grad_knots) + control_grads
 
 
+def _mlp_upper_half(H, C):
+    """32 hidden units x 16 channels (config 5 at hidden size 32: 14 logsignature channels): twice the 16 tiles -- the kernels
+    read the upper unit groups straight from the output layer's tensors (csrc/cde_mfma.h: MlpHi)."""
+    return 16 < H <= 32 and 8 < C <= 16
+
+
+# which requests of the 32 x 16 shape the kernels take (the rest of that shape is solved step-wise)
+_UPPER_HALF_PATHS = {"mlp_rk4_forward", "mlp_dopri5_forward"}
+
+
 def _mlp_fusable(field, H, C, z0, packed):
     w1, w2 = field.hidden.weight, field.output.weight
-    # tiles of the two-layer kernels: 32 hidden units x 8 channels, or 16 x 16 (cde_mi355x.h: cde_rk4_forward_mlp)
+    # tiles of the two-layer kernels: 32 hidden units x 8 channels, or 16 x 16 (cde_mi355x.h: cde_rk4_forward_mlp); 32 x 16 with
+    # the upper half read from the raw tensors (16-byte rows: width a multiple of 4, an aligned contiguous weight)
+    upper = (_mlp_upper_half(H, C) and w1.size(0) % 4 == 0 and w2.is_contiguous() and w2.data_ptr() % 16 == 0
+             and field.output.bias.is_contiguous())
     return (z0.dtype == packed.dtype == w1.dtype == w2.dtype == torch.float32
-            and ((H <= 32 and C <= 8) or (H <= 16 and C <= 16))
+            and ((H <= 32 and C <= 8) or (H <= 16 and C <= 16) or upper)
             and w1.size(0) <= 128 and tuple(w1.shape) == (w1.size(0), H) and tuple(w2.shape) == (H * C, w1.size(0)))
 
 
@@ -1663,6 +1676,10 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         # the probe recognised the formula but the shape / dtype is beyond the tiles: say so in the record and the warning
         request = request._replace(kind=recognised_kind, tiles_ok=False)
     choice = dispatch.select_path(request)
+    if mlp is not None and _mlp_upper_half(H, C) and choice.path not in _UPPER_HALF_PATHS and choice.path != dispatch.STEPWISE:
+        # 32 units x 16 channels: fused where the kernels read the upper half (see _UPPER_HALF_PATHS)
+        request = request._replace(tiles_ok=False)
+        choice = dispatch.select_path(request)
     dispatch.record(choice, request)
 
     if choice.path == dispatch.STEPWISE:

@@ -432,6 +432,12 @@ constexpr int W2M_FLOATS = 16 * 8 * 64 * 4;          // layer 2: 16 tiles x 8 gr
 constexpr int MLP16_LDS_FLOATS = W1M_FLOATS + B1M_FLOATS + W2M_FLOATS + BY_FLOATS;
 struct MlpDims { int H, C, width; };
 bool mlp_shape_ok(int64_t C, int64_t H, int64_t width);     // rk4_mfma.hip
+// 32 hidden units x 16 channels (round 6; config 5 at hidden size 32: 14 logsignature channels): twice the 16 tiles.  The LDS
+// images hold unit groups 0..3 as before; groups 4..7 (hidden units 16..31) are read straight from the caller's output-layer
+// tensors in global memory -- a lane's A operand of (row (h, c), hidden-layer columns 16 T1 + 4 kq .. + 3) is four consecutive
+// floats of W2's row (h, c), so no second image is needed (width a multiple of 4, the tensor 16-byte aligned).
+bool mlp_shape_hi(int64_t C, int64_t H, int64_t width);     // rk4_mfma.hip
+struct MlpHi { const float* W2; const float* b2; int H, C, width; };      // W2 == nullptr: no upper half
 
 // value of the combined image [layer-1 weights | layer-1 bias | layer-2 weights | layer-2 bias] at flat index e
 __device__ __forceinline__ float mlp16_image(const float* __restrict__ W1, const float* __restrict__ b1,
@@ -474,8 +480,10 @@ __device__ __forceinline__ void stage_mlp16(const float* __restrict__ W1, const 
 template <int ACT, int CT = MC, bool SPLIT = false>
 __device__ __forceinline__ void field_mlp16(const float* img, int lane, int q, const f32x4& za, const f32x4& zb,
                                             const float (&dX)[CT], f32x4& fa, f32x4& fb, int pw = 0, float* xwin = nullptr,
-                                            float* xu = nullptr) {
+                                            float* xu = nullptr, MlpHi hi = MlpHi{nullptr, nullptr, 0, 0, 0}) {
   constexpr int NB = CT / 4, NP = 16 / NB;
+  constexpr int NPX = CT == 16 ? 8 : NP;          // 16-channel layout: unit groups 4..7 exist when `hi` names the raw tensors
+  const bool has_hi = CT == 16 && hi.W2 != nullptr;
   if constexpr (SPLIT && CT == MC) {
     // Eight waves, 8-channel tiles (round 4): layer 1 is split as well -- wave pw computes hidden-layer tile pw (8 MFMAs
     // instead of 64 redundant ones), the 8 x 16 units meet in `xu` (8 KB of LDS, one barrier) and are read from there as
@@ -555,19 +563,36 @@ __device__ __forceinline__ void field_mlp16(const float* img, int lane, int q, c
   fa = f32x4{0.f, 0.f, 0.f, 0.f};
   fb = fa;
 #pragma unroll
-  for (int P = 0; P < NP; ++P) {
+  for (int P = 0; P < NPX; ++P) {
     if (SPLIT && P != pw) continue;                          // (wave-uniform: another wave's unit group)
+    if (P >= NP && !has_hi) continue;                        // (uniform: no upper half)
     f32x4 y[NB];
+    const float* hrow[NB];                                   // upper half: this lane's row (h, c) of W2, at its column 4 kq
+    bool hrow_ok[NB];
 #pragma unroll
     for (int tb = 0; tb < NB; ++tb) {
-      const float4 c0 = bb2[4 * (NB * P + tb)];
-      y[tb] = f32x4{c0.x, c0.y, c0.z, c0.w};
+      if (P < NP) {
+        const float4 c0 = bb2[4 * (NB * P + tb)];
+        y[tb] = f32x4{c0.x, c0.y, c0.z, c0.w};
+        hrow[tb] = nullptr; hrow_ok[tb] = false;
+      } else {
+        const int hb = 4 * P + q;                            // bias of the lane's own D rows: (h = 4P + q, c = 4 tb + r)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[tb][r] = (hb < hi.H && 4 * tb + r < hi.C) ? hi.b2[hb * hi.C + 4 * tb + r] : 0.f;
+        const int i = lane & 15, h = 4 * P + (i >> 2), c = 4 * tb + (i & 3);
+        hrow_ok[tb] = h < hi.H && c < hi.C;
+        hrow[tb] = hi.W2 + (int64_t)(hrow_ok[tb] ? h * hi.C + c : 0) * hi.width + 4 * (lane >> 4);
+      }
     }
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
       float4 a[NB];
 #pragma unroll
-      for (int tb = 0; tb < NB; ++tb) a[tb] = w2[(8 * (NB * P + tb) + g) * 64];    // tile NB*P + tb: groups 8T .. 8T+7
+      for (int tb = 0; tb < NB; ++tb) {
+        if (P < NP) a[tb] = w2[(8 * (NB * P + tb) + g) * 64];                      // tile NB*P + tb: groups 8T .. 8T+7
+        else a[tb] = (hrow_ok[tb] && 16 * g + 4 * (lane >> 4) < hi.width) ? *reinterpret_cast<const float4*>(hrow[tb] + 16 * g)
+                                                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
       // the NB accumulator chains alternate, so no MFMA waits for its own predecessor
 #pragma unroll
       for (int tb = 0; tb < NB; ++tb) y[tb] = mfma16(a[tb].x, u[4 * g], y[tb]);
@@ -591,14 +616,18 @@ __device__ __forceinline__ void field_mlp16(const float* img, int lane, int q, c
     __builtin_amdgcn_sched_barrier(0);
   }
   if constexpr (SPLIT) {
-    // wave P holds f of unit group P (waves beyond NP hold nothing): everybody collects all of them
+    // wave P holds f of unit group P (waves beyond the last group hold nothing): everybody collects all of them
     float mine = 0.f;
 #pragma unroll
-    for (int P = 0; P < NP; ++P) if (P == pw) mine = P < 4 ? fa[P] : fb[P - 4];
+    for (int P = 0; P < NPX; ++P) if (P == pw) mine = P < 4 ? fa[P] : fb[P - 4];
     xwin[pw * 64 + lane] = mine;
     __syncthreads();
 #pragma unroll
-    for (int P = 0; P < NP; ++P) { const float v = xwin[P * 64 + lane]; if (P < 4) fa[P] = v; else fb[P - 4] = v; }
+    for (int P = 0; P < NPX; ++P) {
+      if (P >= NP && !has_hi) continue;
+      const float v = xwin[P * 64 + lane];
+      if (P < 4) fa[P] = v; else fb[P - 4] = v;
+    }
     __syncthreads();
   }
 }

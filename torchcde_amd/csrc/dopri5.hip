@@ -417,6 +417,9 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   float4 wA[PRODUCT ? W16_GROUPS : 1], wB[PRODUCT ? W16_GROUPS : 1];
   const Dims dims{(int)g.H, (int)g.C};
   const int Hr = dims.H;
+  // two-layer field with more than 16 hidden units on the 16-channel layout: unit groups 4..7 from the raw output layer
+  const MlpHi mlp_hi = (MLP && CT == 16 && dims.H > 16) ? MlpHi{(const float*)g.W, (const float*)g.bias, dims.H, dims.C, g.width}
+                                                        : MlpHi{nullptr, nullptr, 0, 0, 0};
   double* red = reinterpret_cast<double*>(lds);                    // 2 * 512 doubles
   // The knot search of every stage time is a chain of dependent loads: from global memory that is ~7 x 0.3 us per
   // stage (it dominated this kernel); the knots are copied to LDS once per launch instead.
@@ -542,7 +545,7 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   const float4* wy = reinterpret_cast<const float4*>(img_lds) + lane;
   const float4* by = reinterpret_cast<const float4*>(img_lds + WY_FLOATS) + q;
   auto field = [&](const f32x4& za, const f32x4& zb, const float (&dXv)[CT], f32x4& fa, f32x4& fb) {
-    if constexpr (MLP) field_mlp16<ACT, CT, SPLIT>(img_lds, lane, q, za, zb, dXv, fa, fb, wave, xwin, reinterpret_cast<float*>(red));
+    if constexpr (MLP) field_mlp16<ACT, CT, SPLIT>(img_lds, lane, q, za, zb, dXv, fa, fb, wave, xwin, reinterpret_cast<float*>(red), mlp_hi);
     else if constexpr (CT == MC) {
       if constexpr (PRODUCT && SPLIT) field16_split(sg0, sg1, sh0, sh1, sba, sbb, za, zb, dXv, q, fa, fb, wave, xwin, lane);
       else if constexpr (PRODUCT) field16(wA, wB, za, zb, dXv, q, fa, fb);
@@ -1115,7 +1118,8 @@ static int dopri5_advance_impl(const void* coeffs, const void* knots, int64_t n_
   const bool mlp = W1 != nullptr;
   if (B < 1 || C < 1 || H < 1 || H > 256 || n_intervals < 1 || n_out < 1 || n_launches < 0 || n_jump < 0) return CDE_ERR_SHAPE;
   if (mlp && (width < 1 || !bias1)) return width < 1 ? CDE_ERR_SHAPE : CDE_ERR_NULL;
-  if (mlp && (dtype != CDE_F32 || !cde::mlp_shape_ok(C, H, width) || variant == CDE_VARIANT_GENERIC))
+  const bool mlp_upper = mlp && cde::mlp_shape_hi(C, H, width) && ((uintptr_t)W & 15) == 0;     // 32 units x 16 channels (cde_mfma.h: MlpHi)
+  if (mlp && (dtype != CDE_F32 || !(cde::mlp_shape_ok(C, H, width) || mlp_upper) || variant == CDE_VARIANT_GENERIC))
     return CDE_ERR_UNSUPPORTED;
   if (act != CDE_ACT_NONE && act != CDE_ACT_TANH) return CDE_ERR_UNSUPPORTED;
   if (degree != CDE_PATH_CUBIC && degree != CDE_PATH_LINEAR) return CDE_ERR_UNSUPPORTED;

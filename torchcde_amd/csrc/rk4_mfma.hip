@@ -101,6 +101,8 @@ __global__ __launch_bounds__((fwd_block_threads<ACT, MLP>()), (fwd_waves_per_sim
   const bool valid = in_range && (!SPLIT || wave == 0);           // who writes (every wave of a split tile LOADS its series)
   const int64_t sc = in_range ? series : B - 1;
   float* xwin = lds + MLP16_LDS_FLOATS;                           // (SPLIT only: 8 x 64 floats behind the images)
+  // two-layer field with more than 16 hidden units on the 16-channel layout: unit groups 4..7 from the raw output layer
+  const MlpHi mlp_hi = (MLP && CT == 16 && dims.H > 16) ? MlpHi{W, bias, dims.H, dims.C, width} : MlpHi{nullptr, nullptr, 0, 0, 0};
 
   // this lane's 8 hidden units in two groups of 4 (zero beyond the real hidden size)
   const int ua = PRODUCT ? 8 * q : q, ub = PRODUCT ? 8 * q + 4 : 16 + q;
@@ -161,7 +163,7 @@ __global__ __launch_bounds__((fwd_block_threads<ACT, MLP>()), (fwd_waves_per_sim
 
       f32x4 fa, fb;
       if constexpr (PRODUCT) { if constexpr (CT == MC) field16(wA, wB, za, zb, dX, q, fa, fb); }
-      else if constexpr (MLP) field_mlp16<ACT, CT, SPLIT>(lds, lane, q, za, zb, dX, fa, fb, wave, xwin, xwin + 8 * 64);
+      else if constexpr (MLP) field_mlp16<ACT, CT, SPLIT>(lds, lane, q, za, zb, dX, fa, fb, wave, xwin, xwin + 8 * 64, mlp_hi);
       else { if constexpr (CT == MC) field_act16<ACT>(wy, by, za, zb, dX, fa, fb); }
       if constexpr (!PRODUCT) {
         __builtin_amdgcn_sched_barrier(0);
@@ -1134,6 +1136,10 @@ __global__ __launch_bounds__(256) void reduce_mfma_partials(const float* __restr
 bool mlp_shape_ok(int64_t C, int64_t H, int64_t width) {
   return width >= 1 && width <= MW && H >= 1 && C >= 1 && ((C <= MC && H <= MH) || (C <= 16 && H <= 16));
 }
+// ... and 32 units x 16 channels (cde_mfma.h: MlpHi): the kernels that take the upper half from the raw tensors
+bool mlp_shape_hi(int64_t C, int64_t H, int64_t width) {
+  return width >= 4 && width <= MW && (width & 3) == 0 && C > MC && C <= 16 && H > 16 && H <= MH;
+}
 
 int launch_reduce_partials(const float* partial, int64_t n_tiles, void* grad_W, void* grad_b, int H, int C, hipStream_t s) {
   // (`partial` is the caller's scratch: pass 1 overwrites the first tile of every group with the group's sum)
@@ -1183,13 +1189,15 @@ int launch_forward_mlp(const void* coeffs, const void* knots, int64_t n_interval
                        const void* bias1, int64_t width, const void* W2, const void* bias2, int act, const void* z0,
                        const void* grid, int64_t n_grid, const void* t_out, int64_t n_out, void* z_out, int64_t B,
                        int64_t C, int64_t H, const int64_t* stage_index, const void* stage_frac, hipStream_t s) {
-  if (!mlp_shape_ok(C, H, width)) return CDE_ERR_UNSUPPORTED;
+  // (32 units x 16 channels: the upper unit groups straight from W2 / bias2 -- 16-byte rows)
+  const bool upper = mlp_shape_hi(C, H, width) && ((uintptr_t)W2 & 15) == 0;
+  if (!mlp_shape_ok(C, H, width) && !upper) return CDE_ERR_UNSUPPORTED;
   if (degree != CDE_PATH_CUBIC && degree != CDE_PATH_LINEAR) return CDE_ERR_UNSUPPORTED;
   if (act != CDE_ACT_NONE && act != CDE_ACT_TANH) return CDE_ERR_UNSUPPORTED;
   const Dims dims{(int)H, (int)C};
   const unsigned blocks = (unsigned)((B + 127) / 128);
   const size_t lds = (size_t)MLP16_LDS_FLOATS * sizeof(float);
-  const bool wide = C > MC;                 // 16 channels x 16 hidden units on the same 16 tiles
+  const bool wide = C > MC;                 // 16 channels x 16 (or, `upper`, 32) hidden units on the same 16 tiles
   // up to 768 tiles (three rounds of one workgroup per CU still beat 8 tiles per workgroup on a quarter of the CUs): the 8
   // waves of a workgroup share a tile (K2m's split form)
   const int64_t tiles = (B + 15) / 16;
