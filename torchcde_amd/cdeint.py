@@ -428,6 +428,15 @@ class _Plan:
         return grad_z0, grad_w, grad_b, grad_x
 
 
+def _output_layer_gradients(acc2, H, C, width):
+    """(dL/dW2, dL/db2) from the reduced images: (halves, 256, 132), rows = the padded (hidden unit, channel) layout of the G2
+    rows -- 32 units x 8 channels, or 16 x 16 per half (two halves: hidden units 0..15 and 16..31) -- bias in column 128."""
+    units, channels = (32, 8) if C <= 8 else (16, 16)
+    w = acc2[:, :, :width].reshape(acc2.size(0) * units, channels, width)[:H, :C].reshape(H * C, width)
+    b = acc2[:, :, 128].reshape(acc2.size(0) * units, channels)[:H, :C].reshape(H * C)
+    return w, b
+
+
 class _MlpPlan:
     """Fused RK4 solves for the two-layer field: forward (K2m, cde_rk4_forward_mlp) and continuous-adjoint backward
     (K3m sweep + two library GEMMs, cde_rk4_adjoint_mlp_*)."""
@@ -490,7 +499,9 @@ class _MlpPlan:
         # .contiguous() would hand the kernel the caller's own output / gradient tensors
         y = z_saved[:, -1].clone(memory_format=torch.contiguous_format)
         a = grad_out[:, -1].to(torch.float32).clone(memory_format=torch.contiguous_format)
-        acc2 = torch.zeros(256, 132, dtype=torch.float32, device=dev)
+        upper = _mlp_upper_half(H, C)     # 32 units x 16 channels: the sweep leaves the upper unit groups' dL/dY2 rows BEHIND
+        halves = 2 if upper else 1        # the lower groups' in G2 (rows n .. 2n - 1); each half is reduced into its own image
+        acc2 = torch.zeros(halves, 256, 132, dtype=torch.float32, device=dev)
         acc1 = torch.zeros(128, 36, dtype=torch.float32, device=dev)
         grad_x = torch.zeros_like(self.coeffs) if want_control else None     # accumulated by the sweep launches
         if g.n_sgrid > 1:
@@ -498,7 +509,7 @@ class _MlpPlan:
                 _lib.ptr(self.knots), self.n_intervals, _lib.ptr(g.sgrid), g.n_sgrid, _lib.ptr(w1), _lib.ptr(b1), width,
                 _lib.ptr(w2), _lib.ptr(b2), C, H, f32, tdt, _lib.ptr(workspace), nbytes, stream),
                 "cde_rk4_adjoint_mlp_prepare")
-            row_bytes = (132 + 256 + 128 + 36) * 4
+            row_bytes = (132 + 256 * halves + 128 + 36) * 4
             longest = max(g.seg_off_host[p + 1] - 1 - g.seg_off_host[p] for p in range(self.n_out - 1))
             chunk = max(1, min(longest, self.scratch_budget // (row_bytes * 4 * B)))
             rows = chunk * 4 * B
@@ -506,7 +517,7 @@ class _MlpPlan:
             U[:, 128] = 1
             Z = torch.zeros(rows, 36, dtype=torch.float32, device=dev)
             Z[:, 32] = 1
-            G2 = torch.empty(rows, 256, dtype=torch.float32, device=dev)
+            G2 = torch.empty(halves * rows, 256, dtype=torch.float32, device=dev)
             G1 = torch.empty(rows, 128, dtype=torch.float32, device=dev)
             reduce_ws = torch.empty(lib.cde_mlp_grad_reduce_workspace_bytes(), dtype=torch.uint8, device=dev)
         for p in range(self.n_out - 1):
@@ -519,17 +530,16 @@ class _MlpPlan:
                     _lib.ptr(Z), _lib.ptr(grad_x), B, C, H, f32, tdt, _lib.ptr(workspace), nbytes, stream),
                     "cde_rk4_adjoint_mlp_sweep")
                 n = 4 * (ke - k) * B
-                _lib.check(lib.cde_mlp_grad_reduce(_lib.ptr(G2), _lib.ptr(U), n, 2, _lib.ptr(acc2), _lib.ptr(reduce_ws),
-                                                   reduce_ws.numel(), stream), "cde_mlp_grad_reduce")
+                for half in range(halves):
+                    _lib.check(lib.cde_mlp_grad_reduce(_lib.ptr(G2[half * n:]), _lib.ptr(U), n, 2, _lib.ptr(acc2[half]),
+                                                       _lib.ptr(reduce_ws), reduce_ws.numel(), stream), "cde_mlp_grad_reduce")
                 _lib.check(lib.cde_mlp_grad_reduce(_lib.ptr(G1), _lib.ptr(Z), n, 1, _lib.ptr(acc1), _lib.ptr(reduce_ws),
                                                    reduce_ws.numel(), stream), "cde_mlp_grad_reduce")
                 k = ke
             i_out = self.n_out - 1 - p
             y.copy_(z_saved[:, i_out - 1])                 # torchdiffeq: re-seed z from the stored forward solution
             a += grad_out[:, i_out - 1]                    # and add the incoming gradient at that output time
-        units, channels = (32, 8) if C <= 8 else (16, 16)        # padded (hidden unit, channel) layout of the G2 rows
-        grad_w2 = acc2[:, :width].reshape(units, channels, width)[:H, :C].reshape(H * C, width)
-        grad_b2 = acc2[:, 128].reshape(units, channels)[:H, :C].reshape(H * C)
+        grad_w2, grad_b2 = _output_layer_gradients(acc2, H, C, width)
         grad_w1 = acc1[:width, :H].contiguous()
         grad_b1 = acc1[:width, 32].contiguous()
         return a.reshape(*self.batch, H), grad_w1, grad_b1, grad_w2, grad_b2, grad_x
@@ -575,7 +585,9 @@ class _MlpPlan:
             for j, wgt in nodes[m]:
                 gy.add_(go[:, j], alpha=wgt)
         land(n_steps)
-        acc2 = torch.zeros(256, 132, dtype=torch.float32, device=dev)
+        upper = _mlp_upper_half(H, C)     # 32 units x 16 channels: the sweep leaves the upper unit groups' dL/dY2 rows BEHIND
+        halves = 2 if upper else 1        # the lower groups' in G2 (rows n .. 2n - 1); each half is reduced into its own image
+        acc2 = torch.zeros(halves, 256, 132, dtype=torch.float32, device=dev)
         acc1 = torch.zeros(128, 36, dtype=torch.float32, device=dev)
         grad_x = torch.zeros_like(self.coeffs) if want_control else None     # accumulated by the sweep launches
         if n_steps > 0:
@@ -587,14 +599,14 @@ class _MlpPlan:
                 _lib.ptr(self.knots), self.n_intervals, _lib.ptr(g.grid), n_grid, _lib.ptr(w1), _lib.ptr(b1), width,
                 _lib.ptr(w2), _lib.ptr(b2), C, H, f32, tdt, _lib.ptr(workspace), nbytes, stream),
                 "cde_rk4_backprop_mlp_prepare")
-            row_bytes = (132 + 256 + 128 + 36) * 4
+            row_bytes = (132 + 256 * halves + 128 + 36) * 4
             chunk = max(1, min(n_steps, self.scratch_budget // (row_bytes * 4 * B)))
             rows = chunk * 4 * B
             U = torch.zeros(rows, 132, dtype=torch.float32, device=dev)
             U[:, 128] = 1
             Z = torch.zeros(rows, 36, dtype=torch.float32, device=dev)
             Z[:, 32] = 1
-            G2 = torch.empty(rows, 256, dtype=torch.float32, device=dev)
+            G2 = torch.empty(halves * rows, 256, dtype=torch.float32, device=dev)
             G1 = torch.empty(rows, 128, dtype=torch.float32, device=dev)
             reduce_ws = torch.empty(lib.cde_mlp_grad_reduce_workspace_bytes(), dtype=torch.uint8, device=dev)
             k_hi = n_steps
@@ -616,17 +628,16 @@ class _MlpPlan:
                         _lib.ptr(gy), _lib.ptr(g.grid), n_grid, k_lo, k_hi, _lib.ptr(U), _lib.ptr(G2), _lib.ptr(G1),
                         _lib.ptr(Z), B, C, H, f32, tdt, _lib.ptr(workspace), nbytes, stream), "cde_rk4_backprop_mlp_sweep")
                 n = 4 * (k_hi - k_lo) * B
-                _lib.check(lib.cde_mlp_grad_reduce(_lib.ptr(G2), _lib.ptr(U), n, 2, _lib.ptr(acc2), _lib.ptr(reduce_ws),
-                                                   reduce_ws.numel(), stream), "cde_mlp_grad_reduce")
+                for half in range(halves):
+                    _lib.check(lib.cde_mlp_grad_reduce(_lib.ptr(G2[half * n:]), _lib.ptr(U), n, 2, _lib.ptr(acc2[half]),
+                                                       _lib.ptr(reduce_ws), reduce_ws.numel(), stream), "cde_mlp_grad_reduce")
                 _lib.check(lib.cde_mlp_grad_reduce(_lib.ptr(G1), _lib.ptr(Z), n, 1, _lib.ptr(acc1), _lib.ptr(reduce_ws),
                                                    reduce_ws.numel(), stream), "cde_mlp_grad_reduce")
                 land(k_lo)
                 k_hi = k_lo
         else:
             pass                                                    # a single output time: node 0 is node n_steps, landed above
-        units, channels = (32, 8) if C <= 8 else (16, 16)        # padded (hidden unit, channel) layout of the G2 rows
-        grad_w2 = acc2[:, :width].reshape(units, channels, width)[:H, :C].reshape(H * C, width)
-        grad_b2 = acc2[:, 128].reshape(units, channels)[:H, :C].reshape(H * C)
+        grad_w2, grad_b2 = _output_layer_gradients(acc2, H, C, width)
         grad_w1 = acc1[:width, :H].contiguous()
         grad_b1 = acc1[:width, 32].contiguous()
         return gy.reshape(*self.batch, H), grad_w1, grad_b1, grad_w2, grad_b2, grad_x
@@ -714,7 +725,7 @@ def _mlp_upper_half(H, C):
 
 
 # which requests of the 32 x 16 shape the kernels take (the rest of that shape is solved step-wise)
-_UPPER_HALF_PATHS = {"mlp_rk4_forward", "mlp_dopri5_forward"}
+_UPPER_HALF_PATHS = {"mlp_rk4_forward", "mlp_dopri5_forward", "mlp_rk4_adjoint", "mlp_rk4_backprop"}
 
 
 def _mlp_fusable(field, H, C, z0, packed):

@@ -42,6 +42,7 @@ int launch_adjoint_split(const void*, const void*, int64_t, int, const void*, co
                          int64_t, const int64_t*, const void*, float*, hipStream_t);
 
 bool mlp_shape_ok(int64_t C, int64_t H, int64_t width);        // rk4_mfma.hip
+bool mlp_shape_upper(int64_t C, int64_t H, int64_t width);     // rk4_mfma.hip
 
 // from rk4_wide.hip: affine fields with H <= 64, C <= 8 or H <= 32, C <= 16
 bool wide_applicable(int64_t C, int64_t H, int dtype, int act);
@@ -574,7 +575,7 @@ extern "C" int cde_rk4_adjoint_mlp_prepare(const void* knots, int64_t n_interval
                                            void* workspace, size_t workspace_bytes, void* stream) {
   if (C < 1 || H < 1 || width < 1 || n_intervals < 1 || n_sgrid < 0) return CDE_ERR_SHAPE;
   if (dtype != CDE_F32) return dtype == CDE_F64 ? CDE_ERR_UNSUPPORTED : CDE_ERR_DTYPE;
-  if (!cde::mlp_shape_ok(C, H, width)) return CDE_ERR_UNSUPPORTED;
+  if (!cde::mlp_shape_ok(C, H, width) && !cde::mlp_shape_upper(C, H, width)) return CDE_ERR_UNSUPPORTED;
   if (!knots || !W1 || !bias1 || !W2 || !bias2 || !workspace || (n_sgrid > 1 && !sgrid)) return CDE_ERR_NULL;
   if (workspace_bytes < cde_rk4_adjoint_mlp_workspace_bytes(n_sgrid)) return CDE_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
@@ -627,7 +628,7 @@ extern "C" int cde_rk4_backprop_mlp_prepare(const void* knots, int64_t n_interva
                                             void* workspace, size_t workspace_bytes, void* stream) {
   if (C < 1 || H < 1 || width < 1 || n_intervals < 1 || n_grid < 0) return CDE_ERR_SHAPE;
   if (dtype != CDE_F32) return dtype == CDE_F64 ? CDE_ERR_UNSUPPORTED : CDE_ERR_DTYPE;
-  if (!cde::mlp_shape_ok(C, H, width)) return CDE_ERR_UNSUPPORTED;
+  if (!cde::mlp_shape_ok(C, H, width) && !cde::mlp_shape_upper(C, H, width)) return CDE_ERR_UNSUPPORTED;
   if (!knots || !W1 || !bias1 || !W2 || !bias2 || !workspace || (n_grid > 1 && !grid)) return CDE_ERR_NULL;
   if (workspace_bytes < cde_rk4_adjoint_mlp_workspace_bytes(n_grid)) return CDE_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
@@ -653,7 +654,7 @@ static int rk4_backprop_mlp_sweep_impl(const void* coeffs, const void* knots, in
                                           size_t workspace_bytes, void* stream) {
   if (B < 1 || C < 1 || H < 1 || n_intervals < 1 || k_begin < 0 || k_end < k_begin || k_end > n_grid - 1) return CDE_ERR_SHAPE;
   if (dtype != CDE_F32) return dtype == CDE_F64 ? CDE_ERR_UNSUPPORTED : CDE_ERR_DTYPE;
-  if (!cde::mlp_shape_ok(C, H, 1)) return CDE_ERR_UNSUPPORTED;
+  if (!cde::mlp_shape_ok(C, H, 1) && !cde::mlp_shape_upper(C, H, 1)) return CDE_ERR_UNSUPPORTED;
   if (!coeffs || !knots || !stages || !g_state || !grid || !U || !G2 || !G1 || !Z || !workspace) return CDE_ERR_NULL;
   if (workspace_bytes < cde_rk4_adjoint_mlp_workspace_bytes(n_grid)) return CDE_ERR_WORKSPACE;
   const int64_t n_steps = n_grid - 1;
@@ -700,7 +701,7 @@ extern "C" int cde_rk4_adjoint_mlp_sweep(const void* coeffs, const void* knots, 
                                          const void* workspace, size_t workspace_bytes, void* stream) {
   if (B < 1 || C < 1 || H < 1 || n_intervals < 1 || k_begin < 0 || k_end < k_begin || k_end > n_sgrid - 1) return CDE_ERR_SHAPE;
   if (dtype != CDE_F32) return dtype == CDE_F64 ? CDE_ERR_UNSUPPORTED : CDE_ERR_DTYPE;
-  if (!cde::mlp_shape_ok(C, H, 1)) return CDE_ERR_UNSUPPORTED;
+  if (!cde::mlp_shape_ok(C, H, 1) && !cde::mlp_shape_upper(C, H, 1)) return CDE_ERR_UNSUPPORTED;
   if (!coeffs || !knots || !y_state || !a_state || !sgrid || !U || !G2 || !G1 || !Z || !workspace) return CDE_ERR_NULL;
   if (workspace_bytes < cde_rk4_adjoint_mlp_workspace_bytes(n_sgrid)) return CDE_ERR_WORKSPACE;
   const int64_t n_steps = n_sgrid - 1;

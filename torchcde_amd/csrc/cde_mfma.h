@@ -437,7 +437,10 @@ bool mlp_shape_ok(int64_t C, int64_t H, int64_t width);     // rk4_mfma.hip
 // tensors in global memory -- a lane's A operand of (row (h, c), hidden-layer columns 16 T1 + 4 kq .. + 3) is four consecutive
 // floats of W2's row (h, c), so no second image is needed (width a multiple of 4, the tensor 16-byte aligned).
 bool mlp_shape_hi(int64_t C, int64_t H, int64_t width);     // rk4_mfma.hip
-struct MlpHi { const float* W2; const float* b2; int H, C, width; };      // W2 == nullptr: no upper half
+bool mlp_shape_upper(int64_t C, int64_t H, int64_t width);  // rk4_mfma.hip: the same shape for the sweeps (padded copy: any width)
+struct MlpHi { const float* W2; const float* b2; int H, C, width; int h0 = 0; };   // W2 == nullptr: no upper half; the rows of
+                                                                                   // hidden unit h start at W2 + (h - h0) C width
+                                                                                   // (h0 = 16: a copy of the upper rows only)
 
 // value of the combined image [layer-1 weights | layer-1 bias | layer-2 weights | layer-2 bias] at flat index e
 __device__ __forceinline__ float mlp16_image(const float* __restrict__ W1, const float* __restrict__ b1,
@@ -480,7 +483,7 @@ __device__ __forceinline__ void stage_mlp16(const float* __restrict__ W1, const 
 template <int ACT, int CT = MC, bool SPLIT = false>
 __device__ __forceinline__ void field_mlp16(const float* img, int lane, int q, const f32x4& za, const f32x4& zb,
                                             const float (&dX)[CT], f32x4& fa, f32x4& fb, int pw = 0, float* xwin = nullptr,
-                                            float* xu = nullptr, MlpHi hi = MlpHi{nullptr, nullptr, 0, 0, 0}) {
+                                            float* xu = nullptr, MlpHi hi = MlpHi{}) {
   constexpr int NB = CT / 4, NP = 16 / NB;
   constexpr int NPX = CT == 16 ? 8 : NP;          // 16-channel layout: unit groups 4..7 exist when `hi` names the raw tensors
   const bool has_hi = CT == 16 && hi.W2 != nullptr;
@@ -578,10 +581,10 @@ __device__ __forceinline__ void field_mlp16(const float* img, int lane, int q, c
       } else {
         const int hb = 4 * P + q;                            // bias of the lane's own D rows: (h = 4P + q, c = 4 tb + r)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) y[tb][r] = (hb < hi.H && 4 * tb + r < hi.C) ? hi.b2[hb * hi.C + 4 * tb + r] : 0.f;
+        for (int r = 0; r < 4; ++r) y[tb][r] = (hb < hi.H && 4 * tb + r < hi.C) ? hi.b2[(hb - hi.h0) * hi.C + 4 * tb + r] : 0.f;
         const int i = lane & 15, h = 4 * P + (i >> 2), c = 4 * tb + (i & 3);
         hrow_ok[tb] = h < hi.H && c < hi.C;
-        hrow[tb] = hi.W2 + (int64_t)(hrow_ok[tb] ? h * hi.C + c : 0) * hi.width + 4 * (lane >> 4);
+        hrow[tb] = hi.W2 + (int64_t)(hrow_ok[tb] ? (h - hi.h0) * hi.C + c : 0) * hi.width + 4 * (lane >> 4);
       }
     }
 #pragma unroll

@@ -11,6 +11,16 @@ constexpr int W2P_FLOATS = 256 * W2P_STRIDE;
 constexpr int W1T_FLOATS = 2 * 8 * 64 * 4;                // [tile][T1][lane][4]
 constexpr int ADJ_LDS_FLOATS = W1M_FLOATS + B1M_FLOATS + W2P_FLOATS + BY_FLOATS;   // [W1 image | b1 | W2 plain | b2]
 constexpr int MLP_ADJ_IMAGE_FLOATS = ADJ_LDS_FLOATS + W1T_FLOATS;
+// 32 hidden units x 16 channels (round 6): behind the images, a zero-padded plain copy of the output layer's UPPER rows --
+// hidden units 16..31 as [(h - 16) * 16 + c][128] (and their biases, [(h - 16) * 16 + c]) -- which the sweeps read from
+// global memory / L2 for unit groups 4..7 (cde_mfma.h: MlpHi with h0 = 16): both access patterns of the plain LDS copy
+// (four consecutive columns of a row for Y2, one column of a row for gu) are plain loads from it.
+constexpr int MLP_ADJ_HI_BIAS_FLOATS = 256, MLP_ADJ_HI_W2_FLOATS = 256 * 128;
+constexpr int MLP_ADJ_IMAGE_HI_FLOATS = MLP_ADJ_IMAGE_FLOATS + MLP_ADJ_HI_BIAS_FLOATS + MLP_ADJ_HI_W2_FLOATS;
+__device__ __forceinline__ MlpHi mlp_adj_hi(const float* img, int H, int CT) {
+  if (CT != 16 || H <= 16) return MlpHi{};
+  return MlpHi{img + MLP_ADJ_IMAGE_FLOATS + MLP_ADJ_HI_BIAS_FLOATS, img + MLP_ADJ_IMAGE_FLOATS, 32, 16, 128, 16};
+}
 // h3 = h&3 enters bit-reversed so that the four lane quarters of a gu read are shifted by 0, 16, 8, 24 banks: the LDS
 // serves a b32 read in two half-waves (lanes 0-31 = quarters 0,1; lanes 32-63 = quarters 2,3) and each half must
 // cover 32 distinct banks.  (With shifts 0, 8, 16, 24 rocprofv3 counted 1.3e8 SQ_LDS_BANK_CONFLICT cycles per launch.)

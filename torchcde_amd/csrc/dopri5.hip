@@ -419,7 +419,7 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   const int Hr = dims.H;
   // two-layer field with more than 16 hidden units on the 16-channel layout: unit groups 4..7 from the raw output layer
   const MlpHi mlp_hi = (MLP && CT == 16 && dims.H > 16) ? MlpHi{(const float*)g.W, (const float*)g.bias, dims.H, dims.C, g.width}
-                                                        : MlpHi{nullptr, nullptr, 0, 0, 0};
+                                                        : MlpHi{};
   double* red = reinterpret_cast<double*>(lds);                    // 2 * 512 doubles
   // The knot search of every stage time is a chain of dependent loads: from global memory that is ~7 x 0.3 us per
   // stage (it dominated this kernel); the knots are copied to LDS once per launch instead.

@@ -102,7 +102,7 @@ __global__ __launch_bounds__((fwd_block_threads<ACT, MLP>()), (fwd_waves_per_sim
   const int64_t sc = in_range ? series : B - 1;
   float* xwin = lds + MLP16_LDS_FLOATS;                           // (SPLIT only: 8 x 64 floats behind the images)
   // two-layer field with more than 16 hidden units on the 16-channel layout: unit groups 4..7 from the raw output layer
-  const MlpHi mlp_hi = (MLP && CT == 16 && dims.H > 16) ? MlpHi{W, bias, dims.H, dims.C, width} : MlpHi{nullptr, nullptr, 0, 0, 0};
+  const MlpHi mlp_hi = (MLP && CT == 16 && dims.H > 16) ? MlpHi{W, bias, dims.H, dims.C, width} : MlpHi{};
 
   // this lane's 8 hidden units in two groups of 4 (zero beyond the real hidden size)
   const int ua = PRODUCT ? 8 * q : q, ub = PRODUCT ? 8 * q + 4 : 16 + q;
@@ -1140,6 +1140,10 @@ bool mlp_shape_ok(int64_t C, int64_t H, int64_t width) {
 bool mlp_shape_hi(int64_t C, int64_t H, int64_t width) {
   return width >= 4 && width <= MW && (width & 3) == 0 && C > MC && C <= 16 && H > 16 && H <= MH;
 }
+// ... and the sweeps, which read a zero-padded copy of the upper rows (cde_mlp_adj.h: mlp_adj_hi): any width
+bool mlp_shape_upper(int64_t C, int64_t H, int64_t width) {
+  return width >= 1 && width <= MW && C > MC && C <= 16 && H > 16 && H <= MH;
+}
 
 int launch_reduce_partials(const float* partial, int64_t n_tiles, void* grad_W, void* grad_b, int H, int C, hipStream_t s) {
   // (`partial` is the caller's scratch: pass 1 overwrites the first tile of every group with the group's sum)
@@ -1273,7 +1277,7 @@ int launch_forward_mlp_stages(const void* coeffs, const void* knots, int64_t n_i
                               const void* grid, int64_t n_grid, const void* t_out, int64_t n_out, void* z_out, void* stages,
                               int64_t B, int64_t C, int64_t H, const int64_t* stage_index, const void* stage_frac,
                               hipStream_t s) {
-  if (!mlp_shape_ok(C, H, width)) return CDE_ERR_UNSUPPORTED;
+  if (!mlp_shape_ok(C, H, width) && !(mlp_shape_hi(C, H, width) && ((uintptr_t)W2 & 15) == 0)) return CDE_ERR_UNSUPPORTED;
   if (degree != CDE_PATH_CUBIC && degree != CDE_PATH_LINEAR) return CDE_ERR_UNSUPPORTED;
   if (act != CDE_ACT_NONE && act != CDE_ACT_TANH) return CDE_ERR_UNSUPPORTED;
   const Dims dims{(int)H, (int)C};

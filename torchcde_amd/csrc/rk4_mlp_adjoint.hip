@@ -61,8 +61,20 @@ __device__ __forceinline__ float mlp_adj_image(const float* __restrict__ W1, con
 __global__ void mlp_adj_image_kernel(const float* __restrict__ W1, const float* __restrict__ b1,
                                      const float* __restrict__ W2, const float* __restrict__ b2,
                                      float* __restrict__ img, MlpDims d, int nb) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < MLP_ADJ_IMAGE_FLOATS) img[e] = mlp_adj_image(W1, b1, W2, b2, e, d, nb);
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < MLP_ADJ_IMAGE_FLOATS) { img[e] = mlp_adj_image(W1, b1, W2, b2, e, d, nb); return; }
+  if (e >= MLP_ADJ_IMAGE_HI_FLOATS) return;
+  // the zero-padded copy of the upper rows (hidden units 16..31 of the 16-channel layout; cde_mlp_adj.h: mlp_adj_hi)
+  const int at = e;
+  e -= MLP_ADJ_IMAGE_FLOATS;
+  if (e < MLP_ADJ_HI_BIAS_FLOATS) {
+    const int h = 16 + (e >> 4), c = e & 15;
+    img[at] = (h < d.H && c < d.C) ? b2[h * d.C + c] : 0.f;
+    return;
+  }
+  e -= MLP_ADJ_HI_BIAS_FLOATS;
+  const int row = e >> 7, col = e & 127, h = 16 + (row >> 4), c = row & 15;
+  img[at] = (h < d.H && c < d.C && col < d.width) ? W2[(h * d.C + c) * d.width + col] : 0.f;
 }
 
 // DCOEFF: also accumulate dL/d(control coefficients) into `grad_coeffs` (zeroed by the caller, layout of `coeffs`),
@@ -97,6 +109,13 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2) void rk4_adjoint_
   __syncthreads();
   constexpr int NB = CT / 4, NP = 16 / NB;      // channel blocks per unit group, unit groups (of 4 hidden units)
   constexpr int NJ = CT / 4;                    // control gradients: channels NJ q .. NJ q + NJ - 1 go to the coefficient row with quarter q
+  // 32 units x 16 channels (round 6): unit groups 4..7 from the zero-padded copy of the upper rows behind the images
+  constexpr int NPX = CT == 16 ? 8 : NP;
+  const MlpHi hi = mlp_adj_hi(img, dims.H, CT);
+  const bool has_hi = CT == 16 && hi.W2 != nullptr;
+  const int per_wave = has_hi ? 2 : NP / 4;     // SPLIT: unit groups per wave
+  // the upper groups' dL/dY2 rows go behind the lower groups' (the caller reduces the two halves separately)
+  float* G2hi = G2 + (int64_t)4 * (k_end - k_begin) * B * G2_COLS;
   static_assert(!(DCOEFF && CT != MC && SPLIT), "control gradients of the 16-channel layout: one wave per tile");
   const int Hr = dims.H, Cr = dims.C;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -234,15 +253,23 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2) void rk4_adjoint_
 #pragma unroll
       for (int c = 0; c < CT; ++c) gdx[c] = 0.f;
 #pragma unroll
-      for (int P = 0; P < NP; ++P) {                                 // unit group P: 4 hidden units x CT channels = NB tiles
-        if (SPLIT && P / (NP / 4) != pw) continue;                   // (wave-uniform: another wave's group)
+      for (int P = 0; P < NPX; ++P) {                                // unit group P: 4 hidden units x CT channels = NB tiles
+        if (SPLIT && P / per_wave != pw) continue;                   // (wave-uniform: another wave's group)
+        if (P >= NP && !has_hi) continue;                            // (uniform: no upper half)
         f32x4 y[NB];
         const float* tp_[NB];
 #pragma unroll
         for (int tb = 0; tb < NB; ++tb) {
-          const float4 c0 = bb2[4 * (NB * P + tb)];
-          y[tb] = f32x4{c0.x, c0.y, c0.z, c0.w};
-          tp_[tb] = w2y + 2 * (NB * P + tb) * 8 * W2P_STRIDE;        // tile T = NB*P + tb: physical rows (2T + hb)*8 + r8
+          if (P < NP) {
+            const float4 c0 = bb2[4 * (NB * P + tb)];
+            y[tb] = f32x4{c0.x, c0.y, c0.z, c0.w};
+            tp_[tb] = w2y + 2 * (NB * P + tb) * 8 * W2P_STRIDE;      // tile T = NB*P + tb: physical rows (2T + hb)*8 + r8
+          } else {
+            // upper half: the lane's D rows are (h = 4P + q, c = 4 tb + r); its A rows (h = 4P + (n >> 2), c = 4 tb + (n & 3))
+            const float4 c0 = *reinterpret_cast<const float4*>(hi.b2 + (4 * P + q - 16) * 16 + 4 * tb);
+            y[tb] = f32x4{c0.x, c0.y, c0.z, c0.w};
+            tp_[tb] = hi.W2 + ((4 * P + (n >> 2) - 16) * 16 + 4 * tb + (n & 3)) * 128 + 4 * q;
+          }
         }
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
@@ -276,14 +303,16 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2) void rk4_adjoint_
         }
         if (P < 4) fa[P] = f; else fb[P - 4] = f;
         if (SPLIT ? in_range : valid) {                              // (split: the rows of a unit group by the wave that owns it)
-          float* grow = G2 + out_row * G2_COLS + 4 * CT * P + CT * q;     // rows (h = 4P+q, c = 0..CT-1) of the padded layout
+          float* grow = (P < NP ? G2 + out_row * G2_COLS + 4 * CT * P : G2hi + out_row * G2_COLS + 4 * CT * (P - NP)) + CT * q;     // rows (h = 4P+q, c = 0..CT-1) of the padded layout
 #pragma unroll
           for (int c4 = 0; c4 < CT; c4 += 4)
             stream_store4(grow + c4, g2[c4] * wq, g2[c4 + 1] * wq, g2[c4 + 2] * wq, g2[c4 + 3] * wq);
         }
 #pragma unroll
         for (int c = 0; c < CT; ++c) {                               // K step (P, c); 8 independent accumulator chains
-          const float* rowp = w2g[c & 3] + 2 * (NB * P + (c >> 2)) * 8 * W2P_STRIDE;
+          // (upper half: row (h = 4P + q, c) of the padded copy, column 16 T1 + n)
+          const float* rowp = P < NP ? w2g[c & 3] + 2 * (NB * P + (c >> 2)) * 8 * W2P_STRIDE
+                                     : hi.W2 + ((4 * P + q - 16) * 16 + c) * 128 + n;
 #pragma unroll
           for (int T1 = 0; T1 < 8; ++T1) gu[T1] = mfma16(rowp[16 * T1], g2[c], gu[T1]);
         }
@@ -512,11 +541,11 @@ __global__ __launch_bounds__(512, 2) void rk4_adjoint_mlp_sweep_s8(
 }
 
 // ------------------------------------------------------------------------------------------ host side
-size_t mlp_adjoint_image_bytes() { return (size_t)MLP_ADJ_IMAGE_FLOATS * sizeof(float); }
+size_t mlp_adjoint_image_bytes() { return (size_t)MLP_ADJ_IMAGE_HI_FLOATS * sizeof(float); }
 
 int launch_mlp_adjoint_images(const void* W1, const void* b1, int64_t width, const void* W2, const void* b2, int64_t C,
                               int64_t H, float* img, hipStream_t s) {
-  mlp_adj_image_kernel<<<(MLP_ADJ_IMAGE_FLOATS + 255) / 256, 256, 0, s>>>(
+  mlp_adj_image_kernel<<<(MLP_ADJ_IMAGE_HI_FLOATS + 255) / 256, 256, 0, s>>>(
       (const float*)W1, (const float*)b1, (const float*)W2, (const float*)b2, img, MlpDims{(int)H, (int)C, (int)width},
       C > MC ? 4 : 2);                          // channel blocks per unit group: 32 units x 8 channels or 16 x 16
   return check_launch();
