@@ -950,7 +950,8 @@ def test_reference_backend_test_scenario_with_midpoint(native):
 
 @pytest.mark.parametrize("H,C,width,degree,final_tanh,chunk_bytes", [
     (32, 8, 128, 3, True, None), (32, 8, 128, 1, True, 3 * 4 * 203 * 552 * 4),   # (second: three steps per sweep launch)
-    (8, 14, 100, 3, True, None), (16, 16, 64, 1, False, None), (12, 5, 48, 3, False, 2 * 4 * 203 * 552 * 4)])
+    (8, 14, 100, 3, True, None), (16, 16, 64, 1, False, None), (12, 5, 48, 3, False, 2 * 4 * 203 * 552 * 4),
+    (32, 14, 128, 3, True, None), (24, 16, 64, 1, False, 2 * 4 * 203 * 808 * 4)])    # 32 units x 16 channels (round 6)
 def test_two_layer_backprop_mode_fused_against_autograd_through_the_oracle(native, H, C, width, degree, final_tanh, chunk_bytes):
     """cdeint(..., method='rk4', adjoint=False) with the examples' two-layer model (example/time_series_classification.py:
     20-51; README.md:103's "faster mode"): K2m stores every stage state, K3m's sweep runs as reverse mode through the steps
@@ -960,9 +961,10 @@ def test_two_layer_backprop_mode_fused_against_autograd_through_the_oracle(nativ
     import sys
     cdeint_mod = sys.modules["torchcde_amd.cdeint"]
     B, L = 203, 12
-    x = make_series(B, L, C, torch.float32, seed=71)
+    seed = 171 if H > 16 and C > 8 else 71         # (as above: a draw without a series on a relu kink in GPU float32)
+    x = make_series(B, L, C, torch.float32, seed=seed)
     coeffs = oracle_interp.hermite_bdiff_coeffs(x) if degree == 3 else x
-    gen = torch.Generator().manual_seed(72)
+    gen = torch.Generator().manual_seed(seed + 1)
     z0 = torch.randn(B, H, generator=gen)
     t_out = torch.tensor([0., 2.0, 4.5, 11.])
     lw = torch.rand(B, 4, H, generator=gen) + 0.5
