@@ -651,6 +651,11 @@ int cde_dopri5_adjoint_advance_dcontrol(const void* coeffs, const void* knots, i
 size_t cde_dopri5_adjoint_mlp_workspace_bytes(int64_t B, int64_t C, int64_t H);
 size_t cde_dopri5_adjoint_mlp_trace_offset(int64_t B, int64_t C, int64_t H, int which);
 size_t cde_dopri5_adjoint_mlp_gradient_offset(int64_t B, int64_t C, int64_t H);
+/* 16 < H <= 32 with 8 < C <= 16 (round 6; one GPU's batch, not the sharded protocol): the kernels run the hidden units 16..31 as
+ * a second 16 x 16 half -- their rows of the output layer from a zero-padded copy behind the weight images, their dL/dY2
+ * rows, slab partials, kept stage images and running totals as a second layer-2 instance.  The totals of that half, again
+ * float [256][129], live at this offset (0 for every other shape). */
+size_t cde_dopri5_adjoint_mlp_gradient_upper_offset(int64_t B, int64_t C, int64_t H);
 /* vjp_t of the two-layer solve (output-time gradients; first_interval bit 1): as cde_dopri5_adjoint_carry_offset */
 size_t cde_dopri5_adjoint_mlp_carry_offset(int64_t B, int64_t C, int64_t H);
 int cde_dopri5_adjoint_mlp_advance(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W1,

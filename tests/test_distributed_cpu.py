@@ -206,6 +206,9 @@ class _ProtocolLib:
     def cde_dopri5_adjoint_mlp_gradient_offset(self, B, C, H):
         return 4096
 
+    def cde_dopri5_adjoint_mlp_gradient_upper_offset(self, B, C, H):
+        return 0
+
     def cde_dopri5_adjoint_mlp_reduced_count(self):
         return self.MLP_REDUCED
 

@@ -258,6 +258,7 @@ _SIGNATURES = {
     "cde_dopri5_adjoint_mlp_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "cde_dopri5_adjoint_mlp_trace_offset": (_sz, [_i64, _i64, _i64, _i]),
     "cde_dopri5_adjoint_mlp_gradient_offset": (_sz, [_i64, _i64, _i64]),
+    "cde_dopri5_adjoint_mlp_gradient_upper_offset": (_sz, [_i64, _i64, _i64]),
     "cde_dopri5_adjoint_mlp_advance": (_i, [_p, _p, _i64, _i, _p, _p, _i64, _p, _p, _i, _p, _p, _d, _d, _p, _i64, _d, _d, _d,
                                             _d, _d, _i, _p, _i64, _i64, _i64, _i, _i, _p, _sz, _i64, _i64, _p]),
     "cde_dopri5_adjoint_state_sums": (_i, [_p, _sz, _i64, _i64, _i64, _i64, _p, _p]),

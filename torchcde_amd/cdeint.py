@@ -725,7 +725,8 @@ def _mlp_upper_half(H, C):
 
 
 # which requests of the 32 x 16 shape the kernels take (the rest of that shape is solved step-wise)
-_UPPER_HALF_PATHS = {"mlp_rk4_forward", "mlp_dopri5_forward", "mlp_rk4_adjoint", "mlp_rk4_backprop"}
+# (the adaptive backward: one GPU's batch -- its shared-controller protocol exchanges one layer-2 image, not two)
+_UPPER_HALF_PATHS = {"mlp_rk4_forward", "mlp_dopri5_forward", "mlp_rk4_adjoint", "mlp_rk4_backprop", "mlp_dopri5_adjoint"}
 
 
 def _mlp_fusable(field, H, C, z0, packed):
@@ -1237,10 +1238,11 @@ class _Dopri5Plan:
             a = a_out + grad_out[:, i - 1]
         off = lib.cde_dopri5_adjoint_mlp_gradient_offset(B, C, H)
         totals = workspace[off:off + 4 * (256 * 129 + 128 * 33)].view(torch.float32)
-        acc2, acc1 = totals[:256 * 129].view(256, 129), totals[256 * 129:].view(128, 33)
-        units, channels = (32, 8) if C <= 8 else (16, 16)        # padded (hidden unit, channel) layout of the layer-2 rows
-        grad_w2 = acc2[:, :width].reshape(units, channels, width)[:H, :C].reshape(H * C, width)
-        grad_b2 = acc2[:, 128].reshape(units, channels)[:H, :C].reshape(H * C)
+        acc2, acc1 = totals[:256 * 129].view(1, 256, 129), totals[256 * 129:].view(128, 33)
+        off = lib.cde_dopri5_adjoint_mlp_gradient_upper_offset(B, C, H)
+        if off:                                                  # 32 units x 16 channels: hidden units 16..31, a second image
+            acc2 = torch.cat([acc2, workspace[off:off + 4 * 256 * 129].view(torch.float32).view(1, 256, 129)])
+        grad_w2, grad_b2 = _output_layer_gradients(acc2, H, C, width)
         grad_w1 = acc1[:width, :H].contiguous()
         grad_b1 = acc1[:width, 32].contiguous()
         last_dopri5_adjoint_stats = self.owner.dopri5_adjoint
@@ -1687,7 +1689,8 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         # the probe recognised the formula but the shape / dtype is beyond the tiles: say so in the record and the warning
         request = request._replace(kind=recognised_kind, tiles_ok=False)
     choice = dispatch.select_path(request)
-    if mlp is not None and _mlp_upper_half(H, C) and choice.path not in _UPPER_HALF_PATHS and choice.path != dispatch.STEPWISE:
+    if (mlp is not None and _mlp_upper_half(H, C) and choice.path != dispatch.STEPWISE
+            and (choice.path not in _UPPER_HALF_PATHS or (choice.path == "mlp_dopri5_adjoint" and request.shared))):
         # 32 units x 16 channels: fused where the kernels read the upper half (see _UPPER_HALF_PATHS)
         request = request._replace(tiles_ok=False)
         choice = dispatch.select_path(request)

@@ -3,6 +3,7 @@
 // bank-conflict analysis of the plain W2 copy), the factor-row layout, and the stage evaluation as a function.
 #pragma once
 #include "cde_mfma.h"
+#include <type_traits>
 
 namespace cde {
 
@@ -74,7 +75,7 @@ __device__ __forceinline__ void mlp_split_allreduce(float* xbuf, int pw, int lan
 
 // DCTRL (control gradients through K4am, round 6): also gxo[c] = sum_h a_h act(Y2)_hc = d(a.f)/d(dX_c) of the lane's SERIES,
 // complete in every lane (the lane's own hidden units, the other waves' unit groups in the SPLIT form, the four lane quarters).
-template <int ACT, int CT, bool TGRAD, bool SPLIT = false, bool DCTRL = false>
+template <int ACT, int CT, bool TGRAD, bool SPLIT = false, bool DCTRL = false, bool HI = false>
 __device__ __forceinline__ void mlp_adjoint_eval(const float* lds_base, const float4* w1t_base, int lane, int n, int q,
                                                  int w2y_off, const int (&w2g_off)[4], const float (&zs)[8],
                                                  const float (&as)[8], const float (&dX)[CT], const float (&d2X)[CT],
@@ -82,7 +83,7 @@ __device__ __forceinline__ void mlp_adjoint_eval(const float* lds_base, const fl
                                                  f32x4& fa, f32x4& fb, f32x4& va, f32x4& vb, float& kt, int pw = 0,
                                                  float* xbuf = nullptr, const float4* w1t_regs = nullptr,
                                                  bool stamp_on = false, unsigned long long* stamp = nullptr,
-                                                 float* gxo = nullptr) {
+                                                 float* gxo = nullptr, MlpHi hi = MlpHi{}, float* g2row_hi = nullptr) {
 #ifdef CDE_PHASE_TRACE
 #define CDE_EVAL_STAMP(slot, ...) do { if (stamp_on) { asm volatile("s_nop 0" : __VA_ARGS__); __builtin_amdgcn_sched_barrier(0); \
                                        stamp[slot] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } } while (0)
@@ -90,6 +91,12 @@ __device__ __forceinline__ void mlp_adjoint_eval(const float* lds_base, const fl
 #define CDE_EVAL_STAMP(slot, ...) do { (void)stamp; (void)stamp_on; } while (0)
 #endif
   constexpr int NB = CT / 4, NP = 16 / NB;      // channel blocks per unit group, unit groups (of 4 hidden units)
+  // 32 units x 16 channels (`hi`, round 6): unit groups NP .. 7 as well, their rows of W2 / b2 from the zero-padded copy behind
+  // the images (mlp_adj_hi), their dL/dY2 rows into a second row block (`g2row_hi`: the same padded layout, units 16..31)
+  // (HI is a template flag: the kernels of the other shapes compile exactly as before)
+  static_assert(!HI || (CT == 16 && SPLIT), "the upper half exists for 16-channel tiles, in the four-wave form");
+  constexpr int NPX = HI ? 8 : NP;
+  constexpr bool has_hi = HI;
   const bool writer = !SPLIT || pw == 0;        // the wave that streams the factor rows every wave holds (U, Z, G1)
   int opaque = 0;                                                // keeps the LDS reads inside the evaluation
   asm volatile("" : "+v"(opaque));
@@ -143,17 +150,25 @@ __device__ __forceinline__ void mlp_adjoint_eval(const float* lds_base, const fl
   for (int c = 0; c < (DCTRL ? CT : 1); ++c) gxl[c] = 0.f;
   // SPLIT: a REAL loop over the wave's unit groups (round 4; the rolled stage loop of the caller then is ~10 KB of code).
   // Every address below is affine in P; only as[P] and the slot of f need a select chain on the (wave-uniform) P.
-  auto group = [&](int P) {                                      // unit group P: 4 hidden units x CT channels = NB tiles
+  auto group = [&](int P, auto upper_c) {                        // unit group P: 4 hidden units x CT channels = NB tiles
     float as_P = as[0];
 #pragma unroll
-    for (int kk = 1; kk < NP; ++kk) as_P = P == kk ? as[kk] : as_P;
+    for (int kk = 1; kk < NPX; ++kk) as_P = P == kk ? as[kk] : as_P;
+    constexpr bool upper = decltype(upper_c)::value;             // (a compile-time flag: LDS and global reads stay apart)
     f32x4 y[NB];
     const float* tp_[NB];
 #pragma unroll
     for (int tb = 0; tb < NB; ++tb) {
-      const float4 c0 = bb2[4 * (NB * P + tb)];
-      y[tb] = f32x4{c0.x, c0.y, c0.z, c0.w};
-      tp_[tb] = w2y + 2 * (NB * P + tb) * 8 * W2P_STRIDE;        // tile T = NB*P + tb: physical rows (2T + hb)*8 + r8
+      if (!upper) {
+        const float4 c0 = bb2[4 * (NB * P + tb)];
+        y[tb] = f32x4{c0.x, c0.y, c0.z, c0.w};
+        tp_[tb] = w2y + 2 * (NB * P + tb) * 8 * W2P_STRIDE;      // tile T = NB*P + tb: physical rows (2T + hb)*8 + r8
+      } else {
+        // the lane's D rows are (h = 4P + q, c = 4 tb + r); its A rows (h = 4P + (n >> 2), c = 4 tb + (n & 3))
+        const float4 c0 = *reinterpret_cast<const float4*>(hi.b2 + (4 * P + q - 16) * 16 + 4 * tb);
+        y[tb] = f32x4{c0.x, c0.y, c0.z, c0.w};
+        tp_[tb] = hi.W2 + ((4 * P + (n >> 2) - 16) * 16 + 4 * tb + (n & 3)) * 128 + 4 * q;
+      }
     }
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
@@ -190,25 +205,39 @@ __device__ __forceinline__ void mlp_adjoint_eval(const float* lds_base, const fl
     for (int kk = 0; kk < 4; ++kk) { fa[kk] = P == kk ? f : fa[kk]; fb[kk] = P == 4 + kk ? f : fb[kk]; }
     if (TGRAD) kt = __builtin_fmaf(as_P, h2, kt);
     if (stream) {
-      float* grow = g2row + 4 * CT * P;                          // rows (h = 4P+q, c = 0..CT-1) of the padded layout
+      float* grow = upper ? g2row_hi + 4 * CT * (P - NP) : g2row + 4 * CT * P;      // rows (h = 4P+q, c = 0..CT-1) of the padded layout
 #pragma unroll
       for (int c4 = 0; c4 < CT; c4 += 4) stream_store4(grow + c4, g2[c4], g2[c4 + 1], g2[c4 + 2], g2[c4 + 3]);
     }
 #pragma unroll
     for (int c = 0; c < CT; ++c) {                               // K step (P, c); 8 independent accumulator chains
-      const float* rowp = w2g[c & 3] + 2 * (NB * P + (c >> 2)) * 8 * W2P_STRIDE;
+      // (upper half: row (h = 4P + q, c) of the padded copy, column 16 T1 + n)
+      const float* rowp = upper ? hi.W2 + ((4 * P + q - 16) * 16 + c) * 128 + n
+                                : w2g[c & 3] + 2 * (NB * P + (c >> 2)) * 8 * W2P_STRIDE;
 #pragma unroll
       for (int T1 = 0; T1 < 8; ++T1) gu[T1] = mfma16(rowp[16 * T1], g2[c], gu[T1]);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
   if constexpr (SPLIT) {
-    const int P_first = pw * (NP / 4);
+    constexpr int per_wave = NPX / 4;
+    const int P_first = pw * per_wave;
+    if (NPX > NP && P_first >= NP) {                             // (wave-uniform: waves 2, 3 take the upper groups)
+      if constexpr (NPX > NP) {
 #pragma clang loop unroll(disable)
-    for (int P = P_first; P < P_first + NP / 4; ++P) group(P);
+        for (int P = P_first; P < P_first + per_wave; ++P) group(P, std::true_type{});
+      }
+    } else {
+#pragma clang loop unroll(disable)
+      for (int P = P_first; P < P_first + per_wave; ++P) group(P, std::false_type{});
+    }
   } else {
 #pragma unroll
-    for (int P = 0; P < NP; ++P) group(P);
+    for (int P = 0; P < NP; ++P) group(P, std::false_type{});
+    if constexpr (NPX > NP) {
+#pragma unroll
+      for (int P = NP; P < NPX; ++P) group(P, std::true_type{});
+    }
   }
 
   CDE_EVAL_STAMP(1, "+v"(gu[0]), "+v"(gu[7]));

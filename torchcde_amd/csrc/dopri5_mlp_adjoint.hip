@@ -72,6 +72,10 @@ struct MlpAdjArgs {
   int n_cblocks;
   double* ktp;                      // [2][n_wg_max][8]: per-workgroup sums of the per-stage time term
   int with_knots;
+  // 32 hidden units x 16 channels (round 6): the dL/dY2 rows of hidden units 16..31, a second block laid out like G2; the
+  // parameter sums then come in two runs of blocks (one per R-kernel instance), `pq_blocks` per parity
+  float* G2hi;
+  int pq_blocks;
 };
 
 // SPLIT (small batches: fewer tiles than SIMDs): the workgroup's four waves share ONE tile and split the middle of every
@@ -81,9 +85,11 @@ constexpr int MADJ_XBUF_FLOATS = 4 * 64 * 9;
 #ifdef CDE_PHASE_TRACE
 __device__ unsigned long long k4am_phase_trace[TRACE_RING * TRACE_BLOCKS * TRACE_SLOTS];
 #endif
-template <int DEGREE, int ACT, int CT, int NWAVE, bool SPLIT = false, bool DCTRL = false>
+// HI (round 6): 32 hidden units x 16 channels -- the four-wave form with twice the unit groups (cde_mlp_adj.h)
+template <int DEGREE, int ACT, int CT, int NWAVE, bool SPLIT = false, bool DCTRL = false, bool HI = false>
 __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adjoint_attempt(MlpAdjArgs g, int parity) {
   static_assert(!SPLIT || NWAVE == 4, "this kernel's split form is four waves per tile (eight: dopri5_mlp_adjoint_attempt_s8)");
+  static_assert(!HI || (SPLIT && CT == 16), "the upper half: 16-channel tiles, four waves per tile");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int p = parity, p2 = parity ^ 1;
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
 #pragma unroll
       for (int i = 0; i < ADJ_NS; ++i) sum[i] += Pp[ADJ_NS * b + i];
     }
-    const double* Qp = g.pq + (int64_t)p * MADJ_RBLOCKS * 8;
+    const double* Qp = g.pq + (int64_t)p * g.pq_blocks * 8;
     for (int b = tid; b < g.n_pq; b += blockDim.x) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) sum[ADJ_NS + i] += Qp[8 * b + i];
@@ -220,6 +226,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
 #pragma unroll
     for (int cl = 0; cl < 4; ++cl) w2g_off[cl] = ((q >> 1) * 8 + w2p_residue(q, cl)) * W2P_STRIDE + n;
     const int ua = q, ub = 16 + q;                                 // this lane's units: q, 4+q, .., 28+q
+    const MlpHi hi = HI ? mlp_adj_hi(g.img, Hr, CT) : MlpHi{};
     // the state this launch starts from
     const float* ysrc = phase_in == 0 ? g.y_init : Sp + (commit ? 2 : 0) * BH;
     const float* asrc = phase_in == 0 ? g.a_init : Sp + (commit ? 3 : 1) * BH;
@@ -279,7 +286,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
       float kt;
       float gxo[DCTRL ? CT : 1];
       {
-        mlp_adjoint_eval<ACT, CT, DEGREE == CDE_PATH_CUBIC, SPLIT, DCTRL>(
+        mlp_adjoint_eval<ACT, CT, DEGREE == CDE_PATH_CUBIC, SPLIT, DCTRL, HI>(
             lds, w1t_base, lane, n, q, w2y_off, w2g_off, zs, as, dX, d2X, stream, g.U + out_row * U_COLS + 4 * q,
             g.Z + out_row * Z_COLS, g.G2 + out_row * G2_COLS + CT * q, g.G1 + out_row * G1_COLS + 4 * q, Hr, fa, fb, va, vb, kt,
             pw, xbuf, w1tr,
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
 #else
             false, nullptr,
 #endif
-            gxo);
+            gxo, hi, HI ? g.G2hi + out_row * G2_COLS + CT * q : nullptr);
       }
       if (DEGREE == CDE_PATH_CUBIC) { vtS = __builtin_fmaf(wS_i, kt, vtS); vtE = __builtin_fmaf(wE_i, kt, vtE); }
       if constexpr (DCTRL) {
@@ -575,7 +582,7 @@ __global__ __launch_bounds__(512, 2) void dopri5_mlp_adjoint_attempt_s8(MlpAdjAr
 #pragma unroll
       for (int i = 0; i < ADJ_NS; ++i) sum[i] += Pp0[ADJ_NS * b + i];
     }
-    const double* Qp = g.pq + (int64_t)p * MADJ_RBLOCKS * 8;
+    const double* Qp = g.pq + (int64_t)p * g.pq_blocks * 8;
     for (int b = tid; b < g.n_pq; b += blockDim.x) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) sum[ADJ_NS + i] += Qp[8 * b + i];
@@ -915,6 +922,9 @@ struct MlpReduceArgs {
   double* sums_out;         // stage 1: [2][MADJ_ELEMS] doubles (S, E)
   const double* sums_in;    // stage 2: the reduced buffer (ADJ_NS state sums, then the S and E images)
   float rtol, atol;
+  // 32 hidden units x 16 channels: the kernel runs a second time on the images of hidden units 16..31 -- a layer-2 block only
+  // (`n_elems` = MADJ_P2, its own kst / G / prevS), its parameter sums in the blocks from `pq_block0` on
+  int n_elems, pq_blocks, pq_block0;
 };
 
 // Launch shape: 32 elements per block x 8 lanes; lane s < 6 adds the slabs of stored stage s (independent loads, eight
@@ -932,7 +942,7 @@ __global__ __launch_bounds__(256) void mlp_adjoint_reduce_kernel(MlpReduceArgs r
   const bool layer2 = e < MADJ_P2;
   if (stage != 2) {
     float sum = 0.f;
-    if (e < MADJ_ELEMS && sl < n_slots) {
+    if (e < r.n_elems && sl < n_slots) {
       auto plane = [](int blk) { return blk == 0 ? 0 : blk - 4; };
       if (k.mode == 2 && sl == 0 && !(k.six & ADJ_FRESH0)) sum = r.kst[(int64_t)plane(k.src0) * MADJ_ELEMS + e];
       else {
@@ -954,14 +964,14 @@ __global__ __launch_bounds__(256) void mlp_adjoint_reduce_kernel(MlpReduceArgs r
   __syncthreads();
   double qv[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   if (sl == 0) {
-    if (stage != 1 && k.mode == 3 && e == 0) {
+    if (stage != 1 && k.mode == 3 && e == 0 && r.pq_block0 == 0) {
       double vt = 0.0;
       if (stage == 2) vt = r.sums_in[4];
       else
         for (int b = 0; b < r.n_wg; ++b) vt += r.partial[((int64_t)p2 * r.n_wg_max + b) * ADJ_NS + 4];
       r.carry[0] = (double)((float)k.T + (float)vt);
     }
-    if (e < MADJ_ELEMS) {
+    if (e < r.n_elems) {
       float S = 0.f, E = 0.f;
       if (stage == 2) {
         S = (float)r.sums_in[ADJ_NS + e]; E = (float)r.sums_in[ADJ_NS + MADJ_ELEMS + e];
@@ -1008,7 +1018,7 @@ __global__ __launch_bounds__(256) void mlp_adjoint_reduce_kernel(MlpReduceArgs r
     const int i = threadIdx.x;
     double t = 0.0;
     for (int x = 0; x < 32; ++x) t += red[i][x];
-    r.pq[((int64_t)p2 * MADJ_RBLOCKS + blockIdx.x) * 8 + i] = t;
+    r.pq[((int64_t)p2 * r.pq_blocks + r.pq_block0 + blockIdx.x) * 8 + i] = t;
   }
 }
 
@@ -1132,7 +1142,7 @@ __global__ __launch_bounds__(256) void mlp_adjoint_small_reduce_kernel(MlpSmallA
     for (int j = 0; j < 8; ++j) red[wave][j] = qv[j];
   __syncthreads();
   if (threadIdx.x < 8)
-    r.pq[((int64_t)p2 * MADJ_RBLOCKS + blockIdx.x) * 8 + threadIdx.x] =
+    r.pq[((int64_t)p2 * r.pq_blocks + blockIdx.x) * 8 + threadIdx.x] =
         (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
@@ -1145,7 +1155,7 @@ __global__ __launch_bounds__(256) void madj_ones_kernel(float* __restrict__ U, f
 // from mlp_grad_reduce.hip: the split-K reduction of one attempt's factor rows, both layers, gated by the controller block
 int launch_mlp_adjoint_factor_reduce(const float* G2, const float* U, const float* G1, const float* Z, int64_t rows_per_stage,
                                      int sps, int64_t rows_per_slab, float* part2, float* part1, const unsigned char* ctrl,
-                                     int parity, hipStream_t s);
+                                     int parity, hipStream_t s, const float* G2hi = nullptr, float* part2hi = nullptr);
 
 static inline size_t m256(size_t x) { return (x + 255) / 256 * 256; }
 
@@ -1168,6 +1178,9 @@ struct MadjLayout {
   size_t partial, pq, carry, image, state, G, prev, Gn, prevn, slopes, stash, kst, part2, part1, U, G2, G1, Z, trace, trace_all, total;
   size_t rec, cq, ktp, gx, total_dcontrol;                         // control gradients: behind everything else
   int n_cblocks, ct;
+  bool upper;                                                      // 32 hidden units x 16 channels: a second layer-2 instance
+  size_t G_hi, prev_hi, kst_hi, part2_hi, G2_hi;
+  int pq_blocks;
 };
 MadjLayout madj_layout(int64_t B, int64_t H, int64_t C) {
   using namespace cde;
@@ -1175,7 +1188,9 @@ MadjLayout madj_layout(int64_t B, int64_t H, int64_t C) {
   L.n_tiles = (B + 15) / 16;
   // 16384 series fill the GPU's 1024 SIMDs with one wave each; CDE_OPT_K4AM_WAVES = 8 runs the large-batch form on any batch
   // (tests: the 8-wave kernel at a size the CPU oracle can follow)
-  L.nwave = (L.n_tiles > 1024 || option(CDE_OPT_K4AM_WAVES) == 8) ? 8 : 4;
+  L.upper = mlp_shape_upper(C, H, 4);
+  L.pq_blocks = L.upper ? 2 * MADJ_RBLOCKS : MADJ_RBLOCKS;
+  L.nwave = ((L.n_tiles > 1024 || option(CDE_OPT_K4AM_WAVES) == 8) && !L.upper) ? 8 : 4;
   // up to MADJ_SPLIT_MAX_TILES tiles (one workgroup per CU in a single round): four waves per tile, the evaluation's middle
   // split four ways
   // (8-channel tiles: the eight-wave form takes ~75 us per round of 256 tiles, the one-wave-per-tile forms 260-420 us
@@ -1187,9 +1202,10 @@ MadjLayout madj_layout(int64_t B, int64_t H, int64_t C) {
   L.split = L.n_tiles <= (s8_shape && s8_tiles > MADJ_SPLIT_MAX_TILES ? s8_tiles : MADJ_SPLIT_MAX_TILES) &&
             !option(CDE_OPT_K4AM_NO_SPLIT);
   // ... eight (two per SIMD, everything split eight ways: mlp_adjoint_eval_split8) when the control fits the 32 x 8 tiling
+  if (L.upper) L.split = true;                     // (32 x 16: the four-wave form at any batch, one workgroup per tile)
   L.split8 = L.split && C <= MC && !option(CDE_OPT_K4AM_SPLIT4);
   // a few hundred rows per attempt: factor reduction + R in one launch (mlp_adjoint_small_reduce_kernel)
-  L.small = B <= MADJ_SMALL_MAX_ROWS && !option(CDE_OPT_K4AM_NO_SMALL_REDUCE);
+  L.small = B <= MADJ_SMALL_MAX_ROWS && !option(CDE_OPT_K4AM_NO_SMALL_REDUCE) && !L.upper;
   L.n_wg = L.split ? (int)L.n_tiles : (int)((L.n_tiles + L.nwave - 1) / L.nwave);
   int64_t sps = (B + 63) / 64;                     // (measured at 4096 series: 40 slabs 193 us per attempt, 16: 209, 6: 284;
   const int64_t sps_req = option(CDE_OPT_K4AM_SPS);                              // (measurements; 0: the default)
@@ -1204,21 +1220,28 @@ MadjLayout madj_layout(int64_t B, int64_t H, int64_t C) {
   const size_t rows = (size_t)MADJ_FSLOTS * L.rows_per_stage;
   L.partial = m256(2 * ADJ_CTRL_STRIDE);
   L.pq = L.partial + m256((size_t)2 * L.n_wg * ADJ_NS * sizeof(double));
-  L.carry = L.pq + m256((size_t)2 * MADJ_RBLOCKS * 8 * sizeof(double));
+  L.carry = L.pq + m256((size_t)2 * L.pq_blocks * 8 * sizeof(double));
   L.image = L.carry + 256;
   L.state = L.image + m256(mlp_adjoint_image_bytes());
   L.G = L.state + m256((size_t)2 * 4 * B * H * sizeof(float));
   L.prev = L.G + m256((size_t)MADJ_ELEMS * sizeof(float));
   L.Gn = L.prev + m256((size_t)2 * MADJ_ELEMS * sizeof(float));        // sharded: the GLOBAL running totals and S sums
   L.prevn = L.Gn + m256((size_t)MADJ_ELEMS * sizeof(float));
-  L.slopes = L.prevn + m256((size_t)2 * MADJ_ELEMS * sizeof(float));
+  // (the upper instance's blocks sit inside the ranges the first launch zeroes: [G, slopes) and [U, trace))
+  const size_t up = L.upper ? 1 : 0;
+  L.G_hi = L.prevn + m256((size_t)2 * MADJ_ELEMS * sizeof(float));
+  L.prev_hi = L.G_hi + up * m256((size_t)MADJ_ELEMS * sizeof(float));
+  L.slopes = L.prev_hi + up * m256((size_t)2 * MADJ_ELEMS * sizeof(float));
   L.stash = L.slopes + m256((size_t)L.n_tiles * 7 * 4 * 64 * 16);
   L.kst = L.stash + m256((size_t)3 * B * (2 * H + 4) * sizeof(float));
-  L.part2 = L.kst + m256((size_t)3 * MADJ_ELEMS * sizeof(float));
-  L.part1 = L.part2 + m256((size_t)MADJ_SLOTS * L.sps * MADJ_P2 * sizeof(float));
+  L.kst_hi = L.kst + m256((size_t)3 * MADJ_ELEMS * sizeof(float));
+  L.part2 = L.kst_hi + up * m256((size_t)3 * MADJ_ELEMS * sizeof(float));
+  L.part2_hi = L.part2 + m256((size_t)MADJ_SLOTS * L.sps * MADJ_P2 * sizeof(float));
+  L.part1 = L.part2_hi + up * m256((size_t)MADJ_SLOTS * L.sps * MADJ_P2 * sizeof(float));
   L.U = L.part1 + m256((size_t)MADJ_SLOTS * L.sps * MADJ_P1 * sizeof(float));
   L.G2 = L.U + m256(rows * U_COLS * sizeof(float));
-  L.G1 = L.G2 + m256(rows * G2_COLS * sizeof(float));
+  L.G2_hi = L.G2 + m256(rows * G2_COLS * sizeof(float));
+  L.G1 = L.G2_hi + up * m256(rows * G2_COLS * sizeof(float));
   L.Z = L.G1 + m256(rows * G1_COLS * sizeof(float));
   L.trace = L.Z + m256(rows * Z_COLS * sizeof(float));
   L.trace_all = L.trace + m256((size_t)CDE_DOPRI5_TRACE_STEPS * 3 * sizeof(double));
@@ -1250,6 +1273,11 @@ extern "C" size_t cde_dopri5_adjoint_mlp_carry_offset(int64_t B, int64_t C, int6
 extern "C" size_t cde_dopri5_adjoint_mlp_gradient_offset(int64_t B, int64_t C, int64_t H) {
   return madj_layout(B, H, C).G;
 }
+// 32 hidden units x 16 channels: the layer-2 totals of hidden units 16..31, again [256][129]; 0 for every other shape
+extern "C" size_t cde_dopri5_adjoint_mlp_gradient_upper_offset(int64_t B, int64_t C, int64_t H) {
+  const MadjLayout L = madj_layout(B, H, C);
+  return L.upper ? L.G_hi : 0;
+}
 
 namespace {
 cde::MlpReduceArgs madj_reduce_args(unsigned char* base, const MadjLayout& L, double rtol, double atol, bool sharded) {
@@ -1262,6 +1290,7 @@ cde::MlpReduceArgs madj_reduce_args(unsigned char* base, const MadjLayout& L, do
   q.partial = (double*)(base + L.partial); q.n_wg = L.n_wg; q.n_wg_max = L.n_wg; q.carry = (double*)(base + L.carry);
   q.sums_out = nullptr; q.sums_in = nullptr;
   q.rtol = (float)rtol; q.atol = (float)atol;
+  q.n_elems = cde::MADJ_ELEMS; q.pq_blocks = L.pq_blocks; q.pq_block0 = 0;
   return q;
 }
 }  // namespace
@@ -1285,7 +1314,8 @@ static int dopri5_adjoint_mlp_advance_impl(const void* coeffs, const void* knots
   if (first_launch > 0 && sharded && !reduced_sums) return CDE_ERR_NULL;
   if (B < 1 || C < 1 || H < 1 || width < 1 || n_intervals < 1 || n_launches < 0 || n_jump < 0 || !(s0 < s1)) return CDE_ERR_SHAPE;
   if (dtype != CDE_F32) return dtype == CDE_F64 ? CDE_ERR_UNSUPPORTED : CDE_ERR_DTYPE;
-  if (!mlp_shape_ok(C, H, width)) return CDE_ERR_UNSUPPORTED;
+  if (!mlp_shape_ok(C, H, width) && !mlp_shape_upper(C, H, width)) return CDE_ERR_UNSUPPORTED;
+  if (mlp_shape_upper(C, H, width) && sharded) return CDE_ERR_UNSUPPORTED;       // (one GPU's batch: no image exchange for the upper half)
   if (act != CDE_ACT_NONE && act != CDE_ACT_TANH) return CDE_ERR_UNSUPPORTED;
   if (degree != CDE_PATH_CUBIC && degree != CDE_PATH_LINEAR) return CDE_ERR_UNSUPPORTED;
   if (norm_kind != 0 && norm_kind != 1) return CDE_ERR_UNSUPPORTED;
@@ -1314,7 +1344,9 @@ static int dopri5_adjoint_mlp_advance_impl(const void* coeffs, const void* knots
 #ifdef CDE_PHASE_TRACE
   { const char* d = getenv("CDE_K4AM_DBG"); g.dbg |= d ? atoi(d) & 1 : 0; }      // timing experiments (wrong gradients!)
 #endif
-  g.n_pq = L.small && (!sharded || norm_kind == 1) ? MADJ_SMALL_BLOCKS : MADJ_RBLOCKS;
+  g.n_pq = L.small && (!sharded || norm_kind == 1) ? MADJ_SMALL_BLOCKS : L.pq_blocks;
+  g.pq_blocks = L.pq_blocks;
+  g.G2hi = L.upper ? (float*)(base + L.G2_hi) : nullptr;
   g.com.s0 = s0; g.com.s1 = s1; g.com.jump_s = jump_s; g.com.n_jump = n_jump;
   g.com.rtol = rtol; g.com.atol = atol; g.com.safety = safety; g.com.ifactor = ifactor; g.com.dfactor = dfactor;
   g.com.n_state = (B_global > 0 ? B_global : B) * H;
@@ -1358,6 +1390,12 @@ static int dopri5_adjoint_mlp_advance_impl(const void* coeffs, const void* knots
   const bool dctrl_one_wave = dctrl && L.split8 && L.n_tiles > MADJ_SPLIT_MAX_TILES;
   const int grid = dctrl_one_wave ? (int)((L.n_tiles + 3) / 4) : L.n_wg;
   r.n_wg = grid;
+  MlpReduceArgs r_hi = r;
+  if (L.upper) {
+    r_hi.part2 = (const float*)(base + L.part2_hi); r_hi.part1 = nullptr;
+    r_hi.kst = (float*)(base + L.kst_hi); r_hi.G = (float*)(base + L.G_hi); r_hi.prevS = (float*)(base + L.prev_hi);
+    r_hi.n_elems = MADJ_P2; r_hi.pq_block0 = MADJ_RBLOCKS;
+  }
   MlpSmallArgs sm;
   sm.r = r; sm.G2 = g.G2; sm.U = g.U; sm.G1 = g.G1; sm.Z = g.Z; sm.rows_per_stage = L.rows_per_stage; sm.B = B;
   // after an attempt launch: the split-K reduction of its factor rows + the R kernel, or (small batches) both in one launch
@@ -1368,9 +1406,11 @@ static int dopri5_adjoint_mlp_advance_impl(const void* coeffs, const void* knots
       return CDE_OK;
     }
     const int rc = launch_mlp_adjoint_factor_reduce(g.G2, g.U, g.G1, g.Z, L.rows_per_stage, L.sps, L.rows_per_slab,
-                                                    (float*)(base + L.part2), (float*)(base + L.part1), base, parity, s);
+                                                    (float*)(base + L.part2), (float*)(base + L.part1), base, parity, s,
+                                                    g.G2hi, L.upper ? (float*)(base + L.part2_hi) : nullptr);
     if (rc != CDE_OK) return rc;
     mlp_adjoint_reduce_kernel<<<MADJ_RBLOCKS, 256, 0, s>>>(r, parity);
+    if (L.upper) mlp_adjoint_reduce_kernel<<<MADJ_RBLOCKS, 256, 0, s>>>(r_hi, parity);
     return CDE_OK;
   };
   // ... and (control gradients) the kernel that owns the coefficient / knot-time blocks (cde_dopri_ctl.h)
@@ -1412,6 +1452,21 @@ static int dopri5_adjoint_mlp_advance_impl(const void* coeffs, const void* knots
       if (rc != CDE_OK) return rc;                                                                                   \
     }                                                                                                                \
   } while (0)
+#define CDE_MADJ_HI(D, A)                                                                                            \
+  do {                                                                                                               \
+    (void)hipFuncSetAttribute((const void*)dopri5_mlp_adjoint_attempt<D, A, 16, 4, true, false, true>,               \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                           \
+    (void)hipFuncSetAttribute((const void*)dopri5_mlp_adjoint_attempt<D, A, 16, 4, true, true, true>,                \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                           \
+    for (int64_t i = 0; i < n_launches; ++i) {                                                                       \
+      const int parity = (int)((first_launch + i) & 1);                                                              \
+      if (dctrl) dopri5_mlp_adjoint_attempt<D, A, 16, 4, true, true, true><<<grid, 256, lds_bytes, s>>>(g, parity);    \
+      else dopri5_mlp_adjoint_attempt<D, A, 16, 4, true, false, true><<<grid, 256, lds_bytes, s>>>(g, parity);       \
+      const int rc = after_attempt(parity);                                                                          \
+      if (rc != CDE_OK) return rc;                                                                                   \
+      control_after(parity);                                                                                         \
+    }                                                                                                                \
+  } while (0)
 #define CDE_MADJ_W(D, A, CTV)                                                                                        \
   do {                                                                                                               \
     if (dctrl_one_wave) CDE_MADJ_LAUNCH(D, A, CTV, 4, false);                                                        \
@@ -1421,7 +1476,8 @@ static int dopri5_adjoint_mlp_advance_impl(const void* coeffs, const void* knots
   } while (0)
 #define CDE_MADJ(D, A)                                                                                               \
   do {                                                                                                               \
-    if (C > MC) CDE_MADJ_W(D, A, 16);                                                                                \
+    if (L.upper) CDE_MADJ_HI(D, A);                                                                                  \
+    else if (C > MC) CDE_MADJ_W(D, A, 16);                                                                           \
     else if (L.split8 && !dctrl) CDE_MADJ_LAUNCH_S8(D, A);       /* (control gradients: the four-wave form) */          \
     else CDE_MADJ_W(D, A, 8);                                                                                        \
   } while (0)
@@ -1432,6 +1488,7 @@ static int dopri5_adjoint_mlp_advance_impl(const void* coeffs, const void* knots
   }
 #undef CDE_MADJ
 #undef CDE_MADJ_W
+#undef CDE_MADJ_HI
 #undef CDE_MADJ_LAUNCH
 #undef CDE_MADJ_LAUNCH_S8
   return check_launch();

@@ -208,7 +208,14 @@ __global__ __launch_bounds__(256, 2) void mlp_grad_partial_pair_kernel(const flo
                                                                        int64_t rows, int64_t rows_per_slab,
                                                                        float* __restrict__ part2, float* __restrict__ part1,
                                                                        const unsigned char* __restrict__ gate, int gate_parity,
-                                                                       int slabs_per_stage) {
+                                                                       int slabs_per_stage, const float* __restrict__ G2hi,
+                                                                       float* __restrict__ part2hi) {
+  // 32 hidden units x 16 channels: blockIdx.y = 3, 4 are the row halves of the upper hidden units' [dW2 | db2] = G2hi^T U
+  if (blockIdx.y >= 3) {
+    mlp_grad_partial_body<2, 4, 2>(G2hi, U, rows, rows_per_slab, 132, part2hi, 256, gate, gate_parity, slabs_per_stage,
+                                   (int)blockIdx.x, (int)blockIdx.y - 3);
+    return;
+  }
   // (layer 2 in two halves of 128 rows: two workgroups per CU instead of one -- a single wave per SIMD overlaps neither its
   //  LDS reads nor its partial stores with its own MFMAs, the second workgroup's waves run in exactly those gaps)
   if (blockIdx.y < 2)
@@ -248,14 +255,15 @@ int launch_wide_grad_reduce(const float* G, const float* Z, int64_t rows, int M,
 // dopri5_mlp_adjoint.hip adds the slabs of each stage in order)
 int launch_mlp_adjoint_factor_reduce(const float* G2, const float* U, const float* G1, const float* Z, int64_t rows_per_stage,
                                      int sps, int64_t rows_per_slab, float* part2, float* part1, const unsigned char* ctrl,
-                                     int parity, hipStream_t s) {
+                                     int parity, hipStream_t s, const float* G2hi, float* part2hi) {
   const int64_t rows = 7 * rows_per_stage;                     // (MADJ_FSLOTS blocks of rows; 6 of them are read per attempt)
-  const dim3 grid((unsigned)(6 * sps), 3);
+  const dim3 grid((unsigned)(6 * sps), G2hi ? 5 : 3);
   const size_t a = grad_partial_lds_bytes<2, 4, 2>(), b = grad_partial_lds_bytes<2, 2, 1>();
   const size_t lds_bytes = a > b ? a : b;
   (void)hipFuncSetAttribute((const void*)mlp_grad_partial_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds_bytes);
-  mlp_grad_partial_pair_kernel<<<grid, 256, lds_bytes, s>>>(G2, U, G1, Z, rows, rows_per_slab, part2, part1, ctrl, parity, sps);
+  mlp_grad_partial_pair_kernel<<<grid, 256, lds_bytes, s>>>(G2, U, G1, Z, rows, rows_per_slab, part2, part1, ctrl, parity, sps, G2hi,
+                                                               part2hi);
   return check_launch();
 }
 
