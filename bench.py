@@ -609,8 +609,9 @@ def run_logode_config(args, cde, device, rank, world, distributed, share_gpu):
     raw = (torch.randn(n, 512, 3, generator=gen) * 0.1).cumsum(1)
     raw[..., 0] = torch.linspace(0, 1, 512)
     raw = raw.to(device)
-    field = TwoLayerField(8, 14, 128, seed=0).to(device)
-    z8 = torch.randn(n, 8, generator=gen).to(device)
+    hidden = args.hidden
+    field = TwoLayerField(hidden, 14, 128, seed=0).to(device)
+    z8 = torch.randn(n, hidden, generator=gen).to(device)
     params = list(field.parameters())
     solver = dict(method="rk4", options={"step_size": 1.0}) if args.method == "rk4" else {}
     if args.method != "rk4" and args.norm == "seminorm":
@@ -670,9 +671,11 @@ def run_logode_config(args, cde, device, rank, world, distributed, share_gpu):
             "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" + (" (LAUNCHER CHECK: ranks share cuda:0 over gloo)" if share_gpu else ""),
             "config": {"workload": "BASELINE configs[4]: logsig_windows(depth 3, window 8) -> LinearInterpolation -> "
-                                   "Linear(8,128)-relu-Linear(128,112)-tanh field, method %s, adjoint=True; %d series in total"
-                                   % ("dopri5 (the reference example's default call)" if args.method != "rk4" else "rk4 step 1",
+                                   "Linear(%d,128)-relu-Linear(128,%d)-tanh field, method %s, adjoint=True; %d series in total"
+                                   % (hidden, hidden * 14,
+                                      "dopri5 (the reference example's default call)" if args.method != "rk4" else "rk4 step 1",
                                       n * world),
+                       "hidden_channels": hidden, "dispatch": front.last_dispatch()[0].path,
                        "method": args.method, "adjoint_norm": args.norm, "controller": "shared" if shared else "local",
                        "batch_per_gpu": n, "global_batch": n * world,
                        "parallelism": "batch-sharded x%d, one gradient all-reduce per step" % world},
@@ -689,6 +692,8 @@ def main():
                     help="--config 4 / 5: one step controller per rank, or ONE for the whole sharded batch (all-reduce per attempt)")
     ap.add_argument("--adjoint", action="store_true", help="--config 4: also time the default adjoint backward")
     ap.add_argument("--method", choices=("dopri5", "rk4"), default="dopri5", help="--config 5: the solver")
+    ap.add_argument("--hidden", type=int, choices=(8, 32), default=8,
+                    help="--config 5: hidden size of the two-layer field (8: example/logsignature_example.py:22; 32: the 32 x 16 tiles)")
     ap.add_argument("--norm", choices=("mixed", "seminorm"), default="mixed",
                     help="adaptive adjoint: torchdiffeq's default mixed norm or adjoint_options=dict(norm='seminorm')")
     ap.add_argument("--steps", type=int, default=20)

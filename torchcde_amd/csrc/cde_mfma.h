@@ -438,7 +438,7 @@ bool mlp_shape_ok(int64_t C, int64_t H, int64_t width);     // rk4_mfma.hip
 // floats of W2's row (h, c), so no second image is needed (width a multiple of 4, the tensor 16-byte aligned).
 bool mlp_shape_hi(int64_t C, int64_t H, int64_t width);     // rk4_mfma.hip
 bool mlp_shape_upper(int64_t C, int64_t H, int64_t width);  // rk4_mfma.hip: the same shape for the sweeps (padded copy: any width)
-struct MlpHi { const float* W2; const float* b2; int H, C, width; int h0 = 0; };   // W2 == nullptr: no upper half; the rows of
+struct MlpHi { const float* W2; const float* b2; int H, C, width; int h0 = 0; const float* W2t = nullptr; };   // W2 == nullptr: no upper half; the rows of
                                                                                    // hidden unit h start at W2 + (h - h0) C width
                                                                                    // (h0 = 16: a copy of the upper rows only)
 

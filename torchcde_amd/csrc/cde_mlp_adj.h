@@ -16,11 +16,15 @@ constexpr int MLP_ADJ_IMAGE_FLOATS = ADJ_LDS_FLOATS + W1T_FLOATS;
 // hidden units 16..31 as [(h - 16) * 16 + c][128] (and their biases, [(h - 16) * 16 + c]) -- which the sweeps read from
 // global memory / L2 for unit groups 4..7 (cde_mfma.h: MlpHi with h0 = 16): both access patterns of the plain LDS copy
 // (four consecutive columns of a row for Y2, one column of a row for gu) are plain loads from it.
+// A second copy serves the gu += W2^T dL/dY2 products: lane (n, q) needs columns n, 16 + n, .., 112 + n of row (4P + q, c) --
+// eight scalar loads per row from the plain copy, two float4 from this one, [row][8 n + T1] = W2[row][16 T1 + n]
+// (config 5 at hidden size 32, rk4 forward + adjoint on 32768 series: 128 -> 66 ms per step with it).
 constexpr int MLP_ADJ_HI_BIAS_FLOATS = 256, MLP_ADJ_HI_W2_FLOATS = 256 * 128;
-constexpr int MLP_ADJ_IMAGE_HI_FLOATS = MLP_ADJ_IMAGE_FLOATS + MLP_ADJ_HI_BIAS_FLOATS + MLP_ADJ_HI_W2_FLOATS;
+constexpr int MLP_ADJ_IMAGE_HI_FLOATS = MLP_ADJ_IMAGE_FLOATS + MLP_ADJ_HI_BIAS_FLOATS + 2 * MLP_ADJ_HI_W2_FLOATS;
 __device__ __forceinline__ MlpHi mlp_adj_hi(const float* img, int H, int CT) {
   if (CT != 16 || H <= 16) return MlpHi{};
-  return MlpHi{img + MLP_ADJ_IMAGE_FLOATS + MLP_ADJ_HI_BIAS_FLOATS, img + MLP_ADJ_IMAGE_FLOATS, 32, 16, 128, 16};
+  const float* w2 = img + MLP_ADJ_IMAGE_FLOATS + MLP_ADJ_HI_BIAS_FLOATS;
+  return MlpHi{w2, img + MLP_ADJ_IMAGE_FLOATS, 32, 16, 128, 16, w2 + MLP_ADJ_HI_W2_FLOATS};
 }
 // h3 = h&3 enters bit-reversed so that the four lane quarters of a gu read are shifted by 0, 16, 8, 24 banks: the LDS
 // serves a b32 read in two half-waves (lanes 0-31 = quarters 0,1; lanes 32-63 = quarters 2,3) and each half must
@@ -211,11 +215,18 @@ __device__ __forceinline__ void mlp_adjoint_eval(const float* lds_base, const fl
     }
 #pragma unroll
     for (int c = 0; c < CT; ++c) {                               // K step (P, c); 8 independent accumulator chains
-      // (upper half: row (h = 4P + q, c) of the padded copy, column 16 T1 + n)
-      const float* rowp = upper ? hi.W2 + ((4 * P + q - 16) * 16 + c) * 128 + n
-                                : w2g[c & 3] + 2 * (NB * P + (c >> 2)) * 8 * W2P_STRIDE;
+      if constexpr (upper) {
+        // row (h = 4P + q, c) of the padded copy, columns 16 T1 + n: two float4 of the copy laid out for this read
+        const float4* rowq = reinterpret_cast<const float4*>(hi.W2t + ((4 * P + q - 16) * 16 + c) * 128 + 8 * n);
+        const float4 r0 = rowq[0], r1 = rowq[1];
+        const float rv[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
-      for (int T1 = 0; T1 < 8; ++T1) gu[T1] = mfma16(rowp[16 * T1], g2[c], gu[T1]);
+        for (int T1 = 0; T1 < 8; ++T1) gu[T1] = mfma16(rv[T1], g2[c], gu[T1]);
+      } else {
+        const float* rowp = w2g[c & 3] + 2 * (NB * P + (c >> 2)) * 8 * W2P_STRIDE;
+#pragma unroll
+        for (int T1 = 0; T1 < 8; ++T1) gu[T1] = mfma16(rowp[16 * T1], g2[c], gu[T1]);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   };

@@ -73,7 +73,10 @@ __global__ void mlp_adj_image_kernel(const float* __restrict__ W1, const float* 
     return;
   }
   e -= MLP_ADJ_HI_BIAS_FLOATS;
-  const int row = e >> 7, col = e & 127, h = 16 + (row >> 4), c = row & 15;
+  const bool by_lane = e >= MLP_ADJ_HI_W2_FLOATS;                  // the second copy: [row][8 n + T1] = W2[row][16 T1 + n]
+  if (by_lane) e -= MLP_ADJ_HI_W2_FLOATS;
+  const int row = e >> 7, at_col = e & 127, h = 16 + (row >> 4), c = row & 15;
+  const int col = by_lane ? 16 * (at_col & 7) + (at_col >> 3) : at_col;
   img[at] = (h < d.H && c < d.C && col < d.width) ? W2[(h * d.C + c) * d.width + col] : 0.f;
 }
 
@@ -310,11 +313,18 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2) void rk4_adjoint_
         }
 #pragma unroll
         for (int c = 0; c < CT; ++c) {                               // K step (P, c); 8 independent accumulator chains
-          // (upper half: row (h = 4P + q, c) of the padded copy, column 16 T1 + n)
-          const float* rowp = P < NP ? w2g[c & 3] + 2 * (NB * P + (c >> 2)) * 8 * W2P_STRIDE
-                                     : hi.W2 + ((4 * P + q - 16) * 16 + c) * 128 + n;
+          if (P < NP) {
+            const float* rowp = w2g[c & 3] + 2 * (NB * P + (c >> 2)) * 8 * W2P_STRIDE;
 #pragma unroll
-          for (int T1 = 0; T1 < 8; ++T1) gu[T1] = mfma16(rowp[16 * T1], g2[c], gu[T1]);
+            for (int T1 = 0; T1 < 8; ++T1) gu[T1] = mfma16(rowp[16 * T1], g2[c], gu[T1]);
+          } else {
+            // upper half: row (h = 4P + q, c), columns 16 T1 + n -- two float4 of the copy laid out for this read
+            const float4* rowq = reinterpret_cast<const float4*>(hi.W2t + ((4 * P + q - 16) * 16 + c) * 128 + 8 * n);
+            const float4 r0 = rowq[0], r1 = rowq[1];
+            const float rv[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+            for (int T1 = 0; T1 < 8; ++T1) gu[T1] = mfma16(rv[T1], g2[c], gu[T1]);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
