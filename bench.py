@@ -457,6 +457,22 @@ def other_configs(cde, device, reps=3):
                                                            if k in ("n_accept", "n_reject")}}
     out["config5_default_method_seminorm_forward_adjoint_ms"] = once(lambda: solve_default(dict(adjoint_options=dict(norm="seminorm"))))
 
+    # the same pipeline at hidden size 32 (round 6: 32 hidden units x 14 channels, the upper unit groups of the output layer read
+    # from L2): rk4 forward + adjoint, and the reference's default call
+    torch.manual_seed(0)
+    field32 = TwoLayer(32, 14).to(device)
+    z32 = torch.randn(B, 32, generator=gen).to(device)
+
+    def solve32(extra):
+        z = z32.detach().requires_grad_(True)
+        Xl = state["X"]
+        cde.cdeint(Xl, field32, z, Xl.interval, **extra)[:, -1].sum().backward()
+
+    out["config5_hidden32_two_layer_forward_adjoint_ms"] = timed(lambda: solve32(dict(method="rk4", options={"step_size": 1.0})))
+    out["config5_hidden32_dispatch"] = front.last_dispatch()[0].path
+    solve32({})
+    out["config5_hidden32_default_method_forward_adjoint_ms"] = once(lambda: solve32({}))
+
     # the example model's own training call (example/time_series_classification.py:83-86: cdeint(X, CDEFunc, z0, X.interval),
     # 4096 series of the headline workload; round 2: 1.0 s forward + 34 s backward step-wise)
     torch.manual_seed(0)

@@ -99,9 +99,7 @@ enum {
   CDE_OPT_K4AM_NO_FSAL = 16,    /* 0 default; 1 evaluate every first stage (bit-identical results), 2 after accepted
                                    steps only, 3 after rejected steps only */
   CDE_OPT_WIDE_SCRATCH_BYTES = 17, /* 0 default (4 GB); otherwise the chunk budget of the wide-shape sweep in bytes */
-  CDE_OPT_SPLIT_FORM = 18,      /* small-batch rk4 kernels of the 32 x 8 affine / tanh field: 0 default (quad kernels where
-                                   they apply), 1 the workgroup-per-tile kernels K2s / K3s */
-  CDE_OPT_COUNT = 19
+  CDE_OPT_COUNT = 18
 };
 /* Set / read one entry of the tuning table.  cde_set_option returns CDE_ERR_SHAPE for an unknown key; cde_get_option
  * returns INT64_MIN for one.  cde_reset_options() restores every default. */

@@ -55,7 +55,6 @@ OPTIONS = {
     "k4am_no_small_reduce": (14, None), "k4am_sps": (15, None),
     "k4am_no_fsal": (16, {False: 0, True: 1, "accepted": 2, "rejected": 3}),
     "wide_scratch_bytes": (17, None),
-    "split_form": (18, {"default": 0, "quad": 0, "workgroup": 1}),
 }
 
 

@@ -1519,9 +1519,9 @@ static constexpr int64_t OPTION_DEFAULTS[CDE_OPT_COUNT] = {
     /* K3_FORM */ 0, /* K3_WAVES */ 0, /* K3D_WAVES */ 0, /* K2M_NO_SPLIT */ 0, /* K3M_NO_SPLIT */ 0, /* K3M_SPLIT4 */ 0,
     /* K3M_S8_TILES */ -1, /* K4_NO_SPLIT */ 0, /* K4M_NO_SPLIT */ 0, /* K4M_SPLIT_TILES */ -1, /* K4AM_WAVES */ 0,
     /* K4AM_S8_TILES */ -1, /* K4AM_SPLIT4 */ 0, /* K4AM_NO_SPLIT */ 0, /* K4AM_NO_SMALL_REDUCE */ 0, /* K4AM_SPS */ 0,
-    /* K4AM_NO_FSAL */ 0, /* WIDE_SCRATCH_BYTES */ 0, /* SPLIT_FORM */ 0};
+    /* K4AM_NO_FSAL */ 0, /* WIDE_SCRATCH_BYTES */ 0};
 static std::atomic<int64_t> g_options[CDE_OPT_COUNT] = {
-    {0}, {0}, {0}, {0}, {0}, {0}, {-1}, {0}, {0}, {-1}, {0}, {-1}, {0}, {0}, {0}, {0}, {0}, {0}, {0}};
+    {0}, {0}, {0}, {0}, {0}, {0}, {-1}, {0}, {0}, {-1}, {0}, {-1}, {0}, {0}, {0}, {0}, {0}, {0}};
 int64_t option(int key) { return g_options[key].load(std::memory_order_relaxed); }
 }  // namespace cde
 
