@@ -405,6 +405,8 @@ def test_reference_grad_paths_scenario_runs_fused(native, family, method):
     through the knot block alone (and `path` gets no gradient, as with the reference)."""
     knots_only = method == "rk4_knots_only"
     method = "rk4" if knots_only else method
+    rows = {("affine", "dopri5"): "affine_dopri5_control_block", ("affine", "rk4"): "affine_rk4_control",
+            ("two_layer", "dopri5"): "two_layer_dopri5_control_block", ("two_layer", "rk4"): "two_layer_rk4_control"}
     front = _front()
     B, L, C, H = 24, 9, 3, 4
     kw = dict(rtol=1e-3, atol=1e-5) if method == "dopri5" else dict(options=dict(step_size=0.25))
@@ -433,9 +435,7 @@ def test_reference_grad_paths_scenario_runs_fused(native, family, method):
             z = native.cdeint(X, func, z0, t_, adjoint=True, method=method,
                               adjoint_params=tuple(func.parameters()) + ((t,) if knots_only else (coeffs, t)), **kw)
         assert not any("step-wise" in str(w.message) for w in caught)
-        _expect_dispatch({("affine", "dopri5"): "affine_dopri5_control_block", ("affine", "rk4"): "affine_rk4_control",
-                          ("two_layer", "dopri5"): "two_layer_dopri5_control_block",
-                          ("two_layer", "rk4"): "two_layer_rk4_control"}[family, method], z)
+        _expect_dispatch(rows[family, method], z)
         fwd = dict(front.last_dopri5_stats)
         for leaf in (t, path, z0, t_) + tuple(func.parameters()):
             assert leaf.grad is None
