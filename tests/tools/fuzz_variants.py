@@ -32,7 +32,9 @@ class TwoLayer(torch.nn.Module):
 def draw(rng):
     kind = rng.choice(["affine", "affine", "tanh", "two_layer"])
     if kind == "two_layer":
-        H, C = rng.choice([(8, 3), (16, 14), (32, 8), (5, 2), (16, 16), (32, 4), (12, 9)])
+        # (round 6: 17..32 hidden units x 9..16 channels -- the upper half of the output layer read from L2)
+        H, C = rng.choice([(8, 3), (16, 14), (32, 8), (5, 2), (16, 16), (32, 4), (12, 9), (32, 14), (24, 16), (20, 9), (32, 16),
+                           (17, 12)])
     else:
         H = rng.choice([1, 3, 8, 16, 24, 31, 32, 33, 48, 64, 70])
         C = rng.choice([1, 2, 4, 7, 8, 9, 14, 16, 17]) if H <= 32 else rng.choice([1, 3, 8, 9])
@@ -40,7 +42,10 @@ def draw(rng):
                 B=rng.choice([1, 2, 15, 16, 17, 33, 100, 257]), L=rng.choice([2, 3, 5, 12, 30]),
                 degree=rng.choice([1, 3]), irregular=rng.random() < 0.5, extra_dim=rng.random() < 0.2,
                 mode=rng.choice(["rk4", "rk4", "dopri5_forward", "default_call", "midpoint", "euler", "rk4_backprop",
-                                 "rk4_backprop_control"]),
+                                 "rk4_backprop_control", "rk4_control", "default_call_control", "default_call_control"]),
+                # round 6 (the *_control modes): adjoint_params = parameters + (coeffs[, t]); the coefficients a leaf or fitted
+                # inside the graph with the same knot tensor (the reference's grad-paths scenario: the fit's chain)
+                knots=rng.random() < 0.5, fit_chain=rng.random() < 0.4, mixed_norm=rng.random() < 0.4,
                 step=rng.choice([1.0, 0.5, 0.37]), n_out=rng.choice([2, 3, 5]), seed=rng.randrange(10 ** 6))
 
 
@@ -58,10 +63,20 @@ def run(cfg, variant, dev):
     if cfg["mode"] == "rk4_backprop_control":         # the data require a gradient: fit -> control -> solve (adjoint=False) -> loss
         x.requires_grad_(True)
     t = ((torch.rand(L, generator=gen) + 0.4).cumsum(0) if cfg["irregular"] else torch.arange(L, dtype=torch.float32)).to(dev)
-    if cfg["degree"] == 3:
-        X = cde.CubicSpline(cde.hermite_cubic_coefficients_with_backward_differences(x, t), t)
-    else:
-        X = cde.LinearInterpolation(cde.linear_interpolation_coeffs(x, t), t)
+    control_mode = cfg["mode"] in ("rk4_control", "default_call_control")
+    leaves = []
+    if control_mode:
+        if cfg["knots"]:
+            t.requires_grad_(True)
+            leaves.append(t)
+        if cfg["fit_chain"]:
+            x.requires_grad_(True)
+            leaves.append(x)
+    fit = cde.hermite_cubic_coefficients_with_backward_differences if cfg["degree"] == 3 else cde.linear_interpolation_coeffs
+    coeffs = fit(x, t) if (not control_mode or cfg["fit_chain"]) else fit(x, t.detach()).detach().requires_grad_(True)
+    if control_mode and not cfg["fit_chain"]:
+        leaves.append(coeffs)
+    X = (cde.CubicSpline if cfg["degree"] == 3 else cde.LinearInterpolation)(coeffs, t)
     lo, hi = t[0].item(), t[-1].item()
     inner = torch.sort(torch.rand(cfg["n_out"] - 2, generator=gen) * (hi - lo) + lo).values
     t_out = torch.cat([torch.tensor([lo]), inner, torch.tensor([hi])]).to(dev)
@@ -76,6 +91,14 @@ def run(cfg, variant, dev):
     elif cfg["mode"] in ("rk4_backprop", "rk4_backprop_control"):   # round 5: adjoint=False, reverse mode through the steps (K3d) vs autograd
         out = cde.cdeint(X, func, z0, t_out, method="rk4", adjoint=False, options=dict(step_size=cfg["step"] * spacing),
                          variant=variant)
+    elif cfg["mode"] == "rk4_control":
+        out = cde.cdeint(X, func, z0, t_out, method="rk4", options=dict(step_size=cfg["step"] * spacing), variant=variant,
+                         adjoint_params=tuple(func.parameters()) + ((coeffs, t) if cfg["knots"] else (coeffs,)))
+    elif cfg["mode"] == "default_call_control":
+        opts = dict(jump_t=X.grid_points.detach()) if cfg["degree"] == 1 else {}
+        adj = dict(opts) if cfg["mixed_norm"] else dict(norm="seminorm", **opts)
+        out = cde.cdeint(X, func, z0, t_out, rtol=1e-6, atol=1e-8, options=opts, adjoint_options=adj, variant=variant,
+                         adjoint_params=tuple(func.parameters()) + ((coeffs, t) if cfg["knots"] else (coeffs,)))
     elif cfg["mode"] == "dopri5_forward":
         opts = dict(jump_t=X.grid_points) if cfg["degree"] == 1 else {}
         with torch.no_grad():
@@ -86,7 +109,8 @@ def run(cfg, variant, dev):
         out = cde.cdeint(X, func, z0, t_out, rtol=1e-6, atol=1e-8, options=opts,
                          adjoint_options=dict(norm="seminorm", **opts), variant=variant)
     (out * w).sum().backward()
-    return [out.detach(), z0.grad] + [p.grad for p in func.parameters()] + ([x.grad] if x.requires_grad else [])
+    return ([out.detach(), z0.grad] + [p.grad for p in func.parameters()] + ([x.grad] if x.requires_grad and not control_mode else [])
+            + [leaf.grad for leaf in leaves])
 
 
 def main():
@@ -101,7 +125,7 @@ def main():
         cfg = draw(rng)
         try:
             got, want = run(cfg, "auto", dev), run(cfg, "generic", dev)
-            tol = 2e-3 if cfg["mode"] in ("rk4", "midpoint", "euler", "rk4_backprop", "rk4_backprop_control") else 2e-2
+            tol = 2e-3 if cfg["mode"] in ("rk4", "midpoint", "euler", "rk4_backprop", "rk4_backprop_control", "rk4_control") else 2e-2
             for k, (g, r) in enumerate(zip(got, want)):
                 scale = max(r.abs().max().item(), 1e-3)
                 err = (g - r).abs().max().item()
