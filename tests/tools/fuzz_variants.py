@@ -95,7 +95,11 @@ def run(cfg, variant, dev):
         out = cde.cdeint(X, func, z0, t_out, method="rk4", options=dict(step_size=cfg["step"] * spacing), variant=variant,
                          adjoint_params=tuple(func.parameters()) + ((coeffs, t) if cfg["knots"] else (coeffs,)))
     elif cfg["mode"] == "default_call_control":
-        opts = dict(jump_t=X.grid_points.detach()) if cfg["degree"] == 1 else {}
+        # under "seminorm" the coefficient / knot blocks are integrated but not error-controlled, and their integrands jump at
+        # the knots (row e is read inside interval e only): two different step sequences -- this comparison -- then differ by
+        # percents unless the steps stop at the knots (seed 311 of round 6: three such cases, each within 1e-5 of the float64
+        # oracle replaying the fused run's own steps: profiles/r06_fuzz_seed311.log)
+        opts = dict(jump_t=X.grid_points.detach()) if (cfg["degree"] == 1 or not cfg["mixed_norm"]) else {}
         adj = dict(opts) if cfg["mixed_norm"] else dict(norm="seminorm", **opts)
         out = cde.cdeint(X, func, z0, t_out, rtol=1e-6, atol=1e-8, options=opts, adjoint_options=adj, variant=variant,
                          adjoint_params=tuple(func.parameters()) + ((coeffs, t) if cfg["knots"] else (coeffs,)))
