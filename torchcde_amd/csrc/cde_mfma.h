@@ -1,6 +1,7 @@
 // cde_mfma.h -- device pieces shared by the MFMA kernels (rk4_mfma.hip, dopri5.hip): fragment layouts,
 // weight images, packed-multiply helpers, control-row handling and the 16-series vector-field evaluation.
 #pragma once
+#include <type_traits>
 #include "cde_common.h"
 
 namespace cde {
@@ -480,13 +481,17 @@ __device__ __forceinline__ void stage_mlp16(const float* __restrict__ W1, const 
 // SPLIT (small batches, dopri5 forward): the 8 waves of a workgroup evaluate the SAME 16 series -- layer 1 redundantly and
 // bit-identically, unit group P of layer 2 by wave P alone -- and gather the NP values of f through `xwin` (LDS, 8 x 64
 // floats): 128 instead of 576 MFMAs per wave and evaluation.
-template <int ACT, int CT = MC, bool SPLIT = false>
+// HI (round 6): 16-channel layout with hidden units 16..31 as unit groups 4..7, read from the raw output layer (`hi`).  A
+// template flag: as a run-time one it cost the kernels of the plain 16-channel shape 40 % (K4, config 5 at hidden size 8:
+// 144 -> 201 us per attempted step -- twice the unrolled unit groups, their global loads hoisted across the stages).
+template <int ACT, int CT = MC, bool SPLIT = false, bool HI = false>
 __device__ __forceinline__ void field_mlp16(const float* img, int lane, int q, const f32x4& za, const f32x4& zb,
                                             const float (&dX)[CT], f32x4& fa, f32x4& fb, int pw = 0, float* xwin = nullptr,
                                             float* xu = nullptr, MlpHi hi = MlpHi{}) {
   constexpr int NB = CT / 4, NP = 16 / NB;
-  constexpr int NPX = CT == 16 ? 8 : NP;          // 16-channel layout: unit groups 4..7 exist when `hi` names the raw tensors
-  const bool has_hi = CT == 16 && hi.W2 != nullptr;
+  static_assert(!HI || CT == 16, "the upper half exists on the 16-channel layout");
+  constexpr int NPX = HI ? 8 : NP;                // unit groups 4..7: from the raw tensors `hi` names
+  constexpr bool has_hi = HI;
   if constexpr (SPLIT && CT == MC) {
     // Eight waves, 8-channel tiles (round 4): layer 1 is split as well -- wave pw computes hidden-layer tile pw (8 MFMAs
     // instead of 64 redundant ones), the 8 x 16 units meet in `xu` (8 KB of LDS, one barrier) and are read from there as
@@ -565,16 +570,17 @@ __device__ __forceinline__ void field_mlp16(const float* img, int lane, int q, c
   // ---- layer 2 + activation + contraction, one unit group (4 hidden units x CT channels = NB tiles) at a time
   fa = f32x4{0.f, 0.f, 0.f, 0.f};
   fb = fa;
-#pragma unroll
-  for (int P = 0; P < NPX; ++P) {
-    if (SPLIT && P != pw) continue;                          // (wave-uniform: another wave's unit group)
-    if (P >= NP && !has_hi) continue;                        // (uniform: no upper half)
+  // (the upper groups as a compile-time flag of the group body: LDS reads and global reads stay apart; outside the SPLIT form
+  //  they run as a ROLLED loop -- four more unrolled groups per evaluation in a kernel that unrolls six evaluations spilled 500
+  //  registers)
+  auto group = [&](int P, auto upper_c) {
+    constexpr bool upper = decltype(upper_c)::value;
     f32x4 y[NB];
     const float* hrow[NB];                                   // upper half: this lane's row (h, c) of W2, at its column 4 kq
     bool hrow_ok[NB];
 #pragma unroll
     for (int tb = 0; tb < NB; ++tb) {
-      if (P < NP) {
+      if constexpr (!upper) {
         const float4 c0 = bb2[4 * (NB * P + tb)];
         y[tb] = f32x4{c0.x, c0.y, c0.z, c0.w};
         hrow[tb] = nullptr; hrow_ok[tb] = false;
@@ -592,7 +598,7 @@ __device__ __forceinline__ void field_mlp16(const float* img, int lane, int q, c
       float4 a[NB];
 #pragma unroll
       for (int tb = 0; tb < NB; ++tb) {
-        if (P < NP) a[tb] = w2[(8 * (NB * P + tb) + g) * 64];                      // tile NB*P + tb: groups 8T .. 8T+7
+        if constexpr (!upper) a[tb] = w2[(8 * (NB * P + tb) + g) * 64];            // tile NB*P + tb: groups 8T .. 8T+7
         else a[tb] = (hrow_ok[tb] && 16 * g + 4 * (lane >> 4) < hi.width) ? *reinterpret_cast<const float4*>(hrow[tb] + 16 * g)
                                                                           : make_float4(0.f, 0.f, 0.f, 0.f);
       }
@@ -615,8 +621,30 @@ __device__ __forceinline__ void field_mlp16(const float* img, int lane, int q, c
       f = __builtin_fmaf(t23[0], dX[4 * tb + 2], f);
       f = __builtin_fmaf(t23[1], dX[4 * tb + 3], f);
     }
-    if (P < 4) fa[P] = f; else fb[P - 4] = f;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { fa[kk] = P == kk ? f : fa[kk]; fb[kk] = P == 4 + kk ? f : fb[kk]; }
     __builtin_amdgcn_sched_barrier(0);
+  };
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int P = 0; P < NP; ++P) {
+      if (P != pw) continue;                                 // (wave-uniform: another wave's unit group)
+      group(P, std::false_type{});
+    }
+    if constexpr (HI) {
+#pragma unroll
+      for (int P = NP; P < NPX; ++P) {
+        if (P != pw) continue;
+        group(P, std::true_type{});
+      }
+    }
+  } else {
+#pragma unroll
+    for (int P = 0; P < NP; ++P) group(P, std::false_type{});
+    if constexpr (HI) {
+#pragma clang loop unroll(disable)
+      for (int P = NP; P < NPX; ++P) group(P, std::true_type{});
+    }
   }
   if constexpr (SPLIT) {
     // wave P holds f of unit group P (waves beyond the last group hold nothing): everybody collects all of them

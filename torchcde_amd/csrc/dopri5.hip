@@ -385,7 +385,8 @@ __device__ unsigned long long k4_phase_trace[TRACE_RING * TRACE_BLOCKS * TRACE_S
 // it, writes outputs and contributes to the error sums.
 constexpr int DOPRI_XWIN_FLOATS = 8 * 64;
 constexpr int64_t DOPRI_MLP_SPLIT_TILES = 768;   // two-layer field, 8-channel tiles: the eight waves of a workgroup share a tile (forward 8192 series: 105 -> 51 ms, 16384: tie)
-template <int DEGREE, int ACT, bool MLP = false, int CT = MC, bool SPLIT = false>
+// HI (round 6): the two-layer field with 17..32 hidden units on the 16-channel layout (cde_mfma.h: field_mlp16<.., HI>)
+template <int DEGREE, int ACT, bool MLP = false, int CT = MC, bool SPLIT = false, bool HI = false>
 __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g, int parity) {
   static_assert(CT == MC || MLP, "16-channel tiles: two-layer fields only");
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -418,8 +419,8 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   const Dims dims{(int)g.H, (int)g.C};
   const int Hr = dims.H;
   // two-layer field with more than 16 hidden units on the 16-channel layout: unit groups 4..7 from the raw output layer
-  const MlpHi mlp_hi = (MLP && CT == 16 && dims.H > 16) ? MlpHi{(const float*)g.W, (const float*)g.bias, dims.H, dims.C, g.width}
-                                                        : MlpHi{};
+  static_assert(!HI || (MLP && CT == 16), "the upper half: two-layer field, 16-channel layout");
+  const MlpHi mlp_hi = HI ? MlpHi{(const float*)g.W, (const float*)g.bias, dims.H, dims.C, g.width} : MlpHi{};
   double* red = reinterpret_cast<double*>(lds);                    // 2 * 512 doubles
   // The knot search of every stage time is a chain of dependent loads: from global memory that is ~7 x 0.3 us per
   // stage (it dominated this kernel); the knots are copied to LDS once per launch instead.
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(512, 2) void dopri5_attempt_mfma(DopriArgs<float> g
   const float4* wy = reinterpret_cast<const float4*>(img_lds) + lane;
   const float4* by = reinterpret_cast<const float4*>(img_lds + WY_FLOATS) + q;
   auto field = [&](const f32x4& za, const f32x4& zb, const float (&dXv)[CT], f32x4& fa, f32x4& fb) {
-    if constexpr (MLP) field_mlp16<ACT, CT, SPLIT>(img_lds, lane, q, za, zb, dXv, fa, fb, wave, xwin, reinterpret_cast<float*>(red), mlp_hi);
+    if constexpr (MLP) field_mlp16<ACT, CT, SPLIT, HI>(img_lds, lane, q, za, zb, dXv, fa, fb, wave, xwin, reinterpret_cast<float*>(red), mlp_hi);
     else if constexpr (CT == MC) {
       if constexpr (PRODUCT && SPLIT) field16_split(sg0, sg1, sh0, sh1, sba, sbb, za, zb, dXv, q, fa, fb, wave, xwin, lane);
       else if constexpr (PRODUCT) field16(wA, wB, za, zb, dXv, q, fa, fb);
@@ -1203,24 +1204,24 @@ static int dopri5_advance_impl(const void* coeffs, const void* knots, int64_t n_
       const int64_t split_tiles = split_req >= 0 && split_req < split_max ? split_req : split_max;
       const bool split = tiles <= split_tiles && !ext_sums && B_global == 0 && !cde::option(CDE_OPT_K4M_NO_SPLIT);
       const size_t lds_split = lds + (size_t)cde::DOPRI_XWIN_FLOATS * sizeof(float);
-#define CDE_MLP_CT(D, A, CTV)                                                                                      \
+#define CDE_MLP_CT(D, A, CTV, HIV)                                                                                 \
   do {                                                                                                             \
     if (split) {                                                                                                   \
-      (void)hipFuncSetAttribute((const void*)cde::dopri5_attempt_mfma<D, A, true, CTV, true>,                      \
+      (void)hipFuncSetAttribute((const void*)cde::dopri5_attempt_mfma<D, A, true, CTV, true, HIV>,                 \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split);                       \
       for (int64_t i = 0; i < n_launches; ++i)                                                                     \
-        cde::dopri5_attempt_mfma<D, A, true, CTV, true><<<(unsigned)tiles, 512, lds_split, s>>>(                   \
+        cde::dopri5_attempt_mfma<D, A, true, CTV, true, HIV><<<(unsigned)tiles, 512, lds_split, s>>>(              \
             g, (int)((first_launch + i) & 1));                                                                     \
     } else {                                                                                                       \
-      (void)hipFuncSetAttribute((const void*)cde::dopri5_attempt_mfma<D, A, true, CTV>,                            \
+      (void)hipFuncSetAttribute((const void*)cde::dopri5_attempt_mfma<D, A, true, CTV, false, HIV>,                \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                             \
       for (int64_t i = 0; i < n_launches; ++i)                                                                     \
-        cde::dopri5_attempt_mfma<D, A, true, CTV><<<grid, 512, lds, s>>>(g, (int)((first_launch + i) & 1));        \
+        cde::dopri5_attempt_mfma<D, A, true, CTV, false, HIV><<<grid, 512, lds, s>>>(g, (int)((first_launch + i) & 1)); \
     }                                                                                                              \
   } while (0)
 #define CDE_MLP(D, A)                                                                                              \
   do {                                                                                                             \
-    if (C > cde::MC) CDE_MLP_CT(D, A, 16); else CDE_MLP_CT(D, A, cde::MC);                                         \
+    if (mlp_upper) CDE_MLP_CT(D, A, 16, true); else if (C > cde::MC) CDE_MLP_CT(D, A, 16, false); else CDE_MLP_CT(D, A, cde::MC, false); \
   } while (0)
       if (act == CDE_ACT_NONE) {
         if (degree == CDE_PATH_CUBIC) CDE_MLP(CDE_PATH_CUBIC, CDE_ACT_NONE); else CDE_MLP(CDE_PATH_LINEAR, CDE_ACT_NONE);

@@ -44,6 +44,10 @@ constexpr int MADJ_MAX_SPS = 40;                 // slabs per stage of the facto
 constexpr int64_t MADJ_S8_MAX_TILES = 768;       // eight waves per tile (8-channel tiles), several rounds: see madj_layout
 constexpr int64_t MADJ_SPLIT_MAX_TILES = 256;    // batches up to 4096 series (one tile per CU): four waves per tile (K4am's split form)
 constexpr int MADJ_NSUM = ADJ_NS + 2 * ADJ_MAX_PT;
+// without control gradients the mixed norm has the four parameter blocks only: the prologue then carries (and reduces) 16 sums,
+// not 20 -- with 20 the eight-wave kernel, which sits at the register limit with its prefetches in flight, ran 5 % slower
+// (81.8 -> 86.1 us per attempted step, profiles/r06_bench_kernel_stats.csv against r05's)
+constexpr int MADJ_NSUM_PLAIN = ADJ_NS + 8;
 __host__ __device__ constexpr int madj_slot(int stage) { return stage == 0 ? 0 : stage - 1; }      // stage 1 is never stored
 
 struct MlpAdjArgs {
@@ -122,9 +126,10 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
   const float rtol = (float)g.com.rtol, atol = (float)g.com.atol;
 
   // ---- pending sums: the state sums of the previous attempt launch, the parameter sums its R kernel left
-  double sum[MADJ_NSUM];
+  constexpr int NSUM = DCTRL ? MADJ_NSUM : MADJ_NSUM_PLAIN;
+  double sum[NSUM];
 #pragma unroll
-  for (int i = 0; i < MADJ_NSUM; ++i) sum[i] = 0.0;
+  for (int i = 0; i < NSUM; ++i) sum[i] = 0.0;
   if (c.phase != 0) {
     for (int64_t b = tid; b < (int64_t)gridDim.x; b += blockDim.x) {
 #pragma unroll
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adj
 #pragma unroll
     for (int i = 0; i < ADJ_NS; ++i) sum[i] = tid == 0 ? g.ext_sums[i] : 0.0;
   }
-  block_total<MADJ_NSUM>(sum, red);                                // (also the barrier after the LDS image copy)
+  block_total<NSUM>(sum, red);                                     // (also the barrier after the LDS image copy)
   CDE_STAMP(1);
   const int phase_in = c.phase;
   const AdjPlan plan = adj_controller(g.com, k, sum, sum + ADJ_NS);
@@ -573,9 +578,10 @@ __global__ __launch_bounds__(512, 2) void dopri5_mlp_adjoint_attempt_s8(MlpAdjAr
   // the pending sums are requested together with the controller block, not after it (both were written by the previous
   // launches, on other XCDs: each dependent round trip through the memory side costs ~2 us); before the first attempt
   // of an interval they are ignored
-  double sum[MADJ_NSUM];
+  constexpr int NSUM = MADJ_NSUM_PLAIN;                            // (this kernel has no control-gradient form)
+  double sum[NSUM];
 #pragma unroll
-  for (int i = 0; i < MADJ_NSUM; ++i) sum[i] = 0.0;
+  for (int i = 0; i < NSUM; ++i) sum[i] = 0.0;
   {
     const double* Pp0 = g.partial + (int64_t)p * g.n_wg_max * ADJ_NS;
     for (int64_t b = tid; b < (int64_t)gridDim.x; b += blockDim.x) {
@@ -650,13 +656,13 @@ __global__ __launch_bounds__(512, 2) void dopri5_mlp_adjoint_attempt_s8(MlpAdjAr
   // ---- pending sums, controller, stage scalars: as in dopri5_mlp_adjoint_attempt
   if (c.phase == 0) {
 #pragma unroll
-    for (int i = 0; i < MADJ_NSUM; ++i) sum[i] = 0.0;
+    for (int i = 0; i < NSUM; ++i) sum[i] = 0.0;
   } else if (g.ext_sums) {                                         // one controller for all shards: the reduced state sums
 #pragma unroll
     for (int i = 0; i < ADJ_NS; ++i) sum[i] = tid == 0 ? g.ext_sums[i] : 0.0;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's part of the LDS image has landed ..
-  block_total<MADJ_NSUM>(sum, red);                                // .. and, past its barriers, everybody's
+  block_total<NSUM>(sum, red);                                     // .. and, past its barriers, everybody's
   CDE_STAMP(1);
   const int phase_in = c.phase;
   const AdjPlan plan = adj_controller(g.com, k, sum, sum + ADJ_NS);

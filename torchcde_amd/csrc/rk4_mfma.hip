@@ -66,8 +66,9 @@ template <int ACT, bool MLP> constexpr int fwd_waves_per_simd() { return 2; }
 // 8q .. 8q+7 are two 16-byte stores) -- what reverse-mode autograd would keep of torchdiffeq's rk4 step.
 // METHOD (CDE_METHOD_*): the same skeleton for torchdiffeq's other fixed-grid methods (reference test/test_cdeint.py:49-63
 // runs `midpoint`) -- two stages (midpoint) or one (euler) per step instead of the four of the 3/8 rule.
+// HI (round 6): the two-layer field with 17..32 hidden units on the 16-channel layout (cde_mfma.h: field_mlp16<.., HI>)
 template <typename TT, int DEGREE, int ACT, bool MLP = false, int CT = MC, bool SPLIT = false, bool SAVE = false,
-          int METHOD = CDE_METHOD_RK4>
+          int METHOD = CDE_METHOD_RK4, bool HI = false>
 __global__ __launch_bounds__((fwd_block_threads<ACT, MLP>()), (fwd_waves_per_simd<ACT, MLP>())) void rk4_forward_mfma(
     const float* __restrict__ coeffs, const float* __restrict__ knots, int64_t n_intervals,
     const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ z0,
@@ -102,7 +103,8 @@ __global__ __launch_bounds__((fwd_block_threads<ACT, MLP>()), (fwd_waves_per_sim
   const int64_t sc = in_range ? series : B - 1;
   float* xwin = lds + MLP16_LDS_FLOATS;                           // (SPLIT only: 8 x 64 floats behind the images)
   // two-layer field with more than 16 hidden units on the 16-channel layout: unit groups 4..7 from the raw output layer
-  const MlpHi mlp_hi = (MLP && CT == 16 && dims.H > 16) ? MlpHi{W, bias, dims.H, dims.C, width} : MlpHi{};
+  static_assert(!HI || (MLP && CT == 16), "the upper half: two-layer field, 16-channel layout");
+  const MlpHi mlp_hi = HI ? MlpHi{W, bias, dims.H, dims.C, width} : MlpHi{};
 
   // this lane's 8 hidden units in two groups of 4 (zero beyond the real hidden size)
   const int ua = PRODUCT ? 8 * q : q, ub = PRODUCT ? 8 * q + 4 : 16 + q;
@@ -163,7 +165,7 @@ __global__ __launch_bounds__((fwd_block_threads<ACT, MLP>()), (fwd_waves_per_sim
 
       f32x4 fa, fb;
       if constexpr (PRODUCT) { if constexpr (CT == MC) field16(wA, wB, za, zb, dX, q, fa, fb); }
-      else if constexpr (MLP) field_mlp16<ACT, CT, SPLIT>(lds, lane, q, za, zb, dX, fa, fb, wave, xwin, xwin + 8 * 64, mlp_hi);
+      else if constexpr (MLP) field_mlp16<ACT, CT, SPLIT, HI>(lds, lane, q, za, zb, dX, fa, fb, wave, xwin, xwin + 8 * 64, mlp_hi);
       else { if constexpr (CT == MC) field_act16<ACT>(wy, by, za, zb, dX, fa, fb); }
       if constexpr (!PRODUCT) {
         __builtin_amdgcn_sched_barrier(0);
@@ -1207,19 +1209,19 @@ int launch_forward_mlp(const void* coeffs, const void* knots, int64_t n_interval
   const int64_t tiles = (B + 15) / 16;
   const bool split = tiles <= 768 && !option(CDE_OPT_K2M_NO_SPLIT);
   const size_t lds_split = lds + (8 * 64 + 8 * 64 * 4) * sizeof(float);     // f window + (8-channel tiles) the u window
-#define CDE_FWD_CT(D, A, CTV)                                                                                       \
+#define CDE_FWD_CT(D, A, CTV, HIV)                                                                                  \
   do {                                                                                                              \
     if (split) {                                                                                                    \
-      (void)hipFuncSetAttribute((const void*)rk4_forward_mfma<TT, D, A, true, CTV, true>,                           \
+      (void)hipFuncSetAttribute((const void*)rk4_forward_mfma<TT, D, A, true, CTV, true, false, CDE_METHOD_RK4, HIV>, \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split);                        \
-      rk4_forward_mfma<TT, D, A, true, CTV, true><<<(unsigned)tiles, 512, lds_split, s>>>(                          \
+      rk4_forward_mfma<TT, D, A, true, CTV, true, false, CDE_METHOD_RK4, HIV><<<(unsigned)tiles, 512, lds_split, s>>>( \
           (const float*)coeffs, (const float*)knots, n_intervals, (const float*)W2, (const float*)bias2,            \
           (const float*)z0, (const TT*)grid, n_grid, (const TT*)t_out, n_out, (float*)z_out, B, stage_index,        \
           (const float*)stage_frac, dims, (const float*)W1, (const float*)bias1, (int)width);                       \
     } else {                                                                                                        \
-      (void)hipFuncSetAttribute((const void*)rk4_forward_mfma<TT, D, A, true, CTV>,                                 \
+      (void)hipFuncSetAttribute((const void*)rk4_forward_mfma<TT, D, A, true, CTV, false, false, CDE_METHOD_RK4, HIV>, \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
-      rk4_forward_mfma<TT, D, A, true, CTV><<<blocks, 512, lds, s>>>(                                               \
+      rk4_forward_mfma<TT, D, A, true, CTV, false, false, CDE_METHOD_RK4, HIV><<<blocks, 512, lds, s>>>(            \
           (const float*)coeffs, (const float*)knots, n_intervals, (const float*)W2, (const float*)bias2,            \
           (const float*)z0, (const TT*)grid, n_grid, (const TT*)t_out, n_out, (float*)z_out, B, stage_index,        \
           (const float*)stage_frac, dims, (const float*)W1, (const float*)bias1, (int)width);                       \
@@ -1227,7 +1229,7 @@ int launch_forward_mlp(const void* coeffs, const void* knots, int64_t n_interval
   } while (0)
 #define CDE_FWD(D, A)                                                                                               \
   do {                                                                                                              \
-    if (wide) CDE_FWD_CT(D, A, 16); else CDE_FWD_CT(D, A, MC);                                                      \
+    if (upper) CDE_FWD_CT(D, A, 16, true); else if (wide) CDE_FWD_CT(D, A, 16, false); else CDE_FWD_CT(D, A, MC, false); \
   } while (0)
   if (act == CDE_ACT_NONE) {
     if (degree == CDE_PATH_CUBIC) CDE_FWD(CDE_PATH_CUBIC, CDE_ACT_NONE); else CDE_FWD(CDE_PATH_LINEAR, CDE_ACT_NONE);
@@ -1283,18 +1285,18 @@ int launch_forward_mlp_stages(const void* coeffs, const void* knots, int64_t n_i
   const Dims dims{(int)H, (int)C};
   const unsigned blocks = (unsigned)((B + 127) / 128);
   const size_t lds = (size_t)MLP16_LDS_FLOATS * sizeof(float);
-#define CDE_FWD_MS(D, A, CTV)                                                                                       \
+#define CDE_FWD_MS(D, A, CTV, HIV)                                                                                  \
   do {                                                                                                              \
-    (void)hipFuncSetAttribute((const void*)rk4_forward_mfma<TT, D, A, true, CTV, false, true>,                      \
+    (void)hipFuncSetAttribute((const void*)rk4_forward_mfma<TT, D, A, true, CTV, false, true, CDE_METHOD_RK4, HIV>, \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
-    rk4_forward_mfma<TT, D, A, true, CTV, false, true><<<blocks, 512, lds, s>>>(                                    \
+    rk4_forward_mfma<TT, D, A, true, CTV, false, true, CDE_METHOD_RK4, HIV><<<blocks, 512, lds, s>>>(               \
         (const float*)coeffs, (const float*)knots, n_intervals, (const float*)W2, (const float*)bias2,              \
         (const float*)z0, (const TT*)grid, n_grid, (const TT*)t_out, n_out, (float*)z_out, B, stage_index,          \
         (const float*)stage_frac, dims, (const float*)W1, (const float*)bias1, (int)width, (float*)stages);         \
   } while (0)
 #define CDE_FWD_MSD(D, A)                                                                                           \
   do {                                                                                                              \
-    if (C > MC) CDE_FWD_MS(D, A, 16); else CDE_FWD_MS(D, A, MC);                                                    \
+    if (H > 16 && C > MC) CDE_FWD_MS(D, A, 16, true); else if (C > MC) CDE_FWD_MS(D, A, 16, false); else CDE_FWD_MS(D, A, MC, false); \
   } while (0)
   if (act == CDE_ACT_NONE) {
     if (degree == CDE_PATH_CUBIC) CDE_FWD_MSD(CDE_PATH_CUBIC, CDE_ACT_NONE); else CDE_FWD_MSD(CDE_PATH_LINEAR, CDE_ACT_NONE);
