@@ -1058,3 +1058,42 @@ def test_reverse_mode_recurrences_of_the_rk4_backprop_kernel_equal_autograd_thro
             # a contraction of the coefficient gradient itself (cdeint.py: _plan_time_gradients)
             per_interval = (coeffs[..., 2 * C:3 * C] * gx[..., C:2 * C] + 2 * coeffs[..., 3 * C:] * gx[..., 2 * C:3 * C]).sum((0, 2))
             assert torch.allclose(torch.cat([-per_interval, per_interval.new_zeros(1)]), knots.grad, rtol=1e-6, atol=1e-9)
+
+
+def test_fit_chain_detection_walks_the_autograd_graph():
+    """Round 6: torchdiffeq's knot block (`autograd.grad(f, adjoint_params)`) runs through the fit that produced the coefficients
+    when the SAME knot tensor went into it (reference test/test_tricks.py:21-49).  cdeint._knot_fit_chain decides that by walking
+    the autograd graph of the path's buffers -- no GPU involved: leaf coefficients have no chain, fitted ones do, for a leaf knot
+    tensor and for one that is itself computed; and the chain's vector-Jacobian product is what autograd gives."""
+    import types
+    import sys
+    from oracle import interp
+    front = sys.modules["torchcde_amd.cdeint"]                      # (the package exports the function under the same name)
+    t = torch.linspace(0, 4, 5, dtype=torch.float64, requires_grad=True)
+    x = torch.randn(3, 5, 2, dtype=torch.float64, generator=torch.Generator().manual_seed(0))
+    fitted = interp.hermite_bdiff_coeffs(x, t)
+    C = 2
+
+    def path(coeffs, knots):
+        bufs = (coeffs[..., C:2 * C], coeffs[..., 2 * C:3 * C], coeffs[..., 3 * C:])
+        return types.SimpleNamespace(_t=knots, _control_buffers=lambda: bufs)
+
+    assert front._reaches(fitted, t) and not front._reaches(fitted.detach().requires_grad_(True), t)
+    assert front._knot_fit_chain(path(fitted.detach().requires_grad_(True), t)) is None           # leaf coefficients: nothing to add
+    assert front._knot_fit_chain(path(fitted, t.detach())) is None                                # knots without a gradient
+    chain = front._knot_fit_chain(path(fitted, t))
+    assert chain is not None and len(chain[0]) == 3 and chain[2] is t
+    u = t * 1.5                                                                                    # a knot tensor that is itself computed
+    fitted_u = interp.hermite_bdiff_coeffs(x, u)
+    assert front._reaches(fitted_u, u) and not front._reaches(fitted, u)
+    assert front._knot_fit_chain(path(fitted_u, u)) is not None
+    # the added term = the fit's vector-Jacobian product with dL/dcoeffs (b, 2c, 3d blocks; the derivative never reads `a`)
+    plan = types.SimpleNamespace(fit_chain=chain, C=C, batch=(3,), degree=_lib.PATH_CUBIC)
+    g = torch.randn(3, 4, 4 * C, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    direct = torch.arange(5, dtype=torch.float64)
+    got = front._with_fit_chain(plan, direct.clone(), g)
+    gz = g.clone()
+    gz[..., :C] = 0
+    (want,) = torch.autograd.grad(fitted, t, gz, retain_graph=True)
+    assert torch.allclose(got, direct + want, rtol=1e-12, atol=1e-14)
+    assert front._with_fit_chain(types.SimpleNamespace(fit_chain=None), direct, g) is direct

@@ -795,13 +795,14 @@ def _reaches(tensor, leaf):
     start = getattr(tensor, "grad_fn", None)
     if start is None:
         return False
+    target = leaf.grad_fn                       # (a knot tensor that is itself computed: its own node is what the graph reaches)
     seen, stack = set(), [start]
     while stack:
         node = stack.pop()
         if node is None or node in seen:
             continue
         seen.add(node)
-        if getattr(node, "variable", None) is leaf:
+        if (target is not None and node is target) or (target is None and getattr(node, "variable", None) is leaf):
             return True
         stack.extend(fn for fn, _ in node.next_functions)
     return False
@@ -817,7 +818,7 @@ def _knot_fit_chain(X):
     integrals are linear in it), added on the host (_with_fit_chain).  With the coefficient tensor in adjoint_params too
     the reference thus counts the fit's chain twice -- once inside the knot block, once when the returned dL/dcoeffs flows
     back through the fit -- and so does this path (the float64 oracle, built on autograd the same way, shows the same)."""
-    if not (isinstance(X._t, torch.Tensor) and X._t.requires_grad and X._t.grad_fn is None):
+    if not (isinstance(X._t, torch.Tensor) and X._t.requires_grad):
         return None
     buffers = tuple(b for b in X._control_buffers() if _reaches(b, X._t))
     return (buffers, tuple(X._control_buffers()), X._t) if buffers else None
