@@ -623,7 +623,7 @@ def test_two_layer_dopri5_adjoint_control_gradients_fused(native, case):
         _close(got.grad, want.grad, 2e-3, 2e-3 * want.grad.abs().max().item())
 
 
-@pytest.mark.parametrize("form", ["split", "four_waves", "one_wave_per_tile"])
+@pytest.mark.parametrize("form", ["split", "four_waves", "one_wave_per_tile", "one_wave_per_tile_eight_per_workgroup"])
 @pytest.mark.parametrize("case", ["example_model", "config5_shape_seminorm", "multi_out_jumps", "upper_half_32x14",
                                   "upper_half_cubic_4200", "upper_half_multi_out_150"])
 def test_two_layer_default_call_runs_fused_with_torchdiffeqs_decisions(native, monkeypatch, case, form):
@@ -641,13 +641,19 @@ def test_two_layer_default_call_runs_fused_with_torchdiffeqs_decisions(native, m
     and all FOUR parameter gradients.  A relu field is only piecewise smooth: where the float32 and float64 states sit on
     different sides of a kink at some stage, an attempt's error estimate differs visibly, so up to 3 % of the attempts
     may leave the 2 % + 0.01 band (observed: 3 of 583 on the multi-output case, none elsewhere)."""
-    if case.startswith("upper_half") and form != "split":
-        pytest.skip("32 hidden units x 16 channels: the backward has the four-wave form only")
+    if form == "one_wave_per_tile_eight_per_workgroup":
+        # the workgroup shape of batches beyond 16384 series (eight one-wave tiles per workgroup, two waves per SIMD), here on
+        # the 32 x 14 shape's three tiles: the upper unit groups as a rolled loop inside seven unrolled stages
+        if case != "upper_half_32x14":
+            pytest.skip("covered at size: test_config5_as_the_reference_calls_it_against_the_oracle[8192-eight_waves-8]")
+        native.set_option("k4am_waves", 8)
+    if case == "upper_half_cubic_4200" and form != "split":
+        pytest.skip("263 tiles: beyond one round of shared tiles this shape runs one wave per tile by default")
     if form == "four_waves":
-        if case == "config5_shape_seminorm":
+        if case == "config5_shape_seminorm" or case.startswith("upper_half"):
             pytest.skip("16-channel tiles always take the four-wave form")
         native.set_option("k4am_split4", 1)          # backward: four waves per tile instead of eight (round 3's split form)
-    if form == "one_wave_per_tile":
+    if form.startswith("one_wave_per_tile"):
         native.set_option("k4am_no_small_reduce", 1)  # the split-K factor reduction + R kernel of larger batches
         native.set_option("k4am_no_split", 1)        # backward: K4am
         native.set_option("k4m_no_split", 1)         # forward: K4 with the two-layer field
@@ -660,7 +666,7 @@ def test_two_layer_default_call_runs_fused_with_torchdiffeqs_decisions(native, m
                                    adj={}),
            # config 5 at hidden size 32 (round 6): 32 hidden units x 14 channels -- the upper unit groups from the padded copy
            # of the output layer, their gradient images a second instance of the reduction / commit kernels; 4200 series: 263
-           # tiles, more than one round of workgroups (band: the relu kinks of a batch that size in the W1 block, as for the
+           # tiles -- beyond one round of shared tiles, so the one-wave-per-tile form with the upper groups (band: the relu kinks of a batch that size in the W1 block, as for the
            # control-gradient cases above -- tests/tools/debug_k4am_upper.py lists the deciding block of every deviating
            # attempt, profiles/r06_k4am_upper_debug.log: W1 throughout, gradients within 1.2e-4 of the oracle's)
            "upper_half_32x14": dict(B=40, L=8, C=14, H=32, width=128, tanh=True, degree=1, t_out=None, jumps=False, adj={}),

@@ -98,7 +98,7 @@ __device__ __forceinline__ void mlp_adjoint_eval(const float* lds_base, const fl
   // 32 units x 16 channels (`hi`, round 6): unit groups NP .. 7 as well, their rows of W2 / b2 from the zero-padded copy behind
   // the images (mlp_adj_hi), their dL/dY2 rows into a second row block (`g2row_hi`: the same padded layout, units 16..31)
   // (HI is a template flag: the kernels of the other shapes compile exactly as before)
-  static_assert(!HI || (CT == 16 && SPLIT), "the upper half exists for 16-channel tiles, in the four-wave form");
+  static_assert(!HI || CT == 16, "the upper half exists for 16-channel tiles");
   constexpr int NPX = HI ? 8 : NP;
   constexpr bool has_hi = HI;
   const bool writer = !SPLIT || pw == 0;        // the wave that streams the factor rows every wave holds (U, Z, G1)
@@ -246,7 +246,9 @@ __device__ __forceinline__ void mlp_adjoint_eval(const float* lds_base, const fl
 #pragma unroll
     for (int P = 0; P < NP; ++P) group(P, std::false_type{});
     if constexpr (NPX > NP) {
-#pragma unroll
+      // (a ROLLED loop: the one-wave-per-tile kernels unroll their seven stages -- four more unrolled unit groups per stage,
+      //  with their global loads hoisted across the stages, spilled over a thousand registers)
+#pragma clang loop unroll(disable)
       for (int P = NP; P < NPX; ++P) group(P, std::true_type{});
     }
   }

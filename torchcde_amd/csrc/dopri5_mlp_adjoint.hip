@@ -93,7 +93,7 @@ __device__ unsigned long long k4am_phase_trace[TRACE_RING * TRACE_BLOCKS * TRACE
 template <int DEGREE, int ACT, int CT, int NWAVE, bool SPLIT = false, bool DCTRL = false, bool HI = false>
 __global__ __launch_bounds__(64 * NWAVE, NWAVE == 8 ? 2 : 1) void dopri5_mlp_adjoint_attempt(MlpAdjArgs g, int parity) {
   static_assert(!SPLIT || NWAVE == 4, "this kernel's split form is four waves per tile (eight: dopri5_mlp_adjoint_attempt_s8)");
-  static_assert(!HI || (SPLIT && CT == 16), "the upper half: 16-channel tiles, four waves per tile");
+  static_assert(!HI || CT == 16, "the upper half: 16-channel tiles");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int p = parity, p2 = parity ^ 1;
@@ -1196,7 +1196,7 @@ MadjLayout madj_layout(int64_t B, int64_t H, int64_t C) {
   // (tests: the 8-wave kernel at a size the CPU oracle can follow)
   L.upper = mlp_shape_upper(C, H, 4);
   L.pq_blocks = L.upper ? 2 * MADJ_RBLOCKS : MADJ_RBLOCKS;
-  L.nwave = ((L.n_tiles > 1024 || option(CDE_OPT_K4AM_WAVES) == 8) && !L.upper) ? 8 : 4;
+  L.nwave = (L.n_tiles > 1024 || option(CDE_OPT_K4AM_WAVES) == 8) ? 8 : 4;
   // up to MADJ_SPLIT_MAX_TILES tiles (one workgroup per CU in a single round): four waves per tile, the evaluation's middle
   // split four ways
   // (8-channel tiles: the eight-wave form takes ~75 us per round of 256 tiles, the one-wave-per-tile forms 260-420 us
@@ -1208,7 +1208,6 @@ MadjLayout madj_layout(int64_t B, int64_t H, int64_t C) {
   L.split = L.n_tiles <= (s8_shape && s8_tiles > MADJ_SPLIT_MAX_TILES ? s8_tiles : MADJ_SPLIT_MAX_TILES) &&
             !option(CDE_OPT_K4AM_NO_SPLIT);
   // ... eight (two per SIMD, everything split eight ways: mlp_adjoint_eval_split8) when the control fits the 32 x 8 tiling
-  if (L.upper) L.split = true;                     // (32 x 16: the four-wave form at any batch, one workgroup per tile)
   L.split8 = L.split && C <= MC && !option(CDE_OPT_K4AM_SPLIT4);
   // a few hundred rows per attempt: factor reduction + R in one launch (mlp_adjoint_small_reduce_kernel)
   L.small = B <= MADJ_SMALL_MAX_ROWS && !option(CDE_OPT_K4AM_NO_SMALL_REDUCE) && !L.upper;
@@ -1432,16 +1431,16 @@ static int dopri5_adjoint_mlp_advance_impl(const void* coeffs, const void* knots
   };
   const size_t lds_bytes = (size_t)ADJ_LDS_FLOATS * sizeof(float) + (size_t)MADJ_NSUM * 8 * sizeof(double) +
                            (L.split ? (size_t)MADJ_XBUF_FLOATS * sizeof(float) : 0);
-#define CDE_MADJ_LAUNCH(D, A, CTV, NWV, SPL)                                                                         \
+#define CDE_MADJ_LAUNCH(D, A, CTV, NWV, SPL, HIV)                                                                    \
   do {                                                                                                               \
-    (void)hipFuncSetAttribute((const void*)dopri5_mlp_adjoint_attempt<D, A, CTV, NWV, SPL>,                          \
+    (void)hipFuncSetAttribute((const void*)dopri5_mlp_adjoint_attempt<D, A, CTV, NWV, SPL, false, HIV>,              \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                           \
-    (void)hipFuncSetAttribute((const void*)dopri5_mlp_adjoint_attempt<D, A, CTV, NWV, SPL, true>,                    \
+    (void)hipFuncSetAttribute((const void*)dopri5_mlp_adjoint_attempt<D, A, CTV, NWV, SPL, true, HIV>,               \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                           \
     for (int64_t i = 0; i < n_launches; ++i) {                                                                       \
       const int parity = (int)((first_launch + i) & 1);                                                              \
-      if (dctrl) dopri5_mlp_adjoint_attempt<D, A, CTV, NWV, SPL, true><<<grid, 64 * NWV, lds_bytes, s>>>(g, parity);   \
-      else dopri5_mlp_adjoint_attempt<D, A, CTV, NWV, SPL><<<L.n_wg, 64 * NWV, lds_bytes, s>>>(g, parity);           \
+      if (dctrl) dopri5_mlp_adjoint_attempt<D, A, CTV, NWV, SPL, true, HIV><<<grid, 64 * NWV, lds_bytes, s>>>(g, parity); \
+      else dopri5_mlp_adjoint_attempt<D, A, CTV, NWV, SPL, false, HIV><<<L.n_wg, 64 * NWV, lds_bytes, s>>>(g, parity); \
       const int rc = after_attempt(parity);                                                                          \
       if (rc != CDE_OK) return rc;                                                                                   \
       control_after(parity);                                                                                         \
@@ -1458,34 +1457,19 @@ static int dopri5_adjoint_mlp_advance_impl(const void* coeffs, const void* knots
       if (rc != CDE_OK) return rc;                                                                                   \
     }                                                                                                                \
   } while (0)
-#define CDE_MADJ_HI(D, A)                                                                                            \
+#define CDE_MADJ_W(D, A, CTV, HIV)                                                                                   \
   do {                                                                                                               \
-    (void)hipFuncSetAttribute((const void*)dopri5_mlp_adjoint_attempt<D, A, 16, 4, true, false, true>,               \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                           \
-    (void)hipFuncSetAttribute((const void*)dopri5_mlp_adjoint_attempt<D, A, 16, 4, true, true, true>,                \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                           \
-    for (int64_t i = 0; i < n_launches; ++i) {                                                                       \
-      const int parity = (int)((first_launch + i) & 1);                                                              \
-      if (dctrl) dopri5_mlp_adjoint_attempt<D, A, 16, 4, true, true, true><<<grid, 256, lds_bytes, s>>>(g, parity);    \
-      else dopri5_mlp_adjoint_attempt<D, A, 16, 4, true, false, true><<<grid, 256, lds_bytes, s>>>(g, parity);       \
-      const int rc = after_attempt(parity);                                                                          \
-      if (rc != CDE_OK) return rc;                                                                                   \
-      control_after(parity);                                                                                         \
-    }                                                                                                                \
-  } while (0)
-#define CDE_MADJ_W(D, A, CTV)                                                                                        \
-  do {                                                                                                               \
-    if (dctrl_one_wave) CDE_MADJ_LAUNCH(D, A, CTV, 4, false);                                                        \
-    else if (L.split) CDE_MADJ_LAUNCH(D, A, CTV, 4, true);                                                           \
-    else if (L.nwave == 8) CDE_MADJ_LAUNCH(D, A, CTV, 8, false);                                                     \
-    else CDE_MADJ_LAUNCH(D, A, CTV, 4, false);                                                                       \
+    if (dctrl_one_wave) CDE_MADJ_LAUNCH(D, A, CTV, 4, false, HIV);                                                   \
+    else if (L.split) CDE_MADJ_LAUNCH(D, A, CTV, 4, true, HIV);                                                      \
+    else if (L.nwave == 8) CDE_MADJ_LAUNCH(D, A, CTV, 8, false, HIV);                                                \
+    else CDE_MADJ_LAUNCH(D, A, CTV, 4, false, HIV);                                                                  \
   } while (0)
 #define CDE_MADJ(D, A)                                                                                               \
   do {                                                                                                               \
-    if (L.upper) CDE_MADJ_HI(D, A);                                                                                  \
-    else if (C > MC) CDE_MADJ_W(D, A, 16);                                                                           \
+    if (L.upper) CDE_MADJ_W(D, A, 16, true);                                                                         \
+    else if (C > MC) CDE_MADJ_W(D, A, 16, false);                                                                    \
     else if (L.split8 && !dctrl) CDE_MADJ_LAUNCH_S8(D, A);       /* (control gradients: the four-wave form) */          \
-    else CDE_MADJ_W(D, A, 8);                                                                                        \
+    else CDE_MADJ_W(D, A, 8, false);                                                                                 \
   } while (0)
   if (act == CDE_ACT_NONE) {
     if (degree == CDE_PATH_CUBIC) CDE_MADJ(CDE_PATH_CUBIC, CDE_ACT_NONE); else CDE_MADJ(CDE_PATH_LINEAR, CDE_ACT_NONE);
@@ -1494,7 +1478,6 @@ static int dopri5_adjoint_mlp_advance_impl(const void* coeffs, const void* knots
   }
 #undef CDE_MADJ
 #undef CDE_MADJ_W
-#undef CDE_MADJ_HI
 #undef CDE_MADJ_LAUNCH
 #undef CDE_MADJ_LAUNCH_S8
   return check_launch();
@@ -1644,3 +1627,4 @@ extern "C" int cde_dopri5_adjoint_mlp_apply_state_sums(void* workspace, size_t w
   madj_carry_kernel<<<1, 1, 0, (hipStream_t)stream>>>(base, parity ^ 1, reduced, (double*)(base + L.carry));
   return check_launch();
 }
+
