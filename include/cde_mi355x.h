@@ -299,6 +299,9 @@ int cde_rk4_forward_linear(const void* coeffs, const void* knots, int64_t n_inte
  * f32 only, width <= 128, and (H <= 32, C <= 8) or (H <= 16, C <= 16) -- the sixteen 16-row MFMA tiles of the
  * second layer hold 32 hidden units x 8 channels or 16 x 16, zero padded; otherwise CDE_ERR_UNSUPPORTED.
  * (The 16 x 16 tiling takes the 14-channel depth-3 logsignature control of example/logsignature_example.py:22.)
+ * Round 6: also 16 < H <= 32 with 8 < C <= 16 (that example at hidden_channels = 32) when width is a multiple of 4 and W2 is
+ * 16-byte aligned: hidden units 16..31 run as four more unit groups whose rows of W2 / bias2 are read straight from the
+ * caller's tensors (no second image).
  * All other arguments as cde_rk4_forward_linear.
  * ------------------------------------------------------------------------------------------- */
 int cde_rk4_forward_mlp(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W1,
@@ -337,6 +340,10 @@ int cde_mlp_grad_reduce(const void* G, const void* X, int64_t rows, int layer, v
  *                                 (as cde_rk4_adjoint_linear_dcontrol)
  * f32, width <= 128, (H <= 32, C <= 8) or (H <= 16, C <= 16) as K2m; `grad_coeffs` on both tile layouts (C > 8: the one-wave-per-tile form at every batch size).  G2's
  * columns are (hidden unit)*8 + channel for C <= 8 and (hidden unit)*16 + channel for 8 < C <= 16.
+ * Round 6: 16 < H <= 32 with 8 < C <= 16 (any width <= 128: the sweep reads the upper rows of W2 from zero-padded copies that
+ * _prepare leaves behind the weight images).  The dL/dY2 rows of hidden units 16..31 then form a SECOND block of G2, laid out
+ * like the first and 4 * (k_end - k_begin) * B rows behind its start: the caller sizes G2 for both and reduces each against U
+ * (cde_mlp_grad_reduce, layer 2) into its own [256][132] image.
  * ------------------------------------------------------------------------------------------- */
 size_t cde_rk4_adjoint_mlp_workspace_bytes(int64_t n_sgrid);
 int cde_rk4_adjoint_mlp_prepare(const void* knots, int64_t n_intervals, const void* sgrid, int64_t n_sgrid,
@@ -631,7 +638,8 @@ int cde_dopri5_adjoint_advance_dcontrol(const void* coeffs, const void* knots, i
 /* ---------------------------------------------------------------------------------------------
  * K4am  K4a for the two-layer field Linear(H, width) -> relu -> Linear(width, H*C) -> tanh | identity of the reference's
  * examples (example/time_series_classification.py:20-51; their training call is cdeint(X, func, z0, X.interval): dopri5
- * with adjoint=True, :83-86).  f32, width <= 128, (H <= 32, C <= 8) or (H <= 16, C <= 16).  Same protocol, controller,
+ * with adjoint=True, :83-86).  f32, width <= 128, (H <= 32, C <= 8) or (H <= 16, C <= 16); round 6: also 16 < H <= 32 with
+ * 8 < C <= 16 (cde_dopri5_adjoint_mlp_gradient_upper_offset below; not in the sharded protocol).  Same protocol, controller,
  * norms (norm_kind) and status / trace blocks as cde_dopri5_adjoint_advance; per attempted step it queues the attempt
  * kernel, the split-K reduction of the attempt's gradient factors (both layers) and the commit / norm kernel.
  * The running parameter gradients live in the workspace at cde_dopri5_adjoint_mlp_gradient_offset():
@@ -730,7 +738,7 @@ int cde_dopri5_advance_sharded(const void* coeffs, const void* knots, int64_t n_
                                const double* reduced_sums, int64_t B_global, void* stream);
 
 /* K4 for the two-layer field of K2m (W1/bias1/width = hidden layer, W2/bias2 = output layer); f32, width <= 128,
- * (H <= 32, C <= 8) or (H <= 16, C <= 16).  Same protocol, workspace (cde_dopri5_workspace_bytes) and status block as
+ * (H <= 32, C <= 8) or (H <= 16, C <= 16), or (round 6, as cde_rk4_forward_mlp) 16 < H <= 32 with 8 < C <= 16.  Same protocol, workspace (cde_dopri5_workspace_bytes) and status block as
  * cde_dopri5_advance. */
 int cde_dopri5_advance_mlp(const void* coeffs, const void* knots, int64_t n_intervals, int degree, const void* W1,
                            const void* bias1, int64_t width, const void* W2, const void* bias2, int act,
