@@ -255,15 +255,19 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2) void rk4_adjoint_
       float gdx[CT];                                                 // d(a.f)/d(dX_c), this lane's hidden units (DCOEFF)
 #pragma unroll
       for (int c = 0; c < CT; ++c) gdx[c] = 0.f;
+      // (the unit-group body with the upper half as a compile-time flag; the four lower groups unrolled as ever, the upper ones --
+      //  32 hidden units x 16 channels only -- a ROLLED loop behind one uniform branch: unrolled they doubled the stage body of
+      //  every 16-channel sweep and cost the plain shape 1.9 %)
+      auto group = [&](int P, auto upper_c) {                        // unit group P: 4 hidden units x CT channels = NB tiles
+        constexpr bool upper = decltype(upper_c)::value;
+        float as_P = as[0];
 #pragma unroll
-      for (int P = 0; P < NPX; ++P) {                                // unit group P: 4 hidden units x CT channels = NB tiles
-        if (SPLIT && P / per_wave != pw) continue;                   // (wave-uniform: another wave's group)
-        if (P >= NP && !has_hi) continue;                            // (uniform: no upper half)
+        for (int kk = 1; kk < 8; ++kk) as_P = P == kk ? as[kk] : as_P;
         f32x4 y[NB];
         const float* tp_[NB];
 #pragma unroll
         for (int tb = 0; tb < NB; ++tb) {
-          if (P < NP) {
+          if constexpr (!upper) {
             const float4 c0 = bb2[4 * (NB * P + tb)];
             y[tb] = f32x4{c0.x, c0.y, c0.z, c0.w};
             tp_[tb] = w2y + 2 * (NB * P + tb) * 8 * W2P_STRIDE;      // tile T = NB*P + tb: physical rows (2T + hb)*8 + r8
@@ -300,20 +304,21 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2) void rk4_adjoint_
             const float t = tv[r];
             f = c == 0 ? t * dX[0] : __builtin_fmaf(t, dX[c], f);
             const float slope = ACT == CDE_ACT_TANH ? __builtin_fmaf(-t, t, 1.f) : 1.f;
-            g2[c] = as[P] * (dX[c] * slope);
-            if constexpr (DCOEFF) gdx[c] = __builtin_fmaf(as[P], t, gdx[c]);
+            g2[c] = as_P * (dX[c] * slope);
+            if constexpr (DCOEFF) gdx[c] = __builtin_fmaf(as_P, t, gdx[c]);
           }
         }
-        if (P < 4) fa[P] = f; else fb[P - 4] = f;
+        #pragma unroll
+        for (int kk = 0; kk < 4; ++kk) { fa[kk] = P == kk ? f : fa[kk]; fb[kk] = P == 4 + kk ? f : fb[kk]; }
         if (SPLIT ? in_range : valid) {                              // (split: the rows of a unit group by the wave that owns it)
-          float* grow = (P < NP ? G2 + out_row * G2_COLS + 4 * CT * P : G2hi + out_row * G2_COLS + 4 * CT * (P - NP)) + CT * q;     // rows (h = 4P+q, c = 0..CT-1) of the padded layout
+          float* grow = (!upper ? G2 + out_row * G2_COLS + 4 * CT * P : G2hi + out_row * G2_COLS + 4 * CT * (P - NP)) + CT * q;     // rows (h = 4P+q, c = 0..CT-1) of the padded layout
 #pragma unroll
           for (int c4 = 0; c4 < CT; c4 += 4)
             stream_store4(grow + c4, g2[c4] * wq, g2[c4 + 1] * wq, g2[c4 + 2] * wq, g2[c4 + 3] * wq);
         }
 #pragma unroll
         for (int c = 0; c < CT; ++c) {                               // K step (P, c); 8 independent accumulator chains
-          if (P < NP) {
+          if constexpr (!upper) {
             const float* rowp = w2g[c & 3] + 2 * (NB * P + (c >> 2)) * 8 * W2P_STRIDE;
 #pragma unroll
             for (int T1 = 0; T1 < 8; ++T1) gu[T1] = mfma16(rowp[16 * T1], g2[c], gu[T1]);
@@ -327,8 +332,21 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2) void rk4_adjoint_
           }
         }
         __builtin_amdgcn_sched_barrier(0);
+      };
+#pragma unroll
+      for (int P = 0; P < NP; ++P) {
+        if (SPLIT && P / per_wave != pw) continue;                   // (wave-uniform: another wave's group)
+        group(P, std::false_type{});
       }
-
+      if constexpr (NPX > NP) {
+        if (has_hi) {
+#pragma clang loop unroll(disable)
+          for (int P = NP; P < NPX; ++P) {
+            if (SPLIT && P / per_wave != pw) continue;
+            group(P, std::true_type{});
+          }
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (SPLIT) {
         // the four waves' shares of gu, f (and of d(a.f)/d(dX)) meet: afterwards every wave holds the complete values
