@@ -529,3 +529,47 @@ def test_example_neural_cde_trains_like_the_reference_model(native, solver, bar)
     _close(fn, fo, bar, bar)
     for a, b in zip(gn, go):
         _close(a, b, 10 * bar, 10 * bar * b.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_higher_order_gradients_fail_loudly_on_the_fused_path_and_work_step_wise(native):
+    """the fused backward functions compute from detached tensors in raw kernels -- a double backward through them
+    must raise (torch's once_differentiable), not return gradients with the higher-order terms silently missing.  With
+    adjoint=False the reference (autograd through torchdiffeq.odeint: solver.py:144,226-227) supports create_graph=True; here
+    variant="generic" keeps that request on the step-wise path, where the Hessian-vector product matches the float64 oracle's."""
+    import warnings
+    B, L, C, H = 12, 7, 3, 8
+    x = make_series(B, L, C, seed=41)
+    z0 = torch.randn(B, H, generator=torch.Generator().manual_seed(41))
+    kw = dict(method="rk4", options=dict(step_size=0.5), adjoint=False)
+
+    def hvp(cdeint, X, func, z):
+        out = cdeint(X, func, z, X.interval, **kw)
+        (g,) = torch.autograd.grad(out[:, -1].square().sum(), z, create_graph=True)
+        return g, g.square().sum()
+
+    func = LinearField(H, C, scale=0.4, tanh=True, seed=5).to(DEV)
+    X = native.CubicSpline(native.hermite_cubic_coefficients_with_backward_differences(x.to(DEV)))
+    zd = z0.to(DEV).requires_grad_(True)
+    g, s = hvp(native.cdeint, X, func, zd)
+    _expect_dispatch("affine_rk4_backprop")
+    with pytest.raises(RuntimeError, match="once_differentiable|differentiate"):
+        s.backward()
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                                        # (the step-wise warning)
+        g2, s2 = hvp(lambda *a, **k: native.cdeint(*a, variant="generic", **k), X, func, zd)
+    assert front_path() == "stepwise"
+    zd.grad = None
+    s2.backward()
+    f64 = LinearField(H, C, torch.float64, scale=0.4, tanh=True, seed=5)
+    Xo = oracle_interp.CubicPath(oracle_interp.hermite_bdiff_coeffs(x.double()))
+    zo = z0.double().requires_grad_(True)
+    g3, s3 = hvp(oracle_cde.cdeint, Xo, f64, zo)
+    s3.backward()
+    _close(g2, g3, 1e-3, 1e-4 * g3.abs().max().item())
+    _close(zd.grad, zo.grad, 2e-3, 2e-4 * zo.grad.abs().max().item())
+
+
+def front_path():
+    return _front().last_dispatch()[0].path
