@@ -521,7 +521,8 @@ def test_two_layer_dopri5_adjoint_output_time_gradients(native):
 
 
 @pytest.mark.parametrize("case", ["example_model_cubic", "logsig_shape_linear_knots", "cubic_knots_times_one_wave",
-                                  "seminorm_jumps", "beyond_one_round_of_tiles", "shared_tile_1200", "upper_half_knots_times"])
+                                  "seminorm_jumps", "beyond_one_round_of_tiles", "shared_tile_1200", "upper_half_knots_times",
+                                  "upper_half_one_wave", "upper_half_one_wave_eight_per_workgroup"])
 def test_two_layer_dopri5_adjoint_control_gradients_fused(native, case):
     """The same for the examples' two-layer model (K4am, cde_dopri5_adjoint_mlp_advance_dcontrol): adjoint_params = the four
     layer parameters + the coefficient tensor (+ the knot times), default dopri5 + adjoint.  The evaluation leaves
@@ -549,11 +550,18 @@ def test_two_layer_dopri5_adjoint_control_gradients_fused(native, case):
                                     form=None, band=0.90),
            # 32 hidden units x 14 channels (the upper unit groups enter d(a.f)/d(dX) like the lower ones)
            "upper_half_knots_times": dict(B=90, L=8, C=14, H=32, degree=3, t_out=[0.3, 3., 6.5], knots=True, times=True, adj={},
-                                          form=None)}[case]
+                                          form=None),
+           # ... and in the one-wave-per-tile forms this shape takes beyond 4096 series (four / eight tiles per workgroup)
+           "upper_half_one_wave": dict(B=50, L=7, C=12, H=24, degree=1, t_out=[0., 6.], knots=True, times=False, adj={},
+                                       form="one_wave"),
+           "upper_half_one_wave_eight_per_workgroup": dict(B=50, L=7, C=12, H=24, degree=3, t_out=[0., 2.5, 6.], knots=False,
+                                                           times=True, adj={}, form="one_wave_8")}[case]
     B, L, C, H, width, kw = cfg["B"], cfg["L"], cfg["C"], cfg["H"], 128, dict(rtol=1e-4, atol=1e-6)
-    if cfg["form"] == "one_wave":
+    if cfg["form"] in ("one_wave", "one_wave_8"):
         native.set_option("k4am_no_split", 1)
         native.set_option("k4m_no_split", 1)
+    if cfg["form"] == "one_wave_8":
+        native.set_option("k4am_waves", 8)
     x = make_series(B, L, C, seed=len(case))
     knots0 = None
     if cfg["knots"]:
