@@ -3,6 +3,7 @@
 # the per-GPU batch sweep.  Everything lands in gpurun_out/.
 set -u
 mkdir -p gpurun_out
+[ -x scripts/ubench/mfma_4x4 ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o scripts/ubench/mfma_4x4 scripts/ubench/mfma_4x4.hip 2>/dev/null   # (built binaries are not tracked)
 ./scripts/ubench/mfma_4x4 > gpurun_out/r06_mfma_4x4_ubench.txt 2>&1
 python scripts/bench_strong.py --steps 20 > gpurun_out/r06_strong_before.log 2>&1
 PMC_OUT=$PWD/gpurun_out bash scripts/pmc_passes.sh r06_split scripts/prof_workload.py "mfma waves fetch write" "20 4096" > gpurun_out/r06_split_pmc.log 2>&1
